@@ -1,0 +1,493 @@
+// index.hip -- index creation (upload + search structures) and the
+// Searcher-level entry points of the C ABI.
+//
+// Reference counterparts: r_divsufsort + Searcher::new, src/bin/asgart.rs:141-155,
+// src/searcher.rs:99-143; Searcher::search, src/searcher.rs:145-180.
+#include "index.hpp"
+#include "search_dev.hpp"
+
+#include <chrono>
+
+namespace asgart {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ---- kernels ---------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void byte_histogram_kernel(const uint8_t *__restrict__ text,
+                                                             uint64_t n,
+                                                             unsigned long long *__restrict__ hist) {
+    __shared__ unsigned int sh[256];
+    sh[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x * 16;
+    for (uint64_t base = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16; base < n;
+         base += stride) {
+        if (base + 16 <= n) {
+            uint4 v = *reinterpret_cast<const uint4 *>(text + base);
+            uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) atomicAdd(&sh[(w[a] >> (8 * b)) & 0xFF], 1u);
+        } else {
+            for (uint64_t j = base; j < n; ++j) atomicAdd(&sh[text[j]], 1u);
+        }
+    }
+    __syncthreads();
+    if (sh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)sh[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void narrow_sa_kernel(const int64_t *__restrict__ in,
+                                                        uint32_t *__restrict__ out, uint64_t cnt) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cnt) out[i] = (uint32_t)in[i];
+}
+
+__global__ __launch_bounds__(256) void widen_sa_kernel(const uint32_t *__restrict__ in,
+                                                       int64_t *__restrict__ out, uint64_t cnt) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cnt) out[i] = (int64_t)in[i];
+}
+
+// keys[r] = first k bases of suffix sa[r], 3-bit codes, end-of-text padded with 0
+template <class SlotT>
+__global__ __launch_bounds__(256) void build_keys_kernel(const uint8_t *__restrict__ text,
+                                                         const SlotT *__restrict__ sa,
+                                                         uint64_t *__restrict__ keys, uint64_t n,
+                                                         int k) {
+    uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    uint64_t x = sa[r];
+    uint64_t q = 0;
+    for (int j = 0; j < k; ++j) {
+        uint32_t c = (x + j < n) ? base_code(text[x + j]) : 0u;
+        q = (q << 3) | c;
+    }
+    keys[r] = q;
+}
+
+template <class SlotT>
+__global__ __launch_bounds__(256) void build_ptab_kernel(const uint64_t *__restrict__ keys,
+                                                         SlotT *__restrict__ ptab, uint64_t n,
+                                                         int k, int d) {
+    uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t entries = 1ull << (2 * d);
+    if (p > entries) return;
+    if (p == entries) {
+        ptab[p] = (SlotT)n;
+        return;
+    }
+    uint64_t target = 0;
+    for (int j = 0; j < d; ++j) {
+        uint32_t dg = (uint32_t)(p >> (2 * (d - 1 - j))) & 3u;
+        uint32_t code = dg == 3u ? 5u : dg + 1u;
+        target |= (uint64_t)code << (3 * (k - 1 - j));
+    }
+    ptab[p] = (SlotT)lower_bound_keys(keys, 0, n, target);
+}
+
+// the reference's 8-mer cache: [lo,hi) of suffixes starting with the 8-mer
+template <class SlotT>
+__global__ __launch_bounds__(256) void build_cache8_kernel(const uint64_t *__restrict__ keys,
+                                                           SlotT *__restrict__ c8lo,
+                                                           SlotT *__restrict__ c8hi, uint64_t n,
+                                                           int k) {
+    uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (uint32_t)kCacheEntries) return;
+    uint32_t v = idx, pre24 = 0;
+    for (int j = kCacheLen - 1; j >= 0; --j) {
+        uint32_t code = v % 5u + 1u;
+        v /= 5u;
+        pre24 |= code << (3 * (kCacheLen - 1 - j));
+    }
+    const int sh = 3 * (k - kCacheLen);
+    uint64_t lo = lower_bound_keys(keys, 0, n, (uint64_t)pre24 << sh);
+    uint64_t hi = lower_bound_keys(keys, lo, n, ((uint64_t)pre24 + 1ull) << sh);
+    c8lo[idx] = (SlotT)lo;
+    c8hi[idx] = (SlotT)hi;
+}
+
+template <class SlotT>
+__global__ __launch_bounds__(256) void cache_get_kernel(IndexView<SlotT> ix,
+                                                        const uint8_t *__restrict__ pats,
+                                                        int64_t n_pat, uint64_t *__restrict__ lo,
+                                                        uint64_t *__restrict__ hi) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_pat) return;
+    uint32_t pre24 = 0;
+    for (int j = 0; j < kCacheLen; ++j) pre24 = (pre24 << 3) | base_code(pats[t * kCacheLen + j]);
+    uint32_t c8;
+    if (cache8_index(pre24, c8)) {
+        lo[t] = ix.c8lo[c8];
+        hi[t] = ix.c8hi[c8];
+    } else {
+        lo[t] = hi[t] = 0;
+    }
+}
+
+template <class SlotT>
+__global__ __launch_bounds__(256) void pattern_search_kernel(IndexView<SlotT> ix,
+                                                             const uint8_t *__restrict__ pats,
+                                                             int64_t n_pat,
+                                                             uint64_t *__restrict__ lo,
+                                                             uint64_t *__restrict__ hi) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_pat) return;
+    uint64_t q = 0;
+    for (int j = 0; j < ix.k; ++j) q = (q << 3) | base_code(pats[t * ix.k + j]);
+    uint64_t l, h;
+    kmer_range(ix, q, l, h);
+    lo[t] = l;
+    hi[t] = h;
+}
+
+// ---- host ------------------------------------------------------------------
+
+static int32_t check_device(int device) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        (void)hipGetLastError();
+        set_error("no HIP device available (%s); libasgart_hip has no CPU fallback",
+                  e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+        return ASGART_E_HIP;
+    }
+    if (device < 0 || device >= count) {
+        set_error("device %d out of range (count %d)", device, count);
+        return ASGART_E_ARG;
+    }
+    HIP_TRY(hipSetDevice(device));
+    return 0;
+}
+
+static inline unsigned grid_for(uint64_t n, unsigned block = 256) {
+    return (unsigned)((n + block - 1) / block);
+}
+
+static void free_k_specific(asgart_index *idx) {
+    if (idx->d_keys) (void)hipFree(idx->d_keys);
+    if (idx->d_ptab) (void)hipFree(idx->d_ptab);
+    if (idx->d_c8lo) (void)hipFree(idx->d_c8lo);
+    if (idx->d_c8hi) (void)hipFree(idx->d_c8hi);
+    idx->d_keys = nullptr;
+    idx->d_ptab = idx->d_c8lo = idx->d_c8hi = nullptr;
+    idx->k = 0;
+}
+
+static int choose_depth(int64_t n, uint64_t k) {
+    int d = 12;
+    if (const char *e = getenv("ASGART_PTAB_DEPTH")) d = atoi(e);
+    else {
+        // ~one table entry per suffix, between 4^6 and 4^13
+        int bits = 0;
+        while ((1ll << bits) < n) ++bits;
+        d = (bits + 1) / 2;
+        if (d < 6) d = 6;
+        if (d > 13) d = 13;
+    }
+    if (d < 1) d = 1;
+    if (d > 14) d = 14;
+    if ((uint64_t)d > k) d = (int)k;
+    return d;
+}
+
+int32_t index_prepare(asgart_index *idx, uint64_t k) {
+    if (k < (uint64_t)kCacheLen || k > (uint64_t)kMaxK) {
+        set_error("probe_size %llu unsupported: need %d <= k <= %d (the reference needs k >= 8, "
+                  "src/searcher.rs:95-97; this build packs a probe into 63 bits)",
+                  (unsigned long long)k, kCacheLen, kMaxK);
+        return ASGART_E_ARG;
+    }
+    if (idx->k == k) return 0;
+    HIP_TRY(hipSetDevice(idx->device));
+    free_k_specific(idx);
+    auto t0 = std::chrono::steady_clock::now();
+    const uint64_t n = (uint64_t)idx->n;
+    const size_t slot = idx->wide ? 8 : 4;
+    const int d = choose_depth(idx->n, k);
+    const uint64_t entries = (1ull << (2 * d)) + 1;
+    HIP_TRY(hipMalloc((void **)&idx->d_keys, (n + 16) * sizeof(uint64_t)));
+    HIP_TRY(hipMalloc(&idx->d_ptab, entries * slot));
+    HIP_TRY(hipMalloc(&idx->d_c8lo, (size_t)kCacheEntries * slot));
+    HIP_TRY(hipMalloc(&idx->d_c8hi, (size_t)kCacheEntries * slot));
+    hipStream_t s = idx->stream;
+    if (idx->wide) {
+        build_keys_kernel<uint64_t><<<grid_for(n), 256, 0, s>>>(
+            idx->d_text, (const uint64_t *)idx->d_sa, idx->d_keys, n, (int)k);
+        build_ptab_kernel<uint64_t><<<grid_for(entries), 256, 0, s>>>(
+            idx->d_keys, (uint64_t *)idx->d_ptab, n, (int)k, d);
+        build_cache8_kernel<uint64_t><<<grid_for(kCacheEntries), 256, 0, s>>>(
+            idx->d_keys, (uint64_t *)idx->d_c8lo, (uint64_t *)idx->d_c8hi, n, (int)k);
+    } else {
+        build_keys_kernel<uint32_t><<<grid_for(n), 256, 0, s>>>(
+            idx->d_text, (const uint32_t *)idx->d_sa, idx->d_keys, n, (int)k);
+        build_ptab_kernel<uint32_t><<<grid_for(entries), 256, 0, s>>>(
+            idx->d_keys, (uint32_t *)idx->d_ptab, n, (int)k, d);
+        build_cache8_kernel<uint32_t><<<grid_for(kCacheEntries), 256, 0, s>>>(
+            idx->d_keys, (uint32_t *)idx->d_c8lo, (uint32_t *)idx->d_c8hi, n, (int)k);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));
+    // text-tail corner list (host, from the last bytes of the text)
+    idx->n_tail8 = 0;
+    idx->tail_bloom = 0;
+    {
+        const int64_t tl = (int64_t)idx->h_tail.size();
+        const int64_t base = idx->n - tl;  // text offset of h_tail[0]
+        for (int64_t x = idx->n - (int64_t)k + 1; x <= idx->n - kCacheLen; ++x) {
+            if (x < 0 || x < base) continue;
+            uint32_t pre24 = 0;
+            bool ok = true;
+            for (int j = 0; j < kCacheLen; ++j) {
+                uint32_t c = base_code(idx->h_tail[(size_t)(x - base + j)]);
+                ok &= c != 0;
+                pre24 = (pre24 << 3) | c;
+            }
+            if (!ok) continue;
+            bool dup = false;
+            for (int j = 0; j < idx->n_tail8; ++j) dup |= idx->tail8[j] == pre24;
+            if (dup) continue;
+            idx->tail8[idx->n_tail8++] = pre24;
+            idx->tail_bloom |= 1ull << (pre24 & 63u);
+        }
+    }
+    idx->k = k;
+    idx->d = d;
+    idx->ms_prepare =
+        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return 0;
+}
+
+}  // namespace asgart
+
+using namespace asgart;
+
+extern "C" {
+
+const char *asgart_last_error(void) { return asgart::g_err; }
+
+const char *asgart_version(void) { return "asgart-hip 0.1.0 gfx950"; }
+
+void asgart_index_destroy(asgart_index *idx) {
+    if (!idx) return;
+    (void)hipSetDevice(idx->device);
+    free_k_specific(idx);
+    if (idx->d_text) (void)hipFree(idx->d_text);
+    if (idx->d_sa) (void)hipFree(idx->d_sa);
+    Workspace &w = idx->ws;
+    DevBuf *bufs[] = {&w.chunks, &w.p_lo, &w.p_raw, &w.p_filt, &w.row_off, &w.blk, &w.hits,
+                      &w.big_list, &w.seg_list, &w.counters, &w.fam_hdr, &w.fam_sds,
+                      &w.ovf_list, &w.pat, &w.out_a, &w.out_b};
+    for (DevBuf *b : bufs) b->release();
+    for (auto &e : idx->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (idx->stream) (void)hipStreamDestroy(idx->stream);
+    delete idx;
+}
+
+int32_t asgart_index_create(const uint8_t *T, int64_t n, const int64_t *SA, int64_t sa_len,
+                            int32_t device, asgart_index **out) {
+    if (!out) {
+        set_error("asgart_index_create: out is NULL");
+        return ASGART_E_ARG;
+    }
+    *out = nullptr;
+    if (!T || n <= 0) {
+        set_error("asgart_index_create: empty text");
+        return ASGART_E_ARG;
+    }
+    if (SA && sa_len != n) {
+        set_error("asgart_index_create: sa_len (%lld) != n (%lld); --trim sub-range suffix "
+                  "arrays are not supported", (long long)sa_len, (long long)n);
+        return ASGART_E_ARG;
+    }
+    RC_TRY(check_device(device));
+    asgart_index *idx = new (std::nothrow) asgart_index();
+    if (!idx) {
+        set_error("out of host memory");
+        return ASGART_E_OOM;
+    }
+    idx->device = device;
+    idx->n = n;
+    idx->wide = (uint64_t)n >= 0xFFFFFF00ull;
+    memset(&idx->stats, 0, sizeof(idx->stats));
+    int32_t rc = [&]() -> int32_t {
+        HIP_TRY(hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking));
+        for (auto &e : idx->ev) HIP_TRY(hipEventCreate(&e));
+        HIP_TRY(hipMalloc((void **)&idx->d_text, (size_t)n + 64));
+        HIP_TRY(hipMemsetAsync(idx->d_text + n, 0, 64, idx->stream));
+        HIP_TRY(hipMemcpyAsync(idx->d_text, T, (size_t)n, hipMemcpyHostToDevice, idx->stream));
+        // validate the alphabet on the device
+        RC_TRY(idx->ws.counters.reserve(256 * sizeof(unsigned long long)));
+        unsigned long long *d_hist = idx->ws.counters.as<unsigned long long>();
+        HIP_TRY(hipMemsetAsync(d_hist, 0, 256 * sizeof(unsigned long long), idx->stream));
+        unsigned blocks = grid_for((uint64_t)n, 256 * 16);
+        if (blocks > 4096) blocks = 4096;
+        byte_histogram_kernel<<<blocks, 256, 0, idx->stream>>>(idx->d_text, (uint64_t)n, d_hist);
+        HIP_TRY(hipGetLastError());
+        unsigned long long hist[256];
+        HIP_TRY(hipMemcpyAsync(hist, d_hist, sizeof(hist), hipMemcpyDeviceToHost, idx->stream));
+        HIP_TRY(hipStreamSynchronize(idx->stream));
+        for (int c = 0; c < 256; ++c)
+            if (hist[c] && !valid_text_byte((uint8_t)c)) {
+                set_error("text contains byte 0x%02x; expected normalised bases {A,C,G,T,N} "
+                          "plus a final '$' (reference src/bin/asgart.rs:289-301,430)", c);
+                return ASGART_E_ARG;
+            }
+        if (hist['$'] > 1 || (hist['$'] == 1 && T[n - 1] != '$')) {
+            set_error("'$' may only appear once, as the last byte of the text");
+            return ASGART_E_ARG;
+        }
+        const int64_t tl = n < 64 ? n : 64;
+        idx->h_tail.assign(T + n - tl, T + n);
+        const size_t slot = idx->wide ? 8 : 4;
+        HIP_TRY(hipMalloc(&idx->d_sa, ((size_t)n + 16) * slot));
+        if (!SA) {
+            RC_TRY(sa_build_device(idx->d_text, n, idx->d_sa, idx->wide, idx->stream));
+        } else if (idx->wide) {
+            HIP_TRY(hipMemcpyAsync(idx->d_sa, SA, (size_t)n * 8, hipMemcpyHostToDevice,
+                                   idx->stream));
+            HIP_TRY(hipStreamSynchronize(idx->stream));
+        } else {
+            const uint64_t slice = 1ull << 25;
+            DevBuf stage;
+            RC_TRY(stage.reserve((size_t)(slice < (uint64_t)n ? slice : (uint64_t)n) * 8));
+            for (uint64_t off = 0; off < (uint64_t)n; off += slice) {
+                uint64_t cnt = (uint64_t)n - off < slice ? (uint64_t)n - off : slice;
+                hipError_t e = hipMemcpyAsync(stage.p, SA + off, cnt * 8, hipMemcpyHostToDevice,
+                                              idx->stream);
+                if (e == hipSuccess) {
+                    narrow_sa_kernel<<<grid_for(cnt), 256, 0, idx->stream>>>(
+                        stage.as<int64_t>(), (uint32_t *)idx->d_sa + off, cnt);
+                    e = hipStreamSynchronize(idx->stream);
+                }
+                if (e != hipSuccess) {
+                    stage.release();
+                    HIP_TRY(e);
+                }
+            }
+            stage.release();
+        }
+        return 0;
+    }();
+    if (rc != 0) {
+        asgart_index_destroy(idx);
+        return rc;
+    }
+    *out = idx;
+    return 0;
+}
+
+int32_t asgart_index_prepare(asgart_index *idx, uint64_t probe_size) {
+    if (!idx) {
+        set_error("index is NULL");
+        return ASGART_E_ARG;
+    }
+    return index_prepare(idx, probe_size);
+}
+
+static bool pattern_bytes_ok(const uint8_t *p, int64_t cnt) {
+    for (int64_t j = 0; j < cnt; ++j) {
+        uint8_t c = p[j];
+        if (!(c == 'A' || c == 'C' || c == 'G' || c == 'T' || c == 'N')) return false;
+    }
+    return true;
+}
+
+static int32_t run_pattern_kernel(asgart_index *idx, const uint8_t *pats, int64_t n_pat,
+                                  int64_t width, bool cache, uint64_t *lo, uint64_t *hi) {
+    if (n_pat == 0) return 0;
+    HIP_TRY(hipSetDevice(idx->device));
+    Workspace &w = idx->ws;
+    RC_TRY(w.pat.reserve((size_t)(n_pat * width)));
+    RC_TRY(w.out_a.reserve((size_t)n_pat * 8));
+    RC_TRY(w.out_b.reserve((size_t)n_pat * 8));
+    hipStream_t s = idx->stream;
+    HIP_TRY(hipMemcpyAsync(w.pat.p, pats, (size_t)(n_pat * width), hipMemcpyHostToDevice, s));
+    unsigned g = grid_for((uint64_t)n_pat);
+    if (idx->wide) {
+        auto v = idx->view<uint64_t>();
+        if (cache) cache_get_kernel<uint64_t><<<g, 256, 0, s>>>(v, w.pat.as<uint8_t>(), n_pat,
+                                                                w.out_a.as<uint64_t>(),
+                                                                w.out_b.as<uint64_t>());
+        else pattern_search_kernel<uint64_t><<<g, 256, 0, s>>>(v, w.pat.as<uint8_t>(), n_pat,
+                                                               w.out_a.as<uint64_t>(),
+                                                               w.out_b.as<uint64_t>());
+    } else {
+        auto v = idx->view<uint32_t>();
+        if (cache) cache_get_kernel<uint32_t><<<g, 256, 0, s>>>(v, w.pat.as<uint8_t>(), n_pat,
+                                                                w.out_a.as<uint64_t>(),
+                                                                w.out_b.as<uint64_t>());
+        else pattern_search_kernel<uint32_t><<<g, 256, 0, s>>>(v, w.pat.as<uint8_t>(), n_pat,
+                                                               w.out_a.as<uint64_t>(),
+                                                               w.out_b.as<uint64_t>());
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(lo, w.out_a.p, (size_t)n_pat * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(hi, w.out_b.p, (size_t)n_pat * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
+int32_t asgart_searcher_cache_get(asgart_index *idx, const uint8_t *patterns8, int64_t n_pat,
+                                  uint64_t *lo, uint64_t *hi) {
+    if (!idx || n_pat < 0 || (n_pat && (!patterns8 || !lo || !hi))) {
+        set_error("asgart_searcher_cache_get: bad argument");
+        return ASGART_E_ARG;
+    }
+    if (!pattern_bytes_ok(patterns8, n_pat * kCacheLen)) {
+        set_error("8-mer outside the alphabet {A,T,G,C,N} (the reference panics here, "
+                  "src/searcher.rs:155-161)");
+        return ASGART_E_ARG;
+    }
+    if (idx->k == 0) RC_TRY(index_prepare(idx, 20));
+    return run_pattern_kernel(idx, patterns8, n_pat, kCacheLen, true, lo, hi);
+}
+
+int32_t asgart_searcher_search(asgart_index *idx, const uint8_t *patterns, int64_t n_pat,
+                               uint64_t k, uint64_t *lo, uint64_t *hi) {
+    if (!idx || n_pat < 0 || (n_pat && (!patterns || !lo || !hi))) {
+        set_error("asgart_searcher_search: bad argument");
+        return ASGART_E_ARG;
+    }
+    RC_TRY(index_prepare(idx, k));
+    if (!pattern_bytes_ok(patterns, n_pat * (int64_t)k)) {
+        set_error("pattern outside the alphabet {A,T,G,C,N} (the reference panics when the "
+                  "first 8 bytes are, src/searcher.rs:155-161)");
+        return ASGART_E_ARG;
+    }
+    return run_pattern_kernel(idx, patterns, n_pat, (int64_t)k, false, lo, hi);
+}
+
+int32_t asgart_sa_read(asgart_index *idx, uint64_t lo, uint64_t hi, int64_t *out) {
+    if (!idx || hi < lo || hi > (uint64_t)idx->n || (hi > lo && !out)) {
+        set_error("asgart_sa_read: bad range");
+        return ASGART_E_ARG;
+    }
+    if (hi == lo) return 0;
+    HIP_TRY(hipSetDevice(idx->device));
+    const uint64_t cnt = hi - lo;
+    if (idx->wide) {
+        HIP_TRY(hipMemcpyAsync(out, (const uint64_t *)idx->d_sa + lo, cnt * 8,
+                               hipMemcpyDeviceToHost, idx->stream));
+    } else {
+        RC_TRY(idx->ws.out_a.reserve(cnt * 8));
+        widen_sa_kernel<<<grid_for(cnt), 256, 0, idx->stream>>>(
+            (const uint32_t *)idx->d_sa + lo, idx->ws.out_a.as<int64_t>(), cnt);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(out, idx->ws.out_a.p, cnt * 8, hipMemcpyDeviceToHost,
+                               idx->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(idx->stream));
+    return 0;
+}
+
+}  // extern "C"

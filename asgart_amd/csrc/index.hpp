@@ -1,0 +1,114 @@
+// index.hpp -- the device-resident index: text + suffix array + k-specific keys.
+//
+// HBM layout (one copy per GPU, replicated across ranks):
+//   text   u8 [n + 64]      raw bytes as given (reference strand.data incl. '$')
+//   sa     u32[n] | u64[n]  suffix array; 32-bit entries whenever n < 2^32-64
+//   keys   u64[n]           keys[r] = first k bases of suffix sa[r] as 3-bit
+//                           order-preserving codes, '$'/end padded with 0:
+//                           a sorted array, so a k-mer lookup is a binary
+//                           search over ONE array with no text gathers
+//   ptab   slot[4^d + 1]    first slot whose key >= the ACGT d-mer prefix
+//   c8lo/c8hi slot[5^8]     the reference's 8-mer cache (Searcher::new)
+#pragma once
+
+#include "common.hpp"
+
+namespace asgart {
+
+template <class SlotT>
+struct IndexView {
+    const uint8_t *text;
+    const SlotT *sa;
+    const uint64_t *keys;
+    const SlotT *ptab;
+    const SlotT *c8lo;
+    const SlotT *c8hi;
+    uint64_t n;
+    int k;
+    int d;
+    // text-tail corner (reference src/searcher.rs:165-166): 8-mer prefixes
+    // (24-bit codes) of the suffixes shorter than k; probes with one of these
+    // prefixes take the exact-bisection slow path.
+    uint32_t tail8[kMaxK];
+    int n_tail8;
+    uint64_t tail_bloom;
+};
+
+struct Workspace {
+    DevBuf chunks;     // ch_start[nc], ch_len[nc] (u64) then pbase[nc+1] (u32)
+    DevBuf p_lo;       // SlotT[P]
+    DevBuf p_raw;      // u32[P]
+    DevBuf p_filt;     // u32[P]
+    DevBuf row_off;    // u64[P+1]
+    DevBuf blk;        // scan block aggregates
+    DevBuf hits;       // PosT[total hits]
+    DevBuf big_list;   // u32[P] probes with large SA intervals
+    DevBuf seg_list;   // u32[...] segment start probes
+    DevBuf counters;   // u64[32] device counters
+    DevBuf fam_hdr;    // FamHdr[cap]
+    DevBuf fam_sds;    // asgart_proto_sd[cap]
+    DevBuf ovf_list;   // u32 segments that overflowed the small arm tier
+    DevBuf pat;        // pattern upload scratch
+    DevBuf out_a, out_b;
+};
+
+}  // namespace asgart
+
+struct asgart_index {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int64_t n = 0;
+    bool wide = false;  // 64-bit slots/positions
+    uint8_t *d_text = nullptr;
+    void *d_sa = nullptr;
+    // k-specific
+    uint64_t k = 0;
+    int d = 0;
+    uint64_t *d_keys = nullptr;
+    void *d_ptab = nullptr;
+    void *d_c8lo = nullptr;
+    void *d_c8hi = nullptr;
+    uint32_t tail8[asgart::kMaxK];
+    int n_tail8 = 0;
+    uint64_t tail_bloom = 0;
+    std::vector<uint8_t> h_tail;  // last 64 bytes of the text (host copy)
+    double ms_prepare = 0.0;
+    asgart::Workspace ws;
+    asgart_stats stats;
+    // inputs of the last call kept for the yardstick kernel
+    uint32_t last_P = 0;
+    hipEvent_t ev[8] = {};
+
+    template <class SlotT>
+    asgart::IndexView<SlotT> view() const {
+        asgart::IndexView<SlotT> v;
+        v.text = d_text;
+        v.sa = reinterpret_cast<const SlotT *>(d_sa);
+        v.keys = d_keys;
+        v.ptab = reinterpret_cast<const SlotT *>(d_ptab);
+        v.c8lo = reinterpret_cast<const SlotT *>(d_c8lo);
+        v.c8hi = reinterpret_cast<const SlotT *>(d_c8hi);
+        v.n = (uint64_t)n;
+        v.k = (int)k;
+        v.d = d;
+        for (int j = 0; j < asgart::kMaxK; ++j) v.tail8[j] = tail8[j];
+        v.n_tail8 = n_tail8;
+        v.tail_bloom = tail_bloom;
+        return v;
+    }
+};
+
+struct asgart_families {
+    std::vector<uint64_t> fam_offsets;  // n_fam + 1
+    std::vector<asgart_proto_sd> sds;
+};
+
+namespace asgart {
+int32_t index_prepare(asgart_index *idx, uint64_t k);
+int32_t run_search(asgart_index *idx, const uint64_t *chunks, int64_t n_chunks,
+                   const asgart_settings *st, int32_t shard, int32_t n_shards, bool want_csr,
+                   asgart_families *fam_out, std::vector<uint8_t> *status_out,
+                   std::vector<uint64_t> *rowoff_out, std::vector<uint64_t> *hits_out);
+int32_t sa_build_device(const uint8_t *d_text, int64_t n, void *d_sa, bool wide,
+                        hipStream_t stream);
+}  // namespace asgart

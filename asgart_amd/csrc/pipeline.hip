@@ -1,0 +1,411 @@
+// pipeline.hip -- host driver of the probe -> search -> extend pipeline and the
+// remaining C ABI entry points.
+//
+// Replaces the body of SearchDuplications::run, reference
+// src/bin/asgart.rs:201-253 (chunk fan-out, needle preparation, automaton,
+// left fix-up, fold in chunk order).
+#include "pipeline_dev.hpp"
+
+#include <algorithm>
+#include <chrono>
+
+namespace asgart {
+
+constexpr int kArmCapSmall = 512;   // arms per wave in LDS, common case
+constexpr int kArmCapBig32 = 5376;  // whole-CU LDS tier (32-bit positions): 5376*28 B = 147 KiB
+constexpr int kArmCapBig64 = 3456;  // 64-bit positions: 3456*44 B = 148.5 KiB
+
+static inline unsigned grid_for(uint64_t n, unsigned block = 256) {
+    return (unsigned)((n + block - 1) / block);
+}
+
+static uint32_t probes_in_chunk(uint64_t L, uint64_t k, uint64_t step, uint64_t M) {
+    // loop of src/automaton.rs:92-97: `while i < L - k - step { i += step; ... }`
+    if (L < M || L < k + step || L - k - step == 0) return 0;
+    return (uint32_t)((L - k - step + step - 1) / step);
+}
+
+template <class SlotT>
+static int32_t run_search_t(asgart_index *idx, const uint64_t *chunks, int64_t n_chunks,
+                            const asgart_settings *st, int32_t shard, int32_t n_shards,
+                            bool want_csr, asgart_families *fam_out,
+                            std::vector<uint8_t> *status_out, std::vector<uint64_t> *rowoff_out,
+                            std::vector<uint64_t> *hits_out) {
+    Workspace &w = idx->ws;
+    hipStream_t s = idx->stream;
+    const uint64_t k = st->probe_size, step = k / 2;
+    const uint64_t n = (uint64_t)idx->n;
+
+    // ---- chunk table -------------------------------------------------------
+    std::vector<uint64_t> h_start((size_t)n_chunks), h_len((size_t)n_chunks);
+    std::vector<uint32_t> h_pbase((size_t)n_chunks + 1);
+    uint64_t P64 = 0;
+    const uint64_t text_end = (idx->h_tail.size() && idx->h_tail.back() == '$') ? n - 1 : n;
+    for (int64_t c = 0; c < n_chunks; ++c) {
+        h_start[c] = chunks[2 * c];
+        h_len[c] = chunks[2 * c + 1];
+        if (h_start[c] > text_end || h_len[c] > text_end - h_start[c]) {
+            set_error("chunk %lld = (%llu, %llu) exceeds the text (%llu bases before '$')",
+                      (long long)c, (unsigned long long)h_start[c], (unsigned long long)h_len[c],
+                      (unsigned long long)text_end);
+            return ASGART_E_ARG;
+        }
+        h_pbase[c] = (uint32_t)P64;
+        P64 += probes_in_chunk(h_len[c], k, step, st->min_duplication_length);
+        if (P64 >= 0xFFFFFF00ull) {
+            set_error("more than 2^32 probes in one call");
+            return ASGART_E_CAP;
+        }
+    }
+    h_pbase[n_chunks] = (uint32_t)P64;
+    const uint32_t P = (uint32_t)P64;
+    idx->last_P = P;
+    memset(&idx->stats, 0, sizeof(idx->stats));
+    idx->stats.probes_total = P;
+    if (fam_out) {
+        fam_out->fam_offsets.assign(1, 0);
+        fam_out->sds.clear();
+    }
+    if (want_csr) {
+        status_out->assign(P, 0);
+        rowoff_out->assign((size_t)P + 1, 0);
+        hits_out->clear();
+    }
+    if (P == 0 || n_chunks == 0) return 0;
+    if (n_shards != 1 || shard != 0) {
+        set_error("probe-range sharding is not implemented in this build yet");
+        return ASGART_E_ARG;
+    }
+
+    const size_t ch_bytes = (size_t)n_chunks * 16 + ((size_t)n_chunks + 1) * 4;
+    RC_TRY(w.chunks.reserve(ch_bytes));
+    uint64_t *d_start = w.chunks.as<uint64_t>();
+    uint64_t *d_len = d_start + n_chunks;
+    uint32_t *d_pbase = reinterpret_cast<uint32_t *>(d_len + n_chunks);
+    HIP_TRY(hipMemcpyAsync(d_start, h_start.data(), (size_t)n_chunks * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_len, h_len.data(), (size_t)n_chunks * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_pbase, h_pbase.data(), ((size_t)n_chunks + 1) * 4,
+                           hipMemcpyHostToDevice, s));
+
+    RunParams rp;
+    rp.ch = ChunkTable{d_start, d_len, d_pbase, (int)n_chunks};
+    rp.g_lo = 0;
+    rp.g_hi = P;
+    rp.k = (int)k;
+    rp.step = (int)step;
+    rp.G = st->max_gap_size;
+    rp.tstar = (uint32_t)((st->max_gap_size + step - 1) / step);
+    if (rp.tstar == 0) rp.tstar = 1;
+    rp.M = st->min_duplication_length;
+    rp.C = st->max_cardinality > 0xFFFFFF00ull ? 0xFFFFFF00u : (uint32_t)st->max_cardinality;
+    rp.reverse = st->reverse ? 1 : 0;
+    rp.complement = st->complement ? 1 : 0;
+
+    // ---- workspace -----------------------------------------------------------
+    const uint32_t n_blk = (P + kScanTile - 1) / kScanTile;
+    const uint64_t seg_cap = (uint64_t)P / (rp.tstar + 1) + (uint64_t)n_chunks + 64;
+    RC_TRY(w.p_lo.reserve((size_t)P * sizeof(SlotT)));
+    RC_TRY(w.p_raw.reserve((size_t)P * 4));
+    RC_TRY(w.p_filt.reserve((size_t)P * 4));
+    RC_TRY(w.row_off.reserve(((size_t)P + 1) * 8));
+    RC_TRY(w.blk.reserve((size_t)n_blk * sizeof(ScanEl)));
+    RC_TRY(w.big_list.reserve((size_t)P * 4));
+    RC_TRY(w.seg_list.reserve((size_t)seg_cap * 4));
+    RC_TRY(w.counters.reserve(CT_COUNT * 8));
+    unsigned long long *d_ctr = w.counters.as<unsigned long long>();
+    HIP_TRY(hipMemsetAsync(d_ctr, 0, CT_COUNT * 8, s));
+
+    IndexView<SlotT> ix = idx->view<SlotT>();
+    SlotT *p_lo = w.p_lo.as<SlotT>();
+    uint32_t *p_raw = w.p_raw.as<uint32_t>();
+    uint32_t *p_filt = w.p_filt.as<uint32_t>();
+    unsigned long long *row_off = w.row_off.as<unsigned long long>();
+    ScanEl *blk = w.blk.as<ScanEl>();
+    uint32_t *big_list = w.big_list.as<uint32_t>();
+    uint32_t *seg_list = w.seg_list.as<uint32_t>();
+
+    const auto t_host0 = std::chrono::steady_clock::now();
+    // ---- K1: probe search + filtered counts -----------------------------------
+    HIP_TRY(hipEventRecord(idx->ev[0], s));
+    probe_count_kernel<SlotT><<<grid_for(P), 256, 0, s>>>(ix, rp, p_lo, p_raw, p_filt, big_list,
+                                                         d_ctr);
+    big_count_kernel<SlotT><<<2048, 256, 0, s>>>(ix, rp, p_lo, p_raw, p_filt, big_list, d_ctr);
+    HIP_TRY(hipEventRecord(idx->ev[1], s));
+    // ---- K2: scans + segmentation ----------------------------------------------
+    scan_reduce_kernel<<<n_blk, kScanBlock, 0, s>>>(rp, p_filt, blk);
+    scan_mid_kernel<<<1, 1024, 0, s>>>(blk, n_blk, d_ctr);
+    scan_down_kernel<<<n_blk, kScanBlock, 0, s>>>(rp, p_filt, p_raw, blk, row_off, seg_list, d_ctr);
+    HIP_TRY(hipEventRecord(idx->ev[2], s));
+    HIP_TRY(hipGetLastError());
+    unsigned long long h_ctr[CT_COUNT];
+    HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, sizeof(h_ctr), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const uint64_t total_hits = h_ctr[CT_TOTAL_HITS];
+    const uint64_t n_seg = h_ctr[CT_SEG];
+    if (n_seg > seg_cap) {
+        set_error("internal: segment list overflow (%llu > %llu)", (unsigned long long)n_seg,
+                  (unsigned long long)seg_cap);
+        return ASGART_E_CAP;
+    }
+    // ---- K3: CSR fill -----------------------------------------------------------
+    RC_TRY(w.hits.reserve((size_t)(total_hits + 64) * sizeof(SlotT)));
+    SlotT *hits = w.hits.as<SlotT>();
+    fill_small_kernel<SlotT><<<grid_for(P), 256, 0, s>>>(ix, rp, p_lo, p_raw, p_filt, row_off, hits);
+    if (h_ctr[CT_BIG])
+        fill_big_kernel<SlotT><<<2048, 256, 0, s>>>(ix, rp, p_lo, p_raw, p_filt, row_off, hits,
+                                                    big_list, d_ctr);
+    HIP_TRY(hipEventRecord(idx->ev[3], s));
+    HIP_TRY(hipGetLastError());
+
+    if (want_csr) {
+        std::vector<uint32_t> h_filt(P);
+        std::vector<SlotT> h_hits((size_t)total_hits);
+        HIP_TRY(hipMemcpyAsync(h_filt.data(), p_filt, (size_t)P * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(rowoff_out->data(), row_off, ((size_t)P + 1) * 8,
+                               hipMemcpyDeviceToHost, s));
+        if (total_hits)
+            HIP_TRY(hipMemcpyAsync(h_hits.data(), hits, (size_t)total_hits * sizeof(SlotT),
+                                   hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        for (uint32_t g = 0; g < P; ++g)
+            (*status_out)[g] = h_filt[g] == kSkipN ? 1 : (h_filt[g] == kSkipCard ? 2 : 0);
+        hits_out->resize((size_t)total_hits);
+        for (uint64_t j = 0; j < total_hits; ++j) (*hits_out)[j] = h_hits[j];
+    }
+
+    // ---- K4: extension automaton ------------------------------------------------
+    std::vector<FamHdr> h_hdr;
+    std::vector<asgart_proto_sd> h_sds;
+    if (fam_out && n_seg) {
+        uint64_t fam_cap = std::max<uint64_t>(1u << 16, w.fam_hdr.cap / sizeof(FamHdr));
+        uint64_t sd_cap = std::max<uint64_t>(1u << 18, w.fam_sds.cap / sizeof(asgart_proto_sd));
+        RC_TRY(w.ovf_list.reserve((size_t)(n_seg + 1) * 4));
+        for (int attempt = 0;; ++attempt) {
+            RC_TRY(w.fam_hdr.reserve((size_t)fam_cap * sizeof(FamHdr)));
+            RC_TRY(w.fam_sds.reserve((size_t)sd_cap * sizeof(asgart_proto_sd)));
+            HIP_TRY(hipMemsetAsync(d_ctr + CT_SEG_CURSOR, 0, 4 * 8, s));  // cursor, fam, sd, ovf
+            ExtParams<SlotT> ep;
+            ep.rp = rp;
+            ep.p_filt = p_filt;
+            ep.row_off = row_off;
+            ep.hits = hits;
+            ep.seg_list = seg_list;
+            ep.n_seg_ptr = d_ctr + CT_SEG;
+            ep.cursor = d_ctr + CT_SEG_CURSOR;
+            ep.fam_hdr = w.fam_hdr.as<FamHdr>();
+            ep.fam_sds = w.fam_sds.as<asgart_proto_sd>();
+            ep.fam_cap = fam_cap;
+            ep.sd_cap = sd_cap;
+            ep.ovf_list = w.ovf_list.as<uint32_t>();
+            ep.ctr = d_ctr;
+            const unsigned waves = (unsigned)std::min<uint64_t>(n_seg, 256ull * 10ull);
+            extend_kernel<SlotT, kArmCapSmall><<<waves, 64, 0, s>>>(ep);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, sizeof(h_ctr), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            if (h_ctr[CT_OVF]) {
+                // second tier: one wave per CU with (almost) the whole LDS for arms
+                const uint64_t n_ovf = h_ctr[CT_OVF];
+                HIP_TRY(hipMemsetAsync(d_ctr + CT_OVF, 0, 8, s));
+                HIP_TRY(hipMemsetAsync(d_ctr + CT_OVF_CURSOR, 0, 8, s));
+                // n_seg_ptr must point at a device word holding n_ovf: reuse CT_BISECT slot
+                HIP_TRY(hipMemcpyAsync(d_ctr + CT_BISECT, &n_ovf, 8, hipMemcpyHostToDevice, s));
+                ep.seg_list = w.ovf_list.as<uint32_t>();
+                ep.n_seg_ptr = d_ctr + CT_BISECT;
+                ep.cursor = d_ctr + CT_OVF_CURSOR;
+                ep.ovf_list = nullptr;
+                const unsigned bw = (unsigned)std::min<uint64_t>(n_ovf, 256ull);
+                if constexpr (sizeof(SlotT) == 4)
+                    extend_kernel<SlotT, kArmCapBig32><<<bw, 64, 0, s>>>(ep);
+                else
+                    extend_kernel<SlotT, kArmCapBig64><<<bw, 64, 0, s>>>(ep);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, sizeof(h_ctr), hipMemcpyDeviceToHost, s));
+                HIP_TRY(hipStreamSynchronize(s));
+                if (h_ctr[CT_OVF]) {
+                    set_error("%llu segment(s) need more than %d simultaneous arms; "
+                              "not supported by this build",
+                              (unsigned long long)h_ctr[CT_OVF],
+                              sizeof(SlotT) == 4 ? kArmCapBig32 : kArmCapBig64);
+                    return ASGART_E_CAP;
+                }
+            }
+            if (h_ctr[CT_FAM] <= fam_cap && h_ctr[CT_SD] <= sd_cap) break;
+            if (attempt >= 3) {
+                set_error("internal: family buffers keep overflowing");
+                return ASGART_E_CAP;
+            }
+            fam_cap = std::max<uint64_t>(fam_cap, h_ctr[CT_FAM] * 2);
+            sd_cap = std::max<uint64_t>(sd_cap, h_ctr[CT_SD] * 2);
+        }
+        HIP_TRY(hipEventRecord(idx->ev[4], s));
+        const uint64_t n_fam = h_ctr[CT_FAM], n_sd = h_ctr[CT_SD];
+        h_hdr.resize((size_t)n_fam);
+        h_sds.resize((size_t)n_sd);
+        if (n_fam) {
+            HIP_TRY(hipMemcpyAsync(h_hdr.data(), w.fam_hdr.p, (size_t)n_fam * sizeof(FamHdr),
+                                   hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(h_sds.data(), w.fam_sds.p,
+                                   (size_t)n_sd * sizeof(asgart_proto_sd), hipMemcpyDeviceToHost, s));
+        }
+        HIP_TRY(hipStreamSynchronize(s));
+        // reference order: chunk order, then discovery order inside the chunk
+        // == (segment start probe, flush ordinal).  Segments re-run in the second
+        // tier emit their first families twice: keep one copy.
+        std::sort(h_hdr.begin(), h_hdr.end(), [](const FamHdr &a, const FamHdr &b) {
+            return a.g_start != b.g_start ? a.g_start < b.g_start : a.seq < b.seq;
+        });
+        for (size_t f = 0; f < h_hdr.size(); ++f) {
+            if (f && h_hdr[f].g_start == h_hdr[f - 1].g_start && h_hdr[f].seq == h_hdr[f - 1].seq)
+                continue;
+            const FamHdr &h = h_hdr[f];
+            fam_out->sds.insert(fam_out->sds.end(), h_sds.begin() + (size_t)h.sd_base,
+                                h_sds.begin() + (size_t)(h.sd_base + h.count));
+            fam_out->fam_offsets.push_back(fam_out->sds.size());
+        }
+    } else {
+        HIP_TRY(hipEventRecord(idx->ev[4], s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+
+    // ---- stats ------------------------------------------------------------------
+    asgart_stats &stt = idx->stats;
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, idx->ev[0], idx->ev[1]));
+    stt.ms_search = ms;
+    HIP_TRY(hipEventElapsedTime(&ms, idx->ev[1], idx->ev[2]));
+    stt.ms_scan = ms;
+    HIP_TRY(hipEventElapsedTime(&ms, idx->ev[2], idx->ev[3]));
+    stt.ms_fill = ms;
+    HIP_TRY(hipEventElapsedTime(&ms, idx->ev[3], idx->ev[4]));
+    stt.ms_extend = ms;
+    stt.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() -
+                                                            t_host0).count();
+    stt.probes_n_skipped = h_ctr[CT_N_SKIPPED];
+    stt.probes_searched = h_ctr[CT_SEARCHED];
+    stt.probes_card_skipped = h_ctr[CT_CARD_SKIPPED];
+    stt.probes_with_hits = h_ctr[CT_WITH_HITS];
+    stt.raw_hits = h_ctr[CT_RAW_HITS];
+    stt.filtered_hits = total_hits;
+    stt.segments = n_seg;
+    stt.families = fam_out ? fam_out->fam_offsets.size() - 1 : 0;
+    stt.proto_sds = fam_out ? fam_out->sds.size() : 0;
+    stt.search_launches = 1;
+    return 0;
+}
+
+int32_t run_search(asgart_index *idx, const uint64_t *chunks, int64_t n_chunks,
+                   const asgart_settings *st, int32_t shard, int32_t n_shards, bool want_csr,
+                   asgart_families *fam_out, std::vector<uint8_t> *status_out,
+                   std::vector<uint64_t> *rowoff_out, std::vector<uint64_t> *hits_out) {
+    if (!idx || !st || n_chunks < 0 || (n_chunks && !chunks)) {
+        set_error("bad argument");
+        return ASGART_E_ARG;
+    }
+    if (n_shards < 1 || shard < 0 || shard >= n_shards) {
+        set_error("bad shard %d of %d", shard, n_shards);
+        return ASGART_E_ARG;
+    }
+    HIP_TRY(hipSetDevice(idx->device));
+    RC_TRY(index_prepare(idx, st->probe_size));
+    if (idx->wide)
+        return run_search_t<uint64_t>(idx, chunks, n_chunks, st, shard, n_shards, want_csr, fam_out,
+                                      status_out, rowoff_out, hits_out);
+    return run_search_t<uint32_t>(idx, chunks, n_chunks, st, shard, n_shards, want_csr, fam_out,
+                                  status_out, rowoff_out, hits_out);
+}
+
+int32_t sa_build_device(const uint8_t *, int64_t, void *, bool, hipStream_t) {
+    set_error("GPU suffix-array construction is not implemented in this build yet: pass SA");
+    return ASGART_E_ARG;
+}
+
+}  // namespace asgart
+
+using namespace asgart;
+
+extern "C" {
+
+int32_t asgart_sa_build64(const uint8_t *, int64_t *, int64_t) {
+    set_error("asgart_sa_build64: GPU suffix-array construction is not implemented yet");
+    return ASGART_E_ARG;
+}
+
+int32_t asgart_search_duplications_shard(asgart_index *idx, const uint64_t *chunks,
+                                         int64_t n_chunks, const asgart_settings *settings,
+                                         int32_t shard, int32_t n_shards, asgart_families **out) {
+    if (!out) {
+        set_error("out is NULL");
+        return ASGART_E_ARG;
+    }
+    *out = nullptr;
+    asgart_families *f = new (std::nothrow) asgart_families();
+    if (!f) {
+        set_error("out of host memory");
+        return ASGART_E_OOM;
+    }
+    int32_t rc = run_search(idx, chunks, n_chunks, settings, shard, n_shards, false, f, nullptr,
+                            nullptr, nullptr);
+    if (rc != 0) {
+        delete f;
+        return rc;
+    }
+    *out = f;
+    return 0;
+}
+
+int32_t asgart_search_duplications(asgart_index *idx, const uint64_t *chunks, int64_t n_chunks,
+                                   const asgart_settings *settings, volatile uint64_t *progress,
+                                   asgart_families **out) {
+    int32_t rc = asgart_search_duplications_shard(idx, chunks, n_chunks, settings, 0, 1, out);
+    if (rc == 0 && progress) {
+        // best effort, like the Relaxed stores of src/automaton.rs:98: report the
+        // last probe offset of every chunk once the call is complete
+        const uint64_t k = settings->probe_size, step = k / 2;
+        for (int64_t c = 0; c < n_chunks; ++c)
+            progress[c] = (uint64_t)probes_in_chunk(chunks[2 * c + 1], k, step,
+                                                    settings->min_duplication_length) * step;
+    }
+    return rc;
+}
+
+void asgart_families_counts(const asgart_families *f, uint64_t *n_families, uint64_t *n_sds) {
+    if (n_families) *n_families = f ? f->fam_offsets.size() - 1 : 0;
+    if (n_sds) *n_sds = f ? f->sds.size() : 0;
+}
+
+void asgart_families_copy(const asgart_families *f, uint64_t *fam_offsets, asgart_proto_sd *sds) {
+    if (!f) return;
+    if (fam_offsets) memcpy(fam_offsets, f->fam_offsets.data(), f->fam_offsets.size() * 8);
+    if (sds && !f->sds.empty()) memcpy(sds, f->sds.data(), f->sds.size() * sizeof(asgart_proto_sd));
+}
+
+void asgart_families_free(asgart_families *f) { delete f; }
+
+int64_t asgart_probe_hits(asgart_index *idx, const uint64_t *chunks, int64_t n_chunks,
+                          const asgart_settings *settings, uint8_t *status, uint64_t *row_offsets,
+                          uint64_t *hits, uint64_t *n_hits) {
+    std::vector<uint8_t> st;
+    std::vector<uint64_t> ro, hv;
+    int32_t rc = run_search(idx, chunks, n_chunks, settings, 0, 1, true, nullptr, &st, &ro, &hv);
+    if (rc != 0) return rc;
+    if (n_hits) *n_hits = hv.size();
+    if (status) {
+        if (!st.empty()) memcpy(status, st.data(), st.size());
+        memcpy(row_offsets, ro.data(), ro.size() * 8);
+        if (!hv.empty()) memcpy(hits, hv.data(), hv.size() * 8);
+    }
+    return (int64_t)st.size();
+}
+
+int32_t asgart_get_stats(asgart_index *idx, uint32_t flags, asgart_stats *out) {
+    if (!idx || !out) {
+        set_error("bad argument");
+        return ASGART_E_ARG;
+    }
+    *out = idx->stats;
+    (void)flags;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,718 @@
+// pipeline_dev.hpp -- device kernels of the probe -> search -> extend pipeline.
+//
+//   K1 probe_count_kernel   one thread per probe: key, SA interval, filtered count
+//   K1b big_count_kernel    one wave per probe with a large interval (early exit)
+//   K2 scan_{reduce,mid,down}  row offsets + quiet-run segmentation
+//   K3 fill_{small,big}_kernel  filtered hits in SA order -> CSR
+//   K4 extend_kernel        one wavefront per independent automaton segment
+//
+// Reference semantics: src/automaton.rs:57-216 (see DESIGN.md for the proof
+// that a run of ceil(G/step) processed zero-hit probes empties the arm list,
+// which is what makes segments independent).
+#pragma once
+
+#include "search_dev.hpp"
+
+namespace asgart {
+
+constexpr int kSmallInterval = 32;  // intervals up to this size are handled by one thread
+constexpr int kScanItems = 8;       // probes per thread in the scan kernels
+constexpr int kScanBlock = 256;
+constexpr int kScanTile = kScanItems * kScanBlock;
+
+// device counters (u64 each)
+enum Counter {
+    CT_BIG = 0,       // entries in big_list
+    CT_SEG,           // entries in seg_list
+    CT_SEG_CURSOR,    // work-fetch cursor of the extend kernel
+    CT_FAM,           // families emitted
+    CT_SD,            // ProtoSDs emitted
+    CT_OVF,           // segments that overflowed the arm capacity
+    CT_TOTAL_HITS,    // CSR size
+    CT_N_SKIPPED,
+    CT_CARD_SKIPPED,
+    CT_WITH_HITS,
+    CT_RAW_HITS,
+    CT_SEARCHED,
+    CT_BISECT,        // yardstick
+    CT_OVF_CURSOR,
+    CT_COUNT = 32
+};
+
+struct ChunkTable {
+    const uint64_t *start;
+    const uint64_t *len;
+    const uint32_t *pbase;  // n_chunks + 1
+    int n_chunks;
+};
+
+struct RunParams {
+    ChunkTable ch;
+    uint32_t g_lo, g_hi;  // probe range of this call
+    int k, step;
+    uint32_t G;           // max_gap_size
+    uint32_t tstar;       // ceil(G / step)
+    uint64_t M;           // min_duplication_length
+    uint32_t C;           // max_cardinality (clamped)
+    uint8_t reverse, complement;
+};
+
+__device__ inline int chunk_of(const ChunkTable &ch, uint32_t g) {
+    // last c with pbase[c] <= g  (pbase non-decreasing; empty chunks repeat values)
+    int lo = 0, hi = ch.n_chunks;  // answer in [lo, hi)
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (ch.pbase[mid] <= g) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// hit filter of src/automaton.rs:105-114
+__device__ inline bool keep_hit(uint64_t x, uint64_t i, uint64_t s, uint64_t L, bool reverse) {
+    if (!reverse) return x > i + s;  // implies x != i
+    return x != i && x >= s + L - i;
+}
+
+// ---------------------------------------------------------------- K1 ---------
+template <class SlotT>
+__global__ __launch_bounds__(256) void probe_count_kernel(IndexView<SlotT> ix, RunParams rp,
+                                                          SlotT *__restrict__ p_lo,
+                                                          uint32_t *__restrict__ p_raw,
+                                                          uint32_t *__restrict__ p_filt,
+                                                          uint32_t *__restrict__ big_list,
+                                                          unsigned long long *__restrict__ ctr) {
+    const uint32_t g = rp.g_lo + blockIdx.x * blockDim.x + threadIdx.x;
+    bool is_big = false;
+    if (g < rp.g_hi) {
+        const int c = chunk_of(rp.ch, g);
+        const uint64_t s = rp.ch.start[c], L = rp.ch.len[c];
+        const uint64_t i = (uint64_t)(g - rp.ch.pbase[c] + 1) * (uint64_t)rp.step;
+        uint32_t first;
+        const uint64_t q = probe_key(ix.text, s, L, i, rp.k, rp.reverse, rp.complement, &first);
+        if (first == 4u) {  // needle[i] == 'N'  (automaton.rs:100-102)
+            p_filt[g] = kSkipN;
+            p_raw[g] = 0;
+            p_lo[g] = 0;
+        } else {
+            uint64_t lo, hi;
+            kmer_range(ix, q, lo, hi);
+            const uint64_t raw = hi - lo;
+            p_lo[g] = (SlotT)lo;
+            p_raw[g] = (uint32_t)raw;
+            if (raw <= (uint64_t)kSmallInterval) {
+                uint32_t cnt = 0;
+                for (uint64_t r = lo; r < hi; ++r)
+                    cnt += keep_hit(ix.sa[r], i, s, L, rp.reverse) ? 1u : 0u;
+                p_filt[g] = cnt > rp.C ? kSkipCard : cnt;
+            } else {
+                p_filt[g] = kPending;
+                is_big = true;
+            }
+        }
+    }
+    // wave-aggregated append to the large-interval work list
+    const unsigned long long m = __ballot(is_big);
+    if (m) {
+        const int lane = threadIdx.x & 63;
+        const int leader = __ffsll((long long)m) - 1;
+        unsigned long long base = 0;
+        if (lane == leader) base = atomicAdd(&ctr[CT_BIG], (unsigned long long)__popcll(m));
+        base = __shfl(base, leader);
+        if (is_big) big_list[base + __popcll(m & ((1ull << lane) - 1ull))] = g;
+    }
+}
+
+// one wave per large interval: coalesced count of the kept hits with early exit
+template <class SlotT>
+__global__ __launch_bounds__(256) void big_count_kernel(IndexView<SlotT> ix, RunParams rp,
+                                                        const SlotT *__restrict__ p_lo,
+                                                        const uint32_t *__restrict__ p_raw,
+                                                        uint32_t *__restrict__ p_filt,
+                                                        const uint32_t *__restrict__ big_list,
+                                                        const unsigned long long *__restrict__ ctr) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t n_big = ctr[CT_BIG];
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t e = wave; e < n_big; e += n_waves) {
+        const uint32_t g = big_list[e];
+        const int c = chunk_of(rp.ch, g);
+        const uint64_t s = rp.ch.start[c], L = rp.ch.len[c];
+        const uint64_t i = (uint64_t)(g - rp.ch.pbase[c] + 1) * (uint64_t)rp.step;
+        const uint64_t lo = p_lo[g], hi = lo + p_raw[g];
+        uint64_t cnt = 0;
+        for (uint64_t base = lo; base < hi && cnt <= rp.C; base += 64) {
+            const uint64_t r = base + lane;
+            const bool keep = r < hi && keep_hit(ix.sa[r], i, s, L, rp.reverse);
+            cnt += __popcll(__ballot(keep));
+        }
+        if (lane == 0) p_filt[g] = cnt > rp.C ? kSkipCard : (uint32_t)cnt;
+    }
+}
+
+// ---------------------------------------------------------------- K2 ---------
+// Scan element.  hits: running CSR offset.  (has, c, reset): "quiet count since
+// the last probe with hits, reset at chunk starts" monoid.
+struct ScanEl {
+    unsigned long long hits;
+    uint32_t c;      // processed probes after the last hit-probe (or all, if none)
+    uint32_t flags;  // bit0 = contains a hit-probe, bit1 = contains a chunk start
+};
+
+__device__ inline ScanEl scan_identity() { return ScanEl{0ull, 0u, 0u}; }
+
+__device__ inline ScanEl scan_combine(const ScanEl &a, const ScanEl &b) {
+    ScanEl r;
+    r.hits = a.hits + b.hits;
+    if (b.flags & 2u) {
+        r.c = b.c;
+        r.flags = b.flags;
+    } else if (b.flags & 1u) {
+        r.c = b.c;
+        r.flags = a.flags | 1u;
+    } else {
+        r.c = a.c + b.c;
+        r.flags = a.flags;
+    }
+    return r;
+}
+
+__device__ inline ScanEl scan_element(uint32_t filt, bool chunk_first) {
+    ScanEl e;
+    const bool skipped = filt >= kPending;
+    const bool hit = !skipped && filt > 0;
+    e.hits = hit ? filt : 0u;
+    e.c = (!skipped && !hit) ? 1u : 0u;
+    e.flags = (hit ? 1u : 0u) | (chunk_first ? 2u : 0u);
+    return e;
+}
+
+// exclusive block scan of one ScanEl per thread (kScanBlock threads)
+__device__ inline ScanEl block_exclusive_scan(ScanEl v, ScanEl *sh, ScanEl *block_total) {
+    const int t = threadIdx.x;
+    sh[t] = v;
+    __syncthreads();
+    for (int off = 1; off < kScanBlock; off <<= 1) {
+        ScanEl cur = sh[t];
+        ScanEl prev = t >= off ? sh[t - off] : scan_identity();
+        __syncthreads();
+        if (t >= off) sh[t] = scan_combine(prev, cur);
+        __syncthreads();
+    }
+    ScanEl excl = t > 0 ? sh[t - 1] : scan_identity();
+    *block_total = sh[kScanBlock - 1];
+    __syncthreads();
+    return excl;
+}
+
+// loads the kScanItems elements of this thread; returns their combination
+__device__ inline ScanEl load_thread_items(const RunParams &rp, const uint32_t *p_filt,
+                                           uint32_t g0, ScanEl *items) {
+    ScanEl agg = scan_identity();
+    int c = -1;
+    uint32_t next_first = 0;
+    for (int a = 0; a < kScanItems; ++a) {
+        const uint32_t g = g0 + a;
+        if (g < rp.g_hi) {
+            if (c < 0) {
+                c = chunk_of(rp.ch, g);
+                next_first = rp.ch.pbase[c];
+            }
+            // advance over chunk boundaries (empty chunks share pbase values)
+            while (c + 1 < rp.ch.n_chunks && rp.ch.pbase[c + 1] <= g) {
+                ++c;
+                next_first = rp.ch.pbase[c];
+            }
+            const bool first = (g == next_first);
+            items[a] = scan_element(p_filt[g], first);
+        } else {
+            items[a] = scan_identity();
+        }
+        agg = scan_combine(agg, items[a]);
+    }
+    return agg;
+}
+
+__global__ __launch_bounds__(kScanBlock) void scan_reduce_kernel(RunParams rp,
+                                                                 const uint32_t *__restrict__ p_filt,
+                                                                 ScanEl *__restrict__ blk) {
+    __shared__ ScanEl sh[kScanBlock];
+    ScanEl items[kScanItems];
+    const uint32_t g0 = rp.g_lo + (blockIdx.x * kScanBlock + threadIdx.x) * kScanItems;
+    ScanEl agg = load_thread_items(rp, p_filt, g0, items);
+    ScanEl total;
+    (void)block_exclusive_scan(agg, sh, &total);
+    if (threadIdx.x == 0) blk[blockIdx.x] = total;
+}
+
+// single block: exclusive scan of the block aggregates in place
+__global__ __launch_bounds__(1024) void scan_mid_kernel(ScanEl *__restrict__ blk, uint32_t n_blk,
+                                                        unsigned long long *__restrict__ ctr) {
+    __shared__ ScanEl sh[1024];
+    const int t = threadIdx.x;
+    const uint32_t per = (n_blk + 1023u) / 1024u;
+    const uint32_t b0 = t * per, b1 = min(n_blk, b0 + per);
+    ScanEl agg = scan_identity();
+    for (uint32_t b = b0; b < b1; ++b) agg = scan_combine(agg, blk[b]);
+    sh[t] = agg;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        ScanEl cur = sh[t];
+        ScanEl prev = t >= off ? sh[t - off] : scan_identity();
+        __syncthreads();
+        if (t >= off) sh[t] = scan_combine(prev, cur);
+        __syncthreads();
+    }
+    ScanEl run = t > 0 ? sh[t - 1] : scan_identity();
+    if (t == 1023) ctr[CT_TOTAL_HITS] = sh[1023].hits;
+    for (uint32_t b = b0; b < b1; ++b) {
+        ScanEl v = blk[b];
+        blk[b] = run;
+        run = scan_combine(run, v);
+    }
+}
+
+__global__ __launch_bounds__(kScanBlock) void scan_down_kernel(RunParams rp,
+                                                               const uint32_t *__restrict__ p_filt,
+                                                               const uint32_t *__restrict__ p_raw,
+                                                               const ScanEl *__restrict__ blk,
+                                                               unsigned long long *__restrict__ row_off,
+                                                               uint32_t *__restrict__ seg_list,
+                                                               unsigned long long *__restrict__ ctr) {
+    __shared__ ScanEl sh[kScanBlock];
+    __shared__ unsigned long long sh_stat[5];
+    if (threadIdx.x < 5) sh_stat[threadIdx.x] = 0;
+    ScanEl items[kScanItems];
+    const uint32_t g0 = rp.g_lo + (blockIdx.x * kScanBlock + threadIdx.x) * kScanItems;
+    ScanEl agg = load_thread_items(rp, p_filt, g0, items);
+    ScanEl total;
+    ScanEl excl = block_exclusive_scan(agg, sh, &total);
+    ScanEl run = scan_combine(blk[blockIdx.x], excl);
+    unsigned long long st_n = 0, st_card = 0, st_hit = 0, st_raw = 0, st_searched = 0;
+    const int lane = threadIdx.x & 63;
+    for (int a = 0; a < kScanItems; ++a) {
+        const uint32_t g = g0 + a;
+        const bool valid = g < rp.g_hi;
+        bool start = false;
+        if (valid) {
+            const uint32_t f = p_filt[g];
+            row_off[g] = run.hits;
+            const bool hit = f < kPending && f > 0;
+            if (f == kSkipN) ++st_n;
+            else {
+                ++st_searched;
+                st_raw += p_raw[g];
+                if (f == kSkipCard) ++st_card;
+                else if (hit) ++st_hit;
+            }
+            if (hit) {
+                const bool chunk_first = items[a].flags & 2u;
+                const bool has_before = !chunk_first && (run.flags & 1u);
+                start = !has_before || run.c >= rp.tstar;
+            }
+            run = scan_combine(run, items[a]);
+        }
+        // wave-aggregated append of segment starts (order is irrelevant: the
+        // families are sorted by (start probe, ordinal) on the host)
+        const unsigned long long m = __ballot(start);
+        if (m) {
+            const int leader = __ffsll((long long)m) - 1;
+            unsigned long long base = 0;
+            if (lane == leader) base = atomicAdd(&ctr[CT_SEG], (unsigned long long)__popcll(m));
+            base = __shfl(base, leader);
+            if (start) seg_list[base + __popcll(m & ((1ull << lane) - 1ull))] = g;
+        }
+    }
+    if (g0 < rp.g_hi && g0 + kScanItems >= rp.g_hi) row_off[rp.g_hi] = run.hits;
+    atomicAdd(&sh_stat[0], st_n);
+    atomicAdd(&sh_stat[1], st_card);
+    atomicAdd(&sh_stat[2], st_hit);
+    atomicAdd(&sh_stat[3], st_raw);
+    atomicAdd(&sh_stat[4], st_searched);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (sh_stat[0]) atomicAdd(&ctr[CT_N_SKIPPED], sh_stat[0]);
+        if (sh_stat[1]) atomicAdd(&ctr[CT_CARD_SKIPPED], sh_stat[1]);
+        if (sh_stat[2]) atomicAdd(&ctr[CT_WITH_HITS], sh_stat[2]);
+        if (sh_stat[3]) atomicAdd(&ctr[CT_RAW_HITS], sh_stat[3]);
+        if (sh_stat[4]) atomicAdd(&ctr[CT_SEARCHED], sh_stat[4]);
+    }
+}
+
+// ---------------------------------------------------------------- K3 ---------
+template <class SlotT>
+__global__ __launch_bounds__(256) void fill_small_kernel(IndexView<SlotT> ix, RunParams rp,
+                                                         const SlotT *__restrict__ p_lo,
+                                                         const uint32_t *__restrict__ p_raw,
+                                                         const uint32_t *__restrict__ p_filt,
+                                                         const unsigned long long *__restrict__ row_off,
+                                                         SlotT *__restrict__ hits) {
+    const uint32_t g = rp.g_lo + blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= rp.g_hi) return;
+    const uint32_t f = p_filt[g];
+    if (f == 0 || f >= kPending) return;
+    const uint32_t raw = p_raw[g];
+    if (raw > (uint32_t)kSmallInterval) return;
+    const int c = chunk_of(rp.ch, g);
+    const uint64_t s = rp.ch.start[c], L = rp.ch.len[c];
+    const uint64_t i = (uint64_t)(g - rp.ch.pbase[c] + 1) * (uint64_t)rp.step;
+    const uint64_t lo = p_lo[g];
+    unsigned long long w = row_off[g];
+    for (uint32_t r = 0; r < raw; ++r) {
+        const SlotT x = ix.sa[lo + r];
+        if (keep_hit(x, i, s, L, rp.reverse)) hits[w++] = x;
+    }
+}
+
+// one wave per large interval: ballot / prefix-popcount compaction, SA order kept
+template <class SlotT>
+__global__ __launch_bounds__(256) void fill_big_kernel(IndexView<SlotT> ix, RunParams rp,
+                                                       const SlotT *__restrict__ p_lo,
+                                                       const uint32_t *__restrict__ p_raw,
+                                                       const uint32_t *__restrict__ p_filt,
+                                                       const unsigned long long *__restrict__ row_off,
+                                                       SlotT *__restrict__ hits,
+                                                       const uint32_t *__restrict__ big_list,
+                                                       const unsigned long long *__restrict__ ctr) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t n_big = ctr[CT_BIG];
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t e = wave; e < n_big; e += n_waves) {
+        const uint32_t g = big_list[e];
+        const uint32_t f = p_filt[g];
+        if (f == 0 || f >= kPending) continue;
+        const int c = chunk_of(rp.ch, g);
+        const uint64_t s = rp.ch.start[c], L = rp.ch.len[c];
+        const uint64_t i = (uint64_t)(g - rp.ch.pbase[c] + 1) * (uint64_t)rp.step;
+        const uint64_t lo = p_lo[g], hi = lo + p_raw[g];
+        unsigned long long w = row_off[g];
+        for (uint64_t base = lo; base < hi; base += 64) {
+            const uint64_t r = base + lane;
+            SlotT x = 0;
+            bool keep = false;
+            if (r < hi) {
+                x = ix.sa[r];
+                keep = keep_hit(x, i, s, L, rp.reverse);
+            }
+            const unsigned long long m = __ballot(keep);
+            if (keep) hits[w + __popcll(m & ((1ull << lane) - 1ull))] = x;
+            w += __popcll(m);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- K4 ---------
+struct FamHdr {
+    uint32_t g_start;  // first probe of the segment (global probe index): sort key 1
+    uint32_t seq;      // flush ordinal inside the segment: sort key 2
+    unsigned long long sd_base;
+    uint32_t count;
+    uint32_t pad;
+};
+
+template <class PosT>
+struct ExtParams {
+    RunParams rp;
+    const uint32_t *p_filt;
+    const unsigned long long *row_off;
+    const PosT *hits;
+    const uint32_t *seg_list;
+    const unsigned long long *n_seg_ptr;  // device count of seg_list entries
+    unsigned long long *cursor;           // work-fetch cursor
+    FamHdr *fam_hdr;
+    asgart_proto_sd *fam_sds;
+    unsigned long long fam_cap, sd_cap;
+    uint32_t *ovf_list;                   // segments whose arms overflowed CAP (may be null)
+    unsigned long long *ctr;
+};
+
+// d_ss(a.right, m) < thr   (src/automaton.rs:69, :207-216)
+__device__ inline bool dss_lt(long long as, long long ae, long long ms, long long me,
+                              long long thr) {
+    if ((ms >= as && ms <= ae) || (me >= as && me <= ae)) return 0 < thr;
+    long long d1 = as - me, d2 = ae - ms;
+    d1 = d1 < 0 ? -d1 : d1;
+    d2 = d2 < 0 ? -d2 : d2;
+    return (d1 < d2 ? d1 : d2) < thr;
+}
+
+// max(e, (0.1 * len as f64) as i64)   (src/automaton.rs:69)
+__device__ inline uint32_t arm_threshold(uint64_t left_len, uint32_t G) {
+    long long tenth = (long long)(0.1 * (double)left_len);
+    long long thr = tenth > (long long)G ? tenth : (long long)G;
+    return thr > 0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)thr;
+}
+
+constexpr uint32_t kActiveBit = 0x80000000u;
+
+template <class PosT, int CAP>
+__global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
+    __shared__ PosT s_ls[CAP], s_le[CAP], s_rs[CAP], s_re[CAP];
+    __shared__ uint32_t s_gap[CAP];   // bit31 = active, low bits = gap
+    __shared__ uint32_t s_thr[CAP];
+    __shared__ uint32_t s_pend[CAP];  // 0 = not extended by this probe, else hit index + 1
+    const int lane = threadIdx.x;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const RunParams &rp = P.rp;
+    const uint64_t n_seg = *P.n_seg_ptr;
+    const uint32_t k = (uint32_t)rp.k, step = (uint32_t)rp.step;
+
+    for (;;) {
+        unsigned long long seg = 0;
+        if (lane == 0) seg = atomicAdd(P.cursor, 1ull);
+        seg = __shfl(seg, 0);
+        if (seg >= n_seg) break;
+        const uint32_t g0 = P.seg_list[seg];
+        const int c = chunk_of(rp.ch, g0);
+        const uint64_t cs = rp.ch.start[c], cl = rp.ch.len[c];
+        const uint32_t pb = rp.ch.pbase[c];
+        const uint32_t g_end = rp.ch.pbase[c + 1];
+        uint32_t A = 0, quiet = 0, fam_seq = 0;
+        bool overflow = false, done = false;
+
+        for (uint32_t gb = g0; gb < g_end && !done; gb += 64) {
+            const uint32_t fl = (gb + lane < g_end) ? P.p_filt[gb + lane] : kSkipN;
+            const unsigned long long rl = (gb + lane < g_end) ? P.row_off[gb + lane] : 0ull;
+            const int nb = (int)min(64u, g_end - gb);
+            for (int b = 0; b < nb; ++b) {
+                const uint32_t f = __shfl(fl, b);
+                if (f >= kPending) continue;  // skipped probe: no ageing, no flush
+                bool any_active = false;
+                if (f == 0) {
+                    // processed probe without hits: age every arm (automaton.rs:166-171)
+                    if (A == 0) {
+                        if (++quiet >= rp.tstar) {
+                            done = true;
+                            break;
+                        }
+                        continue;
+                    }
+                    ++quiet;
+                    for (uint32_t j = lane; j < A; j += 64) {
+                        uint32_t gp = s_gap[j];
+                        if (gp & kActiveBit) {
+                            uint32_t gap = (gp & ~kActiveBit) + step;
+                            gp = gap >= rp.G ? gap : (gap | kActiveBit);
+                            s_gap[j] = gp;
+                        }
+                        any_active |= (gp & kActiveBit) != 0;
+                    }
+                    any_active = __ballot(any_active) != 0ull;
+                    __syncthreads();
+                } else {
+                    quiet = 0;
+                    const uint64_t i = (uint64_t)(gb + b - pb + 1) * step;
+                    const unsigned long long row = __shfl(rl, b);
+                    const uint32_t cnt = f;
+                    // make room: drop arms the reference would prune anyway (they are
+                    // inactive and too short to be reported, so dropping them early is
+                    // unobservable)
+                    if (A + cnt > (uint32_t)CAP) {
+                        uint32_t w = 0;
+                        for (uint32_t t0 = 0; t0 < A; t0 += 64) {
+                            const uint32_t j = t0 + lane;
+                            bool keep = false;
+                            PosT ls = 0, le = 0, rs = 0, re = 0;
+                            uint32_t gp = 0, th = 0;
+                            if (j < A) {
+                                ls = s_ls[j]; le = s_le[j]; rs = s_rs[j]; re = s_re[j];
+                                gp = s_gap[j]; th = s_thr[j];
+                                keep = (gp & kActiveBit) || (uint64_t)(le - ls) >= rp.M ||
+                                       (uint64_t)(re - rs) >= rp.M;
+                            }
+                            const unsigned long long m = __ballot(keep);
+                            __syncthreads();
+                            if (keep) {
+                                const uint32_t d = w + __popcll(m & lt_mask);
+                                s_ls[d] = ls; s_le[d] = le; s_rs[d] = rs; s_re[d] = re;
+                                s_gap[d] = gp; s_thr[d] = th; s_pend[d] = 0;
+                            }
+                            w += __popcll(m);
+                            __syncthreads();
+                        }
+                        A = w;
+                        if (A + cnt > (uint32_t)CAP) {
+                            overflow = true;
+                            done = true;
+                            break;
+                        }
+                    }
+                    const uint32_t A_old = A;
+                    // try_extend_arms for every hit against the unchanged arms
+                    for (uint32_t t0 = 0; t0 < cnt; t0 += 64) {
+                        const uint32_t t = t0 + lane;
+                        const bool valid = t < cnt;
+                        const PosT x = valid ? P.hits[row + t] : (PosT)0;
+                        const long long ms = (long long)x, me = (long long)x + k;
+                        int found = -1;
+                        for (uint32_t j = 0; j < A_old; ++j) {
+                            const uint32_t gp = s_gap[j];
+                            if (gp & kActiveBit) {
+                                const long long re = (long long)s_re[j];
+                                if (valid && found < 0 && me > re &&
+                                    dss_lt((long long)s_rs[j], re, ms, me, (long long)s_thr[j]))
+                                    found = (int)j;
+                            }
+                            if ((j & 7u) == 7u && __ballot(valid && found < 0) == 0ull) break;
+                        }
+                        if (valid && found >= 0) atomicMax(&s_pend[found], t + 1u);
+                        const bool is_new = valid && found < 0;
+                        const unsigned long long m = __ballot(is_new);
+                        if (is_new) {  // NewArm, appended in hit order (automaton.rs:145-163)
+                            const uint32_t d = A + __popcll(m & lt_mask);
+                            s_ls[d] = (PosT)i;
+                            s_le[d] = (PosT)(i + k);
+                            s_rs[d] = x;
+                            s_re[d] = (PosT)(x + k);
+                            // not dirty => aged by this very probe (automaton.rs:166-171)
+                            s_gap[d] = step >= rp.G ? step : (step | kActiveBit);
+                            s_thr[d] = arm_threshold(k, rp.G);
+                            s_pend[d] = 0;
+                        }
+                        A += __popcll(m);
+                    }
+                    __syncthreads();
+                    any_active = (A > A_old) && (step < rp.G);
+                    // apply ExtendArm (last hit in SA order wins, automaton.rs:136-143)
+                    // and age the arms that were not extended
+                    bool act = false;
+                    for (uint32_t j = lane; j < A_old; j += 64) {
+                        const uint32_t pd = s_pend[j];
+                        uint32_t gp = s_gap[j];
+                        if (pd) {
+                            s_pend[j] = 0;
+                            s_re[j] = (PosT)(P.hits[row + pd - 1u] + k);
+                            s_le[j] = (PosT)(i + k);
+                            s_thr[j] = arm_threshold((uint64_t)(i + k) - (uint64_t)s_ls[j], rp.G);
+                            gp = kActiveBit;  // gap = 0, still active
+                            s_gap[j] = gp;
+                        } else if (gp & kActiveBit) {
+                            uint32_t gap = (gp & ~kActiveBit) + step;
+                            gp = gap >= rp.G ? gap : (gap | kActiveBit);
+                            s_gap[j] = gp;
+                        }
+                        act |= (gp & kActiveBit) != 0;
+                    }
+                    any_active |= __ballot(act) != 0ull;
+                    __syncthreads();
+                }
+                // prune (automaton.rs:173-179); never removes an active arm
+                if (A > 200u) {
+                    uint32_t w = 0;
+                    for (uint32_t t0 = 0; t0 < A; t0 += 64) {
+                        const uint32_t j = t0 + lane;
+                        bool keep = false;
+                        PosT ls = 0, le = 0, rs = 0, re = 0;
+                        uint32_t gp = 0, th = 0;
+                        if (j < A) {
+                            ls = s_ls[j]; le = s_le[j]; rs = s_rs[j]; re = s_re[j];
+                            gp = s_gap[j]; th = s_thr[j];
+                            keep = (gp & kActiveBit) || (uint64_t)(le - ls) >= rp.M ||
+                                   (uint64_t)(re - rs) >= rp.M;
+                        }
+                        const unsigned long long m = __ballot(keep);
+                        __syncthreads();
+                        if (keep) {
+                            const uint32_t d = w + __popcll(m & lt_mask);
+                            s_ls[d] = ls; s_le[d] = le; s_rs[d] = rs; s_re[d] = re;
+                            s_gap[d] = gp; s_thr[d] = th; s_pend[d] = 0;
+                        }
+                        w += __popcll(m);
+                        __syncthreads();
+                    }
+                    A = w;
+                }
+                // flush the family once every arm is inactive (automaton.rs:182-200)
+                if (A > 0 && !any_active) {
+                    uint32_t total = 0;
+                    for (uint32_t t0 = 0; t0 < A; t0 += 64) {
+                        const uint32_t j = t0 + lane;
+                        const bool emit = j < A && (uint64_t)(s_re[j] - s_rs[j]) >= rp.M;
+                        total += __popcll(__ballot(emit));
+                    }
+                    if (total > 0) {
+                        unsigned long long sd_base = 0, fam_idx = 0;
+                        if (lane == 0) {
+                            sd_base = atomicAdd(&P.ctr[CT_SD], (unsigned long long)total);
+                            fam_idx = atomicAdd(&P.ctr[CT_FAM], 1ull);
+                        }
+                        sd_base = __shfl(sd_base, 0);
+                        fam_idx = __shfl(fam_idx, 0);
+                        if (fam_idx < P.fam_cap && sd_base + total <= P.sd_cap) {
+                            if (lane == 0) {
+                                FamHdr h;
+                                h.g_start = g0;
+                                h.seq = fam_seq;
+                                h.sd_base = sd_base;
+                                h.count = total;
+                                h.pad = 0;
+                                P.fam_hdr[fam_idx] = h;
+                            }
+                            uint32_t w = 0;
+                            for (uint32_t t0 = 0; t0 < A; t0 += 64) {
+                                const uint32_t j = t0 + lane;
+                                const bool emit = j < A && (uint64_t)(s_re[j] - s_rs[j]) >= rp.M;
+                                const unsigned long long m = __ballot(emit);
+                                if (emit) {
+                                    const uint64_t ls = s_ls[j], ll = (uint64_t)s_le[j] - ls;
+                                    asgart_proto_sd sd;
+                                    // left fix-up, src/bin/asgart.rs:229-237
+                                    sd.left = rp.reverse ? cs + cl - ls - ll : ls + cs;
+                                    sd.right = s_rs[j];
+                                    sd.left_length = ll;
+                                    sd.right_length = (uint64_t)s_re[j] - (uint64_t)s_rs[j];
+                                    P.fam_sds[sd_base + w + __popcll(m & lt_mask)] = sd;
+                                }
+                                w += __popcll(m);
+                            }
+                        }
+                        ++fam_seq;
+                    }
+                    A = 0;
+                    __syncthreads();
+                }
+                if (A == 0 && quiet >= rp.tstar) {
+                    done = true;
+                    break;
+                }
+            }
+        }
+        // arms still alive at the end of the chunk are dropped (automaton.rs:201-203)
+        if (overflow && P.ovf_list && lane == 0)
+            P.ovf_list[atomicAdd(&P.ctr[CT_OVF], 1ull)] = g0;
+        else if (overflow && lane == 0)
+            atomicAdd(&P.ctr[CT_OVF], 1ull);
+        __syncthreads();
+    }
+}
+
+// yardstick: sum over searched probes of ceil(log2(b_p + 1)), b_p = size of the
+// reference's 8-mer bucket.  Untimed.
+template <class SlotT>
+__global__ __launch_bounds__(256) void yardstick_kernel(IndexView<SlotT> ix, RunParams rp,
+                                                        const uint32_t *__restrict__ p_filt,
+                                                        unsigned long long *__restrict__ ctr) {
+    const uint32_t g = rp.g_lo + blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long steps = 0;
+    if (g < rp.g_hi && p_filt[g] != kSkipN) {
+        const int c = chunk_of(rp.ch, g);
+        const uint64_t s = rp.ch.start[c], L = rp.ch.len[c];
+        const uint64_t i = (uint64_t)(g - rp.ch.pbase[c] + 1) * (uint64_t)rp.step;
+        uint32_t first;
+        const uint64_t q = probe_key(ix.text, s, L, i, rp.k, rp.reverse, rp.complement, &first);
+        uint32_t c8;
+        if (cache8_index((uint32_t)(q >> (3 * (ix.k - kCacheLen))), c8)) {
+            const uint64_t b = (uint64_t)ix.c8hi[c8] - (uint64_t)ix.c8lo[c8];
+            uint64_t v = 1;
+            while (v < b + 1) {
+                v <<= 1;
+                ++steps;
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) steps += __shfl_down(steps, off);
+    if ((threadIdx.x & 63) == 0 && steps) atomicAdd(&ctr[CT_BISECT], steps);
+}
+
+}  // namespace asgart

@@ -1,0 +1,170 @@
+// search_dev.hpp -- device-side k-mer -> SA-interval lookup.
+//
+// Replaces Searcher::search (reference src/searcher.rs:145-180).  The
+// reference bisects sa[lo8..hi8) of the probe's 8-mer bucket, gathering
+// dna[sa[mid]..+k] at every step (two dependent random reads per step).  Here
+// the keys array holds the first k bases of every suffix in SA order as one
+// sorted u64 array, so the interval is [lower_bound(q), upper_bound(q)) over a
+// single array, entered through a 4^d prefix table: ~log2(n/4^d) dependent
+// 8-byte reads instead of ~2*log2(n/5^8) (sa, text) pairs.
+#pragma once
+
+#include "index.hpp"
+
+namespace asgart {
+
+// index into the ACGT-only d-mer table from a k-mer key; false if one of the
+// first d bases is not A/C/G/T.
+__device__ inline bool prefix_index(uint64_t q, int k, int d, uint32_t &p) {
+    uint32_t idx = 0;
+    bool ok = true;
+    for (int j = 0; j < d; ++j) {
+        uint32_t code = (uint32_t)(q >> (3 * (k - 1 - j))) & 7u;
+        uint32_t dg = acgt_digit(code);
+        ok &= dg < 4u;
+        idx = (idx << 2) | (dg & 3u);
+    }
+    p = idx;
+    return ok;
+}
+
+__device__ inline uint64_t lower_bound_keys(const uint64_t *__restrict__ keys, uint64_t lo,
+                                            uint64_t hi, uint64_t q) {
+    while (lo < hi) {
+        uint64_t mid = lo + ((hi - lo) >> 1);
+        if (keys[mid] < q) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__device__ inline uint64_t upper_bound_keys(const uint64_t *__restrict__ keys, uint64_t lo,
+                                            uint64_t hi, uint64_t q) {
+    while (lo < hi) {
+        uint64_t mid = lo + ((hi - lo) >> 1);
+        if (keys[mid] <= q) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// dense index of an 8-mer over the 5-letter alphabet in code order (A,C,G,N,T)
+__device__ inline bool cache8_index(uint32_t pre24, uint32_t &idx) {
+    uint32_t v = 0;
+    bool ok = true;
+    for (int j = 0; j < kCacheLen; ++j) {
+        uint32_t code = (pre24 >> (3 * (kCacheLen - 1 - j))) & 7u;
+        ok &= (code >= 1u && code <= 5u);
+        v = v * 5u + (code - 1u);
+    }
+    idx = v;
+    return ok;
+}
+
+template <class SlotT>
+__device__ inline bool in_tail_list(const IndexView<SlotT> &ix, uint32_t pre24) {
+    if (!((ix.tail_bloom >> (pre24 & 63u)) & 1ull)) return false;
+    for (int j = 0; j < ix.n_tail8; ++j)
+        if (ix.tail8[j] == pre24) return true;
+    return false;
+}
+
+// Exact emulation of the reference's bisection for the text-tail corner
+// (reference src/searcher.rs:164-170 + superslice equal_range_by): comparator
+// says Less for suffixes shorter than k although they may sort Greater.
+template <class SlotT>
+__device__ inline void kmer_range_tail(const IndexView<SlotT> &ix, uint64_t q, uint64_t &lo,
+                                       uint64_t &hi) {
+    uint32_t pre24 = (uint32_t)(q >> (3 * (ix.k - kCacheLen)));
+    uint32_t c8;
+    if (!cache8_index(pre24, c8)) {  // cannot happen for validated text
+        lo = hi = 0;
+        return;
+    }
+    const uint64_t L = ix.c8lo[c8], R = ix.c8hi[c8];
+    uint64_t size = R - L;
+    if (size == 0) {
+        lo = hi = L;
+        return;
+    }
+    auto cmp = [&](uint64_t r) -> int {
+        uint64_t x = ix.sa[r];
+        if (x + (uint64_t)ix.k > ix.n) return -1;
+        uint64_t kv = ix.keys[r];
+        return kv < q ? -1 : (kv > q ? 1 : 0);
+    };
+    uint64_t b0 = 0, b1 = 0;
+    while (size > 1) {
+        uint64_t half = size >> 1;
+        uint64_t m0 = b0 + half, m1 = b1 + half;
+        int c0 = cmp(L + m0);
+        int c1 = (m1 == m0) ? c0 : cmp(L + m1);
+        if (c0 < 0) b0 = m0;
+        if (c1 <= 0) b1 = m1;
+        size -= half;
+    }
+    int c0 = cmp(L + b0);
+    int c1 = (b1 == b0) ? c0 : cmp(L + b1);
+    uint64_t rs = b0 + (c0 < 0 ? 1 : 0), re = b1 + (c1 <= 0 ? 1 : 0);
+    if (re < rs) re = rs;
+    lo = L + rs;
+    hi = L + re;
+}
+
+// SA slot interval [lo,hi) of the k-mer with key q.
+template <class SlotT>
+__device__ inline void kmer_range(const IndexView<SlotT> &ix, uint64_t q, uint64_t &lo,
+                                  uint64_t &hi) {
+    uint32_t pre24 = (uint32_t)(q >> (3 * (ix.k - kCacheLen)));
+    if (ix.n_tail8 && in_tail_list(ix, pre24)) {
+        kmer_range_tail(ix, q, lo, hi);
+        return;
+    }
+    uint64_t lo0 = 0, hi0 = ix.n;
+    uint32_t p;
+    if (prefix_index(q, ix.k, ix.d, p)) {
+        lo0 = ix.ptab[p];
+        hi0 = ix.ptab[p + 1];
+    }
+    uint64_t l = lower_bound_keys(ix.keys, lo0, hi0, q);
+    // most k-mers are unique or absent: walk a few equal keys (same cache
+    // line) before falling back to a second bisection
+    uint64_t h = l;
+    int walk = 0;
+    while (h < hi0 && walk < 8 && ix.keys[h] == q) {
+        ++h;
+        ++walk;
+    }
+    if (walk == 8 && h < hi0 && ix.keys[h] == q) h = upper_bound_keys(ix.keys, h, hi0, q);
+    lo = l;
+    hi = h;
+}
+
+// key of the probe at needle-local offset i of chunk (s, L) under the run's
+// orientation: needle = chunk | complemented | reversed (reference
+// src/bin/asgart.rs:206-218), probe = needle[i..i+k].  *first = first base code.
+__device__ inline uint64_t probe_key(const uint8_t *__restrict__ text, uint64_t s, uint64_t L,
+                                     uint64_t i, int k, bool reverse, bool complement,
+                                     uint32_t *first) {
+    uint64_t q = 0;
+    uint32_t f = 0;
+    if (!reverse) {
+        const uint8_t *p = text + s + i;
+        for (int j = 0; j < k; ++j) {
+            uint32_t c = base_code(p[j]);
+            if (complement) c = comp_code(c);
+            if (j == 0) f = c;
+            q = (q << 3) | c;
+        }
+    } else {
+        const uint8_t *p = text + s + L - 1 - i;
+        for (int j = 0; j < k; ++j) {
+            uint32_t c = base_code(*(p - j));
+            if (complement) c = comp_code(c);
+            if (j == 0) f = c;
+            q = (q << 3) | c;
+        }
+    }
+    *first = f;
+    return q;
+}
+
+}  // namespace asgart

@@ -1,0 +1,94 @@
+"""Host-side input preparation: what `prepare_data` hands to the search step.
+
+Mirrors reference src/bin/asgart.rs:273-471 for in-memory records (FASTA parsing
+itself is `read_records`): per-record normalisation (:289-301), chunking at
+N-runs longer than 5000 (:317-366), concatenation with per-record chunk offsets
+(:375-395) and the final '$' (:430).  Vectorised numpy; no GPU work here.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Iterable, List, Sequence, Tuple
+
+import numpy as np
+
+N_RUN_THRESHOLD = 5000  # reference src/bin/asgart.rs:326
+
+_UPPER = np.arange(256, dtype=np.uint8)
+_UPPER[ord("a"):ord("z") + 1] -= 32
+_KEEP = np.full(256, ord("N"), dtype=np.uint8)
+for _c in b"ATGCN":
+    _KEEP[_c] = _c
+_NORM_PLAIN = _KEEP[_UPPER]  # upper-case first, then non-alphabet -> N
+_NORM_MASKED = _KEEP.copy()  # lower-case (masked) letters are not in ALPHABET -> N
+
+
+def normalise(seq: np.ndarray, skip_masked: bool) -> np.ndarray:
+    """reference src/bin/asgart.rs:289-301."""
+    return (_NORM_MASKED if skip_masked else _NORM_PLAIN)[seq]
+
+
+def find_chunks_to_process(strand: np.ndarray) -> List[Tuple[int, int]]:
+    """reference src/bin/asgart.rs:317-366: maximal pieces between N-runs > 5000."""
+    n = len(strand)
+    isn = (strand == ord("N")) | (strand == ord("n"))
+    edges = np.diff(np.concatenate(([0], isn.view(np.int8), [0])))
+    starts = np.flatnonzero(edges == 1)
+    ends = np.flatnonzero(edges == -1)
+    long_runs = (ends - starts) > N_RUN_THRESHOLD
+    cut_s, cut_e = starts[long_runs], ends[long_runs]
+    piece_s = np.concatenate(([0], cut_e))
+    piece_e = np.concatenate((cut_s, [n]))
+    chunks = [(int(a), int(b - a)) for a, b in zip(piece_s, piece_e) if b > a]
+    if not chunks:
+        chunks = [(0, n)]
+    return chunks
+
+
+@dataclass
+class Start:
+    """reference src/structs.rs:60-65"""
+
+    name: str
+    position: int
+    length: int
+
+
+@dataclass
+class Prepared:
+    data: np.ndarray                      # concatenated, normalised, '$'-terminated
+    chunks: List[Tuple[int, int]]         # global (start, len)
+    map: List[Start]
+
+
+def prepare_records(records: Sequence[Tuple[str, np.ndarray]], skip_masked: bool = False) -> Prepared:
+    """prepare_data for records already in memory (one or several files' worth)."""
+    parts, chunks, starts = [], [], []
+    offset = 0
+    for name, seq in records:
+        seq = normalise(np.asarray(seq, dtype=np.uint8), skip_masked)
+        chunks.extend((offset + s, l) for s, l in find_chunks_to_process(seq))
+        starts.append(Start(name, offset, len(seq)))
+        offset += len(seq)
+        parts.append(seq)
+    parts.append(np.frombuffer(b"$", dtype=np.uint8))
+    return Prepared(np.concatenate(parts), chunks, starts)
+
+
+def read_records(path: str) -> Iterable[Tuple[str, np.ndarray]]:
+    """Minimal FASTA reader (id = header up to the first whitespace), standing in
+    for bio::io::fasta::Reader at reference src/bin/asgart.rs:282-288."""
+    name, buf = None, []
+    with open(path, "rb") as fh:
+        for line in fh:
+            line = line.rstrip(b"\r\n")
+            if line.startswith(b">"):
+                if name is not None:
+                    yield name, np.frombuffer(b"".join(buf), dtype=np.uint8)
+                hdr = line[1:].split()
+                name = hdr[0].decode() if hdr else ""
+                buf = []
+            elif name is not None:
+                buf.append(line)
+    if name is not None:
+        yield name, np.frombuffer(b"".join(buf), dtype=np.uint8)

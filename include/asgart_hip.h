@@ -1,0 +1,160 @@
+/*
+ * asgart_hip.h -- C ABI of the MI355X-native segmental-duplication search core.
+ *
+ * Drop-in boundary for ONE path of delehef/asgart 2.5.1: the body of
+ * `SearchDuplications::run` (reference src/bin/asgart.rs:137-258), i.e.
+ *   suffix array  ->  Searcher (8-mer interval cache + k-mer equal range)
+ *   ->  automaton::search_duplications over every chunk  ->  left fix-up.
+ * Everything is plain pointers + sizes in the style of the reference's own FFI
+ * to libdivsufsort (reference src/divsufsort.rs:8-33): extern "C", caller-owned
+ * inputs, caller-allocated outputs (two-call count/copy), int32 status
+ * (0 ok, <0 error), no callbacks, no torch types.
+ *
+ * All compute runs in hand-written HIP kernels for gfx950; there is NO CPU
+ * fallback: every entry point that needs the GPU fails with ASGART_E_HIP when
+ * no device is usable.
+ *
+ * The reference-side binding (Rust `extern "C"` block + build.rs line) is shown
+ * in INTEGRATION.md.
+ */
+#ifndef ASGART_HIP_H
+#define ASGART_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ASGART_OK 0
+#define ASGART_E_ARG (-1)  /* bad argument / unsupported setting            */
+#define ASGART_E_OOM (-2)  /* host or device allocation failed              */
+#define ASGART_E_HIP (-3)  /* HIP runtime error, or no usable gfx950 device */
+#define ASGART_E_CAP (-4)  /* an internal capacity was exceeded (see msg)   */
+
+/* RunSettings as it reaches the path (reference src/structs.rs:36-58; Copy).
+ * max_gap_size already includes +probe_size (reference src/bin/asgart.rs:681). */
+typedef struct asgart_settings {
+    uint64_t probe_size;              /* -k ; 8 <= k <= 21 in this build          */
+    uint32_t max_gap_size;            /* -g + -k                                 */
+    uint64_t min_duplication_length;  /* --min-length                            */
+    uint64_t max_cardinality;         /* --max-cardinality                       */
+    uint8_t reverse;                  /* -R                                      */
+    uint8_t complement;               /* -C                                      */
+} asgart_settings;
+
+/* ProtoSD (reference src/structs.rs:418-429).  `left` is already global (the
+ * fix-up of src/bin/asgart.rs:229-237 is applied inside); identity is 0.0 and
+ * reversed/complemented equal the settings of the call (:245-247). */
+typedef struct asgart_proto_sd {
+    uint64_t left, right, left_length, right_length;
+} asgart_proto_sd;
+
+/* Device-side timings (HIP events on the library's own stream) and work
+ * counters of the LAST asgart_search_duplications / asgart_probe_hits call. */
+typedef struct asgart_stats {
+    double ms_total;        /* first kernel -> results on host                   */
+    double ms_search;       /* probe-search + count kernels (dominant, HBM-bound) */
+    double ms_scan;         /* prefix scans + segment detection                   */
+    double ms_fill;         /* hit materialisation (CSR fill)                     */
+    double ms_extend;       /* seed-extension automaton kernel                    */
+    uint64_t probes_total;
+    uint64_t probes_n_skipped;
+    uint64_t probes_searched;
+    uint64_t probes_card_skipped;
+    uint64_t probes_with_hits;
+    uint64_t raw_hits;      /* sum of SA-interval sizes h_p                       */
+    uint64_t filtered_hits; /* CSR size                                            */
+    uint64_t segments;      /* independent automaton instances                     */
+    uint64_t families;
+    uint64_t proto_sds;
+    uint64_t bisect_steps;  /* sum ceil(log2(b_p+1)), b_p = 8-mer bucket (yardstick;
+                               filled only when ASGART_STATS_YARDSTICK was requested) */
+    uint64_t search_launches; /* number of launches of the dominant kernel          */
+} asgart_stats;
+
+typedef struct asgart_index asgart_index;
+typedef struct asgart_families asgart_families;
+
+/* Replaces `divsufsort64` (reference src/divsufsort.rs:10, call site
+ * src/bin/asgart.rs:473-479): signature-identical.  Builds the suffix array of
+ * T[0..n) on the GPU (prefix doubling) into the caller-allocated SA. */
+int32_t asgart_sa_build64(const uint8_t *T, int64_t *SA, int64_t n);
+
+/* Replaces `Searcher::new(dna, sa, 0)` plus the Arc-sharing of text and SA
+ * (reference src/bin/asgart.rs:142-155, src/searcher.rs:99-143): uploads text
+ * and suffix array to HBM of `device` and builds the search structures.
+ * T must consist of bytes in {A,C,G,T,N} with at most one '$', as its last
+ * byte (what prepare_data produces, src/bin/asgart.rs:289-301,430).
+ * SA may be NULL: the library then builds it on the GPU itself. */
+int32_t asgart_index_create(const uint8_t *T, int64_t n, const int64_t *SA, int64_t sa_len,
+                            int32_t device, asgart_index **out);
+void asgart_index_destroy(asgart_index *idx);
+
+/* Optional: build the probe_size-specific search keys now (otherwise done
+ * lazily by the first call that needs them; kept until another k is used). */
+int32_t asgart_index_prepare(asgart_index *idx, uint64_t probe_size);
+
+/* Replaces the body of SearchDuplications::run from the chunk fan-out to the
+ * fold (reference src/bin/asgart.rs:201-253): for every chunk (start,len) runs
+ * automaton::search_duplications (src/automaton.rs:57-204) on the prepared
+ * needle and returns the families in (chunk, discovery) order.
+ * chunks: n_chunks pairs (start, len).  progress: nullable, n_chunks entries,
+ * best-effort (reference src/automaton.rs:98). */
+int32_t asgart_search_duplications(asgart_index *idx, const uint64_t *chunks, int64_t n_chunks,
+                                   const asgart_settings *settings, volatile uint64_t *progress,
+                                   asgart_families **out);
+
+/* Same, restricted to shard `shard` of `n_shards` of the global probe
+ * sequence (multi-GPU: one process per GPU, index replicated, no exchange
+ * between shards).  Concatenating the results of shards 0..n_shards-1 in
+ * shard order gives exactly the unsharded result. */
+int32_t asgart_search_duplications_shard(asgart_index *idx, const uint64_t *chunks,
+                                         int64_t n_chunks, const asgart_settings *settings,
+                                         int32_t shard, int32_t n_shards,
+                                         asgart_families **out);
+
+void asgart_families_counts(const asgart_families *f, uint64_t *n_families, uint64_t *n_sds);
+/* fam_offsets: n_families+1 entries; sds: n_sds entries */
+void asgart_families_copy(const asgart_families *f, uint64_t *fam_offsets, asgart_proto_sd *sds);
+void asgart_families_free(asgart_families *f);
+
+/* ---- finer-grained entry points mirroring the reference's inner API;
+ *      used by the parity tests ------------------------------------------ */
+
+/* Searcher cache entries (reference src/searcher.rs:99-143): for each of the
+ * n_pat 8-byte patterns the SA slot interval [lo,hi) of suffixes starting
+ * with it.  Patterns must be over {A,T,G,C,N}. */
+int32_t asgart_searcher_cache_get(asgart_index *idx, const uint8_t *patterns8, int64_t n_pat,
+                                  uint64_t *lo, uint64_t *hi);
+/* Searcher::search (reference src/searcher.rs:145-180) for n_pat patterns of
+ * k bytes each: SA slot interval [lo,hi) whose entries are the hits, in SA
+ * order.  Read the hit positions with asgart_sa_read. */
+int32_t asgart_searcher_search(asgart_index *idx, const uint8_t *patterns, int64_t n_pat,
+                               uint64_t k, uint64_t *lo, uint64_t *hi);
+int32_t asgart_sa_read(asgart_index *idx, uint64_t lo, uint64_t hi, int64_t *out);
+
+/* Per-probe filtered hit lists exactly as the automaton consumes them
+ * (reference src/automaton.rs:96-117), for all chunks concatenated: probe j of
+ * a chunk sits at needle offset (j+1)*(k/2).  status: 0 processed, 1 skipped
+ * ('N' first base), 2 skipped (cardinality).  Two-call: with status==NULL
+ * returns the probe count and *n_hits; then fills status[n_probes],
+ * row_offsets[n_probes+1], hits[n_hits] (hit starts, SA order). <0 on error. */
+int64_t asgart_probe_hits(asgart_index *idx, const uint64_t *chunks, int64_t n_chunks,
+                          const asgart_settings *settings, uint8_t *status,
+                          uint64_t *row_offsets, uint64_t *hits, uint64_t *n_hits);
+
+#define ASGART_STATS_YARDSTICK 1u
+/* Stats of the last search call on this index.  With ASGART_STATS_YARDSTICK in
+ * `flags` an extra (untimed) kernel also fills bisect_steps. */
+int32_t asgart_get_stats(asgart_index *idx, uint32_t flags, asgart_stats *out);
+
+/* Thread-local message of the last error returned on this thread. */
+const char *asgart_last_error(void);
+/* "asgart-hip <version> gfx950" */
+const char *asgart_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
