@@ -284,7 +284,7 @@ void asgart_index_destroy(asgart_index *idx) {
     if (idx->d_sa) (void)hipFree(idx->d_sa);
     Workspace &w = idx->ws;
     DevBuf *bufs[] = {&w.chunks, &w.p_lo, &w.p_raw, &w.p_filt, &w.row_off, &w.blk, &w.hits,
-                      &w.big_list, &w.seg_list, &w.counters, &w.fam_hdr, &w.fam_sds,
+                      &w.big_list, &w.seg_list, &w.counters, &w.fam_sds,
                       &w.ovf_list, &w.pat, &w.out_a, &w.out_b};
     for (DevBuf *b : bufs) b->release();
     for (auto &e : idx->ev)

@@ -34,6 +34,24 @@ struct IndexView {
     uint64_t tail_bloom;
 };
 
+struct ChunkTable {
+    const uint64_t *start;
+    const uint64_t *len;
+    const uint32_t *pbase;  // n_chunks + 1
+    int n_chunks;
+};
+
+struct RunParams {
+    ChunkTable ch;
+    uint32_t g_lo, g_hi;  // probe range of this call
+    int k, step;
+    uint32_t G;           // max_gap_size
+    uint32_t tstar;       // ceil(G / step)
+    uint64_t M;           // min_duplication_length
+    uint32_t C;           // max_cardinality (clamped)
+    uint8_t reverse, complement;
+};
+
 struct Workspace {
     DevBuf chunks;     // ch_start[nc], ch_len[nc] (u64) then pbase[nc+1] (u32)
     DevBuf p_lo;       // SlotT[P]
@@ -45,8 +63,7 @@ struct Workspace {
     DevBuf big_list;   // u32[P] probes with large SA intervals
     DevBuf seg_list;   // u32[...] segment start probes
     DevBuf counters;   // u64[32] device counters
-    DevBuf fam_hdr;    // FamHdr[cap]
-    DevBuf fam_sds;    // asgart_proto_sd[cap]
+    DevBuf fam_sds;    // SdRec[cap] output records of the extension kernel
     DevBuf ovf_list;   // u32 segments that overflowed the small arm tier
     DevBuf pat;        // pattern upload scratch
     DevBuf out_a, out_b;
@@ -77,6 +94,8 @@ struct asgart_index {
     asgart_stats stats;
     // inputs of the last call kept for the yardstick kernel
     uint32_t last_P = 0;
+    asgart::RunParams last_rp;
+    bool has_last = false;
     hipEvent_t ev[8] = {};
 
     template <class SlotT>

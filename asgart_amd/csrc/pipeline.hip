@@ -11,9 +11,9 @@
 
 namespace asgart {
 
-constexpr int kArmCapSmall = 512;   // arms per wave in LDS, common case
-constexpr int kArmCapBig32 = 5376;  // whole-CU LDS tier (32-bit positions): 5376*28 B = 147 KiB
-constexpr int kArmCapBig64 = 3456;  // 64-bit positions: 3456*44 B = 148.5 KiB
+constexpr int kArmCapSmall = 256;   // live arms per wave in LDS, common case
+constexpr int kArmCapBig32 = 4608;  // whole-CU LDS tier (32-bit positions): 4608*32 B + hits = 148 KiB
+constexpr int kArmCapBig64 = 3072;  // 64-bit positions: 3072*48 B + hits = 152 KiB
 
 static inline unsigned grid_for(uint64_t n, unsigned block = 256) {
     return (unsigned)((n + block - 1) / block);
@@ -100,6 +100,8 @@ static int32_t run_search_t(asgart_index *idx, const uint64_t *chunks, int64_t n
     rp.C = st->max_cardinality > 0xFFFFFF00ull ? 0xFFFFFF00u : (uint32_t)st->max_cardinality;
     rp.reverse = st->reverse ? 1 : 0;
     rp.complement = st->complement ? 1 : 0;
+    idx->last_rp = rp;
+    idx->has_last = false;
 
     // ---- workspace -----------------------------------------------------------
     const uint32_t n_blk = (P + kScanTile - 1) / kScanTile;
@@ -174,15 +176,12 @@ static int32_t run_search_t(asgart_index *idx, const uint64_t *chunks, int64_t n
     }
 
     // ---- K4: extension automaton ------------------------------------------------
-    std::vector<FamHdr> h_hdr;
-    std::vector<asgart_proto_sd> h_sds;
     if (fam_out && n_seg) {
-        uint64_t fam_cap = std::max<uint64_t>(1u << 16, w.fam_hdr.cap / sizeof(FamHdr));
-        uint64_t sd_cap = std::max<uint64_t>(1u << 18, w.fam_sds.cap / sizeof(asgart_proto_sd));
+        uint64_t rec_cap = std::max<uint64_t>(1u << 18, w.fam_sds.cap / sizeof(SdRec));
         RC_TRY(w.ovf_list.reserve((size_t)(n_seg + 1) * 4));
+        std::vector<SdRec> h_recs;
         for (int attempt = 0;; ++attempt) {
-            RC_TRY(w.fam_hdr.reserve((size_t)fam_cap * sizeof(FamHdr)));
-            RC_TRY(w.fam_sds.reserve((size_t)sd_cap * sizeof(asgart_proto_sd)));
+            RC_TRY(w.fam_sds.reserve((size_t)rec_cap * sizeof(SdRec)));
             HIP_TRY(hipMemsetAsync(d_ctr + CT_SEG_CURSOR, 0, 4 * 8, s));  // cursor, fam, sd, ovf
             ExtParams<SlotT> ep;
             ep.rp = rp;
@@ -192,23 +191,21 @@ static int32_t run_search_t(asgart_index *idx, const uint64_t *chunks, int64_t n
             ep.seg_list = seg_list;
             ep.n_seg_ptr = d_ctr + CT_SEG;
             ep.cursor = d_ctr + CT_SEG_CURSOR;
-            ep.fam_hdr = w.fam_hdr.as<FamHdr>();
-            ep.fam_sds = w.fam_sds.as<asgart_proto_sd>();
-            ep.fam_cap = fam_cap;
-            ep.sd_cap = sd_cap;
+            ep.recs = w.fam_sds.as<SdRec>();
+            ep.rec_cap = rec_cap;
             ep.ovf_list = w.ovf_list.as<uint32_t>();
             ep.ctr = d_ctr;
-            const unsigned waves = (unsigned)std::min<uint64_t>(n_seg, 256ull * 10ull);
+            const unsigned waves = (unsigned)std::min<uint64_t>(n_seg, 256ull * 12ull);
             extend_kernel<SlotT, kArmCapSmall><<<waves, 64, 0, s>>>(ep);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, sizeof(h_ctr), hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
             if (h_ctr[CT_OVF]) {
-                // second tier: one wave per CU with (almost) the whole LDS for arms
+                // second tier: one wave per CU with (almost) the whole LDS for live arms
                 const uint64_t n_ovf = h_ctr[CT_OVF];
                 HIP_TRY(hipMemsetAsync(d_ctr + CT_OVF, 0, 8, s));
                 HIP_TRY(hipMemsetAsync(d_ctr + CT_OVF_CURSOR, 0, 8, s));
-                // n_seg_ptr must point at a device word holding n_ovf: reuse CT_BISECT slot
+                // n_seg_ptr must point at a device word holding n_ovf: reuse the CT_BISECT slot
                 HIP_TRY(hipMemcpyAsync(d_ctr + CT_BISECT, &n_ovf, 8, hipMemcpyHostToDevice, s));
                 ep.seg_list = w.ovf_list.as<uint32_t>();
                 ep.n_seg_ptr = d_ctr + CT_BISECT;
@@ -223,45 +220,49 @@ static int32_t run_search_t(asgart_index *idx, const uint64_t *chunks, int64_t n
                 HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, sizeof(h_ctr), hipMemcpyDeviceToHost, s));
                 HIP_TRY(hipStreamSynchronize(s));
                 if (h_ctr[CT_OVF]) {
-                    set_error("%llu segment(s) need more than %d simultaneous arms; "
+                    set_error("%llu segment(s) need more than %d simultaneously live arms; "
                               "not supported by this build",
                               (unsigned long long)h_ctr[CT_OVF],
                               sizeof(SlotT) == 4 ? kArmCapBig32 : kArmCapBig64);
                     return ASGART_E_CAP;
                 }
             }
-            if (h_ctr[CT_FAM] <= fam_cap && h_ctr[CT_SD] <= sd_cap) break;
+            if (h_ctr[CT_SD] <= rec_cap) break;
             if (attempt >= 3) {
-                set_error("internal: family buffers keep overflowing");
+                set_error("internal: record buffer keeps overflowing");
                 return ASGART_E_CAP;
             }
-            fam_cap = std::max<uint64_t>(fam_cap, h_ctr[CT_FAM] * 2);
-            sd_cap = std::max<uint64_t>(sd_cap, h_ctr[CT_SD] * 2);
+            rec_cap = h_ctr[CT_SD] * 2;
         }
         HIP_TRY(hipEventRecord(idx->ev[4], s));
-        const uint64_t n_fam = h_ctr[CT_FAM], n_sd = h_ctr[CT_SD];
-        h_hdr.resize((size_t)n_fam);
-        h_sds.resize((size_t)n_sd);
-        if (n_fam) {
-            HIP_TRY(hipMemcpyAsync(h_hdr.data(), w.fam_hdr.p, (size_t)n_fam * sizeof(FamHdr),
+        const uint64_t n_rec = h_ctr[CT_SD];
+        h_recs.resize((size_t)n_rec);
+        if (n_rec)
+            HIP_TRY(hipMemcpyAsync(h_recs.data(), w.fam_sds.p, (size_t)n_rec * sizeof(SdRec),
                                    hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipMemcpyAsync(h_sds.data(), w.fam_sds.p,
-                                   (size_t)n_sd * sizeof(asgart_proto_sd), hipMemcpyDeviceToHost, s));
-        }
         HIP_TRY(hipStreamSynchronize(s));
-        // reference order: chunk order, then discovery order inside the chunk
-        // == (segment start probe, flush ordinal).  Segments re-run in the second
-        // tier emit their first families twice: keep one copy.
-        std::sort(h_hdr.begin(), h_hdr.end(), [](const FamHdr &a, const FamHdr &b) {
-            return a.g_start != b.g_start ? a.g_start < b.g_start : a.seq < b.seq;
+        // Reference order: chunk order, discovery order inside the chunk, arm order
+        // inside the family == (segment start probe, family ordinal, creation number).
+        // A tombstone voids its family; segments re-run in the second tier emit some
+        // records twice (same key): keep one copy.
+        std::sort(h_recs.begin(), h_recs.end(), [](const SdRec &a, const SdRec &b) {
+            if (a.g_start != b.g_start) return a.g_start < b.g_start;
+            if (a.fam_seq != b.fam_seq) return a.fam_seq < b.fam_seq;
+            return a.create_seq < b.create_seq;
         });
-        for (size_t f = 0; f < h_hdr.size(); ++f) {
-            if (f && h_hdr[f].g_start == h_hdr[f - 1].g_start && h_hdr[f].seq == h_hdr[f - 1].seq)
-                continue;
-            const FamHdr &h = h_hdr[f];
-            fam_out->sds.insert(fam_out->sds.end(), h_sds.begin() + (size_t)h.sd_base,
-                                h_sds.begin() + (size_t)(h.sd_base + h.count));
-            fam_out->fam_offsets.push_back(fam_out->sds.size());
+        for (size_t f0 = 0; f0 < h_recs.size();) {
+            size_t f1 = f0;
+            while (f1 < h_recs.size() && h_recs[f1].g_start == h_recs[f0].g_start &&
+                   h_recs[f1].fam_seq == h_recs[f0].fam_seq)
+                ++f1;
+            if (h_recs[f1 - 1].create_seq != kTombstone) {
+                for (size_t j = f0; j < f1; ++j) {
+                    if (j > f0 && h_recs[j].create_seq == h_recs[j - 1].create_seq) continue;
+                    fam_out->sds.push_back(h_recs[j].sd);
+                }
+                fam_out->fam_offsets.push_back(fam_out->sds.size());
+            }
+            f0 = f1;
         }
     } else {
         HIP_TRY(hipEventRecord(idx->ev[4], s));
@@ -291,6 +292,7 @@ static int32_t run_search_t(asgart_index *idx, const uint64_t *chunks, int64_t n
     stt.families = fam_out ? fam_out->fam_offsets.size() - 1 : 0;
     stt.proto_sds = fam_out ? fam_out->sds.size() : 0;
     stt.search_launches = 1;
+    idx->has_last = true;
     return 0;
 }
 
@@ -403,8 +405,26 @@ int32_t asgart_get_stats(asgart_index *idx, uint32_t flags, asgart_stats *out) {
         set_error("bad argument");
         return ASGART_E_ARG;
     }
+    if ((flags & ASGART_STATS_YARDSTICK) && idx->has_last && idx->last_P) {
+        HIP_TRY(hipSetDevice(idx->device));
+        unsigned long long *d_ctr = idx->ws.counters.as<unsigned long long>();
+        hipStream_t s = idx->stream;
+        HIP_TRY(hipMemsetAsync(d_ctr + CT_BISECT, 0, 8, s));
+        const RunParams &rp = idx->last_rp;
+        const unsigned g = grid_for(rp.g_hi - rp.g_lo);
+        if (idx->wide)
+            yardstick_kernel<uint64_t><<<g, 256, 0, s>>>(idx->view<uint64_t>(), rp,
+                                                         idx->ws.p_filt.as<uint32_t>(), d_ctr);
+        else
+            yardstick_kernel<uint32_t><<<g, 256, 0, s>>>(idx->view<uint32_t>(), rp,
+                                                         idx->ws.p_filt.as<uint32_t>(), d_ctr);
+        HIP_TRY(hipGetLastError());
+        unsigned long long v = 0;
+        HIP_TRY(hipMemcpyAsync(&v, d_ctr + CT_BISECT, 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        idx->stats.bisect_steps = v;
+    }
     *out = idx->stats;
-    (void)flags;
     return 0;
 }
 

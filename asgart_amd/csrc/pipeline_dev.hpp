@@ -39,24 +39,6 @@ enum Counter {
     CT_COUNT = 32
 };
 
-struct ChunkTable {
-    const uint64_t *start;
-    const uint64_t *len;
-    const uint32_t *pbase;  // n_chunks + 1
-    int n_chunks;
-};
-
-struct RunParams {
-    ChunkTable ch;
-    uint32_t g_lo, g_hi;  // probe range of this call
-    int k, step;
-    uint32_t G;           // max_gap_size
-    uint32_t tstar;       // ceil(G / step)
-    uint64_t M;           // min_duplication_length
-    uint32_t C;           // max_cardinality (clamped)
-    uint8_t reverse, complement;
-};
-
 __device__ inline int chunk_of(const ChunkTable &ch, uint32_t g) {
     // last c with pbase[c] <= g  (pbase non-decreasing; empty chunks repeat values)
     int lo = 0, hi = ch.n_chunks;  // answer in [lo, hi)
@@ -403,13 +385,34 @@ __global__ __launch_bounds__(256) void fill_big_kernel(IndexView<SlotT> ix, RunP
 }
 
 // ---------------------------------------------------------------- K4 ---------
-struct FamHdr {
-    uint32_t g_start;  // first probe of the segment (global probe index): sort key 1
-    uint32_t seq;      // flush ordinal inside the segment: sort key 2
-    unsigned long long sd_base;
-    uint32_t count;
+// Seed-extension automaton, one wavefront per independent segment.
+//
+// Representation (equivalent to, not a transcription of, src/automaton.rs:87-200):
+//   * only LIVE (active) arms are kept.  An arm that turns inactive can never
+//     be extended again (try_extend_arms tests `a.active`, :68) and is only
+//     looked at once more, when its family is flushed (:182-200), so it is
+//     retired at once: written to the output list if len(right) >= M, dropped
+//     otherwise.  (The reference's `retain` at :173-179 removes a subset of the
+//     same arms; both removals are unobservable.)
+//   * the family is flushed when the live list becomes empty; its members are
+//     the retired arms, ordered by creation number (== position in the
+//     reference's `arms` vector).  The host sorts records by
+//     (segment start, family ordinal, creation number).
+//   * arms still live at the end of the chunk are dropped AND their family's
+//     retired members are void (:201-203): a tombstone record says so.
+//   * <= 64 live arms: one arm per lane, in registers; otherwise LDS arrays.
+//   * the hit rows of up to 64 consecutive probes are contiguous in the CSR and
+//     are staged through LDS with one coalesced load.
+struct SdRec {
+    uint32_t g_start;     // first probe of the segment: sort key 1
+    uint32_t fam_seq;     // family ordinal inside the segment: sort key 2
+    uint32_t create_seq;  // creation number inside the family: sort key 3; ~0u = tombstone
     uint32_t pad;
+    asgart_proto_sd sd;
 };
+
+constexpr uint32_t kTombstone = 0xFFFFFFFFu;
+constexpr int kHitBatch = 1024;  // LDS staging for the hit rows of one probe batch
 
 template <class PosT>
 struct ExtParams {
@@ -420,10 +423,9 @@ struct ExtParams {
     const uint32_t *seg_list;
     const unsigned long long *n_seg_ptr;  // device count of seg_list entries
     unsigned long long *cursor;           // work-fetch cursor
-    FamHdr *fam_hdr;
-    asgart_proto_sd *fam_sds;
-    unsigned long long fam_cap, sd_cap;
-    uint32_t *ovf_list;                   // segments whose arms overflowed CAP (may be null)
+    SdRec *recs;
+    unsigned long long rec_cap;
+    uint32_t *ovf_list;                   // segments whose live arms overflowed CAP (may be null)
     unsigned long long *ctr;
 };
 
@@ -444,19 +446,17 @@ __device__ inline uint32_t arm_threshold(uint64_t left_len, uint32_t G) {
     return thr > 0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)thr;
 }
 
-constexpr uint32_t kActiveBit = 0x80000000u;
-
 template <class PosT, int CAP>
 __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
     __shared__ PosT s_ls[CAP], s_le[CAP], s_rs[CAP], s_re[CAP];
-    __shared__ uint32_t s_gap[CAP];   // bit31 = active, low bits = gap
-    __shared__ uint32_t s_thr[CAP];
-    __shared__ uint32_t s_pend[CAP];  // 0 = not extended by this probe, else hit index + 1
+    __shared__ uint32_t s_gap[CAP], s_thr[CAP], s_seq[CAP], s_pend[CAP];
+    __shared__ PosT s_hits[kHitBatch];
     const int lane = threadIdx.x;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const RunParams &rp = P.rp;
     const uint64_t n_seg = *P.n_seg_ptr;
-    const uint32_t k = (uint32_t)rp.k, step = (uint32_t)rp.step;
+    const uint32_t k = (uint32_t)rp.k, step = (uint32_t)rp.step, G = rp.G;
+    const uint32_t thr0 = arm_threshold(k, G);
 
     for (;;) {
         unsigned long long seg = 0;
@@ -468,221 +468,292 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
         const uint64_t cs = rp.ch.start[c], cl = rp.ch.len[c];
         const uint32_t pb = rp.ch.pbase[c];
         const uint32_t g_end = rp.ch.pbase[c + 1];
-        uint32_t A = 0, quiet = 0, fam_seq = 0;
-        bool overflow = false, done = false;
 
-        for (uint32_t gb = g0; gb < g_end && !done; gb += 64) {
-            const uint32_t fl = (gb + lane < g_end) ? P.p_filt[gb + lane] : kSkipN;
-            const unsigned long long rl = (gb + lane < g_end) ? P.row_off[gb + lane] : 0ull;
-            const int nb = (int)min(64u, g_end - gb);
-            for (int b = 0; b < nb; ++b) {
-                const uint32_t f = __shfl(fl, b);
-                if (f >= kPending) continue;  // skipped probe: no ageing, no flush
-                bool any_active = false;
-                if (f == 0) {
-                    // processed probe without hits: age every arm (automaton.rs:166-171)
-                    if (A == 0) {
-                        if (++quiet >= rp.tstar) {
-                            done = true;
-                            break;
-                        }
-                        continue;
-                    }
-                    ++quiet;
-                    for (uint32_t j = lane; j < A; j += 64) {
-                        uint32_t gp = s_gap[j];
-                        if (gp & kActiveBit) {
-                            uint32_t gap = (gp & ~kActiveBit) + step;
-                            gp = gap >= rp.G ? gap : (gap | kActiveBit);
-                            s_gap[j] = gp;
-                        }
-                        any_active |= (gp & kActiveBit) != 0;
-                    }
-                    any_active = __ballot(any_active) != 0ull;
-                    __syncthreads();
+        // live arms: lane j holds arm j while in_regs (A <= 64), else s_*[0..A)
+        PosT r_ls = 0, r_le = 0, r_rs = 0, r_re = 0;
+        uint32_t r_gap = 0, r_thr = 0, r_seq = 0;
+        uint32_t A = 0, quiet = 0, fam_seq = 0, next_seq = 0;
+        bool in_regs = true, overflow = false, done = false;
+
+        // ---- helpers -------------------------------------------------------
+        auto emit_records = [&](bool emit, PosT ls, PosT le, PosT rs, PosT re, uint32_t seq) {
+            const unsigned long long em = __ballot(emit);
+            if (!em) return;
+            const int leader = __ffsll((long long)em) - 1;
+            unsigned long long base = 0;
+            if (lane == leader) base = atomicAdd(&P.ctr[CT_SD], (unsigned long long)__popcll(em));
+            base = __shfl(base, leader);
+            if (emit) {
+                const unsigned long long at = base + __popcll(em & lt_mask);
+                if (at < P.rec_cap) {
+                    const uint64_t ll = (uint64_t)le - (uint64_t)ls;
+                    SdRec r;
+                    r.g_start = g0;
+                    r.fam_seq = fam_seq;
+                    r.create_seq = seq;
+                    r.pad = 0;
+                    // left fix-up, src/bin/asgart.rs:229-237
+                    r.sd.left = rp.reverse ? cs + cl - (uint64_t)ls - ll : (uint64_t)ls + cs;
+                    r.sd.right = rs;
+                    r.sd.left_length = ll;
+                    r.sd.right_length = (uint64_t)re - (uint64_t)rs;
+                    P.recs[at] = r;
+                }
+            }
+        };
+        auto family_closed = [&]() {  // live list just became empty: the flush of :182-200
+            ++fam_seq;
+            next_seq = 0;
+        };
+        // retire arms whose gap reached G (src/automaton.rs:166-171 + flush bookkeeping)
+        auto retire_regs = [&]() {
+            const bool dead = (uint32_t)lane < A && r_gap >= G;
+            if (!__ballot(dead)) return;
+            emit_records(dead && (uint64_t)(r_re - r_rs) >= rp.M, r_ls, r_le, r_rs, r_re, r_seq);
+            const bool alive = (uint32_t)lane < A && !dead;
+            const unsigned long long am = __ballot(alive);
+            if (alive) {
+                const int d = __popcll(am & lt_mask);
+                s_ls[d] = r_ls; s_le[d] = r_le; s_rs[d] = r_rs; s_re[d] = r_re;
+                s_gap[d] = r_gap; s_thr[d] = r_thr; s_seq[d] = r_seq;
+            }
+            __syncthreads();
+            A = (uint32_t)__popcll(am);
+            if ((uint32_t)lane < A) {
+                r_ls = s_ls[lane]; r_le = s_le[lane]; r_rs = s_rs[lane]; r_re = s_re[lane];
+                r_gap = s_gap[lane]; r_thr = s_thr[lane]; r_seq = s_seq[lane];
+            }
+            __syncthreads();
+            if (A == 0) family_closed();
+        };
+        auto retire_lds = [&]() {
+            uint32_t w = 0;
+            bool any_dead = false;
+            for (uint32_t t0 = 0; t0 < A; t0 += 64) {
+                const uint32_t j = t0 + lane;
+                PosT ls = 0, le = 0, rs = 0, re = 0;
+                uint32_t gp = 0, th = 0, sq = 0;
+                bool valid = j < A;
+                if (valid) {
+                    ls = s_ls[j]; le = s_le[j]; rs = s_rs[j]; re = s_re[j];
+                    gp = s_gap[j]; th = s_thr[j]; sq = s_seq[j];
+                }
+                const bool dead = valid && gp >= G;
+                any_dead |= __ballot(dead) != 0ull;
+                emit_records(dead && (uint64_t)(re - rs) >= rp.M, ls, le, rs, re, sq);
+                const bool alive = valid && !dead;
+                const unsigned long long am = __ballot(alive);
+                __syncthreads();
+                if (alive && any_dead) {
+                    const uint32_t d = w + __popcll(am & lt_mask);
+                    s_ls[d] = ls; s_le[d] = le; s_rs[d] = rs; s_re[d] = re;
+                    s_gap[d] = gp; s_thr[d] = th; s_seq[d] = sq; s_pend[d] = 0;
+                }
+                w += __popcll(am);
+                __syncthreads();
+            }
+            const bool was_nonempty = A > 0;
+            A = w;
+            if (A == 0 && was_nonempty) family_closed();
+        };
+        auto to_lds = [&]() {
+            if ((uint32_t)lane < A) {
+                s_ls[lane] = r_ls; s_le[lane] = r_le; s_rs[lane] = r_rs; s_re[lane] = r_re;
+                s_gap[lane] = r_gap; s_thr[lane] = r_thr; s_seq[lane] = r_seq; s_pend[lane] = 0;
+            }
+            __syncthreads();
+            in_regs = false;
+        };
+        auto to_regs = [&]() {
+            if ((uint32_t)lane < A) {
+                r_ls = s_ls[lane]; r_le = s_le[lane]; r_rs = s_rs[lane]; r_re = s_re[lane];
+                r_gap = s_gap[lane]; r_thr = s_thr[lane]; r_seq = s_seq[lane];
+            }
+            __syncthreads();
+            in_regs = true;
+        };
+        // q consecutive processed probes without hits
+        auto advance_quiet = [&](uint32_t q) {
+            quiet += q;
+            if (A > 0) {
+                const uint32_t add = q * step;
+                if (in_regs) {
+                    if ((uint32_t)lane < A) r_gap = r_gap + add < r_gap ? 0xFFFFFFFFu : r_gap + add;
+                    retire_regs();
                 } else {
-                    quiet = 0;
-                    const uint64_t i = (uint64_t)(gb + b - pb + 1) * step;
-                    const unsigned long long row = __shfl(rl, b);
-                    const uint32_t cnt = f;
-                    // make room: drop arms the reference would prune anyway (they are
-                    // inactive and too short to be reported, so dropping them early is
-                    // unobservable)
+                    for (uint32_t j = lane; j < A; j += 64) {
+                        const uint32_t gp = s_gap[j];
+                        s_gap[j] = gp + add < gp ? 0xFFFFFFFFu : gp + add;
+                    }
+                    __syncthreads();
+                    retire_lds();
+                    if (A <= 32) to_regs();
+                }
+            }
+            if (A == 0 && quiet >= rp.tstar) done = true;
+        };
+
+        for (uint32_t g = g0; g < g_end && !done;) {
+            // ---- stage a batch of up to 64 probes ------------------------------
+            const uint32_t nb = min(64u, g_end - g);
+            const uint32_t f_l = (uint32_t)lane < nb ? P.p_filt[g + lane] : kSkipN;
+            const unsigned long long r_l = (uint32_t)lane < nb ? P.row_off[g + lane] : 0ull;
+            const unsigned long long r_hi = P.row_off[g + nb];
+            const unsigned long long base = __shfl(r_l, 0);
+            unsigned long long r_next = __shfl_down(r_l, 1);
+            if ((uint32_t)lane + 1 >= nb) r_next = r_hi;
+            const bool fits = (uint32_t)lane < nb && r_next - base <= (unsigned long long)kHitBatch;
+            const unsigned long long fm = __ballot(fits);
+            uint32_t nbb = (~fm == 0ull) ? 64u : (uint32_t)(__ffsll((long long)~fm) - 1);
+            if (nbb > nb) nbb = nb;
+            bool first_from_global = false;
+            if (nbb == 0) {  // a single row larger than the staging buffer
+                nbb = 1;
+                first_from_global = true;
+            }
+            const uint32_t rel_l = (uint32_t)(r_l - base);
+            if (!first_from_global) {
+                const unsigned long long end = nbb == nb ? r_hi : __shfl(r_l, (int)nbb);
+                const uint32_t tot = (uint32_t)(end - base);
+                for (uint32_t r = lane; r < tot; r += 64) s_hits[r] = P.hits[base + r];
+            }
+            __syncthreads();
+            const unsigned long long in_batch = nbb >= 64 ? ~0ull : ((1ull << nbb) - 1ull);
+            const unsigned long long hm = __ballot(f_l >= 1u && f_l < kPending) & in_batch;
+            const unsigned long long qm = __ballot(f_l == 0u) & in_batch;
+            uint32_t pos = 0;
+            while (!done) {
+                const unsigned long long hmr = pos >= 64 ? 0ull : (hm >> pos) << pos;
+                if (!hmr) break;
+                const uint32_t b = (uint32_t)(__ffsll((long long)hmr) - 1);
+                {
+                    const unsigned long long range = ((1ull << b) - 1ull) & ~((1ull << pos) - 1ull);
+                    const uint32_t q = (uint32_t)__popcll(qm & range);
+                    if (q) {
+                        advance_quiet(q);
+                        if (done) break;
+                    }
+                }
+                quiet = 0;
+                pos = b + 1;
+                const uint32_t cnt = __shfl(f_l, (int)b);
+                const uint32_t off = __shfl(rel_l, (int)b);
+                const uint64_t i = (uint64_t)(g + b - pb + 1) * step;
+                const unsigned long long row = base + off;
+                if (in_regs && A + cnt <= 64u && !first_from_global) {
+                    // ---------------- register path -------------------------------
+                    bool pend = false;
+                    PosT pend_x = 0;
+                    uint32_t newc = 0;
+                    for (uint32_t t = 0; t < cnt; ++t) {
+                        const PosT x = s_hits[off + t];
+                        const long long ms = (long long)x, me = (long long)x + k;
+                        const bool ok = (uint32_t)lane < A && me > (long long)r_re &&
+                                        dss_lt((long long)r_rs, (long long)r_re, ms, me,
+                                               (long long)r_thr);
+                        const unsigned long long m = __ballot(ok);
+                        if (m) {  // ExtendArm on the first matching arm; last hit wins
+                            if (lane == __ffsll((long long)m) - 1) {
+                                pend = true;
+                                pend_x = x;
+                            }
+                        } else {  // NewArm
+                            if ((uint32_t)lane == A + newc) {
+                                r_ls = (PosT)i; r_le = (PosT)(i + k); r_rs = x; r_re = (PosT)(x + k);
+                                r_gap = step;  // not dirty: aged by this very probe
+                                r_thr = thr0;
+                                r_seq = next_seq + newc;
+                            }
+                            ++newc;
+                        }
+                    }
+                    if ((uint32_t)lane < A) {
+                        if (pend) {
+                            r_re = (PosT)(pend_x + k);
+                            r_le = (PosT)(i + k);
+                            r_thr = arm_threshold((uint64_t)(i + k) - (uint64_t)r_ls, G);
+                            r_gap = 0;
+                        } else {
+                            r_gap += step;
+                        }
+                    }
+                    A += newc;
+                    next_seq += newc;
+                    retire_regs();
+                } else {
+                    // ---------------- LDS path ------------------------------------
+                    if (in_regs) to_lds();
                     if (A + cnt > (uint32_t)CAP) {
-                        uint32_t w = 0;
-                        for (uint32_t t0 = 0; t0 < A; t0 += 64) {
-                            const uint32_t j = t0 + lane;
-                            bool keep = false;
-                            PosT ls = 0, le = 0, rs = 0, re = 0;
-                            uint32_t gp = 0, th = 0;
-                            if (j < A) {
-                                ls = s_ls[j]; le = s_le[j]; rs = s_rs[j]; re = s_re[j];
-                                gp = s_gap[j]; th = s_thr[j];
-                                keep = (gp & kActiveBit) || (uint64_t)(le - ls) >= rp.M ||
-                                       (uint64_t)(re - rs) >= rp.M;
-                            }
-                            const unsigned long long m = __ballot(keep);
-                            __syncthreads();
-                            if (keep) {
-                                const uint32_t d = w + __popcll(m & lt_mask);
-                                s_ls[d] = ls; s_le[d] = le; s_rs[d] = rs; s_re[d] = re;
-                                s_gap[d] = gp; s_thr[d] = th; s_pend[d] = 0;
-                            }
-                            w += __popcll(m);
-                            __syncthreads();
-                        }
-                        A = w;
-                        if (A + cnt > (uint32_t)CAP) {
-                            overflow = true;
-                            done = true;
-                            break;
-                        }
+                        overflow = true;
+                        done = true;
+                        break;
                     }
                     const uint32_t A_old = A;
-                    // try_extend_arms for every hit against the unchanged arms
+                    const bool from_lds = !first_from_global;
                     for (uint32_t t0 = 0; t0 < cnt; t0 += 64) {
                         const uint32_t t = t0 + lane;
                         const bool valid = t < cnt;
-                        const PosT x = valid ? P.hits[row + t] : (PosT)0;
+                        PosT x = 0;
+                        if (valid) x = from_lds ? s_hits[off + t] : P.hits[row + t];
                         const long long ms = (long long)x, me = (long long)x + k;
                         int found = -1;
                         for (uint32_t j = 0; j < A_old; ++j) {
-                            const uint32_t gp = s_gap[j];
-                            if (gp & kActiveBit) {
-                                const long long re = (long long)s_re[j];
-                                if (valid && found < 0 && me > re &&
-                                    dss_lt((long long)s_rs[j], re, ms, me, (long long)s_thr[j]))
-                                    found = (int)j;
-                            }
+                            const long long re = (long long)s_re[j];
+                            if (valid && found < 0 && me > re &&
+                                dss_lt((long long)s_rs[j], re, ms, me, (long long)s_thr[j]))
+                                found = (int)j;
                             if ((j & 7u) == 7u && __ballot(valid && found < 0) == 0ull) break;
                         }
                         if (valid && found >= 0) atomicMax(&s_pend[found], t + 1u);
                         const bool is_new = valid && found < 0;
                         const unsigned long long m = __ballot(is_new);
-                        if (is_new) {  // NewArm, appended in hit order (automaton.rs:145-163)
+                        if (is_new) {
                             const uint32_t d = A + __popcll(m & lt_mask);
-                            s_ls[d] = (PosT)i;
-                            s_le[d] = (PosT)(i + k);
-                            s_rs[d] = x;
+                            s_ls[d] = (PosT)i; s_le[d] = (PosT)(i + k); s_rs[d] = x;
                             s_re[d] = (PosT)(x + k);
-                            // not dirty => aged by this very probe (automaton.rs:166-171)
-                            s_gap[d] = step >= rp.G ? step : (step | kActiveBit);
-                            s_thr[d] = arm_threshold(k, rp.G);
+                            s_gap[d] = step;
+                            s_thr[d] = thr0;
+                            s_seq[d] = next_seq + (d - A_old);
                             s_pend[d] = 0;
                         }
                         A += __popcll(m);
                     }
+                    next_seq += A - A_old;
                     __syncthreads();
-                    any_active = (A > A_old) && (step < rp.G);
-                    // apply ExtendArm (last hit in SA order wins, automaton.rs:136-143)
-                    // and age the arms that were not extended
-                    bool act = false;
                     for (uint32_t j = lane; j < A_old; j += 64) {
                         const uint32_t pd = s_pend[j];
-                        uint32_t gp = s_gap[j];
                         if (pd) {
                             s_pend[j] = 0;
-                            s_re[j] = (PosT)(P.hits[row + pd - 1u] + k);
+                            const PosT x = from_lds ? s_hits[off + pd - 1u] : P.hits[row + pd - 1u];
+                            s_re[j] = (PosT)(x + k);
                             s_le[j] = (PosT)(i + k);
-                            s_thr[j] = arm_threshold((uint64_t)(i + k) - (uint64_t)s_ls[j], rp.G);
-                            gp = kActiveBit;  // gap = 0, still active
-                            s_gap[j] = gp;
-                        } else if (gp & kActiveBit) {
-                            uint32_t gap = (gp & ~kActiveBit) + step;
-                            gp = gap >= rp.G ? gap : (gap | kActiveBit);
-                            s_gap[j] = gp;
+                            s_thr[j] = arm_threshold((uint64_t)(i + k) - (uint64_t)s_ls[j], G);
+                            s_gap[j] = 0;
+                        } else {
+                            s_gap[j] += step;
                         }
-                        act |= (gp & kActiveBit) != 0;
                     }
-                    any_active |= __ballot(act) != 0ull;
                     __syncthreads();
-                }
-                // prune (automaton.rs:173-179); never removes an active arm
-                if (A > 200u) {
-                    uint32_t w = 0;
-                    for (uint32_t t0 = 0; t0 < A; t0 += 64) {
-                        const uint32_t j = t0 + lane;
-                        bool keep = false;
-                        PosT ls = 0, le = 0, rs = 0, re = 0;
-                        uint32_t gp = 0, th = 0;
-                        if (j < A) {
-                            ls = s_ls[j]; le = s_le[j]; rs = s_rs[j]; re = s_re[j];
-                            gp = s_gap[j]; th = s_thr[j];
-                            keep = (gp & kActiveBit) || (uint64_t)(le - ls) >= rp.M ||
-                                   (uint64_t)(re - rs) >= rp.M;
-                        }
-                        const unsigned long long m = __ballot(keep);
-                        __syncthreads();
-                        if (keep) {
-                            const uint32_t d = w + __popcll(m & lt_mask);
-                            s_ls[d] = ls; s_le[d] = le; s_rs[d] = rs; s_re[d] = re;
-                            s_gap[d] = gp; s_thr[d] = th; s_pend[d] = 0;
-                        }
-                        w += __popcll(m);
-                        __syncthreads();
-                    }
-                    A = w;
-                }
-                // flush the family once every arm is inactive (automaton.rs:182-200)
-                if (A > 0 && !any_active) {
-                    uint32_t total = 0;
-                    for (uint32_t t0 = 0; t0 < A; t0 += 64) {
-                        const uint32_t j = t0 + lane;
-                        const bool emit = j < A && (uint64_t)(s_re[j] - s_rs[j]) >= rp.M;
-                        total += __popcll(__ballot(emit));
-                    }
-                    if (total > 0) {
-                        unsigned long long sd_base = 0, fam_idx = 0;
-                        if (lane == 0) {
-                            sd_base = atomicAdd(&P.ctr[CT_SD], (unsigned long long)total);
-                            fam_idx = atomicAdd(&P.ctr[CT_FAM], 1ull);
-                        }
-                        sd_base = __shfl(sd_base, 0);
-                        fam_idx = __shfl(fam_idx, 0);
-                        if (fam_idx < P.fam_cap && sd_base + total <= P.sd_cap) {
-                            if (lane == 0) {
-                                FamHdr h;
-                                h.g_start = g0;
-                                h.seq = fam_seq;
-                                h.sd_base = sd_base;
-                                h.count = total;
-                                h.pad = 0;
-                                P.fam_hdr[fam_idx] = h;
-                            }
-                            uint32_t w = 0;
-                            for (uint32_t t0 = 0; t0 < A; t0 += 64) {
-                                const uint32_t j = t0 + lane;
-                                const bool emit = j < A && (uint64_t)(s_re[j] - s_rs[j]) >= rp.M;
-                                const unsigned long long m = __ballot(emit);
-                                if (emit) {
-                                    const uint64_t ls = s_ls[j], ll = (uint64_t)s_le[j] - ls;
-                                    asgart_proto_sd sd;
-                                    // left fix-up, src/bin/asgart.rs:229-237
-                                    sd.left = rp.reverse ? cs + cl - ls - ll : ls + cs;
-                                    sd.right = s_rs[j];
-                                    sd.left_length = ll;
-                                    sd.right_length = (uint64_t)s_re[j] - (uint64_t)s_rs[j];
-                                    P.fam_sds[sd_base + w + __popcll(m & lt_mask)] = sd;
-                                }
-                                w += __popcll(m);
-                            }
-                        }
-                        ++fam_seq;
-                    }
-                    A = 0;
-                    __syncthreads();
-                }
-                if (A == 0 && quiet >= rp.tstar) {
-                    done = true;
-                    break;
+                    retire_lds();
+                    if (A <= 32) to_regs();
                 }
             }
+            if (!done) {
+                const unsigned long long range = pos >= 64 ? 0ull : ~((1ull << pos) - 1ull);
+                const uint32_t q = (uint32_t)__popcll(qm & range);
+                if (q) advance_quiet(q);
+            }
+            __syncthreads();
+            g += nbb;
         }
-        // arms still alive at the end of the chunk are dropped (automaton.rs:201-203)
-        if (overflow && P.ovf_list && lane == 0)
-            P.ovf_list[atomicAdd(&P.ctr[CT_OVF], 1ull)] = g0;
-        else if (overflow && lane == 0)
-            atomicAdd(&P.ctr[CT_OVF], 1ull);
+        // arms still alive at the end of the chunk are dropped together with the
+        // unflushed family they belong to (src/automaton.rs:201-203)
+        if (!overflow && A > 0)
+            emit_records(lane == 0, (PosT)0, (PosT)0, (PosT)0, (PosT)0, kTombstone);
+        if (overflow && lane == 0) {
+            const unsigned long long at = atomicAdd(&P.ctr[CT_OVF], 1ull);
+            if (P.ovf_list) P.ovf_list[at] = g0;
+        }
         __syncthreads();
     }
 }

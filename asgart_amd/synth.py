@@ -75,7 +75,8 @@ def _indels(rng: np.random.Generator, seq: np.ndarray, rate: float, max_len: int
 def make_genome(record_lengths: Sequence[int], seed: int, *, sd_per_mb: float = 2.0,
                 sd_len: Tuple[int, int] = (1000, 200_000), alu_frac: float = 0.08,
                 l1_frac: float = 0.02, sat_per_record: int = 2, gaps: bool = True,
-                short_n_per_mb: float = 0.5, soft_mask: bool = True
+                short_n_per_mb: float = 0.5, soft_mask: bool = True,
+                alu_div: Tuple[float, float] = (0.10, 0.15), sat_copies: Tuple[int, int] = (200, 10_000)
                 ) -> List[Tuple[str, np.ndarray]]:
     """-> [(name, uint8 sequence with upper/lower-case ACGT and N)]"""
     rng = np.random.default_rng(seed)
@@ -109,7 +110,7 @@ def make_genome(record_lengths: Sequence[int], seed: int, *, sd_per_mb: float = 
         for off in range(0, n_alu, blk):
             m = min(blk, n_alu - off)
             copies = np.broadcast_to(cons, (m, 300)).copy()
-            rate = rng.uniform(0.10, 0.15, size=(m, 1))
+            rate = rng.uniform(alu_div[0], alu_div[1], size=(m, 1))
             mask = rng.random((m, 300)) < rate
             copies[mask] = (copies[mask] + rng.integers(1, 4, size=int(mask.sum()), dtype=np.uint8)) & 3
             rev = rng.random(m) < 0.5
@@ -129,11 +130,11 @@ def make_genome(record_lengths: Sequence[int], seed: int, *, sd_per_mb: float = 
             place(cp, True)
     # tandem satellite arrays (171-bp monomer)
     for r in range(len(lens)):
-        if lens[r] < 2_000_000:
+        if lens[r] < 2_000_000 and sat_copies[1] > 1000:
             continue
         for _ in range(sat_per_record):
             mono = _background(rng, 171)
-            copies = int(rng.integers(200, max(201, min(10_000, lens[r] // 171 // 50))))
+            copies = int(rng.integers(sat_copies[0], max(sat_copies[0] + 1, min(sat_copies[1], lens[r] // 171 // 50))))
             arr = np.tile(mono, copies)
             arr = _mutate(rng, arr, float(rng.uniform(0.01, 0.05)))
             p = int(offs[r] + rng.integers(0, lens[r] - len(arr)))

@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""bench.py -- Mbp/s of the probe -> SA search -> extend hot path on MI355X.
+
+A "step" is one pass of the hot path over the whole synthetic genome: the direct run
+plus the reverse-complement run (`asgart` and `asgart -RC`, BASELINE.json "direct+RC"),
+i.e. the equivalent of reference src/bin/asgart.rs:201-253 executed twice over the same
+index.  The index (text, suffix array, search keys) is resident in HBM before the timed
+region; results (families of ProtoSD) are back on the host when it ends.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|cfg4|tiny]
+
+Prints ONE JSON line on rank 0 (see the driver contract in the task description), with
+two extra objects: "roofline" (dominant kernel = probe-search, HBM-bound, algorithmic
+bytes of SURVEY.md section 8d over the HIP-event duration measured inside the library on
+its own stream) and "cpu_baseline" (the CPU oracle, OpenMP over chunks like the
+reference's rayon par_iter, timed on this host on a bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import asgart_amd  # noqa: E402
+from asgart_amd import prep, synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+MODES = ((False, False), (True, True))  # direct, then -RC
+WORKLOADS = {
+    # name: (config id, scale, description)
+    "tiny": (2, 0.05, "S. cerevisiae-shaped synthetic x0.05 (0.6 Mb), direct+RC, k=20 g=100"),
+    "cfg2": (2, 1.0, "S. cerevisiae S288C-shaped synthetic (12.2 Mb, 17 records), direct+RC, k=20 g=100"),
+    "cfg3": (3, 1.0, "human chr1-shaped synthetic (249 Mb), direct+RC, k=20 g=100"),
+    "cfg4": (4, 1.0, "GRCh38-shaped synthetic (3.1 Gb, 25 records), direct+RC, k=20 g=100"),
+}
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def algorithmic_bytes(st: dict, k: int, W: int = 8) -> int:
+    """B_p = k + 16 + 2*ceil(log2(b_p+1))*(W+k) + W*h_p summed over the
+    searched probes (reference algorithm at reference widths, W = 8-byte SA entries)."""
+    return (st["probes_searched"] * (k + 16) + 2 * st["bisect_steps"] * (W + k)
+            + W * st["raw_hits"])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default=os.environ.get("ASGART_BENCH_WORKLOAD", "cfg2"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}")
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist_mod
+
+        torch.cuda.set_device(local_rank)
+        dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist = dist_mod
+
+    cfg, scale, desc = WORKLOADS[args.workload]
+    k, gap = 20, 100
+    t0 = time.time()
+    recs = synth.config_genome(cfg, scale)
+    pr = prep.prepare_records(recs, skip_masked=False)
+    total_bp = sum(l for _, l in pr.chunks)
+    t_gen = time.time() - t0
+    if rank == 0:
+        log(f"[bench] {desc}: {len(pr.data)} bytes, {len(pr.chunks)} chunks, gen {t_gen:.1f}s")
+
+    # ---- index build (outside the timed region, reported separately) -------------
+    t0 = time.time()
+    import oracle  # SA construction for now comes from the oracle's SA-IS (CPU); see DESIGN.md
+
+    sa = oracle.divsufsort64(pr.data)
+    t_sa = time.time() - t0
+    t0 = time.time()
+    idx = asgart_amd.Index(pr.data, sa, device=local_rank)
+    idx.prepare(k)
+    t_index = time.time() - t0
+    if rank == 0:
+        log(f"[bench] SA build {t_sa:.1f}s (CPU SA-IS), upload+keys {t_index:.2f}s")
+
+    settings = [asgart_amd.RunSettings.from_cli(k=k, gap=gap, reverse=r, complement=c) for r, c in MODES]
+
+    def sync():
+        if dist is not None:
+            import torch
+
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def one_step():
+        out = []
+        for st in settings:
+            if world > 1:
+                out.append(idx.search_duplications_raw(pr.chunks, st, shard=rank, n_shards=world))
+            else:
+                out.append(idx.search_duplications_raw(pr.chunks, st))
+        return out
+
+    for _ in range(args.warmup):
+        one_step()
+    # per-pass device timings + work counters (one extra untimed pass per mode)
+    pass_stats = []
+    for st in settings:
+        idx.search_duplications_raw(pr.chunks, st)
+        pass_stats.append(idx.stats(1).as_dict())
+
+    sync()
+    t0 = time.perf_counter()
+    search_ms = 0.0
+    phase_ms = {"search": 0.0, "scan": 0.0, "fill": 0.0, "extend": 0.0}
+    for _ in range(args.steps):
+        for st in settings:
+            if world > 1:
+                res = idx.search_duplications_raw(pr.chunks, st, shard=rank, n_shards=world)
+            else:
+                res = idx.search_duplications_raw(pr.chunks, st)
+            s = idx.stats(0)
+            search_ms += s.ms_search
+            for ph in phase_ms:
+                phase_ms[ph] += getattr(s, "ms_" + ph)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+
+        t = torch.tensor([elapsed], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    passes = len(MODES)
+    value = total_bp * passes * args.steps / elapsed / 1e6
+    n_launch = args.steps * passes
+    alg_bytes = sum(algorithmic_bytes(s, k) for s in pass_stats)  # per step (both passes)
+    achieved = (alg_bytes * args.steps) / (search_ms / 1e3) / 1e9 if search_ms > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(args.workload)
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "Mbp/s probe+extend (direct+RC, k=20 g=100)",
+        "value": round(value, 3),
+        "unit": "Mbp/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "u64 keys / u32 SA",
+        "data": "synthetic",
+        "config": {"workload": desc, "bp_per_pass": total_bp, "passes": passes,
+                   "text_bytes": int(len(pr.data)), "chunks": len(pr.chunks),
+                   "parallelism": f"probe-shard x{world}" if world > 1 else "1 GPU"},
+        "roofline": {
+            "bound": "hbm", "kernel": "probe_count_kernel (+big_count_kernel)",
+            "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5),
+            "algorithmic_bytes_per_launch": int(alg_bytes / passes),
+            "avg_launch_ms": round(search_ms / n_launch, 5),
+            "traffic": traffic,
+        },
+        "phases_ms_per_step": {ph: round(v / args.steps, 4) for ph, v in phase_ms.items()},
+        "index_build_s": {"suffix_array": round(t_sa, 2), "upload_and_keys": round(t_index, 3),
+                          "sa_builder": "oracle SA-IS on CPU (GPU builder pending)"},
+        "work_per_step": {key: sum(s[key] for s in pass_stats) for key in
+                          ("probes_total", "probes_searched", "probes_card_skipped", "raw_hits",
+                           "filtered_hits", "segments", "families", "proto_sds")},
+    }
+
+    if rank == 0 and not args.no_cpu_baseline:
+        # CPU reference: the oracle with the reference's parallel structure (OpenMP over
+        # chunks == rayon par_iter, src/bin/asgart.rs:201-205), same index, same chunks.
+        cores = os.cpu_count() or 1
+        oidx = oracle.Index.build(pr.data, sa)
+        sample_chunks, sample_bp = [], 0
+        budget_bp = 400e6  # bounded sample: keeps the CPU leg within ~10-30 s
+        for c in pr.chunks:
+            sample_chunks.append(c)
+            sample_bp += c[1]
+            if sample_bp >= budget_bp:
+                break
+        t0 = time.perf_counter()
+        for r, c in MODES:
+            oidx.run_raw(sample_chunks, oracle.make_settings(k=k, gap=gap, reverse=r, complement=c),
+                         threads=cores)
+        t_cpu = time.perf_counter() - t0
+        out["cpu_baseline"] = {
+            "value": round(sample_bp * passes / t_cpu / 1e6, 3), "unit": "Mbp/s", "cores": cores,
+            "kind": "port",
+            "sample": (f"first {len(sample_chunks)} of {len(pr.chunks)} chunks "
+                       f"({sample_bp} bp) x {passes} passes against the full index, {t_cpu:.2f} s"),
+        }
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    idx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

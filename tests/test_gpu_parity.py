@@ -90,3 +90,61 @@ def test_families_match_oracle(case, reverse, complement):
     assert np.array_equal(sds, esds)
     if not reverse and not complement:
         assert len(offs) > 1  # the planted duplications are found
+
+
+# ---- a battery of harder shapes: every case compares families (and the CSR for one
+# orientation) of the HIP path with the oracle ------------------------------------
+BATTERY = {
+    # dense low-divergence repeat family: hundreds of hits per probe, > 64 live arms
+    "dense_repeats": dict(lens=(150_000,), seed=11, gen=dict(alu_frac=0.35, alu_div=(0.005, 0.03),
+                                                             sd_per_mb=10, sd_len=(1000, 5000)),
+                          cli=dict(min_length=150)),
+    # cardinality skips (max_cardinality lowered) + repeats
+    "card_skip": dict(lens=(200_000,), seed=12, gen=dict(alu_frac=0.3, alu_div=(0.01, 0.05)),
+                      cli=dict(max_cardinality=40)),
+    # tandem satellite arrays
+    "satellites": dict(lens=(400_000,), seed=13, gen=dict(alu_frac=0.02, sat_per_record=3,
+                                                          sat_copies=(50, 400))),
+    # long diverged duplications: many retired pieces per family
+    "long_sds": dict(lens=(600_000, 300_000), seed=14, gen=dict(alu_frac=0.0, sd_per_mb=12,
+                                                                sd_len=(20_000, 80_000))),
+    # many tiny families
+    "short_min_len": dict(lens=(250_000,), seed=15, gen=dict(alu_frac=0.1), cli=dict(min_length=100)),
+    "k12": dict(lens=(120_000,), seed=16, gen=dict(alu_frac=0.05), cli=dict(k=12, gap=50)),
+    "k21_odd": dict(lens=(200_000,), seed=17, gen=dict(alu_frac=0.05), cli=dict(k=21, gap=33)),
+    "k9_gap0": dict(lens=(60_000,), seed=18, gen=dict(alu_frac=0.02), cli=dict(k=9, gap=0, min_length=200)),
+    "masked": dict(lens=(300_000, 200_000), seed=19, gen=dict(alu_frac=0.2), skip_masked=True),
+}
+
+
+def _battery_case(name):
+    spec = BATTERY[name]
+    recs = _small_genome(seed=spec["seed"], lens=spec["lens"], **spec.get("gen", {}))
+    pr = prep.prepare_records(recs, skip_masked=spec.get("skip_masked", False))
+    return pr, spec.get("cli", {})
+
+
+@pytest.mark.parametrize("name", sorted(BATTERY))
+def test_battery_families_and_csr(hiplib, name):
+    pr, cli = _battery_case(name)
+    oidx = oracle.Index.build(pr.data)
+    with asgart_amd.Index(pr.data, oidx.sa) as idx:
+        for reverse, complement in MODES:
+            st = asgart_amd.RunSettings.from_cli(reverse=reverse, complement=complement, **cli)
+            ost = oracle.make_settings(reverse=reverse, complement=complement, **cli)
+            offs, sds = idx.search_duplications_raw(pr.chunks, st)
+            eoffs, esds = oidx.run_raw(pr.chunks, ost, threads=4)
+            assert np.array_equal(offs, eoffs), (name, reverse, complement, len(offs), len(eoffs))
+            assert np.array_equal(sds, esds), (name, reverse, complement)
+        st = asgart_amd.RunSettings.from_cli(reverse=True, complement=False, **cli)
+        ost = oracle.make_settings(reverse=True, complement=False, **cli)
+        status, offs, hits = idx.probe_hits(pr.chunks, st)
+        e_status, e_offs, e_hits = [], [0], []
+        for ch in pr.chunks:
+            s1, o1, h1 = oidx.probe_hits(oracle.prepare_needle(pr.data, ch, ost), ch[0], ost)
+            e_status.append(s1)
+            e_offs.extend((o1[1:] + e_offs[-1]).tolist())
+            e_hits.append(h1)
+        assert np.array_equal(status, np.concatenate(e_status))
+        assert np.array_equal(offs, np.array(e_offs, dtype=np.uint64))
+        assert np.array_equal(hits, np.concatenate(e_hits))
