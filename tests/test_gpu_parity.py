@@ -148,3 +148,64 @@ def test_battery_families_and_csr(hiplib, name):
         assert np.array_equal(status, np.concatenate(e_status))
         assert np.array_equal(offs, np.array(e_offs, dtype=np.uint64))
         assert np.array_equal(hits, np.concatenate(e_hits))
+
+
+def test_golden_kat_on_gpu(hiplib):
+    """The committed known-answer vectors (tests/golden/kat.json) through the HIP path."""
+    import json
+    import os
+
+    kat = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kat.json")))
+    for case in kat["cases"]:
+        s = case["settings"]
+        text = case["text"].encode() + b"$"
+        sa = oracle.divsufsort64(text)
+        st = asgart_amd.RunSettings.from_cli(k=s["k"], gap=s["gap"], min_length=s["min_length"],
+                                             max_cardinality=s["max_cardinality"],
+                                             reverse=s["reverse"], complement=s["complement"])
+        strand = asgart_amd.Strand("kat", np.frombuffer(text, dtype=np.uint8))
+        step = asgart_amd.SearchDuplications([tuple(c) for c in case["chunks"]], None, st, suffix_array=sa)
+        got = [[sd.as_tuple() for sd in fam] for fam in step.run([], strand)]
+        assert got == [[tuple(sd) for sd in fam] for fam in case["families"]], case["name"]
+
+
+def test_tail_corner_on_gpu(hiplib):
+    """Probes sharing an 8-mer with the last (< k) bases of the text take the exact-bisection
+    path (reference src/searcher.rs:164-170); same answers as the oracle."""
+    import random
+
+    rng = random.Random(5)
+    core = bytes(rng.choice(b"ACGT") for _ in range(1500))
+    motif = b"ACGTTGCAAC"
+    for fill in (b"A", b"T", b"G"):
+        text = core[:400] + motif + fill * 10 + core[400:900] + motif + b"T" * 10 + core[900:] + motif
+        strand = text + b"$"
+        oidx = oracle.Index.build(strand)
+        with asgart_amd.Index(strand, oidx.sa) as idx:
+            s = asgart_amd.Searcher(idx)
+            pats = [motif + fill * 10, motif + b"T" * 10, motif + b"A" * 10, motif + b"C" * 10,
+                    motif + b"G" * 10]
+            for p, (lo, hi) in zip(pats, s.search_ranges(pats)):
+                exp, _ = oidx.search(p)
+                assert np.array_equal(idx.sa_read(lo, hi).astype(np.uint64), exp), p
+            for r, c in MODES:
+                st = asgart_amd.RunSettings.from_cli(min_length=100, reverse=r, complement=c)
+                offs, sds = idx.search_duplications_raw([(0, len(text))], st)
+                eo, es = oidx.run_raw([(0, len(text))], oracle.make_settings(min_length=100, reverse=r, complement=c))
+                assert np.array_equal(offs, eo) and np.array_equal(sds, es)
+
+
+def test_errors_on_gpu(hiplib):
+    with pytest.raises(asgart_amd.AsgartError) as e:
+        asgart_amd.Index(b"ACGTXACGT$")
+    assert e.value.code == -1
+    text = b"ACGT" * 100 + b"$"
+    with asgart_amd.Index(text, oracle.divsufsort64(text)) as idx:
+        with pytest.raises(asgart_amd.AsgartError):
+            idx.search_duplications_raw([(0, 401)], asgart_amd.RunSettings.from_cli())     # covers '$'
+        with pytest.raises(asgart_amd.AsgartError):
+            idx.search_duplications_raw([(0, 400)], asgart_amd.RunSettings.from_cli(k=30))  # k > 21
+        offs, sds = idx.search_duplications_raw([], asgart_amd.RunSettings.from_cli())
+        assert len(offs) == 1 and len(sds) == 0
+        offs, sds = idx.search_duplications_raw([(0, 25)], asgart_amd.RunSettings.from_cli(min_length=10))
+        assert len(offs) == 1

@@ -1,0 +1,54 @@
+"""The C oracle against the committed known-answer vectors (tests/golden/kat.json, produced by
+the independent brute-force restatement) -- the pin of the oracle, since the reference has no
+vectors of its own (PARITY UNPINNED, oracle/README.md)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+with open(os.path.join(HERE, "golden", "kat.json")) as fh:
+    KAT = json.load(fh)
+
+
+@pytest.mark.parametrize("case", KAT["cases"], ids=[c["name"] for c in KAT["cases"]])
+def test_kat_families(case):
+    text = case["text"].encode()
+    s = case["settings"]
+    chunks = [tuple(c) for c in case["chunks"]]
+    assert oracle.find_chunks(text) == chunks
+    idx = oracle.Index.build(text + b"$")
+    assert oracle.sa_check(idx.text, idx.sa) == 0
+    st = oracle.make_settings(k=s["k"], gap=s["gap"], min_length=s["min_length"],
+                              max_cardinality=s["max_cardinality"], reverse=s["reverse"],
+                              complement=s["complement"])
+    got = idx.run(chunks, st)
+    assert got == [[tuple(sd) for sd in fam] for fam in case["families"]]
+    # thread count must not change the result (ordered collect, asgart.rs:240)
+    assert idx.run(chunks, st, threads=4) == got
+
+
+def test_d_ss_kat():
+    for a, m, exp in KAT["d_ss"]:
+        assert oracle.d_ss(tuple(a), tuple(m)) == exp
+
+
+def test_probe_positions_kat():
+    pp = KAT["probe_positions"]
+    rng = np.random.default_rng(0)
+    text = bytes(rng.choice(list(b"ACGT"), size=pp["L"]).astype(np.uint8)) + b"$"
+    idx = oracle.Index.build(text)
+    st = oracle.make_settings(k=pp["k"])
+    status, offs, hits = idx.probe_hits(text[:-1], 0, st)
+    assert len(status) == pp["count"]          # probes at i = 10, 20, ..., 970
+    assert (len(status)) * (pp["k"] // 2) == pp["last"]
+
+
+def test_tenth_threshold_is_integer_division():
+    """(0.1 * len as f64) as i64 == len / 10 for every length the kernels can see
+    (src/automaton.rs:69); the HIP kernel evaluates the same double expression."""
+    lens = np.concatenate([np.arange(0, 2_000_000), np.random.default_rng(1).integers(0, 1 << 40, 1_000_000)])
+    assert np.array_equal((0.1 * lens.astype(np.float64)).astype(np.int64), lens // 10)

@@ -1,0 +1,103 @@
+"""C oracle == independent pure-Python restatement on seeded random inputs."""
+import random
+
+import numpy as np
+import pytest
+
+import bruteforce as B
+import oracle
+
+
+def _rand_text(rng, n, planted=True):
+    t = bytearray(rng.choice(b"ACGT") for _ in range(n))
+    if planted and n > 600:
+        for _ in range(rng.randint(1, 4)):
+            ln = rng.randint(150, min(600, n // 3))
+            a = rng.randrange(0, n - ln)
+            b = rng.randrange(0, n - ln)
+            seg = bytes(t[a:a + ln])
+            if rng.random() < 0.5:
+                seg = B.revcomp(seg)
+            seg = bytearray(seg)
+            for j in range(len(seg)):
+                if rng.random() < 0.02:
+                    seg[j] = rng.choice(b"ACGT")
+            t[b:b + ln] = seg
+        for _ in range(rng.randint(0, 3)):
+            a = rng.randrange(0, n - 40)
+            t[a:a + rng.randint(1, 40)] = b"N" * 40
+    return bytes(t[:n])
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_sa_cache_search(seed):
+    rng = random.Random(seed)
+    text = _rand_text(rng, rng.randint(50, 3000)) + b"$"
+    sa = B.suffix_array(text)
+    idx = oracle.Index.build(text)
+    assert list(idx.sa) == sa
+    for _ in range(40):
+        p = rng.randrange(0, len(text) - 9)
+        p8 = text[p:p + 8]
+        if b"$" in p8:
+            continue
+        lo, hi = idx.cache_get(p8)
+        elo, ehi = B.cache_entry(text, sa, p8)
+        assert hi - lo == ehi - elo and (hi == lo or (lo, hi) == (elo, ehi))
+    for _ in range(60):
+        k = rng.choice([8, 12, 20, 21])
+        p = rng.randrange(0, max(1, len(text) - k - 1))
+        pat = text[p:p + k]
+        if len(pat) < k or b"$" in pat[:8]:
+            continue
+        got, _ = idx.search(pat)
+        assert list(got) == B.search(text, sa, pat)
+
+
+@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("mode", [(False, False), (True, False), (False, True), (True, True)])
+def test_run_matches_bruteforce(seed, mode):
+    rng = random.Random(1000 + seed)
+    n = rng.randint(700, 2500)
+    text = _rand_text(rng, n)
+    strand = text + b"$"
+    chunks = B.find_chunks(text)
+    k = rng.choice([10, 12, 16, 20])
+    gap = rng.choice([0, 20, 100])
+    min_len = rng.choice([50, 100, 200])
+    card = rng.choice([1, 3, 500])
+    sa = B.suffix_array(strand)
+    exp = B.run(strand, sa, chunks, k=k, gap=gap, min_len=min_len, max_card=card,
+                reverse=mode[0], complement=mode[1])
+    idx = oracle.Index.build(strand)
+    st = oracle.make_settings(k=k, gap=gap, min_length=min_len, max_cardinality=card,
+                              reverse=mode[0], complement=mode[1])
+    assert idx.run(chunks, st) == exp
+
+
+def test_tail_corner_bisection_is_emulated():
+    """Text whose last bases share an 8-mer with a probe: the comparator of
+    src/searcher.rs:164-170 calls the short tail suffixes Less.  Both restatements follow the same
+    (recalled) superslice bisection; this pins them to each other on that corner."""
+    rng = random.Random(5)
+    core = bytes(rng.choice(b"ACGT") for _ in range(1500))
+    motif = b"ACGTTGCAAC"                     # 10 bases: the text ends with it
+    for fill in (b"A", b"T", b"G"):
+        text = core[:400] + motif + fill * 10 + core[400:900] + motif + b"T" * 10 + core[900:] + motif
+        strand = text + b"$"
+        sa = B.suffix_array(strand)
+        idx = oracle.Index.build(strand)
+        for pat in (motif + fill * 10, motif + b"T" * 10, motif + b"A" * 10, motif + b"C" * 10):
+            got, _ = idx.search(pat)
+            assert list(got) == B.search(strand, sa, pat, exact_bisection=True)
+        chunks = [(0, len(text))]
+        exp = B.run(strand, sa, chunks, min_len=100)
+        assert idx.run(chunks, oracle.make_settings(min_length=100)) == exp
+
+
+def test_short_and_empty_needles():
+    text = b"ACGT" * 10 + b"$"
+    idx = oracle.Index.build(text)
+    assert idx.run([(0, 40)], oracle.make_settings(min_length=10)) == []      # L < k + step... few probes
+    assert idx.run([(0, 20)], oracle.make_settings(min_length=1000)) == []    # L < M
+    assert idx.run([], oracle.make_settings()) == []
