@@ -22,7 +22,7 @@ import numpy as np
 
 __all__ = [
     "AsgartError", "RunSettings", "ProtoSD", "Strand", "Index", "Searcher", "SearchDuplications",
-    "load_library", "library_path", "ABI_SYMBOLS",
+    "load_library", "library_path", "ABI_SYMBOLS", "sa_build64",
 ]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -284,6 +284,15 @@ class Index:
         _check(L.asgart_probe_hits(self._h, _ptr(ch), len(chunks), C.byref(st), _ptr(status),
                                    _ptr(offs), _ptr(hits), C.byref(nh)))
         return status, offs, hits
+
+
+def sa_build64(text) -> np.ndarray:
+    """`r_divsufsort` (reference src/bin/asgart.rs:473-479) on the GPU: the suffix array of
+    `text` as int64, via asgart_sa_build64 (signature-identical to divsufsort64)."""
+    t = _as_u8(text)
+    sa = np.empty(len(t), dtype=np.int64)
+    _check(load_library().asgart_sa_build64(_ptr(t), _ptr(sa), len(t)))
+    return sa
 
 
 class Searcher:

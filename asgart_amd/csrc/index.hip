@@ -199,6 +199,30 @@ static int choose_depth(int64_t n, uint64_t k) {
     return d;
 }
 
+// true iff every byte of the device text is one of {$,A,C,G,N,T}
+int32_t text_is_dna(const uint8_t *d_text, int64_t n, hipStream_t s, bool *dna) {
+    DevBuf hist_b;
+    RC_TRY(hist_b.reserve(256 * sizeof(unsigned long long)));
+    unsigned long long *d_hist = hist_b.as<unsigned long long>();
+    unsigned long long hist[256];
+    int32_t rc = [&]() -> int32_t {
+        HIP_TRY(hipMemsetAsync(d_hist, 0, sizeof(hist), s));
+        unsigned blocks = grid_for((uint64_t)n, 256 * 16);
+        if (blocks > 4096) blocks = 4096;
+        byte_histogram_kernel<<<blocks, 256, 0, s>>>(d_text, (uint64_t)n, d_hist);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(hist, d_hist, sizeof(hist), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        return 0;
+    }();
+    hist_b.release();
+    if (rc) return rc;
+    *dna = true;
+    for (int c = 0; c < 256; ++c)
+        if (hist[c] && !valid_text_byte((uint8_t)c)) *dna = false;
+    return 0;
+}
+
 int32_t index_prepare(asgart_index *idx, uint64_t k) {
     if (k < (uint64_t)kCacheLen || k > (uint64_t)kMaxK) {
         set_error("probe_size %llu unsupported: need %d <= k <= %d (the reference needs k >= 8, "

@@ -128,6 +128,7 @@ int32_t run_search(asgart_index *idx, const uint64_t *chunks, int64_t n_chunks,
                    const asgart_settings *st, int32_t shard, int32_t n_shards, bool want_csr,
                    asgart_families *fam_out, std::vector<uint8_t> *status_out,
                    std::vector<uint64_t> *rowoff_out, std::vector<uint64_t> *hits_out);
+int32_t text_is_dna(const uint8_t *d_text, int64_t n, hipStream_t s, bool *dna);
 int32_t sa_build_device(const uint8_t *d_text, int64_t n, void *d_sa, bool wide,
                         hipStream_t stream);
 }  // namespace asgart

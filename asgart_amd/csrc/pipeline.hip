@@ -317,21 +317,11 @@ int32_t run_search(asgart_index *idx, const uint64_t *chunks, int64_t n_chunks,
                                   status_out, rowoff_out, hits_out);
 }
 
-int32_t sa_build_device(const uint8_t *, int64_t, void *, bool, hipStream_t) {
-    set_error("GPU suffix-array construction is not implemented in this build yet: pass SA");
-    return ASGART_E_ARG;
-}
-
 }  // namespace asgart
 
 using namespace asgart;
 
 extern "C" {
-
-int32_t asgart_sa_build64(const uint8_t *, int64_t *, int64_t) {
-    set_error("asgart_sa_build64: GPU suffix-array construction is not implemented yet");
-    return ASGART_E_ARG;
-}
 
 int32_t asgart_search_duplications_shard(asgart_index *idx, const uint64_t *chunks,
                                          int64_t n_chunks, const asgart_settings *settings,

@@ -209,3 +209,35 @@ def test_errors_on_gpu(hiplib):
         assert len(offs) == 1 and len(sds) == 0
         offs, sds = idx.search_duplications_raw([(0, 25)], asgart_amd.RunSettings.from_cli(min_length=10))
         assert len(offs) == 1
+
+
+def test_gpu_suffix_array_matches_oracle(hiplib):
+    """asgart_sa_build64 == divsufsort64 contract (reference src/divsufsort.rs:10): the unique
+    suffix array, checked against the oracle's SA-IS and its O(n) verifier."""
+    rng = np.random.default_rng(3)
+    texts = []
+    pr = prep.prepare_records(_small_genome(seed=21, lens=(200_000, 90_000), alu_frac=0.2,
+                                            sat_per_record=2, sat_copies=(50, 300)))
+    texts.append(pr.data)
+    texts.append(np.frombuffer(b"A" * 5000 + b"$", dtype=np.uint8))
+    texts.append(np.frombuffer(b"ACG" * 3000 + b"N" * 7000 + b"ACGT" * 100 + b"$", dtype=np.uint8))
+    texts.append(np.frombuffer(b"N" * 30000 + b"$", dtype=np.uint8))
+    texts.append(rng.integers(0, 256, size=50_000, dtype=np.uint8))       # arbitrary bytes
+    texts.append(rng.integers(0, 2, size=70_000, dtype=np.uint8))         # binary, long repeats
+    texts.append(np.frombuffer(b"\x00" * 100 + b"\xff" * 100 + b"\x00" * 50, dtype=np.uint8))
+    texts.append(np.frombuffer(b"G", dtype=np.uint8))
+    for t in texts:
+        t = np.ascontiguousarray(t)
+        sa = asgart_amd.sa_build64(t)
+        assert oracle.sa_check(t, sa) == 0
+        assert np.array_equal(sa, oracle.divsufsort64(t))
+
+
+def test_index_builds_its_own_suffix_array(case):
+    pr, oidx, idx = case
+    with asgart_amd.Index(pr.data, None) as idx2:
+        assert np.array_equal(idx2.sa_read(0, len(pr.data)), oidx.sa)
+        st = asgart_amd.RunSettings.from_cli()
+        a = idx.search_duplications_raw(pr.chunks, st)
+        b = idx2.search_duplications_raw(pr.chunks, st)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
