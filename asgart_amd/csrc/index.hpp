@@ -43,7 +43,9 @@ struct ChunkTable {
 
 struct RunParams {
     ChunkTable ch;
-    uint32_t g_lo, g_hi;  // probe range of this call
+    uint32_t g_lo, g_hi;  // probe window computed by this call (own range + halo)
+    uint32_t own_lo, own_hi;  // segments starting in [own_lo, own_hi) belong to this call
+    uint32_t init_unknown;    // 1: the automaton state just before g_lo is unknown (mid-chunk window)
     int k, step;
     uint32_t G;           // max_gap_size
     uint32_t tstar;       // ceil(G / step)

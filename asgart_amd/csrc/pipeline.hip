@@ -72,10 +72,23 @@ static int32_t run_search_t(asgart_index *idx, const uint64_t *chunks, int64_t n
         hits_out->clear();
     }
     if (P == 0 || n_chunks == 0) return 0;
-    if (n_shards != 1 || shard != 0) {
-        set_error("probe-range sharding is not implemented in this build yet");
+    if (want_csr && n_shards != 1) {
+        set_error("asgart_probe_hits is not sharded");
         return ASGART_E_ARG;
     }
+    // Multi-GPU sharding: shard r owns the automaton segments that START in its slice of the
+    // global probe sequence.  It computes probe-search over that slice plus a look-back halo
+    // (to decide whether its first probes continue an earlier segment) and a look-ahead halo
+    // (to finish segments that run past the slice); no data is exchanged between shards.
+    const uint32_t own_lo = (uint32_t)((uint64_t)P * (uint64_t)shard / (uint64_t)n_shards);
+    const uint32_t own_hi = (uint32_t)((uint64_t)P * (uint64_t)(shard + 1) / (uint64_t)n_shards);
+    if (own_lo == own_hi) return 0;
+    uint64_t look_back = 4096, look_ahead = std::max<uint64_t>(65536, (own_hi - own_lo) / 16);
+    if (const char *e = getenv("ASGART_SHARD_LOOKBACK")) look_back = std::max(1, atoi(e));
+    if (const char *e = getenv("ASGART_SHARD_LOOKAHEAD")) look_ahead = std::max(1, atoi(e));
+    auto chunk_of_host = [&](uint32_t g) {
+        return (int64_t)(std::upper_bound(h_pbase.begin(), h_pbase.end(), g) - h_pbase.begin()) - 1;
+    };
 
     const size_t ch_bytes = (size_t)n_chunks * 16 + ((size_t)n_chunks + 1) * 4;
     RC_TRY(w.chunks.reserve(ch_bytes));
@@ -87,10 +100,29 @@ static int32_t run_search_t(asgart_index *idx, const uint64_t *chunks, int64_t n
     HIP_TRY(hipMemcpyAsync(d_pbase, h_pbase.data(), ((size_t)n_chunks + 1) * 4,
                            hipMemcpyHostToDevice, s));
 
+    unsigned long long h_ctr[CT_COUNT];
+    uint64_t total_hits = 0, n_seg = 0;
     RunParams rp;
+    const auto t_host0 = std::chrono::steady_clock::now();
+    for (int win_try = 0;; ++win_try) {
+    if (win_try > 40) {
+        set_error("internal: shard window did not converge");
+        return ASGART_E_CAP;
+    }
+    uint32_t w_lo = own_lo, w_hi = own_hi;
+    {
+        const int64_t c0 = chunk_of_host(own_lo), c1 = chunk_of_host(own_hi - 1);
+        const uint64_t lo_lim = h_pbase[c0], hi_lim = h_pbase[c1 + 1];
+        w_lo = (uint32_t)std::max<uint64_t>(lo_lim, own_lo > look_back ? own_lo - look_back : 0);
+        w_hi = (uint32_t)std::min<uint64_t>(hi_lim, (uint64_t)own_hi + look_ahead);
+        rp.init_unknown = w_lo != lo_lim ? 1u : 0u;
+    }
+    const uint32_t W = w_hi - w_lo;
     rp.ch = ChunkTable{d_start, d_len, d_pbase, (int)n_chunks};
-    rp.g_lo = 0;
-    rp.g_hi = P;
+    rp.g_lo = w_lo;
+    rp.g_hi = w_hi;
+    rp.own_lo = own_lo;
+    rp.own_hi = own_hi;
     rp.k = (int)k;
     rp.step = (int)step;
     rp.G = st->max_gap_size;
@@ -103,33 +135,32 @@ static int32_t run_search_t(asgart_index *idx, const uint64_t *chunks, int64_t n
     idx->last_rp = rp;
     idx->has_last = false;
 
-    // ---- workspace -----------------------------------------------------------
-    const uint32_t n_blk = (P + kScanTile - 1) / kScanTile;
-    const uint64_t seg_cap = (uint64_t)P / (rp.tstar + 1) + (uint64_t)n_chunks + 64;
-    RC_TRY(w.p_lo.reserve((size_t)P * sizeof(SlotT)));
-    RC_TRY(w.p_raw.reserve((size_t)P * 4));
-    RC_TRY(w.p_filt.reserve((size_t)P * 4));
-    RC_TRY(w.row_off.reserve(((size_t)P + 1) * 8));
+    // ---- workspace (indexed by absolute probe number through shifted pointers) ---
+    const uint32_t n_blk = (W + kScanTile - 1) / kScanTile;
+    const uint64_t seg_cap = (uint64_t)W / (rp.tstar + 1) + (uint64_t)n_chunks + 64;
+    RC_TRY(w.p_lo.reserve((size_t)W * sizeof(SlotT)));
+    RC_TRY(w.p_raw.reserve((size_t)W * 4));
+    RC_TRY(w.p_filt.reserve((size_t)W * 4));
+    RC_TRY(w.row_off.reserve(((size_t)W + 1) * 8));
     RC_TRY(w.blk.reserve((size_t)n_blk * sizeof(ScanEl)));
-    RC_TRY(w.big_list.reserve((size_t)P * 4));
+    RC_TRY(w.big_list.reserve((size_t)W * 4));
     RC_TRY(w.seg_list.reserve((size_t)seg_cap * 4));
     RC_TRY(w.counters.reserve(CT_COUNT * 8));
     unsigned long long *d_ctr = w.counters.as<unsigned long long>();
     HIP_TRY(hipMemsetAsync(d_ctr, 0, CT_COUNT * 8, s));
 
     IndexView<SlotT> ix = idx->view<SlotT>();
-    SlotT *p_lo = w.p_lo.as<SlotT>();
-    uint32_t *p_raw = w.p_raw.as<uint32_t>();
-    uint32_t *p_filt = w.p_filt.as<uint32_t>();
-    unsigned long long *row_off = w.row_off.as<unsigned long long>();
+    SlotT *p_lo = w.p_lo.as<SlotT>() - w_lo;
+    uint32_t *p_raw = w.p_raw.as<uint32_t>() - w_lo;
+    uint32_t *p_filt = w.p_filt.as<uint32_t>() - w_lo;
+    unsigned long long *row_off = w.row_off.as<unsigned long long>() - w_lo;
     ScanEl *blk = w.blk.as<ScanEl>();
     uint32_t *big_list = w.big_list.as<uint32_t>();
     uint32_t *seg_list = w.seg_list.as<uint32_t>();
 
-    const auto t_host0 = std::chrono::steady_clock::now();
     // ---- K1: probe search + filtered counts -----------------------------------
     HIP_TRY(hipEventRecord(idx->ev[0], s));
-    probe_count_kernel<SlotT><<<grid_for(P), 256, 0, s>>>(ix, rp, p_lo, p_raw, p_filt, big_list,
+    probe_count_kernel<SlotT><<<grid_for(W), 256, 0, s>>>(ix, rp, p_lo, p_raw, p_filt, big_list,
                                                          d_ctr);
     big_count_kernel<SlotT><<<2048, 256, 0, s>>>(ix, rp, p_lo, p_raw, p_filt, big_list, d_ctr);
     HIP_TRY(hipEventRecord(idx->ev[1], s));
@@ -139,11 +170,14 @@ static int32_t run_search_t(asgart_index *idx, const uint64_t *chunks, int64_t n
     scan_down_kernel<<<n_blk, kScanBlock, 0, s>>>(rp, p_filt, p_raw, blk, row_off, seg_list, d_ctr);
     HIP_TRY(hipEventRecord(idx->ev[2], s));
     HIP_TRY(hipGetLastError());
-    unsigned long long h_ctr[CT_COUNT];
     HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, sizeof(h_ctr), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    const uint64_t total_hits = h_ctr[CT_TOTAL_HITS];
-    const uint64_t n_seg = h_ctr[CT_SEG];
+    total_hits = h_ctr[CT_TOTAL_HITS];
+    n_seg = h_ctr[CT_SEG];
+    if (h_ctr[CT_AMBIG]) {  // a start decision needs more history: widen the look-back halo
+        look_back *= 8;
+        continue;
+    }
     if (n_seg > seg_cap) {
         set_error("internal: segment list overflow (%llu > %llu)", (unsigned long long)n_seg,
                   (unsigned long long)seg_cap);
@@ -152,7 +186,7 @@ static int32_t run_search_t(asgart_index *idx, const uint64_t *chunks, int64_t n
     // ---- K3: CSR fill -----------------------------------------------------------
     RC_TRY(w.hits.reserve((size_t)(total_hits + 64) * sizeof(SlotT)));
     SlotT *hits = w.hits.as<SlotT>();
-    fill_small_kernel<SlotT><<<grid_for(P), 256, 0, s>>>(ix, rp, p_lo, p_raw, p_filt, row_off, hits);
+    fill_small_kernel<SlotT><<<grid_for(W), 256, 0, s>>>(ix, rp, p_lo, p_raw, p_filt, row_off, hits);
     if (h_ctr[CT_BIG])
         fill_big_kernel<SlotT><<<2048, 256, 0, s>>>(ix, rp, p_lo, p_raw, p_filt, row_off, hits,
                                                     big_list, d_ctr);
@@ -227,12 +261,17 @@ static int32_t run_search_t(asgart_index *idx, const uint64_t *chunks, int64_t n
                     return ASGART_E_CAP;
                 }
             }
+            if (h_ctr[CT_RANOUT]) break;
             if (h_ctr[CT_SD] <= rec_cap) break;
             if (attempt >= 3) {
                 set_error("internal: record buffer keeps overflowing");
                 return ASGART_E_CAP;
             }
             rec_cap = h_ctr[CT_SD] * 2;
+        }
+        if (h_ctr[CT_RANOUT]) {  // a segment runs past the look-ahead halo: widen it
+            look_ahead *= 8;
+            continue;
         }
         HIP_TRY(hipEventRecord(idx->ev[4], s));
         const uint64_t n_rec = h_ctr[CT_SD];
@@ -268,6 +307,8 @@ static int32_t run_search_t(asgart_index *idx, const uint64_t *chunks, int64_t n
         HIP_TRY(hipEventRecord(idx->ev[4], s));
         HIP_TRY(hipStreamSynchronize(s));
     }
+    break;
+    }  // shard-window retry loop
 
     // ---- stats ------------------------------------------------------------------
     asgart_stats &stt = idx->stats;
@@ -404,10 +445,10 @@ int32_t asgart_get_stats(asgart_index *idx, uint32_t flags, asgart_stats *out) {
         const unsigned g = grid_for(rp.g_hi - rp.g_lo);
         if (idx->wide)
             yardstick_kernel<uint64_t><<<g, 256, 0, s>>>(idx->view<uint64_t>(), rp,
-                                                         idx->ws.p_filt.as<uint32_t>(), d_ctr);
+                                                         idx->ws.p_filt.as<uint32_t>() - rp.g_lo, d_ctr);
         else
             yardstick_kernel<uint32_t><<<g, 256, 0, s>>>(idx->view<uint32_t>(), rp,
-                                                         idx->ws.p_filt.as<uint32_t>(), d_ctr);
+                                                         idx->ws.p_filt.as<uint32_t>() - rp.g_lo, d_ctr);
         HIP_TRY(hipGetLastError());
         unsigned long long v = 0;
         HIP_TRY(hipMemcpyAsync(&v, d_ctr + CT_BISECT, 8, hipMemcpyDeviceToHost, s));

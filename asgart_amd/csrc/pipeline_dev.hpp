@@ -36,6 +36,8 @@ enum Counter {
     CT_SEARCHED,
     CT_BISECT,        // yardstick
     CT_OVF_CURSOR,
+    CT_AMBIG,         // sharding: start decisions that need a longer look-back
+    CT_RANOUT,        // sharding: segments that ran past the look-ahead window
     CT_COUNT = 32
 };
 
@@ -270,6 +272,14 @@ __global__ __launch_bounds__(kScanBlock) void scan_down_kernel(RunParams rp,
     ScanEl total;
     ScanEl excl = block_exclusive_scan(agg, sh, &total);
     ScanEl run = scan_combine(blk[blockIdx.x], excl);
+    if (rp.init_unknown) {
+        // Window starts mid-chunk: prepend "state unknown" (bit2).  It is cleared by a chunk
+        // start or a hit-probe; while set, `c` is only a lower bound of the quiet run.
+        ScanEl init{0ull, 0u, 4u};
+        ScanEl r2 = scan_combine(init, run);
+        r2.flags = (r2.flags & 3u) | ((run.flags & 3u) ? 0u : 4u);
+        run = r2;
+    }
     unsigned long long st_n = 0, st_card = 0, st_hit = 0, st_raw = 0, st_searched = 0;
     const int lane = threadIdx.x & 63;
     for (int a = 0; a < kScanItems; ++a) {
@@ -287,12 +297,18 @@ __global__ __launch_bounds__(kScanBlock) void scan_down_kernel(RunParams rp,
                 if (f == kSkipCard) ++st_card;
                 else if (hit) ++st_hit;
             }
-            if (hit) {
+            if (hit && g >= rp.own_lo && g < rp.own_hi) {
                 const bool chunk_first = items[a].flags & 2u;
                 const bool has_before = !chunk_first && (run.flags & 1u);
+                const bool unknown = !chunk_first && (run.flags & 4u);
+                if (unknown && run.c < rp.tstar) atomicAdd(&ctr[CT_AMBIG], 1ull);
                 start = !has_before || run.c >= rp.tstar;
             }
-            run = scan_combine(run, items[a]);
+            {
+                const uint32_t keep_unknown = (run.flags & 4u) && !(items[a].flags & 3u) ? 4u : 0u;
+                run = scan_combine(run, items[a]);
+                run.flags = (run.flags & 3u) | keep_unknown;
+            }
         }
         // wave-aggregated append of segment starts (order is irrelevant: the
         // families are sorted by (start probe, ordinal) on the host)
@@ -467,7 +483,8 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
         const int c = chunk_of(rp.ch, g0);
         const uint64_t cs = rp.ch.start[c], cl = rp.ch.len[c];
         const uint32_t pb = rp.ch.pbase[c];
-        const uint32_t g_end = rp.ch.pbase[c + 1];
+        const uint32_t chunk_end = rp.ch.pbase[c + 1];
+        const uint32_t g_end = min(chunk_end, rp.g_hi);
 
         // live arms: lane j holds arm j while in_regs (A <= 64), else s_*[0..A)
         PosT r_ls = 0, r_le = 0, r_rs = 0, r_re = 0;
@@ -748,7 +765,10 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
         }
         // arms still alive at the end of the chunk are dropped together with the
         // unflushed family they belong to (src/automaton.rs:201-203)
-        if (!overflow && A > 0)
+        if (!done && g_end < chunk_end) {
+            // sharded call: the segment is not finished inside the look-ahead window
+            if (lane == 0) atomicAdd(&P.ctr[CT_RANOUT], 1ull);
+        } else if (!overflow && A > 0)
             emit_records(lane == 0, (PosT)0, (PosT)0, (PosT)0, (PosT)0, kTombstone);
         if (overflow && lane == 0) {
             const unsigned long long at = atomicAdd(&P.ctr[CT_OVF], 1ull);

@@ -241,3 +241,30 @@ def test_index_builds_its_own_suffix_array(case):
         a = idx.search_duplications_raw(pr.chunks, st)
         b = idx2.search_duplications_raw(pr.chunks, st)
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+@pytest.mark.parametrize("name", ["long_sds", "dense_repeats", "satellites", "masked"])
+@pytest.mark.parametrize("halo", ["default", "tiny"])
+def test_shards_concatenate_to_unsharded(hiplib, name, halo, monkeypatch):
+    """Multi-GPU logic on one GPU: shards 0..R-1 of the probe sequence, run one after the other,
+    must concatenate to exactly the unsharded result (segments are never split; no exchange).
+    `tiny` halos force the look-back / look-ahead retry paths."""
+    if halo == "tiny":
+        monkeypatch.setenv("ASGART_SHARD_LOOKBACK", "2")
+        monkeypatch.setenv("ASGART_SHARD_LOOKAHEAD", "3")
+    pr, cli = _battery_case(name)
+    sa = oracle.divsufsort64(pr.data)
+    with asgart_amd.Index(pr.data, sa) as idx:
+        for reverse, complement in ((False, False), (True, True)):
+            st = asgart_amd.RunSettings.from_cli(reverse=reverse, complement=complement, **cli)
+            offs, sds = idx.search_duplications_raw(pr.chunks, st)
+            for R in (2, 3, 8, 61):
+                fam_counts, parts = [], []
+                for r in range(R):
+                    o, s_ = idx.search_duplications_raw(pr.chunks, st, shard=r, n_shards=R)
+                    fam_counts.append(np.diff(o.astype(np.int64)))
+                    parts.append(s_)
+                got_sds = np.concatenate(parts) if parts else np.zeros((0, 4), np.uint64)
+                got_offs = np.concatenate([[0], np.cumsum(np.concatenate(fam_counts))]).astype(np.uint64)
+                assert np.array_equal(got_offs, offs), (name, R, reverse)
+                assert np.array_equal(got_sds, sds), (name, R, reverse)
