@@ -12,8 +12,9 @@
 namespace asgart {
 
 constexpr int kArmCapSmall = 256;   // live arms per wave in LDS, common case
-constexpr int kArmCapBig32 = 4608;  // whole-CU LDS tier (32-bit positions): 4608*32 B + hits = 148 KiB
-constexpr int kArmCapBig64 = 3072;  // 64-bit positions: 3072*48 B + hits = 152 KiB
+constexpr int kArmCapMid = 1024;    // second tier: same kernel, 3 waves per CU
+constexpr int kArmCapBig32 = 3072;  // heavy tier, 32-bit positions: 3072*40 B + hits + scratch = 128 KiB
+constexpr int kArmCapBig64 = 2048;  // heavy tier, 64-bit positions: 2048*60 B + hits + scratch = 132 KiB
 
 static inline unsigned grid_for(uint64_t n, unsigned block = 256) {
     return (unsigned)((n + block - 1) / block);
@@ -101,7 +102,8 @@ static int32_t run_search_t(asgart_index *idx, const uint64_t *chunks, int64_t n
                            hipMemcpyHostToDevice, s));
 
     unsigned long long h_ctr[CT_COUNT];
-    uint64_t total_hits = 0, n_seg = 0;
+    uint64_t total_hits = 0, n_seg = 0, n_overflow = 0, n_heavy = 0;
+    double ms_tier2 = 0.0;
     RunParams rp;
     const auto t_host0 = std::chrono::steady_clock::now();
     for (int win_try = 0;; ++win_try) {
@@ -212,7 +214,7 @@ static int32_t run_search_t(asgart_index *idx, const uint64_t *chunks, int64_t n
     // ---- K4: extension automaton ------------------------------------------------
     if (fam_out && n_seg) {
         uint64_t rec_cap = std::max<uint64_t>(1u << 18, w.fam_sds.cap / sizeof(SdRec));
-        RC_TRY(w.ovf_list.reserve((size_t)(n_seg + 1) * 4));
+        RC_TRY(w.ovf_list.reserve((size_t)(n_seg + 1) * 8));
         std::vector<SdRec> h_recs;
         for (int attempt = 0;; ++attempt) {
             RC_TRY(w.fam_sds.reserve((size_t)rec_cap * sizeof(SdRec)));
@@ -235,24 +237,45 @@ static int32_t run_search_t(asgart_index *idx, const uint64_t *chunks, int64_t n
             HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, sizeof(h_ctr), hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
             if (h_ctr[CT_OVF]) {
-                // second tier: one wave per CU with (almost) the whole LDS for live arms
-                const uint64_t n_ovf = h_ctr[CT_OVF];
-                HIP_TRY(hipMemsetAsync(d_ctr + CT_OVF, 0, 8, s));
-                HIP_TRY(hipMemsetAsync(d_ctr + CT_OVF_CURSOR, 0, 8, s));
-                // n_seg_ptr must point at a device word holding n_ovf: reuse the CT_BISECT slot
-                HIP_TRY(hipMemcpyAsync(d_ctr + CT_BISECT, &n_ovf, 8, hipMemcpyHostToDevice, s));
-                ep.seg_list = w.ovf_list.as<uint32_t>();
-                ep.n_seg_ptr = d_ctr + CT_BISECT;
-                ep.cursor = d_ctr + CT_OVF_CURSOR;
-                ep.ovf_list = nullptr;
-                const unsigned bw = (unsigned)std::min<uint64_t>(n_ovf, 256ull);
-                if constexpr (sizeof(SlotT) == 4)
-                    extend_kernel<SlotT, kArmCapBig32><<<bw, 64, 0, s>>>(ep);
-                else
-                    extend_kernel<SlotT, kArmCapBig64><<<bw, 64, 0, s>>>(ep);
-                HIP_TRY(hipGetLastError());
-                HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, sizeof(h_ctr), hipMemcpyDeviceToHost, s));
+                // Escalation: segments the one-wave kernel gave up on are re-run from their start
+                // by (tier 2) the same kernel with a 4x larger LDS share, then (tier 3) the
+                // block-cooperative heavy kernel, one workgroup per CU.
+                n_overflow = h_ctr[CT_OVF];
+                HIP_TRY(hipEventRecord(idx->ev[5], s));
+                uint32_t *list_a = w.ovf_list.as<uint32_t>();
+                uint32_t *list_b = list_a + (n_seg + 1);
+                for (int tier = 2; tier <= 3 && h_ctr[CT_OVF]; ++tier) {
+                    const uint64_t n_ovf = h_ctr[CT_OVF];
+                    HIP_TRY(hipMemsetAsync(d_ctr + CT_OVF, 0, 8, s));
+                    HIP_TRY(hipMemsetAsync(d_ctr + CT_OVF_CURSOR, 0, 8, s));
+                    // n_seg_ptr must point at a device word holding the list length
+                    HIP_TRY(hipMemcpyAsync(d_ctr + CT_BISECT, &n_ovf, 8, hipMemcpyHostToDevice, s));
+                    ep.seg_list = tier == 2 ? list_a : list_b;
+                    ep.n_seg_ptr = d_ctr + CT_BISECT;
+                    ep.cursor = d_ctr + CT_OVF_CURSOR;
+                    ep.ovf_list = tier == 2 ? list_b : nullptr;
+                    if (tier == 2) {
+                        const unsigned mw = (unsigned)std::min<uint64_t>(n_ovf, 256ull * 3ull);
+                        extend_kernel<SlotT, kArmCapMid><<<mw, 64, 0, s>>>(ep);
+                    } else {
+                        const unsigned bw = (unsigned)std::min<uint64_t>(n_ovf, 256ull);
+                        if constexpr (sizeof(SlotT) == 4)
+                            extend_heavy_kernel<SlotT, kArmCapBig32><<<bw, kHeavyThreads, 0, s>>>(ep);
+                        else
+                            extend_heavy_kernel<SlotT, kArmCapBig64><<<bw, kHeavyThreads, 0, s>>>(ep);
+                    }
+                    HIP_TRY(hipGetLastError());
+                    HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, sizeof(h_ctr), hipMemcpyDeviceToHost, s));
+                    HIP_TRY(hipStreamSynchronize(s));
+                    if (tier == 2) n_heavy = h_ctr[CT_OVF];
+                }
+                HIP_TRY(hipEventRecord(idx->ev[6], s));
                 HIP_TRY(hipStreamSynchronize(s));
+                {
+                    float t2 = 0.f;
+                    HIP_TRY(hipEventElapsedTime(&t2, idx->ev[5], idx->ev[6]));
+                    ms_tier2 = t2;
+                }
                 if (h_ctr[CT_OVF]) {
                     set_error("%llu segment(s) need more than %d simultaneously live arms; "
                               "not supported by this build",
@@ -333,6 +356,18 @@ static int32_t run_search_t(asgart_index *idx, const uint64_t *chunks, int64_t n
     stt.families = fam_out ? fam_out->fam_offsets.size() - 1 : 0;
     stt.proto_sds = fam_out ? fam_out->sds.size() : 0;
     stt.search_launches = 1;
+    stt.overflow_segments = n_overflow;
+    stt.heavy_segments = n_heavy;
+#ifdef ASGART_PROFILE_EXTEND
+    fprintf(stderr, "[extend profile] stage_cyc=%llu batches=%llu | reg_cyc=%llu reg_probes=%llu | "
+            "lds: build_cyc=%llu probes=%llu hits_cyc=%llu apply_cyc=%llu retire_cyc=%llu | sumA=%llu sumCnt=%llu\n",
+            h_ctr[16], h_ctr[17], h_ctr[18], h_ctr[19], h_ctr[20], h_ctr[21], h_ctr[22], h_ctr[23],
+            h_ctr[24], h_ctr[26], h_ctr[27]);
+    fprintf(stderr, "[extend profile] longest segment: %llu cycles, g0=%llu, lds_probes=%llu reg_probes=%llu "
+            "sumA=%llu sumCnt=%llu stage_cyc=%llu hits_cyc=%llu\n", h_ctr[28], h_ctr[29], h_ctr[30] >> 32,
+            h_ctr[30] & 0xffffffffull, h_ctr[31] >> 32, h_ctr[31] & 0xffffffffull, h_ctr[32], h_ctr[33]);
+#endif
+    stt.ms_extend_tier2 = ms_tier2;
     idx->has_last = true;
     return 0;
 }

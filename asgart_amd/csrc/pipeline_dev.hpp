@@ -38,7 +38,7 @@ enum Counter {
     CT_OVF_CURSOR,
     CT_AMBIG,         // sharding: start decisions that need a longer look-back
     CT_RANOUT,        // sharding: segments that ran past the look-ahead window
-    CT_COUNT = 32
+    CT_COUNT = 48
 };
 
 __device__ inline int chunk_of(const ChunkTable &ch, uint32_t g) {
@@ -428,7 +428,40 @@ struct SdRec {
 };
 
 constexpr uint32_t kTombstone = 0xFFFFFFFFu;
+
+// Diagnostic build only (-DASGART_PROFILE_EXTEND): per-phase cycle sums of the extension kernel
+// are added to ctr[16..]; never enabled in the shipped library.
+#ifdef ASGART_PROFILE_EXTEND
+#define PROF_DECL unsigned long long pf_t0 = 0, pf_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define PROF_START() pf_t0 = __builtin_amdgcn_s_memtime()
+#define PROF_STOP(slot) pf_acc[slot] += __builtin_amdgcn_s_memtime() - pf_t0
+#define PROF_COUNT(slot, v) pf_acc[slot] += (v)
+#define PROF_SEG_BEGIN() const unsigned long long pf_seg0 = __builtin_amdgcn_s_memtime()
+#define PROF_FLUSH()                                                             \
+    do {                                                                         \
+        const unsigned long long pf_dt = __builtin_amdgcn_s_memtime() - pf_seg0; \
+        if (lane == 0 && atomicMax(&P.ctr[28], pf_dt) < pf_dt) {                 \
+            P.ctr[29] = g0;                                                      \
+            P.ctr[30] = ((unsigned long long)pf_acc[5] << 32) | pf_acc[3];       \
+            P.ctr[31] = ((unsigned long long)pf_acc[10] << 32) | pf_acc[11];     \
+            P.ctr[32] = pf_acc[0];                                               \
+            P.ctr[33] = pf_acc[6];                                               \
+        }                                                                        \
+        if (lane == 0)                                                           \
+            for (int pf_i = 0; pf_i < 12; ++pf_i)                                \
+                if (pf_acc[pf_i]) atomicAdd(&P.ctr[16 + pf_i], pf_acc[pf_i]);     \
+        for (int pf_i = 0; pf_i < 12; ++pf_i) pf_acc[pf_i] = 0;                  \
+    } while (0)
+#else
+#define PROF_DECL
+#define PROF_START()
+#define PROF_STOP(slot)
+#define PROF_COUNT(slot, v)
+#define PROF_SEG_BEGIN()
+#define PROF_FLUSH()
+#endif
 constexpr int kHitBatch = 1024;  // LDS staging for the hit rows of one probe batch
+constexpr uint32_t kEscalateCost = 40000;  // sum of (live arms + hits) over LDS-path probes
 
 template <class PosT>
 struct ExtParams {
@@ -445,14 +478,21 @@ struct ExtParams {
     unsigned long long *ctr;
 };
 
-// d_ss(a.right, m) < thr   (src/automaton.rs:69, :207-216)
-__device__ inline bool dss_lt(long long as, long long ae, long long ms, long long me,
-                              long long thr) {
-    if ((ms >= as && ms <= ae) || (me >= as && me <= ae)) return 0 < thr;
-    long long d1 = as - me, d2 = ae - ms;
-    d1 = d1 < 0 ? -d1 : d1;
-    d2 = d2 < 0 ? -d2 : d2;
-    return (d1 < d2 ? d1 : d2) < thr;
+// The whole predicate of try_extend_arms (src/automaton.rs:68-70) for an active arm with right
+// segment [rs, re], threshold thr, and a hit m = [x, x+k]:
+//     d_ss(a.right, m) < thr  &&  m.end > a.right.end
+// Because len(right) >= k always (an arm starts as [x0, x0+k] and re only grows), this is
+// exactly   re - k < x < re + thr   (thr >= 1), i.e. (x - lo) < w in unsigned arithmetic with
+// lo = re - k + 1, w = thr + k - 1:
+//   x <= re : x > re-k >= rs so m.start lies in [rs, re]            -> d_ss = 0 < thr
+//   x >  re : no containment, d_ss = min(x+k-rs, x-re) = x - re     -> accept iff x - re < thr
+// (thr == 0 accepts nothing.)  tests/test_oracle_golden.py checks the equivalence exhaustively
+// against the oracle's literal d_ss.
+template <class PosT>
+__device__ inline bool arm_accepts(PosT x, PosT re, uint32_t thr, uint32_t k) {
+    const PosT lo = (PosT)(re - k + 1u);
+    const uint64_t w = thr ? (uint64_t)thr + k - 1u : 0u;
+    return (uint64_t)(PosT)(x - lo) < w;
 }
 
 // max(e, (0.1 * len as f64) as i64)   (src/automaton.rs:69)
@@ -467,12 +507,19 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
     __shared__ PosT s_ls[CAP], s_le[CAP], s_rs[CAP], s_re[CAP];
     __shared__ uint32_t s_gap[CAP], s_thr[CAP], s_seq[CAP], s_pend[CAP];
     __shared__ PosT s_hits[kHitBatch];
+    // candidate index of the LDS path: arms bucketed by right end (see "LDS path")
+    constexpr uint32_t HT = CAP <= 256 ? 256u : (CAP <= 1024 ? 1024u : 4096u);
+    __shared__ uint32_t s_head[HT];
+    __shared__ uint16_t s_next[CAP], s_wide[CAP];
+    __shared__ PosT s_wlo[CAP];      // wide arms, packed: accepts x iff (x - s_wlo[w]) < s_ww[w]
+    __shared__ uint32_t s_ww[CAP];
     const int lane = threadIdx.x;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const RunParams &rp = P.rp;
     const uint64_t n_seg = *P.n_seg_ptr;
     const uint32_t k = (uint32_t)rp.k, step = (uint32_t)rp.step, G = rp.G;
     const uint32_t thr0 = arm_threshold(k, G);
+    PROF_DECL;
 
     for (;;) {
         unsigned long long seg = 0;
@@ -480,6 +527,7 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
         seg = __shfl(seg, 0);
         if (seg >= n_seg) break;
         const uint32_t g0 = P.seg_list[seg];
+        PROF_SEG_BEGIN();
         const int c = chunk_of(rp.ch, g0);
         const uint64_t cs = rp.ch.start[c], cl = rp.ch.len[c];
         const uint32_t pb = rp.ch.pbase[c];
@@ -489,7 +537,7 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
         // live arms: lane j holds arm j while in_regs (A <= 64), else s_*[0..A)
         PosT r_ls = 0, r_le = 0, r_rs = 0, r_re = 0;
         uint32_t r_gap = 0, r_thr = 0, r_seq = 0;
-        uint32_t A = 0, quiet = 0, fam_seq = 0, next_seq = 0;
+        uint32_t A = 0, quiet = 0, fam_seq = 0, next_seq = 0, lds_cost = 0;
         bool in_regs = true, overflow = false, done = false;
 
         // ---- helpers -------------------------------------------------------
@@ -603,8 +651,11 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
                         s_gap[j] = gp + add < gp ? 0xFFFFFFFFu : gp + add;
                     }
                     __syncthreads();
+                    PROF_STOP(7);
+                    PROF_START();
                     retire_lds();
                     if (A <= 32) to_regs();
+                    PROF_STOP(8);
                 }
             }
             if (A == 0 && quiet >= rp.tstar) done = true;
@@ -612,6 +663,7 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
 
         for (uint32_t g = g0; g < g_end && !done;) {
             // ---- stage a batch of up to 64 probes ------------------------------
+            PROF_START();
             const uint32_t nb = min(64u, g_end - g);
             const uint32_t f_l = (uint32_t)lane < nb ? P.p_filt[g + lane] : kSkipN;
             const unsigned long long r_l = (uint32_t)lane < nb ? P.row_off[g + lane] : 0ull;
@@ -632,12 +684,25 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
             if (!first_from_global) {
                 const unsigned long long end = nbb == nb ? r_hi : __shfl(r_l, (int)nbb);
                 const uint32_t tot = (uint32_t)(end - base);
-                for (uint32_t r = lane; r < tot; r += 64) s_hits[r] = P.hits[base + r];
+                // all loads in flight before the first LDS write (one HBM round trip, not 16)
+                PosT tmp[kHitBatch / 64];
+#pragma unroll
+                for (int u = 0; u < kHitBatch / 64; ++u) {
+                    const uint32_t r = lane + 64u * u;
+                    tmp[u] = r < tot ? P.hits[base + r] : (PosT)0;
+                }
+#pragma unroll
+                for (int u = 0; u < kHitBatch / 64; ++u) {
+                    const uint32_t r = lane + 64u * u;
+                    if (r < tot) s_hits[r] = tmp[u];
+                }
             }
             __syncthreads();
             const unsigned long long in_batch = nbb >= 64 ? ~0ull : ((1ull << nbb) - 1ull);
             const unsigned long long hm = __ballot(f_l >= 1u && f_l < kPending) & in_batch;
             const unsigned long long qm = __ballot(f_l == 0u) & in_batch;
+            PROF_STOP(0);
+            PROF_COUNT(1, 1);
             uint32_t pos = 0;
             while (!done) {
                 const unsigned long long hmr = pos >= 64 ? 0ull : (hm >> pos) << pos;
@@ -659,15 +724,14 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
                 const unsigned long long row = base + off;
                 if (in_regs && A + cnt <= 64u && !first_from_global) {
                     // ---------------- register path -------------------------------
+                    PROF_START();
+                    PROF_COUNT(3, 1);
                     bool pend = false;
                     PosT pend_x = 0;
                     uint32_t newc = 0;
                     for (uint32_t t = 0; t < cnt; ++t) {
                         const PosT x = s_hits[off + t];
-                        const long long ms = (long long)x, me = (long long)x + k;
-                        const bool ok = (uint32_t)lane < A && me > (long long)r_re &&
-                                        dss_lt((long long)r_rs, (long long)r_re, ms, me,
-                                               (long long)r_thr);
+                        const bool ok = (uint32_t)lane < A && arm_accepts<PosT>(x, r_re, r_thr, k);
                         const unsigned long long m = __ballot(ok);
                         if (m) {  // ExtendArm on the first matching arm; last hit wins
                             if (lane == __ffsll((long long)m) - 1) {
@@ -697,30 +761,93 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
                     A += newc;
                     next_seq += newc;
                     retire_regs();
+                    PROF_STOP(2);
                 } else {
                     // ---------------- LDS path ------------------------------------
                     if (in_regs) to_lds();
-                    if (A + cnt > (uint32_t)CAP) {
+                    // hand the segment to the block-cooperative heavy tier when it does not fit
+                    // this wave's LDS share, or keeps producing many-hit x many-arm probes
+                    lds_cost += A + cnt;
+                    if (A + cnt > (uint32_t)CAP || lds_cost > kEscalateCost) {
                         overflow = true;
                         done = true;
                         break;
                     }
                     const uint32_t A_old = A;
                     const bool from_lds = !first_from_global;
+                    PROF_COUNT(5, 1);
+                    PROF_COUNT(10, A_old);
+                    PROF_COUNT(11, cnt);
+                    PROF_START();
+                    // An arm accepts hit x iff  re - k < x < re + thr  (d_ss of src/automaton.rs:207-216
+                    // with m = [x, x+k) and len(right) >= k).  So instead of testing every arm
+                    // (automaton.rs:67-78) the arms whose thr is the floor G ("narrow") are hashed by
+                    // bucket(re) with bucket width G + k: a hit can only be accepted by narrow arms
+                    // in two buckets.  The few arms with a long left segment (thr > G) are kept in a
+                    // list and tested one by one.  The answer is the smallest accepting arm index.
+                    const uint32_t Wb = G + k;
+                    uint32_t hmask = 63u;  // table sized to the live arms (power of two <= HT)
+                    while (hmask + 1u < HT && hmask + 1u < 2u * A_old) hmask = (hmask << 1) | 1u;
+                    for (uint32_t h = lane; h <= hmask; h += 64) s_head[h] = 0xFFFFFFFFu;
+                    __syncthreads();
+                    uint32_t n_wide = 0;
+                    for (uint32_t t0 = 0; t0 < A_old; t0 += 64) {
+                        const uint32_t j = t0 + lane;
+                        const bool valid = j < A_old;
+                        const bool narrow = valid && s_thr[j] <= G;
+                        if (narrow) {
+                            const uint32_t b = (uint32_t)((uint64_t)s_re[j] / Wb);
+                            const uint32_t h = ((b * 2654435761u) >> 12) & hmask;
+                            s_next[j] = (uint16_t)atomicExch(&s_head[h], j);
+                        }
+                        const unsigned long long wm = __ballot(valid && !narrow);
+                        if (valid && !narrow) {
+                            const uint32_t d = n_wide + __popcll(wm & lt_mask);
+                            const uint32_t th = s_thr[j];
+                            const uint64_t wv = (uint64_t)th + k - 1u;
+                            s_wide[d] = (uint16_t)j;
+                            s_wlo[d] = (PosT)(s_re[j] - k + 1u);
+                            s_ww[d] = wv > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)wv;
+                        }
+                        n_wide += __popcll(wm);
+                    }
+                    __syncthreads();
+                    PROF_STOP(4);
+                    PROF_START();
                     for (uint32_t t0 = 0; t0 < cnt; t0 += 64) {
                         const uint32_t t = t0 + lane;
                         const bool valid = t < cnt;
                         PosT x = 0;
                         if (valid) x = from_lds ? s_hits[off + t] : P.hits[row + t];
-                        const long long ms = (long long)x, me = (long long)x + k;
-                        int found = -1;
-                        for (uint32_t j = 0; j < A_old; ++j) {
-                            const long long re = (long long)s_re[j];
-                            if (valid && found < 0 && me > re &&
-                                dss_lt((long long)s_rs[j], re, ms, me, (long long)s_thr[j]))
-                                found = (int)j;
-                            if ((j & 7u) == 7u && __ballot(valid && found < 0) == 0ull) break;
+                        uint32_t best = 0xFFFFFFFFu;
+                        if (valid) {
+                            // narrow candidates: re in (x - G, x + k)
+                            const uint64_t lo_re = (uint64_t)x + 1u > (uint64_t)G ? (uint64_t)x + 1u - G : 0u;
+                            const uint32_t b0 = (uint32_t)(lo_re / Wb);
+                            const uint32_t b1 = (uint32_t)(((uint64_t)x + k - 1u) / Wb);
+                            for (uint32_t b = b0; b <= b1; ++b) {
+                                uint32_t j = s_head[((b * 2654435761u) >> 12) & hmask];
+                                while (j != 0xFFFFFFFFu && j != 0xFFFFu) {
+                                    if (j < best && arm_accepts<PosT>(x, s_re[j], s_thr[j], k)) best = j;
+                                    j = s_next[j];
+                                }
+                            }
                         }
+                        {   // wide arms: branch-free scan of the packed list (increasing arm index)
+                            uint32_t wbest = 0xFFFFFFFFu;
+                            uint32_t wdx = 0;
+                            for (; wdx + 4 <= n_wide; wdx += 4) {
+                                const uint32_t a0 = (uint64_t)(PosT)(x - s_wlo[wdx]) < s_ww[wdx] ? wdx : 0xFFFFFFFFu;
+                                const uint32_t a1 = (uint64_t)(PosT)(x - s_wlo[wdx + 1]) < s_ww[wdx + 1] ? wdx + 1 : 0xFFFFFFFFu;
+                                const uint32_t a2 = (uint64_t)(PosT)(x - s_wlo[wdx + 2]) < s_ww[wdx + 2] ? wdx + 2 : 0xFFFFFFFFu;
+                                const uint32_t a3 = (uint64_t)(PosT)(x - s_wlo[wdx + 3]) < s_ww[wdx + 3] ? wdx + 3 : 0xFFFFFFFFu;
+                                wbest = min(wbest, min(min(a0, a1), min(a2, a3)));
+                            }
+                            for (; wdx < n_wide; ++wdx)
+                                wbest = min(wbest, (uint64_t)(PosT)(x - s_wlo[wdx]) < s_ww[wdx] ? wdx : 0xFFFFFFFFu);
+                            if (valid && wbest != 0xFFFFFFFFu) best = min(best, (uint32_t)s_wide[wbest]);
+                        }
+                        const int found = best == 0xFFFFFFFFu ? -1 : (int)best;
                         if (valid && found >= 0) atomicMax(&s_pend[found], t + 1u);
                         const bool is_new = valid && found < 0;
                         const unsigned long long m = __ballot(is_new);
@@ -737,6 +864,8 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
                     }
                     next_seq += A - A_old;
                     __syncthreads();
+                    PROF_STOP(6);
+                    PROF_START();
                     for (uint32_t j = lane; j < A_old; j += 64) {
                         const uint32_t pd = s_pend[j];
                         if (pd) {
@@ -751,8 +880,11 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
                         }
                     }
                     __syncthreads();
+                    PROF_STOP(7);
+                    PROF_START();
                     retire_lds();
                     if (A <= 32) to_regs();
+                    PROF_STOP(8);
                 }
             }
             if (!done) {
@@ -770,9 +902,320 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
             if (lane == 0) atomicAdd(&P.ctr[CT_RANOUT], 1ull);
         } else if (!overflow && A > 0)
             emit_records(lane == 0, (PosT)0, (PosT)0, (PosT)0, (PosT)0, kTombstone);
+        PROF_COUNT(9, 1);
+        PROF_FLUSH();
         if (overflow && lane == 0) {
             const unsigned long long at = atomicAdd(&P.ctr[CT_OVF], 1ull);
             if (P.ovf_list) P.ovf_list[at] = g0;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------- K4b --------
+// Heavy tier of the extension automaton: ONE 1024-thread workgroup (16 waves, a whole CU's
+// LDS) per segment.  Used for the segments that the one-wave kernel gives up on (more live
+// arms than its LDS share, or a long run of many-hit probes): satellite-array tails and dense
+// repeat clusters, where a probe has hundreds of hits against hundreds of live arms.  Same
+// representation and results as extend_kernel; every per-probe phase is spread over the block:
+//   match   thread = (hit, arm-range part): scans its arm range in index order, first accept
+//           -> atomicMin on the hit's best arm
+//   new     order-preserving slots for NewArm by a block-wide ballot scan
+//   apply   arms strided over threads; retire/compact with a block-wide ordered scan
+constexpr int kHeavyThreads = 1024;
+constexpr int kHeavyWaves = kHeavyThreads / 64;
+
+// ordered exclusive prefix of a per-thread flag over the block (thread id order)
+__device__ inline uint32_t block_flag_scan(bool flag, uint32_t *s_wsum, uint32_t *total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long m = __ballot(flag);
+    if (lane == 0) s_wsum[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t before = 0, tot = 0;
+    for (int wv = 0; wv < kHeavyWaves; ++wv) {
+        const uint32_t v = s_wsum[wv];
+        if (wv < wave) before += v;
+        tot += v;
+    }
+    __syncthreads();
+    *total = tot;
+    return before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+}
+
+template <class PosT, int CAP>
+__global__ __launch_bounds__(kHeavyThreads) void extend_heavy_kernel(ExtParams<PosT> P) {
+    __shared__ PosT s_ls[CAP], s_le[CAP], s_rs[CAP], s_re[CAP];
+    __shared__ uint32_t s_gap[CAP], s_thr[CAP], s_seq[CAP], s_pend[CAP];
+    __shared__ PosT s_hits[kHitBatch];
+    __shared__ uint32_t s_best[kHeavyThreads];
+    __shared__ PosT s_ivlo[CAP];      // acceptance interval of arm j for this probe:
+    __shared__ uint32_t s_ivw[CAP];   //   accepts x  iff  (x - s_ivlo[j]) < s_ivw[j]  (unsigned)
+    __shared__ uint32_t s_wsum[kHeavyWaves];
+    __shared__ unsigned long long s_bcast;
+    constexpr int PER = (CAP + kHeavyThreads - 1) / kHeavyThreads;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const RunParams &rp = P.rp;
+    const uint64_t n_seg = *P.n_seg_ptr;
+    const uint32_t k = (uint32_t)rp.k, step = (uint32_t)rp.step, G = rp.G;
+    const uint32_t thr0 = arm_threshold(k, G);
+    PROF_DECL;
+
+    for (;;) {
+        if (tid == 0) s_bcast = atomicAdd(P.cursor, 1ull);
+        __syncthreads();
+        const unsigned long long seg = s_bcast;
+        __syncthreads();
+        if (seg >= n_seg) break;
+        const uint32_t g0 = P.seg_list[seg];
+        PROF_SEG_BEGIN();
+        const int c = chunk_of(rp.ch, g0);
+        const uint64_t cs = rp.ch.start[c], cl = rp.ch.len[c];
+        const uint32_t pb = rp.ch.pbase[c];
+        const uint32_t chunk_end = rp.ch.pbase[c + 1];
+        const uint32_t g_end = min(chunk_end, rp.g_hi);
+        uint32_t A = 0, quiet = 0, fam_seq = 0, next_seq = 0;
+        bool overflow = false, done = false;
+
+        // per-wave aggregated append of output records
+        auto emit_records = [&](bool emit, PosT ls, PosT le, PosT rs, PosT re, uint32_t seq) {
+            const unsigned long long em = __ballot(emit);
+            if (!em) return;
+            const int leader = __ffsll((long long)em) - 1;
+            unsigned long long base = 0;
+            if (lane == leader) base = atomicAdd(&P.ctr[CT_SD], (unsigned long long)__popcll(em));
+            base = __shfl(base, leader);
+            if (emit) {
+                const unsigned long long at = base + __popcll(em & lt_mask);
+                if (at < P.rec_cap) {
+                    const uint64_t ll = (uint64_t)le - (uint64_t)ls;
+                    SdRec r;
+                    r.g_start = g0;
+                    r.fam_seq = fam_seq;
+                    r.create_seq = seq;
+                    r.pad = 0;
+                    r.sd.left = rp.reverse ? cs + cl - (uint64_t)ls - ll : (uint64_t)ls + cs;
+                    r.sd.right = rs;
+                    r.sd.left_length = ll;
+                    r.sd.right_length = (uint64_t)re - (uint64_t)rs;
+                    P.recs[at] = r;
+                }
+            }
+        };
+        // retire arms whose gap reached G; order-preserving compaction over the whole block
+        auto retire = [&]() {
+            PosT ls[PER], le[PER], rs[PER], re[PER];
+            uint32_t gp[PER], th[PER], sq[PER];
+            bool alive[PER];
+            bool any_dead = false;
+#pragma unroll
+            for (int u = 0; u < PER; ++u) {
+                const uint32_t j = (uint32_t)u * kHeavyThreads + tid;
+                const bool valid = j < A;
+                ls[u] = le[u] = rs[u] = re[u] = 0;
+                gp[u] = th[u] = sq[u] = 0;
+                if (valid) {
+                    ls[u] = s_ls[j]; le[u] = s_le[j]; rs[u] = s_rs[j]; re[u] = s_re[j];
+                    gp[u] = s_gap[j]; th[u] = s_thr[j]; sq[u] = s_seq[j];
+                }
+                const bool dead = valid && gp[u] >= G;
+                alive[u] = valid && !dead;
+                any_dead |= dead;
+                emit_records(dead && (uint64_t)(re[u] - rs[u]) >= rp.M, ls[u], le[u], rs[u], re[u], sq[u]);
+            }
+            uint32_t n_dead_total = 0;
+            (void)block_flag_scan(any_dead, s_wsum, &n_dead_total);
+            if (n_dead_total == 0) return;  // block-uniform
+            uint32_t w = 0;
+#pragma unroll
+            for (int u = 0; u < PER; ++u) {
+                uint32_t tot = 0;
+                const uint32_t d = w + block_flag_scan(alive[u], s_wsum, &tot);
+                if (alive[u]) {
+                    s_ls[d] = ls[u]; s_le[d] = le[u]; s_rs[d] = rs[u]; s_re[d] = re[u];
+                    s_gap[d] = gp[u]; s_thr[d] = th[u]; s_seq[d] = sq[u]; s_pend[d] = 0;
+                }
+                w += tot;
+            }
+            __syncthreads();
+            const bool was_nonempty = A > 0;
+            A = w;
+            if (A == 0 && was_nonempty) {
+                ++fam_seq;
+                next_seq = 0;
+            }
+        };
+        auto advance_quiet = [&](uint32_t q) {
+            quiet += q;
+            if (A > 0) {
+                const uint32_t add = q * step;
+                for (uint32_t j = tid; j < A; j += kHeavyThreads) {
+                    const uint32_t gp = s_gap[j];
+                    s_gap[j] = gp + add < gp ? 0xFFFFFFFFu : gp + add;
+                }
+                __syncthreads();
+                retire();
+            }
+            if (A == 0 && quiet >= rp.tstar) done = true;
+        };
+
+        for (uint32_t g = g0; g < g_end && !done;) {
+            // ---- stage a batch of up to 64 probes (every wave computes the same masks) ----
+            PROF_START();
+            const uint32_t nb = min(64u, g_end - g);
+            const uint32_t f_l = (uint32_t)lane < nb ? P.p_filt[g + lane] : kSkipN;
+            const unsigned long long r_l = (uint32_t)lane < nb ? P.row_off[g + lane] : 0ull;
+            const unsigned long long r_hi = P.row_off[g + nb];
+            const unsigned long long base = __shfl(r_l, 0);
+            unsigned long long r_next = __shfl_down(r_l, 1);
+            if ((uint32_t)lane + 1 >= nb) r_next = r_hi;
+            const bool fits = (uint32_t)lane < nb && r_next - base <= (unsigned long long)kHitBatch;
+            const unsigned long long fm = __ballot(fits);
+            uint32_t nbb = (~fm == 0ull) ? 64u : (uint32_t)(__ffsll((long long)~fm) - 1);
+            if (nbb > nb) nbb = nb;
+            bool first_from_global = false;
+            if (nbb == 0) {
+                nbb = 1;
+                first_from_global = true;
+            }
+            const uint32_t rel_l = (uint32_t)(r_l - base);
+            if (!first_from_global) {
+                const unsigned long long end = nbb == nb ? r_hi : __shfl(r_l, (int)nbb);
+                const uint32_t tot = (uint32_t)(end - base);
+                if ((uint32_t)tid < tot) s_hits[tid] = P.hits[base + tid];
+            }
+            __syncthreads();
+            const unsigned long long in_batch = nbb >= 64 ? ~0ull : ((1ull << nbb) - 1ull);
+            const unsigned long long hm = __ballot(f_l >= 1u && f_l < kPending) & in_batch;
+            const unsigned long long qm = __ballot(f_l == 0u) & in_batch;
+            PROF_STOP(0);
+            PROF_COUNT(1, 1);
+            uint32_t pos = 0;
+            while (!done) {
+                const unsigned long long hmr = pos >= 64 ? 0ull : (hm >> pos) << pos;
+                if (!hmr) break;
+                const uint32_t b = (uint32_t)(__ffsll((long long)hmr) - 1);
+                {
+                    const unsigned long long range = ((1ull << b) - 1ull) & ~((1ull << pos) - 1ull);
+                    const uint32_t q = (uint32_t)__popcll(qm & range);
+                    if (q) {
+                        advance_quiet(q);
+                        if (done) break;
+                    }
+                }
+                quiet = 0;
+                pos = b + 1;
+                const uint32_t cnt = __shfl(f_l, (int)b);
+                const uint32_t off = __shfl(rel_l, (int)b);
+                const uint64_t i = (uint64_t)(g + b - pb + 1) * step;
+                const unsigned long long row = base + off;
+                if (A + cnt > (uint32_t)CAP) {
+                    overflow = true;
+                    done = true;
+                    break;
+                }
+                const uint32_t A_old = A;
+                const bool from_lds = !first_from_global;
+                PROF_COUNT(5, 1);
+                PROF_COUNT(10, A_old);
+                PROF_COUNT(11, cnt);
+                PROF_START();
+                for (uint32_t j = tid; j < A_old; j += kHeavyThreads) {
+                    const uint32_t th = s_thr[j];
+                    const uint64_t wv = th ? (uint64_t)th + k - 1u : 0u;
+                    s_ivlo[j] = (PosT)(s_re[j] - k + 1u);
+                    s_ivw[j] = wv > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)wv;
+                }
+                __syncthreads();
+                for (uint32_t t0 = 0; t0 < cnt; t0 += kHeavyThreads) {
+                    const uint32_t ct = min((uint32_t)kHeavyThreads, cnt - t0);
+                    const uint32_t Hr = (ct + 63u) & ~63u;          // hits rounded up to waves
+                    const uint32_t NP = kHeavyThreads / Hr;         // arm-range parts
+                    s_best[tid] = 0xFFFFFFFFu;
+                    __syncthreads();
+                    const uint32_t tl = (uint32_t)tid % Hr, part = (uint32_t)tid / Hr;
+                    const bool valid = tl < ct && part < NP;
+                    PosT x = 0;
+                    if (valid) x = from_lds ? s_hits[off + t0 + tl] : P.hits[row + t0 + tl];
+                    if (part < NP) {  // wave-uniform
+                        const uint32_t j0 = (uint32_t)((uint64_t)A_old * part / NP);
+                        const uint32_t j1 = (uint32_t)((uint64_t)A_old * (part + 1) / NP);
+                        uint32_t found = 0xFFFFFFFFu;
+                        // branch-free scan in index order: the smallest accepting index wins
+                        uint32_t j = j0;
+                        for (; j + 4 <= j1; j += 4) {
+                            const uint32_t a0 = (uint64_t)(PosT)(x - s_ivlo[j]) < s_ivw[j] ? j : 0xFFFFFFFFu;
+                            const uint32_t a1 = (uint64_t)(PosT)(x - s_ivlo[j + 1]) < s_ivw[j + 1] ? j + 1 : 0xFFFFFFFFu;
+                            const uint32_t a2 = (uint64_t)(PosT)(x - s_ivlo[j + 2]) < s_ivw[j + 2] ? j + 2 : 0xFFFFFFFFu;
+                            const uint32_t a3 = (uint64_t)(PosT)(x - s_ivlo[j + 3]) < s_ivw[j + 3] ? j + 3 : 0xFFFFFFFFu;
+                            found = min(found, min(min(a0, a1), min(a2, a3)));
+                        }
+                        for (; j < j1; ++j)
+                            found = min(found, (uint64_t)(PosT)(x - s_ivlo[j]) < s_ivw[j] ? j : 0xFFFFFFFFu);
+                        if (valid && found != 0xFFFFFFFFu) atomicMin(&s_best[tl], found);
+                    }
+                    __syncthreads();
+                    // one thread per hit from here on
+                    const bool mine = (uint32_t)tid < ct;
+                    PosT hx = 0;
+                    uint32_t best = 0xFFFFFFFFu;
+                    if (mine) {
+                        hx = from_lds ? s_hits[off + t0 + tid] : P.hits[row + t0 + tid];
+                        best = s_best[tid];
+                        if (best != 0xFFFFFFFFu) atomicMax(&s_pend[best], t0 + tid + 1u);
+                    }
+                    const bool is_new = mine && best == 0xFFFFFFFFu;
+                    uint32_t n_new = 0;
+                    const uint32_t slot = A + block_flag_scan(is_new, s_wsum, &n_new);
+                    if (is_new) {
+                        s_ls[slot] = (PosT)i; s_le[slot] = (PosT)(i + k); s_rs[slot] = hx;
+                        s_re[slot] = (PosT)(hx + k);
+                        s_gap[slot] = step;
+                        s_thr[slot] = thr0;
+                        s_seq[slot] = next_seq + (slot - A_old);
+                        s_pend[slot] = 0;
+                    }
+                    A += n_new;
+                    __syncthreads();
+                }
+                next_seq += A - A_old;
+                PROF_STOP(6);
+                PROF_START();
+                for (uint32_t j = tid; j < A_old; j += kHeavyThreads) {
+                    const uint32_t pd = s_pend[j];
+                    if (pd) {
+                        s_pend[j] = 0;
+                        const PosT x = from_lds ? s_hits[off + pd - 1u] : P.hits[row + pd - 1u];
+                        s_re[j] = (PosT)(x + k);
+                        s_le[j] = (PosT)(i + k);
+                        s_thr[j] = arm_threshold((uint64_t)(i + k) - (uint64_t)s_ls[j], G);
+                        s_gap[j] = 0;
+                    } else {
+                        s_gap[j] += step;
+                    }
+                }
+                __syncthreads();
+                PROF_STOP(7);
+                PROF_START();
+                retire();
+                PROF_STOP(8);
+            }
+            if (!done) {
+                const unsigned long long range = pos >= 64 ? 0ull : ~((1ull << pos) - 1ull);
+                const uint32_t q = (uint32_t)__popcll(qm & range);
+                if (q) advance_quiet(q);
+            }
+            __syncthreads();
+            g += nbb;
+        }
+        if (!done && g_end < chunk_end) {
+            if (tid == 0) atomicAdd(&P.ctr[CT_RANOUT], 1ull);
+        } else if (!overflow && A > 0) {
+            emit_records(tid == 0, (PosT)0, (PosT)0, (PosT)0, (PosT)0, kTombstone);
+        }
+        if (overflow && tid == 0) atomicAdd(&P.ctr[CT_OVF], 1ull);
+        if (tid < 64) {
+            PROF_FLUSH();
         }
         __syncthreads();
     }

@@ -126,7 +126,7 @@ def main():
     sync()
     t0 = time.perf_counter()
     search_ms = 0.0
-    phase_ms = {"search": 0.0, "scan": 0.0, "fill": 0.0, "extend": 0.0}
+    phase_ms = {"search": 0.0, "scan": 0.0, "fill": 0.0, "extend": 0.0, "extend_tier2": 0.0}
     for _ in range(args.steps):
         for st in settings:
             if world > 1:
@@ -188,7 +188,7 @@ def main():
                           "sa_builder": "GPU prefix doubling (asgart_sa_build64 path)"},
         "work_per_step": {key: sum(s[key] for s in pass_stats) for key in
                           ("probes_total", "probes_searched", "probes_card_skipped", "raw_hits",
-                           "filtered_hits", "segments", "families", "proto_sds")},
+                           "filtered_hits", "segments", "overflow_segments", "heavy_segments", "families", "proto_sds")},
     }
 
     if rank == 0 and not args.no_cpu_baseline:

@@ -71,6 +71,9 @@ typedef struct asgart_stats {
     uint64_t bisect_steps;  /* sum ceil(log2(b_p+1)), b_p = 8-mer bucket (yardstick;
                                filled only when ASGART_STATS_YARDSTICK was requested) */
     uint64_t search_launches; /* number of launches of the dominant kernel          */
+    uint64_t overflow_segments; /* segments re-run with a larger LDS share (tier 2)  */
+    double ms_extend_tier2;   /* part of ms_extend spent in the escalation tiers     */
+    uint64_t heavy_segments;  /* segments that went on to the block-cooperative tier */
 } asgart_stats;
 
 typedef struct asgart_index asgart_index;

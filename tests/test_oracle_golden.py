@@ -52,3 +52,18 @@ def test_tenth_threshold_is_integer_division():
     (src/automaton.rs:69); the HIP kernel evaluates the same double expression."""
     lens = np.concatenate([np.arange(0, 2_000_000), np.random.default_rng(1).integers(0, 1 << 40, 1_000_000)])
     assert np.array_equal((0.1 * lens.astype(np.float64)).astype(np.int64), lens // 10)
+
+
+def test_interval_form_of_the_arm_predicate():
+    """The HIP kernels test `re - k < x < re + thr` instead of evaluating d_ss
+    (pipeline_dev.hpp: arm_accepts).  Check it against the oracle's literal d_ss
+    (src/automaton.rs:68-70,207-216) for every small configuration with len(right) >= k."""
+    k = 8
+    for rs in (0, 5, 40):
+        for rlen in range(k, k + 30):
+            re = rs + rlen
+            for thr in (0, 1, 2, 7, 28, 100):
+                for x in range(0, re + thr + 40):
+                    literal = oracle.d_ss((rs, re), (x, x + k)) < thr and x + k > re
+                    fast = thr > 0 and (re - k < x < re + thr)
+                    assert literal == fast, (rs, re, thr, x)
