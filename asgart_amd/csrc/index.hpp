@@ -67,6 +67,7 @@ struct Workspace {
     DevBuf counters;   // u64[32] device counters
     DevBuf fam_sds;    // SdRec[cap] output records of the extension kernel
     DevBuf ovf_list;   // u32 segments that overflowed the small arm tier
+    DevBuf scratch;    // arm storage of the global heavy tier
     DevBuf pat;        // pattern upload scratch
     DevBuf out_a, out_b;
 };

@@ -13,6 +13,8 @@ namespace asgart {
 
 constexpr int kArmCapSmall = 256;   // live arms per wave in LDS, common case
 constexpr int kArmCapMid = 1024;    // second tier: same kernel, 3 waves per CU
+constexpr int kArmCapGlobal32 = 16384;  // last tier: arms in HBM scratch, intervals in LDS (128 KiB)
+constexpr int kArmCapGlobal64 = 8192;
 constexpr int kArmCapBig32 = 3072;  // heavy tier, 32-bit positions: 3072*40 B + hits + scratch = 128 KiB
 constexpr int kArmCapBig64 = 2048;  // heavy tier, 64-bit positions: 2048*60 B + hits + scratch = 132 KiB
 
@@ -230,6 +232,11 @@ static int32_t run_search_t(asgart_index *idx, const uint64_t *chunks, int64_t n
             ep.recs = w.fam_sds.as<SdRec>();
             ep.rec_cap = rec_cap;
             ep.ovf_list = w.ovf_list.as<uint32_t>();
+            ep.scratch = nullptr;
+            // ASGART_FORCE_TIER=t (tests): make every tier below t give up at once
+            const int force_tier = getenv("ASGART_FORCE_TIER") ? atoi(getenv("ASGART_FORCE_TIER")) : 0;
+            ep.escalate_cost = force_tier > 1 ? 0u : kEscalateCost;
+            ep.cap_limit = 0xFFFFFFFFu;
             ep.ctr = d_ctr;
             const unsigned waves = (unsigned)std::min<uint64_t>(n_seg, 256ull * 12ull);
             extend_kernel<SlotT, kArmCapSmall><<<waves, 64, 0, s>>>(ep);
@@ -244,25 +251,34 @@ static int32_t run_search_t(asgart_index *idx, const uint64_t *chunks, int64_t n
                 HIP_TRY(hipEventRecord(idx->ev[5], s));
                 uint32_t *list_a = w.ovf_list.as<uint32_t>();
                 uint32_t *list_b = list_a + (n_seg + 1);
-                for (int tier = 2; tier <= 3 && h_ctr[CT_OVF]; ++tier) {
+                uint32_t *lists[2] = {list_a, list_b};
+                for (int tier = 2; tier <= 4 && h_ctr[CT_OVF]; ++tier) {
                     const uint64_t n_ovf = h_ctr[CT_OVF];
                     HIP_TRY(hipMemsetAsync(d_ctr + CT_OVF, 0, 8, s));
                     HIP_TRY(hipMemsetAsync(d_ctr + CT_OVF_CURSOR, 0, 8, s));
                     // n_seg_ptr must point at a device word holding the list length
                     HIP_TRY(hipMemcpyAsync(d_ctr + CT_BISECT, &n_ovf, 8, hipMemcpyHostToDevice, s));
-                    ep.seg_list = tier == 2 ? list_a : list_b;
+                    ep.seg_list = lists[tier & 1];        // tier 2 reads a, 3 reads b, 4 reads a
                     ep.n_seg_ptr = d_ctr + CT_BISECT;
                     ep.cursor = d_ctr + CT_OVF_CURSOR;
-                    ep.ovf_list = tier == 2 ? list_b : nullptr;
+                    ep.ovf_list = tier < 4 ? lists[(tier + 1) & 1] : nullptr;
+                    ep.escalate_cost = force_tier > tier ? 0u : kEscalateCost;
+                    ep.cap_limit = (tier == 3 && force_tier > 3) ? 4u : 0xFFFFFFFFu;
+                    const unsigned bw = (unsigned)std::min<uint64_t>(n_ovf, 256ull);
                     if (tier == 2) {
                         const unsigned mw = (unsigned)std::min<uint64_t>(n_ovf, 256ull * 3ull);
                         extend_kernel<SlotT, kArmCapMid><<<mw, 64, 0, s>>>(ep);
-                    } else {
-                        const unsigned bw = (unsigned)std::min<uint64_t>(n_ovf, 256ull);
+                    } else if (tier == 3) {
                         if constexpr (sizeof(SlotT) == 4)
-                            extend_heavy_kernel<SlotT, kArmCapBig32><<<bw, kHeavyThreads, 0, s>>>(ep);
+                            extend_heavy_kernel<SlotT, kArmCapBig32, false><<<bw, kHeavyThreads, 0, s>>>(ep);
                         else
-                            extend_heavy_kernel<SlotT, kArmCapBig64><<<bw, kHeavyThreads, 0, s>>>(ep);
+                            extend_heavy_kernel<SlotT, kArmCapBig64, false><<<bw, kHeavyThreads, 0, s>>>(ep);
+                    } else {
+                        constexpr int capg = sizeof(SlotT) == 4 ? kArmCapGlobal32 : kArmCapGlobal64;
+                        const size_t per_wg = 2 * (size_t)capg * (4 * sizeof(SlotT) + 16);
+                        RC_TRY(w.scratch.reserve(per_wg * bw));
+                        ep.scratch = w.scratch.as<char>();
+                        extend_heavy_kernel<SlotT, capg, true><<<bw, kHeavyThreads, 0, s>>>(ep);
                     }
                     HIP_TRY(hipGetLastError());
                     HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, sizeof(h_ctr), hipMemcpyDeviceToHost, s));
@@ -280,7 +296,7 @@ static int32_t run_search_t(asgart_index *idx, const uint64_t *chunks, int64_t n
                     set_error("%llu segment(s) need more than %d simultaneously live arms; "
                               "not supported by this build",
                               (unsigned long long)h_ctr[CT_OVF],
-                              sizeof(SlotT) == 4 ? kArmCapBig32 : kArmCapBig64);
+                              sizeof(SlotT) == 4 ? kArmCapGlobal32 : kArmCapGlobal64);
                     return ASGART_E_CAP;
                 }
             }

@@ -475,6 +475,9 @@ struct ExtParams {
     SdRec *recs;
     unsigned long long rec_cap;
     uint32_t *ovf_list;                   // segments whose live arms overflowed CAP (may be null)
+    char *scratch;                        // heavy global tier: per-workgroup arm storage
+    uint32_t escalate_cost;               // one-wave tiers: give up after this much LDS-path work
+    uint32_t cap_limit;                   // effective live-arm capacity (<= CAP; tests lower it)
     unsigned long long *ctr;
 };
 
@@ -768,7 +771,7 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
                     // hand the segment to the block-cooperative heavy tier when it does not fit
                     // this wave's LDS share, or keeps producing many-hit x many-arm probes
                     lds_cost += A + cnt;
-                    if (A + cnt > (uint32_t)CAP || lds_cost > kEscalateCost) {
+                    if (A + cnt > min((uint32_t)CAP, P.cap_limit) || lds_cost > P.escalate_cost) {
                         overflow = true;
                         done = true;
                         break;
@@ -942,17 +945,61 @@ __device__ inline uint32_t block_flag_scan(bool flag, uint32_t *s_wsum, uint32_t
     return before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
 }
 
-template <class PosT, int CAP>
+// ordered exclusive prefix of a per-thread count over the block (thread id order)
+__device__ inline uint32_t block_count_scan(uint32_t v, uint32_t *s_wsum, uint32_t *total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(incl, off);
+        if (lane >= off) incl += o;
+    }
+    if (lane == 63) s_wsum[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0, tot = 0;
+    for (int wv = 0; wv < kHeavyWaves; ++wv) {
+        const uint32_t x = s_wsum[wv];
+        if (wv < wave) before += x;
+        tot += x;
+    }
+    __syncthreads();
+    *total = tot;
+    return before + incl - v;
+}
+
+// GLOBAL = false: arm arrays in LDS (CAP <= 3072).  GLOBAL = true: arm arrays in a per-workgroup
+// slice of HBM scratch (two copies, compaction ping-pongs between them); only the packed
+// acceptance intervals of the current probe live in LDS, so CAP can reach 16384.
+template <class PosT, int CAP, bool GLOBAL>
 __global__ __launch_bounds__(kHeavyThreads) void extend_heavy_kernel(ExtParams<PosT> P) {
-    __shared__ PosT s_ls[CAP], s_le[CAP], s_rs[CAP], s_re[CAP];
-    __shared__ uint32_t s_gap[CAP], s_thr[CAP], s_seq[CAP], s_pend[CAP];
+    constexpr int LCAP = GLOBAL ? 1 : CAP;
+    __shared__ PosT l_ls[LCAP], l_le[LCAP], l_rs[LCAP], l_re[LCAP];
+    __shared__ uint32_t l_gap[LCAP], l_thr[LCAP], l_seq[LCAP], l_pend[LCAP];
+    PosT *s_ls = l_ls, *s_le = l_le, *s_rs = l_rs, *s_re = l_re;
+    uint32_t *s_gap = l_gap, *s_thr = l_thr, *s_seq = l_seq, *s_pend = l_pend;
+    // second copy (GLOBAL only)
+    PosT *t_ls = nullptr, *t_le = nullptr, *t_rs = nullptr, *t_re = nullptr;
+    uint32_t *t_gap = nullptr, *t_thr = nullptr, *t_seq = nullptr, *t_pend = nullptr;
+    if constexpr (GLOBAL) {
+        // layout per workgroup: 2 copies x (4 PosT + 4 u32 arrays) of CAP entries
+        const size_t copy_bytes = (size_t)CAP * (4 * sizeof(PosT) + 4 * sizeof(uint32_t));
+        char *basep = P.scratch + (size_t)blockIdx.x * 2 * copy_bytes;
+        auto carve = [&](char *b, PosT *&ls, PosT *&le, PosT *&rs, PosT *&re, uint32_t *&gp,
+                         uint32_t *&th, uint32_t *&sq, uint32_t *&pd) {
+            ls = reinterpret_cast<PosT *>(b);
+            le = ls + CAP; rs = le + CAP; re = rs + CAP;
+            gp = reinterpret_cast<uint32_t *>(re + CAP);
+            th = gp + CAP; sq = th + CAP; pd = sq + CAP;
+        };
+        carve(basep, s_ls, s_le, s_rs, s_re, s_gap, s_thr, s_seq, s_pend);
+        carve(basep + copy_bytes, t_ls, t_le, t_rs, t_re, t_gap, t_thr, t_seq, t_pend);
+    }
     __shared__ PosT s_hits[kHitBatch];
     __shared__ uint32_t s_best[kHeavyThreads];
     __shared__ PosT s_ivlo[CAP];      // acceptance interval of arm j for this probe:
     __shared__ uint32_t s_ivw[CAP];   //   accepts x  iff  (x - s_ivlo[j]) < s_ivw[j]  (unsigned)
     __shared__ uint32_t s_wsum[kHeavyWaves];
     __shared__ unsigned long long s_bcast;
-    constexpr int PER = (CAP + kHeavyThreads - 1) / kHeavyThreads;
+    constexpr int PER = GLOBAL ? 1 : (CAP + kHeavyThreads - 1) / kHeavyThreads;
     const int tid = threadIdx.x, lane = tid & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const RunParams &rp = P.rp;
@@ -1002,8 +1049,62 @@ __global__ __launch_bounds__(kHeavyThreads) void extend_heavy_kernel(ExtParams<P
                 }
             }
         };
+        auto emit_one = [&](PosT ls, PosT le, PosT rs, PosT re, uint32_t seq) {
+            const unsigned long long at = atomicAdd(&P.ctr[CT_SD], 1ull);
+            if (at < P.rec_cap) {
+                const uint64_t ll = (uint64_t)le - (uint64_t)ls;
+                SdRec r;
+                r.g_start = g0;
+                r.fam_seq = fam_seq;
+                r.create_seq = seq;
+                r.pad = 0;
+                r.sd.left = rp.reverse ? cs + cl - (uint64_t)ls - ll : (uint64_t)ls + cs;
+                r.sd.right = rs;
+                r.sd.left_length = ll;
+                r.sd.right_length = (uint64_t)re - (uint64_t)rs;
+                P.recs[at] = r;
+            }
+        };
         // retire arms whose gap reached G; order-preserving compaction over the whole block
         auto retire = [&]() {
+            if constexpr (GLOBAL) {
+                // contiguous arm range per thread, one block scan of the survivor counts, copy
+                // into the other buffer (order preserved), swap buffers
+                const uint32_t per = (A + kHeavyThreads - 1) / kHeavyThreads;
+                const uint32_t j0 = min(A, (uint32_t)tid * per), j1 = min(A, j0 + per);
+                uint32_t n_alive = 0, n_dead = 0;
+                for (uint32_t j = j0; j < j1; ++j) {
+                    if (s_gap[j] >= G) ++n_dead; else ++n_alive;
+                }
+                uint32_t dead_total = 0, alive_total = 0;
+                (void)block_count_scan(n_dead, s_wsum, &dead_total);
+                if (dead_total == 0) return;  // block-uniform
+                uint32_t d = block_count_scan(n_alive, s_wsum, &alive_total);
+                for (uint32_t j = j0; j < j1; ++j) {
+                    const PosT ls = s_ls[j], le = s_le[j], rs = s_rs[j], re = s_re[j];
+                    const uint32_t gp = s_gap[j], th = s_thr[j], sq = s_seq[j];
+                    if (gp >= G) {
+                        if ((uint64_t)(re - rs) >= rp.M) emit_one(ls, le, rs, re, sq);
+                    } else {
+                        t_ls[d] = ls; t_le[d] = le; t_rs[d] = rs; t_re[d] = re;
+                        t_gap[d] = gp; t_thr[d] = th; t_seq[d] = sq; t_pend[d] = 0;
+                        ++d;
+                    }
+                }
+                __syncthreads();
+                { PosT *x; uint32_t *y;
+                  x = s_ls; s_ls = t_ls; t_ls = x;  x = s_le; s_le = t_le; t_le = x;
+                  x = s_rs; s_rs = t_rs; t_rs = x;  x = s_re; s_re = t_re; t_re = x;
+                  y = s_gap; s_gap = t_gap; t_gap = y;  y = s_thr; s_thr = t_thr; t_thr = y;
+                  y = s_seq; s_seq = t_seq; t_seq = y;  y = s_pend; s_pend = t_pend; t_pend = y; }
+                const bool was_nonempty = A > 0;
+                A = alive_total;
+                if (A == 0 && was_nonempty) {
+                    ++fam_seq;
+                    next_seq = 0;
+                }
+                return;
+            }
             PosT ls[PER], le[PER], rs[PER], re[PER];
             uint32_t gp[PER], th[PER], sq[PER];
             bool alive[PER];
@@ -1109,7 +1210,7 @@ __global__ __launch_bounds__(kHeavyThreads) void extend_heavy_kernel(ExtParams<P
                 const uint32_t off = __shfl(rel_l, (int)b);
                 const uint64_t i = (uint64_t)(g + b - pb + 1) * step;
                 const unsigned long long row = base + off;
-                if (A + cnt > (uint32_t)CAP) {
+                if (A + cnt > min((uint32_t)CAP, P.cap_limit)) {
                     overflow = true;
                     done = true;
                     break;

@@ -268,3 +268,22 @@ def test_shards_concatenate_to_unsharded(hiplib, name, halo, monkeypatch):
                 got_offs = np.concatenate([[0], np.cumsum(np.concatenate(fam_counts))]).astype(np.uint64)
                 assert np.array_equal(got_offs, offs), (name, R, reverse)
                 assert np.array_equal(got_sds, sds), (name, R, reverse)
+
+
+@pytest.mark.parametrize("tier", [2, 3, 4])
+@pytest.mark.parametrize("name", ["dense_repeats", "satellites", "long_sds"])
+def test_escalation_tiers_give_identical_results(hiplib, name, tier, monkeypatch):
+    """The one-wave kernel hands heavy segments to larger tiers (bigger LDS share, block-cooperative
+    kernel, HBM-scratch kernel).  Forcing every segment with a multi-hit probe into tier `tier`
+    must not change a single ProtoSD."""
+    pr, cli = _battery_case(name)
+    oidx = oracle.Index.build(pr.data)
+    monkeypatch.setenv("ASGART_FORCE_TIER", str(tier))
+    with asgart_amd.Index(pr.data, oidx.sa) as idx:
+        for reverse, complement in ((False, False), (True, True)):
+            st = asgart_amd.RunSettings.from_cli(reverse=reverse, complement=complement, **cli)
+            offs, sds = idx.search_duplications_raw(pr.chunks, st)
+            if name == "dense_repeats":
+                assert idx.stats().overflow_segments > 0
+            eoffs, esds = oidx.run_raw(pr.chunks, oracle.make_settings(reverse=reverse, complement=complement, **cli), threads=4)
+            assert np.array_equal(offs, eoffs) and np.array_equal(sds, esds), (name, tier, reverse)
