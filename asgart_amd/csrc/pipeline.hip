@@ -12,7 +12,8 @@
 namespace asgart {
 
 constexpr int kArmCapSmall = 256;   // live arms per wave in LDS, common case
-constexpr int kArmCapMid = 1024;    // second tier: same kernel, 3 waves per CU
+constexpr int kArmCapMid = 1024;    // second tier: block-cooperative kernel, 256 threads per segment
+constexpr uint32_t kEscalateCostMid = 2000000;  // mid -> heavy: sum of (live arms + hits) over probes
 constexpr int kArmCapGlobal32 = 16384;  // last tier: arms in HBM scratch, intervals in LDS (128 KiB)
 constexpr int kArmCapGlobal64 = 8192;
 constexpr int kArmCapBig32 = 3072;  // heavy tier, 32-bit positions: 3072*40 B + hits + scratch = 128 KiB
@@ -266,19 +267,21 @@ static int32_t run_search_t(asgart_index *idx, const uint64_t *chunks, int64_t n
                     ep.cap_limit = (tier == 3 && force_tier > 3) ? 4u : 0xFFFFFFFFu;
                     const unsigned bw = (unsigned)std::min<uint64_t>(n_ovf, 256ull);
                     if (tier == 2) {
+                        // 4 waves per segment, ~3 workgroups per CU
                         const unsigned mw = (unsigned)std::min<uint64_t>(n_ovf, 256ull * 3ull);
-                        extend_kernel<SlotT, kArmCapMid><<<mw, 64, 0, s>>>(ep);
+                        ep.escalate_cost = force_tier > tier ? 0u : kEscalateCostMid;
+                        extend_heavy_kernel<SlotT, kArmCapMid, kMidThreads, false><<<mw, kMidThreads, 0, s>>>(ep);
                     } else if (tier == 3) {
                         if constexpr (sizeof(SlotT) == 4)
-                            extend_heavy_kernel<SlotT, kArmCapBig32, false><<<bw, kHeavyThreads, 0, s>>>(ep);
+                            extend_heavy_kernel<SlotT, kArmCapBig32, kHeavyThreads, false><<<bw, kHeavyThreads, 0, s>>>(ep);
                         else
-                            extend_heavy_kernel<SlotT, kArmCapBig64, false><<<bw, kHeavyThreads, 0, s>>>(ep);
+                            extend_heavy_kernel<SlotT, kArmCapBig64, kHeavyThreads, false><<<bw, kHeavyThreads, 0, s>>>(ep);
                     } else {
                         constexpr int capg = sizeof(SlotT) == 4 ? kArmCapGlobal32 : kArmCapGlobal64;
                         const size_t per_wg = 2 * (size_t)capg * (4 * sizeof(SlotT) + 16);
                         RC_TRY(w.scratch.reserve(per_wg * bw));
                         ep.scratch = w.scratch.as<char>();
-                        extend_heavy_kernel<SlotT, capg, true><<<bw, kHeavyThreads, 0, s>>>(ep);
+                        extend_heavy_kernel<SlotT, capg, kHeavyThreads, true><<<bw, kHeavyThreads, 0, s>>>(ep);
                     }
                     HIP_TRY(hipGetLastError());
                     HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, sizeof(h_ctr), hipMemcpyDeviceToHost, s));

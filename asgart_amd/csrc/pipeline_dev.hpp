@@ -925,17 +925,18 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
 //           -> atomicMin on the hit's best arm
 //   new     order-preserving slots for NewArm by a block-wide ballot scan
 //   apply   arms strided over threads; retire/compact with a block-wide ordered scan
-constexpr int kHeavyThreads = 1024;
-constexpr int kHeavyWaves = kHeavyThreads / 64;
+constexpr int kHeavyThreads = 1024;  // heavy tiers
+constexpr int kMidThreads = 256;     // mid tier: 4 waves per segment, several workgroups per CU
 
 // ordered exclusive prefix of a per-thread flag over the block (thread id order)
+template <int NW>
 __device__ inline uint32_t block_flag_scan(bool flag, uint32_t *s_wsum, uint32_t *total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long m = __ballot(flag);
     if (lane == 0) s_wsum[wave] = (uint32_t)__popcll(m);
     __syncthreads();
     uint32_t before = 0, tot = 0;
-    for (int wv = 0; wv < kHeavyWaves; ++wv) {
+    for (int wv = 0; wv < NW; ++wv) {
         const uint32_t v = s_wsum[wv];
         if (wv < wave) before += v;
         tot += v;
@@ -946,6 +947,7 @@ __device__ inline uint32_t block_flag_scan(bool flag, uint32_t *s_wsum, uint32_t
 }
 
 // ordered exclusive prefix of a per-thread count over the block (thread id order)
+template <int NW>
 __device__ inline uint32_t block_count_scan(uint32_t v, uint32_t *s_wsum, uint32_t *total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t incl = v;
@@ -956,7 +958,7 @@ __device__ inline uint32_t block_count_scan(uint32_t v, uint32_t *s_wsum, uint32
     if (lane == 63) s_wsum[wave] = incl;
     __syncthreads();
     uint32_t before = 0, tot = 0;
-    for (int wv = 0; wv < kHeavyWaves; ++wv) {
+    for (int wv = 0; wv < NW; ++wv) {
         const uint32_t x = s_wsum[wv];
         if (wv < wave) before += x;
         tot += x;
@@ -969,8 +971,9 @@ __device__ inline uint32_t block_count_scan(uint32_t v, uint32_t *s_wsum, uint32
 // GLOBAL = false: arm arrays in LDS (CAP <= 3072).  GLOBAL = true: arm arrays in a per-workgroup
 // slice of HBM scratch (two copies, compaction ping-pongs between them); only the packed
 // acceptance intervals of the current probe live in LDS, so CAP can reach 16384.
-template <class PosT, int CAP, bool GLOBAL>
-__global__ __launch_bounds__(kHeavyThreads) void extend_heavy_kernel(ExtParams<PosT> P) {
+template <class PosT, int CAP, int NT, bool GLOBAL>
+__global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
+    constexpr int NW = NT / 64;
     constexpr int LCAP = GLOBAL ? 1 : CAP;
     __shared__ PosT l_ls[LCAP], l_le[LCAP], l_rs[LCAP], l_re[LCAP];
     __shared__ uint32_t l_gap[LCAP], l_thr[LCAP], l_seq[LCAP], l_pend[LCAP];
@@ -994,12 +997,12 @@ __global__ __launch_bounds__(kHeavyThreads) void extend_heavy_kernel(ExtParams<P
         carve(basep + copy_bytes, t_ls, t_le, t_rs, t_re, t_gap, t_thr, t_seq, t_pend);
     }
     __shared__ PosT s_hits[kHitBatch];
-    __shared__ uint32_t s_best[kHeavyThreads];
+    __shared__ uint32_t s_best[NT];
     __shared__ PosT s_ivlo[CAP];      // acceptance interval of arm j for this probe:
     __shared__ uint32_t s_ivw[CAP];   //   accepts x  iff  (x - s_ivlo[j]) < s_ivw[j]  (unsigned)
-    __shared__ uint32_t s_wsum[kHeavyWaves];
+    __shared__ uint32_t s_wsum[NW];
     __shared__ unsigned long long s_bcast;
-    constexpr int PER = GLOBAL ? 1 : (CAP + kHeavyThreads - 1) / kHeavyThreads;
+    constexpr int PER = GLOBAL ? 1 : (CAP + NT - 1) / NT;
     const int tid = threadIdx.x, lane = tid & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const RunParams &rp = P.rp;
@@ -1022,6 +1025,7 @@ __global__ __launch_bounds__(kHeavyThreads) void extend_heavy_kernel(ExtParams<P
         const uint32_t chunk_end = rp.ch.pbase[c + 1];
         const uint32_t g_end = min(chunk_end, rp.g_hi);
         uint32_t A = 0, quiet = 0, fam_seq = 0, next_seq = 0;
+        unsigned long long blk_cost = 0;
         bool overflow = false, done = false;
 
         // per-wave aggregated append of output records
@@ -1070,16 +1074,16 @@ __global__ __launch_bounds__(kHeavyThreads) void extend_heavy_kernel(ExtParams<P
             if constexpr (GLOBAL) {
                 // contiguous arm range per thread, one block scan of the survivor counts, copy
                 // into the other buffer (order preserved), swap buffers
-                const uint32_t per = (A + kHeavyThreads - 1) / kHeavyThreads;
+                const uint32_t per = (A + NT - 1) / NT;
                 const uint32_t j0 = min(A, (uint32_t)tid * per), j1 = min(A, j0 + per);
                 uint32_t n_alive = 0, n_dead = 0;
                 for (uint32_t j = j0; j < j1; ++j) {
                     if (s_gap[j] >= G) ++n_dead; else ++n_alive;
                 }
                 uint32_t dead_total = 0, alive_total = 0;
-                (void)block_count_scan(n_dead, s_wsum, &dead_total);
+                (void)block_count_scan<NW>(n_dead, s_wsum, &dead_total);
                 if (dead_total == 0) return;  // block-uniform
-                uint32_t d = block_count_scan(n_alive, s_wsum, &alive_total);
+                uint32_t d = block_count_scan<NW>(n_alive, s_wsum, &alive_total);
                 for (uint32_t j = j0; j < j1; ++j) {
                     const PosT ls = s_ls[j], le = s_le[j], rs = s_rs[j], re = s_re[j];
                     const uint32_t gp = s_gap[j], th = s_thr[j], sq = s_seq[j];
@@ -1111,7 +1115,7 @@ __global__ __launch_bounds__(kHeavyThreads) void extend_heavy_kernel(ExtParams<P
             bool any_dead = false;
 #pragma unroll
             for (int u = 0; u < PER; ++u) {
-                const uint32_t j = (uint32_t)u * kHeavyThreads + tid;
+                const uint32_t j = (uint32_t)u * NT + tid;
                 const bool valid = j < A;
                 ls[u] = le[u] = rs[u] = re[u] = 0;
                 gp[u] = th[u] = sq[u] = 0;
@@ -1125,13 +1129,13 @@ __global__ __launch_bounds__(kHeavyThreads) void extend_heavy_kernel(ExtParams<P
                 emit_records(dead && (uint64_t)(re[u] - rs[u]) >= rp.M, ls[u], le[u], rs[u], re[u], sq[u]);
             }
             uint32_t n_dead_total = 0;
-            (void)block_flag_scan(any_dead, s_wsum, &n_dead_total);
+            (void)block_flag_scan<NW>(any_dead, s_wsum, &n_dead_total);
             if (n_dead_total == 0) return;  // block-uniform
             uint32_t w = 0;
 #pragma unroll
             for (int u = 0; u < PER; ++u) {
                 uint32_t tot = 0;
-                const uint32_t d = w + block_flag_scan(alive[u], s_wsum, &tot);
+                const uint32_t d = w + block_flag_scan<NW>(alive[u], s_wsum, &tot);
                 if (alive[u]) {
                     s_ls[d] = ls[u]; s_le[d] = le[u]; s_rs[d] = rs[u]; s_re[d] = re[u];
                     s_gap[d] = gp[u]; s_thr[d] = th[u]; s_seq[d] = sq[u]; s_pend[d] = 0;
@@ -1150,7 +1154,7 @@ __global__ __launch_bounds__(kHeavyThreads) void extend_heavy_kernel(ExtParams<P
             quiet += q;
             if (A > 0) {
                 const uint32_t add = q * step;
-                for (uint32_t j = tid; j < A; j += kHeavyThreads) {
+                for (uint32_t j = tid; j < A; j += NT) {
                     const uint32_t gp = s_gap[j];
                     s_gap[j] = gp + add < gp ? 0xFFFFFFFFu : gp + add;
                 }
@@ -1183,7 +1187,7 @@ __global__ __launch_bounds__(kHeavyThreads) void extend_heavy_kernel(ExtParams<P
             if (!first_from_global) {
                 const unsigned long long end = nbb == nb ? r_hi : __shfl(r_l, (int)nbb);
                 const uint32_t tot = (uint32_t)(end - base);
-                if ((uint32_t)tid < tot) s_hits[tid] = P.hits[base + tid];
+                for (uint32_t r = tid; r < tot; r += NT) s_hits[r] = P.hits[base + r];
             }
             __syncthreads();
             const unsigned long long in_batch = nbb >= 64 ? ~0ull : ((1ull << nbb) - 1ull);
@@ -1210,7 +1214,9 @@ __global__ __launch_bounds__(kHeavyThreads) void extend_heavy_kernel(ExtParams<P
                 const uint32_t off = __shfl(rel_l, (int)b);
                 const uint64_t i = (uint64_t)(g + b - pb + 1) * step;
                 const unsigned long long row = base + off;
-                if (A + cnt > min((uint32_t)CAP, P.cap_limit)) {
+                blk_cost += (unsigned long long)A + cnt;
+                if (A + cnt > min((uint32_t)CAP, P.cap_limit) ||
+                    (P.ovf_list && blk_cost > (unsigned long long)P.escalate_cost)) {
                     overflow = true;
                     done = true;
                     break;
@@ -1221,17 +1227,17 @@ __global__ __launch_bounds__(kHeavyThreads) void extend_heavy_kernel(ExtParams<P
                 PROF_COUNT(10, A_old);
                 PROF_COUNT(11, cnt);
                 PROF_START();
-                for (uint32_t j = tid; j < A_old; j += kHeavyThreads) {
+                for (uint32_t j = tid; j < A_old; j += NT) {
                     const uint32_t th = s_thr[j];
                     const uint64_t wv = th ? (uint64_t)th + k - 1u : 0u;
                     s_ivlo[j] = (PosT)(s_re[j] - k + 1u);
                     s_ivw[j] = wv > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)wv;
                 }
                 __syncthreads();
-                for (uint32_t t0 = 0; t0 < cnt; t0 += kHeavyThreads) {
-                    const uint32_t ct = min((uint32_t)kHeavyThreads, cnt - t0);
+                for (uint32_t t0 = 0; t0 < cnt; t0 += NT) {
+                    const uint32_t ct = min((uint32_t)NT, cnt - t0);
                     const uint32_t Hr = (ct + 63u) & ~63u;          // hits rounded up to waves
-                    const uint32_t NP = kHeavyThreads / Hr;         // arm-range parts
+                    const uint32_t NP = NT / Hr;         // arm-range parts
                     s_best[tid] = 0xFFFFFFFFu;
                     __syncthreads();
                     const uint32_t tl = (uint32_t)tid % Hr, part = (uint32_t)tid / Hr;
@@ -1267,7 +1273,7 @@ __global__ __launch_bounds__(kHeavyThreads) void extend_heavy_kernel(ExtParams<P
                     }
                     const bool is_new = mine && best == 0xFFFFFFFFu;
                     uint32_t n_new = 0;
-                    const uint32_t slot = A + block_flag_scan(is_new, s_wsum, &n_new);
+                    const uint32_t slot = A + block_flag_scan<NW>(is_new, s_wsum, &n_new);
                     if (is_new) {
                         s_ls[slot] = (PosT)i; s_le[slot] = (PosT)(i + k); s_rs[slot] = hx;
                         s_re[slot] = (PosT)(hx + k);
@@ -1282,7 +1288,7 @@ __global__ __launch_bounds__(kHeavyThreads) void extend_heavy_kernel(ExtParams<P
                 next_seq += A - A_old;
                 PROF_STOP(6);
                 PROF_START();
-                for (uint32_t j = tid; j < A_old; j += kHeavyThreads) {
+                for (uint32_t j = tid; j < A_old; j += NT) {
                     const uint32_t pd = s_pend[j];
                     if (pd) {
                         s_pend[j] = 0;
@@ -1314,7 +1320,10 @@ __global__ __launch_bounds__(kHeavyThreads) void extend_heavy_kernel(ExtParams<P
         } else if (!overflow && A > 0) {
             emit_records(tid == 0, (PosT)0, (PosT)0, (PosT)0, (PosT)0, kTombstone);
         }
-        if (overflow && tid == 0) atomicAdd(&P.ctr[CT_OVF], 1ull);
+        if (overflow && tid == 0) {
+            const unsigned long long at = atomicAdd(&P.ctr[CT_OVF], 1ull);
+            if (P.ovf_list) P.ovf_list[at] = g0;
+        }
         if (tid < 64) {
             PROF_FLUSH();
         }
