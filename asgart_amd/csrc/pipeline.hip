@@ -11,13 +11,28 @@
 
 namespace asgart {
 
+#ifdef ASGART_PROFILE_EXTEND
+#define PROF_DUMP(tag)                                                                          \
+    do {                                                                                       \
+        fprintf(stderr, "[extend profile %s] stage=%llu batches=%llu | reg_cyc=%llu reg_probes=%llu | build=%llu "\
+                "lds_probes=%llu match=%llu apply=%llu retire=%llu segs=%llu sumA=%llu sumCnt=%llu | longest: "   \
+                "cyc=%llu g0=%llu lds_probes=%llu reg_probes=%llu sumA=%llu sumCnt=%llu stage=%llu match=%llu\n", \
+                tag, h_ctr[16], h_ctr[17], h_ctr[18], h_ctr[19], h_ctr[20], h_ctr[21], h_ctr[22], h_ctr[23],  \
+                h_ctr[24], h_ctr[25], h_ctr[26], h_ctr[27], h_ctr[28], h_ctr[29], h_ctr[30] >> 32,            \
+                h_ctr[30] & 0xffffffffull, h_ctr[31] >> 32, h_ctr[31] & 0xffffffffull, h_ctr[32], h_ctr[33]); \
+        (void)hipMemsetAsync(d_ctr + 16, 0, 32 * 8, s);                                        \
+    } while (0)
+#else
+#define PROF_DUMP(tag)
+#endif
+
 constexpr int kArmCapSmall = 256;   // live arms per wave in LDS, common case
 constexpr int kArmCapMid = 1024;    // second tier: block-cooperative kernel, 256 threads per segment
-constexpr uint32_t kEscalateCostMid = 2000000;  // mid -> heavy: sum of (live arms + hits) over probes
+constexpr uint32_t kEscalateCostMid = 0xFFFFFFFFu;  // mid -> heavy: sum of (live arms + hits) over probes
 constexpr int kArmCapGlobal32 = 16384;  // last tier: arms in HBM scratch, intervals in LDS (128 KiB)
 constexpr int kArmCapGlobal64 = 8192;
-constexpr int kArmCapBig32 = 3072;  // heavy tier, 32-bit positions: 3072*40 B + hits + scratch = 128 KiB
-constexpr int kArmCapBig64 = 2048;  // heavy tier, 64-bit positions: 2048*60 B + hits + scratch = 132 KiB
+constexpr int kArmCapBig32 = 2816;  // heavy tier, 32-bit positions: 3072*40 B + hits + scratch = 128 KiB
+constexpr int kArmCapBig64 = 1792;  // heavy tier, 64-bit positions: 2048*60 B + hits + scratch = 132 KiB
 
 static inline unsigned grid_for(uint64_t n, unsigned block = 256) {
     return (unsigned)((n + block - 1) / block);
@@ -244,6 +259,7 @@ static int32_t run_search_t(asgart_index *idx, const uint64_t *chunks, int64_t n
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, sizeof(h_ctr), hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
+            PROF_DUMP("tier1");
             if (h_ctr[CT_OVF]) {
                 // Escalation: segments the one-wave kernel gave up on are re-run from their start
                 // by (tier 2) the same kernel with a 4x larger LDS share, then (tier 3) the
@@ -263,7 +279,8 @@ static int32_t run_search_t(asgart_index *idx, const uint64_t *chunks, int64_t n
                     ep.n_seg_ptr = d_ctr + CT_BISECT;
                     ep.cursor = d_ctr + CT_OVF_CURSOR;
                     ep.ovf_list = tier < 4 ? lists[(tier + 1) & 1] : nullptr;
-                    ep.escalate_cost = force_tier > tier ? 0u : kEscalateCost;
+                    // only the one-wave and 256-thread tiers give up on cost; tier 3 only on capacity
+                    ep.escalate_cost = force_tier > tier ? 0u : 0xFFFFFFFFu;
                     ep.cap_limit = (tier == 3 && force_tier > 3) ? 4u : 0xFFFFFFFFu;
                     const unsigned bw = (unsigned)std::min<uint64_t>(n_ovf, 256ull);
                     if (tier == 2) {
@@ -286,6 +303,7 @@ static int32_t run_search_t(asgart_index *idx, const uint64_t *chunks, int64_t n
                     HIP_TRY(hipGetLastError());
                     HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, sizeof(h_ctr), hipMemcpyDeviceToHost, s));
                     HIP_TRY(hipStreamSynchronize(s));
+                    PROF_DUMP(tier == 2 ? "tier2" : (tier == 3 ? "tier3" : "tier4"));
                     if (tier == 2) n_heavy = h_ctr[CT_OVF];
                 }
                 HIP_TRY(hipEventRecord(idx->ev[6], s));
@@ -377,15 +395,7 @@ static int32_t run_search_t(asgart_index *idx, const uint64_t *chunks, int64_t n
     stt.search_launches = 1;
     stt.overflow_segments = n_overflow;
     stt.heavy_segments = n_heavy;
-#ifdef ASGART_PROFILE_EXTEND
-    fprintf(stderr, "[extend profile] stage_cyc=%llu batches=%llu | reg_cyc=%llu reg_probes=%llu | "
-            "lds: build_cyc=%llu probes=%llu hits_cyc=%llu apply_cyc=%llu retire_cyc=%llu | sumA=%llu sumCnt=%llu\n",
-            h_ctr[16], h_ctr[17], h_ctr[18], h_ctr[19], h_ctr[20], h_ctr[21], h_ctr[22], h_ctr[23],
-            h_ctr[24], h_ctr[26], h_ctr[27]);
-    fprintf(stderr, "[extend profile] longest segment: %llu cycles, g0=%llu, lds_probes=%llu reg_probes=%llu "
-            "sumA=%llu sumCnt=%llu stage_cyc=%llu hits_cyc=%llu\n", h_ctr[28], h_ctr[29], h_ctr[30] >> 32,
-            h_ctr[30] & 0xffffffffull, h_ctr[31] >> 32, h_ctr[31] & 0xffffffffull, h_ctr[32], h_ctr[33]);
-#endif
+
     stt.ms_extend_tier2 = ms_tier2;
     idx->has_last = true;
     return 0;

@@ -998,8 +998,17 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
     }
     __shared__ PosT s_hits[kHitBatch];
     __shared__ uint32_t s_best[NT];
-    __shared__ PosT s_ivlo[CAP];      // acceptance interval of arm j for this probe:
-    __shared__ uint32_t s_ivw[CAP];   //   accepts x  iff  (x - s_ivlo[j]) < s_ivw[j]  (unsigned)
+    // candidate index rebuilt for every probe (see extend_kernel "LDS path"): narrow arms
+    // (thr == G) hashed by bucket(re), wide arms as a packed list of acceptance intervals
+    constexpr uint32_t HT = CAP <= 1024 ? 1024u : (CAP <= 4096 ? 4096u : 8192u);
+    constexpr uint32_t WCAP = GLOBAL ? 4096u : (uint32_t)CAP;
+    __shared__ uint32_t s_head[HT];
+    __shared__ uint16_t s_next[CAP];
+    __shared__ PosT s_ivlo[WCAP];     // wide arm w accepts x iff (x - s_ivlo[w]) < s_ivw[w]
+    __shared__ uint32_t s_ivw[WCAP];
+    __shared__ uint16_t s_widx[WCAP];
+    __shared__ uint32_t s_nwide;
+    __shared__ uint32_t s_anydead;   // set by any thread that sees an arm's gap reach G
     __shared__ uint32_t s_wsum[NW];
     __shared__ unsigned long long s_bcast;
     constexpr int PER = GLOBAL ? 1 : (CAP + NT - 1) / NT;
@@ -1009,6 +1018,8 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
     const uint64_t n_seg = *P.n_seg_ptr;
     const uint32_t k = (uint32_t)rp.k, step = (uint32_t)rp.step, G = rp.G;
     const uint32_t thr0 = arm_threshold(k, G);
+    uint32_t bsh = 3;  // bucket(re) = re >> bsh with 2^bsh >= G + k: a hit meets <= 2 buckets
+    while ((1ull << bsh) < (unsigned long long)G + k) ++bsh;
     PROF_DECL;
 
     for (;;) {
@@ -1076,13 +1087,10 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
                 // into the other buffer (order preserved), swap buffers
                 const uint32_t per = (A + NT - 1) / NT;
                 const uint32_t j0 = min(A, (uint32_t)tid * per), j1 = min(A, j0 + per);
-                uint32_t n_alive = 0, n_dead = 0;
-                for (uint32_t j = j0; j < j1; ++j) {
-                    if (s_gap[j] >= G) ++n_dead; else ++n_alive;
-                }
-                uint32_t dead_total = 0, alive_total = 0;
-                (void)block_count_scan<NW>(n_dead, s_wsum, &dead_total);
-                if (dead_total == 0) return;  // block-uniform
+                uint32_t n_alive = 0;
+                for (uint32_t j = j0; j < j1; ++j)
+                    if (s_gap[j] < G) ++n_alive;
+                uint32_t alive_total = 0;
                 uint32_t d = block_count_scan<NW>(n_alive, s_wsum, &alive_total);
                 for (uint32_t j = j0; j < j1; ++j) {
                     const PosT ls = s_ls[j], le = s_le[j], rs = s_rs[j], re = s_re[j];
@@ -1128,9 +1136,7 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
                 any_dead |= dead;
                 emit_records(dead && (uint64_t)(re[u] - rs[u]) >= rp.M, ls[u], le[u], rs[u], re[u], sq[u]);
             }
-            uint32_t n_dead_total = 0;
-            (void)block_flag_scan<NW>(any_dead, s_wsum, &n_dead_total);
-            if (n_dead_total == 0) return;  // block-uniform
+            (void)any_dead;  // retire() is only called when s_anydead was raised
             uint32_t w = 0;
 #pragma unroll
             for (int u = 0; u < PER; ++u) {
@@ -1154,12 +1160,16 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
             quiet += q;
             if (A > 0) {
                 const uint32_t add = q * step;
+                if (tid == 0) s_anydead = 0;
+                __syncthreads();
                 for (uint32_t j = tid; j < A; j += NT) {
                     const uint32_t gp = s_gap[j];
-                    s_gap[j] = gp + add < gp ? 0xFFFFFFFFu : gp + add;
+                    const uint32_t ng = gp + add < gp ? 0xFFFFFFFFu : gp + add;
+                    s_gap[j] = ng;
+                    if (ng >= G) s_anydead = 1;
                 }
                 __syncthreads();
-                retire();
+                if (s_anydead) retire();
             }
             if (A == 0 && quiet >= rp.tstar) done = true;
         };
@@ -1227,39 +1237,82 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
                 PROF_COUNT(10, A_old);
                 PROF_COUNT(11, cnt);
                 PROF_START();
-                for (uint32_t j = tid; j < A_old; j += NT) {
-                    const uint32_t th = s_thr[j];
-                    const uint64_t wv = th ? (uint64_t)th + k - 1u : 0u;
-                    s_ivlo[j] = (PosT)(s_re[j] - k + 1u);
-                    s_ivw[j] = wv > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)wv;
+                // ---- candidate index ------------------------------------------------------
+                uint32_t hmask = 63u;
+                while (hmask + 1u < HT && hmask + 1u < 2u * A_old) hmask = (hmask << 1) | 1u;
+                for (uint32_t h = tid; h <= hmask; h += NT) s_head[h] = 0xFFFFFFFFu;
+                if (tid == 0) {
+                    s_nwide = 0;
+                    s_anydead = (step >= G) ? 1u : 0u;  // new arms are born with gap = step
                 }
                 __syncthreads();
+                for (uint32_t j = tid; j < A_old; j += NT) {
+                    const uint32_t th = s_thr[j];
+                    const PosT re = s_re[j];
+                    if (th <= G) {
+                        const uint32_t bkt = (uint32_t)((uint64_t)re >> bsh);
+                        s_next[j] = (uint16_t)atomicExch(&s_head[((bkt * 2654435761u) >> 12) & hmask], j);
+                    } else {
+                        const uint32_t d = atomicAdd(&s_nwide, 1u);
+                        if (d < WCAP) {
+                            const uint64_t wv = (uint64_t)th + k - 1u;
+                            s_ivlo[d] = (PosT)(re - k + 1u);
+                            s_ivw[d] = wv > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)wv;
+                            s_widx[d] = (uint16_t)j;
+                        }
+                    }
+                }
+                __syncthreads();
+                const uint32_t n_wide = s_nwide;
+                if (n_wide > WCAP) {  // only possible in the HBM tier
+                    overflow = true;
+                    done = true;
+                    break;
+                }
                 for (uint32_t t0 = 0; t0 < cnt; t0 += NT) {
                     const uint32_t ct = min((uint32_t)NT, cnt - t0);
-                    const uint32_t Hr = (ct + 63u) & ~63u;          // hits rounded up to waves
-                    const uint32_t NP = NT / Hr;         // arm-range parts
-                    s_best[tid] = 0xFFFFFFFFu;
-                    __syncthreads();
-                    const uint32_t tl = (uint32_t)tid % Hr, part = (uint32_t)tid / Hr;
-                    const bool valid = tl < ct && part < NP;
-                    PosT x = 0;
-                    if (valid) x = from_lds ? s_hits[off + t0 + tl] : P.hits[row + t0 + tl];
-                    if (part < NP) {  // wave-uniform
-                        const uint32_t j0 = (uint32_t)((uint64_t)A_old * part / NP);
-                        const uint32_t j1 = (uint32_t)((uint64_t)A_old * (part + 1) / NP);
-                        uint32_t found = 0xFFFFFFFFu;
-                        // branch-free scan in index order: the smallest accepting index wins
-                        uint32_t j = j0;
-                        for (; j + 4 <= j1; j += 4) {
-                            const uint32_t a0 = (uint64_t)(PosT)(x - s_ivlo[j]) < s_ivw[j] ? j : 0xFFFFFFFFu;
-                            const uint32_t a1 = (uint64_t)(PosT)(x - s_ivlo[j + 1]) < s_ivw[j + 1] ? j + 1 : 0xFFFFFFFFu;
-                            const uint32_t a2 = (uint64_t)(PosT)(x - s_ivlo[j + 2]) < s_ivw[j + 2] ? j + 2 : 0xFFFFFFFFu;
-                            const uint32_t a3 = (uint64_t)(PosT)(x - s_ivlo[j + 3]) < s_ivw[j + 3] ? j + 3 : 0xFFFFFFFFu;
-                            found = min(found, min(min(a0, a1), min(a2, a3)));
+                    if (t0) __syncthreads();  // previous tile's s_best fully consumed
+                    // narrow arms: one thread per hit, two buckets
+                    if ((uint32_t)tid < ct) {
+                        const PosT x = from_lds ? s_hits[off + t0 + tid] : P.hits[row + t0 + tid];
+                        const uint64_t lo_re = (uint64_t)x + 1u > (uint64_t)G ? (uint64_t)x + 1u - G : 0u;
+                        const uint32_t b0 = (uint32_t)(lo_re >> bsh);
+                        const uint32_t b1 = (uint32_t)(((uint64_t)x + k - 1u) >> bsh);
+                        uint32_t best = 0xFFFFFFFFu;
+                        for (uint32_t bkt = b0; bkt <= b1; ++bkt) {
+                            uint32_t j = s_head[((bkt * 2654435761u) >> 12) & hmask];
+                            while (j != 0xFFFFFFFFu && j != 0xFFFFu) {
+                                if (j < best && arm_accepts<PosT>(x, s_re[j], s_thr[j], k)) best = j;
+                                j = s_next[j];
+                            }
                         }
-                        for (; j < j1; ++j)
-                            found = min(found, (uint64_t)(PosT)(x - s_ivlo[j]) < s_ivw[j] ? j : 0xFFFFFFFFu);
-                        if (valid && found != 0xFFFFFFFFu) atomicMin(&s_best[tl], found);
+                        s_best[tid] = best;
+                    }
+                    __syncthreads();
+                    // wide arms: thread = (hit, part of the packed list), branch-free scan
+                    if (n_wide) {
+                        const uint32_t Hr = (ct + 63u) & ~63u;  // hits rounded up to waves
+                        const uint32_t NP = NT / Hr;            // list parts
+                        const uint32_t tl = (uint32_t)tid % Hr, part = (uint32_t)tid / Hr;
+                        const bool valid = tl < ct && part < NP;
+                        PosT x = 0;
+                        if (valid) x = from_lds ? s_hits[off + t0 + tl] : P.hits[row + t0 + tl];
+                        if (part < NP) {  // wave-uniform
+                            const uint32_t j0 = (uint32_t)((uint64_t)n_wide * part / NP);
+                            const uint32_t j1 = (uint32_t)((uint64_t)n_wide * (part + 1) / NP);
+                            uint32_t found = 0xFFFFFFFFu;
+                            uint32_t j = j0;
+                            for (; j + 4 <= j1; j += 4) {
+                                const uint32_t a0 = (uint64_t)(PosT)(x - s_ivlo[j]) < s_ivw[j] ? s_widx[j] : 0xFFFFFFFFu;
+                                const uint32_t a1 = (uint64_t)(PosT)(x - s_ivlo[j + 1]) < s_ivw[j + 1] ? s_widx[j + 1] : 0xFFFFFFFFu;
+                                const uint32_t a2 = (uint64_t)(PosT)(x - s_ivlo[j + 2]) < s_ivw[j + 2] ? s_widx[j + 2] : 0xFFFFFFFFu;
+                                const uint32_t a3 = (uint64_t)(PosT)(x - s_ivlo[j + 3]) < s_ivw[j + 3] ? s_widx[j + 3] : 0xFFFFFFFFu;
+                                found = min(found, min(min(a0, a1), min(a2, a3)));
+                            }
+                            for (; j < j1; ++j)
+                                found = min(found, (uint64_t)(PosT)(x - s_ivlo[j]) < s_ivw[j] ? (uint32_t)s_widx[j] : 0xFFFFFFFFu);
+                            if (valid && found != 0xFFFFFFFFu) atomicMin(&s_best[tl], found);
+                        }
                     }
                     __syncthreads();
                     // one thread per hit from here on
@@ -1272,8 +1325,18 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
                         if (best != 0xFFFFFFFFu) atomicMax(&s_pend[best], t0 + tid + 1u);
                     }
                     const bool is_new = mine && best == 0xFFFFFFFFu;
-                    uint32_t n_new = 0;
-                    const uint32_t slot = A + block_flag_scan<NW>(is_new, s_wsum, &n_new);
+                    // order-preserving NewArm slots: every wave counts the unmatched hits of the
+                    // 64-hit groups before its own straight from s_best (no block scan, no barrier)
+                    uint32_t before = 0, n_new = 0;
+                    for (uint32_t c0 = 0; c0 < ct; c0 += 64) {
+                        const uint32_t hidx = c0 + lane;
+                        const unsigned long long nm = __ballot(hidx < ct && s_best[hidx] == 0xFFFFFFFFu);
+                        const uint32_t pc = (uint32_t)__popcll(nm);
+                        if (c0 < ((uint32_t)tid & ~63u)) before += pc;
+                        else if (c0 == ((uint32_t)tid & ~63u)) before += (uint32_t)__popcll(nm & lt_mask);
+                        n_new += pc;
+                    }
+                    const uint32_t slot = A + before;
                     if (is_new) {
                         s_ls[slot] = (PosT)i; s_le[slot] = (PosT)(i + k); s_rs[slot] = hx;
                         s_re[slot] = (PosT)(hx + k);
@@ -1298,13 +1361,15 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
                         s_thr[j] = arm_threshold((uint64_t)(i + k) - (uint64_t)s_ls[j], G);
                         s_gap[j] = 0;
                     } else {
-                        s_gap[j] += step;
+                        const uint32_t ng = s_gap[j] + step;
+                        s_gap[j] = ng;
+                        if (ng >= G) s_anydead = 1;
                     }
                 }
                 __syncthreads();
                 PROF_STOP(7);
                 PROF_START();
-                retire();
+                if (s_anydead) retire();
                 PROF_STOP(8);
             }
             if (!done) {

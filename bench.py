@@ -30,7 +30,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 import asgart_amd  # noqa: E402
-from asgart_amd import prep, synth  # noqa: E402
+from asgart_amd import multi, prep, synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 MODES = ((False, False), (True, True))  # direct, then -RC
@@ -110,7 +110,8 @@ def main():
         out = []
         for st in settings:
             if world > 1:
-                out.append(idx.search_duplications_raw(pr.chunks, st, shard=rank, n_shards=world))
+                r_ = idx.search_duplications_raw(pr.chunks, st, shard=rank, n_shards=world)
+                out.append(multi.gather_families(r_[0], r_[1], dist, device=f"cuda:{local_rank}"))
             else:
                 out.append(idx.search_duplications_raw(pr.chunks, st))
         return out
@@ -120,8 +121,11 @@ def main():
     # per-pass device timings + work counters (one extra untimed pass per mode)
     pass_stats = []
     for st in settings:
-        idx.search_duplications_raw(pr.chunks, st)
-        pass_stats.append(idx.stats(1).as_dict())
+        if world > 1:
+            idx.search_duplications_raw(pr.chunks, st, shard=rank, n_shards=world)
+        else:
+            idx.search_duplications_raw(pr.chunks, st)
+        pass_stats.append(idx.stats(1).as_dict())   # rank-local work counters
 
     sync()
     t0 = time.perf_counter()
@@ -131,6 +135,8 @@ def main():
         for st in settings:
             if world > 1:
                 res = idx.search_duplications_raw(pr.chunks, st, shard=rank, n_shards=world)
+                # the only exchange of the path: duplicon lists -> rank 0 over RCCL
+                res = multi.gather_families(res[0], res[1], dist, device=f"cuda:{local_rank}")
             else:
                 res = idx.search_duplications_raw(pr.chunks, st)
             s = idx.stats(0)

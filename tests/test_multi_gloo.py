@@ -1,0 +1,61 @@
+"""World-size-2 test of the multi-GPU host path on CPU (gloo): each rank produces the results of
+its contiguous share of the chunks with the oracle (a stand-in for asgart_search_duplications_shard,
+whose shards are also contiguous in chunk/probe order), gather_families must reassemble exactly
+the single-process result on rank 0."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    import oracle
+    from asgart_amd import multi, prep, synth
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    recs = synth.make_genome([90_000, 60_000, 50_000, 40_000], seed=5, sd_per_mb=60,
+                             sd_len=(1000, 6000), alu_frac=0.03, l1_frac=0.0, sat_per_record=0)
+    pr = prep.prepare_records(recs)
+    idx = oracle.Index.build(pr.data)
+    st = oracle.make_settings()
+    n = len(pr.chunks)
+    mine = pr.chunks[rank * n // world:(rank + 1) * n // world]
+    offs, sds = idx.run_raw(mine, st)
+    got = multi.gather_families(offs, sds, dist)
+    if rank == 0:
+        full = idx.run_raw(pr.chunks, st)
+        ok = np.array_equal(got[0], full[0]) and np.array_equal(got[1], full[1]) and len(full[1]) > 0
+        q.put(bool(ok))
+    else:
+        assert got is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gather_families_world(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
