@@ -73,9 +73,18 @@ def main():
         import torch
         import torch.distributed as dist_mod
 
+        # debugging knobs for 1-GPU boxes: all ranks on device 0 + gloo (RCCL refuses two ranks
+        # on one device); the driver's multi-GPU runs use neither
+        if os.environ.get("ASGART_BENCH_ONE_DEVICE"):
+            local_rank = 0
+        backend = os.environ.get("ASGART_BENCH_BACKEND", "nccl")
         torch.cuda.set_device(local_rank)
-        dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist_mod.init_process_group(backend)
         dist = dist_mod
+        comm_device = f"cuda:{local_rank}" if backend == "nccl" else "cpu"
 
     cfg, scale, desc = WORKLOADS[args.workload]
     k, gap = 20, 100
@@ -111,7 +120,7 @@ def main():
         for st in settings:
             if world > 1:
                 r_ = idx.search_duplications_raw(pr.chunks, st, shard=rank, n_shards=world)
-                out.append(multi.gather_families(r_[0], r_[1], dist, device=f"cuda:{local_rank}"))
+                out.append(multi.gather_families(r_[0], r_[1], dist, device=comm_device))
             else:
                 out.append(idx.search_duplications_raw(pr.chunks, st))
         return out
@@ -136,7 +145,7 @@ def main():
             if world > 1:
                 res = idx.search_duplications_raw(pr.chunks, st, shard=rank, n_shards=world)
                 # the only exchange of the path: duplicon lists -> rank 0 over RCCL
-                res = multi.gather_families(res[0], res[1], dist, device=f"cuda:{local_rank}")
+                res = multi.gather_families(res[0], res[1], dist, device=comm_device)
             else:
                 res = idx.search_duplications_raw(pr.chunks, st)
             s = idx.stats(0)
@@ -148,7 +157,7 @@ def main():
     if dist is not None:
         import torch
 
-        t = torch.tensor([elapsed], device="cuda")
+        t = torch.tensor([elapsed], device=comm_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
