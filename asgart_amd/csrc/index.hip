@@ -309,11 +309,13 @@ void asgart_index_destroy(asgart_index *idx) {
     Workspace &w = idx->ws;
     DevBuf *bufs[] = {&w.chunks, &w.p_lo, &w.p_raw, &w.p_filt, &w.row_off, &w.blk, &w.hits,
                       &w.big_list, &w.seg_list, &w.counters, &w.fam_sds,
-                      &w.ovf_list, &w.scratch, &w.pat, &w.out_a, &w.out_b};
+                      &w.ovf_list, &w.scratch, &w.seg_keys, &w.seg_vals, &w.sort_tmp, &w.pat, &w.out_a, &w.out_b};
     for (DevBuf *b : bufs) b->release();
     for (auto &e : idx->ev)
         if (e) (void)hipEventDestroy(e);
     if (idx->stream) (void)hipStreamDestroy(idx->stream);
+    if (idx->stream2) (void)hipStreamDestroy(idx->stream2);
+    if (idx->stream3) (void)hipStreamDestroy(idx->stream3);
     delete idx;
 }
 
@@ -345,6 +347,8 @@ int32_t asgart_index_create(const uint8_t *T, int64_t n, const int64_t *SA, int6
     memset(&idx->stats, 0, sizeof(idx->stats));
     int32_t rc = [&]() -> int32_t {
         HIP_TRY(hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&idx->stream2, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&idx->stream3, hipStreamNonBlocking));
         for (auto &e : idx->ev) HIP_TRY(hipEventCreate(&e));
         HIP_TRY(hipMalloc((void **)&idx->d_text, (size_t)n + 64));
         HIP_TRY(hipMemsetAsync(idx->d_text + n, 0, 64, idx->stream));

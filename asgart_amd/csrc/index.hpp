@@ -68,6 +68,7 @@ struct Workspace {
     DevBuf fam_sds;    // SdRec[cap] output records of the extension kernel
     DevBuf ovf_list;   // u32 segments that overflowed the small arm tier
     DevBuf scratch;    // arm storage of the global heavy tier
+    DevBuf seg_keys, seg_vals, sort_tmp;  // segment placement: (tier, work) keys, double-buffered
     DevBuf pat;        // pattern upload scratch
     DevBuf out_a, out_b;
 };
@@ -77,6 +78,7 @@ struct Workspace {
 struct asgart_index {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr, stream3 = nullptr;  // concurrent extension tiers
     int64_t n = 0;
     bool wide = false;  // 64-bit slots/positions
     uint8_t *d_text = nullptr;
@@ -131,6 +133,8 @@ int32_t run_search(asgart_index *idx, const uint64_t *chunks, int64_t n_chunks,
                    const asgart_settings *st, int32_t shard, int32_t n_shards, bool want_csr,
                    asgart_families *fam_out, std::vector<uint8_t> *status_out,
                    std::vector<uint64_t> *rowoff_out, std::vector<uint64_t> *hits_out);
+int32_t sort_segments(Workspace &w, uint32_t *keys, uint32_t *vals, uint64_t n, hipStream_t s,
+                      const uint32_t **sorted_vals);
 int32_t text_is_dna(const uint8_t *d_text, int64_t n, hipStream_t s, bool *dna);
 int32_t sa_build_device(const uint8_t *d_text, int64_t n, void *d_sa, bool wide,
                         hipStream_t stream);

@@ -20,14 +20,15 @@ namespace asgart {
                 tag, h_ctr[16], h_ctr[17], h_ctr[18], h_ctr[19], h_ctr[20], h_ctr[21], h_ctr[22], h_ctr[23],  \
                 h_ctr[24], h_ctr[25], h_ctr[26], h_ctr[27], h_ctr[28], h_ctr[29], h_ctr[30] >> 32,            \
                 h_ctr[30] & 0xffffffffull, h_ctr[31] >> 32, h_ctr[31] & 0xffffffffull, h_ctr[32], h_ctr[33]); \
-        (void)hipMemsetAsync(d_ctr + 16, 0, 32 * 8, s);                                        \
+        (void)hipMemsetAsync(d_ctr + 16, 0, 18 * 8, s);                                        \
     } while (0)
 #else
 #define PROF_DUMP(tag)
 #endif
 
 constexpr int kArmCapSmall = 256;   // live arms per wave in LDS, common case
-constexpr int kArmCapMid = 1024;    // second tier: block-cooperative kernel, 256 threads per segment
+constexpr uint32_t kTier1MaxSum = 20000;  // placement: busier segments never run on a single wave
+constexpr int kArmCapMid = 896;     // second tier: block-cooperative kernel, 256 threads per segment
 constexpr uint32_t kEscalateCostMid = 0xFFFFFFFFu;  // mid -> heavy: sum of (live arms + hits) over probes
 constexpr int kArmCapGlobal32 = 16384;  // last tier: arms in HBM scratch, intervals in LDS (128 KiB)
 constexpr int kArmCapGlobal64 = 8192;
@@ -232,94 +233,145 @@ static int32_t run_search_t(asgart_index *idx, const uint64_t *chunks, int64_t n
     // ---- K4: extension automaton ------------------------------------------------
     if (fam_out && n_seg) {
         uint64_t rec_cap = std::max<uint64_t>(1u << 18, w.fam_sds.cap / sizeof(SdRec));
-        RC_TRY(w.ovf_list.reserve((size_t)(n_seg + 1) * 8));
+        RC_TRY(w.ovf_list.reserve((size_t)(n_seg + 1) * 12));
         std::vector<SdRec> h_recs;
+        // ---- placement: per-segment work estimate -> tier, longest first --------------------
+        // ASGART_FORCE_TIER=t (tests): start every segment with a multi-hit probe in tier >= t
+        const int force_tier = getenv("ASGART_FORCE_TIER") ? atoi(getenv("ASGART_FORCE_TIER")) : 0;
+        RC_TRY(w.seg_keys.reserve((size_t)n_seg * 4 * 2));
+        RC_TRY(w.seg_vals.reserve((size_t)n_seg * 4 * 2));
+        uint32_t *kbuf = w.seg_keys.as<uint32_t>(), *vbuf = w.seg_vals.as<uint32_t>();
+        HIP_TRY(hipMemsetAsync(d_ctr + CT_N1, 0, 14 * 8, s));
+        PlaceParams pp;
+        pp.cap1 = kArmCapSmall;
+        pp.cap2 = kArmCapMid;
+        pp.cap3 = sizeof(SlotT) == 4 ? kArmCapBig32 : kArmCapBig64;
+        pp.sum1 = kTier1MaxSum;
+        pp.force_tier = force_tier;
+        seg_stats_kernel<<<(unsigned)std::min<uint64_t>(n_seg, 8192), 64, 0, s>>>(
+            rp, p_filt, seg_list, d_ctr + CT_SEG, kbuf, vbuf, pp, d_ctr);
+        HIP_TRY(hipGetLastError());
+        const uint32_t *order = nullptr;
+        RC_TRY(sort_segments(w, kbuf, vbuf, n_seg, s, &order));
+        HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, sizeof(h_ctr), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        const uint64_t n_t[4] = {h_ctr[CT_N1], h_ctr[CT_N2], h_ctr[CT_N3], h_ctr[CT_N4]};
+        uint32_t *ovf[3] = {w.ovf_list.as<uint32_t>(), w.ovf_list.as<uint32_t>() + (n_seg + 1),
+                            w.ovf_list.as<uint32_t>() + 2 * (n_seg + 1)};
+        constexpr int capg = sizeof(SlotT) == 4 ? kArmCapGlobal32 : kArmCapGlobal64;
+        const size_t per_wg = (size_t)capg * (4 * sizeof(SlotT) + 16);
+        RC_TRY(w.scratch.reserve(per_wg * 256));
         for (int attempt = 0;; ++attempt) {
             RC_TRY(w.fam_sds.reserve((size_t)rec_cap * sizeof(SdRec)));
-            HIP_TRY(hipMemsetAsync(d_ctr + CT_SEG_CURSOR, 0, 4 * 8, s));  // cursor, fam, sd, ovf
+            HIP_TRY(hipMemsetAsync(d_ctr + CT_SD, 0, 8, s));
+            HIP_TRY(hipMemsetAsync(d_ctr + CT_NF, 0, 10 * 8, s));  // NF, cursors, OVF1..4
+            HIP_TRY(hipEventRecord(idx->ev[7], s));
             ExtParams<SlotT> ep;
             ep.rp = rp;
             ep.p_filt = p_filt;
             ep.row_off = row_off;
             ep.hits = hits;
-            ep.seg_list = seg_list;
-            ep.n_seg_ptr = d_ctr + CT_SEG;
-            ep.cursor = d_ctr + CT_SEG_CURSOR;
             ep.recs = w.fam_sds.as<SdRec>();
             ep.rec_cap = rec_cap;
-            ep.ovf_list = w.ovf_list.as<uint32_t>();
-            ep.scratch = nullptr;
-            // ASGART_FORCE_TIER=t (tests): make every tier below t give up at once
-            const int force_tier = getenv("ASGART_FORCE_TIER") ? atoi(getenv("ASGART_FORCE_TIER")) : 0;
-            ep.escalate_cost = force_tier > 1 ? 0u : kEscalateCost;
-            ep.cap_limit = 0xFFFFFFFFu;
+            ep.scratch = w.scratch.as<char>();
+            // ASGART_TEST_CAP_LIMIT (tests): shrink the tiers' capacity to exercise the cascade
+            ep.cap_limit = getenv("ASGART_TEST_CAP_LIMIT") ? (uint32_t)atoi(getenv("ASGART_TEST_CAP_LIMIT")) : 0xFFFFFFFFu;
+            ep.escalate_cost = 0xFFFFFFFFu;
             ep.ctr = d_ctr;
-            const unsigned waves = (unsigned)std::min<uint64_t>(n_seg, 256ull * 12ull);
-            extend_kernel<SlotT, kArmCapSmall><<<waves, 64, 0, s>>>(ep);
+            // The tiers run concurrently, each on its own share of the segments (longest first)
+            // and of the CUs (grid sizes); the window bound guarantees that a segment fits its
+            // tier, so the overflow lists normally stay empty (they feed the cascade below).
+            hipStream_t st2 = idx->stream2, st3 = idx->stream3;
+            HIP_TRY(hipStreamWaitEvent(st2, idx->ev[7], 0));
+            HIP_TRY(hipStreamWaitEvent(st3, idx->ev[7], 0));
+            if (n_t[0]) {
+                ep.seg_list = order;
+                ep.n_seg_ptr = d_ctr + CT_N1;
+                ep.cursor = d_ctr + CT_CUR1;
+                ep.ovf_list = ovf[0];
+                ep.ovf_count = d_ctr + CT_OVF1;
+                const unsigned g1 = (unsigned)std::min<uint64_t>(n_t[0], 256ull * 8ull);
+                extend_kernel<SlotT, kArmCapSmall><<<g1, 64, 0, s>>>(ep);
+            }
+            if (n_t[1]) {
+                ep.seg_list = order + n_t[0];
+                ep.n_seg_ptr = d_ctr + CT_N2;
+                ep.cursor = d_ctr + CT_CUR2;
+                ep.ovf_list = ovf[1];
+                ep.ovf_count = d_ctr + CT_OVF2;
+                const unsigned g2 = (unsigned)std::min<uint64_t>(n_t[1], 256ull * 2ull);
+                extend_heavy_kernel<SlotT, kArmCapMid, kMidThreads, false><<<g2, kMidThreads, 0, st2>>>(ep);
+            }
+            if (n_t[2]) {
+                ep.seg_list = order + n_t[0] + n_t[1];
+                ep.n_seg_ptr = d_ctr + CT_N3;
+                ep.cursor = d_ctr + CT_CUR3;
+                ep.ovf_list = ovf[2];
+                ep.ovf_count = d_ctr + CT_OVF3;
+                const unsigned g3 = (unsigned)std::min<uint64_t>(n_t[2], 96ull);
+                if constexpr (sizeof(SlotT) == 4)
+                    extend_heavy_kernel<SlotT, kArmCapBig32, kHeavyThreads, false><<<g3, kHeavyThreads, 0, st3>>>(ep);
+                else
+                    extend_heavy_kernel<SlotT, kArmCapBig64, kHeavyThreads, false><<<g3, kHeavyThreads, 0, st3>>>(ep);
+            }
+            if (n_t[3]) {
+                ep.seg_list = order + n_t[0] + n_t[1] + n_t[2];
+                ep.n_seg_ptr = d_ctr + CT_N4;
+                ep.cursor = d_ctr + CT_CUR4;
+                ep.ovf_list = nullptr;
+                ep.ovf_count = d_ctr + CT_OVF4;
+                const unsigned g4 = (unsigned)std::min<uint64_t>(n_t[3], 64ull);
+                extend_heavy_kernel<SlotT, capg, kHeavyThreads, true><<<g4, kHeavyThreads, 0, st3>>>(ep);
+            }
             HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(idx->ev[5], st2));
+            HIP_TRY(hipEventRecord(idx->ev[6], st3));
+            HIP_TRY(hipStreamWaitEvent(s, idx->ev[5], 0));
+            HIP_TRY(hipStreamWaitEvent(s, idx->ev[6], 0));
             HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, sizeof(h_ctr), hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
-            PROF_DUMP("tier1");
-            if (h_ctr[CT_OVF]) {
-                // Escalation: segments the one-wave kernel gave up on are re-run from their start
-                // by (tier 2) the same kernel with a 4x larger LDS share, then (tier 3) the
-                // block-cooperative heavy kernel, one workgroup per CU.
-                n_overflow = h_ctr[CT_OVF];
-                HIP_TRY(hipEventRecord(idx->ev[5], s));
-                uint32_t *list_a = w.ovf_list.as<uint32_t>();
-                uint32_t *list_b = list_a + (n_seg + 1);
-                uint32_t *lists[2] = {list_a, list_b};
-                for (int tier = 2; tier <= 4 && h_ctr[CT_OVF]; ++tier) {
-                    const uint64_t n_ovf = h_ctr[CT_OVF];
-                    HIP_TRY(hipMemsetAsync(d_ctr + CT_OVF, 0, 8, s));
-                    HIP_TRY(hipMemsetAsync(d_ctr + CT_OVF_CURSOR, 0, 8, s));
-                    // n_seg_ptr must point at a device word holding the list length
-                    HIP_TRY(hipMemcpyAsync(d_ctr + CT_BISECT, &n_ovf, 8, hipMemcpyHostToDevice, s));
-                    ep.seg_list = lists[tier & 1];        // tier 2 reads a, 3 reads b, 4 reads a
-                    ep.n_seg_ptr = d_ctr + CT_BISECT;
-                    ep.cursor = d_ctr + CT_OVF_CURSOR;
-                    ep.ovf_list = tier < 4 ? lists[(tier + 1) & 1] : nullptr;
-                    // only the one-wave and 256-thread tiers give up on cost; tier 3 only on capacity
-                    ep.escalate_cost = force_tier > tier ? 0u : 0xFFFFFFFFu;
-                    ep.cap_limit = (tier == 3 && force_tier > 3) ? 4u : 0xFFFFFFFFu;
-                    const unsigned bw = (unsigned)std::min<uint64_t>(n_ovf, 256ull);
-                    if (tier == 2) {
-                        // 4 waves per segment, ~3 workgroups per CU
-                        const unsigned mw = (unsigned)std::min<uint64_t>(n_ovf, 256ull * 3ull);
-                        ep.escalate_cost = force_tier > tier ? 0u : kEscalateCostMid;
-                        extend_heavy_kernel<SlotT, kArmCapMid, kMidThreads, false><<<mw, kMidThreads, 0, s>>>(ep);
-                    } else if (tier == 3) {
-                        if constexpr (sizeof(SlotT) == 4)
-                            extend_heavy_kernel<SlotT, kArmCapBig32, kHeavyThreads, false><<<bw, kHeavyThreads, 0, s>>>(ep);
-                        else
-                            extend_heavy_kernel<SlotT, kArmCapBig64, kHeavyThreads, false><<<bw, kHeavyThreads, 0, s>>>(ep);
-                    } else {
-                        constexpr int capg = sizeof(SlotT) == 4 ? kArmCapGlobal32 : kArmCapGlobal64;
-                        const size_t per_wg = 2 * (size_t)capg * (4 * sizeof(SlotT) + 16);
-                        RC_TRY(w.scratch.reserve(per_wg * bw));
-                        ep.scratch = w.scratch.as<char>();
-                        extend_heavy_kernel<SlotT, capg, kHeavyThreads, true><<<bw, kHeavyThreads, 0, s>>>(ep);
-                    }
-                    HIP_TRY(hipGetLastError());
-                    HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, sizeof(h_ctr), hipMemcpyDeviceToHost, s));
-                    HIP_TRY(hipStreamSynchronize(s));
-                    PROF_DUMP(tier == 2 ? "tier2" : (tier == 3 ? "tier3" : "tier4"));
-                    if (tier == 2) n_heavy = h_ctr[CT_OVF];
+            PROF_DUMP("concurrent tiers");
+            n_overflow = h_ctr[CT_OVF1] + h_ctr[CT_OVF2] + h_ctr[CT_OVF3];
+            n_heavy = n_t[2] + n_t[3];
+            // ---- cascade for the segments a tier gave up on (capacity or cost) -----------------
+            const auto t_casc0 = std::chrono::steady_clock::now();
+            for (int tier = 2; tier <= 4; ++tier) {
+                const int src = tier - 2;  // overflow list written by tier-1 level kernels
+                const uint64_t n_ovf = h_ctr[CT_OVF1 + src];
+                if (!n_ovf) continue;
+                HIP_TRY(hipMemcpyAsync(d_ctr + CT_NF, &n_ovf, 8, hipMemcpyHostToDevice, s));
+                HIP_TRY(hipMemsetAsync(d_ctr + CT_CURF, 0, 8, s));
+                ep.seg_list = ovf[src];
+                ep.n_seg_ptr = d_ctr + CT_NF;
+                ep.cursor = d_ctr + CT_CURF;
+                ep.ovf_list = tier < 4 ? ovf[src + 1] : nullptr;
+                ep.ovf_count = d_ctr + CT_OVF1 + src + 1;  // appended behind what is already there
+                ep.escalate_cost = 0xFFFFFFFFu;
+                ep.cap_limit = 0xFFFFFFFFu;
+                const unsigned bw = (unsigned)std::min<uint64_t>(n_ovf, 256ull);
+                if (tier == 2) {
+                    const unsigned mw = (unsigned)std::min<uint64_t>(n_ovf, 256ull * 3ull);
+                    extend_heavy_kernel<SlotT, kArmCapMid, kMidThreads, false><<<mw, kMidThreads, 0, s>>>(ep);
+                } else if (tier == 3) {
+                    if constexpr (sizeof(SlotT) == 4)
+                        extend_heavy_kernel<SlotT, kArmCapBig32, kHeavyThreads, false><<<bw, kHeavyThreads, 0, s>>>(ep);
+                    else
+                        extend_heavy_kernel<SlotT, kArmCapBig64, kHeavyThreads, false><<<bw, kHeavyThreads, 0, s>>>(ep);
+                } else {
+                    extend_heavy_kernel<SlotT, capg, kHeavyThreads, true><<<bw, kHeavyThreads, 0, s>>>(ep);
                 }
-                HIP_TRY(hipEventRecord(idx->ev[6], s));
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, sizeof(h_ctr), hipMemcpyDeviceToHost, s));
                 HIP_TRY(hipStreamSynchronize(s));
-                {
-                    float t2 = 0.f;
-                    HIP_TRY(hipEventElapsedTime(&t2, idx->ev[5], idx->ev[6]));
-                    ms_tier2 = t2;
-                }
-                if (h_ctr[CT_OVF]) {
-                    set_error("%llu segment(s) need more than %d simultaneously live arms; "
-                              "not supported by this build",
-                              (unsigned long long)h_ctr[CT_OVF],
-                              sizeof(SlotT) == 4 ? kArmCapGlobal32 : kArmCapGlobal64);
-                    return ASGART_E_CAP;
-                }
+                PROF_DUMP(tier == 2 ? "cascade2" : (tier == 3 ? "cascade3" : "cascade4"));
+            }
+            ms_tier2 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() -
+                                                                 t_casc0).count();
+            if (h_ctr[CT_OVF4]) {
+                set_error("%llu segment(s) need more than %d simultaneously live arms; "
+                          "not supported by this build", (unsigned long long)h_ctr[CT_OVF4],
+                          sizeof(SlotT) == 4 ? kArmCapGlobal32 : kArmCapGlobal64);
+                return ASGART_E_CAP;
             }
             if (h_ctr[CT_RANOUT]) break;
             if (h_ctr[CT_SD] <= rec_cap) break;

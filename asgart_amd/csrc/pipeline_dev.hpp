@@ -38,6 +38,9 @@ enum Counter {
     CT_OVF_CURSOR,
     CT_AMBIG,         // sharding: start decisions that need a longer look-back
     CT_RANOUT,        // sharding: segments that ran past the look-ahead window
+    CT_N1 = 34, CT_N2, CT_N3, CT_N4, CT_NF,          // list lengths: concurrent tiers, fallback launch
+    CT_CUR1, CT_CUR2, CT_CUR3, CT_CUR4, CT_CURF,     // their work cursors
+    CT_OVF1, CT_OVF2, CT_OVF3, CT_OVF4,    // segments handed on to tier 2 / 3 / 4 / nobody
     CT_COUNT = 48
 };
 
@@ -474,7 +477,8 @@ struct ExtParams {
     unsigned long long *cursor;           // work-fetch cursor
     SdRec *recs;
     unsigned long long rec_cap;
-    uint32_t *ovf_list;                   // segments whose live arms overflowed CAP (may be null)
+    uint32_t *ovf_list;                   // segments this launch gives up on go here (may be null)
+    unsigned long long *ovf_count;        // ... appended at *ovf_count (device counter)
     char *scratch;                        // heavy global tier: per-workgroup arm storage
     uint32_t escalate_cost;               // one-wave tiers: give up after this much LDS-path work
     uint32_t cap_limit;                   // effective live-arm capacity (<= CAP; tests lower it)
@@ -908,69 +912,135 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
         PROF_COUNT(9, 1);
         PROF_FLUSH();
         if (overflow && lane == 0) {
-            const unsigned long long at = atomicAdd(&P.ctr[CT_OVF], 1ull);
+            const unsigned long long at = atomicAdd(P.ovf_count, 1ull);
             if (P.ovf_list) P.ovf_list[at] = g0;
         }
         __syncthreads();
     }
 }
 
+// ---------------------------------------------------------------- K3b --------
+// Per-segment placement (one 64-thread workgroup = one wave per segment, same walk as the
+// extension kernels but without arm state).  Every live arm was created or extended by one hit of
+// the last t*+1 processed probes, so
+//     B = max over probes of (sum of the hit counts of the last t*+1 processed probes)
+// bounds (live arms + hits of the current probe) from above, and at genome scale (arms are mostly
+// single-hit arms that die after t* probes) the bound is tight.  B picks the tier whose arm
+// capacity fits -- no restarts --, the total hit count orders the tier's list longest-first:
+//   key = tier << 30 | (2^30-1 - min(sum, 2^30-1))   (ascending sort = tier, then longest first)
+struct PlaceParams {
+    uint32_t cap1, cap2, cap3;  // arm capacities of tiers 1..3
+    uint32_t sum1;              // segments with more hits than this never go to the one-wave tier
+    int force_tier;             // tests: minimum tier for segments with a multi-hit probe
+};
+
+__global__ __launch_bounds__(64) void seg_stats_kernel(RunParams rp, const uint32_t *__restrict__ p_filt,
+                                                       const uint32_t *__restrict__ seg_list,
+                                                       const unsigned long long *__restrict__ n_seg_ptr,
+                                                       uint32_t *__restrict__ keys,
+                                                       uint32_t *__restrict__ vals, PlaceParams pp,
+                                                       unsigned long long *__restrict__ ctr) {
+    __shared__ uint32_t s_ext[64 + 64];  // [0,TW): carry of the previous batches, then this batch
+    const int lane = threadIdx.x;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const uint64_t n_seg = *n_seg_ptr;
+    const uint32_t TW = min(rp.tstar, 64u);
+    for (uint64_t sidx = blockIdx.x; sidx < n_seg; sidx += gridDim.x) {
+        const uint32_t g0 = seg_list[sidx];
+        const int c = chunk_of(rp.ch, g0);
+        const uint32_t g_end = min(rp.ch.pbase[c + 1], rp.g_hi);
+        uint32_t quiet = 0, mx = 0, bound = 0;
+        unsigned long long sum = 0;
+        bool done = false;
+        s_ext[lane] = 0;
+        __syncthreads();
+        for (uint32_t g = g0; g < g_end && !done; g += 64) {
+            const uint32_t nb = min(64u, g_end - g);
+            const uint32_t f = (uint32_t)lane < nb ? p_filt[g + lane] : kSkipN;
+            const unsigned long long hm = __ballot(f >= 1u && f < kPending);
+            const unsigned long long qm = __ballot(f == 0u);
+            // the segment ends at the first run of tstar quiet probes (skipped ones are transparent)
+            unsigned long long live = ~0ull;  // probes of this batch that belong to the segment
+            uint32_t pos = 0;
+            unsigned long long rest = hm;
+            while (true) {
+                const uint32_t b = rest ? (uint32_t)(__ffsll((long long)rest) - 1) : 64u;
+                const unsigned long long range = (b >= 64 ? ~0ull : ((1ull << b) - 1ull)) &
+                                                 ~(pos >= 64 ? ~0ull : ((1ull << pos) - 1ull));
+                const uint32_t q = (uint32_t)__popcll(qm & range);
+                if (quiet + q >= rp.tstar) {
+                    done = true;
+                    live = pos >= 64 ? ~0ull : ((1ull << pos) - 1ull);
+                    break;
+                }
+                if (b >= 64) {
+                    quiet += q;
+                    break;
+                }
+                quiet = 0;
+                pos = b + 1;
+                rest &= rest - 1;
+            }
+            const unsigned long long procm = (hm | qm) & live;
+            const bool proc = (procm >> lane) & 1ull;
+            const uint32_t v = ((hm & live) >> lane) & 1ull ? f : 0u;
+            const uint32_t r = (uint32_t)__popcll(procm & lt_mask);
+            const uint32_t n_proc = (uint32_t)__popcll(procm);
+            if (proc) s_ext[TW + r] = v;
+            __syncthreads();
+            uint32_t wsum = 0;
+            if (proc)
+                for (uint32_t d = 0; d <= TW; ++d) wsum += s_ext[TW + r - d];
+            uint32_t m = v, wm = wsum;
+            unsigned long long sv = v;
+            for (int off = 32; off > 0; off >>= 1) {
+                sv += __shfl_down(sv, off);
+                m = max(m, (uint32_t)__shfl_down(m, off));
+                wm = max(wm, (uint32_t)__shfl_down(wm, off));
+            }
+            sum += __shfl(sv, 0);
+            mx = max(mx, (uint32_t)__shfl(m, 0));
+            bound = max(bound, (uint32_t)__shfl(wm, 0));
+            // carry: the last TW processed probes seen so far
+            const uint32_t keep = (uint32_t)lane < TW ? s_ext[n_proc + lane] : 0u;
+            __syncthreads();
+            if ((uint32_t)lane < TW) s_ext[lane] = keep;
+            __syncthreads();
+        }
+        if (rp.tstar > 64u) bound *= (rp.tstar + 1u + TW) / (TW + 1u);  // conservative for huge gaps
+        if (lane == 0) {
+            int tier = (bound <= pp.cap1 && sum <= pp.sum1) ? 1 : (bound <= pp.cap2 ? 2 : (bound <= pp.cap3 ? 3 : 4));
+            if (mx > 1 && pp.force_tier > tier) tier = min(pp.force_tier, 4);
+            const uint32_t s30 = sum > 0x3FFFFFFFull ? 0x3FFFFFFFu : (uint32_t)sum;
+            keys[sidx] = (((uint32_t)tier - 1u) << 30) | (0x3FFFFFFFu - s30);
+            vals[sidx] = g0;
+            atomicAdd(&ctr[CT_N1 + tier - 1], 1ull);
+        }
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------- K4b --------
-// Heavy tier of the extension automaton: ONE 1024-thread workgroup (16 waves, a whole CU's
-// LDS) per segment.  Used for the segments that the one-wave kernel gives up on (more live
-// arms than its LDS share, or a long run of many-hit probes): satellite-array tails and dense
-// repeat clusters, where a probe has hundreds of hits against hundreds of live arms.  Same
-// representation and results as extend_kernel; every per-probe phase is spread over the block:
-//   match   thread = (hit, arm-range part): scans its arm range in index order, first accept
-//           -> atomicMin on the hit's best arm
-//   new     order-preserving slots for NewArm by a block-wide ballot scan
-//   apply   arms strided over threads; retire/compact with a block-wide ordered scan
+// Block-cooperative extension kernel: ONE workgroup (NT = 256 or 1024 threads) per segment, for
+// the segments whose live-arm bound does not fit the one-wave kernel.  At genome scale these are
+// dense-repeat clusters and satellite tails: hundreds of hits per probe, hundreds to thousands of
+// live arms, most of them single-hit arms that die t* probes after they were born.
+//
+// Same results as extend_kernel, different bookkeeping:
+//   * arms live in SLOTS; a dead arm's slot goes on a free list and is reused, so there is no
+//     order-preserving compaction.  "First matching arm in list order" (src/automaton.rs:67-78)
+//     is the accepting arm with the smallest CREATION NUMBER (list order == creation order), so
+//     slot order is irrelevant.
+//   * per probe: (0) clear hash heads, (1) hash narrow arms by bucket(re) / list wide arms,
+//     (2) one thread per hit: two buckets + wide list -> best (creation number, slot),
+//     (3) ExtendArm = atomicMax of the hit index on the slot, NewArm = slot from the free list in
+//     hit order, (4) apply / age / retire in place.
+//   * GLOBAL = true keeps the arm arrays in an HBM scratch slice per workgroup (up to 16384
+//     live arms); the per-probe candidate index stays in LDS.
 constexpr int kHeavyThreads = 1024;  // heavy tiers
 constexpr int kMidThreads = 256;     // mid tier: 4 waves per segment, several workgroups per CU
+constexpr uint32_t kNoSeq = 0xFFFFFFFFu;  // s_seq value of an empty slot
 
-// ordered exclusive prefix of a per-thread flag over the block (thread id order)
-template <int NW>
-__device__ inline uint32_t block_flag_scan(bool flag, uint32_t *s_wsum, uint32_t *total) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned long long m = __ballot(flag);
-    if (lane == 0) s_wsum[wave] = (uint32_t)__popcll(m);
-    __syncthreads();
-    uint32_t before = 0, tot = 0;
-    for (int wv = 0; wv < NW; ++wv) {
-        const uint32_t v = s_wsum[wv];
-        if (wv < wave) before += v;
-        tot += v;
-    }
-    __syncthreads();
-    *total = tot;
-    return before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-}
-
-// ordered exclusive prefix of a per-thread count over the block (thread id order)
-template <int NW>
-__device__ inline uint32_t block_count_scan(uint32_t v, uint32_t *s_wsum, uint32_t *total) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t incl = v;
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t o = __shfl_up(incl, off);
-        if (lane >= off) incl += o;
-    }
-    if (lane == 63) s_wsum[wave] = incl;
-    __syncthreads();
-    uint32_t before = 0, tot = 0;
-    for (int wv = 0; wv < NW; ++wv) {
-        const uint32_t x = s_wsum[wv];
-        if (wv < wave) before += x;
-        tot += x;
-    }
-    __syncthreads();
-    *total = tot;
-    return before + incl - v;
-}
-
-// GLOBAL = false: arm arrays in LDS (CAP <= 3072).  GLOBAL = true: arm arrays in a per-workgroup
-// slice of HBM scratch (two copies, compaction ping-pongs between them); only the packed
-// acceptance intervals of the current probe live in LDS, so CAP can reach 16384.
 template <class PosT, int CAP, int NT, bool GLOBAL>
 __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
     constexpr int NW = NT / 64;
@@ -979,39 +1049,26 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
     __shared__ uint32_t l_gap[LCAP], l_thr[LCAP], l_seq[LCAP], l_pend[LCAP];
     PosT *s_ls = l_ls, *s_le = l_le, *s_rs = l_rs, *s_re = l_re;
     uint32_t *s_gap = l_gap, *s_thr = l_thr, *s_seq = l_seq, *s_pend = l_pend;
-    // second copy (GLOBAL only)
-    PosT *t_ls = nullptr, *t_le = nullptr, *t_rs = nullptr, *t_re = nullptr;
-    uint32_t *t_gap = nullptr, *t_thr = nullptr, *t_seq = nullptr, *t_pend = nullptr;
     if constexpr (GLOBAL) {
-        // layout per workgroup: 2 copies x (4 PosT + 4 u32 arrays) of CAP entries
-        const size_t copy_bytes = (size_t)CAP * (4 * sizeof(PosT) + 4 * sizeof(uint32_t));
-        char *basep = P.scratch + (size_t)blockIdx.x * 2 * copy_bytes;
-        auto carve = [&](char *b, PosT *&ls, PosT *&le, PosT *&rs, PosT *&re, uint32_t *&gp,
-                         uint32_t *&th, uint32_t *&sq, uint32_t *&pd) {
-            ls = reinterpret_cast<PosT *>(b);
-            le = ls + CAP; rs = le + CAP; re = rs + CAP;
-            gp = reinterpret_cast<uint32_t *>(re + CAP);
-            th = gp + CAP; sq = th + CAP; pd = sq + CAP;
-        };
-        carve(basep, s_ls, s_le, s_rs, s_re, s_gap, s_thr, s_seq, s_pend);
-        carve(basep + copy_bytes, t_ls, t_le, t_rs, t_re, t_gap, t_thr, t_seq, t_pend);
+        const size_t bytes = (size_t)CAP * (4 * sizeof(PosT) + 4 * sizeof(uint32_t));
+        char *b = P.scratch + (size_t)blockIdx.x * bytes;
+        s_ls = reinterpret_cast<PosT *>(b);
+        s_le = s_ls + CAP; s_rs = s_le + CAP; s_re = s_rs + CAP;
+        s_gap = reinterpret_cast<uint32_t *>(s_re + CAP);
+        s_thr = s_gap + CAP; s_seq = s_thr + CAP; s_pend = s_seq + CAP;
     }
-    __shared__ PosT s_hits[kHitBatch];
-    __shared__ uint32_t s_best[NT];
-    // candidate index rebuilt for every probe (see extend_kernel "LDS path"): narrow arms
-    // (thr == G) hashed by bucket(re), wide arms as a packed list of acceptance intervals
     constexpr uint32_t HT = CAP <= 1024 ? 1024u : (CAP <= 4096 ? 4096u : 8192u);
     constexpr uint32_t WCAP = GLOBAL ? 4096u : (uint32_t)CAP;
     __shared__ uint32_t s_head[HT];
     __shared__ uint16_t s_next[CAP];
+    __shared__ uint16_t s_free[CAP];  // stack of empty slots below the high-water mark
     __shared__ PosT s_ivlo[WCAP];     // wide arm w accepts x iff (x - s_ivlo[w]) < s_ivw[w]
     __shared__ uint32_t s_ivw[WCAP];
     __shared__ uint16_t s_widx[WCAP];
-    __shared__ uint32_t s_nwide;
-    __shared__ uint32_t s_anydead;   // set by any thread that sees an arm's gap reach G
-    __shared__ uint32_t s_wsum[NW];
+    __shared__ PosT s_hits[kHitBatch];
+    __shared__ unsigned long long s_best[NT];  // per hit: (creation number << 20) | slot, or ~0
+    __shared__ uint32_t s_nwide, s_ndead, s_nfreed;
     __shared__ unsigned long long s_bcast;
-    constexpr int PER = GLOBAL ? 1 : (CAP + NT - 1) / NT;
     const int tid = threadIdx.x, lane = tid & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const RunParams &rp = P.rp;
@@ -1020,6 +1077,7 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
     const uint32_t thr0 = arm_threshold(k, G);
     uint32_t bsh = 3;  // bucket(re) = re >> bsh with 2^bsh >= G + k: a hit meets <= 2 buckets
     while ((1ull << bsh) < (unsigned long long)G + k) ++bsh;
+    const uint32_t cap_eff = min((uint32_t)CAP, P.cap_limit);
     PROF_DECL;
 
     for (;;) {
@@ -1035,11 +1093,10 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
         const uint32_t pb = rp.ch.pbase[c];
         const uint32_t chunk_end = rp.ch.pbase[c + 1];
         const uint32_t g_end = min(chunk_end, rp.g_hi);
-        uint32_t A = 0, quiet = 0, fam_seq = 0, next_seq = 0;
-        unsigned long long blk_cost = 0;
+        // block-uniform state: A live arms in slots [0,H), n_free of them empty (on s_free)
+        uint32_t A = 0, H = 0, n_free = 0, quiet = 0, fam_seq = 0, next_seq = 0;
         bool overflow = false, done = false;
 
-        // per-wave aggregated append of output records
         auto emit_records = [&](bool emit, PosT ls, PosT le, PosT rs, PosT re, uint32_t seq) {
             const unsigned long long em = __ballot(emit);
             if (!em) return;
@@ -1064,113 +1121,61 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
                 }
             }
         };
-        auto emit_one = [&](PosT ls, PosT le, PosT rs, PosT re, uint32_t seq) {
-            const unsigned long long at = atomicAdd(&P.ctr[CT_SD], 1ull);
-            if (at < P.rec_cap) {
-                const uint64_t ll = (uint64_t)le - (uint64_t)ls;
-                SdRec r;
-                r.g_start = g0;
-                r.fam_seq = fam_seq;
-                r.create_seq = seq;
-                r.pad = 0;
-                r.sd.left = rp.reverse ? cs + cl - (uint64_t)ls - ll : (uint64_t)ls + cs;
-                r.sd.right = rs;
-                r.sd.left_length = ll;
-                r.sd.right_length = (uint64_t)re - (uint64_t)rs;
-                P.recs[at] = r;
+        // Age every live arm by `add` (unless `extended` applies first), retire in place the ones
+        // whose gap reaches G.  i, off, row, from_lds describe the probe that may have extended
+        // arms (with_pend); block-uniform on exit: A, n_free, fam_seq, next_seq, H.
+        auto age_and_retire = [&](uint32_t add, bool with_pend, uint64_t i, uint32_t off,
+                                  unsigned long long row, bool from_lds) {
+            if (tid == 0) {
+                s_ndead = 0;
+                s_nfreed = 0;
             }
-        };
-        // retire arms whose gap reached G; order-preserving compaction over the whole block
-        auto retire = [&]() {
-            if constexpr (GLOBAL) {
-                // contiguous arm range per thread, one block scan of the survivor counts, copy
-                // into the other buffer (order preserved), swap buffers
-                const uint32_t per = (A + NT - 1) / NT;
-                const uint32_t j0 = min(A, (uint32_t)tid * per), j1 = min(A, j0 + per);
-                uint32_t n_alive = 0;
-                for (uint32_t j = j0; j < j1; ++j)
-                    if (s_gap[j] < G) ++n_alive;
-                uint32_t alive_total = 0;
-                uint32_t d = block_count_scan<NW>(n_alive, s_wsum, &alive_total);
-                for (uint32_t j = j0; j < j1; ++j) {
-                    const PosT ls = s_ls[j], le = s_le[j], rs = s_rs[j], re = s_re[j];
-                    const uint32_t gp = s_gap[j], th = s_thr[j], sq = s_seq[j];
-                    if (gp >= G) {
-                        if ((uint64_t)(re - rs) >= rp.M) emit_one(ls, le, rs, re, sq);
+            __syncthreads();
+            for (uint32_t j0 = 0; j0 < H; j0 += NT) {
+                const uint32_t j = j0 + tid;
+                bool dead = false;
+                PosT ls = 0, le = 0, rs = 0, re = 0;
+                uint32_t sq = kNoSeq;
+                if (j < H && (sq = s_seq[j]) != kNoSeq) {
+                    const uint32_t pd = with_pend ? s_pend[j] : 0u;
+                    if (pd) {
+                        s_pend[j] = 0;
+                        const PosT x = from_lds ? s_hits[off + pd - 1u] : P.hits[row + pd - 1u];
+                        s_re[j] = (PosT)(x + k);
+                        s_le[j] = (PosT)(i + k);
+                        s_thr[j] = arm_threshold((uint64_t)(i + k) - (uint64_t)s_ls[j], G);
+                        s_gap[j] = 0;
                     } else {
-                        t_ls[d] = ls; t_le[d] = le; t_rs[d] = rs; t_re[d] = re;
-                        t_gap[d] = gp; t_thr[d] = th; t_seq[d] = sq; t_pend[d] = 0;
-                        ++d;
+                        const uint32_t gp = s_gap[j];
+                        const uint32_t ng = gp + add < gp ? 0xFFFFFFFFu : gp + add;
+                        s_gap[j] = ng;
+                        if (ng >= G) {
+                            dead = true;
+                            ls = s_ls[j]; le = s_le[j]; rs = s_rs[j]; re = s_re[j];
+                            s_seq[j] = kNoSeq;
+                            s_free[n_free + atomicAdd(&s_nfreed, 1u)] = (uint16_t)j;
+                        }
                     }
                 }
-                __syncthreads();
-                { PosT *x; uint32_t *y;
-                  x = s_ls; s_ls = t_ls; t_ls = x;  x = s_le; s_le = t_le; t_le = x;
-                  x = s_rs; s_rs = t_rs; t_rs = x;  x = s_re; s_re = t_re; t_re = x;
-                  y = s_gap; s_gap = t_gap; t_gap = y;  y = s_thr; s_thr = t_thr; t_thr = y;
-                  y = s_seq; s_seq = t_seq; t_seq = y;  y = s_pend; s_pend = t_pend; t_pend = y; }
-                const bool was_nonempty = A > 0;
-                A = alive_total;
-                if (A == 0 && was_nonempty) {
+                emit_records(dead && (uint64_t)(re - rs) >= rp.M, ls, le, rs, re, sq);
+            }
+            __syncthreads();
+            const uint32_t nd = s_nfreed;
+            __syncthreads();
+            A -= nd;
+            n_free += nd;
+            if (A == 0) {  // the flush of src/automaton.rs:182-200
+                if (H) {
                     ++fam_seq;
                     next_seq = 0;
                 }
-                return;
-            }
-            PosT ls[PER], le[PER], rs[PER], re[PER];
-            uint32_t gp[PER], th[PER], sq[PER];
-            bool alive[PER];
-            bool any_dead = false;
-#pragma unroll
-            for (int u = 0; u < PER; ++u) {
-                const uint32_t j = (uint32_t)u * NT + tid;
-                const bool valid = j < A;
-                ls[u] = le[u] = rs[u] = re[u] = 0;
-                gp[u] = th[u] = sq[u] = 0;
-                if (valid) {
-                    ls[u] = s_ls[j]; le[u] = s_le[j]; rs[u] = s_rs[j]; re[u] = s_re[j];
-                    gp[u] = s_gap[j]; th[u] = s_thr[j]; sq[u] = s_seq[j];
-                }
-                const bool dead = valid && gp[u] >= G;
-                alive[u] = valid && !dead;
-                any_dead |= dead;
-                emit_records(dead && (uint64_t)(re[u] - rs[u]) >= rp.M, ls[u], le[u], rs[u], re[u], sq[u]);
-            }
-            (void)any_dead;  // retire() is only called when s_anydead was raised
-            uint32_t w = 0;
-#pragma unroll
-            for (int u = 0; u < PER; ++u) {
-                uint32_t tot = 0;
-                const uint32_t d = w + block_flag_scan<NW>(alive[u], s_wsum, &tot);
-                if (alive[u]) {
-                    s_ls[d] = ls[u]; s_le[d] = le[u]; s_rs[d] = rs[u]; s_re[d] = re[u];
-                    s_gap[d] = gp[u]; s_thr[d] = th[u]; s_seq[d] = sq[u]; s_pend[d] = 0;
-                }
-                w += tot;
-            }
-            __syncthreads();
-            const bool was_nonempty = A > 0;
-            A = w;
-            if (A == 0 && was_nonempty) {
-                ++fam_seq;
-                next_seq = 0;
+                H = 0;
+                n_free = 0;
             }
         };
         auto advance_quiet = [&](uint32_t q) {
             quiet += q;
-            if (A > 0) {
-                const uint32_t add = q * step;
-                if (tid == 0) s_anydead = 0;
-                __syncthreads();
-                for (uint32_t j = tid; j < A; j += NT) {
-                    const uint32_t gp = s_gap[j];
-                    const uint32_t ng = gp + add < gp ? 0xFFFFFFFFu : gp + add;
-                    s_gap[j] = ng;
-                    if (ng >= G) s_anydead = 1;
-                }
-                __syncthreads();
-                if (s_anydead) retire();
-            }
+            if (A > 0) age_and_retire(q * step, false, 0, 0, 0, true);
             if (A == 0 && quiet >= rp.tstar) done = true;
         };
 
@@ -1224,29 +1229,24 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
                 const uint32_t off = __shfl(rel_l, (int)b);
                 const uint64_t i = (uint64_t)(g + b - pb + 1) * step;
                 const unsigned long long row = base + off;
-                blk_cost += (unsigned long long)A + cnt;
-                if (A + cnt > min((uint32_t)CAP, P.cap_limit) ||
-                    (P.ovf_list && blk_cost > (unsigned long long)P.escalate_cost)) {
+                if (A + cnt > cap_eff) {
                     overflow = true;
                     done = true;
                     break;
                 }
-                const uint32_t A_old = A;
                 const bool from_lds = !first_from_global;
                 PROF_COUNT(5, 1);
-                PROF_COUNT(10, A_old);
+                PROF_COUNT(10, A);
                 PROF_COUNT(11, cnt);
                 PROF_START();
-                // ---- candidate index ------------------------------------------------------
+                // ---- (0)+(1) candidate index over the live arms ------------------------------
                 uint32_t hmask = 63u;
-                while (hmask + 1u < HT && hmask + 1u < 2u * A_old) hmask = (hmask << 1) | 1u;
+                while (hmask + 1u < HT && hmask + 1u < 2u * A) hmask = (hmask << 1) | 1u;
                 for (uint32_t h = tid; h <= hmask; h += NT) s_head[h] = 0xFFFFFFFFu;
-                if (tid == 0) {
-                    s_nwide = 0;
-                    s_anydead = (step >= G) ? 1u : 0u;  // new arms are born with gap = step
-                }
+                if (tid == 0) s_nwide = 0;
                 __syncthreads();
-                for (uint32_t j = tid; j < A_old; j += NT) {
+                for (uint32_t j = tid; j < H; j += NT) {
+                    if (s_seq[j] == kNoSeq) continue;
                     const uint32_t th = s_thr[j];
                     const PosT re = s_re[j];
                     if (th <= G) {
@@ -1269,27 +1269,30 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
                     done = true;
                     break;
                 }
+                const uint32_t seq_base = next_seq;
                 for (uint32_t t0 = 0; t0 < cnt; t0 += NT) {
                     const uint32_t ct = min((uint32_t)NT, cnt - t0);
-                    if (t0) __syncthreads();  // previous tile's s_best fully consumed
-                    // narrow arms: one thread per hit, two buckets
+                    if (t0) __syncthreads();
+                    // ---- (2) narrow arms: one thread per hit, two buckets ----------------------
+                    PosT hx = 0;
                     if ((uint32_t)tid < ct) {
-                        const PosT x = from_lds ? s_hits[off + t0 + tid] : P.hits[row + t0 + tid];
-                        const uint64_t lo_re = (uint64_t)x + 1u > (uint64_t)G ? (uint64_t)x + 1u - G : 0u;
+                        hx = from_lds ? s_hits[off + t0 + tid] : P.hits[row + t0 + tid];
+                        const uint64_t lo_re = (uint64_t)hx + 1u > (uint64_t)G ? (uint64_t)hx + 1u - G : 0u;
                         const uint32_t b0 = (uint32_t)(lo_re >> bsh);
-                        const uint32_t b1 = (uint32_t)(((uint64_t)x + k - 1u) >> bsh);
-                        uint32_t best = 0xFFFFFFFFu;
+                        const uint32_t b1 = (uint32_t)(((uint64_t)hx + k - 1u) >> bsh);
+                        unsigned long long best = ~0ull;
                         for (uint32_t bkt = b0; bkt <= b1; ++bkt) {
                             uint32_t j = s_head[((bkt * 2654435761u) >> 12) & hmask];
                             while (j != 0xFFFFFFFFu && j != 0xFFFFu) {
-                                if (j < best && arm_accepts<PosT>(x, s_re[j], s_thr[j], k)) best = j;
+                                if (arm_accepts<PosT>(hx, s_re[j], s_thr[j], k))
+                                    best = min(best, ((unsigned long long)s_seq[j] << 20) | j);
                                 j = s_next[j];
                             }
                         }
                         s_best[tid] = best;
                     }
                     __syncthreads();
-                    // wide arms: thread = (hit, part of the packed list), branch-free scan
+                    // ---- wide arms: thread = (hit, part of the packed list), branch-free --------
                     if (n_wide) {
                         const uint32_t Hr = (ct + 63u) & ~63u;  // hits rounded up to waves
                         const uint32_t NP = NT / Hr;            // list parts
@@ -1300,77 +1303,61 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
                         if (part < NP) {  // wave-uniform
                             const uint32_t j0 = (uint32_t)((uint64_t)n_wide * part / NP);
                             const uint32_t j1 = (uint32_t)((uint64_t)n_wide * (part + 1) / NP);
-                            uint32_t found = 0xFFFFFFFFu;
-                            uint32_t j = j0;
-                            for (; j + 4 <= j1; j += 4) {
-                                const uint32_t a0 = (uint64_t)(PosT)(x - s_ivlo[j]) < s_ivw[j] ? s_widx[j] : 0xFFFFFFFFu;
-                                const uint32_t a1 = (uint64_t)(PosT)(x - s_ivlo[j + 1]) < s_ivw[j + 1] ? s_widx[j + 1] : 0xFFFFFFFFu;
-                                const uint32_t a2 = (uint64_t)(PosT)(x - s_ivlo[j + 2]) < s_ivw[j + 2] ? s_widx[j + 2] : 0xFFFFFFFFu;
-                                const uint32_t a3 = (uint64_t)(PosT)(x - s_ivlo[j + 3]) < s_ivw[j + 3] ? s_widx[j + 3] : 0xFFFFFFFFu;
-                                found = min(found, min(min(a0, a1), min(a2, a3)));
+                            unsigned long long found = ~0ull;
+                            for (uint32_t j = j0; j < j1; ++j) {
+                                const uint32_t slot = s_widx[j];
+                                const unsigned long long key = ((unsigned long long)s_seq[slot] << 20) | slot;
+                                found = min(found, (uint64_t)(PosT)(x - s_ivlo[j]) < s_ivw[j] ? key : ~0ull);
                             }
-                            for (; j < j1; ++j)
-                                found = min(found, (uint64_t)(PosT)(x - s_ivlo[j]) < s_ivw[j] ? (uint32_t)s_widx[j] : 0xFFFFFFFFu);
-                            if (valid && found != 0xFFFFFFFFu) atomicMin(&s_best[tl], found);
+                            if (valid && found != ~0ull) atomicMin(&s_best[tl], found);
                         }
+                        __syncthreads();
                     }
-                    __syncthreads();
-                    // one thread per hit from here on
+                    // ---- (3) ExtendArm / NewArm, one thread per hit -----------------------------
                     const bool mine = (uint32_t)tid < ct;
-                    PosT hx = 0;
-                    uint32_t best = 0xFFFFFFFFu;
+                    unsigned long long best = ~0ull;
                     if (mine) {
-                        hx = from_lds ? s_hits[off + t0 + tid] : P.hits[row + t0 + tid];
                         best = s_best[tid];
-                        if (best != 0xFFFFFFFFu) atomicMax(&s_pend[best], t0 + tid + 1u);
+                        if (best != ~0ull) atomicMax(&s_pend[(uint32_t)(best & 0xFFFFFu)], t0 + tid + 1u);
                     }
-                    const bool is_new = mine && best == 0xFFFFFFFFu;
-                    // order-preserving NewArm slots: every wave counts the unmatched hits of the
-                    // 64-hit groups before its own straight from s_best (no block scan, no barrier)
+                    const bool is_new = mine && best == ~0ull;
+                    // rank of this hit among the unmatched hits, in hit order (= creation order)
                     uint32_t before = 0, n_new = 0;
                     for (uint32_t c0 = 0; c0 < ct; c0 += 64) {
                         const uint32_t hidx = c0 + lane;
-                        const unsigned long long nm = __ballot(hidx < ct && s_best[hidx] == 0xFFFFFFFFu);
+                        const unsigned long long nm = __ballot(hidx < ct && s_best[hidx] == ~0ull);
                         const uint32_t pc = (uint32_t)__popcll(nm);
                         if (c0 < ((uint32_t)tid & ~63u)) before += pc;
                         else if (c0 == ((uint32_t)tid & ~63u)) before += (uint32_t)__popcll(nm & lt_mask);
                         n_new += pc;
                     }
-                    const uint32_t slot = A + before;
                     if (is_new) {
+                        // reuse empty slots first (top of the stack), then grow the high-water mark
+                        const uint32_t slot = before < n_free ? (uint32_t)s_free[n_free - 1u - before]
+                                                              : H + (before - n_free);
                         s_ls[slot] = (PosT)i; s_le[slot] = (PosT)(i + k); s_rs[slot] = hx;
                         s_re[slot] = (PosT)(hx + k);
-                        s_gap[slot] = step;
+                        s_gap[slot] = 0;  // aged to `step` by this very probe in (4)
                         s_thr[slot] = thr0;
-                        s_seq[slot] = next_seq + (slot - A_old);
+                        s_seq[slot] = next_seq + before;
                         s_pend[slot] = 0;
                     }
+                    if (n_new <= n_free) {
+                        n_free -= n_new;
+                    } else {
+                        H += n_new - n_free;
+                        n_free = 0;
+                    }
                     A += n_new;
+                    next_seq += n_new;
                     __syncthreads();
                 }
-                next_seq += A - A_old;
+                (void)seq_base;
                 PROF_STOP(6);
                 PROF_START();
-                for (uint32_t j = tid; j < A_old; j += NT) {
-                    const uint32_t pd = s_pend[j];
-                    if (pd) {
-                        s_pend[j] = 0;
-                        const PosT x = from_lds ? s_hits[off + pd - 1u] : P.hits[row + pd - 1u];
-                        s_re[j] = (PosT)(x + k);
-                        s_le[j] = (PosT)(i + k);
-                        s_thr[j] = arm_threshold((uint64_t)(i + k) - (uint64_t)s_ls[j], G);
-                        s_gap[j] = 0;
-                    } else {
-                        const uint32_t ng = s_gap[j] + step;
-                        s_gap[j] = ng;
-                        if (ng >= G) s_anydead = 1;
-                    }
-                }
-                __syncthreads();
+                // ---- (4) apply ExtendArm (last hit in SA order wins), age, retire -----------------
+                age_and_retire(step, true, i, off, row, from_lds);
                 PROF_STOP(7);
-                PROF_START();
-                if (s_anydead) retire();
-                PROF_STOP(8);
             }
             if (!done) {
                 const unsigned long long range = pos >= 64 ? 0ull : ~((1ull << pos) - 1ull);
@@ -1386,7 +1373,7 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
             emit_records(tid == 0, (PosT)0, (PosT)0, (PosT)0, (PosT)0, kTombstone);
         }
         if (overflow && tid == 0) {
-            const unsigned long long at = atomicAdd(&P.ctr[CT_OVF], 1ull);
+            const unsigned long long at = atomicAdd(P.ovf_count, 1ull);
             if (P.ovf_list) P.ovf_list[at] = g0;
         }
         if (tid < 64) {
