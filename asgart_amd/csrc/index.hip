@@ -316,6 +316,7 @@ void asgart_index_destroy(asgart_index *idx) {
     if (idx->stream) (void)hipStreamDestroy(idx->stream);
     if (idx->stream2) (void)hipStreamDestroy(idx->stream2);
     if (idx->stream3) (void)hipStreamDestroy(idx->stream3);
+    if (idx->stream4) (void)hipStreamDestroy(idx->stream4);
     delete idx;
 }
 
@@ -349,6 +350,7 @@ int32_t asgart_index_create(const uint8_t *T, int64_t n, const int64_t *SA, int6
         HIP_TRY(hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking));
         HIP_TRY(hipStreamCreateWithFlags(&idx->stream2, hipStreamNonBlocking));
         HIP_TRY(hipStreamCreateWithFlags(&idx->stream3, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&idx->stream4, hipStreamNonBlocking));
         for (auto &e : idx->ev) HIP_TRY(hipEventCreate(&e));
         HIP_TRY(hipMalloc((void **)&idx->d_text, (size_t)n + 64));
         HIP_TRY(hipMemsetAsync(idx->d_text + n, 0, 64, idx->stream));

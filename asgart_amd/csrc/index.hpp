@@ -78,7 +78,7 @@ struct Workspace {
 struct asgart_index {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr, stream3 = nullptr;  // concurrent extension tiers
+    hipStream_t stream2 = nullptr, stream3 = nullptr, stream4 = nullptr;  // concurrent extension tiers
     int64_t n = 0;
     bool wide = false;  // 64-bit slots/positions
     uint8_t *d_text = nullptr;
@@ -101,7 +101,7 @@ struct asgart_index {
     uint32_t last_P = 0;
     asgart::RunParams last_rp;
     bool has_last = false;
-    hipEvent_t ev[8] = {};
+    hipEvent_t ev[10] = {};
 
     template <class SlotT>
     asgart::IndexView<SlotT> view() const {

@@ -256,6 +256,9 @@ static int32_t run_search_t(asgart_index *idx, const uint64_t *chunks, int64_t n
         HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, sizeof(h_ctr), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         const uint64_t n_t[4] = {h_ctr[CT_N1], h_ctr[CT_N2], h_ctr[CT_N3], h_ctr[CT_N4]};
+        if (getenv("ASGART_DEBUG"))
+            fprintf(stderr, "[asgart] segments per tier: %llu %llu %llu %llu\n", (unsigned long long)n_t[0],
+                    (unsigned long long)n_t[1], (unsigned long long)n_t[2], (unsigned long long)n_t[3]);
         uint32_t *ovf[3] = {w.ovf_list.as<uint32_t>(), w.ovf_list.as<uint32_t>() + (n_seg + 1),
                             w.ovf_list.as<uint32_t>() + 2 * (n_seg + 1)};
         constexpr int capg = sizeof(SlotT) == 4 ? kArmCapGlobal32 : kArmCapGlobal64;
@@ -278,12 +281,15 @@ static int32_t run_search_t(asgart_index *idx, const uint64_t *chunks, int64_t n
             ep.cap_limit = getenv("ASGART_TEST_CAP_LIMIT") ? (uint32_t)atoi(getenv("ASGART_TEST_CAP_LIMIT")) : 0xFFFFFFFFu;
             ep.escalate_cost = 0xFFFFFFFFu;
             ep.ctr = d_ctr;
-            // The tiers run concurrently, each on its own share of the segments (longest first)
-            // and of the CUs (grid sizes); the window bound guarantees that a segment fits its
+            // The tiers are launched together on separate streams, each with a grid that can fill
+            // the chip on its own (persistent workgroups, longest segment first): the hardware
+            // back-fills CUs as workgroups retire, so the tails of one tier overlap the next.
+            // The window bound guarantees that a segment fits its
             // tier, so the overflow lists normally stay empty (they feed the cascade below).
-            hipStream_t st2 = idx->stream2, st3 = idx->stream3;
+            hipStream_t st2 = idx->stream2, st3 = idx->stream3, st4 = idx->stream4;
             HIP_TRY(hipStreamWaitEvent(st2, idx->ev[7], 0));
             HIP_TRY(hipStreamWaitEvent(st3, idx->ev[7], 0));
+            HIP_TRY(hipStreamWaitEvent(st4, idx->ev[7], 0));
             if (n_t[0]) {
                 ep.seg_list = order;
                 ep.n_seg_ptr = d_ctr + CT_N1;
@@ -299,7 +305,7 @@ static int32_t run_search_t(asgart_index *idx, const uint64_t *chunks, int64_t n
                 ep.cursor = d_ctr + CT_CUR2;
                 ep.ovf_list = ovf[1];
                 ep.ovf_count = d_ctr + CT_OVF2;
-                const unsigned g2 = (unsigned)std::min<uint64_t>(n_t[1], 256ull * 2ull);
+                const unsigned g2 = (unsigned)std::min<uint64_t>(n_t[1], 256ull * 3ull);
                 extend_heavy_kernel<SlotT, kArmCapMid, kMidThreads, false><<<g2, kMidThreads, 0, st2>>>(ep);
             }
             if (n_t[2]) {
@@ -308,7 +314,7 @@ static int32_t run_search_t(asgart_index *idx, const uint64_t *chunks, int64_t n
                 ep.cursor = d_ctr + CT_CUR3;
                 ep.ovf_list = ovf[2];
                 ep.ovf_count = d_ctr + CT_OVF3;
-                const unsigned g3 = (unsigned)std::min<uint64_t>(n_t[2], 96ull);
+                const unsigned g3 = (unsigned)std::min<uint64_t>(n_t[2], 256ull);
                 if constexpr (sizeof(SlotT) == 4)
                     extend_heavy_kernel<SlotT, kArmCapBig32, kHeavyThreads, false><<<g3, kHeavyThreads, 0, st3>>>(ep);
                 else
@@ -320,14 +326,16 @@ static int32_t run_search_t(asgart_index *idx, const uint64_t *chunks, int64_t n
                 ep.cursor = d_ctr + CT_CUR4;
                 ep.ovf_list = nullptr;
                 ep.ovf_count = d_ctr + CT_OVF4;
-                const unsigned g4 = (unsigned)std::min<uint64_t>(n_t[3], 64ull);
-                extend_heavy_kernel<SlotT, capg, kHeavyThreads, true><<<g4, kHeavyThreads, 0, st3>>>(ep);
+                const unsigned g4 = (unsigned)std::min<uint64_t>(n_t[3], 256ull);
+                extend_heavy_kernel<SlotT, capg, kHeavyThreads, true><<<g4, kHeavyThreads, 0, st4>>>(ep);
             }
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(idx->ev[5], st2));
             HIP_TRY(hipEventRecord(idx->ev[6], st3));
+            HIP_TRY(hipEventRecord(idx->ev[8], st4));
             HIP_TRY(hipStreamWaitEvent(s, idx->ev[5], 0));
             HIP_TRY(hipStreamWaitEvent(s, idx->ev[6], 0));
+            HIP_TRY(hipStreamWaitEvent(s, idx->ev[8], 0));
             HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, sizeof(h_ctr), hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
             PROF_DUMP("concurrent tiers");
