@@ -309,7 +309,7 @@ void asgart_index_destroy(asgart_index *idx) {
     Workspace &w = idx->ws;
     DevBuf *bufs[] = {&w.chunks, &w.p_lo, &w.p_raw, &w.p_filt, &w.row_off, &w.blk, &w.hits,
                       &w.big_list, &w.seg_list, &w.counters, &w.fam_sds,
-                      &w.ovf_list, &w.scratch, &w.seg_keys, &w.seg_vals, &w.sort_tmp, &w.pat, &w.out_a, &w.out_b};
+                      &w.ovf_list, &w.scratch, &w.hit_flag, &w.seg_keys, &w.seg_vals, &w.sort_tmp, &w.pat, &w.out_a, &w.out_b};
     for (DevBuf *b : bufs) b->release();
     for (auto &e : idx->ev)
         if (e) (void)hipEventDestroy(e);

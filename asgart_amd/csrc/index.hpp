@@ -68,6 +68,7 @@ struct Workspace {
     DevBuf fam_sds;    // SdRec[cap] output records of the extension kernel
     DevBuf ovf_list;   // u32 segments that overflowed the small arm tier
     DevBuf scratch;    // arm storage of the global heavy tier
+    DevBuf hit_flag;   // u8 per CSR entry: continuation flag (pre-pass)
     DevBuf seg_keys, seg_vals, sort_tmp;  // segment placement: (tier, work) keys, double-buffered
     DevBuf pat;        // pattern upload scratch
     DevBuf out_a, out_b;

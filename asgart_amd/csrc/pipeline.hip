@@ -248,8 +248,13 @@ static int32_t run_search_t(asgart_index *idx, const uint64_t *chunks, int64_t n
         pp.cap3 = sizeof(SlotT) == 4 ? kArmCapBig32 : kArmCapBig64;
         pp.sum1 = kTier1MaxSum;
         pp.force_tier = force_tier;
-        seg_stats_kernel<<<(unsigned)std::min<uint64_t>(n_seg, 8192), 64, 0, s>>>(
-            rp, p_filt, seg_list, d_ctr + CT_SEG, kbuf, vbuf, pp, d_ctr);
+        // an unextended arm has len(right) = k: it may only be dropped when that is never reported
+        pp.use_filter = (k < st->min_duplication_length && rp.tstar <= 64u && rp.C <= 5000u &&
+                         !getenv("ASGART_NO_FILTER")) ? 1 : 0;
+        RC_TRY(w.hit_flag.reserve((size_t)total_hits + 64));
+        uint8_t *hit_flag = w.hit_flag.as<uint8_t>();
+        seg_prepass_kernel<SlotT><<<(unsigned)std::min<uint64_t>(n_seg, 256ull * 9ull), 64, 0, s>>>(
+            rp, p_filt, row_off, hits, hit_flag, p_raw, seg_list, d_ctr + CT_SEG, kbuf, vbuf, pp, d_ctr);
         HIP_TRY(hipGetLastError());
         const uint32_t *order = nullptr;
         RC_TRY(sort_segments(w, kbuf, vbuf, n_seg, s, &order));
@@ -274,6 +279,8 @@ static int32_t run_search_t(asgart_index *idx, const uint64_t *chunks, int64_t n
             ep.p_filt = p_filt;
             ep.row_off = row_off;
             ep.hits = hits;
+            ep.hit_flag = hit_flag;
+            ep.p_nflag = p_raw;  // rewritten by the pre-pass: flagged hits per probe
             ep.recs = w.fam_sds.as<SdRec>();
             ep.rec_cap = rec_cap;
             ep.scratch = w.scratch.as<char>();

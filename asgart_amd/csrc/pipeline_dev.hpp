@@ -472,6 +472,8 @@ struct ExtParams {
     const uint32_t *p_filt;
     const unsigned long long *row_off;
     const PosT *hits;
+    const uint8_t *hit_flag;              // 1: the hit may start an arm that matches later (K3b)
+    const uint32_t *p_nflag;              // per probe: number of flagged hits
     const uint32_t *seg_list;
     const unsigned long long *n_seg_ptr;  // device count of seg_list entries
     unsigned long long *cursor;           // work-fetch cursor
@@ -514,6 +516,7 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
     __shared__ PosT s_ls[CAP], s_le[CAP], s_rs[CAP], s_re[CAP];
     __shared__ uint32_t s_gap[CAP], s_thr[CAP], s_seq[CAP], s_pend[CAP];
     __shared__ PosT s_hits[kHitBatch];
+    __shared__ uint8_t s_hflag[kHitBatch];  // continuation flags of the staged hits
     // candidate index of the LDS path: arms bucketed by right end (see "LDS path")
     constexpr uint32_t HT = CAP <= 256 ? 256u : (CAP <= 1024 ? 1024u : 4096u);
     __shared__ uint32_t s_head[HT];
@@ -545,7 +548,10 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
         PosT r_ls = 0, r_le = 0, r_rs = 0, r_re = 0;
         uint32_t r_gap = 0, r_thr = 0, r_seq = 0;
         uint32_t A = 0, quiet = 0, fam_seq = 0, next_seq = 0, lds_cost = 0;
-        bool in_regs = true, overflow = false, done = false;
+        // t_proc: processed probes so far; spur_until: processed-probe index at whose end the last
+        // dropped (never-matching) arm would have turned inactive; fam_open: a family is pending
+        uint32_t t_proc = 0, spur_until = 0;
+        bool in_regs = true, overflow = false, done = false, fam_open = false;
 
         // ---- helpers -------------------------------------------------------
         auto emit_records = [&](bool emit, PosT ls, PosT le, PosT rs, PosT re, uint32_t seq) {
@@ -573,9 +579,13 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
                 }
             }
         };
-        auto family_closed = [&]() {  // live list just became empty: the flush of :182-200
-            ++fam_seq;
-            next_seq = 0;
+        // the flush of src/automaton.rs:182-200: every arm inactive, including the dropped ones
+        auto maybe_close = [&]() {
+            if (fam_open && A == 0 && t_proc >= spur_until) {
+                ++fam_seq;
+                next_seq = 0;
+                fam_open = false;
+            }
         };
         // retire arms whose gap reached G (src/automaton.rs:166-171 + flush bookkeeping)
         auto retire_regs = [&]() {
@@ -596,7 +606,6 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
                 r_gap = s_gap[lane]; r_thr = s_thr[lane]; r_seq = s_seq[lane];
             }
             __syncthreads();
-            if (A == 0) family_closed();
         };
         auto retire_lds = [&]() {
             uint32_t w = 0;
@@ -624,9 +633,7 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
                 w += __popcll(am);
                 __syncthreads();
             }
-            const bool was_nonempty = A > 0;
             A = w;
-            if (A == 0 && was_nonempty) family_closed();
         };
         auto to_lds = [&]() {
             if ((uint32_t)lane < A) {
@@ -647,6 +654,7 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
         // q consecutive processed probes without hits
         auto advance_quiet = [&](uint32_t q) {
             quiet += q;
+            t_proc += q;
             if (A > 0) {
                 const uint32_t add = q * step;
                 if (in_regs) {
@@ -665,6 +673,7 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
                     PROF_STOP(8);
                 }
             }
+            maybe_close();
             if (A == 0 && quiet >= rp.tstar) done = true;
         };
 
@@ -673,6 +682,7 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
             PROF_START();
             const uint32_t nb = min(64u, g_end - g);
             const uint32_t f_l = (uint32_t)lane < nb ? P.p_filt[g + lane] : kSkipN;
+            const uint32_t nfl_l = (uint32_t)lane < nb ? P.p_nflag[g + lane] : 0u;  // flagged hits
             const unsigned long long r_l = (uint32_t)lane < nb ? P.row_off[g + lane] : 0ull;
             const unsigned long long r_hi = P.row_off[g + nb];
             const unsigned long long base = __shfl(r_l, 0);
@@ -698,10 +708,19 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
                     const uint32_t r = lane + 64u * u;
                     tmp[u] = r < tot ? P.hits[base + r] : (PosT)0;
                 }
+                uint8_t ftmp[kHitBatch / 64];
 #pragma unroll
                 for (int u = 0; u < kHitBatch / 64; ++u) {
                     const uint32_t r = lane + 64u * u;
-                    if (r < tot) s_hits[r] = tmp[u];
+                    ftmp[u] = r < tot ? P.hit_flag[base + r] : (uint8_t)0;
+                }
+#pragma unroll
+                for (int u = 0; u < kHitBatch / 64; ++u) {
+                    const uint32_t r = lane + 64u * u;
+                    if (r < tot) {
+                        s_hits[r] = tmp[u];
+                        s_hflag[r] = ftmp[u];
+                    }
                 }
             }
             __syncthreads();
@@ -726,10 +745,13 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
                 quiet = 0;
                 pos = b + 1;
                 const uint32_t cnt = __shfl(f_l, (int)b);
+                const uint32_t nfl = __shfl(nfl_l, (int)b);  // only flagged hits can create arms
                 const uint32_t off = __shfl(rel_l, (int)b);
                 const uint64_t i = (uint64_t)(g + b - pb + 1) * step;
                 const unsigned long long row = base + off;
-                if (in_regs && A + cnt <= 64u && !first_from_global) {
+                ++t_proc;
+                bool spur = false;
+                if (in_regs && A + nfl <= 64u && cnt <= 192u && !first_from_global) {
                     // ---------------- register path -------------------------------
                     PROF_START();
                     PROF_COUNT(3, 1);
@@ -745,7 +767,7 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
                                 pend = true;
                                 pend_x = x;
                             }
-                        } else {  // NewArm
+                        } else if (s_hflag[off + t]) {  // NewArm
                             if ((uint32_t)lane == A + newc) {
                                 r_ls = (PosT)i; r_le = (PosT)(i + k); r_rs = x; r_re = (PosT)(x + k);
                                 r_gap = step;  // not dirty: aged by this very probe
@@ -753,6 +775,8 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
                                 r_seq = next_seq + newc;
                             }
                             ++newc;
+                        } else {  // NewArm that can never match: not materialised (K3b)
+                            spur = true;
                         }
                     }
                     if ((uint32_t)lane < A) {
@@ -775,7 +799,7 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
                     // hand the segment to the block-cooperative heavy tier when it does not fit
                     // this wave's LDS share, or keeps producing many-hit x many-arm probes
                     lds_cost += A + cnt;
-                    if (A + cnt > min((uint32_t)CAP, P.cap_limit) || lds_cost > P.escalate_cost) {
+                    if (A + nfl > min((uint32_t)CAP, P.cap_limit) || lds_cost > P.escalate_cost) {
                         overflow = true;
                         done = true;
                         break;
@@ -856,7 +880,9 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
                         }
                         const int found = best == 0xFFFFFFFFu ? -1 : (int)best;
                         if (valid && found >= 0) atomicMax(&s_pend[found], t + 1u);
-                        const bool is_new = valid && found < 0;
+                        const bool fl = valid && (from_lds ? s_hflag[off + t] : P.hit_flag[row + t]) != 0;
+                        const bool is_new = valid && found < 0 && fl;
+                        spur |= __ballot(valid && found < 0 && !fl) != 0ull;
                         const unsigned long long m = __ballot(is_new);
                         if (is_new) {
                             const uint32_t d = A + __popcll(m & lt_mask);
@@ -893,6 +919,10 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
                     if (A <= 32) to_regs();
                     PROF_STOP(8);
                 }
+                // every hit of this probe extended an arm or created one (materialised or not)
+                fam_open = true;
+                if (spur) spur_until = max(spur_until, t_proc + rp.tstar - 1u);
+                maybe_close();
             }
             if (!done) {
                 const unsigned long long range = pos >= 64 ? 0ull : ~((1ull << pos) - 1ull);
@@ -907,7 +937,7 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
         if (!done && g_end < chunk_end) {
             // sharded call: the segment is not finished inside the look-ahead window
             if (lane == 0) atomicAdd(&P.ctr[CT_RANOUT], 1ull);
-        } else if (!overflow && A > 0)
+        } else if (!overflow && fam_open)
             emit_records(lane == 0, (PosT)0, (PosT)0, (PosT)0, (PosT)0, kTombstone);
         PROF_COUNT(9, 1);
         PROF_FLUSH();
@@ -920,94 +950,153 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
 }
 
 // ---------------------------------------------------------------- K3b --------
-// Per-segment placement (one 64-thread workgroup = one wave per segment, same walk as the
-// extension kernels but without arm state).  Every live arm was created or extended by one hit of
-// the last t*+1 processed probes, so
-//     B = max over probes of (sum of the hit counts of the last t*+1 processed probes)
-// bounds (live arms + hits of the current probe) from above, and at genome scale (arms are mostly
-// single-hit arms that die after t* probes) the bound is tight.  B picks the tier whose arm
-// capacity fits -- no restarts --, the total hit count orders the tier's list longest-first:
-//   key = tier << 30 | (2^30-1 - min(sum, 2^30-1))   (ascending sort = tier, then longest first)
+// Per-segment pre-pass (one wave per segment): continuation flags + placement.
+//
+// (1) Continuation filter.  A NewArm created by hit x at processed probe t has right = [x, x+k],
+//     thr = max(G, k/10), and stays active for the next W = t*-1 processed probes.  Unless one of
+//     those probes has a hit x' with  x < x' < x + k + thr  it never accepts anything
+//     (arm_accepts), so it never changes another arm's fate and, with k < M, is never reported:
+//     its only effect is to keep its family open until it dies.  Such hits get flag 0; the
+//     extension kernels do not create the arm and only remember when it would have died
+//     (`spur_until`).  At genome scale this removes most arms of dense repeat clusters.
+//     Implementation: a sliding counting filter in LDS over the hit positions (buckets of
+//     2^bsh >= k + thr bases) of the W processed probes ahead of the current one.  Bucket
+//     granularity and hash collisions can only produce flag 1 for a dead-end hit (harmless:
+//     the arm is created and dies), never the reverse.
+// (2) Placement.  B = max over probes of (hits of this probe + flagged hits of the previous t*
+//     processed probes) estimates live arms + hits; the tier whose capacity fits is chosen, the
+//     overflow cascade catches the rare segment kept alive by unflagged extending hits.
+//     key = (tier-1) << 30 | (2^30-1 - min(total hits, 2^30-1)): ascending sort = tier, longest first.
 struct PlaceParams {
     uint32_t cap1, cap2, cap3;  // arm capacities of tiers 1..3
     uint32_t sum1;              // segments with more hits than this never go to the one-wave tier
     int force_tier;             // tests: minimum tier for segments with a multi-hit probe
+    int use_filter;             // 0: flag every hit (k >= M, huge gaps or cardinalities)
 };
 
-__global__ __launch_bounds__(64) void seg_stats_kernel(RunParams rp, const uint32_t *__restrict__ p_filt,
-                                                       const uint32_t *__restrict__ seg_list,
-                                                       const unsigned long long *__restrict__ n_seg_ptr,
-                                                       uint32_t *__restrict__ keys,
-                                                       uint32_t *__restrict__ vals, PlaceParams pp,
-                                                       unsigned long long *__restrict__ ctr) {
-    __shared__ uint32_t s_ext[64 + 64];  // [0,TW): carry of the previous batches, then this batch
+constexpr uint32_t kFilterBits = 13;  // 8192 16-bit counters = 16 KB of LDS per wave
+
+template <class PosT>
+__global__ __launch_bounds__(64) void seg_prepass_kernel(RunParams rp, const uint32_t *__restrict__ p_filt,
+                                                         const unsigned long long *__restrict__ row_off,
+                                                         const PosT *__restrict__ hits,
+                                                         uint8_t *__restrict__ hit_flag,
+                                                         uint32_t *__restrict__ p_nflag,
+                                                         const uint32_t *__restrict__ seg_list,
+                                                         const unsigned long long *__restrict__ n_seg_ptr,
+                                                         uint32_t *__restrict__ keys,
+                                                         uint32_t *__restrict__ vals, PlaceParams pp,
+                                                         unsigned long long *__restrict__ ctr) {
+    __shared__ uint32_t s_cnt[1u << (kFilterBits - 1)];  // two 16-bit counters per word
+    __shared__ unsigned long long s_qrow[64];            // queue of processed probes ahead: CSR row start
+    __shared__ uint32_t s_qcnt[64];                      //   and hit count (0 = quiet probe)
+    __shared__ uint32_t s_qg[64];                        //   and probe number
+    __shared__ uint32_t s_nf[64];                        // ring: flagged hits of the last t* probes
     const int lane = threadIdx.x;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const uint64_t n_seg = *n_seg_ptr;
-    const uint32_t TW = min(rp.tstar, 64u);
+    const uint32_t k = (uint32_t)rp.k;
+    const uint32_t thr0 = arm_threshold(k, rp.G);
+    uint32_t bsh = 3;
+    while ((1ull << bsh) < (unsigned long long)thr0 + k) ++bsh;
+    const uint32_t W = rp.tstar - 1u;  // probes during which a fresh arm can still accept a hit
+    const bool filt = pp.use_filter && rp.tstar <= 64u;
+    for (uint32_t h = lane; h < (1u << (kFilterBits - 1)); h += 64) s_cnt[h] = 0;
+    __syncthreads();
+    auto slot_of = [&](uint64_t v) -> uint32_t {
+        return (((uint32_t)(v >> bsh)) * 2654435761u) >> (32 - kFilterBits);
+    };
+    auto filter_add = [&](unsigned long long row, uint32_t cnt, bool add) {
+        for (uint32_t t0 = 0; t0 < cnt; t0 += 64) {
+            if (t0 + lane < cnt) {
+                const uint32_t sl = slot_of((uint64_t)hits[row + t0 + lane]);
+                const uint32_t inc = 1u << (16u * (sl & 1u));
+                if (add) atomicAdd(&s_cnt[sl >> 1], inc); else atomicSub(&s_cnt[sl >> 1], inc);
+            }
+        }
+    };
     for (uint64_t sidx = blockIdx.x; sidx < n_seg; sidx += gridDim.x) {
         const uint32_t g0 = seg_list[sidx];
         const int c = chunk_of(rp.ch, g0);
         const uint32_t g_end = min(rp.ch.pbase[c + 1], rp.g_hi);
-        uint32_t quiet = 0, mx = 0, bound = 0;
+        // lead cursor state
+        uint32_t quiet = 0, q_head = 0, q_size = 0;  // queue = ring of 64
+        bool lead_done = false;
+        // trail (current probe) state
+        uint32_t mx = 0, bound = 0, nf_sum = 0, t_idx = 0;
         unsigned long long sum = 0;
-        bool done = false;
-        s_ext[lane] = 0;
+        s_nf[lane] = 0;
         __syncthreads();
-        for (uint32_t g = g0; g < g_end && !done; g += 64) {
+        // pops the oldest queued probe = the current probe of the trail cursor
+        auto trail_step = [&]() {
+            const unsigned long long row = s_qrow[q_head];
+            const uint32_t cnt = s_qcnt[q_head];
+            const uint32_t gq = s_qg[q_head];
+            q_head = (q_head + 1u) & 63u;
+            --q_size;
+            uint32_t nf = 0;
+            if (cnt) {
+                if (filt) filter_add(row, cnt, false);  // window = probes strictly ahead
+                __syncthreads();
+                for (uint32_t t0 = 0; t0 < cnt; t0 += 64) {
+                    bool fl = false;
+                    if (t0 + lane < cnt) {
+                        fl = true;
+                        if (filt) {
+                            const uint64_t x = (uint64_t)hits[row + t0 + lane];
+                            const uint32_t s0 = slot_of(x + 1u), s1 = slot_of(x + k + thr0 - 1u);
+                            const uint32_t c0 = (s_cnt[s0 >> 1] >> (16u * (s0 & 1u))) & 0xFFFFu;
+                            const uint32_t c1 = (s_cnt[s1 >> 1] >> (16u * (s1 & 1u))) & 0xFFFFu;
+                            fl = (c0 | c1) != 0u;
+                        }
+                        hit_flag[row + t0 + lane] = fl ? 1 : 0;
+                    }
+                    nf += (uint32_t)__popcll(__ballot(fl));
+                }
+                if (lane == 0) p_nflag[gq] = nf;
+                sum += cnt;
+                mx = max(mx, cnt);
+                bound = max(bound, nf_sum + cnt);
+            }
+            // sliding sum of the flagged hits of the last t* processed probes
+            const uint32_t ring = min(rp.tstar, 64u);
+            const uint32_t pos = t_idx % ring;
+            const uint32_t old = s_nf[pos];
+            __syncthreads();
+            if (lane == 0) s_nf[pos] = nf;
+            nf_sum = nf_sum - old + nf;
+            ++t_idx;
+            __syncthreads();
+        };
+        for (uint32_t g = g0; g < g_end && !lead_done; g += 64) {
             const uint32_t nb = min(64u, g_end - g);
             const uint32_t f = (uint32_t)lane < nb ? p_filt[g + lane] : kSkipN;
-            const unsigned long long hm = __ballot(f >= 1u && f < kPending);
-            const unsigned long long qm = __ballot(f == 0u);
-            // the segment ends at the first run of tstar quiet probes (skipped ones are transparent)
-            unsigned long long live = ~0ull;  // probes of this batch that belong to the segment
-            uint32_t pos = 0;
-            unsigned long long rest = hm;
-            while (true) {
-                const uint32_t b = rest ? (uint32_t)(__ffsll((long long)rest) - 1) : 64u;
-                const unsigned long long range = (b >= 64 ? ~0ull : ((1ull << b) - 1ull)) &
-                                                 ~(pos >= 64 ? ~0ull : ((1ull << pos) - 1ull));
-                const uint32_t q = (uint32_t)__popcll(qm & range);
-                if (quiet + q >= rp.tstar) {
-                    done = true;
-                    live = pos >= 64 ? ~0ull : ((1ull << pos) - 1ull);
-                    break;
-                }
-                if (b >= 64) {
-                    quiet += q;
-                    break;
-                }
-                quiet = 0;
-                pos = b + 1;
+            const unsigned long long r = (uint32_t)lane < nb ? row_off[g + lane] : 0ull;
+            const unsigned long long procm = __ballot(f < kPending);
+            unsigned long long rest = procm;
+            while (rest && !lead_done) {
+                const uint32_t b = (uint32_t)(__ffsll((long long)rest) - 1);
                 rest &= rest - 1;
+                const uint32_t cnt = __shfl(f, (int)b);
+                const unsigned long long row = __shfl(r, (int)b);
+                if (cnt == 0) {
+                    if (++quiet >= rp.tstar) lead_done = true;  // the segment ends here
+                } else {
+                    quiet = 0;
+                }
+                if (q_size == W + 1u || q_size == 64u) trail_step();
+                const uint32_t tail = (q_head + q_size) & 63u;
+                if (lane == 0) {
+                    s_qrow[tail] = row;
+                    s_qcnt[tail] = cnt;
+                    s_qg[tail] = g + b;
+                }
+                ++q_size;
+                if (cnt && filt) filter_add(row, cnt, true);
+                __syncthreads();
             }
-            const unsigned long long procm = (hm | qm) & live;
-            const bool proc = (procm >> lane) & 1ull;
-            const uint32_t v = ((hm & live) >> lane) & 1ull ? f : 0u;
-            const uint32_t r = (uint32_t)__popcll(procm & lt_mask);
-            const uint32_t n_proc = (uint32_t)__popcll(procm);
-            if (proc) s_ext[TW + r] = v;
-            __syncthreads();
-            uint32_t wsum = 0;
-            if (proc)
-                for (uint32_t d = 0; d <= TW; ++d) wsum += s_ext[TW + r - d];
-            uint32_t m = v, wm = wsum;
-            unsigned long long sv = v;
-            for (int off = 32; off > 0; off >>= 1) {
-                sv += __shfl_down(sv, off);
-                m = max(m, (uint32_t)__shfl_down(m, off));
-                wm = max(wm, (uint32_t)__shfl_down(wm, off));
-            }
-            sum += __shfl(sv, 0);
-            mx = max(mx, (uint32_t)__shfl(m, 0));
-            bound = max(bound, (uint32_t)__shfl(wm, 0));
-            // carry: the last TW processed probes seen so far
-            const uint32_t keep = (uint32_t)lane < TW ? s_ext[n_proc + lane] : 0u;
-            __syncthreads();
-            if ((uint32_t)lane < TW) s_ext[lane] = keep;
-            __syncthreads();
         }
-        if (rp.tstar > 64u) bound *= (rp.tstar + 1u + TW) / (TW + 1u);  // conservative for huge gaps
+        while (q_size) trail_step();
+        if (rp.tstar > 64u) bound = 0xFFFFFFFFu;  // no estimate for huge gap settings: largest tier
         if (lane == 0) {
             int tier = (bound <= pp.cap1 && sum <= pp.sum1) ? 1 : (bound <= pp.cap2 ? 2 : (bound <= pp.cap3 ? 3 : 4));
             if (mx > 1 && pp.force_tier > tier) tier = min(pp.force_tier, 4);
@@ -1066,6 +1155,7 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
     __shared__ uint32_t s_ivw[WCAP];
     __shared__ uint16_t s_widx[WCAP];
     __shared__ PosT s_hits[kHitBatch];
+    __shared__ uint8_t s_hflag[kHitBatch];
     __shared__ unsigned long long s_best[NT];  // per hit: (creation number << 20) | slot, or ~0
     __shared__ uint32_t s_nwide, s_ndead, s_nfreed;
     __shared__ unsigned long long s_bcast;
@@ -1095,7 +1185,8 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
         const uint32_t g_end = min(chunk_end, rp.g_hi);
         // block-uniform state: A live arms in slots [0,H), n_free of them empty (on s_free)
         uint32_t A = 0, H = 0, n_free = 0, quiet = 0, fam_seq = 0, next_seq = 0;
-        bool overflow = false, done = false;
+        uint32_t t_proc = 0, spur_until = 0;  // see extend_kernel
+        bool overflow = false, done = false, fam_open = false;
 
         auto emit_records = [&](bool emit, PosT ls, PosT le, PosT rs, PosT re, uint32_t seq) {
             const unsigned long long em = __ballot(emit);
@@ -1164,18 +1255,24 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
             __syncthreads();
             A -= nd;
             n_free += nd;
-            if (A == 0) {  // the flush of src/automaton.rs:182-200
-                if (H) {
-                    ++fam_seq;
-                    next_seq = 0;
-                }
+            if (A == 0) {  // every slot is empty again
                 H = 0;
                 n_free = 0;
             }
         };
+        // the flush of src/automaton.rs:182-200: every arm inactive, including the dropped ones
+        auto maybe_close = [&]() {
+            if (fam_open && A == 0 && t_proc >= spur_until) {
+                ++fam_seq;
+                next_seq = 0;
+                fam_open = false;
+            }
+        };
         auto advance_quiet = [&](uint32_t q) {
             quiet += q;
+            t_proc += q;
             if (A > 0) age_and_retire(q * step, false, 0, 0, 0, true);
+            maybe_close();
             if (A == 0 && quiet >= rp.tstar) done = true;
         };
 
@@ -1184,6 +1281,7 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
             PROF_START();
             const uint32_t nb = min(64u, g_end - g);
             const uint32_t f_l = (uint32_t)lane < nb ? P.p_filt[g + lane] : kSkipN;
+            const uint32_t nfl_l = (uint32_t)lane < nb ? P.p_nflag[g + lane] : 0u;
             const unsigned long long r_l = (uint32_t)lane < nb ? P.row_off[g + lane] : 0ull;
             const unsigned long long r_hi = P.row_off[g + nb];
             const unsigned long long base = __shfl(r_l, 0);
@@ -1202,7 +1300,10 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
             if (!first_from_global) {
                 const unsigned long long end = nbb == nb ? r_hi : __shfl(r_l, (int)nbb);
                 const uint32_t tot = (uint32_t)(end - base);
-                for (uint32_t r = tid; r < tot; r += NT) s_hits[r] = P.hits[base + r];
+                for (uint32_t r = tid; r < tot; r += NT) {
+                    s_hits[r] = P.hits[base + r];
+                    s_hflag[r] = P.hit_flag[base + r];
+                }
             }
             __syncthreads();
             const unsigned long long in_batch = nbb >= 64 ? ~0ull : ((1ull << nbb) - 1ull);
@@ -1226,10 +1327,13 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
                 quiet = 0;
                 pos = b + 1;
                 const uint32_t cnt = __shfl(f_l, (int)b);
+                const uint32_t nfl = __shfl(nfl_l, (int)b);
                 const uint32_t off = __shfl(rel_l, (int)b);
                 const uint64_t i = (uint64_t)(g + b - pb + 1) * step;
                 const unsigned long long row = base + off;
-                if (A + cnt > cap_eff) {
+                ++t_proc;
+                bool spur = false;
+                if (A + nfl > cap_eff) {
                     overflow = true;
                     done = true;
                     break;
@@ -1320,12 +1424,19 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
                         best = s_best[tid];
                         if (best != ~0ull) atomicMax(&s_pend[(uint32_t)(best & 0xFFFFFu)], t0 + tid + 1u);
                     }
-                    const bool is_new = mine && best == ~0ull;
-                    // rank of this hit among the unmatched hits, in hit order (= creation order)
+                    // unmatched hits: flagged ones become arms, the others are dropped (K3b)
+                    bool fl = false;
+                    if (mine) fl = (from_lds ? s_hflag[off + t0 + tid] : P.hit_flag[row + t0 + tid]) != 0;
+                    if (mine && best == ~0ull && !fl) s_best[tid] = ~0ull - 1ull;  // marks "dropped"
+                    __syncthreads();
+                    const bool is_new = mine && best == ~0ull && fl;
+                    // rank of this hit among the new arms, in hit order (= creation order)
                     uint32_t before = 0, n_new = 0;
                     for (uint32_t c0 = 0; c0 < ct; c0 += 64) {
                         const uint32_t hidx = c0 + lane;
-                        const unsigned long long nm = __ballot(hidx < ct && s_best[hidx] == ~0ull);
+                        const unsigned long long bv = hidx < ct ? s_best[hidx] : 0ull;
+                        const unsigned long long nm = __ballot(bv == ~0ull);
+                        spur |= __ballot(bv == ~0ull - 1ull) != 0ull;
                         const uint32_t pc = (uint32_t)__popcll(nm);
                         if (c0 < ((uint32_t)tid & ~63u)) before += pc;
                         else if (c0 == ((uint32_t)tid & ~63u)) before += (uint32_t)__popcll(nm & lt_mask);
@@ -1357,6 +1468,9 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
                 PROF_START();
                 // ---- (4) apply ExtendArm (last hit in SA order wins), age, retire -----------------
                 age_and_retire(step, true, i, off, row, from_lds);
+                fam_open = true;
+                if (spur) spur_until = max(spur_until, t_proc + rp.tstar - 1u);
+                maybe_close();
                 PROF_STOP(7);
             }
             if (!done) {
@@ -1369,7 +1483,7 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
         }
         if (!done && g_end < chunk_end) {
             if (tid == 0) atomicAdd(&P.ctr[CT_RANOUT], 1ull);
-        } else if (!overflow && A > 0) {
+        } else if (!overflow && fam_open) {
             emit_records(tid == 0, (PosT)0, (PosT)0, (PosT)0, (PosT)0, kTombstone);
         }
         if (overflow && tid == 0) {
