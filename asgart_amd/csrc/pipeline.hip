@@ -20,6 +20,9 @@ namespace asgart {
                 tag, h_ctr[16], h_ctr[17], h_ctr[18], h_ctr[19], h_ctr[20], h_ctr[21], h_ctr[22], h_ctr[23],  \
                 h_ctr[24], h_ctr[25], h_ctr[26], h_ctr[27], h_ctr[28], h_ctr[29], h_ctr[30] >> 32,            \
                 h_ctr[30] & 0xffffffffull, h_ctr[31] >> 32, h_ctr[31] & 0xffffffffull, h_ctr[32], h_ctr[33]); \
+        fprintf(stderr, "    longest slots:");                                                  \
+        for (int pf_i = 0; pf_i < 12; ++pf_i) fprintf(stderr, " [%d]=%llu", pf_i, h_ctr[56 + pf_i]); \
+        fprintf(stderr, "\n");                                                                 \
         (void)hipMemsetAsync(d_ctr + 16, 0, 18 * 8, s);                                        \
     } while (0)
 #else
@@ -28,12 +31,14 @@ namespace asgart {
 
 constexpr int kArmCapSmall = 256;   // live arms per wave in LDS, common case
 constexpr uint32_t kTier1MaxSum = 20000;  // placement: busier segments never run on a single wave
-constexpr int kArmCapMid = 896;     // second tier: block-cooperative kernel, 256 threads per segment
+constexpr int kArmCapMid = 768;     // second tier: block-cooperative kernel, 256 threads per segment
 constexpr uint32_t kEscalateCostMid = 0xFFFFFFFFu;  // mid -> heavy: sum of (live arms + hits) over probes
-constexpr int kArmCapGlobal32 = 16384;  // last tier: arms in HBM scratch, intervals in LDS (128 KiB)
+constexpr int kArmCapHybrid32 = 4608;   // tier 4: hot fields in LDS, (rs, le) in HBM scratch
+constexpr int kArmCapHybrid64 = 3072;
+constexpr int kArmCapGlobal32 = 16384;  // tier 5: all arm fields in HBM scratch
 constexpr int kArmCapGlobal64 = 8192;
-constexpr int kArmCapBig32 = 2816;  // heavy tier, 32-bit positions: 3072*40 B + hits + scratch = 128 KiB
-constexpr int kArmCapBig64 = 1792;  // heavy tier, 64-bit positions: 2048*60 B + hits + scratch = 132 KiB
+constexpr int kArmCapBig32 = 2432;  // heavy tier, 32-bit positions: 3072*40 B + hits + scratch = 128 KiB
+constexpr int kArmCapBig64 = 1664;  // heavy tier, 64-bit positions: 2048*60 B + hits + scratch = 132 KiB
 
 static inline unsigned grid_for(uint64_t n, unsigned block = 256) {
     return (unsigned)((n + block - 1) / block);
@@ -233,7 +238,7 @@ static int32_t run_search_t(asgart_index *idx, const uint64_t *chunks, int64_t n
     // ---- K4: extension automaton ------------------------------------------------
     if (fam_out && n_seg) {
         uint64_t rec_cap = std::max<uint64_t>(1u << 18, w.fam_sds.cap / sizeof(SdRec));
-        RC_TRY(w.ovf_list.reserve((size_t)(n_seg + 1) * 12));
+        RC_TRY(w.ovf_list.reserve((size_t)(n_seg + 1) * 16));
         std::vector<SdRec> h_recs;
         // ---- placement: per-segment work estimate -> tier, longest first --------------------
         // ASGART_FORCE_TIER=t (tests): start every segment with a multi-hit probe in tier >= t
@@ -241,16 +246,25 @@ static int32_t run_search_t(asgart_index *idx, const uint64_t *chunks, int64_t n
         RC_TRY(w.seg_keys.reserve((size_t)n_seg * 4 * 2));
         RC_TRY(w.seg_vals.reserve((size_t)n_seg * 4 * 2));
         uint32_t *kbuf = w.seg_keys.as<uint32_t>(), *vbuf = w.seg_vals.as<uint32_t>();
-        HIP_TRY(hipMemsetAsync(d_ctr + CT_N1, 0, 14 * 8, s));
+        HIP_TRY(hipMemsetAsync(d_ctr + CT_N1, 0, 17 * 8, s));
         PlaceParams pp;
         pp.cap1 = kArmCapSmall;
         pp.cap2 = kArmCapMid;
         pp.cap3 = sizeof(SlotT) == 4 ? kArmCapBig32 : kArmCapBig64;
+        // the window bound is up to ~1.7x pessimistic for tandem arrays (hits extend arms there);
+        // the HBM tier is several times slower per probe, so the hybrid tier also takes segments
+        // whose bound exceeds its capacity by up to 40 % (a real overflow falls through the cascade)
+        pp.cap4 = (sizeof(SlotT) == 4 ? kArmCapHybrid32 : kArmCapHybrid64) * 7 / 5;
+        if (rp.G >= 0xFFF0u || rp.C >= 0xFFF0u) pp.cap4 = pp.cap3;  // 16-bit gap/pend would not do
         pp.sum1 = kTier1MaxSum;
         pp.force_tier = force_tier;
         // an unextended arm has len(right) = k: it may only be dropped when that is never reported
+        // Measured on the GRCh38-shaped workload the filter removes ~85 % of the arms of dense
+        // repeat clusters but its LDS-atomic pre-pass costs more than the extension tiers gain
+        // while a few long tandem-array segments set the critical path, so it is opt-in
+        // (ASGART_FILTER=1) until the pre-pass is cheaper.  Results are identical either way.
         pp.use_filter = (k < st->min_duplication_length && rp.tstar <= 64u && rp.C <= 5000u &&
-                         !getenv("ASGART_NO_FILTER")) ? 1 : 0;
+                         getenv("ASGART_FILTER") && atoi(getenv("ASGART_FILTER")) != 0) ? 1 : 0;
         RC_TRY(w.hit_flag.reserve((size_t)total_hits + 64));
         uint8_t *hit_flag = w.hit_flag.as<uint8_t>();
         seg_prepass_kernel<SlotT><<<(unsigned)std::min<uint64_t>(n_seg, 256ull * 9ull), 64, 0, s>>>(
@@ -260,19 +274,22 @@ static int32_t run_search_t(asgart_index *idx, const uint64_t *chunks, int64_t n
         RC_TRY(sort_segments(w, kbuf, vbuf, n_seg, s, &order));
         HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, sizeof(h_ctr), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
-        const uint64_t n_t[4] = {h_ctr[CT_N1], h_ctr[CT_N2], h_ctr[CT_N3], h_ctr[CT_N4]};
+        const uint64_t n_t[5] = {h_ctr[CT_N1], h_ctr[CT_N2], h_ctr[CT_N3], h_ctr[CT_N4], h_ctr[CT_N5]};
         if (getenv("ASGART_DEBUG"))
-            fprintf(stderr, "[asgart] segments per tier: %llu %llu %llu %llu\n", (unsigned long long)n_t[0],
-                    (unsigned long long)n_t[1], (unsigned long long)n_t[2], (unsigned long long)n_t[3]);
-        uint32_t *ovf[3] = {w.ovf_list.as<uint32_t>(), w.ovf_list.as<uint32_t>() + (n_seg + 1),
-                            w.ovf_list.as<uint32_t>() + 2 * (n_seg + 1)};
+            fprintf(stderr, "[asgart] segments per tier: %llu %llu %llu %llu %llu\n", (unsigned long long)n_t[0],
+                    (unsigned long long)n_t[1], (unsigned long long)n_t[2], (unsigned long long)n_t[3],
+                    (unsigned long long)n_t[4]);
+        uint32_t *ovf[4] = {w.ovf_list.as<uint32_t>(), w.ovf_list.as<uint32_t>() + (n_seg + 1),
+                            w.ovf_list.as<uint32_t>() + 2 * (n_seg + 1),
+                            w.ovf_list.as<uint32_t>() + 3 * (n_seg + 1)};
+        constexpr int caph = sizeof(SlotT) == 4 ? kArmCapHybrid32 : kArmCapHybrid64;
         constexpr int capg = sizeof(SlotT) == 4 ? kArmCapGlobal32 : kArmCapGlobal64;
         const size_t per_wg = (size_t)capg * (4 * sizeof(SlotT) + 16);
         RC_TRY(w.scratch.reserve(per_wg * 256));
         for (int attempt = 0;; ++attempt) {
             RC_TRY(w.fam_sds.reserve((size_t)rec_cap * sizeof(SdRec)));
             HIP_TRY(hipMemsetAsync(d_ctr + CT_SD, 0, 8, s));
-            HIP_TRY(hipMemsetAsync(d_ctr + CT_NF, 0, 10 * 8, s));  // NF, cursors, OVF1..4
+            HIP_TRY(hipMemsetAsync(d_ctr + CT_NF, 0, 12 * 8, s));  // NF, cursors, OVF1..5
             HIP_TRY(hipEventRecord(idx->ev[7], s));
             ExtParams<SlotT> ep;
             ep.rp = rp;
@@ -313,7 +330,7 @@ static int32_t run_search_t(asgart_index *idx, const uint64_t *chunks, int64_t n
                 ep.ovf_list = ovf[1];
                 ep.ovf_count = d_ctr + CT_OVF2;
                 const unsigned g2 = (unsigned)std::min<uint64_t>(n_t[1], 256ull * 3ull);
-                extend_heavy_kernel<SlotT, kArmCapMid, kMidThreads, false><<<g2, kMidThreads, 0, st2>>>(ep);
+                extend_heavy_kernel<SlotT, kArmCapMid, kMidThreads, 0><<<g2, kMidThreads, 0, st2>>>(ep);
             }
             if (n_t[2]) {
                 ep.seg_list = order + n_t[0] + n_t[1];
@@ -323,18 +340,27 @@ static int32_t run_search_t(asgart_index *idx, const uint64_t *chunks, int64_t n
                 ep.ovf_count = d_ctr + CT_OVF3;
                 const unsigned g3 = (unsigned)std::min<uint64_t>(n_t[2], 256ull);
                 if constexpr (sizeof(SlotT) == 4)
-                    extend_heavy_kernel<SlotT, kArmCapBig32, kHeavyThreads, false><<<g3, kHeavyThreads, 0, st3>>>(ep);
+                    extend_heavy_kernel<SlotT, kArmCapBig32, kHeavyThreads, 0><<<g3, kHeavyThreads, 0, st3>>>(ep);
                 else
-                    extend_heavy_kernel<SlotT, kArmCapBig64, kHeavyThreads, false><<<g3, kHeavyThreads, 0, st3>>>(ep);
+                    extend_heavy_kernel<SlotT, kArmCapBig64, kHeavyThreads, 0><<<g3, kHeavyThreads, 0, st3>>>(ep);
             }
             if (n_t[3]) {
                 ep.seg_list = order + n_t[0] + n_t[1] + n_t[2];
                 ep.n_seg_ptr = d_ctr + CT_N4;
                 ep.cursor = d_ctr + CT_CUR4;
-                ep.ovf_list = nullptr;
+                ep.ovf_list = ovf[3];
                 ep.ovf_count = d_ctr + CT_OVF4;
                 const unsigned g4 = (unsigned)std::min<uint64_t>(n_t[3], 256ull);
-                extend_heavy_kernel<SlotT, capg, kHeavyThreads, true><<<g4, kHeavyThreads, 0, st4>>>(ep);
+                extend_heavy_kernel<SlotT, caph, kHeavyThreads, 1><<<g4, kHeavyThreads, 0, st4>>>(ep);
+            }
+            if (n_t[4]) {
+                ep.seg_list = order + n_t[0] + n_t[1] + n_t[2] + n_t[3];
+                ep.n_seg_ptr = d_ctr + CT_N5;
+                ep.cursor = d_ctr + CT_CUR5;
+                ep.ovf_list = nullptr;
+                ep.ovf_count = d_ctr + CT_OVF5;
+                const unsigned g5 = (unsigned)std::min<uint64_t>(n_t[4], 256ull);
+                extend_heavy_kernel<SlotT, capg, kHeavyThreads, 2><<<g5, kHeavyThreads, 0, st4>>>(ep);
             }
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(idx->ev[5], st2));
@@ -346,11 +372,14 @@ static int32_t run_search_t(asgart_index *idx, const uint64_t *chunks, int64_t n
             HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, sizeof(h_ctr), hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
             PROF_DUMP("concurrent tiers");
-            n_overflow = h_ctr[CT_OVF1] + h_ctr[CT_OVF2] + h_ctr[CT_OVF3];
-            n_heavy = n_t[2] + n_t[3];
+            n_overflow = h_ctr[CT_OVF1] + h_ctr[CT_OVF2] + h_ctr[CT_OVF3] + h_ctr[CT_OVF4];
+            if (getenv("ASGART_DEBUG"))
+                fprintf(stderr, "[asgart] overflow out of tiers 1-4: %llu %llu %llu %llu\n", h_ctr[CT_OVF1],
+                        h_ctr[CT_OVF2], h_ctr[CT_OVF3], h_ctr[CT_OVF4]);
+            n_heavy = n_t[2] + n_t[3] + n_t[4];
             // ---- cascade for the segments a tier gave up on (capacity or cost) -----------------
             const auto t_casc0 = std::chrono::steady_clock::now();
-            for (int tier = 2; tier <= 4; ++tier) {
+            for (int tier = 2; tier <= 5; ++tier) {
                 const int src = tier - 2;  // overflow list written by tier-1 level kernels
                 const uint64_t n_ovf = h_ctr[CT_OVF1 + src];
                 if (!n_ovf) continue;
@@ -359,32 +388,34 @@ static int32_t run_search_t(asgart_index *idx, const uint64_t *chunks, int64_t n
                 ep.seg_list = ovf[src];
                 ep.n_seg_ptr = d_ctr + CT_NF;
                 ep.cursor = d_ctr + CT_CURF;
-                ep.ovf_list = tier < 4 ? ovf[src + 1] : nullptr;
+                ep.ovf_list = tier < 5 ? ovf[src + 1] : nullptr;
                 ep.ovf_count = d_ctr + CT_OVF1 + src + 1;  // appended behind what is already there
                 ep.escalate_cost = 0xFFFFFFFFu;
                 ep.cap_limit = 0xFFFFFFFFu;
                 const unsigned bw = (unsigned)std::min<uint64_t>(n_ovf, 256ull);
                 if (tier == 2) {
                     const unsigned mw = (unsigned)std::min<uint64_t>(n_ovf, 256ull * 3ull);
-                    extend_heavy_kernel<SlotT, kArmCapMid, kMidThreads, false><<<mw, kMidThreads, 0, s>>>(ep);
+                    extend_heavy_kernel<SlotT, kArmCapMid, kMidThreads, 0><<<mw, kMidThreads, 0, s>>>(ep);
                 } else if (tier == 3) {
                     if constexpr (sizeof(SlotT) == 4)
-                        extend_heavy_kernel<SlotT, kArmCapBig32, kHeavyThreads, false><<<bw, kHeavyThreads, 0, s>>>(ep);
+                        extend_heavy_kernel<SlotT, kArmCapBig32, kHeavyThreads, 0><<<bw, kHeavyThreads, 0, s>>>(ep);
                     else
-                        extend_heavy_kernel<SlotT, kArmCapBig64, kHeavyThreads, false><<<bw, kHeavyThreads, 0, s>>>(ep);
+                        extend_heavy_kernel<SlotT, kArmCapBig64, kHeavyThreads, 0><<<bw, kHeavyThreads, 0, s>>>(ep);
+                } else if (tier == 4) {
+                    extend_heavy_kernel<SlotT, caph, kHeavyThreads, 1><<<bw, kHeavyThreads, 0, s>>>(ep);
                 } else {
-                    extend_heavy_kernel<SlotT, capg, kHeavyThreads, true><<<bw, kHeavyThreads, 0, s>>>(ep);
+                    extend_heavy_kernel<SlotT, capg, kHeavyThreads, 2><<<bw, kHeavyThreads, 0, s>>>(ep);
                 }
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, sizeof(h_ctr), hipMemcpyDeviceToHost, s));
                 HIP_TRY(hipStreamSynchronize(s));
-                PROF_DUMP(tier == 2 ? "cascade2" : (tier == 3 ? "cascade3" : "cascade4"));
+                PROF_DUMP(tier == 2 ? "cascade2" : (tier == 3 ? "cascade3" : (tier == 4 ? "cascade4" : "cascade5")));
             }
             ms_tier2 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() -
                                                                  t_casc0).count();
-            if (h_ctr[CT_OVF4]) {
+            if (h_ctr[CT_OVF5]) {
                 set_error("%llu segment(s) need more than %d simultaneously live arms; "
-                          "not supported by this build", (unsigned long long)h_ctr[CT_OVF4],
+                          "not supported by this build", (unsigned long long)h_ctr[CT_OVF5],
                           sizeof(SlotT) == 4 ? kArmCapGlobal32 : kArmCapGlobal64);
                 return ASGART_E_CAP;
             }

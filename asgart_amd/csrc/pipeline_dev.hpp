@@ -13,6 +13,8 @@
 
 #include "search_dev.hpp"
 
+#include <type_traits>
+
 namespace asgart {
 
 constexpr int kSmallInterval = 32;  // intervals up to this size are handled by one thread
@@ -38,10 +40,10 @@ enum Counter {
     CT_OVF_CURSOR,
     CT_AMBIG,         // sharding: start decisions that need a longer look-back
     CT_RANOUT,        // sharding: segments that ran past the look-ahead window
-    CT_N1 = 34, CT_N2, CT_N3, CT_N4, CT_NF,          // list lengths: concurrent tiers, fallback launch
-    CT_CUR1, CT_CUR2, CT_CUR3, CT_CUR4, CT_CURF,     // their work cursors
-    CT_OVF1, CT_OVF2, CT_OVF3, CT_OVF4,    // segments handed on to tier 2 / 3 / 4 / nobody
-    CT_COUNT = 48
+    CT_N1 = 34, CT_N2, CT_N3, CT_N4, CT_N5, CT_NF,           // list lengths: tiers 1-5, fallback launch
+    CT_CUR1, CT_CUR2, CT_CUR3, CT_CUR4, CT_CUR5, CT_CURF,   // their work cursors
+    CT_OVF1, CT_OVF2, CT_OVF3, CT_OVF4, CT_OVF5,            // segments handed on to tier 2..5 / nobody
+    CT_COUNT = 72
 };
 
 __device__ inline int chunk_of(const ChunkTable &ch, uint32_t g) {
@@ -52,6 +54,17 @@ __device__ inline int chunk_of(const ChunkTable &ch, uint32_t g) {
         if (ch.pbase[mid] <= g) lo = mid; else hi = mid;
     }
     return lo;
+}
+
+// same for a wave-uniform probe number: keeps the bisection in scalar registers / scalar loads
+__device__ inline int chunk_of_uniform(const ChunkTable &ch, uint32_t g) {
+    g = __builtin_amdgcn_readfirstlane(g);
+    int lo = 0, hi = ch.n_chunks;
+    while (hi - lo > 1) {
+        const int mid = __builtin_amdgcn_readfirstlane((lo + hi) >> 1);
+        if (ch.pbase[mid] <= g) lo = mid; else hi = mid;
+    }
+    return __builtin_amdgcn_readfirstlane(lo);
 }
 
 // hit filter of src/automaton.rs:105-114
@@ -439,6 +452,7 @@ constexpr uint32_t kTombstone = 0xFFFFFFFFu;
 #define PROF_START() pf_t0 = __builtin_amdgcn_s_memtime()
 #define PROF_STOP(slot) pf_acc[slot] += __builtin_amdgcn_s_memtime() - pf_t0
 #define PROF_COUNT(slot, v) pf_acc[slot] += (v)
+#define PROF_MAX(slot, v) pf_acc[slot] = pf_acc[slot] > (unsigned long long)(v) ? pf_acc[slot] : (unsigned long long)(v)
 #define PROF_SEG_BEGIN() const unsigned long long pf_seg0 = __builtin_amdgcn_s_memtime()
 #define PROF_FLUSH()                                                             \
     do {                                                                         \
@@ -449,6 +463,8 @@ constexpr uint32_t kTombstone = 0xFFFFFFFFu;
             P.ctr[31] = ((unsigned long long)pf_acc[10] << 32) | pf_acc[11];     \
             P.ctr[32] = pf_acc[0];                                               \
             P.ctr[33] = pf_acc[6];                                               \
+            P.ctr[25] = pf_acc[9];                                               \
+            for (int pf_i = 0; pf_i < 12; ++pf_i) P.ctr[56 + pf_i] = pf_acc[pf_i]; \
         }                                                                        \
         if (lane == 0)                                                           \
             for (int pf_i = 0; pf_i < 12; ++pf_i)                                \
@@ -460,6 +476,7 @@ constexpr uint32_t kTombstone = 0xFFFFFFFFu;
 #define PROF_START()
 #define PROF_STOP(slot)
 #define PROF_COUNT(slot, v)
+#define PROF_MAX(slot, v)
 #define PROF_SEG_BEGIN()
 #define PROF_FLUSH()
 #endif
@@ -538,7 +555,7 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
         if (seg >= n_seg) break;
         const uint32_t g0 = P.seg_list[seg];
         PROF_SEG_BEGIN();
-        const int c = chunk_of(rp.ch, g0);
+        const int c = chunk_of_uniform(rp.ch, g0);
         const uint64_t cs = rp.ch.start[c], cl = rp.ch.len[c];
         const uint32_t pb = rp.ch.pbase[c];
         const uint32_t chunk_end = rp.ch.pbase[c + 1];
@@ -800,6 +817,9 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
                     // this wave's LDS share, or keeps producing many-hit x many-arm probes
                     lds_cost += A + cnt;
                     if (A + nfl > min((uint32_t)CAP, P.cap_limit) || lds_cost > P.escalate_cost) {
+#ifdef ASGART_PROFILE_EXTEND
+                        if (lane == 0) printf("[light overflow] g0=%u g=%u A=%u nfl=%u cnt=%u t_proc=%u cost=%u first_glob=%d\n", g0, g + b, A, nfl, cnt, t_proc, lds_cost, (int)first_from_global);
+#endif
                         overflow = true;
                         done = true;
                         break;
@@ -939,7 +959,6 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
             if (lane == 0) atomicAdd(&P.ctr[CT_RANOUT], 1ull);
         } else if (!overflow && fam_open)
             emit_records(lane == 0, (PosT)0, (PosT)0, (PosT)0, (PosT)0, kTombstone);
-        PROF_COUNT(9, 1);
         PROF_FLUSH();
         if (overflow && lane == 0) {
             const unsigned long long at = atomicAdd(P.ovf_count, 1ull);
@@ -963,12 +982,13 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
 //     2^bsh >= k + thr bases) of the W processed probes ahead of the current one.  Bucket
 //     granularity and hash collisions can only produce flag 1 for a dead-end hit (harmless:
 //     the arm is created and dies), never the reverse.
-// (2) Placement.  B = max over probes of (hits of this probe + flagged hits of the previous t*
-//     processed probes) estimates live arms + hits; the tier whose capacity fits is chosen, the
-//     overflow cascade catches the rare segment kept alive by unflagged extending hits.
-//     key = (tier-1) << 30 | (2^30-1 - min(total hits, 2^30-1)): ascending sort = tier, longest first.
+// (2) Placement.  Every live arm was created or extended by a distinct hit of the last t*
+//     processed probes, so B = max over probes of (hits of this probe + hits of the previous t*
+//     processed probes) bounds live arms + new arms from above: the tier whose capacity fits B
+//     never overflows (the cascade only serves the test knobs).
+//     key = (tier-1) << 29 | (2^29-1 - min(total hits, 2^29-1)): ascending sort = tier, longest first.
 struct PlaceParams {
-    uint32_t cap1, cap2, cap3;  // arm capacities of tiers 1..3
+    uint32_t cap1, cap2, cap3, cap4;  // arm capacities of tiers 1..4 (tier 5 takes the rest)
     uint32_t sum1;              // segments with more hits than this never go to the one-wave tier
     int force_tier;             // tests: minimum tier for segments with a multi-hit probe
     int use_filter;             // 0: flag every hit (k >= M, huge gaps or cardinalities)
@@ -1016,7 +1036,7 @@ __global__ __launch_bounds__(64) void seg_prepass_kernel(RunParams rp, const uin
     };
     for (uint64_t sidx = blockIdx.x; sidx < n_seg; sidx += gridDim.x) {
         const uint32_t g0 = seg_list[sidx];
-        const int c = chunk_of(rp.ch, g0);
+        const int c = chunk_of_uniform(rp.ch, g0);
         const uint32_t g_end = min(rp.ch.pbase[c + 1], rp.g_hi);
         // lead cursor state
         uint32_t quiet = 0, q_head = 0, q_size = 0;  // queue = ring of 64
@@ -1055,15 +1075,15 @@ __global__ __launch_bounds__(64) void seg_prepass_kernel(RunParams rp, const uin
                 if (lane == 0) p_nflag[gq] = nf;
                 sum += cnt;
                 mx = max(mx, cnt);
-                bound = max(bound, nf_sum + cnt);
+                bound = max(bound, nf_sum + cnt);  // nf_sum: ALL hits of the previous t* processed probes
             }
             // sliding sum of the flagged hits of the last t* processed probes
             const uint32_t ring = min(rp.tstar, 64u);
             const uint32_t pos = t_idx % ring;
             const uint32_t old = s_nf[pos];
             __syncthreads();
-            if (lane == 0) s_nf[pos] = nf;
-            nf_sum = nf_sum - old + nf;
+            if (lane == 0) s_nf[pos] = cnt;  // strict: an unflagged hit can still extend a (wide) arm
+            nf_sum = nf_sum - old + cnt;
             ++t_idx;
             __syncthreads();
         };
@@ -1098,10 +1118,13 @@ __global__ __launch_bounds__(64) void seg_prepass_kernel(RunParams rp, const uin
         while (q_size) trail_step();
         if (rp.tstar > 64u) bound = 0xFFFFFFFFu;  // no estimate for huge gap settings: largest tier
         if (lane == 0) {
-            int tier = (bound <= pp.cap1 && sum <= pp.sum1) ? 1 : (bound <= pp.cap2 ? 2 : (bound <= pp.cap3 ? 3 : 4));
-            if (mx > 1 && pp.force_tier > tier) tier = min(pp.force_tier, 4);
-            const uint32_t s30 = sum > 0x3FFFFFFFull ? 0x3FFFFFFFu : (uint32_t)sum;
-            keys[sidx] = (((uint32_t)tier - 1u) << 30) | (0x3FFFFFFFu - s30);
+            int tier = (bound <= pp.cap1 && sum <= pp.sum1) ? 1 : (bound <= pp.cap2 ? 2 : (bound <= pp.cap3 ? 3 : (bound <= pp.cap4 ? 4 : 5)));
+            if (mx > 1 && pp.force_tier > tier) tier = min(pp.force_tier, 5);
+#ifdef ASGART_PROFILE_EXTEND
+            if (g0 == 4841535u || g0 == 22631158u) printf("[prepass] g0=%u sidx=%llu bound=%u sum=%llu mx=%u tier=%d t_idx=%u\n", g0, (unsigned long long)sidx, bound, sum, mx, tier, t_idx);
+#endif
+            const uint32_t s29 = sum > 0x1FFFFFFFull ? 0x1FFFFFFFu : (uint32_t)sum;
+            keys[sidx] = (((uint32_t)tier - 1u) << 29) | (0x1FFFFFFFu - s29);
             vals[sidx] = g0;
             atomicAdd(&ctr[CT_N1 + tier - 1], 1ull);
         }
@@ -1126,38 +1149,78 @@ __global__ __launch_bounds__(64) void seg_prepass_kernel(RunParams rp, const uin
 //     hit order, (4) apply / age / retire in place.
 //   * GLOBAL = true keeps the arm arrays in an HBM scratch slice per workgroup (up to 16384
 //     live arms); the per-probe candidate index stays in LDS.
-constexpr int kHeavyThreads = 1024;  // heavy tiers
+constexpr int kHeavyThreads = 512;   // heavy tiers (1024 threads would cap VGPRs at 128 -> spills)
 constexpr int kMidThreads = 256;     // mid tier: 4 waves per segment, several workgroups per CU
 constexpr uint32_t kNoSeq = 0xFFFFFFFFu;  // s_seq value of an empty slot
 
-template <class PosT, int CAP, int NT, bool GLOBAL>
+// MODE 0: every arm field in LDS.  MODE 1 ("hybrid"): everything a probe reads or updates (ls, le,
+// re, thr, seq, gap, pend) in LDS; rs, written once at creation and read once at retirement, in an
+// HBM scratch slice (no global access on the per-probe path: a pending global store would stall
+// every workgroup barrier); 16-bit gap/pend and an index-form wide list -> ~1.9x the capacity.
+// MODE 2: all fields in HBM scratch (last resort, up to 16384 live arms).
+// atomic max on a 32-bit or (LDS, packed pairs) 16-bit element
+__device__ inline void pend_max(uint32_t *a, uint32_t idx, uint32_t v) { atomicMax(&a[idx], v); }
+__device__ inline void pend_max(uint16_t *a, uint32_t idx, uint32_t v) {
+    // two 16-bit elements per word: the other half must be left untouched -> CAS loop
+    uint32_t *w = reinterpret_cast<uint32_t *>(a) + (idx >> 1);
+    const uint32_t sh = (idx & 1u) * 16u;
+    uint32_t old = *w;
+    for (;;) {
+        const uint32_t cur = (old >> sh) & 0xFFFFu;
+        if (cur >= v) break;
+        const uint32_t upd = (old & ~(0xFFFFu << sh)) | (v << sh);
+        const uint32_t prev = atomicCAS(w, old, upd);
+        if (prev == old) break;
+        old = prev;
+    }
+}
+
+template <class PosT, int CAP, int NT, int MODE>
 __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
     constexpr int NW = NT / 64;
-    constexpr int LCAP = GLOBAL ? 1 : CAP;
-    __shared__ PosT l_ls[LCAP], l_le[LCAP], l_rs[LCAP], l_re[LCAP];
-    __shared__ uint32_t l_gap[LCAP], l_thr[LCAP], l_seq[LCAP], l_pend[LCAP];
+    constexpr bool GLOBAL = MODE == 2;
+    constexpr bool PACKED_WIDE = MODE == 0;
+    constexpr int HCAP = MODE != 2 ? CAP : 1;  // hot fields in LDS
+    constexpr int CCAP = MODE == 0 ? CAP : 1;  // cold field (rs) in LDS
+    __shared__ PosT l_ls[HCAP], l_re[HCAP], l_le[HCAP], l_rs[CCAP];
+    // gap and pend are 16-bit in the hybrid tier (gap saturates; the host only uses that tier when
+    // G and max_cardinality fit): 24 B of LDS per arm instead of 32
+    using SmallT = typename std::conditional<MODE == 1, uint16_t, uint32_t>::type;
+    constexpr uint32_t kGapMax = MODE == 1 ? 0xFFFFu : 0xFFFFFFFFu;
+    __shared__ uint32_t l_thr[HCAP], l_seq[HCAP];
+    __shared__ SmallT l_gap[HCAP], l_pend[HCAP];
     PosT *s_ls = l_ls, *s_le = l_le, *s_rs = l_rs, *s_re = l_re;
-    uint32_t *s_gap = l_gap, *s_thr = l_thr, *s_seq = l_seq, *s_pend = l_pend;
-    if constexpr (GLOBAL) {
+    uint32_t *s_thr = l_thr, *s_seq = l_seq;
+    SmallT *s_gap = l_gap, *s_pend = l_pend;
+    if constexpr (MODE != 0) {
         const size_t bytes = (size_t)CAP * (4 * sizeof(PosT) + 4 * sizeof(uint32_t));
         char *b = P.scratch + (size_t)blockIdx.x * bytes;
-        s_ls = reinterpret_cast<PosT *>(b);
-        s_le = s_ls + CAP; s_rs = s_le + CAP; s_re = s_rs + CAP;
-        s_gap = reinterpret_cast<uint32_t *>(s_re + CAP);
-        s_thr = s_gap + CAP; s_seq = s_thr + CAP; s_pend = s_seq + CAP;
+        PosT *g0p = reinterpret_cast<PosT *>(b);
+        s_rs = g0p + 2 * CAP;
+        if constexpr (MODE == 2) {
+            s_ls = g0p;
+            s_le = g0p + CAP;
+            s_re = g0p + 3 * CAP;
+            s_gap = reinterpret_cast<SmallT *>(g0p + 4 * CAP);
+            s_thr = reinterpret_cast<uint32_t *>(s_gap + CAP);
+            s_seq = s_thr + CAP;
+            s_pend = reinterpret_cast<SmallT *>(s_seq + CAP);
+        }
     }
-    constexpr uint32_t HT = CAP <= 1024 ? 1024u : (CAP <= 4096 ? 4096u : 8192u);
-    constexpr uint32_t WCAP = GLOBAL ? 4096u : (uint32_t)CAP;
+    constexpr uint32_t HT = CAP <= 1024 ? 1024u : (MODE == 1 ? 2048u : (CAP <= 4608 ? 4096u : 8192u));
+    constexpr uint32_t WCAP = PACKED_WIDE ? (uint32_t)CAP : 1u;
     __shared__ uint32_t s_head[HT];
     __shared__ uint16_t s_next[CAP];
     __shared__ uint16_t s_free[CAP];  // stack of empty slots below the high-water mark
     __shared__ PosT s_ivlo[WCAP];     // wide arm w accepts x iff (x - s_ivlo[w]) < s_ivw[w]
     __shared__ uint32_t s_ivw[WCAP];
-    __shared__ uint16_t s_widx[WCAP];
+    __shared__ unsigned long long s_wkey[WCAP];  // (creation number << 20) | slot of wide arm w
+    __shared__ uint16_t s_widx[PACKED_WIDE ? 1 : CAP];  // index form of the wide list
     __shared__ PosT s_hits[kHitBatch];
     __shared__ uint8_t s_hflag[kHitBatch];
     __shared__ unsigned long long s_best[NT];  // per hit: (creation number << 20) | slot, or ~0
     __shared__ uint32_t s_nwide, s_ndead, s_nfreed;
+    __shared__ uint32_t s_wcnt[NT / 64];
     __shared__ unsigned long long s_bcast;
     const int tid = threadIdx.x, lane = tid & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -1178,7 +1241,7 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
         if (seg >= n_seg) break;
         const uint32_t g0 = P.seg_list[seg];
         PROF_SEG_BEGIN();
-        const int c = chunk_of(rp.ch, g0);
+        const int c = chunk_of_uniform(rp.ch, g0);
         const uint64_t cs = rp.ch.start[c], cl = rp.ch.len[c];
         const uint32_t pb = rp.ch.pbase[c];
         const uint32_t chunk_end = rp.ch.pbase[c + 1];
@@ -1186,6 +1249,7 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
         // block-uniform state: A live arms in slots [0,H), n_free of them empty (on s_free)
         uint32_t A = 0, H = 0, n_free = 0, quiet = 0, fam_seq = 0, next_seq = 0;
         uint32_t t_proc = 0, spur_until = 0;  // see extend_kernel
+        if (tid == 0) s_nfreed = 0;
         bool overflow = false, done = false, fam_open = false;
 
         auto emit_records = [&](bool emit, PosT ls, PosT le, PosT rs, PosT re, uint32_t seq) {
@@ -1217,11 +1281,7 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
         // arms (with_pend); block-uniform on exit: A, n_free, fam_seq, next_seq, H.
         auto age_and_retire = [&](uint32_t add, bool with_pend, uint64_t i, uint32_t off,
                                   unsigned long long row, bool from_lds) {
-            if (tid == 0) {
-                s_ndead = 0;
-                s_nfreed = 0;
-            }
-            __syncthreads();
+            // s_nfreed was cleared at least one barrier ago (probe start / previous call's end)
             for (uint32_t j0 = 0; j0 < H; j0 += NT) {
                 const uint32_t j = j0 + tid;
                 bool dead = false;
@@ -1238,8 +1298,9 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
                         s_gap[j] = 0;
                     } else {
                         const uint32_t gp = s_gap[j];
-                        const uint32_t ng = gp + add < gp ? 0xFFFFFFFFu : gp + add;
-                        s_gap[j] = ng;
+                        const uint64_t sum_g = (uint64_t)gp + add;
+                        const uint32_t ng = sum_g > kGapMax ? kGapMax : (uint32_t)sum_g;
+                        s_gap[j] = (SmallT)ng;
                         if (ng >= G) {
                             dead = true;
                             ls = s_ls[j]; le = s_le[j]; rs = s_rs[j]; re = s_re[j];
@@ -1253,10 +1314,47 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
             __syncthreads();
             const uint32_t nd = s_nfreed;
             __syncthreads();
+            if (tid == 0) s_nfreed = 0;  // visible after the next barrier, before the next use
             A -= nd;
             n_free += nd;
             if (A == 0) {  // every slot is empty again
                 H = 0;
+                n_free = 0;
+            } else if (H > 2u * A + 128u) {
+                // Mostly holes (a long segment past its peak): pack the live arms into [0, A) so
+                // that the per-probe loops run over A slots again.  Slot order is free (matching
+                // goes by creation number).  Iteration by iteration: read, barrier, write below.
+                uint32_t w = 0;
+                for (uint32_t j0 = 0; j0 < H; j0 += NT) {
+                    const uint32_t j = j0 + tid;
+                    const bool live = j < H && s_seq[j] != kNoSeq;
+                    PosT ls = 0, le = 0, rs = 0, re = 0;
+                    uint32_t gp = 0, th = 0, sq = kNoSeq;
+                    if (live) {
+                        ls = s_ls[j]; le = s_le[j]; rs = s_rs[j]; re = s_re[j];
+                        gp = s_gap[j]; th = s_thr[j]; sq = s_seq[j];
+                    }
+                    // ordered prefix of `live` over the workgroup
+                    const unsigned long long lm = __ballot(live);
+                    if (lane == 0) s_wcnt[tid >> 6] = (uint32_t)__popcll(lm);
+                    __syncthreads();
+                    uint32_t before = 0, tot = 0;
+                    for (int wv = 0; wv < NW; ++wv) {
+                        const uint32_t v = s_wcnt[wv];
+                        if (wv < (tid >> 6)) before += v;
+                        tot += v;
+                    }
+                    if (j < H) s_seq[j] = kNoSeq;  // every slot of this stripe has been read
+                    __syncthreads();
+                    if (live) {
+                        const uint32_t d = w + before + (uint32_t)__popcll(lm & lt_mask);
+                        s_ls[d] = ls; s_le[d] = le; s_rs[d] = rs; s_re[d] = re;
+                        s_gap[d] = (SmallT)gp; s_thr[d] = th; s_seq[d] = sq; s_pend[d] = 0;
+                    }
+                    w += tot;
+                    __syncthreads();
+                }
+                H = A;
                 n_free = 0;
             }
         };
@@ -1342,6 +1440,7 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
                 PROF_COUNT(5, 1);
                 PROF_COUNT(10, A);
                 PROF_COUNT(11, cnt);
+                PROF_MAX(9, A + nfl);
                 PROF_START();
                 // ---- (0)+(1) candidate index over the live arms ------------------------------
                 uint32_t hmask = 63u;
@@ -1349,30 +1448,44 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
                 for (uint32_t h = tid; h <= hmask; h += NT) s_head[h] = 0xFFFFFFFFu;
                 if (tid == 0) s_nwide = 0;
                 __syncthreads();
-                for (uint32_t j = tid; j < H; j += NT) {
-                    if (s_seq[j] == kNoSeq) continue;
-                    const uint32_t th = s_thr[j];
-                    const PosT re = s_re[j];
-                    if (th <= G) {
+                for (uint32_t j0 = 0; j0 < H; j0 += NT) {
+                    const uint32_t j = j0 + tid;
+                    uint32_t sq = kNoSeq, th = 0;
+                    PosT re = 0;
+                    if (j < H && (sq = s_seq[j]) != kNoSeq) {
+                        th = s_thr[j];
+                        re = s_re[j];
+                    }
+                    const bool live = sq != kNoSeq;
+                    if (live && th <= G) {
                         const uint32_t bkt = (uint32_t)((uint64_t)re >> bsh);
                         s_next[j] = (uint16_t)atomicExch(&s_head[((bkt * 2654435761u) >> 12) & hmask], j);
-                    } else {
-                        const uint32_t d = atomicAdd(&s_nwide, 1u);
-                        if (d < WCAP) {
-                            const uint64_t wv = (uint64_t)th + k - 1u;
-                            s_ivlo[d] = (PosT)(re - k + 1u);
-                            s_ivw[d] = wv > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)wv;
-                            s_widx[d] = (uint16_t)j;
+                    }
+                    // wide arms: one LDS atomic per wave, not per arm
+                    const bool wide = live && th > G;
+                    const unsigned long long wm = __ballot(wide);
+                    if (wm) {
+                        const int leader = __ffsll((long long)wm) - 1;
+                        uint32_t wbase = 0;
+                        if (lane == leader) wbase = atomicAdd(&s_nwide, (uint32_t)__popcll(wm));
+                        wbase = __shfl(wbase, leader);
+                        const uint32_t d = wbase + (uint32_t)__popcll(wm & lt_mask);
+                        if (wide) {
+                            if constexpr (PACKED_WIDE) {
+                                const uint64_t wv = (uint64_t)th + k - 1u;
+                                s_ivlo[d] = (PosT)(re - k + 1u);
+                                s_ivw[d] = wv > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)wv;
+                                s_wkey[d] = ((unsigned long long)sq << 20) | j;
+                            } else {
+                                s_widx[d] = (uint16_t)j;
+                            }
                         }
                     }
                 }
                 __syncthreads();
+                PROF_STOP(2);
+                PROF_START();
                 const uint32_t n_wide = s_nwide;
-                if (n_wide > WCAP) {  // only possible in the HBM tier
-                    overflow = true;
-                    done = true;
-                    break;
-                }
                 const uint32_t seq_base = next_seq;
                 for (uint32_t t0 = 0; t0 < cnt; t0 += NT) {
                     const uint32_t ct = min((uint32_t)NT, cnt - t0);
@@ -1396,6 +1509,8 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
                         s_best[tid] = best;
                     }
                     __syncthreads();
+                    PROF_STOP(4);
+                    PROF_START();
                     // ---- wide arms: thread = (hit, part of the packed list), branch-free --------
                     if (n_wide) {
                         const uint32_t Hr = (ct + 63u) & ~63u;  // hits rounded up to waves
@@ -1408,35 +1523,79 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
                             const uint32_t j0 = (uint32_t)((uint64_t)n_wide * part / NP);
                             const uint32_t j1 = (uint32_t)((uint64_t)n_wide * (part + 1) / NP);
                             unsigned long long found = ~0ull;
-                            for (uint32_t j = j0; j < j1; ++j) {
-                                const uint32_t slot = s_widx[j];
-                                const unsigned long long key = ((unsigned long long)s_seq[slot] << 20) | slot;
-                                found = min(found, (uint64_t)(PosT)(x - s_ivlo[j]) < s_ivw[j] ? key : ~0ull);
+                            // 8 independent LDS load chains in flight per thread (the scan is
+                            // latency-bound otherwise), smallest accepting key wins
+                            uint32_t j = j0;
+                            if constexpr (PACKED_WIDE) {
+                                for (; j + 8 <= j1; j += 8) {
+                                    PosT lo8[8];
+                                    uint32_t w8[8];
+                                    unsigned long long k8[8];
+#pragma unroll
+                                    for (int u = 0; u < 8; ++u) {
+                                        lo8[u] = s_ivlo[j + u];
+                                        w8[u] = s_ivw[j + u];
+                                        k8[u] = s_wkey[j + u];
+                                    }
+#pragma unroll
+                                    for (int u = 0; u < 8; ++u)
+                                        found = min(found, (uint64_t)(PosT)(x - lo8[u]) < w8[u] ? k8[u] : ~0ull);
+                                }
+                                for (; j < j1; ++j)
+                                    found = min(found, (uint64_t)(PosT)(x - s_ivlo[j]) < s_ivw[j] ? s_wkey[j] : ~0ull);
+                            } else {
+                                for (; j + 8 <= j1; j += 8) {
+                                    uint32_t sl8[8], th8[8], sq8[8];
+                                    PosT re8[8];
+#pragma unroll
+                                    for (int u = 0; u < 8; ++u) sl8[u] = s_widx[j + u];
+#pragma unroll
+                                    for (int u = 0; u < 8; ++u) {
+                                        re8[u] = s_re[sl8[u]];
+                                        th8[u] = s_thr[sl8[u]];
+                                        sq8[u] = s_seq[sl8[u]];
+                                    }
+#pragma unroll
+                                    for (int u = 0; u < 8; ++u) {
+                                        const unsigned long long key = ((unsigned long long)sq8[u] << 20) | sl8[u];
+                                        found = min(found, arm_accepts<PosT>(x, re8[u], th8[u], k) ? key : ~0ull);
+                                    }
+                                }
+                                for (; j < j1; ++j) {
+                                    const uint32_t slot = s_widx[j];
+                                    const unsigned long long key = ((unsigned long long)s_seq[slot] << 20) | slot;
+                                    found = min(found, arm_accepts<PosT>(x, s_re[slot], s_thr[slot], k) ? key : ~0ull);
+                                }
                             }
                             if (valid && found != ~0ull) atomicMin(&s_best[tl], found);
                         }
                         __syncthreads();
                     }
+                    PROF_STOP(8);
+                    PROF_START();
                     // ---- (3) ExtendArm / NewArm, one thread per hit -----------------------------
                     const bool mine = (uint32_t)tid < ct;
                     unsigned long long best = ~0ull;
                     if (mine) {
                         best = s_best[tid];
-                        if (best != ~0ull) atomicMax(&s_pend[(uint32_t)(best & 0xFFFFFu)], t0 + tid + 1u);
+                        if (best != ~0ull) pend_max(s_pend, (uint32_t)(best & 0xFFFFFu), t0 + tid + 1u);
                     }
                     // unmatched hits: flagged ones become arms, the others are dropped (K3b)
                     bool fl = false;
                     if (mine) fl = (from_lds ? s_hflag[off + t0 + tid] : P.hit_flag[row + t0 + tid]) != 0;
-                    if (mine && best == ~0ull && !fl) s_best[tid] = ~0ull - 1ull;  // marks "dropped"
-                    __syncthreads();
                     const bool is_new = mine && best == ~0ull && fl;
-                    // rank of this hit among the new arms, in hit order (= creation order)
+                    // rank of this hit among the new arms, in hit order (= creation order): every
+                    // wave recomputes the per-group counts from s_best + flags (no barrier)
                     uint32_t before = 0, n_new = 0;
                     for (uint32_t c0 = 0; c0 < ct; c0 += 64) {
                         const uint32_t hidx = c0 + lane;
-                        const unsigned long long bv = hidx < ct ? s_best[hidx] : 0ull;
-                        const unsigned long long nm = __ballot(bv == ~0ull);
-                        spur |= __ballot(bv == ~0ull - 1ull) != 0ull;
+                        bool un = false, hf = false;
+                        if (hidx < ct) {
+                            un = s_best[hidx] == ~0ull;
+                            hf = (from_lds ? s_hflag[off + t0 + hidx] : P.hit_flag[row + t0 + hidx]) != 0;
+                        }
+                        const unsigned long long nm = __ballot(un && hf);
+                        spur |= __ballot(un && !hf) != 0ull;
                         const uint32_t pc = (uint32_t)__popcll(nm);
                         if (c0 < ((uint32_t)tid & ~63u)) before += pc;
                         else if (c0 == ((uint32_t)tid & ~63u)) before += (uint32_t)__popcll(nm & lt_mask);

@@ -124,8 +124,11 @@ def _battery_case(name):
     return pr, spec.get("cli", {})
 
 
+@pytest.mark.parametrize("filt", ["0", "1"])
 @pytest.mark.parametrize("name", sorted(BATTERY))
-def test_battery_families_and_csr(hiplib, name):
+def test_battery_families_and_csr(hiplib, name, filt, monkeypatch):
+    # filt=1: with the continuation filter (arms that can never match are not materialised)
+    monkeypatch.setenv("ASGART_FILTER", filt)
     pr, cli = _battery_case(name)
     oidx = oracle.Index.build(pr.data)
     with asgart_amd.Index(pr.data, oidx.sa) as idx:
@@ -286,7 +289,7 @@ def test_overflow_cascade_gives_identical_results(hiplib, cap, monkeypatch):
             assert np.array_equal(offs, eoffs) and np.array_equal(sds, esds), (cap, reverse)
 
 
-@pytest.mark.parametrize("tier", [2, 3, 4])
+@pytest.mark.parametrize("tier", [2, 3, 4, 5])
 @pytest.mark.parametrize("name", ["dense_repeats", "satellites", "long_sds"])
 def test_escalation_tiers_give_identical_results(hiplib, name, tier, monkeypatch):
     """The one-wave kernel hands heavy segments to larger tiers (bigger LDS share, block-cooperative
@@ -295,6 +298,7 @@ def test_escalation_tiers_give_identical_results(hiplib, name, tier, monkeypatch
     pr, cli = _battery_case(name)
     oidx = oracle.Index.build(pr.data)
     monkeypatch.setenv("ASGART_FORCE_TIER", str(tier))
+    monkeypatch.setenv("ASGART_FILTER", "1" if tier % 2 else "0")
     with asgart_amd.Index(pr.data, oidx.sa) as idx:
         for reverse, complement in ((False, False), (True, True)):
             st = asgart_amd.RunSettings.from_cli(reverse=reverse, complement=complement, **cli)
