@@ -267,8 +267,16 @@ static int32_t run_search_t(asgart_index *idx, const uint64_t *chunks, int64_t n
                          getenv("ASGART_FILTER") && atoi(getenv("ASGART_FILTER")) != 0) ? 1 : 0;
         RC_TRY(w.hit_flag.reserve((size_t)total_hits + 64));
         uint8_t *hit_flag = w.hit_flag.as<uint8_t>();
-        seg_prepass_kernel<SlotT><<<(unsigned)std::min<uint64_t>(n_seg, 256ull * 9ull), 64, 0, s>>>(
-            rp, p_filt, row_off, hits, hit_flag, p_raw, seg_list, d_ctr + CT_SEG, kbuf, vbuf, pp, d_ctr);
+        const uint32_t *p_nflag = p_filt;  // without the filter every hit may create an arm
+        if (pp.use_filter) {
+            seg_prepass_kernel<SlotT><<<(unsigned)std::min<uint64_t>(n_seg, 256ull * 9ull), 64, 0, s>>>(
+                rp, p_filt, row_off, hits, hit_flag, p_raw, seg_list, d_ctr + CT_SEG, kbuf, vbuf, pp, d_ctr);
+            p_nflag = p_raw;  // rewritten by the pre-pass: flagged hits per probe
+        } else {
+            HIP_TRY(hipMemsetAsync(hit_flag, 1, (size_t)total_hits, s));
+            seg_stats_kernel<<<(unsigned)std::min<uint64_t>(n_seg, 256ull * 32ull), 64, 0, s>>>(
+                rp, p_filt, seg_list, d_ctr + CT_SEG, kbuf, vbuf, pp, d_ctr);
+        }
         HIP_TRY(hipGetLastError());
         const uint32_t *order = nullptr;
         RC_TRY(sort_segments(w, kbuf, vbuf, n_seg, s, &order));
@@ -297,7 +305,7 @@ static int32_t run_search_t(asgart_index *idx, const uint64_t *chunks, int64_t n
             ep.row_off = row_off;
             ep.hits = hits;
             ep.hit_flag = hit_flag;
-            ep.p_nflag = p_raw;  // rewritten by the pre-pass: flagged hits per probe
+            ep.p_nflag = p_nflag;
             ep.recs = w.fam_sds.as<SdRec>();
             ep.rec_cap = rec_cap;
             ep.scratch = w.scratch.as<char>();

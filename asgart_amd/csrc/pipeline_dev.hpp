@@ -1132,6 +1132,92 @@ __global__ __launch_bounds__(64) void seg_prepass_kernel(RunParams rp, const uin
     }
 }
 
+// Placement only (continuation filter off): the same walk and window bound as the pre-pass, with
+// no hit accesses at all.  One wave per segment.
+__global__ __launch_bounds__(64) void seg_stats_kernel(RunParams rp, const uint32_t *__restrict__ p_filt,
+                                                       const uint32_t *__restrict__ seg_list,
+                                                       const unsigned long long *__restrict__ n_seg_ptr,
+                                                       uint32_t *__restrict__ keys,
+                                                       uint32_t *__restrict__ vals, PlaceParams pp,
+                                                       unsigned long long *__restrict__ ctr) {
+    __shared__ uint32_t s_ext[64 + 64];  // [0,TW): hit counts of the previous processed probes
+    const int lane = threadIdx.x;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const uint64_t n_seg = *n_seg_ptr;
+    const uint32_t TW = min(rp.tstar, 64u);
+    for (uint64_t sidx = blockIdx.x; sidx < n_seg; sidx += gridDim.x) {
+        const uint32_t g0 = seg_list[sidx];
+        const int c = chunk_of_uniform(rp.ch, g0);
+        const uint32_t g_end = min(rp.ch.pbase[c + 1], rp.g_hi);
+        uint32_t quiet = 0, mx = 0, bound = 0;
+        unsigned long long sum = 0;
+        bool done = false;
+        s_ext[lane] = 0;
+        __syncthreads();
+        for (uint32_t g = g0; g < g_end && !done; g += 64) {
+            const uint32_t nb = min(64u, g_end - g);
+            const uint32_t f = (uint32_t)lane < nb ? p_filt[g + lane] : kSkipN;
+            const unsigned long long hm = __ballot(f >= 1u && f < kPending);
+            const unsigned long long qm = __ballot(f == 0u);
+            unsigned long long live = ~0ull;  // probes of this batch that belong to the segment
+            uint32_t pos = 0;
+            unsigned long long rest = hm;
+            while (true) {
+                const uint32_t b = rest ? (uint32_t)(__ffsll((long long)rest) - 1) : 64u;
+                const unsigned long long range = (b >= 64 ? ~0ull : ((1ull << b) - 1ull)) &
+                                                 ~(pos >= 64 ? ~0ull : ((1ull << pos) - 1ull));
+                const uint32_t q = (uint32_t)__popcll(qm & range);
+                if (quiet + q >= rp.tstar) {
+                    done = true;
+                    live = pos >= 64 ? ~0ull : ((1ull << pos) - 1ull);
+                    break;
+                }
+                if (b >= 64) {
+                    quiet += q;
+                    break;
+                }
+                quiet = 0;
+                pos = b + 1;
+                rest &= rest - 1;
+            }
+            const unsigned long long procm = (hm | qm) & live;
+            const bool proc = (procm >> lane) & 1ull;
+            const uint32_t v = ((hm & live) >> lane) & 1ull ? f : 0u;
+            const uint32_t r = (uint32_t)__popcll(procm & lt_mask);
+            const uint32_t n_proc = (uint32_t)__popcll(procm);
+            if (proc) s_ext[TW + r] = v;
+            __syncthreads();
+            uint32_t wsum = 0;
+            if (proc)
+                for (uint32_t d = 0; d <= TW; ++d) wsum += s_ext[TW + r - d];
+            uint32_t m = v, wm = wsum;
+            unsigned long long sv = v;
+            for (int off = 32; off > 0; off >>= 1) {
+                sv += __shfl_down(sv, off);
+                m = max(m, (uint32_t)__shfl_down(m, off));
+                wm = max(wm, (uint32_t)__shfl_down(wm, off));
+            }
+            sum += __shfl(sv, 0);
+            mx = max(mx, (uint32_t)__shfl(m, 0));
+            bound = max(bound, (uint32_t)__shfl(wm, 0));
+            const uint32_t keep = (uint32_t)lane < TW ? s_ext[n_proc + lane] : 0u;
+            __syncthreads();
+            if ((uint32_t)lane < TW) s_ext[lane] = keep;
+            __syncthreads();
+        }
+        if (rp.tstar > 64u) bound = 0xFFFFFFFFu;
+        if (lane == 0) {
+            int tier = (bound <= pp.cap1 && sum <= pp.sum1) ? 1 : (bound <= pp.cap2 ? 2 : (bound <= pp.cap3 ? 3 : (bound <= pp.cap4 ? 4 : 5)));
+            if (mx > 1 && pp.force_tier > tier) tier = min(pp.force_tier, 5);
+            const uint32_t s29 = sum > 0x1FFFFFFFull ? 0x1FFFFFFFu : (uint32_t)sum;
+            keys[sidx] = (((uint32_t)tier - 1u) << 29) | (0x1FFFFFFFu - s29);
+            vals[sidx] = g0;
+            atomicAdd(&ctr[CT_N1 + tier - 1], 1ull);
+        }
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------- K4b --------
 // Block-cooperative extension kernel: ONE workgroup (NT = 256 or 1024 threads) per segment, for
 // the segments whose live-arm bound does not fit the one-wave kernel.  At genome scale these are
