@@ -135,7 +135,7 @@ int32_t run_search(asgart_index *idx, const uint64_t *chunks, int64_t n_chunks,
                    asgart_families *fam_out, std::vector<uint8_t> *status_out,
                    std::vector<uint64_t> *rowoff_out, std::vector<uint64_t> *hits_out);
 int32_t sort_segments(Workspace &w, uint32_t *keys, uint32_t *vals, uint64_t n, hipStream_t s,
-                      const uint32_t **sorted_vals);
+                      const uint32_t **sorted_vals, const uint32_t **sorted_keys);
 int32_t text_is_dna(const uint8_t *d_text, int64_t n, hipStream_t s, bool *dna);
 int32_t sa_build_device(const uint8_t *d_text, int64_t n, void *d_sa, bool wide,
                         hipStream_t stream);

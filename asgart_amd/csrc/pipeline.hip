@@ -279,7 +279,10 @@ static int32_t run_search_t(asgart_index *idx, const uint64_t *chunks, int64_t n
         }
         HIP_TRY(hipGetLastError());
         const uint32_t *order = nullptr;
-        RC_TRY(sort_segments(w, kbuf, vbuf, n_seg, s, &order));
+        const uint32_t *sorted_keys = nullptr;
+        RC_TRY(sort_segments(w, kbuf, vbuf, n_seg, s, &order, &sorted_keys));
+        tier_bounds_kernel<<<1, 64, 0, s>>>(sorted_keys, d_ctr + CT_SEG, d_ctr);
+        HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, sizeof(h_ctr), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         const uint64_t n_t[5] = {h_ctr[CT_N1], h_ctr[CT_N2], h_ctr[CT_N3], h_ctr[CT_N4], h_ctr[CT_N5]};

@@ -110,15 +110,18 @@ __global__ __launch_bounds__(256) void probe_count_kernel(IndexView<SlotT> ix, R
             }
         }
     }
-    // wave-aggregated append to the large-interval work list
-    const unsigned long long m = __ballot(is_big);
-    if (m) {
-        const int lane = threadIdx.x & 63;
-        const int leader = __ffsll((long long)m) - 1;
-        unsigned long long base = 0;
-        if (lane == leader) base = atomicAdd(&ctr[CT_BIG], (unsigned long long)__popcll(m));
-        base = __shfl(base, leader);
-        if (is_big) big_list[base + __popcll(m & ((1ull << lane) - 1ull))] = g;
+    // workgroup-aggregated append to the large-interval work list (one global atomic per group)
+    __shared__ uint32_t s_nbig, s_big[256];
+    __shared__ unsigned long long s_bbase;
+    if (threadIdx.x == 0) s_nbig = 0;
+    __syncthreads();
+    if (is_big) s_big[atomicAdd(&s_nbig, 1u)] = g;
+    __syncthreads();
+    const uint32_t nbig = s_nbig;
+    if (nbig) {
+        if (threadIdx.x == 0) s_bbase = atomicAdd(&ctr[CT_BIG], (unsigned long long)nbig);
+        __syncthreads();
+        if (threadIdx.x < nbig) big_list[s_bbase + threadIdx.x] = s_big[threadIdx.x];
     }
 }
 
@@ -205,29 +208,37 @@ __device__ inline ScanEl block_exclusive_scan(ScanEl v, ScanEl *sh, ScanEl *bloc
     return excl;
 }
 
-// loads the kScanItems elements of this thread; returns their combination
-__device__ inline ScanEl load_thread_items(const RunParams &rp, const uint32_t *p_filt,
-                                           uint32_t g0, ScanEl *items) {
-    ScanEl agg = scan_identity();
-    int c = -1;
-    uint32_t next_first = 0;
-    for (int a = 0; a < kScanItems; ++a) {
-        const uint32_t g = g0 + a;
-        if (g < rp.g_hi) {
-            if (c < 0) {
-                c = chunk_of(rp.ch, g);
-                next_first = rp.ch.pbase[c];
-            }
-            // advance over chunk boundaries (empty chunks share pbase values)
-            while (c + 1 < rp.ch.n_chunks && rp.ch.pbase[c + 1] <= g) {
-                ++c;
-                next_first = rp.ch.pbase[c];
-            }
-            const bool first = (g == next_first);
-            items[a] = scan_element(p_filt[g], first);
-        } else {
-            items[a] = scan_identity();
+// Coalesced staging of one scan tile: hit counts and "first probe of a chunk" marks go through
+// LDS so that each thread can then walk its kScanItems consecutive probes without strided global
+// accesses or a per-thread chunk bisection.
+__device__ inline void stage_scan_tile(const RunParams &rp, const uint32_t *__restrict__ p_filt,
+                                       uint32_t tile_g0, uint32_t *s_f, uint8_t *s_first) {
+    for (uint32_t idx = threadIdx.x; idx < (uint32_t)kScanTile; idx += kScanBlock) {
+        const uint32_t g = tile_g0 + idx;
+        s_f[idx] = g < rp.g_hi ? p_filt[g] : kSkipN;
+        s_first[idx] = 0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t tile_end = tile_g0 + (uint32_t)kScanTile;
+        for (int c = chunk_of(rp.ch, tile_g0); c < rp.ch.n_chunks; ++c) {
+            const uint32_t pb = rp.ch.pbase[c];
+            if (pb >= tile_end) break;
+            // only non-empty chunks have a first probe
+            if (pb >= tile_g0 && rp.ch.pbase[c + 1] > pb) s_first[pb - tile_g0] = 1;
         }
+    }
+    __syncthreads();
+}
+
+// the kScanItems elements of this thread (from the staged tile); returns their combination
+__device__ inline ScanEl load_thread_items(const uint32_t *s_f, const uint8_t *s_first, ScanEl *items) {
+    ScanEl agg = scan_identity();
+    const uint32_t i0 = threadIdx.x * kScanItems;
+    for (int a = 0; a < kScanItems; ++a) {
+        const uint32_t f = s_f[i0 + a];
+        // probes past the end of the window were staged as skipped: identity elements
+        items[a] = scan_element(f, s_first[i0 + a] != 0);
         agg = scan_combine(agg, items[a]);
     }
     return agg;
@@ -237,9 +248,11 @@ __global__ __launch_bounds__(kScanBlock) void scan_reduce_kernel(RunParams rp,
                                                                  const uint32_t *__restrict__ p_filt,
                                                                  ScanEl *__restrict__ blk) {
     __shared__ ScanEl sh[kScanBlock];
+    __shared__ uint32_t s_f[kScanTile];
+    __shared__ uint8_t s_first[kScanTile];
     ScanEl items[kScanItems];
-    const uint32_t g0 = rp.g_lo + (blockIdx.x * kScanBlock + threadIdx.x) * kScanItems;
-    ScanEl agg = load_thread_items(rp, p_filt, g0, items);
+    stage_scan_tile(rp, p_filt, rp.g_lo + blockIdx.x * (uint32_t)kScanTile, s_f, s_first);
+    ScanEl agg = load_thread_items(s_f, s_first, items);
     ScanEl total;
     (void)block_exclusive_scan(agg, sh, &total);
     if (threadIdx.x == 0) blk[blockIdx.x] = total;
@@ -281,10 +294,20 @@ __global__ __launch_bounds__(kScanBlock) void scan_down_kernel(RunParams rp,
                                                                unsigned long long *__restrict__ ctr) {
     __shared__ ScanEl sh[kScanBlock];
     __shared__ unsigned long long sh_stat[5];
+    __shared__ uint32_t s_f[kScanTile];
+    __shared__ uint8_t s_first[kScanTile];
+    __shared__ unsigned long long s_row[kScanTile];
+    __shared__ uint32_t s_start[kScanTile];
+    __shared__ uint32_t s_nstart;
+    __shared__ unsigned long long s_gbase;
     if (threadIdx.x < 5) sh_stat[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_nstart = 0;
     ScanEl items[kScanItems];
-    const uint32_t g0 = rp.g_lo + (blockIdx.x * kScanBlock + threadIdx.x) * kScanItems;
-    ScanEl agg = load_thread_items(rp, p_filt, g0, items);
+    const uint32_t tile_g0 = rp.g_lo + blockIdx.x * (uint32_t)kScanTile;
+    const uint32_t i0 = threadIdx.x * kScanItems;
+    const uint32_t g0 = tile_g0 + i0;
+    stage_scan_tile(rp, p_filt, tile_g0, s_f, s_first);
+    ScanEl agg = load_thread_items(s_f, s_first, items);
     ScanEl total;
     ScanEl excl = block_exclusive_scan(agg, sh, &total);
     ScanEl run = scan_combine(blk[blockIdx.x], excl);
@@ -303,13 +326,12 @@ __global__ __launch_bounds__(kScanBlock) void scan_down_kernel(RunParams rp,
         const bool valid = g < rp.g_hi;
         bool start = false;
         if (valid) {
-            const uint32_t f = p_filt[g];
-            row_off[g] = run.hits;
+            const uint32_t f = s_f[i0 + a];
+            s_row[i0 + a] = run.hits;
             const bool hit = f < kPending && f > 0;
             if (f == kSkipN) ++st_n;
             else {
                 ++st_searched;
-                st_raw += p_raw[g];
                 if (f == kSkipCard) ++st_card;
                 else if (hit) ++st_hit;
             }
@@ -326,23 +348,53 @@ __global__ __launch_bounds__(kScanBlock) void scan_down_kernel(RunParams rp,
                 run.flags = (run.flags & 3u) | keep_unknown;
             }
         }
-        // wave-aggregated append of segment starts (order is irrelevant: the
-        // families are sorted by (start probe, ordinal) on the host)
+        // segment starts are collected per workgroup in LDS (order is irrelevant: families are
+        // sorted by (start probe, ordinal) on the host) and appended with ONE global atomic per
+        // workgroup: same-address global atomics run at only ~88 per microsecond chip-wide
         const unsigned long long m = __ballot(start);
         if (m) {
             const int leader = __ffsll((long long)m) - 1;
-            unsigned long long base = 0;
-            if (lane == leader) base = atomicAdd(&ctr[CT_SEG], (unsigned long long)__popcll(m));
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(&s_nstart, (uint32_t)__popcll(m));
             base = __shfl(base, leader);
-            if (start) seg_list[base + __popcll(m & ((1ull << lane) - 1ull))] = g;
+            if (start) s_start[base + __popcll(m & ((1ull << lane) - 1ull))] = g;
+        }
+    }
+    __syncthreads();
+    {
+        const uint32_t ns = s_nstart;
+        if (ns) {
+            if (threadIdx.x == 0) s_gbase = atomicAdd(&ctr[CT_SEG], (unsigned long long)ns);
+            __syncthreads();
+            const unsigned long long gb = s_gbase;
+            for (uint32_t idx = threadIdx.x; idx < ns; idx += kScanBlock) seg_list[gb + idx] = s_start[idx];
         }
     }
     if (g0 < rp.g_hi && g0 + kScanItems >= rp.g_hi) row_off[rp.g_hi] = run.hits;
-    atomicAdd(&sh_stat[0], st_n);
-    atomicAdd(&sh_stat[1], st_card);
-    atomicAdd(&sh_stat[2], st_hit);
-    atomicAdd(&sh_stat[3], st_raw);
-    atomicAdd(&sh_stat[4], st_searched);
+    __syncthreads();
+    // coalesced write-out of the row offsets and coalesced read of the interval sizes (stats)
+    for (uint32_t idx = threadIdx.x; idx < (uint32_t)kScanTile; idx += kScanBlock) {
+        const uint32_t g = tile_g0 + idx;
+        if (g < rp.g_hi) {
+            row_off[g] = s_row[idx];
+            if (s_f[idx] != kSkipN) st_raw += p_raw[g];
+        }
+    }
+    // wave reduction first: 256 same-address LDS atomics per counter would serialise
+    for (int off = 32; off > 0; off >>= 1) {
+        st_n += __shfl_down(st_n, off);
+        st_card += __shfl_down(st_card, off);
+        st_hit += __shfl_down(st_hit, off);
+        st_raw += __shfl_down(st_raw, off);
+        st_searched += __shfl_down(st_searched, off);
+    }
+    if (lane == 0) {
+        atomicAdd(&sh_stat[0], st_n);
+        atomicAdd(&sh_stat[1], st_card);
+        atomicAdd(&sh_stat[2], st_hit);
+        atomicAdd(&sh_stat[3], st_raw);
+        atomicAdd(&sh_stat[4], st_searched);
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         if (sh_stat[0]) atomicAdd(&ctr[CT_N_SKIPPED], sh_stat[0]);
@@ -548,10 +600,17 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
     const uint32_t thr0 = arm_threshold(k, G);
     PROF_DECL;
 
+    // segments are fetched kFetch at a time: one contended global atomic per group
+    constexpr unsigned long long kFetch = 8;
+    unsigned long long seg_next = 0, seg_stop = 0;
     for (;;) {
-        unsigned long long seg = 0;
-        if (lane == 0) seg = atomicAdd(P.cursor, 1ull);
-        seg = __shfl(seg, 0);
+        if (seg_next == seg_stop) {
+            unsigned long long sb = 0;
+            if (lane == 0) sb = atomicAdd(P.cursor, kFetch);
+            seg_next = __shfl(sb, 0);
+            seg_stop = seg_next + kFetch;
+        }
+        const unsigned long long seg = seg_next++;
         if (seg >= n_seg) break;
         const uint32_t g0 = P.seg_list[seg];
         PROF_SEG_BEGIN();
@@ -1126,7 +1185,6 @@ __global__ __launch_bounds__(64) void seg_prepass_kernel(RunParams rp, const uin
             const uint32_t s29 = sum > 0x1FFFFFFFull ? 0x1FFFFFFFu : (uint32_t)sum;
             keys[sidx] = (((uint32_t)tier - 1u) << 29) | (0x1FFFFFFFu - s29);
             vals[sidx] = g0;
-            atomicAdd(&ctr[CT_N1 + tier - 1], 1ull);
         }
         __syncthreads();
     }
@@ -1212,10 +1270,28 @@ __global__ __launch_bounds__(64) void seg_stats_kernel(RunParams rp, const uint3
             const uint32_t s29 = sum > 0x1FFFFFFFull ? 0x1FFFFFFFu : (uint32_t)sum;
             keys[sidx] = (((uint32_t)tier - 1u) << 29) | (0x1FFFFFFFu - s29);
             vals[sidx] = g0;
-            atomicAdd(&ctr[CT_N1 + tier - 1], 1ull);
         }
         __syncthreads();
     }
+}
+
+// tier list lengths from the sorted placement keys (tier-1 = key >> 29): n_t = first index whose
+// tier exceeds t, by bisection -- instead of one contended global atomic per segment
+__global__ void tier_bounds_kernel(const uint32_t *__restrict__ sorted_keys,
+                                   const unsigned long long *__restrict__ n_seg_ptr,
+                                   unsigned long long *__restrict__ ctr) {
+    const int t = threadIdx.x;  // 0..4
+    if (t >= 5) return;
+    const uint64_t n = *n_seg_ptr;
+    auto first_ge = [&](uint32_t tier_idx) {  // first position with (key >> 29) >= tier_idx
+        uint64_t lo = 0, hi = n;
+        while (lo < hi) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if ((sorted_keys[mid] >> 29) < tier_idx) lo = mid + 1; else hi = mid;
+        }
+        return lo;
+    };
+    ctr[CT_N1 + t] = first_ge((uint32_t)t + 1u) - first_ge((uint32_t)t);
 }
 
 // ---------------------------------------------------------------- K4b --------

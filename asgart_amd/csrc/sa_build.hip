@@ -248,13 +248,14 @@ int32_t build_t(const uint8_t *d_text, int64_t n_, IdxT *d_sa, bool dna, hipStre
 // Segment placement of the extension step: ascending radix sort of (tier, longest-first) keys.
 // keys/vals hold 2*n entries each (second half = alternate buffer).
 int32_t sort_segments(Workspace &w, uint32_t *keys, uint32_t *vals, uint64_t n, hipStream_t s,
-                      const uint32_t **sorted_vals) {
+                      const uint32_t **sorted_vals, const uint32_t **sorted_keys) {
     rocprim::double_buffer<uint32_t> kd(keys, keys + n), vd(vals, vals + n);
     size_t bytes = 0;
     HIP_TRY(rocprim::radix_sort_pairs(nullptr, bytes, kd, vd, (size_t)n, 0, 32, s));
     RC_TRY(w.sort_tmp.reserve(bytes));
     HIP_TRY(rocprim::radix_sort_pairs(w.sort_tmp.p, bytes, kd, vd, (size_t)n, 0, 32, s));
     *sorted_vals = vd.current();
+    *sorted_keys = kd.current();
     return 0;
 }
 
