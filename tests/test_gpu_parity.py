@@ -307,3 +307,38 @@ def test_escalation_tiers_give_identical_results(hiplib, name, tier, monkeypatch
                 assert idx.stats().heavy_segments > 0 or tier < 3
             eoffs, esds = oidx.run_raw(pr.chunks, oracle.make_settings(reverse=reverse, complement=complement, **cli), threads=4)
             assert np.array_equal(offs, eoffs) and np.array_equal(sds, esds), (name, tier, reverse)
+
+
+def test_cfg2_yeast_sized_direct_and_rc_bit_exact(hiplib):
+    """BASELINE.json configs[1]: S. cerevisiae-sized synthetic (12.2 Mb, 17 records), direct + RC
+    on one MI355X, suffix array built on the GPU, bit-exact against the CPU oracle; also as
+    4 shards (multi-GPU logic)."""
+    pr = prep.prepare_records(synth.config_genome(2))
+    with asgart_amd.Index(pr.data, None) as idx:
+        sa = idx.sa_read(0, len(pr.data))
+        oidx = oracle.Index.build(pr.data, sa)
+        assert oracle.sa_check(pr.data, sa) == 0
+        for reverse, complement in ((False, False), (True, True)):
+            st = asgart_amd.RunSettings.from_cli(reverse=reverse, complement=complement)
+            offs, sds = idx.search_duplications_raw(pr.chunks, st)
+            eoffs, esds = oidx.run_raw(pr.chunks, oracle.make_settings(reverse=reverse, complement=complement),
+                                       threads=16)
+            assert np.array_equal(offs, eoffs) and np.array_equal(sds, esds)
+            assert len(sds) > 100
+            parts = [idx.search_duplications_raw(pr.chunks, st, shard=r, n_shards=4) for r in range(4)]
+            assert np.array_equal(np.concatenate([p[1] for p in parts]), sds)
+
+
+def test_chr1_sized_sample_parity(hiplib):
+    """A 40 Mb slice of the chr1-shaped synthetic (satellite arrays, dense repeat family,
+    cardinality skips): the HIP path over all chunks vs the oracle."""
+    recs = synth.make_genome([40_000_000], seed=synth.SEED_BASE + 3)
+    pr = prep.prepare_records(recs)
+    with asgart_amd.Index(pr.data, None) as idx:
+        sa = idx.sa_read(0, len(pr.data))
+        oidx = oracle.Index.build(pr.data, sa)
+        st = asgart_amd.RunSettings.from_cli(reverse=True, complement=True)
+        offs, sds = idx.search_duplications_raw(pr.chunks, st)
+        eoffs, esds = oidx.run_raw(pr.chunks, oracle.make_settings(reverse=True, complement=True), threads=16)
+        assert np.array_equal(offs, eoffs) and np.array_equal(sds, esds)
+        assert len(sds) > 0 and idx.stats().heavy_segments >= 0
