@@ -231,6 +231,15 @@ int32_t index_prepare(asgart_index *idx, uint64_t k) {
                   (unsigned long long)k, kCacheLen, kMaxK);
         return ASGART_E_ARG;
     }
+    {
+        std::lock_guard<std::mutex> lk(idx->mu);
+        if (idx->k == k) return 0;
+    }
+    idx->acquire_all();  // no search call may be using the old keys
+    struct Unlock {
+        asgart_index *i;
+        ~Unlock() { i->release_all(); }
+    } unlock{idx};
     if (idx->k == k) return 0;
     HIP_TRY(hipSetDevice(idx->device));
     free_k_specific(idx);
@@ -243,7 +252,7 @@ int32_t index_prepare(asgart_index *idx, uint64_t k) {
     HIP_TRY(hipMalloc(&idx->d_ptab, entries * slot));
     HIP_TRY(hipMalloc(&idx->d_c8lo, (size_t)kCacheEntries * slot));
     HIP_TRY(hipMalloc(&idx->d_c8hi, (size_t)kCacheEntries * slot));
-    hipStream_t s = idx->stream;
+    hipStream_t s = idx->ctx[0].stream;
     if (idx->wide) {
         build_keys_kernel<uint64_t><<<grid_for(n), 256, 0, s>>>(
             idx->d_text, (const uint64_t *)idx->d_sa, idx->d_keys, n, (int)k);
@@ -307,17 +316,18 @@ void asgart_index_destroy(asgart_index *idx) {
     free_k_specific(idx);
     if (idx->d_text) (void)hipFree(idx->d_text);
     if (idx->d_sa) (void)hipFree(idx->d_sa);
-    Workspace &w = idx->ws;
-    DevBuf *bufs[] = {&w.chunks, &w.p_lo, &w.p_raw, &w.p_filt, &w.row_off, &w.blk, &w.hits,
-                      &w.big_list, &w.seg_list, &w.counters, &w.fam_sds,
-                      &w.ovf_list, &w.scratch, &w.hit_flag, &w.seg_keys, &w.seg_vals, &w.sort_tmp, &w.pat, &w.out_a, &w.out_b};
-    for (DevBuf *b : bufs) b->release();
-    for (auto &e : idx->ev)
-        if (e) (void)hipEventDestroy(e);
-    if (idx->stream) (void)hipStreamDestroy(idx->stream);
-    if (idx->stream2) (void)hipStreamDestroy(idx->stream2);
-    if (idx->stream3) (void)hipStreamDestroy(idx->stream3);
-    if (idx->stream4) (void)hipStreamDestroy(idx->stream4);
+    for (auto &cx : idx->ctx) {
+        Workspace &w = cx.ws;
+        DevBuf *bufs[] = {&w.chunks, &w.p_lo, &w.p_raw, &w.p_filt, &w.row_off, &w.blk, &w.hits,
+                          &w.big_list, &w.seg_list, &w.counters, &w.fam_sds, &w.ovf_list,
+                          &w.scratch, &w.hit_flag, &w.seg_keys, &w.seg_vals, &w.sort_tmp, &w.pat,
+                          &w.out_a, &w.out_b};
+        for (DevBuf *b : bufs) b->release();
+        for (auto &e : cx.ev)
+            if (e) (void)hipEventDestroy(e);
+        for (hipStream_t st : {cx.stream, cx.stream2, cx.stream3, cx.stream4})
+            if (st) (void)hipStreamDestroy(st);
+    }
     delete idx;
 }
 
@@ -346,27 +356,29 @@ int32_t asgart_index_create(const uint8_t *T, int64_t n, const int64_t *SA, int6
     idx->device = device;
     idx->n = n;
     idx->wide = (uint64_t)n >= 0xFFFFFF00ull;
-    memset(&idx->stats, 0, sizeof(idx->stats));
+    for (auto &cx : idx->ctx) memset(&cx.stats, 0, sizeof(cx.stats));
     int32_t rc = [&]() -> int32_t {
-        HIP_TRY(hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking));
-        HIP_TRY(hipStreamCreateWithFlags(&idx->stream2, hipStreamNonBlocking));
-        HIP_TRY(hipStreamCreateWithFlags(&idx->stream3, hipStreamNonBlocking));
-        HIP_TRY(hipStreamCreateWithFlags(&idx->stream4, hipStreamNonBlocking));
-        for (auto &e : idx->ev) HIP_TRY(hipEventCreate(&e));
+        for (auto &cx : idx->ctx) {
+            HIP_TRY(hipStreamCreateWithFlags(&cx.stream, hipStreamNonBlocking));
+            HIP_TRY(hipStreamCreateWithFlags(&cx.stream2, hipStreamNonBlocking));
+            HIP_TRY(hipStreamCreateWithFlags(&cx.stream3, hipStreamNonBlocking));
+            HIP_TRY(hipStreamCreateWithFlags(&cx.stream4, hipStreamNonBlocking));
+            for (auto &e : cx.ev) HIP_TRY(hipEventCreate(&e));
+        }
         HIP_TRY(hipMalloc((void **)&idx->d_text, (size_t)n + 64));
-        HIP_TRY(hipMemsetAsync(idx->d_text + n, 0, 64, idx->stream));
-        HIP_TRY(hipMemcpyAsync(idx->d_text, T, (size_t)n, hipMemcpyHostToDevice, idx->stream));
+        HIP_TRY(hipMemsetAsync(idx->d_text + n, 0, 64, idx->ctx[0].stream));
+        HIP_TRY(hipMemcpyAsync(idx->d_text, T, (size_t)n, hipMemcpyHostToDevice, idx->ctx[0].stream));
         // validate the alphabet on the device
-        RC_TRY(idx->ws.counters.reserve(256 * sizeof(unsigned long long)));
-        unsigned long long *d_hist = idx->ws.counters.as<unsigned long long>();
-        HIP_TRY(hipMemsetAsync(d_hist, 0, 256 * sizeof(unsigned long long), idx->stream));
+        RC_TRY(idx->ctx[0].ws.counters.reserve(256 * sizeof(unsigned long long)));
+        unsigned long long *d_hist = idx->ctx[0].ws.counters.as<unsigned long long>();
+        HIP_TRY(hipMemsetAsync(d_hist, 0, 256 * sizeof(unsigned long long), idx->ctx[0].stream));
         unsigned blocks = grid_for((uint64_t)n, 256 * 16);
         if (blocks > 4096) blocks = 4096;
-        byte_histogram_kernel<<<blocks, 256, 0, idx->stream>>>(idx->d_text, (uint64_t)n, d_hist);
+        byte_histogram_kernel<<<blocks, 256, 0, idx->ctx[0].stream>>>(idx->d_text, (uint64_t)n, d_hist);
         HIP_TRY(hipGetLastError());
         unsigned long long hist[256];
-        HIP_TRY(hipMemcpyAsync(hist, d_hist, sizeof(hist), hipMemcpyDeviceToHost, idx->stream));
-        HIP_TRY(hipStreamSynchronize(idx->stream));
+        HIP_TRY(hipMemcpyAsync(hist, d_hist, sizeof(hist), hipMemcpyDeviceToHost, idx->ctx[0].stream));
+        HIP_TRY(hipStreamSynchronize(idx->ctx[0].stream));
         for (int c = 0; c < 256; ++c)
             if (hist[c] && !valid_text_byte((uint8_t)c)) {
                 set_error("text contains byte 0x%02x; expected normalised bases {A,C,G,T,N} "
@@ -382,11 +394,11 @@ int32_t asgart_index_create(const uint8_t *T, int64_t n, const int64_t *SA, int6
         const size_t slot = idx->wide ? 8 : 4;
         HIP_TRY(hipMalloc(&idx->d_sa, ((size_t)n + 16) * slot));
         if (!SA) {
-            RC_TRY(sa_build_device(idx->d_text, n, idx->d_sa, idx->wide, idx->stream));
+            RC_TRY(sa_build_device(idx->d_text, n, idx->d_sa, idx->wide, idx->ctx[0].stream));
         } else if (idx->wide) {
             HIP_TRY(hipMemcpyAsync(idx->d_sa, SA, (size_t)n * 8, hipMemcpyHostToDevice,
-                                   idx->stream));
-            HIP_TRY(hipStreamSynchronize(idx->stream));
+                                   idx->ctx[0].stream));
+            HIP_TRY(hipStreamSynchronize(idx->ctx[0].stream));
         } else {
             const uint64_t slice = 1ull << 25;
             DevBuf stage;
@@ -394,11 +406,11 @@ int32_t asgart_index_create(const uint8_t *T, int64_t n, const int64_t *SA, int6
             for (uint64_t off = 0; off < (uint64_t)n; off += slice) {
                 uint64_t cnt = (uint64_t)n - off < slice ? (uint64_t)n - off : slice;
                 hipError_t e = hipMemcpyAsync(stage.p, SA + off, cnt * 8, hipMemcpyHostToDevice,
-                                              idx->stream);
+                                              idx->ctx[0].stream);
                 if (e == hipSuccess) {
-                    narrow_sa_kernel<<<grid_for(cnt), 256, 0, idx->stream>>>(
+                    narrow_sa_kernel<<<grid_for(cnt), 256, 0, idx->ctx[0].stream>>>(
                         stage.as<int64_t>(), (uint32_t *)idx->d_sa + off, cnt);
-                    e = hipStreamSynchronize(idx->stream);
+                    e = hipStreamSynchronize(idx->ctx[0].stream);
                 }
                 if (e != hipSuccess) {
                     stage.release();
@@ -437,11 +449,16 @@ static int32_t run_pattern_kernel(asgart_index *idx, const uint8_t *pats, int64_
                                   int64_t width, bool cache, uint64_t *lo, uint64_t *hi) {
     if (n_pat == 0) return 0;
     HIP_TRY(hipSetDevice(idx->device));
-    Workspace &w = idx->ws;
+    idx->acquire_all();
+    struct Unlock {
+        asgart_index *i;
+        ~Unlock() { i->release_all(); }
+    } unlock{idx};
+    Workspace &w = idx->ctx[0].ws;
     RC_TRY(w.pat.reserve((size_t)(n_pat * width)));
     RC_TRY(w.out_a.reserve((size_t)n_pat * 8));
     RC_TRY(w.out_b.reserve((size_t)n_pat * 8));
-    hipStream_t s = idx->stream;
+    hipStream_t s = idx->ctx[0].stream;
     HIP_TRY(hipMemcpyAsync(w.pat.p, pats, (size_t)(n_pat * width), hipMemcpyHostToDevice, s));
     unsigned g = grid_for((uint64_t)n_pat);
     if (idx->wide) {
@@ -505,19 +522,24 @@ int32_t asgart_sa_read(asgart_index *idx, uint64_t lo, uint64_t hi, int64_t *out
     }
     if (hi == lo) return 0;
     HIP_TRY(hipSetDevice(idx->device));
+    idx->acquire_all();
+    struct Unlock {
+        asgart_index *i;
+        ~Unlock() { i->release_all(); }
+    } unlock{idx};
     const uint64_t cnt = hi - lo;
     if (idx->wide) {
         HIP_TRY(hipMemcpyAsync(out, (const uint64_t *)idx->d_sa + lo, cnt * 8,
-                               hipMemcpyDeviceToHost, idx->stream));
+                               hipMemcpyDeviceToHost, idx->ctx[0].stream));
     } else {
-        RC_TRY(idx->ws.out_a.reserve(cnt * 8));
-        widen_sa_kernel<<<grid_for(cnt), 256, 0, idx->stream>>>(
-            (const uint32_t *)idx->d_sa + lo, idx->ws.out_a.as<int64_t>(), cnt);
+        RC_TRY(idx->ctx[0].ws.out_a.reserve(cnt * 8));
+        widen_sa_kernel<<<grid_for(cnt), 256, 0, idx->ctx[0].stream>>>(
+            (const uint32_t *)idx->d_sa + lo, idx->ctx[0].ws.out_a.as<int64_t>(), cnt);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(out, idx->ws.out_a.p, cnt * 8, hipMemcpyDeviceToHost,
-                               idx->stream));
+        HIP_TRY(hipMemcpyAsync(out, idx->ctx[0].ws.out_a.p, cnt * 8, hipMemcpyDeviceToHost,
+                               idx->ctx[0].stream));
     }
-    HIP_TRY(hipStreamSynchronize(idx->stream));
+    HIP_TRY(hipStreamSynchronize(idx->ctx[0].stream));
     return 0;
 }
 

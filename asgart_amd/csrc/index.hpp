@@ -13,6 +13,9 @@
 
 #include "common.hpp"
 
+#include <condition_variable>
+#include <mutex>
+
 namespace asgart {
 
 template <class SlotT>
@@ -76,10 +79,26 @@ struct Workspace {
 
 }  // namespace asgart
 
-struct asgart_index {
-    int device = 0;
+namespace asgart {
+// Everything one search call mutates.  The index owns two of them so that two passes (say the
+// direct and the -RC run, reference src/bin/asgart.rs runs them as separate invocations) can be
+// in flight at once from two host threads; text, suffix array and keys are shared read-only.
+struct SearchCtx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr, stream3 = nullptr, stream4 = nullptr;  // concurrent extension tiers
+    hipEvent_t ev[10] = {};
+    Workspace ws;
+    asgart_stats stats;
+    RunParams last_rp;   // inputs of the last call, kept for the yardstick kernel
+    bool has_last = false;
+    uint32_t last_P = 0;
+    bool busy = false;
+};
+constexpr int kNumCtx = 2;
+}  // namespace asgart
+
+struct asgart_index {
+    int device = 0;
     int64_t n = 0;
     bool wide = false;  // 64-bit slots/positions
     uint8_t *d_text = nullptr;
@@ -96,13 +115,49 @@ struct asgart_index {
     uint64_t tail_bloom = 0;
     std::vector<uint8_t> h_tail;  // last 64 bytes of the text (host copy)
     double ms_prepare = 0.0;
-    asgart::Workspace ws;
-    asgart_stats stats;
-    // inputs of the last call kept for the yardstick kernel
-    uint32_t last_P = 0;
-    asgart::RunParams last_rp;
-    bool has_last = false;
-    hipEvent_t ev[10] = {};
+    asgart::SearchCtx ctx[asgart::kNumCtx];
+    int last_ctx = 0;  // context of the most recent search call (asgart_get_stats)
+    std::mutex mu;
+    std::condition_variable cv;
+
+    // one free context for a search call / all contexts for calls that change shared state
+    asgart::SearchCtx &acquire_one(int *which) {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            for (int i = 0; i < asgart::kNumCtx; ++i)
+                if (!ctx[i].busy) {
+                    ctx[i].busy = true;
+                    *which = i;
+                    return ctx[i];
+                }
+            cv.wait(lk);
+        }
+    }
+    void acquire_all() {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            bool any = false;
+            for (auto &c : ctx) any |= c.busy;
+            if (!any) break;
+            cv.wait(lk);
+        }
+        for (auto &c : ctx) c.busy = true;
+    }
+    void release_one(int which) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            ctx[which].busy = false;
+            last_ctx = which;
+        }
+        cv.notify_all();
+    }
+    void release_all() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (auto &c : ctx) c.busy = false;
+        }
+        cv.notify_all();
+    }
 
     template <class SlotT>
     asgart::IndexView<SlotT> view() const {

@@ -51,13 +51,13 @@ static uint32_t probes_in_chunk(uint64_t L, uint64_t k, uint64_t step, uint64_t 
 }
 
 template <class SlotT>
-static int32_t run_search_t(asgart_index *idx, const uint64_t *chunks, int64_t n_chunks,
+static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *chunks, int64_t n_chunks,
                             const asgart_settings *st, int32_t shard, int32_t n_shards,
                             bool want_csr, asgart_families *fam_out,
                             std::vector<uint8_t> *status_out, std::vector<uint64_t> *rowoff_out,
                             std::vector<uint64_t> *hits_out) {
-    Workspace &w = idx->ws;
-    hipStream_t s = idx->stream;
+    Workspace &w = cx.ws;
+    hipStream_t s = cx.stream;
     const uint64_t k = st->probe_size, step = k / 2;
     const uint64_t n = (uint64_t)idx->n;
 
@@ -84,9 +84,9 @@ static int32_t run_search_t(asgart_index *idx, const uint64_t *chunks, int64_t n
     }
     h_pbase[n_chunks] = (uint32_t)P64;
     const uint32_t P = (uint32_t)P64;
-    idx->last_P = P;
-    memset(&idx->stats, 0, sizeof(idx->stats));
-    idx->stats.probes_total = P;
+    cx.last_P = P;
+    memset(&cx.stats, 0, sizeof(cx.stats));
+    cx.stats.probes_total = P;
     if (fam_out) {
         fam_out->fam_offsets.assign(1, 0);
         fam_out->sds.clear();
@@ -158,8 +158,8 @@ static int32_t run_search_t(asgart_index *idx, const uint64_t *chunks, int64_t n
     rp.C = st->max_cardinality > 0xFFFFFF00ull ? 0xFFFFFF00u : (uint32_t)st->max_cardinality;
     rp.reverse = st->reverse ? 1 : 0;
     rp.complement = st->complement ? 1 : 0;
-    idx->last_rp = rp;
-    idx->has_last = false;
+    cx.last_rp = rp;
+    cx.has_last = false;
 
     // ---- workspace (indexed by absolute probe number through shifted pointers) ---
     const uint32_t n_blk = (W + kScanTile - 1) / kScanTile;
@@ -185,16 +185,16 @@ static int32_t run_search_t(asgart_index *idx, const uint64_t *chunks, int64_t n
     uint32_t *seg_list = w.seg_list.as<uint32_t>();
 
     // ---- K1: probe search + filtered counts -----------------------------------
-    HIP_TRY(hipEventRecord(idx->ev[0], s));
+    HIP_TRY(hipEventRecord(cx.ev[0], s));
     probe_count_kernel<SlotT><<<grid_for(W), 256, 0, s>>>(ix, rp, p_lo, p_raw, p_filt, big_list,
                                                          d_ctr);
     big_count_kernel<SlotT><<<2048, 256, 0, s>>>(ix, rp, p_lo, p_raw, p_filt, big_list, d_ctr);
-    HIP_TRY(hipEventRecord(idx->ev[1], s));
+    HIP_TRY(hipEventRecord(cx.ev[1], s));
     // ---- K2: scans + segmentation ----------------------------------------------
     scan_reduce_kernel<<<n_blk, kScanBlock, 0, s>>>(rp, p_filt, blk);
     scan_mid_kernel<<<1, 1024, 0, s>>>(blk, n_blk, d_ctr);
     scan_down_kernel<<<n_blk, kScanBlock, 0, s>>>(rp, p_filt, p_raw, blk, row_off, seg_list, d_ctr);
-    HIP_TRY(hipEventRecord(idx->ev[2], s));
+    HIP_TRY(hipEventRecord(cx.ev[2], s));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, sizeof(h_ctr), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -216,7 +216,7 @@ static int32_t run_search_t(asgart_index *idx, const uint64_t *chunks, int64_t n
     if (h_ctr[CT_BIG])
         fill_big_kernel<SlotT><<<2048, 256, 0, s>>>(ix, rp, p_lo, p_raw, p_filt, row_off, hits,
                                                     big_list, d_ctr);
-    HIP_TRY(hipEventRecord(idx->ev[3], s));
+    HIP_TRY(hipEventRecord(cx.ev[3], s));
     HIP_TRY(hipGetLastError());
 
     if (want_csr) {
@@ -301,7 +301,7 @@ static int32_t run_search_t(asgart_index *idx, const uint64_t *chunks, int64_t n
             RC_TRY(w.fam_sds.reserve((size_t)rec_cap * sizeof(SdRec)));
             HIP_TRY(hipMemsetAsync(d_ctr + CT_SD, 0, 8, s));
             HIP_TRY(hipMemsetAsync(d_ctr + CT_NF, 0, 12 * 8, s));  // NF, cursors, OVF1..5
-            HIP_TRY(hipEventRecord(idx->ev[7], s));
+            HIP_TRY(hipEventRecord(cx.ev[7], s));
             ExtParams<SlotT> ep;
             ep.rp = rp;
             ep.p_filt = p_filt;
@@ -321,10 +321,10 @@ static int32_t run_search_t(asgart_index *idx, const uint64_t *chunks, int64_t n
             // back-fills CUs as workgroups retire, so the tails of one tier overlap the next.
             // The window bound guarantees that a segment fits its
             // tier, so the overflow lists normally stay empty (they feed the cascade below).
-            hipStream_t st2 = idx->stream2, st3 = idx->stream3, st4 = idx->stream4;
-            HIP_TRY(hipStreamWaitEvent(st2, idx->ev[7], 0));
-            HIP_TRY(hipStreamWaitEvent(st3, idx->ev[7], 0));
-            HIP_TRY(hipStreamWaitEvent(st4, idx->ev[7], 0));
+            hipStream_t st2 = cx.stream2, st3 = cx.stream3, st4 = cx.stream4;
+            HIP_TRY(hipStreamWaitEvent(st2, cx.ev[7], 0));
+            HIP_TRY(hipStreamWaitEvent(st3, cx.ev[7], 0));
+            HIP_TRY(hipStreamWaitEvent(st4, cx.ev[7], 0));
             if (n_t[0]) {
                 ep.seg_list = order;
                 ep.n_seg_ptr = d_ctr + CT_N1;
@@ -374,12 +374,12 @@ static int32_t run_search_t(asgart_index *idx, const uint64_t *chunks, int64_t n
                 extend_heavy_kernel<SlotT, capg, kHeavyThreads, 2><<<g5, kHeavyThreads, 0, st4>>>(ep);
             }
             HIP_TRY(hipGetLastError());
-            HIP_TRY(hipEventRecord(idx->ev[5], st2));
-            HIP_TRY(hipEventRecord(idx->ev[6], st3));
-            HIP_TRY(hipEventRecord(idx->ev[8], st4));
-            HIP_TRY(hipStreamWaitEvent(s, idx->ev[5], 0));
-            HIP_TRY(hipStreamWaitEvent(s, idx->ev[6], 0));
-            HIP_TRY(hipStreamWaitEvent(s, idx->ev[8], 0));
+            HIP_TRY(hipEventRecord(cx.ev[5], st2));
+            HIP_TRY(hipEventRecord(cx.ev[6], st3));
+            HIP_TRY(hipEventRecord(cx.ev[8], st4));
+            HIP_TRY(hipStreamWaitEvent(s, cx.ev[5], 0));
+            HIP_TRY(hipStreamWaitEvent(s, cx.ev[6], 0));
+            HIP_TRY(hipStreamWaitEvent(s, cx.ev[8], 0));
             HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, sizeof(h_ctr), hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
             PROF_DUMP("concurrent tiers");
@@ -442,7 +442,7 @@ static int32_t run_search_t(asgart_index *idx, const uint64_t *chunks, int64_t n
             look_ahead *= 8;
             continue;
         }
-        HIP_TRY(hipEventRecord(idx->ev[4], s));
+        HIP_TRY(hipEventRecord(cx.ev[4], s));
         const uint64_t n_rec = h_ctr[CT_SD];
         h_recs.resize((size_t)n_rec);
         if (n_rec)
@@ -473,22 +473,22 @@ static int32_t run_search_t(asgart_index *idx, const uint64_t *chunks, int64_t n
             f0 = f1;
         }
     } else {
-        HIP_TRY(hipEventRecord(idx->ev[4], s));
+        HIP_TRY(hipEventRecord(cx.ev[4], s));
         HIP_TRY(hipStreamSynchronize(s));
     }
     break;
     }  // shard-window retry loop
 
     // ---- stats ------------------------------------------------------------------
-    asgart_stats &stt = idx->stats;
+    asgart_stats &stt = cx.stats;
     float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, idx->ev[0], idx->ev[1]));
+    HIP_TRY(hipEventElapsedTime(&ms, cx.ev[0], cx.ev[1]));
     stt.ms_search = ms;
-    HIP_TRY(hipEventElapsedTime(&ms, idx->ev[1], idx->ev[2]));
+    HIP_TRY(hipEventElapsedTime(&ms, cx.ev[1], cx.ev[2]));
     stt.ms_scan = ms;
-    HIP_TRY(hipEventElapsedTime(&ms, idx->ev[2], idx->ev[3]));
+    HIP_TRY(hipEventElapsedTime(&ms, cx.ev[2], cx.ev[3]));
     stt.ms_fill = ms;
-    HIP_TRY(hipEventElapsedTime(&ms, idx->ev[3], idx->ev[4]));
+    HIP_TRY(hipEventElapsedTime(&ms, cx.ev[3], cx.ev[4]));
     stt.ms_extend = ms;
     stt.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() -
                                                             t_host0).count();
@@ -506,7 +506,7 @@ static int32_t run_search_t(asgart_index *idx, const uint64_t *chunks, int64_t n
     stt.heavy_segments = n_heavy;
 
     stt.ms_extend_tier2 = ms_tier2;
-    idx->has_last = true;
+    cx.has_last = true;
     return 0;
 }
 
@@ -523,12 +523,25 @@ int32_t run_search(asgart_index *idx, const uint64_t *chunks, int64_t n_chunks,
         return ASGART_E_ARG;
     }
     HIP_TRY(hipSetDevice(idx->device));
-    RC_TRY(index_prepare(idx, st->probe_size));
+    // take a free per-call context; the keys can only change while no context is in use
+    int which = 0;
+    for (;;) {
+        SearchCtx &probe = idx->acquire_one(&which);
+        (void)probe;
+        if (idx->k == st->probe_size) break;
+        idx->release_one(which);
+        RC_TRY(index_prepare(idx, st->probe_size));
+    }
+    SearchCtx &cx = idx->ctx[which];
+    int32_t rc;
     if (idx->wide)
-        return run_search_t<uint64_t>(idx, chunks, n_chunks, st, shard, n_shards, want_csr, fam_out,
-                                      status_out, rowoff_out, hits_out);
-    return run_search_t<uint32_t>(idx, chunks, n_chunks, st, shard, n_shards, want_csr, fam_out,
-                                  status_out, rowoff_out, hits_out);
+        rc = run_search_t<uint64_t>(idx, cx, chunks, n_chunks, st, shard, n_shards, want_csr, fam_out,
+                                    status_out, rowoff_out, hits_out);
+    else
+        rc = run_search_t<uint32_t>(idx, cx, chunks, n_chunks, st, shard, n_shards, want_csr, fam_out,
+                                    status_out, rowoff_out, hits_out);
+    idx->release_one(which);
+    return rc;
 }
 
 }  // namespace asgart
@@ -609,27 +622,36 @@ int32_t asgart_get_stats(asgart_index *idx, uint32_t flags, asgart_stats *out) {
         set_error("bad argument");
         return ASGART_E_ARG;
     }
-    if ((flags & ASGART_STATS_YARDSTICK) && idx->has_last && idx->last_P) {
-        HIP_TRY(hipSetDevice(idx->device));
-        unsigned long long *d_ctr = idx->ws.counters.as<unsigned long long>();
-        hipStream_t s = idx->stream;
-        HIP_TRY(hipMemsetAsync(d_ctr + CT_BISECT, 0, 8, s));
-        const RunParams &rp = idx->last_rp;
-        const unsigned g = grid_for(rp.g_hi - rp.g_lo);
-        if (idx->wide)
-            yardstick_kernel<uint64_t><<<g, 256, 0, s>>>(idx->view<uint64_t>(), rp,
-                                                         idx->ws.p_filt.as<uint32_t>() - rp.g_lo, d_ctr);
-        else
-            yardstick_kernel<uint32_t><<<g, 256, 0, s>>>(idx->view<uint32_t>(), rp,
-                                                         idx->ws.p_filt.as<uint32_t>() - rp.g_lo, d_ctr);
-        HIP_TRY(hipGetLastError());
-        unsigned long long v = 0;
-        HIP_TRY(hipMemcpyAsync(&v, d_ctr + CT_BISECT, 8, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        idx->stats.bisect_steps = v;
-    }
-    *out = idx->stats;
-    return 0;
+    idx->acquire_all();
+    // bits 8.. of flags select a specific context (ASGART_STATS_CTX(i) = (i+1) << 8); default:
+    // the context of the most recent search call
+    const int sel = (int)((flags >> 8) & 0xFFu);
+    SearchCtx &cx = idx->ctx[sel >= 1 && sel <= kNumCtx ? sel - 1 : idx->last_ctx];
+    int32_t rc = [&]() -> int32_t {
+        if ((flags & ASGART_STATS_YARDSTICK) && cx.has_last && cx.last_P) {
+            HIP_TRY(hipSetDevice(idx->device));
+            unsigned long long *d_ctr = cx.ws.counters.as<unsigned long long>();
+            hipStream_t s = cx.stream;
+            HIP_TRY(hipMemsetAsync(d_ctr + CT_BISECT, 0, 8, s));
+            const RunParams &rp = cx.last_rp;
+            const unsigned g = grid_for(rp.g_hi - rp.g_lo);
+            if (idx->wide)
+                yardstick_kernel<uint64_t><<<g, 256, 0, s>>>(idx->view<uint64_t>(), rp,
+                                                             cx.ws.p_filt.as<uint32_t>() - rp.g_lo, d_ctr);
+            else
+                yardstick_kernel<uint32_t><<<g, 256, 0, s>>>(idx->view<uint32_t>(), rp,
+                                                             cx.ws.p_filt.as<uint32_t>() - rp.g_lo, d_ctr);
+            HIP_TRY(hipGetLastError());
+            unsigned long long v = 0;
+            HIP_TRY(hipMemcpyAsync(&v, d_ctr + CT_BISECT, 8, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            cx.stats.bisect_steps = v;
+        }
+        *out = cx.stats;
+        return 0;
+    }();
+    idx->release_all();
+    return rc;
 }
 
 }  // extern "C"

@@ -148,6 +148,10 @@ int64_t asgart_probe_hits(asgart_index *idx, const uint64_t *chunks, int64_t n_c
                           uint64_t *row_offsets, uint64_t *hits, uint64_t *n_hits);
 
 #define ASGART_STATS_YARDSTICK 1u
+/* asgart_search_duplications is re-entrant: up to two calls on one index may be in flight from
+ * different host threads (e.g. the direct and the -RC pass), each in its own internal context.
+ * ASGART_STATS_CTX(i), i = 0 or 1, selects the stats of context i instead of the last call's. */
+#define ASGART_STATS_CTX(i) (((uint32_t)(i) + 1u) << 8)
 /* Stats of the last search call on this index.  With ASGART_STATS_YARDSTICK in
  * `flags` an extra (untimed) kernel also fills bisect_steps. */
 int32_t asgart_get_stats(asgart_index *idx, uint32_t flags, asgart_stats *out);
