@@ -1,0 +1,210 @@
+"""Post-processing steps that follow the search step, and the RunResult JSON surface.
+
+Host code mirroring the reference's `Step`s in the order fixed at src/bin/asgart.rs:738-747:
+FilterNs (:81-96, ProtoSD::n_content src/structs.rs:454-467), ReOrder (:33-51), ReduceOverlap
+(:67-79, helpers :481-562), Sort (:53-65); then ProtoSD -> SD with chromosome lookup (:770-821) and
+the JSON exporter (src/exporters.rs:12-25, struct field order of src/structs.rs:36-58,60-98,471-493).
+ComputeScore (--compute-score, Levenshtein) is not implemented.
+
+These steps are cheap host work in the reference as well; nothing here
+touches the GPU.  All quirks are kept (see the comments), tests/test_postprocess.py checks the chain
+against the oracle's C restatement.
+"""
+from __future__ import annotations
+
+import json
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import ProtoSD, ProtoSDsFamily, RunSettings
+from .prep import Start
+
+
+class FilterNs:
+    def name(self) -> str:
+        return "Filtering uncertain duplications"
+
+    def run(self, families: List[ProtoSDsFamily], strand) -> List[ProtoSDsFamily]:
+        data = strand.data
+        is_n = ((data == ord("N")) | (data == ord("n")))
+        csum = np.concatenate(([0], np.cumsum(is_n, dtype=np.int64)))
+
+        def n_content(sd: ProtoSD) -> np.float32:
+            # inclusive ranges [p ..= p+len], divided by len, in f32 (src/structs.rs:454-467)
+            cl = csum[sd.left + sd.left_length + 1] - csum[sd.left]
+            cr = csum[sd.right + sd.right_length + 1] - csum[sd.right]
+            a = np.float32(cl) / np.float32(sd.left_length)
+            b = np.float32(cr) / np.float32(sd.right_length)
+            return max(a, b)
+
+        out = []
+        for fam in families:
+            kept = [sd for sd in fam if n_content(sd) <= np.float32(0.2)]
+            if kept:
+                out.append(kept)
+        return out
+
+
+class ReOrder:
+    def name(self) -> str:
+        return "Re-ordering"
+
+    def run(self, families, _strand):
+        for fam in families:
+            for sd in fam:
+                if sd.left > sd.right:  # positions are swapped, the lengths are NOT (:42-46)
+                    sd.left, sd.right = sd.right, sd.left
+        return families
+
+
+def _subsegment(xs, xl, ys, yl) -> bool:
+    return xs >= ys and xs + xl <= ys + yl
+
+
+def _overlap(xs, xl, ys, yl) -> bool:
+    xe, ye = xs + xl, ys + yl
+    return (ys <= xs <= ye and xe >= ye) or (xs <= ys <= xe and ye >= xe)
+
+
+def _merge(x: ProtoSD, y: ProtoSD) -> ProtoSD:
+    # src/bin/asgart.rs:497-513: x contributes left_length to BOTH arms, y right_length to both
+    nl = min(x.left, y.left)
+    ll = max(x.left + x.left_length, y.left + y.right_length) - nl
+    nr = min(x.right, y.right)
+    rl = max(x.right + x.left_length, y.right + y.right_length) - nr
+    return ProtoSD(nl, nr, ll, rl, 0.0, x.reversed, x.complemented)
+
+
+def _reduce(result: Sequence[ProtoSD]) -> List[ProtoSD]:
+    news: List[ProtoSD] = []
+    for x in result:
+        for y in news:
+            if (_subsegment(x.left, x.left_length, y.left, y.left_length)
+                    and _subsegment(x.right, x.right_length, y.right, y.right_length)):
+                break
+            if (_subsegment(y.left, y.left_length, x.left, x.left_length)
+                    and _subsegment(y.right, y.right_length, x.right, x.right_length)):
+                y.left, y.right, y.left_length, y.right_length = x.left, x.right, x.left_length, x.right_length
+                break
+            if (_overlap(x.left, x.left_length, y.left, y.left_length)
+                    and _overlap(x.right, x.right_length, y.right, y.right_length)):
+                z = _merge(x, y)
+                y.left, y.right, y.left_length, y.right_length = z.left, z.right, z.left_length, z.right_length
+                break
+        else:
+            news.append(ProtoSD(x.left, x.right, x.left_length, x.right_length, x.identity,
+                                x.reversed, x.complemented))
+    return news
+
+
+class ReduceOverlap:
+    def name(self) -> str:
+        return "Reducing overlap"
+
+    def run(self, families, _strand):
+        out = []
+        for fam in families:
+            old = len(fam)
+            news = _reduce(fam)
+            while len(news) < old:
+                old = len(news)
+                news = _reduce(news)
+            out.append(news)
+        return out
+
+
+class Sort:
+    def name(self) -> str:
+        return "Sorting"
+
+    def run(self, families, _strand):
+        for fam in families:
+            fam.sort(key=lambda sd: sd.left)  # stable, like slice::sort_by
+        return families
+
+
+def post_process(families: List[ProtoSDsFamily], strand) -> List[ProtoSDsFamily]:
+    """The steps after SearchDuplications, in the reference's order (no ComputeScore)."""
+    for step in (FilterNs(), ReOrder(), ReduceOverlap(), Sort()):
+        families = step.run(families, strand)
+    return families
+
+
+# ---- result surface -------------------------------------------------------------------------
+def _find_chr_by_pos(starts: Sequence[Start], pos: int) -> Optional[Start]:
+    for c in starts:  # first match, linear scan (src/structs.rs:85-90)
+        if c.position <= pos < c.position + c.length:
+            return c
+    return None
+
+
+def run_result(families: List[ProtoSDsFamily], strand, settings: RunSettings) -> dict:
+    """RunResult as a dict in serde field order (src/bin/asgart.rs:770-821, src/structs.rs)."""
+    fams = []
+    for fam in families:
+        out = []
+        for sd in fam:
+            cl, cr = _find_chr_by_pos(strand.map, sd.left), _find_chr_by_pos(strand.map, sd.right)
+            out.append({
+                "chr_left": cl.name if cl else "unknown",
+                "chr_right": cr.name if cr else "unknown",
+                "global_left_position": sd.left,
+                "global_right_position": sd.right,
+                "chr_left_position": sd.left - (cl.position if cl else 0),
+                "chr_right_position": sd.right - (cr.position if cr else 0),
+                "left_length": sd.left_length,
+                "right_length": sd.right_length,
+                "left_seq": None,
+                "right_seq": None,
+                "identity": float(sd.identity),
+                "reversed": bool(sd.reversed),
+                "complemented": bool(sd.complemented),
+            })
+        fams.append(out)
+    return {
+        "strand": {
+            "name": strand.file_names,
+            "length": sum(c.length for c in strand.map),
+            "map": [{"name": c.name, "position": c.position, "length": c.length} for c in strand.map],
+        },
+        # reverse/complement/threads_count/compute_score are skip_serializing (src/structs.rs:44-57)
+        "settings": {
+            "probe_size": settings.probe_size,
+            "max_gap_size": settings.max_gap_size,
+            "min_duplication_length": settings.min_duplication_length,
+            "max_cardinality": settings.max_cardinality,
+            "trim": list(settings.trim) if settings.trim else None,
+            "skip_masked": bool(settings.skip_masked),
+        },
+        "families": fams,
+    }
+
+
+def to_json(result: dict) -> str:
+    """serde_json::to_string_pretty layout (2-space indent, `0.0`, `null`)."""
+    return json.dumps(result, indent=2)
+
+
+def out_filename(files: Sequence[str], settings: RunSettings, prefix: str = "") -> str:
+    """Default output name, src/bin/asgart.rs:642-714: {prefix}{stems joined '-'}[_][R][C][_a-b].json"""
+    import os
+
+    radix = "-".join(os.path.splitext(os.path.basename(f))[0] for f in files)
+    rc = ("_" if settings.reverse or settings.complement else "") + \
+         ("R" if settings.reverse else "") + ("C" if settings.complement else "")
+    trim = f"_{settings.trim[0]}-{settings.trim[1]}" if settings.trim else ""
+    return f"{prefix}{radix}{rc}{trim}.json"
+
+
+def search_duplications(strands_files: Sequence[str], settings: RunSettings, device: int = 0) -> dict:
+    """`search_duplications()` of src/bin/asgart.rs:731-822: prepare_data, the step chain with the
+    HIP search step first, then the RunResult.  Raises AsgartError without a GPU (no CPU fallback)."""
+    from . import SearchDuplications, Strand
+    from .prep import prepare_records, read_records
+
+    records = [rec for f in strands_files for rec in read_records(f)]
+    pr = prepare_records(records, settings.skip_masked)
+    strand = Strand(", ".join(strands_files), pr.data, pr.map)  # file_names, :437
+    families = SearchDuplications(pr.chunks, settings.trim, settings, device=device).run([], strand)
+    return run_result(post_process(families, strand), strand, settings)

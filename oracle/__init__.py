@@ -20,7 +20,7 @@ _LIB_PATH = os.path.join(_HERE, "libasgart_oracle.so")
 
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (make).  Idempotent."""
-    srcs = [os.path.join(_HERE, f) for f in ("asgart_oracle.c", "sais.c", "asgart_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("asgart_oracle.c", "sais.c", "postprocess.c", "asgart_oracle.h")]
     stale = force or not os.path.exists(_LIB_PATH) or any(
         os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs
     )
@@ -104,6 +104,8 @@ def lib() -> C.CDLL:
     L.oracle_find_chunks.restype = C.c_int64
     L.oracle_complemented.argtypes = [vp, vp, C.c_uint64]
     L.oracle_complemented.restype = None
+    L.oracle_postprocess.argtypes = [vp, vp, C.c_uint64, vp, C.POINTER(vp)]
+    L.oracle_postprocess.restype = C.c_int32
     L.oracle_d_ss.argtypes = [C.c_uint64] * 4
     L.oracle_d_ss.restype = C.c_int64
     _lib = L
@@ -285,6 +287,18 @@ class Index:
         hits = np.zeros(nh.value, dtype=np.uint64)
         L.oracle_probe_hits(*args, _ptr(status), _ptr(offs), _ptr(hits), C.byref(nh))
         return status, offs, hits
+
+
+def postprocess(strand: np.ndarray, offs: np.ndarray, sds: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """FilterNs -> ReOrder -> ReduceOverlap -> Sort on raw family arrays (src/bin/asgart.rs:738-747)."""
+    strand = as_text(strand)
+    offs = np.ascontiguousarray(offs, dtype=np.uint64)
+    sds = np.ascontiguousarray(sds, dtype=np.uint64)
+    h = C.c_void_p()
+    rc = lib().oracle_postprocess(_ptr(strand), _ptr(offs), len(offs) - 1, _ptr(sds), C.byref(h))
+    if rc != 0:
+        raise RuntimeError(f"oracle_postprocess -> {rc}")
+    return _take_families(h)
 
 
 def prepare_needle(text: np.ndarray, chunk: Tuple[int, int], settings: Settings) -> np.ndarray:

@@ -229,6 +229,19 @@ static int families_close_family(oracle_families *f) {
     return 0;
 }
 
+int32_t oracle_families_from_arrays(const uint64_t *fam_offsets, uint64_t n_fam,
+                                    const oracle_proto_sd *sds, oracle_families **out) {
+    oracle_families *f = families_new();
+    if (!f) return -2;
+    for (uint64_t fam = 0; fam < n_fam; ++fam) {
+        for (uint64_t j = fam_offsets[fam]; j < fam_offsets[fam + 1]; ++j)
+            if (families_push_sd(f, sds[j])) return -2;
+        if (families_close_family(f)) return -2;
+    }
+    *out = f;
+    return 0;
+}
+
 void oracle_families_counts(const oracle_families *f, uint64_t *n_families, uint64_t *n_sds) {
     *n_families = f->n_fam;
     *n_sds = f->n_sd;

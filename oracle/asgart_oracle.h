@@ -82,6 +82,12 @@ void oracle_families_counts(const oracle_families *f, uint64_t *n_families, uint
 void oracle_families_copy(const oracle_families *f, uint64_t *fam_offsets, oracle_proto_sd *sds);
 void oracle_families_free(oracle_families *f);
 
+int32_t oracle_families_from_arrays(const uint64_t *fam_offsets, uint64_t n_fam,
+                                    const oracle_proto_sd *sds, oracle_families **out);
+/* FilterNs -> ReOrder -> ReduceOverlap -> Sort (src/bin/asgart.rs:33-96,481-562,738-747) */
+int32_t oracle_postprocess(const uint8_t *strand, const uint64_t *fam_offsets, uint64_t n_fam,
+                           const oracle_proto_sd *sds, oracle_families **out);
+
 /* ---- automaton::search_duplications for ONE needle (src/automaton.rs:57-204).
  * `left` in the result is needle-local, `right` global, exactly as the
  * reference returns them.  progress may be NULL.  Returns 0 or <0. */

@@ -342,3 +342,38 @@ def test_chr1_sized_sample_parity(hiplib):
         eoffs, esds = oidx.run_raw(pr.chunks, oracle.make_settings(reverse=True, complement=True), threads=16)
         assert np.array_equal(offs, eoffs) and np.array_equal(sds, esds)
         assert len(sds) > 0 and idx.stats().heavy_segments >= 0
+
+
+@pytest.mark.parametrize("rc", [False, True])
+def test_fasta_to_run_result_end_to_end(hiplib, tmp_path, rc):
+    """FASTA files -> prepare -> HIP search step -> FilterNs/ReOrder/ReduceOverlap/Sort -> RunResult,
+    against the oracle's search + post-processing chain on the same records."""
+    from asgart_amd import postprocess
+    recs = synth.make_genome([240_000, 150_000, 90_000], seed=77, sd_per_mb=50, sd_len=(800, 6000),
+                             alu_frac=0.05, l1_frac=0.02, sat_per_record=1, sat_copies=(20, 60),
+                             short_n_per_mb=15)
+    files = []
+    for i, part in enumerate((recs[:2], recs[2:])):
+        p = tmp_path / f"part{i}.fa"
+        with open(p, "wb") as fh:
+            for name, seq in part:
+                fh.write(b">" + name.encode() + b" some description\n")
+                raw = seq.tobytes()
+                for o in range(0, len(raw), 70):
+                    fh.write(raw[o:o + 70] + b"\n")
+        files.append(str(p))
+    settings = asgart_amd.RunSettings.from_cli(min_length=400, reverse=rc, complement=rc)
+    res = postprocess.search_duplications(files, settings)
+
+    pr = prep.prepare_records(recs)
+    oidx = oracle.Index.build(pr.data)
+    offs, sds = oidx.run_raw(pr.chunks, oracle.make_settings(min_length=400, reverse=rc, complement=rc))
+    eo, es = oracle.postprocess(pr.data, offs, sds)
+    want = oracle.families_to_list(eo, es)
+    got = [[(sd["global_left_position"], sd["global_right_position"], sd["left_length"], sd["right_length"])
+            for sd in fam] for fam in res["families"]]
+    assert got == want and len(want) > 0
+    assert res["strand"]["name"] == ", ".join(files)
+    assert [m["name"] for m in res["strand"]["map"]] == [n for n, _ in recs]
+    assert all(sd["reversed"] == rc and sd["complemented"] == rc for fam in res["families"] for sd in fam)
+    assert postprocess.to_json(res).startswith('{\n  "strand": {\n    "name": ')

@@ -1,0 +1,112 @@
+"""N1/N2 of SURVEY.md section 8f: the host post-processing chain and the RunResult surface against
+the oracle's C restatement (oracle/postprocess.c) on the families of seeded synthetic genomes."""
+import json
+
+import numpy as np
+import pytest
+
+import oracle
+import asgart_amd
+from asgart_amd import postprocess, prep, synth
+
+
+def _to_families(offs, sds, reverse=False, complement=False):
+    return [[asgart_amd.ProtoSD(int(r[0]), int(r[1]), int(r[2]), int(r[3]), 0.0, reverse, complement)
+             for r in sds[int(offs[f]):int(offs[f + 1])]] for f in range(len(offs) - 1)]
+
+
+def _case(seed, **kw):
+    args = dict(sd_per_mb=60, sd_len=(1000, 6000), alu_frac=0.05, l1_frac=0.02, sat_per_record=1,
+                sat_copies=(20, 80), short_n_per_mb=20)
+    args.update(kw)
+    recs = synth.make_genome([220_000, 130_000], seed=seed, **args)
+    pr = prep.prepare_records(recs)
+    return pr, oracle.Index.build(pr.data)
+
+
+@pytest.mark.parametrize("seed,mode,min_len", [(31, (False, False), 300), (32, (True, True), 300),
+                                               (33, (False, False), 1000), (34, (False, False), 200)])
+def test_chain_matches_oracle(seed, mode, min_len):
+    pr, oidx = _case(seed)
+    offs, sds = oidx.run_raw(pr.chunks, oracle.make_settings(min_length=min_len, reverse=mode[0], complement=mode[1]))
+    assert len(sds) > 3
+    eoffs, esds = oracle.postprocess(pr.data, offs, sds)
+    strand = asgart_amd.Strand("x.fa", pr.data, pr.map)
+    fams = postprocess.post_process(_to_families(offs, sds, *mode), strand)
+    got = [[sd.as_tuple() for sd in fam] for fam in fams]
+    assert got == oracle.families_to_list(eoffs, esds)
+    assert all(sd.reversed == mode[0] and sd.complemented == mode[1] for fam in fams for sd in fam)
+
+
+def test_filter_ns_inclusive_range_and_threshold():
+    text = np.frombuffer(b"A" * 100 + b"N" * 21 + b"A" * 200 + b"$", dtype=np.uint8)
+    strand = asgart_amd.Strand("t", text, [prep.Start("c", 0, 320)])
+    # left arm [90 ..= 190] holds 21 N over length 100 -> 0.21 > 0.2 : dropped
+    # left arm [91 ..= 196] holds 21 N over length 105 -> exactly 0.2 in f32 : kept (<=)
+    fams = [[asgart_amd.ProtoSD(90, 200, 100, 100)], [asgart_amd.ProtoSD(91, 200, 105, 100)]]
+    out = postprocess.FilterNs().run(fams, strand)
+    assert [[sd.as_tuple() for sd in f] for f in out] == [[(91, 200, 105, 100)]]
+    offs = np.array([0, 1, 2], dtype=np.uint64)
+    sds = np.array([[90, 200, 100, 100], [91, 200, 105, 100]], dtype=np.uint64)
+    eo, es = oracle.postprocess(text, offs, sds)
+    assert oracle.families_to_list(eo, es) == [[(91, 200, 105, 100)]]
+
+
+def test_reorder_keeps_lengths_and_merge_quirk():
+    sd = asgart_amd.ProtoSD(500, 100, 30, 40)
+    postprocess.ReOrder().run([[sd]], None)
+    assert sd.as_tuple() == (100, 500, 30, 40)
+    x = asgart_amd.ProtoSD(10, 1000, 50, 70)
+    y = asgart_amd.ProtoSD(40, 1030, 60, 80)
+    z = postprocess._merge(x, y)        # x uses left_length (50), y right_length (80) on both arms
+    assert z.as_tuple() == (10, 1000, max(10 + 50, 40 + 80) - 10, max(1000 + 50, 1030 + 80) - 1000)
+
+
+def test_run_result_json_surface(tmp_path):
+    pr, oidx = _case(35)
+    settings = asgart_amd.RunSettings.from_cli(min_length=300, reverse=True, complement=True)
+    offs, sds = oidx.run_raw(pr.chunks, oracle.make_settings(min_length=300, reverse=True, complement=True))
+    strand = asgart_amd.Strand("a.fa, b.fa", pr.data, pr.map)
+    fams = postprocess.post_process(_to_families(offs, sds, True, True), strand)
+    res = postprocess.run_result(fams, strand, settings)
+    txt = postprocess.to_json(res)
+    back = json.loads(txt)
+    assert list(back.keys()) == ["strand", "settings", "families"]
+    assert list(back["settings"].keys()) == ["probe_size", "max_gap_size", "min_duplication_length",
+                                             "max_cardinality", "trim", "skip_masked"]
+    sd0 = back["families"][0][0]
+    assert list(sd0.keys()) == ["chr_left", "chr_right", "global_left_position", "global_right_position",
+                                "chr_left_position", "chr_right_position", "left_length", "right_length",
+                                "left_seq", "right_seq", "identity", "reversed", "complemented"]
+    assert sd0["identity"] == 0.0 and '"identity": 0.0' in txt and '"trim": null' in txt
+    assert sd0["reversed"] is True and sd0["left_seq"] is None
+    for fam in back["families"]:
+        for sd in fam:
+            c = next(m for m in back["strand"]["map"] if m["name"] == sd["chr_left"])
+            assert sd["chr_left_position"] == sd["global_left_position"] - c["position"]
+    assert back["strand"]["length"] == len(pr.data) - 1
+    assert postprocess.out_filename(["/x/a.fa", "b.fasta"], settings) == "a-b_RC.json"
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_chain_random_families(seed):
+    """Arbitrary (not search-produced) families: every branch of _reduce, swapped arms, N-rich arms."""
+    rng = np.random.default_rng(900 + seed)
+    n = 20_000
+    text = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=n + 1)
+    for _ in range(12):
+        s = int(rng.integers(0, n - 600)); text[s:s + int(rng.integers(20, 500))] = ord("N")
+    text[n] = ord("$")
+    offs, rows = [0], []
+    for _ in range(40):
+        base_l, base_r = int(rng.integers(0, n - 3000)), int(rng.integers(0, n - 3000))
+        for _ in range(int(rng.integers(1, 9))):
+            l = base_l + int(rng.integers(0, 1200)); r = base_r + int(rng.integers(0, 1200))
+            rows.append((l, r, int(rng.integers(50, 900)), int(rng.integers(50, 900))))
+        offs.append(len(rows))
+    offs = np.array(offs, dtype=np.uint64); sds = np.array(rows, dtype=np.uint64)
+    eo, es = oracle.postprocess(text, offs, sds)
+    strand = asgart_amd.Strand("r", text, [prep.Start("c", 0, n)])
+    fams = postprocess.post_process(_to_families(offs, sds), strand)
+    assert [[sd.as_tuple() for sd in f] for f in fams] == oracle.families_to_list(eo, es)
+    assert len(es) < len(sds)
