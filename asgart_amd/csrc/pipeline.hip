@@ -23,12 +23,40 @@ namespace asgart {
         fprintf(stderr, "    longest slots:");                                                  \
         for (int pf_i = 0; pf_i < 12; ++pf_i) fprintf(stderr, " [%d]=%llu", pf_i, h_ctr[56 + pf_i]); \
         fprintf(stderr, "\n");                                                                 \
+        fprintf(stderr, "    segments by peak arms (log2 bins):");                             \
+        for (int pf_i = 0; pf_i < 16; ++pf_i) fprintf(stderr, " %llu", h_ctr[CT_HIST_PEAK + pf_i]); \
+        fprintf(stderr, "\n    probes by segment length (log2 bins):");                        \
+        for (int pf_i = 0; pf_i < 16; ++pf_i) fprintf(stderr, " %llu", h_ctr[CT_HIST_PROBES + pf_i]); \
+        fprintf(stderr, "\n");                                                                 \
         (void)hipMemsetAsync(d_ctr + 16, 0, 18 * 8, s);                                        \
+        (void)hipMemsetAsync(d_ctr + 56, 0, (CT_COUNT - 56) * 8, s);                           \
+    } while (0)
+// one tier at a time, with its own dump (the diagnostic build gives up the overlap)
+#define PROF_TIER(tag, stream, n)                                                               \
+    do {                                                                                       \
+        const auto pf_c0 = std::chrono::steady_clock::now();                                   \
+        (void)hipStreamSynchronize(stream);                                                    \
+        const double pf_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - pf_c0).count(); \
+        (void)hipMemcpy(h_ctr, d_ctr, sizeof(h_ctr), hipMemcpyDeviceToHost);                   \
+        fprintf(stderr, "[tier %s] segments=%llu  %.2f ms\n", tag, (unsigned long long)(n), pf_ms); \
+        PROF_DUMP(tag);                                                                        \
+        (void)hipStreamSynchronize(s);                                                         \
     } while (0)
 #else
 #define PROF_DUMP(tag)
+#define PROF_TIER(tag, stream, n)
 #endif
 
+// default launch order / grid sizes of the extension tiers (see the launch site)
+constexpr const char *kTierOrder = "12345";
+constexpr uint64_t kGrid1 = 256ull * 8ull, kGrid2 = 256ull * 3ull, kGrid3 = 256ull, kGrid4 = 256ull, kGrid5 = 256ull;
+// arms per thread of the arm-resident kernel: 9 x 512 = 4608 live arms (6 x 512 with 64-bit positions)
+template <class SlotT> constexpr int kArmsLayers = sizeof(SlotT) == 4 ? 9 : 6;
+constexpr uint64_t kGrid4Arms = 512ull;
+// its one-wave shape: 8 x 64 = 512 live arms per wave, probes with up to 512 hits
+template <class SlotT> constexpr int kWaveArmsLayers = sizeof(SlotT) == 4 ? 8 : 5;
+constexpr int kWaveArmsHits = 512;
+constexpr uint64_t kGrid2Arms = 256ull * 8ull;
 constexpr int kArmCapSmall = 256;   // live arms per wave in LDS, common case
 constexpr uint32_t kTier1MaxSum = 20000;  // placement: busier segments never run on a single wave
 constexpr int kArmCapMid = 768;     // second tier: block-cooperative kernel, 256 threads per segment
@@ -256,6 +284,18 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
         // whose bound exceeds its capacity by up to 40 % (a real overflow falls through the cascade)
         pp.cap4 = (sizeof(SlotT) == 4 ? kArmCapHybrid32 : kArmCapHybrid64) * 7 / 5;
         if (rp.G >= 0xFFF0u || rp.C >= 0xFFF0u) pp.cap4 = pp.cap3;  // 16-bit gap/pend would not do
+        // Arm-resident kernel (K4c) in place of the three block tiers whenever a probe's hits fit
+        // its staging area; ASGART_ARMS_KERNEL=0 keeps the LDS-array tiers (tests run both).
+        const bool arms_kernel = rp.C <= (uint64_t)kHitBatch &&
+                                 !(getenv("ASGART_ARMS_KERNEL") && atoi(getenv("ASGART_ARMS_KERNEL")) == 0);
+        // ... and its one-wave shape as tier 2 (several segments per CU) when a probe's hits fit
+        // that shape's smaller staging area.  Tier 3 is empty then.
+        const bool arms_wave = arms_kernel && rp.C <= (uint64_t)kWaveArmsHits;
+        if (arms_kernel) {
+            pp.cap4 = (uint32_t)kArmsLayers<SlotT> * kHeavyThreads * 7 / 5;
+            pp.cap2 = pp.cap3 = arms_wave ? (uint32_t)kWaveArmsLayers<SlotT> * 64u : 0u;
+            if (const char *e = getenv("ASGART_CAP1")) pp.cap1 = (uint32_t)std::max(1, std::min(atoi(e), kArmCapSmall));
+        }
         pp.sum1 = kTier1MaxSum;
         pp.force_tier = force_tier;
         // an unextended arm has len(right) = k: it may only be dropped when that is never reported
@@ -315,6 +355,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             // ASGART_TEST_CAP_LIMIT (tests): shrink the tiers' capacity to exercise the cascade
             ep.cap_limit = getenv("ASGART_TEST_CAP_LIMIT") ? (uint32_t)atoi(getenv("ASGART_TEST_CAP_LIMIT")) : 0xFFFFFFFFu;
             ep.escalate_cost = 0xFFFFFFFFu;
+            ep.n_levels = getenv("ASGART_TEST_LEVELS") ? (uint32_t)atoi(getenv("ASGART_TEST_LEVELS")) : 4u;
             ep.ctr = d_ctr;
             // The tiers are launched together on separate streams, each with a grid that can fill
             // the chip on its own (persistent workgroups, longest segment first): the hardware
@@ -325,54 +366,63 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             HIP_TRY(hipStreamWaitEvent(st2, cx.ev[7], 0));
             HIP_TRY(hipStreamWaitEvent(st3, cx.ev[7], 0));
             HIP_TRY(hipStreamWaitEvent(st4, cx.ev[7], 0));
-            if (n_t[0]) {
-                ep.seg_list = order;
-                ep.n_seg_ptr = d_ctr + CT_N1;
-                ep.cursor = d_ctr + CT_CUR1;
-                ep.ovf_list = ovf[0];
-                ep.ovf_count = d_ctr + CT_OVF1;
-                const unsigned g1 = (unsigned)std::min<uint64_t>(n_t[0], 256ull * 8ull);
-                extend_kernel<SlotT, kArmCapSmall><<<g1, 64, 0, s>>>(ep);
-            }
-            if (n_t[1]) {
-                ep.seg_list = order + n_t[0];
-                ep.n_seg_ptr = d_ctr + CT_N2;
-                ep.cursor = d_ctr + CT_CUR2;
-                ep.ovf_list = ovf[1];
-                ep.ovf_count = d_ctr + CT_OVF2;
-                const unsigned g2 = (unsigned)std::min<uint64_t>(n_t[1], 256ull * 3ull);
-                extend_heavy_kernel<SlotT, kArmCapMid, kMidThreads, 0><<<g2, kMidThreads, 0, st2>>>(ep);
-            }
-            if (n_t[2]) {
-                ep.seg_list = order + n_t[0] + n_t[1];
-                ep.n_seg_ptr = d_ctr + CT_N3;
-                ep.cursor = d_ctr + CT_CUR3;
-                ep.ovf_list = ovf[2];
-                ep.ovf_count = d_ctr + CT_OVF3;
-                const unsigned g3 = (unsigned)std::min<uint64_t>(n_t[2], 256ull);
-                if constexpr (sizeof(SlotT) == 4)
-                    extend_heavy_kernel<SlotT, kArmCapBig32, kHeavyThreads, 0><<<g3, kHeavyThreads, 0, st3>>>(ep);
-                else
-                    extend_heavy_kernel<SlotT, kArmCapBig64, kHeavyThreads, 0><<<g3, kHeavyThreads, 0, st3>>>(ep);
-            }
-            if (n_t[3]) {
-                ep.seg_list = order + n_t[0] + n_t[1] + n_t[2];
-                ep.n_seg_ptr = d_ctr + CT_N4;
-                ep.cursor = d_ctr + CT_CUR4;
-                ep.ovf_list = ovf[3];
-                ep.ovf_count = d_ctr + CT_OVF4;
-                const unsigned g4 = (unsigned)std::min<uint64_t>(n_t[3], 256ull);
-                extend_heavy_kernel<SlotT, caph, kHeavyThreads, 1><<<g4, kHeavyThreads, 0, st4>>>(ep);
-            }
-            if (n_t[4]) {
-                ep.seg_list = order + n_t[0] + n_t[1] + n_t[2] + n_t[3];
-                ep.n_seg_ptr = d_ctr + CT_N5;
-                ep.cursor = d_ctr + CT_CUR5;
-                ep.ovf_list = nullptr;
-                ep.ovf_count = d_ctr + CT_OVF5;
-                const unsigned g5 = (unsigned)std::min<uint64_t>(n_t[4], 256ull);
-                extend_heavy_kernel<SlotT, capg, kHeavyThreads, 2><<<g5, kHeavyThreads, 0, st4>>>(ep);
-            }
+            // Launch order and grid sizes: workgroups are persistent and hold their LDS until the
+            // tier's work list is exhausted, so whatever is dispatched first owns the CUs.  The
+            // critical path of a pass is the longest tandem-array segment of the heavy tiers
+            // (tens of thousands of probes, strictly serial): those tiers go first, the one-wave
+            // tier last, and the heavy grids are sized so that every tier's longest segments
+            // start at once instead of queueing behind another tier's bulk.
+            const char *order_env = getenv("ASGART_TIER_ORDER");
+            const std::string tier_order = order_env ? order_env : kTierOrder;
+            auto grid_of = [&](int tier, uint64_t dflt) -> unsigned {
+                char name[32];
+                snprintf(name, sizeof name, "ASGART_GRID%d", tier);
+                const char *e = getenv(name);
+                const uint64_t gmax = e ? (uint64_t)std::max(1, atoi(e)) : dflt;
+                return (unsigned)std::min<uint64_t>(n_t[tier - 1], gmax);
+            };
+            uint64_t seg_off[6] = {0, 0, 0, 0, 0, 0};
+            for (int t = 1; t <= 5; ++t) seg_off[t] = seg_off[t - 1] + n_t[t - 1];
+            auto launch_tier = [&](int tier) {
+                if (tier < 1 || tier > 5 || !n_t[tier - 1]) return;
+                ep.seg_list = order + seg_off[tier - 1];
+                ep.n_seg_ptr = d_ctr + CT_N1 + (tier - 1);
+                ep.cursor = d_ctr + CT_CUR1 + (tier - 1);
+                ep.ovf_list = tier < 5 ? ovf[tier - 1] : nullptr;
+                ep.ovf_count = d_ctr + CT_OVF1 + (tier - 1);
+                switch (tier) {
+                case 1:
+                    extend_kernel<SlotT, kArmCapSmall><<<grid_of(1, kGrid1), 64, 0, s>>>(ep);
+                    PROF_TIER("1", s, n_t[0]);
+                    break;
+                case 2:
+                    if (arms_wave)
+                        extend_arms_kernel<SlotT, kWaveArmsLayers<SlotT>, 64, kWaveArmsHits, 512, 3><<<grid_of(2, kGrid2Arms), 64, 0, st2>>>(ep);
+                    else
+                        extend_heavy_kernel<SlotT, kArmCapMid, kMidThreads, 0><<<grid_of(2, kGrid2), kMidThreads, 0, st2>>>(ep);
+                    PROF_TIER("2", st2, n_t[1]);
+                    break;
+                case 3:
+                    if constexpr (sizeof(SlotT) == 4)
+                        extend_heavy_kernel<SlotT, kArmCapBig32, kHeavyThreads, 0><<<grid_of(3, kGrid3), kHeavyThreads, 0, st3>>>(ep);
+                    else
+                        extend_heavy_kernel<SlotT, kArmCapBig64, kHeavyThreads, 0><<<grid_of(3, kGrid3), kHeavyThreads, 0, st3>>>(ep);
+                    PROF_TIER("3", st3, n_t[2]);
+                    break;
+                case 4:
+                    if (arms_kernel)
+                        extend_arms_kernel<SlotT, kArmsLayers<SlotT>, kHeavyThreads, kHitBatch, 1024, 4><<<grid_of(4, kGrid4Arms), kHeavyThreads, 0, st4>>>(ep);
+                    else
+                        extend_heavy_kernel<SlotT, caph, kHeavyThreads, 1><<<grid_of(4, kGrid4), kHeavyThreads, 0, st4>>>(ep);
+                    PROF_TIER("4", st4, n_t[3]);
+                    break;
+                default:
+                    extend_heavy_kernel<SlotT, capg, kHeavyThreads, 2><<<grid_of(5, kGrid5), kHeavyThreads, 0, st4>>>(ep);
+                    PROF_TIER("5", st4, n_t[4]);
+                    break;
+                }
+            };
+            for (char c : tier_order) launch_tier(c - '0');
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(cx.ev[5], st2));
             HIP_TRY(hipEventRecord(cx.ev[6], st3));
@@ -406,14 +456,20 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                 const unsigned bw = (unsigned)std::min<uint64_t>(n_ovf, 256ull);
                 if (tier == 2) {
                     const unsigned mw = (unsigned)std::min<uint64_t>(n_ovf, 256ull * 3ull);
-                    extend_heavy_kernel<SlotT, kArmCapMid, kMidThreads, 0><<<mw, kMidThreads, 0, s>>>(ep);
+                    if (arms_wave)
+                        extend_arms_kernel<SlotT, kWaveArmsLayers<SlotT>, 64, kWaveArmsHits, 512, 3><<<(unsigned)std::min<uint64_t>(n_ovf, kGrid2Arms), 64, 0, s>>>(ep);
+                    else
+                        extend_heavy_kernel<SlotT, kArmCapMid, kMidThreads, 0><<<mw, kMidThreads, 0, s>>>(ep);
                 } else if (tier == 3) {
                     if constexpr (sizeof(SlotT) == 4)
                         extend_heavy_kernel<SlotT, kArmCapBig32, kHeavyThreads, 0><<<bw, kHeavyThreads, 0, s>>>(ep);
                     else
                         extend_heavy_kernel<SlotT, kArmCapBig64, kHeavyThreads, 0><<<bw, kHeavyThreads, 0, s>>>(ep);
                 } else if (tier == 4) {
-                    extend_heavy_kernel<SlotT, caph, kHeavyThreads, 1><<<bw, kHeavyThreads, 0, s>>>(ep);
+                    if (arms_kernel)
+                        extend_arms_kernel<SlotT, kArmsLayers<SlotT>, kHeavyThreads, kHitBatch, 1024, 4><<<bw, kHeavyThreads, 0, s>>>(ep);
+                    else
+                        extend_heavy_kernel<SlotT, caph, kHeavyThreads, 1><<<bw, kHeavyThreads, 0, s>>>(ep);
                 } else {
                     extend_heavy_kernel<SlotT, capg, kHeavyThreads, 2><<<bw, kHeavyThreads, 0, s>>>(ep);
                 }

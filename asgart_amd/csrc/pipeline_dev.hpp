@@ -43,7 +43,9 @@ enum Counter {
     CT_N1 = 34, CT_N2, CT_N3, CT_N4, CT_N5, CT_NF,           // list lengths: tiers 1-5, fallback launch
     CT_CUR1, CT_CUR2, CT_CUR3, CT_CUR4, CT_CUR5, CT_CURF,   // their work cursors
     CT_OVF1, CT_OVF2, CT_OVF3, CT_OVF4, CT_OVF5,            // segments handed on to tier 2..5 / nobody
-    CT_COUNT = 72
+    CT_HIST_PEAK = 72,   // diagnostic build: log2 histograms per launch (16 bins each)
+    CT_HIST_PROBES = 88,
+    CT_COUNT = 104
 };
 
 __device__ inline int chunk_of(const ChunkTable &ch, uint32_t g) {
@@ -521,6 +523,14 @@ constexpr uint32_t kTombstone = 0xFFFFFFFFu;
         if (lane == 0)                                                           \
             for (int pf_i = 0; pf_i < 12; ++pf_i)                                \
                 if (pf_acc[pf_i]) atomicAdd(&P.ctr[16 + pf_i], pf_acc[pf_i]);     \
+        if (lane == 0) {                                                         \
+            int pf_b = 0;                                                        \
+            while (pf_b < 15 && (2ull << pf_b) <= pf_acc[9]) ++pf_b;             \
+            atomicAdd(&P.ctr[CT_HIST_PEAK + pf_b], 1ull);                        \
+            pf_b = 0;                                                            \
+            while (pf_b < 15 && (2ull << pf_b) <= pf_acc[5] + pf_acc[3]) ++pf_b; \
+            atomicAdd(&P.ctr[CT_HIST_PROBES + pf_b], pf_acc[5] + pf_acc[3]);     \
+        }                                                                        \
         for (int pf_i = 0; pf_i < 12; ++pf_i) pf_acc[pf_i] = 0;                  \
     } while (0)
 #else
@@ -551,6 +561,7 @@ struct ExtParams {
     uint32_t *ovf_list;                   // segments this launch gives up on go here (may be null)
     unsigned long long *ovf_count;        // ... appended at *ovf_count (device counter)
     char *scratch;                        // heavy global tier: per-workgroup arm storage
+    uint32_t n_levels;                    // K4c: usable hit-table levels (tests shrink it)
     uint32_t escalate_cost;               // one-wave tiers: give up after this much LDS-path work
     uint32_t cap_limit;                   // effective live-arm capacity (<= CAP; tests lower it)
     unsigned long long *ctr;
@@ -831,6 +842,7 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
                     // ---------------- register path -------------------------------
                     PROF_START();
                     PROF_COUNT(3, 1);
+                    PROF_MAX(9, A + nfl);
                     bool pend = false;
                     PosT pend_x = 0;
                     uint32_t newc = 0;
@@ -888,6 +900,7 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
                     PROF_COUNT(5, 1);
                     PROF_COUNT(10, A_old);
                     PROF_COUNT(11, cnt);
+                    PROF_MAX(9, A_old + nfl);
                     PROF_START();
                     // An arm accepts hit x iff  re - k < x < re + thr  (d_ss of src/automaton.rs:207-216
                     // with m = [x, x+k) and len(right) >= k).  So instead of testing every arm
@@ -1811,6 +1824,383 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
             const unsigned long long at = atomicAdd(P.ovf_count, 1ull);
             if (P.ovf_list) P.ovf_list[at] = g0;
         }
+        if (tid < 64) {
+            PROF_FLUSH();
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------- K4c --------
+// Arm-resident extension kernel: ONE workgroup per segment, every live arm OWNED by a thread and
+// kept in that thread's registers (S arms per thread, slot = layer * NT + thread).  The roles of
+// K4b are reversed: per probe the HITS are indexed (a few hundred at most), and every arm looks
+// up the hits inside its own accept window.  Nothing about an arm ever lives in LDS, the
+// per-probe passes over arm arrays (index build, apply, age) become register work of the owner,
+// and a probe costs three workgroup barriers:
+//   P0  hit h -> four hash tables keyed by x >> (bsh + 2*level); generation-tagged heads, so the
+//       tables are never cleared                                                    | barrier
+//   P1  each arm walks the buckets covering its window [re-k+1, re+thr-1] at the level whose
+//       bucket is at least a quarter of the window; accepted hits take
+//       atomicMin(best[h], creation number << 20 | slot): first arm in list order
+//       (src/automaton.rs:67-78)                                                    | barrier
+//   P2  each hit posts h+1 to its winner's mailbox (atomicMax: last hit in SA order wins) or,
+//       unmatched and flagged, to a free slot in hit order (= creation order)       | barrier
+//   P3  each owner reads its mailboxes: extend / age / retire (emit if len(right) >= M) / create.
+// Results are identical to K4 and K4b; tested by forcing every multi-hit segment through it.
+// Two shapes: NT = 64 (one wave per segment, several segments per CU: the bulk of the dense
+// segments) and NT = 512 (one workgroup per segment: the few segments with thousands of arms).
+template <class PosT, int S, int NT, int HB, int kHT, int kLevels>
+__global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
+    constexpr int CAP = S * NT;
+    constexpr int NW = NT / 64;
+    constexpr uint32_t kGenBits = 22, kNoHit = 0xFFFFu;
+    static_assert(HB <= 1024 && HB <= kHitBatch, "hit index is packed into 10 bits");
+    __shared__ PosT s_hits[HB];
+    __shared__ uint8_t s_hflag[HB];
+    __shared__ uint32_t s_head[kLevels][kHT];        // (generation << 10) | hit, newest first
+    __shared__ uint16_t s_next[kLevels][HB];         // chain through the hits of one bucket
+    __shared__ unsigned long long s_best[HB];        // per hit: (creation number << 20) | slot
+    __shared__ uint16_t s_rank[HB];                  // per new hit: rank among the new arms
+    __shared__ uint32_t s_msg[CAP];                  // per slot: 1 + index of the hit for it
+    __shared__ uint16_t s_free[CAP];                 // stack of empty slots below H
+    __shared__ uint32_t s_nfreed[2];
+    __shared__ unsigned long long s_bcast;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const RunParams &rp = P.rp;
+    const uint64_t n_seg = *P.n_seg_ptr;
+    const uint32_t k = (uint32_t)rp.k, step = (uint32_t)rp.step, G = rp.G;
+    const uint32_t thr0 = arm_threshold(k, G);
+    uint32_t bsh = 3;  // level-0 bucket: 2^bsh >= G + k, a narrow arm's window meets <= 2 of them
+    while ((1ull << bsh) < (unsigned long long)G + k) ++bsh;
+    const uint32_t cap_eff = min((uint32_t)CAP, P.cap_limit);
+    const uint32_t n_lv = min((uint32_t)kLevels, P.n_levels);
+    PROF_DECL;
+
+    // arm state, one arm per (thread, layer)
+    PosT a_ls[S], a_le[S], a_rs[S], a_re[S];
+    uint32_t a_thr[S], a_gap[S], a_seq[S];
+#pragma unroll
+    for (int L = 0; L < S; ++L) {
+        a_seq[L] = kNoSeq;
+        a_ls[L] = a_le[L] = a_rs[L] = a_re[L] = 0;
+        a_thr[L] = a_gap[L] = 0;
+    }
+    for (uint32_t h = tid; h < (uint32_t)(kLevels * kHT); h += NT) (&s_head[0][0])[h] = 0u;
+    for (uint32_t j = tid; j < (uint32_t)CAP; j += NT) s_msg[j] = 0u;
+    if (tid < 2) s_nfreed[tid] = 0u;
+    // Freed-slot counters: two, used by alternate owner passes and never reset (a pass reads its
+    // counter after its barrier; the next pass already adds to the other one).
+    uint32_t gen = 0, par = 0, freed_seen0 = 0, freed_seen1 = 0;
+    __syncthreads();
+
+    for (;;) {
+        if (tid == 0) s_bcast = atomicAdd(P.cursor, 1ull);
+        __syncthreads();
+        const unsigned long long seg = s_bcast;
+        __syncthreads();
+        if (seg >= n_seg) break;
+        const uint32_t g0 = P.seg_list[seg];
+        PROF_SEG_BEGIN();
+        const int c = chunk_of_uniform(rp.ch, g0);
+        const uint64_t cs = rp.ch.start[c], cl = rp.ch.len[c];
+        const uint32_t pb = rp.ch.pbase[c];
+        const uint32_t chunk_end = rp.ch.pbase[c + 1];
+        const uint32_t g_end = min(chunk_end, rp.g_hi);
+        // block-uniform: A live arms in slots [0,H), n_free empty ones on s_free
+        uint32_t A = 0, H = 0, n_free = 0, quiet = 0, fam_seq = 0, next_seq = 0;
+        uint32_t t_proc = 0, spur_until = 0;
+        bool overflow = false, done = false, fam_open = false;
+
+        auto emit_records = [&](bool emit, PosT ls, PosT le, PosT rs, PosT re, uint32_t seq) {
+            const unsigned long long em = __ballot(emit);
+            if (!em) return;
+            const int leader = __ffsll((long long)em) - 1;
+            unsigned long long base = 0;
+            if (lane == leader) base = atomicAdd(&P.ctr[CT_SD], (unsigned long long)__popcll(em));
+            base = __shfl(base, leader);
+            if (emit) {
+                const unsigned long long at = base + __popcll(em & lt_mask);
+                if (at < P.rec_cap) {
+                    const uint64_t ll = (uint64_t)le - (uint64_t)ls;
+                    SdRec r;
+                    r.g_start = g0;
+                    r.fam_seq = fam_seq;
+                    r.create_seq = seq;
+                    r.pad = 0;
+                    r.sd.left = rp.reverse ? cs + cl - (uint64_t)ls - ll : (uint64_t)ls + cs;
+                    r.sd.right = rs;
+                    r.sd.left_length = ll;
+                    r.sd.right_length = (uint64_t)re - (uint64_t)rs;
+                    P.recs[at] = r;
+                }
+            }
+        };
+        // owner pass: mailboxes (with_msg) / ageing by `add` / retirement / creation.
+        // i, off: the probe whose hits are referenced by the mailboxes; seq_base: creation number
+        // of its first new arm.  Block-uniform on exit: A, n_free, H.
+        auto owner_pass = [&](uint32_t add, bool with_msg, uint64_t i, uint32_t off, uint32_t seq_base) {
+            const uint32_t n_layers = (H + NT - 1u) / NT;
+            const uint32_t freed_base = par ? freed_seen1 : freed_seen0;
+#pragma unroll
+            for (int L = 0; L < S; ++L) {
+                if ((uint32_t)L < n_layers) {  // block-uniform
+                    const uint32_t slot = (uint32_t)L * NT + tid;
+                    uint32_t m = 0;
+                    if (with_msg && slot < H) {
+                        m = s_msg[slot];
+                        if (m) s_msg[slot] = 0u;
+                    }
+                    bool dead = false;
+                    PosT ls = 0, le = 0, rs = 0, re = 0;
+                    uint32_t sq = a_seq[L];
+                    if (sq != kNoSeq) {
+                        if (m) {  // ExtendArm, src/automaton.rs:133-150
+                            const PosT x = s_hits[off + m - 1u];
+                            a_re[L] = (PosT)(x + k);
+                            a_le[L] = (PosT)(i + k);
+                            a_thr[L] = arm_threshold((uint64_t)(i + k) - (uint64_t)a_ls[L], G);
+                            a_gap[L] = 0;
+                        } else {
+                            const uint64_t sum_g = (uint64_t)a_gap[L] + add;
+                            const uint32_t ng = sum_g > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)sum_g;
+                            a_gap[L] = ng;
+                            if (ng >= G) {  // src/automaton.rs:166-171: never matches again
+                                dead = true;
+                                ls = a_ls[L]; le = a_le[L]; rs = a_rs[L]; re = a_re[L];
+                                a_seq[L] = kNoSeq;
+                                s_free[n_free + (atomicAdd(&s_nfreed[par], 1u) - freed_base)] = (uint16_t)slot;
+                            }
+                        }
+                    } else if (m) {  // NewArm, src/automaton.rs:151-164 (aged by this very probe)
+                        const PosT x = s_hits[off + m - 1u];
+                        a_ls[L] = (PosT)i; a_le[L] = (PosT)(i + k); a_rs[L] = x; a_re[L] = (PosT)(x + k);
+                        a_gap[L] = step;
+                        a_thr[L] = thr0;
+                        a_seq[L] = seq_base + s_rank[m - 1u];
+                    }
+                    emit_records(dead && (uint64_t)(re - rs) >= rp.M, ls, le, rs, re, sq);
+                }
+            }
+            __syncthreads();
+            const uint32_t freed_now = s_nfreed[par];
+            const uint32_t nd = freed_now - freed_base;
+            if (par) freed_seen1 = freed_now; else freed_seen0 = freed_now;
+            par ^= 1u;
+            A -= nd;
+            n_free += nd;
+            if (A == 0) {  // every slot is empty again
+                H = 0;
+                n_free = 0;
+            }
+        };
+        auto maybe_close = [&]() {  // the flush of src/automaton.rs:182-200
+            if (fam_open && A == 0 && t_proc >= spur_until) {
+                ++fam_seq;
+                next_seq = 0;
+                fam_open = false;
+            }
+        };
+        auto advance_quiet = [&](uint32_t q) {
+            quiet += q;
+            t_proc += q;
+            if (A > 0) owner_pass(q * step, false, 0, 0, 0);
+            maybe_close();
+            if (A == 0 && quiet >= rp.tstar) done = true;
+        };
+
+        for (uint32_t g = g0; g < g_end && !done;) {
+            // ---- stage a batch of up to 64 probes (every wave computes the same masks) ----
+            PROF_START();
+            const uint32_t nb = min(64u, g_end - g);
+            const uint32_t f_l = (uint32_t)lane < nb ? P.p_filt[g + lane] : kSkipN;
+            const uint32_t nfl_l = (uint32_t)lane < nb ? P.p_nflag[g + lane] : 0u;
+            const unsigned long long r_l = (uint32_t)lane < nb ? P.row_off[g + lane] : 0ull;
+            const unsigned long long r_hi = P.row_off[g + nb];
+            const unsigned long long base = __shfl(r_l, 0);
+            unsigned long long r_next = __shfl_down(r_l, 1);
+            if ((uint32_t)lane + 1 >= nb) r_next = r_hi;
+            const bool fits = (uint32_t)lane < nb && r_next - base <= (unsigned long long)HB;
+            const unsigned long long fm = __ballot(fits);
+            uint32_t nbb = (~fm == 0ull) ? 64u : (uint32_t)(__ffsll((long long)~fm) - 1);
+            if (nbb > nb) nbb = nb;
+            if (nbb == 0) {  // one probe with more hits than the staging area: not for this kernel
+                overflow = true;
+                break;
+            }
+            const uint32_t rel_l = (uint32_t)(r_l - base);
+            {
+                const unsigned long long end = nbb == nb ? r_hi : __shfl(r_l, (int)nbb);
+                const uint32_t tot = (uint32_t)(end - base);
+                for (uint32_t r = tid; r < tot; r += NT) {
+                    s_hits[r] = P.hits[base + r];
+                    s_hflag[r] = P.hit_flag[base + r];
+                }
+            }
+            __syncthreads();
+            const unsigned long long in_batch = nbb >= 64 ? ~0ull : ((1ull << nbb) - 1ull);
+            const unsigned long long hm = __ballot(f_l >= 1u && f_l < kPending) & in_batch;
+            const unsigned long long qm = __ballot(f_l == 0u) & in_batch;
+            PROF_STOP(0);
+            PROF_COUNT(1, 1);
+            uint32_t pos = 0;
+            while (!done) {
+                const unsigned long long hmr = pos >= 64 ? 0ull : (hm >> pos) << pos;
+                if (!hmr) break;
+                const uint32_t b = (uint32_t)(__ffsll((long long)hmr) - 1);
+                {
+                    const unsigned long long range = ((1ull << b) - 1ull) & ~((1ull << pos) - 1ull);
+                    const uint32_t q = (uint32_t)__popcll(qm & range);
+                    if (q) {
+                        advance_quiet(q);
+                        if (done) break;
+                    }
+                }
+                quiet = 0;
+                pos = b + 1;
+                const uint32_t cnt = __shfl(f_l, (int)b);
+                const uint32_t nfl = __shfl(nfl_l, (int)b);
+                const uint32_t off = __shfl(rel_l, (int)b);
+                const uint64_t i = (uint64_t)(g + b - pb + 1) * step;
+                ++t_proc;
+                if (A + nfl > cap_eff) {
+                    overflow = true;
+                    done = true;
+                    break;
+                }
+                PROF_COUNT(5, 1);
+                PROF_COUNT(10, A);
+                PROF_COUNT(11, cnt);
+                PROF_MAX(9, A + nfl);
+                PROF_START();
+                // ---- P0: index the hits of this probe ----------------------------------------
+                if (++gen >> kGenBits) {  // generation wrap: clear the tables once
+                    __syncthreads();
+                    for (uint32_t h = tid; h < (uint32_t)(kLevels * kHT); h += NT) (&s_head[0][0])[h] = 0u;
+                    gen = 1;
+                    __syncthreads();
+                }
+                for (uint32_t h = tid; h < cnt; h += NT) {
+                    const PosT x = s_hits[off + h];
+                    s_best[h] = ~0ull;
+#pragma unroll
+                    for (uint32_t lv = 0; lv < (uint32_t)kLevels; ++lv) {
+                        const uint32_t bkt = (uint32_t)((uint64_t)x >> (bsh + 2u * lv));
+                        const uint32_t old = atomicExch(&s_head[lv][((bkt * 2654435761u) >> 12) & ((uint32_t)kHT - 1u)],
+                                                        (gen << 10) | h);
+                        s_next[lv][h] = (old >> 10) == gen ? (uint16_t)(old & 1023u) : (uint16_t)kNoHit;
+                    }
+                }
+                __syncthreads();
+                PROF_STOP(2);
+                PROF_START();
+                // ---- P1: every arm looks up the hits inside its window ------------------------
+                {
+                    const uint32_t n_layers = (H + NT - 1u) / NT;
+#pragma unroll
+                    for (int L = 0; L < S; ++L) {
+                        if ((uint32_t)L < n_layers && a_seq[L] != kNoSeq) {
+                            const PosT lo = (PosT)(a_re[L] - k + 1u);
+                            const uint64_t w = (uint64_t)a_thr[L] + k - 1u;
+                            const unsigned long long key =
+                                ((unsigned long long)a_seq[L] << 20) | ((uint32_t)L * NT + tid);
+                            uint32_t lv = 0;
+                            while (lv < n_lv && w > (4ull << (bsh + 2u * lv))) ++lv;
+                            if (lv == n_lv) {  // wider than any table: every hit is a candidate
+                                for (uint32_t h = 0; h < cnt; ++h)
+                                    if ((uint64_t)(PosT)(s_hits[off + h] - lo) < w) atomicMin(&s_best[h], key);
+                            } else {
+                                const uint32_t sh = bsh + 2u * lv;
+                                const uint64_t b0 = (uint64_t)lo >> sh, b1 = ((uint64_t)lo + w - 1u) >> sh;
+                                for (uint64_t bk = b0; bk <= b1; ++bk) {
+                                    const uint32_t e = s_head[lv][(((uint32_t)bk * 2654435761u) >> 12) & ((uint32_t)kHT - 1u)];
+                                    if ((e >> 10) != gen) continue;
+                                    uint32_t h = e & 1023u;
+                                    while (h != kNoHit) {
+                                        if ((uint64_t)(PosT)(s_hits[off + h] - lo) < w) atomicMin(&s_best[h], key);
+                                        h = s_next[lv][h];
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+                PROF_STOP(4);
+                PROF_START();
+                // ---- P2: hits notify arms / claim free slots ----------------------------------
+                // rank of each unmatched flagged hit among the new arms, in hit order: every wave
+                // recomputes the per-group counts (no barrier)
+                uint32_t n_new = 0;
+                bool spur = false;
+                for (uint32_t c0 = 0, grp = 0; c0 < cnt; c0 += 64, ++grp) {
+                    const uint32_t h = c0 + lane;
+                    unsigned long long best = 0;
+                    bool un = false, hf = false;
+                    if (h < cnt) {
+                        best = s_best[h];
+                        un = best == ~0ull;
+                        hf = s_hflag[off + h] != 0;
+                    }
+                    const unsigned long long nm = __ballot(un && hf);
+                    spur |= __ballot(un && !hf) != 0ull;
+                    if (grp % NW == (uint32_t)(tid >> 6) && h < cnt) {  // this wave owns the group
+                        if (!un) {
+                            atomicMax(&s_msg[(uint32_t)(best & 0xFFFFFu)], h + 1u);
+                        } else if (hf) {
+                            const uint32_t bf = n_new + (uint32_t)__popcll(nm & lt_mask);
+                            const uint32_t slot = bf < n_free ? (uint32_t)s_free[n_free - 1u - bf] : H + (bf - n_free);
+                            s_msg[slot] = h + 1u;
+                            s_rank[h] = (uint16_t)bf;
+                        }
+                    }
+                    n_new += (uint32_t)__popcll(nm);
+                }
+                if (n_new <= n_free) {
+                    n_free -= n_new;
+                } else {
+                    H += n_new - n_free;
+                    n_free = 0;
+                }
+                A += n_new;
+                const uint32_t seq_base = next_seq;
+                next_seq += n_new;
+                __syncthreads();
+                PROF_STOP(6);
+                PROF_START();
+                // ---- P3: owners apply -----------------------------------------------------------
+                owner_pass(step, true, i, off, seq_base);
+                fam_open = true;
+                if (spur) spur_until = max(spur_until, t_proc + rp.tstar - 1u);
+                maybe_close();
+                PROF_STOP(7);
+            }
+            if (overflow) break;
+            if (!done) {
+                const unsigned long long range = pos >= 64 ? 0ull : ~((1ull << pos) - 1ull);
+                const uint32_t q = (uint32_t)__popcll(qm & range);
+                if (q) advance_quiet(q);
+            }
+            __syncthreads();
+            g += nbb;
+        }
+        if (overflow) done = true;
+        if (!done && g_end < chunk_end) {
+            if (tid == 0) atomicAdd(&P.ctr[CT_RANOUT], 1ull);
+        } else if (!overflow && fam_open) {
+            emit_records(tid == 0, (PosT)0, (PosT)0, (PosT)0, (PosT)0, kTombstone);
+        }
+        if (overflow && tid == 0) {
+            const unsigned long long at = atomicAdd(P.ovf_count, 1ull);
+            if (P.ovf_list) P.ovf_list[at] = g0;
+        }
+        // leave no arm and no message behind for the next segment
+        if (A > 0) {
+#pragma unroll
+            for (int L = 0; L < S; ++L) a_seq[L] = kNoSeq;
+        }
+        // (mailboxes are empty here: every P2 is followed by its P3)
         if (tid < 64) {
             PROF_FLUSH();
         }

@@ -289,16 +289,24 @@ def test_overflow_cascade_gives_identical_results(hiplib, cap, monkeypatch):
             assert np.array_equal(offs, eoffs) and np.array_equal(sds, esds), (cap, reverse)
 
 
-@pytest.mark.parametrize("tier", [2, 3, 4, 5])
+@pytest.mark.parametrize("tier", [2, 3, 4, 5, "4-lds", "4-arms-filter"])
 @pytest.mark.parametrize("name", ["dense_repeats", "satellites", "long_sds"])
 def test_escalation_tiers_give_identical_results(hiplib, name, tier, monkeypatch):
-    """The one-wave kernel hands heavy segments to larger tiers (bigger LDS share, block-cooperative
-    kernel, HBM-scratch kernel).  Forcing every segment with a multi-hit probe into tier `tier`
-    must not change a single ProtoSD."""
+    """Segments that do not fit the one-wave kernel go to larger tiers (arm-resident workgroup kernel;
+    LDS-array workgroup kernels; HBM-scratch kernel).  Forcing every segment with a multi-hit probe
+    into tier `tier` must not change a single ProtoSD.  Tier 4 is the arm-resident kernel by default,
+    "4-lds" the hybrid LDS-array kernel it replaced (still used when max_cardinality > 1024)."""
     pr, cli = _battery_case(name)
     oidx = oracle.Index.build(pr.data)
+    if tier == "4-lds":
+        monkeypatch.setenv("ASGART_ARMS_KERNEL", "0")
+        tier = 4
+    arms_filter = tier == "4-arms-filter"
+    if arms_filter:
+        tier = 4
+    filt = "1" if tier % 2 else "0"
     monkeypatch.setenv("ASGART_FORCE_TIER", str(tier))
-    monkeypatch.setenv("ASGART_FILTER", "1" if tier % 2 else "0")
+    monkeypatch.setenv("ASGART_FILTER", filt if not arms_filter else "1")
     with asgart_amd.Index(pr.data, oidx.sa) as idx:
         for reverse, complement in ((False, False), (True, True)):
             st = asgart_amd.RunSettings.from_cli(reverse=reverse, complement=complement, **cli)
@@ -307,6 +315,23 @@ def test_escalation_tiers_give_identical_results(hiplib, name, tier, monkeypatch
                 assert idx.stats().heavy_segments > 0 or tier < 3
             eoffs, esds = oidx.run_raw(pr.chunks, oracle.make_settings(reverse=reverse, complement=complement, **cli), threads=4)
             assert np.array_equal(offs, eoffs) and np.array_equal(sds, esds), (name, tier, reverse)
+
+
+@pytest.mark.parametrize("levels", [0, 1, 2])
+def test_arm_kernel_window_levels(hiplib, levels, monkeypatch):
+    """The arm-resident kernel looks hits up in per-probe hash tables at four bucket widths and falls
+    back to a linear scan for windows wider than the coarsest; with fewer usable levels the long arms
+    of `long_sds` take the coarser paths and the scan."""
+    pr, cli = _battery_case("long_sds")
+    oidx = oracle.Index.build(pr.data)
+    monkeypatch.setenv("ASGART_FORCE_TIER", "4")
+    monkeypatch.setenv("ASGART_TEST_LEVELS", str(levels))
+    with asgart_amd.Index(pr.data, oidx.sa) as idx:
+        for rc in (False, True):
+            st = asgart_amd.RunSettings.from_cli(reverse=rc, complement=rc, **cli)
+            offs, sds = idx.search_duplications_raw(pr.chunks, st)
+            eoffs, esds = oidx.run_raw(pr.chunks, oracle.make_settings(reverse=rc, complement=rc, **cli), threads=4)
+            assert np.array_equal(offs, eoffs) and np.array_equal(sds, esds), (levels, rc)
 
 
 def test_cfg2_yeast_sized_direct_and_rc_bit_exact(hiplib):

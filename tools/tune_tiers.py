@@ -1,0 +1,49 @@
+"""Tuning aid: build the GRCh38-shaped index once, then time the search call under a list of
+environment configurations (launch order / grid sizes of the extension tiers are read per call).
+Usage: python tools/tune_tiers.py [cfg] 'A=1 B=2' 'A=3' ...   (one quoted config per argument)"""
+import hashlib
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import asgart_amd  # noqa: E402
+from asgart_amd import prep, synth  # noqa: E402
+
+args = sys.argv[1:]
+cfg, scale = 4, 1.0
+if args and args[0].startswith("cfg"):
+    cfg = int(args[0][3:]); args = args[1:]
+configs = args or [""]
+recs = synth.config_genome(cfg, scale)
+pr = prep.prepare_records(recs)
+idx = asgart_amd.Index(pr.data, None)
+idx.prepare(20)
+settings = [asgart_amd.RunSettings.from_cli(reverse=r, complement=r) for r in (False, True)]
+ref = None
+for conf in configs:
+    kv = dict(x.split("=", 1) for x in conf.split()) if conf.strip() else {}
+    for k_, v in kv.items():
+        os.environ[k_] = v
+    line = []
+    sig = hashlib.sha1()
+    for st in settings:
+        best = None
+        for rep in range(2):
+            t0 = time.perf_counter()
+            offs, sds = idx.search_duplications_raw(pr.chunks, st)
+            dt = (time.perf_counter() - t0) * 1e3
+            s = idx.stats(0)
+            if best is None or dt < best[0]:
+                best = (dt, s.ms_extend, s.ms_search, s.overflow_segments)
+        sig.update(offs.tobytes()); sig.update(sds.tobytes())
+        line.append("call %.1f ms extend %.1f search %.1f ovf %d" % best)
+    ok = ""
+    if ref is None:
+        ref = sig.hexdigest()
+    elif ref != sig.hexdigest():
+        ok = "  RESULT DIFFERS"
+    print(f"[{conf or 'default'}] " + " | ".join(line) + ok, flush=True)
+    for k_ in kv:
+        os.environ.pop(k_, None)
