@@ -584,11 +584,14 @@ __device__ inline bool arm_accepts(PosT x, PosT re, uint32_t thr, uint32_t k) {
     return (uint64_t)(PosT)(x - lo) < w;
 }
 
-// max(e, (0.1 * len as f64) as i64)   (src/automaton.rs:69)
+// max(e, (0.1 * len as f64) as i64)   (src/automaton.rs:69).  The double product truncates to
+// len / 10 for every len < 9e15 (0.1 rounds UP to 0.1000000000000000055, so the product can only
+// cross an integer boundary once len / 10 * 1.1e-16 reaches 0.1; checked for 3M values up to 2^40 in
+// tests/test_oracle_golden.py::test_tenth_threshold_is_integer_division), so the kernels divide.
 __device__ inline uint32_t arm_threshold(uint64_t left_len, uint32_t G) {
-    long long tenth = (long long)(0.1 * (double)left_len);
-    long long thr = tenth > (long long)G ? tenth : (long long)G;
-    return thr > 0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)thr;
+    const uint64_t tenth = left_len <= 0xFFFFFFFFull ? (uint64_t)((uint32_t)left_len / 10u) : left_len / 10u;
+    const uint64_t thr = tenth > (uint64_t)G ? tenth : (uint64_t)G;
+    return thr > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)thr;
 }
 
 template <class PosT, int CAP>
@@ -1064,7 +1067,19 @@ struct PlaceParams {
     uint32_t sum1;              // segments with more hits than this never go to the one-wave tier
     int force_tier;             // tests: minimum tier for segments with a multi-hit probe
     int use_filter;             // 0: flag every hit (k >= M, huge gaps or cardinalities)
+    uint32_t long3;             // > 0: tier 3 is reserved for segments of at least this many probes
 };
+
+// Tier of a segment from its live-arm bound, hit total and processed-probe count.  With long3 set,
+// tier 3 (lowest per-probe latency, one workgroup of 1024 threads per CU) only takes the long
+// segments whose serial chain is the critical path of a pass; everything else goes by capacity.
+__device__ inline int place_tier(uint32_t bound, unsigned long long sum, uint32_t n_probes, const PlaceParams &pp) {
+    if (bound <= pp.cap1 && sum <= pp.sum1) return 1;
+    if (pp.long3 && n_probes >= pp.long3 && bound <= pp.cap3) return 3;
+    if (bound <= pp.cap2) return 2;
+    if (!pp.long3 && bound <= pp.cap3) return 3;
+    return bound <= pp.cap4 ? 4 : 5;
+}
 
 constexpr uint32_t kFilterBits = 13;  // 8192 16-bit counters = 16 KB of LDS per wave
 
@@ -1190,7 +1205,7 @@ __global__ __launch_bounds__(64) void seg_prepass_kernel(RunParams rp, const uin
         while (q_size) trail_step();
         if (rp.tstar > 64u) bound = 0xFFFFFFFFu;  // no estimate for huge gap settings: largest tier
         if (lane == 0) {
-            int tier = (bound <= pp.cap1 && sum <= pp.sum1) ? 1 : (bound <= pp.cap2 ? 2 : (bound <= pp.cap3 ? 3 : (bound <= pp.cap4 ? 4 : 5)));
+            int tier = place_tier(bound, sum, t_idx, pp);
             if (mx > 1 && pp.force_tier > tier) tier = min(pp.force_tier, 5);
 #ifdef ASGART_PROFILE_EXTEND
             if (g0 == 4841535u || g0 == 22631158u) printf("[prepass] g0=%u sidx=%llu bound=%u sum=%llu mx=%u tier=%d t_idx=%u\n", g0, (unsigned long long)sidx, bound, sum, mx, tier, t_idx);
@@ -1220,7 +1235,7 @@ __global__ __launch_bounds__(64) void seg_stats_kernel(RunParams rp, const uint3
         const uint32_t g0 = seg_list[sidx];
         const int c = chunk_of_uniform(rp.ch, g0);
         const uint32_t g_end = min(rp.ch.pbase[c + 1], rp.g_hi);
-        uint32_t quiet = 0, mx = 0, bound = 0;
+        uint32_t quiet = 0, mx = 0, bound = 0, n_probes = 0;
         unsigned long long sum = 0;
         bool done = false;
         s_ext[lane] = 0;
@@ -1256,6 +1271,7 @@ __global__ __launch_bounds__(64) void seg_stats_kernel(RunParams rp, const uint3
             const uint32_t v = ((hm & live) >> lane) & 1ull ? f : 0u;
             const uint32_t r = (uint32_t)__popcll(procm & lt_mask);
             const uint32_t n_proc = (uint32_t)__popcll(procm);
+            n_probes += n_proc;
             if (proc) s_ext[TW + r] = v;
             __syncthreads();
             uint32_t wsum = 0;
@@ -1278,7 +1294,7 @@ __global__ __launch_bounds__(64) void seg_stats_kernel(RunParams rp, const uint3
         }
         if (rp.tstar > 64u) bound = 0xFFFFFFFFu;
         if (lane == 0) {
-            int tier = (bound <= pp.cap1 && sum <= pp.sum1) ? 1 : (bound <= pp.cap2 ? 2 : (bound <= pp.cap3 ? 3 : (bound <= pp.cap4 ? 4 : 5)));
+            int tier = place_tier(bound, sum, n_probes, pp);
             if (mx > 1 && pp.force_tier > tier) tier = min(pp.force_tier, 5);
             const uint32_t s29 = sum > 0x1FFFFFFFull ? 0x1FFFFFFFu : (uint32_t)sum;
             keys[sidx] = (((uint32_t)tier - 1u) << 29) | (0x1FFFFFFFu - s29);
@@ -1831,48 +1847,70 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
     }
 }
 
+// Wave-uniform values the compiler cannot prove uniform (read from LDS, or a lane of a vector):
+// forcing them into scalar registers keeps the per-probe bookkeeping and branches on the scalar
+// unit instead of exec-masked vector code and LDS permutes.
+__device__ inline uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ inline unsigned long long uni(unsigned long long v) {
+    return ((unsigned long long)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v);
+}
+__device__ inline uint32_t lane_of(uint32_t v, uint32_t l) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l);
+}
+__device__ inline unsigned long long lane_of(unsigned long long v, uint32_t l) {
+    return ((unsigned long long)lane_of((uint32_t)(v >> 32), l) << 32) | lane_of((uint32_t)v, l);
+}
+
 // ---------------------------------------------------------------- K4c --------
-// Arm-resident extension kernel: ONE workgroup per segment, every live arm OWNED by a thread and
-// kept in that thread's registers (S arms per thread, slot = layer * NT + thread).  The roles of
-// K4b are reversed: per probe the HITS are indexed (a few hundred at most), and every arm looks
-// up the hits inside its own accept window.  Nothing about an arm ever lives in LDS, the
-// per-probe passes over arm arrays (index build, apply, age) become register work of the owner,
-// and a probe costs three workgroup barriers:
-//   P0  hit h -> four hash tables keyed by x >> (bsh + 2*level); generation-tagged heads, so the
-//       tables are never cleared                                                    | barrier
+// Arm-resident extension kernel: one workgroup (or one wave) per segment, every live arm OWNED
+// by a thread and kept in that thread's registers (S arms per thread, slot = layer * NT +
+// thread).  Per probe the HITS are indexed (a few hundred at most) and every arm looks up the
+// hits inside its own accept window, so nothing about an arm lives in LDS:
+//   P0  hit h -> hash tables keyed by x >> (bsh + 2*level); generation-tagged heads, so the
+//       tables are never cleared; head and chain nodes carry the hit's position, one LDS
+//       round trip per chain link (PACK)                                             | barrier
 //   P1  each arm walks the buckets covering its window [re-k+1, re+thr-1] at the level whose
 //       bucket is at least a quarter of the window; accepted hits take
 //       atomicMin(best[h], creation number << 20 | slot): first arm in list order
-//       (src/automaton.rs:67-78)                                                    | barrier
+//       (src/automaton.rs:67-78)                                                     | barrier
 //   P2  each hit posts h+1 to its winner's mailbox (atomicMax: last hit in SA order wins) or,
-//       unmatched and flagged, to a free slot in hit order (= creation order)       | barrier
-//   P3  each owner reads its mailboxes: extend / age / retire (emit if len(right) >= M) / create.
-// Results are identical to K4 and K4b; tested by forcing every multi-hit segment through it.
+//       unmatched and flagged, to a free slot in hit order (= creation order)        | barrier
+//   P3  owners read their mailboxes: extend / age / retire (emit if len(right) >= M) / create.
+// The per-probe bookkeeping is wave-uniform and kept in scalar registers (uni / lane_of).
 // Two shapes: NT = 64 (one wave per segment, several segments per CU: the bulk of the dense
-// segments) and NT = 512 (one workgroup per segment: the few segments with thousands of arms).
-template <class PosT, int S, int NT, int HB, int kHT, int kLevels>
+// segments) and NT >= 512 (the few segments with thousands of live arms or tens of thousands
+// of probes, whose serial chain sets the critical path of a pass).
+// Results are identical to K4 and K4b; tested by forcing every multi-hit segment through it.
+template <class PosT, int S, int NT, int HB, int kHT, int kLevels, bool PACK, int PAD = 0>
 __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
     constexpr int CAP = S * NT;
     constexpr int NW = NT / 64;
     constexpr uint32_t kGenBits = 22, kNoHit = 0xFFFFu;
-    static_assert(HB <= 1024 && HB <= kHitBatch, "hit index is packed into 10 bits");
+    static_assert(HB <= 1024 && HB <= kHitBatch && CAP < (1 << 20), "hit index is packed into 10 bits");
+    // PACK: head = ((generation << 10 | hit) << 32) | low word of x, node[h] = (next hit << 32) | its x
+    using HeadT = typename std::conditional<PACK, unsigned long long, uint32_t>::type;
+    using NodeT = typename std::conditional<PACK, unsigned long long, uint16_t>::type;
     __shared__ PosT s_hits[HB];
     __shared__ uint8_t s_hflag[HB];
-    __shared__ uint32_t s_head[kLevels][kHT];        // (generation << 10) | hit, newest first
-    __shared__ uint16_t s_next[kLevels][HB];         // chain through the hits of one bucket
+    __shared__ HeadT s_head[kLevels][kHT];
+    __shared__ NodeT s_node[kLevels][HB];            // chain through the hits of one bucket
     __shared__ unsigned long long s_best[HB];        // per hit: (creation number << 20) | slot
     __shared__ uint16_t s_rank[HB];                  // per new hit: rank among the new arms
     __shared__ uint32_t s_msg[CAP];                  // per slot: 1 + index of the hit for it
     __shared__ uint16_t s_free[CAP];                 // stack of empty slots below H
-    __shared__ uint32_t s_nfreed[2];
+    __shared__ uint32_t s_nfreed[2], s_nnew[2], s_nspur[2];
     __shared__ unsigned long long s_bcast;
+    // PAD > 0: claim the rest of the CU's LDS so that no other workgroup shares the CU with a
+    // latency-critical segment (its waves would take issue slots and LDS bandwidth)
+    __shared__ uint32_t s_pad[PAD > 0 ? PAD / 4 : 1];
+    if (P.cap_limit == 0xFEEDF00Du) s_pad[threadIdx.x % (PAD > 0 ? PAD / 4 : 1)] = 1u;  // keeps the allocation
     const int tid = threadIdx.x, lane = tid & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const RunParams &rp = P.rp;
     const uint64_t n_seg = *P.n_seg_ptr;
     const uint32_t k = (uint32_t)rp.k, step = (uint32_t)rp.step, G = rp.G;
     const uint32_t thr0 = arm_threshold(k, G);
-    uint32_t bsh = 3;  // level-0 bucket: 2^bsh >= G + k, a narrow arm's window meets <= 2 of them
+    uint32_t bsh = 3;  // level-0 bucket: 2^bsh >= G + k covers a narrow arm's window
     while ((1ull << bsh) < (unsigned long long)G + k) ++bsh;
     const uint32_t cap_eff = min((uint32_t)CAP, P.cap_limit);
     const uint32_t n_lv = min((uint32_t)kLevels, P.n_levels);
@@ -1887,18 +1925,22 @@ __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
         a_ls[L] = a_le[L] = a_rs[L] = a_re[L] = 0;
         a_thr[L] = a_gap[L] = 0;
     }
-    for (uint32_t h = tid; h < (uint32_t)(kLevels * kHT); h += NT) (&s_head[0][0])[h] = 0u;
+    auto clear_tables = [&]() {
+        for (uint32_t h = tid; h < (uint32_t)(kLevels * kHT); h += NT) (&s_head[0][0])[h] = 0;
+    };
+    clear_tables();
     for (uint32_t j = tid; j < (uint32_t)CAP; j += NT) s_msg[j] = 0u;
-    if (tid < 2) s_nfreed[tid] = 0u;
-    // Freed-slot counters: two, used by alternate owner passes and never reset (a pass reads its
-    // counter after its barrier; the next pass already adds to the other one).
+    if (tid < 2) s_nfreed[tid] = s_nnew[tid] = s_nspur[tid] = 0u;
+    // Monotonic counters in pairs, used by alternate probes / owner passes and never reset: a
+    // pass reads its counter after its barrier while the next pass already adds to the other.
     uint32_t gen = 0, par = 0, freed_seen0 = 0, freed_seen1 = 0;
+    uint32_t ppar = 0, new_seen0 = 0, new_seen1 = 0, spur_seen0 = 0, spur_seen1 = 0;
     __syncthreads();
 
     for (;;) {
         if (tid == 0) s_bcast = atomicAdd(P.cursor, 1ull);
         __syncthreads();
-        const unsigned long long seg = s_bcast;
+        const unsigned long long seg = uni(s_bcast);
         __syncthreads();
         if (seg >= n_seg) break;
         const uint32_t g0 = P.seg_list[seg];
@@ -1919,7 +1961,7 @@ __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
             const int leader = __ffsll((long long)em) - 1;
             unsigned long long base = 0;
             if (lane == leader) base = atomicAdd(&P.ctr[CT_SD], (unsigned long long)__popcll(em));
-            base = __shfl(base, leader);
+            base = lane_of(base, (uint32_t)leader);
             if (emit) {
                 const unsigned long long at = base + __popcll(em & lt_mask);
                 if (at < P.rec_cap) {
@@ -1953,8 +1995,7 @@ __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
                         if (m) s_msg[slot] = 0u;
                     }
                     bool dead = false;
-                    PosT ls = 0, le = 0, rs = 0, re = 0;
-                    uint32_t sq = a_seq[L];
+                    const uint32_t sq = a_seq[L];
                     if (sq != kNoSeq) {
                         if (m) {  // ExtendArm, src/automaton.rs:133-150
                             const PosT x = s_hits[off + m - 1u];
@@ -1966,12 +2007,7 @@ __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
                             const uint64_t sum_g = (uint64_t)a_gap[L] + add;
                             const uint32_t ng = sum_g > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)sum_g;
                             a_gap[L] = ng;
-                            if (ng >= G) {  // src/automaton.rs:166-171: never matches again
-                                dead = true;
-                                ls = a_ls[L]; le = a_le[L]; rs = a_rs[L]; re = a_re[L];
-                                a_seq[L] = kNoSeq;
-                                s_free[n_free + (atomicAdd(&s_nfreed[par], 1u) - freed_base)] = (uint16_t)slot;
-                            }
+                            dead = ng >= G;  // src/automaton.rs:166-171: never matches again
                         }
                     } else if (m) {  // NewArm, src/automaton.rs:151-164 (aged by this very probe)
                         const PosT x = s_hits[off + m - 1u];
@@ -1980,11 +2016,18 @@ __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
                         a_thr[L] = thr0;
                         a_seq[L] = seq_base + s_rank[m - 1u];
                     }
-                    emit_records(dead && (uint64_t)(re - rs) >= rp.M, ls, le, rs, re, sq);
+                    if (__ballot(dead)) {  // wave-uniform
+                        if (dead) {
+                            a_seq[L] = kNoSeq;
+                            s_free[n_free + (atomicAdd(&s_nfreed[par], 1u) - freed_base)] = (uint16_t)slot;
+                        }
+                        emit_records(dead && (uint64_t)(a_re[L] - a_rs[L]) >= rp.M, a_ls[L], a_le[L], a_rs[L],
+                                     a_re[L], sq);
+                    }
                 }
             }
             __syncthreads();
-            const uint32_t freed_now = s_nfreed[par];
+            const uint32_t freed_now = uni(s_nfreed[par]);
             const uint32_t nd = freed_now - freed_base;
             if (par) freed_seen1 = freed_now; else freed_seen0 = freed_now;
             par ^= 1u;
@@ -2017,8 +2060,8 @@ __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
             const uint32_t f_l = (uint32_t)lane < nb ? P.p_filt[g + lane] : kSkipN;
             const uint32_t nfl_l = (uint32_t)lane < nb ? P.p_nflag[g + lane] : 0u;
             const unsigned long long r_l = (uint32_t)lane < nb ? P.row_off[g + lane] : 0ull;
-            const unsigned long long r_hi = P.row_off[g + nb];
-            const unsigned long long base = __shfl(r_l, 0);
+            const unsigned long long r_hi = uni(P.row_off[g + nb]);
+            const unsigned long long base = lane_of(r_l, 0u);
             unsigned long long r_next = __shfl_down(r_l, 1);
             if ((uint32_t)lane + 1 >= nb) r_next = r_hi;
             const bool fits = (uint32_t)lane < nb && r_next - base <= (unsigned long long)HB;
@@ -2031,7 +2074,7 @@ __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
             }
             const uint32_t rel_l = (uint32_t)(r_l - base);
             {
-                const unsigned long long end = nbb == nb ? r_hi : __shfl(r_l, (int)nbb);
+                const unsigned long long end = nbb == nb ? r_hi : lane_of(r_l, nbb);
                 const uint32_t tot = (uint32_t)(end - base);
                 for (uint32_t r = tid; r < tot; r += NT) {
                     s_hits[r] = P.hits[base + r];
@@ -2059,9 +2102,9 @@ __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
                 }
                 quiet = 0;
                 pos = b + 1;
-                const uint32_t cnt = __shfl(f_l, (int)b);
-                const uint32_t nfl = __shfl(nfl_l, (int)b);
-                const uint32_t off = __shfl(rel_l, (int)b);
+                const uint32_t cnt = lane_of(f_l, b);
+                const uint32_t nfl = lane_of(nfl_l, b);
+                const uint32_t off = lane_of(rel_l, b);
                 const uint64_t i = (uint64_t)(g + b - pb + 1) * step;
                 ++t_proc;
                 if (A + nfl > cap_eff) {
@@ -2077,19 +2120,31 @@ __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
                 // ---- P0: index the hits of this probe ----------------------------------------
                 if (++gen >> kGenBits) {  // generation wrap: clear the tables once
                     __syncthreads();
-                    for (uint32_t h = tid; h < (uint32_t)(kLevels * kHT); h += NT) (&s_head[0][0])[h] = 0u;
+                    clear_tables();
                     gen = 1;
                     __syncthreads();
                 }
                 for (uint32_t h = tid; h < cnt; h += NT) {
                     const PosT x = s_hits[off + h];
                     s_best[h] = ~0ull;
+                    const HeadT mine = PACK ? (HeadT)(((unsigned long long)((gen << 10) | h) << 32) | (uint32_t)x)
+                                            : (HeadT)((gen << 10) | h);
+                    HeadT old[kLevels];  // all exchanges in flight before the first result is used
 #pragma unroll
                     for (uint32_t lv = 0; lv < (uint32_t)kLevels; ++lv) {
                         const uint32_t bkt = (uint32_t)((uint64_t)x >> (bsh + 2u * lv));
-                        const uint32_t old = atomicExch(&s_head[lv][((bkt * 2654435761u) >> 12) & ((uint32_t)kHT - 1u)],
-                                                        (gen << 10) | h);
-                        s_next[lv][h] = (old >> 10) == gen ? (uint16_t)(old & 1023u) : (uint16_t)kNoHit;
+                        old[lv] = atomicExch(&s_head[lv][((bkt * 2654435761u) >> 12) & ((uint32_t)kHT - 1u)], mine);
+                    }
+#pragma unroll
+                    for (uint32_t lv = 0; lv < (uint32_t)kLevels; ++lv) {
+                        if constexpr (PACK) {
+                            const uint32_t tag = (uint32_t)(old[lv] >> 32);
+                            s_node[lv][h] = (tag >> 10) == gen
+                                                ? ((unsigned long long)(tag & 1023u) << 32) | (uint32_t)old[lv]
+                                                : (unsigned long long)kNoHit << 32;
+                        } else {
+                            s_node[lv][h] = (old[lv] >> 10) == gen ? (uint16_t)(old[lv] & 1023u) : (uint16_t)kNoHit;
+                        }
                     }
                 }
                 __syncthreads();
@@ -2105,21 +2160,51 @@ __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
                             const uint64_t w = (uint64_t)a_thr[L] + k - 1u;
                             const unsigned long long key =
                                 ((unsigned long long)a_seq[L] << 20) | ((uint32_t)L * NT + tid);
+                            // exact test on the full position (the packed low word is a pre-filter
+                            // that is already exact for 32-bit positions)
+                            auto offer = [&](uint32_t h, uint32_t x32) {
+                                if constexpr (sizeof(PosT) == 4) {
+                                    if ((uint64_t)(uint32_t)(x32 - (uint32_t)lo) < w) atomicMin(&s_best[h], key);
+                                } else {
+                                    if ((uint64_t)(uint32_t)(x32 - (uint32_t)lo) < w &&
+                                        (uint64_t)(PosT)(s_hits[off + h] - lo) < w)
+                                        atomicMin(&s_best[h], key);
+                                }
+                            };
+                            // smallest level whose bucket is at least a quarter of the window
                             uint32_t lv = 0;
-                            while (lv < n_lv && w > (4ull << (bsh + 2u * lv))) ++lv;
-                            if (lv == n_lv) {  // wider than any table: every hit is a candidate
+                            if (w > (4ull << bsh)) {
+                                const uint32_t bits = 64u - (uint32_t)__clzll((long long)(w - 1u));  // ceil(log2 w)
+                                lv = (bits - bsh - 1u) >> 1;  // ceil((bits - bsh - 2) / 2)
+                            }
+                            if (lv >= n_lv) {  // wider than any table: every hit is a candidate
                                 for (uint32_t h = 0; h < cnt; ++h)
                                     if ((uint64_t)(PosT)(s_hits[off + h] - lo) < w) atomicMin(&s_best[h], key);
                             } else {
                                 const uint32_t sh = bsh + 2u * lv;
                                 const uint64_t b0 = (uint64_t)lo >> sh, b1 = ((uint64_t)lo + w - 1u) >> sh;
                                 for (uint64_t bk = b0; bk <= b1; ++bk) {
-                                    const uint32_t e = s_head[lv][(((uint32_t)bk * 2654435761u) >> 12) & ((uint32_t)kHT - 1u)];
-                                    if ((e >> 10) != gen) continue;
-                                    uint32_t h = e & 1023u;
-                                    while (h != kNoHit) {
-                                        if ((uint64_t)(PosT)(s_hits[off + h] - lo) < w) atomicMin(&s_best[h], key);
-                                        h = s_next[lv][h];
+                                    const HeadT e = s_head[lv][(((uint32_t)bk * 2654435761u) >> 12) & ((uint32_t)kHT - 1u)];
+                                    if constexpr (PACK) {
+                                        const uint32_t tag = (uint32_t)(e >> 32);
+                                        if ((tag >> 10) != gen) continue;
+                                        uint32_t h = tag & 1023u, x32 = (uint32_t)e;
+                                        for (;;) {
+                                            const unsigned long long nd = s_node[lv][h];
+                                            offer(h, x32);
+                                            h = (uint32_t)(nd >> 32);
+                                            x32 = (uint32_t)nd;
+                                            if (h == kNoHit) break;
+                                        }
+                                    } else {
+                                        if ((e >> 10) != gen) continue;
+                                        uint32_t h = e & 1023u;
+                                        while (h != kNoHit) {
+                                            const PosT x = s_hits[off + h];
+                                            const uint32_t nx = s_node[lv][h];
+                                            if ((uint64_t)(PosT)(x - lo) < w) atomicMin(&s_best[h], key);
+                                            h = nx;
+                                        }
                                     }
                                 }
                             }
@@ -2130,33 +2215,52 @@ __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
                 PROF_STOP(4);
                 PROF_START();
                 // ---- P2: hits notify arms / claim free slots ----------------------------------
-                // rank of each unmatched flagged hit among the new arms, in hit order: every wave
-                // recomputes the per-group counts (no barrier)
-                uint32_t n_new = 0;
-                bool spur = false;
-                for (uint32_t c0 = 0, grp = 0; c0 < cnt; c0 += 64, ++grp) {
-                    const uint32_t h = c0 + lane;
-                    unsigned long long best = 0;
-                    bool un = false, hf = false;
-                    if (h < cnt) {
-                        best = s_best[h];
-                        un = best == ~0ull;
-                        hf = s_hflag[off + h] != 0;
-                    }
-                    const unsigned long long nm = __ballot(un && hf);
-                    spur |= __ballot(un && !hf) != 0ull;
-                    if (grp % NW == (uint32_t)(tid >> 6) && h < cnt) {  // this wave owns the group
-                        if (!un) {
-                            atomicMax(&s_msg[(uint32_t)(best & 0xFFFFFu)], h + 1u);
-                        } else if (hf) {
-                            const uint32_t bf = n_new + (uint32_t)__popcll(nm & lt_mask);
-                            const uint32_t slot = bf < n_free ? (uint32_t)s_free[n_free - 1u - bf] : H + (bf - n_free);
-                            s_msg[slot] = h + 1u;
-                            s_rank[h] = (uint16_t)bf;
+                // Wave w owns the hit groups w, w + NW, ...; the rank of an unmatched flagged hit
+                // among the new arms (hit order = creation order) needs the counts of the earlier
+                // groups, which the owning wave recomputes itself (no barrier).  The totals reach
+                // the other waves through counters read after the barrier.
+                const uint32_t new_base = ppar ? new_seen1 : new_seen0;
+                const uint32_t spur_base = ppar ? spur_seen1 : spur_seen0;
+                for (uint32_t h0 = (uint32_t)tid & ~63u; h0 < cnt; h0 += NT) {
+                    uint32_t before = 0;
+                    bool any_spur = false;
+                    for (uint32_t c0 = 0; c0 <= h0; c0 += 64) {
+                        const uint32_t h = c0 + lane;
+                        unsigned long long best = 0;
+                        bool un = false, hf = false;
+                        if (h < cnt) {
+                            best = s_best[h];
+                            un = best == ~0ull;
+                            hf = s_hflag[off + h] != 0;
+                        }
+                        const unsigned long long nm = __ballot(un && hf);
+                        if (c0 < h0) {
+                            before += (uint32_t)__popcll(nm);
+                            continue;
+                        }
+                        any_spur = __ballot(un && !hf) != 0ull;
+                        if (h < cnt) {
+                            if (!un) {
+                                atomicMax(&s_msg[(uint32_t)(best & 0xFFFFFu)], h + 1u);
+                            } else if (hf) {
+                                const uint32_t bf = before + (uint32_t)__popcll(nm & lt_mask);
+                                const uint32_t slot = bf < n_free ? (uint32_t)s_free[n_free - 1u - bf] : H + (bf - n_free);
+                                s_msg[slot] = h + 1u;
+                                s_rank[h] = (uint16_t)bf;
+                            }
+                        }
+                        if (lane == 0) {
+                            if (nm) atomicAdd(&s_nnew[ppar], (uint32_t)__popcll(nm));
+                            if (any_spur) atomicAdd(&s_nspur[ppar], 1u);
                         }
                     }
-                    n_new += (uint32_t)__popcll(nm);
                 }
+                __syncthreads();
+                const uint32_t new_now = uni(s_nnew[ppar]), spur_now = uni(s_nspur[ppar]);
+                const uint32_t n_new = new_now - new_base;
+                const bool spur = spur_now != spur_base;
+                if (ppar) { new_seen1 = new_now; spur_seen1 = spur_now; } else { new_seen0 = new_now; spur_seen0 = spur_now; }
+                ppar ^= 1u;
                 if (n_new <= n_free) {
                     n_free -= n_new;
                 } else {
@@ -2166,7 +2270,6 @@ __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
                 A += n_new;
                 const uint32_t seq_base = next_seq;
                 next_seq += n_new;
-                __syncthreads();
                 PROF_STOP(6);
                 PROF_START();
                 // ---- P3: owners apply -----------------------------------------------------------
@@ -2195,12 +2298,11 @@ __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
             const unsigned long long at = atomicAdd(P.ovf_count, 1ull);
             if (P.ovf_list) P.ovf_list[at] = g0;
         }
-        // leave no arm and no message behind for the next segment
+        // leave no arm behind for the next segment (mailboxes are empty: every P2 has its P3)
         if (A > 0) {
 #pragma unroll
             for (int L = 0; L < S; ++L) a_seq[L] = kNoSeq;
         }
-        // (mailboxes are empty here: every P2 is followed by its P3)
         if (tid < 64) {
             PROF_FLUSH();
         }
