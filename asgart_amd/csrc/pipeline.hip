@@ -57,6 +57,7 @@ constexpr uint64_t kGrid4Arms = 512ull;
 template <class SlotT> constexpr int kWaveArmsLayers = sizeof(SlotT) == 4 ? 8 : 5;
 constexpr int kWaveArmsHits = 512;
 constexpr uint64_t kGrid2Arms = 256ull * 8ull;
+template <class SlotT> constexpr int kLongArmsLayers = sizeof(SlotT) == 4 ? 4 : 2;  // tier 3: 4 x 1024 arms
 constexpr int kPoleLdsPad = 0;             // > 0: tier 3 workgroups take a whole CU (measured: no gain)
 constexpr uint32_t kLongSegment = 4096;  // probes; longer segments get the low-latency shape (tier 3)
 constexpr int kArmCapSmall = 256;   // live arms per wave in LDS, common case
@@ -298,7 +299,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             pp.cap4 = (uint32_t)kArmsLayers<SlotT> * kHeavyThreads * 7 / 5;
             pp.cap2 = arms_wave ? (uint32_t)kWaveArmsLayers<SlotT> * 64u : 0u;
             // tier 3: few layers, 1024 threads -- the lowest per-probe latency, for the long segments
-            pp.cap3 = std::max<uint32_t>(pp.cap2, 2u * 1024u);
+            pp.cap3 = std::max<uint32_t>(pp.cap2, (uint32_t)kLongArmsLayers<SlotT> * 1024u);
             pp.long3 = getenv("ASGART_LONG3") ? (uint32_t)atoi(getenv("ASGART_LONG3")) : kLongSegment;
             if (force_tier == 3) pp.long3 = 1;
             if (const char *e = getenv("ASGART_CAP1")) pp.cap1 = (uint32_t)std::max(1, std::min(atoi(e), kArmCapSmall));
@@ -411,7 +412,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                     break;
                 case 3:
                     if (arms_kernel)
-                        extend_arms_kernel<SlotT, 2, 1024, kHitBatch, 1024, 4, false, kPoleLdsPad><<<grid_of(3, kGrid3), 1024, 0, st3>>>(ep);
+                        extend_arms_kernel<SlotT, kLongArmsLayers<SlotT>, 1024, kHitBatch, 1024, 4, false, true, kPoleLdsPad><<<grid_of(3, kGrid3), 1024, 0, st3>>>(ep);
                     else if constexpr (sizeof(SlotT) == 4)
                         extend_heavy_kernel<SlotT, kArmCapBig32, kHeavyThreads, 0><<<grid_of(3, kGrid3), kHeavyThreads, 0, st3>>>(ep);
                     else
@@ -419,16 +420,8 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                     PROF_TIER("3", st3, n_t[2]);
                     break;
                 case 4:
-                    if (arms_kernel && getenv("ASGART_SHAPE")) {  // experiment: other shapes of K4c
-                        switch (atoi(getenv("ASGART_SHAPE"))) {
-                        case 1: extend_arms_kernel<SlotT, 5, 1024, kHitBatch, 1024, 4, false><<<grid_of(4, kGrid4Arms), 1024, 0, st4>>>(ep); break;
-                        case 2: extend_arms_kernel<SlotT, 2, 1024, kHitBatch, 1024, 4, true><<<grid_of(4, kGrid4Arms), 1024, 0, st4>>>(ep); break;
-                        case 3: extend_arms_kernel<SlotT, 4, 1024, kHitBatch, 1024, 4, false><<<grid_of(4, kGrid4Arms), 1024, 0, st4>>>(ep); break;
-                        case 4: extend_arms_kernel<SlotT, 2, 512, kHitBatch, 1024, 4, true><<<grid_of(4, kGrid4Arms), 512, 0, st4>>>(ep); break;
-                        default: extend_arms_kernel<SlotT, 1, 1024, kHitBatch, 1024, 4, true><<<grid_of(4, kGrid4Arms), 1024, 0, st4>>>(ep); break;
-                        }
-                    } else if (arms_kernel)
-                        extend_arms_kernel<SlotT, kArmsLayers<SlotT>, kHeavyThreads, kHitBatch, 1024, 4, true><<<grid_of(4, kGrid4Arms), kHeavyThreads, 0, st4>>>(ep);
+                    if (arms_kernel)
+                        extend_arms_kernel<SlotT, kArmsLayers<SlotT>, kHeavyThreads, kHitBatch, 1024, 4, false, true><<<grid_of(4, kGrid4Arms), kHeavyThreads, 0, st4>>>(ep);
                     else
                         extend_heavy_kernel<SlotT, caph, kHeavyThreads, 1><<<grid_of(4, kGrid4), kHeavyThreads, 0, st4>>>(ep);
                     PROF_TIER("4", st4, n_t[3]);
@@ -479,14 +472,14 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                         extend_heavy_kernel<SlotT, kArmCapMid, kMidThreads, 0><<<mw, kMidThreads, 0, s>>>(ep);
                 } else if (tier == 3) {
                     if (arms_kernel)
-                        extend_arms_kernel<SlotT, 2, 1024, kHitBatch, 1024, 4, false><<<bw, 1024, 0, s>>>(ep);
+                        extend_arms_kernel<SlotT, kLongArmsLayers<SlotT>, 1024, kHitBatch, 1024, 4, false, true, kPoleLdsPad><<<bw, 1024, 0, s>>>(ep);
                     else if constexpr (sizeof(SlotT) == 4)
                         extend_heavy_kernel<SlotT, kArmCapBig32, kHeavyThreads, 0><<<bw, kHeavyThreads, 0, s>>>(ep);
                     else
                         extend_heavy_kernel<SlotT, kArmCapBig64, kHeavyThreads, 0><<<bw, kHeavyThreads, 0, s>>>(ep);
                 } else if (tier == 4) {
                     if (arms_kernel)
-                        extend_arms_kernel<SlotT, kArmsLayers<SlotT>, kHeavyThreads, kHitBatch, 1024, 4, true><<<bw, kHeavyThreads, 0, s>>>(ep);
+                        extend_arms_kernel<SlotT, kArmsLayers<SlotT>, kHeavyThreads, kHitBatch, 1024, 4, false, true><<<bw, kHeavyThreads, 0, s>>>(ep);
                     else
                         extend_heavy_kernel<SlotT, caph, kHeavyThreads, 1><<<bw, kHeavyThreads, 0, s>>>(ep);
                 } else {

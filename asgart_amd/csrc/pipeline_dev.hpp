@@ -1881,7 +1881,7 @@ __device__ inline unsigned long long lane_of(unsigned long long v, uint32_t l) {
 // segments) and NT >= 512 (the few segments with thousands of live arms or tens of thousands
 // of probes, whose serial chain sets the critical path of a pass).
 // Results are identical to K4 and K4b; tested by forcing every multi-hit segment through it.
-template <class PosT, int S, int NT, int HB, int kHT, int kLevels, bool PACK, int PAD = 0>
+template <class PosT, int S, int NT, int HB, int kHT, int kLevels, bool PACK, bool COLD = false, int PAD = 0>
 __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
     constexpr int CAP = S * NT;
     constexpr int NW = NT / 64;
@@ -1900,6 +1900,9 @@ __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
     __shared__ uint16_t s_free[CAP];                 // stack of empty slots below H
     __shared__ uint32_t s_nfreed[2], s_nnew[2], s_nspur[2];
     __shared__ unsigned long long s_bcast;
+    // COLD: the fields an arm only needs when it is extended or retired (left start, left end,
+    // right start) live in LDS instead of registers -- more arms per thread without spilling
+    __shared__ PosT s_cls[COLD ? CAP : 1], s_cle[COLD ? CAP : 1], s_crs[COLD ? CAP : 1];
     // PAD > 0: claim the rest of the CU's LDS so that no other workgroup shares the CU with a
     // latency-critical segment (its waves would take issue slots and LDS bandwidth)
     __shared__ uint32_t s_pad[PAD > 0 ? PAD / 4 : 1];
@@ -1917,12 +1920,14 @@ __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
     PROF_DECL;
 
     // arm state, one arm per (thread, layer)
-    PosT a_ls[S], a_le[S], a_rs[S], a_re[S];
+    constexpr int SC = COLD ? 1 : S;
+    PosT a_ls[SC], a_le[SC], a_rs[SC], a_re[S];
     uint32_t a_thr[S], a_gap[S], a_seq[S];
 #pragma unroll
     for (int L = 0; L < S; ++L) {
         a_seq[L] = kNoSeq;
-        a_ls[L] = a_le[L] = a_rs[L] = a_re[L] = 0;
+        a_re[L] = 0;
+        if (L < SC) a_ls[L] = a_le[L] = a_rs[L] = 0;
         a_thr[L] = a_gap[L] = 0;
     }
     auto clear_tables = [&]() {
@@ -2000,8 +2005,15 @@ __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
                         if (m) {  // ExtendArm, src/automaton.rs:133-150
                             const PosT x = s_hits[off + m - 1u];
                             a_re[L] = (PosT)(x + k);
-                            a_le[L] = (PosT)(i + k);
-                            a_thr[L] = arm_threshold((uint64_t)(i + k) - (uint64_t)a_ls[L], G);
+                            PosT ls;
+                            if constexpr (COLD) {
+                                ls = s_cls[slot];
+                                s_cle[slot] = (PosT)(i + k);
+                            } else {
+                                ls = a_ls[L];
+                                a_le[L] = (PosT)(i + k);
+                            }
+                            a_thr[L] = arm_threshold((uint64_t)(i + k) - (uint64_t)ls, G);
                             a_gap[L] = 0;
                         } else {
                             const uint64_t sum_g = (uint64_t)a_gap[L] + add;
@@ -2011,7 +2023,12 @@ __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
                         }
                     } else if (m) {  // NewArm, src/automaton.rs:151-164 (aged by this very probe)
                         const PosT x = s_hits[off + m - 1u];
-                        a_ls[L] = (PosT)i; a_le[L] = (PosT)(i + k); a_rs[L] = x; a_re[L] = (PosT)(x + k);
+                        if constexpr (COLD) {
+                            s_cls[slot] = (PosT)i; s_cle[slot] = (PosT)(i + k); s_crs[slot] = x;
+                        } else {
+                            a_ls[L] = (PosT)i; a_le[L] = (PosT)(i + k); a_rs[L] = x;
+                        }
+                        a_re[L] = (PosT)(x + k);
                         a_gap[L] = step;
                         a_thr[L] = thr0;
                         a_seq[L] = seq_base + s_rank[m - 1u];
@@ -2021,8 +2038,15 @@ __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
                             a_seq[L] = kNoSeq;
                             s_free[n_free + (atomicAdd(&s_nfreed[par], 1u) - freed_base)] = (uint16_t)slot;
                         }
-                        emit_records(dead && (uint64_t)(a_re[L] - a_rs[L]) >= rp.M, a_ls[L], a_le[L], a_rs[L],
-                                     a_re[L], sq);
+                        PosT ls = 0, le = 0, rs = 0;
+                        if (dead) {
+                            if constexpr (COLD) {
+                                ls = s_cls[slot]; le = s_cle[slot]; rs = s_crs[slot];
+                            } else {
+                                ls = a_ls[L]; le = a_le[L]; rs = a_rs[L];
+                            }
+                        }
+                        emit_records(dead && (uint64_t)(a_re[L] - rs) >= rp.M, ls, le, rs, a_re[L], sq);
                     }
                 }
             }
