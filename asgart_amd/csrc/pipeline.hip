@@ -299,7 +299,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             pp.cap4 = (uint32_t)kArmsLayers<SlotT> * kHeavyThreads * 7 / 5;
             pp.cap2 = arms_wave ? (uint32_t)kWaveArmsLayers<SlotT> * 64u : 0u;
             // tier 3: few layers, 1024 threads -- the lowest per-probe latency, for the long segments
-            pp.cap3 = std::max<uint32_t>(pp.cap2, (uint32_t)kLongArmsLayers<SlotT> * 1024u);
+            pp.cap3 = std::max<uint32_t>(pp.cap2, (uint32_t)kLongArmsLayers<SlotT> * 1024u * (getenv("ASGART_CAP3_PCT") ? (uint32_t)atoi(getenv("ASGART_CAP3_PCT")) : 100u) / 100u);
             pp.long3 = getenv("ASGART_LONG3") ? (uint32_t)atoi(getenv("ASGART_LONG3")) : kLongSegment;
             if (force_tier == 3) pp.long3 = 1;
             if (const char *e = getenv("ASGART_CAP1")) pp.cap1 = (uint32_t)std::max(1, std::min(atoi(e), kArmCapSmall));
