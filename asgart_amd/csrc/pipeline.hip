@@ -57,7 +57,7 @@ constexpr uint64_t kGrid4Arms = 512ull;
 template <class SlotT> constexpr int kWaveArmsLayers = sizeof(SlotT) == 4 ? 8 : 5;
 constexpr int kWaveArmsHits = 512;
 constexpr uint64_t kGrid2Arms = 256ull * 8ull;
-template <class SlotT> constexpr int kLongArmsLayers = sizeof(SlotT) == 4 ? 4 : 2;  // tier 3: 4 x 1024 arms
+template <class SlotT> constexpr int kLongArmsLayers = sizeof(SlotT) == 4 ? 5 : 2;  // tier 3: 4 x 1024 arms
 constexpr int kPoleLdsPad = 0;             // > 0: tier 3 workgroups take a whole CU (measured: no gain)
 constexpr uint32_t kLongSegment = 4096;  // probes; longer segments get the low-latency shape (tier 3)
 constexpr int kArmCapSmall = 256;   // live arms per wave in LDS, common case
