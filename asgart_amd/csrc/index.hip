@@ -325,7 +325,7 @@ void asgart_index_destroy(asgart_index *idx) {
         for (DevBuf *b : bufs) b->release();
         for (auto &e : cx.ev)
             if (e) (void)hipEventDestroy(e);
-        for (hipStream_t st : {cx.stream, cx.stream2, cx.stream3, cx.stream4})
+        for (hipStream_t st : {cx.stream, cx.stream2, cx.stream3, cx.stream4, cx.stream5, cx.stream6})
             if (st) (void)hipStreamDestroy(st);
     }
     delete idx;
@@ -363,6 +363,8 @@ int32_t asgart_index_create(const uint8_t *T, int64_t n, const int64_t *SA, int6
             HIP_TRY(hipStreamCreateWithFlags(&cx.stream2, hipStreamNonBlocking));
             HIP_TRY(hipStreamCreateWithFlags(&cx.stream3, hipStreamNonBlocking));
             HIP_TRY(hipStreamCreateWithFlags(&cx.stream4, hipStreamNonBlocking));
+            HIP_TRY(hipStreamCreateWithFlags(&cx.stream5, hipStreamNonBlocking));
+            HIP_TRY(hipStreamCreateWithFlags(&cx.stream6, hipStreamNonBlocking));
             for (auto &e : cx.ev) HIP_TRY(hipEventCreate(&e));
         }
         HIP_TRY(hipMalloc((void **)&idx->d_text, (size_t)n + 64));

@@ -86,7 +86,8 @@ namespace asgart {
 struct SearchCtx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr, stream3 = nullptr, stream4 = nullptr;  // concurrent extension tiers
-    hipEvent_t ev[10] = {};
+    hipStream_t stream5 = nullptr, stream6 = nullptr;
+    hipEvent_t ev[12] = {};
     Workspace ws;
     asgart_stats stats;
     RunParams last_rp;   // inputs of the last call, kept for the yardstick kernel

@@ -29,7 +29,7 @@ namespace asgart {
         for (int pf_i = 0; pf_i < 16; ++pf_i) fprintf(stderr, " %llu", h_ctr[CT_HIST_PROBES + pf_i]); \
         fprintf(stderr, "\n");                                                                 \
         (void)hipMemsetAsync(d_ctr + 16, 0, 18 * 8, s);                                        \
-        (void)hipMemsetAsync(d_ctr + 56, 0, (CT_COUNT - 56) * 8, s);                           \
+        (void)hipMemsetAsync(d_ctr + 56, 0, (CT_N1 - 56) * 8, s);                              \
     } while (0)
 // one tier at a time, with its own dump (the diagnostic build gives up the overlap)
 #define PROF_TIER(tag, stream, n)                                                               \
@@ -48,13 +48,15 @@ namespace asgart {
 #endif
 
 // default launch order / grid sizes of the extension tiers (see the launch site)
-constexpr const char *kTierOrder = "12345";
+constexpr const char *kTierOrder = "3654217";
 constexpr uint64_t kGrid1 = 256ull * 8ull, kGrid2 = 256ull * 3ull, kGrid3 = 256ull, kGrid4 = 256ull, kGrid5 = 256ull;
 // arms per thread of the arm-resident kernel: 9 x 512 = 4608 live arms (6 x 512 with 64-bit positions)
 template <class SlotT> constexpr int kArmsLayers = sizeof(SlotT) == 4 ? 9 : 6;
 constexpr uint64_t kGrid4Arms = 512ull;
 // its one-wave shape: 8 x 64 = 512 live arms per wave, probes with up to 512 hits
 template <class SlotT> constexpr int kWaveArmsLayers = sizeof(SlotT) == 4 ? 8 : 5;
+// tiers 4 and 5: 4 arms per thread x 256 / 512 threads, cold fields in LDS
+template <class SlotT> constexpr int kMidArmsLayers = sizeof(SlotT) == 4 ? 4 : 2;
 constexpr int kWaveArmsHits = 512;
 constexpr uint64_t kGrid2Arms = 256ull * 8ull;
 template <class SlotT> constexpr int kLongArmsLayers = sizeof(SlotT) == 4 ? 5 : 2;  // tier 3: 4 x 1024 arms
@@ -269,7 +271,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
     // ---- K4: extension automaton ------------------------------------------------
     if (fam_out && n_seg) {
         uint64_t rec_cap = std::max<uint64_t>(1u << 18, w.fam_sds.cap / sizeof(SdRec));
-        RC_TRY(w.ovf_list.reserve((size_t)(n_seg + 1) * 16));
+        RC_TRY(w.ovf_list.reserve((size_t)(n_seg + 1) * 4 * kTiers));
         std::vector<SdRec> h_recs;
         // ---- placement: per-segment work estimate -> tier, longest first --------------------
         // ASGART_FORCE_TIER=t (tests): start every segment with a multi-hit probe in tier >= t
@@ -277,35 +279,56 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
         RC_TRY(w.seg_keys.reserve((size_t)n_seg * 4 * 2));
         RC_TRY(w.seg_vals.reserve((size_t)n_seg * 4 * 2));
         uint32_t *kbuf = w.seg_keys.as<uint32_t>(), *vbuf = w.seg_vals.as<uint32_t>();
-        HIP_TRY(hipMemsetAsync(d_ctr + CT_N1, 0, 17 * 8, s));
-        PlaceParams pp;
-        pp.long3 = 0;
-        pp.cap1 = kArmCapSmall;
-        pp.cap2 = kArmCapMid;
-        pp.cap3 = sizeof(SlotT) == 4 ? kArmCapBig32 : kArmCapBig64;
-        // the window bound is up to ~1.7x pessimistic for tandem arrays (hits extend arms there);
-        // the HBM tier is several times slower per probe, so the hybrid tier also takes segments
-        // whose bound exceeds its capacity by up to 40 % (a real overflow falls through the cascade)
-        pp.cap4 = (sizeof(SlotT) == 4 ? kArmCapHybrid32 : kArmCapHybrid64) * 7 / 5;
-        if (rp.G >= 0xFFF0u || rp.C >= 0xFFF0u) pp.cap4 = pp.cap3;  // 16-bit gap/pend would not do
-        // Arm-resident kernel (K4c) in place of the three block tiers whenever a probe's hits fit
-        // its staging area; ASGART_ARMS_KERNEL=0 keeps the LDS-array tiers (tests run both).
+        HIP_TRY(hipMemsetAsync(d_ctr + CT_N1, 0, (size_t)(CT_COUNT - CT_N1) * 8, s));
+        // ---- the tiers ------------------------------------------------------------------------
+        //  1  one wave per segment, arms in registers / LDS arrays (K4)              <= 256 arms
+        //  2  arm-resident, one wave, 8 per CU (K4c 8x64)                            <= 512
+        //  3  arm-resident, 1024 threads: lowest per-probe latency, LONG segments    <= 5120
+        //  4  arm-resident, 256 threads, 4 workgroups per CU (K4c 4x256)             <= 1024
+        //  5  arm-resident, 512 threads, 2 per CU (K4c 4x512)                        <= 2048
+        //  6  arm-resident, 512 threads, 1 per CU (K4c 9x512)                        <= 4608 * 1.4 (by the bound)
+        //  7  arms in HBM scratch (K4b MODE 2)                                       <= 16384
+        // With max_cardinality > 1024 (or ASGART_ARMS_KERNEL=0, tests) the LDS-array kernels K4b take
+        // tiers 2, 4 and 6 (768 / 2432 / 4608 * 1.4 arms) and tiers 3 and 5 stay empty; the small
+        // shapes 2 and 4 stage 512 hits per probe and are skipped when max_cardinality > 512.
+        constexpr int caph = sizeof(SlotT) == 4 ? kArmCapHybrid32 : kArmCapHybrid64;
+        constexpr int capg = sizeof(SlotT) == 4 ? kArmCapGlobal32 : kArmCapGlobal64;
         const bool arms_kernel = rp.C <= (uint64_t)kHitBatch &&
                                  !(getenv("ASGART_ARMS_KERNEL") && atoi(getenv("ASGART_ARMS_KERNEL")) == 0);
-        // ... and its one-wave shape as tier 2 (several segments per CU) when a probe's hits fit
-        // that shape's smaller staging area.  Tier 3 is empty then.
-        const bool arms_wave = arms_kernel && rp.C <= (uint64_t)kWaveArmsHits;
+        const bool arms_small = arms_kernel && rp.C <= (uint64_t)kWaveArmsHits;
+        uint32_t tier_cap[kTiers + 1] = {0, kArmCapSmall, 0, 0, 0, 0, 0, (uint32_t)capg};
         if (arms_kernel) {
-            pp.cap4 = (uint32_t)kArmsLayers<SlotT> * kHeavyThreads * 7 / 5;
-            pp.cap2 = arms_wave ? (uint32_t)kWaveArmsLayers<SlotT> * 64u : 0u;
-            // tier 3: few layers, 1024 threads -- the lowest per-probe latency, for the long segments
-            pp.cap3 = std::max<uint32_t>(pp.cap2, (uint32_t)kLongArmsLayers<SlotT> * 1024u * (getenv("ASGART_CAP3_PCT") ? (uint32_t)atoi(getenv("ASGART_CAP3_PCT")) : 100u) / 100u);
+            if (arms_small) {
+                tier_cap[2] = (uint32_t)kWaveArmsLayers<SlotT> * 64u;
+                tier_cap[4] = (uint32_t)kMidArmsLayers<SlotT> * 256u;
+            }
+            tier_cap[3] = (uint32_t)kLongArmsLayers<SlotT> * 1024u;
+            tier_cap[5] = (uint32_t)kMidArmsLayers<SlotT> * 512u;
+            // the window bound is pessimistic for tandem arrays (hits extend arms there) and the HBM
+            // tier is several times slower per probe: tier 6 also takes segments whose bound exceeds
+            // its capacity by up to 40 % (a real overflow falls through the cascade)
+            tier_cap[6] = (uint32_t)kArmsLayers<SlotT> * kHeavyThreads * 7 / 5;
+            // tier 3 holds more arms than tier 6: a long segment that tier 6 would accept by the bound
+            // is at least as safe in tier 3
+            tier_cap[3] = std::max(tier_cap[3], tier_cap[6]);
+        } else {
+            tier_cap[2] = kArmCapMid;
+            tier_cap[4] = sizeof(SlotT) == 4 ? kArmCapBig32 : kArmCapBig64;
+            tier_cap[6] = (rp.G >= 0xFFF0u || rp.C >= 0xFFF0u) ? 0u : (uint32_t)caph * 7 / 5;  // 16-bit gap/pend
+        }
+        auto tier_enabled = [&](int t) { return t >= 1 && t <= kTiers && tier_cap[t] != 0; };
+        PlaceParams pp;
+        pp.long3 = 0;
+        for (int t = 1; t < kTiers; ++t) pp.cap[t - 1] = tier_cap[t];
+        if (arms_kernel) {
             pp.long3 = getenv("ASGART_LONG3") ? (uint32_t)atoi(getenv("ASGART_LONG3")) : kLongSegment;
             if (force_tier == 3) pp.long3 = 1;
-            if (const char *e = getenv("ASGART_CAP1")) pp.cap1 = (uint32_t)std::max(1, std::min(atoi(e), kArmCapSmall));
+            if (const char *e = getenv("ASGART_CAP1")) pp.cap[0] = (uint32_t)std::max(1, std::min(atoi(e), kArmCapSmall));
         }
+        int force_eff = force_tier;  // a forced tier that has no kernel in this mode: the next one that has
+        while (force_eff > 1 && force_eff < kTiers && !tier_enabled(force_eff)) ++force_eff;
         pp.sum1 = kTier1MaxSum;
-        pp.force_tier = force_tier;
+        pp.force_tier = force_eff;
         // an unextended arm has len(right) = k: it may only be dropped when that is never reported
         // Measured on the GRCh38-shaped workload the filter removes ~85 % of the arms of dense
         // repeat clusters but its LDS-atomic pre-pass costs more than the extension tiers gain
@@ -333,22 +356,24 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, sizeof(h_ctr), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
-        const uint64_t n_t[5] = {h_ctr[CT_N1], h_ctr[CT_N2], h_ctr[CT_N3], h_ctr[CT_N4], h_ctr[CT_N5]};
-        if (getenv("ASGART_DEBUG"))
-            fprintf(stderr, "[asgart] segments per tier: %llu %llu %llu %llu %llu\n", (unsigned long long)n_t[0],
-                    (unsigned long long)n_t[1], (unsigned long long)n_t[2], (unsigned long long)n_t[3],
-                    (unsigned long long)n_t[4]);
-        uint32_t *ovf[4] = {w.ovf_list.as<uint32_t>(), w.ovf_list.as<uint32_t>() + (n_seg + 1),
-                            w.ovf_list.as<uint32_t>() + 2 * (n_seg + 1),
-                            w.ovf_list.as<uint32_t>() + 3 * (n_seg + 1)};
-        constexpr int caph = sizeof(SlotT) == 4 ? kArmCapHybrid32 : kArmCapHybrid64;
-        constexpr int capg = sizeof(SlotT) == 4 ? kArmCapGlobal32 : kArmCapGlobal64;
+        uint64_t n_t[kTiers], seg_off[kTiers + 1] = {0};
+        for (int t = 0; t < kTiers; ++t) {
+            n_t[t] = h_ctr[CT_N1 + t];
+            seg_off[t + 1] = seg_off[t] + n_t[t];
+        }
+        if (getenv("ASGART_DEBUG")) {
+            fprintf(stderr, "[asgart] segments per tier:");
+            for (int t = 0; t < kTiers; ++t) fprintf(stderr, " %llu", (unsigned long long)n_t[t]);
+            fprintf(stderr, "\n");
+        }
+        uint32_t *ovf[kTiers];  // ovf[t-1]: segments tier t gave up on
+        for (int t = 0; t < kTiers; ++t) ovf[t] = w.ovf_list.as<uint32_t>() + (size_t)t * (n_seg + 1);
         const size_t per_wg = (size_t)capg * (4 * sizeof(SlotT) + 16);
         RC_TRY(w.scratch.reserve(per_wg * 256));
         for (int attempt = 0;; ++attempt) {
             RC_TRY(w.fam_sds.reserve((size_t)rec_cap * sizeof(SdRec)));
             HIP_TRY(hipMemsetAsync(d_ctr + CT_SD, 0, 8, s));
-            HIP_TRY(hipMemsetAsync(d_ctr + CT_NF, 0, 12 * 8, s));  // NF, cursors, OVF1..5
+            HIP_TRY(hipMemsetAsync(d_ctr + CT_NF, 0, (size_t)(CT_COUNT - CT_NF) * 8, s));  // NF, cursors, overflow counts
             HIP_TRY(hipEventRecord(cx.ev[7], s));
             ExtParams<SlotT> ep;
             ep.rp = rp;
@@ -370,10 +395,12 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             // back-fills CUs as workgroups retire, so the tails of one tier overlap the next.
             // The window bound guarantees that a segment fits its
             // tier, so the overflow lists normally stay empty (they feed the cascade below).
-            hipStream_t st2 = cx.stream2, st3 = cx.stream3, st4 = cx.stream4;
+            hipStream_t st2 = cx.stream2, st3 = cx.stream3, st4 = cx.stream4, st5 = cx.stream5, st6 = cx.stream6;
             HIP_TRY(hipStreamWaitEvent(st2, cx.ev[7], 0));
             HIP_TRY(hipStreamWaitEvent(st3, cx.ev[7], 0));
             HIP_TRY(hipStreamWaitEvent(st4, cx.ev[7], 0));
+            HIP_TRY(hipStreamWaitEvent(st5, cx.ev[7], 0));
+            HIP_TRY(hipStreamWaitEvent(st6, cx.ev[7], 0));
             // Launch order and grid sizes: workgroups are persistent and hold their LDS until the
             // tier's work list is exhausted, so whatever is dispatched first owns the CUs.  The
             // critical path of a pass is the longest tandem-array segment of the heavy tiers
@@ -382,119 +409,116 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             // start at once instead of queueing behind another tier's bulk.
             const char *order_env = getenv("ASGART_TIER_ORDER");
             const std::string tier_order = order_env ? order_env : kTierOrder;
-            auto grid_of = [&](int tier, uint64_t dflt) -> unsigned {
-                char name[32];
-                snprintf(name, sizeof name, "ASGART_GRID%d", tier);
-                const char *e = getenv(name);
-                const uint64_t gmax = e ? (uint64_t)std::max(1, atoi(e)) : dflt;
-                return (unsigned)std::min<uint64_t>(n_t[tier - 1], gmax);
-            };
-            uint64_t seg_off[6] = {0, 0, 0, 0, 0, 0};
-            for (int t = 1; t <= 5; ++t) seg_off[t] = seg_off[t - 1] + n_t[t - 1];
-            auto launch_tier = [&](int tier) {
-                if (tier < 1 || tier > 5 || !n_t[tier - 1]) return;
-                ep.seg_list = order + seg_off[tier - 1];
-                ep.n_seg_ptr = d_ctr + CT_N1 + (tier - 1);
-                ep.cursor = d_ctr + CT_CUR1 + (tier - 1);
-                ep.ovf_list = tier < 5 ? ovf[tier - 1] : nullptr;
-                ep.ovf_count = d_ctr + CT_OVF1 + (tier - 1);
+            // one launch of tier `tier`'s kernel over the list described by ep
+            auto launch_kernel = [&](int tier, uint64_t n_items, hipStream_t st) {
+                auto grid = [&](uint64_t dflt) -> unsigned {
+                    char name[32];
+                    snprintf(name, sizeof name, "ASGART_GRID%d", tier);
+                    const char *e = getenv(name);
+                    return (unsigned)std::min<uint64_t>(n_items, e ? (uint64_t)std::max(1, atoi(e)) : dflt);
+                };
                 switch (tier) {
                 case 1:
-                    extend_kernel<SlotT, kArmCapSmall><<<grid_of(1, kGrid1), 64, 0, s>>>(ep);
-                    PROF_TIER("1", s, n_t[0]);
+                    extend_kernel<SlotT, kArmCapSmall><<<grid(kGrid1), 64, 0, st>>>(ep);
                     break;
                 case 2:
-                    if (arms_wave)
-                        extend_arms_kernel<SlotT, kWaveArmsLayers<SlotT>, 64, kWaveArmsHits, 512, 3, false><<<grid_of(2, kGrid2Arms), 64, 0, st2>>>(ep);
+                    if (arms_kernel)
+                        extend_arms_kernel<SlotT, kWaveArmsLayers<SlotT>, 64, kWaveArmsHits, 512, 3, false><<<grid(kGrid2Arms), 64, 0, st>>>(ep);
                     else
-                        extend_heavy_kernel<SlotT, kArmCapMid, kMidThreads, 0><<<grid_of(2, kGrid2), kMidThreads, 0, st2>>>(ep);
-                    PROF_TIER("2", st2, n_t[1]);
+                        extend_heavy_kernel<SlotT, kArmCapMid, kMidThreads, 0><<<grid(kGrid2), kMidThreads, 0, st>>>(ep);
                     break;
                 case 3:
-                    if (arms_kernel)
-                        extend_arms_kernel<SlotT, kLongArmsLayers<SlotT>, 1024, kHitBatch, 1024, 4, false, true, kPoleLdsPad><<<grid_of(3, kGrid3), 1024, 0, st3>>>(ep);
-                    else if constexpr (sizeof(SlotT) == 4)
-                        extend_heavy_kernel<SlotT, kArmCapBig32, kHeavyThreads, 0><<<grid_of(3, kGrid3), kHeavyThreads, 0, st3>>>(ep);
-                    else
-                        extend_heavy_kernel<SlotT, kArmCapBig64, kHeavyThreads, 0><<<grid_of(3, kGrid3), kHeavyThreads, 0, st3>>>(ep);
-                    PROF_TIER("3", st3, n_t[2]);
+                    extend_arms_kernel<SlotT, kLongArmsLayers<SlotT>, 1024, kHitBatch, 1024, 4, false, true, kPoleLdsPad><<<grid(256), 1024, 0, st>>>(ep);
                     break;
                 case 4:
                     if (arms_kernel)
-                        extend_arms_kernel<SlotT, kArmsLayers<SlotT>, kHeavyThreads, kHitBatch, 1024, 4, false, true><<<grid_of(4, kGrid4Arms), kHeavyThreads, 0, st4>>>(ep);
+                        extend_arms_kernel<SlotT, kMidArmsLayers<SlotT>, 256, kWaveArmsHits, 512, 4, false, true><<<grid(256 * 4), 256, 0, st>>>(ep);
+                    else if constexpr (sizeof(SlotT) == 4)
+                        extend_heavy_kernel<SlotT, kArmCapBig32, kHeavyThreads, 0><<<grid(256), kHeavyThreads, 0, st>>>(ep);
                     else
-                        extend_heavy_kernel<SlotT, caph, kHeavyThreads, 1><<<grid_of(4, kGrid4), kHeavyThreads, 0, st4>>>(ep);
-                    PROF_TIER("4", st4, n_t[3]);
+                        extend_heavy_kernel<SlotT, kArmCapBig64, kHeavyThreads, 0><<<grid(256), kHeavyThreads, 0, st>>>(ep);
+                    break;
+                case 5:
+                    extend_arms_kernel<SlotT, kMidArmsLayers<SlotT>, 512, kHitBatch, 1024, 4, false, true><<<grid(256 * 2), 512, 0, st>>>(ep);
+                    break;
+                case 6:
+                    if (arms_kernel)
+                        extend_arms_kernel<SlotT, kArmsLayers<SlotT>, kHeavyThreads, kHitBatch, 1024, 4, false, true><<<grid(256), kHeavyThreads, 0, st>>>(ep);
+                    else
+                        extend_heavy_kernel<SlotT, caph, kHeavyThreads, 1><<<grid(256), kHeavyThreads, 0, st>>>(ep);
                     break;
                 default:
-                    extend_heavy_kernel<SlotT, capg, kHeavyThreads, 2><<<grid_of(5, kGrid5), kHeavyThreads, 0, st4>>>(ep);
-                    PROF_TIER("5", st4, n_t[4]);
+                    extend_heavy_kernel<SlotT, capg, kHeavyThreads, 2><<<grid(256), kHeavyThreads, 0, st>>>(ep);
                     break;
                 }
+            };
+            hipStream_t tier_stream[kTiers + 1] = {s, s, st2, st3, st4, st5, st6, st3};
+            auto launch_tier = [&](int tier) {
+                if (tier < 1 || tier > kTiers || !n_t[tier - 1]) return;
+                ep.seg_list = order + seg_off[tier - 1];
+                ep.n_seg_ptr = d_ctr + CT_N1 + (tier - 1);
+                ep.cursor = d_ctr + CT_CUR1 + (tier - 1);
+                ep.ovf_list = tier < kTiers ? ovf[tier - 1] : nullptr;
+                ep.ovf_count = d_ctr + CT_OVF1 + (tier - 1);
+                launch_kernel(tier, n_t[tier - 1], tier_stream[tier]);
+#ifdef ASGART_PROFILE_EXTEND
+                char tag[8];
+                snprintf(tag, sizeof tag, "%d", tier);
+                PROF_TIER(tag, tier_stream[tier], n_t[tier - 1]);
+#endif
             };
             for (char c : tier_order) launch_tier(c - '0');
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(cx.ev[5], st2));
             HIP_TRY(hipEventRecord(cx.ev[6], st3));
             HIP_TRY(hipEventRecord(cx.ev[8], st4));
+            HIP_TRY(hipEventRecord(cx.ev[9], st5));
+            HIP_TRY(hipEventRecord(cx.ev[10], st6));
             HIP_TRY(hipStreamWaitEvent(s, cx.ev[5], 0));
             HIP_TRY(hipStreamWaitEvent(s, cx.ev[6], 0));
             HIP_TRY(hipStreamWaitEvent(s, cx.ev[8], 0));
+            HIP_TRY(hipStreamWaitEvent(s, cx.ev[9], 0));
+            HIP_TRY(hipStreamWaitEvent(s, cx.ev[10], 0));
             HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, sizeof(h_ctr), hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
             PROF_DUMP("concurrent tiers");
-            n_overflow = h_ctr[CT_OVF1] + h_ctr[CT_OVF2] + h_ctr[CT_OVF3] + h_ctr[CT_OVF4];
-            if (getenv("ASGART_DEBUG"))
-                fprintf(stderr, "[asgart] overflow out of tiers 1-4: %llu %llu %llu %llu\n", h_ctr[CT_OVF1],
-                        h_ctr[CT_OVF2], h_ctr[CT_OVF3], h_ctr[CT_OVF4]);
-            n_heavy = n_t[2] + n_t[3] + n_t[4];
-            // ---- cascade for the segments a tier gave up on (capacity or cost) -----------------
+            n_overflow = 0;
+            for (int t = 1; t < kTiers; ++t) n_overflow += h_ctr[CT_OVF1 + t - 1];
+            if (getenv("ASGART_DEBUG")) {
+                fprintf(stderr, "[asgart] overflow out of tiers 1..%d:", kTiers - 1);
+                for (int t = 1; t < kTiers; ++t) fprintf(stderr, " %llu", (unsigned long long)h_ctr[CT_OVF1 + t - 1]);
+                fprintf(stderr, "\n");
+            }
+            n_heavy = 0;
+            for (int t = 3; t <= kTiers; ++t) n_heavy += n_t[t - 1];
+            // ---- cascade: what tier t gave up on is re-run from its start by the next tier that
+            // is in use and holds more arms (its own overflow is appended to that tier's list) ------
             const auto t_casc0 = std::chrono::steady_clock::now();
-            for (int tier = 2; tier <= 5; ++tier) {
-                const int src = tier - 2;  // overflow list written by tier-1 level kernels
-                const uint64_t n_ovf = h_ctr[CT_OVF1 + src];
+            for (int src = 1; src < kTiers; ++src) {
+                const uint64_t n_ovf = h_ctr[CT_OVF1 + src - 1];
                 if (!n_ovf) continue;
+                int dst = src + 1;
+                while (dst < kTiers && (!tier_enabled(dst) || tier_cap[dst] <= tier_cap[src])) ++dst;
                 HIP_TRY(hipMemcpyAsync(d_ctr + CT_NF, &n_ovf, 8, hipMemcpyHostToDevice, s));
                 HIP_TRY(hipMemsetAsync(d_ctr + CT_CURF, 0, 8, s));
-                ep.seg_list = ovf[src];
+                ep.seg_list = ovf[src - 1];
                 ep.n_seg_ptr = d_ctr + CT_NF;
                 ep.cursor = d_ctr + CT_CURF;
-                ep.ovf_list = tier < 5 ? ovf[src + 1] : nullptr;
-                ep.ovf_count = d_ctr + CT_OVF1 + src + 1;  // appended behind what is already there
+                ep.ovf_list = dst < kTiers ? ovf[dst - 1] : nullptr;
+                ep.ovf_count = d_ctr + CT_OVF1 + dst - 1;  // appended behind what is already there
                 ep.escalate_cost = 0xFFFFFFFFu;
                 ep.cap_limit = 0xFFFFFFFFu;
-                const unsigned bw = (unsigned)std::min<uint64_t>(n_ovf, 256ull);
-                if (tier == 2) {
-                    const unsigned mw = (unsigned)std::min<uint64_t>(n_ovf, 256ull * 3ull);
-                    if (arms_wave)
-                        extend_arms_kernel<SlotT, kWaveArmsLayers<SlotT>, 64, kWaveArmsHits, 512, 3, false><<<(unsigned)std::min<uint64_t>(n_ovf, kGrid2Arms), 64, 0, s>>>(ep);
-                    else
-                        extend_heavy_kernel<SlotT, kArmCapMid, kMidThreads, 0><<<mw, kMidThreads, 0, s>>>(ep);
-                } else if (tier == 3) {
-                    if (arms_kernel)
-                        extend_arms_kernel<SlotT, kLongArmsLayers<SlotT>, 1024, kHitBatch, 1024, 4, false, true, kPoleLdsPad><<<bw, 1024, 0, s>>>(ep);
-                    else if constexpr (sizeof(SlotT) == 4)
-                        extend_heavy_kernel<SlotT, kArmCapBig32, kHeavyThreads, 0><<<bw, kHeavyThreads, 0, s>>>(ep);
-                    else
-                        extend_heavy_kernel<SlotT, kArmCapBig64, kHeavyThreads, 0><<<bw, kHeavyThreads, 0, s>>>(ep);
-                } else if (tier == 4) {
-                    if (arms_kernel)
-                        extend_arms_kernel<SlotT, kArmsLayers<SlotT>, kHeavyThreads, kHitBatch, 1024, 4, false, true><<<bw, kHeavyThreads, 0, s>>>(ep);
-                    else
-                        extend_heavy_kernel<SlotT, caph, kHeavyThreads, 1><<<bw, kHeavyThreads, 0, s>>>(ep);
-                } else {
-                    extend_heavy_kernel<SlotT, capg, kHeavyThreads, 2><<<bw, kHeavyThreads, 0, s>>>(ep);
-                }
+                launch_kernel(dst, n_ovf, s);
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, sizeof(h_ctr), hipMemcpyDeviceToHost, s));
                 HIP_TRY(hipStreamSynchronize(s));
-                PROF_DUMP(tier == 2 ? "cascade2" : (tier == 3 ? "cascade3" : (tier == 4 ? "cascade4" : "cascade5")));
+                PROF_DUMP("cascade");
             }
             ms_tier2 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() -
                                                                  t_casc0).count();
-            if (h_ctr[CT_OVF5]) {
+            if (h_ctr[CT_OVF1 + kTiers - 1]) {
                 set_error("%llu segment(s) need more than %d simultaneously live arms; "
-                          "not supported by this build", (unsigned long long)h_ctr[CT_OVF5],
+                          "not supported by this build", (unsigned long long)h_ctr[CT_OVF1 + kTiers - 1],
                           sizeof(SlotT) == 4 ? kArmCapGlobal32 : kArmCapGlobal64);
                 return ASGART_E_CAP;
             }

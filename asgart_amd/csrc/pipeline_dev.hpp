@@ -22,6 +22,8 @@ constexpr int kScanItems = 8;       // probes per thread in the scan kernels
 constexpr int kScanBlock = 256;
 constexpr int kScanTile = kScanItems * kScanBlock;
 
+constexpr int kTiers = 7;  // extension tiers (see the placement in pipeline.hip)
+
 // device counters (u64 each)
 enum Counter {
     CT_BIG = 0,       // entries in big_list
@@ -40,12 +42,14 @@ enum Counter {
     CT_OVF_CURSOR,
     CT_AMBIG,         // sharding: start decisions that need a longer look-back
     CT_RANOUT,        // sharding: segments that ran past the look-ahead window
-    CT_N1 = 34, CT_N2, CT_N3, CT_N4, CT_N5, CT_NF,           // list lengths: tiers 1-5, fallback launch
-    CT_CUR1, CT_CUR2, CT_CUR3, CT_CUR4, CT_CUR5, CT_CURF,   // their work cursors
-    CT_OVF1, CT_OVF2, CT_OVF3, CT_OVF4, CT_OVF5,            // segments handed on to tier 2..5 / nobody
     CT_HIST_PEAK = 72,   // diagnostic build: log2 histograms per launch (16 bins each)
     CT_HIST_PROBES = 88,
-    CT_COUNT = 104
+    CT_N1 = 104,       // list lengths of the extension tiers 1..kTiers (kTiers entries)
+    CT_NF = 111,       // ... of a cascade launch
+    CT_CUR1 = 112,     // work cursors of the tiers (kTiers entries)
+    CT_CURF = 119,
+    CT_OVF1 = 120,     // segments tier t gave up on (kTiers entries; the last one has nowhere to go)
+    CT_COUNT = 128
 };
 
 __device__ inline int chunk_of(const ChunkTable &ch, uint32_t g) {
@@ -1063,7 +1067,7 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
 //     never overflows (the cascade only serves the test knobs).
 //     key = (tier-1) << 29 | (2^29-1 - min(total hits, 2^29-1)): ascending sort = tier, longest first.
 struct PlaceParams {
-    uint32_t cap1, cap2, cap3, cap4;  // arm capacities of tiers 1..4 (tier 5 takes the rest)
+    uint32_t cap[kTiers - 1];   // live-arm capacity of tiers 1..kTiers-1 (0: tier unused); the last takes the rest
     uint32_t sum1;              // segments with more hits than this never go to the one-wave tier
     int force_tier;             // tests: minimum tier for segments with a multi-hit probe
     int use_filter;             // 0: flag every hit (k >= M, huge gaps or cardinalities)
@@ -1074,11 +1078,13 @@ struct PlaceParams {
 // tier 3 (lowest per-probe latency, one workgroup of 1024 threads per CU) only takes the long
 // segments whose serial chain is the critical path of a pass; everything else goes by capacity.
 __device__ inline int place_tier(uint32_t bound, unsigned long long sum, uint32_t n_probes, const PlaceParams &pp) {
-    if (bound <= pp.cap1 && sum <= pp.sum1) return 1;
-    if (pp.long3 && n_probes >= pp.long3 && bound <= pp.cap3) return 3;
-    if (bound <= pp.cap2) return 2;
-    if (!pp.long3 && bound <= pp.cap3) return 3;
-    return bound <= pp.cap4 ? 4 : 5;
+    if (bound <= pp.cap[0] && sum <= pp.sum1) return 1;
+    if (pp.long3 && n_probes >= pp.long3 && bound <= pp.cap[2]) return 3;
+    for (int t = 2; t < kTiers; ++t) {
+        if (t == 3 && pp.long3) continue;
+        if (bound <= pp.cap[t - 1]) return t;
+    }
+    return kTiers;
 }
 
 constexpr uint32_t kFilterBits = 13;  // 8192 16-bit counters = 16 KB of LDS per wave
@@ -1206,7 +1212,7 @@ __global__ __launch_bounds__(64) void seg_prepass_kernel(RunParams rp, const uin
         if (rp.tstar > 64u) bound = 0xFFFFFFFFu;  // no estimate for huge gap settings: largest tier
         if (lane == 0) {
             int tier = place_tier(bound, sum, t_idx, pp);
-            if (mx > 1 && pp.force_tier > tier) tier = min(pp.force_tier, 5);
+            if (mx > 1 && pp.force_tier > tier) tier = min(pp.force_tier, kTiers);
 #ifdef ASGART_PROFILE_EXTEND
             if (g0 == 4841535u || g0 == 22631158u) printf("[prepass] g0=%u sidx=%llu bound=%u sum=%llu mx=%u tier=%d t_idx=%u\n", g0, (unsigned long long)sidx, bound, sum, mx, tier, t_idx);
 #endif
@@ -1295,7 +1301,7 @@ __global__ __launch_bounds__(64) void seg_stats_kernel(RunParams rp, const uint3
         if (rp.tstar > 64u) bound = 0xFFFFFFFFu;
         if (lane == 0) {
             int tier = place_tier(bound, sum, n_probes, pp);
-            if (mx > 1 && pp.force_tier > tier) tier = min(pp.force_tier, 5);
+            if (mx > 1 && pp.force_tier > tier) tier = min(pp.force_tier, kTiers);
             const uint32_t s29 = sum > 0x1FFFFFFFull ? 0x1FFFFFFFu : (uint32_t)sum;
             keys[sidx] = (((uint32_t)tier - 1u) << 29) | (0x1FFFFFFFu - s29);
             vals[sidx] = g0;
@@ -1310,7 +1316,7 @@ __global__ void tier_bounds_kernel(const uint32_t *__restrict__ sorted_keys,
                                    const unsigned long long *__restrict__ n_seg_ptr,
                                    unsigned long long *__restrict__ ctr) {
     const int t = threadIdx.x;  // 0..4
-    if (t >= 5) return;
+    if (t >= kTiers) return;
     const uint64_t n = *n_seg_ptr;
     auto first_ge = [&](uint32_t tier_idx) {  // first position with (key >> 29) >= tier_idx
         uint64_t lo = 0, hi = n;

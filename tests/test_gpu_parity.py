@@ -289,24 +289,25 @@ def test_overflow_cascade_gives_identical_results(hiplib, cap, monkeypatch):
             assert np.array_equal(offs, eoffs) and np.array_equal(sds, esds), (cap, reverse)
 
 
-@pytest.mark.parametrize("tier", [2, 3, 4, 5, "4-lds", "4-arms-filter"])
+@pytest.mark.parametrize("tier", [2, 3, 4, 5, 6, 7, "2-lds", "4-lds", "6-lds", "6-filter"])
 @pytest.mark.parametrize("name", ["dense_repeats", "satellites", "long_sds"])
 def test_escalation_tiers_give_identical_results(hiplib, name, tier, monkeypatch):
-    """Segments that do not fit the one-wave kernel go to larger tiers (arm-resident workgroup kernel;
-    LDS-array workgroup kernels; HBM-scratch kernel).  Forcing every segment with a multi-hit probe
-    into tier `tier` must not change a single ProtoSD.  Tier 4 is the arm-resident kernel by default,
-    "4-lds" the hybrid LDS-array kernel it replaced (still used when max_cardinality > 1024)."""
+    """Segments that do not fit the one-wave kernel go to larger tiers: the arm-resident kernel in five
+    shapes (2: one wave, 3: 1024 threads for long segments, 4/5/6: 256/512/512 threads by capacity), the
+    HBM-scratch kernel (7), or -- "N-lds", what max_cardinality > 1024 selects -- the LDS-array workgroup
+    kernels in tiers 2, 4 and 6.  Forcing every segment with a multi-hit probe into tier `tier` must not
+    change a single ProtoSD."""
     pr, cli = _battery_case(name)
     oidx = oracle.Index.build(pr.data)
-    if tier == "4-lds":
-        monkeypatch.setenv("ASGART_ARMS_KERNEL", "0")
-        tier = 4
-    arms_filter = tier == "4-arms-filter"
-    if arms_filter:
-        tier = 4
-    filt = "1" if tier % 2 else "0"
+    filt = False
+    if isinstance(tier, str):
+        tier, variant = tier.split("-")
+        tier = int(tier)
+        if variant == "lds":
+            monkeypatch.setenv("ASGART_ARMS_KERNEL", "0")
+        filt = variant == "filter"
     monkeypatch.setenv("ASGART_FORCE_TIER", str(tier))
-    monkeypatch.setenv("ASGART_FILTER", filt if not arms_filter else "1")
+    monkeypatch.setenv("ASGART_FILTER", "1" if (filt or tier % 2) else "0")
     with asgart_amd.Index(pr.data, oidx.sa) as idx:
         for reverse, complement in ((False, False), (True, True)):
             st = asgart_amd.RunSettings.from_cli(reverse=reverse, complement=complement, **cli)
@@ -317,6 +318,20 @@ def test_escalation_tiers_give_identical_results(hiplib, name, tier, monkeypatch
             assert np.array_equal(offs, eoffs) and np.array_equal(sds, esds), (name, tier, reverse)
 
 
+def test_large_max_cardinality_uses_the_lds_array_tiers(hiplib):
+    """max_cardinality above the arm-resident kernel's staging area (1024 hits per probe) switches the
+    placement to the LDS-array kernels; results still match the oracle."""
+    pr, cli = _battery_case("dense_repeats")
+    cli = dict(cli, max_cardinality=3000)
+    oidx = oracle.Index.build(pr.data)
+    with asgart_amd.Index(pr.data, oidx.sa) as idx:
+        for rc in (False, True):
+            st = asgart_amd.RunSettings.from_cli(reverse=rc, complement=rc, **cli)
+            offs, sds = idx.search_duplications_raw(pr.chunks, st)
+            eoffs, esds = oidx.run_raw(pr.chunks, oracle.make_settings(reverse=rc, complement=rc, **cli), threads=4)
+            assert np.array_equal(offs, eoffs) and np.array_equal(sds, esds), rc
+
+
 @pytest.mark.parametrize("levels", [0, 1, 2])
 def test_arm_kernel_window_levels(hiplib, levels, monkeypatch):
     """The arm-resident kernel looks hits up in per-probe hash tables at four bucket widths and falls
@@ -324,7 +339,7 @@ def test_arm_kernel_window_levels(hiplib, levels, monkeypatch):
     of `long_sds` take the coarser paths and the scan."""
     pr, cli = _battery_case("long_sds")
     oidx = oracle.Index.build(pr.data)
-    monkeypatch.setenv("ASGART_FORCE_TIER", "4")
+    monkeypatch.setenv("ASGART_FORCE_TIER", "5")
     monkeypatch.setenv("ASGART_TEST_LEVELS", str(levels))
     with asgart_amd.Index(pr.data, oidx.sa) as idx:
         for rc in (False, True):
