@@ -57,6 +57,16 @@ struct RunParams {
     uint8_t reverse, complement;
 };
 
+// One emitted duplication arm, keyed for the reference's output order (chunk order, discovery order
+// inside the chunk, arm order inside the family).
+struct SdRec {
+    uint32_t g_start;     // first probe of the segment: sort key 1
+    uint32_t fam_seq;     // family ordinal inside the segment: sort key 2
+    uint32_t create_seq;  // creation number inside the family: sort key 3; ~0u = tombstone
+    uint32_t pad;
+    asgart_proto_sd sd;
+};
+
 struct Workspace {
     DevBuf chunks;     // ch_start[nc], ch_len[nc] (u64) then pbase[nc+1] (u32)
     DevBuf p_lo;       // SlotT[P]
@@ -73,6 +83,7 @@ struct Workspace {
     DevBuf scratch;    // arm storage of the global heavy tier
     DevBuf hit_flag;   // u8 per CSR entry: continuation flag (pre-pass)
     DevBuf seg_keys, seg_vals, sort_tmp;  // segment placement: (tier, work) keys, double-buffered
+    DevBuf rec_k32, rec_k64, rec_idx, rec_sorted;  // ordering of the output records
     DevBuf pat;        // pattern upload scratch
     DevBuf out_a, out_b;
 };
@@ -190,6 +201,8 @@ int32_t run_search(asgart_index *idx, const uint64_t *chunks, int64_t n_chunks,
                    const asgart_settings *st, int32_t shard, int32_t n_shards, bool want_csr,
                    asgart_families *fam_out, std::vector<uint8_t> *status_out,
                    std::vector<uint64_t> *rowoff_out, std::vector<uint64_t> *hits_out);
+// records -> reference order (g_start, fam_seq, create_seq), stable; result in w.rec_sorted
+int32_t sort_records(Workspace &w, const SdRec *recs, uint64_t n, hipStream_t s);
 int32_t sort_segments(Workspace &w, uint32_t *keys, uint32_t *vals, uint64_t n, hipStream_t s,
                       const uint32_t **sorted_vals, const uint32_t **sorted_keys);
 int32_t text_is_dna(const uint8_t *d_text, int64_t n, hipStream_t s, bool *dna);

@@ -537,19 +537,16 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
         HIP_TRY(hipEventRecord(cx.ev[4], s));
         const uint64_t n_rec = h_ctr[CT_SD];
         h_recs.resize((size_t)n_rec);
-        if (n_rec)
-            HIP_TRY(hipMemcpyAsync(h_recs.data(), w.fam_sds.p, (size_t)n_rec * sizeof(SdRec),
-                                   hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
         // Reference order: chunk order, discovery order inside the chunk, arm order
-        // inside the family == (segment start probe, family ordinal, creation number).
-        // A tombstone voids its family; segments re-run in the second tier emit some
+        // inside the family == (segment start probe, family ordinal, creation number): sorted on
+        // the GPU.  A tombstone voids its family; segments re-run by a later tier emit some
         // records twice (same key): keep one copy.
-        std::sort(h_recs.begin(), h_recs.end(), [](const SdRec &a, const SdRec &b) {
-            if (a.g_start != b.g_start) return a.g_start < b.g_start;
-            if (a.fam_seq != b.fam_seq) return a.fam_seq < b.fam_seq;
-            return a.create_seq < b.create_seq;
-        });
+        if (n_rec) {
+            RC_TRY(sort_records(w, w.fam_sds.as<SdRec>(), n_rec, s));
+            HIP_TRY(hipMemcpyAsync(h_recs.data(), w.rec_sorted.p, (size_t)n_rec * sizeof(SdRec),
+                                   hipMemcpyDeviceToHost, s));
+        }
+        HIP_TRY(hipStreamSynchronize(s));
         for (size_t f0 = 0; f0 < h_recs.size();) {
             size_t f1 = f0;
             while (f1 < h_recs.size() && h_recs[f1].g_start == h_recs[f0].g_start &&

@@ -493,14 +493,6 @@ __global__ __launch_bounds__(256) void fill_big_kernel(IndexView<SlotT> ix, RunP
 //   * <= 64 live arms: one arm per lane, in registers; otherwise LDS arrays.
 //   * the hit rows of up to 64 consecutive probes are contiguous in the CSR and
 //     are staged through LDS with one coalesced load.
-struct SdRec {
-    uint32_t g_start;     // first probe of the segment: sort key 1
-    uint32_t fam_seq;     // family ordinal inside the segment: sort key 2
-    uint32_t create_seq;  // creation number inside the family: sort key 3; ~0u = tombstone
-    uint32_t pad;
-    asgart_proto_sd sd;
-};
-
 constexpr uint32_t kTombstone = 0xFFFFFFFFu;
 
 // Diagnostic build only (-DASGART_PROFILE_EXTEND): per-phase cycle sums of the extension kernel

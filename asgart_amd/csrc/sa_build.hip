@@ -259,6 +259,62 @@ int32_t sort_segments(Workspace &w, uint32_t *keys, uint32_t *vals, uint64_t n, 
     return 0;
 }
 
+namespace {
+__global__ void rec_keys32_kernel(const SdRec *__restrict__ recs, uint64_t n, uint32_t *__restrict__ k32,
+                                  uint32_t *__restrict__ idx) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        k32[i] = recs[i].create_seq;
+        idx[i] = (uint32_t)i;
+    }
+}
+__global__ void rec_keys64_kernel(const SdRec *__restrict__ recs, const uint32_t *__restrict__ idx, uint64_t n,
+                                  uint64_t *__restrict__ k64) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) {
+        const SdRec &r = recs[idx[j]];
+        k64[j] = ((uint64_t)r.g_start << 32) | r.fam_seq;
+    }
+}
+__global__ void rec_gather_kernel(const SdRec *__restrict__ recs, const uint32_t *__restrict__ idx, uint64_t n,
+                                  SdRec *__restrict__ out) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) out[j] = recs[idx[j]];
+}
+}  // namespace
+
+// Output records in the reference's order: LSD over the composite key -- stable radix sort by the
+// creation number, then by (segment start probe, family ordinal) -- on an index, then one gather.
+int32_t sort_records(Workspace &w, const SdRec *recs, uint64_t n, hipStream_t s) {
+    if (n == 0) return 0;
+    if (n >= 0xFFFFFFFFull) {
+        set_error("more than 2^32 output records in one call");
+        return ASGART_E_CAP;
+    }
+    RC_TRY(w.rec_k32.reserve((size_t)n * 4 * 2));
+    RC_TRY(w.rec_idx.reserve((size_t)n * 4 * 2));
+    RC_TRY(w.rec_k64.reserve((size_t)n * 8 * 2));
+    RC_TRY(w.rec_sorted.reserve((size_t)n * sizeof(SdRec)));
+    uint32_t *k32 = w.rec_k32.as<uint32_t>(), *idx = w.rec_idx.as<uint32_t>();
+    uint64_t *k64 = w.rec_k64.as<uint64_t>();
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    rec_keys32_kernel<<<nb, 256, 0, s>>>(recs, n, k32, idx);
+    rocprim::double_buffer<uint32_t> kd(k32, k32 + n), vd(idx, idx + n);
+    size_t bytes = 0;
+    HIP_TRY(rocprim::radix_sort_pairs(nullptr, bytes, kd, vd, (size_t)n, 0, 32, s));
+    RC_TRY(w.sort_tmp.reserve(bytes));
+    HIP_TRY(rocprim::radix_sort_pairs(w.sort_tmp.p, bytes, kd, vd, (size_t)n, 0, 32, s));
+    rec_keys64_kernel<<<nb, 256, 0, s>>>(recs, vd.current(), n, k64);
+    rocprim::double_buffer<uint64_t> kd2(k64, k64 + n);
+    bytes = 0;
+    HIP_TRY(rocprim::radix_sort_pairs(nullptr, bytes, kd2, vd, (size_t)n, 0, 64, s));
+    RC_TRY(w.sort_tmp.reserve(bytes));
+    HIP_TRY(rocprim::radix_sort_pairs(w.sort_tmp.p, bytes, kd2, vd, (size_t)n, 0, 64, s));
+    rec_gather_kernel<<<nb, 256, 0, s>>>(recs, vd.current(), n, w.rec_sorted.as<SdRec>());
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int32_t sa_build_device(const uint8_t *d_text, int64_t n, void *d_sa, bool wide, hipStream_t stream) {
     bool dna = false;
     RC_TRY(text_is_dna(d_text, n, stream, &dna));
