@@ -417,3 +417,33 @@ def test_fasta_to_run_result_end_to_end(hiplib, tmp_path, rc):
     assert [m["name"] for m in res["strand"]["map"]] == [n for n, _ in recs]
     assert all(sd["reversed"] == rc and sd["complemented"] == rc for fam in res["families"] for sd in fam)
     assert postprocess.to_json(res).startswith('{\n  "strand": {\n    "name": ')
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_sweep_default_and_forced_tiers(hiplib, seed, monkeypatch):
+    """Seeded random genomes x random settings (k, gap, min length, cardinality, strand mode), first with
+    the default placement and then with every multi-hit segment forced through a randomly chosen tier."""
+    rng = np.random.default_rng(5000 + seed)
+    lens = [int(x) for x in rng.integers(60_000, 260_000, size=int(rng.integers(1, 4)))]
+    gen = dict(sd_per_mb=float(rng.uniform(5, 60)), sd_len=(500, int(rng.integers(2_000, 40_000))),
+               alu_frac=float(rng.uniform(0.0, 0.25)), l1_frac=float(rng.uniform(0.0, 0.05)),
+               sat_per_record=int(rng.integers(0, 3)), sat_copies=(20, int(rng.integers(60, 500))),
+               alu_div=(0.01, float(rng.uniform(0.05, 0.15))))
+    recs = synth.make_genome(lens, seed=int(rng.integers(1, 1 << 30)), **gen)
+    pr = prep.prepare_records(recs, skip_masked=bool(rng.integers(0, 2)))
+    k = int(rng.choice([10, 12, 16, 20, 21]))
+    cli = dict(k=k, gap=int(rng.choice([0, 30, 100, 250])), min_length=int(rng.choice([100, 300, 1000])),
+               max_cardinality=int(rng.choice([30, 200, 500, 1500])))
+    rc = bool(rng.integers(0, 2))
+    oidx = oracle.Index.build(pr.data)
+    eoffs, esds = oidx.run_raw(pr.chunks, oracle.make_settings(reverse=rc, complement=rc, **cli), threads=4)
+    st = asgart_amd.RunSettings.from_cli(reverse=rc, complement=rc, **cli)
+    with asgart_amd.Index(pr.data, oidx.sa) as idx:
+        offs, sds = idx.search_duplications_raw(pr.chunks, st)
+        assert np.array_equal(offs, eoffs) and np.array_equal(sds, esds), ("default", cli, rc)
+        tier = int(rng.integers(2, 8))
+        monkeypatch.setenv("ASGART_FORCE_TIER", str(tier))
+        if rng.integers(0, 2):
+            monkeypatch.setenv("ASGART_FILTER", "1")
+        offs, sds = idx.search_duplications_raw(pr.chunks, st)
+        assert np.array_equal(offs, eoffs) and np.array_equal(sds, esds), ("forced", tier, cli, rc)
