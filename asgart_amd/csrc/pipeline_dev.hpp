@@ -1985,7 +1985,8 @@ __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
         // owner pass: mailboxes (with_msg) / ageing by `add` / retirement / creation.
         // i, off: the probe whose hits are referenced by the mailboxes; seq_base: creation number
         // of its first new arm.  Block-uniform on exit: A, n_free, H.
-        auto owner_pass = [&](uint32_t add, bool with_msg, uint64_t i, uint32_t off, uint32_t seq_base) {
+        // `pre`: work that shares the pass's barrier interval (P0 of the next probe)
+        auto owner_pass = [&](uint32_t add, bool with_msg, uint64_t i, uint32_t off, uint32_t seq_base, auto &&pre) {
             const uint32_t n_layers = (H + NT - 1u) / NT;
             const uint32_t freed_base = par ? freed_seen1 : freed_seen0;
 #pragma unroll
@@ -2048,6 +2049,7 @@ __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
                     }
                 }
             }
+            pre();
             __syncthreads();
             const uint32_t freed_now = uni(s_nfreed[par]);
             const uint32_t nd = freed_now - freed_base;
@@ -2060,6 +2062,32 @@ __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
                 n_free = 0;
             }
         };
+        // P0: index the hits of one probe (cnt hits at s_hits[off..]) under generation `gen`
+        auto index_hits = [&](uint32_t cnt, uint32_t off) {
+            for (uint32_t h = tid; h < cnt; h += NT) {
+                const PosT x = s_hits[off + h];
+                s_best[h] = ~0ull;
+                const HeadT mine = PACK ? (HeadT)(((unsigned long long)((gen << 10) | h) << 32) | (uint32_t)x)
+                                        : (HeadT)((gen << 10) | h);
+                HeadT old[kLevels];  // all exchanges in flight before the first result is used
+#pragma unroll
+                for (uint32_t lv = 0; lv < (uint32_t)kLevels; ++lv) {
+                    const uint32_t bkt = (uint32_t)((uint64_t)x >> (bsh + 2u * lv));
+                    old[lv] = atomicExch(&s_head[lv][((bkt * 2654435761u) >> 12) & ((uint32_t)kHT - 1u)], mine);
+                }
+#pragma unroll
+                for (uint32_t lv = 0; lv < (uint32_t)kLevels; ++lv) {
+                    if constexpr (PACK) {
+                        const uint32_t tag = (uint32_t)(old[lv] >> 32);
+                        s_node[lv][h] = (tag >> 10) == gen
+                                            ? ((unsigned long long)(tag & 1023u) << 32) | (uint32_t)old[lv]
+                                            : (unsigned long long)kNoHit << 32;
+                    } else {
+                        s_node[lv][h] = (old[lv] >> 10) == gen ? (uint16_t)(old[lv] & 1023u) : (uint16_t)kNoHit;
+                    }
+                }
+            }
+        };
         auto maybe_close = [&]() {  // the flush of src/automaton.rs:182-200
             if (fam_open && A == 0 && t_proc >= spur_until) {
                 ++fam_seq;
@@ -2070,7 +2098,7 @@ __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
         auto advance_quiet = [&](uint32_t q) {
             quiet += q;
             t_proc += q;
-            if (A > 0) owner_pass(q * step, false, 0, 0, 0);
+            if (A > 0) owner_pass(q * step, false, 0, 0, 0, [] {});
             maybe_close();
             if (A == 0 && quiet >= rp.tstar) done = true;
         };
@@ -2110,6 +2138,7 @@ __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
             PROF_STOP(0);
             PROF_COUNT(1, 1);
             uint32_t pos = 0;
+            bool pre_indexed = false;
             while (!done) {
                 const unsigned long long hmr = pos >= 64 ? 0ull : (hm >> pos) << pos;
                 if (!hmr) break;
@@ -2139,37 +2168,19 @@ __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
                 PROF_COUNT(11, cnt);
                 PROF_MAX(9, A + nfl);
                 PROF_START();
-                // ---- P0: index the hits of this probe ----------------------------------------
-                if (++gen >> kGenBits) {  // generation wrap: clear the tables once
-                    __syncthreads();
-                    clear_tables();
-                    gen = 1;
+                // ---- P0: index the hits of this probe (unless the previous probe's owner pass
+                // already did, in its own barrier interval) -------------------------------------
+                if (!pre_indexed) {
+                    if (++gen >> kGenBits) {  // generation wrap: clear the tables once
+                        __syncthreads();
+                        clear_tables();
+                        gen = 1;
+                        __syncthreads();
+                    }
+                    index_hits(cnt, off);
                     __syncthreads();
                 }
-                for (uint32_t h = tid; h < cnt; h += NT) {
-                    const PosT x = s_hits[off + h];
-                    s_best[h] = ~0ull;
-                    const HeadT mine = PACK ? (HeadT)(((unsigned long long)((gen << 10) | h) << 32) | (uint32_t)x)
-                                            : (HeadT)((gen << 10) | h);
-                    HeadT old[kLevels];  // all exchanges in flight before the first result is used
-#pragma unroll
-                    for (uint32_t lv = 0; lv < (uint32_t)kLevels; ++lv) {
-                        const uint32_t bkt = (uint32_t)((uint64_t)x >> (bsh + 2u * lv));
-                        old[lv] = atomicExch(&s_head[lv][((bkt * 2654435761u) >> 12) & ((uint32_t)kHT - 1u)], mine);
-                    }
-#pragma unroll
-                    for (uint32_t lv = 0; lv < (uint32_t)kLevels; ++lv) {
-                        if constexpr (PACK) {
-                            const uint32_t tag = (uint32_t)(old[lv] >> 32);
-                            s_node[lv][h] = (tag >> 10) == gen
-                                                ? ((unsigned long long)(tag & 1023u) << 32) | (uint32_t)old[lv]
-                                                : (unsigned long long)kNoHit << 32;
-                        } else {
-                            s_node[lv][h] = (old[lv] >> 10) == gen ? (uint16_t)(old[lv] & 1023u) : (uint16_t)kNoHit;
-                        }
-                    }
-                }
-                __syncthreads();
+                pre_indexed = false;
                 PROF_STOP(2);
                 PROF_START();
                 // ---- P1: every arm looks up the hits inside its window ------------------------
@@ -2295,7 +2306,23 @@ __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
                 PROF_STOP(6);
                 PROF_START();
                 // ---- P3: owners apply -----------------------------------------------------------
-                owner_pass(step, true, i, off, seq_base);
+                {
+                    // next hit probe of this staged batch, if any: its P0 rides in this pass's barrier
+                    // interval (nothing in P3 reads the hit tables, s_best or the chain nodes)
+                    const unsigned long long nxt = pos >= 64 ? 0ull : (hm >> pos) << pos;
+                    const bool can_pre = nxt != 0ull && ((gen + 1u) >> kGenBits) == 0u;
+                    uint32_t ncnt = 0, noff = 0;
+                    if (can_pre) {
+                        const uint32_t nb2 = (uint32_t)(__ffsll((long long)nxt) - 1);
+                        ncnt = lane_of(f_l, nb2);
+                        noff = lane_of(rel_l, nb2);
+                        ++gen;
+                    }
+                    owner_pass(step, true, i, off, seq_base, [&] {
+                        if (can_pre) index_hits(ncnt, noff);
+                    });
+                    pre_indexed = can_pre;
+                }
                 fam_open = true;
                 if (spur) spur_until = max(spur_until, t_proc + rp.tstar - 1u);
                 maybe_close();
