@@ -136,14 +136,16 @@ def main():
             idx.search_duplications_raw(pr.chunks, st)
         pass_stats.append(idx.stats(1).as_dict())   # rank-local work counters
 
-    # Timed region.  The library is re-entrant (one internal context per call), so the two passes
-    # of a step can be issued from two host threads (ASGART_BENCH_OVERLAP=1); measured on the
-    # GRCh38-shaped workload that does not help -- the extension tiers already keep the chip
-    # busy -- so the default runs the passes back to back, which also keeps the per-kernel
-    # HIP-event timings clean.
+    # Timed region.  The library is re-entrant (one internal context per call), so the direct and
+    # the RC pass of a step are issued from two host threads and overlap on the GPU.  The critical
+    # path of a pass is one long tandem-array segment (tens of thousands of strictly serial probes
+    # on one CU): overlapped, the rest of the chip works on the other pass meanwhile.  On one GPU
+    # this is worth a few per cent; on a probe-sharded multi-GPU run, where the bulk shrinks with
+    # 1/N and the longest segments do not, it is what keeps a step near max(pass) instead of
+    # sum(pass).  ASGART_BENCH_OVERLAP=0 runs the passes back to back.
     from concurrent.futures import ThreadPoolExecutor
 
-    sequential = not os.environ.get("ASGART_BENCH_OVERLAP")
+    sequential = os.environ.get("ASGART_BENCH_OVERLAP", "1") == "0"
     pool = ThreadPoolExecutor(max_workers=len(settings))
 
     def run_pass(st):
