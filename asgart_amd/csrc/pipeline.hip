@@ -221,6 +221,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
     HIP_TRY(hipEventRecord(cx.ev[0], s));
     probe_count_kernel<SlotT><<<grid_for(W), 256, 0, s>>>(ix, rp, p_lo, p_raw, p_filt, big_list,
                                                          d_ctr);
+    HIP_TRY(hipEventRecord(cx.ev[11], s));
     big_count_kernel<SlotT><<<2048, 256, 0, s>>>(ix, rp, p_lo, p_raw, p_filt, big_list, d_ctr);
     HIP_TRY(hipEventRecord(cx.ev[1], s));
     // ---- K2: scans + segmentation ----------------------------------------------
@@ -595,6 +596,8 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
     stt.heavy_segments = n_heavy;
 
     stt.ms_extend_tier2 = ms_tier2;
+    HIP_TRY(hipEventElapsedTime(&ms, cx.ev[0], cx.ev[11]));
+    stt.ms_probe_count = ms;
     cx.has_last = true;
     return 0;
 }

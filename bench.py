@@ -156,6 +156,7 @@ def main():
     sync()
     t0 = time.perf_counter()
     search_ms = 0.0
+    probe_count_ms = 0.0
     phase_ms = {"search": 0.0, "scan": 0.0, "fill": 0.0, "extend": 0.0, "extend_tier2": 0.0}
     for _ in range(args.steps):
         per_call = []
@@ -172,6 +173,7 @@ def main():
             results = [multi.gather_families(r_[0], r_[1], dist, device=comm_device) for r_ in results]
         for s in per_call:
             search_ms += s.ms_search
+            probe_count_ms += s.ms_probe_count
             for ph in phase_ms:
                 phase_ms[ph] += getattr(s, "ms_" + ph)
     sync()
@@ -219,6 +221,9 @@ def main():
             "frac": round(achieved / HBM_PEAK_GBS, 5),
             "algorithmic_bytes_per_launch": int(alg_bytes / passes),
             "avg_launch_ms": round(search_ms / n_launch, 5),
+            # first kernel of the pair alone (compare with rocprofv3's per-kernel average; with the two
+            # passes overlapped the pair's event span also holds the wait for CUs between the kernels)
+            "probe_count_kernel_ms": round(probe_count_ms / n_launch, 5),
             "traffic": traffic,
         },
         "phases_ms_per_step": {ph: round(v / args.steps, 4) for ph, v in phase_ms.items()},

@@ -74,6 +74,7 @@ typedef struct asgart_stats {
     uint64_t overflow_segments; /* segments re-run with a larger LDS share (tier 2)  */
     double ms_extend_tier2;   /* part of ms_extend spent in the escalation tiers     */
     uint64_t heavy_segments;  /* segments that went on to the block-cooperative tier */
+    double ms_probe_count;    /* probe_count_kernel alone (first kernel of ms_search) */
 } asgart_stats;
 
 typedef struct asgart_index asgart_index;
