@@ -590,6 +590,20 @@ __device__ inline uint32_t arm_threshold(uint64_t left_len, uint32_t G) {
     return thr > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)thr;
 }
 
+// Wave-uniform values the compiler cannot prove uniform (read from LDS, or a lane of a vector):
+// forcing them into scalar registers keeps the per-probe bookkeeping and branches on the scalar
+// unit instead of exec-masked vector code and LDS permutes.
+__device__ inline uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ inline unsigned long long uni(unsigned long long v) {
+    return ((unsigned long long)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v);
+}
+__device__ inline uint32_t lane_of(uint32_t v, uint32_t l) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l);
+}
+__device__ inline unsigned long long lane_of(unsigned long long v, uint32_t l) {
+    return ((unsigned long long)lane_of((uint32_t)(v >> 32), l) << 32) | lane_of((uint32_t)v, l);
+}
+
 template <class PosT, int CAP>
 __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
     __shared__ PosT s_ls[CAP], s_le[CAP], s_rs[CAP], s_re[CAP];
@@ -610,18 +624,26 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
     const uint32_t thr0 = arm_threshold(k, G);
     PROF_DECL;
 
-    // segments are fetched kFetch at a time: one contended global atomic per group
+    // Segments are fetched kFetch at a time (one contended global atomic per group).  The list is
+    // sorted longest first: in its head the members of a group are strided, so that the longest
+    // segments go to different waves instead of eight of them to the same one.
     constexpr unsigned long long kFetch = 8;
-    unsigned long long seg_next = 0, seg_stop = 0;
+    const unsigned long long head_groups = min((unsigned long long)gridDim.x, n_seg / kFetch);
+    const unsigned long long head = head_groups * kFetch;
+    unsigned long long seg_base = 0;
+    uint32_t seg_j = (uint32_t)kFetch;
     for (;;) {
-        if (seg_next == seg_stop) {
+        if (seg_j == (uint32_t)kFetch) {
             unsigned long long sb = 0;
             if (lane == 0) sb = atomicAdd(P.cursor, kFetch);
-            seg_next = __shfl(sb, 0);
-            seg_stop = seg_next + kFetch;
+            seg_base = uni(sb);
+            seg_j = 0;
         }
-        const unsigned long long seg = seg_next++;
-        if (seg >= n_seg) break;
+        const uint32_t j = seg_j++;
+        const unsigned long long seg = seg_base < head ? seg_base / kFetch + (unsigned long long)j * head_groups
+                                                       : seg_base + j;
+        if (seg_base >= n_seg) break;
+        if (seg >= n_seg) continue;
         const uint32_t g0 = P.seg_list[seg];
         PROF_SEG_BEGIN();
         const int c = chunk_of_uniform(rp.ch, g0);
@@ -787,25 +809,23 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
             if (!first_from_global) {
                 const unsigned long long end = nbb == nb ? r_hi : __shfl(r_l, (int)nbb);
                 const uint32_t tot = (uint32_t)(end - base);
-                // all loads in flight before the first LDS write (one HBM round trip, not 16)
-                PosT tmp[kHitBatch / 64];
+                // four loads per lane in flight per round trip; most batches need a single round
+                for (uint32_t r0 = 0; r0 < tot; r0 += 256u) {
+                    PosT tmp[4];
+                    uint8_t ftmp[4];
 #pragma unroll
-                for (int u = 0; u < kHitBatch / 64; ++u) {
-                    const uint32_t r = lane + 64u * u;
-                    tmp[u] = r < tot ? P.hits[base + r] : (PosT)0;
-                }
-                uint8_t ftmp[kHitBatch / 64];
+                    for (int u = 0; u < 4; ++u) {
+                        const uint32_t r = r0 + lane + 64u * u;
+                        tmp[u] = r < tot ? P.hits[base + r] : (PosT)0;
+                        ftmp[u] = r < tot ? P.hit_flag[base + r] : (uint8_t)0;
+                    }
 #pragma unroll
-                for (int u = 0; u < kHitBatch / 64; ++u) {
-                    const uint32_t r = lane + 64u * u;
-                    ftmp[u] = r < tot ? P.hit_flag[base + r] : (uint8_t)0;
-                }
-#pragma unroll
-                for (int u = 0; u < kHitBatch / 64; ++u) {
-                    const uint32_t r = lane + 64u * u;
-                    if (r < tot) {
-                        s_hits[r] = tmp[u];
-                        s_hflag[r] = ftmp[u];
+                    for (int u = 0; u < 4; ++u) {
+                        const uint32_t r = r0 + lane + 64u * u;
+                        if (r < tot) {
+                            s_hits[r] = tmp[u];
+                            s_hflag[r] = ftmp[u];
+                        }
                     }
                 }
             }
@@ -1066,6 +1086,22 @@ struct PlaceParams {
     uint32_t long3;             // > 0: tier 3 is reserved for segments of at least this many probes
 };
 
+// Sort key of a segment inside its tier (ascending = launch order).  Heavy tiers: longest first,
+// so that the serial chains start early.  Tier 1 holds over a million mostly tiny segments whose
+// cost is the latency of fetching their probe rows: apart from its few long ones (first, by
+// length) they run in genome order, so that the segments in flight at any time share cache lines
+// and pages of p_filt / row_off / hits.
+__device__ inline uint32_t placement_key(int tier, unsigned long long sum, uint32_t g0) {
+    uint32_t low;
+    if (tier == 1) {
+        low = sum >= 1024ull ? 1023u - (uint32_t)min(sum >> 5, 1023ull) : 1024u + (g0 >> 4);
+    } else {
+        const uint32_t s29 = sum > 0x1FFFFFFFull ? 0x1FFFFFFFu : (uint32_t)sum;
+        low = 0x1FFFFFFFu - s29;
+    }
+    return (((uint32_t)tier - 1u) << 29) | low;
+}
+
 // Tier of a segment from its live-arm bound, hit total and processed-probe count.  With long3 set,
 // tier 3 (lowest per-probe latency, one workgroup of 1024 threads per CU) only takes the long
 // segments whose serial chain is the critical path of a pass; everything else goes by capacity.
@@ -1208,8 +1244,7 @@ __global__ __launch_bounds__(64) void seg_prepass_kernel(RunParams rp, const uin
 #ifdef ASGART_PROFILE_EXTEND
             if (g0 == 4841535u || g0 == 22631158u) printf("[prepass] g0=%u sidx=%llu bound=%u sum=%llu mx=%u tier=%d t_idx=%u\n", g0, (unsigned long long)sidx, bound, sum, mx, tier, t_idx);
 #endif
-            const uint32_t s29 = sum > 0x1FFFFFFFull ? 0x1FFFFFFFu : (uint32_t)sum;
-            keys[sidx] = (((uint32_t)tier - 1u) << 29) | (0x1FFFFFFFu - s29);
+            keys[sidx] = placement_key(tier, sum, g0);
             vals[sidx] = g0;
         }
         __syncthreads();
@@ -1294,8 +1329,7 @@ __global__ __launch_bounds__(64) void seg_stats_kernel(RunParams rp, const uint3
         if (lane == 0) {
             int tier = place_tier(bound, sum, n_probes, pp);
             if (mx > 1 && pp.force_tier > tier) tier = min(pp.force_tier, kTiers);
-            const uint32_t s29 = sum > 0x1FFFFFFFull ? 0x1FFFFFFFu : (uint32_t)sum;
-            keys[sidx] = (((uint32_t)tier - 1u) << 29) | (0x1FFFFFFFu - s29);
+            keys[sidx] = placement_key(tier, sum, g0);
             vals[sidx] = g0;
         }
         __syncthreads();
@@ -1843,20 +1877,6 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
         }
         __syncthreads();
     }
-}
-
-// Wave-uniform values the compiler cannot prove uniform (read from LDS, or a lane of a vector):
-// forcing them into scalar registers keeps the per-probe bookkeeping and branches on the scalar
-// unit instead of exec-masked vector code and LDS permutes.
-__device__ inline uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-__device__ inline unsigned long long uni(unsigned long long v) {
-    return ((unsigned long long)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v);
-}
-__device__ inline uint32_t lane_of(uint32_t v, uint32_t l) {
-    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l);
-}
-__device__ inline unsigned long long lane_of(unsigned long long v, uint32_t l) {
-    return ((unsigned long long)lane_of((uint32_t)(v >> 32), l) << 32) | lane_of((uint32_t)v, l);
 }
 
 // ---------------------------------------------------------------- K4c --------
