@@ -355,7 +355,9 @@ int32_t asgart_index_create(const uint8_t *T, int64_t n, const int64_t *SA, int6
     }
     idx->device = device;
     idx->n = n;
-    idx->wide = (uint64_t)n >= 0xFFFFFF00ull;
+    // ASGART_FORCE_WIDE=1 (tests): 64-bit slots and positions also for a small text, so that the
+    // instantiations a > 4 Gb input selects can be checked against the oracle
+    idx->wide = (uint64_t)n >= 0xFFFFFF00ull || (getenv("ASGART_FORCE_WIDE") && atoi(getenv("ASGART_FORCE_WIDE")) != 0);
     for (auto &cx : idx->ctx) memset(&cx.stats, 0, sizeof(cx.stats));
     int32_t rc = [&]() -> int32_t {
         for (auto &cx : idx->ctx) {

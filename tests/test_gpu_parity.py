@@ -447,3 +447,25 @@ def test_random_sweep_default_and_forced_tiers(hiplib, seed, monkeypatch):
             monkeypatch.setenv("ASGART_FILTER", "1")
         offs, sds = idx.search_duplications_raw(pr.chunks, st)
         assert np.array_equal(offs, eoffs) and np.array_equal(sds, esds), ("forced", tier, cli, rc)
+
+
+@pytest.mark.parametrize("tier", [0, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("name", ["dense_repeats", "long_sds", "satellites"])
+def test_64bit_slots_and_positions(hiplib, name, tier, monkeypatch):
+    """Texts of 2^32 bases and more use 64-bit suffix-array slots and positions (other template
+    instantiations of every kernel, smaller arm capacities).  ASGART_FORCE_WIDE selects them for a small
+    text: default placement (tier 0) and every forced tier against the oracle."""
+    pr, cli = _battery_case(name)
+    oidx = oracle.Index.build(pr.data)
+    monkeypatch.setenv("ASGART_FORCE_WIDE", "1")
+    if tier:
+        monkeypatch.setenv("ASGART_FORCE_TIER", str(tier))
+    with asgart_amd.Index(pr.data, oidx.sa) as idx:
+        for rc in (False, True):
+            st = asgart_amd.RunSettings.from_cli(reverse=rc, complement=rc, **cli)
+            offs, sds = idx.search_duplications_raw(pr.chunks, st)
+            eoffs, esds = oidx.run_raw(pr.chunks, oracle.make_settings(reverse=rc, complement=rc, **cli), threads=4)
+            assert np.array_equal(offs, eoffs) and np.array_equal(sds, esds), (name, tier, rc)
+        # searcher surface on the wide index
+        lo, hi = idx.sa_read(0, 16), None
+        assert np.array_equal(lo, oidx.sa[:16])
