@@ -49,10 +49,9 @@ namespace asgart {
 
 // default launch order / grid sizes of the extension tiers (see the launch site)
 constexpr const char *kTierOrder = "3654217";
-constexpr uint64_t kGrid1 = 256ull * 8ull, kGrid2 = 256ull * 3ull, kGrid3 = 256ull, kGrid4 = 256ull, kGrid5 = 256ull;
+constexpr uint64_t kGrid1 = 256ull * 8ull, kGrid2 = 256ull * 3ull;
 // arms per thread of the arm-resident kernel: 9 x 512 = 4608 live arms (6 x 512 with 64-bit positions)
 template <class SlotT> constexpr int kArmsLayers = sizeof(SlotT) == 4 ? 9 : 6;
-constexpr uint64_t kGrid4Arms = 512ull;
 // its one-wave shape: 8 x 64 = 512 live arms per wave, probes with up to 512 hits
 template <class SlotT> constexpr int kWaveArmsLayers = sizeof(SlotT) == 4 ? 8 : 5;
 // tiers 4 and 5: 4 arms per thread x 256 / 512 threads, cold fields in LDS
@@ -65,7 +64,6 @@ constexpr uint32_t kLongSegment = 4096;  // probes; longer segments get the low-
 constexpr int kArmCapSmall = 256;   // live arms per wave in LDS, common case
 constexpr uint32_t kTier1MaxSum = 20000;  // placement: busier segments never run on a single wave
 constexpr int kArmCapMid = 768;     // second tier: block-cooperative kernel, 256 threads per segment
-constexpr uint32_t kEscalateCostMid = 0xFFFFFFFFu;  // mid -> heavy: sum of (live arms + hits) over probes
 constexpr int kArmCapHybrid32 = 4608;   // tier 4: hot fields in LDS, (rs, le) in HBM scratch
 constexpr int kArmCapHybrid64 = 3072;
 constexpr int kArmCapGlobal32 = 16384;  // tier 5: all arm fields in HBM scratch

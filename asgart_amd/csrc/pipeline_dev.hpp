@@ -1370,7 +1370,7 @@ __global__ void tier_bounds_kernel(const uint32_t *__restrict__ sorted_keys,
 //     (2) one thread per hit: two buckets + wide list -> best (creation number, slot),
 //     (3) ExtendArm = atomicMax of the hit index on the slot, NewArm = slot from the free list in
 //     hit order, (4) apply / age / retire in place.
-//   * GLOBAL = true keeps the arm arrays in an HBM scratch slice per workgroup (up to 16384
+//   * MODE 2 keeps the arm arrays in an HBM scratch slice per workgroup (up to 16384
 //     live arms); the per-probe candidate index stays in LDS.
 constexpr int kHeavyThreads = 512;   // heavy tiers (1024 threads would cap VGPRs at 128 -> spills)
 constexpr int kMidThreads = 256;     // mid tier: 4 waves per segment, several workgroups per CU
@@ -1401,7 +1401,6 @@ __device__ inline void pend_max(uint16_t *a, uint32_t idx, uint32_t v) {
 template <class PosT, int CAP, int NT, int MODE>
 __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
     constexpr int NW = NT / 64;
-    constexpr bool GLOBAL = MODE == 2;
     constexpr bool PACKED_WIDE = MODE == 0;
     constexpr int HCAP = MODE != 2 ? CAP : 1;  // hot fields in LDS
     constexpr int CCAP = MODE == 0 ? CAP : 1;  // cold field (rs) in LDS
@@ -1442,7 +1441,7 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
     __shared__ PosT s_hits[kHitBatch];
     __shared__ uint8_t s_hflag[kHitBatch];
     __shared__ unsigned long long s_best[NT];  // per hit: (creation number << 20) | slot, or ~0
-    __shared__ uint32_t s_nwide, s_ndead, s_nfreed;
+    __shared__ uint32_t s_nwide, s_nfreed;
     __shared__ uint32_t s_wcnt[NT / 64];
     __shared__ unsigned long long s_bcast;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1902,7 +1901,6 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
 template <class PosT, int S, int NT, int HB, int kHT, int kLevels, bool PACK, bool COLD = false, int PAD = 0>
 __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
     constexpr int CAP = S * NT;
-    constexpr int NW = NT / 64;
     constexpr uint32_t kGenBits = 22, kNoHit = 0xFFFFu;
     static_assert(HB <= 1024 && HB <= kHitBatch && CAP < (1 << 20), "hit index is packed into 10 bits");
     // PACK: head = ((generation << 10 | hit) << 32) | low word of x, node[h] = (next hit << 32) | its x
@@ -2268,7 +2266,7 @@ __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
                 PROF_STOP(4);
                 PROF_START();
                 // ---- P2: hits notify arms / claim free slots ----------------------------------
-                // Wave w owns the hit groups w, w + NW, ...; the rank of an unmatched flagged hit
+                // Wave w owns the hit groups w, w + NT/64, ...; the rank of an unmatched flagged hit
                 // among the new arms (hit order = creation order) needs the counts of the earlier
                 // groups, which the owning wave recomputes itself (no barrier).  The totals reach
                 // the other waves through counters read after the barrier.

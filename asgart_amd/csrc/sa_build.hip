@@ -183,7 +183,7 @@ int32_t build_t(const uint8_t *d_text, int64_t n_, IdxT *d_sa, bool dna, hipStre
         uint64_t m = n;
         const IdxT *slots = nullptr;  // round 0: slot j == j
         bool two_keys = false;
-        for (int round = 0;; ++round) {
+        for (;;) {
             mark_heads_kernel<IdxT><<<grid_for(m), 256, 0, s>>>(
                 K1.db.current(), two_keys ? K2.db.current() : nullptr, slots, m, head);
             HIP_TRY(hipGetLastError());
