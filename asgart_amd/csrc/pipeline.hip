@@ -388,6 +388,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             ep.cap_limit = getenv("ASGART_TEST_CAP_LIMIT") ? (uint32_t)atoi(getenv("ASGART_TEST_CAP_LIMIT")) : 0xFFFFFFFFu;
             ep.escalate_cost = 0xFFFFFFFFu;
             ep.n_levels = getenv("ASGART_TEST_LEVELS") ? (uint32_t)atoi(getenv("ASGART_TEST_LEVELS")) : 4u;
+            ep.gen_bits = getenv("ASGART_TEST_GENBITS") ? (uint32_t)atoi(getenv("ASGART_TEST_GENBITS")) : 22u;
             ep.ctr = d_ctr;
             // The tiers are launched together on separate streams, each with a grid that can fill
             // the chip on its own (persistent workgroups, longest segment first): the hardware

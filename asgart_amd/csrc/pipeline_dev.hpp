@@ -558,6 +558,7 @@ struct ExtParams {
     unsigned long long *ovf_count;        // ... appended at *ovf_count (device counter)
     char *scratch;                        // heavy global tier: per-workgroup arm storage
     uint32_t n_levels;                    // K4c: usable hit-table levels (tests shrink it)
+    uint32_t gen_bits;                    // K4c: bits of the table generation counter (tests shrink it)
     uint32_t escalate_cost;               // one-wave tiers: give up after this much LDS-path work
     uint32_t cap_limit;                   // effective live-arm capacity (<= CAP; tests lower it)
     unsigned long long *ctr;
@@ -1901,7 +1902,8 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
 template <class PosT, int S, int NT, int HB, int kHT, int kLevels, bool PACK, bool COLD = false, int PAD = 0>
 __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
     constexpr int CAP = S * NT;
-    constexpr uint32_t kGenBits = 22, kNoHit = 0xFFFFu;
+    constexpr uint32_t kNoHit = 0xFFFFu;
+    const uint32_t kGenBits = min(22u, max(2u, P.gen_bits));  // generation counter width (22; tests: less)
     static_assert(HB <= 1024 && HB <= kHitBatch && CAP < (1 << 20), "hit index is packed into 10 bits");
     // PACK: head = ((generation << 10 | hit) << 32) | low word of x, node[h] = (next hit << 32) | its x
     using HeadT = typename std::conditional<PACK, unsigned long long, uint32_t>::type;

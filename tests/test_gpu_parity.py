@@ -469,3 +469,21 @@ def test_64bit_slots_and_positions(hiplib, name, tier, monkeypatch):
         # searcher surface on the wide index
         lo, hi = idx.sa_read(0, 16), None
         assert np.array_equal(lo, oidx.sa[:16])
+
+
+@pytest.mark.parametrize("bits", [2, 5])
+@pytest.mark.parametrize("tier", [2, 3, 5])
+def test_arm_kernel_generation_wrap(hiplib, bits, tier, monkeypatch):
+    """The per-probe hit tables of the arm-resident kernel are never cleared: heads carry a generation
+    number, and the tables are wiped when the counter wraps (every 4M probes of a workgroup).  With a
+    2- or 5-bit counter the wrap happens every few probes."""
+    pr, cli = _battery_case("satellites")
+    oidx = oracle.Index.build(pr.data)
+    monkeypatch.setenv("ASGART_FORCE_TIER", str(tier))
+    monkeypatch.setenv("ASGART_TEST_GENBITS", str(bits))
+    with asgart_amd.Index(pr.data, oidx.sa) as idx:
+        for rc in (False, True):
+            st = asgart_amd.RunSettings.from_cli(reverse=rc, complement=rc, **cli)
+            offs, sds = idx.search_duplications_raw(pr.chunks, st)
+            eoffs, esds = oidx.run_raw(pr.chunks, oracle.make_settings(reverse=rc, complement=rc, **cli), threads=4)
+            assert np.array_equal(offs, eoffs) and np.array_equal(sds, esds), (bits, tier, rc)
