@@ -317,11 +317,12 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
         }
         auto tier_enabled = [&](int t) { return t >= 1 && t <= kTiers && tier_cap[t] != 0; };
         PlaceParams pp;
-        pp.long3 = 0;
+        pp.long3 = pp.long3_big = 0;
         for (int t = 1; t < kTiers; ++t) pp.cap[t - 1] = tier_cap[t];
         if (arms_kernel) {
             pp.long3 = getenv("ASGART_LONG3") ? (uint32_t)atoi(getenv("ASGART_LONG3")) : kLongSegment;
-            if (force_tier == 3) pp.long3 = 1;
+            pp.long3_big = getenv("ASGART_LONG3_BIG") ? (uint32_t)atoi(getenv("ASGART_LONG3_BIG")) : pp.long3 / 4u;
+            if (force_tier == 3) pp.long3 = pp.long3_big = 1;
             if (const char *e = getenv("ASGART_CAP1")) pp.cap[0] = (uint32_t)std::max(1, std::min(atoi(e), kArmCapSmall));
         }
         int force_eff = force_tier;  // a forced tier that has no kernel in this mode: the next one that has

@@ -1085,6 +1085,7 @@ struct PlaceParams {
     int force_tier;             // tests: minimum tier for segments with a multi-hit probe
     int use_filter;             // 0: flag every hit (k >= M, huge gaps or cardinalities)
     uint32_t long3;             // > 0: tier 3 is reserved for segments of at least this many probes
+    uint32_t long3_big;         // ... or this many, for segments beyond tier 5's capacity
 };
 
 // Sort key of a segment inside its tier (ascending = launch order).  Heavy tiers: longest first,
@@ -1108,7 +1109,11 @@ __device__ inline uint32_t placement_key(int tier, unsigned long long sum, uint3
 // segments whose serial chain is the critical path of a pass; everything else goes by capacity.
 __device__ inline int place_tier(uint32_t bound, unsigned long long sum, uint32_t n_probes, const PlaceParams &pp) {
     if (bound <= pp.cap[0] && sum <= pp.sum1) return 1;
-    if (pp.long3 && n_probes >= pp.long3 && bound <= pp.cap[2]) return 3;
+    // tier 6 pays ~3x tier 3's time per probe (many arms per thread): its segments count as long
+    // from a quarter of the threshold on
+    if (pp.long3 && bound <= pp.cap[2] &&
+        (n_probes >= pp.long3 || (bound > pp.cap[4] && n_probes >= pp.long3_big)))
+        return 3;
     for (int t = 2; t < kTiers; ++t) {
         if (t == 3 && pp.long3) continue;
         if (bound <= pp.cap[t - 1]) return t;
