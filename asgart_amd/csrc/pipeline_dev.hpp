@@ -101,13 +101,17 @@ __global__ __launch_bounds__(256) void probe_count_kernel(IndexView<SlotT> ix, R
             p_lo[g] = 0;
         } else {
             uint64_t lo, hi;
-            kmer_range(ix, q, lo, hi);
+            const bool all_occurrences = kmer_range(ix, q, lo, hi);
             const uint64_t raw = hi - lo;
             p_lo[g] = (SlotT)lo;
             p_raw[g] = (uint32_t)raw;
             if (raw <= (uint64_t)kSmallInterval) {
                 uint32_t cnt = 0;
-                for (uint64_t r = lo; r < hi; ++r)
+                // Direct pass: the needle is the text itself, so the probe's own position is one of
+                // the occurrences; a single occurrence is that one, and the filter (x > i + s)
+                // drops it -- no need to fetch the suffix-array entry (most probes of a genome).
+                const bool only_self = all_occurrences && raw == 1 && !rp.reverse && !rp.complement;
+                for (uint64_t r = lo; r < hi && !only_self; ++r)
                     cnt += keep_hit(ix.sa[r], i, s, L, rp.reverse) ? 1u : 0u;
                 p_filt[g] = cnt > rp.C ? kSkipCard : cnt;
             } else {

@@ -109,14 +109,16 @@ __device__ inline void kmer_range_tail(const IndexView<SlotT> &ix, uint64_t q, u
     hi = L + re;
 }
 
-// SA slot interval [lo,hi) of the k-mer with key q.
+// SA slot interval [lo,hi) of the k-mer with key q.  Returns false when the interval comes from the
+// emulated bisection of the text-tail corner (it is then what the reference finds, not necessarily
+// the set of all occurrences).
 template <class SlotT>
-__device__ inline void kmer_range(const IndexView<SlotT> &ix, uint64_t q, uint64_t &lo,
+__device__ inline bool kmer_range(const IndexView<SlotT> &ix, uint64_t q, uint64_t &lo,
                                   uint64_t &hi) {
     uint32_t pre24 = (uint32_t)(q >> (3 * (ix.k - kCacheLen)));
     if (ix.n_tail8 && in_tail_list(ix, pre24)) {
         kmer_range_tail(ix, q, lo, hi);
-        return;
+        return false;
     }
     uint64_t lo0 = 0, hi0 = ix.n;
     uint32_t p;
@@ -136,6 +138,7 @@ __device__ inline void kmer_range(const IndexView<SlotT> &ix, uint64_t q, uint64
     if (walk == 8 && h < hi0 && ix.keys[h] == q) h = upper_bound_keys(ix.keys, h, hi0, q);
     lo = l;
     hi = h;
+    return true;
 }
 
 // key of the probe at needle-local offset i of chunk (s, L) under the run's
