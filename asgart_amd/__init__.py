@@ -32,7 +32,7 @@ ABI_SYMBOLS = (
     "asgart_search_duplications", "asgart_search_duplications_shard", "asgart_families_counts",
     "asgart_families_copy", "asgart_families_free", "asgart_searcher_cache_get",
     "asgart_searcher_search", "asgart_sa_read", "asgart_probe_hits", "asgart_get_stats",
-    "asgart_last_error", "asgart_version",
+    "asgart_last_error", "asgart_version", "asgart_compute_scores",
 )
 
 
@@ -110,6 +110,8 @@ def load_library() -> C.CDLL:
     L.asgart_searcher_search.restype = C.c_int32
     L.asgart_sa_read.argtypes = [vp, C.c_uint64, C.c_uint64, vp]
     L.asgart_sa_read.restype = C.c_int32
+    L.asgart_compute_scores.argtypes = [vp, vp, C.c_int64, C.c_int32, C.c_int32, vp]
+    L.asgart_compute_scores.restype = C.c_int32
     L.asgart_probe_hits.argtypes = [vp, vp, C.c_int64, C.POINTER(_Settings), vp, vp, vp, u64p]
     L.asgart_probe_hits.restype = C.c_int64
     L.asgart_get_stats.argtypes = [vp, C.c_uint32, C.POINTER(Stats)]
@@ -238,6 +240,15 @@ class Index:
     def sa_read(self, lo: int, hi: int) -> np.ndarray:
         out = np.empty(max(0, hi - lo), dtype=np.int64)
         _check(load_library().asgart_sa_read(self._h, lo, hi, _ptr(out)))
+        return out
+
+    def compute_scores(self, sds: np.ndarray, reversed_: bool = False, complemented: bool = False) -> np.ndarray:
+        """ComputeScore of reference src/bin/asgart.rs:98-112 for an (n, 4) uint64 array of
+        (left, right, left_length, right_length): Levenshtein identities as float32."""
+        sds = np.ascontiguousarray(sds, dtype=np.uint64).reshape(-1, 4)
+        out = np.empty(len(sds), dtype=np.float32)
+        _check(load_library().asgart_compute_scores(self._h, _ptr(sds), len(sds), int(reversed_),
+                                                    int(complemented), _ptr(out)))
         return out
 
     def stats(self, flags: int = 0) -> Stats:

@@ -4,7 +4,8 @@ Host code mirroring the reference's `Step`s in the order fixed at src/bin/asgart
 FilterNs (:81-96, ProtoSD::n_content src/structs.rs:454-467), ReOrder (:33-51), ReduceOverlap
 (:67-79, helpers :481-562), Sort (:53-65); then ProtoSD -> SD with chromosome lookup (:770-821) and
 the JSON exporter (src/exporters.rs:12-25, struct field order of src/structs.rs:36-58,60-98,471-493).
-ComputeScore (--compute-score, Levenshtein) is not implemented.
+ComputeScore (--compute-score, src/bin/asgart.rs:98-112) is the one step that is not cheap: it runs on
+the GPU (`asgart_compute_scores`, exact Levenshtein by anti-diagonal DP) and needs the index.
 
 These steps are cheap host work in the reference as well; nothing here
 touches the GPU.  All quirks are kept (see the comments), tests/test_postprocess.py checks the chain
@@ -114,6 +115,28 @@ class ReduceOverlap:
         return out
 
 
+class ComputeScore:
+    """`sd.identity = sd.levenshtein(&strand.data) as f32` for every duplication (src/bin/asgart.rs:98-112,
+    src/structs.rs:439-452), on the GPU.  `index` is the asgart_amd.Index of the strand."""
+
+    def __init__(self, index):
+        self.index = index
+
+    def name(self) -> str:
+        return "Computing Levenshtein distance"
+
+    def run(self, families, _strand):
+        flat = [sd for fam in families for sd in fam]
+        # the flags are constant per run (src/bin/asgart.rs:245-247) but ReduceOverlap keeps x's: group
+        for key in {(sd.reversed, sd.complemented) for sd in flat}:
+            group = [sd for sd in flat if (sd.reversed, sd.complemented) == key]
+            arr = np.array([sd.as_tuple() for sd in group], dtype=np.uint64).reshape(-1, 4)
+            ident = self.index.compute_scores(arr, key[0], key[1])
+            for sd, v in zip(group, ident):
+                sd.identity = float(v)
+        return families
+
+
 class Sort:
     def name(self) -> str:
         return "Sorting"
@@ -124,9 +147,16 @@ class Sort:
         return families
 
 
-def post_process(families: List[ProtoSDsFamily], strand) -> List[ProtoSDsFamily]:
-    """The steps after SearchDuplications, in the reference's order (no ComputeScore)."""
-    for step in (FilterNs(), ReOrder(), ReduceOverlap(), Sort()):
+def post_process(families: List[ProtoSDsFamily], strand, index=None, compute_score: bool = False) -> List[ProtoSDsFamily]:
+    """The steps after SearchDuplications, in the reference's order (src/bin/asgart.rs:738-747);
+    ComputeScore only with compute_score (it needs the GPU index)."""
+    steps = [FilterNs(), ReOrder(), ReduceOverlap()]
+    if compute_score:
+        if index is None:
+            raise ValueError("compute_score needs the asgart_amd.Index of the strand")
+        steps.append(ComputeScore(index))
+    steps.append(Sort())
+    for step in steps:
         families = step.run(families, strand)
     return families
 
@@ -197,14 +227,17 @@ def out_filename(files: Sequence[str], settings: RunSettings, prefix: str = "") 
     return f"{prefix}{radix}{rc}{trim}.json"
 
 
-def search_duplications(strands_files: Sequence[str], settings: RunSettings, device: int = 0) -> dict:
+def search_duplications(strands_files: Sequence[str], settings: RunSettings, device: int = 0,
+                        compute_score: bool = False) -> dict:
     """`search_duplications()` of src/bin/asgart.rs:731-822: prepare_data, the step chain with the
     HIP search step first, then the RunResult.  Raises AsgartError without a GPU (no CPU fallback)."""
-    from . import SearchDuplications, Strand
+    from . import Index, SearchDuplications, Strand
     from .prep import prepare_records, read_records
 
     records = [rec for f in strands_files for rec in read_records(f)]
     pr = prepare_records(records, settings.skip_masked)
     strand = Strand(", ".join(strands_files), pr.data, pr.map)  # file_names, :437
-    families = SearchDuplications(pr.chunks, settings.trim, settings, device=device).run([], strand)
-    return run_result(post_process(families, strand), strand, settings)
+    with Index(strand.data, None, device) as index:
+        families = SearchDuplications(pr.chunks, settings.trim, settings, index=index).run([], strand)
+        families = post_process(families, strand, index, compute_score)
+    return run_result(families, strand, settings)

@@ -123,6 +123,17 @@ void asgart_families_counts(const asgart_families *f, uint64_t *n_families, uint
 void asgart_families_copy(const asgart_families *f, uint64_t *fam_offsets, asgart_proto_sd *sds);
 void asgart_families_free(asgart_families *f);
 
+/* ---- ComputeScore (`--compute-score`) --------------------------------------
+ * Replaces the ComputeScore step, reference src/bin/asgart.rs:98-112 with
+ * ProtoSD::levenshtein, src/structs.rs:439-452: for each of the n_sd duplications
+ * identity = 100 * (1 - levenshtein(left arm, right arm) / max(left_length, right_length)),
+ * arms taken over the INCLUSIVE ranges [p ..= p + length] of the text, the right arm
+ * reversed / complemented first when the flags say so; computed in f64, stored as f32
+ * like `sd.identity`.  Exact unit-cost edit distance (anti-diagonal DP on the GPU).
+ * Errors: a range that reaches past the text (the reference panics), two empty arms. */
+int32_t asgart_compute_scores(asgart_index *idx, const asgart_proto_sd *sds, int64_t n_sd,
+                              int32_t reversed, int32_t complemented, float *identity);
+
 /* ---- finer-grained entry points mirroring the reference's inner API;
  *      used by the parity tests ------------------------------------------ */
 

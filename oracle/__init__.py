@@ -301,6 +301,16 @@ def postprocess(strand: np.ndarray, offs: np.ndarray, sds: np.ndarray) -> Tuple[
     return _take_families(h)
 
 
+def levenshtein_identity(strand: np.ndarray, sd, reversed_: bool = False, complemented_: bool = False) -> np.float32:
+    """ProtoSD::levenshtein as f32 (src/structs.rs:439-452, src/bin/asgart.rs:108)."""
+    strand = as_text(strand)
+    f = lib().oracle_levenshtein_identity
+    f.restype = C.c_double
+    f.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32]
+    left, right, ll, rl = (int(v) for v in sd)
+    return np.float32(f(_ptr(strand), left, right, ll, rl, int(reversed_), int(complemented_)))
+
+
 def prepare_needle(text: np.ndarray, chunk: Tuple[int, int], settings: Settings) -> np.ndarray:
     """Needle preparation of src/bin/asgart.rs:206-218."""
     nd = np.ascontiguousarray(text[chunk[0]:chunk[0] + chunk[1]])

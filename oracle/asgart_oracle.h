@@ -88,6 +88,10 @@ int32_t oracle_families_from_arrays(const uint64_t *fam_offsets, uint64_t n_fam,
 int32_t oracle_postprocess(const uint8_t *strand, const uint64_t *fam_offsets, uint64_t n_fam,
                            const oracle_proto_sd *sds, oracle_families **out);
 
+/* ProtoSD::levenshtein (src/structs.rs:439-452): identity in percent, as f64 */
+double oracle_levenshtein_identity(const uint8_t *strand, uint64_t left, uint64_t right, uint64_t left_length,
+                                   uint64_t right_length, int32_t reversed, int32_t complemented);
+
 /* ---- automaton::search_duplications for ONE needle (src/automaton.rs:57-204).
  * `left` in the result is needle-local, `right` global, exactly as the
  * reference returns them.  progress may be NULL.  Returns 0 or <0. */

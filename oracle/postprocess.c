@@ -136,3 +136,48 @@ int32_t oracle_postprocess(const uint8_t *strand, const uint64_t *fam_offsets, u
     free(a); free(b); free(offs); free(res);
     return rc;
 }
+
+
+/* ---- ComputeScore: ProtoSD::levenshtein, src/structs.rs:439-452 -------------------------------
+ * bio::alignment::distance::levenshtein (crate `bio`, version unpinned in the reference) is the
+ * textbook unit-cost global edit distance; restated with two rolling rows. */
+static uint8_t tr_complement(uint8_t c) { /* src/structs.rs:11-26 (TR) */
+    switch (c) {
+    case 'A': return 'T'; case 'T': return 'A'; case 'G': return 'C'; case 'C': return 'G';
+    case 'a': return 't'; case 't': return 'a'; case 'g': return 'c'; case 'c': return 'g';
+    default: return c; /* 'N'/'n' map to themselves; the reference panics on anything else */
+    }
+}
+
+double oracle_levenshtein_identity(const uint8_t *strand, uint64_t left, uint64_t right, uint64_t left_length,
+                                   uint64_t right_length, int32_t reversed, int32_t complemented) {
+    const uint64_t la = left_length + 1, lb = right_length + 1; /* inclusive ranges, :441-442 */
+    uint8_t *b = (uint8_t *)malloc(lb);
+    uint32_t *prev = (uint32_t *)malloc((lb + 1) * sizeof(uint32_t));
+    uint32_t *cur = (uint32_t *)malloc((lb + 1) * sizeof(uint32_t));
+    for (uint64_t j = 0; j < lb; ++j) b[j] = strand[right + j];
+    if (reversed) /* :443-445 */
+        for (uint64_t j = 0; j < lb / 2; ++j) {
+            uint8_t t = b[j];
+            b[j] = b[lb - 1 - j];
+            b[lb - 1 - j] = t;
+        }
+    if (complemented) /* :446-448 */
+        for (uint64_t j = 0; j < lb; ++j) b[j] = tr_complement(b[j]);
+    for (uint64_t j = 0; j <= lb; ++j) prev[j] = (uint32_t)j;
+    for (uint64_t i = 1; i <= la; ++i) {
+        cur[0] = (uint32_t)i;
+        const uint8_t a = strand[left + i - 1];
+        for (uint64_t j = 1; j <= lb; ++j) {
+            uint32_t v = prev[j - 1] + (a != b[j - 1] ? 1u : 0u);
+            if (prev[j] + 1 < v) v = prev[j] + 1;
+            if (cur[j - 1] + 1 < v) v = cur[j - 1] + 1;
+            cur[j] = v;
+        }
+        uint32_t *t = prev; prev = cur; cur = t;
+    }
+    const double dist = (double)prev[lb];
+    free(b); free(prev); free(cur);
+    const uint64_t longest = left_length > right_length ? left_length : right_length;
+    return 100.0 * (1.0 - dist / (double)longest); /* :451 */
+}

@@ -487,3 +487,55 @@ def test_arm_kernel_generation_wrap(hiplib, bits, tier, monkeypatch):
             offs, sds = idx.search_duplications_raw(pr.chunks, st)
             eoffs, esds = oidx.run_raw(pr.chunks, oracle.make_settings(reverse=rc, complement=rc, **cli), threads=4)
             assert np.array_equal(offs, eoffs) and np.array_equal(sds, esds), (bits, tier, rc)
+
+
+@pytest.mark.parametrize("rc", [(False, False), (True, True), (True, False), (False, True)])
+def test_compute_scores_match_oracle(hiplib, rc):
+    """`--compute-score`: Levenshtein identities of the GPU (anti-diagonal DP, LDS and HBM-scratch
+    paths) against the oracle's restatement of ProtoSD::levenshtein, bit-exact as f32."""
+    rng = np.random.default_rng(900 + 2 * rc[0] + rc[1])
+    recs = synth.make_genome([300_000], seed=91, sd_per_mb=30, sd_len=(500, 9000), alu_frac=0.05, short_n_per_mb=30)
+    pr = prep.prepare_records(recs)
+    n = len(pr.data) - 1
+    sds = []
+    for ll, rl in [(1, 1), (1, 40), (40, 1), (63, 64), (255, 256), (1000, 900), (4094, 4094), (4095, 100),
+                   (4096, 4200), (9000, 8700)] + [tuple(int(v) for v in rng.integers(20, 3000, 2)) for _ in range(40)]:
+        left = int(rng.integers(0, n - ll - 1)); right = int(rng.integers(0, n - rl - 1))
+        sds.append((left, right, ll, rl))
+    # planted near-identical pairs: right arm = left arm shifted into a diverged copy region
+    for _ in range(10):
+        ll = int(rng.integers(200, 2500)); left = int(rng.integers(0, n - 2 * ll - 10))
+        sds.append((left, left + 3, ll, ll + int(rng.integers(0, 5))))
+    arr = np.array(sds, dtype=np.uint64)
+    with asgart_amd.Index(pr.data, None) as idx:
+        got = idx.compute_scores(arr, rc[0], rc[1])
+        # errors: range past the text, two empty arms
+        with pytest.raises(asgart_amd.AsgartError):
+            idx.compute_scores(np.array([[n - 5, 0, 10, 3]], dtype=np.uint64))
+        with pytest.raises(asgart_amd.AsgartError):
+            idx.compute_scores(np.array([[5, 9, 0, 0]], dtype=np.uint64))
+    want = np.array([oracle.levenshtein_identity(pr.data, sd, rc[0], rc[1]) for sd in sds], dtype=np.float32)
+    assert got.dtype == np.float32 and np.array_equal(got, want)
+    assert want.min() < 60.0 and (rc != (False, False) or want.max() > 99.0)
+
+
+def test_compute_score_step_end_to_end(hiplib, tmp_path):
+    """FASTA -> search -> FilterNs/ReOrder/ReduceOverlap -> ComputeScore (GPU) -> Sort -> RunResult JSON:
+    the identities in the JSON equal the oracle's for the very same duplications."""
+    from asgart_amd import postprocess
+    recs = synth.make_genome([260_000, 120_000], seed=92, sd_per_mb=40, sd_len=(800, 5000), alu_frac=0.03)
+    p = tmp_path / "g.fa"
+    with open(p, "wb") as fh:
+        for name, seq in recs:
+            fh.write(b">" + name.encode() + b"\n" + seq.tobytes() + b"\n")
+    settings = asgart_amd.RunSettings.from_cli(min_length=500, reverse=True, complement=True)
+    res = postprocess.search_duplications([str(p)], settings, compute_score=True)
+    pr = prep.prepare_records(recs)
+    n_checked = 0
+    for fam in res["families"]:
+        for sd in fam:
+            tup = (sd["global_left_position"], sd["global_right_position"], sd["left_length"], sd["right_length"])
+            want = oracle.levenshtein_identity(pr.data, tup, True, True)
+            assert np.float32(sd["identity"]) == want, tup
+            n_checked += 1
+    assert n_checked > 5

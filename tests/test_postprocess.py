@@ -110,3 +110,35 @@ def test_chain_random_families(seed):
     fams = postprocess.post_process(_to_families(offs, sds), strand)
     assert [[sd.as_tuple() for sd in f] for f in fams] == oracle.families_to_list(eo, es)
     assert len(es) < len(sds)
+
+
+def _py_levenshtein(a: bytes, b: bytes) -> int:
+    prev = list(range(len(b) + 1))
+    for i, ca in enumerate(a, 1):
+        cur = [i]
+        for j, cb in enumerate(b, 1):
+            cur.append(min(prev[j - 1] + (ca != cb), prev[j] + 1, cur[j - 1] + 1))
+        prev = cur
+    return prev[-1]
+
+
+def test_oracle_levenshtein_identity_against_plain_python():
+    """The oracle's ComputeScore restatement vs a textbook DP, incl. inclusive ranges, reverse and
+    complement of the right arm (src/structs.rs:439-452)."""
+    rng = np.random.default_rng(77)
+    text = rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), size=4000, p=[.24, .24, .24, .24, .04])
+    text = np.concatenate([text, np.frombuffer(b"$", dtype=np.uint8)])
+    tr = bytes.maketrans(b"ACGTacgt", b"TGCAtgca")
+    for _ in range(40):
+        ll, rl = int(rng.integers(1, 120)), int(rng.integers(1, 120))
+        left, right = int(rng.integers(0, 3800)), int(rng.integers(0, 3800))
+        for rev, comp in ((False, False), (True, False), (False, True), (True, True)):
+            a = text[left:left + ll + 1].tobytes()
+            b = text[right:right + rl + 1].tobytes()
+            if rev:
+                b = b[::-1]
+            if comp:
+                b = b.translate(tr)
+            want = np.float32(100.0 * (1.0 - _py_levenshtein(a, b) / max(ll, rl)))
+            got = oracle.levenshtein_identity(text, (left, right, ll, rl), rev, comp)
+            assert got == want, (left, right, ll, rl, rev, comp)
