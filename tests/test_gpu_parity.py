@@ -497,9 +497,9 @@ def test_compute_scores_match_oracle(hiplib, rc):
     recs = synth.make_genome([300_000], seed=91, sd_per_mb=30, sd_len=(500, 9000), alu_frac=0.05, short_n_per_mb=30)
     pr = prep.prepare_records(recs)
     n = len(pr.data) - 1
-    sds = []
+    sds = []   # (incl. arms of one band, several bands, and the multi-wave kernel for >= 8192 rows)
     for ll, rl in [(1, 1), (1, 40), (40, 1), (63, 64), (255, 256), (1000, 900), (4094, 4094), (4095, 100),
-                   (4096, 4200), (9000, 8700)] + [tuple(int(v) for v in rng.integers(20, 3000, 2)) for _ in range(40)]:
+                   (4096, 4200), (9000, 8700), (8191, 300), (8192, 8192), (20000, 1000), (17000, 33000), (40000, 150)] + [tuple(int(v) for v in rng.integers(20, 3000, 2)) for _ in range(40)]:
         left = int(rng.integers(0, n - ll - 1)); right = int(rng.integers(0, n - rl - 1))
         sds.append((left, right, ll, rl))
     # planted near-identical pairs: right arm = left arm shifted into a diverged copy region
