@@ -499,7 +499,8 @@ def test_compute_scores_match_oracle(hiplib, rc):
     n = len(pr.data) - 1
     sds = []   # (incl. arms of one band, several bands, and the multi-wave kernel for >= 8192 rows)
     for ll, rl in [(1, 1), (1, 40), (40, 1), (63, 64), (255, 256), (1000, 900), (4094, 4094), (4095, 100),
-                   (4096, 4200), (9000, 8700), (8191, 300), (8192, 8192), (20000, 1000), (17000, 33000), (40000, 150)] + [tuple(int(v) for v in rng.integers(20, 3000, 2)) for _ in range(40)]:
+                   (4096, 4200), (9000, 8700), (8191, 300), (8192, 8192), (20000, 1000), (17000, 33000), (40000, 150), (9000, 1), (1, 9000),
+                   (16384, 64), (16385, 127), (25000, 20000)] + [tuple(int(v) for v in rng.integers(20, 3000, 2)) for _ in range(40)]:
         left = int(rng.integers(0, n - ll - 1)); right = int(rng.integers(0, n - rl - 1))
         sds.append((left, right, ll, rl))
     # planted near-identical pairs: right arm = left arm shifted into a diverged copy region
