@@ -336,15 +336,15 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
         // (ASGART_FILTER=1) until the pre-pass is cheaper.  Results are identical either way.
         pp.use_filter = (k < st->min_duplication_length && rp.tstar <= 64u && rp.C <= 5000u &&
                          getenv("ASGART_FILTER") && atoi(getenv("ASGART_FILTER")) != 0) ? 1 : 0;
-        RC_TRY(w.hit_flag.reserve((size_t)total_hits + 64));
-        uint8_t *hit_flag = w.hit_flag.as<uint8_t>();
-        const uint32_t *p_nflag = p_filt;  // without the filter every hit may create an arm
+        uint8_t *hit_flag = nullptr;             // without the filter: no flag array at all
+        const uint32_t *p_nflag = p_filt;        // ... and every hit may create an arm
         if (pp.use_filter) {
+            RC_TRY(w.hit_flag.reserve((size_t)total_hits + 64));
+            hit_flag = w.hit_flag.as<uint8_t>();
             seg_prepass_kernel<SlotT><<<(unsigned)std::min<uint64_t>(n_seg, 256ull * 9ull), 64, 0, s>>>(
                 rp, p_filt, row_off, hits, hit_flag, p_raw, seg_list, d_ctr + CT_SEG, kbuf, vbuf, pp, d_ctr);
             p_nflag = p_raw;  // rewritten by the pre-pass: flagged hits per probe
         } else {
-            HIP_TRY(hipMemsetAsync(hit_flag, 1, (size_t)total_hits, s));
             seg_stats_kernel<<<(unsigned)std::min<uint64_t>(n_seg, 256ull * 32ull), 64, 0, s>>>(
                 rp, p_filt, seg_list, d_ctr + CT_SEG, kbuf, vbuf, pp, d_ctr);
         }

@@ -551,7 +551,7 @@ struct ExtParams {
     const uint32_t *p_filt;
     const unsigned long long *row_off;
     const PosT *hits;
-    const uint8_t *hit_flag;              // 1: the hit may start an arm that matches later (K3b)
+    const uint8_t *hit_flag;              // 1: the hit may start an arm that matches later (K3b); null: every hit
     const uint32_t *p_nflag;              // per probe: number of flagged hits
     const uint32_t *seg_list;
     const unsigned long long *n_seg_ptr;  // device count of seg_list entries
@@ -822,7 +822,7 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
                     for (int u = 0; u < 4; ++u) {
                         const uint32_t r = r0 + lane + 64u * u;
                         tmp[u] = r < tot ? P.hits[base + r] : (PosT)0;
-                        ftmp[u] = r < tot ? P.hit_flag[base + r] : (uint8_t)0;
+                        ftmp[u] = r < tot ? (P.hit_flag ? P.hit_flag[base + r] : (uint8_t)1) : (uint8_t)0;
                     }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
@@ -996,7 +996,7 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
                         }
                         const int found = best == 0xFFFFFFFFu ? -1 : (int)best;
                         if (valid && found >= 0) atomicMax(&s_pend[found], t + 1u);
-                        const bool fl = valid && (from_lds ? s_hflag[off + t] : P.hit_flag[row + t]) != 0;
+                        const bool fl = valid && (from_lds ? s_hflag[off + t] : (P.hit_flag ? P.hit_flag[row + t] : (uint8_t)1)) != 0;
                         const bool is_new = valid && found < 0 && fl;
                         spur |= __ballot(valid && found < 0 && !fl) != 0ull;
                         const unsigned long long m = __ballot(is_new);
@@ -1632,7 +1632,7 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
                 const uint32_t tot = (uint32_t)(end - base);
                 for (uint32_t r = tid; r < tot; r += NT) {
                     s_hits[r] = P.hits[base + r];
-                    s_hflag[r] = P.hit_flag[base + r];
+                    s_hflag[r] = (P.hit_flag ? P.hit_flag[base + r] : (uint8_t)1);
                 }
             }
             __syncthreads();
@@ -1814,7 +1814,7 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
                     }
                     // unmatched hits: flagged ones become arms, the others are dropped (K3b)
                     bool fl = false;
-                    if (mine) fl = (from_lds ? s_hflag[off + t0 + tid] : P.hit_flag[row + t0 + tid]) != 0;
+                    if (mine) fl = (from_lds ? s_hflag[off + t0 + tid] : (P.hit_flag ? P.hit_flag[row + t0 + tid] : (uint8_t)1)) != 0;
                     const bool is_new = mine && best == ~0ull && fl;
                     // rank of this hit among the new arms, in hit order (= creation order): every
                     // wave recomputes the per-group counts from s_best + flags (no barrier)
@@ -1824,7 +1824,7 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
                         bool un = false, hf = false;
                         if (hidx < ct) {
                             un = s_best[hidx] == ~0ull;
-                            hf = (from_lds ? s_hflag[off + t0 + hidx] : P.hit_flag[row + t0 + hidx]) != 0;
+                            hf = (from_lds ? s_hflag[off + t0 + hidx] : (P.hit_flag ? P.hit_flag[row + t0 + hidx] : (uint8_t)1)) != 0;
                         }
                         const unsigned long long nm = __ballot(un && hf);
                         spur |= __ballot(un && !hf) != 0ull;
@@ -2157,7 +2157,7 @@ __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
                 const uint32_t tot = (uint32_t)(end - base);
                 for (uint32_t r = tid; r < tot; r += NT) {
                     s_hits[r] = P.hits[base + r];
-                    s_hflag[r] = P.hit_flag[base + r];
+                    s_hflag[r] = (P.hit_flag ? P.hit_flag[base + r] : (uint8_t)1);
                 }
             }
             __syncthreads();
