@@ -154,10 +154,20 @@ __global__ __launch_bounds__(256) void big_count_kernel(IndexView<SlotT> ix, Run
         const uint64_t i = (uint64_t)(g - rp.ch.pbase[c] + 1) * (uint64_t)rp.step;
         const uint64_t lo = p_lo[g], hi = lo + p_raw[g];
         uint64_t cnt = 0;
-        for (uint64_t base = lo; base < hi && cnt <= rp.C; base += 64) {
-            const uint64_t r = base + lane;
-            const bool keep = r < hi && keep_hit(ix.sa[r], i, s, L, rp.reverse);
-            cnt += __popcll(__ballot(keep));
+        // four 64-entry slices per round trip (the early exit makes the rounds dependent)
+        for (uint64_t base = lo; base < hi && cnt <= rp.C; base += 256) {
+            SlotT x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint64_t r = base + 64u * u + lane;
+                x[u] = r < hi ? ix.sa[r] : (SlotT)0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint64_t r = base + 64u * u + lane;
+                const bool keep = r < hi && keep_hit(x[u], i, s, L, rp.reverse);
+                cnt += __popcll(__ballot(keep));
+            }
         }
         if (lane == 0) p_filt[g] = cnt > rp.C ? kSkipCard : (uint32_t)cnt;
     }
@@ -463,17 +473,21 @@ __global__ __launch_bounds__(256) void fill_big_kernel(IndexView<SlotT> ix, RunP
         const uint64_t i = (uint64_t)(g - rp.ch.pbase[c] + 1) * (uint64_t)rp.step;
         const uint64_t lo = p_lo[g], hi = lo + p_raw[g];
         unsigned long long w = row_off[g];
-        for (uint64_t base = lo; base < hi; base += 64) {
-            const uint64_t r = base + lane;
-            SlotT x = 0;
-            bool keep = false;
-            if (r < hi) {
-                x = ix.sa[r];
-                keep = keep_hit(x, i, s, L, rp.reverse);
+        for (uint64_t base = lo; base < hi; base += 256) {  // four slices in flight per round trip
+            SlotT x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint64_t r = base + 64u * u + lane;
+                x[u] = r < hi ? ix.sa[r] : (SlotT)0;
             }
-            const unsigned long long m = __ballot(keep);
-            if (keep) hits[w + __popcll(m & ((1ull << lane) - 1ull))] = x;
-            w += __popcll(m);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint64_t r = base + 64u * u + lane;
+                const bool keep = r < hi && keep_hit(x[u], i, s, L, rp.reverse);
+                const unsigned long long m = __ballot(keep);
+                if (keep) hits[w + __popcll(m & ((1ull << lane) - 1ull))] = x[u];
+                w += __popcll(m);
+            }
         }
     }
 }
