@@ -1,6 +1,7 @@
 """Timing aid for --compute-score: search a synthetic genome (direct pass), run the host steps, then the GPU
 ComputeScore over all surviving duplications; a sample of them is also scored by the CPU oracle.
-Usage: python tools/score_bench.py [cfg3|cfg2]"""
+Lives under tests/ because it loads the CPU oracle (test infrastructure) for the comparison leg.
+Usage: python tests/score_bench.py [cfg3|cfg2]"""
 import os
 import sys
 import time
