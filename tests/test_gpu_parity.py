@@ -318,11 +318,16 @@ def test_escalation_tiers_give_identical_results(hiplib, name, tier, monkeypatch
             assert np.array_equal(offs, eoffs) and np.array_equal(sds, esds), (name, tier, reverse)
 
 
-def test_large_max_cardinality_uses_the_lds_array_tiers(hiplib):
-    """max_cardinality above the arm-resident kernel's staging area (1024 hits per probe) switches the
-    placement to the LDS-array kernels; results still match the oracle."""
+@pytest.mark.parametrize("card", [600, 1024, 3000])
+@pytest.mark.parametrize("force", [0, 2, 4, 6])
+def test_large_max_cardinality_tier_sets(hiplib, card, force, monkeypatch):
+    """max_cardinality decides which kernels exist: up to 512 every arm-resident shape; up to 1024 only the
+    shapes that stage 1024 hits per probe (tiers 3, 5, 6 -- tiers 2 and 4 are skipped, a forced tier moves on
+    to the next one that exists); above, the LDS-array kernels.  Results match the oracle in every set."""
     pr, cli = _battery_case("dense_repeats")
-    cli = dict(cli, max_cardinality=3000)
+    cli = dict(cli, max_cardinality=card)
+    if force:
+        monkeypatch.setenv("ASGART_FORCE_TIER", str(force))
     oidx = oracle.Index.build(pr.data)
     with asgart_amd.Index(pr.data, oidx.sa) as idx:
         for rc in (False, True):
