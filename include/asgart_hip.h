@@ -57,7 +57,7 @@ typedef struct asgart_stats {
     double ms_search;       /* probe-search + count kernels (dominant, HBM-bound) */
     double ms_scan;         /* prefix scans + segment detection                   */
     double ms_fill;         /* hit materialisation (CSR fill)                     */
-    double ms_extend;       /* seed-extension automaton kernel                    */
+    double ms_extend;       /* placement + all extension tiers + cascade            */
     uint64_t probes_total;
     uint64_t probes_n_skipped;
     uint64_t probes_searched;
@@ -71,9 +71,9 @@ typedef struct asgart_stats {
     uint64_t bisect_steps;  /* sum ceil(log2(b_p+1)), b_p = 8-mer bucket (yardstick;
                                filled only when ASGART_STATS_YARDSTICK was requested) */
     uint64_t search_launches; /* number of launches of the dominant kernel          */
-    uint64_t overflow_segments; /* segments re-run with a larger LDS share (tier 2)  */
-    double ms_extend_tier2;   /* part of ms_extend spent in the escalation tiers     */
-    uint64_t heavy_segments;  /* segments that went on to the block-cooperative tier */
+    uint64_t overflow_segments; /* segments a tier gave up on (re-run by a larger tier)  */
+    double ms_extend_tier2;   /* part of ms_extend spent re-running those (cascade)    */
+    uint64_t heavy_segments;  /* segments placed in tiers 3..7 (workgroup kernels)      */
     double ms_probe_count;    /* probe_count_kernel alone (first kernel of ms_search) */
 } asgart_stats;
 
