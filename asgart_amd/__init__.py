@@ -32,7 +32,7 @@ ABI_SYMBOLS = (
     "asgart_search_duplications", "asgart_search_duplications_shard", "asgart_families_counts",
     "asgart_families_copy", "asgart_families_free", "asgart_searcher_cache_get",
     "asgart_searcher_search", "asgart_sa_read", "asgart_probe_hits", "asgart_get_stats",
-    "asgart_last_error", "asgart_version", "asgart_compute_scores",
+    "asgart_last_error", "asgart_version", "asgart_compute_scores", "asgart_index_set_option",
 )
 
 
@@ -90,6 +90,8 @@ def load_library() -> C.CDLL:
     L.asgart_index_create.restype = C.c_int32
     L.asgart_index_destroy.argtypes = [vp]
     L.asgart_index_destroy.restype = None
+    L.asgart_index_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
+    L.asgart_index_set_option.restype = C.c_int32
     L.asgart_index_prepare.argtypes = [vp, C.c_uint64]
     L.asgart_index_prepare.restype = C.c_int32
     L.asgart_search_duplications.argtypes = [vp, vp, C.c_int64, C.POINTER(_Settings), vp,
@@ -233,6 +235,10 @@ class Index:
 
     def __exit__(self, *exc):
         self.close()
+
+    def set_option(self, name: str, value: int):
+        """Tuning / test option (include/asgart_hip.h: asgart_index_set_option)."""
+        _check(load_library().asgart_index_set_option(self._h, name.encode(), int(value)))
 
     def prepare(self, probe_size: int):
         _check(load_library().asgart_index_prepare(self._h, probe_size))

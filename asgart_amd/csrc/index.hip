@@ -6,6 +6,7 @@
 #include "index.hpp"
 #include "search_dev.hpp"
 
+#include <cctype>
 #include <chrono>
 
 namespace asgart {
@@ -17,6 +18,88 @@ void set_error(const char *fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+// ---- options ---------------------------------------------------------------
+namespace {
+struct OptDesc {
+    const char *name;
+    int64_t Options::*field;
+    int64_t lo, hi;
+};
+const OptDesc kOptions[] = {
+    {"shard_lookback", &Options::shard_lookback, 1, 1ll << 31},
+    {"shard_lookahead", &Options::shard_lookahead, 0, 1ll << 31},
+    {"force_tier", &Options::force_tier, 0, 7},
+    {"arms_kernel", &Options::arms_kernel, 0, 1},
+    {"long3", &Options::long3, 0, 1ll << 31},
+    {"long3_big", &Options::long3_big, -1, 1ll << 31},
+    {"cap1", &Options::cap1, 1, 256},
+    {"filter", &Options::filter, 0, 1},
+    {"debug", &Options::debug, 0, 1},
+    {"test_cap_limit", &Options::test_cap_limit, -1, 1ll << 31},
+    {"test_levels", &Options::test_levels, 0, 4},
+    {"test_genbits", &Options::test_genbits, 2, 22},
+    {"tier_order", &Options::tier_order, 1, 7777777},
+    {"ptab_depth", &Options::ptab_depth, 0, 15},
+    {"force_wide", &Options::force_wide, 0, 1},
+};
+}  // namespace
+
+int32_t option_set(Options &o, const char *name, int64_t value) {
+    if (!name) {
+        set_error("option name is NULL");
+        return ASGART_E_ARG;
+    }
+    if (!strncmp(name, "grid", 4) && name[4] >= '1' && name[4] <= '7' && !name[5]) {
+        // a tier's grid: every workgroup kernel reserves per-workgroup resources for at most
+        // its default grid, so larger requests are clamped at the launch site
+        if (value < 0 || value > (1ll << 20)) {
+            set_error("option %s: value %lld out of range", name, (long long)value);
+            return ASGART_E_ARG;
+        }
+        o.grid[name[4] - '0'] = value;
+        return 0;
+    }
+    for (const OptDesc &d : kOptions)
+        if (!strcmp(name, d.name)) {
+            if (value < d.lo || value > d.hi) {
+                set_error("option %s: value %lld outside [%lld, %lld]", name, (long long)value,
+                          (long long)d.lo, (long long)d.hi);
+                return ASGART_E_ARG;
+            }
+            if (d.field == &Options::tier_order)
+                for (int64_t v = value; v; v /= 10)
+                    if (v % 10 < 1 || v % 10 > 7) {
+                        set_error("option tier_order: digits must be tiers 1..7");
+                        return ASGART_E_ARG;
+                    }
+            o.*(d.field) = value;
+            return 0;
+        }
+    set_error("unknown option '%s'", name);
+    return ASGART_E_ARG;
+}
+
+// ASGART_<NAME> for every option; malformed or out-of-range values are ignored (defaults stay)
+void options_from_env(Options &o) {
+    auto one = [&](const char *name) {
+        char env[64] = "ASGART_";
+        size_t j = 7;
+        for (const char *c = name; *c && j + 1 < sizeof(env); ++c) env[j++] = (char)toupper((unsigned char)*c);
+        env[j] = 0;
+        const char *e = getenv(env);
+        if (!e || !*e) return;
+        char *end = nullptr;
+        const long long v = strtoll(e, &end, 10);
+        if (end && *end == 0) (void)option_set(o, name, (int64_t)v);
+    };
+    for (const OptDesc &d : kOptions) one(d.name);
+    for (int t = 1; t <= 7; ++t) {
+        char nm[8];
+        snprintf(nm, sizeof nm, "grid%d", t);
+        one(nm);
+    }
 }
 
 // ---- kernels ---------------------------------------------------------------
@@ -182,9 +265,9 @@ static void free_k_specific(asgart_index *idx) {
     idx->k = 0;
 }
 
-static int choose_depth(int64_t n, uint64_t k) {
+static int choose_depth(int64_t n, uint64_t k, int64_t forced) {
     int d = 12;
-    if (const char *e = getenv("ASGART_PTAB_DEPTH")) d = atoi(e);
+    if (forced > 0) d = (int)forced;
     else {
         // ~one table entry per suffix, between 4^6 and 4^15 (measured at n = 3.1 G: search
         // 61 / 53 / 47 / 45 ms per launch for d = 12 / 13 / 14 / 15)
@@ -246,7 +329,7 @@ int32_t index_prepare(asgart_index *idx, uint64_t k) {
     auto t0 = std::chrono::steady_clock::now();
     const uint64_t n = (uint64_t)idx->n;
     const size_t slot = idx->wide ? 8 : 4;
-    const int d = choose_depth(idx->n, k);
+    const int d = choose_depth(idx->n, k, idx->opt.ptab_depth);
     const uint64_t entries = (1ull << (2 * d)) + 1;
     HIP_TRY(hipMalloc((void **)&idx->d_keys, (n + 16) * sizeof(uint64_t)));
     HIP_TRY(hipMalloc(&idx->d_ptab, entries * slot));
@@ -355,9 +438,10 @@ int32_t asgart_index_create(const uint8_t *T, int64_t n, const int64_t *SA, int6
     }
     idx->device = device;
     idx->n = n;
-    // ASGART_FORCE_WIDE=1 (tests): 64-bit slots and positions also for a small text, so that the
+    options_from_env(idx->opt);  // the only place the environment is read
+    // force_wide (tests): 64-bit slots and positions also for a small text, so that the
     // instantiations a > 4 Gb input selects can be checked against the oracle
-    idx->wide = (uint64_t)n >= 0xFFFFFF00ull || (getenv("ASGART_FORCE_WIDE") && atoi(getenv("ASGART_FORCE_WIDE")) != 0);
+    idx->wide = (uint64_t)n >= 0xFFFFFF00ull || idx->opt.force_wide != 0;
     for (auto &cx : idx->ctx) memset(&cx.stats, 0, sizeof(cx.stats));
     int32_t rc = [&]() -> int32_t {
         for (auto &cx : idx->ctx) {
@@ -431,6 +515,22 @@ int32_t asgart_index_create(const uint8_t *T, int64_t n, const int64_t *SA, int6
     }
     *out = idx;
     return 0;
+}
+
+int32_t asgart_index_set_option(asgart_index *idx, const char *name, int64_t value) {
+    if (!idx) {
+        set_error("index is NULL");
+        return ASGART_E_ARG;
+    }
+    if (name && (!strcmp(name, "force_wide") || !strcmp(name, "ptab_depth")) ) {
+        set_error("option %s is fixed when the index is created (set ASGART_%s before)", name,
+                  !strcmp(name, "force_wide") ? "FORCE_WIDE" : "PTAB_DEPTH");
+        return ASGART_E_ARG;
+    }
+    idx->acquire_all();  // never changes under a running call
+    const int32_t rc = option_set(idx->opt, name, value);
+    idx->release_all();
+    return rc;
 }
 
 int32_t asgart_index_prepare(asgart_index *idx, uint64_t probe_size) {

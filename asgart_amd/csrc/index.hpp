@@ -107,6 +107,30 @@ struct SearchCtx {
     bool busy = false;
 };
 constexpr int kNumCtx = 2;
+
+// Tuning / test options of one index.  They are read from the environment (ASGART_<NAME>) exactly
+// once, by asgart_index_create, range-checked there, and can be changed between calls with
+// asgart_index_set_option; the search path itself never calls getenv.
+struct Options {
+    int64_t shard_lookback = 4096;  // probes of look-back halo of a sharded call (grows on retry)
+    int64_t shard_lookahead = 0;    // 0: max(65536, own range / 16)
+    int64_t force_tier = 0;         // tests: minimum extension tier of segments with a multi-hit probe
+    int64_t arms_kernel = 1;        // 0: LDS-array kernels in tiers 2, 4, 6 (what max_cardinality > 1024 selects)
+    int64_t long3 = 4096;           // probes; longer segments go to the low-latency tier 3
+    int64_t long3_big = -1;         // -1: long3 / 4
+    int64_t cap1 = 256;             // live-arm bound up to which a segment may use the one-wave tier
+    int64_t filter = 0;             // 1: continuation filter pre-pass
+    int64_t debug = 0;              // 1: per-call tier statistics on stderr
+    int64_t test_cap_limit = -1;    // tests: shrink every tier's capacity (forces the cascade)
+    int64_t test_levels = 4;        // tests: usable hit-table levels of the arm-resident kernel
+    int64_t test_genbits = 22;      // tests: width of its generation counter
+    int64_t tier_order = 3654217;   // launch order of the extension tiers, as decimal digits
+    int64_t grid[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // grid[t] > 0: workgroups of tier t (clamped to its maximum)
+    int64_t ptab_depth = 0;         // 0: chosen from the text length
+    int64_t force_wide = 0;         // tests: 64-bit slots and positions for a small text
+};
+int32_t option_set(Options &o, const char *name, int64_t value);  // ASGART_E_ARG: unknown name / bad value
+void options_from_env(Options &o);
 }  // namespace asgart
 
 struct asgart_index {
@@ -127,6 +151,7 @@ struct asgart_index {
     uint64_t tail_bloom = 0;
     std::vector<uint8_t> h_tail;  // last 64 bytes of the text (host copy)
     double ms_prepare = 0.0;
+    asgart::Options opt;
     asgart::SearchCtx ctx[asgart::kNumCtx];
     int last_ctx = 0;  // context of the most recent search call (asgart_get_stats)
     std::mutex mu;

@@ -48,7 +48,6 @@ namespace asgart {
 #endif
 
 // default launch order / grid sizes of the extension tiers (see the launch site)
-constexpr const char *kTierOrder = "3654217";
 constexpr uint64_t kGrid1 = 256ull * 8ull, kGrid2 = 256ull * 3ull;
 // arms per thread of the arm-resident kernel: 9 x 512 = 4608 live arms (6 x 512 with 64-bit positions)
 template <class SlotT> constexpr int kArmsLayers = sizeof(SlotT) == 4 ? 9 : 6;
@@ -60,7 +59,6 @@ constexpr int kWaveArmsHits = 512;
 constexpr uint64_t kGrid2Arms = 256ull * 8ull;
 template <class SlotT> constexpr int kLongArmsLayers = sizeof(SlotT) == 4 ? 5 : 2;  // tier 3: 4 x 1024 arms
 constexpr int kPoleLdsPad = 0;             // > 0: tier 3 workgroups take a whole CU (measured: no gain)
-constexpr uint32_t kLongSegment = 4096;  // probes; longer segments get the low-latency shape (tier 3)
 constexpr int kArmCapSmall = 256;   // live arms per wave in LDS, common case
 constexpr uint32_t kTier1MaxSum = 20000;  // placement: busier segments never run on a single wave
 constexpr int kArmCapMid = 768;     // second tier: block-cooperative kernel, 256 threads per segment
@@ -139,9 +137,10 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
     const uint32_t own_lo = (uint32_t)((uint64_t)P * (uint64_t)shard / (uint64_t)n_shards);
     const uint32_t own_hi = (uint32_t)((uint64_t)P * (uint64_t)(shard + 1) / (uint64_t)n_shards);
     if (own_lo == own_hi) return 0;
-    uint64_t look_back = 4096, look_ahead = std::max<uint64_t>(65536, (own_hi - own_lo) / 16);
-    if (const char *e = getenv("ASGART_SHARD_LOOKBACK")) look_back = std::max(1, atoi(e));
-    if (const char *e = getenv("ASGART_SHARD_LOOKAHEAD")) look_ahead = std::max(1, atoi(e));
+    const Options opt = idx->opt;  // options cannot change while this call holds a context
+    uint64_t look_back = (uint64_t)opt.shard_lookback;
+    uint64_t look_ahead = opt.shard_lookahead > 0 ? (uint64_t)opt.shard_lookahead
+                                                  : std::max<uint64_t>(65536, (own_hi - own_lo) / 16);
     auto chunk_of_host = [&](uint32_t g) {
         return (int64_t)(std::upper_bound(h_pbase.begin(), h_pbase.end(), g) - h_pbase.begin()) - 1;
     };
@@ -273,8 +272,8 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
         RC_TRY(w.ovf_list.reserve((size_t)(n_seg + 1) * 4 * kTiers));
         std::vector<SdRec> h_recs;
         // ---- placement: per-segment work estimate -> tier, longest first --------------------
-        // ASGART_FORCE_TIER=t (tests): start every segment with a multi-hit probe in tier >= t
-        const int force_tier = getenv("ASGART_FORCE_TIER") ? atoi(getenv("ASGART_FORCE_TIER")) : 0;
+        // option force_tier = t (tests): start every segment with a multi-hit probe in tier >= t
+        const int force_tier = (int)opt.force_tier;
         RC_TRY(w.seg_keys.reserve((size_t)n_seg * 4 * 2));
         RC_TRY(w.seg_vals.reserve((size_t)n_seg * 4 * 2));
         uint32_t *kbuf = w.seg_keys.as<uint32_t>(), *vbuf = w.seg_vals.as<uint32_t>();
@@ -292,8 +291,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
         // shapes 2 and 4 stage 512 hits per probe and are skipped when max_cardinality > 512.
         constexpr int caph = sizeof(SlotT) == 4 ? kArmCapHybrid32 : kArmCapHybrid64;
         constexpr int capg = sizeof(SlotT) == 4 ? kArmCapGlobal32 : kArmCapGlobal64;
-        const bool arms_kernel = rp.C <= (uint64_t)kHitBatch &&
-                                 !(getenv("ASGART_ARMS_KERNEL") && atoi(getenv("ASGART_ARMS_KERNEL")) == 0);
+        const bool arms_kernel = rp.C <= (uint64_t)kHitBatch && opt.arms_kernel != 0;
         const bool arms_small = arms_kernel && rp.C <= (uint64_t)kWaveArmsHits;
         uint32_t tier_cap[kTiers + 1] = {0, kArmCapSmall, 0, 0, 0, 0, 0, (uint32_t)capg};
         if (arms_kernel) {
@@ -320,10 +318,10 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
         pp.long3 = pp.long3_big = 0;
         for (int t = 1; t < kTiers; ++t) pp.cap[t - 1] = tier_cap[t];
         if (arms_kernel) {
-            pp.long3 = getenv("ASGART_LONG3") ? (uint32_t)atoi(getenv("ASGART_LONG3")) : kLongSegment;
-            pp.long3_big = getenv("ASGART_LONG3_BIG") ? (uint32_t)atoi(getenv("ASGART_LONG3_BIG")) : pp.long3 / 4u;
+            pp.long3 = (uint32_t)opt.long3;
+            pp.long3_big = opt.long3_big >= 0 ? (uint32_t)opt.long3_big : pp.long3 / 4u;
             if (force_tier == 3) pp.long3 = pp.long3_big = 1;
-            if (const char *e = getenv("ASGART_CAP1")) pp.cap[0] = (uint32_t)std::max(1, std::min(atoi(e), kArmCapSmall));
+            pp.cap[0] = (uint32_t)std::min<int64_t>(opt.cap1, kArmCapSmall);
         }
         int force_eff = force_tier;  // a forced tier that has no kernel in this mode: the next one that has
         while (force_eff > 1 && force_eff < kTiers && !tier_enabled(force_eff)) ++force_eff;
@@ -333,9 +331,9 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
         // Measured on the GRCh38-shaped workload the filter removes ~85 % of the arms of dense
         // repeat clusters but its LDS-atomic pre-pass costs more than the extension tiers gain
         // while a few long tandem-array segments set the critical path, so it is opt-in
-        // (ASGART_FILTER=1) until the pre-pass is cheaper.  Results are identical either way.
+        // (option filter = 1) until the pre-pass is cheaper.  Results are identical either way.
         pp.use_filter = (k < st->min_duplication_length && rp.tstar <= 64u && rp.C <= 5000u &&
-                         getenv("ASGART_FILTER") && atoi(getenv("ASGART_FILTER")) != 0) ? 1 : 0;
+                         opt.filter != 0) ? 1 : 0;
         uint8_t *hit_flag = nullptr;             // without the filter: no flag array at all
         const uint32_t *p_nflag = p_filt;        // ... and every hit may create an arm
         if (pp.use_filter) {
@@ -361,15 +359,18 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             n_t[t] = h_ctr[CT_N1 + t];
             seg_off[t + 1] = seg_off[t] + n_t[t];
         }
-        if (getenv("ASGART_DEBUG")) {
+        if (opt.debug) {
             fprintf(stderr, "[asgart] segments per tier:");
             for (int t = 0; t < kTiers; ++t) fprintf(stderr, " %llu", (unsigned long long)n_t[t]);
             fprintf(stderr, "\n");
         }
         uint32_t *ovf[kTiers];  // ovf[t-1]: segments tier t gave up on
         for (int t = 0; t < kTiers; ++t) ovf[t] = w.ovf_list.as<uint32_t>() + (size_t)t * (n_seg + 1);
+        // HBM arm storage of the LDS-array kernels: tier 6 (MODE 1) and tier 7 (MODE 2) may run at the
+        // same time on different streams, so each gets its own region of 256 per-workgroup slices
         const size_t per_wg = (size_t)capg * (4 * sizeof(SlotT) + 16);
-        RC_TRY(w.scratch.reserve(per_wg * 256));
+        RC_TRY(w.scratch.reserve(per_wg * 256 * 2));
+        char *const scratch6 = w.scratch.as<char>(), *const scratch7 = scratch6 + per_wg * 256;
         for (int attempt = 0;; ++attempt) {
             RC_TRY(w.fam_sds.reserve((size_t)rec_cap * sizeof(SdRec)));
             HIP_TRY(hipMemsetAsync(d_ctr + CT_SD, 0, 8, s));
@@ -384,12 +385,12 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             ep.p_nflag = p_nflag;
             ep.recs = w.fam_sds.as<SdRec>();
             ep.rec_cap = rec_cap;
-            ep.scratch = w.scratch.as<char>();
-            // ASGART_TEST_CAP_LIMIT (tests): shrink the tiers' capacity to exercise the cascade
-            ep.cap_limit = getenv("ASGART_TEST_CAP_LIMIT") ? (uint32_t)atoi(getenv("ASGART_TEST_CAP_LIMIT")) : 0xFFFFFFFFu;
+            ep.scratch = scratch6;
+            // option test_cap_limit (tests): shrink the tiers' capacity to exercise the cascade
+            ep.cap_limit = opt.test_cap_limit >= 0 ? (uint32_t)opt.test_cap_limit : 0xFFFFFFFFu;
             ep.escalate_cost = 0xFFFFFFFFu;
-            ep.n_levels = getenv("ASGART_TEST_LEVELS") ? (uint32_t)atoi(getenv("ASGART_TEST_LEVELS")) : 4u;
-            ep.gen_bits = getenv("ASGART_TEST_GENBITS") ? (uint32_t)atoi(getenv("ASGART_TEST_GENBITS")) : 22u;
+            ep.n_levels = (uint32_t)opt.test_levels;
+            ep.gen_bits = (uint32_t)opt.test_genbits;
             ep.ctr = d_ctr;
             // The tiers are launched together on separate streams, each with a grid that can fill
             // the chip on its own (persistent workgroups, longest segment first): the hardware
@@ -408,15 +409,15 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             // (tens of thousands of probes, strictly serial): those tiers go first, the one-wave
             // tier last, and the heavy grids are sized so that every tier's longest segments
             // start at once instead of queueing behind another tier's bulk.
-            const char *order_env = getenv("ASGART_TIER_ORDER");
-            const std::string tier_order = order_env ? order_env : kTierOrder;
+            const std::string tier_order = std::to_string((long long)opt.tier_order);
             // one launch of tier `tier`'s kernel over the list described by ep
             auto launch_kernel = [&](int tier, uint64_t n_items, hipStream_t st) {
+                // option grid<t> may shrink a tier's grid; the workgroup kernels (tiers 3..7) never get
+                // more workgroups than their default (HBM scratch is reserved for that many)
                 auto grid = [&](uint64_t dflt) -> unsigned {
-                    char name[32];
-                    snprintf(name, sizeof name, "ASGART_GRID%d", tier);
-                    const char *e = getenv(name);
-                    return (unsigned)std::min<uint64_t>(n_items, e ? (uint64_t)std::max(1, atoi(e)) : dflt);
+                    uint64_t g = dflt;
+                    if (opt.grid[tier] > 0) g = tier >= 3 ? std::min<uint64_t>(dflt, (uint64_t)opt.grid[tier]) : (uint64_t)opt.grid[tier];
+                    return (unsigned)std::min<uint64_t>(n_items, g);
                 };
                 switch (tier) {
                 case 1:
@@ -449,7 +450,9 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                         extend_heavy_kernel<SlotT, caph, kHeavyThreads, 1><<<grid(256), kHeavyThreads, 0, st>>>(ep);
                     break;
                 default:
+                    ep.scratch = scratch7;
                     extend_heavy_kernel<SlotT, capg, kHeavyThreads, 2><<<grid(256), kHeavyThreads, 0, st>>>(ep);
+                    ep.scratch = scratch6;
                     break;
                 }
             };
@@ -485,7 +488,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             PROF_DUMP("concurrent tiers");
             n_overflow = 0;
             for (int t = 1; t < kTiers; ++t) n_overflow += h_ctr[CT_OVF1 + t - 1];
-            if (getenv("ASGART_DEBUG")) {
+            if (opt.debug) {
                 fprintf(stderr, "[asgart] overflow out of tiers 1..%d:", kTiers - 1);
                 for (int t = 1; t < kTiers; ++t) fprintf(stderr, " %llu", (unsigned long long)h_ctr[CT_OVF1 + t - 1]);
                 fprintf(stderr, "\n");
@@ -608,6 +611,11 @@ int32_t run_search(asgart_index *idx, const uint64_t *chunks, int64_t n_chunks,
                    std::vector<uint64_t> *rowoff_out, std::vector<uint64_t> *hits_out) {
     if (!idx || !st || n_chunks < 0 || (n_chunks && !chunks)) {
         set_error("bad argument");
+        return ASGART_E_ARG;
+    }
+    if (st->max_gap_size == 0) {
+        // the CLI always passes gap + probe_size (reference src/bin/asgart.rs:681), never 0
+        set_error("max_gap_size must be >= 1 (it includes probe_size, src/bin/asgart.rs:681)");
         return ASGART_E_ARG;
     }
     if (n_shards < 1 || shard < 0 || shard >= n_shards) {

@@ -187,7 +187,7 @@ def run_result(families: List[ProtoSDsFamily], strand, settings: RunSettings) ->
                 "right_length": sd.right_length,
                 "left_seq": None,
                 "right_seq": None,
-                "identity": float(sd.identity),
+                "identity": F32(sd.identity),
                 "reversed": bool(sd.reversed),
                 "complemented": bool(sd.complemented),
             })
@@ -211,9 +211,72 @@ def run_result(families: List[ProtoSDsFamily], strand, settings: RunSettings) ->
     }
 
 
+def f32_repr(v) -> str:
+    """An f32 the way serde_json prints it (ryu): the shortest decimal that reads back as the same
+    f32, `97.3` not `97.30000305175781`; always with a fraction or an exponent (`0.0`, `100.0`,
+    `1e-7`).  NaN and infinities serialise as `null` (serde_json)."""
+    x = np.float32(v)
+    if not np.isfinite(x):
+        return "null"
+    if x == 0:
+        return "-0.0" if np.signbit(x) else "0.0"
+    digits, exp = np.format_float_scientific(x, unique=True, trim="-", exp_digits=1).split("e")
+    e10 = int(exp)
+    mant = digits.replace(".", "").lstrip("-")
+    kk = e10 + 1  # position of the decimal point relative to the first digit
+    if -6 < kk <= 13:  # ryu's f32 pretty printer: plain decimal notation for 1e-6 <= |x| < 1e13
+        return np.format_float_positional(x, unique=True, trim="0")
+    sign = "-" if x < 0 else ""
+    body = mant[0] + ("." + mant[1:] if len(mant) > 1 else "")
+    return f"{sign}{body}e{kk - 1}"
+
+
+class F32(float):
+    """A float that `to_json` prints as an f32 (ProtoSD/SD.identity is `f32`, src/structs.rs:424,485)."""
+
+
+def _dump(obj, ind: int, out: list):
+    pad, pad_in = "  " * ind, "  " * (ind + 1)
+    if isinstance(obj, dict):
+        if not obj:
+            out.append("{}")
+            return
+        out.append("{\n")
+        for j, (key, val) in enumerate(obj.items()):
+            out.append(pad_in + json.dumps(str(key), ensure_ascii=False) + ": ")
+            _dump(val, ind + 1, out)
+            out.append(",\n" if j + 1 < len(obj) else "\n")
+        out.append(pad + "}")
+    elif isinstance(obj, (list, tuple)):
+        if not obj:
+            out.append("[]")
+            return
+        out.append("[\n")
+        for j, val in enumerate(obj):
+            out.append(pad_in)
+            _dump(val, ind + 1, out)
+            out.append(",\n" if j + 1 < len(obj) else "\n")
+        out.append(pad + "]")
+    elif obj is None:
+        out.append("null")
+    elif isinstance(obj, bool):
+        out.append("true" if obj else "false")
+    elif isinstance(obj, (F32, np.float32)):
+        out.append(f32_repr(obj))
+    elif isinstance(obj, (int, np.integer)):
+        out.append(str(int(obj)))
+    elif isinstance(obj, float):
+        out.append(json.dumps(obj))
+    else:
+        out.append(json.dumps(str(obj), ensure_ascii=False))
+
+
 def to_json(result: dict) -> str:
-    """serde_json::to_string_pretty layout (2-space indent, `0.0`, `null`)."""
-    return json.dumps(result, indent=2)
+    """`serde_json::to_string_pretty` text of a RunResult (src/exporters.rs:12-25): 2-space indent,
+    fields in struct order, `null`, UTF-8 unescaped, `identity` as the shortest f32 decimal."""
+    out: list = []
+    _dump(result, 0, out)
+    return "".join(out)
 
 
 def out_filename(files: Sequence[str], settings: RunSettings, prefix: str = "") -> str:

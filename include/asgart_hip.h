@@ -95,6 +95,17 @@ int32_t asgart_index_create(const uint8_t *T, int64_t n, const int64_t *SA, int6
                             int32_t device, asgart_index **out);
 void asgart_index_destroy(asgart_index *idx);
 
+/* Tuning and test options of an index.  Production code never needs this call: the defaults
+ * are the tuned ones.  Each option can also be preset through the environment variable
+ * ASGART_<NAME> (upper case), which is read ONCE, inside asgart_index_create -- the search path
+ * itself never reads the environment.  Values are range-checked; ASGART_E_ARG for an unknown
+ * name or a value out of range.  Names: shard_lookback, shard_lookahead (halo sizes of a sharded
+ * call, in probes), force_tier, arms_kernel, long3, long3_big, cap1, filter, tier_order,
+ * grid1..grid7 (placement of segments on the extension kernels -- results never depend on
+ * them), debug, test_cap_limit, test_levels, test_genbits (parity tests).  ptab_depth and
+ * force_wide are fixed at creation (environment only).  Blocks until no call is in flight. */
+int32_t asgart_index_set_option(asgart_index *idx, const char *name, int64_t value);
+
 /* Optional: build the probe_size-specific search keys now (otherwise done
  * lazily by the first call that needs them; kept until another k is used). */
 int32_t asgart_index_prepare(asgart_index *idx, uint64_t probe_size);

@@ -447,9 +447,9 @@ def test_random_sweep_default_and_forced_tiers(hiplib, seed, monkeypatch):
         offs, sds = idx.search_duplications_raw(pr.chunks, st)
         assert np.array_equal(offs, eoffs) and np.array_equal(sds, esds), ("default", cli, rc)
         tier = int(rng.integers(2, 8))
-        monkeypatch.setenv("ASGART_FORCE_TIER", str(tier))
+        idx.set_option("force_tier", tier)
         if rng.integers(0, 2):
-            monkeypatch.setenv("ASGART_FILTER", "1")
+            idx.set_option("filter", 1)
         offs, sds = idx.search_duplications_raw(pr.chunks, st)
         assert np.array_equal(offs, eoffs) and np.array_equal(sds, esds), ("forced", tier, cli, rc)
 

@@ -88,6 +88,105 @@ def test_run_result_json_surface(tmp_path):
     assert postprocess.out_filename(["/x/a.fa", "b.fasta"], settings) == "a-b_RC.json"
 
 
+def test_json_text_is_serde_exact_for_f32_identity():
+    """`identity` is an f32 (src/structs.rs:485); serde_json prints the shortest decimal that reads
+    back as the same f32 (ryu), always with a fraction: 98.7, not 98.69999694824219.  Full text of a
+    small RunResult, laid out as serde_json::to_string_pretty lays it out (src/exporters.rs:12-25)."""
+    strand = asgart_amd.Strand("t.fa", np.frombuffer(b"ACGT" * 10 + b"$", dtype=np.uint8),
+                               [postprocess.Start("chr\u00e9 1", 0, 30), postprocess.Start("c2", 30, 10)])
+    settings = asgart_amd.RunSettings.from_cli(reverse=True)
+    fams = [[asgart_amd.ProtoSD(2, 31, 5, 6, float(np.float32(98.7)), True, False)],
+            [asgart_amd.ProtoSD(1, 100, 3, 3, float(np.float32(100.0)), True, False),
+             asgart_amd.ProtoSD(4, 20, 3, 3, float(np.float32(100.0 * (1.0 - 1.0 / 3.0))), True, False)]]
+    txt = postprocess.to_json(postprocess.run_result(fams, strand, settings))
+    want = """{
+  "strand": {
+    "name": "t.fa",
+    "length": 40,
+    "map": [
+      {
+        "name": "chr\u00e9 1",
+        "position": 0,
+        "length": 30
+      },
+      {
+        "name": "c2",
+        "position": 30,
+        "length": 10
+      }
+    ]
+  },
+  "settings": {
+    "probe_size": 20,
+    "max_gap_size": 120,
+    "min_duplication_length": 1000,
+    "max_cardinality": 500,
+    "trim": null,
+    "skip_masked": false
+  },
+  "families": [
+    [
+      {
+        "chr_left": "chr\u00e9 1",
+        "chr_right": "c2",
+        "global_left_position": 2,
+        "global_right_position": 31,
+        "chr_left_position": 2,
+        "chr_right_position": 1,
+        "left_length": 5,
+        "right_length": 6,
+        "left_seq": null,
+        "right_seq": null,
+        "identity": 98.7,
+        "reversed": true,
+        "complemented": false
+      }
+    ],
+    [
+      {
+        "chr_left": "chr\u00e9 1",
+        "chr_right": "unknown",
+        "global_left_position": 1,
+        "global_right_position": 100,
+        "chr_left_position": 1,
+        "chr_right_position": 100,
+        "left_length": 3,
+        "right_length": 3,
+        "left_seq": null,
+        "right_seq": null,
+        "identity": 100.0,
+        "reversed": true,
+        "complemented": false
+      },
+      {
+        "chr_left": "chr\u00e9 1",
+        "chr_right": "chr\u00e9 1",
+        "global_left_position": 4,
+        "global_right_position": 20,
+        "chr_left_position": 4,
+        "chr_right_position": 20,
+        "left_length": 3,
+        "right_length": 3,
+        "left_seq": null,
+        "right_seq": null,
+        "identity": 66.666664,
+        "reversed": true,
+        "complemented": false
+      }
+    ]
+  ]
+}"""
+    assert txt == want
+    assert json.loads(txt)["families"][0][0]["identity"] == 98.7
+    # the printer itself: ryu's f32 rules (plain decimals for 1e-6 <= |x| < 1e13, else d.ddde[-]N)
+    for v, text in ((0.0, "0.0"), (97.3, "97.3"), (98.69999694824219, "98.7"), (1e-7, "1e-7"),
+                    (1.5e-7, "1.5e-7"), (1e-6, "0.000001"), (1 / 3, "0.33333334"), (1e13, "1e13"),
+                    (123456.0, "123456.0"), (99.99999, "99.99999"), (float("nan"), "null")):
+        assert postprocess.f32_repr(v) == text, (v, postprocess.f32_repr(v))
+        if text != "null":
+            assert np.float32(float(text)) == np.float32(v)
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_chain_random_families(seed):
     """Arbitrary (not search-produced) families: every branch of _reduce, swapped arms, N-rich arms."""

@@ -1,8 +1,8 @@
 """Tuning aid: time the extension of ONE long tandem-array segment of the GRCh38-shaped workload.
 The segment is given by its global start probe g0 (from the diagnostic build's "longest" line), the
 pass (0 direct / 1 RC) and its length in probes; the script carves a sub-chunk around it and runs the
-search on that sub-chunk only, under each environment configuration given.
-Usage: python tools/pole.py PASS G0 NPROBES ['ENV=1 ...' ...]"""
+search on that sub-chunk only, under each option configuration given.
+Usage: python tools/pole.py PASS G0 NPROBES ['grid3=64 long3=2048' ...]"""
 import os
 import sys
 import time
@@ -11,6 +11,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import asgart_amd  # noqa: E402
 from asgart_amd import prep, synth  # noqa: E402
+
+# option defaults (asgart_amd/csrc/index.hpp: struct Options); grid<t> = 0 means "default grid"
+DEFAULTS = {"shard_lookback": 4096, "arms_kernel": 1, "long3": 4096, "long3_big": -1, "cap1": 256,
+            "test_cap_limit": -1, "test_levels": 4, "test_genbits": 22, "tier_order": 3654217}
+
+
+def opt_name(key):  # "ASGART_GRID3" or "grid3" -> "grid3"
+    key = key.lower()
+    return key[7:] if key.startswith("asgart_") else key
 
 rc, g0, npr = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 configs = sys.argv[4:] or [""]
@@ -47,7 +56,8 @@ st = asgart_amd.RunSettings.from_cli(reverse=bool(rc), complement=bool(rc))
 ref = None
 for conf in configs:
     kv = dict(x.split("=", 1) for x in conf.split()) if conf.strip() else {}
-    os.environ.update(kv)
+    for k_, v in kv.items():
+        idx.set_option(opt_name(k_), int(v))
     best = None
     for rep in range(3):
         t0 = time.perf_counter()
@@ -61,4 +71,4 @@ for conf in configs:
     ref = ref or sig
     print(f"[{conf or 'default'}] call {best[0]:.1f} ms extend {best[1]:.2f} ms segs {best[2]} heavy {best[3]} ovf {best[4]} sds {best[5]}{flag}", flush=True)
     for k_ in kv:
-        os.environ.pop(k_, None)
+        idx.set_option(opt_name(k_), DEFAULTS.get(opt_name(k_), 0))

@@ -1,5 +1,5 @@
 """Tuning aid: build the GRCh38-shaped index once, then time the search call under a list of
-environment configurations (launch order / grid sizes of the extension tiers are read per call).
+option configurations (launch order / grid sizes of the extension tiers are read per call).
 Usage: python tools/tune_tiers.py [cfg] 'A=1 B=2' 'A=3' ...   (one quoted config per argument)"""
 import hashlib
 import os
@@ -10,6 +10,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import asgart_amd  # noqa: E402
 from asgart_amd import prep, synth  # noqa: E402
+
+# option defaults (asgart_amd/csrc/index.hpp: struct Options); grid<t> = 0 means "default grid"
+DEFAULTS = {"shard_lookback": 4096, "arms_kernel": 1, "long3": 4096, "long3_big": -1, "cap1": 256,
+            "test_cap_limit": -1, "test_levels": 4, "test_genbits": 22, "tier_order": 3654217}
+
+
+def opt_name(key):  # "ASGART_GRID3" or "grid3" -> "grid3"
+    key = key.lower()
+    return key[7:] if key.startswith("asgart_") else key
 
 args = sys.argv[1:]
 cfg, scale = 4, 1.0
@@ -25,7 +34,7 @@ ref = None
 for conf in configs:
     kv = dict(x.split("=", 1) for x in conf.split()) if conf.strip() else {}
     for k_, v in kv.items():
-        os.environ[k_] = v
+        idx.set_option(opt_name(k_), int(v))
     line = []
     sig = hashlib.sha1()
     for st in settings:
@@ -46,4 +55,4 @@ for conf in configs:
         ok = "  RESULT DIFFERS"
     print(f"[{conf or 'default'}] " + " | ".join(line) + ok, flush=True)
     for k_ in kv:
-        os.environ.pop(k_, None)
+        idx.set_option(opt_name(k_), DEFAULTS.get(opt_name(k_), 0))
