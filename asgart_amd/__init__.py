@@ -64,7 +64,8 @@ class Stats(C.Structure):
         (n, C.c_uint64) for n in (
             "probes_total", "probes_n_skipped", "probes_searched", "probes_card_skipped",
             "probes_with_hits", "raw_hits", "filtered_hits", "segments", "families", "proto_sds",
-            "bisect_steps", "search_launches", "overflow_segments")] + [("ms_extend_tier2", C.c_double), ("heavy_segments", C.c_uint64), ("ms_probe_count", C.c_double)]
+            "bisect_steps", "search_launches", "overflow_segments")] + [("ms_extend_tier2", C.c_double), ("heavy_segments", C.c_uint64), ("ms_probe_count", C.c_double),
+        ("search_bytes", C.c_uint64), ("probes_filter_rejected", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

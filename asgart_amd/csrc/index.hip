@@ -43,6 +43,7 @@ const OptDesc kOptions[] = {
     {"tier_order", &Options::tier_order, 1, 7777777},
     {"ptab_depth", &Options::ptab_depth, 0, 15},
     {"force_wide", &Options::force_wide, 0, 1},
+    {"kfilter_bits", &Options::kfilter_bits, 0, 34},
 };
 }  // namespace
 
@@ -198,6 +199,39 @@ __global__ __launch_bounds__(256) void build_cache8_kernel(const uint64_t *__res
     c8hi[idx] = (SlotT)hi;
 }
 
+// presence filter of one orientation (search_dev.hpp): one thread per suffix-array slot, the first
+// slot of every run of equal keys decides for its k-mer
+template <class SlotT>
+__global__ __launch_bounds__(256) void build_filter_kernel(IndexView<SlotT> ix, bool reverse, bool complement,
+                                                           unsigned long long *__restrict__ flt, int bits) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= ix.n) return;
+    const uint64_t u = ix.keys[r];
+    if (r > 0 && ix.keys[r - 1] == u) return;
+    bool full = true;  // all k bases inside the text (no '$' / end padding): only those can equal a probe
+    for (int j = 0; j < ix.k; ++j) full &= ((u >> (3 * j)) & 7u) != 0u;
+    if (!full) return;
+    bool keep;
+    if (!reverse && !complement) {
+        keep = r + 1 < ix.n && ix.keys[r + 1] == u;  // occurs at least twice
+    } else {
+        const uint64_t t = transform_key(u, ix.k, reverse, complement);
+        uint64_t lo0 = 0, hi0 = ix.n;
+        uint32_t p;
+        if (prefix_index(t, ix.k, ix.d, p)) {
+            lo0 = ix.ptab[p];
+            hi0 = ix.ptab[p + 1];
+        }
+        const uint64_t l = lower_bound_keys(ix.keys, lo0, hi0, t);
+        keep = l < hi0 && ix.keys[l] == t;
+    }
+    if (keep) {
+        uint64_t w, m;
+        filter_slot(u, bits, w, m);
+        atomicOr(&flt[w], (unsigned long long)m);
+    }
+}
+
 template <class SlotT>
 __global__ __launch_bounds__(256) void cache_get_kernel(IndexView<SlotT> ix,
                                                         const uint8_t *__restrict__ pats,
@@ -260,8 +294,13 @@ static void free_k_specific(asgart_index *idx) {
     if (idx->d_ptab) (void)hipFree(idx->d_ptab);
     if (idx->d_c8lo) (void)hipFree(idx->d_c8lo);
     if (idx->d_c8hi) (void)hipFree(idx->d_c8hi);
+    for (auto &f : idx->d_filter) {
+        if (f) (void)hipFree(f);
+        f = nullptr;
+    }
     idx->d_keys = nullptr;
     idx->d_ptab = idx->d_c8lo = idx->d_c8hi = nullptr;
+    idx->filter_bits = 0;
     idx->k = 0;
 }
 
@@ -380,6 +419,58 @@ int32_t index_prepare(asgart_index *idx, uint64_t k) {
     idx->d = d;
     idx->ms_prepare =
         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return 0;
+}
+
+// Builds the presence filter of orientation `mode` for probe size k (keys prepared first).
+int32_t index_prepare_filter(asgart_index *idx, uint64_t k, int mode) {
+    RC_TRY(index_prepare(idx, k));
+    if (idx->opt.kfilter_bits == 0 || mode < 0 || mode > 3) return 0;
+    {
+        std::lock_guard<std::mutex> lk(idx->mu);
+        if (idx->k == k && idx->d_filter[mode]) return 0;
+    }
+    idx->acquire_all();
+    struct Unlock {
+        asgart_index *i;
+        ~Unlock() { i->release_all(); }
+    } unlock{idx};
+    if (idx->k != k || idx->d_filter[mode]) return 0;
+    HIP_TRY(hipSetDevice(idx->device));
+    if (!idx->filter_bits) {
+        // about 8 bits per text position, at most the configured size (the default, 2^30 bits =
+        // 128 MiB, fits the Infinity Cache next to the streams of a search call)
+        int bits = 16;
+        while (bits < 40 && (1ll << bits) < idx->n) ++bits;
+        bits += 3;
+        if (bits > (int)idx->opt.kfilter_bits) bits = (int)idx->opt.kfilter_bits;
+        if (bits < 16) bits = 16;
+        idx->filter_bits = bits;
+    }
+    const int bits = idx->filter_bits;
+    const size_t bytes = (size_t)1 << (bits - 3);
+    uint64_t *flt = nullptr;
+    HIP_TRY(hipMalloc((void **)&flt, bytes));
+    hipStream_t s = idx->ctx[0].stream;
+    int32_t rc = [&]() -> int32_t {
+        HIP_TRY(hipMemsetAsync(flt, 0, bytes, s));
+        const bool rev = (mode & 2) != 0, comp = (mode & 1) != 0;
+        const unsigned g = grid_for((uint64_t)idx->n);
+        if (idx->wide)
+            build_filter_kernel<uint64_t><<<g, 256, 0, s>>>(idx->view<uint64_t>(), rev, comp,
+                                                            (unsigned long long *)flt, bits);
+        else
+            build_filter_kernel<uint32_t><<<g, 256, 0, s>>>(idx->view<uint32_t>(), rev, comp,
+                                                            (unsigned long long *)flt, bits);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(s));
+        return 0;
+    }();
+    if (rc != 0) {
+        (void)hipFree(flt);
+        return rc;
+    }
+    idx->d_filter[mode] = flt;
     return 0;
 }
 
@@ -522,13 +613,20 @@ int32_t asgart_index_set_option(asgart_index *idx, const char *name, int64_t val
         set_error("index is NULL");
         return ASGART_E_ARG;
     }
-    if (name && (!strcmp(name, "force_wide") || !strcmp(name, "ptab_depth")) ) {
-        set_error("option %s is fixed when the index is created (set ASGART_%s before)", name,
-                  !strcmp(name, "force_wide") ? "FORCE_WIDE" : "PTAB_DEPTH");
+    if (name && (!strcmp(name, "force_wide") || !strcmp(name, "ptab_depth"))) {
+        set_error("option %s is fixed when the index is created (set ASGART_<NAME> in the environment before)", name);
         return ASGART_E_ARG;
     }
     idx->acquire_all();  // never changes under a running call
     const int32_t rc = option_set(idx->opt, name, value);
+    if (rc == 0 && !strcmp(name, "kfilter_bits")) {  // rebuilt at the new size by the next call
+        (void)hipSetDevice(idx->device);
+        for (auto &f : idx->d_filter) {
+            if (f) (void)hipFree(f);
+            f = nullptr;
+        }
+        idx->filter_bits = 0;
+    }
     idx->release_all();
     return rc;
 }

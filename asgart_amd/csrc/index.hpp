@@ -35,6 +35,9 @@ struct IndexView {
     uint32_t tail8[kMaxK];
     int n_tail8;
     uint64_t tail_bloom;
+    // presence filter of the orientation of this call (search_dev.hpp); null: no filter
+    const uint64_t *flt;
+    int flt_bits;
 };
 
 struct ChunkTable {
@@ -128,6 +131,7 @@ struct Options {
     int64_t grid[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // grid[t] > 0: workgroups of tier t (clamped to its maximum)
     int64_t ptab_depth = 0;         // 0: chosen from the text length
     int64_t force_wide = 0;         // tests: 64-bit slots and positions for a small text
+    int64_t kfilter_bits = 30;      // log2(bits) of the k-mer presence filter (search_dev.hpp); 0: no filter
 };
 int32_t option_set(Options &o, const char *name, int64_t value);  // ASGART_E_ARG: unknown name / bad value
 void options_from_env(Options &o);
@@ -146,6 +150,8 @@ struct asgart_index {
     void *d_ptab = nullptr;
     void *d_c8lo = nullptr;
     void *d_c8hi = nullptr;
+    uint64_t *d_filter[4] = {nullptr, nullptr, nullptr, nullptr};  // per orientation: reverse * 2 + complement
+    int filter_bits = 0;                                           // log2 of their size in bits
     uint32_t tail8[asgart::kMaxK];
     int n_tail8 = 0;
     uint64_t tail_bloom = 0;
@@ -211,6 +217,8 @@ struct asgart_index {
         for (int j = 0; j < asgart::kMaxK; ++j) v.tail8[j] = tail8[j];
         v.n_tail8 = n_tail8;
         v.tail_bloom = tail_bloom;
+        v.flt = nullptr;
+        v.flt_bits = 0;
         return v;
     }
 };
@@ -222,6 +230,7 @@ struct asgart_families {
 
 namespace asgart {
 int32_t index_prepare(asgart_index *idx, uint64_t k);
+int32_t index_prepare_filter(asgart_index *idx, uint64_t k, int mode);  // mode = reverse * 2 + complement
 int32_t run_search(asgart_index *idx, const uint64_t *chunks, int64_t n_chunks,
                    const asgart_settings *st, int32_t shard, int32_t n_shards, bool want_csr,
                    asgart_families *fam_out, std::vector<uint8_t> *status_out,

@@ -20,6 +20,10 @@ namespace asgart {
                 tag, h_ctr[16], h_ctr[17], h_ctr[18], h_ctr[19], h_ctr[20], h_ctr[21], h_ctr[22], h_ctr[23],  \
                 h_ctr[24], h_ctr[25], h_ctr[26], h_ctr[27], h_ctr[28], h_ctr[29], h_ctr[30] >> 32,            \
                 h_ctr[30] & 0xffffffffull, h_ctr[31] >> 32, h_ctr[31] & 0xffffffffull, h_ctr[32], h_ctr[33]); \
+        fprintf(stderr, "    P1: arm lookups=%llu linear=%llu chain nodes=%llu accepts=%llu by level:", h_ctr[40], h_ctr[41], h_ctr[42], h_ctr[43]); \
+        for (int pf_i = 0; pf_i < 8; ++pf_i) fprintf(stderr, " %llu", h_ctr[44 + pf_i]);       \
+        fprintf(stderr, "\n");                                                                 \
+        (void)hipMemsetAsync(d_ctr + 40, 0, 12 * 8, s);                                        \
         fprintf(stderr, "    longest slots:");                                                  \
         for (int pf_i = 0; pf_i < 12; ++pf_i) fprintf(stderr, " [%d]=%llu", pf_i, h_ctr[56 + pf_i]); \
         fprintf(stderr, "\n");                                                                 \
@@ -206,6 +210,8 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
     HIP_TRY(hipMemsetAsync(d_ctr, 0, CT_COUNT * 8, s));
 
     IndexView<SlotT> ix = idx->view<SlotT>();
+    ix.flt = idx->d_filter[(st->reverse ? 2 : 0) | (st->complement ? 1 : 0)];  // null: filter off
+    ix.flt_bits = idx->filter_bits;
     SlotT *p_lo = w.p_lo.as<SlotT>() - w_lo;
     uint32_t *p_raw = w.p_raw.as<uint32_t>() - w_lo;
     uint32_t *p_filt = w.p_filt.as<uint32_t>() - w_lo;
@@ -216,10 +222,10 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
 
     // ---- K1: probe search + filtered counts -----------------------------------
     HIP_TRY(hipEventRecord(cx.ev[0], s));
-    probe_count_kernel<SlotT><<<grid_for(W), 256, 0, s>>>(ix, rp, p_lo, p_raw, p_filt, big_list,
-                                                         d_ctr);
+    probe_count_kernel<SlotT, false><<<grid_for(W, kProbeBlock), kProbeBlock, 0, s>>>(
+        ix, rp, p_lo, p_raw, p_filt, big_list, d_ctr);
     HIP_TRY(hipEventRecord(cx.ev[11], s));
-    big_count_kernel<SlotT><<<2048, 256, 0, s>>>(ix, rp, p_lo, p_raw, p_filt, big_list, d_ctr);
+    big_count_kernel<SlotT, false><<<2048, 256, 0, s>>>(ix, rp, p_lo, p_raw, p_filt, big_list, d_ctr);
     HIP_TRY(hipEventRecord(cx.ev[1], s));
     // ---- K2: scans + segmentation ----------------------------------------------
     scan_reduce_kernel<<<n_blk, kScanBlock, 0, s>>>(rp, p_filt, blk);
@@ -552,6 +558,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
         }
         HIP_TRY(hipStreamSynchronize(s));
         for (size_t f0 = 0; f0 < h_recs.size();) {
+            if (h_recs[f0].g_start == kVoidStart) break;  // unused slots of the waves' record chunks: sorted last
             size_t f1 = f0;
             while (f1 < h_recs.size() && h_recs[f1].g_start == h_recs[f0].g_start &&
                    h_recs[f1].fam_seq == h_recs[f0].fam_seq)
@@ -628,9 +635,10 @@ int32_t run_search(asgart_index *idx, const uint64_t *chunks, int64_t n_chunks,
     for (;;) {
         SearchCtx &probe = idx->acquire_one(&which);
         (void)probe;
-        if (idx->k == st->probe_size) break;
+        const int mode = (st->reverse ? 2 : 0) | (st->complement ? 1 : 0);
+        if (idx->k == st->probe_size && (idx->opt.kfilter_bits == 0 || idx->d_filter[mode])) break;
         idx->release_one(which);
-        RC_TRY(index_prepare(idx, st->probe_size));
+        RC_TRY(index_prepare_filter(idx, st->probe_size, mode));
     }
     SearchCtx &cx = idx->ctx[which];
     int32_t rc;
@@ -742,10 +750,32 @@ int32_t asgart_get_stats(asgart_index *idx, uint32_t flags, asgart_stats *out) {
                 yardstick_kernel<uint32_t><<<g, 256, 0, s>>>(idx->view<uint32_t>(), rp,
                                                              cx.ws.p_filt.as<uint32_t>() - rp.g_lo, d_ctr);
             HIP_TRY(hipGetLastError());
-            unsigned long long v = 0;
+            // accounting pass of the probe-search kernels (same control flow, loads and stores priced
+            // in bytes instead of executed); the work list of the large intervals is the one the
+            // call left in the workspace
+            HIP_TRY(hipMemsetAsync(d_ctr + CT_ALG_BYTES, 0, 16, s));
+            const int mode = (rp.reverse ? 2 : 0) | (rp.complement ? 1 : 0);
+            const unsigned gp = grid_for(rp.g_hi - rp.g_lo, kProbeBlock);
+            auto account = [&](auto slot_tag) {
+                using SlotT = decltype(slot_tag);
+                IndexView<SlotT> ix = idx->view<SlotT>();
+                ix.flt = idx->d_filter[mode];
+                ix.flt_bits = idx->filter_bits;
+                probe_count_kernel<SlotT, true><<<gp, kProbeBlock, 0, s>>>(
+                    ix, rp, nullptr, nullptr, nullptr, nullptr, d_ctr);
+                big_count_kernel<SlotT, true><<<2048, 256, 0, s>>>(
+                    ix, rp, cx.ws.p_lo.as<SlotT>() - rp.g_lo, cx.ws.p_raw.as<uint32_t>() - rp.g_lo, nullptr,
+                    cx.ws.big_list.as<uint32_t>(), d_ctr);
+            };
+            if (idx->wide) account(uint64_t{}); else account(uint32_t{});
+            HIP_TRY(hipGetLastError());
+            unsigned long long v = 0, ab[2] = {0, 0};
             HIP_TRY(hipMemcpyAsync(&v, d_ctr + CT_BISECT, 8, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(ab, d_ctr + CT_ALG_BYTES, 16, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
             cx.stats.bisect_steps = v;
+            cx.stats.search_bytes = ab[0];
+            cx.stats.probes_filter_rejected = ab[1];
         }
         *out = cx.stats;
         return 0;

@@ -42,6 +42,9 @@ enum Counter {
     CT_OVF_CURSOR,
     CT_AMBIG,         // sharding: start decisions that need a longer look-back
     CT_RANOUT,        // sharding: segments that ran past the look-ahead window
+    // 16..33 and 56..67: per-phase cycle sums of the diagnostic build (-DASGART_PROFILE_EXTEND)
+    CT_ALG_BYTES = 68,  // accounting pass: bytes the probe-search kernels move by design
+    CT_FLT_REJECTED,    // accounting pass: probes answered by the presence filter alone
     CT_HIST_PEAK = 72,   // diagnostic build: log2 histograms per launch (16 bins each)
     CT_HIST_PROBES = 88,
     CT_N1 = 104,       // list lengths of the extension tiers 1..kTiers (kTiers entries)
@@ -80,79 +83,195 @@ __device__ inline bool keep_hit(uint64_t x, uint64_t i, uint64_t s, uint64_t L, 
 }
 
 // ---------------------------------------------------------------- K1 ---------
-template <class SlotT>
-__global__ __launch_bounds__(256) void probe_count_kernel(IndexView<SlotT> ix, RunParams rp,
-                                                          SlotT *__restrict__ p_lo,
-                                                          uint32_t *__restrict__ p_raw,
-                                                          uint32_t *__restrict__ p_filt,
-                                                          uint32_t *__restrict__ big_list,
-                                                          unsigned long long *__restrict__ ctr) {
-    const uint32_t g = rp.g_lo + blockIdx.x * blockDim.x + threadIdx.x;
-    bool is_big = false;
-    if (g < rp.g_hi) {
+// Probe search: one thread per probe, one workgroup per 256 consecutive probes.
+//
+//   1. The workgroup's probes cover ONE contiguous text window (stride k/2, so 256 probes =
+//      2570 bases at k = 20): it is staged into LDS with one coalesced 16-byte load per lane.
+//   2. Every base is converted once: thread h packs the 3-bit codes of "half" h (k/2 bases) and
+//      the key of probe t is half[t] ++ half[t+1] (plus one more base when k is odd).  -R walks
+//      the window downwards, -C complements the codes: needle preparation (reference
+//      src/bin/asgart.rs:206-218) without a needle.
+//   3. Presence filter (search_dev.hpp): one load from a cache-resident bitmap; a rejected probe
+//      has no hit and is done.
+//   4. The others: prefix table -> bisection over the sorted keys -> filtered count of the
+//      suffix-array interval (intervals > 32 go to the wave kernel through big_list).
+//
+// COUNT = true is the accounting pass behind bench.py's `kernel_algorithmic_bytes`: the same
+// control flow, no stores, every load / store of the real kernel priced in bytes.
+constexpr int kProbeBlock = 256;
+constexpr int kMaxHalf = (kMaxK + 1) / 2;                                   // bases per half
+constexpr int kWinBytes = ((kProbeBlock + 2) * kMaxHalf + 15 + 16 + 15) / 16 * 16;  // <= 256 lanes x 16 B
+
+template <class SlotT, bool COUNT>
+__global__ __launch_bounds__(kProbeBlock) void probe_count_kernel(IndexView<SlotT> ix, RunParams rp,
+                                                                  SlotT *__restrict__ p_lo,
+                                                                  uint32_t *__restrict__ p_raw,
+                                                                  uint32_t *__restrict__ p_filt,
+                                                                  uint32_t *__restrict__ big_list,
+                                                                  unsigned long long *__restrict__ ctr) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_text[kWinBytes];
+    __shared__ uint32_t s_half[kProbeBlock + 2];
+    typename std::conditional<COUNT, CountBytes, NoBytes>::type cb;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t gb = rp.g_lo + blockIdx.x * (uint32_t)kProbeBlock;  // first probe of the workgroup
+    const uint32_t g = gb + tid;
+    const uint32_t g_last = min(gb + (uint32_t)kProbeBlock, rp.g_hi) - 1u;
+    const int k = rp.k, H = rp.step;
+    // one chunk for the whole workgroup (all but a handful of workgroups): staged window
+    const int c0 = chunk_of_uniform(rp.ch, gb);
+    const bool uniform = rp.ch.pbase[c0 + 1] > g_last;
+    uint64_t s = 0, L = 0, i = 0, q = 0;
+    uint32_t first = 0;
+    const bool valid = g < rp.g_hi;
+    if (uniform) {
+        s = rp.ch.start[c0];
+        L = rp.ch.len[c0];
+        const uint64_t i0 = (uint64_t)(gb - rp.ch.pbase[c0] + 1) * (uint64_t)H;  // needle offset of probe gb
+        i = i0 + (uint64_t)tid * (uint64_t)H;
+        const int n_half = kProbeBlock + 2;
+        // text positions of half h, base j:  direct  b0 + h*H + j ;  reversed  e0 - h*H - j
+        const long long b0 = (long long)(s + i0), e0 = (long long)(s + L - 1u - i0);
+        const long long w_lo = rp.reverse ? e0 - (long long)n_half * H + 1 : b0;
+        const long long a_lo = w_lo & ~15ll;  // floor to 16 (two's complement: also for negatives)
+        const long long w_hi = rp.reverse ? e0 : b0 + (long long)n_half * H - 1;  // inclusive
+        const uint32_t n_load = (uint32_t)((w_hi - a_lo) / 16 + 1);  // <= kWinBytes / 16
+        if (tid < n_load) {
+            const long long a = a_lo + 16ll * tid;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (a >= 0 && (uint64_t)a + 16u <= ix.n + 64u) {  // the text allocation has 64 spare bytes
+                v = *reinterpret_cast<const uint4 *>(ix.text + a);
+                cb.rd(16);
+            }
+            *reinterpret_cast<uint4 *>(s_text + 16u * tid) = v;
+        }
+        __syncthreads();
+        for (uint32_t h = tid; h < (uint32_t)n_half; h += kProbeBlock) {
+            const long long p0 = rp.reverse ? (e0 - a_lo) - (long long)h * H : (b0 - a_lo) + (long long)h * H;
+            uint32_t v = 0;
+            for (int j = 0; j < H; ++j) {
+                uint32_t c = base_code(s_text[rp.reverse ? p0 - j : p0 + j]);
+                if (rp.complement) c = comp_code(c);
+                v = (v << 3) | c;
+            }
+            s_half[h] = v;
+        }
+        __syncthreads();
+        q = ((uint64_t)s_half[tid] << (3 * H)) | (uint64_t)s_half[tid + 1];
+        if (k & 1) q = (q << 3) | (uint64_t)(s_half[tid + 2] >> (3 * (H - 1)));
+        first = (uint32_t)(q >> (3 * (k - 1))) & 7u;
+    } else if (valid) {  // the workgroup straddles a chunk boundary: every thread on its own
         const int c = chunk_of(rp.ch, g);
-        const uint64_t s = rp.ch.start[c], L = rp.ch.len[c];
-        const uint64_t i = (uint64_t)(g - rp.ch.pbase[c] + 1) * (uint64_t)rp.step;
-        uint32_t first;
-        const uint64_t q = probe_key(ix.text, s, L, i, rp.k, rp.reverse, rp.complement, &first);
+        s = rp.ch.start[c];
+        L = rp.ch.len[c];
+        i = (uint64_t)(g - rp.ch.pbase[c] + 1) * (uint64_t)H;
+        q = probe_key(ix.text, s, L, i, k, rp.reverse, rp.complement, &first);
+        cb.rd((uint32_t)k);
+    }
+    bool is_big = false;
+    uint32_t n_rej = 0;
+    if (valid) {
         if (first == 4u) {  // needle[i] == 'N'  (automaton.rs:100-102)
-            p_filt[g] = kSkipN;
-            p_raw[g] = 0;
-            p_lo[g] = 0;
+            if (!COUNT) p_filt[g] = kSkipN;
+            cb.wr(4);
         } else {
-            uint64_t lo, hi;
-            const bool all_occurrences = kmer_range(ix, q, lo, hi);
-            const uint64_t raw = hi - lo;
-            p_lo[g] = (SlotT)lo;
-            p_raw[g] = (uint32_t)raw;
-            if (raw <= (uint64_t)kSmallInterval) {
-                uint32_t cnt = 0;
-                // Direct pass: the needle is the text itself, so the probe's own position is one of
-                // the occurrences; a single occurrence is that one, and the filter (x > i + s)
-                // drops it -- no need to fetch the suffix-array entry (most probes of a genome).
-                const bool only_self = all_occurrences && raw == 1 && !rp.reverse && !rp.complement;
-                for (uint64_t r = lo; r < hi && !only_self; ++r)
-                    cnt += keep_hit(ix.sa[r], i, s, L, rp.reverse) ? 1u : 0u;
-                p_filt[g] = cnt > rp.C ? kSkipCard : cnt;
+            bool lookup = true;
+            if (ix.flt && !is_tail_corner(ix, q)) {
+                cb.rd(8);
+                lookup = filter_test(ix.flt, ix.flt_bits, q);
+            }
+            if (!lookup) {
+                // no hit possible: in the direct pass the interval is the probe itself
+                if (!COUNT) {
+                    p_raw[g] = (!rp.reverse && !rp.complement) ? 1u : 0u;
+                    p_filt[g] = 0u;
+                }
+                cb.wr(8);
+                n_rej = 1;
             } else {
-                p_filt[g] = kPending;
-                is_big = true;
+                uint64_t lo, hi;
+                const bool all_occurrences = kmer_range(ix, q, lo, hi, cb);
+                const uint64_t raw = hi - lo;
+                if (!COUNT) {
+                    p_lo[g] = (SlotT)lo;
+                    p_raw[g] = (uint32_t)raw;
+                }
+                cb.wr(sizeof(SlotT) + 4);
+                if (raw <= (uint64_t)kSmallInterval) {
+                    uint32_t cnt = 0;
+                    // Direct pass: the needle is the text itself, so the probe's own position is one of
+                    // the occurrences; a single occurrence is that one, and the filter (x > i + s)
+                    // drops it -- no need to fetch the suffix-array entry.
+                    const bool only_self = all_occurrences && raw == 1 && !rp.reverse && !rp.complement;
+                    for (uint64_t r = lo; r < hi && !only_self; ++r) {
+                        cb.rd(sizeof(SlotT));
+                        cnt += keep_hit(ix.sa[r], i, s, L, rp.reverse) ? 1u : 0u;
+                    }
+                    if (!COUNT) p_filt[g] = cnt > rp.C ? kSkipCard : cnt;
+                    cb.wr(4);
+                } else {
+                    if (!COUNT) p_filt[g] = kPending;
+                    cb.wr(4 + 4);  // + its big_list entry
+                    is_big = true;
+                }
             }
         }
     }
-    // workgroup-aggregated append to the large-interval work list (one global atomic per group)
-    __shared__ uint32_t s_nbig, s_big[256];
-    __shared__ unsigned long long s_bbase;
-    if (threadIdx.x == 0) s_nbig = 0;
-    __syncthreads();
-    if (is_big) s_big[atomicAdd(&s_nbig, 1u)] = g;
-    __syncthreads();
-    const uint32_t nbig = s_nbig;
-    if (nbig) {
-        if (threadIdx.x == 0) s_bbase = atomicAdd(&ctr[CT_BIG], (unsigned long long)nbig);
+    if constexpr (COUNT) {
+        // workgroup totals -> two global atomics
+        __shared__ unsigned long long s_tot[2];
+        if (tid < 2) s_tot[tid] = 0;
         __syncthreads();
-        if (threadIdx.x < nbig) big_list[s_bbase + threadIdx.x] = s_big[threadIdx.x];
+        unsigned long long b = cb.n, r = n_rej;
+        for (int off = 32; off > 0; off >>= 1) {
+            b += __shfl_down(b, off);
+            r += __shfl_down(r, off);
+        }
+        if ((tid & 63u) == 0) {
+            atomicAdd(&s_tot[0], b);
+            atomicAdd(&s_tot[1], r);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            atomicAdd(&ctr[CT_ALG_BYTES], s_tot[0]);
+            if (s_tot[1]) atomicAdd(&ctr[CT_FLT_REJECTED], s_tot[1]);
+        }
+    } else {
+        // workgroup-aggregated append to the large-interval work list (one global atomic per group)
+        __shared__ uint32_t s_nbig, s_big[kProbeBlock];
+        __shared__ unsigned long long s_bbase;
+        if (tid == 0) s_nbig = 0;
+        __syncthreads();
+        if (is_big) s_big[atomicAdd(&s_nbig, 1u)] = g;
+        __syncthreads();
+        const uint32_t nbig = s_nbig;
+        if (nbig) {
+            if (tid == 0) s_bbase = atomicAdd(&ctr[CT_BIG], (unsigned long long)nbig);
+            __syncthreads();
+            if (tid < nbig) big_list[s_bbase + tid] = s_big[tid];
+        }
     }
 }
 
 // one wave per large interval: coalesced count of the kept hits with early exit
-template <class SlotT>
+template <class SlotT, bool COUNT>
 __global__ __launch_bounds__(256) void big_count_kernel(IndexView<SlotT> ix, RunParams rp,
                                                         const SlotT *__restrict__ p_lo,
                                                         const uint32_t *__restrict__ p_raw,
                                                         uint32_t *__restrict__ p_filt,
                                                         const uint32_t *__restrict__ big_list,
-                                                        const unsigned long long *__restrict__ ctr) {
+                                                        unsigned long long *__restrict__ ctr) {
     const int lane = threadIdx.x & 63;
     const uint64_t n_big = ctr[CT_BIG];
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    unsigned long long bytes = 0;
     for (uint64_t e = wave; e < n_big; e += n_waves) {
         const uint32_t g = big_list[e];
         const int c = chunk_of(rp.ch, g);
         const uint64_t s = rp.ch.start[c], L = rp.ch.len[c];
         const uint64_t i = (uint64_t)(g - rp.ch.pbase[c] + 1) * (uint64_t)rp.step;
         const uint64_t lo = p_lo[g], hi = lo + p_raw[g];
+        bytes += 4 + sizeof(SlotT) + 4 + 4;  // list entry, interval, final count
         uint64_t cnt = 0;
         // four 64-entry slices per round trip (the early exit makes the rounds dependent)
         for (uint64_t base = lo; base < hi && cnt <= rp.C; base += 256) {
@@ -162,6 +281,7 @@ __global__ __launch_bounds__(256) void big_count_kernel(IndexView<SlotT> ix, Run
                 const uint64_t r = base + 64u * u + lane;
                 x[u] = r < hi ? ix.sa[r] : (SlotT)0;
             }
+            bytes += sizeof(SlotT) * (hi - base < 256u ? hi - base : 256u);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const uint64_t r = base + 64u * u + lane;
@@ -169,8 +289,9 @@ __global__ __launch_bounds__(256) void big_count_kernel(IndexView<SlotT> ix, Run
                 cnt += __popcll(__ballot(keep));
             }
         }
-        if (lane == 0) p_filt[g] = cnt > rp.C ? kSkipCard : (uint32_t)cnt;
+        if (!COUNT && lane == 0) p_filt[g] = cnt > rp.C ? kSkipCard : (uint32_t)cnt;
     }
+    if (COUNT && lane == 0 && bytes) atomicAdd(&ctr[CT_ALG_BYTES], bytes);
 }
 
 // ---------------------------------------------------------------- K2 ---------
@@ -547,7 +668,9 @@ constexpr uint32_t kTombstone = 0xFFFFFFFFu;
         }                                                                        \
         for (int pf_i = 0; pf_i < 12; ++pf_i) pf_acc[pf_i] = 0;                  \
     } while (0)
+#define DBG_ADD(slot, v) atomicAdd(&P.ctr[40 + (slot)], (unsigned long long)(v))
 #else
+#define DBG_ADD(slot, v)
 #define PROF_DECL
 #define PROF_START()
 #define PROF_STOP(slot)
@@ -623,6 +746,40 @@ __device__ inline unsigned long long lane_of(unsigned long long v, uint32_t l) {
     return ((unsigned long long)lane_of((uint32_t)(v >> 32), l) << 32) | lane_of((uint32_t)v, l);
 }
 
+// Output records are appended to one device-wide list.  A global atomic WITH its return value costs
+// a full memory round trip (a microsecond on the critical path of a serial segment), so every wave
+// reserves kRecChunk slots at a time and hands them out from registers; what is left of a chunk
+// when the wave takes the next one (or exits) is marked void (g_start = kVoidStart: sorts last, the
+// host stops there).
+constexpr uint32_t kRecChunk = 32;
+constexpr uint32_t kVoidStart = 0xFFFFFFFFu;
+struct RecAlloc {
+    unsigned long long next = 0;  // wave-uniform
+    uint32_t left = 0;
+};
+template <class PosT>
+__device__ inline void rec_flush(RecAlloc &ra, const ExtParams<PosT> &P, int lane) {
+    if ((uint32_t)lane < ra.left && ra.next + (unsigned)lane < P.rec_cap) P.recs[ra.next + (unsigned)lane].g_start = kVoidStart;
+    ra.left = 0;
+}
+// all 64 lanes call; em = ballot of the emitting lanes (non-zero); returns this lane's slot
+template <class PosT>
+__device__ inline unsigned long long rec_slot(RecAlloc &ra, const ExtParams<PosT> &P, unsigned long long em, int lane) {
+    const uint32_t n = (uint32_t)__popcll(em);
+    if (n > ra.left) {
+        rec_flush(ra, P, lane);
+        const uint32_t take = n > kRecChunk ? n : kRecChunk;
+        unsigned long long b = 0;
+        if (lane == 0) b = atomicAdd(&P.ctr[CT_SD], (unsigned long long)take);
+        ra.next = lane_of(b, 0u);
+        ra.left = take;
+    }
+    const unsigned long long at = ra.next + (unsigned)__popcll(em & ((1ull << lane) - 1ull));
+    ra.next += n;
+    ra.left -= n;
+    return at;
+}
+
 template <class PosT, int CAP>
 __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
     __shared__ PosT s_ls[CAP], s_le[CAP], s_rs[CAP], s_re[CAP];
@@ -641,6 +798,7 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
     const uint64_t n_seg = *P.n_seg_ptr;
     const uint32_t k = (uint32_t)rp.k, step = (uint32_t)rp.step, G = rp.G;
     const uint32_t thr0 = arm_threshold(k, G);
+    RecAlloc rec_alloc;
     PROF_DECL;
 
     // Segments are fetched kFetch at a time (one contended global atomic per group).  The list is
@@ -684,12 +842,8 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
         auto emit_records = [&](bool emit, PosT ls, PosT le, PosT rs, PosT re, uint32_t seq) {
             const unsigned long long em = __ballot(emit);
             if (!em) return;
-            const int leader = __ffsll((long long)em) - 1;
-            unsigned long long base = 0;
-            if (lane == leader) base = atomicAdd(&P.ctr[CT_SD], (unsigned long long)__popcll(em));
-            base = __shfl(base, leader);
+            const unsigned long long at = rec_slot(rec_alloc, P, em, lane);
             if (emit) {
-                const unsigned long long at = base + __popcll(em & lt_mask);
                 if (at < P.rec_cap) {
                     const uint64_t ll = (uint64_t)le - (uint64_t)ls;
                     SdRec r;
@@ -1076,6 +1230,7 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
         }
         __syncthreads();
     }
+    rec_flush(rec_alloc, P, lane);
 }
 
 // ---------------------------------------------------------------- K3b --------
@@ -1477,6 +1632,7 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
     uint32_t bsh = 3;  // bucket(re) = re >> bsh with 2^bsh >= G + k: a hit meets <= 2 buckets
     while ((1ull << bsh) < (unsigned long long)G + k) ++bsh;
     const uint32_t cap_eff = min((uint32_t)CAP, P.cap_limit);
+    RecAlloc rec_alloc;
     PROF_DECL;
 
     for (;;) {
@@ -1501,12 +1657,8 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
         auto emit_records = [&](bool emit, PosT ls, PosT le, PosT rs, PosT re, uint32_t seq) {
             const unsigned long long em = __ballot(emit);
             if (!em) return;
-            const int leader = __ffsll((long long)em) - 1;
-            unsigned long long base = 0;
-            if (lane == leader) base = atomicAdd(&P.ctr[CT_SD], (unsigned long long)__popcll(em));
-            base = __shfl(base, leader);
+            const unsigned long long at = rec_slot(rec_alloc, P, em, lane);
             if (emit) {
-                const unsigned long long at = base + __popcll(em & lt_mask);
                 if (at < P.rec_cap) {
                     const uint64_t ll = (uint64_t)le - (uint64_t)ls;
                     SdRec r;
@@ -1900,6 +2052,7 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
         }
         __syncthreads();
     }
+    rec_flush(rec_alloc, P, lane);
 }
 
 // ---------------------------------------------------------------- K4c --------
@@ -1958,6 +2111,7 @@ __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
     while ((1ull << bsh) < (unsigned long long)G + k) ++bsh;
     const uint32_t cap_eff = min((uint32_t)CAP, P.cap_limit);
     const uint32_t n_lv = min((uint32_t)kLevels, P.n_levels);
+    RecAlloc rec_alloc;
     PROF_DECL;
 
     // arm state, one arm per (thread, layer)
@@ -2004,12 +2158,8 @@ __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
         auto emit_records = [&](bool emit, PosT ls, PosT le, PosT rs, PosT re, uint32_t seq) {
             const unsigned long long em = __ballot(emit);
             if (!em) return;
-            const int leader = __ffsll((long long)em) - 1;
-            unsigned long long base = 0;
-            if (lane == leader) base = atomicAdd(&P.ctr[CT_SD], (unsigned long long)__popcll(em));
-            base = lane_of(base, (uint32_t)leader);
+            const unsigned long long at = rec_slot(rec_alloc, P, em, lane);
             if (emit) {
-                const unsigned long long at = base + __popcll(em & lt_mask);
                 if (at < P.rec_cap) {
                     const uint64_t ll = (uint64_t)le - (uint64_t)ls;
                     SdRec r;
@@ -2253,9 +2403,15 @@ __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
                                 const uint32_t bits = 64u - (uint32_t)__clzll((long long)(w - 1u));  // ceil(log2 w)
                                 lv = (bits - bsh - 1u) >> 1;  // ceil((bits - bsh - 2) / 2)
                             }
+                            DBG_ADD(0, 1);            // arms looking up
+                            DBG_ADD(4 + min(lv, 7u), 1);  // ... by level
                             if (lv >= n_lv) {  // wider than any table: every hit is a candidate
+                                DBG_ADD(1, 1);
                                 for (uint32_t h = 0; h < cnt; ++h)
-                                    if ((uint64_t)(PosT)(s_hits[off + h] - lo) < w) atomicMin(&s_best[h], key);
+                                    if ((uint64_t)(PosT)(s_hits[off + h] - lo) < w) {
+                                        atomicMin(&s_best[h], key);
+                                        DBG_ADD(3, 1);
+                                    }
                             } else {
                                 const uint32_t sh = bsh + 2u * lv;
                                 const uint64_t b0 = (uint64_t)lo >> sh, b1 = ((uint64_t)lo + w - 1u) >> sh;
@@ -2267,6 +2423,7 @@ __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
                                         uint32_t h = tag & 1023u, x32 = (uint32_t)e;
                                         for (;;) {
                                             const unsigned long long nd = s_node[lv][h];
+                                            DBG_ADD(2, 1);  // chain nodes visited
                                             offer(h, x32);
                                             h = (uint32_t)(nd >> 32);
                                             x32 = (uint32_t)nd;
@@ -2278,6 +2435,8 @@ __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
                                         while (h != kNoHit) {
                                             const PosT x = s_hits[off + h];
                                             const uint32_t nx = s_node[lv][h];
+                                            DBG_ADD(2, 1);  // chain nodes visited
+                                            if ((uint64_t)(PosT)(x - lo) < w) DBG_ADD(3, 1);
                                             if ((uint64_t)(PosT)(x - lo) < w) atomicMin(&s_best[h], key);
                                             h = nx;
                                         }
@@ -2400,6 +2559,7 @@ __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
         }
         __syncthreads();
     }
+    rec_flush(rec_alloc, P, lane);
 }
 
 // yardstick: sum over searched probes of ceil(log2(b_p + 1)), b_p = size of the

@@ -13,6 +13,19 @@
 
 namespace asgart {
 
+// Byte accounting of the lookup path: NoBytes compiles to nothing (the product kernels);
+// CountBytes sums the bytes each load / store of THIS design moves (the counting pass behind
+// `kernel_algorithmic_bytes` of bench.py's roofline object).
+struct NoBytes {
+    __device__ inline void rd(uint32_t) {}
+    __device__ inline void wr(uint32_t) {}
+};
+struct CountBytes {
+    unsigned long long n = 0;
+    __device__ inline void rd(uint32_t b) { n += b; }
+    __device__ inline void wr(uint32_t b) { n += b; }
+};
+
 // index into the ACGT-only d-mer table from a k-mer key; false if one of the
 // first d bases is not A/C/G/T.
 __device__ inline bool prefix_index(uint64_t q, int k, int d, uint32_t &p) {
@@ -28,19 +41,23 @@ __device__ inline bool prefix_index(uint64_t q, int k, int d, uint32_t &p) {
     return ok;
 }
 
+template <class Cnt = NoBytes>
 __device__ inline uint64_t lower_bound_keys(const uint64_t *__restrict__ keys, uint64_t lo,
-                                            uint64_t hi, uint64_t q) {
+                                            uint64_t hi, uint64_t q, Cnt &&cb = Cnt()) {
     while (lo < hi) {
         uint64_t mid = lo + ((hi - lo) >> 1);
+        cb.rd(8);
         if (keys[mid] < q) lo = mid + 1; else hi = mid;
     }
     return lo;
 }
 
+template <class Cnt = NoBytes>
 __device__ inline uint64_t upper_bound_keys(const uint64_t *__restrict__ keys, uint64_t lo,
-                                            uint64_t hi, uint64_t q) {
+                                            uint64_t hi, uint64_t q, Cnt &&cb = Cnt()) {
     while (lo < hi) {
         uint64_t mid = lo + ((hi - lo) >> 1);
+        cb.rd(8);
         if (keys[mid] <= q) lo = mid + 1; else hi = mid;
     }
     return lo;
@@ -70,9 +87,9 @@ __device__ inline bool in_tail_list(const IndexView<SlotT> &ix, uint32_t pre24) 
 // Exact emulation of the reference's bisection for the text-tail corner
 // (reference src/searcher.rs:164-170 + superslice equal_range_by): comparator
 // says Less for suffixes shorter than k although they may sort Greater.
-template <class SlotT>
+template <class SlotT, class Cnt = NoBytes>
 __device__ inline void kmer_range_tail(const IndexView<SlotT> &ix, uint64_t q, uint64_t &lo,
-                                       uint64_t &hi) {
+                                       uint64_t &hi, Cnt &&cb = Cnt()) {
     uint32_t pre24 = (uint32_t)(q >> (3 * (ix.k - kCacheLen)));
     uint32_t c8;
     if (!cache8_index(pre24, c8)) {  // cannot happen for validated text
@@ -80,6 +97,7 @@ __device__ inline void kmer_range_tail(const IndexView<SlotT> &ix, uint64_t q, u
         return;
     }
     const uint64_t L = ix.c8lo[c8], R = ix.c8hi[c8];
+    cb.rd(2 * sizeof(SlotT));
     uint64_t size = R - L;
     if (size == 0) {
         lo = hi = L;
@@ -87,6 +105,7 @@ __device__ inline void kmer_range_tail(const IndexView<SlotT> &ix, uint64_t q, u
     }
     auto cmp = [&](uint64_t r) -> int {
         uint64_t x = ix.sa[r];
+        cb.rd(sizeof(SlotT) + 8);
         if (x + (uint64_t)ix.k > ix.n) return -1;
         uint64_t kv = ix.keys[r];
         return kv < q ? -1 : (kv > q ? 1 : 0);
@@ -113,11 +132,15 @@ __device__ inline void kmer_range_tail(const IndexView<SlotT> &ix, uint64_t q, u
 // emulated bisection of the text-tail corner (it is then what the reference finds, not necessarily
 // the set of all occurrences).
 template <class SlotT>
+__device__ inline bool is_tail_corner(const IndexView<SlotT> &ix, uint64_t q) {
+    return ix.n_tail8 && in_tail_list(ix, (uint32_t)(q >> (3 * (ix.k - kCacheLen))));
+}
+
+template <class SlotT, class Cnt = NoBytes>
 __device__ inline bool kmer_range(const IndexView<SlotT> &ix, uint64_t q, uint64_t &lo,
-                                  uint64_t &hi) {
-    uint32_t pre24 = (uint32_t)(q >> (3 * (ix.k - kCacheLen)));
-    if (ix.n_tail8 && in_tail_list(ix, pre24)) {
-        kmer_range_tail(ix, q, lo, hi);
+                                  uint64_t &hi, Cnt &&cb = Cnt()) {
+    if (is_tail_corner(ix, q)) {
+        kmer_range_tail(ix, q, lo, hi, cb);
         return false;
     }
     uint64_t lo0 = 0, hi0 = ix.n;
@@ -125,20 +148,61 @@ __device__ inline bool kmer_range(const IndexView<SlotT> &ix, uint64_t q, uint64
     if (prefix_index(q, ix.k, ix.d, p)) {
         lo0 = ix.ptab[p];
         hi0 = ix.ptab[p + 1];
+        cb.rd(2 * sizeof(SlotT));
     }
-    uint64_t l = lower_bound_keys(ix.keys, lo0, hi0, q);
+    uint64_t l = lower_bound_keys(ix.keys, lo0, hi0, q, cb);
     // most k-mers are unique or absent: walk a few equal keys (same cache
     // line) before falling back to a second bisection
     uint64_t h = l;
     int walk = 0;
-    while (h < hi0 && walk < 8 && ix.keys[h] == q) {
+    while (h < hi0 && walk < 8) {
+        cb.rd(8);
+        if (ix.keys[h] != q) break;
         ++h;
         ++walk;
     }
-    if (walk == 8 && h < hi0 && ix.keys[h] == q) h = upper_bound_keys(ix.keys, h, hi0, q);
+    if (walk == 8 && h < hi0) {
+        cb.rd(8);
+        if (ix.keys[h] == q) h = upper_bound_keys(ix.keys, h, hi0, q, cb);
+    }
     lo = l;
     hi = h;
     return true;
+}
+
+// ---- k-mer presence filter ---------------------------------------------------------------
+// A blocked two-bit Bloom filter over k-mer keys, small enough (2^filt_bits bits, 128 MiB by
+// default) to stay resident in the 256 MiB Infinity Cache: both bits of a key live in one 64-bit
+// word, so a test is ONE load that normally never reaches HBM.  One filter per orientation of
+// the run (index.hip builds it): it holds every k-mer q of the text whose probe could have a hit,
+//   direct pass:      q occurs at least twice in the text (one occurrence is the probe itself),
+//   -R / -C / -RC:    q occurs in the text AND T(q) occurs in the text, T = the needle
+//                     transformation (an involution) -- the probe IS T(some text k-mer).
+// No false negatives: a probe the filter rejects provably has no hit (its SA interval holds just
+// the probe itself in the direct pass, nothing otherwise), so it skips the prefix table, the
+// key bisection and the suffix-array read -- the random HBM gathers of the lookup.
+__device__ inline void filter_slot(uint64_t q, int bits, uint64_t &word, uint64_t &mask) {
+    const uint64_t h = q * 0x9E3779B97F4A7C15ull;
+    word = h >> (64 - (bits - 6));
+    const uint64_t h2 = (q ^ (q >> 29)) * 0xD6E8FEB86659FD93ull;
+    mask = (1ull << (h2 >> 58)) | (1ull << ((h2 >> 52) & 63u));
+}
+__device__ inline bool filter_test(const uint64_t *__restrict__ flt, int bits, uint64_t q) {
+    uint64_t w, m;
+    filter_slot(q, bits, w, m);
+    return (flt[w] & m) == m;
+}
+
+// the needle transformation on a packed key: complement every code, then reverse the order
+__device__ inline uint64_t transform_key(uint64_t q, int k, bool reverse, bool complement) {
+    uint64_t out = 0;
+    for (int j = 0; j < k; ++j) {
+        uint32_t c = (uint32_t)(q >> (3 * (k - 1 - j))) & 7u;  // j-th base
+        if (complement) c = comp_code(c);
+        const int dst = reverse ? k - 1 - j : j;               // its place in the result
+        out |= (uint64_t)c << (3 * (k - 1 - dst));
+    }
+    return out;
 }
 
 // key of the probe at needle-local offset i of chunk (s, L) under the run's

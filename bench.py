@@ -4,16 +4,29 @@
 A "step" is one pass of the hot path over the whole synthetic genome: the direct run
 plus the reverse-complement run (`asgart` and `asgart -RC`, BASELINE.json "direct+RC"),
 i.e. the equivalent of reference src/bin/asgart.rs:201-253 executed twice over the same
-index.  The index (text, suffix array, search keys) is resident in HBM before the timed
-region; results (families of ProtoSD) are back on the host when it ends.
+index.  The index (text, suffix array, search keys, presence filters) is resident in HBM
+before the timed region; results (families of ProtoSD) are back on the host when it ends.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|cfg4|tiny]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg1|cfg2|cfg3|cfg4|cfg5|tiny]
 
-Prints ONE JSON line on rank 0 (see the driver contract in the task description), with
-two extra objects: "roofline" (dominant kernel = probe-search, HBM-bound, algorithmic
-bytes of SURVEY.md section 8d over the HIP-event duration measured inside the library on
-its own stream) and "cpu_baseline" (the CPU oracle, OpenMP over chunks like the
-reference's rayon par_iter, timed on this host on a bounded sample).
+cfg1..cfg5 are BASELINE.json configs[0..4] (cfg1: direct pass only; cfg3: --skip-masked).
+Prints ONE JSON line on rank 0 (driver contract), with two extra objects:
+
+"roofline" -- the dominant HBM-bound kernel pair, probe_count_kernel + big_count_kernel:
+    achieved  = kernel_algorithmic_bytes / avg_launch_ms: the bytes THIS kernel's design loads and
+                stores per launch (window staging, filter word, prefix-table entries, keys the
+                bisection reads, suffix-array entries read, outputs), counted exactly by the
+                library's accounting pass over the same probes, over the kernels' duration
+                measured live with HIP events on the library's stream in the timed region;
+    frac      = achieved / peak (8 TB/s);
+    traffic   = HBM-side bytes per launch from the rocprofv3 PMC passes kept in profiles/
+                (FETCH_SIZE + WRITE_SIZE, tools/profile_round.sh), traffic_ms the kernels'
+                duration in those passes, traffic_frac = traffic / traffic_ms / peak,
+                waste = traffic / kernel_algorithmic_bytes;
+    reference_algorithm_bytes = SURVEY.md section 8d yardstick (the REFERENCE's algorithm at its
+                widths) -- context only, never used for frac.
+"cpu_baseline" -- the CPU oracle (OpenMP over chunks like the reference's rayon par_iter) timed on
+    this host on a bounded sample of the same workload.
 """
 from __future__ import annotations
 
@@ -33,13 +46,15 @@ import asgart_amd  # noqa: E402
 from asgart_amd import multi, prep, synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
-MODES = ((False, False), (True, True))  # direct, then -RC
+DIRECT_RC = ((False, False), (True, True))  # direct, then -RC
 WORKLOADS = {
-    # name: (config id, scale, description)
-    "tiny": (2, 0.05, "S. cerevisiae-shaped synthetic x0.05 (0.6 Mb), direct+RC, k=20 g=100"),
-    "cfg2": (2, 1.0, "S. cerevisiae S288C-shaped synthetic (12.2 Mb, 17 records), direct+RC, k=20 g=100"),
-    "cfg3": (3, 1.0, "human chr1-shaped synthetic (249 Mb), direct+RC, k=20 g=100"),
-    "cfg4": (4, 1.0, "GRCh38-shaped synthetic (3.1 Gb, 25 records), direct+RC, k=20 g=100"),
+    # name: (synth config id, scale, skip_masked, modes, description)
+    "tiny": (2, 0.05, False, DIRECT_RC, "S. cerevisiae-shaped synthetic x0.05 (0.6 Mb), direct+RC, k=20 g=100"),
+    "cfg1": (1, 1.0, False, ((False, False),), "E. coli K-12 MG1655-shaped synthetic (4.6 Mb), direct, k=20 g=100"),
+    "cfg2": (2, 1.0, False, DIRECT_RC, "S. cerevisiae S288C-shaped synthetic (12.2 Mb, 17 records), direct+RC, k=20 g=100"),
+    "cfg3": (3, 1.0, True, DIRECT_RC, "human chr1-shaped synthetic (249 Mb), direct+RC, --skip-masked, k=20 g=100"),
+    "cfg4": (4, 1.0, False, DIRECT_RC, "GRCh38-shaped synthetic (3.1 Gb, 25 records), direct+RC, k=20 g=100"),
+    "cfg5": (5, 1.0, False, DIRECT_RC, "GRCh38-shaped + 1.2 %-diverged second genome (two files, 6.1 Gb), direct+RC, k=20 g=100"),
 }
 
 
@@ -47,7 +62,7 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def algorithmic_bytes(st: dict, k: int, W: int = 8) -> int:
+def reference_algorithm_bytes(st: dict, k: int, W: int = 8) -> int:
     """B_p = k + 16 + 2*ceil(log2(b_p+1))*(W+k) + W*h_p summed over the
     searched probes (reference algorithm at reference widths, W = 8-byte SA entries)."""
     return (st["probes_searched"] * (k + 16) + 2 * st["bisect_steps"] * (W + k)
@@ -86,11 +101,12 @@ def main():
         dist = dist_mod
         comm_device = f"cuda:{local_rank}" if backend == "nccl" else "cpu"
 
-    cfg, scale, desc = WORKLOADS[args.workload]
+    cfg, scale, skip_masked, modes, desc = WORKLOADS[args.workload]
     k, gap = 20, 100
     t0 = time.time()
     recs = synth.config_genome(cfg, scale)
-    pr = prep.prepare_records(recs, skip_masked=False)
+    pr = prep.prepare_records(recs, skip_masked=skip_masked)
+    del recs
     total_bp = sum(l for _, l in pr.chunks)
     t_gen = time.time() - t0
     if rank == 0:
@@ -106,7 +122,8 @@ def main():
     if rank == 0:
         log(f"[bench] upload + GPU suffix array {t_sa:.2f}s, search keys/tables {t_index:.2f}s")
 
-    settings = [asgart_amd.RunSettings.from_cli(k=k, gap=gap, reverse=r, complement=c) for r, c in MODES]
+    settings = [asgart_amd.RunSettings.from_cli(k=k, gap=gap, reverse=r, complement=c, skip_masked=skip_masked)
+                for r, c in modes]
 
     def sync():
         if dist is not None:
@@ -115,43 +132,37 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def one_step():
-        out = []
-        for st in settings:
-            if world > 1:
-                r_ = idx.search_duplications_raw(pr.chunks, st, shard=rank, n_shards=world)
-                out.append(multi.gather_families(r_[0], r_[1], dist, device=comm_device))
-            else:
-                out.append(idx.search_duplications_raw(pr.chunks, st))
-        return out
-
-    for _ in range(args.warmup):
-        one_step()
-    # per-pass device timings + work counters (one extra untimed pass per mode)
-    pass_stats = []
-    for st in settings:
-        if world > 1:
-            idx.search_duplications_raw(pr.chunks, st, shard=rank, n_shards=world)
-        else:
-            idx.search_duplications_raw(pr.chunks, st)
-        pass_stats.append(idx.stats(1).as_dict())   # rank-local work counters
-
-    # Timed region.  The library is re-entrant (one internal context per call), so the direct and
-    # the RC pass of a step are issued from two host threads and overlap on the GPU.  The critical
-    # path of a pass is one long tandem-array segment (tens of thousands of strictly serial probes
-    # on one CU): overlapped, the rest of the chip works on the other pass meanwhile.  On one GPU
-    # this is worth a few per cent; on a probe-sharded multi-GPU run, where the bulk shrinks with
-    # 1/N and the longest segments do not, it is what keeps a step near max(pass) instead of
-    # sum(pass).  ASGART_BENCH_OVERLAP=0 runs the passes back to back.
-    from concurrent.futures import ThreadPoolExecutor
-
-    sequential = os.environ.get("ASGART_BENCH_OVERLAP", "1") == "0"
-    pool = ThreadPoolExecutor(max_workers=len(settings))
-
     def run_pass(st):
         if world > 1:
             return idx.search_duplications_raw(pr.chunks, st, shard=rank, n_shards=world)
         return idx.search_duplications_raw(pr.chunks, st)
+
+    def one_step():
+        out = []
+        for st in settings:
+            r_ = run_pass(st)
+            out.append(multi.gather_families(r_[0], r_[1], dist, device=comm_device) if world > 1 else r_)
+        return out
+
+    t0 = time.time()
+    for _ in range(args.warmup):   # the first call of an orientation also builds its presence filter
+        one_step()
+    t_warm = time.time() - t0
+    # per-pass device timings + work counters + the accounting pass (one extra untimed call per
+    # mode, the passes one after the other: "alone on the chip" kernel durations)
+    pass_stats = []
+    for st in settings:
+        run_pass(st)
+        pass_stats.append(idx.stats(1).as_dict())   # rank-local work counters
+
+    # Timed region.  The library is re-entrant (one internal context per call), so the direct and
+    # the RC pass of a step are issued from two host threads and overlap on the GPU: while one
+    # pass runs its serial extension chains the other one's search kernels use the idle CUs.
+    # ASGART_BENCH_OVERLAP=0 runs the passes back to back.
+    from concurrent.futures import ThreadPoolExecutor
+
+    sequential = os.environ.get("ASGART_BENCH_OVERLAP", "1") == "0" or len(settings) == 1
+    pool = ThreadPoolExecutor(max_workers=len(settings))
 
     sync()
     t0 = time.perf_counter()
@@ -185,18 +196,48 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    passes = len(MODES)
+    passes = len(modes)
     value = total_bp * passes * args.steps / elapsed / 1e6
     n_launch = args.steps * passes
-    alg_bytes = sum(algorithmic_bytes(s, k) for s in pass_stats)  # per step (both passes)
-    achieved = (alg_bytes * args.steps) / (search_ms / 1e3) / 1e9 if search_ms > 0 else 0.0
-    traffic = None
+    alg_bytes = sum(s["search_bytes"] for s in pass_stats) / passes          # per launch, this design
+    ref_bytes = sum(reference_algorithm_bytes(s, k) for s in pass_stats) / passes
+    avg_launch_ms = search_ms / n_launch if n_launch else 0.0
+    achieved = alg_bytes / (avg_launch_ms / 1e3) / 1e9 if avg_launch_ms > 0 else 0.0
+    alone_ms = sum(s["ms_search"] for s in pass_stats) / passes
+    prof = {}
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(args.workload)
+            prof = json.load(open(tpath)).get(args.workload) or {}
+            if not isinstance(prof, dict):
+                prof = {}
         except Exception:
-            traffic = None
+            prof = {}
+    traffic = prof.get("traffic_bytes_per_launch")
+    traffic_ms = prof.get("kernel_ms_per_launch")
+    roofline = {
+        "bound": "hbm", "kernel": "probe_count_kernel + big_count_kernel (one launch = one pass)",
+        "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 5),
+        "kernel_algorithmic_bytes": int(alg_bytes),
+        "avg_launch_ms": round(avg_launch_ms, 5),
+        "launch_timing": "HIP events on the library's stream, timed region" +
+                         ("" if sequential else " (the other pass's kernels share the chip)"),
+        # first kernel of the pair alone (rocprofv3 lists the two kernels separately)
+        "probe_count_kernel_ms": round(probe_count_ms / n_launch, 5) if n_launch else 0.0,
+        "alone_launch_ms": round(alone_ms, 5),
+        "achieved_alone": round(alg_bytes / (alone_ms / 1e3) / 1e9, 2) if alone_ms > 0 else 0.0,
+        "traffic": traffic,
+        "traffic_ms": traffic_ms,
+        "traffic_frac": (round(traffic / (traffic_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5)
+                         if traffic and traffic_ms else None),
+        "traffic_x2_applied": False,
+        "traffic_source": prof.get("source"),
+        "waste": round(traffic / alg_bytes, 3) if traffic and alg_bytes else None,
+        "reference_algorithm_bytes": int(ref_bytes),
+        "filter_rejected_frac": round(sum(s["probes_filter_rejected"] for s in pass_stats) /
+                                      max(1, sum(s["probes_searched"] for s in pass_stats)), 4),
+    }
 
     out = {
         "metric": "Mbp/s probe+extend (direct+RC, k=20 g=100)",
@@ -209,29 +250,22 @@ def main():
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
-        "dtype": "u64 keys / u32 SA",
+        "dtype": "u64 keys / u32 SA" if len(pr.data) < 0xFFFFFF00 else "u64 keys / u64 SA",
         "data": "synthetic",
         "config": {"workload": desc, "bp_per_pass": total_bp, "passes": passes,
+                   "skip_masked": skip_masked,
                    "text_bytes": int(len(pr.data)), "chunks": len(pr.chunks),
                    "parallelism": f"probe-shard x{world}" if world > 1 else "1 GPU",
                    "passes_overlapped": not sequential},
-        "roofline": {
-            "bound": "hbm", "kernel": "probe_count_kernel (+big_count_kernel)",
-            "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5),
-            "algorithmic_bytes_per_launch": int(alg_bytes / passes),
-            "avg_launch_ms": round(search_ms / n_launch, 5),
-            # first kernel of the pair alone (compare with rocprofv3's per-kernel average; with the two
-            # passes overlapped the pair's event span also holds the wait for CUs between the kernels)
-            "probe_count_kernel_ms": round(probe_count_ms / n_launch, 5),
-            "traffic": traffic,
-        },
+        "roofline": roofline,
         "phases_ms_per_step": {ph: round(v / args.steps, 4) for ph, v in phase_ms.items()},
         "index_build_s": {"upload_and_suffix_array": round(t_sa, 2), "keys_and_tables": round(t_index, 3),
+                          "first_calls_incl_presence_filters": round(t_warm, 3),
                           "sa_builder": "GPU prefix doubling (asgart_sa_build64 path)"},
         "work_per_step": {key: sum(s[key] for s in pass_stats) for key in
-                          ("probes_total", "probes_searched", "probes_card_skipped", "raw_hits",
-                           "filtered_hits", "segments", "overflow_segments", "heavy_segments", "families", "proto_sds")},
+                          ("probes_total", "probes_searched", "probes_card_skipped", "probes_filter_rejected",
+                           "raw_hits", "filtered_hits", "segments", "overflow_segments", "heavy_segments",
+                           "families", "proto_sds")},
     }
 
     if rank == 0 and not args.no_cpu_baseline:
@@ -249,7 +283,7 @@ def main():
         sample_chunks = [(s0, min(l0, per_chunk)) for s0, l0 in pr.chunks]
         sample_bp = sum(l0 for _, l0 in sample_chunks)
         t0 = time.perf_counter()
-        for r, c in MODES:
+        for r, c in modes:
             oidx.run_raw(sample_chunks, oracle.make_settings(k=k, gap=gap, reverse=r, complement=c),
                          threads=cores)
         t_cpu = time.perf_counter() - t0

@@ -75,6 +75,11 @@ typedef struct asgart_stats {
     double ms_extend_tier2;   /* part of ms_extend spent re-running those (cascade)    */
     uint64_t heavy_segments;  /* segments placed in tiers 3..7 (workgroup kernels)      */
     double ms_probe_count;    /* probe_count_kernel alone (first kernel of ms_search) */
+    /* filled only with ASGART_STATS_YARDSTICK, by an untimed accounting pass over the same probes: */
+    uint64_t search_bytes;    /* bytes the probe-search kernels load and store BY DESIGN (window
+                                 staging, filter word, prefix-table entries, keys read by the bisection,
+                                 suffix-array entries read, outputs): the algorithmic bytes of this kernel */
+    uint64_t probes_filter_rejected; /* probes answered by the k-mer presence filter alone          */
 } asgart_stats;
 
 typedef struct asgart_index asgart_index;

@@ -389,6 +389,59 @@ def test_chr1_sized_sample_parity(hiplib):
         assert len(sds) > 0 and idx.stats().heavy_segments >= 0
 
 
+def _sha_slabs(arrays, dtype):
+    import hashlib
+    h = hashlib.sha256()
+    for a in arrays:
+        h.update(np.ascontiguousarray(a).astype(dtype, copy=False).tobytes())
+    return h.hexdigest()
+
+
+def _check_against_oracle_digest(name):
+    """Full-size parity of a benchmarked configuration: the HIP path on the seeded synthetic input
+    against tests/golden/digests.json, which tests/golden/make_digests.py wrote from the CPU oracle
+    (its own SA-IS suffix array + the literal restatement of the reference's search path): input and
+    suffix array by sha256, then per pass the probe/hit counters, family and ProtoSD counts and the
+    sha256 of the complete result arrays."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(__file__), "golden", "digests.json")) as fh:
+        d = json.load(fh)[name]
+    recs = synth.config_genome(d["synth_config"], d["scale"])
+    pr = prep.prepare_records(recs, skip_masked=d["skip_masked"])
+    del recs
+    n = len(pr.data)
+    assert n == d["text_bytes"] and len(pr.chunks) == d["chunks"]
+    slab = 1 << 26
+    assert _sha_slabs((pr.data[o:o + slab] for o in range(0, n, slab)), "<u1") == d["text_sha256"]
+    assert _sha_slabs([np.array(pr.chunks, dtype=np.uint64)], "<u8") == d["chunks_sha256"]
+    cli = d["settings"]
+    with asgart_amd.Index(pr.data, None) as idx:   # suffix array built on the GPU
+        assert _sha_slabs((idx.sa_read(o, min(n, o + slab)) for o in range(0, n, slab)), "<u4") == d["sa_sha256_u32"]
+        for label, want in d["passes"].items():
+            st = asgart_amd.RunSettings.from_cli(k=cli["k"], gap=cli["gap"], min_length=cli["min_length"],
+                                                 max_cardinality=cli["max_cardinality"],
+                                                 reverse=want["reverse"], complement=want["complement"])
+            offs, sds = idx.search_duplications_raw(pr.chunks, st)
+            got = idx.stats().as_dict()
+            for key, val in want["counters"].items():
+                assert got[key] == val, (name, label, key, got[key], val)
+            assert (len(offs) - 1, len(sds)) == (want["n_families"], want["n_sds"]), (name, label)
+            assert _sha_slabs([offs], "<u8") == want["fam_offsets_sha256"], (name, label)
+            assert _sha_slabs([sds], "<u8") == want["sds_sha256"], (name, label)
+
+
+def test_cfg3_full_skip_masked_digest(hiplib):
+    """BASELINE.json configs[2] as stated: chr1-sized synthetic (249 Mb), direct + RC, --skip-masked."""
+    _check_against_oracle_digest("cfg3s")
+
+
+def test_cfg4_full_digest(hiplib):
+    """BASELINE.json configs[3], the benchmarked workload: GRCh38-sized synthetic (3.1 Gb, 25 records),
+    direct + RC, on one MI355X, against the oracle's digests of the same seeded genome."""
+    _check_against_oracle_digest("cfg4")
+
+
 @pytest.mark.parametrize("rc", [False, True])
 def test_fasta_to_run_result_end_to_end(hiplib, tmp_path, rc):
     """FASTA files -> prepare -> HIP search step -> FilterNs/ReOrder/ReduceOverlap/Sort -> RunResult,

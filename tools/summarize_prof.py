@@ -22,13 +22,13 @@ def short(name):
     return name.replace("void ", "")
 
 
-for f in glob.glob(os.path.join(out, f"{tag}_stats", "**", "*kernel_stats.csv"), recursive=True):
+for f in glob.glob(os.path.join(out, f"{tag}_{workload}_stats", "**", "*kernel_stats.csv"), recursive=True):
     shutil.copy(f, os.path.join(dst, f"{tag}_{workload}_kernel_stats.csv"))
 
 pmc = {}
 for ctr, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
     agg = defaultdict(lambda: [0, 0.0, 0])
-    for f in glob.glob(os.path.join(out, f"{tag}_{sub}", "**", "*counter_collection.csv"), recursive=True):
+    for f in glob.glob(os.path.join(out, f"{tag}_{workload}_{sub}", "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
             if row["Counter_Name"] != ctr:
                 continue
@@ -41,18 +41,47 @@ for ctr, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
 json.dump(pmc, open(os.path.join(dst, f"{tag}_{workload}_pmc_fetch_write.json"), "w"), indent=1)
 
 
-def per_launch(ctr, prefix):
-    return sum(v["avg_KB_per_launch"] for k, v in pmc.get(ctr, {}).items() if k.startswith(prefix)) * 1024
+def per_launch(ctr, prefix, field="avg_KB_per_launch"):
+    return sum(v[field] for k, v in pmc.get(ctr, {}).items() if k.startswith(prefix))
 
 
 probe = "asgart::probe_count_kernel"
 big = "asgart::big_count_kernel"
-search = sum(per_launch(c, p) for c in ("FETCH_SIZE", "WRITE_SIZE") for p in (probe, big))
+search = sum(per_launch(c, p) for c in ("FETCH_SIZE", "WRITE_SIZE") for p in (probe, big)) * 1024
+# the kernels' own durations in the (serialising) PMC passes, averaged over the two passes
+pmc_ms = sum(per_launch(c, p, "avg_ns") for c in ("FETCH_SIZE", "WRITE_SIZE") for p in (probe, big)) / 2 / 1e6
+stats_ms = None
+sfile = os.path.join(dst, f"{tag}_{workload}_kernel_stats.csv")
+if os.path.exists(sfile):
+    tot = 0.0
+    for row in csv.DictReader(open(sfile)):
+        nm = short(row["Name"])
+        if nm.startswith(probe) or nm.startswith(big):
+            tot += float(row["AverageNs"])
+    stats_ms = tot / 1e6
 if search > 0:
-    json.dump({workload: int(search),
-               "_note": "HBM-side bytes per launch of probe_count_kernel+big_count_kernel = (FETCH_SIZE+WRITE_SIZE) KB*1024 "
-                        f"from separate rocprofv3 --pmc passes (profiles/{tag}_{workload}_pmc_fetch_write.json); narrow "
-                        "(4-8 byte) gathers: not the calibrated 16 B/lane stream of MI355X_MICROARCH.md (HBM), so no x2 is "
-                        "applied to FETCH_SIZE; Infinity-Cache hits are included in the counter"},
-              open(os.path.join(dst, "pmc_traffic.json"), "w"))
-print("summarised into", dst, "search bytes/launch", int(search))
+    tfile = os.path.join(dst, "pmc_traffic.json")
+    allw = {}
+    # keep the other workloads' entries (repo copy first, then this run's scratch copy)
+    for prev in (os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json"), tfile):
+        if os.path.exists(prev):
+            try:
+                allw.update({k: v for k, v in json.load(open(prev)).items() if isinstance(v, dict)})
+            except Exception:
+                pass
+    allw[workload] = {
+        "traffic_bytes_per_launch": int(search),
+        "kernel_ms_per_launch": round(pmc_ms, 4),
+        "stats_kernel_ms_per_launch": None if stats_ms is None else round(stats_ms, 4),
+        "source": f"profiles/{tag}_{workload}_pmc_fetch_write.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
+                  f"passes, kernels serialised) and profiles/{tag}_{workload}_kernel_stats.csv (--kernel-trace --stats of "
+                  "the default bench run)",
+    }
+    allw["_note"] = ("per workload: HBM-side bytes per launch (= per pass) of probe_count_kernel + big_count_kernel = "
+                     "(FETCH_SIZE + WRITE_SIZE) KB * 1024; kernel_ms_per_launch = the two kernels' durations in those "
+                     "PMC passes; stats_kernel_ms_per_launch = their rocprofv3 --stats averages in the un-instrumented "
+                     "bench run (passes overlapped).  Narrow 4-8 byte gathers: FETCH_SIZE is used as reported (no x2); "
+                     "tools/ubench_gather.hip calibrates bytes per random gather; Infinity-Cache hits are included in "
+                     "the counter")
+    json.dump(allw, open(tfile, "w"), indent=1)
+print("summarised into", dst, "search bytes/launch", int(search), "pmc ms", round(pmc_ms, 3), "stats ms", stats_ms)
