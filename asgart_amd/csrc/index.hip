@@ -32,7 +32,6 @@ const OptDesc kOptions[] = {
     {"shard_lookahead", &Options::shard_lookahead, 0, 1ll << 31},
     {"force_tier", &Options::force_tier, 0, 7},
     {"arms_kernel", &Options::arms_kernel, 0, 1},
-    {"arms2", &Options::arms2, 0, 1},
     {"prio3", &Options::prio3, 0, 1},
     {"long3", &Options::long3, 0, 1ll << 31},
     {"long3_big", &Options::long3_big, -1, 1ll << 31},

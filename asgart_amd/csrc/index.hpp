@@ -119,7 +119,6 @@ struct Options {
     int64_t shard_lookahead = 0;    // 0: max(65536, own range / 16)
     int64_t force_tier = 0;         // tests: minimum extension tier of segments with a multi-hit probe
     int64_t arms_kernel = 1;        // 0: LDS-array kernels in tiers 2, 4, 6 (what max_cardinality > 1024 selects)
-    int64_t arms2 = 0;              // 1: two-phase arm-resident kernel (K4d); 0: its three-phase predecessor (K4c)
     int64_t prio3 = 1;              // 1: tier 3's waves run at raised issue priority (s_setprio)
     int64_t long3 = 4096;           // probes; longer segments go to the low-latency tier 3
     int64_t long3_big = -1;         // -1: long3 / 4

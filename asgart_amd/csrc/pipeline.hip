@@ -54,16 +54,15 @@ namespace asgart {
 // default launch order / grid sizes of the extension tiers (see the launch site)
 constexpr uint64_t kGrid1 = 256ull * 8ull, kGrid2 = 256ull * 3ull;
 // arms per thread of the arm-resident kernel: 9 x 512 = 4608 live arms (6 x 512 with 64-bit positions)
-template <class SlotT> constexpr int kArmsLayers = sizeof(SlotT) == 4 ? 9 : 4;
+template <class SlotT> constexpr int kArmsLayers = sizeof(SlotT) == 4 ? 9 : 6;
 // its one-wave shape: 8 x 64 = 512 live arms per wave, probes with up to 512 hits
 template <class SlotT> constexpr int kWaveArmsLayers = sizeof(SlotT) == 4 ? 8 : 5;
 // tiers 4 and 5: 4 arms per thread x 256 / 512 threads, cold fields in LDS
 template <class SlotT> constexpr int kMidArmsLayers = sizeof(SlotT) == 4 ? 4 : 2;
 constexpr int kWaveArmsHits = 512;
 constexpr uint64_t kGrid2Arms = 256ull * 8ull;
-template <class SlotT> constexpr int kLongArmsLayers = sizeof(SlotT) == 4 ? 5 : 2;  // tier 3 (K4c): 5 x 1024 arms
-template <class SlotT> constexpr int kLongArms2Layers = sizeof(SlotT) == 4 ? 4 : 2;  // tier 3 (K4d): 4 x 1024 arms
-constexpr int kPoleLdsPad = 30000;             // > 0: tier 3 workgroups take a whole CU (measured: no gain)
+template <class SlotT> constexpr int kLongArmsLayers = sizeof(SlotT) == 4 ? 5 : 2;  // tier 3: 5 x 1024 arms
+constexpr int kPoleLdsPad = 0;             // > 0: tier 3 workgroups take a whole CU (measured: no gain)
 constexpr int kArmCapSmall = 256;   // live arms per wave in LDS, common case
 constexpr uint32_t kTier1MaxSum = 20000;  // placement: busier segments never run on a single wave
 constexpr int kArmCapMid = 768;     // second tier: block-cooperative kernel, 256 threads per segment
@@ -306,7 +305,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                 tier_cap[2] = (uint32_t)kWaveArmsLayers<SlotT> * 64u;
                 tier_cap[4] = (uint32_t)kMidArmsLayers<SlotT> * 256u;
             }
-            tier_cap[3] = (uint32_t)(opt.arms2 ? kLongArms2Layers<SlotT> : kLongArmsLayers<SlotT>) * 1024u;
+            tier_cap[3] = (uint32_t)kLongArmsLayers<SlotT> * 1024u;
             tier_cap[5] = (uint32_t)kMidArmsLayers<SlotT> * 512u;
             // the window bound is pessimistic for tandem arrays (hits extend arms there) and the HBM
             // tier is several times slower per probe: tier 6 also takes segments whose bound exceeds
@@ -432,23 +431,16 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                     extend_kernel<SlotT, kArmCapSmall><<<grid(kGrid1), 64, 0, st>>>(ep);
                     break;
                 case 2:
-                    if (arms_kernel && opt.arms2)
-                        extend_arms2_kernel<SlotT, kWaveArmsLayers<SlotT>, 64, kWaveArmsHits, 512, 3><<<grid(kGrid2Arms), 64, 0, st>>>(ep);
-                    else if (arms_kernel)
+                    if (arms_kernel)
                         extend_arms_kernel<SlotT, kWaveArmsLayers<SlotT>, 64, kWaveArmsHits, 512, 3, false><<<grid(kGrid2Arms), 64, 0, st>>>(ep);
                     else
                         extend_heavy_kernel<SlotT, kArmCapMid, kMidThreads, 0><<<grid(kGrid2), kMidThreads, 0, st>>>(ep);
                     break;
                 case 3:
-                    if (opt.arms2)
-                        extend_arms2_kernel<SlotT, kLongArms2Layers<SlotT>, 1024, kHitBatch, 1024, 4><<<grid(256), 1024, 0, st>>>(ep);
-                    else
                         extend_arms_kernel<SlotT, kLongArmsLayers<SlotT>, 1024, kHitBatch, 1024, 4, false, true, kPoleLdsPad><<<grid(256), 1024, 0, st>>>(ep);
                     break;
                 case 4:
-                    if (arms_kernel && opt.arms2)
-                        extend_arms2_kernel<SlotT, kMidArmsLayers<SlotT>, 256, kWaveArmsHits, 512, 4><<<grid(256 * 4), 256, 0, st>>>(ep);
-                    else if (arms_kernel)
+                    if (arms_kernel)
                         extend_arms_kernel<SlotT, kMidArmsLayers<SlotT>, 256, kWaveArmsHits, 512, 4, false, true><<<grid(256 * 4), 256, 0, st>>>(ep);
                     else if constexpr (sizeof(SlotT) == 4)
                         extend_heavy_kernel<SlotT, kArmCapBig32, kHeavyThreads, 0><<<grid(256), kHeavyThreads, 0, st>>>(ep);
@@ -456,15 +448,10 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                         extend_heavy_kernel<SlotT, kArmCapBig64, kHeavyThreads, 0><<<grid(256), kHeavyThreads, 0, st>>>(ep);
                     break;
                 case 5:
-                    if (opt.arms2)
-                        extend_arms2_kernel<SlotT, kMidArmsLayers<SlotT>, 512, kHitBatch, 1024, 4><<<grid(256 * 2), 512, 0, st>>>(ep);
-                    else
                         extend_arms_kernel<SlotT, kMidArmsLayers<SlotT>, 512, kHitBatch, 1024, 4, false, true><<<grid(256 * 2), 512, 0, st>>>(ep);
                     break;
                 case 6:
-                    if (arms_kernel && opt.arms2)
-                        extend_arms2_kernel<SlotT, kArmsLayers<SlotT>, kHeavyThreads, kHitBatch, 1024, 4><<<grid(256), kHeavyThreads, 0, st>>>(ep);
-                    else if (arms_kernel)
+                    if (arms_kernel)
                         extend_arms_kernel<SlotT, kArmsLayers<SlotT>, kHeavyThreads, kHitBatch, 1024, 4, false, true><<<grid(256), kHeavyThreads, 0, st>>>(ep);
                     else
                         extend_heavy_kernel<SlotT, caph, kHeavyThreads, 1><<<grid(256), kHeavyThreads, 0, st>>>(ep);

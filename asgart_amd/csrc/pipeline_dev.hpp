@@ -2145,13 +2145,13 @@ __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
     // pass reads its counter after its barrier while the next pass already adds to the other.
     uint32_t gen = 0, par = 0, freed_seen0 = 0, freed_seen1 = 0;
     uint32_t ppar = 0, new_seen0 = 0, new_seen1 = 0, spur_seen0 = 0, spur_seen1 = 0;
-    __syncthreads();
+    lds_barrier();
 
     for (;;) {
         if (tid == 0) s_bcast = atomicAdd(P.cursor, 1ull);
-        __syncthreads();
+        lds_barrier();
         const unsigned long long seg = uni(s_bcast);
-        __syncthreads();
+        lds_barrier();
         if (seg >= n_seg) break;
         const uint32_t g0 = P.seg_list[seg];
         PROF_SEG_BEGIN();
@@ -2253,7 +2253,7 @@ __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
                 }
             }
             pre();
-            __syncthreads();
+            lds_barrier();
             const uint32_t freed_now = uni(s_nfreed[par]);
             const uint32_t nd = freed_now - freed_base;
             if (par) freed_seen1 = freed_now; else freed_seen0 = freed_now;
@@ -2334,7 +2334,7 @@ __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
                     s_hflag[r] = (P.hit_flag ? P.hit_flag[base + r] : (uint8_t)1);
                 }
             }
-            __syncthreads();
+            lds_barrier();
             const unsigned long long in_batch = nbb >= 64 ? ~0ull : ((1ull << nbb) - 1ull);
             const unsigned long long hm = __ballot(f_l >= 1u && f_l < kPending) & in_batch;
             const unsigned long long qm = __ballot(f_l == 0u) & in_batch;
@@ -2375,13 +2375,13 @@ __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
                 // already did, in its own barrier interval) -------------------------------------
                 if (!pre_indexed) {
                     if (++gen >> kGenBits) {  // generation wrap: clear the tables once
-                        __syncthreads();
+                        lds_barrier();
                         clear_tables();
                         gen = 1;
-                        __syncthreads();
+                        lds_barrier();
                     }
                     index_hits(cnt, off);
-                    __syncthreads();
+                    lds_barrier();
                 }
                 pre_indexed = false;
                 PROF_STOP(2);
@@ -2456,7 +2456,7 @@ __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
                         }
                     }
                 }
-                __syncthreads();
+                lds_barrier();
                 PROF_STOP(4);
                 PROF_START();
                 // ---- P2: hits notify arms / claim free slots ----------------------------------
@@ -2500,7 +2500,7 @@ __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
                         }
                     }
                 }
-                __syncthreads();
+                lds_barrier();
                 const uint32_t new_now = uni(s_nnew[ppar]), spur_now = uni(s_nspur[ppar]);
                 const uint32_t n_new = new_now - new_base;
                 const bool spur = spur_now != spur_base;
@@ -2546,7 +2546,7 @@ __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
                 const uint32_t q = (uint32_t)__popcll(qm & range);
                 if (q) advance_quiet(q);
             }
-            __syncthreads();
+            lds_barrier();
             g += nbb;
         }
         if (overflow) done = true;
@@ -2567,640 +2567,7 @@ __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
         if (tid < 64) {
             PROF_FLUSH();
         }
-        __syncthreads();
-    }
-    rec_flush(rec_alloc, P, lane);
-}
-
-// ---------------------------------------------------------------- K4d --------
-// Arm-resident extension kernel, TWO barrier phases per probe (successor of K4c; same results).
-//
-// The serial chain of a segment is probe -> probe -> probe, and inside a probe every exchange
-// between "the arms" and "the hits" is an LDS write, a workgroup barrier and an LDS read (>= 300
-// cycles, tools/ubench_phases.hip).  K4c needs three exchanges per probe plus one more pass per run
-// of quiet probes, and spends most of a probe in dependent LDS round trips.  Here:
-//
-//   phase 1 (arms)   every live arm loads the heads of the (at most two, for a narrow arm) buckets
-//                    that cover its accept window together; head and chain entries carry the hit's
-//                    position, so the common single-hit bucket is ONE round trip.  An accepted hit
-//                    gets atomicMin(best[h], creation number) -- the first arm in list order wins,
-//                    src/automaton.rs:67-78 -- and the arm remembers its candidates in registers.
-//                                                                                     | barrier
-//   phase 2          arm waves (low thread numbers): re-read best[] of the candidates; the last
-//                    hit an arm won extends it (src/automaton.rs:133-150), the others age and
-//                    retire (one LDS atomic per wave).  What an arm needs every probe (window, gap,
-//                    creation number, candidates) lives in registers; left start / left end / right
-//                    start, touched only at extension and retirement, in LDS.
-//                    hit waves (high thread numbers, in parallel): unmatched hits take an empty
-//                    slot in hit order (= creation order) and post the new arm to its owner's
-//                    mailbox; then they index the NEXT probe's hits.                   | barrier
-//
-// Quiet probes are not executed at all: their ageing is a wave-uniform `pending` gap that the next
-// phase 1 adds (an arm it kills is "dead on arrival": it offers nothing and is retired in phase 2
-// under the family number it died in).  All per-probe counts are monotonic LDS counters read once
-// after a barrier; a new arm is adopted by its owner at the start of the next phase 1.
-template <class PosT, int S, int NT, int HB, int kHT, int kLevels>
-__global__ __launch_bounds__(NT) void extend_arms2_kernel(ExtParams<PosT> P) {
-    constexpr int CAP = S * NT;
-    constexpr int NW = NT / 64;
-    constexpr unsigned long long kNone = ~0ull;
-    if (NT >= 1024 && P.hi_prio) __builtin_amdgcn_s_setprio(3);  // see K4c
-    static_assert(HB <= 1023 + 1 && HB <= kHitBatch && CAP <= 0xFFFF, "hit index: 10 bits, slot: 16 bits");
-    const uint32_t kGenBits = min(21u, max(2u, P.gen_bits));  // generation counter width (21; tests: less)
-    __shared__ PosT s_hits[HB];
-    __shared__ uint8_t s_hflag[HB];
-    // head of a bucket: [generation:21][more:1][hit:10] << 32 | low word of the hit's position;
-    // node[h]: the entry that follows hit h in its bucket ([hit:10] << 32 | position), or kNone
-    __shared__ unsigned long long s_head[kLevels][kHT];
-    __shared__ unsigned long long s_node[kLevels][HB];
-    // per hit: smallest creation number among the arms that accept it.  Two copies by probe parity:
-    // phase 2 still reads the current probe's while the next probe's hits are being indexed
-    constexpr int NBEST = NT > 64 ? 2 : 1;
-    __shared__ uint32_t s_best[NBEST][HB];
-    __shared__ uint32_t s_msg[CAP];   // mailbox of an empty slot: 1 + rank of the arm created for it
-    __shared__ PosT s_cls[CAP], s_cle[CAP], s_crs[CAP];  // left start, left end, right start of every arm
-    __shared__ uint16_t s_free[CAP];  // ring of empty slots below H
-    __shared__ uint32_t s_new, s_spur, s_freed, s_doa;  // monotonic counters
-    __shared__ unsigned long long s_bcast;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    const RunParams &rp = P.rp;
-    const uint64_t n_seg = *P.n_seg_ptr;
-    const uint32_t k = (uint32_t)rp.k, step = (uint32_t)rp.step, G = rp.G;
-    // accept window of an arm: x - lo < w with lo = re - k + 1, w = thr + k - 1 (arm_accepts)
-    auto window_of = [&](uint64_t left_len) -> uint32_t {
-        const uint32_t thr = arm_threshold(left_len, G);
-        return thr > 0xFFFFFF00u ? 0xFFFFFFFFu : thr + k - 1u;
-    };
-    const uint32_t w0 = window_of(k);
-    uint32_t bsh = 3;  // level-0 bucket: 2^bsh >= G + k covers a narrow arm's window
-    while ((1ull << bsh) < (unsigned long long)G + k) ++bsh;
-    const uint32_t cap_eff = min((uint32_t)CAP, P.cap_limit);
-    const uint32_t n_lv = min((uint32_t)kLevels, P.n_levels);
-    RecAlloc rec_alloc;
-    PROF_DECL;
-
-    // arm state owned by this thread: slot = layer * NT + tid
-    PosT a_lo[S], a_cx[S];
-    uint32_t a_w[S], a_gap[S], a_seq[S], a_cand[S];
-#pragma unroll
-    for (int L = 0; L < S; ++L) {
-        a_seq[L] = kNoSeq;
-        a_lo[L] = a_cx[L] = 0;
-        a_w[L] = a_gap[L] = a_cand[L] = 0;
-    }
-    auto clear_tables = [&]() {
-        for (uint32_t h = tid; h < (uint32_t)(kLevels * kHT); h += NT) (&s_head[0][0])[h] = 0ull;
-    };
-    clear_tables();
-    for (uint32_t j = tid; j < (uint32_t)CAP; j += NT) s_msg[j] = 0u;
-    if (tid == 0) s_new = s_spur = s_freed = s_doa = 0u;
-    uint32_t gen = 0, new_seen = 0, spur_seen = 0, freed_seen = 0, doa_seen = 0;
-    __syncthreads();
-    auto bucket_slot = [&](uint64_t bkt) -> uint32_t {
-        return (((uint32_t)bkt * 2654435761u) >> 12) & ((uint32_t)kHT - 1u);
-    };
-
-    for (;;) {
-        if (tid == 0) s_bcast = atomicAdd(P.cursor, 1ull);
-        __syncthreads();
-        const unsigned long long seg = uni(s_bcast);
-        __syncthreads();
-        if (seg >= n_seg) break;
-        const uint32_t g0 = P.seg_list[seg];
-        PROF_SEG_BEGIN();
-        const int c = chunk_of_uniform(rp.ch, g0);
-        const uint32_t pb = rp.ch.pbase[c];
-        const uint32_t chunk_end = rp.ch.pbase[c + 1];
-        const uint32_t g_end = min(chunk_end, rp.g_hi);
-        // block-uniform: A live arms (incl. arms created but not yet adopted) in slots [0,H); n_free
-        // empty slots queued in the ring s_free[fq .. fq + n_free)
-        uint32_t A = 0, H = 0, n_free = 0, fq = 0, quiet = 0, fam_seq = 0, next_seq = 0;
-        uint32_t t_proc = 0, spur_until = 0, pending = 0;
-        uint32_t prev_seq_base = 0, prev_tp = 0;  // of the last hit probe (its new arms are adopted later)
-        bool have_new = false;                    // ... and whether it created any
-        bool overflow = false, done = false, fam_open = false;
-
-        // records are rare: the chunk geometry is re-read here instead of living in registers
-        auto emit_records = [&](bool emit, PosT ls, PosT le, PosT rs, PosT re, uint32_t seq, uint32_t fam) {
-            const unsigned long long em = __ballot(emit);
-            if (!em) return;
-            const unsigned long long at = rec_slot(rec_alloc, P, em, lane);
-            if (emit && at < P.rec_cap) {
-                const uint64_t cs = rp.ch.start[c], cl = rp.ch.len[c];
-                const uint64_t ll = (uint64_t)le - (uint64_t)ls;
-                SdRec r;
-                r.g_start = g0;
-                r.fam_seq = fam;
-                r.create_seq = seq;
-                r.pad = 0;
-                // left fix-up, src/bin/asgart.rs:229-237
-                r.sd.left = rp.reverse ? cs + cl - (uint64_t)ls - ll : (uint64_t)ls + cs;
-                r.sd.right = rs;
-                r.sd.left_length = ll;
-                r.sd.right_length = (uint64_t)re - (uint64_t)rs;
-                P.recs[at] = r;
-            }
-        };
-        // the flush of src/automaton.rs:182-200: every arm inactive, including the dropped ones
-        auto maybe_close = [&](uint32_t alive) {
-            if (fam_open && alive == 0 && t_proc >= spur_until) {
-                ++fam_seq;
-                next_seq = 0;
-                fam_open = false;
-            }
-        };
-        // after the barrier that ends a phase 2: what that probe created and retired
-        auto absorb = [&]() {
-            const uint32_t new_now = s_new, spur_now = s_spur, freed_now = s_freed;  // one round trip
-            const uint32_t n_new = uni(new_now) - new_seen, nd = uni(freed_now) - freed_seen;
-            const bool spur = uni(spur_now) != spur_seen;
-            new_seen += n_new;
-            freed_seen += nd;
-            spur_seen = uni(spur_now);
-            const uint32_t pops = min(n_new, n_free);
-            fq += pops;
-            if (fq >= (uint32_t)CAP) fq -= (uint32_t)CAP;
-            n_free = n_free - pops + nd;
-            H += n_new - pops;
-            A = A + n_new - nd;
-            prev_seq_base = next_seq;
-            next_seq += n_new;
-            have_new = n_new != 0u;
-            if (spur) spur_until = max(spur_until, prev_tp + rp.tstar - 1u);
-            if (A == 0) {  // every slot is empty again (A counts the arms waiting for adoption too)
-                H = 0;
-                n_free = 0;
-                fq = 0;
-            }
-        };
-        // an empty slot adopts the arm a hit of the previous hit probe created for it
-        // (src/automaton.rs:151-164; aged by that very probe: gap = step)
-        auto adopt = [&](int L, uint32_t slot) {
-            const bool ask = a_seq[L] == kNoSeq && slot < H;
-            const uint32_t m = ask ? s_msg[slot] : 0u;
-            const PosT x = ask ? s_crs[slot] : (PosT)0;
-            if (m) {
-                s_msg[slot] = 0u;
-                a_lo[L] = (PosT)(x + 1u);
-                a_w[L] = w0;
-                a_gap[L] = step;
-                a_seq[L] = prev_seq_base + (m - 1u);
-            }
-        };
-        // retire the arms of layer L flagged `dead` (wave-uniform call): one LDS atomic per wave
-        // hands out ring positions for the freed slots; long enough arms are reported
-        auto retire = [&](bool dead, int L, uint32_t slot, uint32_t fam, PosT rs) {
-            const unsigned long long dm = __ballot(dead);
-            if (!dm) return;
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&s_freed, (uint32_t)__popcll(dm));
-            base = lane_of(base, 0u) - freed_seen;
-            const uint32_t sq = a_seq[L];
-            if (dead) {
-                uint32_t at = fq + n_free + base + (uint32_t)__popcll(dm & lt_mask);
-                if (at >= (uint32_t)CAP) at -= (uint32_t)CAP;
-                if (at >= (uint32_t)CAP) at -= (uint32_t)CAP;
-                s_free[at] = (uint16_t)slot;
-                a_seq[L] = kNoSeq;
-            }
-            const PosT re = (PosT)(a_lo[L] + k - 1u);
-            const bool emit = dead && (uint64_t)(re - rs) >= rp.M;
-            if (__ballot(emit)) {
-                PosT ls = 0, le = 0;
-                if (emit) {
-                    ls = s_cls[slot];
-                    le = s_cle[slot];
-                }
-                emit_records(emit, ls, le, rs, re, sq, fam);
-            }
-        };
-        // P0: index the hits of one probe (cnt hits at s_hits[off..]) under generation `gen`; the
-        // hit groups are dealt to the waves from the top (the arms fill the slots from the bottom)
-        auto index_hits = [&](uint32_t cnt, uint32_t off) {
-            uint32_t *const best = s_best[gen & (uint32_t)(NBEST - 1)];
-            for (uint32_t h0 = (uint32_t)(NW - 1 - wave) * 64u; h0 < cnt; h0 += NT) {
-                const uint32_t h = h0 + lane;
-                if (h >= cnt) continue;
-                const PosT x = s_hits[off + h];
-                best[h] = 0xFFFFFFFFu;
-                const unsigned long long mine = ((unsigned long long)((gen << 11) | h) << 32) | (uint32_t)x;
-                unsigned long long old[kLevels];  // all exchanges in flight before the first result is used
-                uint32_t at[kLevels];
-#pragma unroll
-                for (uint32_t lv = 0; lv < (uint32_t)kLevels; ++lv) {
-                    at[lv] = bucket_slot((uint64_t)x >> (bsh + 2u * lv));
-                    old[lv] = atomicExch(&s_head[lv][at[lv]], mine);
-                }
-#pragma unroll
-                for (uint32_t lv = 0; lv < (uint32_t)kLevels; ++lv) {
-                    const bool chained = (uint32_t)(old[lv] >> 43) == gen;
-                    s_node[lv][h] = chained ? (old[lv] & 0x000003FFFFFFFFFFull) : kNone;
-                    // whoever is the head by now has a successor: the "more" bit
-                    if (chained) atomicOr(&s_head[lv][at[lv]], 1ull << 42);
-                }
-            }
-        };
-        auto next_gen = [&]() {  // generation wrap: clear the tables once (every thread, between barriers)
-            if (++gen >> kGenBits) {
-                __syncthreads();
-                clear_tables();
-                gen = 1;
-                __syncthreads();
-            }
-        };
-        // End of the segment (or of its chunk): adopt what is waiting, apply the pending quiet age,
-        // retire what that kills.  Called after a barrier.  Leaves A = arms still alive.
-        auto drain = [&]() {
-            absorb();
-            maybe_close(A);
-#pragma unroll
-            for (int L = 0; L < S; ++L) {
-                if ((uint32_t)L * NT + ((uint32_t)wave << 6) < H) {
-                    const uint32_t slot = (uint32_t)L * NT + tid;
-                    if (have_new) adopt(L, slot);
-                    bool dead = false;
-                    if (a_seq[L] != kNoSeq) {
-                        const uint64_t eff = (uint64_t)a_gap[L] + pending;
-                        a_gap[L] = eff > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)eff;
-                        dead = eff >= G;
-                    }
-                    retire(dead, L, slot, fam_seq, dead ? s_crs[slot] : (PosT)0);
-                }
-            }
-            pending = 0;
-            have_new = false;
-            __syncthreads();
-            const uint32_t nd = uni(s_freed) - freed_seen;
-            freed_seen += nd;
-            A -= nd;
-            maybe_close(A);
-        };
-
-        for (uint32_t g = g0; g < g_end && !done;) {
-            // ---- stage a batch of up to 64 probes (every wave computes the same masks) ----
-            PROF_START();
-            const uint32_t nb = min(64u, g_end - g);
-            const uint32_t f_l = (uint32_t)lane < nb ? P.p_filt[g + lane] : kSkipN;
-            const uint32_t nfl_l = (uint32_t)lane < nb ? P.p_nflag[g + lane] : 0u;
-            const unsigned long long r_l = (uint32_t)lane < nb ? P.row_off[g + lane] : 0ull;
-            const unsigned long long r_hi = uni(P.row_off[g + nb]);
-            const unsigned long long base = lane_of(r_l, 0u);
-            unsigned long long r_next = __shfl_down(r_l, 1);
-            if ((uint32_t)lane + 1 >= nb) r_next = r_hi;
-            const bool fits = (uint32_t)lane < nb && r_next - base <= (unsigned long long)HB;
-            const unsigned long long fm = __ballot(fits);
-            uint32_t nbb = (~fm == 0ull) ? 64u : (uint32_t)(__ffsll((long long)~fm) - 1);
-            if (nbb > nb) nbb = nb;
-            if (nbb == 0) {  // one probe with more hits than the staging area: not for this kernel
-                overflow = true;
-                break;
-            }
-            const uint32_t rel_l = (uint32_t)(r_l - base);
-            {
-                const unsigned long long end = nbb == nb ? r_hi : lane_of(r_l, nbb);
-                const uint32_t tot = (uint32_t)(end - base);
-                for (uint32_t r = tid; r < tot; r += NT) {
-                    s_hits[r] = P.hits[base + r];
-                    s_hflag[r] = (P.hit_flag ? P.hit_flag[base + r] : (uint8_t)1);
-                }
-            }
-            __syncthreads();
-            const unsigned long long in_batch = nbb >= 64 ? ~0ull : ((1ull << nbb) - 1ull);
-            const unsigned long long hm = __ballot(f_l >= 1u && f_l < kPending) & in_batch;
-            const unsigned long long qm = __ballot(f_l == 0u) & in_batch;
-            PROF_STOP(0);
-            PROF_COUNT(1, 1);
-            uint32_t pos = 0;
-            bool pre_indexed = false;
-            while (!done) {
-                const unsigned long long hmr = pos >= 64 ? 0ull : (hm >> pos) << pos;
-                if (!hmr) break;
-                const uint32_t b = (uint32_t)(__ffsll((long long)hmr) - 1);
-                {   // quiet probes before this one: only bookkeeping (their ageing is `pending`)
-                    const unsigned long long range = ((1ull << b) - 1ull) & ~((1ull << pos) - 1ull);
-                    const uint32_t q = (uint32_t)__popcll(qm & range);
-                    if (q) {
-                        quiet += q;
-                        t_proc += q;
-                        const uint64_t pn = (uint64_t)pending + (uint64_t)q * step;
-                        pending = pn > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)pn;
-                        if (quiet >= rp.tstar) {  // every arm is dead by now: the segment ends here
-                            done = true;
-                            break;
-                        }
-                    }
-                }
-                quiet = 0;
-                pos = b + 1;
-                const uint32_t cnt = lane_of(f_l, b);
-                const uint32_t nfl = lane_of(nfl_l, b);
-                const uint32_t off = lane_of(rel_l, b);
-                const uint64_t i = (uint64_t)(g + b - pb + 1) * step;
-                PROF_START();
-                // ---- P0 for the first hit probe of a batch (the others ride in the previous phase 2)
-                if (!pre_indexed) {
-                    next_gen();
-                    index_hits(cnt, off);
-                    __syncthreads();
-                }
-                pre_indexed = false;
-                absorb();          // what the previous hit probe created / retired
-                maybe_close(A);    // ... and whether that emptied the family
-                if (A + nfl > cap_eff) {
-                    overflow = true;
-                    done = true;
-                    break;
-                }
-                PROF_COUNT(5, 1);
-                PROF_COUNT(10, A);
-                PROF_COUNT(11, cnt);
-                PROF_MAX(9, A + nfl);
-                PROF_STOP(2);
-                PROF_START();
-                uint32_t *const best = s_best[gen & (uint32_t)(NBEST - 1)];
-                // ---- phase 1: adopt, detect dead-on-arrival, look up -----------------------------
-                uint32_t doa_mask = 0;  // bit L: arm of layer L died in the quiet run before this probe
-#pragma unroll
-                for (int L = 0; L < S; ++L) {
-                    if ((uint32_t)L * NT + ((uint32_t)wave << 6) < H) {  // this wave owns slots below H in layer L
-                        const uint32_t slot = (uint32_t)L * NT + tid;
-                        PROF_STOP(3);
-                        PROF_START();
-                        if (have_new) adopt(L, slot);
-                        bool live = a_seq[L] != kNoSeq;
-                        PROF_STOP(10);
-                        PROF_START();
-                        if (pending) {  // wave-uniform
-                            bool doa = false;
-                            if (live) {
-                                const uint64_t eff = (uint64_t)a_gap[L] + pending;
-                                a_gap[L] = eff > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)eff;
-                                doa = eff >= G;
-                            }
-                            const unsigned long long dm = __ballot(doa);
-                            if (dm && lane == 0) atomicAdd(&s_doa, (uint32_t)__popcll(dm));
-                            if (doa) {
-                                doa_mask |= 1u << L;
-                                live = false;
-                            }
-                        }
-                        const PosT lo = a_lo[L];
-                        const uint32_t w = a_w[L], seq = a_seq[L];
-                        // candidates: the two LARGEST accepted hit indices (the last hit an arm wins, in SA
-                        // order, is the one that extends it); cn = 3: there are more below them
-                        uint32_t ca = 0, cb = 0, cn = 0;
-                        PosT cx = 0;  // position of candidate ca
-                        auto offer = [&](uint32_t h, PosT x) {
-                            atomicMin(&best[h], seq);
-                            if (cn == 0u) {
-                                ca = h;
-                                cx = x;
-                                cn = 1u;
-                            } else if (h > ca) {
-                                cb = ca;
-                                ca = h;
-                                cx = x;
-                                cn = min(cn + 1u, 3u);
-                            } else if (h != ca) {  // (two buckets that share a table slot offer a hit twice)
-                                if (cn == 1u) {
-                                    cb = h;
-                                    cn = 2u;
-                                } else if (h > cb) {
-                                    cb = h;
-                                    cn = 3u;
-                                } else if (h != cb) {
-                                    cn = 3u;
-                                }
-                            }
-                        };
-                        // one bucket chain: the entries carry the low word of the hit's position
-                        auto walk = [&](unsigned long long e, uint32_t lv) {
-                            if ((uint32_t)(e >> 43) != gen) return;
-                            bool more = (e >> 42) & 1ull;
-                            for (;;) {
-                                const uint32_t h = (uint32_t)(e >> 32) & 1023u, x32 = (uint32_t)e;
-                                if (sizeof(PosT) == 4) {
-                                    if ((uint32_t)(x32 - (uint32_t)lo) < w) offer(h, (PosT)x32);
-                                } else if ((uint32_t)(x32 - (uint32_t)lo) < w) {
-                                    const PosT x = s_hits[off + h];
-                                    if ((uint64_t)(PosT)(x - lo) < (uint64_t)w) offer(h, x);
-                                }
-                                if (!more) break;
-                                e = s_node[lv][h];
-                                if (e == kNone) break;
-                            }
-                        };
-                        if (__ballot(live && w > (1u << bsh)) == 0ull) {
-                            // every live arm of this wave is narrow: at most two level-0 buckets
-                            const uint64_t b0 = (uint64_t)lo >> bsh, b1 = ((uint64_t)lo + w - 1u) >> bsh;
-                            const uint32_t t0 = bucket_slot(b0), t1 = bucket_slot(b1);
-                            const unsigned long long e0 = live ? s_head[0][t0] : 0ull;
-                            const unsigned long long e1 = live && t1 != t0 ? s_head[0][t1] : 0ull;
-#ifdef ASGART_PROFILE_EXTEND
-                            if (e0 == 12345ull && e1 == 6789ull) cx = 1;  // forces the wait for both heads here
-                            PROF_STOP(11);
-                            PROF_START();
-#endif
-                            if (live) {
-                                walk(e0, 0u);
-                                if (t1 != t0) walk(e1, 0u);
-                            }
-                        } else if (live) {
-                            // smallest level whose bucket is at least a quarter of the window
-                            uint32_t lv = 0;
-                            if (w > (4u << bsh)) {
-                                const uint32_t bits = 32u - (uint32_t)__clz((int)(w - 1u));  // ceil(log2 w)
-                                lv = (bits - bsh - 1u) >> 1;  // ceil((bits - bsh - 2) / 2)
-                            }
-                            if (lv >= n_lv) {  // wider than any table: every hit is a candidate
-                                for (uint32_t h = 0; h < cnt; ++h) {
-                                    const PosT x = s_hits[off + h];
-                                    if ((uint64_t)(PosT)(x - lo) < (uint64_t)w) offer(h, x);
-                                }
-                            } else {
-                                const uint32_t sh = bsh + 2u * lv;
-                                const uint64_t b0 = (uint64_t)lo >> sh, b1 = ((uint64_t)lo + w - 1u) >> sh;
-                                for (uint64_t bk = b0; bk <= b1; ++bk) walk(s_head[lv][bucket_slot(bk)], lv);
-                            }
-                        }
-                        a_cand[L] = ca | (cb << 10) | (cn << 30);
-                        a_cx[L] = cx;
-                        PROF_STOP(1);
-                        PROF_START();
-                    }
-                }
-                PROF_STOP(3);
-                PROF_START();
-                lds_barrier();
-                PROF_STOP(4);
-                PROF_START();
-                // arms that died in the quiet run belong to the family that was open then; if they
-                // were all of them, that family is closed and this probe starts the next one
-                const uint32_t fam_doa = fam_seq;
-                if (pending) {
-                    const uint32_t n_doa = uni(s_doa) - doa_seen;
-                    doa_seen += n_doa;
-                    maybe_close(A - n_doa);
-                }
-                ++t_proc;
-                prev_tp = t_proc;
-                // ---- phase 2, arm side: settle ---------------------------------------------------
-#pragma unroll
-                for (int L = 0; L < S; ++L) {
-                    if ((uint32_t)L * NT + ((uint32_t)wave << 6) < H) {  // this wave owns slots below H in layer L
-                        const uint32_t slot = (uint32_t)L * NT + tid;
-                        const bool doa = (doa_mask >> L) & 1u;
-                        const bool live = a_seq[L] != kNoSeq && !doa;
-                        const uint32_t cand = live ? a_cand[L] : 0u, nc = cand >> 30, seq = a_seq[L];
-                        const uint32_t ha = cand & 1023u, hb = (cand >> 10) & 1023u;
-                        const uint32_t bav = nc ? best[ha] : 0xFFFFFFFFu;       // all four loads in flight
-                        const uint32_t bbv = nc > 1u ? best[hb] : 0xFFFFFFFFu;
-                        const PosT ls = nc ? s_cls[slot] : (PosT)0;
-                        const PosT rs = live || doa ? s_crs[slot] : (PosT)0;
-                        uint32_t won = 0;  // 1 + the last hit (SA order) this arm won
-                        PosT x = a_cx[L];
-                        if (nc && bav == seq) {
-                            won = ha + 1u;
-                        } else if (nc > 1u && bbv == seq) {
-                            won = hb + 1u;
-                            x = s_hits[off + hb];
-                        }
-                        // an arm that lost its two highest candidates to older arms and has more: look
-                        // for the highest hit it did win below them, eight loads in flight at a time
-                        if (__ballot(nc == 3u && !won)) {
-                            if (nc == 3u && !won) {
-                                for (uint32_t top = hb; top > 0u && !won;) {
-                                    uint32_t v[8];
-#pragma unroll
-                                    for (uint32_t u = 0; u < 8u; ++u) v[u] = top > u ? best[top - 1u - u] : 0xFFFFFFFFu;
-#pragma unroll
-                                    for (uint32_t u = 0; u < 8u; ++u)
-                                        if (!won && top > u && v[u] == seq) won = top - u;
-                                    top = top > 8u ? top - 8u : 0u;
-                                }
-                                if (won) x = s_hits[off + won - 1u];
-                            }
-                        }
-                        bool dead = doa;
-                        if (live) {
-                            if (won) {  // ExtendArm, src/automaton.rs:133-150 (last hit in SA order wins)
-                                a_lo[L] = (PosT)(x + 1u);
-                                s_cle[slot] = (PosT)(i + k);
-                                a_w[L] = window_of((uint64_t)(i + k) - (uint64_t)ls);
-                                a_gap[L] = 0;
-                            } else {    // src/automaton.rs:166-171
-                                const uint64_t sum_g = (uint64_t)a_gap[L] + step;
-                                a_gap[L] = sum_g > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)sum_g;
-                                dead = sum_g >= G;
-                            }
-                        }
-                        retire(dead, L, slot, doa ? fam_doa : fam_seq, rs);
-                    }
-                }
-                PROF_STOP(7);
-                PROF_START();
-                // ---- phase 2, hit side (waves from the top): unmatched hits create arms ----------
-                // The rank of an unmatched flagged hit among the new arms (hit order = creation order)
-                // needs the counts of the earlier groups, which the owning wave recomputes itself.
-                for (uint32_t h0 = (uint32_t)(NW - 1 - wave) * 64u; h0 < cnt; h0 += NT) {
-                    uint32_t before = 0;
-                    for (uint32_t c0 = 0; c0 <= h0; c0 += 64) {
-                        const uint32_t h = c0 + lane;
-                        bool un = false, hf = false;
-                        if (h < cnt) {
-                            un = best[h] == 0xFFFFFFFFu;
-                            hf = s_hflag[off + h] != 0;
-                        }
-                        const unsigned long long nm = __ballot(un && hf);
-                        if (c0 < h0) {
-                            before += (uint32_t)__popcll(nm);
-                            continue;
-                        }
-                        const bool any_spur = __ballot(un && !hf) != 0ull;
-                        if (un && hf) {  // NewArm: its slot comes off the ring of empty slots, then from above H
-                            const uint32_t bf = before + (uint32_t)__popcll(nm & lt_mask);
-                            uint32_t slot;
-                            if (bf < n_free) {
-                                uint32_t at = fq + bf;
-                                if (at >= (uint32_t)CAP) at -= (uint32_t)CAP;
-                                slot = s_free[at];
-                            } else {
-                                slot = H + (bf - n_free);
-                            }
-                            s_cls[slot] = (PosT)i;
-                            s_cle[slot] = (PosT)(i + k);
-                            s_crs[slot] = s_hits[off + h];
-                            s_msg[slot] = bf + 1u;
-                        }
-                        if (lane == 0) {
-                            if (nm) atomicAdd(&s_new, (uint32_t)__popcll(nm));
-                            if (any_spur) atomicAdd(&s_spur, 1u);
-                        }
-                    }
-                }
-                fam_open = true;  // every hit of this probe extended an arm or created one (materialised or not)
-                pending = 0;
-                PROF_STOP(8);
-                PROF_START();
-                {   // next hit probe of this staged batch, if any: its P0 rides in this barrier interval
-                    const unsigned long long nxt = pos >= 64 ? 0ull : (hm >> pos) << pos;
-                    const bool can_pre = nxt != 0ull && ((gen + 1u) >> kGenBits) == 0u;
-                    if (can_pre) {
-                        const uint32_t nb2 = (uint32_t)(__ffsll((long long)nxt) - 1);
-                        ++gen;
-                        index_hits(lane_of(f_l, nb2), lane_of(rel_l, nb2));
-                    }
-                    pre_indexed = can_pre;
-                }
-                lds_barrier();
-                PROF_STOP(6);
-            }
-            if (overflow) break;
-            if (!done) {
-                const unsigned long long range = pos >= 64 ? 0ull : ~((1ull << pos) - 1ull);
-                const uint32_t q = (uint32_t)__popcll(qm & range);
-                if (q) {
-                    quiet += q;
-                    t_proc += q;
-                    const uint64_t pn = (uint64_t)pending + (uint64_t)q * step;
-                    pending = pn > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)pn;
-                    if (quiet >= rp.tstar) done = true;
-                }
-            }
-            __syncthreads();
-            g += nbb;
-        }
-        __syncthreads();
-        if (overflow) {
-            // abandoned (re-run by a larger tier): forget the arms and what waits for adoption
-            absorb();
-            for (uint32_t j = tid; j < H; j += NT) s_msg[j] = 0u;
-#pragma unroll
-            for (int L = 0; L < S; ++L) a_seq[L] = kNoSeq;
-            if (tid == 0) {
-                const unsigned long long at = atomicAdd(P.ovf_count, 1ull);
-                if (P.ovf_list) P.ovf_list[at] = g0;
-            }
-        } else {
-            drain();
-            if (!done && g_end < chunk_end) {
-                // sharded call: the segment is not finished inside the look-ahead window
-                if (tid == 0) atomicAdd(&P.ctr[CT_RANOUT], 1ull);
-            } else if (fam_open) {
-                // arms still alive at the end of the chunk are dropped together with the unflushed
-                // family they belong to (src/automaton.rs:201-203)
-                emit_records(tid == 0, (PosT)0, (PosT)0, (PosT)0, (PosT)0, kTombstone, fam_seq);
-            }
-            if (A > 0) {
-#pragma unroll
-                for (int L = 0; L < S; ++L) a_seq[L] = kNoSeq;
-            }
-        }
-        if (tid < 64) {
-            PROF_FLUSH();
-        }
-        __syncthreads();
+        lds_barrier();
     }
     rec_flush(rec_alloc, P, lane);
 }

@@ -1,0 +1,4 @@
+export TMPDIR=/tmp
+python tools/pole_synth.py --copies 3800 --sub 0.03 --check '' 2>&1 | grep direct
+python tools/tune_tiers.py cfg4 '' 2>&1 | tail -1
+python -m pytest tests -m gpu -x -q -k "not cfg4_full and not cfg3_full" 2>&1 | tail -3

@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import asgart_amd  # noqa: E402
 
-DEFAULTS = {"shard_lookback": 4096, "arms_kernel": 1, "arms2": 0, "prio3": 1, "kfilter_bits": 30, "long3": 4096, "long3_big": -1, "cap1": 256,
+DEFAULTS = {"shard_lookback": 4096, "arms_kernel": 1, "prio3": 1, "kfilter_bits": 30, "long3": 4096, "long3_big": -1, "cap1": 256,
             "test_cap_limit": -1, "test_levels": 4, "test_genbits": 22, "tier_order": 3654217}
 
 
