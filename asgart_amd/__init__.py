@@ -33,6 +33,7 @@ ABI_SYMBOLS = (
     "asgart_families_copy", "asgart_families_free", "asgart_searcher_cache_get",
     "asgart_searcher_search", "asgart_sa_read", "asgart_probe_hits", "asgart_get_stats",
     "asgart_last_error", "asgart_version", "asgart_compute_scores", "asgart_index_set_option",
+    "asgart_index_check_sa",
 )
 
 
@@ -93,6 +94,8 @@ def load_library() -> C.CDLL:
     L.asgart_index_destroy.restype = None
     L.asgart_index_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
     L.asgart_index_set_option.restype = C.c_int32
+    L.asgart_index_check_sa.argtypes = [vp]
+    L.asgart_index_check_sa.restype = C.c_int64
     L.asgart_index_prepare.argtypes = [vp, C.c_uint64]
     L.asgart_index_prepare.restype = C.c_int32
     L.asgart_search_duplications.argtypes = [vp, vp, C.c_int64, C.POINTER(_Settings), vp,
@@ -240,6 +243,12 @@ class Index:
     def set_option(self, name: str, value: int):
         """Tuning / test option (include/asgart_hip.h: asgart_index_set_option)."""
         _check(load_library().asgart_index_set_option(self._h, name.encode(), int(value)))
+
+    def check_sa(self) -> int:
+        """GPU verifier of the resident suffix array: number of violating slots (0 = valid)."""
+        r = int(load_library().asgart_index_check_sa(self._h))
+        _check(r)
+        return r
 
     def prepare(self, probe_size: int):
         _check(load_library().asgart_index_prepare(self._h, probe_size))

@@ -44,6 +44,7 @@ const OptDesc kOptions[] = {
     {"tier_order", &Options::tier_order, 1, 7777777},
     {"ptab_depth", &Options::ptab_depth, 0, 15},
     {"force_wide", &Options::force_wide, 0, 1},
+    {"test_wide_batch", &Options::test_wide_batch, 0, 1ll << 40},
     {"kfilter_bits", &Options::kfilter_bits, 0, 34},
 };
 }  // namespace
@@ -148,15 +149,16 @@ __global__ __launch_bounds__(256) void build_keys_kernel(const uint8_t *__restri
                                                          const SlotT *__restrict__ sa,
                                                          uint64_t *__restrict__ keys, uint64_t n,
                                                          int k) {
-    uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    uint64_t x = sa[r];
-    uint64_t q = 0;
-    for (int j = 0; j < k; ++j) {
-        uint32_t c = (x + j < n) ? base_code(text[x + j]) : 0u;
-        q = (q << 3) | c;
+    // grid-stride: a launch holds fewer than 2^32 threads, a 6-Gbp index more than 2^32 slots
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t x = sa[r];
+        uint64_t q = 0;
+        for (int j = 0; j < k; ++j) {
+            uint32_t c = (x + j < n) ? base_code(text[x + j]) : 0u;
+            q = (q << 3) | c;
+        }
+        keys[r] = q;
     }
-    keys[r] = q;
 }
 
 template <class SlotT>
@@ -205,13 +207,12 @@ __global__ __launch_bounds__(256) void build_cache8_kernel(const uint64_t *__res
 template <class SlotT>
 __global__ __launch_bounds__(256) void build_filter_kernel(IndexView<SlotT> ix, bool reverse, bool complement,
                                                            unsigned long long *__restrict__ flt, int bits) {
-    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= ix.n) return;
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < ix.n; r += (uint64_t)gridDim.x * blockDim.x) {
     const uint64_t u = ix.keys[r];
-    if (r > 0 && ix.keys[r - 1] == u) return;
+    if (r > 0 && ix.keys[r - 1] == u) continue;
     bool full = true;  // all k bases inside the text (no '$' / end padding): only those can equal a probe
     for (int j = 0; j < ix.k; ++j) full &= ((u >> (3 * j)) & 7u) != 0u;
-    if (!full) return;
+    if (!full) continue;
     bool keep;
     if (!reverse && !complement) {
         keep = r + 1 < ix.n && ix.keys[r + 1] == u;  // occurs at least twice
@@ -230,6 +231,7 @@ __global__ __launch_bounds__(256) void build_filter_kernel(IndexView<SlotT> ix, 
         uint64_t w, m;
         filter_slot(u, bits, w, m);
         atomicOr(&flt[w], (unsigned long long)m);
+    }
     }
 }
 
@@ -267,6 +269,38 @@ __global__ __launch_bounds__(256) void pattern_search_kernel(IndexView<SlotT> ix
     hi[t] = h;
 }
 
+// O(n) verifier of the resident suffix array (the rank trick of oracle/sais.c::oracle_sa_check):
+// isa[sa[r]] = r must invert sa, and adjacent suffixes must be in strictly increasing bytewise order,
+// decided by their first bytes and the ranks of the suffixes one position further.
+template <class SlotT>
+__global__ __launch_bounds__(256) void isa_scatter_kernel(const SlotT *__restrict__ sa, SlotT *__restrict__ isa,
+                                                          uint64_t n) {
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (uint64_t)gridDim.x * blockDim.x)
+        if ((uint64_t)sa[r] < n) isa[sa[r]] = (SlotT)r;
+}
+template <class SlotT>
+__global__ __launch_bounds__(256) void sa_check_kernel(const uint8_t *__restrict__ text, const SlotT *__restrict__ sa,
+                                                       const SlotT *__restrict__ isa, uint64_t n,
+                                                       unsigned long long *__restrict__ errs) {
+    unsigned long long n_bad = 0;
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t b = sa[r];
+        bool bad = b >= n || (uint64_t)isa[b] != r;
+        if (!bad && r > 0) {
+            const uint64_t a = sa[r - 1];
+            if (a >= n) bad = true;
+            else {
+                const uint64_t ra = a + 1 < n ? (uint64_t)isa[a + 1] + 1u : 0u;
+                const uint64_t rb = b + 1 < n ? (uint64_t)isa[b + 1] + 1u : 0u;
+                bad = !(text[a] < text[b] || (text[a] == text[b] && ra < rb));
+            }
+        }
+        n_bad += bad ? 1u : 0u;
+    }
+    for (int off = 32; off > 0; off >>= 1) n_bad += __shfl_down(n_bad, off);
+    if (n_bad && (threadIdx.x & 63) == 0) atomicAdd(errs, n_bad);
+}
+
 // ---- host ------------------------------------------------------------------
 
 static int32_t check_device(int device) {
@@ -288,6 +322,11 @@ static int32_t check_device(int device) {
 
 static inline unsigned grid_for(uint64_t n, unsigned block = 256) {
     return (unsigned)((n + block - 1) / block);
+}
+// for grid-stride kernels over up to 2^33 elements: a dispatch holds fewer than 2^32 work-items
+static inline unsigned grid_capped(uint64_t n, unsigned block = 256) {
+    const uint64_t g = (n + block - 1) / block;
+    return (unsigned)(g < (1ull << 22) ? g : (1ull << 22));
 }
 
 static void free_k_specific(asgart_index *idx) {
@@ -377,14 +416,14 @@ int32_t index_prepare(asgart_index *idx, uint64_t k) {
     HIP_TRY(hipMalloc(&idx->d_c8hi, (size_t)kCacheEntries * slot));
     hipStream_t s = idx->ctx[0].stream;
     if (idx->wide) {
-        build_keys_kernel<uint64_t><<<grid_for(n), 256, 0, s>>>(
+        build_keys_kernel<uint64_t><<<grid_capped(n), 256, 0, s>>>(
             idx->d_text, (const uint64_t *)idx->d_sa, idx->d_keys, n, (int)k);
         build_ptab_kernel<uint64_t><<<grid_for(entries), 256, 0, s>>>(
             idx->d_keys, (uint64_t *)idx->d_ptab, n, (int)k, d);
         build_cache8_kernel<uint64_t><<<grid_for(kCacheEntries), 256, 0, s>>>(
             idx->d_keys, (uint64_t *)idx->d_c8lo, (uint64_t *)idx->d_c8hi, n, (int)k);
     } else {
-        build_keys_kernel<uint32_t><<<grid_for(n), 256, 0, s>>>(
+        build_keys_kernel<uint32_t><<<grid_capped(n), 256, 0, s>>>(
             idx->d_text, (const uint32_t *)idx->d_sa, idx->d_keys, n, (int)k);
         build_ptab_kernel<uint32_t><<<grid_for(entries), 256, 0, s>>>(
             idx->d_keys, (uint32_t *)idx->d_ptab, n, (int)k, d);
@@ -456,7 +495,7 @@ int32_t index_prepare_filter(asgart_index *idx, uint64_t k, int mode) {
     int32_t rc = [&]() -> int32_t {
         HIP_TRY(hipMemsetAsync(flt, 0, bytes, s));
         const bool rev = (mode & 2) != 0, comp = (mode & 1) != 0;
-        const unsigned g = grid_for((uint64_t)idx->n);
+        const unsigned g = grid_capped((uint64_t)idx->n);
         if (idx->wide)
             build_filter_kernel<uint64_t><<<g, 256, 0, s>>>(idx->view<uint64_t>(), rev, comp,
                                                             (unsigned long long *)flt, bits);
@@ -574,7 +613,8 @@ int32_t asgart_index_create(const uint8_t *T, int64_t n, const int64_t *SA, int6
         const size_t slot = idx->wide ? 8 : 4;
         HIP_TRY(hipMalloc(&idx->d_sa, ((size_t)n + 16) * slot));
         if (!SA) {
-            RC_TRY(sa_build_device(idx->d_text, n, idx->d_sa, idx->wide, idx->ctx[0].stream));
+            RC_TRY(sa_build_device(idx->d_text, n, idx->d_sa, idx->wide, idx->ctx[0].stream,
+                                   (uint64_t)idx->opt.test_wide_batch));
         } else if (idx->wide) {
             HIP_TRY(hipMemcpyAsync(idx->d_sa, SA, (size_t)n * 8, hipMemcpyHostToDevice,
                                    idx->ctx[0].stream));
@@ -630,6 +670,48 @@ int32_t asgart_index_set_option(asgart_index *idx, const char *name, int64_t val
     }
     idx->release_all();
     return rc;
+}
+
+int64_t asgart_index_check_sa(asgart_index *idx) {
+    if (!idx) {
+        set_error("index is NULL");
+        return ASGART_E_ARG;
+    }
+    HIP_TRY(hipSetDevice(idx->device));
+    idx->acquire_all();
+    struct Unlock {
+        asgart_index *i;
+        ~Unlock() { i->release_all(); }
+    } unlock{idx};
+    const uint64_t n = (uint64_t)idx->n;
+    const size_t slot = idx->wide ? 8 : 4;
+    DevBuf isa, errs;
+    hipStream_t s = idx->ctx[0].stream;
+    unsigned long long h_errs = 0;
+    int32_t rc = [&]() -> int32_t {
+        RC_TRY(isa.reserve(n * slot));
+        RC_TRY(errs.reserve(8));
+        HIP_TRY(hipMemsetAsync(isa.p, 0xFF, n * slot, s));
+        HIP_TRY(hipMemsetAsync(errs.p, 0, 8, s));
+        const unsigned g = grid_capped(n);
+        if (idx->wide) {
+            isa_scatter_kernel<uint64_t><<<g, 256, 0, s>>>((const uint64_t *)idx->d_sa, isa.as<uint64_t>(), n);
+            sa_check_kernel<uint64_t><<<g, 256, 0, s>>>(idx->d_text, (const uint64_t *)idx->d_sa, isa.as<uint64_t>(), n,
+                                                        errs.as<unsigned long long>());
+        } else {
+            isa_scatter_kernel<uint32_t><<<g, 256, 0, s>>>((const uint32_t *)idx->d_sa, isa.as<uint32_t>(), n);
+            sa_check_kernel<uint32_t><<<g, 256, 0, s>>>(idx->d_text, (const uint32_t *)idx->d_sa, isa.as<uint32_t>(), n,
+                                                        errs.as<unsigned long long>());
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(&h_errs, errs.p, 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        return 0;
+    }();
+    isa.release();
+    errs.release();
+    if (rc != 0) return rc;
+    return (int64_t)h_errs;
 }
 
 int32_t asgart_index_prepare(asgart_index *idx, uint64_t probe_size) {

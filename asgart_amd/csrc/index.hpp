@@ -132,6 +132,7 @@ struct Options {
     int64_t grid[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // grid[t] > 0: workgroups of tier t (clamped to its maximum)
     int64_t ptab_depth = 0;         // 0: chosen from the text length
     int64_t force_wide = 0;         // tests: 64-bit slots and positions for a small text
+    int64_t test_wide_batch = 0;    // tests: batch size of the 64-bit suffix sorter's doubling rounds (0: 2^29)
     int64_t kfilter_bits = 30;      // log2(bits) of the k-mer presence filter (search_dev.hpp); 0: no filter
 };
 int32_t option_set(Options &o, const char *name, int64_t value);  // ASGART_E_ARG: unknown name / bad value
@@ -242,5 +243,5 @@ int32_t sort_segments(Workspace &w, uint32_t *keys, uint32_t *vals, uint64_t n, 
                       const uint32_t **sorted_vals, const uint32_t **sorted_keys);
 int32_t text_is_dna(const uint8_t *d_text, int64_t n, hipStream_t s, bool *dna);
 int32_t sa_build_device(const uint8_t *d_text, int64_t n, void *d_sa, bool wide,
-                        hipStream_t stream);
+                        hipStream_t stream, uint64_t wide_batch);
 }  // namespace asgart

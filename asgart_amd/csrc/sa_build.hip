@@ -20,6 +20,8 @@
 
 #include <rocprim/rocprim.hpp>
 
+#include <algorithm>
+
 namespace asgart {
 
 namespace {
@@ -45,6 +47,17 @@ __device__ inline uint64_t initial_key(const uint8_t *__restrict__ text, uint64_
     return q;
 }
 
+__global__ __launch_bounds__(256) void byte_histogram_for_sa(const uint8_t *__restrict__ text, uint64_t n,
+                                                             unsigned long long *__restrict__ hist) {
+    __shared__ unsigned int sh[256];
+    sh[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) atomicAdd(&sh[text[i]], 1u);
+    __syncthreads();
+    if (sh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)sh[threadIdx.x]);
+}
+
 template <class IdxT, bool DNA>
 __global__ __launch_bounds__(256) void init_keys_kernel(const uint8_t *__restrict__ text, uint64_t n,
                                                         uint64_t *__restrict__ keys,
@@ -60,11 +73,11 @@ template <class IdxT>
 __global__ __launch_bounds__(256) void mark_heads_kernel(const uint64_t *__restrict__ k1,
                                                          const uint64_t *__restrict__ k2,
                                                          const IdxT *__restrict__ slots, uint64_t m,
-                                                         IdxT *__restrict__ head) {
+                                                         IdxT *__restrict__ head, uint64_t slot_base) {
     uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m) return;
     bool is_head = j == 0 || k1[j] != k1[j - 1] || (k2 && k2[j] != k2[j - 1]);
-    IdxT slot = slots ? slots[j] : (IdxT)j;
+    IdxT slot = slots ? slots[j] : (IdxT)(slot_base + j);
     head[j] = is_head ? slot : (IdxT)0;
 }
 
@@ -76,11 +89,11 @@ __global__ __launch_bounds__(256) void apply_round_kernel(const IdxT *__restrict
                                                           const IdxT *__restrict__ slots, uint64_t m,
                                                           IdxT *__restrict__ sa,
                                                           IdxT *__restrict__ rank,
-                                                          uint8_t *__restrict__ tied) {
+                                                          uint8_t *__restrict__ tied, uint64_t slot_base) {
     uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m) return;
     const IdxT x = vals[j];
-    const IdxT slot = slots ? slots[j] : (IdxT)j;
+    const IdxT slot = slots ? slots[j] : (IdxT)(slot_base + j);
     const IdxT g = grp[j];
     sa[slot] = x;
     rank[x] = g;
@@ -185,13 +198,13 @@ int32_t build_t(const uint8_t *d_text, int64_t n_, IdxT *d_sa, bool dna, hipStre
         bool two_keys = false;
         for (;;) {
             mark_heads_kernel<IdxT><<<grid_for(m), 256, 0, s>>>(
-                K1.db.current(), two_keys ? K2.db.current() : nullptr, slots, m, head);
+                K1.db.current(), two_keys ? K2.db.current() : nullptr, slots, m, head, 0);
             HIP_TRY(hipGetLastError());
             size_t bytes = 0;
             HIP_TRY(rocprim::inclusive_scan(nullptr, bytes, head, grp, (size_t)m, rocprim::maximum<IdxT>(), s));
             RC_TRY(temp.reserve(bytes));
             HIP_TRY(rocprim::inclusive_scan(temp.p, bytes, head, grp, (size_t)m, rocprim::maximum<IdxT>(), s));
-            apply_round_kernel<IdxT><<<grid_for(m), 256, 0, s>>>(V.db.current(), grp, slots, m, d_sa, rank, tied);
+            apply_round_kernel<IdxT><<<grid_for(m), 256, 0, s>>>(V.db.current(), grp, slots, m, d_sa, rank, tied, 0);
             HIP_TRY(hipGetLastError());
             // ---- compact the slots that are still tied ---------------------------
             DevBuf &outb = (slots == slots_a.as<IdxT>() && slots) ? slots_b : slots_a;
@@ -235,6 +248,277 @@ int32_t build_t(const uint8_t *d_text, int64_t n_, IdxT *d_sa, bool dna, hipStre
                 set_error("texts of 2^32 bytes or more: GPU suffix sort not implemented; pass SA");
                 return ASGART_E_CAP;
             }
+            h *= 2;
+        }
+        return 0;
+    }();
+    cleanup();
+    return rc;
+}
+
+// ---- texts of 2^32 bytes and more ------------------------------------------------------
+// Same prefix doubling with 64-bit suffix numbers, laid out so that it fits next to a 6-Gbp index
+// even when most suffixes stay tied for several rounds (two similar genomes in one text):
+//   round 0 is done class by class -- suffixes starting with the same two bytes (small alphabets;
+//   one byte otherwise), a few hundred million each: select the class's positions, key them by their
+//   first 21 bases, sort, split into groups, write that stretch of the suffix array.  Classes in
+//   byte order concatenate to the order by 21-mer;
+//   doubling rounds sort the still-tied suffixes by the pair (rank[i], rank[i + h]), which no longer
+//   fits one 64-bit key: LSD over the two words (stable sort by the second, then by the first),
+//   carried by a permutation -- and they do it batch by batch (whole groups, <= kWideBatch suffixes):
+//   groups are independent, and rank[] of a group only changes when its own batch is applied, so a
+//   batch may already see the refined ranks of earlier batches;
+//   the list of tied slots is compacted in place (the survivors of a batch never outnumber it).
+constexpr uint64_t kWideBatch = 1ull << 29;
+
+struct ClassPred {
+    const uint8_t *text;
+    uint64_t n;
+    int c0, c1;  // c1: second byte, -1 = "the suffix is one byte long", -2 = any
+    __device__ bool operator()(uint64_t i) const {
+        if (text[i] != (uint8_t)c0) return false;
+        if (c1 == -2) return true;
+        if (i + 1 >= n) return c1 == -1;
+        return c1 >= 0 && text[i + 1] == (uint8_t)c1;
+    }
+};
+
+template <bool DNA>
+__global__ __launch_bounds__(256) void class_keys_kernel(const uint8_t *__restrict__ text, uint64_t n,
+                                                         const uint64_t *__restrict__ vals, uint64_t m,
+                                                         uint64_t *__restrict__ keys) {
+    uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < m) keys[j] = initial_key<DNA>(text, n, vals[j]);
+}
+
+__global__ __launch_bounds__(256) void iota_kernel(uint64_t *__restrict__ p, uint64_t m) {
+    uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < m) p[j] = j;
+}
+
+__global__ __launch_bounds__(256) void gather64_kernel(const uint64_t *__restrict__ src,
+                                                       const uint64_t *__restrict__ perm, uint64_t m,
+                                                       uint64_t *__restrict__ dst) {
+    uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < m) dst[j] = src[perm[j]];
+}
+
+__global__ __launch_bounds__(256) void offset_slots_kernel(uint64_t *__restrict__ slots, uint64_t m, uint64_t base) {
+    uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < m) slots[j] += base;
+}
+
+// pair histogram over a small alphabet: code[byte] in 0..S-1 (255: absent), bins S * (S + 1)
+__global__ __launch_bounds__(256) void pair_histogram_kernel(const uint8_t *__restrict__ text, uint64_t n,
+                                                             const uint8_t *__restrict__ code, int S,
+                                                             unsigned long long *__restrict__ hist) {
+    __shared__ unsigned int sh[16 * 17];
+    __shared__ uint8_t s_code[256];
+    s_code[threadIdx.x] = code[threadIdx.x];
+    for (int j = threadIdx.x; j < 16 * 17; j += 256) sh[j] = 0;
+    __syncthreads();
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int a = s_code[text[i]];
+        const int b = i + 1 < n ? s_code[text[i + 1]] + 1 : 0;
+        atomicAdd(&sh[a * (S + 1) + b], 1u);
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < S * (S + 1); j += 256)
+        if (sh[j]) atomicAdd(&hist[j], (unsigned long long)sh[j]);
+}
+
+// first entry of the next group at or after position p of the tied list: groups are runs of equal
+// rank[sa[slot]] (a run of N's is one group of millions), and a batch must end on a group boundary
+__global__ void group_end_kernel(const uint64_t *__restrict__ slots, const uint64_t *__restrict__ sa,
+                                 const uint64_t *__restrict__ rank, uint64_t m, uint64_t p,
+                                 uint64_t *__restrict__ out) {
+    if (threadIdx.x || blockIdx.x) return;
+    uint64_t lo = p, hi = m;  // rank[sa[slots[j]]] is non-decreasing in j: upper bound of the group of p - 1
+    if (p > 0 && p < m) {
+        const uint64_t g = rank[sa[slots[p - 1]]];
+        while (lo < hi) {
+            const uint64_t mid = lo + ((hi - lo) >> 1);
+            if (rank[sa[slots[mid]]] <= g) lo = mid + 1; else hi = mid;
+        }
+    }
+    *out = lo;
+}
+
+int32_t build_wide(const uint8_t *d_text, int64_t n_, uint64_t *d_sa, bool dna, hipStream_t s, uint64_t batch) {
+    using IdxT = uint64_t;
+    const uint64_t n = (uint64_t)n_;
+    Dbuf<uint64_t> K1, K2, V, Pm;
+    DevBuf rank_b, grp_b, tied_b, list_b, out_b, temp, cnt_b, hist_b, code_b, k1o, k2o, vo;
+    auto cleanup = [&]() {
+        K1.release(); K2.release(); V.release(); Pm.release();
+        rank_b.release(); grp_b.release(); tied_b.release(); list_b.release(); out_b.release();
+        temp.release(); cnt_b.release(); hist_b.release(); code_b.release(); k1o.release(); k2o.release(); vo.release();
+    };
+    int32_t rc = [&]() -> int32_t {
+        // ---- classes ------------------------------------------------------------------------
+        RC_TRY(hist_b.reserve(512 * sizeof(unsigned long long)));
+        unsigned long long hist[512];
+        HIP_TRY(hipMemsetAsync(hist_b.p, 0, sizeof(hist), s));
+        unsigned blocks = grid_for(n, 256 * 16);
+        if (blocks > 4096) blocks = 4096;
+        byte_histogram_for_sa<<<blocks, 256, 0, s>>>(d_text, n, hist_b.as<unsigned long long>());
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(hist, hist_b.p, 256 * 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        std::vector<int> syms;
+        for (int c = 0; c < 256; ++c)
+            if (hist[c]) syms.push_back(c);
+        const int S = (int)syms.size();
+        struct Cls { int c0, c1; uint64_t cnt; };
+        std::vector<Cls> classes;
+        if (S <= 16) {
+            uint8_t code[256];
+            memset(code, 255, sizeof code);
+            for (int j = 0; j < S; ++j) code[syms[j]] = (uint8_t)j;
+            RC_TRY(code_b.reserve(256));
+            HIP_TRY(hipMemcpyAsync(code_b.p, code, 256, hipMemcpyHostToDevice, s));
+            HIP_TRY(hipMemsetAsync(hist_b.p, 0, sizeof(hist), s));
+            pair_histogram_kernel<<<blocks, 256, 0, s>>>(d_text, n, code_b.as<uint8_t>(), S, hist_b.as<unsigned long long>());
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(hist, hist_b.p, (size_t)S * (S + 1) * 8, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            for (int a = 0; a < S; ++a)
+                for (int b = 0; b <= S; ++b)   // b == 0: the one-byte suffix, sorts first
+                    if (hist[a * (S + 1) + b]) classes.push_back({syms[a], b ? syms[b - 1] : -1, hist[a * (S + 1) + b]});
+        } else {
+            for (int c : syms) classes.push_back({c, -2, hist[c]});
+        }
+        uint64_t biggest = 0;
+        for (const Cls &c : classes) biggest = std::max(biggest, c.cnt);
+        if (biggest >= 0xFFFFFF00ull) {
+            set_error("suffix sort: a first-bytes class holds %llu suffixes (>= 2^32); not supported",
+                      (unsigned long long)biggest);
+            return ASGART_E_CAP;
+        }
+        RC_TRY(rank_b.reserve(n * 8));
+        RC_TRY(cnt_b.reserve(16));
+        uint64_t *rank = rank_b.as<uint64_t>();
+        size_t *d_count = cnt_b.as<size_t>();
+        RC_TRY(K1.reserve(biggest));
+        RC_TRY(V.reserve(biggest));
+        RC_TRY(grp_b.reserve(biggest * 8));
+        RC_TRY(tied_b.reserve(biggest));
+        RC_TRY(out_b.reserve(biggest * 8));
+        RC_TRY(list_b.reserve(n * 8));  // the tied slots, ascending; at most every slot
+        uint64_t *grp = grp_b.as<uint64_t>();
+        uint8_t *tied = tied_b.as<uint8_t>();
+        uint64_t *list = list_b.as<uint64_t>();
+        uint64_t m = 0;
+        size_t bytes = 0;
+        rocprim::counting_iterator<uint64_t> it(0);
+        // ---- round 0, one class at a time --------------------------------------------------------
+        uint64_t slot_base = 0;
+        for (const Cls &c : classes) {
+            const uint64_t cnt = c.cnt;
+            ClassPred pred{d_text, n, c.c0, c.c1};
+            bytes = 0;
+            HIP_TRY(rocprim::select(nullptr, bytes, it, V.db.current(), d_count, (size_t)n, pred, s));
+            RC_TRY(temp.reserve(bytes));
+            HIP_TRY(rocprim::select(temp.p, bytes, it, V.db.current(), d_count, (size_t)n, pred, s));
+            if (dna) class_keys_kernel<true><<<grid_for(cnt), 256, 0, s>>>(d_text, n, V.db.current(), cnt, K1.db.current());
+            else class_keys_kernel<false><<<grid_for(cnt), 256, 0, s>>>(d_text, n, V.db.current(), cnt, K1.db.current());
+            HIP_TRY(hipGetLastError());
+            RC_TRY(sort_pairs<IdxT>(temp, K1.db, V.db, cnt, 0, 63, s));
+            mark_heads_kernel<IdxT><<<grid_for(cnt), 256, 0, s>>>(K1.db.current(), nullptr, nullptr, cnt, grp, slot_base);
+            HIP_TRY(hipGetLastError());
+            bytes = 0;
+            HIP_TRY(rocprim::inclusive_scan(nullptr, bytes, grp, grp, (size_t)cnt, rocprim::maximum<IdxT>(), s));
+            RC_TRY(temp.reserve(bytes));
+            HIP_TRY(rocprim::inclusive_scan(temp.p, bytes, grp, grp, (size_t)cnt, rocprim::maximum<IdxT>(), s));
+            apply_round_kernel<IdxT><<<grid_for(cnt), 256, 0, s>>>(V.db.current(), grp, nullptr, cnt, d_sa, rank, tied, slot_base);
+            HIP_TRY(hipGetLastError());
+            // tied slots of this class (class-local numbers + slot_base) -> appended to the list
+            bytes = 0;
+            HIP_TRY(rocprim::select(nullptr, bytes, it, tied, out_b.as<uint64_t>(), d_count, (size_t)cnt, s));
+            RC_TRY(temp.reserve(bytes));
+            HIP_TRY(rocprim::select(temp.p, bytes, it, tied, out_b.as<uint64_t>(), d_count, (size_t)cnt, s));
+            size_t h_count = 0;
+            HIP_TRY(hipMemcpyAsync(&h_count, d_count, sizeof(size_t), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            if (h_count) {
+                offset_slots_kernel<<<grid_for(h_count), 256, 0, s>>>(out_b.as<uint64_t>(), h_count, slot_base);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipMemcpyAsync(list + m, out_b.p, h_count * 8, hipMemcpyDeviceToDevice, s));
+                m += h_count;
+            }
+            slot_base += cnt;
+        }
+        HIP_TRY(hipStreamSynchronize(s));
+        K1.release(); V.release(); grp_b.release(); tied_b.release(); out_b.release();
+        // ---- doubling rounds over the tied suffixes, batch by batch --------------------------------
+        uint64_t h = dna ? 21 : 7;
+        const unsigned nb = bits_for(n + 1);
+        while (m) {
+            if (h >= n) {
+                set_error("internal: suffix sort did not converge");
+                return ASGART_E_CAP;
+            }
+            const uint64_t B = std::min<uint64_t>(m, batch ? batch : kWideBatch);
+            // a batch ends on a group boundary, so it may exceed B by the tail of its last group
+            uint64_t done = 0, kept = 0;
+            while (done < m) {
+                uint64_t end = std::min<uint64_t>(m, done + B);
+                if (end < m) {
+                    group_end_kernel<<<1, 1, 0, s>>>(list, d_sa, rank, m, end, reinterpret_cast<uint64_t *>(d_count));
+                    HIP_TRY(hipGetLastError());
+                    HIP_TRY(hipMemcpyAsync(&end, d_count, 8, hipMemcpyDeviceToHost, s));
+                    HIP_TRY(hipStreamSynchronize(s));
+                }
+                const uint64_t bm = end - done;
+                const uint64_t *slots = list + done;
+                RC_TRY(k1o.reserve(bm * 8));
+                RC_TRY(k2o.reserve(bm * 8));
+                RC_TRY(vo.reserve(bm * 8));
+                RC_TRY(K1.reserve(bm));
+                RC_TRY(K2.reserve(bm));
+                RC_TRY(Pm.reserve(bm));
+                RC_TRY(grp_b.reserve(bm * 8));
+                RC_TRY(tied_b.reserve(bm));
+                RC_TRY(out_b.reserve(bm * 8));
+                grp = grp_b.as<uint64_t>();
+                tied = tied_b.as<uint8_t>();
+                round_keys_kernel<IdxT><<<grid_for(bm), 256, 0, s>>>(d_sa, rank, slots, bm, n, h, k1o.as<uint64_t>(),
+                                                                     k2o.as<uint64_t>(), vo.as<uint64_t>());
+                HIP_TRY(hipGetLastError());
+                // LSD: stable sort of a permutation by the second word, then by the first
+                HIP_TRY(hipMemcpyAsync(K2.db.current(), k2o.p, bm * 8, hipMemcpyDeviceToDevice, s));
+                iota_kernel<<<grid_for(bm), 256, 0, s>>>(Pm.db.current(), bm);
+                RC_TRY(sort_pairs<IdxT>(temp, K2.db, Pm.db, bm, 0, nb + 1, s));
+                gather64_kernel<<<grid_for(bm), 256, 0, s>>>(k1o.as<uint64_t>(), Pm.db.current(), bm, K1.db.current());
+                RC_TRY(sort_pairs<IdxT>(temp, K1.db, Pm.db, bm, 0, nb, s));
+                // sorted (k1, k2, suffix): k1 is K1.current; the other two through the permutation
+                gather64_kernel<<<grid_for(bm), 256, 0, s>>>(k2o.as<uint64_t>(), Pm.db.current(), bm, K2.db.current());
+                gather64_kernel<<<grid_for(bm), 256, 0, s>>>(vo.as<uint64_t>(), Pm.db.current(), bm, Pm.db.alternate());
+                HIP_TRY(hipGetLastError());
+                const uint64_t *vs = Pm.db.alternate();
+                mark_heads_kernel<IdxT><<<grid_for(bm), 256, 0, s>>>(K1.db.current(), K2.db.current(), slots, bm, grp, 0);
+                HIP_TRY(hipGetLastError());
+                bytes = 0;
+                HIP_TRY(rocprim::inclusive_scan(nullptr, bytes, grp, grp, (size_t)bm, rocprim::maximum<IdxT>(), s));
+                RC_TRY(temp.reserve(bytes));
+                HIP_TRY(rocprim::inclusive_scan(temp.p, bytes, grp, grp, (size_t)bm, rocprim::maximum<IdxT>(), s));
+                apply_round_kernel<IdxT><<<grid_for(bm), 256, 0, s>>>(vs, grp, slots, bm, d_sa, rank, tied, 0);
+                HIP_TRY(hipGetLastError());
+                bytes = 0;
+                HIP_TRY(rocprim::select(nullptr, bytes, slots, tied, out_b.as<uint64_t>(), d_count, (size_t)bm, s));
+                RC_TRY(temp.reserve(bytes));
+                HIP_TRY(rocprim::select(temp.p, bytes, slots, tied, out_b.as<uint64_t>(), d_count, (size_t)bm, s));
+                size_t h_count = 0;
+                HIP_TRY(hipMemcpyAsync(&h_count, d_count, sizeof(size_t), hipMemcpyDeviceToHost, s));
+                HIP_TRY(hipStreamSynchronize(s));
+                // in-place compaction of the list: the survivors trail the read position
+                if (h_count) HIP_TRY(hipMemcpyAsync(list + kept, out_b.p, h_count * 8, hipMemcpyDeviceToDevice, s));
+                kept += h_count;
+                done = end;
+            }
+            HIP_TRY(hipStreamSynchronize(s));
+            m = kept;
             h *= 2;
         }
         return 0;
@@ -315,10 +599,11 @@ int32_t sort_records(Workspace &w, const SdRec *recs, uint64_t n, hipStream_t s)
     return 0;
 }
 
-int32_t sa_build_device(const uint8_t *d_text, int64_t n, void *d_sa, bool wide, hipStream_t stream) {
+int32_t sa_build_device(const uint8_t *d_text, int64_t n, void *d_sa, bool wide, hipStream_t stream,
+                        uint64_t wide_batch) {
     bool dna = false;
     RC_TRY(text_is_dna(d_text, n, stream, &dna));
-    if (wide) return build_t<uint64_t>(d_text, n, (uint64_t *)d_sa, dna, stream);
+    if (wide) return build_wide(d_text, n, (uint64_t *)d_sa, dna, stream, wide_batch);
     return build_t<uint32_t>(d_text, n, (uint32_t *)d_sa, dna, stream);
 }
 
@@ -345,7 +630,7 @@ extern "C" int32_t asgart_sa_build64(const uint8_t *T, int64_t *SA, int64_t n) {
         RC_TRY(text.reserve((size_t)n + 64));
         RC_TRY(sa.reserve(((size_t)n + 16) * (wide ? 8 : 4)));
         HIP_TRY(hipMemcpyAsync(text.p, T, (size_t)n, hipMemcpyHostToDevice, s));
-        RC_TRY(sa_build_device(text.as<uint8_t>(), n, sa.p, wide, s));
+        RC_TRY(sa_build_device(text.as<uint8_t>(), n, sa.p, wide, s, 0));
         if (wide) {
             HIP_TRY(hipMemcpyAsync(SA, sa.p, (size_t)n * 8, hipMemcpyDeviceToHost, s));
         } else {

@@ -186,8 +186,56 @@ def scaled(lengths: Sequence[int], total: int) -> List[int]:
     return [max(1000, int(x * f)) for x in lengths]
 
 
+_COMP_BYTE = np.arange(256, dtype=np.uint8)
+for _a, _b in ((b"A", b"T"), (b"C", b"G"), (b"a", b"t"), (b"c", b"g")):
+    _COMP_BYTE[_a[0]], _COMP_BYTE[_b[0]] = _b[0], _a[0]
+_SUB_LUT = np.zeros((256, 3), dtype=np.uint8)          # base -> its three substitutes, case kept
+for _set in (b"ACGT", b"acgt"):
+    for _j, _c in enumerate(_set):
+        _SUB_LUT[_c] = [_set[(_j + d) % 4] for d in (1, 2, 3)]
+
+
+def diverged_genome(records: List[Tuple[str, np.ndarray]], seed: int, sub_rate: float = 0.012,
+                    prefix: str = "b_") -> List[Tuple[str, np.ndarray]]:
+    """A second genome derived from `records` the way a sister species' assembly relates to the
+    first: every base substituted with probability `sub_rate`
+    (case and N kept), then per record a few large inversions (reverse-complemented in place) and
+    block swaps."""
+    rng = np.random.default_rng(seed)
+    out = []
+    blk = 1 << 26
+    for name, seq in records:
+        s = seq.copy()
+        n = len(s)
+        for off in range(0, n, blk):
+            part = s[off:off + blk]
+            hit = np.flatnonzero(rng.random(len(part), dtype=np.float32) < sub_rate)
+            alt = _SUB_LUT[part[hit], rng.integers(0, 3, size=len(hit))]
+            keep = alt != 0                     # N and anything else that is not a base stays
+            part[hit[keep]] = alt[keep]
+        if n >= 200_000:
+            for _ in range(max(1, n // 50_000_000)):   # inversions, 0.2-2 % of the record each
+                ln = int(rng.integers(n // 500, n // 50))
+                p = int(rng.integers(0, n - ln))
+                s[p:p + ln] = _COMP_BYTE[s[p:p + ln][::-1]]
+            for _ in range(max(1, n // 100_000_000)):  # swaps of two equally long blocks
+                ln = int(rng.integers(n // 1000, n // 100))
+                p, q = sorted(int(x) for x in rng.integers(0, n - ln, size=2))
+                if q - p >= ln:
+                    tmp = s[p:p + ln].copy()
+                    s[p:p + ln] = s[q:q + ln]
+                    s[q:q + ln] = tmp
+        out.append((prefix + name, s))
+    return out
+
+
 def config_genome(cfg: int, scale: float = 1.0) -> List[Tuple[str, np.ndarray]]:
-    """Synthetic stand-ins for BASELINE.json configs 1-4 (scale<1 shrinks them)."""
+    """Synthetic stand-ins for BASELINE.json configs 1-5 (scale<1 shrinks them).  Config 5 is two
+    "files": the config-4 genome plus a 1.2 %-diverged, rearranged copy of it (the cross-genome
+    run concatenates the records of all input files, reference src/bin/asgart.rs:375-395)."""
+    if cfg == 5:
+        first = config_genome(4, scale)
+        return first + diverged_genome(first, SEED_BASE + 5)
     table = {1: ECOLI_MG1655, 2: SCEREVISIAE_S288C, 3: GRCH38_PRIMARY[:1], 4: GRCH38_PRIMARY}[cfg]
     lens = table if scale == 1.0 else scaled(table, int(sum(table) * scale))
     return make_genome(lens, SEED_BASE + cfg)

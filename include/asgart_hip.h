@@ -111,6 +111,14 @@ void asgart_index_destroy(asgart_index *idx);
  * force_wide are fixed at creation (environment only).  Blocks until no call is in flight. */
 int32_t asgart_index_set_option(asgart_index *idx, const char *name, int64_t value);
 
+/* O(n) verifier of the suffix array held by the index, on the GPU: SA must be a permutation of
+ * 0..n-1 whose adjacent suffixes are in strictly increasing bytewise order (the same rank trick as
+ * the CPU oracle's checker).  Returns the number of violating slots (0 = valid), < 0 on error.
+ * The reference never checks its suffix array (it even ignores divsufsort64's status,
+ * src/bin/asgart.rs:475-477); this exists for the full-size parity tests, where the text is too
+ * large for the CPU checker (n >= 2^32: 64-bit suffix numbers). */
+int64_t asgart_index_check_sa(asgart_index *idx);
+
 /* Optional: build the probe_size-specific search keys now (otherwise done
  * lazily by the first call that needs them; kept until another k is used). */
 int32_t asgart_index_prepare(asgart_index *idx, uint64_t probe_size);

@@ -431,6 +431,65 @@ def _check_against_oracle_digest(name):
             assert _sha_slabs([sds], "<u8") == want["sds_sha256"], (name, label)
 
 
+@pytest.mark.parametrize("kind", ["dna", "bytes", "runs", "dna-batched", "runs-batched"])
+def test_wide_suffix_array_builder_matches_oracle(hiplib, kind, monkeypatch):
+    """Texts of 2^32 bytes and more take the 64-bit suffix sorter (round 0 class by class, doubling
+    rounds as two-word LSD sorts).  ASGART_FORCE_WIDE selects it for small texts: its suffix array must
+    equal the oracle's SA-IS, and the GPU verifier must accept it (and reject a damaged one)."""
+    rng = np.random.default_rng(11)
+    if kind.endswith("-batched"):   # doubling rounds in batches of ~1000 suffixes (whole groups)
+        monkeypatch.setenv("ASGART_TEST_WIDE_BATCH", "1000")
+        kind = kind.split("-")[0]
+    if kind == "dna":
+        text = prep.prepare_records(_small_genome(seed=21, lens=(300_000, 200_000), sat_per_record=1,
+                                                  sat_copies=(50, 200))).data
+    elif kind == "runs":   # long runs and periodic stretches: many doubling rounds
+        parts = [np.full(70_000, ord("N"), np.uint8), np.tile(np.frombuffer(b"ACGTTGCA", np.uint8), 9_000),
+                 np.full(40_000, ord("A"), np.uint8), rng.choice(np.frombuffer(b"ACGT", np.uint8), size=50_000),
+                 np.tile(np.frombuffer(b"AC", np.uint8), 30_000), np.frombuffer(b"$", np.uint8)]
+        text = np.concatenate(parts)
+    else:                  # arbitrary bytes (asgart_sa_build64 is a general suffix sorter)
+        text = rng.integers(0, 256, size=200_000, dtype=np.uint8)
+        text[5000:9000] = text[100_000:104_000]
+    want = oracle.divsufsort64(text)
+    monkeypatch.setenv("ASGART_FORCE_WIDE", "1")
+    if kind == "bytes":
+        got = asgart_amd.sa_build64(text)           # 32-bit path of the C entry point, for comparison
+        assert np.array_equal(got, want)
+        return
+    with asgart_amd.Index(text, None) as idx:
+        assert np.array_equal(idx.sa_read(0, len(text)), want)
+        assert idx.check_sa() == 0
+    bad = want.copy()
+    bad[[1000, 1001]] = bad[[1001, 1000]]
+    with asgart_amd.Index(text, bad) as idx:
+        assert idx.check_sa() > 0
+    monkeypatch.delenv("ASGART_FORCE_WIDE")
+    with asgart_amd.Index(text, None) as idx:        # the verifier on a 32-bit index
+        assert idx.check_sa() == 0
+
+
+def test_cfg5_shaped_two_files_wide(hiplib, monkeypatch):
+    """BASELINE.json configs[4] scaled down: two "files" (a GRCh38-shaped genome and its 1.2 %-diverged,
+    rearranged copy, 50 records) concatenated as the reference concatenates its inputs
+    (src/bin/asgart.rs:375-395), through the 64-bit instantiations a 6.1-Gb text selects (suffix sorter,
+    slots, positions), direct and RC, against the oracle."""
+    pr = prep.prepare_records(synth.config_genome(5, 0.003))
+    assert len(pr.map) == 50
+    monkeypatch.setenv("ASGART_FORCE_WIDE", "1")
+    with asgart_amd.Index(pr.data, None) as idx:
+        assert idx.check_sa() == 0
+        sa = idx.sa_read(0, len(pr.data))
+        oidx = oracle.Index.build(pr.data, sa)
+        assert oracle.sa_check(pr.data, sa) == 0
+        for rc in (False, True):
+            st = asgart_amd.RunSettings.from_cli(reverse=rc, complement=rc)
+            offs, sds = idx.search_duplications_raw(pr.chunks, st)
+            eoffs, esds = oidx.run_raw(pr.chunks, oracle.make_settings(reverse=rc, complement=rc), threads=16)
+            assert np.array_equal(offs, eoffs) and np.array_equal(sds, esds), rc
+            assert len(sds) > 100
+
+
 def test_cfg3_full_skip_masked_digest(hiplib):
     """BASELINE.json configs[2] as stated: chr1-sized synthetic (249 Mb), direct + RC, --skip-masked."""
     _check_against_oracle_digest("cfg3s")

@@ -1,4 +1,4 @@
 export TMPDIR=/tmp
-python tools/pole_synth.py --copies 3800 --sub 0.03 --check '' 2>&1 | grep direct
-python tools/tune_tiers.py cfg4 '' 2>&1 | tail -1
-python -m pytest tests -m gpu -x -q -k "not cfg4_full and not cfg3_full" 2>&1 | tail -3
+mkdir -p gpurun_out/g3
+python -m pytest tests -m gpu -x -q -k "wide or cfg5 or searcher or tail" 2>&1 | tail -3
+timeout 1500 python tools/cfg5_check.py > gpurun_out/g3/cfg5.log 2>&1; echo rc=$?; tail -15 gpurun_out/g3/cfg5.log
