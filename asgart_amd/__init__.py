@@ -33,7 +33,7 @@ ABI_SYMBOLS = (
     "asgart_families_copy", "asgart_families_free", "asgart_searcher_cache_get",
     "asgart_searcher_search", "asgart_sa_read", "asgart_probe_hits", "asgart_get_stats",
     "asgart_last_error", "asgart_version", "asgart_compute_scores", "asgart_index_set_option",
-    "asgart_index_check_sa",
+    "asgart_index_check_sa", "asgart_index_create_trim",
 )
 
 
@@ -90,6 +90,9 @@ def load_library() -> C.CDLL:
     L.asgart_sa_build64.restype = C.c_int32
     L.asgart_index_create.argtypes = [vp, C.c_int64, vp, C.c_int64, C.c_int32, C.POINTER(vp)]
     L.asgart_index_create.restype = C.c_int32
+    L.asgart_index_create_trim.argtypes = [vp, C.c_int64, vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32,
+                                           C.POINTER(vp)]
+    L.asgart_index_create_trim.restype = C.c_int32
     L.asgart_index_destroy.argtypes = [vp]
     L.asgart_index_destroy.restype = None
     L.asgart_index_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
@@ -210,18 +213,28 @@ class Index:
     (reference src/bin/asgart.rs:141-155).
     """
 
-    def __init__(self, text, sa: Optional[np.ndarray] = None, device: int = 0):
+    def __init__(self, text, sa: Optional[np.ndarray] = None, device: int = 0,
+                 trim: Optional[Tuple[int, int]] = None):
+        """trim=(start, end): the `--trim` variant (reference src/bin/asgart.rs:142-148): the suffix array
+        covers data[start..end] + '$' only (entries shifted by +start) and the whole text is searched
+        against it.  `sa` is then that shifted array (end - start + 1 entries) or None."""
         L = load_library()
         self.text = _as_u8(text)
         self._h = C.c_void_p()
+        self.trim = trim
         sa_arr = None
+        want = len(self.text) if trim is None else trim[1] - trim[0] + 1
         if sa is not None:
             sa_arr = np.ascontiguousarray(sa, dtype=np.int64)
-            if len(sa_arr) != len(self.text):
-                raise ValueError("suffix array length != text length")
-        _check(L.asgart_index_create(_ptr(self.text), len(self.text), _ptr(sa_arr),
-                                     len(self.text) if sa_arr is not None else 0, device,
-                                     C.byref(self._h)))
+            if len(sa_arr) != want:
+                raise ValueError("suffix array length != text length (or the trimmed window + 1)")
+        if trim is None:
+            _check(L.asgart_index_create(_ptr(self.text), len(self.text), _ptr(sa_arr),
+                                         want if sa_arr is not None else 0, device, C.byref(self._h)))
+        else:
+            _check(L.asgart_index_create_trim(_ptr(self.text), len(self.text), _ptr(sa_arr),
+                                              want if sa_arr is not None else 0, int(trim[0]), int(trim[1]),
+                                              device, C.byref(self._h)))
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
@@ -373,8 +386,7 @@ class SearchDuplications:
                  trim: Optional[Tuple[int, int]], settings: RunSettings,
                  suffix_array: Optional[np.ndarray] = None, device: int = 0,
                  index: Optional[Index] = None):
-        if trim is not None:
-            raise AsgartError(-1, "--trim is not supported by the HIP search core")
+        self.trim = trim
         self.chunks_to_process = list(chunks_to_process)
         self.settings = settings
         self.suffix_array = suffix_array
@@ -385,7 +397,7 @@ class SearchDuplications:
         return "Looking for proto-duplications"
 
     def run(self, _input: List[ProtoSDsFamily], strand: Strand) -> List[ProtoSDsFamily]:
-        index = self.index or Index(strand.data, self.suffix_array, self.device)
+        index = self.index or Index(strand.data, self.suffix_array, self.device, trim=self.trim)
         try:
             offs, sds = index.search_duplications_raw(self.chunks_to_process, self.settings)
         finally:

@@ -6,6 +6,7 @@
 #include "index.hpp"
 #include "search_dev.hpp"
 
+#include <algorithm>
 #include <cctype>
 #include <chrono>
 
@@ -148,9 +149,9 @@ template <class SlotT>
 __global__ __launch_bounds__(256) void build_keys_kernel(const uint8_t *__restrict__ text,
                                                          const SlotT *__restrict__ sa,
                                                          uint64_t *__restrict__ keys, uint64_t n,
-                                                         int k) {
+                                                         uint64_t n_sa, int k) {
     // grid-stride: a launch holds fewer than 2^32 threads, a 6-Gbp index more than 2^32 slots
-    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (uint64_t)gridDim.x * blockDim.x) {
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_sa; r += (uint64_t)gridDim.x * blockDim.x) {
         uint64_t x = sa[r];
         uint64_t q = 0;
         for (int j = 0; j < k; ++j) {
@@ -200,6 +201,98 @@ __global__ __launch_bounds__(256) void build_cache8_kernel(const uint64_t *__res
     uint64_t hi = lower_bound_keys(keys, lo, n, ((uint64_t)pre24 + 1ull) << sh);
     c8lo[idx] = (SlotT)lo;
     c8hi[idx] = (SlotT)hi;
+}
+
+// --trim: Searcher::new's cache entries are whatever `sa_searchb64` finds (reference
+// src/searcher.rs:118-128) on an array that is NOT sorted under its comparator for the few suffixes
+// ending within 8 bases of the window, so the bisection itself is replayed: libdivsufsort's published
+// `sa_search` + `_compare` (lib/utils.c; the fork's bounded variant is taken to be the same routine on
+// [init_left, init_right) -- its source is absent), one thread per 8-mer.
+__device__ inline int published_compare(const uint8_t *T, uint64_t Tsize, const uint8_t *P, int Psize,
+                                        uint64_t suf, int *match) {
+    uint64_t i = suf + (uint64_t)*match;
+    int j = *match, r = 0;
+    for (; i < Tsize && j < Psize && (r = (int)T[i] - (int)P[j]) == 0; ++i, ++j) {
+    }
+    *match = j;
+    return r == 0 ? -(j != Psize) : r;
+}
+
+template <class SlotT>
+__global__ __launch_bounds__(256) void build_cache8_trim_kernel(const uint8_t *__restrict__ T, uint64_t Tsize,
+                                                                const SlotT *__restrict__ SA, uint64_t n_sa,
+                                                                SlotT *__restrict__ c8lo, SlotT *__restrict__ c8hi) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (uint32_t)kCacheEntries) return;
+    uint8_t P[kCacheLen];
+    {   // dense index -> 8 bytes, code order A < C < G < N < T (cache8_index)
+        const uint8_t alpha[5] = {'A', 'C', 'G', 'N', 'T'};
+        uint32_t v = idx;
+        for (int j = kCacheLen - 1; j >= 0; --j) {
+            P[j] = alpha[v % 5u];
+            v /= 5u;
+        }
+    }
+    const int Psize = kCacheLen;
+    long long i = 0, j = 0, k = 0, size = (long long)n_sa, half = size >> 1, lsize, rsize;
+    int match, lmatch = 0, rmatch = 0, llmatch, lrmatch, rlmatch, rrmatch, r;
+    for (; 0 < size; size = half, half >>= 1) {
+        match = lmatch < rmatch ? lmatch : rmatch;
+        r = published_compare(T, Tsize, P, Psize, (uint64_t)SA[i + half], &match);
+        if (r < 0) {
+            i += half + 1;
+            half -= (size & 1) ^ 1;
+            lmatch = match;
+        } else if (r > 0) {
+            rmatch = match;
+        } else {
+            lsize = half, j = i, rsize = size - half - 1, k = i + half + 1;
+            for (llmatch = lmatch, lrmatch = match, half = lsize >> 1; 0 < lsize; lsize = half, half >>= 1) {
+                lmatch = llmatch < lrmatch ? llmatch : lrmatch;
+                r = published_compare(T, Tsize, P, Psize, (uint64_t)SA[j + half], &lmatch);
+                if (r < 0) {
+                    j += half + 1;
+                    half -= (lsize & 1) ^ 1;
+                    llmatch = lmatch;
+                } else {
+                    lrmatch = lmatch;
+                }
+            }
+            for (rlmatch = match, rrmatch = rmatch, half = rsize >> 1; 0 < rsize; rsize = half, half >>= 1) {
+                rmatch = rlmatch < rrmatch ? rlmatch : rrmatch;
+                r = published_compare(T, Tsize, P, Psize, (uint64_t)SA[k + half], &rmatch);
+                if (r <= 0) {
+                    k += half + 1;
+                    half -= (rsize & 1) ^ 1;
+                    rlmatch = rmatch;
+                } else {
+                    rrmatch = rmatch;
+                }
+            }
+            break;
+        }
+    }
+    const long long left = (0 < (k - j)) ? j : i, count = k - j;
+    c8lo[idx] = (SlotT)left;
+    c8hi[idx] = (SlotT)(left + count);
+}
+
+// --trim: slots of the sub-strand suffixes shorter than k (start position > end - k)
+template <class SlotT>
+__global__ __launch_bounds__(256) void bad_slots_kernel(const SlotT *__restrict__ sa, uint64_t n_sa,
+                                                        uint64_t first_bad_pos, unsigned long long *__restrict__ out,
+                                                        unsigned long long *__restrict__ count, int cap) {
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_sa; r += (uint64_t)gridDim.x * blockDim.x)
+        if ((uint64_t)sa[r] >= first_bad_pos) {
+            const unsigned long long at = atomicAdd(count, 1ull);
+            if (at < (unsigned long long)cap) out[at] = r;
+        }
+}
+
+template <class SlotT>
+__global__ __launch_bounds__(256) void add_offset_kernel(SlotT *__restrict__ sa, uint64_t cnt, uint64_t add) {
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < cnt; r += (uint64_t)gridDim.x * blockDim.x)
+        sa[r] = (SlotT)((uint64_t)sa[r] + add);
 }
 
 // presence filter of one orientation (search_dev.hpp): one thread per suffix-array slot, the first
@@ -406,30 +499,46 @@ int32_t index_prepare(asgart_index *idx, uint64_t k) {
     HIP_TRY(hipSetDevice(idx->device));
     free_k_specific(idx);
     auto t0 = std::chrono::steady_clock::now();
-    const uint64_t n = (uint64_t)idx->n;
+    const uint64_t n = (uint64_t)idx->n, n_sa = (uint64_t)idx->n_sa;
     const size_t slot = idx->wide ? 8 : 4;
-    const int d = choose_depth(idx->n, k, idx->opt.ptab_depth);
+    // a --trim index is searched through the 8-mer cache like the reference: no prefix table
+    const int d = idx->trimmed ? 1 : choose_depth(idx->n_sa, k, idx->opt.ptab_depth);
     const uint64_t entries = (1ull << (2 * d)) + 1;
-    HIP_TRY(hipMalloc((void **)&idx->d_keys, (n + 16) * sizeof(uint64_t)));
+    HIP_TRY(hipMalloc((void **)&idx->d_keys, (n_sa + 16) * sizeof(uint64_t)));
     HIP_TRY(hipMalloc(&idx->d_ptab, entries * slot));
     HIP_TRY(hipMalloc(&idx->d_c8lo, (size_t)kCacheEntries * slot));
     HIP_TRY(hipMalloc(&idx->d_c8hi, (size_t)kCacheEntries * slot));
     hipStream_t s = idx->ctx[0].stream;
-    if (idx->wide) {
-        build_keys_kernel<uint64_t><<<grid_capped(n), 256, 0, s>>>(
-            idx->d_text, (const uint64_t *)idx->d_sa, idx->d_keys, n, (int)k);
-        build_ptab_kernel<uint64_t><<<grid_for(entries), 256, 0, s>>>(
-            idx->d_keys, (uint64_t *)idx->d_ptab, n, (int)k, d);
-        build_cache8_kernel<uint64_t><<<grid_for(kCacheEntries), 256, 0, s>>>(
-            idx->d_keys, (uint64_t *)idx->d_c8lo, (uint64_t *)idx->d_c8hi, n, (int)k);
-    } else {
-        build_keys_kernel<uint32_t><<<grid_capped(n), 256, 0, s>>>(
-            idx->d_text, (const uint32_t *)idx->d_sa, idx->d_keys, n, (int)k);
-        build_ptab_kernel<uint32_t><<<grid_for(entries), 256, 0, s>>>(
-            idx->d_keys, (uint32_t *)idx->d_ptab, n, (int)k, d);
-        build_cache8_kernel<uint32_t><<<grid_for(kCacheEntries), 256, 0, s>>>(
-            idx->d_keys, (uint32_t *)idx->d_c8lo, (uint32_t *)idx->d_c8hi, n, (int)k);
-    }
+    idx->n_bad = 0;
+    auto build = [&](auto tag) -> int32_t {
+        using SlotT = decltype(tag);
+        const SlotT *sa = (const SlotT *)idx->d_sa;
+        build_keys_kernel<SlotT><<<grid_capped(n_sa), 256, 0, s>>>(idx->d_text, sa, idx->d_keys, n, n_sa, (int)k);
+        if (!idx->trimmed) {
+            build_ptab_kernel<SlotT><<<grid_for(entries), 256, 0, s>>>(idx->d_keys, (SlotT *)idx->d_ptab, n_sa, (int)k, d);
+            build_cache8_kernel<SlotT><<<grid_for(kCacheEntries), 256, 0, s>>>(
+                idx->d_keys, (SlotT *)idx->d_c8lo, (SlotT *)idx->d_c8hi, n_sa, (int)k);
+            HIP_TRY(hipGetLastError());
+            return 0;
+        }
+        build_cache8_trim_kernel<SlotT><<<grid_for(kCacheEntries), 256, 0, s>>>(
+            idx->d_text, n, sa, n_sa, (SlotT *)idx->d_c8lo, (SlotT *)idx->d_c8hi);
+        // the out-of-place slots: sub-strand suffixes shorter than k
+        DevBuf &cb = idx->ctx[0].ws.counters;
+        RC_TRY(cb.reserve(256 * 8));
+        unsigned long long *d_cnt = cb.as<unsigned long long>(), *d_out = d_cnt + 8;
+        HIP_TRY(hipMemsetAsync(d_cnt, 0, 8, s));
+        const uint64_t first_bad = (uint64_t)idx->trim_end >= k ? (uint64_t)idx->trim_end - k + 1 : 0;
+        bad_slots_kernel<SlotT><<<grid_capped(n_sa), 256, 0, s>>>(sa, n_sa, first_bad, d_out, d_cnt, kMaxK + 2);
+        HIP_TRY(hipGetLastError());
+        unsigned long long h[8 + kMaxK + 2];
+        HIP_TRY(hipMemcpyAsync(h, d_cnt, sizeof(h), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        idx->n_bad = (int)std::min<unsigned long long>(h[0], kMaxK + 2);
+        for (int j = 0; j < idx->n_bad; ++j) idx->bad[j] = h[8 + j];
+        return 0;
+    };
+    RC_TRY(idx->wide ? build(uint64_t{}) : build(uint32_t{}));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));
     // text-tail corner list (host, from the last bytes of the text)
@@ -465,7 +574,8 @@ int32_t index_prepare(asgart_index *idx, uint64_t k) {
 // Builds the presence filter of orientation `mode` for probe size k (keys prepared first).
 int32_t index_prepare_filter(asgart_index *idx, uint64_t k, int mode) {
     RC_TRY(index_prepare(idx, k));
-    if (idx->opt.kfilter_bits == 0 || mode < 0 || mode > 3) return 0;
+    // (a --trim index has no filter: its array does not hold the probes' own positions)
+    if (idx->opt.kfilter_bits == 0 || idx->trimmed || mode < 0 || mode > 3) return 0;
     {
         std::lock_guard<std::mutex> lk(idx->mu);
         if (idx->k == k && idx->d_filter[mode]) return 0;
@@ -545,8 +655,9 @@ void asgart_index_destroy(asgart_index *idx) {
     delete idx;
 }
 
-int32_t asgart_index_create(const uint8_t *T, int64_t n, const int64_t *SA, int64_t sa_len,
-                            int32_t device, asgart_index **out) {
+static int32_t index_create_impl(const uint8_t *T, int64_t n, const int64_t *SA, int64_t sa_len,
+                                 bool trimmed, int64_t trim_start, int64_t trim_end, int32_t device,
+                                 asgart_index **out) {
     if (!out) {
         set_error("asgart_index_create: out is NULL");
         return ASGART_E_ARG;
@@ -556,9 +667,16 @@ int32_t asgart_index_create(const uint8_t *T, int64_t n, const int64_t *SA, int6
         set_error("asgart_index_create: empty text");
         return ASGART_E_ARG;
     }
-    if (SA && sa_len != n) {
-        set_error("asgart_index_create: sa_len (%lld) != n (%lld); --trim sub-range suffix "
-                  "arrays are not supported", (long long)sa_len, (long long)n);
+    if (trimmed && !(0 <= trim_start && trim_start < trim_end && trim_end <= n - 1)) {
+        // what prepare_data lets through (reference src/bin/asgart.rs:432-463): start < end <= len - 1
+        set_error("asgart_index_create_trim: need 0 <= start (%lld) < end (%lld) <= n - 1 (%lld)",
+                  (long long)trim_start, (long long)trim_end, (long long)(n - 1));
+        return ASGART_E_ARG;
+    }
+    const int64_t n_sa = trimmed ? trim_end - trim_start + 1 : n;  // + the '$' of the sub-strand
+    if (SA && sa_len != n_sa) {
+        set_error("asgart_index_create: sa_len (%lld) != %lld (the text length, or end - start + 1 for a "
+                  "trimmed index)", (long long)sa_len, (long long)n_sa);
         return ASGART_E_ARG;
     }
     RC_TRY(check_device(device));
@@ -569,6 +687,10 @@ int32_t asgart_index_create(const uint8_t *T, int64_t n, const int64_t *SA, int6
     }
     idx->device = device;
     idx->n = n;
+    idx->n_sa = n_sa;
+    idx->trimmed = trimmed;
+    idx->trim_start = trim_start;
+    idx->trim_end = trim_end;
     options_from_env(idx->opt);  // the only place the environment is read
     // force_wide (tests): 64-bit slots and positions also for a small text, so that the
     // instantiations a > 4 Gb input selects can be checked against the oracle
@@ -611,20 +733,42 @@ int32_t asgart_index_create(const uint8_t *T, int64_t n, const int64_t *SA, int6
         const int64_t tl = n < 64 ? n : 64;
         idx->h_tail.assign(T + n - tl, T + n);
         const size_t slot = idx->wide ? 8 : 4;
-        HIP_TRY(hipMalloc(&idx->d_sa, ((size_t)n + 16) * slot));
-        if (!SA) {
+        HIP_TRY(hipMalloc(&idx->d_sa, ((size_t)n_sa + 16) * slot));
+        if (!SA && trimmed) {
+            // suffix array of data[start..end] + '$', every entry shifted by +start
+            // (reference src/bin/asgart.rs:142-148)
+            hipStream_t s = idx->ctx[0].stream;
+            DevBuf sub;
+            RC_TRY(sub.reserve((size_t)n_sa + 64));
+            int32_t rc2 = [&]() -> int32_t {
+                HIP_TRY(hipMemsetAsync(sub.p, 0, (size_t)n_sa + 64, s));
+                HIP_TRY(hipMemcpyAsync(sub.p, idx->d_text + trim_start, (size_t)(n_sa - 1), hipMemcpyDeviceToDevice, s));
+                HIP_TRY(hipMemsetAsync(sub.as<uint8_t>() + (n_sa - 1), '$', 1, s));
+                RC_TRY(sa_build_device(sub.as<uint8_t>(), n_sa, idx->d_sa, idx->wide, s,
+                                       (uint64_t)idx->opt.test_wide_batch));
+                if (idx->wide)
+                    add_offset_kernel<uint64_t><<<grid_capped((uint64_t)n_sa), 256, 0, s>>>((uint64_t *)idx->d_sa, (uint64_t)n_sa, (uint64_t)trim_start);
+                else
+                    add_offset_kernel<uint32_t><<<grid_capped((uint64_t)n_sa), 256, 0, s>>>((uint32_t *)idx->d_sa, (uint64_t)n_sa, (uint64_t)trim_start);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipStreamSynchronize(s));
+                return 0;
+            }();
+            sub.release();
+            RC_TRY(rc2);
+        } else if (!SA) {
             RC_TRY(sa_build_device(idx->d_text, n, idx->d_sa, idx->wide, idx->ctx[0].stream,
                                    (uint64_t)idx->opt.test_wide_batch));
         } else if (idx->wide) {
-            HIP_TRY(hipMemcpyAsync(idx->d_sa, SA, (size_t)n * 8, hipMemcpyHostToDevice,
+            HIP_TRY(hipMemcpyAsync(idx->d_sa, SA, (size_t)n_sa * 8, hipMemcpyHostToDevice,
                                    idx->ctx[0].stream));
             HIP_TRY(hipStreamSynchronize(idx->ctx[0].stream));
         } else {
             const uint64_t slice = 1ull << 25;
             DevBuf stage;
-            RC_TRY(stage.reserve((size_t)(slice < (uint64_t)n ? slice : (uint64_t)n) * 8));
-            for (uint64_t off = 0; off < (uint64_t)n; off += slice) {
-                uint64_t cnt = (uint64_t)n - off < slice ? (uint64_t)n - off : slice;
+            RC_TRY(stage.reserve((size_t)(slice < (uint64_t)n_sa ? slice : (uint64_t)n_sa) * 8));
+            for (uint64_t off = 0; off < (uint64_t)n_sa; off += slice) {
+                uint64_t cnt = (uint64_t)n_sa - off < slice ? (uint64_t)n_sa - off : slice;
                 hipError_t e = hipMemcpyAsync(stage.p, SA + off, cnt * 8, hipMemcpyHostToDevice,
                                               idx->ctx[0].stream);
                 if (e == hipSuccess) {
@@ -647,6 +791,17 @@ int32_t asgart_index_create(const uint8_t *T, int64_t n, const int64_t *SA, int6
     }
     *out = idx;
     return 0;
+}
+
+int32_t asgart_index_create(const uint8_t *T, int64_t n, const int64_t *SA, int64_t sa_len,
+                            int32_t device, asgart_index **out) {
+    return index_create_impl(T, n, SA, sa_len, false, 0, 0, device, out);
+}
+
+int32_t asgart_index_create_trim(const uint8_t *T, int64_t n, const int64_t *SA, int64_t sa_len,
+                                 int64_t trim_start, int64_t trim_end, int32_t device,
+                                 asgart_index **out) {
+    return index_create_impl(T, n, SA, sa_len, true, trim_start, trim_end, device, out);
 }
 
 int32_t asgart_index_set_option(asgart_index *idx, const char *name, int64_t value) {
@@ -675,6 +830,10 @@ int32_t asgart_index_set_option(asgart_index *idx, const char *name, int64_t val
 int64_t asgart_index_check_sa(asgart_index *idx) {
     if (!idx) {
         set_error("index is NULL");
+        return ASGART_E_ARG;
+    }
+    if (idx->trimmed) {
+        set_error("asgart_index_check_sa: not for a --trim index (its array covers a window of the text)");
         return ASGART_E_ARG;
     }
     HIP_TRY(hipSetDevice(idx->device));
@@ -801,7 +960,7 @@ int32_t asgart_searcher_search(asgart_index *idx, const uint8_t *patterns, int64
 }
 
 int32_t asgart_sa_read(asgart_index *idx, uint64_t lo, uint64_t hi, int64_t *out) {
-    if (!idx || hi < lo || hi > (uint64_t)idx->n || (hi > lo && !out)) {
+    if (!idx || hi < lo || hi > (uint64_t)idx->n_sa || (hi > lo && !out)) {
         set_error("asgart_sa_read: bad range");
         return ASGART_E_ARG;
     }

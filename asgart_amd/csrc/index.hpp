@@ -38,6 +38,15 @@ struct IndexView {
     // presence filter of the orientation of this call (search_dev.hpp); null: no filter
     const uint64_t *flt;
     int flt_bits;
+    // number of suffix-array slots: n, or end - start + 1 for a --trim index (reference
+    // src/bin/asgart.rs:142-148), whose array holds the suffixes of data[start..end] + '$' only
+    uint64_t n_sa;
+    // --trim: slots whose sub-strand suffix is shorter than k.  The array is sorted by the sub-strand's
+    // suffixes but compared through the whole text, so these few are out of place: any 8-mer bucket that
+    // contains one is searched by replaying the reference's bisection step by step.
+    int trim;
+    int n_bad;
+    uint64_t bad[kMaxK + 2];
 };
 
 struct ChunkTable {
@@ -142,6 +151,11 @@ void options_from_env(Options &o);
 struct asgart_index {
     int device = 0;
     int64_t n = 0;
+    int64_t n_sa = 0;       // suffix-array slots (== n unless trimmed)
+    bool trimmed = false;   // --trim index: SA of data[trim_start..trim_end] + '$', entries shifted by +trim_start
+    int64_t trim_start = 0, trim_end = 0;
+    int n_bad = 0;
+    uint64_t bad[asgart::kMaxK + 2] = {};
     bool wide = false;  // 64-bit slots/positions
     uint8_t *d_text = nullptr;
     void *d_sa = nullptr;
@@ -221,6 +235,10 @@ struct asgart_index {
         v.tail_bloom = tail_bloom;
         v.flt = nullptr;
         v.flt_bits = 0;
+        v.n_sa = (uint64_t)n_sa;
+        v.trim = trimmed ? 1 : 0;
+        v.n_bad = n_bad;
+        for (int j = 0; j < asgart::kMaxK + 2; ++j) v.bad[j] = bad[j];
         return v;
     }
 };

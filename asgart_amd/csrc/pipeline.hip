@@ -637,7 +637,7 @@ int32_t run_search(asgart_index *idx, const uint64_t *chunks, int64_t n_chunks,
         SearchCtx &probe = idx->acquire_one(&which);
         (void)probe;
         const int mode = (st->reverse ? 2 : 0) | (st->complement ? 1 : 0);
-        if (idx->k == st->probe_size && (idx->opt.kfilter_bits == 0 || idx->d_filter[mode])) break;
+        if (idx->k == st->probe_size && (idx->opt.kfilter_bits == 0 || idx->trimmed || idx->d_filter[mode])) break;
         idx->release_one(which);
         RC_TRY(index_prepare_filter(idx, st->probe_size, mode));
     }

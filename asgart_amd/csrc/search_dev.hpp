@@ -136,14 +136,42 @@ __device__ inline bool is_tail_corner(const IndexView<SlotT> &ix, uint64_t q) {
     return ix.n_tail8 && in_tail_list(ix, (uint32_t)(q >> (3 * (ix.k - kCacheLen))));
 }
 
+// --trim index (reference src/bin/asgart.rs:142-148): exactly the reference's two steps -- the 8-mer
+// cache entry (Searcher::new's bisection, replayed when the index was prepared), then the equal range
+// inside that bucket: plain bounds over the keys when the bucket is clean, the step-by-step replay of
+// equal_range_by when it holds one of the out-of-place suffixes.
+template <class SlotT, class Cnt = NoBytes>
+__device__ inline void kmer_range_trim(const IndexView<SlotT> &ix, uint64_t q, uint64_t &lo,
+                                       uint64_t &hi, Cnt &&cb = Cnt()) {
+    uint32_t c8;
+    if (!cache8_index((uint32_t)(q >> (3 * (ix.k - kCacheLen))), c8)) {
+        lo = hi = 0;
+        return;
+    }
+    const uint64_t L = ix.c8lo[c8], R = ix.c8hi[c8];
+    cb.rd(2 * sizeof(SlotT));
+    bool dirty = false;
+    for (int j = 0; j < ix.n_bad; ++j) dirty |= ix.bad[j] >= L && ix.bad[j] < R;
+    if (dirty) {
+        kmer_range_tail(ix, q, lo, hi, cb);
+        return;
+    }
+    lo = lower_bound_keys(ix.keys, L, R, q, cb);
+    hi = upper_bound_keys(ix.keys, lo, R, q, cb);
+}
+
 template <class SlotT, class Cnt = NoBytes>
 __device__ inline bool kmer_range(const IndexView<SlotT> &ix, uint64_t q, uint64_t &lo,
                                   uint64_t &hi, Cnt &&cb = Cnt()) {
+    if (ix.trim) {
+        kmer_range_trim(ix, q, lo, hi, cb);
+        return false;  // the interval need not hold the probe's own position
+    }
     if (is_tail_corner(ix, q)) {
         kmer_range_tail(ix, q, lo, hi, cb);
         return false;
     }
-    uint64_t lo0 = 0, hi0 = ix.n;
+    uint64_t lo0 = 0, hi0 = ix.n_sa;
     uint32_t p;
     if (prefix_index(q, ix.k, ix.d, p)) {
         lo0 = ix.ptab[p];

@@ -295,12 +295,13 @@ def search_duplications(strands_files: Sequence[str], settings: RunSettings, dev
     """`search_duplications()` of src/bin/asgart.rs:731-822: prepare_data, the step chain with the
     HIP search step first, then the RunResult.  Raises AsgartError without a GPU (no CPU fallback)."""
     from . import Index, SearchDuplications, Strand
-    from .prep import prepare_records, read_records
+    from .prep import prepare_records, read_records, validate_trim
 
     records = [rec for f in strands_files for rec in read_records(f)]
     pr = prepare_records(records, settings.skip_masked)
     strand = Strand(", ".join(strands_files), pr.data, pr.map)  # file_names, :437
-    with Index(strand.data, None, device) as index:
-        families = SearchDuplications(pr.chunks, settings.trim, settings, index=index).run([], strand)
+    trim = validate_trim(settings.trim, len(pr.data))           # prepare_data's checks, :432-463
+    with Index(strand.data, None, device, trim=trim) as index:
+        families = SearchDuplications(pr.chunks, trim, settings, index=index).run([], strand)
         families = post_process(families, strand, index, compute_score)
     return run_result(families, strand, settings)

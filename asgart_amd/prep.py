@@ -75,6 +75,20 @@ def prepare_records(records: Sequence[Tuple[str, np.ndarray]], skip_masked: bool
     return Prepared(np.concatenate(parts), chunks, starts)
 
 
+def validate_trim(trim, strand_len: int):
+    """The --trim checks of prepare_data, reference src/bin/asgart.rs:432-463 (`strand_len` counts the
+    final '$'): a stop past the data is clamped to the '$', an empty or out-of-range window disables
+    trimming.  -> (start, stop) or None."""
+    if trim is None:
+        return None
+    shift, stop = int(trim[0]), int(trim[1])
+    if stop >= strand_len:
+        stop = strand_len - 1
+    if stop <= shift or shift >= strand_len:
+        return None
+    return (shift, stop)
+
+
 def read_records(path: str) -> Iterable[Tuple[str, np.ndarray]]:
     """Minimal FASTA reader (id = header up to the first whitespace), standing in
     for bio::io::fasta::Reader at reference src/bin/asgart.rs:282-288."""

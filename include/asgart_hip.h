@@ -100,6 +100,19 @@ int32_t asgart_index_create(const uint8_t *T, int64_t n, const int64_t *SA, int6
                             int32_t device, asgart_index **out);
 void asgart_index_destroy(asgart_index *idx);
 
+/* `--trim START END` (reference src/bin/asgart.rs:142-148, validation :432-463, README "trimming"):
+ * the suffix array covers only data[start..end] + '$' -- its entries shifted by +start -- and the WHOLE
+ * input is then searched against it (Searcher::new(&strand.data, &suffix_array, 0), :151-155).  SA: that
+ * shifted array with sa_len == end - start + 1 entries (what the reference's r_divsufsort + shift
+ * produces), or NULL to build it on the GPU.  Requires 0 <= start < end <= n - 1 (the trim the
+ * reference's prepare_data lets through).  The array is sorted by the sub-strand's suffixes but
+ * compared through the full text, so the suffixes ending within k bases of `end` are out of place; the
+ * library replays the reference's two bisections (libdivsufsort sa_search for the 8-mer cache,
+ * superslice equal_range_by per probe) wherever one of them is in range -- results equal the oracle's. */
+int32_t asgart_index_create_trim(const uint8_t *T, int64_t n, const int64_t *SA, int64_t sa_len,
+                                 int64_t trim_start, int64_t trim_end, int32_t device,
+                                 asgart_index **out);
+
 /* Tuning and test options of an index.  Production code never needs this call: the defaults
  * are the tuned ones.  Each option can also be preset through the environment variable
  * ASGART_<NAME> (upper case), which is read ONCE, inside asgart_index_create -- the search path

@@ -205,6 +205,15 @@ class Index:
             raise MemoryError("oracle_searcher_new")
         return cls(text, sa, h)
 
+    @classmethod
+    def build_trim(cls, text, start: int, end: int) -> "Index":
+        """`--trim START END` (src/bin/asgart.rs:142-148): the suffix array of data[start..end] + '$',
+        every entry shifted by +start; the Searcher is built over it against the FULL text."""
+        text = as_text(text)
+        sub = np.concatenate([text[start:end], np.frombuffer(b"$", dtype=np.uint8)])
+        sa = divsufsort64(sub) + np.int64(start)
+        return cls.build(text, sa)
+
     def close(self):
         if self.searcher:
             lib().oracle_searcher_free(self.searcher)

@@ -38,31 +38,80 @@ struct oracle_searcher {
  * suffix that ends before P does compares smaller.  Returns the count, *left =
  * first slot (for count==0: the insertion point).
  * ------------------------------------------------------------------------ */
-static int cmp_suffix_prefix(const uint8_t *T, int64_t n, int64_t x, const uint8_t *P, int64_t m) {
-    int64_t avail = n - x;
-    int64_t len = avail < m ? avail : m;
-    int c = memcmp(T + x, P, (size_t)len);
-    if (c != 0) return c < 0 ? -1 : 1;
-    return avail < m ? -1 : 0;
+/* `sa_searchb64` of the delehef fork of libdivsufsort (declared at src/divsufsort.rs:22-32, called
+ * at src/searcher.rs:118-128 with init_left = 0, init_right = sa.len()).  The fork's source is absent
+ * from /root/reference (empty submodule), so this restates the PUBLISHED upstream routine it extends,
+ * libdivsufsort 2.0.x lib/utils.c `sa_search` (+ its `_compare`), started on [init_left, init_right)
+ * instead of [0, SAsize): a halving bisection that, once a matching suffix is found, bisects the left
+ * and the right part separately, skipping the characters already known to match (`match`).  For a
+ * suffix array that is sorted under the comparator this returns the unique equal range; the probing
+ * order only matters for --trim (src/bin/asgart.rs:142-148), where the array holds the suffixes of
+ * data[start..end]+'$' but is compared through the FULL text, so the few suffixes that end within
+ * 8 bases of `end` are out of place.  That corner is unpinned twice over (fork source absent, no
+ * reference vectors). */
+static int published_compare(const uint8_t *T, int64_t Tsize, const uint8_t *P, int64_t Psize,
+                             int64_t suf, int64_t *match) {
+    int64_t i, j;
+    int r = 0;
+    for (i = suf + *match, j = *match; (i < Tsize) && (j < Psize) && ((r = (int)T[i] - (int)P[j]) == 0); ++i, ++j) {
+    }
+    *match = j;
+    return (r == 0) ? -(j != Psize) : r;
 }
 
-static int64_t sa_searchb(const uint8_t *T, int64_t n, const uint8_t *P, int64_t m,
+#define MIN_(a, b) ((a) < (b) ? (a) : (b))
+static int64_t sa_searchb(const uint8_t *T, int64_t Tsize, const uint8_t *P, int64_t Psize,
                           const int64_t *SA, int64_t *left, int64_t init_left,
                           int64_t init_right) {
-    int64_t lo = init_left, hi = init_right;
-    while (lo < hi) { /* first slot with cmp >= 0 */
-        int64_t mid = lo + (hi - lo) / 2;
-        if (cmp_suffix_prefix(T, n, SA[mid], P, m) < 0) lo = mid + 1; else hi = mid;
+    int64_t size, lsize, rsize, half;
+    int64_t match, lmatch, rmatch, llmatch, lrmatch, rlmatch, rrmatch;
+    int64_t i, j, k;
+    int r;
+    *left = -1;
+    if (Tsize == 0 || init_right <= init_left) return 0;
+    for (i = j = k = init_left, lmatch = rmatch = 0, size = init_right - init_left, half = size >> 1; 0 < size;
+         size = half, half >>= 1) {
+        match = MIN_(lmatch, rmatch);
+        r = published_compare(T, Tsize, P, Psize, SA[i + half], &match);
+        if (r < 0) {
+            i += half + 1;
+            half -= (size & 1) ^ 1;
+            lmatch = match;
+        } else if (r > 0) {
+            rmatch = match;
+        } else {
+            lsize = half, j = i, rsize = size - half - 1, k = i + half + 1;
+            /* left part */
+            for (llmatch = lmatch, lrmatch = match, half = lsize >> 1; 0 < lsize; lsize = half, half >>= 1) {
+                lmatch = MIN_(llmatch, lrmatch);
+                r = published_compare(T, Tsize, P, Psize, SA[j + half], &lmatch);
+                if (r < 0) {
+                    j += half + 1;
+                    half -= (lsize & 1) ^ 1;
+                    llmatch = lmatch;
+                } else {
+                    lrmatch = lmatch;
+                }
+            }
+            /* right part */
+            for (rlmatch = match, rrmatch = rmatch, half = rsize >> 1; 0 < rsize; rsize = half, half >>= 1) {
+                rmatch = MIN_(rlmatch, rrmatch);
+                r = published_compare(T, Tsize, P, Psize, SA[k + half], &rmatch);
+                if (r <= 0) {
+                    k += half + 1;
+                    half -= (rsize & 1) ^ 1;
+                    rlmatch = rmatch;
+                } else {
+                    rrmatch = rmatch;
+                }
+            }
+            break;
+        }
     }
-    int64_t first = lo;
-    hi = init_right;
-    while (lo < hi) { /* first slot with cmp > 0 */
-        int64_t mid = lo + (hi - lo) / 2;
-        if (cmp_suffix_prefix(T, n, SA[mid], P, m) <= 0) lo = mid + 1; else hi = mid;
-    }
-    *left = first;
-    return lo - first;
+    *left = (0 < (k - j)) ? j : i;
+    return k - j;
 }
+#undef MIN_
 
 /* Searcher::indexize packs 8 bytes little-endian into a u64 HashMap key
  * (src/searcher.rs:95-97); a dense base-5 index over ALPHABET is equivalent. */

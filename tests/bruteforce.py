@@ -27,6 +27,73 @@ def cache_entry(text: bytes, sa: List[int], p8: bytes) -> Tuple[int, int]:
     return (slots[0], slots[-1] + 1)
 
 
+def _published_compare(T: bytes, P: bytes, suf: int, match: int):
+    """libdivsufsort lib/utils.c `_compare` (published upstream source, restated)."""
+    i, j, r = suf + match, match, 0
+    while i < len(T) and j < len(P):
+        r = T[i] - P[j]
+        if r != 0:
+            break
+        i += 1
+        j += 1
+    return ((-1 if j != len(P) else 0) if r == 0 else r), j
+
+
+def sa_search_published(T: bytes, P: bytes, SA: List[int], init_left: int, init_right: int) -> Tuple[int, int]:
+    """libdivsufsort lib/utils.c `sa_search` started on [init_left, init_right): what the fork's
+    `sa_searchb64` (src/searcher.rs:118-128) is taken to be.  -> (left, count).  Matters only when SA
+    is not sorted under the comparator (--trim: suffixes of the sub-strand compared through the whole
+    text)."""
+    if len(T) == 0 or init_right <= init_left:
+        return (-1, 0)
+    i = j = k = init_left
+    lmatch = rmatch = 0
+    size = init_right - init_left
+    half = size >> 1
+    while 0 < size:
+        match = min(lmatch, rmatch)
+        r, match = _published_compare(T, P, SA[i + half], match)
+        if r < 0:
+            i += half + 1
+            half -= (size & 1) ^ 1
+            lmatch = match
+        elif r > 0:
+            rmatch = match
+        else:
+            lsize, j, rsize, k = half, i, size - half - 1, i + half + 1
+            llmatch, lrmatch, half = lmatch, match, lsize >> 1
+            while 0 < lsize:
+                lmatch = min(llmatch, lrmatch)
+                r, lmatch = _published_compare(T, P, SA[j + half], lmatch)
+                if r < 0:
+                    j += half + 1
+                    half -= (lsize & 1) ^ 1
+                    llmatch = lmatch
+                else:
+                    lrmatch = lmatch
+                lsize, half = half, half >> 1
+            rlmatch, rrmatch, half = match, rmatch, rsize >> 1
+            while 0 < rsize:
+                rmatch = min(rlmatch, rrmatch)
+                r, rmatch = _published_compare(T, P, SA[k + half], rmatch)
+                if r <= 0:
+                    k += half + 1
+                    half -= (rsize & 1) ^ 1
+                    rlmatch = rmatch
+                else:
+                    rrmatch = rmatch
+                rsize, half = half, half >> 1
+            break
+        size, half = half, half >> 1
+    return ((j if 0 < k - j else i), k - j)
+
+
+def trim_suffix_array(text: bytes, start: int, end: int) -> List[int]:
+    """src/bin/asgart.rs:142-148: SA of data[start..end] + '$', shifted by +start."""
+    sub = text[start:end] + b"$"
+    return [x + start for x in suffix_array(sub)]
+
+
 def _cmp(text: bytes, x: int, pattern: bytes) -> int:
     """comparator of src/searcher.rs:164-170: -1 Less, 0 Equal, 1 Greater"""
     if x + len(pattern) > len(text):
@@ -57,7 +124,11 @@ def equal_range_superslice(text: bytes, sl: List[int], pattern: bytes) -> Tuple[
 def search(text: bytes, sa: List[int], pattern: bytes, exact_bisection: bool = True) -> List[int]:
     """Searcher::search -> hit starts in SA order."""
     assert all(c in ALPHABET for c in pattern[:8]), "reference panics here"
-    lo, hi = cache_entry(text, sa, pattern[:8])
+    if len(sa) != len(text):   # --trim: the cache entries are what the bisection of sa_searchb64 finds
+        left, count = sa_search_published(text, pattern[:8], sa, 0, len(sa))
+        lo, hi = left, left + count
+    else:
+        lo, hi = cache_entry(text, sa, pattern[:8])
     if exact_bisection:
         s, e = equal_range_superslice(text, sa[lo:hi], pattern)
         return sa[lo + s:lo + max(s, e)]

@@ -42,6 +42,12 @@ def cases():
     yield "H_n_inside", U[:8000] + X[:600] + b"N" * 90 + X[690:] + U[9500:], dict()
     # cardinality skip (automaton.rs:115-117)
     yield "I_cardinality", (U[:2000] + X) * 4 + U[3600:5000], dict(max_card=2)
+    # --trim START END (src/bin/asgart.rs:142-148): the whole input is searched against the suffixes of
+    # data[start..end] only.  F has copies of X at 2003, 5000 and 8000:
+    yield "T_trim_right_copy", U[:5000] + X + U[6500:8000] + X + U[9500:], dict(trim=(7500, 10000))
+    yield "T_trim_middle_copy", U[:5000] + X + U[6500:8000] + X + U[9500:], dict(trim=(4000, 7000))
+    yield "T_trim_cuts_a_copy", U[:5000] + X + U[6500:8000] + X + U[9500:], dict(trim=(8500, 20000))
+    yield "T_trim_rc", U[:8000] + B.revcomp(X) + U[9500:], dict(trim=(7000, 11000), reverse=True, complement=True)
 
 
 def main():
@@ -49,7 +55,10 @@ def main():
            "cases": []}
     for name, text, kw in cases():
         strand = text + b"$"
-        sa = B.suffix_array(strand)
+        trim = kw.get("trim")
+        if trim is not None:   # the checks of prepare_data, src/bin/asgart.rs:432-463
+            trim = (trim[0], min(trim[1], len(strand) - 1))
+        sa = B.trim_suffix_array(strand, *trim) if trim else B.suffix_array(strand)
         chunks = B.find_chunks(text)
         fams = B.run(strand, sa, chunks, k=20, gap=100, min_len=kw.get("min_len", 1000),
                      max_card=kw.get("max_card", 500), reverse=kw.get("reverse", False),
@@ -58,7 +67,8 @@ def main():
             "name": name, "text": text.decode(), "chunks": chunks,
             "settings": {"k": 20, "gap": 100, "min_length": kw.get("min_len", 1000),
                          "max_cardinality": kw.get("max_card", 500),
-                         "reverse": kw.get("reverse", False), "complement": kw.get("complement", False)},
+                         "reverse": kw.get("reverse", False), "complement": kw.get("complement", False),
+                         "trim": list(trim) if trim else None},
             "families": [[list(sd) for sd in fam] for fam in fams],
         })
         print(name, fams)

@@ -162,12 +162,13 @@ def test_golden_kat_on_gpu(hiplib):
     for case in kat["cases"]:
         s = case["settings"]
         text = case["text"].encode() + b"$"
-        sa = oracle.divsufsort64(text)
+        trim = tuple(s["trim"]) if s.get("trim") else None    # --trim cases: sub-range array built on the GPU
+        sa = None if trim else oracle.divsufsort64(text)
         st = asgart_amd.RunSettings.from_cli(k=s["k"], gap=s["gap"], min_length=s["min_length"],
                                              max_cardinality=s["max_cardinality"],
                                              reverse=s["reverse"], complement=s["complement"])
         strand = asgart_amd.Strand("kat", np.frombuffer(text, dtype=np.uint8))
-        step = asgart_amd.SearchDuplications([tuple(c) for c in case["chunks"]], None, st, suffix_array=sa)
+        step = asgart_amd.SearchDuplications([tuple(c) for c in case["chunks"]], trim, st, suffix_array=sa)
         got = [[sd.as_tuple() for sd in fam] for fam in step.run([], strand)]
         assert got == [[tuple(sd) for sd in fam] for fam in case["families"]], case["name"]
 
@@ -488,6 +489,71 @@ def test_cfg5_shaped_two_files_wide(hiplib, monkeypatch):
             eoffs, esds = oidx.run_raw(pr.chunks, oracle.make_settings(reverse=rc, complement=rc), threads=16)
             assert np.array_equal(offs, eoffs) and np.array_equal(sds, esds), rc
             assert len(sds) > 100
+
+
+@pytest.mark.parametrize("build_on_gpu", [False, True])
+@pytest.mark.parametrize("window", ["inside", "to_end", "cuts_copy", "tiny_tail"])
+def test_trim_matches_oracle(hiplib, window, build_on_gpu):
+    """`--trim START END` (reference src/bin/asgart.rs:142-148): suffix array of data[start..end]+'$' shifted by
+    +start, whole input searched against it.  Cache entries, searches, per-probe hits and families against the
+    oracle, with the sub-range array handed over or built on the GPU, in all four orientations."""
+    pr, cli = _battery_case("long_sds")
+    n = len(pr.data)
+    rng = np.random.default_rng({"inside": 1, "to_end": 2, "cuts_copy": 3, "tiny_tail": 4}[window])
+    a = int(rng.integers(0, n // 3))
+    b = {"inside": int(rng.integers(n // 2, n - 100)), "to_end": n + 10, "cuts_copy": int(rng.integers(n // 2, n - 100)) | 1,
+         "tiny_tail": n - 3}[window]
+    trim = prep.validate_trim((a, b), n)
+    oidx = oracle.Index.build_trim(pr.data, *trim)
+    with asgart_amd.Index(pr.data, None if build_on_gpu else oidx.sa, trim=trim) as idx:
+        assert np.array_equal(idx.sa_read(0, len(oidx.sa)), oidx.sa)
+        s = asgart_amd.Searcher(idx)
+        text = pr.data
+        pats8 = [bytes(text[p:p + 8]) for p in rng.integers(0, n - 30, size=1500)]
+        pats8 += [bytes(text[p:p + 8]) for p in range(max(0, trim[1] - 40), min(n - 9, trim[1] + 10))]
+        pats8 = [p for p in pats8 if b"$" not in p]
+        for p, (lo, hi) in zip(pats8, s.cache(pats8)):
+            elo, ehi = oidx.cache_get(p)
+            assert hi - lo == ehi - elo and (hi == lo or lo == elo), p
+        pats = [bytes(text[p:p + 20]) for p in rng.integers(0, n - 30, size=1500)]
+        pats += [bytes(text[p:p + 20]) for p in range(max(0, trim[1] - 60), min(n - 21, trim[1] + 10))]
+        pats = [p for p in pats if b"$" not in p]
+        for p, (lo, hi) in zip(pats, s.search_ranges(pats)):
+            exp, (elo, ehi) = oidx.search(p)
+            assert hi - lo == len(exp), p
+            if len(exp):
+                assert np.array_equal(idx.sa_read(lo, hi).astype(np.uint64), exp)
+        for reverse, complement in MODES:
+            st = asgart_amd.RunSettings.from_cli(reverse=reverse, complement=complement, **cli)
+            offs, sds = idx.search_duplications_raw(pr.chunks, st)
+            eoffs, esds = oidx.run_raw(pr.chunks, oracle.make_settings(reverse=reverse, complement=complement, **cli), threads=4)
+            assert np.array_equal(offs, eoffs) and np.array_equal(sds, esds), (window, reverse, complement)
+        with pytest.raises(asgart_amd.AsgartError):
+            idx.check_sa()
+    with pytest.raises(asgart_amd.AsgartError):
+        asgart_amd.Index(pr.data, None, trim=(100, n + 5))      # end past the '$': not a validated trim
+
+
+def test_golden_trim_kats_on_gpu(hiplib):
+    """The --trim known-answer cases of tests/golden/kat.json through the HIP path."""
+    import json
+    import os
+    kat = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kat.json")))
+    seen = 0
+    for case in kat["cases"]:
+        s = case["settings"]
+        if not s.get("trim"):
+            continue
+        seen += 1
+        text = np.frombuffer(case["text"].encode() + b"$", dtype=np.uint8)
+        st = asgart_amd.RunSettings.from_cli(k=s["k"], gap=s["gap"], min_length=s["min_length"],
+                                             max_cardinality=s["max_cardinality"], reverse=s["reverse"],
+                                             complement=s["complement"])
+        with asgart_amd.Index(text, None, trim=tuple(s["trim"])) as idx:
+            offs, sds = idx.search_duplications_raw([tuple(c) for c in case["chunks"]], st)
+        got = [[tuple(int(v) for v in sds[j]) for j in range(int(offs[f]), int(offs[f + 1]))] for f in range(len(offs) - 1)]
+        assert got == [[tuple(sd) for sd in fam] for fam in case["families"]], case["name"]
+    assert seen >= 4
 
 
 def test_cfg3_full_skip_masked_digest(hiplib):

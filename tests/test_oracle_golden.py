@@ -20,8 +20,11 @@ def test_kat_families(case):
     s = case["settings"]
     chunks = [tuple(c) for c in case["chunks"]]
     assert oracle.find_chunks(text) == chunks
-    idx = oracle.Index.build(text + b"$")
-    assert oracle.sa_check(idx.text, idx.sa) == 0
+    if s.get("trim"):
+        idx = oracle.Index.build_trim(text + b"$", *s["trim"])   # --trim START END, src/bin/asgart.rs:142-148
+    else:
+        idx = oracle.Index.build(text + b"$")
+        assert oracle.sa_check(idx.text, idx.sa) == 0
     st = oracle.make_settings(k=s["k"], gap=s["gap"], min_length=s["min_length"],
                               max_cardinality=s["max_cardinality"], reverse=s["reverse"],
                               complement=s["complement"])

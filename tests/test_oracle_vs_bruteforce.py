@@ -75,6 +75,54 @@ def test_run_matches_bruteforce(seed, mode):
     assert idx.run(chunks, st) == exp
 
 
+@pytest.mark.parametrize("seed", range(16))
+def test_trim_matches_bruteforce(seed):
+    """`--trim START END` (src/bin/asgart.rs:142-148): the suffix array covers data[start..end]+'$' only and
+    is compared through the whole text, so the suffixes that end within 8 (cache) / k (search) bases of `end`
+    are out of place for the bisections.  Both restatements follow the same published routines
+    (libdivsufsort `sa_search`, superslice `equal_range_by`) step by step; random windows, including windows
+    that end inside a planted copy or at the end of the text."""
+    rng = random.Random(4000 + seed)
+    n = rng.randint(900, 2600)
+    text = _rand_text(rng, n)
+    strand = text + b"$"
+    chunks = B.find_chunks(text)
+    a = rng.randrange(0, n - 50)
+    b = rng.choice([n, n + 5, rng.randrange(a + 30, n + 1)])
+    from asgart_amd.prep import validate_trim
+    trim = validate_trim((a, b), len(strand))
+    assert trim is not None and trim[1] <= len(strand) - 1
+    k = rng.choice([10, 12, 20])
+    mode = rng.choice([(False, False), (True, True), (True, False), (False, True)])
+    sa = B.trim_suffix_array(strand, *trim)
+    idx = oracle.Index.build_trim(strand, *trim)
+    assert list(idx.sa) == sa and len(sa) == trim[1] - trim[0] + 1
+    for _ in range(60):   # cache entries and searches, the two bisections that see the misplaced suffixes
+        p = rng.randrange(0, len(text) - 21)
+        pat = text[p:p + k]
+        if b"N" in pat:
+            continue
+        left, count = B.sa_search_published(strand, pat[:8], sa, 0, len(sa))
+        lo, hi = idx.cache_get(pat[:8])
+        assert (hi - lo == count) and (count == 0 or lo == left)
+        got, _ = idx.search(pat)
+        assert list(got) == B.search(strand, sa, pat)
+    exp = B.run(strand, sa, chunks, k=k, gap=50, min_len=100, max_card=500, reverse=mode[0], complement=mode[1])
+    st = oracle.make_settings(k=k, gap=50, min_length=100, max_cardinality=500, reverse=mode[0], complement=mode[1])
+    assert idx.run(chunks, st) == exp
+
+
+def test_trim_validation():
+    from asgart_amd.prep import validate_trim
+    assert validate_trim(None, 100) is None
+    assert validate_trim((10, 50), 100) == (10, 50)
+    assert validate_trim((10, 100), 100) == (10, 99)     # stop >= len: clamped to the '$' (asgart.rs:437-446)
+    assert validate_trim((10, 500), 100) == (10, 99)
+    assert validate_trim((50, 50), 100) is None          # stop <= shift (:448-453)
+    assert validate_trim((60, 50), 100) is None
+    assert validate_trim((100, 200), 100) is None        # clamped stop 99 <= shift (:448)
+
+
 def test_tail_corner_bisection_is_emulated():
     """Text whose last bases share an 8-mer with a probe: the comparator of
     src/searcher.rs:164-170 calls the short tail suffixes Less.  Both restatements follow the same
