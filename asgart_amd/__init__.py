@@ -22,7 +22,7 @@ import numpy as np
 
 __all__ = [
     "AsgartError", "RunSettings", "ProtoSD", "Strand", "Index", "Searcher", "SearchDuplications",
-    "load_library", "library_path", "ABI_SYMBOLS", "sa_build64",
+    "load_library", "library_path", "ABI_SYMBOLS", "sa_build64", "search_duplications_multi",
 ]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -33,7 +33,8 @@ ABI_SYMBOLS = (
     "asgart_families_copy", "asgart_families_free", "asgart_searcher_cache_get",
     "asgart_searcher_search", "asgart_sa_read", "asgart_probe_hits", "asgart_get_stats",
     "asgart_last_error", "asgart_version", "asgart_compute_scores", "asgart_index_set_option",
-    "asgart_index_check_sa", "asgart_index_create_trim",
+    "asgart_index_check_sa", "asgart_index_create_trim", "asgart_index_clone",
+    "asgart_search_duplications_multi",
 )
 
 
@@ -93,6 +94,11 @@ def load_library() -> C.CDLL:
     L.asgart_index_create_trim.argtypes = [vp, C.c_int64, vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32,
                                            C.POINTER(vp)]
     L.asgart_index_create_trim.restype = C.c_int32
+    L.asgart_index_clone.argtypes = [vp, C.c_int32, C.POINTER(vp)]
+    L.asgart_index_clone.restype = C.c_int32
+    L.asgart_search_duplications_multi.argtypes = [C.POINTER(vp), C.c_int32, vp, C.c_int64, C.POINTER(_Settings), vp,
+                                                   C.POINTER(vp)]
+    L.asgart_search_duplications_multi.restype = C.c_int32
     L.asgart_index_destroy.argtypes = [vp]
     L.asgart_index_destroy.restype = None
     L.asgart_index_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
@@ -253,6 +259,15 @@ class Index:
     def __exit__(self, *exc):
         self.close()
 
+    def clone(self, device: int = 0) -> "Index":
+        """A replica of this index on `device` (text + suffix array copied device to device)."""
+        other = Index.__new__(Index)
+        other.text = self.text
+        other.trim = self.trim
+        other._h = C.c_void_p()
+        _check(load_library().asgart_index_clone(self._h, device, C.byref(other._h)))
+        return other
+
     def set_option(self, name: str, value: int):
         """Tuning / test option (include/asgart_hip.h: asgart_index_set_option)."""
         _check(load_library().asgart_index_set_option(self._h, name.encode(), int(value)))
@@ -325,6 +340,28 @@ class Index:
         _check(L.asgart_probe_hits(self._h, _ptr(ch), len(chunks), C.byref(st), _ptr(status),
                                    _ptr(offs), _ptr(hits), C.byref(nh)))
         return status, offs, hits
+
+
+def search_duplications_multi(indices: Sequence[Index], chunks: Sequence[Tuple[int, int]],
+                              settings: RunSettings) -> Tuple[np.ndarray, np.ndarray]:
+    """asgart_search_duplications_multi: one shard per index replica (one per GPU), one host thread each,
+    results concatenated in shard order -> (fam_offsets, sds) like Index.search_duplications_raw."""
+    L = load_library()
+    ch = np.array(chunks, dtype=np.uint64).reshape(-1)
+    st = settings._c()
+    arr = (C.c_void_p * len(indices))(*[i._h for i in indices])
+    h = C.c_void_p()
+    _check(L.asgart_search_duplications_multi(arr, len(indices), _ptr(ch), len(chunks), C.byref(st), None,
+                                              C.byref(h)))
+    try:
+        nf, ns = C.c_uint64(), C.c_uint64()
+        L.asgart_families_counts(h, C.byref(nf), C.byref(ns))
+        offs = np.zeros(nf.value + 1, dtype=np.uint64)
+        sds = np.zeros((ns.value, 4), dtype=np.uint64)
+        L.asgart_families_copy(h, _ptr(offs), _ptr(sds))
+    finally:
+        L.asgart_families_free(h)
+    return offs, sds
 
 
 def sa_build64(text) -> np.ndarray:

@@ -804,6 +804,60 @@ int32_t asgart_index_create_trim(const uint8_t *T, int64_t n, const int64_t *SA,
     return index_create_impl(T, n, SA, sa_len, true, trim_start, trim_end, device, out);
 }
 
+int32_t asgart_index_clone(asgart_index *src, int32_t device, asgart_index **out) {
+    if (!out) {
+        set_error("asgart_index_clone: out is NULL");
+        return ASGART_E_ARG;
+    }
+    *out = nullptr;
+    if (!src) {
+        set_error("asgart_index_clone: source index is NULL");
+        return ASGART_E_ARG;
+    }
+    RC_TRY(check_device(device));
+    asgart_index *idx = new (std::nothrow) asgart_index();
+    if (!idx) {
+        set_error("out of host memory");
+        return ASGART_E_OOM;
+    }
+    idx->device = device;
+    idx->n = src->n;
+    idx->n_sa = src->n_sa;
+    idx->trimmed = src->trimmed;
+    idx->trim_start = src->trim_start;
+    idx->trim_end = src->trim_end;
+    idx->wide = src->wide;
+    idx->opt = src->opt;
+    idx->h_tail = src->h_tail;
+    for (auto &cx : idx->ctx) memset(&cx.stats, 0, sizeof(cx.stats));
+    src->acquire_all();  // the source's buffers must not change under the copy
+    int32_t rc = [&]() -> int32_t {
+        HIP_TRY(hipSetDevice(device));
+        for (auto &cx : idx->ctx) {
+            for (hipStream_t *st : {&cx.stream, &cx.stream2, &cx.stream3, &cx.stream4, &cx.stream5, &cx.stream6})
+                HIP_TRY(hipStreamCreateWithFlags(st, hipStreamNonBlocking));
+            for (auto &e : cx.ev) HIP_TRY(hipEventCreate(&e));
+        }
+        const size_t slot = idx->wide ? 8 : 4;
+        const size_t text_bytes = (size_t)idx->n + 64, sa_bytes = ((size_t)idx->n_sa + 16) * slot;
+        HIP_TRY(hipMalloc((void **)&idx->d_text, text_bytes));
+        HIP_TRY(hipMalloc(&idx->d_sa, sa_bytes));
+        // device-to-device over xGMI when the devices differ (peer copy), a plain copy otherwise
+        hipStream_t s = idx->ctx[0].stream;
+        HIP_TRY(hipMemcpyPeerAsync(idx->d_text, device, src->d_text, src->device, text_bytes, s));
+        HIP_TRY(hipMemcpyPeerAsync(idx->d_sa, device, src->d_sa, src->device, sa_bytes, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        return 0;
+    }();
+    src->release_all();
+    if (rc != 0) {
+        asgart_index_destroy(idx);
+        return rc;
+    }
+    *out = idx;
+    return 0;
+}
+
 int32_t asgart_index_set_option(asgart_index *idx, const char *name, int64_t value) {
     if (!idx) {
         set_error("index is NULL");

@@ -8,6 +8,8 @@
 
 #include <algorithm>
 #include <chrono>
+#include <string>
+#include <thread>
 
 namespace asgart {
 
@@ -695,6 +697,62 @@ int32_t asgart_search_duplications(asgart_index *idx, const uint64_t *chunks, in
                                                     settings->min_duplication_length) * step;
     }
     return rc;
+}
+
+int32_t asgart_search_duplications_multi(asgart_index *const *indices, int32_t n_devices,
+                                         const uint64_t *chunks, int64_t n_chunks,
+                                         const asgart_settings *settings, volatile uint64_t *progress,
+                                         asgart_families **out) {
+    if (!out) {
+        set_error("out is NULL");
+        return ASGART_E_ARG;
+    }
+    *out = nullptr;
+    if (!indices || n_devices < 1 || n_devices > 64) {
+        set_error("bad argument: %d devices", n_devices);
+        return ASGART_E_ARG;
+    }
+    for (int32_t r = 0; r < n_devices; ++r)
+        if (!indices[r] || indices[r]->n != indices[0]->n || indices[r]->n_sa != indices[0]->n_sa) {
+            set_error("index %d is NULL or not a replica of index 0", r);
+            return ASGART_E_ARG;
+        }
+    // one host thread per device; shard r = the segments that start in the r-th slice of the global
+    // probe sequence (no exchange between shards); results concatenated in shard order
+    std::vector<asgart_families> parts((size_t)n_devices);
+    std::vector<int32_t> rcs((size_t)n_devices, 0);
+    std::vector<std::string> errs((size_t)n_devices);
+    std::vector<std::thread> workers;
+    for (int32_t r = 0; r < n_devices; ++r)
+        workers.emplace_back([&, r]() {
+            rcs[r] = run_search(indices[r], chunks, n_chunks, settings, r, n_devices, false, &parts[r], nullptr,
+                                nullptr, nullptr);
+            if (rcs[r] != 0) errs[r] = asgart_last_error();  // the message is thread-local
+        });
+    for (auto &t : workers) t.join();
+    for (int32_t r = 0; r < n_devices; ++r)
+        if (rcs[r] != 0) {
+            set_error("shard %d of %d: %s", r, n_devices, errs[r].c_str());
+            return rcs[r];
+        }
+    asgart_families *f = new (std::nothrow) asgart_families();
+    if (!f) {
+        set_error("out of host memory");
+        return ASGART_E_OOM;
+    }
+    f->fam_offsets.assign(1, 0);
+    for (int32_t r = 0; r < n_devices; ++r) {
+        const uint64_t base = f->sds.size();
+        f->sds.insert(f->sds.end(), parts[r].sds.begin(), parts[r].sds.end());
+        for (size_t j = 1; j < parts[r].fam_offsets.size(); ++j) f->fam_offsets.push_back(base + parts[r].fam_offsets[j]);
+    }
+    if (progress && settings) {
+        const uint64_t k = settings->probe_size, step = k / 2;
+        for (int64_t c = 0; c < n_chunks; ++c)
+            progress[c] = (uint64_t)probes_in_chunk(chunks[2 * c + 1], k, step, settings->min_duplication_length) * step;
+    }
+    *out = f;
+    return 0;
 }
 
 void asgart_families_counts(const asgart_families *f, uint64_t *n_families, uint64_t *n_sds) {

@@ -100,6 +100,12 @@ int32_t asgart_index_create(const uint8_t *T, int64_t n, const int64_t *SA, int6
                             int32_t device, asgart_index **out);
 void asgart_index_destroy(asgart_index *idx);
 
+/* Replicates an index on another device (text + suffix array copied device to device -- over xGMI
+ * between two GPUs -- instead of sorting the suffixes once per GPU; the probe_size-specific tables are
+ * rebuilt there on first use).  Replaces nothing in the reference (it has one address space); it is the
+ * "SA + text replicated in each HBM" step of the multi-GPU design. */
+int32_t asgart_index_clone(asgart_index *src, int32_t device, asgart_index **out);
+
 /* `--trim START END` (reference src/bin/asgart.rs:142-148, validation :432-463, README "trimming"):
  * the suffix array covers only data[start..end] + '$' -- its entries shifted by +start -- and the WHOLE
  * input is then searched against it (Searcher::new(&strand.data, &suffix_array, 0), :151-155).  SA: that
@@ -140,8 +146,11 @@ int32_t asgart_index_prepare(asgart_index *idx, uint64_t probe_size);
  * fold (reference src/bin/asgart.rs:201-253): for every chunk (start,len) runs
  * automaton::search_duplications (src/automaton.rs:57-204) on the prepared
  * needle and returns the families in (chunk, discovery) order.
- * chunks: n_chunks pairs (start, len).  progress: nullable, n_chunks entries,
- * best-effort (reference src/automaton.rs:98). */
+ * chunks: n_chunks pairs (start, len).  progress: nullable, n_chunks entries; the reference stores
+ * the needle offset of every probe as it goes (src/automaton.rs:98, Relaxed) for a progress bar that
+ * polls every 500 ms (src/bin/asgart.rs:160-197).  Here all chunks advance together through a few
+ * device-wide phases, so the entries are written once, with each chunk's final offset, when the call
+ * completes (a whole-genome call takes a fraction of a second). */
 int32_t asgart_search_duplications(asgart_index *idx, const uint64_t *chunks, int64_t n_chunks,
                                    const asgart_settings *settings, volatile uint64_t *progress,
                                    asgart_families **out);
@@ -153,6 +162,19 @@ int32_t asgart_search_duplications(asgart_index *idx, const uint64_t *chunks, in
 int32_t asgart_search_duplications_shard(asgart_index *idx, const uint64_t *chunks,
                                          int64_t n_chunks, const asgart_settings *settings,
                                          int32_t shard, int32_t n_shards,
+                                         asgart_families **out);
+
+/* Multi-GPU in ONE process: indices[r] is a replica of the same index on device r
+ * (asgart_index_create on every device, or asgart_index_clone from the device that built it).  One host
+ * thread per device runs shard r of n_devices; the per-shard families -- tens of MB -- come back over
+ * each device's own host link and are concatenated in shard order: exactly the result of
+ * asgart_search_duplications on one device.  No device-to-device exchange is needed inside one process
+ * (the host is common); one-process-per-GPU hosts gather the shards' lists with RCCL instead, see
+ * INTEGRATION.md section 4 and asgart_amd/multi.py.  The same index may appear more than once (each call
+ * takes one of its internal contexts), which is how the sharding logic is tested on a single GPU. */
+int32_t asgart_search_duplications_multi(asgart_index *const *indices, int32_t n_devices,
+                                         const uint64_t *chunks, int64_t n_chunks,
+                                         const asgart_settings *settings, volatile uint64_t *progress,
                                          asgart_families **out);
 
 void asgart_families_counts(const asgart_families *f, uint64_t *n_families, uint64_t *n_sds);

@@ -556,6 +556,26 @@ def test_golden_trim_kats_on_gpu(hiplib):
     assert seen >= 4
 
 
+@pytest.mark.parametrize("name", ["long_sds", "dense_repeats", "satellites"])
+def test_multi_device_entry_equals_one_device(hiplib, name):
+    """asgart_search_duplications_multi (one host thread per index replica, shard r of n on replica r, results
+    concatenated) against the single call and the oracle.  On a one-GPU box the replicas are the same index
+    taken several times and clones of it on the same device (asgart_index_clone: device-to-device copy of
+    text + suffix array)."""
+    pr, cli = _battery_case(name)
+    oidx = oracle.Index.build(pr.data)
+    with asgart_amd.Index(pr.data, oidx.sa) as idx, idx.clone(0) as rep:
+        assert np.array_equal(rep.sa_read(0, 64), oidx.sa[:64])
+        for reverse, complement in ((False, False), (True, True)):
+            st = asgart_amd.RunSettings.from_cli(reverse=reverse, complement=complement, **cli)
+            one = idx.search_duplications_raw(pr.chunks, st)
+            exp = oidx.run_raw(pr.chunks, oracle.make_settings(reverse=reverse, complement=complement, **cli), threads=4)
+            assert np.array_equal(one[0], exp[0]) and np.array_equal(one[1], exp[1])
+            for group in ([idx], [idx, rep], [rep, idx, rep], [idx, idx, rep, rep, idx], [rep] * 8):
+                offs, sds = asgart_amd.search_duplications_multi(group, pr.chunks, st)
+                assert np.array_equal(offs, one[0]) and np.array_equal(sds, one[1]), (name, len(group), reverse)
+
+
 def test_cfg3_full_skip_masked_digest(hiplib):
     """BASELINE.json configs[2] as stated: chr1-sized synthetic (249 Mb), direct + RC, --skip-masked."""
     _check_against_oracle_digest("cfg3s")

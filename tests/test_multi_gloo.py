@@ -59,3 +59,53 @@ def test_gather_families_world(world):
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+def _gpu_worker(rank, world, port, q):
+    """The real pair: asgart_search_duplications_shard on the GPU + gather_families (every rank on device 0:
+    one-GPU boxes; the transport is gloo because RCCL refuses two ranks on one device)."""
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    import asgart_amd
+    import oracle
+    from asgart_amd import multi, prep, synth
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    recs = synth.make_genome([300_000, 200_000, 120_000], seed=9, sd_per_mb=50, sd_len=(1000, 8000),
+                             alu_frac=0.05, l1_frac=0.01, sat_per_record=1, sat_copies=(30, 120))
+    pr = prep.prepare_records(recs)
+    ok = True
+    with asgart_amd.Index(pr.data, None, device=0) as idx:
+        for rc in (False, True):
+            st = asgart_amd.RunSettings.from_cli(reverse=rc, complement=rc)
+            offs, sds = idx.search_duplications_raw(pr.chunks, st, shard=rank, n_shards=world)
+            got = multi.gather_families(offs, sds, dist)
+            if rank == 0:
+                full = idx.search_duplications_raw(pr.chunks, st)
+                oidx = oracle.Index.build(pr.data, idx.sa_read(0, len(pr.data)))
+                exp = oidx.run_raw(pr.chunks, oracle.make_settings(reverse=rc, complement=rc), threads=4)
+                ok = ok and np.array_equal(got[0], full[0]) and np.array_equal(got[1], full[1])
+                ok = ok and np.array_equal(got[0], exp[0]) and np.array_equal(got[1], exp[1]) and len(exp[1]) > 0
+            else:
+                assert got is None
+    if rank == 0:
+        q.put(bool(ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_shard_on_gpu_and_gather(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True

@@ -1,2 +1,2 @@
 export TMPDIR=/tmp
-python -m pytest tests -m gpu -x -q 2>&1 | tail -5
+python -m pytest tests -m gpu -x -q -k "multi or gather" 2>&1 | tail -15
