@@ -82,6 +82,26 @@ __device__ inline bool keep_hit(uint64_t x, uint64_t i, uint64_t s, uint64_t L, 
     return x != i && x >= s + L - i;
 }
 
+// Workgroup barrier for data exchanged through LDS only.  __syncthreads() also waits for the
+// wave's outstanding GLOBAL stores (vmcnt(0)): one record written to HBM would stall every wave
+// of the workgroup for a memory round trip at the next barrier.  The extension kernels never
+// read back what they store to global memory, so their per-probe barriers only drain LDS traffic.
+__device__ inline void lds_barrier() { __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Wave-uniform values the compiler cannot prove uniform (read from LDS, or a lane of a vector):
+// forcing them into scalar registers keeps the per-probe bookkeeping and branches on the scalar
+// unit instead of exec-masked vector code and LDS permutes.
+__device__ inline uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ inline unsigned long long uni(unsigned long long v) {
+    return ((unsigned long long)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v);
+}
+__device__ inline uint32_t lane_of(uint32_t v, uint32_t l) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l);
+}
+__device__ inline unsigned long long lane_of(unsigned long long v, uint32_t l) {
+    return ((unsigned long long)lane_of((uint32_t)(v >> 32), l) << 32) | lane_of((uint32_t)v, l);
+}
+
 // ---------------------------------------------------------------- K1 ---------
 // Probe search: one thread per probe, one workgroup per 256 consecutive probes.
 //
@@ -252,7 +272,10 @@ __global__ __launch_bounds__(kProbeBlock) void probe_count_kernel(IndexView<Slot
     }
 }
 
-// one wave per large interval: coalesced count of the kept hits with early exit
+// Large intervals, one wave per 64 of them: the per-probe set-up (work-list entry, chunk, interval) is a
+// chain of dependent global loads, so the 64 lanes each set up one probe at the same time; the wave then
+// counts the intervals one after the other -- 256 suffix-array entries per round trip, early exit at
+// max_cardinality + 1 -- with the first round of the NEXT interval already in flight.
 template <class SlotT, bool COUNT>
 __global__ __launch_bounds__(256) void big_count_kernel(IndexView<SlotT> ix, RunParams rp,
                                                         const SlotT *__restrict__ p_lo,
@@ -260,36 +283,71 @@ __global__ __launch_bounds__(256) void big_count_kernel(IndexView<SlotT> ix, Run
                                                         uint32_t *__restrict__ p_filt,
                                                         const uint32_t *__restrict__ big_list,
                                                         unsigned long long *__restrict__ ctr) {
-    const int lane = threadIdx.x & 63;
+    const uint32_t lane = threadIdx.x & 63u;
     const uint64_t n_big = ctr[CT_BIG];
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     unsigned long long bytes = 0;
-    for (uint64_t e = wave; e < n_big; e += n_waves) {
-        const uint32_t g = big_list[e];
-        const int c = chunk_of(rp.ch, g);
-        const uint64_t s = rp.ch.start[c], L = rp.ch.len[c];
-        const uint64_t i = (uint64_t)(g - rp.ch.pbase[c] + 1) * (uint64_t)rp.step;
-        const uint64_t lo = p_lo[g], hi = lo + p_raw[g];
-        bytes += 4 + sizeof(SlotT) + 4 + 4;  // list entry, interval, final count
-        uint64_t cnt = 0;
-        // four 64-entry slices per round trip (the early exit makes the rounds dependent)
-        for (uint64_t base = lo; base < hi && cnt <= rp.C; base += 256) {
-            SlotT x[4];
+    for (uint64_t e0 = wave * 64u; e0 < n_big; e0 += n_waves * 64u) {
+        const uint32_t np = (uint32_t)min((uint64_t)64, n_big - e0);
+        // lane l sets up probe e0 + l
+        uint32_t g = 0;
+        unsigned long long s = 0, L = 0, i = 0, lo = 0, hi = 0;
+        if (lane < np) {
+            g = big_list[e0 + lane];
+            const int c = chunk_of(rp.ch, g);
+            s = rp.ch.start[c];
+            L = rp.ch.len[c];
+            i = (unsigned long long)(g - rp.ch.pbase[c] + 1) * (unsigned long long)rp.step;
+            lo = p_lo[g];
+            hi = lo + p_raw[g];
+        }
+        bytes += (unsigned long long)np * (4 + sizeof(SlotT) + 4 + 4);  // list entry, interval, final count
+        uint32_t my_cnt = 0;
+        // first round of probe 0
+        SlotT xn[4];
+        {
+            const unsigned long long l0 = lane_of(lo, 0u), h0 = lane_of(hi, 0u);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const uint64_t r = base + 64u * u + lane;
-                x[u] = r < hi ? ix.sa[r] : (SlotT)0;
-            }
-            bytes += sizeof(SlotT) * (hi - base < 256u ? hi - base : 256u);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint64_t r = base + 64u * u + lane;
-                const bool keep = r < hi && keep_hit(x[u], i, s, L, rp.reverse);
-                cnt += __popcll(__ballot(keep));
+                const unsigned long long r = l0 + 64u * u + lane;
+                xn[u] = r < h0 ? ix.sa[r] : (SlotT)0;
             }
         }
-        if (!COUNT && lane == 0) p_filt[g] = cnt > rp.C ? kSkipCard : (uint32_t)cnt;
+        for (uint32_t p = 0; p < np; ++p) {
+            const unsigned long long lo_p = lane_of(lo, p), hi_p = lane_of(hi, p), i_p = lane_of(i, p),
+                                     s_p = lane_of(s, p), L_p = lane_of(L, p);
+            SlotT x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) x[u] = xn[u];
+            if (p + 1 < np) {  // the next interval's first 256 entries: in flight while this one is counted
+                const unsigned long long l1 = lane_of(lo, p + 1u), h1 = lane_of(hi, p + 1u);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const unsigned long long r = l1 + 64u * u + lane;
+                    xn[u] = r < h1 ? ix.sa[r] : (SlotT)0;
+                }
+            }
+            unsigned long long cnt = 0;
+            for (unsigned long long base = lo_p;;) {
+                bytes += sizeof(SlotT) * (hi_p - base < 256u ? hi_p - base : 256u);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const unsigned long long r = base + 64u * u + lane;
+                    const bool keep = r < hi_p && keep_hit(x[u], i_p, s_p, L_p, rp.reverse);
+                    cnt += __popcll(__ballot(keep));
+                }
+                base += 256;
+                if (base >= hi_p || cnt > rp.C) break;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {  // (the early exit makes the rounds dependent)
+                    const unsigned long long r = base + 64u * u + lane;
+                    x[u] = r < hi_p ? ix.sa[r] : (SlotT)0;
+                }
+            }
+            if (lane == p) my_cnt = cnt > rp.C ? kSkipCard : (uint32_t)cnt;
+        }
+        if (!COUNT && lane < np) p_filt[g] = my_cnt;
     }
     if (COUNT && lane == 0 && bytes) atomicAdd(&ctr[CT_ALG_BYTES], bytes);
 }
@@ -571,7 +629,8 @@ __global__ __launch_bounds__(256) void fill_small_kernel(IndexView<SlotT> ix, Ru
     }
 }
 
-// one wave per large interval: ballot / prefix-popcount compaction, SA order kept
+// Large intervals, one wave per 64 of them (set-up in parallel across the lanes, like the count
+// kernel): ballot / prefix-popcount compaction of the kept hits, SA order kept.
 template <class SlotT>
 __global__ __launch_bounds__(256) void fill_big_kernel(IndexView<SlotT> ix, RunParams rp,
                                                        const SlotT *__restrict__ p_lo,
@@ -581,33 +640,51 @@ __global__ __launch_bounds__(256) void fill_big_kernel(IndexView<SlotT> ix, RunP
                                                        SlotT *__restrict__ hits,
                                                        const uint32_t *__restrict__ big_list,
                                                        const unsigned long long *__restrict__ ctr) {
-    const int lane = threadIdx.x & 63;
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const uint64_t n_big = ctr[CT_BIG];
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    for (uint64_t e = wave; e < n_big; e += n_waves) {
-        const uint32_t g = big_list[e];
-        const uint32_t f = p_filt[g];
-        if (f == 0 || f >= kPending) continue;
-        const int c = chunk_of(rp.ch, g);
-        const uint64_t s = rp.ch.start[c], L = rp.ch.len[c];
-        const uint64_t i = (uint64_t)(g - rp.ch.pbase[c] + 1) * (uint64_t)rp.step;
-        const uint64_t lo = p_lo[g], hi = lo + p_raw[g];
-        unsigned long long w = row_off[g];
-        for (uint64_t base = lo; base < hi; base += 256) {  // four slices in flight per round trip
-            SlotT x[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint64_t r = base + 64u * u + lane;
-                x[u] = r < hi ? ix.sa[r] : (SlotT)0;
+    for (uint64_t e0 = wave * 64u; e0 < n_big; e0 += n_waves * 64u) {
+        const uint32_t np = (uint32_t)min((uint64_t)64, n_big - e0);
+        unsigned long long s = 0, L = 0, i = 0, lo = 0, hi = 0, w0 = 0;
+        bool want = false;
+        if (lane < np) {
+            const uint32_t g = big_list[e0 + lane];
+            const uint32_t f = p_filt[g];
+            want = f != 0 && f < kPending;  // skipped / empty rows have nothing to fill
+            if (want) {
+                const int c = chunk_of(rp.ch, g);
+                s = rp.ch.start[c];
+                L = rp.ch.len[c];
+                i = (unsigned long long)(g - rp.ch.pbase[c] + 1) * (unsigned long long)rp.step;
+                lo = p_lo[g];
+                hi = lo + p_raw[g];
+                w0 = row_off[g];
             }
+        }
+        unsigned long long todo = __ballot(want);
+        while (todo) {
+            const uint32_t p = (uint32_t)(__ffsll((long long)todo) - 1);
+            todo &= todo - 1;
+            const unsigned long long lo_p = lane_of(lo, p), hi_p = lane_of(hi, p), i_p = lane_of(i, p),
+                                     s_p = lane_of(s, p), L_p = lane_of(L, p);
+            unsigned long long w = lane_of(w0, p);
+            for (unsigned long long base = lo_p; base < hi_p; base += 256) {  // four slices in flight per round trip
+                SlotT x[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint64_t r = base + 64u * u + lane;
-                const bool keep = r < hi && keep_hit(x[u], i, s, L, rp.reverse);
-                const unsigned long long m = __ballot(keep);
-                if (keep) hits[w + __popcll(m & ((1ull << lane) - 1ull))] = x[u];
-                w += __popcll(m);
+                for (int u = 0; u < 4; ++u) {
+                    const unsigned long long r = base + 64u * u + lane;
+                    x[u] = r < hi_p ? ix.sa[r] : (SlotT)0;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const unsigned long long r = base + 64u * u + lane;
+                    const bool keep = r < hi_p && keep_hit(x[u], i_p, s_p, L_p, rp.reverse);
+                    const unsigned long long m = __ballot(keep);
+                    if (keep) hits[w + __popcll(m & lt_mask)] = x[u];
+                    w += __popcll(m);
+                }
             }
         }
     }
@@ -731,26 +808,6 @@ __device__ inline uint32_t arm_threshold(uint64_t left_len, uint32_t G) {
     const uint64_t tenth = left_len <= 0xFFFFFFFFull ? (uint64_t)((uint32_t)left_len / 10u) : left_len / 10u;
     const uint64_t thr = tenth > (uint64_t)G ? tenth : (uint64_t)G;
     return thr > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)thr;
-}
-
-// Workgroup barrier for data exchanged through LDS only.  __syncthreads() also waits for the
-// wave's outstanding GLOBAL stores (vmcnt(0)): one record written to HBM would stall every wave
-// of the workgroup for a memory round trip at the next barrier.  The extension kernels never
-// read back what they store to global memory, so their per-probe barriers only drain LDS traffic.
-__device__ inline void lds_barrier() { __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-// Wave-uniform values the compiler cannot prove uniform (read from LDS, or a lane of a vector):
-// forcing them into scalar registers keeps the per-probe bookkeeping and branches on the scalar
-// unit instead of exec-masked vector code and LDS permutes.
-__device__ inline uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-__device__ inline unsigned long long uni(unsigned long long v) {
-    return ((unsigned long long)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v);
-}
-__device__ inline uint32_t lane_of(uint32_t v, uint32_t l) {
-    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l);
-}
-__device__ inline unsigned long long lane_of(unsigned long long v, uint32_t l) {
-    return ((unsigned long long)lane_of((uint32_t)(v >> 32), l) << 32) | lane_of((uint32_t)v, l);
 }
 
 // Output records are appended to one device-wide list.  A global atomic WITH its return value costs

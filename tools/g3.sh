@@ -1,2 +1,4 @@
 export TMPDIR=/tmp
-python -m pytest tests -m gpu -x -q -k "multi or gather" 2>&1 | tail -15
+python tools/pole_synth.py --copies 3800 --sub 0.03 --check '' 2>&1 | grep direct
+python tools/tune_tiers.py cfg4 '' 2>&1 | tail -1
+python -m pytest tests -m gpu -x -q -k "escalation or battery" 2>&1 | tail -3

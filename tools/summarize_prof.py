@@ -38,15 +38,22 @@ for ctr, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
             a[2] += int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
     pmc[ctr] = {k: {"launches": v[0], "sum_KB": v[1], "avg_KB_per_launch": v[1] / v[0], "avg_ns": v[2] / v[0]}
                 for k, v in agg.items() if k.startswith("asgart::")}
-json.dump(pmc, open(os.path.join(dst, f"{tag}_{workload}_pmc_fetch_write.json"), "w"), indent=1)
+pj = os.path.join(dst, f"{tag}_{workload}_pmc_fetch_write.json")
+if any(pmc.values()):
+    json.dump(pmc, open(pj, "w"), indent=1)
+elif os.path.exists(pj):          # raw traces already deleted: re-summarise from the per-kernel file
+    pmc = json.load(open(pj))
 
 
 def per_launch(ctr, prefix, field="avg_KB_per_launch"):
     return sum(v[field] for k, v in pmc.get(ctr, {}).items() if k.startswith(prefix))
 
 
-probe = "asgart::probe_count_kernel"
-big = "asgart::big_count_kernel"
+# the product kernels only: <..., true> are the byte-accounting variants bench.py runs once per pass
+probe = "asgart::probe_count_kernel<unsigned int, false>"
+big = "asgart::big_count_kernel<unsigned int, false>"
+if not any(k.startswith(probe) for k in pmc.get("FETCH_SIZE", {})):   # 64-bit index
+    probe, big = probe.replace("unsigned int", "unsigned long"), big.replace("unsigned int", "unsigned long")
 search = sum(per_launch(c, p) for c in ("FETCH_SIZE", "WRITE_SIZE") for p in (probe, big)) * 1024
 # the kernels' own durations in the (serialising) PMC passes, averaged over the two passes
 pmc_ms = sum(per_launch(c, p, "avg_ns") for c in ("FETCH_SIZE", "WRITE_SIZE") for p in (probe, big)) / 2 / 1e6
@@ -56,7 +63,7 @@ if os.path.exists(sfile):
     tot = 0.0
     for row in csv.DictReader(open(sfile)):
         nm = short(row["Name"])
-        if nm.startswith(probe) or nm.startswith(big):
+        if nm.startswith(probe) or nm.startswith(big):  # (short() keeps the template arguments)
             tot += float(row["AverageNs"])
     stats_ms = tot / 1e6
 if search > 0:
