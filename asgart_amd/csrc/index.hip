@@ -632,7 +632,7 @@ extern "C" {
 
 const char *asgart_last_error(void) { return asgart::g_err; }
 
-const char *asgart_version(void) { return "asgart-hip 0.1.0 gfx950"; }
+const char *asgart_version(void) { return "asgart-hip 0.2.0 gfx950"; }
 
 void asgart_index_destroy(asgart_index *idx) {
     if (!idx) return;

@@ -439,7 +439,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                         extend_heavy_kernel<SlotT, kArmCapMid, kMidThreads, 0><<<grid(kGrid2), kMidThreads, 0, st>>>(ep);
                     break;
                 case 3:
-                        extend_arms_kernel<SlotT, kLongArmsLayers<SlotT>, 1024, kHitBatch, 1024, 4, false, true, kPoleLdsPad><<<grid(256), 1024, 0, st>>>(ep);
+                    extend_arms_kernel<SlotT, kLongArmsLayers<SlotT>, 1024, kHitBatch, 1024, 4, false, true, kPoleLdsPad><<<grid(256), 1024, 0, st>>>(ep);
                     break;
                 case 4:
                     if (arms_kernel)
@@ -450,7 +450,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                         extend_heavy_kernel<SlotT, kArmCapBig64, kHeavyThreads, 0><<<grid(256), kHeavyThreads, 0, st>>>(ep);
                     break;
                 case 5:
-                        extend_arms_kernel<SlotT, kMidArmsLayers<SlotT>, 512, kHitBatch, 1024, 4, false, true><<<grid(256 * 2), 512, 0, st>>>(ep);
+                    extend_arms_kernel<SlotT, kMidArmsLayers<SlotT>, 512, kHitBatch, 1024, 4, false, true><<<grid(256 * 2), 512, 0, st>>>(ep);
                     break;
                 case 6:
                     if (arms_kernel)

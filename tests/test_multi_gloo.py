@@ -109,3 +109,34 @@ def test_shard_on_gpu_and_gather(world):
         p.join(300)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+def _nccl_worker(rank, world, port, q):
+    """gather_families over the RCCL backend with CUDA tensors (one rank: a 1-GPU box cannot hold two)."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+
+    from asgart_amd import multi
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    offs = np.array([0, 2, 5], dtype=np.uint64)
+    sds = np.arange(20, dtype=np.uint64).reshape(5, 4) + (1 << 40)   # values beyond 32 bits survive the int64 payload
+    got = multi.gather_families(offs, sds, dist, device="cuda:0")
+    empty = multi.gather_families(np.zeros(1, np.uint64), np.zeros((0, 4), np.uint64), dist, device="cuda:0")
+    q.put(bool(np.array_equal(got[0], offs) and np.array_equal(got[1], sds) and len(empty[1]) == 0 and len(empty[0]) == 1))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_gather_families_rccl_backend():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_worker, args=(0, 1, _free_port(), q))
+    p.start()
+    p.join(300)
+    assert p.exitcode == 0
+    assert q.get(timeout=5) is True
