@@ -1,3 +1,4 @@
 export TMPDIR=/tmp
-python -m pytest tests/test_multi_gloo.py -m gpu -x -q 2>&1 | tail -5
-python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 2 --warmup 1 --workload cfg2 --no-cpu-baseline 2>&1 | tail -2 | cut -c1-400
+python tools/pole_synth.py --copies 3800 --sub 0.03 --check '' 'force_tier=6' 'force_tier=5' 2>&1 | grep direct
+python tools/tune_tiers.py cfg4 '' 2>&1 | tail -1
+python -m pytest tests -m gpu -x -q -k "escalation or battery or wrap or levels or 64bit" 2>&1 | tail -3
