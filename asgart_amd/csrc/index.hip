@@ -647,6 +647,8 @@ void asgart_index_destroy(asgart_index *idx) {
                           &w.scratch, &w.hit_flag, &w.seg_keys, &w.seg_vals, &w.sort_tmp, &w.pat,
                           &w.out_a, &w.out_b};
         for (DevBuf *b : bufs) b->release();
+        if (cx.h_pinned) (void)hipHostFree(cx.h_pinned);
+        cx.h_pinned = nullptr;
         for (auto &e : cx.ev)
             if (e) (void)hipEventDestroy(e);
         for (hipStream_t st : {cx.stream, cx.stream2, cx.stream3, cx.stream4, cx.stream5, cx.stream6})

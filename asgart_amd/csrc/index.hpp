@@ -117,6 +117,27 @@ struct SearchCtx {
     bool has_last = false;
     uint32_t last_P = 0;
     bool busy = false;
+    // pinned host staging for the sorted output records (a pageable target makes the D2H copy several
+    // times slower than the kernels that produce it); grow-only, freed with the index
+    void *h_pinned = nullptr;
+    size_t h_pinned_cap = 0;
+    int32_t pinned(size_t bytes, void **out) {
+        if (bytes > h_pinned_cap) {
+            if (h_pinned) (void)hipHostFree(h_pinned);
+            h_pinned = nullptr;
+            h_pinned_cap = 0;
+            const size_t want = bytes + bytes / 4 + 4096;
+            if (hipHostMalloc(&h_pinned, want, hipHostMallocDefault) != hipSuccess) {
+                (void)hipGetLastError();
+                h_pinned = nullptr;
+                set_error("hipHostMalloc(%zu bytes) failed", want);
+                return ASGART_E_OOM;
+            }
+            h_pinned_cap = want;
+        }
+        *out = h_pinned;
+        return 0;
+    }
 };
 constexpr int kNumCtx = 2;
 

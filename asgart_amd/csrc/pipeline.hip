@@ -278,7 +278,8 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
     if (fam_out && n_seg) {
         uint64_t rec_cap = std::max<uint64_t>(1u << 18, w.fam_sds.cap / sizeof(SdRec));
         RC_TRY(w.ovf_list.reserve((size_t)(n_seg + 1) * 4 * kTiers));
-        std::vector<SdRec> h_recs;
+        const SdRec *h_recs = nullptr;  // sorted records on the host (pinned staging of the context)
+        size_t n_hrec = 0;
         // ---- placement: per-segment work estimate -> tier, longest first --------------------
         // option force_tier = t (tests): start every segment with a multi-hit probe in tier >= t
         const int force_tier = (int)opt.force_tier;
@@ -549,21 +550,27 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
         }
         HIP_TRY(hipEventRecord(cx.ev[4], s));
         const uint64_t n_rec = h_ctr[CT_SD];
-        h_recs.resize((size_t)n_rec);
+        if (n_rec) {
+            void *hp = nullptr;
+            RC_TRY(cx.pinned((size_t)n_rec * sizeof(SdRec), &hp));
+            h_recs = static_cast<const SdRec *>(hp);
+            n_hrec = (size_t)n_rec;
+        }
         // Reference order: chunk order, discovery order inside the chunk, arm order
         // inside the family == (segment start probe, family ordinal, creation number): sorted on
         // the GPU.  A tombstone voids its family; segments re-run by a later tier emit some
         // records twice (same key): keep one copy.
         if (n_rec) {
             RC_TRY(sort_records(w, w.fam_sds.as<SdRec>(), n_rec, s));
-            HIP_TRY(hipMemcpyAsync(h_recs.data(), w.rec_sorted.p, (size_t)n_rec * sizeof(SdRec),
+            HIP_TRY(hipMemcpyAsync(const_cast<SdRec *>(h_recs), w.rec_sorted.p, (size_t)n_rec * sizeof(SdRec),
                                    hipMemcpyDeviceToHost, s));
         }
         HIP_TRY(hipStreamSynchronize(s));
-        for (size_t f0 = 0; f0 < h_recs.size();) {
+        fam_out->sds.reserve(n_hrec);
+        for (size_t f0 = 0; f0 < n_hrec;) {
             if (h_recs[f0].g_start == kVoidStart) break;  // unused slots of the waves' record chunks: sorted last
             size_t f1 = f0;
-            while (f1 < h_recs.size() && h_recs[f1].g_start == h_recs[f0].g_start &&
+            while (f1 < n_hrec && h_recs[f1].g_start == h_recs[f0].g_start &&
                    h_recs[f1].fam_seq == h_recs[f0].fam_seq)
                 ++f1;
             if (h_recs[f1 - 1].create_seq != kTombstone) {

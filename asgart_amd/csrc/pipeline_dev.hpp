@@ -389,22 +389,38 @@ __device__ inline ScanEl scan_element(uint32_t filt, bool chunk_first) {
     return e;
 }
 
-// exclusive block scan of one ScanEl per thread (kScanBlock threads)
+// exclusive block scan of one ScanEl per thread (kScanBlock threads): wave-level scans through
+// register shuffles, one LDS exchange of the four wave totals
+__device__ inline ScanEl shfl_up_el(const ScanEl &e, int d) {
+    ScanEl r;
+    r.hits = __shfl_up(e.hits, d);
+    r.c = __shfl_up(e.c, d);
+    r.flags = __shfl_up(e.flags, d);
+    return r;
+}
+
 __device__ inline ScanEl block_exclusive_scan(ScanEl v, ScanEl *sh, ScanEl *block_total) {
-    const int t = threadIdx.x;
-    sh[t] = v;
-    __syncthreads();
-    for (int off = 1; off < kScanBlock; off <<= 1) {
-        ScanEl cur = sh[t];
-        ScanEl prev = t >= off ? sh[t - off] : scan_identity();
-        __syncthreads();
-        if (t >= off) sh[t] = scan_combine(prev, cur);
-        __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    ScanEl inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const ScanEl o = shfl_up_el(inc, d);
+        if (lane >= d) inc = scan_combine(o, inc);
     }
-    ScanEl excl = t > 0 ? sh[t - 1] : scan_identity();
-    *block_total = sh[kScanBlock - 1];
+    if (lane == 63) sh[wave] = inc;
     __syncthreads();
-    return excl;
+    ScanEl before = scan_identity(), total = scan_identity();
+#pragma unroll
+    for (int w = 0; w < kScanBlock / 64; ++w) {
+        const ScanEl a = sh[w];
+        if (w < wave) before = scan_combine(before, a);
+        total = scan_combine(total, a);
+    }
+    ScanEl excl = shfl_up_el(inc, 1);
+    if (lane == 0) excl = scan_identity();
+    *block_total = total;
+    __syncthreads();
+    return scan_combine(before, excl);
 }
 
 // Coalesced staging of one scan tile: hit counts and "first probe of a chunk" marks go through

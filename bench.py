@@ -156,13 +156,37 @@ def main():
         pass_stats.append(idx.stats(1).as_dict())   # rank-local work counters
 
     # Timed region.  The library is re-entrant (one internal context per call), so the direct and
-    # the RC pass of a step are issued from two host threads and overlap on the GPU: while one
+    # the RC pass of a step can be issued from two host threads and overlap on the GPU: while one
     # pass runs its serial extension chains the other one's search kernels use the idle CUs.
-    # ASGART_BENCH_OVERLAP=0 runs the passes back to back.
     from concurrent.futures import ThreadPoolExecutor
 
-    sequential = os.environ.get("ASGART_BENCH_OVERLAP", "1") == "0" or len(settings) == 1
     pool = ThreadPoolExecutor(max_workers=len(settings))
+    # Which is faster depends on how much of a step is the serial extension chains (overlap wins) and how
+    # much is chip-wide work that the two passes only steal from each other (back to back wins): one
+    # untimed step of each decides (ASGART_BENCH_OVERLAP=0/1 forces a mode).
+    mode_probe_ms = None
+    forced = os.environ.get("ASGART_BENCH_OVERLAP")
+    if len(settings) == 1:
+        sequential = True
+    elif forced in ("0", "1"):
+        sequential = forced == "0"
+    else:
+        sync()
+        t_a = time.perf_counter()
+        for st in settings:
+            run_pass(st)
+        t_b = time.perf_counter()
+        list(pool.map(run_pass, settings))
+        t_c = time.perf_counter()
+        mode_probe_ms = {"back_to_back": round((t_b - t_a) * 1e3, 2), "overlapped": round((t_c - t_b) * 1e3, 2)}
+        local = 1.0 if (t_b - t_a) <= (t_c - t_b) else 0.0
+        if dist is not None:   # every rank must use the same mode: majority
+            import torch
+
+            v = torch.tensor([local], device=comm_device)
+            dist.all_reduce(v)
+            local = 1.0 if float(v.item()) * 2 >= world else 0.0
+        sequential = local == 1.0
 
     sync()
     t0 = time.perf_counter()
@@ -256,7 +280,7 @@ def main():
                    "skip_masked": skip_masked,
                    "text_bytes": int(len(pr.data)), "chunks": len(pr.chunks),
                    "parallelism": f"probe-shard x{world}" if world > 1 else "1 GPU",
-                   "passes_overlapped": not sequential},
+                   "passes_overlapped": not sequential, "mode_probe_ms": mode_probe_ms},
         "roofline": roofline,
         "phases_ms_per_step": {ph: round(v / args.steps, 4) for ph, v in phase_ms.items()},
         "index_build_s": {"upload_and_suffix_array": round(t_sa, 2), "keys_and_tables": round(t_index, 3),

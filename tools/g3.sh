@@ -1,4 +1,4 @@
 export TMPDIR=/tmp
-python tools/pole_synth.py --copies 3800 --sub 0.03 --check '' 'force_tier=6' 'force_tier=5' 2>&1 | grep direct
-python tools/tune_tiers.py cfg4 '' 2>&1 | tail -1
-python -m pytest tests -m gpu -x -q -k "escalation or battery or wrap or levels or 64bit" 2>&1 | tail -3
+python -m pytest tests -m gpu -x -q -k "not cfg4_full" 2>&1 | tail -3
+ASGART_BENCH_OVERLAP=0 python bench.py --workload cfg4 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('seq', d['value'], d['ms_per_step'], d['phases_ms_per_step'])"
+python bench.py --workload cfg4 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('ovl', d['value'], d['ms_per_step'], d['phases_ms_per_step'])"
