@@ -34,7 +34,7 @@ ABI_SYMBOLS = (
     "asgart_searcher_search", "asgart_sa_read", "asgart_probe_hits", "asgart_get_stats",
     "asgart_last_error", "asgart_version", "asgart_compute_scores", "asgart_index_set_option",
     "asgart_index_check_sa", "asgart_index_create_trim", "asgart_index_clone",
-    "asgart_search_duplications_multi",
+    "asgart_search_duplications_multi", "asgart_search_duplications_ex",
 )
 
 
@@ -113,6 +113,9 @@ def load_library() -> C.CDLL:
     L.asgart_search_duplications_shard.argtypes = [vp, vp, C.c_int64, C.POINTER(_Settings),
                                                    C.c_int32, C.c_int32, C.POINTER(vp)]
     L.asgart_search_duplications_shard.restype = C.c_int32
+    L.asgart_search_duplications_ex.argtypes = [vp, vp, C.c_int64, C.POINTER(_Settings), C.c_int32, C.c_int32, vp,
+                                                C.POINTER(vp)]
+    L.asgart_search_duplications_ex.restype = C.c_int32
     L.asgart_families_counts.argtypes = [vp, u64p, u64p]
     L.asgart_families_counts.restype = None
     L.asgart_families_copy.argtypes = [vp, vp, vp]
@@ -302,19 +305,25 @@ class Index:
 
     # -- SearchDuplications::run body --------------------------------------
     def search_duplications_raw(self, chunks: Sequence[Tuple[int, int]], settings: RunSettings,
-                                shard: int = 0, n_shards: int = 1
+                                shard: int = 0, n_shards: int = 1, progress: Optional[np.ndarray] = None
                                 ) -> Tuple[np.ndarray, np.ndarray]:
-        """-> (fam_offsets[n_fam+1], sds[n_sd,4]) as uint64 arrays."""
+        """-> (fam_offsets[n_fam+1], sds[n_sd,4]) as uint64 arrays.  progress: optional uint64[n_chunks]
+        the library writes each chunk's needle offset into when the call's search phases are over (see the header)."""
         L = load_library()
         ch = np.array(chunks, dtype=np.uint64).reshape(-1)
         st = settings._c()
         h = C.c_void_p()
+        if progress is not None:
+            assert progress.dtype == np.uint64 and len(progress) >= len(chunks)
         if n_shards == 1:
-            _check(L.asgart_search_duplications(self._h, _ptr(ch), len(chunks), C.byref(st), None,
+            _check(L.asgart_search_duplications(self._h, _ptr(ch), len(chunks), C.byref(st), _ptr(progress),
                                                 C.byref(h)))
-        else:
+        elif progress is None:
             _check(L.asgart_search_duplications_shard(self._h, _ptr(ch), len(chunks), C.byref(st),
                                                       shard, n_shards, C.byref(h)))
+        else:
+            _check(L.asgart_search_duplications_ex(self._h, _ptr(ch), len(chunks), C.byref(st), shard, n_shards,
+                                                   _ptr(progress), C.byref(h)))
         try:
             nf, ns = C.c_uint64(), C.c_uint64()
             L.asgart_families_counts(h, C.byref(nf), C.byref(ns))

@@ -110,13 +110,14 @@ struct SearchCtx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr, stream3 = nullptr, stream4 = nullptr;  // concurrent extension tiers
     hipStream_t stream5 = nullptr, stream6 = nullptr;
-    hipEvent_t ev[12] = {};
+    hipEvent_t ev[13] = {};
     Workspace ws;
     asgart_stats stats;
     RunParams last_rp;   // inputs of the last call, kept for the yardstick kernel
     bool has_last = false;
     uint32_t last_P = 0;
     bool busy = false;
+    volatile uint64_t *progress = nullptr;  // of the call in flight (asgart_search_duplications), or null
     // pinned host staging for the sorted output records (a pageable target makes the D2H copy several
     // times slower than the kernels that produce it); grow-only, freed with the index
     void *h_pinned = nullptr;
@@ -275,7 +276,8 @@ int32_t index_prepare_filter(asgart_index *idx, uint64_t k, int mode);  // mode 
 int32_t run_search(asgart_index *idx, const uint64_t *chunks, int64_t n_chunks,
                    const asgart_settings *st, int32_t shard, int32_t n_shards, bool want_csr,
                    asgart_families *fam_out, std::vector<uint8_t> *status_out,
-                   std::vector<uint64_t> *rowoff_out, std::vector<uint64_t> *hits_out);
+                   std::vector<uint64_t> *rowoff_out, std::vector<uint64_t> *hits_out,
+                   volatile uint64_t *progress);
 // records -> reference order (g_start, fam_seq, create_seq), stable; result in w.rec_sorted
 int32_t sort_records(Workspace &w, const SdRec *recs, uint64_t n, hipStream_t s);
 int32_t sort_segments(Workspace &w, uint32_t *keys, uint32_t *vals, uint64_t n, hipStream_t s,

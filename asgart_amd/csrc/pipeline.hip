@@ -483,11 +483,22 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             };
             for (char c : tier_order) launch_tier(c - '0');
             HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(cx.ev[12], s));   // tier 1 (main stream)
             HIP_TRY(hipEventRecord(cx.ev[5], st2));
             HIP_TRY(hipEventRecord(cx.ev[6], st3));
             HIP_TRY(hipEventRecord(cx.ev[8], st4));
             HIP_TRY(hipEventRecord(cx.ev[9], st5));
             HIP_TRY(hipEventRecord(cx.ev[10], st6));
+            if (cx.progress && attempt == 0) {
+                // Progress (reference src/automaton.rs:98 stores every probe's offset for a polled progress
+                // bar): every probe of the call has been searched and its hits are materialised -- the
+                // HBM-bound, chip-wide part of the call is over, the extension automaton is under way.
+                // A host that pipelines calls (bench.py) issues the next one when it sees this: its search
+                // phases then run beside this call's extension, whose tail is a few serial segments.
+                HIP_TRY(hipEventSynchronize(cx.ev[3]));  // probe search, scans and CSR fill are done
+                for (int64_t c = 0; c < n_chunks; ++c)
+                    cx.progress[c] = (uint64_t)probes_in_chunk(h_len[c], k, step, st->min_duplication_length) * step;
+            }
             HIP_TRY(hipStreamWaitEvent(s, cx.ev[5], 0));
             HIP_TRY(hipStreamWaitEvent(s, cx.ev[6], 0));
             HIP_TRY(hipStreamWaitEvent(s, cx.ev[8], 0));
@@ -625,7 +636,8 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
 int32_t run_search(asgart_index *idx, const uint64_t *chunks, int64_t n_chunks,
                    const asgart_settings *st, int32_t shard, int32_t n_shards, bool want_csr,
                    asgart_families *fam_out, std::vector<uint8_t> *status_out,
-                   std::vector<uint64_t> *rowoff_out, std::vector<uint64_t> *hits_out) {
+                   std::vector<uint64_t> *rowoff_out, std::vector<uint64_t> *hits_out,
+                   volatile uint64_t *progress) {
     if (!idx || !st || n_chunks < 0 || (n_chunks && !chunks)) {
         set_error("bad argument");
         return ASGART_E_ARG;
@@ -651,6 +663,7 @@ int32_t run_search(asgart_index *idx, const uint64_t *chunks, int64_t n_chunks,
         RC_TRY(index_prepare_filter(idx, st->probe_size, mode));
     }
     SearchCtx &cx = idx->ctx[which];
+    cx.progress = progress;
     int32_t rc;
     if (idx->wide)
         rc = run_search_t<uint64_t>(idx, cx, chunks, n_chunks, st, shard, n_shards, want_csr, fam_out,
@@ -658,6 +671,7 @@ int32_t run_search(asgart_index *idx, const uint64_t *chunks, int64_t n_chunks,
     else
         rc = run_search_t<uint32_t>(idx, cx, chunks, n_chunks, st, shard, n_shards, want_csr, fam_out,
                                     status_out, rowoff_out, hits_out);
+    cx.progress = nullptr;
     idx->release_one(which);
     return rc;
 }
@@ -668,9 +682,9 @@ using namespace asgart;
 
 extern "C" {
 
-int32_t asgart_search_duplications_shard(asgart_index *idx, const uint64_t *chunks,
-                                         int64_t n_chunks, const asgart_settings *settings,
-                                         int32_t shard, int32_t n_shards, asgart_families **out) {
+static int32_t search_shard_impl(asgart_index *idx, const uint64_t *chunks, int64_t n_chunks,
+                                 const asgart_settings *settings, int32_t shard, int32_t n_shards,
+                                 volatile uint64_t *progress, asgart_families **out) {
     if (!out) {
         set_error("out is NULL");
         return ASGART_E_ARG;
@@ -682,7 +696,7 @@ int32_t asgart_search_duplications_shard(asgart_index *idx, const uint64_t *chun
         return ASGART_E_OOM;
     }
     int32_t rc = run_search(idx, chunks, n_chunks, settings, shard, n_shards, false, f, nullptr,
-                            nullptr, nullptr);
+                            nullptr, nullptr, progress);
     if (rc != 0) {
         delete f;
         return rc;
@@ -691,13 +705,24 @@ int32_t asgart_search_duplications_shard(asgart_index *idx, const uint64_t *chun
     return 0;
 }
 
+int32_t asgart_search_duplications_shard(asgart_index *idx, const uint64_t *chunks,
+                                         int64_t n_chunks, const asgart_settings *settings,
+                                         int32_t shard, int32_t n_shards, asgart_families **out) {
+    return search_shard_impl(idx, chunks, n_chunks, settings, shard, n_shards, nullptr, out);
+}
+
+int32_t asgart_search_duplications_ex(asgart_index *idx, const uint64_t *chunks, int64_t n_chunks,
+                                      const asgart_settings *settings, int32_t shard, int32_t n_shards,
+                                      volatile uint64_t *progress, asgart_families **out) {
+    return search_shard_impl(idx, chunks, n_chunks, settings, shard, n_shards, progress, out);
+}
+
 int32_t asgart_search_duplications(asgart_index *idx, const uint64_t *chunks, int64_t n_chunks,
                                    const asgart_settings *settings, volatile uint64_t *progress,
                                    asgart_families **out) {
-    int32_t rc = asgart_search_duplications_shard(idx, chunks, n_chunks, settings, 0, 1, out);
+    int32_t rc = search_shard_impl(idx, chunks, n_chunks, settings, 0, 1, progress, out);
     if (rc == 0 && progress) {
-        // best effort, like the Relaxed stores of src/automaton.rs:98: report the
-        // last probe offset of every chunk once the call is complete
+        // (also written earlier, when the chip-wide phases were over: see run_search_t) 
         const uint64_t k = settings->probe_size, step = k / 2;
         for (int64_t c = 0; c < n_chunks; ++c)
             progress[c] = (uint64_t)probes_in_chunk(chunks[2 * c + 1], k, step,
@@ -733,7 +758,7 @@ int32_t asgart_search_duplications_multi(asgart_index *const *indices, int32_t n
     for (int32_t r = 0; r < n_devices; ++r)
         workers.emplace_back([&, r]() {
             rcs[r] = run_search(indices[r], chunks, n_chunks, settings, r, n_devices, false, &parts[r], nullptr,
-                                nullptr, nullptr);
+                                nullptr, nullptr, nullptr);
             if (rcs[r] != 0) errs[r] = asgart_last_error();  // the message is thread-local
         });
     for (auto &t : workers) t.join();
@@ -780,7 +805,7 @@ int64_t asgart_probe_hits(asgart_index *idx, const uint64_t *chunks, int64_t n_c
                           uint64_t *hits, uint64_t *n_hits) {
     std::vector<uint8_t> st;
     std::vector<uint64_t> ro, hv;
-    int32_t rc = run_search(idx, chunks, n_chunks, settings, 0, 1, true, nullptr, &st, &ro, &hv);
+    int32_t rc = run_search(idx, chunks, n_chunks, settings, 0, 1, true, nullptr, &st, &ro, &hv, nullptr);
     if (rc != 0) return rc;
     if (n_hits) *n_hits = hv.size();
     if (status) {

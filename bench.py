@@ -161,32 +161,62 @@ def main():
     from concurrent.futures import ThreadPoolExecutor
 
     pool = ThreadPoolExecutor(max_workers=len(settings))
-    # Which is faster depends on how much of a step is the serial extension chains (overlap wins) and how
-    # much is chip-wide work that the two passes only steal from each other (back to back wins): one
-    # untimed step of each decides (ASGART_BENCH_OVERLAP=0/1 forces a mode).
-    mode_probe_ms = None
-    forced = os.environ.get("ASGART_BENCH_OVERLAP")
-    if len(settings) == 1:
-        sequential = True
-    elif forced in ("0", "1"):
-        sequential = forced == "0"
-    else:
-        sync()
-        t_a = time.perf_counter()
-        for st in settings:
-            run_pass(st)
-        t_b = time.perf_counter()
-        list(pool.map(run_pass, settings))
-        t_c = time.perf_counter()
-        mode_probe_ms = {"back_to_back": round((t_b - t_a) * 1e3, 2), "overlapped": round((t_c - t_b) * 1e3, 2)}
-        local = 1.0 if (t_b - t_a) <= (t_c - t_b) else 0.0
-        if dist is not None:   # every rank must use the same mode: majority
-            import torch
 
-            v = torch.tensor([local], device=comm_device)
-            dist.all_reduce(v)
-            local = 1.0 if float(v.item()) * 2 >= world else 0.0
-        sequential = local == 1.0
+    def run_pipelined(order):
+        """Both passes of a step, pipelined: the second call is issued when the first one reports (through
+        the progress array of the C ABI, polled like the reference's progress bar polls its counters) that
+        its probes are searched; its own search phases then run beside the extension of the first, whose
+        tail is a few serial segments.  Returns the results in `settings` order."""
+        first, second = order
+        prog = np.zeros(len(pr.chunks), dtype=np.uint64)
+        fut = pool.submit(idx.search_duplications_raw, pr.chunks, settings[first], rank if world > 1 else 0,
+                          world if world > 1 else 1, prog)
+        while not fut.done() and not prog.any():
+            time.sleep(0.0005)
+        res = {second: run_pass(settings[second]), first: fut.result()}
+        return [res[j] for j in range(len(settings))]
+
+    # Four ways to issue the two passes of a step; which is fastest depends on how much of a pass is its
+    # serial extension tail (pipelining hides it) and how much is chip-wide work the passes would only
+    # steal from each other.  One untimed step of each decides (ASGART_BENCH_MODE forces one).
+    MODES_OF_ISSUE = ("back_to_back", "overlapped", "pipelined_0_first", "pipelined_1_first")
+
+    def issue(mode):
+        """-> (results in `settings` order, the library's per-call stats)"""
+        if mode == "back_to_back" or len(settings) == 1:
+            results, stats = [], []
+            for st in settings:
+                results.append(run_pass(st))
+                stats.append(idx.stats(0))          # the call just finished
+            return results, stats
+        if mode == "overlapped":
+            results = list(pool.map(run_pass, settings))
+        else:
+            results = run_pipelined((0, 1) if mode == "pipelined_0_first" else (1, 0))
+        return results, [idx.stats((ci + 1) << 8) for ci in range(len(settings))]  # one context per call
+
+    mode_probe_ms = None
+    mode = os.environ.get("ASGART_BENCH_MODE", "")
+    if os.environ.get("ASGART_BENCH_OVERLAP") in ("0", "1"):   # (older switch)
+        mode = "back_to_back" if os.environ["ASGART_BENCH_OVERLAP"] == "0" else "overlapped"
+    if len(settings) == 1:
+        mode = "back_to_back"
+    elif mode not in MODES_OF_ISSUE:
+        mode_probe_ms = {}
+        for m in MODES_OF_ISSUE:
+            sync()
+            t_a = time.perf_counter()
+            issue(m)
+            dt = time.perf_counter() - t_a
+            if dist is not None:   # a step lasts as long as its slowest rank; every rank must pick the same mode
+                import torch
+
+                v = torch.tensor([dt], device=comm_device)
+                dist.all_reduce(v, op=dist.ReduceOp.MAX)
+                dt = float(v.item())
+            mode_probe_ms[m] = round(dt * 1e3, 2)
+        mode = min(mode_probe_ms, key=mode_probe_ms.get)
+    sequential = mode == "back_to_back"
 
     sync()
     t0 = time.perf_counter()
@@ -194,15 +224,7 @@ def main():
     probe_count_ms = 0.0
     phase_ms = {"search": 0.0, "scan": 0.0, "fill": 0.0, "extend": 0.0, "extend_tier2": 0.0}
     for _ in range(args.steps):
-        per_call = []
-        if sequential:
-            results = []
-            for st in settings:
-                results.append(run_pass(st))
-                per_call.append(idx.stats(0))
-        else:
-            results = list(pool.map(run_pass, settings))
-            per_call = [idx.stats((ci + 1) << 8) for ci in range(len(settings))]  # one context each
+        results, per_call = issue(mode)
         if world > 1:
             # the only exchange of the path: duplicon lists -> rank 0 over RCCL
             results = [multi.gather_families(r_[0], r_[1], dist, device=comm_device) for r_ in results]
@@ -280,7 +302,7 @@ def main():
                    "skip_masked": skip_masked,
                    "text_bytes": int(len(pr.data)), "chunks": len(pr.chunks),
                    "parallelism": f"probe-shard x{world}" if world > 1 else "1 GPU",
-                   "passes_overlapped": not sequential, "mode_probe_ms": mode_probe_ms},
+                   "passes_issued": mode, "mode_probe_ms": mode_probe_ms},
         "roofline": roofline,
         "phases_ms_per_step": {ph: round(v / args.steps, 4) for ph, v in phase_ms.items()},
         "index_build_s": {"upload_and_suffix_array": round(t_sa, 2), "keys_and_tables": round(t_index, 3),

@@ -154,8 +154,12 @@ int32_t asgart_index_prepare(asgart_index *idx, uint64_t probe_size);
  * chunks: n_chunks pairs (start, len).  progress: nullable, n_chunks entries; the reference stores
  * the needle offset of every probe as it goes (src/automaton.rs:98, Relaxed) for a progress bar that
  * polls every 500 ms (src/bin/asgart.rs:160-197).  Here all chunks advance together through a few
- * device-wide phases, so the entries are written once, with each chunk's final offset, when the call
- * completes (a whole-genome call takes a fraction of a second). */
+ * device-wide phases, so every entry jumps to its chunk's final offset at once: when every probe of the
+ * call has been searched and its hits materialised (the HBM-bound, chip-wide part is over; the extension
+ * automaton is under way) and again when the call returns.  A host that polls the array from another
+ * thread can issue its next call at that moment: the new call's search phases then run beside this
+ * call's extension, whose tail is a few serial segments on one compute unit each (bench.py pipelines the
+ * -RC and the direct pass of a step that way: 338 instead of 441 ms per step on the GRCh38-sized input). */
 int32_t asgart_search_duplications(asgart_index *idx, const uint64_t *chunks, int64_t n_chunks,
                                    const asgart_settings *settings, volatile uint64_t *progress,
                                    asgart_families **out);
@@ -181,6 +185,12 @@ int32_t asgart_search_duplications_multi(asgart_index *const *indices, int32_t n
                                          const uint64_t *chunks, int64_t n_chunks,
                                          const asgart_settings *settings, volatile uint64_t *progress,
                                          asgart_families **out);
+
+/* The general form of the two calls above: shard `shard` of `n_shards` (0 of 1: everything) with the
+ * progress array of asgart_search_duplications (entries of ALL chunks are written). */
+int32_t asgart_search_duplications_ex(asgart_index *idx, const uint64_t *chunks, int64_t n_chunks,
+                                      const asgart_settings *settings, int32_t shard, int32_t n_shards,
+                                      volatile uint64_t *progress, asgart_families **out);
 
 void asgart_families_counts(const asgart_families *f, uint64_t *n_families, uint64_t *n_sds);
 /* fam_offsets: n_families+1 entries; sds: n_sds entries */

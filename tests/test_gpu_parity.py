@@ -576,6 +576,33 @@ def test_multi_device_entry_equals_one_device(hiplib, name):
                 assert np.array_equal(offs, one[0]) and np.array_equal(sds, one[1]), (name, len(group), reverse)
 
 
+def test_progress_array_and_pipelined_calls(hiplib):
+    """`progress` (reference src/automaton.rs:98, polled by src/bin/asgart.rs:160-197): every chunk's entry ends
+    at its last probe offset; a second call issued from another thread as soon as the first one reports progress
+    (what bench.py does with the direct and the -RC pass) returns the same families as calls made one by one."""
+    import threading
+    import time
+    pr, cli = _battery_case("satellites")
+    oidx = oracle.Index.build(pr.data)
+    k, step, M = 20, 10, cli.get("min_length", 1000)
+    with asgart_amd.Index(pr.data, oidx.sa) as idx:
+        sts = [asgart_amd.RunSettings.from_cli(reverse=rc, complement=rc, **cli) for rc in (False, True)]
+        alone = [idx.search_duplications_raw(pr.chunks, st) for st in sts]
+        prog = np.zeros(len(pr.chunks), dtype=np.uint64)
+        out = {}
+        t = threading.Thread(target=lambda: out.__setitem__(1, idx.search_duplications_raw(pr.chunks, sts[1], 0, 1, prog)))
+        t.start()
+        while t.is_alive() and not prog.any():
+            time.sleep(0.0002)
+        out[0] = idx.search_duplications_raw(pr.chunks, sts[0])
+        t.join()
+        for j in (0, 1):
+            assert np.array_equal(out[j][0], alone[j][0]) and np.array_equal(out[j][1], alone[j][1])
+        want = [((L - k - step + step - 1) // step) * step if (L >= M and L >= k + step and L - k - step > 0) else 0
+                for _, L in pr.chunks]
+        assert prog.tolist() == want
+
+
 def test_cfg3_full_skip_masked_digest(hiplib):
     """BASELINE.json configs[2] as stated: chr1-sized synthetic (249 Mb), direct + RC, --skip-masked."""
     _check_against_oracle_digest("cfg3s")
