@@ -47,6 +47,7 @@ const OptDesc kOptions[] = {
     {"force_wide", &Options::force_wide, 0, 1},
     {"test_wide_batch", &Options::test_wide_batch, 0, 1ll << 40},
     {"kfilter_bits", &Options::kfilter_bits, 0, 34},
+    {"tier_streams", &Options::tier_streams, 1111111, 6666666},
 };
 }  // namespace
 
@@ -354,10 +355,13 @@ __global__ __launch_bounds__(256) void pattern_search_kernel(IndexView<SlotT> ix
                                                              uint64_t *__restrict__ hi) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_pat) return;
-    uint64_t q = 0;
-    for (int j = 0; j < ix.k; ++j) q = (q << 3) | base_code(pats[t * ix.k + j]);
+    uint64_t q = 0, q2 = 0;
+    for (int j = 0; j < ix.k; ++j) {
+        const uint64_t c = base_code(pats[t * ix.k + j]);
+        if (j < kMaxKey) q = (q << 3) | c; else q2 = (q2 << 3) | c;
+    }
     uint64_t l, h;
-    kmer_range(ix, q, l, h);
+    kmer_range(ix, q, q2, l, h);
     lo[t] = l;
     hi[t] = h;
 }
@@ -482,7 +486,7 @@ int32_t text_is_dna(const uint8_t *d_text, int64_t n, hipStream_t s, bool *dna) 
 int32_t index_prepare(asgart_index *idx, uint64_t k) {
     if (k < (uint64_t)kCacheLen || k > (uint64_t)kMaxK) {
         set_error("probe_size %llu unsupported: need %d <= k <= %d (the reference needs k >= 8, "
-                  "src/searcher.rs:95-97; this build packs a probe into 63 bits)",
+                  "src/searcher.rs:95-97; this build compares a 63-bit key word plus at most 21 more bases)",
                   (unsigned long long)k, kCacheLen, kMaxK);
         return ASGART_E_ARG;
     }
@@ -502,7 +506,8 @@ int32_t index_prepare(asgart_index *idx, uint64_t k) {
     const uint64_t n = (uint64_t)idx->n, n_sa = (uint64_t)idx->n_sa;
     const size_t slot = idx->wide ? 8 : 4;
     // a --trim index is searched through the 8-mer cache like the reference: no prefix table
-    const int d = idx->trimmed ? 1 : choose_depth(idx->n_sa, k, idx->opt.ptab_depth);
+    const uint64_t kk = std::min<uint64_t>(k, (uint64_t)kMaxKey);  // bases in a key word
+    const int d = idx->trimmed ? 1 : choose_depth(idx->n_sa, kk, idx->opt.ptab_depth);
     const uint64_t entries = (1ull << (2 * d)) + 1;
     HIP_TRY(hipMalloc((void **)&idx->d_keys, (n_sa + 16) * sizeof(uint64_t)));
     HIP_TRY(hipMalloc(&idx->d_ptab, entries * slot));
@@ -513,11 +518,11 @@ int32_t index_prepare(asgart_index *idx, uint64_t k) {
     auto build = [&](auto tag) -> int32_t {
         using SlotT = decltype(tag);
         const SlotT *sa = (const SlotT *)idx->d_sa;
-        build_keys_kernel<SlotT><<<grid_capped(n_sa), 256, 0, s>>>(idx->d_text, sa, idx->d_keys, n, n_sa, (int)k);
+        build_keys_kernel<SlotT><<<grid_capped(n_sa), 256, 0, s>>>(idx->d_text, sa, idx->d_keys, n, n_sa, (int)kk);
         if (!idx->trimmed) {
-            build_ptab_kernel<SlotT><<<grid_for(entries), 256, 0, s>>>(idx->d_keys, (SlotT *)idx->d_ptab, n_sa, (int)k, d);
+            build_ptab_kernel<SlotT><<<grid_for(entries), 256, 0, s>>>(idx->d_keys, (SlotT *)idx->d_ptab, n_sa, (int)kk, d);
             build_cache8_kernel<SlotT><<<grid_for(kCacheEntries), 256, 0, s>>>(
-                idx->d_keys, (SlotT *)idx->d_c8lo, (SlotT *)idx->d_c8hi, n_sa, (int)k);
+                idx->d_keys, (SlotT *)idx->d_c8lo, (SlotT *)idx->d_c8hi, n_sa, (int)kk);
             HIP_TRY(hipGetLastError());
             return 0;
         }
@@ -575,7 +580,8 @@ int32_t index_prepare(asgart_index *idx, uint64_t k) {
 int32_t index_prepare_filter(asgart_index *idx, uint64_t k, int mode) {
     RC_TRY(index_prepare(idx, k));
     // (a --trim index has no filter: its array does not hold the probes' own positions)
-    if (idx->opt.kfilter_bits == 0 || idx->trimmed || mode < 0 || mode > 3) return 0;
+    // (nor have probes longer than one key word: the filter is keyed by the key word)
+    if (idx->opt.kfilter_bits == 0 || idx->trimmed || mode < 0 || mode > 3 || k > (uint64_t)kMaxKey) return 0;
     {
         std::lock_guard<std::mutex> lk(idx->mu);
         if (idx->k == k && idx->d_filter[mode]) return 0;

@@ -27,7 +27,9 @@ struct IndexView {
     const SlotT *c8lo;
     const SlotT *c8hi;
     uint64_t n;
-    int k;
+    int k;   // probe size
+    int kk;  // bases held by a key word: min(k, kMaxKey)
+    int k2;  // k - kk: bases of a long probe compared through the text
     int d;
     // text-tail corner (reference src/searcher.rs:165-166): 8-mer prefixes
     // (24-bit codes) of the suffixes shorter than k; probes with one of these
@@ -165,6 +167,7 @@ struct Options {
     int64_t force_wide = 0;         // tests: 64-bit slots and positions for a small text
     int64_t test_wide_batch = 0;    // tests: batch size of the 64-bit suffix sorter's doubling rounds (0: 2^29)
     int64_t kfilter_bits = 30;      // log2(bits) of the k-mer presence filter (search_dev.hpp); 0: no filter
+    int64_t tier_streams = 1234563; // digit t (from the left): the stream (1..6, 1 = the call's main stream) tier t runs on
 };
 int32_t option_set(Options &o, const char *name, int64_t value);  // ASGART_E_ARG: unknown name / bad value
 void options_from_env(Options &o);
@@ -251,6 +254,8 @@ struct asgart_index {
         v.c8hi = reinterpret_cast<const SlotT *>(d_c8hi);
         v.n = (uint64_t)n;
         v.k = (int)k;
+        v.kk = (int)std::min<uint64_t>(k, (uint64_t)asgart::kMaxKey);
+        v.k2 = v.k - v.kk;
         v.d = d;
         for (int j = 0; j < asgart::kMaxK; ++j) v.tail8[j] = tail8[j];
         v.n_tail8 = n_tail8;

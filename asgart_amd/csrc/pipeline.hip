@@ -467,6 +467,12 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                 }
             };
             hipStream_t tier_stream[kTiers + 1] = {s, s, st2, st3, st4, st5, st6, st3};
+            {   // option tier_streams: tiers that share a stream run one after the other, in launch order
+                const hipStream_t pool[7] = {s, s, st2, st3, st4, st5, st6};
+                const std::string ts = std::to_string((long long)opt.tier_streams);
+                for (int t = 1; t <= kTiers && t <= (int)ts.size(); ++t)
+                    if (ts[t - 1] >= '1' && ts[t - 1] <= '6') tier_stream[t] = pool[ts[t - 1] - '0'];
+            }
             auto launch_tier = [&](int tier) {
                 if (tier < 1 || tier > kTiers || !n_t[tier - 1]) return;
                 ep.seg_list = order + seg_off[tier - 1];
@@ -658,7 +664,9 @@ int32_t run_search(asgart_index *idx, const uint64_t *chunks, int64_t n_chunks,
         SearchCtx &probe = idx->acquire_one(&which);
         (void)probe;
         const int mode = (st->reverse ? 2 : 0) | (st->complement ? 1 : 0);
-        if (idx->k == st->probe_size && (idx->opt.kfilter_bits == 0 || idx->trimmed || idx->d_filter[mode])) break;
+        if (idx->k == st->probe_size && (idx->opt.kfilter_bits == 0 || idx->trimmed || idx->d_filter[mode] ||
+                                         st->probe_size > (uint64_t)kMaxKey))
+            break;
         idx->release_one(which);
         RC_TRY(index_prepare_filter(idx, st->probe_size, mode));
     }

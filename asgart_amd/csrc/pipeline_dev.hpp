@@ -119,7 +119,7 @@ __device__ inline unsigned long long lane_of(unsigned long long v, uint32_t l) {
 // COUNT = true is the accounting pass behind bench.py's `kernel_algorithmic_bytes`: the same
 // control flow, no stores, every load / store of the real kernel priced in bytes.
 constexpr int kProbeBlock = 256;
-constexpr int kMaxHalf = (kMaxK + 1) / 2;                                   // bases per half
+constexpr int kMaxHalf = (kMaxKey + 1) / 2;                                 // bases per half (one-word keys)
 constexpr int kWinBytes = ((kProbeBlock + 2) * kMaxHalf + 15 + 16 + 15) / 16 * 16;  // <= 256 lanes x 16 B
 
 template <class SlotT, bool COUNT>
@@ -139,8 +139,9 @@ __global__ __launch_bounds__(kProbeBlock) void probe_count_kernel(IndexView<Slot
     const int k = rp.k, H = rp.step;
     // one chunk for the whole workgroup (all but a handful of workgroups): staged window
     const int c0 = chunk_of_uniform(rp.ch, gb);
-    const bool uniform = rp.ch.pbase[c0 + 1] > g_last;
-    uint64_t s = 0, L = 0, i = 0, q = 0;
+    // (probes longer than one key word -- rare -- take the per-thread path as well)
+    const bool uniform = rp.ch.pbase[c0 + 1] > g_last && k <= kMaxKey;
+    uint64_t s = 0, L = 0, i = 0, q = 0, q2 = 0;
     uint32_t first = 0;
     const bool valid = g < rp.g_hi;
     if (uniform) {
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(kProbeBlock) void probe_count_kernel(IndexView<Slot
         s = rp.ch.start[c];
         L = rp.ch.len[c];
         i = (uint64_t)(g - rp.ch.pbase[c] + 1) * (uint64_t)H;
-        q = probe_key(ix.text, s, L, i, k, rp.reverse, rp.complement, &first);
+        q = probe_key(ix.text, s, L, i, k, rp.reverse, rp.complement, &first, &q2);
         cb.rd((uint32_t)k);
     }
     bool is_big = false;
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(kProbeBlock) void probe_count_kernel(IndexView<Slot
                 n_rej = 1;
             } else {
                 uint64_t lo, hi;
-                const bool all_occurrences = kmer_range(ix, q, lo, hi, cb);
+                const bool all_occurrences = kmer_range(ix, q, q2, lo, hi, cb);
                 const uint64_t raw = hi - lo;
                 if (!COUNT) {
                     p_lo[g] = (SlotT)lo;
@@ -2660,7 +2661,7 @@ __global__ __launch_bounds__(256) void yardstick_kernel(IndexView<SlotT> ix, Run
         uint32_t first;
         const uint64_t q = probe_key(ix.text, s, L, i, rp.k, rp.reverse, rp.complement, &first);
         uint32_t c8;
-        if (cache8_index((uint32_t)(q >> (3 * (ix.k - kCacheLen))), c8)) {
+        if (cache8_index((uint32_t)(q >> (3 * (ix.kk - kCacheLen))), c8)) {
             const uint64_t b = (uint64_t)ix.c8hi[c8] - (uint64_t)ix.c8lo[c8];
             uint64_t v = 1;
             while (v < b + 1) {

@@ -63,6 +63,42 @@ __device__ inline uint64_t upper_bound_keys(const uint64_t *__restrict__ keys, u
     return lo;
 }
 
+// Probe sizes above kMaxKey: a key word holds the first kk = 21 bases of a suffix, the remaining k2 = k - 21
+// are packed on demand from the text (bases past the end of the text count as 0, like the padding of the key
+// words).  Slots with equal key words are in suffix order, so their tails are non-decreasing.
+template <class SlotT, class Cnt = NoBytes>
+__device__ inline uint64_t tail_key(const IndexView<SlotT> &ix, uint64_t x, Cnt &&cb = Cnt()) {
+    uint64_t t = 0;
+    for (int j = 0; j < ix.k2; ++j) {
+        const uint64_t p = x + (uint64_t)ix.kk + (uint64_t)j;
+        t = (t << 3) | (p < ix.n ? base_code(ix.text[p]) : 0u);
+    }
+    cb.rd((uint32_t)ix.k2);
+    return t;
+}
+
+// [lo,hi): slots whose key word equals the probe's -> the slots whose tail equals q2 as well
+template <class SlotT, class Cnt = NoBytes>
+__device__ inline void refine_tail(const IndexView<SlotT> &ix, uint64_t q2, uint64_t &lo, uint64_t &hi,
+                                   Cnt &&cb = Cnt()) {
+    if (!ix.k2 || lo >= hi) return;
+    uint64_t a = lo, b = hi;
+    while (a < b) {  // first slot with tail >= q2
+        const uint64_t mid = a + ((b - a) >> 1);
+        cb.rd(sizeof(SlotT));
+        if (tail_key(ix, (uint64_t)ix.sa[mid], cb) < q2) a = mid + 1; else b = mid;
+    }
+    const uint64_t l = a;
+    b = hi;
+    while (a < b) {  // first slot with tail > q2
+        const uint64_t mid = a + ((b - a) >> 1);
+        cb.rd(sizeof(SlotT));
+        if (tail_key(ix, (uint64_t)ix.sa[mid], cb) <= q2) a = mid + 1; else b = mid;
+    }
+    lo = l;
+    hi = a;
+}
+
 // dense index of an 8-mer over the 5-letter alphabet in code order (A,C,G,N,T)
 __device__ inline bool cache8_index(uint32_t pre24, uint32_t &idx) {
     uint32_t v = 0;
@@ -88,9 +124,9 @@ __device__ inline bool in_tail_list(const IndexView<SlotT> &ix, uint32_t pre24) 
 // (reference src/searcher.rs:164-170 + superslice equal_range_by): comparator
 // says Less for suffixes shorter than k although they may sort Greater.
 template <class SlotT, class Cnt = NoBytes>
-__device__ inline void kmer_range_tail(const IndexView<SlotT> &ix, uint64_t q, uint64_t &lo,
+__device__ inline void kmer_range_tail(const IndexView<SlotT> &ix, uint64_t q, uint64_t q2, uint64_t &lo,
                                        uint64_t &hi, Cnt &&cb = Cnt()) {
-    uint32_t pre24 = (uint32_t)(q >> (3 * (ix.k - kCacheLen)));
+    uint32_t pre24 = (uint32_t)(q >> (3 * (ix.kk - kCacheLen)));
     uint32_t c8;
     if (!cache8_index(pre24, c8)) {  // cannot happen for validated text
         lo = hi = 0;
@@ -108,7 +144,10 @@ __device__ inline void kmer_range_tail(const IndexView<SlotT> &ix, uint64_t q, u
         cb.rd(sizeof(SlotT) + 8);
         if (x + (uint64_t)ix.k > ix.n) return -1;
         uint64_t kv = ix.keys[r];
-        return kv < q ? -1 : (kv > q ? 1 : 0);
+        if (kv != q) return kv < q ? -1 : 1;
+        if (!ix.k2) return 0;
+        const uint64_t t = tail_key(ix, x, cb);
+        return t < q2 ? -1 : (t > q2 ? 1 : 0);
     };
     uint64_t b0 = 0, b1 = 0;
     while (size > 1) {
@@ -133,7 +172,7 @@ __device__ inline void kmer_range_tail(const IndexView<SlotT> &ix, uint64_t q, u
 // the set of all occurrences).
 template <class SlotT>
 __device__ inline bool is_tail_corner(const IndexView<SlotT> &ix, uint64_t q) {
-    return ix.n_tail8 && in_tail_list(ix, (uint32_t)(q >> (3 * (ix.k - kCacheLen))));
+    return ix.n_tail8 && in_tail_list(ix, (uint32_t)(q >> (3 * (ix.kk - kCacheLen))));
 }
 
 // --trim index (reference src/bin/asgart.rs:142-148): exactly the reference's two steps -- the 8-mer
@@ -141,10 +180,10 @@ __device__ inline bool is_tail_corner(const IndexView<SlotT> &ix, uint64_t q) {
 // inside that bucket: plain bounds over the keys when the bucket is clean, the step-by-step replay of
 // equal_range_by when it holds one of the out-of-place suffixes.
 template <class SlotT, class Cnt = NoBytes>
-__device__ inline void kmer_range_trim(const IndexView<SlotT> &ix, uint64_t q, uint64_t &lo,
+__device__ inline void kmer_range_trim(const IndexView<SlotT> &ix, uint64_t q, uint64_t q2, uint64_t &lo,
                                        uint64_t &hi, Cnt &&cb = Cnt()) {
     uint32_t c8;
-    if (!cache8_index((uint32_t)(q >> (3 * (ix.k - kCacheLen))), c8)) {
+    if (!cache8_index((uint32_t)(q >> (3 * (ix.kk - kCacheLen))), c8)) {
         lo = hi = 0;
         return;
     }
@@ -153,27 +192,28 @@ __device__ inline void kmer_range_trim(const IndexView<SlotT> &ix, uint64_t q, u
     bool dirty = false;
     for (int j = 0; j < ix.n_bad; ++j) dirty |= ix.bad[j] >= L && ix.bad[j] < R;
     if (dirty) {
-        kmer_range_tail(ix, q, lo, hi, cb);
+        kmer_range_tail(ix, q, q2, lo, hi, cb);
         return;
     }
     lo = lower_bound_keys(ix.keys, L, R, q, cb);
     hi = upper_bound_keys(ix.keys, lo, R, q, cb);
+    refine_tail(ix, q2, lo, hi, cb);
 }
 
 template <class SlotT, class Cnt = NoBytes>
-__device__ inline bool kmer_range(const IndexView<SlotT> &ix, uint64_t q, uint64_t &lo,
+__device__ inline bool kmer_range(const IndexView<SlotT> &ix, uint64_t q, uint64_t q2, uint64_t &lo,
                                   uint64_t &hi, Cnt &&cb = Cnt()) {
     if (ix.trim) {
-        kmer_range_trim(ix, q, lo, hi, cb);
+        kmer_range_trim(ix, q, q2, lo, hi, cb);
         return false;  // the interval need not hold the probe's own position
     }
     if (is_tail_corner(ix, q)) {
-        kmer_range_tail(ix, q, lo, hi, cb);
+        kmer_range_tail(ix, q, q2, lo, hi, cb);
         return false;
     }
     uint64_t lo0 = 0, hi0 = ix.n_sa;
     uint32_t p;
-    if (prefix_index(q, ix.k, ix.d, p)) {
+    if (prefix_index(q, ix.kk, ix.d, p)) {
         lo0 = ix.ptab[p];
         hi0 = ix.ptab[p + 1];
         cb.rd(2 * sizeof(SlotT));
@@ -195,6 +235,7 @@ __device__ inline bool kmer_range(const IndexView<SlotT> &ix, uint64_t q, uint64
     }
     lo = l;
     hi = h;
+    refine_tail(ix, q2, lo, hi, cb);
     return true;
 }
 
@@ -236,29 +277,21 @@ __device__ inline uint64_t transform_key(uint64_t q, int k, bool reverse, bool c
 // key of the probe at needle-local offset i of chunk (s, L) under the run's
 // orientation: needle = chunk | complemented | reversed (reference
 // src/bin/asgart.rs:206-218), probe = needle[i..i+k].  *first = first base code.
+// Probes longer than kMaxKey: the key word is the first kMaxKey bases, *q2 the packed rest.
 __device__ inline uint64_t probe_key(const uint8_t *__restrict__ text, uint64_t s, uint64_t L,
                                      uint64_t i, int k, bool reverse, bool complement,
-                                     uint32_t *first) {
-    uint64_t q = 0;
+                                     uint32_t *first, uint64_t *q2 = nullptr) {
+    uint64_t q = 0, t = 0;
     uint32_t f = 0;
-    if (!reverse) {
-        const uint8_t *p = text + s + i;
-        for (int j = 0; j < k; ++j) {
-            uint32_t c = base_code(p[j]);
-            if (complement) c = comp_code(c);
-            if (j == 0) f = c;
-            q = (q << 3) | c;
-        }
-    } else {
-        const uint8_t *p = text + s + L - 1 - i;
-        for (int j = 0; j < k; ++j) {
-            uint32_t c = base_code(*(p - j));
-            if (complement) c = comp_code(c);
-            if (j == 0) f = c;
-            q = (q << 3) | c;
-        }
+    const uint8_t *p = reverse ? text + s + L - 1 - i : text + s + i;
+    for (int j = 0; j < k; ++j) {
+        uint32_t c = base_code(reverse ? *(p - j) : p[j]);
+        if (complement) c = comp_code(c);
+        if (j == 0) f = c;
+        if (j < kMaxKey) q = (q << 3) | c; else t = (t << 3) | c;
     }
     *first = f;
+    if (q2) *q2 = t;
     return q;
 }
 

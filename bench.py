@@ -216,6 +216,8 @@ def main():
                 dt = float(v.item())
             mode_probe_ms[m] = round(dt * 1e3, 2)
         mode = min(mode_probe_ms, key=mode_probe_ms.get)
+    elif mode != "back_to_back":
+        issue(mode)   # untimed: a forced concurrent mode allocates its second call context here, not in the timed region
     sequential = mode == "back_to_back"
 
     sync()

@@ -113,6 +113,12 @@ BATTERY = {
     "k12": dict(lens=(120_000,), seed=16, gen=dict(alu_frac=0.05), cli=dict(k=12, gap=50)),
     "k21_odd": dict(lens=(200_000,), seed=17, gen=dict(alu_frac=0.05), cli=dict(k=21, gap=33)),
     "k9_gap0": dict(lens=(60_000,), seed=18, gen=dict(alu_frac=0.02), cli=dict(k=9, gap=0, min_length=200)),
+    # probes longer than one 63-bit key word (21 bases): key word + tail compared through the text
+    "k22": dict(lens=(200_000,), seed=21, gen=dict(alu_frac=0.1, alu_div=(0.0, 0.02)), cli=dict(k=22, gap=60)),
+    "k31_odd": dict(lens=(250_000,), seed=22, gen=dict(alu_frac=0.15, alu_div=(0.0, 0.01), sat_per_record=2,
+                                                       sat_copies=(50, 300)), cli=dict(k=31, gap=100)),
+    "k42": dict(lens=(300_000, 100_000), seed=23, gen=dict(alu_frac=0.2, alu_div=(0.0, 0.01)),
+                cli=dict(k=42, gap=200, min_length=500)),
     "masked": dict(lens=(300_000, 200_000), seed=19, gen=dict(alu_frac=0.2), skip_masked=True),
 }
 
@@ -199,6 +205,44 @@ def test_tail_corner_on_gpu(hiplib):
                 assert np.array_equal(offs, eo) and np.array_equal(sds, es)
 
 
+@pytest.mark.parametrize("k", [22, 29, 42])
+def test_long_probes_search_and_tail_corner(hiplib, k, monkeypatch):
+    """Probe sizes 22..42 (the reference takes any k >= 8, src/bin/asgart.rs:564-631): Searcher::search against
+    the oracle for patterns from the text, random patterns, patterns that differ from a text k-mer only in their
+    last bases (same key word, different tail) and the text-tail corner; then whole runs, also with 64-bit slots."""
+    import random
+
+    rng = random.Random(k)
+    core = bytes(rng.choice(b"ACGT") for _ in range(3000))
+    rep = bytes(rng.choice(b"ACGT") for _ in range(300))
+    motif = b"ACGTTGCAAC"
+    text = core[:700] + rep + motif + b"A" * 40 + core[700:1500] + rep[:150] + b"G" + rep[151:] + core[1500:] + rep + motif
+    strand = text + b"$"
+    oidx = oracle.Index.build(strand)
+    for wide in (0, 1):
+        monkeypatch.setenv("ASGART_FORCE_WIDE", str(wide))
+        with asgart_amd.Index(strand, oidx.sa) as idx:
+            s = asgart_amd.Searcher(idx)
+            pats = [text[p:p + k] for p in range(0, len(text) - k, 7)]
+            pats += [bytes(rng.choice(b"ACGT") for _ in range(k)) for _ in range(300)]
+            for p0 in range(690, 1050, 5):   # same first 21 bases as a text k-mer, another tail
+                t = bytearray(text[p0:p0 + k])
+                t[rng.randrange(21, k)] = rng.choice(b"ACGT")
+                pats.append(bytes(t))
+            pats += [motif + b"A" * (k - 10), motif + b"T" * (k - 10), (motif + rep)[:k], (motif + b"A" * 40)[:k]]
+            for p, (lo, hi) in zip(pats, s.search_ranges(pats)):
+                exp, (elo, ehi) = oidx.search(p)
+                assert hi - lo == len(exp), p
+                if len(exp):
+                    assert np.array_equal(idx.sa_read(lo, hi).astype(np.uint64), exp), p
+            for r, c in MODES:
+                st = asgart_amd.RunSettings.from_cli(k=k, gap=50, min_length=60, reverse=r, complement=c)
+                offs, sds = idx.search_duplications_raw([(0, len(text))], st)
+                eo, es = oidx.run_raw([(0, len(text))], oracle.make_settings(k=k, gap=50, min_length=60, reverse=r, complement=c))
+                assert np.array_equal(offs, eo) and np.array_equal(sds, es), (k, r, c)
+                assert len(es) > 0 or r or c
+
+
 def test_errors_on_gpu(hiplib):
     with pytest.raises(asgart_amd.AsgartError) as e:
         asgart_amd.Index(b"ACGTXACGT$")
@@ -208,7 +252,9 @@ def test_errors_on_gpu(hiplib):
         with pytest.raises(asgart_amd.AsgartError):
             idx.search_duplications_raw([(0, 401)], asgart_amd.RunSettings.from_cli())     # covers '$'
         with pytest.raises(asgart_amd.AsgartError):
-            idx.search_duplications_raw([(0, 400)], asgart_amd.RunSettings.from_cli(k=30))  # k > 21
+            idx.search_duplications_raw([(0, 400)], asgart_amd.RunSettings.from_cli(k=43))  # k > 42
+        with pytest.raises(asgart_amd.AsgartError):
+            idx.search_duplications_raw([(0, 400)], asgart_amd.RunSettings.from_cli(k=7))   # k < 8 (searcher.rs:95-97)
         offs, sds = idx.search_duplications_raw([], asgart_amd.RunSettings.from_cli())
         assert len(offs) == 1 and len(sds) == 0
         offs, sds = idx.search_duplications_raw([(0, 25)], asgart_amd.RunSettings.from_cli(min_length=10))
@@ -532,6 +578,33 @@ def test_trim_matches_oracle(hiplib, window, build_on_gpu):
             idx.check_sa()
     with pytest.raises(asgart_amd.AsgartError):
         asgart_amd.Index(pr.data, None, trim=(100, n + 5))      # end past the '$': not a validated trim
+
+
+@pytest.mark.parametrize("k", [25, 40])
+def test_trim_with_long_probes(hiplib, k):
+    """--trim and a probe longer than one key word together: the literal bisection replay compares key word + tail."""
+    pr, cli = _battery_case("long_sds")
+    n = len(pr.data)
+    rng = np.random.default_rng(k)
+    trim = prep.validate_trim((int(rng.integers(0, n // 3)), int(rng.integers(n // 2, n - 100)) | 1), n)
+    oidx = oracle.Index.build_trim(pr.data, *trim)
+    with asgart_amd.Index(pr.data, None, trim=trim) as idx:
+        s = asgart_amd.Searcher(idx)
+        text = pr.data
+        pats = [bytes(text[p:p + k]) for p in rng.integers(0, n - 50, size=1000)]
+        pats += [bytes(text[p:p + k]) for p in range(max(0, trim[1] - 3 * k), min(n - k - 1, trim[1] + 10))]
+        pats = [p for p in pats if b"$" not in p]
+        for p, (lo, hi) in zip(pats, s.search_ranges(pats)):
+            exp, _ = oidx.search(p)
+            assert hi - lo == len(exp), p
+            if len(exp):
+                assert np.array_equal(idx.sa_read(lo, hi).astype(np.uint64), exp)
+        for reverse, complement in ((False, False), (True, True)):
+            st = asgart_amd.RunSettings.from_cli(k=k, reverse=reverse, complement=complement)
+            offs, sds = idx.search_duplications_raw(pr.chunks, st)
+            eoffs, esds = oidx.run_raw(pr.chunks, oracle.make_settings(k=k, reverse=reverse, complement=complement), threads=4)
+            assert np.array_equal(offs, eoffs) and np.array_equal(sds, esds), (k, reverse)
+            assert len(esds) > 0 or reverse
 
 
 def test_golden_trim_kats_on_gpu(hiplib):

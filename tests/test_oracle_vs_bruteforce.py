@@ -45,7 +45,7 @@ def test_sa_cache_search(seed):
         elo, ehi = B.cache_entry(text, sa, p8)
         assert hi - lo == ehi - elo and (hi == lo or (lo, hi) == (elo, ehi))
     for _ in range(60):
-        k = rng.choice([8, 12, 20, 21])
+        k = rng.choice([8, 12, 20, 21, 22, 30, 42])
         p = rng.randrange(0, max(1, len(text) - k - 1))
         pat = text[p:p + k]
         if len(pat) < k or b"$" in pat[:8]:
@@ -72,6 +72,24 @@ def test_run_matches_bruteforce(seed, mode):
     idx = oracle.Index.build(strand)
     st = oracle.make_settings(k=k, gap=gap, min_length=min_len, max_cardinality=card,
                               reverse=mode[0], complement=mode[1])
+    assert idx.run(chunks, st) == exp
+
+
+@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("mode", [(False, False), (True, True)])
+def test_run_with_long_probes_matches_bruteforce(seed, mode):
+    """probe sizes above 21 (one 63-bit key word of the HIP path): the oracle itself is pinned for them"""
+    rng = random.Random(3000 + seed)
+    n = rng.randint(1200, 3000)
+    text = _rand_text(rng, n)
+    strand = text + b"$"
+    chunks = B.find_chunks(text)
+    k = rng.choice([22, 25, 31, 42])
+    gap = rng.choice([0, 40, 100])
+    sa = B.suffix_array(strand)
+    exp = B.run(strand, sa, chunks, k=k, gap=gap, min_len=60, max_card=500, reverse=mode[0], complement=mode[1])
+    idx = oracle.Index.build(strand)
+    st = oracle.make_settings(k=k, gap=gap, min_length=60, max_cardinality=500, reverse=mode[0], complement=mode[1])
     assert idx.run(chunks, st) == exp
 
 

@@ -13,7 +13,7 @@ from asgart_amd import prep, synth  # noqa: E402
 
 # option defaults (asgart_amd/csrc/index.hpp: struct Options); grid<t> = 0 means "default grid"
 DEFAULTS = {"shard_lookback": 4096, "arms_kernel": 1, "prio3": 1, "kfilter_bits": 30, "long3": 4096, "long3_big": -1, "cap1": 256,
-            "test_cap_limit": -1, "test_levels": 4, "test_genbits": 22, "tier_order": 3654217}
+            "test_cap_limit": -1, "test_levels": 4, "test_genbits": 22, "tier_order": 3654217, "tier_streams": 1234563}
 
 
 def opt_name(key):  # "ASGART_GRID3" or "grid3" -> "grid3"
@@ -21,6 +21,8 @@ def opt_name(key):  # "ASGART_GRID3" or "grid3" -> "grid3"
     return key[7:] if key.startswith("asgart_") else key
 
 args = sys.argv[1:]
+PIPELINED = "--pipelined" in args   # time whole steps (RC pass first, direct pass issued at its progress signal)
+args = [a for a in args if a != "--pipelined"]
 cfg, scale = 4, 1.0
 if args and args[0].startswith("cfg"):
     cfg = int(args[0][3:]); args = args[1:]
@@ -37,7 +39,24 @@ for conf in configs:
         idx.set_option(opt_name(k_), int(v))
     line = []
     sig = hashlib.sha1()
-    for st in settings:
+    if PIPELINED:
+        import numpy as np
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=1)
+        times = []
+        for rep in range(int(os.environ.get("TUNE_REPS", "5"))):
+            t0 = time.perf_counter()
+            prog = np.zeros(len(pr.chunks), dtype=np.uint64)
+            fut = pool.submit(idx.search_duplications_raw, pr.chunks, settings[1], 0, 1, prog)
+            while not fut.done() and not prog.any():
+                time.sleep(0.0005)
+            r0 = idx.search_duplications_raw(pr.chunks, settings[0])
+            r1 = fut.result()
+            times.append((time.perf_counter() - t0) * 1e3)
+        for r in (r0, r1):
+            sig.update(r[0].tobytes()); sig.update(r[1].tobytes())
+        line.append("step min %.1f median %.1f ms" % (min(times[1:]), sorted(times[1:])[len(times[1:]) // 2]))
+    for st in ([] if PIPELINED else settings):
         best = None
         for rep in range(2):
             t0 = time.perf_counter()
