@@ -75,6 +75,9 @@ class Stats(C.Structure):
 
 _lib: Optional[C.CDLL] = None
 
+# see the load-time note in csrc/index.hip: one hardware queue per tier stream (effective before the first HIP call)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 
 def load_library() -> C.CDLL:
     """dlopen libasgart_hip.so; raises (never falls back) when it is missing."""

@@ -9,10 +9,18 @@
 #include <algorithm>
 #include <cctype>
 #include <chrono>
+#include <cstdlib>
 
 namespace asgart {
 
 static thread_local char g_err[512] = "";
+
+// Load-time runtime default.  The extension tiers of one call run on six HIP streams (twelve with two calls in
+// flight); ROCm maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and kernels of streams that
+// share a queue run one after the other.  Ask for 8 unless the host chose a value itself.  It takes effect when
+// this library is loaded before the process's first HIP call; measured on the GRCh38-shaped
+// workload: 441 -> 421 ms per step back to back, chr1-shaped 40 -> 31 ms.
+__attribute__((constructor)) static void runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
 
 void set_error(const char *fmt, ...) {
     va_list ap;

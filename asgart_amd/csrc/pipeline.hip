@@ -232,7 +232,8 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
     // ---- K2: scans + segmentation ----------------------------------------------
     scan_reduce_kernel<<<n_blk, kScanBlock, 0, s>>>(rp, p_filt, blk);
     scan_mid_kernel<<<1, 1024, 0, s>>>(blk, n_blk, d_ctr);
-    scan_down_kernel<<<n_blk, kScanBlock, 0, s>>>(rp, p_filt, p_raw, blk, row_off, seg_list, d_ctr);
+    scan_down_kernel<<<std::min<uint32_t>(n_blk, 256u * 3u * 2u), kScanBlock, 0, s>>>(rp, p_filt, p_raw, blk, n_blk, row_off,
+                                                                                     seg_list, d_ctr);
     HIP_TRY(hipEventRecord(cx.ev[2], s));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, sizeof(h_ctr), hipMemcpyDeviceToHost, s));
@@ -352,8 +353,13 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                 rp, p_filt, row_off, hits, hit_flag, p_raw, seg_list, d_ctr + CT_SEG, kbuf, vbuf, pp, d_ctr);
             p_nflag = p_raw;  // rewritten by the pre-pass: flagged hits per probe
         } else {
-            seg_stats_kernel<<<(unsigned)std::min<uint64_t>(n_seg, 256ull * 32ull), 64, 0, s>>>(
-                rp, p_filt, seg_list, d_ctr + CT_SEG, kbuf, vbuf, pp, d_ctr);
+            // one segment per lane for the first kLaneWalk probes, the longer ones wave by wave (their list
+            // borrows the overflow lists' buffer, which the tiers only use afterwards)
+            uint32_t *long_list = w.ovf_list.as<uint32_t>();
+            seg_stats_lanes_kernel<<<(unsigned)std::min<uint64_t>((n_seg + 63) / 64, 256ull * 9ull * 2ull), 64, 0, s>>>(
+                rp, p_filt, seg_list, d_ctr + CT_SEG, kbuf, vbuf, pp, long_list, d_ctr);
+            seg_stats_kernel<<<(unsigned)std::min<uint64_t>(n_seg, 256ull * 16ull), 64, 0, s>>>(
+                rp, p_filt, seg_list, d_ctr + CT_LONGSEG, long_list, kbuf, vbuf, pp, d_ctr);
         }
         HIP_TRY(hipGetLastError());
         const uint32_t *order = nullptr;
@@ -369,7 +375,8 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             seg_off[t + 1] = seg_off[t] + n_t[t];
         }
         if (opt.debug) {
-            fprintf(stderr, "[asgart] segments per tier:");
+            fprintf(stderr, "[asgart] %llu segments, %llu walked wave by wave; per tier:", (unsigned long long)n_seg,
+                    (unsigned long long)h_ctr[CT_LONGSEG]);
             for (int t = 0; t < kTiers; ++t) fprintf(stderr, " %llu", (unsigned long long)n_t[t]);
             fprintf(stderr, "\n");
         }

@@ -45,6 +45,7 @@ enum Counter {
     // 16..33 and 56..67: per-phase cycle sums of the diagnostic build (-DASGART_PROFILE_EXTEND)
     CT_ALG_BYTES = 68,  // accounting pass: bytes the probe-search kernels move by design
     CT_FLT_REJECTED,    // accounting pass: probes answered by the presence filter alone
+    CT_LONGSEG,         // placement: segments the lane-per-segment walk handed to the wave-per-segment kernel
     CT_HIST_PEAK = 72,   // diagnostic build: log2 histograms per launch (16 bins each)
     CT_HIST_PROBES = 88,
     CT_N1 = 104,       // list lengths of the extension tiers 1..kTiers (kTiers entries)
@@ -501,10 +502,17 @@ __global__ __launch_bounds__(1024) void scan_mid_kernel(ScanEl *__restrict__ blk
     }
 }
 
+// Down-sweep: row offsets, segment starts and the per-call statistics.  Workgroups are persistent (tile =
+// blockIdx.x, + gridDim.x, ...): the statistics stay in registers across tiles and the segment starts in LDS, so a
+// workgroup issues its handful of global atomics once, not per tile -- same-address global atomics run at only
+// ~88 per microsecond chip-wide, and with one workgroup per tile (150 K tiles x 6 counters in one cache line at
+// 3.1 Gbp) they, not the 5 GB the kernel streams, set its duration.
+constexpr int kStartCap = 2 * kScanTile;  // a tile adds at most kScanTile starts (one-probe chunks)
+
 __global__ __launch_bounds__(kScanBlock) void scan_down_kernel(RunParams rp,
                                                                const uint32_t *__restrict__ p_filt,
                                                                const uint32_t *__restrict__ p_raw,
-                                                               const ScanEl *__restrict__ blk,
+                                                               const ScanEl *__restrict__ blk, uint32_t n_blk,
                                                                unsigned long long *__restrict__ row_off,
                                                                uint32_t *__restrict__ seg_list,
                                                                unsigned long long *__restrict__ ctr) {
@@ -513,89 +521,95 @@ __global__ __launch_bounds__(kScanBlock) void scan_down_kernel(RunParams rp,
     __shared__ uint32_t s_f[kScanTile];
     __shared__ uint8_t s_first[kScanTile];
     __shared__ unsigned long long s_row[kScanTile];
-    __shared__ uint32_t s_start[kScanTile];
+    __shared__ uint32_t s_start[kStartCap];
     __shared__ uint32_t s_nstart;
     __shared__ unsigned long long s_gbase;
     if (threadIdx.x < 5) sh_stat[threadIdx.x] = 0;
     if (threadIdx.x == 0) s_nstart = 0;
-    ScanEl items[kScanItems];
-    const uint32_t tile_g0 = rp.g_lo + blockIdx.x * (uint32_t)kScanTile;
-    const uint32_t i0 = threadIdx.x * kScanItems;
-    const uint32_t g0 = tile_g0 + i0;
-    stage_scan_tile(rp, p_filt, tile_g0, s_f, s_first);
-    ScanEl agg = load_thread_items(s_f, s_first, items);
-    ScanEl total;
-    ScanEl excl = block_exclusive_scan(agg, sh, &total);
-    ScanEl run = scan_combine(blk[blockIdx.x], excl);
-    if (rp.init_unknown) {
-        // Window starts mid-chunk: prepend "state unknown" (bit2).  It is cleared by a chunk
-        // start or a hit-probe; while set, `c` is only a lower bound of the quiet run.
-        ScanEl init{0ull, 0u, 4u};
-        ScanEl r2 = scan_combine(init, run);
-        r2.flags = (r2.flags & 3u) | ((run.flags & 3u) ? 0u : 4u);
-        run = r2;
-    }
     unsigned long long st_n = 0, st_card = 0, st_hit = 0, st_raw = 0, st_searched = 0;
     const int lane = threadIdx.x & 63;
-    for (int a = 0; a < kScanItems; ++a) {
-        const uint32_t g = g0 + a;
-        const bool valid = g < rp.g_hi;
-        bool start = false;
-        if (valid) {
-            const uint32_t f = s_f[i0 + a];
-            s_row[i0 + a] = run.hits;
-            const bool hit = f < kPending && f > 0;
-            if (f == kSkipN) ++st_n;
-            else {
-                ++st_searched;
-                if (f == kSkipCard) ++st_card;
-                else if (hit) ++st_hit;
-            }
-            if (hit && g >= rp.own_lo && g < rp.own_hi) {
-                const bool chunk_first = items[a].flags & 2u;
-                const bool has_before = !chunk_first && (run.flags & 1u);
-                const bool unknown = !chunk_first && (run.flags & 4u);
-                if (unknown && run.c < rp.tstar) atomicAdd(&ctr[CT_AMBIG], 1ull);
-                start = !has_before || run.c >= rp.tstar;
-            }
-            {
-                const uint32_t keep_unknown = (run.flags & 4u) && !(items[a].flags & 3u) ? 4u : 0u;
-                run = scan_combine(run, items[a]);
-                run.flags = (run.flags & 3u) | keep_unknown;
-            }
-        }
-        // segment starts are collected per workgroup in LDS (order is irrelevant: families are
-        // sorted by (start probe, ordinal) on the host) and appended with ONE global atomic per
-        // workgroup: same-address global atomics run at only ~88 per microsecond chip-wide
-        const unsigned long long m = __ballot(start);
-        if (m) {
-            const int leader = __ffsll((long long)m) - 1;
-            uint32_t base = 0;
-            if (lane == leader) base = atomicAdd(&s_nstart, (uint32_t)__popcll(m));
-            base = __shfl(base, leader);
-            if (start) s_start[base + __popcll(m & ((1ull << lane) - 1ull))] = g;
-        }
-    }
-    __syncthreads();
-    {
+    const uint32_t i0 = threadIdx.x * kScanItems;
+    // (block-uniform) append the collected segment starts: order is irrelevant, families are sorted by
+    // (start probe, ordinal) afterwards
+    auto flush_starts = [&]() {
         const uint32_t ns = s_nstart;
         if (ns) {
             if (threadIdx.x == 0) s_gbase = atomicAdd(&ctr[CT_SEG], (unsigned long long)ns);
             __syncthreads();
             const unsigned long long gb = s_gbase;
             for (uint32_t idx = threadIdx.x; idx < ns; idx += kScanBlock) seg_list[gb + idx] = s_start[idx];
+            __syncthreads();
+            if (threadIdx.x == 0) s_nstart = 0;
+            __syncthreads();
         }
-    }
-    if (g0 < rp.g_hi && g0 + kScanItems >= rp.g_hi) row_off[rp.g_hi] = run.hits;
-    __syncthreads();
-    // coalesced write-out of the row offsets and coalesced read of the interval sizes (stats)
-    for (uint32_t idx = threadIdx.x; idx < (uint32_t)kScanTile; idx += kScanBlock) {
-        const uint32_t g = tile_g0 + idx;
-        if (g < rp.g_hi) {
-            row_off[g] = s_row[idx];
-            if (s_f[idx] != kSkipN) st_raw += p_raw[g];
+    };
+    for (uint32_t tile = blockIdx.x; tile < n_blk; tile += gridDim.x) {
+        ScanEl items[kScanItems];
+        const uint32_t tile_g0 = rp.g_lo + tile * (uint32_t)kScanTile;
+        const uint32_t g0 = tile_g0 + i0;
+        stage_scan_tile(rp, p_filt, tile_g0, s_f, s_first);
+        ScanEl agg = load_thread_items(s_f, s_first, items);
+        ScanEl total;
+        ScanEl excl = block_exclusive_scan(agg, sh, &total);
+        ScanEl run = scan_combine(blk[tile], excl);
+        if (rp.init_unknown) {
+            // Window starts mid-chunk: prepend "state unknown" (bit2).  It is cleared by a chunk
+            // start or a hit-probe; while set, `c` is only a lower bound of the quiet run.
+            ScanEl init{0ull, 0u, 4u};
+            ScanEl r2 = scan_combine(init, run);
+            r2.flags = (r2.flags & 3u) | ((run.flags & 3u) ? 0u : 4u);
+            run = r2;
         }
+        for (int a = 0; a < kScanItems; ++a) {
+            const uint32_t g = g0 + a;
+            const bool valid = g < rp.g_hi;
+            bool start = false;
+            if (valid) {
+                const uint32_t f = s_f[i0 + a];
+                s_row[i0 + a] = run.hits;
+                const bool hit = f < kPending && f > 0;
+                if (f == kSkipN) ++st_n;
+                else {
+                    ++st_searched;
+                    if (f == kSkipCard) ++st_card;
+                    else if (hit) ++st_hit;
+                }
+                if (hit && g >= rp.own_lo && g < rp.own_hi) {
+                    const bool chunk_first = items[a].flags & 2u;
+                    const bool has_before = !chunk_first && (run.flags & 1u);
+                    const bool unknown = !chunk_first && (run.flags & 4u);
+                    if (unknown && run.c < rp.tstar) atomicAdd(&ctr[CT_AMBIG], 1ull);
+                    start = !has_before || run.c >= rp.tstar;
+                }
+                {
+                    const uint32_t keep_unknown = (run.flags & 4u) && !(items[a].flags & 3u) ? 4u : 0u;
+                    run = scan_combine(run, items[a]);
+                    run.flags = (run.flags & 3u) | keep_unknown;
+                }
+            }
+            const unsigned long long m = __ballot(start);
+            if (m) {
+                const int leader = __ffsll((long long)m) - 1;
+                uint32_t base = 0;
+                if (lane == leader) base = atomicAdd(&s_nstart, (uint32_t)__popcll(m));
+                base = __shfl(base, leader);
+                if (start) s_start[base + __popcll(m & ((1ull << lane) - 1ull))] = g;
+            }
+        }
+        if (g0 < rp.g_hi && g0 + kScanItems >= rp.g_hi) row_off[rp.g_hi] = run.hits;
+        __syncthreads();
+        // coalesced write-out of the row offsets and coalesced read of the interval sizes (stats)
+        for (uint32_t idx = threadIdx.x; idx < (uint32_t)kScanTile; idx += kScanBlock) {
+            const uint32_t g = tile_g0 + idx;
+            if (g < rp.g_hi) {
+                row_off[g] = s_row[idx];
+                if (s_f[idx] != kSkipN) st_raw += p_raw[g];
+            }
+        }
+        __syncthreads();  // the staged tile is overwritten by the next one
+        if (s_nstart > (uint32_t)(kStartCap - kScanTile)) flush_starts();
     }
+    flush_starts();
     // wave reduction first: 256 same-address LDS atomics per counter would serialise
     for (int off = 32; off > 0; off >>= 1) {
         st_n += __shfl_down(st_n, off);
@@ -1512,19 +1526,95 @@ __global__ __launch_bounds__(64) void seg_prepass_kernel(RunParams rp, const uin
 }
 
 // Placement only (continuation filter off): the same walk and window bound as the pre-pass, with
-// no hit accesses at all.  One wave per segment.
+// no hit accesses at all.
+//
+// Most segments are a handful of probes long (3.4 M segments per GRCh38-shaped step, a dozen probes each), and a
+// wave per segment spends its time on the per-segment chain of dependent loads.  So the first kernel walks ONE
+// SEGMENT PER LANE, 64 segments per wave side by side, for at most kLaneWalk probes; the few segments that are
+// longer go to a list and the wave-per-segment kernel below (64 probes per round trip) finishes them.
+constexpr uint32_t kLaneWalk = 256;
+
+__global__ __launch_bounds__(64) void seg_stats_lanes_kernel(RunParams rp, const uint32_t *__restrict__ p_filt,
+                                                             const uint32_t *__restrict__ seg_list,
+                                                             const unsigned long long *__restrict__ n_seg_ptr,
+                                                             uint32_t *__restrict__ keys,
+                                                             uint32_t *__restrict__ vals, PlaceParams pp,
+                                                             uint32_t *__restrict__ long_list,
+                                                             unsigned long long *__restrict__ ctr) {
+    __shared__ uint32_t s_ring[65 * 64];  // [slot][lane]: hit counts of the last TW + 1 processed probes
+    const uint32_t lane = threadIdx.x;
+    const uint64_t n_seg = *n_seg_ptr;
+    const uint32_t RW = min(rp.tstar, 64u) + 1u;
+    for (uint64_t base = (uint64_t)blockIdx.x * 64u; base < n_seg; base += (uint64_t)gridDim.x * 64u) {
+        const uint64_t sidx = base + lane;
+        const bool have = sidx < n_seg;
+        uint32_t g0 = 0, g_end = 0;
+        if (have) {
+            g0 = seg_list[sidx];
+            g_end = min(rp.ch.pbase[chunk_of(rp.ch, g0) + 1], rp.g_hi);
+        }
+        for (uint32_t r = 0; r < RW; ++r) s_ring[r * 64u + lane] = 0;
+        uint32_t quiet = 0, mx = 0, bound = 0, n_probes = 0, wsum = 0, head = 0, steps = 0, g = g0;
+        unsigned long long sum = 0;
+        bool done = !have;
+        while (!done && g < g_end && steps < kLaneWalk) {
+            const uint32_t f = p_filt[g];
+            ++g;
+            ++steps;
+            const bool hit = f >= 1u && f < kPending;
+            if (!hit && f != 0u) continue;  // skipped probes (N, cardinality) are not processed
+            if (!hit) {
+                if (++quiet >= rp.tstar) {  // t* quiet probes: every arm has been retired, the segment is over
+                    done = true;
+                    break;
+                }
+            } else {
+                quiet = 0;
+            }
+            const uint32_t v = hit ? f : 0u;
+            ++n_probes;
+            const uint32_t at = head * 64u + lane;
+            wsum += v - s_ring[at];
+            s_ring[at] = v;
+            head = head + 1u == RW ? 0u : head + 1u;
+            bound = max(bound, wsum);
+            mx = max(mx, v);
+            sum += v;
+        }
+        if (g >= g_end) done = true;
+        if (have && done) {
+            if (rp.tstar > 64u) bound = 0xFFFFFFFFu;  // no estimate for huge gap settings: largest tier
+            int tier = place_tier(bound, sum, n_probes, pp);
+            if (mx > 1 && pp.force_tier > tier) tier = min(pp.force_tier, kTiers);
+            keys[sidx] = placement_key(tier, sum, g0);
+            vals[sidx] = g0;
+        }
+        const unsigned long long lm = __ballot(have && !done);
+        if (lm) {
+            const int leader = __ffsll((long long)lm) - 1;
+            unsigned long long at = 0;
+            if ((int)lane == leader) at = atomicAdd(&ctr[CT_LONGSEG], (unsigned long long)__popcll(lm));
+            at = __shfl(at, leader);
+            if (have && !done) long_list[at + __popcll(lm & ((1ull << lane) - 1ull))] = (uint32_t)sidx;
+        }
+    }
+}
+
+// One wave per segment: the entries idx_list[0 .. *n_ptr) of the segment list (all of it when idx_list is null).
 __global__ __launch_bounds__(64) void seg_stats_kernel(RunParams rp, const uint32_t *__restrict__ p_filt,
                                                        const uint32_t *__restrict__ seg_list,
-                                                       const unsigned long long *__restrict__ n_seg_ptr,
+                                                       const unsigned long long *__restrict__ n_ptr,
+                                                       const uint32_t *__restrict__ idx_list,
                                                        uint32_t *__restrict__ keys,
                                                        uint32_t *__restrict__ vals, PlaceParams pp,
                                                        unsigned long long *__restrict__ ctr) {
     __shared__ uint32_t s_ext[64 + 64];  // [0,TW): hit counts of the previous processed probes
     const int lane = threadIdx.x;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    const uint64_t n_seg = *n_seg_ptr;
+    const uint64_t n_items = *n_ptr;
     const uint32_t TW = min(rp.tstar, 64u);
-    for (uint64_t sidx = blockIdx.x; sidx < n_seg; sidx += gridDim.x) {
+    for (uint64_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const uint64_t sidx = idx_list ? (uint64_t)idx_list[item] : item;
         const uint32_t g0 = seg_list[sidx];
         const int c = chunk_of_uniform(rp.ch, g0);
         const uint32_t g_end = min(rp.ch.pbase[c + 1], rp.g_hi);
@@ -1532,32 +1622,38 @@ __global__ __launch_bounds__(64) void seg_stats_kernel(RunParams rp, const uint3
         unsigned long long sum = 0;
         bool done = false;
         s_ext[lane] = 0;
-        __syncthreads();
+        lds_barrier();
+        // the next batch's hit counts are in flight while this one is processed: a long segment's walk is a chain
+        // of dependent round trips (64 probes each) and sets the duration of the whole launch
+        uint32_t f_next = g0 + (uint32_t)lane < g_end ? p_filt[g0 + lane] : kSkipN;
         for (uint32_t g = g0; g < g_end && !done; g += 64) {
-            const uint32_t nb = min(64u, g_end - g);
-            const uint32_t f = (uint32_t)lane < nb ? p_filt[g + lane] : kSkipN;
+            const uint32_t f = f_next;
+            f_next = g + 64u + (uint32_t)lane < g_end ? p_filt[g + 64u + lane] : kSkipN;
             const unsigned long long hm = __ballot(f >= 1u && f < kPending);
             const unsigned long long qm = __ballot(f == 0u);
+            if (!(hm | qm)) continue;  // 64 skipped probes (cardinality, N): nothing is processed, nothing changes
             unsigned long long live = ~0ull;  // probes of this batch that belong to the segment
-            uint32_t pos = 0;
-            unsigned long long rest = hm;
-            while (true) {
-                const uint32_t b = rest ? (uint32_t)(__ffsll((long long)rest) - 1) : 64u;
-                const unsigned long long range = (b >= 64 ? ~0ull : ((1ull << b) - 1ull)) &
-                                                 ~(pos >= 64 ? ~0ull : ((1ull << pos) - 1ull));
-                const uint32_t q = (uint32_t)__popcll(qm & range);
-                if (quiet + q >= rp.tstar) {
+            // The segment ends with the t*-th quiet probe in a row (skipped probes neither count nor interrupt,
+            // a hit restarts the count).  Every lane prices the quiet run that ends at its own probe -- no walk
+            // from hit to hit: in a dense array with interleaved quiet probes that scalar walk, 40-odd dependent
+            // steps per batch, was the whole cost of placing the longest segment.
+            {
+                const unsigned long long hb = hm & lt_mask;  // hits before this lane
+                const int lh = hb ? 63 - __clzll((long long)hb) : -1;
+                const unsigned long long above_lh = lh < 0 ? ~0ull : (lh == 63 ? 0ull : ~((2ull << lh) - 1ull));
+                const uint32_t run = (uint32_t)__popcll(qm & (lt_mask | (1ull << lane)) & above_lh) + (lh < 0 ? quiet : 0u);
+                const unsigned long long term = __ballot(((qm >> lane) & 1ull) && run >= rp.tstar);
+                if (term) {
+                    // the run that reaches t* starts behind the hit at lh (of the terminating lane): only the
+                    // probes up to that hit still belong to the segment
+                    const uint32_t pos = (uint32_t)(__shfl(lh, __ffsll((long long)term) - 1) + 1);
                     done = true;
-                    live = pos >= 64 ? ~0ull : ((1ull << pos) - 1ull);
-                    break;
+                    live = (1ull << pos) - 1ull;  // pos <= 63
+                } else {
+                    const int last = hm ? 63 - __clzll((long long)hm) : -1;
+                    const unsigned long long above = last < 0 ? ~0ull : (last == 63 ? 0ull : ~((2ull << last) - 1ull));
+                    quiet = (uint32_t)__popcll(qm & above) + (last < 0 ? quiet : 0u);
                 }
-                if (b >= 64) {
-                    quiet += q;
-                    break;
-                }
-                quiet = 0;
-                pos = b + 1;
-                rest &= rest - 1;
             }
             const unsigned long long procm = (hm | qm) & live;
             const bool proc = (procm >> lane) & 1ull;
@@ -1566,7 +1662,7 @@ __global__ __launch_bounds__(64) void seg_stats_kernel(RunParams rp, const uint3
             const uint32_t n_proc = (uint32_t)__popcll(procm);
             n_probes += n_proc;
             if (proc) s_ext[TW + r] = v;
-            __syncthreads();
+            lds_barrier();
             uint32_t wsum = 0;
             if (proc)
                 for (uint32_t d = 0; d <= TW; ++d) wsum += s_ext[TW + r - d];
@@ -1581,9 +1677,9 @@ __global__ __launch_bounds__(64) void seg_stats_kernel(RunParams rp, const uint3
             mx = max(mx, (uint32_t)__shfl(m, 0));
             bound = max(bound, (uint32_t)__shfl(wm, 0));
             const uint32_t keep = (uint32_t)lane < TW ? s_ext[n_proc + lane] : 0u;
-            __syncthreads();
+            lds_barrier();
             if ((uint32_t)lane < TW) s_ext[lane] = keep;
-            __syncthreads();
+            lds_barrier();
         }
         if (rp.tstar > 64u) bound = 0xFFFFFFFFu;
         if (lane == 0) {
@@ -1592,7 +1688,7 @@ __global__ __launch_bounds__(64) void seg_stats_kernel(RunParams rp, const uint3
             keys[sidx] = placement_key(tier, sum, g0);
             vals[sidx] = g0;
         }
-        __syncthreads();
+        lds_barrier();
     }
 }
 

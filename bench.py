@@ -38,6 +38,11 @@ import time
 
 import numpy as np
 
+# The extension tiers of a call run on six HIP streams (twelve with both passes of a step in flight).  ROCm maps
+# streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); kernels of streams that share a queue run one after
+# the other.  Must be set before the process's first HIP call; the library sets the same default when it is loaded.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

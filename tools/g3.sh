@@ -1,1 +1,5 @@
-timeout 1200 python3 -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "long_probes or k22 or k31 or k42 or errors or trim_with_long or searcher or k21 or k12 or tail_corner" 2>&1 | tail -15
+export TMPDIR=/tmp
+export ASGART_BENCH_MODE=back_to_back
+rocprofv3 --output-format csv --kernel-trace -d gpurun_out/tl -o run -- python3 bench.py --workload cfg4 --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/tl_bench.json 2> gpurun_out/tl_err.log
+python3 tools/timeline.py gpurun_out/tl 450 > gpurun_out/timeline_b2b.txt
+rm -rf gpurun_out/tl

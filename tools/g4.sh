@@ -1,8 +1,3 @@
-export TMPDIR=/tmp
-python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-bash tools/profile_round.sh r02 cfg4 2>&1 | grep -E "rc=|summarised"
-bash tools/profile_round.sh r02 cfg3 2>&1 | grep -E "rc=|summarised"
-bash tools/profile_round.sh r02 cfg2 2>&1 | grep -E "rc=|summarised"
-python bench.py --workload cfg1 > gpurun_out/r02_cfg1_bench.json 2> gpurun_out/r02_cfg1_bench_err.log; echo cfg1 rc=$?
-python bench.py --workload cfg5 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/r02_cfg5_bench.json 2> gpurun_out/r02_cfg5_bench_err.log; echo cfg5 rc=$?
-python __graft_entry__.py smoke 2>&1 | tail -3
+timeout 1500 python3 -m pytest tests -x -q -m gpu 2>&1 | tail -3
+timeout 600 python3 bench.py --workload cfg4 --no-cpu-baseline 2>&1 | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('probe', d['ms_per_step'], d['config']['mode_probe_ms'], d['phases_ms_per_step'])"
+timeout 600 python3 bench.py --workload cfg3 --no-cpu-baseline 2>&1 | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('cfg3', d['ms_per_step'], d['config']['mode_probe_ms'], d['phases_ms_per_step'])"

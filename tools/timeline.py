@@ -31,7 +31,7 @@ def main():
     t0 = rows[0][0]
     for s, e, n, q, st in rows:
         d = (e - s) / 1e6
-        if d < 0.5:
+        if d < 0.1:
             continue
         print(f"{(s - t0) / 1e6:9.2f} {(e - t0) / 1e6:9.2f} {d:8.2f} q{q:>3} s{st:>3} {short(n)}")
 
