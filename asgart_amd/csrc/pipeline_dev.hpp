@@ -189,19 +189,34 @@ __global__ __launch_bounds__(kProbeBlock) void probe_count_kernel(IndexView<Slot
         q = probe_key(ix.text, s, L, i, k, rp.reverse, rp.complement, &first, &q2);
         cb.rd((uint32_t)k);
     }
-    bool is_big = false;
+    // ---- presence filter (every probe), then the lookup of the survivors ---------------------------------
+    // About four probes in five are answered by the filter.  The lookup behind it -- prefix table, key bisection,
+    // suffix-array entries -- is a chain of dependent random gathers, and a wave runs it at the speed of its
+    // slowest lane however few lanes are left: the surviving probes of the workgroup are therefore compacted
+    // (wave ballot + one LDS atomic per wave) and looked up by the first ceil(n / 64) waves with all lanes busy;
+    // the other waves retire at once and their slots go to the next workgroup, so that more full waves of
+    // gathers are in flight per CU.
+    __shared__ uint32_t s_nsurv, s_nbig;
+    __shared__ uint8_t s_surv[kProbeBlock];
+    __shared__ uint32_t s_big[kProbeBlock];
+    __shared__ unsigned long long s_bbase;
+    if (tid == 0) {  // (ordered before their first use by the barrier behind the filter tests)
+        s_nsurv = 0;
+        s_nbig = 0;
+    }
     uint32_t n_rej = 0;
+    bool survivor = false;
     if (valid) {
         if (first == 4u) {  // needle[i] == 'N'  (automaton.rs:100-102)
             if (!COUNT) p_filt[g] = kSkipN;
             cb.wr(4);
         } else {
-            bool lookup = true;
+            survivor = true;
             if (ix.flt && !is_tail_corner(ix, q)) {
                 cb.rd(8);
-                lookup = filter_test(ix.flt, ix.flt_bits, q);
+                survivor = filter_test(ix.flt, ix.flt_bits, q);
             }
-            if (!lookup) {
+            if (!survivor) {
                 // no hit possible: in the direct pass the interval is the probe itself
                 if (!COUNT) {
                     p_raw[g] = (!rp.reverse && !rp.complement) ? 1u : 0u;
@@ -209,34 +224,63 @@ __global__ __launch_bounds__(kProbeBlock) void probe_count_kernel(IndexView<Slot
                 }
                 cb.wr(8);
                 n_rej = 1;
-            } else {
-                uint64_t lo, hi;
-                const bool all_occurrences = kmer_range(ix, q, q2, lo, hi, cb);
-                const uint64_t raw = hi - lo;
-                if (!COUNT) {
-                    p_lo[g] = (SlotT)lo;
-                    p_raw[g] = (uint32_t)raw;
-                }
-                cb.wr(sizeof(SlotT) + 4);
-                if (raw <= (uint64_t)kSmallInterval) {
-                    uint32_t cnt = 0;
-                    // Direct pass: the needle is the text itself, so the probe's own position is one of
-                    // the occurrences; a single occurrence is that one, and the filter (x > i + s)
-                    // drops it -- no need to fetch the suffix-array entry.
-                    const bool only_self = all_occurrences && raw == 1 && !rp.reverse && !rp.complement;
-                    for (uint64_t r = lo; r < hi && !only_self; ++r) {
-                        cb.rd(sizeof(SlotT));
-                        cnt += keep_hit(ix.sa[r], i, s, L, rp.reverse) ? 1u : 0u;
-                    }
-                    if (!COUNT) p_filt[g] = cnt > rp.C ? kSkipCard : cnt;
-                    cb.wr(4);
-                } else {
-                    if (!COUNT) p_filt[g] = kPending;
-                    cb.wr(4 + 4);  // + its big_list entry
-                    is_big = true;
-                }
             }
         }
+    }
+    // one probe's lookup: SA interval, filtered count of a small interval (large ones go to big_list)
+    auto lookup = [&](uint32_t g_, uint64_t q_, uint64_t q2_, uint64_t i_, uint64_t s_, uint64_t L_) {
+        uint64_t lo, hi;
+        const bool all_occurrences = kmer_range(ix, q_, q2_, lo, hi, cb);
+        const uint64_t raw = hi - lo;
+        if (!COUNT) {
+            p_lo[g_] = (SlotT)lo;
+            p_raw[g_] = (uint32_t)raw;
+        }
+        cb.wr(sizeof(SlotT) + 4);
+        if (raw <= (uint64_t)kSmallInterval) {
+            uint32_t cnt = 0;
+            // Direct pass: the needle is the text itself, so the probe's own position is one of
+            // the occurrences; a single occurrence is that one, and the filter (x > i + s)
+            // drops it -- no need to fetch the suffix-array entry.
+            const bool only_self = all_occurrences && raw == 1 && !rp.reverse && !rp.complement;
+            for (uint64_t r = lo; r < hi && !only_self; ++r) {
+                cb.rd(sizeof(SlotT));
+                cnt += keep_hit(ix.sa[r], i_, s_, L_, rp.reverse) ? 1u : 0u;
+            }
+            if (!COUNT) p_filt[g_] = cnt > rp.C ? kSkipCard : cnt;
+            cb.wr(4);
+        } else {
+            if (!COUNT) {
+                p_filt[g_] = kPending;
+                s_big[atomicAdd(&s_nbig, 1u)] = g_;
+            }
+            cb.wr(4 + 4);  // + its big_list entry
+        }
+    };
+    if (uniform) {
+        const unsigned long long sm = __ballot(survivor);
+        const uint32_t lane = tid & 63u;
+        __syncthreads();  // s_nsurv = 0 is visible
+        if (sm) {
+            uint32_t base = 0;
+            if (lane == (uint32_t)(__ffsll((long long)sm) - 1)) base = atomicAdd(&s_nsurv, (uint32_t)__popcll(sm));
+            base = __shfl(base, __ffsll((long long)sm) - 1);
+            if (survivor) s_surv[base + (uint32_t)__popcll(sm & ((1ull << lane) - 1ull))] = (uint8_t)tid;
+        }
+        __syncthreads();
+        const uint32_t n_surv = s_nsurv;
+        // (the accounting pass keeps every wave: its totals are reduced by the whole workgroup below)
+        if (!COUNT && (tid & ~63u) >= n_surv) return;  // this wave has nothing to look up
+        const uint64_t i0 = i - (uint64_t)tid * (uint64_t)H;
+        for (uint32_t j = tid; j < n_surv; j += kProbeBlock) {
+            const uint32_t t = s_surv[j];
+            uint64_t qt = ((uint64_t)s_half[t] << (3 * H)) | (uint64_t)s_half[t + 1];
+            if (k & 1) qt = (qt << 3) | (uint64_t)(s_half[t + 2] >> (3 * (H - 1)));
+            lookup(gb + t, qt, 0ull, i0 + (uint64_t)t * (uint64_t)H, s, L);
+        }
+    } else {
+        __syncthreads();
+        if (survivor) lookup(g, q, q2, i, s, L);
     }
     if constexpr (COUNT) {
         // workgroup totals -> two global atomics
@@ -258,12 +302,8 @@ __global__ __launch_bounds__(kProbeBlock) void probe_count_kernel(IndexView<Slot
             if (s_tot[1]) atomicAdd(&ctr[CT_FLT_REJECTED], s_tot[1]);
         }
     } else {
-        // workgroup-aggregated append to the large-interval work list (one global atomic per group)
-        __shared__ uint32_t s_nbig, s_big[kProbeBlock];
-        __shared__ unsigned long long s_bbase;
-        if (tid == 0) s_nbig = 0;
-        __syncthreads();
-        if (is_big) s_big[atomicAdd(&s_nbig, 1u)] = g;
+        // workgroup-aggregated append to the large-interval work list (one global atomic per group); the waves
+        // still running hold every entry: nbig <= the number of survivors
         __syncthreads();
         const uint32_t nbig = s_nbig;
         if (nbig) {
@@ -342,7 +382,8 @@ __global__ __launch_bounds__(256) void big_count_kernel(IndexView<SlotT> ix, Run
                 base += 256;
                 if (base >= hi_p || cnt > rp.C) break;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {  // (the early exit makes the rounds dependent)
+                for (int u = 0; u < 4; ++u) {  // (the early exit makes the rounds dependent; requesting the next
+                                               // round ahead of the count was measured: 7.0 -> 8.2 ms, more bytes)
                     const unsigned long long r = base + 64u * u + lane;
                     x[u] = r < hi_p ? ix.sa[r] : (SlotT)0;
                 }

@@ -1,3 +1,2 @@
-timeout 1500 python3 -m pytest tests -x -q -m gpu 2>&1 | tail -3
-timeout 600 python3 bench.py --workload cfg4 --no-cpu-baseline 2>&1 | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('probe', d['ms_per_step'], d['config']['mode_probe_ms'], d['phases_ms_per_step'])"
-timeout 600 python3 bench.py --workload cfg3 --no-cpu-baseline 2>&1 | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('cfg3', d['ms_per_step'], d['config']['mode_probe_ms'], d['phases_ms_per_step'])"
+timeout 1500 python3 -m pytest tests -x -q -m gpu -k "not cfg4 and not cfg3 and not cfg5 and not wide_suffix" 2>&1 | tail -3
+ASGART_BENCH_MODE=back_to_back timeout 600 python3 bench.py --workload cfg4 --no-cpu-baseline 2>&1 | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('b2b', d['ms_per_step'], d['phases_ms_per_step'], d['roofline'])"
