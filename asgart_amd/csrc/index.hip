@@ -55,9 +55,27 @@ const OptDesc kOptions[] = {
     {"force_wide", &Options::force_wide, 0, 1},
     {"test_wide_batch", &Options::test_wide_batch, 0, 1ll << 40},
     {"kfilter_bits", &Options::kfilter_bits, 0, 34},
-    {"tier_streams", &Options::tier_streams, 1111111, 6666666},
+    {"tier_streams", &Options::tier_streams, 1111111, 7777777},
+    {"cap6_pct", &Options::cap6_pct, 100, 200},
+    {"wg_items", &Options::wg_items, 0, 1 << 30},
+    {"wg_items12", &Options::wg_items12, 0, 1 << 30},
 };
 }  // namespace
+
+// The main stream of a call context carries the chip-wide, short kernels of a call (probe search, scans, CSR
+// fill, placement, record sort) and its small copies; the extension tiers, whose persistent workgroups hold
+// their CU slots for tens of milliseconds, run on the other six.  The main stream gets the highest priority the
+// device offers: when two calls are in flight, the short kernels of one are dispatched into the first slots
+// the other's tiers give back instead of queueing behind the tiers' own backlog of workgroups.
+int32_t create_ctx_streams(SearchCtx &cx) {
+    int least = 0, greatest = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    HIP_TRY(hipStreamCreateWithPriority(&cx.stream, hipStreamNonBlocking, greatest));
+    for (hipStream_t *st : {&cx.stream2, &cx.stream3, &cx.stream4, &cx.stream5, &cx.stream6, &cx.stream7})
+        HIP_TRY(hipStreamCreateWithPriority(st, hipStreamNonBlocking, least));
+    for (auto &e : cx.ev) HIP_TRY(hipEventCreate(&e));
+    return 0;
+}
 
 int32_t option_set(Options &o, const char *name, int64_t value) {
     if (!name) {
@@ -663,9 +681,12 @@ void asgart_index_destroy(asgart_index *idx) {
         for (DevBuf *b : bufs) b->release();
         if (cx.h_pinned) (void)hipHostFree(cx.h_pinned);
         cx.h_pinned = nullptr;
+        if (cx.h_ctl) (void)hipHostFree(cx.h_ctl);
+        cx.h_ctl = nullptr;
+        cx.h_ctl_cap = 0;
         for (auto &e : cx.ev)
             if (e) (void)hipEventDestroy(e);
-        for (hipStream_t st : {cx.stream, cx.stream2, cx.stream3, cx.stream4, cx.stream5, cx.stream6})
+        for (hipStream_t st : {cx.stream, cx.stream2, cx.stream3, cx.stream4, cx.stream5, cx.stream6, cx.stream7})
             if (st) (void)hipStreamDestroy(st);
     }
     delete idx;
@@ -713,15 +734,7 @@ static int32_t index_create_impl(const uint8_t *T, int64_t n, const int64_t *SA,
     idx->wide = (uint64_t)n >= 0xFFFFFF00ull || idx->opt.force_wide != 0;
     for (auto &cx : idx->ctx) memset(&cx.stats, 0, sizeof(cx.stats));
     int32_t rc = [&]() -> int32_t {
-        for (auto &cx : idx->ctx) {
-            HIP_TRY(hipStreamCreateWithFlags(&cx.stream, hipStreamNonBlocking));
-            HIP_TRY(hipStreamCreateWithFlags(&cx.stream2, hipStreamNonBlocking));
-            HIP_TRY(hipStreamCreateWithFlags(&cx.stream3, hipStreamNonBlocking));
-            HIP_TRY(hipStreamCreateWithFlags(&cx.stream4, hipStreamNonBlocking));
-            HIP_TRY(hipStreamCreateWithFlags(&cx.stream5, hipStreamNonBlocking));
-            HIP_TRY(hipStreamCreateWithFlags(&cx.stream6, hipStreamNonBlocking));
-            for (auto &e : cx.ev) HIP_TRY(hipEventCreate(&e));
-        }
+        for (auto &cx : idx->ctx) RC_TRY(create_ctx_streams(cx));
         HIP_TRY(hipMalloc((void **)&idx->d_text, (size_t)n + 64));
         HIP_TRY(hipMemsetAsync(idx->d_text + n, 0, 64, idx->ctx[0].stream));
         HIP_TRY(hipMemcpyAsync(idx->d_text, T, (size_t)n, hipMemcpyHostToDevice, idx->ctx[0].stream));
@@ -849,11 +862,7 @@ int32_t asgart_index_clone(asgart_index *src, int32_t device, asgart_index **out
     src->acquire_all();  // the source's buffers must not change under the copy
     int32_t rc = [&]() -> int32_t {
         HIP_TRY(hipSetDevice(device));
-        for (auto &cx : idx->ctx) {
-            for (hipStream_t *st : {&cx.stream, &cx.stream2, &cx.stream3, &cx.stream4, &cx.stream5, &cx.stream6})
-                HIP_TRY(hipStreamCreateWithFlags(st, hipStreamNonBlocking));
-            for (auto &e : cx.ev) HIP_TRY(hipEventCreate(&e));
-        }
+        for (auto &cx : idx->ctx) RC_TRY(create_ctx_streams(cx));
         const size_t slot = idx->wide ? 8 : 4;
         const size_t text_bytes = (size_t)idx->n + 64, sa_bytes = ((size_t)idx->n_sa + 16) * slot;
         HIP_TRY(hipMalloc((void **)&idx->d_text, text_bytes));

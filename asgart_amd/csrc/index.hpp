@@ -111,7 +111,7 @@ namespace asgart {
 struct SearchCtx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr, stream3 = nullptr, stream4 = nullptr;  // concurrent extension tiers
-    hipStream_t stream5 = nullptr, stream6 = nullptr;
+    hipStream_t stream5 = nullptr, stream6 = nullptr, stream7 = nullptr;
     hipEvent_t ev[13] = {};
     Workspace ws;
     asgart_stats stats;
@@ -141,6 +141,28 @@ struct SearchCtx {
         *out = h_pinned;
         return 0;
     }
+    // pinned control block: the counters read back several times per call, then the chunk table.  Transfers
+    // to and from pageable memory go through a staging copy KERNEL, which needs a free CU -- with another
+    // call's persistent extension workgroups on the chip that wait was 20-30 ms per copy.
+    void *h_ctl = nullptr;
+    size_t h_ctl_cap = 0;
+    int32_t ctl(size_t bytes, void **out) {
+        if (bytes > h_ctl_cap) {
+            if (h_ctl) (void)hipHostFree(h_ctl);
+            h_ctl = nullptr;
+            h_ctl_cap = 0;
+            const size_t want = bytes + 65536;
+            if (hipHostMalloc(&h_ctl, want, hipHostMallocDefault) != hipSuccess) {
+                (void)hipGetLastError();
+                h_ctl = nullptr;
+                set_error("hipHostMalloc(%zu bytes) failed", want);
+                return ASGART_E_OOM;
+            }
+            h_ctl_cap = want;
+        }
+        *out = h_ctl;
+        return 0;
+    }
 };
 constexpr int kNumCtx = 2;
 
@@ -167,8 +189,12 @@ struct Options {
     int64_t force_wide = 0;         // tests: 64-bit slots and positions for a small text
     int64_t test_wide_batch = 0;    // tests: batch size of the 64-bit suffix sorter's doubling rounds (0: 2^29)
     int64_t kfilter_bits = 30;      // log2(bits) of the k-mer presence filter (search_dev.hpp); 0: no filter
-    int64_t tier_streams = 1234563; // digit t (from the left): the stream (1..6, 1 = the call's main stream) tier t runs on
+    int64_t wg_items = 0;           // segments a workgroup of tiers 3..7 runs before it retires (0: persistent)
+    int64_t wg_items12 = 0;         // ... work-list fetches (8 segments / 1 segment) of a tier-1 / tier-2 wave
+    int64_t cap6_pct = 140;         // tier 6 accepts segments whose arm bound is up to this percentage of its capacity
+    int64_t tier_streams = 7234563; // digit t (from the left): the stream (1..7, 1 = the call's high-priority main stream) tier t runs on
 };
+int32_t create_ctx_streams(SearchCtx &cx);  // the streams and events of one call context (current device)
 int32_t option_set(Options &o, const char *name, int64_t value);  // ASGART_E_ARG: unknown name / bad value
 void options_from_env(Options &o);
 }  // namespace asgart

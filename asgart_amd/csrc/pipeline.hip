@@ -43,7 +43,7 @@ namespace asgart {
         const auto pf_c0 = std::chrono::steady_clock::now();                                   \
         (void)hipStreamSynchronize(stream);                                                    \
         const double pf_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - pf_c0).count(); \
-        (void)hipMemcpy(h_ctr, d_ctr, sizeof(h_ctr), hipMemcpyDeviceToHost);                   \
+        (void)hipMemcpy(h_ctr, d_ctr, kCtrBytes, hipMemcpyDeviceToHost);                   \
         fprintf(stderr, "[tier %s] segments=%llu  %.2f ms\n", tag, (unsigned long long)(n), pf_ms); \
         PROF_DUMP(tag);                                                                        \
         (void)hipStreamSynchronize(s);                                                         \
@@ -97,8 +97,16 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
     const uint64_t n = (uint64_t)idx->n;
 
     // ---- chunk table -------------------------------------------------------
-    std::vector<uint64_t> h_start((size_t)n_chunks), h_len((size_t)n_chunks);
-    std::vector<uint32_t> h_pbase((size_t)n_chunks + 1);
+    // (in the call context's pinned control block: [counters | one scalar | start[nc] | len[nc] | pbase[nc + 1]])
+    constexpr size_t kCtrBytes = (size_t)CT_COUNT * 8;
+    const size_t ch_bytes = (size_t)n_chunks * 16 + ((size_t)n_chunks + 1) * 4;
+    void *ctl_p = nullptr;
+    RC_TRY(cx.ctl(kCtrBytes + ch_bytes + 16, &ctl_p));
+    unsigned long long *const h_ctr = static_cast<unsigned long long *>(ctl_p);
+    unsigned long long *const h_scalar = h_ctr + CT_COUNT;  // source of small host-to-device updates
+    uint64_t *const h_start = reinterpret_cast<uint64_t *>(static_cast<char *>(ctl_p) + kCtrBytes + 16);
+    uint64_t *const h_len = h_start + n_chunks;
+    uint32_t *const h_pbase = reinterpret_cast<uint32_t *>(h_len + n_chunks);
     uint64_t P64 = 0;
     const uint64_t text_end = (idx->h_tail.size() && idx->h_tail.back() == '$') ? n - 1 : n;
     for (int64_t c = 0; c < n_chunks; ++c) {
@@ -148,20 +156,14 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
     uint64_t look_ahead = opt.shard_lookahead > 0 ? (uint64_t)opt.shard_lookahead
                                                   : std::max<uint64_t>(65536, (own_hi - own_lo) / 16);
     auto chunk_of_host = [&](uint32_t g) {
-        return (int64_t)(std::upper_bound(h_pbase.begin(), h_pbase.end(), g) - h_pbase.begin()) - 1;
+        return (int64_t)(std::upper_bound(h_pbase, h_pbase + n_chunks + 1, g) - h_pbase) - 1;
     };
 
-    const size_t ch_bytes = (size_t)n_chunks * 16 + ((size_t)n_chunks + 1) * 4;
     RC_TRY(w.chunks.reserve(ch_bytes));
     uint64_t *d_start = w.chunks.as<uint64_t>();
     uint64_t *d_len = d_start + n_chunks;
     uint32_t *d_pbase = reinterpret_cast<uint32_t *>(d_len + n_chunks);
-    HIP_TRY(hipMemcpyAsync(d_start, h_start.data(), (size_t)n_chunks * 8, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(d_len, h_len.data(), (size_t)n_chunks * 8, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(d_pbase, h_pbase.data(), ((size_t)n_chunks + 1) * 4,
-                           hipMemcpyHostToDevice, s));
-
-    unsigned long long h_ctr[CT_COUNT];
+    HIP_TRY(hipMemcpyAsync(d_start, h_start, ch_bytes, hipMemcpyHostToDevice, s));  // same layout on the device
     uint64_t total_hits = 0, n_seg = 0, n_overflow = 0, n_heavy = 0;
     double ms_tier2 = 0.0;
     RunParams rp;
@@ -236,7 +238,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                                                                                      seg_list, d_ctr);
     HIP_TRY(hipEventRecord(cx.ev[2], s));
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, sizeof(h_ctr), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, kCtrBytes, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     total_hits = h_ctr[CT_TOTAL_HITS];
     n_seg = h_ctr[CT_SEG];
@@ -314,7 +316,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             // the window bound is pessimistic for tandem arrays (hits extend arms there) and the HBM
             // tier is several times slower per probe: tier 6 also takes segments whose bound exceeds
             // its capacity by up to 40 % (a real overflow falls through the cascade)
-            tier_cap[6] = (uint32_t)kArmsLayers<SlotT> * kHeavyThreads * 7 / 5;
+            tier_cap[6] = (uint32_t)((uint64_t)kArmsLayers<SlotT> * kHeavyThreads * (uint64_t)opt.cap6_pct / 100u);
             // tier 3 holds more arms than tier 6: a long segment that tier 6 would accept by the bound
             // is at least as safe in tier 3
             tier_cap[3] = std::max(tier_cap[3], tier_cap[6]);
@@ -367,7 +369,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
         RC_TRY(sort_segments(w, kbuf, vbuf, n_seg, s, &order, &sorted_keys));
         tier_bounds_kernel<<<1, 64, 0, s>>>(sorted_keys, d_ctr + CT_SEG, d_ctr);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, sizeof(h_ctr), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, kCtrBytes, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         uint64_t n_t[kTiers], seg_off[kTiers + 1] = {0};
         for (int t = 0; t < kTiers; ++t) {
@@ -406,6 +408,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             ep.cap_limit = opt.test_cap_limit >= 0 ? (uint32_t)opt.test_cap_limit : 0xFFFFFFFFu;
             ep.escalate_cost = 0xFFFFFFFFu;
             ep.hi_prio = (uint32_t)opt.prio3;
+            ep.max_items = 0;
             ep.n_levels = (uint32_t)opt.test_levels;
             ep.gen_bits = (uint32_t)opt.test_genbits;
             ep.ctr = d_ctr;
@@ -414,12 +417,14 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             // back-fills CUs as workgroups retire, so the tails of one tier overlap the next.
             // The window bound guarantees that a segment fits its
             // tier, so the overflow lists normally stay empty (they feed the cascade below).
-            hipStream_t st2 = cx.stream2, st3 = cx.stream3, st4 = cx.stream4, st5 = cx.stream5, st6 = cx.stream6;
+            hipStream_t st2 = cx.stream2, st3 = cx.stream3, st4 = cx.stream4, st5 = cx.stream5, st6 = cx.stream6,
+                        st7 = cx.stream7;
             HIP_TRY(hipStreamWaitEvent(st2, cx.ev[7], 0));
             HIP_TRY(hipStreamWaitEvent(st3, cx.ev[7], 0));
             HIP_TRY(hipStreamWaitEvent(st4, cx.ev[7], 0));
             HIP_TRY(hipStreamWaitEvent(st5, cx.ev[7], 0));
             HIP_TRY(hipStreamWaitEvent(st6, cx.ev[7], 0));
+            HIP_TRY(hipStreamWaitEvent(st7, cx.ev[7], 0));
             // Launch order and grid sizes: workgroups are persistent and hold their LDS until the
             // tier's work list is exhausted, so whatever is dispatched first owns the CUs.  The
             // critical path of a pass is the longest tandem-array segment of the heavy tiers
@@ -428,12 +433,23 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             // start at once instead of queueing behind another tier's bulk.
             const std::string tier_order = std::to_string((long long)opt.tier_order);
             // one launch of tier `tier`'s kernel over the list described by ep
+            bool cascade_launch = false;
             auto launch_kernel = [&](int tier, uint64_t n_items, hipStream_t st) {
                 // option grid<t> may shrink a tier's grid; the workgroup kernels (tiers 3..7) never get
                 // more workgroups than their default (HBM scratch is reserved for that many)
+                // options wg_items / wg_items12: workgroups that retire after that many work-list fetches
+                // (the grid then covers the list; slots are given back to the device all along)
+                // (not the LDS-array kernels: their HBM arm slices are indexed by workgroup, 256 of them)
+                const bool retiring = !cascade_launch && (tier == 1 || (arms_kernel && tier >= 2 && tier <= 6));
+                const uint64_t items_wg = retiring ? (uint64_t)(tier <= 2 ? opt.wg_items12 : opt.wg_items) : 0;
+                ep.max_items = (uint32_t)items_wg;
                 auto grid = [&](uint64_t dflt) -> unsigned {
                     uint64_t g = dflt;
                     if (opt.grid[tier] > 0) g = tier >= 3 ? std::min<uint64_t>(dflt, (uint64_t)opt.grid[tier]) : (uint64_t)opt.grid[tier];
+                    if (items_wg) {
+                        const uint64_t fetch = tier == 1 ? 8 : 1;  // extend_kernel fetches 8 segments at a time
+                        return (unsigned)std::min<uint64_t>((n_items + fetch * items_wg - 1) / (fetch * items_wg) + 1, 0x7FFFFFFFull);
+                    }
                     return (unsigned)std::min<uint64_t>(n_items, g);
                 };
                 switch (tier) {
@@ -473,12 +489,12 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                     break;
                 }
             };
-            hipStream_t tier_stream[kTiers + 1] = {s, s, st2, st3, st4, st5, st6, st3};
+            hipStream_t tier_stream[kTiers + 1] = {s, st7, st2, st3, st4, st5, st6, st3};
             {   // option tier_streams: tiers that share a stream run one after the other, in launch order
-                const hipStream_t pool[7] = {s, s, st2, st3, st4, st5, st6};
+                const hipStream_t pool[8] = {s, s, st2, st3, st4, st5, st6, st7};
                 const std::string ts = std::to_string((long long)opt.tier_streams);
                 for (int t = 1; t <= kTiers && t <= (int)ts.size(); ++t)
-                    if (ts[t - 1] >= '1' && ts[t - 1] <= '6') tier_stream[t] = pool[ts[t - 1] - '0'];
+                    if (ts[t - 1] >= '1' && ts[t - 1] <= '7') tier_stream[t] = pool[ts[t - 1] - '0'];
             }
             auto launch_tier = [&](int tier) {
                 if (tier < 1 || tier > kTiers || !n_t[tier - 1]) return;
@@ -496,7 +512,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             };
             for (char c : tier_order) launch_tier(c - '0');
             HIP_TRY(hipGetLastError());
-            HIP_TRY(hipEventRecord(cx.ev[12], s));   // tier 1 (main stream)
+            HIP_TRY(hipEventRecord(cx.ev[12], st7));
             HIP_TRY(hipEventRecord(cx.ev[5], st2));
             HIP_TRY(hipEventRecord(cx.ev[6], st3));
             HIP_TRY(hipEventRecord(cx.ev[8], st4));
@@ -517,7 +533,8 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             HIP_TRY(hipStreamWaitEvent(s, cx.ev[8], 0));
             HIP_TRY(hipStreamWaitEvent(s, cx.ev[9], 0));
             HIP_TRY(hipStreamWaitEvent(s, cx.ev[10], 0));
-            HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, sizeof(h_ctr), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamWaitEvent(s, cx.ev[12], 0));
+            HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, kCtrBytes, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
             PROF_DUMP("concurrent tiers");
             n_overflow = 0;
@@ -537,7 +554,8 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                 if (!n_ovf) continue;
                 int dst = src + 1;
                 while (dst < kTiers && (!tier_enabled(dst) || tier_cap[dst] <= tier_cap[src])) ++dst;
-                HIP_TRY(hipMemcpyAsync(d_ctr + CT_NF, &n_ovf, 8, hipMemcpyHostToDevice, s));
+                *h_scalar = n_ovf;  // (the previous cascade launch has been waited for)
+                HIP_TRY(hipMemcpyAsync(d_ctr + CT_NF, h_scalar, 8, hipMemcpyHostToDevice, s));
                 HIP_TRY(hipMemsetAsync(d_ctr + CT_CURF, 0, 8, s));
                 ep.seg_list = ovf[src - 1];
                 ep.n_seg_ptr = d_ctr + CT_NF;
@@ -546,9 +564,10 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                 ep.ovf_count = d_ctr + CT_OVF1 + dst - 1;  // appended behind what is already there
                 ep.escalate_cost = 0xFFFFFFFFu;
                 ep.cap_limit = 0xFFFFFFFFu;
+                cascade_launch = true;
                 launch_kernel(dst, n_ovf, s);
                 HIP_TRY(hipGetLastError());
-                HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, sizeof(h_ctr), hipMemcpyDeviceToHost, s));
+                HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, kCtrBytes, hipMemcpyDeviceToHost, s));
                 HIP_TRY(hipStreamSynchronize(s));
                 PROF_DUMP("cascade");
             }

@@ -852,6 +852,7 @@ struct ExtParams {
     uint32_t escalate_cost;               // one-wave tiers: give up after this much LDS-path work
     uint32_t cap_limit;                   // effective live-arm capacity (<= CAP; tests lower it)
     uint32_t hi_prio;                     // 1: the long-segment shape raises its waves' issue priority
+    uint32_t max_items;                   // work-list fetches per workgroup before it retires (0: until the list is empty)
     unsigned long long *ctr;
 };
 
@@ -944,9 +945,10 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
     const unsigned long long head_groups = min((unsigned long long)gridDim.x, n_seg / kFetch);
     const unsigned long long head = head_groups * kFetch;
     unsigned long long seg_base = 0;
-    uint32_t seg_j = (uint32_t)kFetch;
+    uint32_t seg_j = (uint32_t)kFetch, n_fetch = 0;
     for (;;) {
         if (seg_j == (uint32_t)kFetch) {
+            if (P.max_items && n_fetch++ >= P.max_items) break;  // retire: the slot goes to whatever is waiting
             unsigned long long sb = 0;
             if (lane == 0) sb = atomicAdd(P.cursor, kFetch);
             seg_base = uni(sb);
@@ -1853,7 +1855,7 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
     RecAlloc rec_alloc;
     PROF_DECL;
 
-    for (;;) {
+    for (uint32_t n_fetch = 0; !P.max_items || n_fetch < P.max_items; ++n_fetch) {
         if (tid == 0) s_bcast = atomicAdd(P.cursor, 1ull);
         __syncthreads();
         const unsigned long long seg = s_bcast;
@@ -2358,7 +2360,7 @@ __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
     uint32_t ppar = 0, new_seen0 = 0, new_seen1 = 0, spur_seen0 = 0, spur_seen1 = 0;
     lds_barrier();
 
-    for (;;) {
+    for (uint32_t n_fetch = 0; !P.max_items || n_fetch < P.max_items; ++n_fetch) {
         if (tid == 0) s_bcast = atomicAdd(P.cursor, 1ull);
         lds_barrier();
         const unsigned long long seg = uni(s_bcast);
