@@ -528,6 +528,32 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                 for (int64_t c = 0; c < n_chunks; ++c)
                     cx.progress[c] = (uint64_t)probes_in_chunk(h_len[c], k, step, st->min_duplication_length) * step;
             }
+            // Early cascade of tier 6.  It is the one tier that accepts segments above its real capacity (by
+            // the 40 % allowance), so a few of its segments overflow on every large call; their re-run in the
+            // HBM tier need not wait for the other tiers -- the longest tier-3 segment runs 60+ ms longer than
+            // tier 6.  The host waits for tier 6 alone, reads its overflow count and launches the re-run
+            // behind it on the same stream (the main stream is idle meanwhile and has the highest priority).
+            uint64_t early6 = 0;
+            if (opt.early_cascade && n_t[5] && !n_t[6] && tier_stream[6] == st6) {
+                HIP_TRY(hipEventSynchronize(cx.ev[10]));
+                HIP_TRY(hipMemcpyAsync(h_scalar, d_ctr + CT_OVF1 + 5, 8, hipMemcpyDeviceToHost, s));
+                HIP_TRY(hipStreamSynchronize(s));
+                early6 = *h_scalar;
+                if (early6) {
+                    ep.seg_list = ovf[5];
+                    ep.n_seg_ptr = d_ctr + CT_OVF1 + 5;  // final: tier 6 is done, nothing else appends before the join
+                    ep.cursor = d_ctr + CT_CURF;
+                    ep.ovf_list = nullptr;
+                    ep.ovf_count = d_ctr + CT_OVF1 + 6;
+                    ep.escalate_cost = 0xFFFFFFFFu;
+                    ep.cap_limit = 0xFFFFFFFFu;
+                    cascade_launch = true;
+                    launch_kernel(kTiers, early6, tier_stream[6]);
+                    cascade_launch = false;
+                    HIP_TRY(hipGetLastError());
+                    HIP_TRY(hipEventRecord(cx.ev[10], tier_stream[6]));
+                }
+            }
             HIP_TRY(hipStreamWaitEvent(s, cx.ev[5], 0));
             HIP_TRY(hipStreamWaitEvent(s, cx.ev[6], 0));
             HIP_TRY(hipStreamWaitEvent(s, cx.ev[8], 0));
@@ -550,14 +576,17 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             // is in use and holds more arms (its own overflow is appended to that tier's list) ------
             const auto t_casc0 = std::chrono::steady_clock::now();
             for (int src = 1; src < kTiers; ++src) {
-                const uint64_t n_ovf = h_ctr[CT_OVF1 + src - 1];
+                // (the first early6 entries of tier 6's list have been re-run already; a lower tier's cascade
+                // into tier 6 may have appended more)
+                const uint64_t skip = src == 6 ? early6 : 0;
+                const uint64_t n_ovf = h_ctr[CT_OVF1 + src - 1] - skip;
                 if (!n_ovf) continue;
                 int dst = src + 1;
                 while (dst < kTiers && (!tier_enabled(dst) || tier_cap[dst] <= tier_cap[src])) ++dst;
                 *h_scalar = n_ovf;  // (the previous cascade launch has been waited for)
                 HIP_TRY(hipMemcpyAsync(d_ctr + CT_NF, h_scalar, 8, hipMemcpyHostToDevice, s));
                 HIP_TRY(hipMemsetAsync(d_ctr + CT_CURF, 0, 8, s));
-                ep.seg_list = ovf[src - 1];
+                ep.seg_list = ovf[src - 1] + skip;
                 ep.n_seg_ptr = d_ctr + CT_NF;
                 ep.cursor = d_ctr + CT_CURF;
                 ep.ovf_list = dst < kTiers ? ovf[dst - 1] : nullptr;
