@@ -193,7 +193,7 @@ struct Options {
     int64_t wg_items12 = 0;         // ... work-list fetches (8 segments / 1 segment) of a tier-1 / tier-2 wave
     int64_t early_cascade = 1;      // 1: tier 6's overflow is re-run as soon as tier 6 is done, not after the last tier
     int64_t cap6_pct = 140;         // tier 6 accepts segments whose arm bound is up to this percentage of its capacity
-    int64_t tier_streams = 7234563; // digit t (from the left): the stream (1..7, 1 = the call's high-priority main stream) tier t runs on
+    int64_t tier_streams = 7234562; // digit t (from the left): the stream (1..7, 1 = the call's high-priority main stream) tier t runs on
 };
 int32_t create_ctx_streams(SearchCtx &cx);  // the streams and events of one call context (current device)
 int32_t option_set(Options &o, const char *name, int64_t value);  // ASGART_E_ARG: unknown name / bad value

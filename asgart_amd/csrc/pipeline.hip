@@ -55,8 +55,12 @@ namespace asgart {
 
 // default launch order / grid sizes of the extension tiers (see the launch site)
 constexpr uint64_t kGrid1 = 256ull * 8ull, kGrid2 = 256ull * 3ull;
-// arms per thread of the arm-resident kernel: 9 x 512 = 4608 live arms (6 x 512 with 64-bit positions)
-template <class SlotT> constexpr int kArmsLayers = sizeof(SlotT) == 4 ? 9 : 6;
+// arms per thread of the largest arm-resident shape
+// tier 6: 9 x 512 = 4608 arm slots, cold fields in LDS; with 64-bit positions 8 x 512 = 4096, the left ends in HBM
+// (COLD = 2; with the cold fields in LDS only 6 x 512 fit).  Measured for 32-bit positions as well: 12 x 512 slots
+// with COLD = 2 need 256 VGPRs + spills and make the GRCh38-shaped step 4 % slower.
+template <class SlotT> constexpr int kArmsLayers = sizeof(SlotT) == 4 ? 9 : 8;
+template <class SlotT> constexpr int kArmsCold = sizeof(SlotT) == 4 ? 1 : 2;
 // its one-wave shape: 8 x 64 = 512 live arms per wave, probes with up to 512 hits
 template <class SlotT> constexpr int kWaveArmsLayers = sizeof(SlotT) == 4 ? 8 : 5;
 // tiers 4 and 5: 4 arms per thread x 256 / 512 threads, cold fields in LDS
@@ -97,14 +101,14 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
     const uint64_t n = (uint64_t)idx->n;
 
     // ---- chunk table -------------------------------------------------------
-    // (in the call context's pinned control block: [counters | one scalar | start[nc] | len[nc] | pbase[nc + 1]])
+    // (in the call context's pinned control block: [counters | four scalars | start[nc] | len[nc] | pbase[nc + 1]])
     constexpr size_t kCtrBytes = (size_t)CT_COUNT * 8;
     const size_t ch_bytes = (size_t)n_chunks * 16 + ((size_t)n_chunks + 1) * 4;
     void *ctl_p = nullptr;
-    RC_TRY(cx.ctl(kCtrBytes + ch_bytes + 16, &ctl_p));
+    RC_TRY(cx.ctl(kCtrBytes + ch_bytes + 32, &ctl_p));
     unsigned long long *const h_ctr = static_cast<unsigned long long *>(ctl_p);
     unsigned long long *const h_scalar = h_ctr + CT_COUNT;  // source of small host-to-device updates
-    uint64_t *const h_start = reinterpret_cast<uint64_t *>(static_cast<char *>(ctl_p) + kCtrBytes + 16);
+    uint64_t *const h_start = reinterpret_cast<uint64_t *>(static_cast<char *>(ctl_p) + kCtrBytes + 32);
     uint64_t *const h_len = h_start + n_chunks;
     uint32_t *const h_pbase = reinterpret_cast<uint32_t *>(h_len + n_chunks);
     uint64_t P64 = 0;
@@ -317,9 +321,11 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             // tier is several times slower per probe: tier 6 also takes segments whose bound exceeds
             // its capacity by up to 40 % (a real overflow falls through the cascade)
             tier_cap[6] = (uint32_t)((uint64_t)kArmsLayers<SlotT> * kHeavyThreads * (uint64_t)opt.cap6_pct / 100u);
-            // tier 3 holds more arms than tier 6: a long segment that tier 6 would accept by the bound
-            // is at least as safe in tier 3
-            tier_cap[3] = std::max(tier_cap[3], tier_cap[6]);
+            // tier 3 accepts what tier 6 would accept by the bound (a long segment is no less safe there), but
+            // never more than the same allowance over its own capacity (with 64-bit positions it holds fewer
+            // arms than tier 6, and what it gives up on is re-run from the start)
+            tier_cap[3] = std::min<uint32_t>(std::max(tier_cap[3], tier_cap[6]),
+                                             (uint32_t)((uint64_t)tier_cap[3] * (uint64_t)opt.cap6_pct / 100u));
         } else {
             tier_cap[2] = kArmCapMid;
             tier_cap[4] = sizeof(SlotT) == 4 ? kArmCapBig32 : kArmCapBig64;
@@ -387,12 +393,13 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
         // HBM arm storage of the LDS-array kernels: tier 6 (MODE 1) and tier 7 (MODE 2) may run at the
         // same time on different streams, so each gets its own region of 256 per-workgroup slices
         const size_t per_wg = (size_t)capg * (4 * sizeof(SlotT) + 16);
-        RC_TRY(w.scratch.reserve(per_wg * 256 * 2));
+        RC_TRY(w.scratch.reserve(per_wg * 256 * 4));  // tier 6, tier 7, and one region per early cascade launch
         char *const scratch6 = w.scratch.as<char>(), *const scratch7 = scratch6 + per_wg * 256;
         for (int attempt = 0;; ++attempt) {
             RC_TRY(w.fam_sds.reserve((size_t)rec_cap * sizeof(SdRec)));
             HIP_TRY(hipMemsetAsync(d_ctr + CT_SD, 0, 8, s));
             HIP_TRY(hipMemsetAsync(d_ctr + CT_NF, 0, (size_t)(CT_COUNT - CT_NF) * 8, s));  // NF, cursors, overflow counts
+            HIP_TRY(hipMemsetAsync(d_ctr + CT_EARLY_N, 0, 4 * 8, s));                       // early cascade counts + cursors
             HIP_TRY(hipEventRecord(cx.ev[7], s));
             ExtParams<SlotT> ep;
             ep.rp = rp;
@@ -434,13 +441,15 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             const std::string tier_order = std::to_string((long long)opt.tier_order);
             // one launch of tier `tier`'s kernel over the list described by ep
             bool cascade_launch = false;
+            char *scratch_override = nullptr;  // HBM slices of an early cascade launch
             auto launch_kernel = [&](int tier, uint64_t n_items, hipStream_t st) {
                 // option grid<t> may shrink a tier's grid; the workgroup kernels (tiers 3..7) never get
                 // more workgroups than their default (HBM scratch is reserved for that many)
                 // options wg_items / wg_items12: workgroups that retire after that many work-list fetches
                 // (the grid then covers the list; slots are given back to the device all along)
                 // (not the LDS-array kernels: their HBM arm slices are indexed by workgroup, 256 of them)
-                const bool retiring = !cascade_launch && (tier == 1 || (arms_kernel && tier >= 2 && tier <= 6));
+                // (nor tier 6: its left-end slices in HBM are indexed by workgroup as well)
+                const bool retiring = !cascade_launch && (tier == 1 || (arms_kernel && tier >= 2 && tier <= 5));
                 const uint64_t items_wg = retiring ? (uint64_t)(tier <= 2 ? opt.wg_items12 : opt.wg_items) : 0;
                 ep.max_items = (uint32_t)items_wg;
                 auto grid = [&](uint64_t dflt) -> unsigned {
@@ -477,19 +486,21 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                     extend_arms_kernel<SlotT, kMidArmsLayers<SlotT>, 512, kHitBatch, 1024, 4, false, true><<<grid(256 * 2), 512, 0, st>>>(ep);
                     break;
                 case 6:
+                    if (scratch_override) ep.scratch = scratch_override;
                     if (arms_kernel)
-                        extend_arms_kernel<SlotT, kArmsLayers<SlotT>, kHeavyThreads, kHitBatch, 1024, 4, false, true><<<grid(256), kHeavyThreads, 0, st>>>(ep);
+                        extend_arms_kernel<SlotT, kArmsLayers<SlotT>, kHeavyThreads, kHitBatch, 1024, 4, false, kArmsCold<SlotT>><<<grid(256), kHeavyThreads, 0, st>>>(ep);
                     else
                         extend_heavy_kernel<SlotT, caph, kHeavyThreads, 1><<<grid(256), kHeavyThreads, 0, st>>>(ep);
+                    ep.scratch = scratch6;
                     break;
                 default:
-                    ep.scratch = scratch7;
+                    ep.scratch = scratch_override ? scratch_override : scratch7;
                     extend_heavy_kernel<SlotT, capg, kHeavyThreads, 2><<<grid(256), kHeavyThreads, 0, st>>>(ep);
                     ep.scratch = scratch6;
                     break;
                 }
             };
-            hipStream_t tier_stream[kTiers + 1] = {s, st7, st2, st3, st4, st5, st6, st3};
+            hipStream_t tier_stream[kTiers + 1] = {s, st7, st2, st3, st4, st5, st6, st2};
             {   // option tier_streams: tiers that share a stream run one after the other, in launch order
                 const hipStream_t pool[8] = {s, s, st2, st3, st4, st5, st6, st7};
                 const std::string ts = std::to_string((long long)opt.tier_streams);
@@ -528,30 +539,68 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                 for (int64_t c = 0; c < n_chunks; ++c)
                     cx.progress[c] = (uint64_t)probes_in_chunk(h_len[c], k, step, st->min_duplication_length) * step;
             }
-            // Early cascade of tier 6.  It is the one tier that accepts segments above its real capacity (by
-            // the 40 % allowance), so a few of its segments overflow on every large call; their re-run in the
-            // HBM tier need not wait for the other tiers -- the longest tier-3 segment runs 60+ ms longer than
-            // tier 6.  The host waits for tier 6 alone, reads its overflow count and launches the re-run
-            // behind it on the same stream (the main stream is idle meanwhile and has the highest priority).
-            uint64_t early6 = 0;
-            if (opt.early_cascade && n_t[5] && !n_t[6] && tier_stream[6] == st6) {
-                HIP_TRY(hipEventSynchronize(cx.ev[10]));
-                HIP_TRY(hipMemcpyAsync(h_scalar, d_ctr + CT_OVF1 + 5, 8, hipMemcpyDeviceToHost, s));
-                HIP_TRY(hipStreamSynchronize(s));
-                early6 = *h_scalar;
-                if (early6) {
-                    ep.seg_list = ovf[5];
-                    ep.n_seg_ptr = d_ctr + CT_OVF1 + 5;  // final: tier 6 is done, nothing else appends before the join
-                    ep.cursor = d_ctr + CT_CURF;
-                    ep.ovf_list = nullptr;
-                    ep.ovf_count = d_ctr + CT_OVF1 + 6;
-                    ep.escalate_cost = 0xFFFFFFFFu;
-                    ep.cap_limit = 0xFFFFFFFFu;
-                    cascade_launch = true;
-                    launch_kernel(kTiers, early6, tier_stream[6]);
-                    cascade_launch = false;
-                    HIP_TRY(hipGetLastError());
-                    HIP_TRY(hipEventRecord(cx.ev[10], tier_stream[6]));
+            // Early cascades of tiers 3 and 6, the two tiers that accept segments above their real capacity (by
+            // the allowance): what they give up on need not wait for the other tiers to be re-run -- the longest
+            // tier-3 segment of a GRCh38-shaped pass runs 60+ ms longer than tier 6, and in a two-genome run tier 6
+            // runs seconds longer than tier 3.  The host waits for whichever of the two finishes first, reads its
+            // overflow count and launches the re-run behind it on the same stream (the main stream is idle
+            // meanwhile and has the highest priority); each such launch has its own counters and HBM slices.
+            uint64_t early_n[kTiers + 1] = {0};
+            {
+                struct Early {
+                    int src, dst;
+                    hipEvent_t ev;
+                    hipStream_t st;
+                    bool pending;
+                } early[2] = {{3, 0, cx.ev[6], st3, false}, {6, 0, cx.ev[10], st6, false}};
+                int n_pending = 0;
+                for (int e = 0; e < 2; ++e) {
+                    Early &E = early[e];
+                    int dst = E.src + 1;
+                    while (dst < kTiers && (!tier_enabled(dst) || tier_cap[dst] <= tier_cap[E.src])) ++dst;
+                    E.dst = dst;
+                    // (a re-run in the HBM tier would share that tier's slices with its own list, if it has one)
+                    E.pending = opt.early_cascade && n_t[E.src - 1] && tier_stream[E.src] == E.st &&
+                                (dst < kTiers || !n_t[kTiers - 1]);
+                    n_pending += E.pending ? 1 : 0;
+                }
+                while (n_pending) {
+                    bool progressed = false;
+                    for (int e = 0; e < 2; ++e) {
+                        Early &E = early[e];
+                        if (!E.pending) continue;
+                        const hipError_t q = hipEventQuery(E.ev);
+                        if (q == hipErrorNotReady) {
+                            (void)hipGetLastError();
+                            continue;
+                        }
+                        HIP_TRY(q);
+                        E.pending = false;
+                        --n_pending;
+                        progressed = true;
+                        HIP_TRY(hipMemcpyAsync(h_scalar + 1 + e, d_ctr + CT_OVF1 + E.src - 1, 8, hipMemcpyDeviceToHost, s));
+                        HIP_TRY(hipStreamSynchronize(s));
+                        const uint64_t n_e = h_scalar[1 + e];
+                        if (!n_e) continue;
+                        early_n[E.src] = n_e;
+                        // the count the launch works on is fixed now (the list itself may still grow)
+                        HIP_TRY(hipMemcpyAsync(d_ctr + CT_EARLY_N + e, h_scalar + 1 + e, 8, hipMemcpyHostToDevice, E.st));
+                        ep.seg_list = ovf[E.src - 1];
+                        ep.n_seg_ptr = d_ctr + CT_EARLY_N + e;
+                        ep.cursor = d_ctr + CT_EARLY_CUR + e;
+                        ep.ovf_list = E.dst < kTiers ? ovf[E.dst - 1] : nullptr;
+                        ep.ovf_count = d_ctr + CT_OVF1 + E.dst - 1;
+                        ep.escalate_cost = 0xFFFFFFFFu;
+                        ep.cap_limit = 0xFFFFFFFFu;
+                        cascade_launch = true;
+                        scratch_override = scratch6 + per_wg * 256 * (size_t)(2 + e);
+                        launch_kernel(E.dst, n_e, E.st);
+                        scratch_override = nullptr;
+                        cascade_launch = false;
+                        HIP_TRY(hipGetLastError());
+                        HIP_TRY(hipEventRecord(E.ev, E.st));
+                    }
+                    if (n_pending && !progressed) std::this_thread::sleep_for(std::chrono::microseconds(50));
                 }
             }
             HIP_TRY(hipStreamWaitEvent(s, cx.ev[5], 0));
@@ -576,9 +625,9 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             // is in use and holds more arms (its own overflow is appended to that tier's list) ------
             const auto t_casc0 = std::chrono::steady_clock::now();
             for (int src = 1; src < kTiers; ++src) {
-                // (the first early6 entries of tier 6's list have been re-run already; a lower tier's cascade
-                // into tier 6 may have appended more)
-                const uint64_t skip = src == 6 ? early6 : 0;
+                // (the first early_n entries of the list have been re-run already; a lower tier's cascade into
+                // this tier may have appended more)
+                const uint64_t skip = early_n[src];
                 const uint64_t n_ovf = h_ctr[CT_OVF1 + src - 1] - skip;
                 if (!n_ovf) continue;
                 int dst = src + 1;

@@ -43,6 +43,8 @@ enum Counter {
     CT_AMBIG,         // sharding: start decisions that need a longer look-back
     CT_RANOUT,        // sharding: segments that ran past the look-ahead window
     // 16..33 and 56..67: per-phase cycle sums of the diagnostic build (-DASGART_PROFILE_EXTEND)
+    CT_EARLY_N = 34,    // early cascade launches (of tiers 3 and 6): list lengths ...
+    CT_EARLY_CUR = 36,  // ... and work cursors
     CT_ALG_BYTES = 68,  // accounting pass: bytes the probe-search kernels move by design
     CT_FLT_REJECTED,    // accounting pass: probes answered by the presence filter alone
     CT_LONGSEG,         // placement: segments the lane-per-segment walk handed to the wave-per-segment kernel
@@ -2295,7 +2297,7 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
 // segments) and NT >= 512 (the few segments with thousands of live arms or tens of thousands
 // of probes, whose serial chain sets the critical path of a pass).
 // Results are identical to K4 and K4b; tested by forcing every multi-hit segment through it.
-template <class PosT, int S, int NT, int HB, int kHT, int kLevels, bool PACK, bool COLD = false, int PAD = 0>
+template <class PosT, int S, int NT, int HB, int kHT, int kLevels, bool PACK, int COLD = 0, int PAD = 0>
 __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
     constexpr int CAP = S * NT;
     constexpr uint32_t kNoHit = 0xFFFFu;
@@ -2317,9 +2319,13 @@ __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
     __shared__ uint16_t s_free[CAP];                 // stack of empty slots below H
     __shared__ uint32_t s_nfreed[2], s_nnew[2], s_nspur[2];
     __shared__ unsigned long long s_bcast;
-    // COLD: the fields an arm only needs when it is extended or retired (left start, left end,
-    // right start) live in LDS instead of registers -- more arms per thread without spilling
-    __shared__ PosT s_cls[COLD ? CAP : 1], s_cle[COLD ? CAP : 1], s_crs[COLD ? CAP : 1];
+    // COLD = 1: the fields an arm only needs when it is extended or retired (left start, left end,
+    // right start) live in LDS instead of registers -- more arms per thread without spilling.
+    // COLD = 2 (the largest shape): left and right start stay in registers, the left END -- written at every
+    // extension, read only when a long enough arm is reported -- lives in the workgroup's slice of the HBM
+    // scratch, and the LDS that the three arrays took holds twice the arm slots instead.
+    __shared__ PosT s_cls[COLD == 1 ? CAP : 1], s_cle[COLD == 1 ? CAP : 1], s_crs[COLD == 1 ? CAP : 1];
+    PosT *const g_cle = COLD == 2 ? reinterpret_cast<PosT *>(P.scratch) + (size_t)blockIdx.x * CAP : nullptr;
     // PAD > 0: claim the rest of the CU's LDS so that no other workgroup shares the CU with a
     // latency-critical segment (its waves would take issue slots and LDS bandwidth)
     __shared__ uint32_t s_pad[PAD > 0 ? PAD / 4 : 1];
@@ -2338,14 +2344,16 @@ __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
     PROF_DECL;
 
     // arm state, one arm per (thread, layer)
-    constexpr int SC = COLD ? 1 : S;
-    PosT a_ls[SC], a_le[SC], a_rs[SC], a_re[S];
+    constexpr int SC = COLD == 1 ? 1 : S;  // left / right start in registers
+    constexpr int SE = COLD == 0 ? S : 1;  // left end in registers
+    PosT a_ls[SC], a_le[SE], a_rs[SC], a_re[S];
     uint32_t a_thr[S], a_gap[S], a_seq[S];
 #pragma unroll
     for (int L = 0; L < S; ++L) {
         a_seq[L] = kNoSeq;
         a_re[L] = 0;
-        if (L < SC) a_ls[L] = a_le[L] = a_rs[L] = 0;
+        if (L < SC) a_ls[L] = a_rs[L] = 0;
+        if (L < SE) a_le[L] = 0;
         a_thr[L] = a_gap[L] = 0;
     }
     auto clear_tables = [&]() {
@@ -2421,9 +2429,12 @@ __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
                             const PosT x = s_hits[off + m - 1u];
                             a_re[L] = (PosT)(x + k);
                             PosT ls;
-                            if constexpr (COLD) {
+                            if constexpr (COLD == 1) {
                                 ls = s_cls[slot];
                                 s_cle[slot] = (PosT)(i + k);
+                            } else if constexpr (COLD == 2) {
+                                ls = a_ls[L];
+                                g_cle[slot] = (PosT)(i + k);
                             } else {
                                 ls = a_ls[L];
                                 a_le[L] = (PosT)(i + k);
@@ -2438,8 +2449,10 @@ __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
                         }
                     } else if (m) {  // NewArm, src/automaton.rs:151-164 (aged by this very probe)
                         const PosT x = s_hits[off + m - 1u];
-                        if constexpr (COLD) {
+                        if constexpr (COLD == 1) {
                             s_cls[slot] = (PosT)i; s_cle[slot] = (PosT)(i + k); s_crs[slot] = x;
+                        } else if constexpr (COLD == 2) {
+                            a_ls[L] = (PosT)i; a_rs[L] = x; g_cle[slot] = (PosT)(i + k);
                         } else {
                             a_ls[L] = (PosT)i; a_le[L] = (PosT)(i + k); a_rs[L] = x;
                         }
@@ -2455,15 +2468,24 @@ __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
                         }
                         PosT ls = 0, le = 0, rs = 0;
                         if (dead) {
-                            if constexpr (COLD) {
+                            if constexpr (COLD == 1) {
                                 ls = s_cls[slot]; le = s_cle[slot]; rs = s_crs[slot];
+                            } else if constexpr (COLD == 2) {
+                                ls = a_ls[L]; rs = a_rs[L];
                             } else {
                                 ls = a_ls[L]; le = a_le[L]; rs = a_rs[L];
                             }
                         }
-                        emit_records(dead && (uint64_t)(a_re[L] - rs) >= rp.M, ls, le, rs, a_re[L], sq);
+                        const bool report = dead && (uint64_t)(a_re[L] - rs) >= rp.M;
+                        if constexpr (COLD == 2) {
+                            if (report) le = g_cle[slot];  // (this thread's own store, or a newer one of its own)
+                        }
+                        emit_records(report, ls, le, rs, a_re[L], sq);
                     }
                 }
+                // (the largest shape: one layer at a time -- interleaving 16 unrolled layers costs hundreds of
+                // registers for their temporaries)
+                if constexpr (COLD == 2) __builtin_amdgcn_sched_barrier(0);
             }
             pre();
             lds_barrier();
@@ -2667,6 +2689,7 @@ __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
                                 }
                             }
                         }
+                        if constexpr (COLD == 2) __builtin_amdgcn_sched_barrier(0);
                     }
                 }
                 lds_barrier();
