@@ -10,6 +10,7 @@ from asgart_amd import prep, synth
 pytestmark = pytest.mark.gpu
 
 MODES = [(False, False), (True, False), (False, True), (True, True)]
+_ORACLE_CACHE = {}
 
 
 def _small_genome(seed=7, lens=(180_000, 120_000), **kw):
@@ -772,6 +773,38 @@ def test_64bit_slots_and_positions(hiplib, name, tier, monkeypatch):
         # searcher surface on the wide index
         lo, hi = idx.sa_read(0, 16), None
         assert np.array_equal(lo, oidx.sa[:16])
+
+
+@pytest.mark.parametrize("wide", [0, 1])
+def test_tier6_with_thousands_of_live_arms(hiplib, wide, monkeypatch):
+    """The largest arm-resident shape with several layers in use: a 100-bp tandem array of 650 diverged copies keeps
+    many hundreds of arms alive (layers of 512 slots; with 64-bit positions the shape that keeps its left ends in
+    HBM).  Forced into tier 6, checked against the oracle, and nothing may fall through to tier 7."""
+    rng = np.random.default_rng(77)
+    bases = np.frombuffer(b"ACGT", dtype=np.uint8)
+    mono = rng.integers(0, 4, size=100)
+    arr = np.tile(mono, 650)
+    mut = rng.random(arr.shape) < 0.04
+    arr[mut] = (arr[mut] + rng.integers(1, 4, size=int(mut.sum()))) & 3
+    g = np.concatenate([rng.integers(0, 4, size=3000), arr, rng.integers(0, 4, size=3000)])
+    text = np.concatenate([bases[g], np.frombuffer(b"$", dtype=np.uint8)])
+    chunks = [(0, len(text) - 1)]
+    oidx = oracle.Index.build(text)
+    monkeypatch.setenv("ASGART_FORCE_WIDE", str(wide))
+    monkeypatch.setenv("ASGART_FORCE_TIER", "6")
+    cli = dict(max_cardinality=1000, min_length=150)
+    with asgart_amd.Index(text, oidx.sa) as idx:
+        for rc in (False, True):
+            st = asgart_amd.RunSettings.from_cli(reverse=rc, complement=rc, **cli)
+            offs, sds = idx.search_duplications_raw(chunks, st)
+            stats = idx.stats()
+            key = ("tier6_layers", rc)
+            if key not in _ORACLE_CACHE:   # (13 s of oracle time: shared by the two parametrisations)
+                _ORACLE_CACHE[key] = oidx.run_raw(chunks, oracle.make_settings(reverse=rc, complement=rc, **cli))
+            eoffs, esds = _ORACLE_CACHE[key]
+            assert np.array_equal(offs, eoffs) and np.array_equal(sds, esds), (wide, rc)
+            if not rc:
+                assert len(esds) > 1000 and stats.heavy_segments >= 1 and stats.overflow_segments == 0
 
 
 @pytest.mark.parametrize("bits", [2, 5])
