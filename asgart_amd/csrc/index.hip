@@ -58,6 +58,7 @@ const OptDesc kOptions[] = {
     {"tier_streams", &Options::tier_streams, 1111111, 7777777},
     {"cap6_pct", &Options::cap6_pct, 100, 200},
     {"early_cascade", &Options::early_cascade, 0, 1},
+    {"progress_at", &Options::progress_at, 0, 2},
     {"wg_items", &Options::wg_items, 0, 1 << 30},
     {"wg_items12", &Options::wg_items12, 0, 1 << 30},
 };

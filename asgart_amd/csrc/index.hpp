@@ -191,6 +191,7 @@ struct Options {
     int64_t kfilter_bits = 30;      // log2(bits) of the k-mer presence filter (search_dev.hpp); 0: no filter
     int64_t wg_items = 0;           // segments a workgroup of tiers 3..7 runs before it retires (0: persistent)
     int64_t wg_items12 = 0;         // ... work-list fetches (8 segments / 1 segment) of a tier-1 / tier-2 wave
+    int64_t progress_at = 2;        // when a call reports its probes as searched (pipeline.hip: progress)
     int64_t early_cascade = 1;      // 1: tier 6's overflow is re-run as soon as tier 6 is done, not after the last tier
     int64_t cap6_pct = 140;         // tier 6 accepts segments whose arm bound is up to this percentage of its capacity
     int64_t tier_streams = 7234562; // digit t (from the left): the stream (1..7, 1 = the call's high-priority main stream) tier t runs on

@@ -169,6 +169,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
     uint32_t *d_pbase = reinterpret_cast<uint32_t *>(d_len + n_chunks);
     HIP_TRY(hipMemcpyAsync(d_start, h_start, ch_bytes, hipMemcpyHostToDevice, s));  // same layout on the device
     uint64_t total_hits = 0, n_seg = 0, n_overflow = 0, n_heavy = 0;
+    bool progress_given = false;
     double ms_tier2 = 0.0;
     RunParams rp;
     const auto t_host0 = std::chrono::steady_clock::now();
@@ -216,6 +217,11 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
     RC_TRY(w.counters.reserve(CT_COUNT * 8));
     unsigned long long *d_ctr = w.counters.as<unsigned long long>();
     HIP_TRY(hipMemsetAsync(d_ctr, 0, CT_COUNT * 8, s));
+    auto signal_progress = [&]() {
+        for (int64_t c = 0; c < n_chunks; ++c)
+            cx.progress[c] = (uint64_t)probes_in_chunk(h_len[c], k, step, st->min_duplication_length) * step;
+        progress_given = true;
+    };
 
     IndexView<SlotT> ix = idx->view<SlotT>();
     ix.flt = idx->d_filter[(st->reverse ? 2 : 0) | (st->complement ? 1 : 0)];  // null: filter off
@@ -246,6 +252,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
     HIP_TRY(hipStreamSynchronize(s));
     total_hits = h_ctr[CT_TOTAL_HITS];
     n_seg = h_ctr[CT_SEG];
+    if (cx.progress && opt.progress_at < 2 && !progress_given && !h_ctr[CT_AMBIG]) signal_progress();
     if (h_ctr[CT_AMBIG]) {  // a start decision needs more history: widen the look-back halo
         look_back *= 8;
         continue;
@@ -535,9 +542,11 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                 // HBM-bound, chip-wide part of the call is over, the extension automaton is under way.
                 // A host that pipelines calls (bench.py) issues the next one when it sees this: its search
                 // phases then run beside this call's extension, whose tail is a few serial segments.
-                HIP_TRY(hipEventSynchronize(cx.ev[3]));  // probe search, scans and CSR fill are done
-                for (int64_t c = 0; c < n_chunks; ++c)
-                    cx.progress[c] = (uint64_t)probes_in_chunk(h_len[c], k, step, st->min_duplication_length) * step;
+                // (option progress_at = 2; with 0 or 1 the signal was given right after the scans, above)
+                if (!progress_given) {
+                    HIP_TRY(hipEventSynchronize(cx.ev[3]));  // probe search, scans and CSR fill are done
+                    signal_progress();
+                }
             }
             // Early cascades of tiers 3 and 6, the two tiers that accept segments above their real capacity (by
             // the allowance): what they give up on need not wait for the other tiers to be re-run -- the longest
