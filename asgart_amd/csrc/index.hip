@@ -59,6 +59,7 @@ const OptDesc kOptions[] = {
     {"cap6_pct", &Options::cap6_pct, 100, 200},
     {"early_cascade", &Options::early_cascade, 0, 1},
     {"progress_at", &Options::progress_at, 0, 2},
+    {"rank_lists", &Options::rank_lists, 0, 1},
     {"wg_items", &Options::wg_items, 0, 1 << 30},
     {"wg_items12", &Options::wg_items12, 0, 1 << 30},
 };
@@ -459,6 +460,8 @@ static void free_k_specific(asgart_index *idx) {
     if (idx->d_ptab) (void)hipFree(idx->d_ptab);
     if (idx->d_c8lo) (void)hipFree(idx->d_c8lo);
     if (idx->d_c8hi) (void)hipFree(idx->d_c8hi);
+    if (idx->d_sap) (void)hipFree(idx->d_sap);
+    idx->d_sap = nullptr;
     for (auto &f : idx->d_filter) {
         if (f) (void)hipFree(f);
         f = nullptr;
@@ -574,6 +577,11 @@ int32_t index_prepare(asgart_index *idx, uint64_t k) {
     RC_TRY(idx->wide ? build(uint64_t{}) : build(uint32_t{}));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));
+    // position-sorted occurrence lists (one key word per probe, whole suffix array, 32-bit positions)
+    if (idx->opt.rank_lists && !idx->wide && !idx->trimmed && k <= (uint64_t)kMaxKey && n_sa > 0) {
+        HIP_TRY(hipMalloc(&idx->d_sap, (n_sa + 16) * 4));
+        RC_TRY(build_rank_lists(idx->d_keys, (const uint32_t *)idx->d_sa, n_sa, (uint32_t *)idx->d_sap, s));
+    }
     // text-tail corner list (host, from the last bytes of the text)
     idx->n_tail8 = 0;
     idx->tail_bloom = 0;
@@ -677,7 +685,7 @@ void asgart_index_destroy(asgart_index *idx) {
     for (auto &cx : idx->ctx) {
         Workspace &w = cx.ws;
         DevBuf *bufs[] = {&w.chunks, &w.p_lo, &w.p_raw, &w.p_filt, &w.row_off, &w.blk, &w.hits,
-                          &w.big_list, &w.seg_list, &w.counters, &w.fam_sds, &w.ovf_list,
+                          &w.big_list, &w.rank_list, &w.seg_list, &w.counters, &w.fam_sds, &w.ovf_list,
                           &w.scratch, &w.hit_flag, &w.seg_keys, &w.seg_vals, &w.sort_tmp, &w.pat,
                           &w.out_a, &w.out_b};
         for (DevBuf *b : bufs) b->release();

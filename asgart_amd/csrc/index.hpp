@@ -40,6 +40,8 @@ struct IndexView {
     // presence filter of the orientation of this call (search_dev.hpp); null: no filter
     const uint64_t *flt;
     int flt_bits;
+    // occurrences of every k-mer interval sorted by position (sa_build.hip: build_rank_lists); null: none
+    const SlotT *sap;
     // number of suffix-array slots: n, or end - start + 1 for a --trim index (reference
     // src/bin/asgart.rs:142-148), whose array holds the suffixes of data[start..end] + '$' only
     uint64_t n_sa;
@@ -90,6 +92,7 @@ struct Workspace {
     DevBuf blk;        // scan block aggregates
     DevBuf hits;       // PosT[total hits]
     DevBuf big_list;   // u32[P] probes with large SA intervals
+    DevBuf rank_list;  // u32[P] ... of them, those counted by bisection (position-sorted lists)
     DevBuf seg_list;   // u32[...] segment start probes
     DevBuf counters;   // u64[32] device counters
     DevBuf fam_sds;    // SdRec[cap] output records of the extension kernel
@@ -191,12 +194,14 @@ struct Options {
     int64_t kfilter_bits = 30;      // log2(bits) of the k-mer presence filter (search_dev.hpp); 0: no filter
     int64_t wg_items = 0;           // segments a workgroup of tiers 3..7 runs before it retires (0: persistent)
     int64_t wg_items12 = 0;         // ... work-list fetches (8 segments / 1 segment) of a tier-1 / tier-2 wave
+    int64_t rank_lists = 1;         // 1: position-sorted occurrence lists for the cardinality test (32-bit indexes, k <= 21)
     int64_t progress_at = 2;        // when a call reports its probes as searched (pipeline.hip: progress)
     int64_t early_cascade = 1;      // 1: tier 6's overflow is re-run as soon as tier 6 is done, not after the last tier
     int64_t cap6_pct = 140;         // tier 6 accepts segments whose arm bound is up to this percentage of its capacity
     int64_t tier_streams = 7234562; // digit t (from the left): the stream (1..7, 1 = the call's high-priority main stream) tier t runs on
 };
-int32_t create_ctx_streams(SearchCtx &cx);  // the streams and events of one call context (current device)
+int32_t create_ctx_streams(SearchCtx &cx);
+int32_t build_rank_lists(const uint64_t *d_keys, const uint32_t *d_sa, uint64_t n, uint32_t *d_sap, hipStream_t s);  // the streams and events of one call context (current device)
 int32_t option_set(Options &o, const char *name, int64_t value);  // ASGART_E_ARG: unknown name / bad value
 void options_from_env(Options &o);
 }  // namespace asgart
@@ -219,6 +224,7 @@ struct asgart_index {
     void *d_ptab = nullptr;
     void *d_c8lo = nullptr;
     void *d_c8hi = nullptr;
+    void *d_sap = nullptr;   // position-sorted occurrence lists (IndexView::sap), or null
     uint64_t *d_filter[4] = {nullptr, nullptr, nullptr, nullptr};  // per orientation: reverse * 2 + complement
     int filter_bits = 0;                                           // log2 of their size in bits
     uint32_t tail8[asgart::kMaxK];
@@ -290,6 +296,7 @@ struct asgart_index {
         v.tail_bloom = tail_bloom;
         v.flt = nullptr;
         v.flt_bits = 0;
+        v.sap = reinterpret_cast<const SlotT *>(d_sap);
         v.n_sa = (uint64_t)n_sa;
         v.trim = trimmed ? 1 : 0;
         v.n_bad = n_bad;

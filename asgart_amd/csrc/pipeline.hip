@@ -213,6 +213,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
     RC_TRY(w.row_off.reserve(((size_t)W + 1) * 8));
     RC_TRY(w.blk.reserve((size_t)n_blk * sizeof(ScanEl)));
     RC_TRY(w.big_list.reserve((size_t)W * 4));
+    if (idx->d_sap) RC_TRY(w.rank_list.reserve((size_t)W * 4));
     RC_TRY(w.seg_list.reserve((size_t)seg_cap * 4));
     RC_TRY(w.counters.reserve(CT_COUNT * 8));
     unsigned long long *d_ctr = w.counters.as<unsigned long long>();
@@ -232,14 +233,18 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
     unsigned long long *row_off = w.row_off.as<unsigned long long>() - w_lo;
     ScanEl *blk = w.blk.as<ScanEl>();
     uint32_t *big_list = w.big_list.as<uint32_t>();
+    uint32_t *rank_list = w.rank_list.as<uint32_t>();
     uint32_t *seg_list = w.seg_list.as<uint32_t>();
 
     // ---- K1: probe search + filtered counts -----------------------------------
     HIP_TRY(hipEventRecord(cx.ev[0], s));
     probe_count_kernel<SlotT, false><<<grid_for(W, kProbeBlock), kProbeBlock, 0, s>>>(
-        ix, rp, p_lo, p_raw, p_filt, big_list, d_ctr);
+        ix, rp, p_lo, p_raw, p_filt, big_list, rank_list, d_ctr);
     HIP_TRY(hipEventRecord(cx.ev[11], s));
     big_count_kernel<SlotT, false><<<2048, 256, 0, s>>>(ix, rp, p_lo, p_raw, p_filt, big_list, d_ctr);
+    // (after big_count_kernel: what it appends to big_list is for the fill only)
+    if (ix.sap)
+        rank_count_kernel<SlotT, false><<<2048, 256, 0, s>>>(ix, rp, p_lo, p_raw, p_filt, rank_list, big_list, d_ctr);
     HIP_TRY(hipEventRecord(cx.ev[1], s));
     // ---- K2: scans + segmentation ----------------------------------------------
     scan_reduce_kernel<<<n_blk, kScanBlock, 0, s>>>(rp, p_filt, blk);
@@ -974,10 +979,14 @@ int32_t asgart_get_stats(asgart_index *idx, uint32_t flags, asgart_stats *out) {
                 ix.flt = idx->d_filter[mode];
                 ix.flt_bits = idx->filter_bits;
                 probe_count_kernel<SlotT, true><<<gp, kProbeBlock, 0, s>>>(
-                    ix, rp, nullptr, nullptr, nullptr, nullptr, d_ctr);
+                    ix, rp, nullptr, nullptr, nullptr, nullptr, nullptr, d_ctr);
                 big_count_kernel<SlotT, true><<<2048, 256, 0, s>>>(
                     ix, rp, cx.ws.p_lo.as<SlotT>() - rp.g_lo, cx.ws.p_raw.as<uint32_t>() - rp.g_lo, nullptr,
                     cx.ws.big_list.as<uint32_t>(), d_ctr);
+                if (ix.sap)
+                    rank_count_kernel<SlotT, true><<<2048, 256, 0, s>>>(
+                        ix, rp, cx.ws.p_lo.as<SlotT>() - rp.g_lo, cx.ws.p_raw.as<uint32_t>() - rp.g_lo, nullptr,
+                        cx.ws.rank_list.as<uint32_t>(), nullptr, d_ctr);
             };
             if (idx->wide) account(uint64_t{}); else account(uint32_t{});
             HIP_TRY(hipGetLastError());

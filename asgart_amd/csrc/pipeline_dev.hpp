@@ -45,6 +45,8 @@ enum Counter {
     // 16..33 and 56..67: per-phase cycle sums of the diagnostic build (-DASGART_PROFILE_EXTEND)
     CT_EARLY_N = 34,    // early cascade launches (of tiers 3 and 6): list lengths ...
     CT_EARLY_CUR = 36,  // ... and work cursors
+    CT_RANK = 38,       // entries in rank_list (large intervals counted by bisection of the position-sorted lists)
+    CT_BIG0 = 39,       // entries of big_list that big_count_kernel counted (later ones were appended for the fill)
     CT_ALG_BYTES = 68,  // accounting pass: bytes the probe-search kernels move by design
     CT_FLT_REJECTED,    // accounting pass: probes answered by the presence filter alone
     CT_LONGSEG,         // placement: segments the lane-per-segment walk handed to the wave-per-segment kernel
@@ -122,6 +124,7 @@ __device__ inline unsigned long long lane_of(unsigned long long v, uint32_t l) {
 // COUNT = true is the accounting pass behind bench.py's `kernel_algorithmic_bytes`: the same
 // control flow, no stores, every load / store of the real kernel priced in bytes.
 constexpr int kProbeBlock = 256;
+constexpr int kRankMin = 256;  // intervals above this size are counted by bisection when the index has position-sorted lists
 constexpr int kMaxHalf = (kMaxKey + 1) / 2;                                 // bases per half (one-word keys)
 constexpr int kWinBytes = ((kProbeBlock + 2) * kMaxHalf + 15 + 16 + 15) / 16 * 16;  // <= 256 lanes x 16 B
 
@@ -131,6 +134,7 @@ __global__ __launch_bounds__(kProbeBlock) void probe_count_kernel(IndexView<Slot
                                                                   uint32_t *__restrict__ p_raw,
                                                                   uint32_t *__restrict__ p_filt,
                                                                   uint32_t *__restrict__ big_list,
+                                                                  uint32_t *__restrict__ rank_list,
                                                                   unsigned long long *__restrict__ ctr) {
     __shared__ __attribute__((aligned(16))) uint8_t s_text[kWinBytes];
     __shared__ uint32_t s_half[kProbeBlock + 2];
@@ -198,13 +202,14 @@ __global__ __launch_bounds__(kProbeBlock) void probe_count_kernel(IndexView<Slot
     // (wave ballot + one LDS atomic per wave) and looked up by the first ceil(n / 64) waves with all lanes busy;
     // the other waves retire at once and their slots go to the next workgroup, so that more full waves of
     // gathers are in flight per CU.
-    __shared__ uint32_t s_nsurv, s_nbig;
+    __shared__ uint32_t s_nsurv, s_nbig, s_nrank;
     __shared__ uint8_t s_surv[kProbeBlock];
-    __shared__ uint32_t s_big[kProbeBlock];
-    __shared__ unsigned long long s_bbase;
+    __shared__ uint32_t s_big[kProbeBlock];   // large intervals: counted by streaming from the front, by bisection from the back
+    __shared__ unsigned long long s_bbase, s_rbase;
     if (tid == 0) {  // (ordered before their first use by the barrier behind the filter tests)
         s_nsurv = 0;
         s_nbig = 0;
+        s_nrank = 0;
     }
     uint32_t n_rej = 0;
     bool survivor = false;
@@ -254,9 +259,13 @@ __global__ __launch_bounds__(kProbeBlock) void probe_count_kernel(IndexView<Slot
         } else {
             if (!COUNT) {
                 p_filt[g_] = kPending;
-                s_big[atomicAdd(&s_nbig, 1u)] = g_;
+                // a whole k-mer interval of some size: its kept count is a bisection of the position-sorted list
+                if (ix.sap && all_occurrences && raw > (uint64_t)kRankMin)
+                    s_big[kProbeBlock - 1 - atomicAdd(&s_nrank, 1u)] = g_;
+                else
+                    s_big[atomicAdd(&s_nbig, 1u)] = g_;
             }
-            cb.wr(4 + 4);  // + its big_list entry
+            cb.wr(4 + 4);  // + its work-list entry
         }
     };
     if (uniform) {
@@ -307,12 +316,89 @@ __global__ __launch_bounds__(kProbeBlock) void probe_count_kernel(IndexView<Slot
         // workgroup-aggregated append to the large-interval work list (one global atomic per group); the waves
         // still running hold every entry: nbig <= the number of survivors
         __syncthreads();
-        const uint32_t nbig = s_nbig;
-        if (nbig) {
-            if (tid == 0) s_bbase = atomicAdd(&ctr[CT_BIG], (unsigned long long)nbig);
+        const uint32_t nbig = s_nbig, nrank = s_nrank;
+        if (nbig | nrank) {
+            if (tid == 0) {
+                if (nbig) s_bbase = atomicAdd(&ctr[CT_BIG], (unsigned long long)nbig);
+                if (nrank) s_rbase = atomicAdd(&ctr[CT_RANK], (unsigned long long)nrank);
+            }
             __syncthreads();
             if (tid < nbig) big_list[s_bbase + tid] = s_big[tid];
+            if (tid < nrank) rank_list[s_rbase + tid] = s_big[kProbeBlock - 1 - tid];
         }
+    }
+}
+
+// Large whole-k-mer intervals when the index holds the position-sorted occurrence lists: the hit filter keeps the
+// occurrences beyond a position threshold (src/automaton.rs:105-114), so the kept count is one bisection of
+// sap[lo..hi) -- a dozen gathers instead of the ~1000 suffix-array entries a probe of a frequent k-mer streams
+// before the early exit at max_cardinality + 1.  One thread per interval.  Probes that stay below the cardinality
+// limit are appended to big_list, from which fill_big_kernel materialises their hits (in suffix-array order).
+template <class SlotT, bool COUNT>
+__global__ __launch_bounds__(256) void rank_count_kernel(IndexView<SlotT> ix, RunParams rp,
+                                                         const SlotT *__restrict__ p_lo,
+                                                         const uint32_t *__restrict__ p_raw,
+                                                         uint32_t *__restrict__ p_filt,
+                                                         const uint32_t *__restrict__ rank_list,
+                                                         uint32_t *__restrict__ big_list,
+                                                         unsigned long long *__restrict__ ctr) {
+    const uint64_t n_rank = ctr[CT_RANK];
+    const uint32_t lane = threadIdx.x & 63u;
+    unsigned long long bytes = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t e0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) & ~63ull; e0 < n_rank; e0 += stride) {
+        const uint64_t e = e0 + lane;
+        bool refill = false;
+        uint32_t g = 0;
+        if (e < n_rank) {
+            g = rank_list[e];
+            const int c = chunk_of(rp.ch, g);
+            const uint64_t s = rp.ch.start[c], L = rp.ch.len[c];
+            const uint64_t i = (uint64_t)(g - rp.ch.pbase[c] + 1) * (uint64_t)rp.step;
+            const SlotT *__restrict__ a = ix.sap + p_lo[g];
+            const uint64_t R = p_raw[g];
+            bytes += 4 + sizeof(SlotT) + 4 + 4;  // list entry, interval, final count
+            // first index whose position is >= t
+            auto first_ge = [&](uint64_t t) {
+                uint64_t lo = 0, hi = R;
+                while (lo < hi) {
+                    const uint64_t mid = lo + ((hi - lo) >> 1);
+                    bytes += sizeof(SlotT);
+                    if ((uint64_t)a[mid] < t) lo = mid + 1; else hi = mid;
+                }
+                return lo;
+            };
+            uint64_t cnt;
+            if (!rp.reverse) {
+                cnt = R - first_ge(i + s + 1u);  // keep_hit: x > i + s
+            } else {
+                const uint64_t t = s + L - i;  // keep_hit: x != i && x >= s + L - i
+                cnt = R - first_ge(t);
+                if (i >= t) {
+                    const uint64_t j = first_ge(i);
+                    if (j < R && (uint64_t)a[j] == i) --cnt;
+                }
+            }
+            const uint32_t f = cnt > (uint64_t)rp.C ? kSkipCard : (uint32_t)cnt;
+            if (!COUNT) p_filt[g] = f;
+            refill = f != 0u && f < kPending;
+        }
+        if (!COUNT) {
+            const unsigned long long m = __ballot(refill);
+            if (m) {
+                const int leader = __ffsll((long long)m) - 1;
+                unsigned long long at = 0;
+                if ((int)lane == leader) at = atomicAdd(&ctr[CT_BIG], (unsigned long long)__popcll(m));
+                at = __shfl(at, leader);
+                if (refill) big_list[at + __popcll(m & ((1ull << lane) - 1ull))] = g;
+            }
+        } else {
+            bytes += refill ? 4u : 0u;
+        }
+    }
+    if (COUNT) {
+        for (int off = 32; off > 0; off >>= 1) bytes += __shfl_down(bytes, off);
+        if (lane == 0 && bytes) atomicAdd(&ctr[CT_ALG_BYTES], bytes);
     }
 }
 
@@ -328,7 +414,9 @@ __global__ __launch_bounds__(256) void big_count_kernel(IndexView<SlotT> ix, Run
                                                         const uint32_t *__restrict__ big_list,
                                                         unsigned long long *__restrict__ ctr) {
     const uint32_t lane = threadIdx.x & 63u;
-    const uint64_t n_big = ctr[CT_BIG];
+    // (the accounting pass runs after the call: the list has grown by what rank_count_kernel appended for the fill)
+    const uint64_t n_big = COUNT ? ctr[CT_BIG0] : ctr[CT_BIG];
+    if (!COUNT && blockIdx.x == 0 && threadIdx.x == 0) ctr[CT_BIG0] = n_big;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     unsigned long long bytes = 0;

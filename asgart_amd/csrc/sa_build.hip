@@ -607,6 +607,58 @@ int32_t sa_build_device(const uint8_t *d_text, int64_t n, void *d_sa, bool wide,
     return build_t<uint32_t>(d_text, n, (uint32_t *)d_sa, dna, stream);
 }
 
+
+// ---- position-sorted occurrence lists (index.hpp: asgart_index::d_sap) -------------------------------------
+// sap[lo..hi) = the suffix-array entries of the k-mer interval [lo,hi), sorted by POSITION.  The probe filter
+// of the reference (src/automaton.rs:105-114) keeps the occurrences beyond a position threshold, so the kept count
+// of a large interval is a bisection in this list instead of a read of the interval -- what the cardinality test
+// of a repeat-rich genome otherwise streams (16 GB per GRCh38-shaped pass).  Built as ONE device-wide sort of
+// (rank of the interval << 32 | position); 32-bit positions only.
+namespace {
+__global__ __launch_bounds__(256) void run_head_kernel(const uint64_t *__restrict__ keys, uint32_t *__restrict__ head,
+                                                       uint64_t n) {
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (uint64_t)gridDim.x * blockDim.x)
+        head[r] = (r > 0 && keys[r] != keys[r - 1]) ? 1u : 0u;
+}
+__global__ __launch_bounds__(256) void rank_pos_kernel(const uint32_t *__restrict__ rank, const uint32_t *__restrict__ sa,
+                                                       unsigned long long *__restrict__ out, uint64_t n) {
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (uint64_t)gridDim.x * blockDim.x)
+        out[r] = ((unsigned long long)rank[r] << 32) | sa[r];
+}
+__global__ __launch_bounds__(256) void low_word_kernel(const unsigned long long *__restrict__ in, uint32_t *__restrict__ out,
+                                                       uint64_t n) {
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (uint64_t)gridDim.x * blockDim.x)
+        out[r] = (uint32_t)in[r];
+}
+}  // namespace
+
+int32_t build_rank_lists(const uint64_t *d_keys, const uint32_t *d_sa, uint64_t n, uint32_t *d_sap, hipStream_t s) {
+    if (n == 0) return 0;
+    const unsigned g = (unsigned)std::min<uint64_t>((n + 255) / 256, 1u << 20);
+    DevBuf a, b, temp;
+    RC_TRY(a.reserve(n * 8));
+    RC_TRY(b.reserve(n * 8));
+    struct Free {
+        DevBuf &x, &y, &z;
+        ~Free() { x.release(); y.release(); z.release(); }
+    } guard{a, b, temp};
+    // interval ranks (in d_sap, which is free until the end): inclusive sum of the run heads
+    run_head_kernel<<<g, 256, 0, s>>>(d_keys, d_sap, n);
+    size_t bytes = 0;
+    HIP_TRY(rocprim::inclusive_scan(nullptr, bytes, d_sap, d_sap, (size_t)n, rocprim::plus<uint32_t>(), s));
+    RC_TRY(temp.reserve(bytes));
+    HIP_TRY(rocprim::inclusive_scan(temp.p, bytes, d_sap, d_sap, (size_t)n, rocprim::plus<uint32_t>(), s));
+    rank_pos_kernel<<<g, 256, 0, s>>>(d_sap, d_sa, a.as<unsigned long long>(), n);
+    bytes = 0;
+    HIP_TRY(rocprim::radix_sort_keys(nullptr, bytes, a.as<unsigned long long>(), b.as<unsigned long long>(), (size_t)n, 0, 64, s));
+    RC_TRY(temp.reserve(bytes));
+    HIP_TRY(rocprim::radix_sort_keys(temp.p, bytes, a.as<unsigned long long>(), b.as<unsigned long long>(), (size_t)n, 0, 64, s));
+    low_word_kernel<<<g, 256, 0, s>>>(b.as<unsigned long long>(), d_sap, n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
 }  // namespace asgart
 
 extern "C" int32_t asgart_sa_build64(const uint8_t *T, int64_t *SA, int64_t n) {

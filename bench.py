@@ -12,7 +12,7 @@ before the timed region; results (families of ProtoSD) are back on the host when
 cfg1..cfg5 are BASELINE.json configs[0..4] (cfg1: direct pass only; cfg3: --skip-masked).
 Prints ONE JSON line on rank 0 (driver contract), with two extra objects:
 
-"roofline" -- the dominant HBM-bound kernel pair, probe_count_kernel + big_count_kernel:
+"roofline" -- the dominant HBM-bound kernels, probe_count_kernel + big_count_kernel + rank_count_kernel:
     achieved  = kernel_algorithmic_bytes / avg_launch_ms: the bytes THIS kernel's design loads and
                 stores per launch (window staging, filter word, prefix-table entries, keys the
                 bisection reads, suffix-array entries read, outputs), counted exactly by the
@@ -51,6 +51,7 @@ import asgart_amd  # noqa: E402
 from asgart_amd import multi, prep, synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+GATHER_CEILING_GBS = 3120.0  # measured: random 4-/8-byte gathers, 64 B counted each (profiles/r02_ubench_gather.txt)
 DIRECT_RC = ((False, False), (True, True))  # direct, then -RC
 WORKLOADS = {
     # name: (synth config id, scale, skip_masked, modes, description)
@@ -269,7 +270,7 @@ def main():
     traffic = prof.get("traffic_bytes_per_launch")
     traffic_ms = prof.get("kernel_ms_per_launch")
     roofline = {
-        "bound": "hbm", "kernel": "probe_count_kernel + big_count_kernel (one launch = one pass)",
+        "bound": "hbm", "kernel": "probe_count_kernel + big_count_kernel + rank_count_kernel (one launch = one pass)",
         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 5),
         "kernel_algorithmic_bytes": int(alg_bytes),
@@ -287,6 +288,13 @@ def main():
         "traffic_x2_applied": False,
         "traffic_source": prof.get("source"),
         "waste": round(traffic / alg_bytes, 3) if traffic and alg_bytes else None,
+        # The kernels are random-gather bound: an 8- or 4-byte gather moves (and FETCH_SIZE counts) one 64-byte
+        # sector, so `traffic` exceeds the algorithmic bytes by design (`waste` is sector granularity, not re-reads),
+        # and the ceiling of this access pattern is the measured gather rate, not the 8 TB/s stream peak:
+        # tools/ubench_gather.hip, profiles/r02_ubench_gather.txt: 48.8 G gathers/s x 64 B.
+        "gather_ceiling": GATHER_CEILING_GBS,
+        "traffic_frac_of_gather_ceiling": (round(traffic / (traffic_ms / 1e3) / 1e9 / GATHER_CEILING_GBS, 4)
+                                           if traffic and traffic_ms else None),
         "reference_algorithm_bytes": int(ref_bytes),
         "filter_rejected_frac": round(sum(s["probes_filter_rejected"] for s in pass_stats) /
                                       max(1, sum(s["probes_searched"] for s in pass_stats)), 4),

@@ -52,18 +52,19 @@ def per_launch(ctr, prefix, field="avg_KB_per_launch"):
 # the product kernels only: <..., true> are the byte-accounting variants bench.py runs once per pass
 probe = "asgart::probe_count_kernel<unsigned int, false>"
 big = "asgart::big_count_kernel<unsigned int, false>"
+rank = "asgart::rank_count_kernel<unsigned int, false>"   # (absent from older profiles: contributes 0 then)
 if not any(k.startswith(probe) for k in pmc.get("FETCH_SIZE", {})):   # 64-bit index
-    probe, big = probe.replace("unsigned int", "unsigned long"), big.replace("unsigned int", "unsigned long")
-search = sum(per_launch(c, p) for c in ("FETCH_SIZE", "WRITE_SIZE") for p in (probe, big)) * 1024
+    probe, big, rank = (x.replace("unsigned int", "unsigned long") for x in (probe, big, rank))
+search = sum(per_launch(c, p) for c in ("FETCH_SIZE", "WRITE_SIZE") for p in (probe, big, rank)) * 1024
 # the kernels' own durations in the (serialising) PMC passes, averaged over the two passes
-pmc_ms = sum(per_launch(c, p, "avg_ns") for c in ("FETCH_SIZE", "WRITE_SIZE") for p in (probe, big)) / 2 / 1e6
+pmc_ms = sum(per_launch(c, p, "avg_ns") for c in ("FETCH_SIZE", "WRITE_SIZE") for p in (probe, big, rank)) / 2 / 1e6
 stats_ms = None
 sfile = os.path.join(dst, f"{tag}_{workload}_kernel_stats.csv")
 if os.path.exists(sfile):
     tot = 0.0
     for row in csv.DictReader(open(sfile)):
         nm = short(row["Name"])
-        if nm.startswith(probe) or nm.startswith(big):  # (short() keeps the template arguments)
+        if nm.startswith(probe) or nm.startswith(big) or nm.startswith(rank):  # (short() keeps the template arguments)
             tot += float(row["AverageNs"])
     stats_ms = tot / 1e6
 if search > 0:
@@ -84,7 +85,7 @@ if search > 0:
                   f"passes, kernels serialised) and profiles/{tag}_{workload}_kernel_stats.csv (--kernel-trace --stats of "
                   "the default bench run)",
     }
-    allw["_note"] = ("per workload: HBM-side bytes per launch (= per pass) of probe_count_kernel + big_count_kernel = "
+    allw["_note"] = ("per workload: HBM-side bytes per launch (= per pass) of probe_count_kernel + big_count_kernel + rank_count_kernel = "
                      "(FETCH_SIZE + WRITE_SIZE) KB * 1024; kernel_ms_per_launch = the two kernels' durations in those "
                      "PMC passes; stats_kernel_ms_per_launch = their rocprofv3 --stats averages in the un-instrumented "
                      "bench run (passes overlapped).  Narrow 4-8 byte gathers: FETCH_SIZE is used as reported (no x2); "
