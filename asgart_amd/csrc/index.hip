@@ -579,8 +579,18 @@ int32_t index_prepare(asgart_index *idx, uint64_t k) {
     HIP_TRY(hipStreamSynchronize(s));
     // position-sorted occurrence lists (one key word per probe, whole suffix array, 32-bit positions)
     if (idx->opt.rank_lists && !idx->wide && !idx->trimmed && k <= (uint64_t)kMaxKey && n_sa > 0) {
-        HIP_TRY(hipMalloc(&idx->d_sap, (n_sa + 16) * 4));
-        RC_TRY(build_rank_lists(idx->d_keys, (const uint32_t *)idx->d_sa, n_sa, (uint32_t *)idx->d_sap, s));
+        // (an optimisation only: without the memory for it -- the list or the sort's scratch -- the index does without)
+        if (hipMalloc(&idx->d_sap, (n_sa + 16) * 4) != hipSuccess) {
+            (void)hipGetLastError();
+            idx->d_sap = nullptr;
+        } else {
+            const int32_t rc_rank = build_rank_lists(idx->d_keys, (const uint32_t *)idx->d_sa, n_sa, (uint32_t *)idx->d_sap, s);
+            if (rc_rank != 0) {
+                (void)hipFree(idx->d_sap);
+                idx->d_sap = nullptr;
+                if (rc_rank != ASGART_E_OOM) return rc_rank;
+            }
+        }
     }
     // text-tail corner list (host, from the last bytes of the text)
     idx->n_tail8 = 0;
