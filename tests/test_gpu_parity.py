@@ -775,6 +775,39 @@ def test_64bit_slots_and_positions(hiplib, name, tier, monkeypatch):
         assert np.array_equal(lo, oidx.sa[:16])
 
 
+@pytest.mark.parametrize("card", [100, 1000])
+@pytest.mark.parametrize("reverse,complement", MODES)
+def test_large_intervals_counted_by_bisection(hiplib, reverse, complement, card):
+    """k-mer intervals of more than 256 entries are counted from the position-sorted occurrence lists (a bisection
+    at the hit filter's threshold, reference src/automaton.rs:105-114) instead of being read.  A tandem array of a
+    reverse-palindromic unit makes every probe of every orientation hit hundreds of positions -- in the reversed
+    orientations including the position equal to the probe's own offset, which the filter excludes by value.
+    Per-probe status / hit lists and the families against the oracle, below and above max_cardinality."""
+    rng = np.random.default_rng(5)
+    bases = np.frombuffer(b"ACGT", dtype=np.uint8)
+    half = rng.integers(0, 4, size=29)
+    unit = np.concatenate([half, half[::-1]])                  # its own reverse
+    arr = np.tile(unit, 700)
+    mut = rng.random(arr.shape) < 0.01
+    arr[mut] = (arr[mut] + rng.integers(1, 4, size=int(mut.sum()))) & 3
+    text = np.concatenate([bases[arr], np.frombuffer(b"$", dtype=np.uint8)])
+    chunks = [(0, len(text) - 1)]
+    oidx = oracle.Index.build(text)
+    cli = dict(max_cardinality=card, min_length=120)
+    with asgart_amd.Index(text, oidx.sa) as idx:
+        st = asgart_amd.RunSettings.from_cli(reverse=reverse, complement=complement, **cli)
+        ost = oracle.make_settings(reverse=reverse, complement=complement, **cli)
+        status, offs, hits = idx.probe_hits(chunks, st)
+        nd = oracle.prepare_needle(text, chunks[0], ost)
+        e_status, e_offs, e_hits = oidx.probe_hits(nd, 0, ost)
+        assert np.array_equal(status, e_status) and np.array_equal(offs, e_offs) and np.array_equal(hits, e_hits)
+        if not complement:   # (the unit is not its own complement: those orientations have no hits here)
+            assert int(np.diff(e_offs.astype(np.int64)).max(initial=0)) > 256 or int((e_status == 2).sum()) > 1000
+        f_offs, sds = idx.search_duplications_raw(chunks, st)
+        eoffs, esds = oidx.run_raw(chunks, ost)
+        assert np.array_equal(f_offs, eoffs) and np.array_equal(sds, esds), (reverse, complement, card)
+
+
 @pytest.mark.parametrize("wide", [0, 1])
 def test_tier6_with_thousands_of_live_arms(hiplib, wide, monkeypatch):
     """The largest arm-resident shape with several layers in use: a 100-bp tandem array of 650 diverged copies keeps
