@@ -314,6 +314,9 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
         //  5  arm-resident, 512 threads, 2 per CU (K4c 4x512)                        <= 2048
         //  6  arm-resident, 512 threads, 1 per CU (K4c 9x512)                        <= 4608 * 1.4 (by the bound)
         //  7  arms in HBM scratch (K4b MODE 2)                                       <= 16384
+        // (64-bit positions: 5x64 / 2x1024 / 2x256 / 2x512 / 8x512 with the left ends in HBM / 8192.)
+        // Streams: the short chip-wide kernels on the call's high-priority main stream; tiers 1..6 on six
+        // low-priority streams of their own, tier 7 behind tier 2 (option tier_streams).
         // With max_cardinality > 1024 (or ASGART_ARMS_KERNEL=0, tests) the LDS-array kernels K4b take
         // tiers 2, 4 and 6 (768 / 2432 / 4608 * 1.4 arms) and tiers 3 and 5 stay empty; the small
         // shapes 2 and 4 stage 512 hits per probe and are skipped when max_cardinality > 512.
