@@ -15,13 +15,10 @@ namespace asgart {
 
 static thread_local char g_err[512] = "";
 
-// Load-time runtime default.  The extension tiers of one call run on six HIP streams (twelve with two calls in
-// flight); ROCm maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and kernels of streams that
-// share a queue run one after the other.  Ask for 8 unless the host chose a value itself.  It takes effect when
-// this library is loaded before the process's first HIP call; measured on the GRCh38-shaped
-// workload: 441 -> 421 ms per step back to back, chr1-shaped 40 -> 31 ms.
-__attribute__((constructor)) static void runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
-
+// Runtime note.  The extension tiers of one call run on six HIP streams (twelve with
+// two calls in flight); ROCm maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and kernels of
+// streams that share a queue run one after the other.  The HOST exports GPU_MAX_HW_QUEUES=8 before its first HIP
+// call (the Python binding and bench.py do); the library never touches the process environment.
 void set_error(const char *fmt, ...) {
     va_list ap;
     va_start(ap, fmt);

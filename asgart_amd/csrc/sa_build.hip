@@ -636,12 +636,12 @@ int32_t build_rank_lists(const uint64_t *d_keys, const uint32_t *d_sa, uint64_t 
     if (n == 0) return 0;
     const unsigned g = (unsigned)std::min<uint64_t>((n + 255) / 256, 1u << 20);
     DevBuf a, b, temp;
-    RC_TRY(a.reserve(n * 8));
-    RC_TRY(b.reserve(n * 8));
-    struct Free {
+    struct Free {  // (before the first reservation: a failed second one must not leave the first behind)
         DevBuf &x, &y, &z;
         ~Free() { x.release(); y.release(); z.release(); }
     } guard{a, b, temp};
+    RC_TRY(a.reserve(n * 8));
+    RC_TRY(b.reserve(n * 8));
     // interval ranks (in d_sap, which is free until the end): inclusive sum of the run heads
     run_head_kernel<<<g, 256, 0, s>>>(d_keys, d_sap, n);
     size_t bytes = 0;

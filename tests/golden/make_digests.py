@@ -16,7 +16,7 @@ same seeded inputs and compare against these digests ("for
 raw families CPU == HIP").
 
 Usage (CPU only; cfg4 needs ~35 GB of RAM and about an hour on 8 cores):
-    python tests/golden/make_digests.py [cfg3s] [cfg4] [--threads N]
+    python tests/golden/make_digests.py [cfg3s] [cfg4] [cfg5h] [--threads N]
 Existing entries of digests.json for configs not named on the command line are kept.
 """
 from __future__ import annotations
@@ -41,7 +41,13 @@ MODES = (("direct", False, False), ("rc", True, True))
 CASES = {
     "cfg3s": (3, 1.0, True),
     "cfg4": (4, 1.0, False),
+    # BASELINE.json configs[4] (two files: genome + its diverged copy) at the smallest scale whose
+    # text needs 64-bit suffix-array entries (n >= 2^32): the natively wide instantiations of every
+    # kernel.  ~50 GB of RAM; the -RC pass is digested first (the direct pass of two near-identical
+    # genomes is one serial chain per record and takes the oracle hours).
+    "cfg5h": (5, 0.7, False),
 }
+WIDE_N = (1 << 32) - 256  # texts from this size on are indexed with 64-bit slots
 
 
 def sha_array(a: np.ndarray, dtype: str, slab: int = 1 << 26) -> str:
@@ -53,7 +59,7 @@ def sha_array(a: np.ndarray, dtype: str, slab: int = 1 << 26) -> str:
     return h.hexdigest()
 
 
-def digest_case(name: str, threads: int) -> dict:
+def digest_case(name: str, threads: int, save=lambda out: None) -> dict:
     cfg, scale, skip_masked = CASES[name]
     t0 = time.time()
     recs = synth.config_genome(cfg, scale)
@@ -69,11 +75,15 @@ def digest_case(name: str, threads: int) -> dict:
         "text_bytes": int(len(pr.data)), "chunks": len(pr.chunks),
         "text_sha256": sha_array(pr.data, "<u1"),
         "chunks_sha256": sha_array(np.array(pr.chunks, dtype=np.uint64), "<u8"),
-        "sa_sha256_u32": sha_array(oidx.sa, "<u4"),
         "numpy": np.__version__,
         "passes": {},
     }
-    for label, rev, comp in MODES:
+    if len(pr.data) >= WIDE_N:
+        out["sa_sha256_u64"] = sha_array(oidx.sa, "<u8")
+    else:
+        out["sa_sha256_u32"] = sha_array(oidx.sa, "<u4")
+    save(out)
+    for label, rev, comp in (MODES[::-1] if len(pr.data) >= WIDE_N else MODES):
         t0 = time.time()
         st = oracle.Stats()
         offs, sds = oidx.run_raw(pr.chunks, oracle.make_settings(reverse=rev, complement=comp),
@@ -90,6 +100,7 @@ def digest_case(name: str, threads: int) -> dict:
             "oracle_seconds": round(time.time() - t0, 1), "oracle_threads": threads,
         }
         print(f"[{name}] {label}: {len(offs) - 1} families, {len(sds)} ProtoSDs ({time.time() - t0:.0f}s)", flush=True)
+        save(out)
     oidx.close()
     return out
 
@@ -102,11 +113,17 @@ def main():
         args = [a for a in args if a != str(threads)]
     names = args or list(CASES)
     res = json.load(open(OUT)) if os.path.exists(OUT) else {}
+    def save_as(name):
+        def save(out):  # after the suffix array and after every pass: a long run leaves what it finished
+            res[name] = out
+            with open(OUT + ".tmp", "w") as fh:
+                json.dump(res, fh, indent=1, sort_keys=True)
+                fh.write("\n")
+            os.replace(OUT + ".tmp", OUT)
+        return save
+
     for name in names:
-        res[name] = digest_case(name, threads)
-        with open(OUT, "w") as fh:
-            json.dump(res, fh, indent=1, sort_keys=True)
-            fh.write("\n")
+        digest_case(name, threads, save_as(name))
 
 
 if __name__ == "__main__":

@@ -402,6 +402,29 @@ def test_arm_kernel_window_levels(hiplib, levels, monkeypatch):
             assert np.array_equal(offs, eoffs) and np.array_equal(sds, esds), (levels, rc)
 
 
+def test_cfg1_ecoli_sized_direct_bit_exact(hiplib):
+    """BASELINE.json configs[0]: E. coli MG1655-sized synthetic (4.6 Mb, one record), direct duplications,
+    k=20 g=100 -- the reference's own CPU-runnable case.  One chunk, so the reference's outer par_iter has no
+    parallelism (src/bin/asgart.rs:201-205); the HIP path (suffix array built on the GPU) must give the
+    oracle's families bit for bit, with the oracle's own SA-IS suffix array as well."""
+    pr = prep.prepare_records(synth.config_genome(1))
+    assert len(pr.data) == 4_641_652 + 1
+    osa = oracle.divsufsort64(pr.data)
+    with asgart_amd.Index(pr.data, None) as idx:
+        assert np.array_equal(idx.sa_read(0, len(pr.data)).astype(np.int64), osa)
+        oidx = oracle.Index.build(pr.data, osa)
+        st = asgart_amd.RunSettings.from_cli()
+        offs, sds = idx.search_duplications_raw(pr.chunks, st)
+        ost = oracle.Stats()
+        eoffs, esds = oidx.run_raw(pr.chunks, oracle.make_settings(), threads=4, stats=ost)
+        assert np.array_equal(offs, eoffs) and np.array_equal(sds, esds)
+        assert len(sds) > 0
+        got, want = idx.stats().as_dict(), ost.as_dict()
+        for key in ("probes_total", "probes_n_skipped", "probes_searched", "probes_card_skipped",
+                    "probes_with_hits", "raw_hits", "filtered_hits"):
+            assert got[key] == want[key], key
+
+
 def test_cfg2_yeast_sized_direct_and_rc_bit_exact(hiplib):
     """BASELINE.json configs[1]: S. cerevisiae-sized synthetic (12.2 Mb, 17 records), direct + RC
     on one MI355X, suffix array built on the GPU, bit-exact against the CPU oracle; also as
@@ -465,7 +488,11 @@ def _check_against_oracle_digest(name):
     assert _sha_slabs([np.array(pr.chunks, dtype=np.uint64)], "<u8") == d["chunks_sha256"]
     cli = d["settings"]
     with asgart_amd.Index(pr.data, None) as idx:   # suffix array built on the GPU
-        assert _sha_slabs((idx.sa_read(o, min(n, o + slab)) for o in range(0, n, slab)), "<u4") == d["sa_sha256_u32"]
+        if "sa_sha256_u64" in d:   # n >= 2^32: 64-bit suffix-array entries
+            assert _sha_slabs((idx.sa_read(o, min(n, o + slab)) for o in range(0, n, slab)), "<u8") == d["sa_sha256_u64"]
+        else:
+            assert _sha_slabs((idx.sa_read(o, min(n, o + slab)) for o in range(0, n, slab)), "<u4") == d["sa_sha256_u32"]
+        assert d["passes"], name
         for label, want in d["passes"].items():
             st = asgart_amd.RunSettings.from_cli(k=cli["k"], gap=cli["gap"], min_length=cli["min_length"],
                                                  max_cardinality=cli["max_cardinality"],
