@@ -53,12 +53,15 @@ const OptDesc kOptions[] = {
     {"test_wide_batch", &Options::test_wide_batch, 0, 1ll << 40},
     {"kfilter_bits", &Options::kfilter_bits, 0, 34},
     {"tier_streams", &Options::tier_streams, 1111111, 7777777},
-    {"cap6_pct", &Options::cap6_pct, 100, 200},
+    {"cap6_pct", &Options::cap6_pct, 100, 400},
     {"early_cascade", &Options::early_cascade, 0, 1},
     {"progress_at", &Options::progress_at, 0, 2},
     {"rank_lists", &Options::rank_lists, 0, 1},
     {"wg_items", &Options::wg_items, 0, 1 << 30},
     {"wg_items12", &Options::wg_items12, 0, 1 << 30},
+    {"fast", &Options::fast, 0, 255},
+    {"fast_nt", &Options::fast_nt, 256, 1024},
+    {"fast_s", &Options::fast_s, 0, 16},
 };
 }  // namespace
 

@@ -5,6 +5,7 @@
 // src/bin/asgart.rs:201-253 (chunk fan-out, needle preparation, automaton,
 // left fix-up, fold in chunk order).
 #include "pipeline_dev.hpp"
+#include "extend_fast_dev.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -68,6 +69,8 @@ template <class SlotT> constexpr int kMidArmsLayers = sizeof(SlotT) == 4 ? 4 : 2
 constexpr int kWaveArmsHits = 512;
 constexpr uint64_t kGrid2Arms = 256ull * 8ull;
 template <class SlotT> constexpr int kLongArmsLayers = sizeof(SlotT) == 4 ? 5 : 2;  // tier 3: 5 x 1024 arms
+// ... of the two-barrier kernel (option fast, extend_fast_dev.hpp): 4 x 1024 / 2 x 1024 arm slots
+template <class SlotT> constexpr int kFastLongLayers = sizeof(SlotT) == 4 ? 4 : 2;
 constexpr int kPoleLdsPad = 0;             // > 0: tier 3 workgroups take a whole CU (measured: no gain)
 constexpr int kArmCapSmall = 256;   // live arms per wave in LDS, common case
 constexpr uint32_t kTier1MaxSum = 20000;  // placement: busier segments never run on a single wave
@@ -324,13 +327,16 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
         constexpr int capg = sizeof(SlotT) == 4 ? kArmCapGlobal32 : kArmCapGlobal64;
         const bool arms_kernel = rp.C <= (uint64_t)kHitBatch && opt.arms_kernel != 0;
         const bool arms_small = arms_kernel && rp.C <= (uint64_t)kWaveArmsHits;
+        // the two-barrier kernel packs a 64-bit position into 42 bits of a table entry
+        auto fast_tier = [&](int t) { return arms_kernel && ((opt.fast >> t) & 1) != 0 && (uint64_t)idx->n < (1ull << 42); };
         uint32_t tier_cap[kTiers + 1] = {0, kArmCapSmall, 0, 0, 0, 0, 0, (uint32_t)capg};
         if (arms_kernel) {
             if (arms_small) {
                 tier_cap[2] = (uint32_t)kWaveArmsLayers<SlotT> * 64u;
                 tier_cap[4] = (uint32_t)kMidArmsLayers<SlotT> * 256u;
             }
-            tier_cap[3] = (uint32_t)kLongArmsLayers<SlotT> * 1024u;
+            tier_cap[3] = (uint32_t)(fast_tier(3) ? kFastLongLayers<SlotT> : kLongArmsLayers<SlotT>) * 1024u;
+            if (fast_tier(3) && opt.fast_s) tier_cap[3] = (uint32_t)(opt.fast_s <= 4 ? 4 : (opt.fast_s <= 8 ? 8 : 16)) * (uint32_t)(opt.fast_nt >= 1024 ? 1024 : (opt.fast_nt >= 512 ? 512 : 256));
             tier_cap[5] = (uint32_t)kMidArmsLayers<SlotT> * 512u;
             // the window bound is pessimistic for tandem arrays (hits extend arms there) and the HBM
             // tier is several times slower per probe: tier 6 also takes segments whose bound exceeds
@@ -487,7 +493,23 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                         extend_heavy_kernel<SlotT, kArmCapMid, kMidThreads, 0><<<grid(kGrid2), kMidThreads, 0, st>>>(ep);
                     break;
                 case 3:
-                    extend_arms_kernel<SlotT, kLongArmsLayers<SlotT>, 1024, kHitBatch, 1024, 4, false, true, kPoleLdsPad><<<grid(256), 1024, 0, st>>>(ep);
+                    if (fast_tier(3)) {
+                        // (the same capacity in three shapes: per-probe work every wave repeats -- ranking the
+                        // empty slots and the unmatched hits -- is paid once per wave sharing a SIMD)
+                        const int nt = opt.fast_nt >= 1024 ? 1024 : (opt.fast_nt >= 512 ? 512 : 256);
+                        const int fs = opt.fast_s ? (int)opt.fast_s : kFastLongLayers<SlotT> * 1024 / nt;
+                        if (nt == 1024)
+                            extend_fast_kernel<SlotT, 4, 1024, kHitBatch><<<grid(256), 1024, 0, st>>>(ep);
+                        else if (nt == 512 && fs <= 4)
+                            extend_fast_kernel<SlotT, 4, 512, kHitBatch><<<grid(256), 512, 0, st>>>(ep);
+                        else if (nt == 512)
+                            extend_fast_kernel<SlotT, 8, 512, kHitBatch><<<grid(256), 512, 0, st>>>(ep);
+                        else if (fs <= 8)
+                            extend_fast_kernel<SlotT, 8, 256, kHitBatch><<<grid(256), 256, 0, st>>>(ep);
+                        else
+                            extend_fast_kernel<SlotT, 16, 256, kHitBatch><<<grid(256), 256, 0, st>>>(ep);
+                    } else
+                        extend_arms_kernel<SlotT, kLongArmsLayers<SlotT>, 1024, kHitBatch, 1024, 4, false, true, kPoleLdsPad><<<grid(256), 1024, 0, st>>>(ep);
                     break;
                 case 4:
                     if (arms_kernel)
