@@ -1,28 +1,38 @@
-// extend_fast_dev.hpp -- "K6": the two-barrier arm-resident extension kernel.
+// extend_fast_dev.hpp -- "K6": the one-barrier arm-resident extension kernel.
 //
 // Same automaton as K4 / K4b / K4c (reference src/automaton.rs:57-204, representation of
 // pipeline_dev.hpp: only live arms are kept, winners by creation number, families by records),
-// organised so that one processed hit-probe costs the workgroup TWO barrier intervals with
-// loop-free lookups, and a run of quiet probes costs nothing until the next hit-probe:
+// organised so that one processed hit-probe costs the workgroup ONE barrier, with loop-free
+// lookups and branch-free per-arm code, and a run of quiet probes costs nothing until the next
+// hit-probe:
 //
-//   table   the hits of one probe sit INLINE in a bucket table: row = (x >> bsh) mod kRows,
-//           four 64-bit entries (generation | hit index | position) per row.  An insert is an
-//           exchange that pushes what it displaces one entry on; a fifth hit of a row goes to a
+//   table   the hits of one probe sit INLINE in a bucket table: row = (x >> bsh) mod kRows, kE
+//           64-bit entries (generation | hit index | position) per row.  An insert is an exchange
+//           that pushes what it displaces one entry on; a hit that finds its row full goes to a
 //           small stash.  Consecutive buckets are consecutive rows, so a tandem array spreads
-//           perfectly, and a narrow arm's window (< 2^bsh wide) is covered by TWO rows = four
-//           16-byte LDS reads issued together: no chains, no loops.
-//   phase A every live arm (kept in its owner's registers, S per thread) first takes the age of
+//           perfectly, and an arm's window (up to 2^bsh wide) is covered by TWO rows = 16-byte
+//           LDS reads issued together: no chains, no loops.
+//   "A"     every live arm (kept in its owner's registers, S per thread) first takes the age of
 //           the quiet probes since the last hit-probe (and retires if that kills it), then reads
 //           its rows and offers atomicMin(best[h], creation number) to the hits inside its
 //           window; it remembers up to three candidates (hit indices packed in one register).
-//           Each wave publishes how many empty slots it has per layer.             | barrier
-//   phase B the arm re-reads best[] of its candidates: equal to its own number = ExtendArm
+//           Each wave publishes how many empty slots it has per layer.
+//   "B"     the arm re-reads best[] of its candidates: equal to its own number = ExtendArm
 //           (src/automaton.rs:133-150), else it ages / retires (:166-171).  Unmatched hits
 //           become arms (:151-164) by OWNER PULL: empty slots are ranked (layer, wave, lane)
 //           from the published counts (one DPP scan), unmatched hits are ranked by ballots that
 //           every wave recomputes from best[], and the r-th empty slot takes the r-th unmatched
 //           hit -- no mailbox, no free list, no atomics, and the arms stay packed in the low
-//           waves.  Meanwhile the TOP threads index the next hit-probe's hits.      | barrier
+//           waves.
+//   Software pipeline: between two barriers a wave runs B of probe t-1, then A of probe t, and the
+//   TOP threads index the hits of probe t+1 (tables double-buffered, best[] and the stash triple-
+//   buffered): the only thing probe t's B waits for is that every wave has finished offering to
+//   probe t's hits -- one barrier per hit-probe, and the waves with little to do (no arms, or
+//   only the indexing) absorb the skew of the others.
+//   The per-arm code has no divergent branches: selects, unconditional LDS operations aimed at a
+//   per-lane sink / a never-matching word when a lane has nothing to do (a lone wave issues
+//   dependent vector instructions back to back, but every exec-mask update costs it a round trip
+//   through the scalar unit; tools/ubench_isa.hip).
 //   Arms wider than kRowsLoop rows, probes whose stash overflowed and arms with more than three
 //   candidates take a wave-cooperative path (one arm at a time against 64 hits per step).
 // Results are identical to the other extension kernels (tests force every segment through it).
@@ -50,28 +60,27 @@ __device__ inline uint32_t wave_incl_scan(uint32_t x) {
 __device__ inline uint32_t select_bit(unsigned long long m, uint32_t n) {
     uint32_t word = (uint32_t)m, pos = 0;
     uint32_t c = (uint32_t)__popc(word);
-    if (n >= c) {
-        n -= c;
-        word = (uint32_t)(m >> 32);
-        pos = 32;
-    }
+    const bool up = n >= c;
+    n = up ? n - c : n;
+    word = up ? (uint32_t)(m >> 32) : word;
+    pos = up ? 32u : 0u;
 #pragma unroll
     for (int sh = 16; sh >= 1; sh >>= 1) {
         c = (uint32_t)__popc(word & ((1u << sh) - 1u));
-        if (n >= c) {
-            n -= c;
-            word >>= sh;
-            pos += (uint32_t)sh;
-        }
+        const bool u2 = n >= c;
+        n = u2 ? n - c : n;
+        word = u2 ? word >> sh : word;
+        pos = u2 ? pos + (uint32_t)sh : pos;
     }
     return pos;
 }
 
-template <class PosT, int S, int NT, int HB, int kRows = 1024>
+template <class PosT, int S, int NT, int HB, int kRows = 1024, int kE = 4, bool kPipe = true>
 __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
     constexpr int CAP = S * NT;
     constexpr int NW = NT / 64;
     constexpr uint32_t kNone = 0xFFFFFFFFu;    // best[]: no arm accepts this hit
+    constexpr uint32_t kNever = 0xFFFFFFFEu;   // what a candidate read of an idle lane returns: no creation number
     // candidate register of an arm: up to three hit indices, 10 bits each, count in bits 30..31;
     // kCoop: more than three, a window too wide for the table walk, or a probe whose stash overflowed
     constexpr uint32_t kCoop = 0xFFFFFFFFu;
@@ -83,18 +92,23 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
     constexpr uint32_t kGenMax = kWidePos ? 12u : 22u;
     constexpr unsigned long long kPosMask = (1ull << kTagShift) - 1ull;
     using WinT = typename std::conditional<kWidePos, uint64_t, uint32_t>::type;
-    static_assert(HB <= 1024 && S * NW <= 64 && (kRows & (kRows - 1)) == 0, "shape");
+    static_assert(HB <= 1024 && S <= 8 && S * NW <= 128 && (kRows & (kRows - 1)) == 0 && (kE == 2 || kE == 4), "shape");
     if (NT >= 1024 && P.hi_prio) __builtin_amdgcn_s_setprio(3);
 
-    __shared__ __attribute__((aligned(16))) unsigned long long s_tab[kRows * 4];
+    __shared__ __attribute__((aligned(16))) unsigned long long s_tab[2][kRows * kE];
     __shared__ PosT s_hits[HB];
     __shared__ uint8_t s_hflag[HB];
-    __shared__ uint32_t s_best[2][HB];
-    __shared__ unsigned long long s_stash[2][kStash];
-    __shared__ uint32_t s_nstash[2];
-    __shared__ uint32_t s_free[64];                       // per (layer, wave): empty slots
+    __shared__ uint32_t s_best[3][HB];
+    __shared__ unsigned long long s_stash[3][kStash];
+    __shared__ uint32_t s_nstash[3];
+    __shared__ __attribute__((aligned(16))) uint32_t s_free[2][NW][8];  // per (wave, layer): empty slots
     __shared__ unsigned long long s_newmask[NW][HB / 64]; // per wave: unmatched hits of each group of 64
     __shared__ unsigned long long s_bcast;
+    // cold fields of an arm, by slot (layer * NT + thread): the left end is written at every extension and read only
+    // when the arm is reported; the right start is read when the arm dies.  Out of the registers they buy a fifth layer.
+    __shared__ PosT s_cle[CAP], s_crs[CAP];
+    __shared__ uint32_t s_sink[64];  // per lane: where the atomicMin of a lane with nothing to offer goes
+    __shared__ uint32_t s_never;     // == kNever
 
     const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6);
@@ -103,34 +117,41 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
     const uint64_t n_seg = *P.n_seg_ptr;
     const uint32_t k = (uint32_t)rp.k, step = (uint32_t)rp.step, G = rp.G;
     const uint32_t thr0 = arm_threshold(k, G);
-    uint32_t bsh = 3;  // bucket width 2^bsh >= G + k: a narrow arm's window spans at most two rows
+    // bucket width: 2^fast_bsh times the smallest power of two >= G + k.  With buckets of G + k a
+    // young arm's window spans at most two rows, but the arms of a tandem array grow longer and most
+    // waves then have a lane that needs a third row: twice that width by default.
+    uint32_t bsh = 3;
     while ((1ull << bsh) < (unsigned long long)G + k) ++bsh;
+    bsh += P.fast_bsh;
     const uint32_t kGenBits = min(kGenMax, max(2u, P.gen_bits));
     const uint32_t cap_eff = min((uint32_t)CAP, P.cap_limit);
     const WinT w_loop = (WinT)(kRowsLoop - 1u) << bsh;  // windows up to this width span <= kRowsLoop rows
+    const bool use_flag = P.hit_flag != nullptr;
     RecAlloc rec_alloc;
     PROF_DECL;
 
-    PosT a_ls[S], a_le[S], a_rs[S], a_re[S];
+    PosT a_ls[S], a_re[S];
     uint32_t a_thr[S], a_gap[S], a_seq[S], c_h[S];
 #pragma unroll
     for (int L = 0; L < S; ++L) {
         a_seq[L] = kNoSeq;
-        a_ls[L] = a_le[L] = a_rs[L] = a_re[L] = 0;
+        a_ls[L] = a_re[L] = 0;
         a_thr[L] = a_gap[L] = 0;
         c_h[L] = 0;
     }
+    uint32_t livemask = 0;  // wave-uniform: layers in which this wave may hold an arm
     auto clear_table = [&]() {
-        for (uint32_t e = tid; e < (uint32_t)(kRows * 4); e += NT) s_tab[e] = 0ull;
+        for (uint32_t e = tid; e < (uint32_t)(2 * kRows * kE); e += NT) (&s_tab[0][0])[e] = 0ull;
     };
     clear_table();
-    if (tid < 2) s_nstash[tid] = 0u;
-    uint32_t gen = 0, par = 0;
+    if (tid == 0) s_never = kNever;
+    for (uint32_t j = tid; j < (uint32_t)(2 * NW * 8); j += NT) (&s_free[0][0][0])[j] = 64u;
+    uint32_t gen = 0, par = 0, tri = 0;  // generation; parity (table, free counts); best[] / stash buffer
     lds_barrier();
 
     for (uint32_t n_fetch = 0; !P.max_items || n_fetch < P.max_items; ++n_fetch) {
         if (tid == 0) s_bcast = atomicAdd(P.cursor, 1ull);
-        if (tid < 2) s_nstash[tid] = 0u;  // (a probe indexed ahead but never reached may have left entries)
+        if (tid < 3) s_nstash[tid] = 0u;  // (a probe indexed ahead but never reached may have left entries)
         lds_barrier();
         const unsigned long long seg = uni(s_bcast);
         lds_barrier();
@@ -166,17 +187,18 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
         };
         auto tag_of = [&](unsigned long long e) { return (uint32_t)(e >> kTagShift); };
         auto pos_of = [&](unsigned long long e) { return (PosT)(e & kPosMask); };
-        // index the hits of one probe (cnt hits at s_hits[off..]) under generation `gen`; the TOP threads do it
-        auto insert_hits = [&](uint32_t cnt, uint32_t off, uint32_t bp) {
+        // index the hits of one probe (cnt hits at s_hits[off..]) under generation `gen` in table tb, with
+        // best[] / stash buffer bb; the TOP threads do it
+        auto insert_hits = [&](uint32_t cnt, uint32_t off, uint32_t tb, uint32_t bb) {
             const uint32_t g10 = gen << 10;
             for (uint32_t h = (uint32_t)(NT - 1 - tid); h < cnt; h += NT) {
                 const PosT x = s_hits[off + h];
-                s_best[bp][h] = kNone;
+                s_best[bb][h] = kNone;
                 unsigned long long e = ((unsigned long long)(g10 | h) << kTagShift) | ((unsigned long long)x & kPosMask);
-                unsigned long long *row = &s_tab[(((uint32_t)((uint64_t)x >> bsh)) & (uint32_t)(kRows - 1)) * 4u];
+                unsigned long long *row = &s_tab[tb][(((uint32_t)((uint64_t)x >> bsh)) & (uint32_t)(kRows - 1)) * (uint32_t)kE];
                 bool placed = false;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < kE; ++j) {
                     if (!placed) {
                         const unsigned long long old = atomicExch(&row[j], e);
                         if (tag_of(old) - g10 >= 1024u) placed = true;  // displaced a stale entry: done
@@ -184,20 +206,20 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
                     }
                 }
                 if (!placed) {
-                    const uint32_t at = atomicAdd(&s_nstash[bp], 1u);
-                    if (at < kStash) s_stash[bp][at] = e;
+                    const uint32_t at = atomicAdd(&s_nstash[bb], 1u);
+                    if (at < kStash) s_stash[bb][at] = e;
                 }
             }
         };
         // wave-cooperative window walk for ONE arm (lo, w, key wave-uniform): offers to every hit inside
-        auto coop_offer = [&](PosT lo, WinT w, uint32_t key, uint32_t cnt, uint32_t off) {
+        auto coop_offer = [&](PosT lo, WinT w, uint32_t key, uint32_t cnt, uint32_t off, uint32_t bb) {
             for (uint32_t h0 = 0; h0 < cnt; h0 += 64u) {
                 const uint32_t h = h0 + (uint32_t)lane;
-                if (h < cnt && (WinT)(PosT)(s_hits[off + h] - lo) < w) atomicMin(&s_best[par][h], key);
+                if (h < cnt && (WinT)(PosT)(s_hits[off + h] - lo) < w) atomicMin(&s_best[bb][h], key);
             }
         };
         // ... and the last hit (SA order) inside the window whose winner is `key`; returns its index or kNone
-        auto coop_resolve = [&](PosT lo, WinT w, uint32_t key, uint32_t cnt, uint32_t off, PosT &x_out) {
+        auto coop_resolve = [&](PosT lo, WinT w, uint32_t key, uint32_t cnt, uint32_t off, uint32_t bb, PosT &x_out) {
             uint32_t hmax = kNone;
             for (uint32_t h0 = 0; h0 < cnt; h0 += 64u) {
                 const uint32_t h = h0 + (uint32_t)lane;
@@ -205,7 +227,7 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
                 bool ok = false;
                 if (h < cnt) {
                     x = s_hits[off + h];
-                    ok = (WinT)(PosT)(x - lo) < w && s_best[par][h] == key;
+                    ok = (WinT)(PosT)(x - lo) < w && s_best[bb][h] == key;
                 }
                 const unsigned long long bm = __ballot(ok);
                 if (bm) {
@@ -218,62 +240,81 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
             return hmax;
         };
 
-        // ---- phase A: pending age, lookups, published free counts ------------------------------
-        bool povf = false;
-        auto phase_a = [&](uint32_t cnt, uint32_t off, bool lookup) {
+        // ---- A: pending age, lookups in table tb / best[] bb, published free counts (buffer tb) ----
+        auto phase_a = [&](uint32_t cnt, uint32_t off, bool lookup, uint32_t tb, uint32_t bb) {
             const uint32_t g10 = gen << 10;
-            const uint32_t ns = lookup ? uni(s_nstash[par]) : 0u;
-            povf = ns > kStash;
+            // (requested first, used after the first rows have been tested: the round trip hides behind them)
+            const uint32_t ns_v = (lookup && livemask) ? s_nstash[bb] : 0u;
+            uint32_t ns = 0;
+            bool ns_known = false, povf = false;
+            uint32_t nfv[8] = {64u, 64u, 64u, 64u, 64u, 64u, 64u, 64u};
 #pragma unroll
             for (int L = 0; L < S; ++L) {
-                bool live = a_seq[L] != kNoSeq;
-                if (__ballot(live)) {
+                uint32_t nf = 64u;
+                if (livemask & (1u << L)) {
+                    bool live = a_seq[L] != kNoSeq;
                     if (pend) {  // the quiet probes since the last hit-probe: src/automaton.rs:166-171
-                        bool dead = false;
-                        if (live) {
-                            const uint64_t sum_g = (uint64_t)a_gap[L] + pend;
-                            a_gap[L] = sum_g > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)sum_g;
-                            dead = a_gap[L] >= G;
-                        }
+                        const uint64_t sum_g = (uint64_t)a_gap[L] + pend;
+                        const uint32_t aged = sum_g > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)sum_g;
+                        const bool dead = live && aged >= G;
+                        a_gap[L] = aged;
                         if (__ballot(dead)) {
-                            const bool report = dead && (uint64_t)(a_re[L] - a_rs[L]) >= rp.M;
-                            emit_records(report, a_ls[L], a_le[L], a_rs[L], a_re[L], a_seq[L]);
-                            if (dead) {
-                                a_seq[L] = kNoSeq;
-                                live = false;
-                            }
+                            const PosT rs = s_crs[L * NT + tid];
+                            const bool report = dead && (uint64_t)(a_re[L] - rs) >= rp.M;
+                            if (__ballot(report)) emit_records(report, a_ls[L], s_cle[L * NT + tid], rs, a_re[L], a_seq[L]);
                         }
+                        a_seq[L] = dead ? kNoSeq : a_seq[L];
+                        live = live && !dead;
                     }
                     if (lookup) {
                         const PosT lo = (PosT)(a_re[L] - k + 1u);
                         const WinT w = (WinT)a_thr[L] + (WinT)(k - 1u);
                         const uint32_t key = a_seq[L];
+                        const bool narrow = live && w <= w_loop;
+                        const WinT w_eff = narrow ? w : (WinT)0;  // (an empty window accepts nothing)
                         uint32_t ch = 0, nc = 0;
+                        uint32_t *const sink = &s_sink[lane];
                         auto offer = [&](unsigned long long e) {
                             const uint32_t d = tag_of(e) - g10;
-                            if (d < 1024u && (WinT)(PosT)(pos_of(e) - lo) < w) {
-                                atomicMin(&s_best[par][d], key);
-                                ch = (ch << 10) | d;
-                                ++nc;
-                            }
+                            const WinT t = d < 1024u ? (WinT)(PosT)(pos_of(e) - lo) : ~(WinT)0;  // (no scalar AND of two masks)
+                            const bool ok = t < w_eff;
+                            atomicMin(ok ? &s_best[bb][d & 1023u] : sink, key);
+                            ch = ok ? ((ch << 10) | d) : ch;
+                            nc += ok ? 1u : 0u;
                         };
-                        const bool narrow = live && w <= w_loop;
-                        if (narrow) {
-                            const uint32_t b0 = (uint32_t)((uint64_t)lo >> bsh);
-                            const uint32_t n_rows = (uint32_t)((((uint64_t)lo & ((1ull << bsh) - 1ull)) + (uint64_t)w - 1ull) >> bsh) + 1u;
-                            const ulonglong2 *r0 = reinterpret_cast<const ulonglong2 *>(&s_tab[(b0 & (uint32_t)(kRows - 1)) * 4u]);
-                            const ulonglong2 *r1 = reinterpret_cast<const ulonglong2 *>(&s_tab[((b0 + 1u) & (uint32_t)(kRows - 1)) * 4u]);
-                            const ulonglong2 e0 = r0[0], e1 = r0[1], e2 = r1[0], e3 = r1[1];
-                            offer(e0.x); offer(e0.y); offer(e1.x); offer(e1.y);
-                            offer(e2.x); offer(e2.y); offer(e3.x); offer(e3.y);
-                            for (uint32_t r = 2; r < n_rows; ++r) {
-                                const ulonglong2 *rr = reinterpret_cast<const ulonglong2 *>(&s_tab[((b0 + r) & (uint32_t)(kRows - 1)) * 4u]);
+                        auto offer_row = [&](uint32_t b) {
+                            const ulonglong2 *rr = reinterpret_cast<const ulonglong2 *>(&s_tab[tb][(b & (uint32_t)(kRows - 1)) * (uint32_t)kE]);
+                            if constexpr (kE == 4) {
                                 const ulonglong2 f0 = rr[0], f1 = rr[1];
                                 offer(f0.x); offer(f0.y); offer(f1.x); offer(f1.y);
+                            } else {
+                                const ulonglong2 f0 = rr[0];
+                                offer(f0.x); offer(f0.y);
                             }
-                            for (uint32_t s = 0; s < min(ns, kStash); ++s) offer(s_stash[par][s]);
-                            ch = nc > 3u ? kCoop : (ch & 0x3FFFFFFFu) | (nc << 30);
+                        };
+                        const uint32_t b0 = (uint32_t)((uint64_t)lo >> bsh);
+                        const uint32_t n_rows = narrow ? (uint32_t)((((uint64_t)lo & ((1ull << bsh) - 1ull)) + (uint64_t)w - 1ull) >> bsh) + 1u : 0u;
+                        {   // the two rows of a narrow window: all reads in flight together
+                            const ulonglong2 *r0 = reinterpret_cast<const ulonglong2 *>(&s_tab[tb][(b0 & (uint32_t)(kRows - 1)) * (uint32_t)kE]);
+                            const ulonglong2 *r1 = reinterpret_cast<const ulonglong2 *>(&s_tab[tb][((b0 + 1u) & (uint32_t)(kRows - 1)) * (uint32_t)kE]);
+                            if constexpr (kE == 4) {
+                                const ulonglong2 e0 = r0[0], e1 = r0[1], e2 = r1[0], e3 = r1[1];
+                                offer(e0.x); offer(e0.y); offer(e1.x); offer(e1.y);
+                                offer(e2.x); offer(e2.y); offer(e3.x); offer(e3.y);
+                            } else {
+                                const ulonglong2 e0 = r0[0], e2 = r1[0];
+                                offer(e0.x); offer(e0.y); offer(e2.x); offer(e2.y);
+                            }
                         }
+                        if (!ns_known) {
+                            ns = uni(ns_v);
+                            povf = ns > kStash;
+                            ns_known = true;
+                        }
+                        // (rows beyond a lane's own window hold nothing its range test accepts)
+                        for (uint32_t r = 2; __ballot(r < n_rows); ++r) offer_row(b0 + r);
+                        for (uint32_t s = 0; s < min(ns, kStash); ++s) offer(s_stash[bb][s]);
+                        ch = nc > 3u ? kCoop : (ch & 0x3FFFFFFFu) | (nc << 30);
                         // arms too wide for the table walk -- and every arm when the stash overflowed
                         unsigned long long sm = __ballot(live && (!narrow || povf));
                         if (sm) {
@@ -290,18 +331,178 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
                                     lo_u = (PosT)lane_of((uint32_t)lo, l);
                                     w_u = (WinT)lane_of((uint32_t)w, l);
                                 }
-                                coop_offer(lo_u, w_u, lane_of(key, l), cnt, off);
+                                coop_offer(lo_u, w_u, lane_of(key, l), cnt, off, bb);
                             }
                         }
                         c_h[L] = ch;
                     }
+                    nf = (uint32_t)__popcll(__ballot(a_seq[L] == kNoSeq));
+                    if (nf == 64u) livemask &= ~(1u << L);
                 }
-                const uint32_t nf = (uint32_t)__popcll(__ballot(a_seq[L] == kNoSeq));
-                if (lane == 0) s_free[L * NW + (int)wave] = nf;
+                nfv[L] = nf;
             }
-            if (tid == 0) s_nstash[par ^ 1u] = 0u;  // the next probe's stash (filled after the barrier)
+            // (every lane, same 16 bytes)
+            *reinterpret_cast<uint4 *>(&s_free[tb][wave][0]) = make_uint4(nfv[0], nfv[1], nfv[2], nfv[3]);
+            if constexpr (S > 4) *reinterpret_cast<uint4 *>(&s_free[tb][wave][4]) = make_uint4(nfv[4], nfv[5], nfv[6], nfv[7]);
         };
 
+        // one hit-probe in flight: the probe whose offers have been made and whose B is still to run
+        struct Probe {
+            uint32_t cnt, off, t_before, t_after, tb, bb;
+            uint64_t i;
+        };
+        // ---- B of probe q: resolve, age / retire, create --------------------------------------------------
+        auto phase_b = [&](const Probe &q) {
+            PROF_START();
+            const uint32_t cnt = q.cnt, off = q.off, bb = q.bb;
+            const uint64_t i = q.i;
+            // every independent read first: free counts, the first 64 hits' winners, the candidates' winners
+            // (entry j = layer j / NW, wave j % NW; a lane holds entries j = lane and lane + 64)
+            const uint32_t fv = lane < S * NW ? s_free[q.tb][lane % NW][lane / NW] : 0u;
+            const uint32_t fv2 = S * NW > 64 && lane + 64 < S * NW ? s_free[q.tb][(lane + 64) % NW][(lane + 64) / NW] : 0u;
+            const uint32_t h_l = min((uint32_t)lane, cnt - 1u);
+            const uint32_t bv0 = s_best[bb][h_l];
+            const uint8_t hf0 = use_flag ? s_hflag[off + h_l] : (uint8_t)1;
+            // empty slots, ranked (layer, wave, lane)
+            const uint32_t fincl = wave_incl_scan(fv);
+            uint32_t total_free = lane_of(fincl, 63u);
+            uint32_t fincl2 = 0;
+            if constexpr (S * NW > 64) {
+                fincl2 = wave_incl_scan(fv2) + total_free;
+                total_free = lane_of(fincl2, 63u);
+            }
+            const uint32_t A0 = (uint32_t)CAP - total_free;  // live arms after the quiet probes' deaths
+            PROF_COUNT(10, A0);
+            if (fam_open && A0 == 0 && q.t_before >= spur_until) {  // the flush of src/automaton.rs:182-200
+                ++fam_seq;
+                next_seq = 0;
+                fam_open = false;
+            }
+            // unmatched hits, in hit order (= creation order, src/automaton.rs:151-164)
+            const bool in0 = (uint32_t)lane < cnt;
+            const unsigned long long m0 = __ballot(in0 && bv0 == kNone && hf0 != 0);  // group 0 stays in registers
+            uint32_t n_new = (uint32_t)__popcll(m0);
+            bool spur = use_flag && __ballot(in0 && bv0 == kNone && hf0 == 0) != 0ull;
+            for (uint32_t h0 = 64u, gi = 1; h0 < cnt; h0 += 64u, ++gi) {  // (most probes have <= 64 hits)
+                const uint32_t h = min(h0 + (uint32_t)lane, cnt - 1u);
+                const bool in = h0 + (uint32_t)lane < cnt;
+                const bool un = in && s_best[bb][h] == kNone;
+                const bool hf = use_flag ? s_hflag[off + h] != 0 : true;
+                const unsigned long long nm = __ballot(un && hf);
+                if (use_flag) spur = spur || __ballot(un && !hf) != 0ull;
+                s_newmask[wave][gi] = nm;
+                n_new += (uint32_t)__popcll(nm);
+            }
+            PROF_MAX(9, A0 + n_new);
+            if (n_new > total_free || A0 + n_new > cap_eff) {  // (identical in every wave)
+                overflow = true;
+                done = true;
+                return;
+            }
+            const uint32_t seq_base = next_seq;
+            PROF_STOP(6);
+            PROF_START();
+#pragma unroll
+            for (int L = 0; L < S; ++L) {
+                const bool was_free = a_seq[L] == kNoSeq;
+                const unsigned long long fmask = __ballot(was_free);
+                if (livemask & (1u << L)) {  // this wave may hold an arm here
+                    // the last hit (SA order) this arm won, if any: src/automaton.rs:133-150 apply in hit order
+                    const uint32_t ch = c_h[L];
+                    const bool coop = !was_free && ch == kCoop;
+                    const uint32_t nc = (was_free || coop) ? 0u : ch >> 30;
+                    uint32_t cb[3];  // the three reads in flight together; a lane without a candidate reads kNever
+#pragma unroll
+                    for (uint32_t j = 0; j < 3; ++j) cb[j] = *(j < nc ? &s_best[bb][(ch >> (10u * j)) & 1023u] : &s_never);
+                    uint32_t hw = 0;  // 1 + that hit
+#pragma unroll
+                    for (uint32_t j = 0; j < 3; ++j) {
+                        const uint32_t hj = (ch >> (10u * j)) & 1023u;
+                        hw = cb[j] == a_seq[L] ? max(hw, hj + 1u) : hw;
+                    }
+                    hw = (was_free || coop) ? 0u : hw;
+                    PosT xw = s_hits[off + (hw ? hw - 1u : 0u)];
+                    unsigned long long sm = __ballot(coop);
+                    while (sm) {  // more than three candidates / wide window: resolved cooperatively
+                        const uint32_t l = (uint32_t)(__ffsll((long long)sm) - 1);
+                        sm &= sm - 1ull;
+                        const PosT lo = (PosT)(a_re[L] - k + 1u);
+                        const WinT w = (WinT)a_thr[L] + (WinT)(k - 1u);
+                        PosT lo_u, x_u = 0;
+                        WinT w_u;
+                        if constexpr (kWidePos) {
+                            lo_u = (PosT)lane_of((unsigned long long)lo, l);
+                            w_u = (WinT)lane_of((unsigned long long)w, l);
+                        } else {
+                            lo_u = (PosT)lane_of((uint32_t)lo, l);
+                            w_u = (WinT)lane_of((uint32_t)w, l);
+                        }
+                        const uint32_t hm_ = coop_resolve(lo_u, w_u, lane_of(a_seq[L], l), cnt, off, bb, x_u);
+                        if ((uint32_t)lane == l && hm_ != kNone) {
+                            hw = hm_ + 1u;
+                            xw = x_u;
+                        }
+                    }
+                    const bool won = hw != 0u;
+                    // ExtendArm (src/automaton.rs:133-150) or one more step of age (:166-171), by selects
+                    uint32_t thr_new;
+                    if constexpr (kWidePos) thr_new = arm_threshold((uint64_t)(i + k) - (uint64_t)a_ls[L], G);
+                    else thr_new = max(G, ((uint32_t)(i + k) - (uint32_t)a_ls[L]) / 10u);
+                    const uint64_t sum_g = (uint64_t)a_gap[L] + step;
+                    const uint32_t aged = sum_g > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)sum_g;
+                    a_re[L] = won ? (PosT)(xw + k) : a_re[L];
+                    if (won) s_cle[L * NT + tid] = (PosT)(i + k);
+                    a_thr[L] = won ? thr_new : a_thr[L];
+                    a_gap[L] = won ? 0u : aged;
+                    const bool dead = !was_free && !won && aged >= G;  // never matches again
+                    if (__ballot(dead)) {
+                        const PosT rs = s_crs[L * NT + tid];
+                        const bool report = dead && (uint64_t)(a_re[L] - rs) >= rp.M;
+                        if (__ballot(report)) emit_records(report, a_ls[L], s_cle[L * NT + tid], rs, a_re[L], a_seq[L]);
+                    }
+                    a_seq[L] = dead ? kNoSeq : a_seq[L];
+                }
+                // NewArm by owner pull: the r-th empty slot takes the r-th unmatched hit
+                if (n_new && fmask) {
+                    const uint32_t base_r = L * NW < 64 ? lane_of(fincl - fv, (uint32_t)(L * NW) + wave)
+                                                        : lane_of(fincl2 - fv2, (uint32_t)(L * NW - 64) + wave);
+                    if (base_r < n_new) {
+                        const uint32_t r = base_r + (uint32_t)__popcll(fmask & lt_mask);
+                        const bool take = was_free && r < n_new;
+                        uint32_t hsel = 0;
+                        if (cnt <= 64u) {
+                            hsel = select_bit(m0, take ? r : 0u);
+                        } else {
+                            uint32_t pfx = 0;
+                            for (uint32_t h0 = 0, gi = 0; h0 < cnt; h0 += 64u, ++gi) {
+                                const unsigned long long nm = gi == 0 ? m0 : uni(s_newmask[wave][gi]);
+                                const uint32_t cg = (uint32_t)__popcll(nm);
+                                if (take && r >= pfx && r < pfx + cg) hsel = h0 + select_bit(nm, r - pfx);
+                                pfx += cg;
+                            }
+                        }
+                        // src/automaton.rs:151-164 (aged by this very probe)
+                        const PosT x = s_hits[off + (take ? hsel : 0u)];
+                        a_ls[L] = take ? (PosT)i : a_ls[L];
+                        if (take) {
+                            s_cle[L * NT + tid] = (PosT)(i + k);
+                            s_crs[L * NT + tid] = x;
+                        }
+                        a_re[L] = take ? (PosT)(x + k) : a_re[L];
+                        a_gap[L] = take ? step : a_gap[L];
+                        a_thr[L] = take ? thr0 : a_thr[L];
+                        a_seq[L] = take ? seq_base + r : a_seq[L];
+                        livemask |= 1u << L;
+                    }
+                }
+            }
+            next_seq += n_new;
+            fam_open = true;
+            if (spur) spur_until = max(spur_until, q.t_after + rp.tstar - 1u);
+            PROF_STOP(7);
+        };
+
+        bool staged_before = false;
         for (uint32_t g = g0; g < g_end && !done;) {
             // ---- stage a batch of up to 64 probes (every wave computes the same masks) ----
             PROF_START();
@@ -321,12 +522,14 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
                 break;
             }
             const uint32_t rel_l = (uint32_t)(r_l - base);
+            if (staged_before) lds_barrier();  // (the last B of the previous batch read the staged hits)
+            staged_before = true;
             {
                 const unsigned long long end = nbb == nb ? r_hi : lane_of(r_l, nbb);
                 const uint32_t tot = (uint32_t)(end - base);
                 for (uint32_t r = tid; r < tot; r += NT) {
                     s_hits[r] = P.hits[base + r];
-                    if (P.hit_flag) s_hflag[r] = P.hit_flag[base + r];
+                    if (use_flag) s_hflag[r] = P.hit_flag[base + r];
                 }
             }
             lds_barrier();
@@ -336,221 +539,105 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
             PROF_STOP(0);
             PROF_COUNT(1, 1);
             uint32_t pos = 0;
-            bool pre_indexed = false;
-            while (!done) {
-                const unsigned long long hmr = pos >= 64 ? 0ull : (hm >> pos) << pos;
-                if (!hmr) break;
-                const uint32_t b = (uint32_t)(__ffsll((long long)hmr) - 1);
-                {
-                    const unsigned long long range = ((1ull << b) - 1ull) & ~((1ull << pos) - 1ull);
-                    const uint32_t q = (uint32_t)__popcll(qm & range);
-                    if (q) {  // quiet probes only age: folded into the next pass over the arms
+            bool pre_indexed = false, have_prev = false;
+            Probe prev{0, 0, 0, 0, 0, 0, 0};
+            for (;;) {
+                // ---- the next hit-probe of the batch; the quiet probes before it only age ----------
+                bool have_cur = false;
+                Probe cur{0, 0, 0, 0, 0, 0, 0};
+                if (!done) {
+                    const unsigned long long hmr = pos >= 64 ? 0ull : (hm >> pos) << pos;
+                    const uint32_t b = hmr ? (uint32_t)(__ffsll((long long)hmr) - 1) : 64u;
+                    const unsigned long long upto = b >= 64 ? ~0ull : ((1ull << b) - 1ull);
+                    const unsigned long long from = pos >= 64 ? 0ull : ~((1ull << pos) - 1ull);
+                    const uint32_t q = (uint32_t)__popcll(qm & upto & from);
+                    if (q) {  // folded into the next pass over the arms
                         quiet += q;
                         t_proc += q;
                         pend += q * step;
-                        if (quiet >= rp.tstar) {  // every arm is dead (gap >= G): the segment is over
-                            done = true;
-                            break;
-                        }
+                        if (quiet >= rp.tstar) done = true;  // every arm is dead (gap >= G): the segment is over
+                    }
+                    if (hmr && !done) {
+                        have_cur = true;
+                        quiet = 0;
+                        pos = b + 1;
+                        cur.cnt = lane_of(f_l, b);
+                        cur.off = lane_of(rel_l, b);
+                        cur.i = (uint64_t)(g + b - pb + 1) * step;
+                        cur.t_before = t_proc;
+                        cur.t_after = ++t_proc;
+                        cur.tb = par;
+                        cur.bb = tri;
+                    } else {
+                        pos = 64;
                     }
                 }
-                quiet = 0;
-                pos = b + 1;
-                const uint32_t cnt = lane_of(f_l, b);
-                const uint32_t off = lane_of(rel_l, b);
-                const uint64_t i = (uint64_t)(g + b - pb + 1) * step;
-                const uint32_t t_before = t_proc;
-                ++t_proc;
+                if (have_prev) {
+                    phase_b(prev);
+                    have_prev = false;
+                    if (overflow) break;
+                }
+                if (!have_cur) break;
                 PROF_COUNT(5, 1);
-                PROF_COUNT(11, cnt);
+                PROF_COUNT(11, cur.cnt);
                 PROF_START();
                 if (!pre_indexed) {
-                    if (++gen >> kGenBits) {  // generation wrap: clear the table once
+                    if (++gen >> kGenBits) {  // generation wrap: clear the tables once
                         lds_barrier();
                         clear_table();
                         gen = 1;
                         lds_barrier();
                     }
-                    insert_hits(cnt, off, par);
+                    insert_hits(cur.cnt, cur.off, cur.tb, cur.bb);
                     lds_barrier();
                 }
-                pre_indexed = false;
                 PROF_STOP(2);
                 PROF_START();
-                phase_a(cnt, off, true);
+                phase_a(cur.cnt, cur.off, true, cur.tb, cur.bb);
                 pend = 0;
+                if (tid == 0) s_nstash[(tri + 2u) % 3u] = 0u;  // the stash of the probe after next (indexed in the next interval)
                 PROF_STOP(4);
+                PROF_START();
+                {   // next hit probe of this staged batch, if any: the top threads index it in this interval
+                    const unsigned long long nxt = pos >= 64 ? 0ull : (hm >> pos) << pos;
+                    const bool can_pre = nxt != 0ull && ((gen + 1u) >> kGenBits) == 0u;
+                    if (can_pre) {
+                        const uint32_t nb2 = (uint32_t)(__ffsll((long long)nxt) - 1);
+                        ++gen;
+                        insert_hits(lane_of(f_l, nb2), lane_of(rel_l, nb2), par ^ 1u, (tri + 1u) % 3u);
+                    }
+                    pre_indexed = can_pre;
+                }
+                PROF_STOP(8);
                 PROF_START();
                 lds_barrier();
                 PROF_STOP(3);
-                PROF_START();
-                // ---- phase B --------------------------------------------------------------------
-                // empty slots, ranked (layer, wave, lane)
-                const uint32_t fv = lane < S * NW ? s_free[lane] : 0u;
-                const uint32_t fincl = wave_incl_scan(fv);
-                const uint32_t total_free = lane_of(fincl, (uint32_t)(S * NW - 1));
-                const uint32_t A0 = (uint32_t)CAP - total_free;  // live arms after the quiet probes' deaths
-                PROF_COUNT(10, A0);
-                if (fam_open && A0 == 0 && t_before >= spur_until) {  // the flush of src/automaton.rs:182-200
-                    ++fam_seq;
-                    next_seq = 0;
-                    fam_open = false;
-                }
-                // unmatched hits, in hit order (= creation order, src/automaton.rs:151-164)
-                uint32_t n_new = 0;
-                bool spur = false;
-                unsigned long long m0 = 0;  // group 0 stays in registers (most probes have <= 64 hits)
-                for (uint32_t h0 = 0, gi = 0; h0 < cnt; h0 += 64u, ++gi) {
-                    const uint32_t h = h0 + (uint32_t)lane;
-                    bool un = false, hf = true;
-                    if (h < cnt) {
-                        un = s_best[par][h] == kNone;
-                        if (P.hit_flag) hf = s_hflag[off + h] != 0;
-                    }
-                    const unsigned long long nm = __ballot(un && hf);
-                    if (P.hit_flag) spur = spur || __ballot(un && !hf) != 0ull;
-                    if (gi == 0) m0 = nm;
-                    else if (lane == 0) s_newmask[wave][gi] = nm;
-                    n_new += (uint32_t)__popcll(nm);
-                }
-                PROF_MAX(9, A0 + n_new);
-                if (n_new > total_free || A0 + n_new > cap_eff) {  // (identical in every wave)
-                    overflow = true;
-                    done = true;
-                    break;
-                }
-                const uint32_t seq_base = next_seq;
-                PROF_STOP(6);
-                PROF_START();
-                // next hit probe of this staged batch, if any: the top threads index it in this interval
-                // (nothing below reads the table; best[] and the stash are double-buffered)
-                const unsigned long long nxt = pos >= 64 ? 0ull : (hm >> pos) << pos;
-                const bool can_pre = nxt != 0ull && ((gen + 1u) >> kGenBits) == 0u;
-#pragma unroll
-                for (int L = 0; L < S; ++L) {
-                    const bool was_free = a_seq[L] == kNoSeq;
-                    const unsigned long long fmask = __ballot(was_free);
-                    if (~fmask) {  // some lane holds an arm
-                        const PosT lo = (PosT)(a_re[L] - k + 1u);
-                        const WinT w = (WinT)a_thr[L] + (WinT)(k - 1u);
-                        // the last hit (SA order) this arm won, if any: src/automaton.rs:133-150 apply in hit order
-                        uint32_t hwon = kNone;
-                        if (!was_free && c_h[L] != kCoop) {
-                            const uint32_t ch = c_h[L], nc = ch >> 30;
-#pragma unroll
-                            for (uint32_t j = 0; j < 3; ++j) {
-                                const uint32_t hj = (ch >> (10u * j)) & 1023u;
-                                if (j < nc && s_best[par][hj] == a_seq[L] && (hwon == kNone || hj > hwon)) hwon = hj;
-                            }
-                        }
-                        bool won = hwon != kNone;
-                        PosT xw = 0;
-                        if (won) xw = s_hits[off + hwon];
-                        unsigned long long sm = __ballot(!was_free && c_h[L] == kCoop);
-                        while (sm) {  // several candidates / wide window: the last hit it won, cooperatively
-                            const uint32_t l = (uint32_t)(__ffsll((long long)sm) - 1);
-                            sm &= sm - 1ull;
-                            PosT lo_u, x_u = 0;
-                            WinT w_u;
-                            if constexpr (kWidePos) {
-                                lo_u = (PosT)lane_of((unsigned long long)lo, l);
-                                w_u = (WinT)lane_of((unsigned long long)w, l);
-                            } else {
-                                lo_u = (PosT)lane_of((uint32_t)lo, l);
-                                w_u = (WinT)lane_of((uint32_t)w, l);
-                            }
-                            const uint32_t hm_ = coop_resolve(lo_u, w_u, lane_of(a_seq[L], l), cnt, off, x_u);
-                            if ((uint32_t)lane == l && hm_ != kNone) {
-                                won = true;
-                                xw = x_u;
-                            }
-                        }
-                        bool dead = false;
-                        if (!was_free) {
-                            if (won) {  // ExtendArm, src/automaton.rs:133-150
-                                a_re[L] = (PosT)(xw + k);
-                                a_le[L] = (PosT)(i + k);
-                                a_thr[L] = arm_threshold((uint64_t)(i + k) - (uint64_t)a_ls[L], G);
-                                a_gap[L] = 0;
-                            } else {
-                                const uint64_t sum_g = (uint64_t)a_gap[L] + step;
-                                a_gap[L] = sum_g > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)sum_g;
-                                dead = a_gap[L] >= G;  // src/automaton.rs:166-171: never matches again
-                            }
-                        }
-                        if (__ballot(dead)) {
-                            const bool report = dead && (uint64_t)(a_re[L] - a_rs[L]) >= rp.M;
-                            emit_records(report, a_ls[L], a_le[L], a_rs[L], a_re[L], a_seq[L]);
-                            if (dead) a_seq[L] = kNoSeq;
-                        }
-                    }
-                    // NewArm by owner pull: the r-th empty slot takes the r-th unmatched hit
-                    if (n_new && fmask) {
-                        const uint32_t base_r = lane_of(fincl - fv, (uint32_t)(L * NW) + wave);
-                        if (base_r < n_new) {
-                            const uint32_t r = base_r + (uint32_t)__popcll(fmask & lt_mask);
-                            const bool take = was_free && r < n_new;
-                            uint32_t hsel = 0;
-                            if (cnt <= 64u) {
-                                if (take) hsel = select_bit(m0, r);
-                            } else {
-                                uint32_t pfx = 0;
-                                for (uint32_t h0 = 0, gi = 0; h0 < cnt; h0 += 64u, ++gi) {
-                                    const unsigned long long nm = gi == 0 ? m0 : uni(s_newmask[wave][gi]);
-                                    const uint32_t cg = (uint32_t)__popcll(nm);
-                                    if (take && r >= pfx && r < pfx + cg) hsel = h0 + select_bit(nm, r - pfx);
-                                    pfx += cg;
-                                }
-                            }
-                            if (take) {  // src/automaton.rs:151-164 (aged by this very probe)
-                                const PosT x = s_hits[off + hsel];
-                                a_ls[L] = (PosT)i;
-                                a_le[L] = (PosT)(i + k);
-                                a_rs[L] = x;
-                                a_re[L] = (PosT)(x + k);
-                                a_gap[L] = step;
-                                a_thr[L] = thr0;
-                                a_seq[L] = seq_base + r;
-                            }
-                        }
-                    }
-                }
-                next_seq += n_new;
-                fam_open = true;
-                if (spur) spur_until = max(spur_until, t_proc + rp.tstar - 1u);
-                PROF_STOP(7);
-                PROF_START();
-                if (can_pre) {
-                    const uint32_t nb2 = (uint32_t)(__ffsll((long long)nxt) - 1);
-                    ++gen;
-                    insert_hits(lane_of(f_l, nb2), lane_of(rel_l, nb2), par ^ 1u);
-                }
-                pre_indexed = can_pre;
-                lds_barrier();
                 par ^= 1u;
-                PROF_STOP(8);
+                tri = (tri + 1u) % 3u;
+                if constexpr (kPipe) {
+                    prev = cur;
+                    have_prev = true;
+                } else {  // two barriers per hit-probe: B right away, the next A after every wave is through it
+                    phase_b(cur);
+                    if (overflow) break;
+                    lds_barrier();
+                }
             }
             if (overflow) break;
-            if (!done) {
-                const unsigned long long range = pos >= 64 ? 0ull : ~((1ull << pos) - 1ull);
-                const uint32_t q = (uint32_t)__popcll(qm & range);
-                if (q) {
-                    quiet += q;
-                    t_proc += q;
-                    pend += q * step;
-                    if (quiet >= rp.tstar) done = true;
-                }
-            }
             g += nbb;
         }
         if (!overflow) {
             // the age of the trailing quiet probes: whatever it kills is reported, and the family closes if
             // nothing is left
-            phase_a(0, 0, false);
+            phase_a(0, 0, false, par, tri);
             pend = 0;
             lds_barrier();
-            const uint32_t fv = lane < S * NW ? s_free[lane] : 0u;
-            const uint32_t total_free = lane_of(wave_incl_scan(fv), (uint32_t)(S * NW - 1));
+            const uint32_t fv = lane < S * NW ? s_free[par][lane % NW][lane / NW] : 0u;
+            uint32_t total_free = lane_of(wave_incl_scan(fv), 63u);
+            if constexpr (S * NW > 64) {
+                const uint32_t fv2 = lane + 64 < S * NW ? s_free[par][(lane + 64) % NW][(lane + 64) / NW] : 0u;
+                total_free += lane_of(wave_incl_scan(fv2), 63u);
+            }
             if (fam_open && total_free == (uint32_t)CAP && t_proc >= spur_until) fam_open = false;
             if (!done && g_end < chunk_end) {
                 if (tid == 0) atomicAdd(&P.ctr[CT_RANOUT], 1ull);
@@ -564,7 +651,8 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
         // leave no arm behind for the next segment
 #pragma unroll
         for (int L = 0; L < S; ++L) a_seq[L] = kNoSeq;
-        if (tid < 64) {
+        livemask = 0;
+        if (wave == min(P.n_levels, (uint32_t)(NW - 1))) {  // (diagnostic build: option test_levels picks the reporting wave)
             PROF_FLUSH();
         }
         lds_barrier();

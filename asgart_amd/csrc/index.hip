@@ -45,7 +45,7 @@ const OptDesc kOptions[] = {
     {"filter", &Options::filter, 0, 1},
     {"debug", &Options::debug, 0, 1},
     {"test_cap_limit", &Options::test_cap_limit, -1, 1ll << 31},
-    {"test_levels", &Options::test_levels, 0, 4},
+    {"test_levels", &Options::test_levels, 0, 15},
     {"test_genbits", &Options::test_genbits, 2, 22},
     {"tier_order", &Options::tier_order, 1, 7777777},
     {"ptab_depth", &Options::ptab_depth, 0, 15},
@@ -53,7 +53,7 @@ const OptDesc kOptions[] = {
     {"test_wide_batch", &Options::test_wide_batch, 0, 1ll << 40},
     {"kfilter_bits", &Options::kfilter_bits, 0, 34},
     {"tier_streams", &Options::tier_streams, 1111111, 7777777},
-    {"cap6_pct", &Options::cap6_pct, 100, 400},
+    {"cap6_pct", &Options::cap6_pct, 100, 200},
     {"early_cascade", &Options::early_cascade, 0, 1},
     {"progress_at", &Options::progress_at, 0, 2},
     {"rank_lists", &Options::rank_lists, 0, 1},
@@ -61,7 +61,10 @@ const OptDesc kOptions[] = {
     {"wg_items12", &Options::wg_items12, 0, 1 << 30},
     {"fast", &Options::fast, 0, 255},
     {"fast_nt", &Options::fast_nt, 256, 1024},
-    {"fast_s", &Options::fast_s, 0, 16},
+    {"cap3_pct", &Options::cap3_pct, 100, 400},
+    {"fast_bsh", &Options::fast_bsh, 0, 3},
+    {"fast_e", &Options::fast_e, 2, 4},
+    {"fast_pipe", &Options::fast_pipe, 0, 1},
 };
 }  // namespace
 

@@ -69,8 +69,8 @@ template <class SlotT> constexpr int kMidArmsLayers = sizeof(SlotT) == 4 ? 4 : 2
 constexpr int kWaveArmsHits = 512;
 constexpr uint64_t kGrid2Arms = 256ull * 8ull;
 template <class SlotT> constexpr int kLongArmsLayers = sizeof(SlotT) == 4 ? 5 : 2;  // tier 3: 5 x 1024 arms
-// ... of the two-barrier kernel (option fast, extend_fast_dev.hpp): 4 x 1024 / 2 x 1024 arm slots
-template <class SlotT> constexpr int kFastLongLayers = sizeof(SlotT) == 4 ? 4 : 2;
+// ... of the one-barrier kernel (option fast, extend_fast_dev.hpp): 5 x 1024 / 2 x 1024 arm slots
+template <class SlotT> constexpr int kFastLongLayers = sizeof(SlotT) == 4 ? 5 : 2;
 constexpr int kPoleLdsPad = 0;             // > 0: tier 3 workgroups take a whole CU (measured: no gain)
 constexpr int kArmCapSmall = 256;   // live arms per wave in LDS, common case
 constexpr uint32_t kTier1MaxSum = 20000;  // placement: busier segments never run on a single wave
@@ -336,7 +336,8 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                 tier_cap[4] = (uint32_t)kMidArmsLayers<SlotT> * 256u;
             }
             tier_cap[3] = (uint32_t)(fast_tier(3) ? kFastLongLayers<SlotT> : kLongArmsLayers<SlotT>) * 1024u;
-            if (fast_tier(3) && opt.fast_s) tier_cap[3] = (uint32_t)(opt.fast_s <= 4 ? 4 : (opt.fast_s <= 8 ? 8 : 16)) * (uint32_t)(opt.fast_nt >= 1024 ? 1024 : (opt.fast_nt >= 512 ? 512 : 256));
+            if (fast_tier(3) && opt.fast_nt < 1024) tier_cap[3] = (uint32_t)kFastLongLayers<SlotT> * (opt.fast_nt >= 512 ? 512u : 256u);
+
             tier_cap[5] = (uint32_t)kMidArmsLayers<SlotT> * 512u;
             // the window bound is pessimistic for tandem arrays (hits extend arms there) and the HBM
             // tier is several times slower per probe: tier 6 also takes segments whose bound exceeds
@@ -345,8 +346,11 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             // tier 3 accepts what tier 6 would accept by the bound (a long segment is no less safe there), but
             // never more than the same allowance over its own capacity (with 64-bit positions it holds fewer
             // arms than tier 6, and what it gives up on is re-run from the start)
+            // (the bound of a tandem array is three to four times what it really holds: the one-barrier kernel, a fifth
+            // faster per probe on such segments, takes them up to cap3_pct of its capacity)
+            const uint64_t pct3 = fast_tier(3) ? (uint64_t)opt.cap3_pct : (uint64_t)opt.cap6_pct;
             tier_cap[3] = std::min<uint32_t>(std::max(tier_cap[3], tier_cap[6]),
-                                             (uint32_t)((uint64_t)tier_cap[3] * (uint64_t)opt.cap6_pct / 100u));
+                                             (uint32_t)((uint64_t)tier_cap[3] * pct3 / 100u));
         } else {
             tier_cap[2] = kArmCapMid;
             tier_cap[4] = sizeof(SlotT) == 4 ? kArmCapBig32 : kArmCapBig64;
@@ -437,6 +441,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             ep.escalate_cost = 0xFFFFFFFFu;
             ep.hi_prio = (uint32_t)opt.prio3;
             ep.max_items = 0;
+            ep.fast_bsh = (uint32_t)opt.fast_bsh;
             ep.n_levels = (uint32_t)opt.test_levels;
             ep.gen_bits = (uint32_t)opt.test_genbits;
             ep.ctr = d_ctr;
@@ -496,18 +501,16 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                     if (fast_tier(3)) {
                         // (the same capacity in three shapes: per-probe work every wave repeats -- ranking the
                         // empty slots and the unmatched hits -- is paid once per wave sharing a SIMD)
-                        const int nt = opt.fast_nt >= 1024 ? 1024 : (opt.fast_nt >= 512 ? 512 : 256);
-                        const int fs = opt.fast_s ? (int)opt.fast_s : kFastLongLayers<SlotT> * 1024 / nt;
-                        if (nt == 1024)
-                            extend_fast_kernel<SlotT, 4, 1024, kHitBatch><<<grid(256), 1024, 0, st>>>(ep);
-                        else if (nt == 512 && fs <= 4)
-                            extend_fast_kernel<SlotT, 4, 512, kHitBatch><<<grid(256), 512, 0, st>>>(ep);
-                        else if (nt == 512)
-                            extend_fast_kernel<SlotT, 8, 512, kHitBatch><<<grid(256), 512, 0, st>>>(ep);
-                        else if (fs <= 8)
-                            extend_fast_kernel<SlotT, 8, 256, kHitBatch><<<grid(256), 256, 0, st>>>(ep);
+                        if (opt.fast_nt >= 1024 && opt.fast_e == 2)
+                            extend_fast_kernel<SlotT, kFastLongLayers<SlotT>, 1024, kHitBatch, 2048, 2><<<grid(256), 1024, 0, st>>>(ep);
+                        else if (opt.fast_nt >= 1024 && opt.fast_pipe == 0)
+                            extend_fast_kernel<SlotT, kFastLongLayers<SlotT>, 1024, kHitBatch, 1024, 4, false><<<grid(256), 1024, 0, st>>>(ep);
+                        else if (opt.fast_nt >= 1024)
+                            extend_fast_kernel<SlotT, kFastLongLayers<SlotT>, 1024, kHitBatch><<<grid(256), 1024, 0, st>>>(ep);
+                        else if (opt.fast_nt >= 512)
+                            extend_fast_kernel<SlotT, kFastLongLayers<SlotT>, 512, kHitBatch><<<grid(256), 512, 0, st>>>(ep);
                         else
-                            extend_fast_kernel<SlotT, 16, 256, kHitBatch><<<grid(256), 256, 0, st>>>(ep);
+                            extend_fast_kernel<SlotT, kFastLongLayers<SlotT>, 256, kHitBatch><<<grid(256), 256, 0, st>>>(ep);
                     } else
                         extend_arms_kernel<SlotT, kLongArmsLayers<SlotT>, 1024, kHitBatch, 1024, 4, false, true, kPoleLdsPad><<<grid(256), 1024, 0, st>>>(ep);
                     break;

@@ -943,6 +943,7 @@ struct ExtParams {
     uint32_t cap_limit;                   // effective live-arm capacity (<= CAP; tests lower it)
     uint32_t hi_prio;                     // 1: the long-segment shape raises its waves' issue priority
     uint32_t max_items;                   // work-list fetches per workgroup before it retires (0: until the list is empty)
+    uint32_t fast_bsh;                    // K6: log2 of the bucket width beyond the smallest power of two >= G + k
     unsigned long long *ctr;
 };
 

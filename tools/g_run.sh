@@ -1,5 +1,5 @@
 mkdir -p gpurun_out/r3
-cd /tmp && export TMPDIR=/tmp
-cd $GRAFT_REPO_ROOT
-rm -rf gpurun_out/r3/pmc1 gpurun_out/r3/pmc2
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_BUSY_CYCLES -d gpurun_out/r3/pmc1 -o pole --output-format csv -- python3 tools/pole_synth.py "fast=8 cap6_pct=400 fast_nt=256 fast_s=8" "fast=8 cap6_pct=400 fast_nt=512 fast_s=4" "fast=0" > gpurun_out/r3/pmc1.log 2>&1
+timeout 1500 python -m pytest tests -x -q -m gpu > gpurun_out/r3/gpu_tests.log 2>&1; echo "rc=$?" >> gpurun_out/r3/gpu_tests.log
+timeout 900 python tools/pole_synth.py --check "fast=8" "fast=0" > gpurun_out/r3/pole.log 2>&1; echo "rc=$?" >> gpurun_out/r3/pole.log
+ASGART_DEBUG=1 timeout 1500 python tools/tune_tiers.py cfg4 "fast=8" "fast=0" > gpurun_out/r3/tune_cfg4.log 2>&1; echo "rc=$?" >> gpurun_out/r3/tune_cfg4.log
+timeout 1500 python tools/tune_tiers.py cfg4 --pipelined "fast=8" "fast=0" > gpurun_out/r3/tune_cfg4_pipe.log 2>&1; echo "rc=$?" >> gpurun_out/r3/tune_cfg4_pipe.log
