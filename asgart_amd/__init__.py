@@ -34,7 +34,8 @@ ABI_SYMBOLS = (
     "asgart_searcher_search", "asgart_sa_read", "asgart_probe_hits", "asgart_get_stats",
     "asgart_last_error", "asgart_version", "asgart_compute_scores", "asgart_index_set_option",
     "asgart_index_check_sa", "asgart_index_create_trim", "asgart_index_clone",
-    "asgart_search_duplications_multi", "asgart_search_duplications_ex",
+    "asgart_search_duplications_multi", "asgart_search_duplications_ex", "asgart_search_duplications_passes",
+    "asgart_search_duplications_passes_shard",
 )
 
 
@@ -119,6 +120,11 @@ def load_library() -> C.CDLL:
     L.asgart_search_duplications_ex.argtypes = [vp, vp, C.c_int64, C.POINTER(_Settings), C.c_int32, C.c_int32, vp,
                                                 C.POINTER(vp)]
     L.asgart_search_duplications_ex.restype = C.c_int32
+    L.asgart_search_duplications_passes.argtypes = [vp, vp, C.c_int64, C.POINTER(_Settings), C.c_int32, C.POINTER(vp)]
+    L.asgart_search_duplications_passes.restype = C.c_int32
+    L.asgart_search_duplications_passes_shard.argtypes = [vp, vp, C.c_int64, C.POINTER(_Settings), C.c_int32, C.c_int32,
+                                                          C.c_int32, C.POINTER(vp)]
+    L.asgart_search_duplications_passes_shard.restype = C.c_int32
     L.asgart_families_counts.argtypes = [vp, u64p, u64p]
     L.asgart_families_counts.restype = None
     L.asgart_families_copy.argtypes = [vp, vp, vp]
@@ -336,6 +342,33 @@ class Index:
         finally:
             L.asgart_families_free(h)
         return offs, sds
+
+    def search_duplications_passes(self, chunks: Sequence[Tuple[int, int]], settings: Sequence[RunSettings],
+                                   shard: int = 0, n_shards: int = 1) -> List[Tuple[np.ndarray, np.ndarray]]:
+        """Several passes (one RunSettings each, e.g. the direct and the -RC run) in one call; the library pipelines
+        them itself.  -> [(fam_offsets, sds)] in the order of `settings`, each as search_duplications_raw returns it."""
+        L = load_library()
+        ch = np.array(chunks, dtype=np.uint64).reshape(-1)
+        n = len(settings)
+        sts = (_Settings * max(n, 1))(*[s._c() for s in settings])
+        hs = (C.c_void_p * max(n, 1))()
+        if n_shards == 1:
+            _check(L.asgart_search_duplications_passes(self._h, _ptr(ch), len(chunks), sts, n, hs))
+        else:
+            _check(L.asgart_search_duplications_passes_shard(self._h, _ptr(ch), len(chunks), sts, n, shard, n_shards, hs))
+        out = []
+        try:
+            for j in range(n):
+                nf, ns = C.c_uint64(), C.c_uint64()
+                L.asgart_families_counts(hs[j], C.byref(nf), C.byref(ns))
+                offs = np.zeros(nf.value + 1, dtype=np.uint64)
+                sds = np.zeros((ns.value, 4), dtype=np.uint64)
+                L.asgart_families_copy(hs[j], _ptr(offs), _ptr(sds))
+                out.append((offs, sds))
+        finally:
+            for j in range(n):
+                L.asgart_families_free(hs[j])
+        return out
 
     def probe_hits(self, chunks: Sequence[Tuple[int, int]], settings: RunSettings):
         """Per-probe filtered hits for all chunks: (status, row_offsets, hits)."""

@@ -238,6 +238,7 @@ struct asgart_index {
     uint64_t tail_bloom = 0;
     std::vector<uint8_t> h_tail;  // last 64 bytes of the text (host copy)
     double ms_prepare = 0.0;
+    double tail_ms[4] = {-1.0, -1.0, -1.0, -1.0};  // per orientation (reverse * 2 + complement): extension time of its last unsharded call
     asgart::Options opt;
     asgart::SearchCtx ctx[asgart::kNumCtx];
     int last_ctx = 0;  // context of the most recent search call (asgart_get_stats)

@@ -8,6 +8,7 @@
 #include "extend_fast_dev.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <string>
 #include <thread>
@@ -826,6 +827,7 @@ int32_t run_search(asgart_index *idx, const uint64_t *chunks, int64_t n_chunks,
         rc = run_search_t<uint32_t>(idx, cx, chunks, n_chunks, st, shard, n_shards, want_csr, fam_out,
                                     status_out, rowoff_out, hits_out);
     cx.progress = nullptr;
+    if (rc == 0 && fam_out) idx->tail_ms[(st->reverse ? 2 : 0) | (st->complement ? 1 : 0)] = cx.stats.ms_extend;
     idx->release_one(which);
     return rc;
 }
@@ -938,6 +940,84 @@ int32_t asgart_search_duplications_multi(asgart_index *const *indices, int32_t n
             progress[c] = (uint64_t)probes_in_chunk(chunks[2 * c + 1], k, step, settings->min_duplication_length) * step;
     }
     *out = f;
+    return 0;
+}
+
+int32_t asgart_search_duplications_passes(asgart_index *idx, const uint64_t *chunks, int64_t n_chunks,
+                                          const asgart_settings *settings, int32_t n_passes,
+                                          asgart_families **out) {
+    return asgart_search_duplications_passes_shard(idx, chunks, n_chunks, settings, n_passes, 0, 1, out);
+}
+
+int32_t asgart_search_duplications_passes_shard(asgart_index *idx, const uint64_t *chunks, int64_t n_chunks,
+                                                const asgart_settings *settings, int32_t n_passes,
+                                                int32_t shard, int32_t n_shards, asgart_families **out) {
+    if (!out || n_passes < 0 || (n_passes && !settings)) {
+        set_error("bad argument");
+        return ASGART_E_ARG;
+    }
+    for (int32_t j = 0; j < n_passes; ++j) out[j] = nullptr;
+    if (!idx || n_chunks < 0 || (n_chunks && !chunks)) {
+        set_error("bad argument");
+        return ASGART_E_ARG;
+    }
+    if (n_passes == 0) return 0;
+    // issue order: longest extension first (what is known from earlier calls; an orientation never run yet
+    // counts as longest, reversed ones ahead of the others: their tandem arrays are walked against the
+    // whole text instead of the part behind the probe)
+    std::vector<int32_t> order((size_t)n_passes);
+    for (int32_t j = 0; j < n_passes; ++j) order[j] = j;
+    auto weight = [&](int32_t j) {
+        const int mode = (settings[j].reverse ? 2 : 0) | (settings[j].complement ? 1 : 0);
+        const double t = idx->tail_ms[mode];
+        return t >= 0.0 ? t : 1e30 + (settings[j].reverse ? 1e29 : 0.0);
+    };
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return weight(a) > weight(b); });
+    // one host thread per pass; thread p starts its call when pass p-1 reports its probes as searched
+    // (or has returned); a call blocks in the index until one of the two contexts is free
+    std::vector<asgart_families *> fams((size_t)n_passes, nullptr);
+    std::vector<int32_t> rcs((size_t)n_passes, 0);
+    std::vector<std::string> errs((size_t)n_passes);
+    std::vector<std::vector<uint64_t>> prog((size_t)n_passes, std::vector<uint64_t>((size_t)std::max<int64_t>(n_chunks, 1), 0));
+    std::vector<std::atomic<int>> finished((size_t)n_passes);
+    for (auto &f : finished) f.store(0);
+    auto searched = [&](int32_t p) {
+        if (finished[p].load(std::memory_order_acquire)) return true;
+        const volatile uint64_t *pr = prog[p].data();
+        for (int64_t c = 0; c < n_chunks; ++c)
+            if (pr[c]) return true;
+        return false;
+    };
+    std::vector<std::thread> workers;
+    for (int32_t p = 0; p < n_passes; ++p)
+        workers.emplace_back([&, p]() {
+            if (p > 0)
+                while (!searched(p - 1)) std::this_thread::sleep_for(std::chrono::microseconds(100));
+            const int32_t j = order[p];
+            asgart_families *f = new (std::nothrow) asgart_families();
+            if (!f) {
+                rcs[p] = ASGART_E_OOM;
+                errs[p] = "out of host memory";
+            } else {
+                rcs[p] = run_search(idx, chunks, n_chunks, &settings[j], shard, n_shards, false, f, nullptr, nullptr,
+                                    nullptr, prog[p].data());
+                if (rcs[p] != 0) {
+                    errs[p] = asgart_last_error();  // the message is thread-local
+                    delete f;
+                } else {
+                    fams[p] = f;
+                }
+            }
+            finished[p].store(1, std::memory_order_release);
+        });
+    for (auto &t : workers) t.join();
+    for (int32_t p = 0; p < n_passes; ++p)
+        if (rcs[p] != 0) {
+            for (auto *f : fams) delete f;
+            set_error("pass %d of %d: %s", order[p], n_passes, errs[p].c_str());
+            return rcs[p];
+        }
+    for (int32_t p = 0; p < n_passes; ++p) out[order[p]] = fams[p];
     return 0;
 }
 

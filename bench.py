@@ -185,10 +185,16 @@ def main():
     # Four ways to issue the two passes of a step; which is fastest depends on how much of a pass is its
     # serial extension tail (pipelining hides it) and how much is chip-wide work the passes would only
     # steal from each other.  One untimed step of each decides (ASGART_BENCH_MODE forces one).
-    MODES_OF_ISSUE = ("back_to_back", "overlapped", "pipelined_0_first", "pipelined_1_first")
+    MODES_OF_ISSUE = ("library", "back_to_back", "overlapped", "pipelined_0_first", "pipelined_1_first")
 
     def issue(mode):
         """-> (results in `settings` order, the library's per-call stats)"""
+        if mode == "library" and len(settings) > 1:
+            # ONE call for the passes of a step (asgart_search_duplications_passes): the library issues pass j+1 when
+            # pass j's probes are searched, longest extension first -- no host threads, no polling here
+            results = idx.search_duplications_passes(pr.chunks, settings, rank if world > 1 else 0,
+                                                     world if world > 1 else 1)
+            return results, [idx.stats((ci + 1) << 8) for ci in range(len(settings))]
         if mode == "back_to_back" or len(settings) == 1:
             results, stats = [], []
             for st in settings:
@@ -208,8 +214,10 @@ def main():
     if len(settings) == 1:
         mode = "back_to_back"
     elif mode not in MODES_OF_ISSUE:
+        # default: the library's own pipelining.  One untimed step of each way of issuing is recorded for
+        # information (ASGART_BENCH_MODE=auto picks the fastest of them instead).
         mode_probe_ms = {}
-        for m in MODES_OF_ISSUE:
+        for m in MODES_OF_ISSUE if (mode == "auto" or os.environ.get("ASGART_BENCH_PROBE_MODES")) else ("back_to_back", "library"):
             sync()
             t_a = time.perf_counter()
             issue(m)
@@ -221,7 +229,7 @@ def main():
                 dist.all_reduce(v, op=dist.ReduceOp.MAX)
                 dt = float(v.item())
             mode_probe_ms[m] = round(dt * 1e3, 2)
-        mode = min(mode_probe_ms, key=mode_probe_ms.get)
+        mode = min(mode_probe_ms, key=mode_probe_ms.get) if mode == "auto" else "library"
     elif mode != "back_to_back":
         issue(mode)   # untimed: a forced concurrent mode allocates its second call context here, not in the timed region
     sequential = mode == "back_to_back"

@@ -192,6 +192,25 @@ int32_t asgart_search_duplications_ex(asgart_index *idx, const uint64_t *chunks,
                                       const asgart_settings *settings, int32_t shard, int32_t n_shards,
                                       volatile uint64_t *progress, asgart_families **out);
 
+/* Several passes over the same chunks in ONE call -- what the `asgart` binary does when it is run with
+ * and without -R / -C over one strand (reference src/bin/asgart.rs:677-693 builds one RunSettings per
+ * invocation; the direct and the -RC run of BASELINE.json's "direct+RC" are two of them): settings[j] are
+ * the RunSettings of pass j, out[j] receives its families (exactly what asgart_search_duplications returns
+ * for settings[j]).  The library pipelines the passes itself: pass j+1 is issued the moment the chip-wide,
+ * HBM-bound phases of pass j are over (probe search, scans, hit materialisation -- the moment the `progress`
+ * array of a single call jumps), so its search runs beside pass j's extension automaton, whose tail is a few
+ * serial segments on one compute unit each; the passes are issued longest extension first (from the
+ * durations the index remembers per orientation; reversed orientations first while nothing is known).
+ * At most two passes are in flight (the index's two call contexts).  Results do not depend on the order.
+ * On error every out[j] is NULL. */
+int32_t asgart_search_duplications_passes(asgart_index *idx, const uint64_t *chunks, int64_t n_chunks,
+                                          const asgart_settings *settings, int32_t n_passes,
+                                          asgart_families **out);
+/* ... restricted to shard `shard` of `n_shards` (every pass; see asgart_search_duplications_shard). */
+int32_t asgart_search_duplications_passes_shard(asgart_index *idx, const uint64_t *chunks, int64_t n_chunks,
+                                                const asgart_settings *settings, int32_t n_passes,
+                                                int32_t shard, int32_t n_shards, asgart_families **out);
+
 void asgart_families_counts(const asgart_families *f, uint64_t *n_families, uint64_t *n_sds);
 /* fam_offsets: n_families+1 entries; sds: n_sds entries */
 void asgart_families_copy(const asgart_families *f, uint64_t *fam_offsets, asgart_proto_sd *sds);

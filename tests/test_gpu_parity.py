@@ -704,6 +704,25 @@ def test_progress_array_and_pipelined_calls(hiplib):
         assert prog.tolist() == want
 
 
+def test_passes_entry_point_equals_single_calls(hiplib):
+    """asgart_search_duplications_passes: all four orientations in one call (the library issues them itself,
+    pipelined, longest extension first) -- every pass equals its own asgart_search_duplications call, whatever
+    order the library chose (first call: nothing known; second call: the remembered durations)."""
+    pr, cli = _battery_case("satellites")
+    oidx = oracle.Index.build(pr.data)
+    with asgart_amd.Index(pr.data, oidx.sa) as idx:
+        sts = [asgart_amd.RunSettings.from_cli(reverse=r, complement=c, **cli) for r, c in MODES]
+        for _ in range(2):
+            got = idx.search_duplications_passes(pr.chunks, sts)
+            assert len(got) == 4
+            for st, (offs, sds) in zip(sts, got):
+                eo, es = idx.search_duplications_raw(pr.chunks, st)
+                assert np.array_equal(offs, eo) and np.array_equal(sds, es)
+        assert idx.search_duplications_passes(pr.chunks, []) == []
+        eo, es = oidx.run_raw(pr.chunks, oracle.make_settings(reverse=True, complement=True, **cli))
+        assert np.array_equal(got[3][0], eo) and np.array_equal(got[3][1], es)
+
+
 def test_cfg3_full_skip_masked_digest(hiplib):
     """BASELINE.json configs[2] as stated: chr1-sized synthetic (249 Mb), direct + RC, --skip-masked."""
     _check_against_oracle_digest("cfg3s")
@@ -713,6 +732,39 @@ def test_cfg4_full_digest(hiplib):
     """BASELINE.json configs[3], the benchmarked workload: GRCh38-sized synthetic (3.1 Gb, 25 records),
     direct + RC, on one MI355X, against the oracle's digests of the same seeded genome."""
     _check_against_oracle_digest("cfg4")
+
+
+def test_cfg5_wide_digest(hiplib):
+    """BASELINE.json configs[4] (two files: the GRCh38-shaped genome + its 1.2 %-diverged, rearranged copy,
+    reference src/bin/asgart.rs:375-395) at the smallest scale that needs 64-bit suffix-array entries
+    (n = 4.32 G >= 2^32): every kernel in its natively wide instantiation -- the 64-bit suffix sorter, 64-bit
+    slots in the search, 64-bit positions in every extension tier -- against the oracle's digests of the same
+    seeded input (suffix array by sha256, per pass counters, family / ProtoSD counts, sha256 of the results)."""
+    _check_against_oracle_digest("cfg5h")
+
+
+def test_cfg5_full_properties(hiplib):
+    """configs[4] at FULL size (6.18 Gb, 64-bit suffix array, one GPU): the oracle cannot hold this input, so the
+    size-independent properties are checked -- the suffix array passes the GPU verifier; every ProtoSD lies inside
+    the text with arms of at least min_length; families are non-empty and offsets strictly increasing; a second
+    call and the concatenation of 3 shards give the identical result; the direct pass pairs the two genomes."""
+    pr = prep.prepare_records(synth.config_genome(5, 1.0))
+    n = len(pr.data)
+    assert n > (1 << 32) and len(pr.chunks) > 50
+    with asgart_amd.Index(pr.data, None) as idx:
+        assert idx.check_sa() == 0
+        for rc in (False, True):
+            st = asgart_amd.RunSettings.from_cli(reverse=rc, complement=rc)
+            offs, sds = idx.search_duplications_raw(pr.chunks, st)
+            assert len(sds) > 100_000 and int(offs[-1]) == len(sds) and np.all(np.diff(offs.astype(np.int64)) > 0)
+            assert np.all(sds[:, 0] + sds[:, 2] <= n) and np.all(sds[:, 1] + sds[:, 3] <= n)
+            assert np.all(sds[:, 3] >= 1000)
+            offs2, sds2 = idx.search_duplications_raw(pr.chunks, st)
+            assert np.array_equal(offs, offs2) and np.array_equal(sds, sds2)
+            parts = [idx.search_duplications_raw(pr.chunks, st, shard=r, n_shards=3) for r in range(3)]
+            assert np.array_equal(np.concatenate([p[1] for p in parts]), sds), "shards != unsharded"
+            cross = int(np.sum((sds[:, 0] < n // 2) != (sds[:, 1] < n // 2)))
+            assert cross > 10_000, cross
 
 
 @pytest.mark.parametrize("rc", [False, True])
