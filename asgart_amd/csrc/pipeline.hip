@@ -329,7 +329,10 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
         const bool arms_kernel = rp.C <= (uint64_t)kHitBatch && opt.arms_kernel != 0;
         const bool arms_small = arms_kernel && rp.C <= (uint64_t)kWaveArmsHits;
         // the two-barrier kernel packs a 64-bit position into 42 bits of a table entry
-        auto fast_tier = [&](int t) { return arms_kernel && ((opt.fast >> t) & 1) != 0 && (uint64_t)idx->n < (1ull << 42); };
+        auto fast_tier = [&](int t) {
+            if (t == 6 && sizeof(SlotT) == 8) return false;  // (2 x 1024 slots would be fewer than K4c's 8 x 512)
+            return arms_kernel && ((opt.fast >> t) & 1) != 0 && (uint64_t)idx->n < (1ull << 42);
+        };
         uint32_t tier_cap[kTiers + 1] = {0, kArmCapSmall, 0, 0, 0, 0, 0, (uint32_t)capg};
         if (arms_kernel) {
             if (arms_small) {
@@ -343,7 +346,8 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             // the window bound is pessimistic for tandem arrays (hits extend arms there) and the HBM
             // tier is several times slower per probe: tier 6 also takes segments whose bound exceeds
             // its capacity by up to 40 % (a real overflow falls through the cascade)
-            tier_cap[6] = (uint32_t)((uint64_t)kArmsLayers<SlotT> * kHeavyThreads * (uint64_t)opt.cap6_pct / 100u);
+            tier_cap[6] = (uint32_t)((uint64_t)(fast_tier(6) ? kFastLongLayers<SlotT> * 1024 : kArmsLayers<SlotT> * kHeavyThreads) *
+                                     (uint64_t)opt.cap6_pct / 100u);
             // tier 3 accepts what tier 6 would accept by the bound (a long segment is no less safe there), but
             // never more than the same allowance over its own capacity (with 64-bit positions it holds fewer
             // arms than tier 6, and what it gives up on is re-run from the start)
@@ -528,7 +532,9 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                     break;
                 case 6:
                     if (scratch_override) ep.scratch = scratch_override;
-                    if (arms_kernel)
+                    if (fast_tier(6))  // the shape of tier 3: a fifth fewer cycles per probe than K4c, 5 x 1024 >= 9 x 512 slots
+                        extend_fast_kernel<SlotT, kFastLongLayers<SlotT>, 1024, kHitBatch, 2048, 2><<<grid(256), 1024, 0, st>>>(ep);
+                    else if (arms_kernel)
                         extend_arms_kernel<SlotT, kArmsLayers<SlotT>, kHeavyThreads, kHitBatch, 1024, 4, false, kArmsCold<SlotT>><<<grid(256), kHeavyThreads, 0, st>>>(ep);
                     else
                         extend_heavy_kernel<SlotT, caph, kHeavyThreads, 1><<<grid(256), kHeavyThreads, 0, st>>>(ep);
