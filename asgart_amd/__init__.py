@@ -22,7 +22,7 @@ import numpy as np
 
 __all__ = [
     "AsgartError", "RunSettings", "ProtoSD", "Strand", "Index", "Searcher", "SearchDuplications",
-    "load_library", "library_path", "ABI_SYMBOLS", "sa_build64", "search_duplications_multi",
+    "load_library", "library_path", "ABI_SYMBOLS", "sa_build64", "search_duplications_multi", "merge_shards",
 ]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -35,8 +35,25 @@ ABI_SYMBOLS = (
     "asgart_last_error", "asgart_version", "asgart_compute_scores", "asgart_index_set_option",
     "asgart_index_check_sa", "asgart_index_create_trim", "asgart_index_clone",
     "asgart_search_duplications_multi", "asgart_search_duplications_ex", "asgart_search_duplications_passes",
-    "asgart_search_duplications_passes_shard",
+    "asgart_search_duplications_passes_shard", "asgart_families_keys",
 )
+
+
+def merge_shards(parts) -> Tuple[np.ndarray, np.ndarray]:
+    """(fam_offsets, sds, keys) of every shard of one call -> (fam_offsets, sds) of the whole call: families ordered
+    by key (segment start probe, family ordinal) == reference order.  What rank 0 does after the gather."""
+    keys = np.concatenate([p[2] for p in parts]) if parts else np.zeros(0, np.uint64)
+    if len(keys) == 0:
+        return np.zeros(1, np.uint64), np.zeros((0, 4), np.uint64)
+    starts = np.concatenate([p[0][:-1].astype(np.int64) + b for p, b in
+                             zip(parts, np.cumsum([0] + [len(p[1]) for p in parts[:-1]]))])
+    lens = np.concatenate([np.diff(p[0].astype(np.int64)) for p in parts])
+    sds = np.concatenate([p[1] for p in parts])
+    order = np.argsort(keys, kind="stable")
+    lens_o, starts_o = lens[order], starts[order]
+    offs = np.concatenate([[0], np.cumsum(lens_o)]).astype(np.uint64)
+    idx = np.repeat(starts_o - offs[:-1].astype(np.int64), lens_o) + np.arange(int(offs[-1]), dtype=np.int64)
+    return offs, sds[idx]
 
 
 class AsgartError(RuntimeError):
@@ -122,6 +139,8 @@ def load_library() -> C.CDLL:
     L.asgart_search_duplications_ex.restype = C.c_int32
     L.asgart_search_duplications_passes.argtypes = [vp, vp, C.c_int64, C.POINTER(_Settings), C.c_int32, C.POINTER(vp)]
     L.asgart_search_duplications_passes.restype = C.c_int32
+    L.asgart_families_keys.argtypes = [vp, vp]
+    L.asgart_families_keys.restype = None
     L.asgart_search_duplications_passes_shard.argtypes = [vp, vp, C.c_int64, C.POINTER(_Settings), C.c_int32, C.c_int32,
                                                           C.c_int32, C.POINTER(vp)]
     L.asgart_search_duplications_passes_shard.restype = C.c_int32
@@ -314,8 +333,8 @@ class Index:
 
     # -- SearchDuplications::run body --------------------------------------
     def search_duplications_raw(self, chunks: Sequence[Tuple[int, int]], settings: RunSettings,
-                                shard: int = 0, n_shards: int = 1, progress: Optional[np.ndarray] = None
-                                ) -> Tuple[np.ndarray, np.ndarray]:
+                                shard: int = 0, n_shards: int = 1, progress: Optional[np.ndarray] = None,
+                                with_keys: bool = False):
         """-> (fam_offsets[n_fam+1], sds[n_sd,4]) as uint64 arrays.  progress: optional uint64[n_chunks]
         the library writes each chunk's needle offset into when the call's search phases are over (see the header)."""
         L = load_library()
@@ -339,12 +358,15 @@ class Index:
             offs = np.zeros(nf.value + 1, dtype=np.uint64)
             sds = np.zeros((ns.value, 4), dtype=np.uint64)
             L.asgart_families_copy(h, _ptr(offs), _ptr(sds))
+            keys = np.zeros(nf.value, dtype=np.uint64)
+            if with_keys:
+                L.asgart_families_keys(h, _ptr(keys))
         finally:
             L.asgart_families_free(h)
-        return offs, sds
+        return (offs, sds, keys) if with_keys else (offs, sds)
 
     def search_duplications_passes(self, chunks: Sequence[Tuple[int, int]], settings: Sequence[RunSettings],
-                                   shard: int = 0, n_shards: int = 1) -> List[Tuple[np.ndarray, np.ndarray]]:
+                                   shard: int = 0, n_shards: int = 1, with_keys: bool = False) -> List[tuple]:
         """Several passes (one RunSettings each, e.g. the direct and the -RC run) in one call; the library pipelines
         them itself.  -> [(fam_offsets, sds)] in the order of `settings`, each as search_duplications_raw returns it."""
         L = load_library()
@@ -364,7 +386,10 @@ class Index:
                 offs = np.zeros(nf.value + 1, dtype=np.uint64)
                 sds = np.zeros((ns.value, 4), dtype=np.uint64)
                 L.asgart_families_copy(hs[j], _ptr(offs), _ptr(sds))
-                out.append((offs, sds))
+                keys = np.zeros(nf.value, dtype=np.uint64)
+                if with_keys:
+                    L.asgart_families_keys(hs[j], _ptr(keys))
+                out.append((offs, sds, keys) if with_keys else (offs, sds))
         finally:
             for j in range(n):
                 L.asgart_families_free(hs[j])

@@ -62,6 +62,7 @@ const OptDesc kOptions[] = {
     {"fast", &Options::fast, 0, 255},
     {"fast_nt", &Options::fast_nt, 256, 1024},
     {"cap3_pct", &Options::cap3_pct, 100, 400},
+    {"shard_lpt", &Options::shard_lpt, 0, 1},
     {"fast_bsh", &Options::fast_bsh, 0, 3},
     {"fast_e", &Options::fast_e, 2, 4},
     {"fast_pipe", &Options::fast_pipe, 0, 1},
@@ -698,7 +699,7 @@ void asgart_index_destroy(asgart_index *idx) {
     for (auto &cx : idx->ctx) {
         Workspace &w = cx.ws;
         DevBuf *bufs[] = {&w.chunks, &w.p_lo, &w.p_raw, &w.p_filt, &w.row_off, &w.blk, &w.hits,
-                          &w.big_list, &w.rank_list, &w.seg_list, &w.counters, &w.fam_sds, &w.ovf_list,
+                          &w.big_list, &w.rank_list, &w.seg_list, &w.counters, &w.fam_sds, &w.ovf_list, &w.own_list,
                           &w.scratch, &w.hit_flag, &w.seg_keys, &w.seg_vals, &w.sort_tmp, &w.pat,
                           &w.out_a, &w.out_b};
         for (DevBuf *b : bufs) b->release();

@@ -97,6 +97,7 @@ struct Workspace {
     DevBuf counters;   // u64[32] device counters
     DevBuf fam_sds;    // SdRec[cap] output records of the extension kernel
     DevBuf ovf_list;   // u32 segments that overflowed the small arm tier
+    DevBuf own_list;   // u32 sharded call with cost-aware ownership: this shard's segments, tier by tier
     DevBuf scratch;    // arm storage of the global heavy tier
     DevBuf hit_flag;   // u8 per CSR entry: continuation flag (pre-pass)
     DevBuf seg_keys, seg_vals, sort_tmp;  // segment placement: (tier, work) keys, double-buffered
@@ -204,6 +205,10 @@ struct Options {
     int64_t fast_pipe = 1;          // experiments: 1 = one barrier per hit-probe (B of probe t-1 runs beside A of probe t)
     int64_t fast_e = 2;             // experiments: entries per table row (2 / 4)
     int64_t cap3_pct = 160;         // tier 3 with the one-barrier kernel accepts segments whose arm bound is up to this percentage of its capacity
+    int64_t shard_lpt = 0;          // sharded calls: 0 = contiguous probe slices with halos; 1 = every shard computes the whole front and
+                                    // owns every n_shards-th segment of each tier's cost-sorted list (snake order) -- measured at
+                                    // cfg4, 8 shards: balanced (91-117 ms direct) but the replicated front makes its slowest shard
+                                    // slower than the slice mode's (211 vs 184 ms -RC, 117 vs 90 ms direct): the floor is the longest segment
     int64_t tier_streams = 7234562; // digit t (from the left): the stream (1..7, 1 = the call's high-priority main stream) tier t runs on
 };
 int32_t create_ctx_streams(SearchCtx &cx);
@@ -314,6 +319,8 @@ struct asgart_index {
 
 struct asgart_families {
     std::vector<uint64_t> fam_offsets;  // n_fam + 1
+    std::vector<uint64_t> fam_keys;     // n_fam: (first probe of the family's segment << 32) | family ordinal inside it --
+                                        // ascending == reference order; what a gatherer merges sharded results by
     std::vector<asgart_proto_sd> sds;
 };
 
@@ -328,7 +335,7 @@ int32_t run_search(asgart_index *idx, const uint64_t *chunks, int64_t n_chunks,
 // records -> reference order (g_start, fam_seq, create_seq), stable; result in w.rec_sorted
 int32_t sort_records(Workspace &w, const SdRec *recs, uint64_t n, hipStream_t s);
 int32_t sort_segments(Workspace &w, uint32_t *keys, uint32_t *vals, uint64_t n, hipStream_t s,
-                      const uint32_t **sorted_vals, const uint32_t **sorted_keys);
+                      const uint32_t **sorted_vals, const uint32_t **sorted_keys, bool ties_by_value);
 int32_t text_is_dna(const uint8_t *d_text, int64_t n, hipStream_t s, bool *dna);
 int32_t sa_build_device(const uint8_t *d_text, int64_t n, void *d_sa, bool wide,
                         hipStream_t stream, uint64_t wide_batch);

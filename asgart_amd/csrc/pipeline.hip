@@ -105,14 +105,14 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
     const uint64_t n = (uint64_t)idx->n;
 
     // ---- chunk table -------------------------------------------------------
-    // (in the call context's pinned control block: [counters | four scalars | start[nc] | len[nc] | pbase[nc + 1]])
+    // (in the call context's pinned control block: [counters | 32 scalars | start[nc] | len[nc] | pbase[nc + 1]])
     constexpr size_t kCtrBytes = (size_t)CT_COUNT * 8;
     const size_t ch_bytes = (size_t)n_chunks * 16 + ((size_t)n_chunks + 1) * 4;
     void *ctl_p = nullptr;
-    RC_TRY(cx.ctl(kCtrBytes + ch_bytes + 32, &ctl_p));
+    RC_TRY(cx.ctl(kCtrBytes + ch_bytes + 256, &ctl_p));
     unsigned long long *const h_ctr = static_cast<unsigned long long *>(ctl_p);
     unsigned long long *const h_scalar = h_ctr + CT_COUNT;  // source of small host-to-device updates
-    uint64_t *const h_start = reinterpret_cast<uint64_t *>(static_cast<char *>(ctl_p) + kCtrBytes + 32);
+    uint64_t *const h_start = reinterpret_cast<uint64_t *>(static_cast<char *>(ctl_p) + kCtrBytes + 256);
     uint64_t *const h_len = h_start + n_chunks;
     uint32_t *const h_pbase = reinterpret_cast<uint32_t *>(h_len + n_chunks);
     uint64_t P64 = 0;
@@ -140,6 +140,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
     cx.stats.probes_total = P;
     if (fam_out) {
         fam_out->fam_offsets.assign(1, 0);
+        fam_out->fam_keys.clear();
         fam_out->sds.clear();
     }
     if (want_csr) {
@@ -156,10 +157,17 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
     // global probe sequence.  It computes probe-search over that slice plus a look-back halo
     // (to decide whether its first probes continue an earlier segment) and a look-ahead halo
     // (to finish segments that run past the slice); no data is exchanged between shards.
-    const uint32_t own_lo = (uint32_t)((uint64_t)P * (uint64_t)shard / (uint64_t)n_shards);
-    const uint32_t own_hi = (uint32_t)((uint64_t)P * (uint64_t)(shard + 1) / (uint64_t)n_shards);
-    if (own_lo == own_hi) return 0;
+    // With option shard_lpt (default) the shards do not cut the probe sequence at all: every shard computes the
+    // whole front -- probe search, scans, hit rows, placement: a tenth of a step -- and then owns every
+    // n_shards-th segment of each tier's cost-sorted list (take_owned_kernel): the long serial segments, which
+    // sit next to each other in the genome, land on different GPUs.  Still no exchange; the gatherer merges the
+    // shards' families by their keys (asgart_families_keys).
     const Options opt = idx->opt;  // options cannot change while this call holds a context
+    const bool lpt = n_shards > 1 && opt.shard_lpt != 0;
+    const int32_t f_shard = lpt ? 0 : shard, f_n = lpt ? 1 : n_shards;
+    const uint32_t own_lo = (uint32_t)((uint64_t)P * (uint64_t)f_shard / (uint64_t)f_n);
+    const uint32_t own_hi = (uint32_t)((uint64_t)P * (uint64_t)(f_shard + 1) / (uint64_t)f_n);
+    if (own_lo == own_hi) return 0;
     uint64_t look_back = (uint64_t)opt.shard_lookback;
     uint64_t look_ahead = opt.shard_lookahead > 0 ? (uint64_t)opt.shard_lookahead
                                                   : std::max<uint64_t>(65536, (own_hi - own_lo) / 16);
@@ -402,7 +410,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
         HIP_TRY(hipGetLastError());
         const uint32_t *order = nullptr;
         const uint32_t *sorted_keys = nullptr;
-        RC_TRY(sort_segments(w, kbuf, vbuf, n_seg, s, &order, &sorted_keys));
+        RC_TRY(sort_segments(w, kbuf, vbuf, n_seg, s, &order, &sorted_keys, lpt));
         tier_bounds_kernel<<<1, 64, 0, s>>>(sorted_keys, d_ctr + CT_SEG, d_ctr);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, kCtrBytes, hipMemcpyDeviceToHost, s));
@@ -417,6 +425,40 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                     (unsigned long long)h_ctr[CT_LONGSEG]);
             for (int t = 0; t < kTiers; ++t) fprintf(stderr, " %llu", (unsigned long long)n_t[t]);
             fprintf(stderr, "\n");
+        }
+        if (lpt) {  // keep this shard's share of every tier's list
+            const uint64_t R = (uint64_t)n_shards, r = (uint64_t)shard;
+            unsigned long long *h_off = h_scalar + 4;  // [kTiers + 1] offsets in order, [kTiers + 1] offsets in own
+            uint64_t own_total = 0;
+            for (int t = 0; t <= kTiers; ++t) h_off[t] = seg_off[t];
+            for (int t = 0; t < kTiers; ++t) {
+                // entries i with i * R + (i even ? r : R - 1 - r) < n_t
+                uint64_t cnt = 0;
+                const uint64_t full = n_t[t] / (2 * R);          // complete pairs of rounds: two entries each
+                cnt = 2 * full;
+                const uint64_t rest = n_t[t] - full * 2 * R;     // < 2 R entries of the last pair of rounds
+                if (rest > r) ++cnt;
+                if (rest > R + (R - 1 - r)) ++cnt;
+                h_off[kTiers + 1 + t] = own_total;
+                own_total += cnt;
+                n_t[t] = cnt;
+            }
+            h_off[kTiers + 1 + kTiers] = own_total;
+            RC_TRY(w.own_list.reserve((size_t)(own_total + 1) * 4 + 2 * (kTiers + 1) * 8));
+            uint32_t *own = w.own_list.as<uint32_t>();
+            unsigned long long *d_off = reinterpret_cast<unsigned long long *>(w.own_list.as<char>() + (((size_t)(own_total + 1) * 4 + 7) & ~(size_t)7));
+            HIP_TRY(hipMemcpyAsync(d_off, h_off, 2 * (kTiers + 1) * 8, hipMemcpyHostToDevice, s));
+            if (own_total)
+                take_owned_kernel<<<grid_for(own_total), 256, 0, s>>>(order, own, d_off, d_off + kTiers + 1, (uint32_t)R, (uint32_t)r);
+            HIP_TRY(hipGetLastError());
+            for (int t = 0; t < kTiers; ++t) {
+                h_off[2 * (kTiers + 1) + t] = n_t[t];
+                seg_off[t + 1] = seg_off[t] + n_t[t];
+            }
+            HIP_TRY(hipMemcpyAsync(d_ctr + CT_N1, h_off + 2 * (kTiers + 1), (size_t)kTiers * 8, hipMemcpyHostToDevice, s));
+            HIP_TRY(hipStreamSynchronize(s));  // (h_off is reused by the next call)
+            order = own;
+            n_seg = own_total;
         }
         uint32_t *ovf[kTiers];  // ovf[t-1]: segments tier t gave up on
         for (int t = 0; t < kTiers; ++t) ovf[t] = w.ovf_list.as<uint32_t>() + (size_t)t * (n_seg + 1);
@@ -749,6 +791,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                     fam_out->sds.push_back(h_recs[j].sd);
                 }
                 fam_out->fam_offsets.push_back(fam_out->sds.size());
+                fam_out->fam_keys.push_back(((uint64_t)h_recs[f0].g_start << 32) | (uint64_t)h_recs[f0].fam_seq);
             }
             f0 = f1;
         }
@@ -911,8 +954,7 @@ int32_t asgart_search_duplications_multi(asgart_index *const *indices, int32_t n
             set_error("index %d is NULL or not a replica of index 0", r);
             return ASGART_E_ARG;
         }
-    // one host thread per device; shard r = the segments that start in the r-th slice of the global
-    // probe sequence (no exchange between shards); results concatenated in shard order
+    // one host thread per device; shard r of n_devices (no exchange between shards)
     std::vector<asgart_families> parts((size_t)n_devices);
     std::vector<int32_t> rcs((size_t)n_devices, 0);
     std::vector<std::string> errs((size_t)n_devices);
@@ -934,11 +976,23 @@ int32_t asgart_search_duplications_multi(asgart_index *const *indices, int32_t n
         set_error("out of host memory");
         return ASGART_E_OOM;
     }
+    // merge the shards' families by key (segment start probe, family ordinal): reference order, whichever way
+    // the segments were dealt out
+    struct Ref {
+        uint64_t key;
+        int32_t r;
+        uint32_t j;
+    };
+    std::vector<Ref> refs;
+    for (int32_t r = 0; r < n_devices; ++r)
+        for (size_t j = 0; j < parts[r].fam_keys.size(); ++j) refs.push_back(Ref{parts[r].fam_keys[j], r, (uint32_t)j});
+    std::stable_sort(refs.begin(), refs.end(), [](const Ref &a, const Ref &b) { return a.key < b.key; });
     f->fam_offsets.assign(1, 0);
-    for (int32_t r = 0; r < n_devices; ++r) {
-        const uint64_t base = f->sds.size();
-        f->sds.insert(f->sds.end(), parts[r].sds.begin(), parts[r].sds.end());
-        for (size_t j = 1; j < parts[r].fam_offsets.size(); ++j) f->fam_offsets.push_back(base + parts[r].fam_offsets[j]);
+    for (const Ref &e : refs) {
+        const asgart_families &p = parts[e.r];
+        f->sds.insert(f->sds.end(), p.sds.begin() + (ptrdiff_t)p.fam_offsets[e.j], p.sds.begin() + (ptrdiff_t)p.fam_offsets[e.j + 1]);
+        f->fam_offsets.push_back(f->sds.size());
+        f->fam_keys.push_back(e.key);
     }
     if (progress && settings) {
         const uint64_t k = settings->probe_size, step = k / 2;
@@ -1036,6 +1090,10 @@ void asgart_families_copy(const asgart_families *f, uint64_t *fam_offsets, asgar
     if (!f) return;
     if (fam_offsets) memcpy(fam_offsets, f->fam_offsets.data(), f->fam_offsets.size() * 8);
     if (sds && !f->sds.empty()) memcpy(sds, f->sds.data(), f->sds.size() * sizeof(asgart_proto_sd));
+}
+
+void asgart_families_keys(const asgart_families *f, uint64_t *keys) {
+    if (f && keys && !f->fam_keys.empty()) memcpy(keys, f->fam_keys.data(), f->fam_keys.size() * 8);
 }
 
 void asgart_families_free(asgart_families *f) { delete f; }

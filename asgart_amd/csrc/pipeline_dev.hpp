@@ -1828,6 +1828,22 @@ __global__ __launch_bounds__(64) void seg_stats_kernel(RunParams rp, const uint3
 
 // tier list lengths from the sorted placement keys (tier-1 = key >> 29): n_t = first index whose
 // tier exceeds t, by bisection -- instead of one contended global atomic per segment
+// Cost-aware ownership of a sharded call (option shard_lpt): the r-th of R shards takes, of every tier's list
+// (sorted by decreasing work), the entries j = i * R + (i even ? r : R - 1 - r) -- the longest segments go to
+// different shards, and the snake order evens out what follows.  One thread per owned entry.
+__global__ __launch_bounds__(256) void take_owned_kernel(const uint32_t *__restrict__ order, uint32_t *__restrict__ own,
+                                                        const unsigned long long *__restrict__ tier_off,   // kTiers + 1 entries: offsets in order
+                                                        const unsigned long long *__restrict__ own_off,    // kTiers + 1 entries: offsets in own
+                                                        uint32_t R, uint32_t r) {
+    const unsigned long long t0 = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t0 >= own_off[kTiers]) return;
+    int t = 0;
+    while (t + 1 < kTiers && t0 >= own_off[t + 1]) ++t;
+    const unsigned long long i = t0 - own_off[t];
+    const unsigned long long j = i * R + ((i & 1ull) ? (unsigned long long)(R - 1u - r) : (unsigned long long)r);
+    own[t0] = order[tier_off[t] + j];
+}
+
 __global__ void tier_bounds_kernel(const uint32_t *__restrict__ sorted_keys,
                                    const unsigned long long *__restrict__ n_seg_ptr,
                                    unsigned long long *__restrict__ ctr) {

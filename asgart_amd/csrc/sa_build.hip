@@ -532,11 +532,15 @@ int32_t build_wide(const uint8_t *d_text, int64_t n_, uint64_t *d_sa, bool dna, 
 // Segment placement of the extension step: ascending radix sort of (tier, longest-first) keys.
 // keys/vals hold 2*n entries each (second half = alternate buffer).
 int32_t sort_segments(Workspace &w, uint32_t *keys, uint32_t *vals, uint64_t n, hipStream_t s,
-                      const uint32_t **sorted_vals, const uint32_t **sorted_keys) {
+                      const uint32_t **sorted_vals, const uint32_t **sorted_keys, bool ties_by_value) {
     rocprim::double_buffer<uint32_t> kd(keys, keys + n), vd(vals, vals + n);
     size_t bytes = 0;
     HIP_TRY(rocprim::radix_sort_pairs(nullptr, bytes, kd, vd, (size_t)n, 0, 32, s));
     RC_TRY(w.sort_tmp.reserve(bytes));
+    // (the segment list is appended to by many workgroups: its order differs from call to call.  When several
+    // shards must agree on the sorted order, equal keys are first put in order of their values -- the sort below
+    // is stable)
+    if (ties_by_value) HIP_TRY(rocprim::radix_sort_pairs(w.sort_tmp.p, bytes, vd, kd, (size_t)n, 0, 32, s));
     HIP_TRY(rocprim::radix_sort_pairs(w.sort_tmp.p, bytes, kd, vd, (size_t)n, 0, 32, s));
     *sorted_vals = vd.current();
     *sorted_keys = kd.current();

@@ -140,14 +140,14 @@ def main():
 
     def run_pass(st):
         if world > 1:
-            return idx.search_duplications_raw(pr.chunks, st, shard=rank, n_shards=world)
+            return idx.search_duplications_raw(pr.chunks, st, shard=rank, n_shards=world, with_keys=True)
         return idx.search_duplications_raw(pr.chunks, st)
 
     def one_step():
         out = []
         for st in settings:
             r_ = run_pass(st)
-            out.append(multi.gather_families(r_[0], r_[1], dist, device=comm_device) if world > 1 else r_)
+            out.append(multi.gather_families(r_[0], r_[1], dist, device=comm_device, keys=r_[2]) if world > 1 else r_)
         return out
 
     t0 = time.time()
@@ -176,7 +176,7 @@ def main():
         first, second = order
         prog = np.zeros(len(pr.chunks), dtype=np.uint64)
         fut = pool.submit(idx.search_duplications_raw, pr.chunks, settings[first], rank if world > 1 else 0,
-                          world if world > 1 else 1, prog)
+                          world if world > 1 else 1, prog, world > 1)
         while not fut.done() and not prog.any():
             time.sleep(0.0005)
         res = {second: run_pass(settings[second]), first: fut.result()}
@@ -193,7 +193,7 @@ def main():
             # ONE call for the passes of a step (asgart_search_duplications_passes): the library issues pass j+1 when
             # pass j's probes are searched, longest extension first -- no host threads, no polling here
             results = idx.search_duplications_passes(pr.chunks, settings, rank if world > 1 else 0,
-                                                     world if world > 1 else 1)
+                                                     world if world > 1 else 1, with_keys=world > 1)
             return results, [idx.stats((ci + 1) << 8) for ci in range(len(settings))]
         if mode == "back_to_back" or len(settings) == 1:
             results, stats = [], []
@@ -243,7 +243,7 @@ def main():
         results, per_call = issue(mode)
         if world > 1:
             # the only exchange of the path: duplicon lists -> rank 0 over RCCL
-            results = [multi.gather_families(r_[0], r_[1], dist, device=comm_device) for r_ in results]
+            results = [multi.gather_families(r_[0], r_[1], dist, device=comm_device, keys=r_[2]) for r_ in results]
         for s in per_call:
             search_ms += s.ms_search
             probe_count_ms += s.ms_probe_count

@@ -164,10 +164,15 @@ int32_t asgart_search_duplications(asgart_index *idx, const uint64_t *chunks, in
                                    const asgart_settings *settings, volatile uint64_t *progress,
                                    asgart_families **out);
 
-/* Same, restricted to shard `shard` of `n_shards` of the global probe
- * sequence (multi-GPU: one process per GPU, index replicated, no exchange
- * between shards).  Concatenating the results of shards 0..n_shards-1 in
- * shard order gives exactly the unsharded result. */
+/* Same, restricted to shard `shard` of `n_shards` (multi-GPU: one process per GPU, index replicated, no
+ * exchange between shards).  Shard r owns the automaton segments that START in the r-th of n_shards equal
+ * slices of the global probe sequence; it searches its slice plus a look-back and a look-ahead halo (retrying
+ * with larger halos when a decision is ambiguous).  The union of the shards' families, merged by
+ * asgart_families_keys -- or simply concatenated in shard order -- is exactly the unsharded result.
+ * Option shard_lpt = 1: every shard computes the whole front (probe search, scans, hit rows, placement: a
+ * tenth of a step) and then owns every n_shards-th segment of each extension tier's cost-sorted list, in snake
+ * order; the shards then interleave and must be merged by key.  Balanced, but not faster where one serial
+ * segment is the floor of a pass. */
 int32_t asgart_search_duplications_shard(asgart_index *idx, const uint64_t *chunks,
                                          int64_t n_chunks, const asgart_settings *settings,
                                          int32_t shard, int32_t n_shards,
@@ -214,6 +219,11 @@ int32_t asgart_search_duplications_passes_shard(asgart_index *idx, const uint64_
 void asgart_families_counts(const asgart_families *f, uint64_t *n_families, uint64_t *n_sds);
 /* fam_offsets: n_families+1 entries; sds: n_sds entries */
 void asgart_families_copy(const asgart_families *f, uint64_t *fam_offsets, asgart_proto_sd *sds);
+/* keys: n_families entries, (first probe of the family's automaton segment << 32) | family ordinal inside it.
+ * Ascending keys == the reference's order (chunk order, discovery order inside a chunk, src/bin/asgart.rs:241-253).
+ * The shards of a sharded call own interleaved segments: a gatherer merges their families by key
+ * (asgart_search_duplications_multi does; one-process-per-GPU hosts do it after the RCCL gather, asgart_amd/multi.py). */
+void asgart_families_keys(const asgart_families *f, uint64_t *keys);
 void asgart_families_free(asgart_families *f);
 
 /* ---- ComputeScore (`--compute-score`) --------------------------------------

@@ -295,11 +295,13 @@ def test_index_builds_its_own_suffix_array(case):
 
 
 @pytest.mark.parametrize("name", ["long_sds", "dense_repeats", "satellites", "masked"])
-@pytest.mark.parametrize("halo", ["default", "tiny"])
-def test_shards_concatenate_to_unsharded(hiplib, name, halo, monkeypatch):
-    """Multi-GPU logic on one GPU: shards 0..R-1 of the probe sequence, run one after the other,
-    must concatenate to exactly the unsharded result (segments are never split; no exchange).
-    `tiny` halos force the look-back / look-ahead retry paths."""
+@pytest.mark.parametrize("halo,lpt", [("default", "1"), ("default", "0"), ("tiny", "0")])
+def test_shards_concatenate_to_unsharded(hiplib, name, halo, lpt, monkeypatch):
+    """Multi-GPU logic on one GPU: shards 0..R-1, run one after the other, merged by their family keys, must
+    give exactly the unsharded result (segments are never split; no exchange).  shard_lpt = 0 (default): contiguous
+    slices of the probe sequence with halos -- `tiny` halos force the look-back / look-ahead retry paths; 1: every
+    shard computes the whole front and owns every R-th segment of each tier's cost-sorted list."""
+    monkeypatch.setenv("ASGART_SHARD_LPT", lpt)
     if halo == "tiny":
         monkeypatch.setenv("ASGART_SHARD_LOOKBACK", "2")
         monkeypatch.setenv("ASGART_SHARD_LOOKAHEAD", "3")
@@ -310,13 +312,10 @@ def test_shards_concatenate_to_unsharded(hiplib, name, halo, monkeypatch):
             st = asgart_amd.RunSettings.from_cli(reverse=reverse, complement=complement, **cli)
             offs, sds = idx.search_duplications_raw(pr.chunks, st)
             for R in (2, 3, 8, 61):
-                fam_counts, parts = [], []
-                for r in range(R):
-                    o, s_ = idx.search_duplications_raw(pr.chunks, st, shard=r, n_shards=R)
-                    fam_counts.append(np.diff(o.astype(np.int64)))
-                    parts.append(s_)
-                got_sds = np.concatenate(parts) if parts else np.zeros((0, 4), np.uint64)
-                got_offs = np.concatenate([[0], np.cumsum(np.concatenate(fam_counts))]).astype(np.uint64)
+                parts = [idx.search_duplications_raw(pr.chunks, st, shard=r, n_shards=R, with_keys=True) for r in range(R)]
+                got_offs, got_sds = asgart_amd.merge_shards(parts)
+                if lpt == "0":   # contiguous slices: plain concatenation in shard order is the result as well
+                    assert np.array_equal(np.concatenate([p[1] for p in parts]), sds)
                 assert np.array_equal(got_offs, offs), (name, R, reverse)
                 assert np.array_equal(got_sds, sds), (name, R, reverse)
 
@@ -441,8 +440,9 @@ def test_cfg2_yeast_sized_direct_and_rc_bit_exact(hiplib):
                                        threads=16)
             assert np.array_equal(offs, eoffs) and np.array_equal(sds, esds)
             assert len(sds) > 100
-            parts = [idx.search_duplications_raw(pr.chunks, st, shard=r, n_shards=4) for r in range(4)]
-            assert np.array_equal(np.concatenate([p[1] for p in parts]), sds)
+            parts = [idx.search_duplications_raw(pr.chunks, st, shard=r, n_shards=4, with_keys=True) for r in range(4)]
+            mo, ms = asgart_amd.merge_shards(parts)
+            assert np.array_equal(mo, offs) and np.array_equal(ms, sds)
 
 
 def test_chr1_sized_sample_parity(hiplib):
@@ -761,8 +761,9 @@ def test_cfg5_full_properties(hiplib):
             assert np.all(sds[:, 3] >= 1000)
             offs2, sds2 = idx.search_duplications_raw(pr.chunks, st)
             assert np.array_equal(offs, offs2) and np.array_equal(sds, sds2)
-            parts = [idx.search_duplications_raw(pr.chunks, st, shard=r, n_shards=3) for r in range(3)]
-            assert np.array_equal(np.concatenate([p[1] for p in parts]), sds), "shards != unsharded"
+            parts = [idx.search_duplications_raw(pr.chunks, st, shard=r, n_shards=3, with_keys=True) for r in range(3)]
+            mo, ms = asgart_amd.merge_shards(parts)
+            assert np.array_equal(mo, offs) and np.array_equal(ms, sds), "shards != unsharded"
             cross = int(np.sum((sds[:, 0] < n // 2) != (sds[:, 1] < n // 2)))
             assert cross > 10_000, cross
 

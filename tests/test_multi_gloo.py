@@ -1,7 +1,8 @@
-"""World-size-2 test of the multi-GPU host path on CPU (gloo): each rank produces the results of
-its contiguous share of the chunks with the oracle (a stand-in for asgart_search_duplications_shard,
-whose shards are also contiguous in chunk/probe order), gather_families must reassemble exactly
-the single-process result on rank 0."""
+"""World-size-2/3 tests of the multi-GPU host path on CPU (gloo): each rank produces the results of its share
+of the chunks with the oracle (a stand-in for asgart_search_duplications_shard) -- a contiguous share
+(concatenated in rank order) or every world-th chunk with family keys (merged by key, the way the shards of
+the HIP path own interleaved segments); gather_families must reassemble exactly the single-process result on
+rank 0."""
 import os
 import socket
 import sys
@@ -19,7 +20,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, keyed=False):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
 
@@ -34,9 +35,20 @@ def _worker(rank, world, port, q):
     idx = oracle.Index.build(pr.data)
     st = oracle.make_settings()
     n = len(pr.chunks)
-    mine = pr.chunks[rank * n // world:(rank + 1) * n // world]
-    offs, sds = idx.run_raw(mine, st)
-    got = multi.gather_families(offs, sds, dist)
+    if keyed:   # interleaved ownership: chunk c belongs to rank c % world; key = (chunk, family ordinal in it)
+        offs, sds, keys = [0], [], []
+        for c in range(rank, n, world):
+            o, s_ = idx.run_raw([pr.chunks[c]], st)
+            offs.extend((o[1:] + offs[-1]).tolist())
+            sds.append(s_)
+            keys.extend((c << 32) | j for j in range(len(o) - 1))
+        offs = np.array(offs, dtype=np.uint64)
+        sds = np.concatenate(sds) if sds else np.zeros((0, 4), np.uint64)
+        got = multi.gather_families(offs, sds, dist, keys=np.array(keys, dtype=np.uint64))
+    else:
+        mine = pr.chunks[rank * n // world:(rank + 1) * n // world]
+        offs, sds = idx.run_raw(mine, st)
+        got = multi.gather_families(offs, sds, dist)
     if rank == 0:
         full = idx.run_raw(pr.chunks, st)
         ok = np.array_equal(got[0], full[0]) and np.array_equal(got[1], full[1]) and len(full[1]) > 0
@@ -47,12 +59,13 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("keyed", [False, True])
 @pytest.mark.parametrize("world", [2, 3])
-def test_gather_families_world(world):
+def test_gather_families_world(world, keyed):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, keyed)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -80,8 +93,8 @@ def _gpu_worker(rank, world, port, q):
     with asgart_amd.Index(pr.data, None, device=0) as idx:
         for rc in (False, True):
             st = asgart_amd.RunSettings.from_cli(reverse=rc, complement=rc)
-            offs, sds = idx.search_duplications_raw(pr.chunks, st, shard=rank, n_shards=world)
-            got = multi.gather_families(offs, sds, dist)
+            offs, sds, keys = idx.search_duplications_raw(pr.chunks, st, shard=rank, n_shards=world, with_keys=True)
+            got = multi.gather_families(offs, sds, dist, keys=keys)
             if rank == 0:
                 full = idx.search_duplications_raw(pr.chunks, st)
                 oidx = oracle.Index.build(pr.data, idx.sa_read(0, len(pr.data)))
