@@ -63,6 +63,7 @@ const OptDesc kOptions[] = {
     {"fast_nt", &Options::fast_nt, 256, 1024},
     {"cap3_pct", &Options::cap3_pct, 100, 400},
     {"shard_lpt", &Options::shard_lpt, 0, 1},
+    {"posbits", &Options::posbits, 0, 1},
     {"fast_bsh", &Options::fast_bsh, 0, 3},
     {"fast_e", &Options::fast_e, 2, 4},
     {"fast_pipe", &Options::fast_pipe, 0, 1},
@@ -362,6 +363,43 @@ __global__ __launch_bounds__(256) void build_filter_kernel(IndexView<SlotT> ix, 
     }
 }
 
+// The filter's answers by text position: bit p = "the probe that covers text[p .. p + k) in this orientation
+// passes the filter" (or is one of the text-tail corner probes, which never take the filter).  One thread per
+// 64 positions: both rolling keys (forward, and reversed for -R), one filter word per position.
+template <class SlotT>
+__global__ __launch_bounds__(256) void build_posbits_kernel(IndexView<SlotT> ix, bool reverse, bool complement,
+                                                            const uint64_t *__restrict__ flt, int bits,
+                                                            unsigned long long *__restrict__ out, uint64_t n_words) {
+    const int k = ix.k;
+    const uint64_t mask = k >= 21 ? ~0ull >> 1 : (1ull << (3 * k)) - 1ull;
+    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t p0 = w * 64ull;
+        auto code_at = [&](uint64_t p) -> uint64_t {
+            uint32_t c = p < ix.n ? base_code(ix.text[p]) : 0u;
+            if (complement && c) c = comp_code(c);
+            return (uint64_t)c;
+        };
+        uint64_t fk = 0, rk = 0;  // keys of the window that ENDS just before the next base
+        for (int j = 0; j < k - 1; ++j) {
+            const uint64_t c = code_at(p0 + (uint64_t)j);
+            fk = (fk << 3) | c;
+            rk = (rk >> 3) | (c << (3 * (k - 1)));
+        }
+        unsigned long long word = 0;
+        for (int b = 0; b < 64; ++b) {
+            const uint64_t p = p0 + (uint64_t)b;
+            const uint64_t c = code_at(p + (uint64_t)(k - 1));
+            fk = ((fk << 3) | c) & mask;
+            rk = (rk >> 3) | (c << (3 * (k - 1)));
+            const uint64_t q = reverse ? rk : fk;
+            bool pass = true;
+            if (p + (uint64_t)k <= ix.n && !is_tail_corner(ix, q)) pass = filter_test(flt, bits, q);
+            word |= (unsigned long long)(pass ? 1u : 0u) << b;
+        }
+        out[w] = word;
+    }
+}
+
 template <class SlotT>
 __global__ __launch_bounds__(256) void cache_get_kernel(IndexView<SlotT> ix,
                                                         const uint8_t *__restrict__ pats,
@@ -470,6 +508,11 @@ static void free_k_specific(asgart_index *idx) {
         if (f) (void)hipFree(f);
         f = nullptr;
     }
+    for (auto &f : idx->d_pbits) {
+        if (f) (void)hipFree(f);
+        f = nullptr;
+    }
+    for (auto &f : idx->filter_off) f = false;
     idx->d_keys = nullptr;
     idx->d_ptab = idx->d_c8lo = idx->d_c8hi = nullptr;
     idx->filter_bits = 0;
@@ -634,14 +677,14 @@ int32_t index_prepare_filter(asgart_index *idx, uint64_t k, int mode) {
     if (idx->opt.kfilter_bits == 0 || idx->trimmed || mode < 0 || mode > 3 || k > (uint64_t)kMaxKey) return 0;
     {
         std::lock_guard<std::mutex> lk(idx->mu);
-        if (idx->k == k && idx->d_filter[mode]) return 0;
+        if (idx->k == k && (idx->d_filter[mode] || idx->filter_off[mode])) return 0;
     }
     idx->acquire_all();
     struct Unlock {
         asgart_index *i;
         ~Unlock() { i->release_all(); }
     } unlock{idx};
-    if (idx->k != k || idx->d_filter[mode]) return 0;
+    if (idx->k != k || idx->d_filter[mode] || idx->filter_off[mode]) return 0;
     HIP_TRY(hipSetDevice(idx->device));
     if (!idx->filter_bits) {
         // about 8 bits per text position, at most the configured size (the default, 2^30 bits =
@@ -656,11 +699,17 @@ int32_t index_prepare_filter(asgart_index *idx, uint64_t k, int mode) {
     const int bits = idx->filter_bits;
     const size_t bytes = (size_t)1 << (bits - 3);
     uint64_t *flt = nullptr;
-    HIP_TRY(hipMalloc((void **)&flt, bytes));
+    if (hipMalloc((void **)&flt, bytes) != hipSuccess) {
+        // the filter is an optimisation: without memory for it this orientation is searched without (every probe
+        // takes the lookup); the call that needed it goes on
+        (void)hipGetLastError();
+        idx->filter_off[mode] = true;
+        return 0;
+    }
     hipStream_t s = idx->ctx[0].stream;
+    const bool rev = (mode & 2) != 0, comp = (mode & 1) != 0;
     int32_t rc = [&]() -> int32_t {
         HIP_TRY(hipMemsetAsync(flt, 0, bytes, s));
-        const bool rev = (mode & 2) != 0, comp = (mode & 1) != 0;
         const unsigned g = grid_capped((uint64_t)idx->n);
         if (idx->wide)
             build_filter_kernel<uint64_t><<<g, 256, 0, s>>>(idx->view<uint64_t>(), rev, comp,
@@ -675,6 +724,34 @@ int32_t index_prepare_filter(asgart_index *idx, uint64_t k, int mode) {
     if (rc != 0) {
         (void)hipFree(flt);
         return rc;
+    }
+    if (idx->opt.posbits) {
+        // the same answers by text position (n bits, padded so that a workgroup's 16-byte loads never leave it)
+        const uint64_t n_words = ((uint64_t)idx->n + 63u) / 64u;
+        uint64_t *pb = nullptr;
+        if (hipMalloc((void **)&pb, (size_t)n_words * 8 + 512) == hipSuccess) {
+            rc = [&]() -> int32_t {
+                HIP_TRY(hipMemsetAsync(pb, 0xFF, (size_t)n_words * 8 + 512, s));
+                const unsigned g = grid_capped(n_words);
+                if (idx->wide)
+                    build_posbits_kernel<uint64_t><<<g, 256, 0, s>>>(idx->view<uint64_t>(), rev, comp, flt, bits,
+                                                                     (unsigned long long *)pb, n_words);
+                else
+                    build_posbits_kernel<uint32_t><<<g, 256, 0, s>>>(idx->view<uint32_t>(), rev, comp, flt, bits,
+                                                                     (unsigned long long *)pb, n_words);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipStreamSynchronize(s));
+                return 0;
+            }();
+            if (rc != 0) {
+                (void)hipFree(pb);
+                (void)hipFree(flt);
+                return rc;
+            }
+            idx->d_pbits[mode] = pb;
+        } else {
+            (void)hipGetLastError();  // no memory: the hashed filter serves
+        }
     }
     idx->d_filter[mode] = flt;
     return 0;

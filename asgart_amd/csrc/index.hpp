@@ -40,6 +40,10 @@ struct IndexView {
     // presence filter of the orientation of this call (search_dev.hpp); null: no filter
     const uint64_t *flt;
     int flt_bits;
+    // ... the same answers laid out by TEXT POSITION (bit p: the probe that covers text[p .. p + k) in this
+    // orientation passes the filter): the 256 probes of a workgroup read 320 contiguous bytes instead of 256
+    // random words.  null: the kernels test the hashed filter.
+    const uint64_t *pbits;
     // occurrences of every k-mer interval sorted by position (sa_build.hip: build_rank_lists); null: none
     const SlotT *sap;
     // number of suffix-array slots: n, or end - start + 1 for a --trim index (reference
@@ -205,6 +209,7 @@ struct Options {
     int64_t fast_pipe = 1;          // experiments: 1 = one barrier per hit-probe (B of probe t-1 runs beside A of probe t)
     int64_t fast_e = 2;             // experiments: entries per table row (2 / 4)
     int64_t cap3_pct = 160;         // tier 3 with the one-barrier kernel accepts segments whose arm bound is up to this percentage of its capacity
+    int64_t posbits = 1;            // 1: the presence filter's answers are also laid out by text position (index build) and the search reads those
     int64_t shard_lpt = 0;          // sharded calls: 0 = contiguous probe slices with halos; 1 = every shard computes the whole front and
                                     // owns every n_shards-th segment of each tier's cost-sorted list (snake order) -- measured at
                                     // cfg4, 8 shards: balanced (91-117 ms direct) but the replicated front makes its slowest shard
@@ -237,6 +242,8 @@ struct asgart_index {
     void *d_c8hi = nullptr;
     void *d_sap = nullptr;   // position-sorted occurrence lists (IndexView::sap), or null
     uint64_t *d_filter[4] = {nullptr, nullptr, nullptr, nullptr};  // per orientation: reverse * 2 + complement
+    uint64_t *d_pbits[4] = {nullptr, nullptr, nullptr, nullptr};   // ... its answers by text position (n bits + padding)
+    bool filter_off[4] = {false, false, false, false};             // no memory for it: this orientation is searched without
     int filter_bits = 0;                                           // log2 of their size in bits
     uint32_t tail8[asgart::kMaxK];
     int n_tail8 = 0;
@@ -308,6 +315,7 @@ struct asgart_index {
         v.tail_bloom = tail_bloom;
         v.flt = nullptr;
         v.flt_bits = 0;
+        v.pbits = nullptr;
         v.sap = reinterpret_cast<const SlotT *>(d_sap);
         v.n_sa = (uint64_t)n_sa;
         v.trim = trimmed ? 1 : 0;

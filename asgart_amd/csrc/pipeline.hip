@@ -239,6 +239,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
     IndexView<SlotT> ix = idx->view<SlotT>();
     ix.flt = idx->d_filter[(st->reverse ? 2 : 0) | (st->complement ? 1 : 0)];  // null: filter off
     ix.flt_bits = idx->filter_bits;
+    ix.pbits = opt.posbits ? idx->d_pbits[(st->reverse ? 2 : 0) | (st->complement ? 1 : 0)] : nullptr;
     SlotT *p_lo = w.p_lo.as<SlotT>() - w_lo;
     uint32_t *p_raw = w.p_raw.as<uint32_t>() - w_lo;
     uint32_t *p_filt = w.p_filt.as<uint32_t>() - w_lo;
@@ -861,7 +862,7 @@ int32_t run_search(asgart_index *idx, const uint64_t *chunks, int64_t n_chunks,
         (void)probe;
         const int mode = (st->reverse ? 2 : 0) | (st->complement ? 1 : 0);
         if (idx->k == st->probe_size && (idx->opt.kfilter_bits == 0 || idx->trimmed || idx->d_filter[mode] ||
-                                         st->probe_size > (uint64_t)kMaxKey))
+                                         idx->filter_off[mode] || st->probe_size > (uint64_t)kMaxKey))
             break;
         idx->release_one(which);
         RC_TRY(index_prepare_filter(idx, st->probe_size, mode));
@@ -1150,6 +1151,7 @@ int32_t asgart_get_stats(asgart_index *idx, uint32_t flags, asgart_stats *out) {
                 IndexView<SlotT> ix = idx->view<SlotT>();
                 ix.flt = idx->d_filter[mode];
                 ix.flt_bits = idx->filter_bits;
+                ix.pbits = idx->opt.posbits ? idx->d_pbits[mode] : nullptr;
                 probe_count_kernel<SlotT, true><<<gp, kProbeBlock, 0, s>>>(
                     ix, rp, nullptr, nullptr, nullptr, nullptr, nullptr, d_ctr);
                 big_count_kernel<SlotT, true><<<2048, 256, 0, s>>>(

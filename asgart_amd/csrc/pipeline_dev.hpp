@@ -138,6 +138,9 @@ __global__ __launch_bounds__(kProbeBlock) void probe_count_kernel(IndexView<Slot
                                                                   unsigned long long *__restrict__ ctr) {
     __shared__ __attribute__((aligned(16))) uint8_t s_text[kWinBytes];
     __shared__ uint32_t s_half[kProbeBlock + 2];
+    // the filter's answers for the workgroup's probes: 256 probes at stride k/2 = one contiguous run of bits
+    constexpr int kPbLoads = (kProbeBlock * kMaxHalf + 127) / 128 + 2;  // 16-byte loads that cover it
+    __shared__ __attribute__((aligned(16))) uint32_t s_pb[kPbLoads * 4];
     typename std::conditional<COUNT, CountBytes, NoBytes>::type cb;
     const uint32_t tid = threadIdx.x;
     const uint32_t gb = rp.g_lo + blockIdx.x * (uint32_t)kProbeBlock;  // first probe of the workgroup
@@ -151,6 +154,7 @@ __global__ __launch_bounds__(kProbeBlock) void probe_count_kernel(IndexView<Slot
     uint64_t s = 0, L = 0, i = 0, q = 0, q2 = 0;
     uint32_t first = 0;
     const bool valid = g < rp.g_hi;
+    long long pb_lo = 0;  // first bit held by s_pb
     if (uniform) {
         s = rp.ch.start[c0];
         L = rp.ch.len[c0];
@@ -171,6 +175,24 @@ __global__ __launch_bounds__(kProbeBlock) void probe_count_kernel(IndexView<Slot
                 cb.rd(16);
             }
             *reinterpret_cast<uint4 *>(s_text + 16u * tid) = v;
+        }
+        if (ix.pbits) {
+            // text positions the probes cover: direct  s + i0 + t H ;  reversed  s + L - i0 - k - t H
+            const long long p_first = rp.reverse ? (long long)(s + L - i0) - k - (long long)(kProbeBlock - 1) * H
+                                                 : (long long)(s + i0);
+            const long long byte_lo = (p_first >> 7) * 16;  // (floor: also for the negatives of the idle lanes)
+            pb_lo = byte_lo * 8;
+            const long long p_last = p_first + (long long)(kProbeBlock - 1) * H;
+            const uint32_t n_pb = (uint32_t)((p_last >> 7) - (p_first >> 7) + 1);  // <= kPbLoads
+            if (tid < n_pb) {
+                const long long a = byte_lo + 16ll * tid;
+                uint4 v = make_uint4(~0u, ~0u, ~0u, ~0u);
+                if (a >= 0 && (uint64_t)a + 16u <= ((ix.n + 63u) / 64u) * 8u + 512u) {  // (the allocation is padded)
+                    v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(ix.pbits) + a);
+                    cb.rd(16);
+                }
+                *reinterpret_cast<uint4 *>(&s_pb[4u * tid]) = v;
+            }
         }
         __syncthreads();
         for (uint32_t h = tid; h < (uint32_t)n_half; h += kProbeBlock) {
@@ -219,7 +241,16 @@ __global__ __launch_bounds__(kProbeBlock) void probe_count_kernel(IndexView<Slot
             cb.wr(4);
         } else {
             survivor = true;
-            if (ix.flt && !is_tail_corner(ix, q)) {
+            if (ix.pbits) {  // the filter's answer, by the text position the probe covers
+                const long long p = rp.reverse ? (long long)(s + L - i) - k : (long long)(s + i);
+                if (uniform) {
+                    const uint32_t b = (uint32_t)(p - pb_lo);
+                    survivor = (s_pb[b >> 5] >> (b & 31u)) & 1u;
+                } else {
+                    cb.rd(8);
+                    survivor = (ix.pbits[(uint64_t)p >> 6] >> ((uint64_t)p & 63u)) & 1ull;
+                }
+            } else if (ix.flt && !is_tail_corner(ix, q)) {
                 cb.rd(8);
                 survivor = filter_test(ix.flt, ix.flt_bits, q);
             }
