@@ -78,8 +78,6 @@ constexpr uint32_t kTier1MaxSum = 20000;  // placement: busier segments never ru
 constexpr int kArmCapMid = 768;     // second tier: block-cooperative kernel, 256 threads per segment
 constexpr int kArmCapHybrid32 = 4608;   // tier 4: hot fields in LDS, (rs, le) in HBM scratch
 constexpr int kArmCapHybrid64 = 3072;
-constexpr int kArmCapGlobal32 = 16384;  // tier 5: all arm fields in HBM scratch
-constexpr int kArmCapGlobal64 = 8192;
 constexpr int kArmCapBig32 = 2432;  // heavy tier, 32-bit positions: 3072*40 B + hits + scratch = 128 KiB
 constexpr int kArmCapBig64 = 1664;  // heavy tier, 64-bit positions: 2048*60 B + hits + scratch = 132 KiB
 
@@ -334,7 +332,6 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
         // tiers 2, 4 and 6 (768 / 2432 / 4608 * 1.4 arms) and tiers 3 and 5 stay empty; the small
         // shapes 2 and 4 stage 512 hits per probe and are skipped when max_cardinality > 512.
         constexpr int caph = sizeof(SlotT) == 4 ? kArmCapHybrid32 : kArmCapHybrid64;
-        constexpr int capg = sizeof(SlotT) == 4 ? kArmCapGlobal32 : kArmCapGlobal64;
         const bool arms_kernel = rp.C <= (uint64_t)kHitBatch && opt.arms_kernel != 0;
         const bool arms_small = arms_kernel && rp.C <= (uint64_t)kWaveArmsHits;
         // the two-barrier kernel packs a 64-bit position into 42 bits of a table entry
@@ -342,7 +339,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             if (t == 6 && sizeof(SlotT) == 8) return false;  // (2 x 1024 slots would be fewer than K4c's 8 x 512)
             return arms_kernel && ((opt.fast >> t) & 1) != 0 && (uint64_t)idx->n < (1ull << 42);
         };
-        uint32_t tier_cap[kTiers + 1] = {0, kArmCapSmall, 0, 0, 0, 0, 0, (uint32_t)capg};
+        uint32_t tier_cap[kTiers + 1] = {0, kArmCapSmall, 0, 0, 0, 0, 0, 0xFFFFFFFFu};  // (tier 7 takes whatever is left)
         if (arms_kernel) {
             if (arms_small) {
                 tier_cap[2] = (uint32_t)kWaveArmsLayers<SlotT> * 64u;
@@ -465,9 +462,25 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
         for (int t = 0; t < kTiers; ++t) ovf[t] = w.ovf_list.as<uint32_t>() + (size_t)t * (n_seg + 1);
         // HBM arm storage of the LDS-array kernels: tier 6 (MODE 1) and tier 7 (MODE 2) may run at the
         // same time on different streams, so each gets its own region of 256 per-workgroup slices
-        const size_t per_wg = (size_t)capg * (4 * sizeof(SlotT) + 16);
-        RC_TRY(w.scratch.reserve(per_wg * 256 * 4));  // tier 6, tier 7, and one region per early cascade launch
-        char *const scratch6 = w.scratch.as<char>(), *const scratch7 = scratch6 + per_wg * 256;
+        // Tier 7 never refuses a segment for its size: max_cardinality * (t* + 1) bounds the live arms of ANY segment
+        // (every live arm was created or extended within the last t* + 1 processed probes, at most max_cardinality
+        // per probe; src/automaton.rs:87 keeps them in an unbounded Vec), and its slices are sized for that.  Large
+        // bounds get fewer workgroups (a 16 GB budget for the four regions), never fewer than one.
+        const uint64_t heavy_cap64 = std::max<uint64_t>((uint64_t)rp.C * ((uint64_t)rp.tstar + 1u) + 64u, 4096u);
+        if (heavy_cap64 >= (1ull << 24)) {
+            set_error("max_cardinality * (max_gap_size / step + 1) = %llu live arms per segment: more than 2^24 are not supported",
+                      (unsigned long long)heavy_cap64);
+            return ASGART_E_CAP;
+        }
+        const size_t per_wg7 = (size_t)heavy_cap64 * (4 * sizeof(SlotT) + 28);
+        const size_t per_wg6 = (size_t)std::max(caph, (int)(kArmsLayers<SlotT> * kHeavyThreads)) * (4 * sizeof(SlotT) + 16);
+        const size_t per_wg = std::max(per_wg6, per_wg7);
+        const unsigned n_wg7 = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(256, (16ull << 30) / (4 * per_wg)));
+        const unsigned n_wg_region = per_wg6 * 256 > per_wg * n_wg7 ? 256u : n_wg7;  // (a region serves either kind of launch)
+        const size_t region = std::max(per_wg6 * 256, per_wg * (size_t)n_wg7);
+        (void)n_wg_region;
+        RC_TRY(w.scratch.reserve(region * 4));  // tier 6, tier 7, and one region per early cascade launch
+        char *const scratch6 = w.scratch.as<char>(), *const scratch7 = scratch6 + region;
         for (int attempt = 0;; ++attempt) {
             RC_TRY(w.fam_sds.reserve((size_t)rec_cap * sizeof(SdRec)));
             HIP_TRY(hipMemsetAsync(d_ctr + CT_SD, 0, 8, s));
@@ -490,6 +503,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             ep.hi_prio = (uint32_t)opt.prio3;
             ep.max_items = 0;
             ep.fast_bsh = (uint32_t)opt.fast_bsh;
+            ep.heavy_cap = (uint32_t)heavy_cap64;
             ep.n_levels = (uint32_t)opt.test_levels;
             ep.gen_bits = (uint32_t)opt.test_genbits;
             ep.ctr = d_ctr;
@@ -585,7 +599,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                     break;
                 default:
                     ep.scratch = scratch_override ? scratch_override : scratch7;
-                    extend_heavy_kernel<SlotT, capg, kHeavyThreads, 2><<<grid(256), kHeavyThreads, 0, st>>>(ep);
+                    extend_heavy_kernel<SlotT, 1, kHeavyThreads, 2><<<grid(n_wg7), kHeavyThreads, 0, st>>>(ep);
                     ep.scratch = scratch6;
                     break;
                 }
@@ -685,7 +699,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                         ep.escalate_cost = 0xFFFFFFFFu;
                         ep.cap_limit = 0xFFFFFFFFu;
                         cascade_launch = true;
-                        scratch_override = scratch6 + per_wg * 256 * (size_t)(2 + e);
+                        scratch_override = scratch6 + region * (size_t)(2 + e);
                         launch_kernel(E.dst, n_e, E.st);
                         scratch_override = nullptr;
                         cascade_launch = false;
@@ -744,9 +758,9 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             ms_tier2 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() -
                                                                  t_casc0).count();
             if (h_ctr[CT_OVF1 + kTiers - 1]) {
-                set_error("%llu segment(s) need more than %d simultaneously live arms; "
-                          "not supported by this build", (unsigned long long)h_ctr[CT_OVF1 + kTiers - 1],
-                          sizeof(SlotT) == 4 ? kArmCapGlobal32 : kArmCapGlobal64);
+                // (cannot happen: tier 7 holds the bound on the live arms of any segment -- unless a test shrank it)
+                set_error("internal: %llu segment(s) overflowed the last extension tier (%llu arm slots)",
+                          (unsigned long long)h_ctr[CT_OVF1 + kTiers - 1], (unsigned long long)heavy_cap64);
                 return ASGART_E_CAP;
             }
             if (h_ctr[CT_RANOUT]) break;

@@ -975,6 +975,7 @@ struct ExtParams {
     uint32_t hi_prio;                     // 1: the long-segment shape raises its waves' issue priority
     uint32_t max_items;                   // work-list fetches per workgroup before it retires (0: until the list is empty)
     uint32_t fast_bsh;                    // K6: log2 of the bucket width beyond the smallest power of two >= G + k
+    uint32_t heavy_cap;                   // K4b MODE 2 (tier 7): arm slots per workgroup in its HBM slice
     unsigned long long *ctr;
 };
 
@@ -1941,6 +1942,15 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
     constexpr bool PACKED_WIDE = MODE == 0;
     constexpr int HCAP = MODE != 2 ? CAP : 1;  // hot fields in LDS
     constexpr int CCAP = MODE == 0 ? CAP : 1;  // cold field (rs) in LDS
+    // MODE 2: the capacity is a launch parameter (P.heavy_cap: max_cardinality * (ceil(G / step) + 1) bounds the
+    // live arms of ANY segment -- every live arm was created or extended within the last t* + 1 processed probes,
+    // at most max_cardinality of them per probe), slots are 32-bit and the per-arm index lists live in the HBM slice
+    // as well; CAP is ignored.
+    const uint32_t cap_rt = MODE == 2 ? P.heavy_cap : (uint32_t)CAP;
+    constexpr uint32_t kSlotBits = MODE == 2 ? 24u : 20u;  // (creation number << kSlotBits) | slot
+    constexpr uint32_t kSlotMask = (1u << kSlotBits) - 1u;
+    using IdxT = typename std::conditional<MODE == 2, uint32_t, uint16_t>::type;
+    constexpr uint32_t kEndIdx = MODE == 2 ? 0xFFFFFFFFu : 0xFFFFu;
     __shared__ PosT l_ls[HCAP], l_re[HCAP], l_le[HCAP], l_rs[CCAP];
     // gap and pend are 16-bit in the hybrid tier (gap saturates; the host only uses that tier when
     // G and max_cardinality fit): 24 B of LDS per arm instead of 32
@@ -1951,30 +1961,40 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
     PosT *s_ls = l_ls, *s_le = l_le, *s_rs = l_rs, *s_re = l_re;
     uint32_t *s_thr = l_thr, *s_seq = l_seq;
     SmallT *s_gap = l_gap, *s_pend = l_pend;
+    IdxT *g_next = nullptr, *g_free = nullptr, *g_widx = nullptr;
     if constexpr (MODE != 0) {
-        const size_t bytes = (size_t)CAP * (4 * sizeof(PosT) + 4 * sizeof(uint32_t));
+        const size_t bytes = (size_t)cap_rt * (4 * sizeof(PosT) + (MODE == 2 ? 7 : 4) * sizeof(uint32_t));
         char *b = P.scratch + (size_t)blockIdx.x * bytes;
         PosT *g0p = reinterpret_cast<PosT *>(b);
-        s_rs = g0p + 2 * CAP;
+        s_rs = g0p + 2 * (size_t)cap_rt;
         if constexpr (MODE == 2) {
             s_ls = g0p;
-            s_le = g0p + CAP;
-            s_re = g0p + 3 * CAP;
-            s_gap = reinterpret_cast<SmallT *>(g0p + 4 * CAP);
-            s_thr = reinterpret_cast<uint32_t *>(s_gap + CAP);
-            s_seq = s_thr + CAP;
-            s_pend = reinterpret_cast<SmallT *>(s_seq + CAP);
+            s_le = g0p + cap_rt;
+            s_re = g0p + 3 * (size_t)cap_rt;
+            s_gap = reinterpret_cast<SmallT *>(g0p + 4 * (size_t)cap_rt);
+            s_thr = reinterpret_cast<uint32_t *>(s_gap + cap_rt);
+            s_seq = s_thr + cap_rt;
+            s_pend = reinterpret_cast<SmallT *>(s_seq + cap_rt);
+            g_next = reinterpret_cast<IdxT *>(s_pend + cap_rt);
+            g_free = g_next + cap_rt;
+            g_widx = g_free + cap_rt;
         }
     }
-    constexpr uint32_t HT = CAP <= 1024 ? 1024u : (MODE == 1 ? 2048u : (CAP <= 4608 ? 4096u : 8192u));
+    constexpr uint32_t HT = MODE == 2 ? 8192u : (CAP <= 1024 ? 1024u : (MODE == 1 ? 2048u : (CAP <= 4608 ? 4096u : 8192u)));
     constexpr uint32_t WCAP = PACKED_WIDE ? (uint32_t)CAP : 1u;
     __shared__ uint32_t s_head[HT];
-    __shared__ uint16_t s_next[CAP];
-    __shared__ uint16_t s_free[CAP];  // stack of empty slots below the high-water mark
+    __shared__ uint16_t l_next[MODE == 2 ? 1 : CAP];
+    __shared__ uint16_t l_free[MODE == 2 ? 1 : CAP];  // stack of empty slots below the high-water mark
     __shared__ PosT s_ivlo[WCAP];     // wide arm w accepts x iff (x - s_ivlo[w]) < s_ivw[w]
     __shared__ uint32_t s_ivw[WCAP];
     __shared__ unsigned long long s_wkey[WCAP];  // (creation number << 20) | slot of wide arm w
-    __shared__ uint16_t s_widx[PACKED_WIDE ? 1 : CAP];  // index form of the wide list
+    __shared__ uint16_t l_widx[(PACKED_WIDE || MODE == 2) ? 1 : CAP];  // index form of the wide list
+    IdxT *s_next, *s_free, *s_widx;
+    if constexpr (MODE == 2) {
+        s_next = g_next; s_free = g_free; s_widx = g_widx;
+    } else {
+        s_next = l_next; s_free = l_free; s_widx = l_widx;
+    }
     __shared__ PosT s_hits[kHitBatch];
     __shared__ uint8_t s_hflag[kHitBatch];
     __shared__ unsigned long long s_best[NT];  // per hit: (creation number << 20) | slot, or ~0
@@ -1989,7 +2009,7 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
     const uint32_t thr0 = arm_threshold(k, G);
     uint32_t bsh = 3;  // bucket(re) = re >> bsh with 2^bsh >= G + k: a hit meets <= 2 buckets
     while ((1ull << bsh) < (unsigned long long)G + k) ++bsh;
-    const uint32_t cap_eff = min((uint32_t)CAP, P.cap_limit);
+    const uint32_t cap_eff = min(cap_rt, P.cap_limit);
     RecAlloc rec_alloc;
     PROF_DECL;
 
@@ -2061,7 +2081,7 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
                             dead = true;
                             ls = s_ls[j]; le = s_le[j]; rs = s_rs[j]; re = s_re[j];
                             s_seq[j] = kNoSeq;
-                            s_free[n_free + atomicAdd(&s_nfreed, 1u)] = (uint16_t)j;
+                            s_free[n_free + atomicAdd(&s_nfreed, 1u)] = (IdxT)j;
                         }
                     }
                 }
@@ -2215,7 +2235,7 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
                     const bool live = sq != kNoSeq;
                     if (live && th <= G) {
                         const uint32_t bkt = (uint32_t)((uint64_t)re >> bsh);
-                        s_next[j] = (uint16_t)atomicExch(&s_head[((bkt * 2654435761u) >> 12) & hmask], j);
+                        s_next[j] = (IdxT)atomicExch(&s_head[((bkt * 2654435761u) >> 12) & hmask], j);
                     }
                     // wide arms: one LDS atomic per wave, not per arm
                     const bool wide = live && th > G;
@@ -2231,9 +2251,9 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
                                 const uint64_t wv = (uint64_t)th + k - 1u;
                                 s_ivlo[d] = (PosT)(re - k + 1u);
                                 s_ivw[d] = wv > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)wv;
-                                s_wkey[d] = ((unsigned long long)sq << 20) | j;
+                                s_wkey[d] = ((unsigned long long)sq << kSlotBits) | j;
                             } else {
-                                s_widx[d] = (uint16_t)j;
+                                s_widx[d] = (IdxT)j;
                             }
                         }
                     }
@@ -2256,9 +2276,9 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
                         unsigned long long best = ~0ull;
                         for (uint32_t bkt = b0; bkt <= b1; ++bkt) {
                             uint32_t j = s_head[((bkt * 2654435761u) >> 12) & hmask];
-                            while (j != 0xFFFFFFFFu && j != 0xFFFFu) {
+                            while (j != 0xFFFFFFFFu && j != kEndIdx) {
                                 if (arm_accepts<PosT>(hx, s_re[j], s_thr[j], k))
-                                    best = min(best, ((unsigned long long)s_seq[j] << 20) | j);
+                                    best = min(best, ((unsigned long long)s_seq[j] << kSlotBits) | j);
                                 j = s_next[j];
                             }
                         }
@@ -2313,13 +2333,13 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
                                     }
 #pragma unroll
                                     for (int u = 0; u < 8; ++u) {
-                                        const unsigned long long key = ((unsigned long long)sq8[u] << 20) | sl8[u];
+                                        const unsigned long long key = ((unsigned long long)sq8[u] << kSlotBits) | sl8[u];
                                         found = min(found, arm_accepts<PosT>(x, re8[u], th8[u], k) ? key : ~0ull);
                                     }
                                 }
                                 for (; j < j1; ++j) {
                                     const uint32_t slot = s_widx[j];
-                                    const unsigned long long key = ((unsigned long long)s_seq[slot] << 20) | slot;
+                                    const unsigned long long key = ((unsigned long long)s_seq[slot] << kSlotBits) | slot;
                                     found = min(found, arm_accepts<PosT>(x, s_re[slot], s_thr[slot], k) ? key : ~0ull);
                                 }
                             }
@@ -2334,7 +2354,7 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
                     unsigned long long best = ~0ull;
                     if (mine) {
                         best = s_best[tid];
-                        if (best != ~0ull) pend_max(s_pend, (uint32_t)(best & 0xFFFFFu), t0 + tid + 1u);
+                        if (best != ~0ull) pend_max(s_pend, (uint32_t)(best & kSlotMask), t0 + tid + 1u);
                     }
                     // unmatched hits: flagged ones become arms, the others are dropped (K3b)
                     bool fl = false;

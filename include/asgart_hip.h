@@ -38,12 +38,11 @@ typedef struct asgart_settings {
     uint64_t probe_size;              /* -k ; 8 <= k <= 42 in this build          */
     uint32_t max_gap_size;            /* -g + -k                                 */
     uint64_t min_duplication_length;  /* --min-length                            */
-    uint64_t max_cardinality;         /* --max-cardinality.  The reference's Vec<Arm> is unbounded; here one
-                                         automaton segment may hold at most 16384 simultaneously live arms
-                                         (8192 on a text of 2^32 bytes or more), else the call fails with
-                                         ASGART_E_CAP.  Live arms never exceed max_cardinality *
-                                         (ceil(max_gap_size / (probe_size/2)) + 1), 6500 at the defaults, so the
-                                         limit can only be met with much larger cardinalities or gaps.        */
+    uint64_t max_cardinality;         /* --max-cardinality.  The reference keeps the arms of a chunk in an unbounded
+                                         Vec (src/automaton.rs:87).  Here the live arms of one automaton segment never
+                                         exceed max_cardinality * (ceil(max_gap_size / (probe_size/2)) + 1) -- 6500 at
+                                         the defaults -- and the last extension tier sizes its HBM slices for exactly
+                                         that bound, whatever the settings (ASGART_E_CAP only if it reaches 2^24).   */
     uint8_t reverse;                  /* -R                                      */
     uint8_t complement;               /* -C                                      */
 } asgart_settings;

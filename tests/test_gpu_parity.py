@@ -920,6 +920,36 @@ def test_tier6_with_thousands_of_live_arms(hiplib, wide, monkeypatch):
                 assert len(esds) > 1000 and stats.heavy_segments >= 1 and stats.overflow_segments == 0
 
 
+@pytest.mark.parametrize("wide", [0, 1])
+def test_more_live_arms_than_any_fixed_capacity(hiplib, wide, monkeypatch):
+    """The reference keeps a chunk's arms in an unbounded Vec (src/automaton.rs:87,173-179).  With
+    --max-cardinality 3000 and -g 400 a stretch that strings together short units of nine 2 900-copy repeat
+    families holds eight families' worth of live arms at once -- 23 200 (counted by a simulation of the automaton),
+    beyond the 16 384 (8 192 with 64-bit positions) slots the last extension tier used to have.  That tier now sizes its HBM slices from the
+    bound max_cardinality * (t* + 1); families must equal the oracle's, with 32- and 64-bit positions."""
+    rng = np.random.default_rng(31)
+    fam, copies, unit, spacer = 9, 2900, 60, 480   # (spacers wider than the gap: a copy's arm never takes the next copy's hit)
+    units = [rng.integers(0, 4, size=unit) for _ in range(fam)]
+    query = np.concatenate(units)
+    parts = [rng.integers(0, 4, size=300), query, rng.integers(0, 4, size=2000)]
+    order = rng.permutation(fam * copies) % fam
+    for f in order:
+        parts.append(units[f])
+        parts.append(rng.integers(0, 4, size=spacer))
+    text = np.concatenate([np.frombuffer(b"ACGT", dtype=np.uint8)[np.concatenate(parts)], np.frombuffer(b"$", dtype=np.uint8)])
+    chunks = [(0, 300 + len(query) + 1500)]   # only the stretch is the needle; its hits lie all over the text
+    cli = dict(gap=400, max_cardinality=3000, min_length=50)
+    if wide:
+        monkeypatch.setenv("ASGART_FORCE_WIDE", "1")
+    oidx = oracle.Index.build(text)
+    with asgart_amd.Index(text, oidx.sa) as idx:
+        st = asgart_amd.RunSettings.from_cli(**cli)
+        offs, sds = idx.search_duplications_raw(chunks, st)
+        eo, es = oidx.run_raw(chunks, oracle.make_settings(**cli))
+        assert np.array_equal(offs, eo) and np.array_equal(sds, es)
+        assert len(sds) > 20_000
+
+
 @pytest.mark.parametrize("bits", [2, 5])
 @pytest.mark.parametrize("tier", [2, 3, 5])
 def test_arm_kernel_generation_wrap(hiplib, bits, tier, monkeypatch):
