@@ -1,5 +1,10 @@
 // common.hpp -- shared host/device definitions of libasgart_hip (gfx950 only).
 #pragma once
+#include <chrono>
+#include <mutex>
+#include <utility>
+#include <cstdio>
+#include <cstdlib>
 
 #include <hip/hip_runtime.h>
 
@@ -34,20 +39,144 @@ void set_error(const char *fmt, ...);
 
 // Grow-only device buffer (workspace reuse across calls: no hipMalloc in the
 // steady state).
+// ASGART_TRACE_ALLOC=1 (diagnostics): every device allocation / release of 1 GiB or more with its duration
+inline bool trace_alloc() {
+    static const bool on = getenv("ASGART_TRACE_ALLOC") != nullptr;
+    return on;
+}
+struct AllocTimer {
+    const char *what;
+    size_t bytes;
+    std::chrono::steady_clock::time_point t0;
+    AllocTimer(const char *w, size_t b) : what(w), bytes(b), t0(std::chrono::steady_clock::now()) {}
+    ~AllocTimer() {
+        if (trace_alloc() && bytes >= ((size_t)1 << 30))
+            fprintf(stderr, "[asgart] %s %6.1f GiB: %8.1f ms\n", what, (double)bytes / (double)((size_t)1 << 30),
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
+};
+
+// Block cache behind DevBuf.  hipMalloc / hipFree of tens of GB are sub-millisecond by themselves on this runtime, but
+// the first large hipMalloc after a lot of memory went back to the driver takes SECONDS (tools/ubench_malloc.hip:
+// 1.5 - 5.5 s for 26 GB after 26 - 150 GB were freed) unless it can take over a block of the same size.  The index
+// build frees ~150 GB of sorter scratch and allocates ~60 GB right after: released blocks of 256 MiB and more are
+// therefore kept (per device, up to kCacheCap bytes) and handed to the next request they fit with little waste;
+// everything is given back when an allocation fails and when the last index of the device is destroyed.
+struct BlockCache {
+    static constexpr size_t kCacheMin = (size_t)256 << 20, kCacheCap = (size_t)200 << 30;
+    struct Dev {
+        std::mutex mu;
+        std::vector<std::pair<void *, size_t>> blocks;
+        size_t bytes = 0;
+    };
+    static Dev &dev() {
+        static Dev d[16];
+        int id = 0;
+        (void)hipGetDevice(&id);
+        return d[(id >= 0 && id < 16) ? id : 0];
+    }
+    // a cached block of at least `bytes` that wastes at most a quarter; nullptr: none
+    static void *take(size_t bytes, size_t *cap) {
+        if (bytes < kCacheMin) return nullptr;
+        Dev &d = dev();
+        std::lock_guard<std::mutex> lk(d.mu);
+        size_t best = (size_t)-1;
+        for (size_t i = 0; i < d.blocks.size(); ++i)
+            if (d.blocks[i].second >= bytes && d.blocks[i].second <= bytes + bytes / 4 &&
+                (best == (size_t)-1 || d.blocks[i].second < d.blocks[best].second))
+                best = i;
+        if (best == (size_t)-1) return nullptr;
+        void *p = d.blocks[best].first;
+        *cap = d.blocks[best].second;
+        d.bytes -= *cap;
+        d.blocks.erase(d.blocks.begin() + (ptrdiff_t)best);
+        return p;
+    }
+    static bool give(void *p, size_t cap) {  // false: not kept (the caller frees it)
+        if (cap < kCacheMin) return false;
+        Dev &d = dev();
+        std::lock_guard<std::mutex> lk(d.mu);
+        if (d.bytes + cap > kCacheCap) return false;
+        d.blocks.emplace_back(p, cap);
+        d.bytes += cap;
+        return true;
+    }
+    static void trim() {
+        Dev &d = dev();
+        std::vector<std::pair<void *, size_t>> out;
+        {
+            std::lock_guard<std::mutex> lk(d.mu);
+            out.swap(d.blocks);
+            d.bytes = 0;
+        }
+        for (auto &b : out) {
+            AllocTimer tm("hipFree  ", b.second);
+            (void)hipFree(b.first);
+        }
+    }
+};
+
+// hipMalloc / hipFree for the long-lived arrays of an index, through the same cache (sizes remembered per pointer)
+inline std::mutex &raw_mu() { static std::mutex m; return m; }
+inline std::vector<std::pair<void *, size_t>> &raw_sizes() { static std::vector<std::pair<void *, size_t>> v; return v; }
+inline hipError_t dev_malloc(void **out, size_t bytes) {
+    size_t cap = 0;
+    void *p = BlockCache::take(bytes, &cap);
+    hipError_t e = hipSuccess;
+    if (!p) {
+        cap = bytes;
+        {
+            AllocTimer tm("hipMalloc", bytes);
+            e = hipMalloc(&p, bytes);
+        }
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            BlockCache::trim();
+            e = hipMalloc(&p, bytes);
+        }
+        if (e != hipSuccess) return e;
+    }
+    {
+        std::lock_guard<std::mutex> lk(raw_mu());
+        raw_sizes().emplace_back(p, cap);
+    }
+    *out = p;
+    return hipSuccess;
+}
+inline void dev_free(void *p) {
+    if (!p) return;
+    size_t cap = 0;
+    {
+        std::lock_guard<std::mutex> lk(raw_mu());
+        auto &v = raw_sizes();
+        for (size_t i = 0; i < v.size(); ++i)
+            if (v[i].first == p) {
+                cap = v[i].second;
+                v.erase(v.begin() + (ptrdiff_t)i);
+                break;
+            }
+    }
+    if (cap && BlockCache::give(p, cap)) return;
+    AllocTimer tm("hipFree  ", cap);
+    (void)hipFree(p);
+}
+
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
     int32_t reserve(size_t bytes) {
         if (bytes <= cap) return 0;
-        if (p) {
-            (void)hipFree(p);
-            p = nullptr;
-            cap = 0;
-        }
+        release();
         size_t want = bytes + bytes / 8 + 256;
-        hipError_t e = hipMalloc(&p, want);
-        if (e != hipSuccess) {
+        if ((p = BlockCache::take(want, &cap)) != nullptr) return 0;
+        hipError_t e;
+        {
+            AllocTimer tm("hipMalloc", want);
+            e = hipMalloc(&p, want);
+        }
+        if (e != hipSuccess) {  // give the cached blocks back, ask for no slack
             (void)hipGetLastError();
+            BlockCache::trim();
             e = hipMalloc(&p, bytes + 256);
             want = bytes + 256;
         }
@@ -61,7 +190,10 @@ struct DevBuf {
         return 0;
     }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p && !BlockCache::give(p, cap)) {
+            AllocTimer tm("hipFree  ", cap);
+            (void)hipFree(p);
+        }
         p = nullptr;
         cap = 0;
     }

@@ -498,18 +498,18 @@ static inline unsigned grid_capped(uint64_t n, unsigned block = 256) {
 }
 
 static void free_k_specific(asgart_index *idx) {
-    if (idx->d_keys) (void)hipFree(idx->d_keys);
-    if (idx->d_ptab) (void)hipFree(idx->d_ptab);
-    if (idx->d_c8lo) (void)hipFree(idx->d_c8lo);
-    if (idx->d_c8hi) (void)hipFree(idx->d_c8hi);
-    if (idx->d_sap) (void)hipFree(idx->d_sap);
+    if (idx->d_keys) dev_free(idx->d_keys);
+    if (idx->d_ptab) dev_free(idx->d_ptab);
+    if (idx->d_c8lo) dev_free(idx->d_c8lo);
+    if (idx->d_c8hi) dev_free(idx->d_c8hi);
+    if (idx->d_sap) dev_free(idx->d_sap);
     idx->d_sap = nullptr;
     for (auto &f : idx->d_filter) {
-        if (f) (void)hipFree(f);
+        if (f) dev_free(f);
         f = nullptr;
     }
     for (auto &f : idx->d_pbits) {
-        if (f) (void)hipFree(f);
+        if (f) dev_free(f);
         f = nullptr;
     }
     for (auto &f : idx->filter_off) f = false;
@@ -581,18 +581,27 @@ int32_t index_prepare(asgart_index *idx, uint64_t k) {
     HIP_TRY(hipSetDevice(idx->device));
     free_k_specific(idx);
     auto t0 = std::chrono::steady_clock::now();
+    auto t_lap = t0;
+    auto lap = [&](const char *what) {  // option debug: where the build's wall time goes
+        if (!idx->opt.debug) return;
+        (void)hipDeviceSynchronize();
+        const auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[asgart] index_prepare: %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(t - t_lap).count());
+        t_lap = t;
+    };
     const uint64_t n = (uint64_t)idx->n, n_sa = (uint64_t)idx->n_sa;
     const size_t slot = idx->wide ? 8 : 4;
     // a --trim index is searched through the 8-mer cache like the reference: no prefix table
     const uint64_t kk = std::min<uint64_t>(k, (uint64_t)kMaxKey);  // bases in a key word
     const int d = idx->trimmed ? 1 : choose_depth(idx->n_sa, kk, idx->opt.ptab_depth);
     const uint64_t entries = (1ull << (2 * d)) + 1;
-    HIP_TRY(hipMalloc((void **)&idx->d_keys, (n_sa + 16) * sizeof(uint64_t)));
-    HIP_TRY(hipMalloc(&idx->d_ptab, entries * slot));
-    HIP_TRY(hipMalloc(&idx->d_c8lo, (size_t)kCacheEntries * slot));
-    HIP_TRY(hipMalloc(&idx->d_c8hi, (size_t)kCacheEntries * slot));
+    HIP_TRY(dev_malloc((void **)&idx->d_keys, (n_sa + 16) * sizeof(uint64_t)));
+    HIP_TRY(dev_malloc(&idx->d_ptab, entries * slot));
+    HIP_TRY(dev_malloc(&idx->d_c8lo, (size_t)kCacheEntries * slot));
+    HIP_TRY(dev_malloc(&idx->d_c8hi, (size_t)kCacheEntries * slot));
     hipStream_t s = idx->ctx[0].stream;
     idx->n_bad = 0;
+    lap("allocations");
     auto build = [&](auto tag) -> int32_t {
         using SlotT = decltype(tag);
         const SlotT *sa = (const SlotT *)idx->d_sa;
@@ -624,21 +633,23 @@ int32_t index_prepare(asgart_index *idx, uint64_t k) {
     RC_TRY(idx->wide ? build(uint64_t{}) : build(uint32_t{}));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));
+    lap("keys + tables");
     // position-sorted occurrence lists (one key word per probe, whole suffix array, 32-bit positions)
     if (idx->opt.rank_lists && !idx->wide && !idx->trimmed && k <= (uint64_t)kMaxKey && n_sa > 0) {
         // (an optimisation only: without the memory for it -- the list or the sort's scratch -- the index does without)
-        if (hipMalloc(&idx->d_sap, (n_sa + 16) * 4) != hipSuccess) {
+        if (dev_malloc(&idx->d_sap, (n_sa + 16) * 4) != hipSuccess) {
             (void)hipGetLastError();
             idx->d_sap = nullptr;
         } else {
             const int32_t rc_rank = build_rank_lists(idx->d_keys, (const uint32_t *)idx->d_sa, n_sa, (uint32_t *)idx->d_sap, s);
             if (rc_rank != 0) {
-                (void)hipFree(idx->d_sap);
+                dev_free(idx->d_sap);
                 idx->d_sap = nullptr;
                 if (rc_rank != ASGART_E_OOM) return rc_rank;
             }
         }
     }
+    lap("position-sorted lists");
     // text-tail corner list (host, from the last bytes of the text)
     idx->n_tail8 = 0;
     idx->tail_bloom = 0;
@@ -699,7 +710,7 @@ int32_t index_prepare_filter(asgart_index *idx, uint64_t k, int mode) {
     const int bits = idx->filter_bits;
     const size_t bytes = (size_t)1 << (bits - 3);
     uint64_t *flt = nullptr;
-    if (hipMalloc((void **)&flt, bytes) != hipSuccess) {
+    if (dev_malloc((void **)&flt, bytes) != hipSuccess) {
         // the filter is an optimisation: without memory for it this orientation is searched without (every probe
         // takes the lookup); the call that needed it goes on
         (void)hipGetLastError();
@@ -722,14 +733,14 @@ int32_t index_prepare_filter(asgart_index *idx, uint64_t k, int mode) {
         return 0;
     }();
     if (rc != 0) {
-        (void)hipFree(flt);
+        dev_free(flt);
         return rc;
     }
     if (idx->opt.posbits) {
         // the same answers by text position (n bits, padded so that a workgroup's 16-byte loads never leave it)
         const uint64_t n_words = ((uint64_t)idx->n + 63u) / 64u;
         uint64_t *pb = nullptr;
-        if (hipMalloc((void **)&pb, (size_t)n_words * 8 + 512) == hipSuccess) {
+        if (dev_malloc((void **)&pb, (size_t)n_words * 8 + 512) == hipSuccess) {
             rc = [&]() -> int32_t {
                 HIP_TRY(hipMemsetAsync(pb, 0xFF, (size_t)n_words * 8 + 512, s));
                 const unsigned g = grid_capped(n_words);
@@ -744,8 +755,8 @@ int32_t index_prepare_filter(asgart_index *idx, uint64_t k, int mode) {
                 return 0;
             }();
             if (rc != 0) {
-                (void)hipFree(pb);
-                (void)hipFree(flt);
+                dev_free(pb);
+                dev_free(flt);
                 return rc;
             }
             idx->d_pbits[mode] = pb;
@@ -771,8 +782,8 @@ void asgart_index_destroy(asgart_index *idx) {
     if (!idx) return;
     (void)hipSetDevice(idx->device);
     free_k_specific(idx);
-    if (idx->d_text) (void)hipFree(idx->d_text);
-    if (idx->d_sa) (void)hipFree(idx->d_sa);
+    if (idx->d_text) dev_free(idx->d_text);
+    if (idx->d_sa) dev_free(idx->d_sa);
     for (auto &cx : idx->ctx) {
         Workspace &w = cx.ws;
         DevBuf *bufs[] = {&w.chunks, &w.p_lo, &w.p_raw, &w.p_filt, &w.row_off, &w.blk, &w.hits,
@@ -836,7 +847,7 @@ static int32_t index_create_impl(const uint8_t *T, int64_t n, const int64_t *SA,
     for (auto &cx : idx->ctx) memset(&cx.stats, 0, sizeof(cx.stats));
     int32_t rc = [&]() -> int32_t {
         for (auto &cx : idx->ctx) RC_TRY(create_ctx_streams(cx));
-        HIP_TRY(hipMalloc((void **)&idx->d_text, (size_t)n + 64));
+        HIP_TRY(dev_malloc((void **)&idx->d_text, (size_t)n + 64));
         HIP_TRY(hipMemsetAsync(idx->d_text + n, 0, 64, idx->ctx[0].stream));
         HIP_TRY(hipMemcpyAsync(idx->d_text, T, (size_t)n, hipMemcpyHostToDevice, idx->ctx[0].stream));
         // validate the alphabet on the device
@@ -863,7 +874,7 @@ static int32_t index_create_impl(const uint8_t *T, int64_t n, const int64_t *SA,
         const int64_t tl = n < 64 ? n : 64;
         idx->h_tail.assign(T + n - tl, T + n);
         const size_t slot = idx->wide ? 8 : 4;
-        HIP_TRY(hipMalloc(&idx->d_sa, ((size_t)n_sa + 16) * slot));
+        HIP_TRY(dev_malloc(&idx->d_sa, ((size_t)n_sa + 16) * slot));
         if (!SA && trimmed) {
             // suffix array of data[start..end] + '$', every entry shifted by +start
             // (reference src/bin/asgart.rs:142-148)
@@ -966,8 +977,8 @@ int32_t asgart_index_clone(asgart_index *src, int32_t device, asgart_index **out
         for (auto &cx : idx->ctx) RC_TRY(create_ctx_streams(cx));
         const size_t slot = idx->wide ? 8 : 4;
         const size_t text_bytes = (size_t)idx->n + 64, sa_bytes = ((size_t)idx->n_sa + 16) * slot;
-        HIP_TRY(hipMalloc((void **)&idx->d_text, text_bytes));
-        HIP_TRY(hipMalloc(&idx->d_sa, sa_bytes));
+        HIP_TRY(dev_malloc((void **)&idx->d_text, text_bytes));
+        HIP_TRY(dev_malloc(&idx->d_sa, sa_bytes));
         // device-to-device over xGMI when the devices differ (peer copy), a plain copy otherwise
         hipStream_t s = idx->ctx[0].stream;
         HIP_TRY(hipMemcpyPeerAsync(idx->d_text, device, src->d_text, src->device, text_bytes, s));
@@ -998,7 +1009,7 @@ int32_t asgart_index_set_option(asgart_index *idx, const char *name, int64_t val
     if (rc == 0 && !strcmp(name, "kfilter_bits")) {  // rebuilt at the new size by the next call
         (void)hipSetDevice(idx->device);
         for (auto &f : idx->d_filter) {
-            if (f) (void)hipFree(f);
+            if (f) dev_free(f);
             f = nullptr;
         }
         idx->filter_bits = 0;

@@ -639,25 +639,33 @@ __global__ __launch_bounds__(256) void low_word_kernel(const unsigned long long 
 int32_t build_rank_lists(const uint64_t *d_keys, const uint32_t *d_sa, uint64_t n, uint32_t *d_sap, hipStream_t s) {
     if (n == 0) return 0;
     const unsigned g = (unsigned)std::min<uint64_t>((n + 255) / 256, 1u << 20);
-    DevBuf a, b, temp;
-    struct Free {  // (before the first reservation: a failed second one must not leave the first behind)
-        DevBuf &x, &y, &z;
-        ~Free() { x.release(); y.release(); z.release(); }
-    } guard{a, b, temp};
-    RC_TRY(a.reserve(n * 8));
-    RC_TRY(b.reserve(n * 8));
+    // Two stable 32-bit pair sorts -- by position, then by interval rank -- on buffers of n words each: the sizes
+    // the suffix sorter has just released (common.hpp: block cache), instead of one 64-bit sort on two fresh
+    // buffers of 2 n words.
+    DevBuf ka, kb, vb, temp;
+    struct Free {  // (before the first reservation: a failed later one must not leave the earlier ones behind)
+        DevBuf &x, &y, &z, &t;
+        ~Free() { x.release(); y.release(); z.release(); t.release(); }
+    } guard{ka, kb, vb, temp};
+    RC_TRY(ka.reserve(n * 4));
+    RC_TRY(kb.reserve(n * 4));
+    RC_TRY(vb.reserve(n * 4));
     // interval ranks (in d_sap, which is free until the end): inclusive sum of the run heads
     run_head_kernel<<<g, 256, 0, s>>>(d_keys, d_sap, n);
     size_t bytes = 0;
     HIP_TRY(rocprim::inclusive_scan(nullptr, bytes, d_sap, d_sap, (size_t)n, rocprim::plus<uint32_t>(), s));
     RC_TRY(temp.reserve(bytes));
     HIP_TRY(rocprim::inclusive_scan(temp.p, bytes, d_sap, d_sap, (size_t)n, rocprim::plus<uint32_t>(), s));
-    rank_pos_kernel<<<g, 256, 0, s>>>(d_sap, d_sa, a.as<unsigned long long>(), n);
+    HIP_TRY(hipMemcpyAsync(ka.p, d_sa, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+    rocprim::double_buffer<uint32_t> pos(ka.as<uint32_t>(), kb.as<uint32_t>()), rank(d_sap, vb.as<uint32_t>());
     bytes = 0;
-    HIP_TRY(rocprim::radix_sort_keys(nullptr, bytes, a.as<unsigned long long>(), b.as<unsigned long long>(), (size_t)n, 0, 64, s));
+    HIP_TRY(rocprim::radix_sort_pairs(nullptr, bytes, pos, rank, (size_t)n, 0, 32, s));
     RC_TRY(temp.reserve(bytes));
-    HIP_TRY(rocprim::radix_sort_keys(temp.p, bytes, a.as<unsigned long long>(), b.as<unsigned long long>(), (size_t)n, 0, 64, s));
-    low_word_kernel<<<g, 256, 0, s>>>(b.as<unsigned long long>(), d_sap, n);
+    HIP_TRY(rocprim::radix_sort_pairs(temp.p, bytes, pos, rank, (size_t)n, 0, 32, s));   // by position
+    rocprim::double_buffer<uint32_t> rank2(rank.current(), rank.alternate()), pos2(pos.current(), pos.alternate());
+    HIP_TRY(rocprim::radix_sort_pairs(temp.p, bytes, rank2, pos2, (size_t)n, 0, 32, s)); // stable, by rank
+    if (pos2.current() != d_sap)
+        HIP_TRY(hipMemcpyAsync(d_sap, pos2.current(), (size_t)n * 4, hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));
     return 0;

@@ -229,6 +229,58 @@ def diverged_genome(records: List[Tuple[str, np.ndarray]], seed: int, sub_rate: 
     return out
 
 
+def repeat_rich_genome(record_lengths: Sequence[int], seed: int, *, sine_frac: float = 0.27, line_frac: float = 0.15,
+                       div: Tuple[float, float] = (0.01, 0.05), sine_family: Tuple[int, int] = (60, 220),
+                       line_family: Tuple[int, int] = (15, 60)) -> List[Tuple[str, np.ndarray]]:
+    """A genome whose interspersed repeats are YOUNG: `sine_frac` of it 300-bp elements and `line_frac` 5'-truncated
+    6-kb elements, in many families of moderate copy number at 1-5 % divergence from their consensus, half of the
+    copies reverse-complemented.  Most 20-mers of a copy then recur exactly in its relatives (0.97^20 = 54 %), so
+    well over a third of the probes pass the presence filter and carry tens of hits -- the regime of the young
+    Alu / L1 subfamilies of a real assembly, which config_genome's single old high-copy family (10-15 % diverged:
+    four probes in five have no second occurrence) does not cover.  Family sizes stay below max_cardinality so the
+    probes are extended, not skipped.  Plus what make_genome plants at its defaults' scale: a few segmental
+    duplications, satellite arrays and N-runs."""
+    recs = make_genome(record_lengths, seed, alu_frac=0.0, l1_frac=0.0)
+    rng = np.random.default_rng(seed + 1000)
+    lens = [len(s) for _, s in recs]
+    offs = np.concatenate(([0], np.cumsum(lens)))
+    total = int(offs[-1])
+    seq = np.concatenate([s for _, s in recs])
+    code = np.zeros(256, dtype=np.uint8)
+    for i_, ch in enumerate(b"ACGT"):
+        code[ch] = i_
+        code[ch | 0x20] = i_
+
+    def plant(cons: np.ndarray, n_copies: int, truncate: bool):
+        ln0 = len(cons)
+        for _ in range(n_copies):
+            cp = _mutate(rng, cons, float(rng.uniform(div[0], div[1])))
+            if truncate:
+                cp = cp[ln0 - int(rng.integers(500, ln0 + 1)):]
+            if rng.random() < 0.5:
+                cp = _COMP_IDX[cp[::-1]]
+            r = int(rng.integers(0, len(lens)))
+            if lens[r] <= len(cp) + 2:
+                continue
+            p = int(offs[r] + rng.integers(0, lens[r] - len(cp)))
+            keep_n = seq[p:p + len(cp)] == ord("N")
+            new = _BASES[cp] | 0x20           # soft-masked, like a RepeatMasker'd assembly
+            new[keep_n] = ord("N")
+            seq[p:p + len(cp)] = new
+
+    planted = 0
+    while planted < total * sine_frac:
+        n = int(rng.integers(sine_family[0], sine_family[1] + 1))
+        plant(_background(rng, 300), n, False)
+        planted += 300 * n
+    planted = 0
+    while planted < total * line_frac:
+        n = int(rng.integers(line_family[0], line_family[1] + 1))
+        plant(_background(rng, 6000), n, True)
+        planted += 3250 * n
+    return [(name, seq[offs[r]:offs[r + 1]]) for r, (name, _) in enumerate(recs)]
+
+
 def config_genome(cfg: int, scale: float = 1.0) -> List[Tuple[str, np.ndarray]]:
     """Synthetic stand-ins for BASELINE.json configs 1-5 (scale<1 shrinks them).  Config 5 is two
     "files": the config-4 genome plus a 1.2 %-diverged, rearranged copy of it (the cross-genome
@@ -236,6 +288,9 @@ def config_genome(cfg: int, scale: float = 1.0) -> List[Tuple[str, np.ndarray]]:
     if cfg == 5:
         first = config_genome(4, scale)
         return first + diverged_genome(first, SEED_BASE + 5)
+    if cfg == 6:   # chr1-sized, repeat-rich (young interspersed repeats): not a BASELINE.json config, a realism check
+        lens6 = GRCH38_PRIMARY[:1] if scale == 1.0 else scaled(GRCH38_PRIMARY[:1], int(GRCH38_PRIMARY[0] * scale))
+        return repeat_rich_genome(lens6, SEED_BASE + 6)
     table = {1: ECOLI_MG1655, 2: SCEREVISIAE_S288C, 3: GRCH38_PRIMARY[:1], 4: GRCH38_PRIMARY}[cfg]
     lens = table if scale == 1.0 else scaled(table, int(sum(table) * scale))
     return make_genome(lens, SEED_BASE + cfg)

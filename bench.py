@@ -61,7 +61,37 @@ WORKLOADS = {
     "cfg3": (3, 1.0, True, DIRECT_RC, "human chr1-shaped synthetic (249 Mb), direct+RC, --skip-masked, k=20 g=100"),
     "cfg4": (4, 1.0, False, DIRECT_RC, "GRCh38-shaped synthetic (3.1 Gb, 25 records), direct+RC, k=20 g=100"),
     "cfg5": (5, 1.0, False, DIRECT_RC, "GRCh38-shaped + 1.2 %-diverged second genome (two files, 6.1 Gb), direct+RC, k=20 g=100"),
+    # not a BASELINE.json config: a realism check (young interspersed repeats: two probes in five pass the filter)
+    "cfg3r": (6, 1.0, False, DIRECT_RC, "human chr1-sized, repeat-rich synthetic (249 Mb; 27 % SINE-like + 15 % LINE-like families at 1-5 % divergence), direct+RC, k=20 g=100"),
 }
+
+
+def fasta_inputs(args):
+    """--fasta a.fa [b.fa ...], or every FASTA file of $ASGART_DATA_DIR (real assemblies are
+    used instead of the synthetic stand-ins when present).  Several files are concatenated record by record, as the
+    reference does (src/bin/asgart.rs:375-395)."""
+    files = list(args.fasta or [])
+    d = os.environ.get("ASGART_DATA_DIR")
+    if not files and d and os.path.isdir(d):
+        files = sorted(os.path.join(d, f) for f in os.listdir(d)
+                       if f.lower().endswith((".fa", ".fasta", ".fna", ".fa.gz", ".fasta.gz", ".fna.gz")))
+    return files
+
+
+def read_fasta_files(files):
+    import gzip
+    import shutil
+    import tempfile
+    recs = []
+    for f in files:
+        if f.endswith(".gz"):
+            with gzip.open(f, "rb") as src, tempfile.NamedTemporaryFile(suffix=".fa") as tmp:
+                shutil.copyfileobj(src, tmp)
+                tmp.flush()
+                recs.extend(prep.read_records(tmp.name))
+        else:
+            recs.extend(prep.read_records(f))
+    return recs
 
 
 def log(*a):
@@ -82,6 +112,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=os.environ.get("ASGART_BENCH_WORKLOAD", "cfg4"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fasta", nargs="+", default=None, help="real FASTA input(s) instead of the synthetic workload")
+    ap.add_argument("--skip-masked", action="store_true", help="with --fasta: lower-case bases count as N (-S)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -110,7 +142,16 @@ def main():
     cfg, scale, skip_masked, modes, desc = WORKLOADS[args.workload]
     k, gap = 20, 100
     t0 = time.time()
-    recs = synth.config_genome(cfg, scale)
+    files = fasta_inputs(args)
+    data_kind = "synthetic"
+    if files:
+        recs = read_fasta_files(files)
+        skip_masked, modes = bool(args.skip_masked), DIRECT_RC
+        desc = (f"FASTA {', '.join(os.path.basename(f) for f in files)} ({len(recs)} records), direct+RC"
+                f"{', --skip-masked' if skip_masked else ''}, k=20 g=100")
+        data_kind = "real"
+    else:
+        recs = synth.config_genome(cfg, scale)
     pr = prep.prepare_records(recs, skip_masked=skip_masked)
     del recs
     total_bp = sum(l for _, l in pr.chunks)
@@ -320,7 +361,7 @@ def main():
         "scaling": "strong",
         "vs_baseline": None,
         "dtype": "u64 keys / u32 SA" if len(pr.data) < 0xFFFFFF00 else "u64 keys / u64 SA",
-        "data": "synthetic",
+        "data": data_kind,
         "config": {"workload": desc, "bp_per_pass": total_bp, "passes": passes,
                    "skip_masked": skip_masked,
                    "text_bytes": int(len(pr.data)), "chunks": len(pr.chunks),
@@ -343,7 +384,11 @@ def main():
         import oracle  # the CPU checker, used here ONLY as the timed CPU baseline
 
         cores = min(os.cpu_count() or 1, len(pr.chunks))  # threads that can be busy: one per chunk
-        sa = idx.sa_read(0, len(pr.data))
+        n_text = len(pr.data)
+        sa = np.empty(n_text, dtype=np.int64)   # (read back in slabs: sa_read returns a fresh array per call)
+        slab = 1 << 28
+        for o in range(0, n_text, slab):
+            sa[o:min(n_text, o + slab)] = idx.sa_read(o, min(n_text, o + slab))
         oidx = oracle.Index.build(pr.data, sa)
         # bounded sample: the first `per_chunk` bases of EVERY chunk, so the CPU leg keeps the
         # reference's chunk-level parallelism (one thread per chunk) without its skew

@@ -734,6 +734,14 @@ def test_cfg4_full_digest(hiplib):
     _check_against_oracle_digest("cfg4")
 
 
+def test_cfg3r_repeat_rich_digest(hiplib):
+    """A chr1-sized genome whose interspersed repeats are young (synth.repeat_rich_genome: 42 % of it in SINE- /
+    LINE-like families at 1-5 % divergence, family sizes below max_cardinality): two probes in five pass the
+    presence filter and carry tens of hits, unlike the BASELINE-shaped stand-ins, whose one old high-copy family
+    is answered by the filter four times in five.  Direct + RC against the oracle's digests (bench workload cfg3r)."""
+    _check_against_oracle_digest("cfg3r")
+
+
 def test_cfg5_wide_digest(hiplib):
     """BASELINE.json configs[4] (two files: the GRCh38-shaped genome + its 1.2 %-diverged, rearranged copy,
     reference src/bin/asgart.rs:375-395) at the smallest scale that needs 64-bit suffix-array entries
@@ -766,6 +774,31 @@ def test_cfg5_full_properties(hiplib):
             assert np.array_equal(mo, offs) and np.array_equal(ms, sds), "shards != unsharded"
             cross = int(np.sum((sds[:, 0] < n // 2) != (sds[:, 1] < n // 2)))
             assert cross > 10_000, cross
+
+
+def test_bench_reads_real_fasta(hiplib, tmp_path):
+    """bench.py --fasta: real FASTA input instead of the synthetic workload, one JSON line
+    with data = "real"."""
+    import json
+    import os
+    import subprocess
+    import sys
+    recs = _small_genome(seed=41)
+    fa = tmp_path / "tiny.fa"
+    with open(fa, "wb") as fh:
+        for name, seq in recs:
+            fh.write(b">" + name.encode() + b"\n")
+            raw = seq.tobytes()
+            for o in range(0, len(raw), 80):
+                fh.write(raw[o:o + 80] + b"\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--fasta", str(fa), "--steps", "1", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["data"] == "real" and line["value"] > 0 and "tiny.fa" in line["config"]["workload"]
+    assert line["cpu_baseline"]["kind"] == "port" and line["roofline"]["bound"] == "hbm"
+    assert line["work_per_step"]["proto_sds"] > 0
 
 
 @pytest.mark.parametrize("rc", [False, True])

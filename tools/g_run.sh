@@ -1,2 +1,3 @@
 mkdir -p gpurun_out/r3
-timeout 2400 python -m pytest tests -x -q -m gpu -k "more_live_arms or tier6 or escalation or cascade or cap or large_max_card or 64bit" > gpurun_out/r3/cap_tests.log 2>&1; echo "rc=$?" >> gpurun_out/r3/cap_tests.log
+ASGART_TRACE_ALLOC=1 ASGART_DEBUG=1 python3 tools/index_build.py cfg4 3 > gpurun_out/r3/index_build.log 2>&1
+timeout 2400 python -m pytest tests -x -q -m gpu > gpurun_out/r3/gpu_tests.log 2>&1; echo "rc=$?" >> gpurun_out/r3/gpu_tests.log
