@@ -107,6 +107,10 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
     // cold fields of an arm, by slot (layer * NT + thread): the left end is written at every extension and read only
     // when the arm is reported; the right start is read when the arm dies.  Out of the registers they buy a fifth layer.
     __shared__ PosT s_cle[CAP], s_crs[CAP];
+    // Bookkeeping of the automaton that every wave keeps in scalar registers (creation counter, family ordinal, open
+    // family, spur horizon): wave 0 publishes it after each B; a wave that skipped the hit ranking of a probe (it could
+    // not be concerned: see phase B) re-reads it before the next B it takes part in.
+    __shared__ __attribute__((aligned(16))) uint32_t s_pub[2][4];
     __shared__ uint32_t s_sink[64];  // per lane: where the atomicMin of a lane with nothing to offer goes
     __shared__ uint32_t s_never;     // == kNever
 
@@ -166,6 +170,7 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
         // block-uniform bookkeeping
         uint32_t quiet = 0, pend = 0, fam_seq = 0, next_seq = 0, t_proc = 0, spur_until = 0;
         bool overflow = false, done = false, fam_open = false;
+        bool ran_full = true;  // this wave took part in the previous probe's hit ranking (its bookkeeping is current)
 
         auto emit_records = [&](bool emit, PosT ls, PosT le, PosT rs, PosT re, uint32_t seq) {
             const unsigned long long em = __ballot(emit);
@@ -250,6 +255,7 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
             uint32_t nfv[8] = {64u, 64u, 64u, 64u, 64u, 64u, 64u, 64u};
 #pragma unroll
             for (int L = 0; L < S; ++L) {
+                if (!(livemask >> L)) break;  // no arm of this wave in this layer or a higher one (nfv stays 64)
                 uint32_t nf = 64u;
                 if (livemask & (1u << L)) {
                     bool live = a_seq[L] != kNoSeq;
@@ -360,9 +366,6 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
             // (entry j = layer j / NW, wave j % NW; a lane holds entries j = lane and lane + 64)
             const uint32_t fv = lane < S * NW ? s_free[q.tb][lane % NW][lane / NW] : 0u;
             const uint32_t fv2 = S * NW > 64 && lane + 64 < S * NW ? s_free[q.tb][(lane + 64) % NW][(lane + 64) / NW] : 0u;
-            const uint32_t h_l = min((uint32_t)lane, cnt - 1u);
-            const uint32_t bv0 = s_best[bb][h_l];
-            const uint8_t hf0 = use_flag ? s_hflag[off + h_l] : (uint8_t)1;
             // empty slots, ranked (layer, wave, lane)
             const uint32_t fincl = wave_incl_scan(fv);
             uint32_t total_free = lane_of(fincl, 63u);
@@ -373,37 +376,63 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
             }
             const uint32_t A0 = (uint32_t)CAP - total_free;  // live arms after the quiet probes' deaths
             PROF_COUNT(10, A0);
-            if (fam_open && A0 == 0 && q.t_before >= spur_until) {  // the flush of src/automaton.rs:182-200
-                ++fam_seq;
-                next_seq = 0;
-                fam_open = false;
+            // Which waves rank the hits.  The new arms of this probe -- at most cnt -- go to the lowest-ranked empty
+            // slots; a wave whose first slot ranks behind cnt others cannot receive one, and if cnt arms fit, nothing
+            // can overflow: such a wave only resolves its own arms below.  Wave 0 always ranks (and publishes).
+            const uint32_t base0 = lane_of(fincl - fv, wave);  // rank of this wave's first layer-0 slot
+            const bool full = wave == 0u || !(base0 >= cnt && cnt <= total_free && A0 + cnt <= cap_eff);
+            uint32_t n_new = 0;
+            bool spur = false;
+            unsigned long long m0 = 0;
+            if (full) {
+                if (!ran_full) {  // bookkeeping as of the end of the previous probe
+                    const uint4 pv = *reinterpret_cast<const uint4 *>(&s_pub[q.tb ^ 1u][0]);
+                    next_seq = uni(pv.x);
+                    fam_seq = uni(pv.y);
+                    fam_open = (uni(pv.z) & 1u) != 0u;
+                    spur_until = uni(pv.w);
+                }
+                if (fam_open && A0 == 0 && q.t_before >= spur_until) {  // the flush of src/automaton.rs:182-200
+                    ++fam_seq;
+                    next_seq = 0;
+                    fam_open = false;
+                }
+                // unmatched hits, in hit order (= creation order, src/automaton.rs:151-164)
+                const uint32_t h_l = min((uint32_t)lane, cnt - 1u);
+                const uint32_t bv0 = s_best[bb][h_l];
+                const uint8_t hf0 = use_flag ? s_hflag[off + h_l] : (uint8_t)1;
+                const bool in0 = (uint32_t)lane < cnt;
+                m0 = __ballot(in0 && bv0 == kNone && hf0 != 0);  // group 0 stays in registers
+                n_new = (uint32_t)__popcll(m0);
+                spur = use_flag && __ballot(in0 && bv0 == kNone && hf0 == 0) != 0ull;
+                for (uint32_t h0 = 64u, gi = 1; h0 < cnt; h0 += 64u, ++gi) {  // (most probes have <= 64 hits)
+                    const uint32_t h = min(h0 + (uint32_t)lane, cnt - 1u);
+                    const bool in = h0 + (uint32_t)lane < cnt;
+                    const bool un = in && s_best[bb][h] == kNone;
+                    const bool hf = use_flag ? s_hflag[off + h] != 0 : true;
+                    const unsigned long long nm = __ballot(un && hf);
+                    if (use_flag) spur = spur || __ballot(un && !hf) != 0ull;
+                    s_newmask[wave][gi] = nm;
+                    n_new += (uint32_t)__popcll(nm);
+                }
+                PROF_MAX(9, A0 + n_new);
+                if (n_new > total_free || A0 + n_new > cap_eff) {  // (identical in every wave that gets here; the
+                    overflow = true;                                //  others have checked that cnt arms fit)
+                    done = true;
+                }
             }
-            // unmatched hits, in hit order (= creation order, src/automaton.rs:151-164)
-            const bool in0 = (uint32_t)lane < cnt;
-            const unsigned long long m0 = __ballot(in0 && bv0 == kNone && hf0 != 0);  // group 0 stays in registers
-            uint32_t n_new = (uint32_t)__popcll(m0);
-            bool spur = use_flag && __ballot(in0 && bv0 == kNone && hf0 == 0) != 0ull;
-            for (uint32_t h0 = 64u, gi = 1; h0 < cnt; h0 += 64u, ++gi) {  // (most probes have <= 64 hits)
-                const uint32_t h = min(h0 + (uint32_t)lane, cnt - 1u);
-                const bool in = h0 + (uint32_t)lane < cnt;
-                const bool un = in && s_best[bb][h] == kNone;
-                const bool hf = use_flag ? s_hflag[off + h] != 0 : true;
-                const unsigned long long nm = __ballot(un && hf);
-                if (use_flag) spur = spur || __ballot(un && !hf) != 0ull;
-                s_newmask[wave][gi] = nm;
-                n_new += (uint32_t)__popcll(nm);
-            }
-            PROF_MAX(9, A0 + n_new);
-            if (n_new > total_free || A0 + n_new > cap_eff) {  // (identical in every wave)
-                overflow = true;
-                done = true;
-                return;
-            }
+            // (an overflow is the same decision in every wave: the waves that skipped the ranking know that cnt arms fit)
+            if (overflow) return;
             const uint32_t seq_base = next_seq;
             PROF_STOP(6);
             PROF_START();
 #pragma unroll
             for (int L = 0; L < S; ++L) {
+                if (!(livemask >> L)) {  // no arm of this wave here or above: go on only while new arms can reach the layer
+                    const uint32_t before = L == 0 ? 0u : (L * NW <= 64 ? lane_of(fincl, (uint32_t)(L * NW - 1))
+                                                                         : lane_of(fincl2, (uint32_t)(L * NW - 65)));
+                    if (!full || before >= n_new) break;  // (the empty slots of the lower layers take them all)
+                }
                 const bool was_free = a_seq[L] == kNoSeq;
                 const unsigned long long fmask = __ballot(was_free);
                 if (livemask & (1u << L)) {  // this wave may hold an arm here
@@ -496,9 +525,14 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
                     }
                 }
             }
-            next_seq += n_new;
-            fam_open = true;
-            if (spur) spur_until = max(spur_until, q.t_after + rp.tstar - 1u);
+            if (full) {
+                next_seq += n_new;
+                fam_open = true;
+                if (spur) spur_until = max(spur_until, q.t_after + rp.tstar - 1u);
+                if (wave == 0u)  // (every lane, same 16 bytes)
+                    *reinterpret_cast<uint4 *>(&s_pub[q.tb][0]) = make_uint4(next_seq, fam_seq, 1u, spur_until);
+            }
+            ran_full = full;
             PROF_STOP(7);
         };
 

@@ -203,7 +203,7 @@ struct Options {
     int64_t progress_at = 2;        // when a call reports its probes as searched (pipeline.hip: progress)
     int64_t early_cascade = 1;      // 1: tier 6's overflow is re-run as soon as tier 6 is done, not after the last tier
     int64_t cap6_pct = 140;         // tier 6 accepts segments whose arm bound is up to this percentage of its capacity
-    int64_t fast = 72;              // bit t set (t = 3, 6): tier t runs the one-barrier arm kernel (extend_fast_dev.hpp) instead of K4c
+    int64_t fast = 124;             // bit t set (t = 2..6): tier t runs the one-barrier arm kernel (extend_fast_dev.hpp) instead of K4c
     int64_t fast_nt = 1024;         // threads per workgroup of tier 3's two-barrier kernel (256 / 512 / 1024; capacity 4096 / 2048 arm slots)
     int64_t fast_bsh = 0;           // its bucket width: 2^fast_bsh times the smallest power of two >= max_gap_size + k
     int64_t fast_pipe = 1;          // experiments: 1 = one barrier per hit-probe (B of probe t-1 runs beside A of probe t)

@@ -346,7 +346,6 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                 tier_cap[4] = (uint32_t)kMidArmsLayers<SlotT> * 256u;
             }
             tier_cap[3] = (uint32_t)(fast_tier(3) ? kFastLongLayers<SlotT> : kLongArmsLayers<SlotT>) * 1024u;
-            if (fast_tier(3) && opt.fast_nt < 1024) tier_cap[3] = (uint32_t)kFastLongLayers<SlotT> * (opt.fast_nt >= 512 ? 512u : 256u);
 
             tier_cap[5] = (uint32_t)kMidArmsLayers<SlotT> * 512u;
             // the window bound is pessimistic for tandem arrays (hits extend arms there) and the HBM
@@ -554,7 +553,9 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                     extend_kernel<SlotT, kArmCapSmall><<<grid(kGrid1), 64, 0, st>>>(ep);
                     break;
                 case 2:
-                    if (arms_kernel)
+                    if (fast_tier(2))
+                        extend_fast_kernel<SlotT, kWaveArmsLayers<SlotT>, 64, kWaveArmsHits, 256, 2><<<grid(kGrid2Arms), 64, 0, st>>>(ep);
+                    else if (arms_kernel)
                         extend_arms_kernel<SlotT, kWaveArmsLayers<SlotT>, 64, kWaveArmsHits, 512, 3, false><<<grid(kGrid2Arms), 64, 0, st>>>(ep);
                     else
                         extend_heavy_kernel<SlotT, kArmCapMid, kMidThreads, 0><<<grid(kGrid2), kMidThreads, 0, st>>>(ep);
@@ -563,21 +564,14 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                     if (fast_tier(3)) {
                         // (the same capacity in three shapes: per-probe work every wave repeats -- ranking the
                         // empty slots and the unmatched hits -- is paid once per wave sharing a SIMD)
-                        if (opt.fast_nt >= 1024 && opt.fast_e == 2)
-                            extend_fast_kernel<SlotT, kFastLongLayers<SlotT>, 1024, kHitBatch, 2048, 2><<<grid(256), 1024, 0, st>>>(ep);
-                        else if (opt.fast_nt >= 1024 && opt.fast_pipe == 0)
-                            extend_fast_kernel<SlotT, kFastLongLayers<SlotT>, 1024, kHitBatch, 1024, 4, false><<<grid(256), 1024, 0, st>>>(ep);
-                        else if (opt.fast_nt >= 1024)
-                            extend_fast_kernel<SlotT, kFastLongLayers<SlotT>, 1024, kHitBatch><<<grid(256), 1024, 0, st>>>(ep);
-                        else if (opt.fast_nt >= 512)
-                            extend_fast_kernel<SlotT, kFastLongLayers<SlotT>, 512, kHitBatch><<<grid(256), 512, 0, st>>>(ep);
-                        else
-                            extend_fast_kernel<SlotT, kFastLongLayers<SlotT>, 256, kHitBatch><<<grid(256), 256, 0, st>>>(ep);
+                        extend_fast_kernel<SlotT, kFastLongLayers<SlotT>, 1024, kHitBatch, 2048, 2><<<grid(256), 1024, 0, st>>>(ep);
                     } else
                         extend_arms_kernel<SlotT, kLongArmsLayers<SlotT>, 1024, kHitBatch, 1024, 4, false, true, kPoleLdsPad><<<grid(256), 1024, 0, st>>>(ep);
                     break;
                 case 4:
-                    if (arms_kernel)
+                    if (fast_tier(4))
+                        extend_fast_kernel<SlotT, kMidArmsLayers<SlotT>, 256, kWaveArmsHits, 512, 2><<<grid(256 * 4), 256, 0, st>>>(ep);
+                    else if (arms_kernel)
                         extend_arms_kernel<SlotT, kMidArmsLayers<SlotT>, 256, kWaveArmsHits, 512, 4, false, true><<<grid(256 * 4), 256, 0, st>>>(ep);
                     else if constexpr (sizeof(SlotT) == 4)
                         extend_heavy_kernel<SlotT, kArmCapBig32, kHeavyThreads, 0><<<grid(256), kHeavyThreads, 0, st>>>(ep);
@@ -585,7 +579,10 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                         extend_heavy_kernel<SlotT, kArmCapBig64, kHeavyThreads, 0><<<grid(256), kHeavyThreads, 0, st>>>(ep);
                     break;
                 case 5:
-                    extend_arms_kernel<SlotT, kMidArmsLayers<SlotT>, 512, kHitBatch, 1024, 4, false, true><<<grid(256 * 2), 512, 0, st>>>(ep);
+                    if (fast_tier(5))
+                        extend_fast_kernel<SlotT, kMidArmsLayers<SlotT>, 512, kHitBatch, 1024, 2><<<grid(256 * 2), 512, 0, st>>>(ep);
+                    else
+                        extend_arms_kernel<SlotT, kMidArmsLayers<SlotT>, 512, kHitBatch, 1024, 4, false, true><<<grid(256 * 2), 512, 0, st>>>(ep);
                     break;
                 case 6:
                     if (scratch_override) ep.scratch = scratch_override;
