@@ -343,11 +343,11 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
         if (arms_kernel) {
             if (arms_small) {
                 tier_cap[2] = (uint32_t)kWaveArmsLayers<SlotT> * 64u;
-                tier_cap[4] = (uint32_t)kMidArmsLayers<SlotT> * 256u;
+                tier_cap[4] = (uint32_t)((uint64_t)kMidArmsLayers<SlotT> * 256u * (uint64_t)opt.cap45_pct / 100u);
             }
             tier_cap[3] = (uint32_t)(fast_tier(3) ? kFastLongLayers<SlotT> : kLongArmsLayers<SlotT>) * 1024u;
 
-            tier_cap[5] = (uint32_t)kMidArmsLayers<SlotT> * 512u;
+            tier_cap[5] = (uint32_t)((uint64_t)kMidArmsLayers<SlotT> * 512u * (uint64_t)opt.cap45_pct / 100u);
             // the window bound is pessimistic for tandem arrays (hits extend arms there) and the HBM
             // tier is several times slower per probe: tier 6 also takes segments whose bound exceeds
             // its capacity by up to 40 % (a real overflow falls through the cascade)

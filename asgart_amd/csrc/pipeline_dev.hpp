@@ -910,7 +910,7 @@ constexpr uint32_t kTombstone = 0xFFFFFFFFu;
 #define PROF_DECL unsigned long long pf_t0 = 0, pf_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define PROF_START() pf_t0 = __builtin_amdgcn_s_memtime()
 #define PROF_STOP(slot) pf_acc[slot] += __builtin_amdgcn_s_memtime() - pf_t0
-#define PROF_COUNT(slot, v) pf_acc[slot] += ((slot) == 1 || (slot) == 10 || (slot) == 11 || (slot) == 5 && 0 ? 0 : (v))
+#define PROF_COUNT(slot, v) pf_acc[slot] += (v)  // (slots 10, 11: sums of live arms and hits over the hit-probes)
 #define PROF_MAX(slot, v) pf_acc[slot] = pf_acc[slot] > (unsigned long long)(v) ? pf_acc[slot] : (unsigned long long)(v)
 #define PROF_SEG_BEGIN() const unsigned long long pf_seg0 = __builtin_amdgcn_s_memtime()
 #define PROF_FLUSH()                                                             \

@@ -1,2 +1,2 @@
 mkdir -p gpurun_out/r3
-timeout 2400 python -m pytest tests -x -q -m gpu > gpurun_out/r3/gpu_tests.log 2>&1; echo "rc=$?" >> gpurun_out/r3/gpu_tests.log
+ASGART_LIB=asgart_amd/libasgart_hip_diag.so timeout 1200 python tools/diag_cfg.py cfg4 > gpurun_out/r3/diag_cfg4.log 2>&1
