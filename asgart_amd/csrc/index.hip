@@ -63,6 +63,7 @@ const OptDesc kOptions[] = {
     {"fast_nt", &Options::fast_nt, 256, 1024},
     {"cap3_pct", &Options::cap3_pct, 100, 400},
     {"cap45_pct", &Options::cap45_pct, 100, 800},
+    {"fast6w", &Options::fast6w, 0, 1},
     {"shard_lpt", &Options::shard_lpt, 0, 1},
     {"posbits", &Options::posbits, 0, 1},
     {"fast_bsh", &Options::fast_bsh, 0, 3},

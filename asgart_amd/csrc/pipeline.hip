@@ -72,6 +72,7 @@ constexpr uint64_t kGrid2Arms = 256ull * 8ull;
 template <class SlotT> constexpr int kLongArmsLayers = sizeof(SlotT) == 4 ? 5 : 2;  // tier 3: 5 x 1024 arms
 // ... of the one-barrier kernel (option fast, extend_fast_dev.hpp): 5 x 1024 / 2 x 1024 arm slots
 template <class SlotT> constexpr int kFastLongLayers = sizeof(SlotT) == 4 ? 5 : 2;
+template <class SlotT> constexpr int kFastHeavyLayers = sizeof(SlotT) == 4 ? 5 : 4;  // tier 6
 constexpr int kPoleLdsPad = 0;             // > 0: tier 3 workgroups take a whole CU (measured: no gain)
 constexpr int kArmCapSmall = 256;   // live arms per wave in LDS, common case
 constexpr uint32_t kTier1MaxSum = 20000;  // placement: busier segments never run on a single wave
@@ -336,7 +337,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
         const bool arms_small = arms_kernel && rp.C <= (uint64_t)kWaveArmsHits;
         // the two-barrier kernel packs a 64-bit position into 42 bits of a table entry
         auto fast_tier = [&](int t) {
-            if (t == 6 && sizeof(SlotT) == 8) return false;  // (2 x 1024 slots would be fewer than K4c's 8 x 512)
+            if (t == 6 && sizeof(SlotT) == 8 && !opt.fast6w) return false;
             return arms_kernel && ((opt.fast >> t) & 1) != 0 && (uint64_t)idx->n < (1ull << 42);
         };
         uint32_t tier_cap[kTiers + 1] = {0, kArmCapSmall, 0, 0, 0, 0, 0, 0xFFFFFFFFu};  // (tier 7 takes whatever is left)
@@ -351,7 +352,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             // the window bound is pessimistic for tandem arrays (hits extend arms there) and the HBM
             // tier is several times slower per probe: tier 6 also takes segments whose bound exceeds
             // its capacity by up to 40 % (a real overflow falls through the cascade)
-            tier_cap[6] = (uint32_t)((uint64_t)(fast_tier(6) ? kFastLongLayers<SlotT> * 1024 : kArmsLayers<SlotT> * kHeavyThreads) *
+            tier_cap[6] = (uint32_t)((uint64_t)(fast_tier(6) ? kFastHeavyLayers<SlotT> * 1024 : kArmsLayers<SlotT> * kHeavyThreads) *
                                      (uint64_t)opt.cap6_pct / 100u);
             // tier 3 accepts what tier 6 would accept by the bound (a long segment is no less safe there), but
             // never more than the same allowance over its own capacity (with 64-bit positions it holds fewer
@@ -586,8 +587,8 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                     break;
                 case 6:
                     if (scratch_override) ep.scratch = scratch_override;
-                    if (fast_tier(6))  // the shape of tier 3: a fifth fewer cycles per probe than K4c, 5 x 1024 >= 9 x 512 slots
-                        extend_fast_kernel<SlotT, kFastLongLayers<SlotT>, 1024, kHitBatch, 2048, 2><<<grid(256), 1024, 0, st>>>(ep);
+                    if (fast_tier(6))  // 5 x 1024 >= 9 x 512 slots; 64-bit positions: 4 x 1024 = 8 x 512 with a smaller table
+                        extend_fast_kernel<SlotT, kFastHeavyLayers<SlotT>, 1024, kHitBatch, (sizeof(SlotT) == 4 ? 2048 : 1024), 2><<<grid(256), 1024, 0, st>>>(ep);
                     else if (arms_kernel)
                         extend_arms_kernel<SlotT, kArmsLayers<SlotT>, kHeavyThreads, kHitBatch, 1024, 4, false, kArmsCold<SlotT>><<<grid(256), kHeavyThreads, 0, st>>>(ep);
                     else
