@@ -56,6 +56,20 @@ __device__ inline uint32_t wave_incl_scan(uint32_t x) {
     return x;
 }
 
+// minimum across the 64 lanes of a wave (same DPP steps as the scan; the result is wave-uniform)
+__device__ inline uint32_t wave_min_u32(uint32_t x) {
+#define ASGART_DPP_MIN(ctrl, rows) \
+    x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)x, ctrl, rows, 0xf, false))
+    ASGART_DPP_MIN(0x111, 0xf);
+    ASGART_DPP_MIN(0x112, 0xf);
+    ASGART_DPP_MIN(0x114, 0xf);
+    ASGART_DPP_MIN(0x118, 0xf);
+    ASGART_DPP_MIN(0x142, 0xa);
+    ASGART_DPP_MIN(0x143, 0xc);
+#undef ASGART_DPP_MIN
+    return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
+
 // position of the n-th (0-based) set bit of m; n < popcount(m)
 __device__ inline uint32_t select_bit(unsigned long long m, uint32_t n) {
     uint32_t word = (uint32_t)m, pos = 0;
@@ -111,6 +125,13 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
     // family, spur horizon): wave 0 publishes it after each B; a wave that skipped the hit ranking of a probe (it could
     // not be concerned: see phase B) re-reads it before the next B it takes part in.
     __shared__ __attribute__((aligned(16))) uint32_t s_pub[2][4];
+    __shared__ uint32_t s_solo_a[2];  // live arms after a probe that wave 0 ran alone (see solo_probe); alternating
+    const uint32_t kSoloHits = min(16u, P.solo_hits);  // option solo (0: never)
+    // arms that move to wave 0's first layer when few are left (migrate below): their fields in transit
+    constexpr uint32_t kMigMax = 48;
+    __shared__ PosT s_x_ls[kMigMax], s_x_re[kMigMax], s_x_le[kMigMax], s_x_rs[kMigMax];
+    __shared__ uint32_t s_x_thr[kMigMax], s_x_gap[kMigMax], s_x_seq[kMigMax];
+    __shared__ uint32_t s_mig[NW][8];  // per (wave, layer): live arms, for the migration
     __shared__ uint32_t s_sink[64];  // per lane: where the atomicMin of a lane with nothing to offer goes
     __shared__ uint32_t s_never;     // == kNever
 
@@ -171,6 +192,12 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
         uint32_t quiet = 0, pend = 0, fam_seq = 0, next_seq = 0, t_proc = 0, spur_until = 0;
         bool overflow = false, done = false, fam_open = false;
         bool ran_full = true;  // this wave took part in the previous probe's hit ranking (its bookkeeping is current)
+        // "solo" probes: while every live arm sits in wave 0's first layer and a probe's few hits cannot overfill it,
+        // wave 0 runs the probe alone, in registers (solo_probe below): solo_w0 / solo_a are what every wave knows
+        bool solo_w0 = true;   // every live arm is in (wave 0, layer 0)
+        uint32_t solo_a = 0;   // upper bound on the live arms
+        uint32_t solo_par = 0;
+        bool want_migrate = false;  // few arms are left and some sit outside (wave 0, layer 0): see migrate
 
         auto emit_records = [&](bool emit, PosT ls, PosT le, PosT rs, PosT re, uint32_t seq) {
             const unsigned long long em = __ballot(emit);
@@ -533,7 +560,176 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
                     *reinterpret_cast<uint4 *>(&s_pub[q.tb][0]) = make_uint4(next_seq, fam_seq, 1u, spur_until);
             }
             ran_full = full;
+            {   // what the next probe can count on (every wave: from the free counts and cnt alone)
+                const uint32_t free00 = lane_of(fv, 0u);  // empty slots of (layer 0, wave 0)
+                solo_w0 = total_free - free00 == (uint32_t)CAP - 64u && cnt <= free00;  // (the new arms fit there too)
+                solo_a = 64u - free00 + cnt;
+                want_migrate = kSoloHits != 0u && !use_flag && !solo_w0 && A0 + cnt <= 40u;  // (few arms, some astray)
+            }
             PROF_STOP(7);
+        };
+
+        // ---- migration: when few arms are left but some sit outside (wave 0, layer 0) -- a burst of a dense repeat is
+        // over and, say, the one long arm of a pair of homologous chromosomes was created in wave 5 -- they move there,
+        // so that the sparse stretch that follows runs as solo probes.  Two barriers, once per burst.
+        auto migrate = [&]() {
+            uint32_t lv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int L = 0; L < S; ++L) lv[L] = (uint32_t)__popcll(__ballot(a_seq[L] != kNoSeq));
+            *reinterpret_cast<uint4 *>(&s_mig[wave][0]) = make_uint4(lv[0], lv[1], lv[2], lv[3]);
+            if constexpr (S > 4) *reinterpret_cast<uint4 *>(&s_mig[wave][4]) = make_uint4(lv[4], lv[5], lv[6], lv[7]);
+            lds_barrier();
+            // movers ranked (layer, wave, lane); the pair (0, 0) stays
+            uint32_t mv = lane < S * NW ? s_mig[lane % NW][lane / NW] : 0u;
+            const uint32_t here = lane_of(mv, 0u);  // live arms already in place
+            if (lane == 0) mv = 0u;
+            const uint32_t mv2 = S * NW > 64 && lane + 64 < S * NW ? s_mig[(lane + 64) % NW][(lane + 64) / NW] : 0u;
+            const uint32_t mincl = wave_incl_scan(mv);
+            uint32_t n_mov = lane_of(mincl, 63u);
+            uint32_t mincl2 = 0;
+            if constexpr (S * NW > 64) {
+                mincl2 = wave_incl_scan(mv2) + n_mov;
+                n_mov = lane_of(mincl2, 63u);
+            }
+            const bool go = n_mov > 0u && n_mov <= kMigMax && here + n_mov <= 64u;  // (the same in every wave)
+            if (tid == 0) DBG_ADD(go ? 5 : 6, 1);
+            if (go) {
+#pragma unroll
+                for (int L = 0; L < S; ++L) {
+                    if (L == 0 && wave == 0u) continue;
+                    const bool live = a_seq[L] != kNoSeq;
+                    const unsigned long long lm = __ballot(live);
+                    if (!lm) continue;
+                    const uint32_t base = L * NW < 64 ? lane_of(mincl - mv, (uint32_t)(L * NW) + wave)
+                                                      : lane_of(mincl2 - mv2, (uint32_t)(L * NW - 64) + wave);
+                    if (live) {
+                        const uint32_t r = base + (uint32_t)__popcll(lm & lt_mask);
+                        s_x_ls[r] = a_ls[L];
+                        s_x_re[r] = a_re[L];
+                        s_x_le[r] = s_cle[L * NT + tid];
+                        s_x_rs[r] = s_crs[L * NT + tid];
+                        s_x_thr[r] = a_thr[L];
+                        s_x_gap[r] = a_gap[L];
+                        s_x_seq[r] = a_seq[L];
+                        a_seq[L] = kNoSeq;
+                    }
+                    livemask &= ~(1u << L);
+                }
+            }
+            lds_barrier();
+            if (go) {
+                if (wave == 0u) {
+                    const bool is_free = a_seq[0] == kNoSeq;
+                    const unsigned long long fmask = __ballot(is_free);
+                    const uint32_t r = (uint32_t)__popcll(fmask & lt_mask);
+                    const bool take = is_free && r < n_mov;
+                    const uint32_t rr = take ? r : 0u;
+                    a_ls[0] = take ? s_x_ls[rr] : a_ls[0];
+                    a_re[0] = take ? s_x_re[rr] : a_re[0];
+                    a_thr[0] = take ? s_x_thr[rr] : a_thr[0];
+                    a_gap[0] = take ? s_x_gap[rr] : a_gap[0];
+                    a_seq[0] = take ? s_x_seq[rr] : a_seq[0];
+                    if (take) {
+                        s_cle[tid] = s_x_le[rr];
+                        s_crs[tid] = s_x_rs[rr];
+                    }
+                    livemask |= 1u;
+                }
+                solo_w0 = true;
+                solo_a = here + n_mov;
+            }
+            want_migrate = false;
+        };
+
+        // ---- a probe run by wave 0 alone: every live arm is one of its 64 layer-0 slots, the hits are few ----------
+        // Same transitions as A + B (src/automaton.rs:96-200), without the table: every hit is tested against the 64
+        // arms at once (ballot), its arm is the accepting one with the smallest creation number (DPP minimum), the
+        // last hit an arm wins extends it, the unmatched hits take the empty lanes in hit order.
+        auto solo_probe = [&](const Probe &q) {
+            const uint32_t cnt = q.cnt, off = q.off;
+            const uint64_t i = q.i;
+            bool live = a_seq[0] != kNoSeq;
+            if (pend) {  // the quiet probes since the last hit-probe: src/automaton.rs:166-171
+                const uint64_t sum_g = (uint64_t)a_gap[0] + pend;
+                const uint32_t aged = sum_g > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)sum_g;
+                const bool dead = live && aged >= G;
+                a_gap[0] = aged;
+                if (__ballot(dead)) {
+                    const PosT rs = s_crs[tid];
+                    const bool report = dead && (uint64_t)(a_re[0] - rs) >= rp.M;
+                    if (__ballot(report)) emit_records(report, a_ls[0], s_cle[tid], rs, a_re[0], a_seq[0]);
+                }
+                a_seq[0] = dead ? kNoSeq : a_seq[0];
+                live = live && !dead;
+            }
+            if (fam_open && !__ballot(live) && q.t_before >= spur_until) {  // the flush of src/automaton.rs:182-200
+                ++fam_seq;
+                next_seq = 0;
+                fam_open = false;
+            }
+            const PosT lo = (PosT)(a_re[0] - k + 1u);
+            const WinT w = live ? (WinT)a_thr[0] + (WinT)(k - 1u) : (WinT)0;
+            const PosT x_l = (uint32_t)lane < cnt ? s_hits[off + lane] : (PosT)0;  // lane j holds hit j (cnt <= kSoloHits)
+            uint32_t ext = 0;               // 1 + the last hit this arm won
+            unsigned long long newm = 0;    // unmatched hits
+            for (uint32_t j = 0; j < cnt; ++j) {
+                PosT x;
+                if constexpr (kWidePos) x = (PosT)lane_of((unsigned long long)x_l, j);
+                else x = (PosT)lane_of((uint32_t)x_l, j);
+                const bool ok = (WinT)(PosT)(x - lo) < w;
+                if (__ballot(ok)) {
+                    const uint32_t first = wave_min_u32(ok ? a_seq[0] : 0xFFFFFFFFu);  // first arm in list order (:67-78)
+                    ext = (ok && a_seq[0] == first) ? j + 1u : ext;
+                } else {
+                    newm |= 1ull << j;
+                }
+            }
+            const bool won = ext != 0u;
+            const PosT xw = s_hits[off + (won ? ext - 1u : 0u)];
+            uint32_t thr_new;
+            if constexpr (kWidePos) thr_new = arm_threshold((uint64_t)(i + k) - (uint64_t)a_ls[0], G);
+            else thr_new = max(G, ((uint32_t)(i + k) - (uint32_t)a_ls[0]) / 10u);
+            const uint64_t sum_g = (uint64_t)a_gap[0] + step;
+            const uint32_t aged = sum_g > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)sum_g;
+            a_re[0] = won ? (PosT)(xw + k) : a_re[0];
+            if (won) s_cle[tid] = (PosT)(i + k);
+            a_thr[0] = won ? thr_new : a_thr[0];
+            a_gap[0] = won ? 0u : aged;
+            const bool dead = live && !won && aged >= G;
+            if (__ballot(dead)) {
+                const PosT rs = s_crs[tid];
+                const bool report = dead && (uint64_t)(a_re[0] - rs) >= rp.M;
+                if (__ballot(report)) emit_records(report, a_ls[0], s_cle[tid], rs, a_re[0], a_seq[0]);
+            }
+            a_seq[0] = dead ? kNoSeq : a_seq[0];
+            // NewArm (src/automaton.rs:151-164): the r-th empty lane takes the r-th unmatched hit
+            const uint32_t n_new = (uint32_t)__popcll(newm);
+            if (n_new) {
+                const bool is_free = a_seq[0] == kNoSeq;
+                const unsigned long long fmask = __ballot(is_free);
+                const uint32_t r = (uint32_t)__popcll(fmask & lt_mask);
+                const bool take = is_free && r < n_new;  // (n_new <= empty lanes: solo_a + cnt <= 64 was checked)
+                const uint32_t hsel = select_bit(newm, take ? r : 0u);
+                const PosT x = s_hits[off + (take ? hsel : 0u)];
+                a_ls[0] = take ? (PosT)i : a_ls[0];
+                if (take) {
+                    s_cle[tid] = (PosT)(i + k);
+                    s_crs[tid] = x;
+                }
+                a_re[0] = take ? (PosT)(x + k) : a_re[0];
+                a_gap[0] = take ? step : a_gap[0];
+                a_thr[0] = take ? thr0 : a_thr[0];
+                a_seq[0] = take ? next_seq + r : a_seq[0];
+            }
+            next_seq += n_new;
+            fam_open = true;
+            const uint32_t a_now = (uint32_t)__popcll(__ballot(a_seq[0] != kNoSeq));
+            livemask = (livemask & ~1u) | (a_now ? 1u : 0u);
+            // (every lane, same words) what the other waves need: the live count, and the bookkeeping for their next B
+            s_solo_a[solo_par] = a_now;
+            const uint4 pv = make_uint4(next_seq, fam_seq, 1u, spur_until);
+            *reinterpret_cast<uint4 *>(&s_pub[0][0]) = pv;
+            *reinterpret_cast<uint4 *>(&s_pub[1][0]) = pv;
         };
 
         bool staged_before = false;
@@ -610,10 +806,32 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
                     phase_b(prev);
                     have_prev = false;
                     if (overflow) break;
+                    if (want_migrate) migrate();
                 }
                 if (!have_cur) break;
                 PROF_COUNT(5, 1);
                 PROF_COUNT(11, cur.cnt);
+                if (solo_w0 && !use_flag && cur.cnt <= kSoloHits && solo_a + cur.cnt <= 64u) {
+                    // wave 0 alone; the others wait for its count at the barrier and will re-read the bookkeeping
+                    if (pre_indexed) {  // (this probe was indexed ahead for nothing: forget its stash)
+                        if (tid == 0) s_nstash[tri] = 0u;
+                        pre_indexed = false;
+                    }
+                    if (wave == 0u) solo_probe(cur);
+                    else ran_full = false;
+                    if (tid == 0) DBG_ADD(0, 1);  // (diagnostic build: probes run solo)
+                    pend = 0;
+                    lds_barrier();
+                    solo_a = uni(s_solo_a[solo_par]);
+                    solo_par ^= 1u;
+                    continue;
+                }
+                if (tid == 0) {  // (diagnostic build: probes run by the workgroup, and why not solo)
+                    DBG_ADD(1, 1);
+                    if (!solo_w0) DBG_ADD(2, 1);
+                    else if (cur.cnt > kSoloHits) DBG_ADD(3, 1);
+                    else DBG_ADD(4, 1);
+                }
                 PROF_START();
                 if (!pre_indexed) {
                     if (++gen >> kGenBits) {  // generation wrap: clear the tables once
@@ -655,6 +873,7 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
                     phase_b(cur);
                     if (overflow) break;
                     lds_barrier();
+                    if (want_migrate) migrate();
                 }
             }
             if (overflow) break;

@@ -64,6 +64,8 @@ const OptDesc kOptions[] = {
     {"cap3_pct", &Options::cap3_pct, 100, 400},
     {"cap45_pct", &Options::cap45_pct, 100, 800},
     {"fast6w", &Options::fast6w, 0, 1},
+    {"cap6w_pct", &Options::cap6w_pct, 100, 400},
+    {"solo", &Options::solo, 0, 1},
     {"shard_lpt", &Options::shard_lpt, 0, 1},
     {"posbits", &Options::posbits, 0, 1},
     {"fast_bsh", &Options::fast_bsh, 0, 3},

@@ -208,7 +208,9 @@ struct Options {
     int64_t fast_bsh = 0;           // its bucket width: 2^fast_bsh times the smallest power of two >= max_gap_size + k
     int64_t fast_pipe = 1;          // experiments: 1 = one barrier per hit-probe (B of probe t-1 runs beside A of probe t)
     int64_t fast_e = 2;             // experiments: entries per table row (2 / 4)
-    int64_t fast6w = 0;             // 64-bit positions: 1 = tier 6 on the one-barrier kernel (4 x 1024 slots) instead of K4c 8 x 512 (measured at cfg5: direct pass 7.0 -> 8.1 s, off)
+    int64_t solo = 1;               // one-barrier kernel: sparse probes run on wave 0 alone, in registers (see solo_probe)
+    int64_t fast6w = 1;             // 64-bit positions: tier 6 on the one-barrier kernel (4 x 1024 slots) instead of K4c 8 x 512
+    int64_t cap6w_pct = 160;        // ... which then accepts segments whose arm bound is up to this percentage of its capacity
     int64_t cap45_pct = 100;        // tiers 4 and 5 accept segments whose arm bound is up to this percentage of their capacity (what overflows is re-run)
     int64_t cap3_pct = 160;         // tier 3 with the one-barrier kernel accepts segments whose arm bound is up to this percentage of its capacity
     int64_t posbits = 1;            // 1: the presence filter's answers are also laid out by text position (index build) and the search reads those

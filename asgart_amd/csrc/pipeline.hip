@@ -71,8 +71,9 @@ constexpr int kWaveArmsHits = 512;
 constexpr uint64_t kGrid2Arms = 256ull * 8ull;
 template <class SlotT> constexpr int kLongArmsLayers = sizeof(SlotT) == 4 ? 5 : 2;  // tier 3: 5 x 1024 arms
 // ... of the one-barrier kernel (option fast, extend_fast_dev.hpp): 5 x 1024 / 2 x 1024 arm slots
-template <class SlotT> constexpr int kFastLongLayers = sizeof(SlotT) == 4 ? 5 : 2;
+template <class SlotT> constexpr int kFastLongLayers = sizeof(SlotT) == 4 ? 5 : 4;   // (64-bit positions: 4 x 1024, a smaller table)
 template <class SlotT> constexpr int kFastHeavyLayers = sizeof(SlotT) == 4 ? 5 : 4;  // tier 6
+template <class SlotT> constexpr int kFastLongRows = sizeof(SlotT) == 4 ? 2048 : 1024;
 constexpr int kPoleLdsPad = 0;             // > 0: tier 3 workgroups take a whole CU (measured: no gain)
 constexpr int kArmCapSmall = 256;   // live arms per wave in LDS, common case
 constexpr uint32_t kTier1MaxSum = 20000;  // placement: busier segments never run on a single wave
@@ -352,8 +353,12 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             // the window bound is pessimistic for tandem arrays (hits extend arms there) and the HBM
             // tier is several times slower per probe: tier 6 also takes segments whose bound exceeds
             // its capacity by up to 40 % (a real overflow falls through the cascade)
+            // (64-bit positions on the one-barrier kernel: the HBM tier is an order of magnitude slower per probe and the
+            // bound three to four times what a segment really holds -- at cfg5 every segment that went to tier 7 by its
+            // bound peaked below 4 096 arms: tier 6 accepts up to cap6w_pct of its capacity)
+            const uint64_t pct6 = (fast_tier(6) && sizeof(SlotT) == 8) ? (uint64_t)opt.cap6w_pct : (uint64_t)opt.cap6_pct;
             tier_cap[6] = (uint32_t)((uint64_t)(fast_tier(6) ? kFastHeavyLayers<SlotT> * 1024 : kArmsLayers<SlotT> * kHeavyThreads) *
-                                     (uint64_t)opt.cap6_pct / 100u);
+                                     pct6 / 100u);
             // tier 3 accepts what tier 6 would accept by the bound (a long segment is no less safe there), but
             // never more than the same allowance over its own capacity (with 64-bit positions it holds fewer
             // arms than tier 6, and what it gives up on is re-run from the start)
@@ -504,6 +509,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             ep.max_items = 0;
             ep.fast_bsh = (uint32_t)opt.fast_bsh;
             ep.heavy_cap = (uint32_t)heavy_cap64;
+            ep.solo_hits = opt.solo ? 16u : 0u;
             ep.n_levels = (uint32_t)opt.test_levels;
             ep.gen_bits = (uint32_t)opt.test_genbits;
             ep.ctr = d_ctr;
@@ -565,7 +571,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                     if (fast_tier(3)) {
                         // (the same capacity in three shapes: per-probe work every wave repeats -- ranking the
                         // empty slots and the unmatched hits -- is paid once per wave sharing a SIMD)
-                        extend_fast_kernel<SlotT, kFastLongLayers<SlotT>, 1024, kHitBatch, 2048, 2><<<grid(256), 1024, 0, st>>>(ep);
+                        extend_fast_kernel<SlotT, kFastLongLayers<SlotT>, 1024, kHitBatch, kFastLongRows<SlotT>, 2><<<grid(256), 1024, 0, st>>>(ep);
                     } else
                         extend_arms_kernel<SlotT, kLongArmsLayers<SlotT>, 1024, kHitBatch, 1024, 4, false, true, kPoleLdsPad><<<grid(256), 1024, 0, st>>>(ep);
                     break;
@@ -588,7 +594,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                 case 6:
                     if (scratch_override) ep.scratch = scratch_override;
                     if (fast_tier(6))  // 5 x 1024 >= 9 x 512 slots; 64-bit positions: 4 x 1024 = 8 x 512 with a smaller table
-                        extend_fast_kernel<SlotT, kFastHeavyLayers<SlotT>, 1024, kHitBatch, (sizeof(SlotT) == 4 ? 2048 : 1024), 2><<<grid(256), 1024, 0, st>>>(ep);
+                        extend_fast_kernel<SlotT, kFastHeavyLayers<SlotT>, 1024, kHitBatch, kFastLongRows<SlotT>, 2><<<grid(256), 1024, 0, st>>>(ep);
                     else if (arms_kernel)
                         extend_arms_kernel<SlotT, kArmsLayers<SlotT>, kHeavyThreads, kHitBatch, 1024, 4, false, kArmsCold<SlotT>><<<grid(256), kHeavyThreads, 0, st>>>(ep);
                     else

@@ -976,6 +976,7 @@ struct ExtParams {
     uint32_t max_items;                   // work-list fetches per workgroup before it retires (0: until the list is empty)
     uint32_t fast_bsh;                    // K6: log2 of the bucket width beyond the smallest power of two >= G + k
     uint32_t heavy_cap;                   // K4b MODE 2 (tier 7): arm slots per workgroup in its HBM slice
+    uint32_t solo_hits;                   // K6: probes with up to this many hits may run on wave 0 alone (0: never)
     unsigned long long *ctr;
 };
 

@@ -13,6 +13,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu via gpurun)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """A test that hangs (a kernel that never returns, a lost rendezvous) fails with the stacks of every thread
+    instead of stalling the run: pytest-timeout, when it is installed, bounds each test."""
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for item in items:
+        if item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(900))
+
+
 @pytest.fixture(scope="session")
 def hiplib():
     """The product library.  GPU tests must exercise it, never a fallback."""
