@@ -125,7 +125,9 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
     // family, spur horizon): wave 0 publishes it after each B; a wave that skipped the hit ranking of a probe (it could
     // not be concerned: see phase B) re-reads it before the next B it takes part in.
     __shared__ __attribute__((aligned(16))) uint32_t s_pub[2][4];
-    __shared__ uint32_t s_solo_a[2];  // live arms after a probe that wave 0 ran alone (see solo_probe); alternating
+    // after a run of probes that wave 0 went through alone (see solo_probe): position in the batch, probes processed,
+    // live arms; alternating
+    __shared__ __attribute__((aligned(16))) uint32_t s_run[2][4];
     const uint32_t kSoloHits = min(16u, P.solo_hits);  // option solo (0: never)
     // arms that move to wave 0's first layer when few are left (migrate below): their fields in transit
     constexpr uint32_t kMigMax = 48;
@@ -645,7 +647,7 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
         // Same transitions as A + B (src/automaton.rs:96-200), without the table: every hit is tested against the 64
         // arms at once (ballot), its arm is the accepting one with the smallest creation number (DPP minimum), the
         // last hit an arm wins extends it, the unmatched hits take the empty lanes in hit order.
-        auto solo_probe = [&](const Probe &q) {
+        auto solo_probe = [&](const Probe &q) -> uint32_t {
             const uint32_t cnt = q.cnt, off = q.off;
             const uint64_t i = q.i;
             bool live = a_seq[0] != kNoSeq;
@@ -725,14 +727,13 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
             fam_open = true;
             const uint32_t a_now = (uint32_t)__popcll(__ballot(a_seq[0] != kNoSeq));
             livemask = (livemask & ~1u) | (a_now ? 1u : 0u);
-            // (every lane, same words) what the other waves need: the live count, and the bookkeeping for their next B
-            s_solo_a[solo_par] = a_now;
-            const uint4 pv = make_uint4(next_seq, fam_seq, 1u, spur_until);
-            *reinterpret_cast<uint4 *>(&s_pub[0][0]) = pv;
-            *reinterpret_cast<uint4 *>(&s_pub[1][0]) = pv;
+            return a_now;
         };
 
         bool staged_before = false;
+        // (Loading the next batch's per-probe words and hit rows ahead, in registers, was measured: the 1024-thread
+        // shapes sit at their 128-register cap, the extra live values spill inside the probe loop, and the tandem
+        // array went from 78 to 86 ms while the two-genome pass did not move.)
         for (uint32_t g = g0; g < g_end && !done;) {
             // ---- stage a batch of up to 64 probes (every wave computes the same masks) ----
             PROF_START();
@@ -752,17 +753,16 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
                 break;
             }
             const uint32_t rel_l = (uint32_t)(r_l - base);
-            if (staged_before) lds_barrier();  // (the last B of the previous batch read the staged hits)
-            staged_before = true;
-            {
-                const unsigned long long end = nbb == nb ? r_hi : lane_of(r_l, nbb);
-                const uint32_t tot = (uint32_t)(end - base);
+            const uint32_t tot = (uint32_t)((nbb == nb ? r_hi : lane_of(r_l, nbb)) - base);
+            if (tot) {  // (a batch of quiet probes stages nothing and needs no barrier)
+                if (staged_before) lds_barrier();  // (the last B of the previous batch read the staged hits)
+                staged_before = true;
                 for (uint32_t r = tid; r < tot; r += NT) {
                     s_hits[r] = P.hits[base + r];
                     if (use_flag) s_hflag[r] = P.hit_flag[base + r];
                 }
+                lds_barrier();
             }
-            lds_barrier();
             const unsigned long long in_batch = nbb >= 64 ? ~0ull : ((1ull << nbb) - 1ull);
             const unsigned long long hm = __ballot(f_l >= 1u && f_l < kPending) & in_batch;
             const unsigned long long qm = __ballot(f_l == 0u) & in_batch;
@@ -817,12 +817,49 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
                         if (tid == 0) s_nstash[tri] = 0u;
                         pre_indexed = false;
                     }
-                    if (wave == 0u) solo_probe(cur);
-                    else ran_full = false;
-                    if (tid == 0) DBG_ADD(0, 1);  // (diagnostic build: probes run solo)
+                    if (wave == 0u) {
+                        uint32_t a_now = solo_probe(cur);
+                        if (lane == 0) DBG_ADD(0, 1);  // (diagnostic build: probes run solo)
+                        // ... and goes on through the staged batch, without a barrier, while the next hit-probe is as
+                        // sparse (the same accounting of the quiet probes in between as at the top of this loop)
+                        for (;;) {
+                            const unsigned long long hmr = pos >= 64 ? 0ull : (hm >> pos) << pos;
+                            if (!hmr) break;
+                            const uint32_t b = (uint32_t)(__ffsll((long long)hmr) - 1);
+                            const unsigned long long span = ((1ull << b) - 1ull) & ~((1ull << pos) - 1ull);
+                            const uint32_t q = (uint32_t)__popcll(qm & span);
+                            if (q >= rp.tstar) break;  // (the segment ends there: left to the workgroup)
+                            const uint32_t cnt2 = lane_of(f_l, b);
+                            if (cnt2 > kSoloHits || a_now + cnt2 > 64u) break;
+                            t_proc += q;
+                            pend = q * step;
+                            Probe nx{0, 0, 0, 0, 0, 0, 0};
+                            nx.cnt = cnt2;
+                            nx.off = lane_of(rel_l, b);
+                            nx.i = (uint64_t)(g + b - pb + 1) * step;
+                            nx.t_before = t_proc;
+                            nx.t_after = ++t_proc;
+                            pos = b + 1;
+                            a_now = solo_probe(nx);
+                            if (lane == 0) DBG_ADD(0, 1);
+                        }
+                        // (every lane, same words) what the other waves need: how far this went, the live count, and
+                        // the bookkeeping for their next B
+                        *reinterpret_cast<uint4 *>(&s_run[solo_par][0]) = make_uint4(pos, t_proc, a_now, 0u);
+                        const uint4 pv = make_uint4(next_seq, fam_seq, 1u, spur_until);
+                        *reinterpret_cast<uint4 *>(&s_pub[0][0]) = pv;
+                        *reinterpret_cast<uint4 *>(&s_pub[1][0]) = pv;
+                    } else {
+                        ran_full = false;
+                    }
                     pend = 0;
                     lds_barrier();
-                    solo_a = uni(s_solo_a[solo_par]);
+                    {
+                        const uint4 rv = *reinterpret_cast<const uint4 *>(&s_run[solo_par][0]);
+                        pos = uni(rv.x);
+                        t_proc = uni(rv.y);
+                        solo_a = uni(rv.z);
+                    }
                     solo_par ^= 1u;
                     continue;
                 }

@@ -629,6 +629,10 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                 PROF_TIER(tag, tier_stream[tier], n_t[tier - 1]);
 #endif
             };
+            const auto t_launch = std::chrono::steady_clock::now();
+            auto since_launch = [&]() {
+                return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_launch).count();
+            };
             for (char c : tier_order) launch_tier(c - '0');
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(cx.ev[12], st7));
@@ -691,6 +695,9 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                         HIP_TRY(hipMemcpyAsync(h_scalar + 1 + e, d_ctr + CT_OVF1 + E.src - 1, 8, hipMemcpyDeviceToHost, s));
                         HIP_TRY(hipStreamSynchronize(s));
                         const uint64_t n_e = h_scalar[1 + e];
+                        if (opt.debug)
+                            fprintf(stderr, "[asgart] tier %d done %.1f ms after the launches, %llu segment(s) to re-run in tier %d\n",
+                                    E.src, since_launch(), (unsigned long long)n_e, E.dst);
                         if (!n_e) continue;
                         early_n[E.src] = n_e;
                         // the count the launch works on is fixed now (the list itself may still grow)
@@ -722,6 +729,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, kCtrBytes, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
             PROF_DUMP("concurrent tiers");
+            if (opt.debug) fprintf(stderr, "[asgart] all tiers and early re-runs done %.1f ms after the launches\n", since_launch());
             n_overflow = 0;
             for (int t = 1; t < kTiers; ++t) n_overflow += h_ctr[CT_OVF1 + t - 1];
             if (opt.debug) {
