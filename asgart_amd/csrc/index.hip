@@ -60,7 +60,6 @@ const OptDesc kOptions[] = {
     {"wg_items", &Options::wg_items, 0, 1 << 30},
     {"wg_items12", &Options::wg_items12, 0, 1 << 30},
     {"fast", &Options::fast, 0, 255},
-    {"fast_nt", &Options::fast_nt, 256, 1024},
     {"cap3_pct", &Options::cap3_pct, 100, 400},
     {"cap45_pct", &Options::cap45_pct, 100, 800},
     {"fast6w", &Options::fast6w, 0, 1},
@@ -69,8 +68,6 @@ const OptDesc kOptions[] = {
     {"shard_lpt", &Options::shard_lpt, 0, 1},
     {"posbits", &Options::posbits, 0, 1},
     {"fast_bsh", &Options::fast_bsh, 0, 3},
-    {"fast_e", &Options::fast_e, 2, 4},
-    {"fast_pipe", &Options::fast_pipe, 0, 1},
 };
 }  // namespace
 

@@ -13,6 +13,9 @@
 
 #include "common.hpp"
 
+#include <functional>
+#include <memory>
+#include <thread>
 #include <condition_variable>
 #include <mutex>
 
@@ -204,10 +207,7 @@ struct Options {
     int64_t early_cascade = 1;      // 1: tier 6's overflow is re-run as soon as tier 6 is done, not after the last tier
     int64_t cap6_pct = 140;         // tier 6 accepts segments whose arm bound is up to this percentage of its capacity
     int64_t fast = 124;             // bit t set (t = 2..6): tier t runs the one-barrier arm kernel (extend_fast_dev.hpp) instead of K4c
-    int64_t fast_nt = 1024;         // threads per workgroup of tier 3's two-barrier kernel (256 / 512 / 1024; capacity 4096 / 2048 arm slots)
     int64_t fast_bsh = 0;           // its bucket width: 2^fast_bsh times the smallest power of two >= max_gap_size + k
-    int64_t fast_pipe = 1;          // experiments: 1 = one barrier per hit-probe (B of probe t-1 runs beside A of probe t)
-    int64_t fast_e = 2;             // experiments: entries per table row (2 / 4)
     int64_t solo = 1;               // one-barrier kernel: sparse probes run on wave 0 alone, in registers (see solo_probe)
     int64_t fast6w = 1;             // 64-bit positions: tier 6 on the one-barrier kernel (4 x 1024 slots) instead of K4c 8 x 512
     int64_t cap6w_pct = 160;        // ... which then accepts segments whose arm bound is up to this percentage of its capacity
@@ -224,6 +224,54 @@ int32_t create_ctx_streams(SearchCtx &cx);
 int32_t build_rank_lists(const uint64_t *d_keys, const uint32_t *d_sa, uint64_t n, uint32_t *d_sap, hipStream_t s);  // the streams and events of one call context (current device)
 int32_t option_set(Options &o, const char *name, int64_t value);  // ASGART_E_ARG: unknown name / bad value
 void options_from_env(Options &o);
+}  // namespace asgart
+
+namespace asgart {
+// A host thread that lives as long as its index and runs one job at a time: the passes of
+// asgart_search_duplications_passes beyond the first (a thread's first HIP call sets up per-thread runtime state,
+// which a thread created per call would pay on every step).
+struct PassWorker {
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<void()> job;
+    bool busy = false, stop = false;
+    std::thread th;
+    PassWorker() : th([this] { loop(); }) {}
+    ~PassWorker() {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            stop = true;
+        }
+        cv.notify_all();
+        th.join();
+    }
+    void loop() {
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            cv.wait(lk, [&] { return stop || (busy && job); });
+            if (stop) return;
+            std::function<void()> j = std::move(job);
+            job = nullptr;
+            lk.unlock();
+            j();
+            lk.lock();
+            busy = false;
+            cv.notify_all();
+        }
+    }
+    void submit(std::function<void()> j) {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            job = std::move(j);
+            busy = true;
+        }
+        cv.notify_all();
+    }
+    void wait() {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return !busy; });
+    }
+};
 }  // namespace asgart
 
 struct asgart_index {
@@ -254,12 +302,14 @@ struct asgart_index {
     uint64_t tail_bloom = 0;
     std::vector<uint8_t> h_tail;  // last 64 bytes of the text (host copy)
     double ms_prepare = 0.0;
-    double tail_ms[4] = {-1.0, -1.0, -1.0, -1.0};  // per orientation (reverse * 2 + complement): extension time of its last unsharded call
+    double tail_ms[4] = {-1.0, -1.0, -1.0, -1.0};  // per orientation (reverse * 2 + complement): shortest extension time of an unsharded call so far
     asgart::Options opt;
     asgart::SearchCtx ctx[asgart::kNumCtx];
     int last_ctx = 0;  // context of the most recent search call (asgart_get_stats)
     std::mutex mu;
     std::condition_variable cv;
+    std::mutex pass_mu;  // one asgart_search_duplications_passes call at a time per index
+    std::vector<std::unique_ptr<asgart::PassWorker>> pass_workers;
 
     // one free context for a search call / all contexts for calls that change shared state
     asgart::SearchCtx &acquire_one(int *which) {

@@ -678,6 +678,14 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                                 (dst < kTiers || !n_t[kTiers - 1]);
                     n_pending += E.pending ? 1 : 0;
                 }
+                // (If tier 3's re-run went to tier 6, its kernel would append to tier 6's overflow list while the host
+                // snapshots that list's length for tier 6's own early re-run -- a count that may be ahead of the entry:
+                // such a re-run waits for the regular cascade below.  With the shipped shapes tier 6 never accepts
+                // more than tier 3 and the case does not arise.)
+                if (early[0].pending && early[1].pending && early[0].dst == early[1].src) {
+                    early[0].pending = false;
+                    --n_pending;
+                }
                 while (n_pending) {
                     bool progressed = false;
                     for (int e = 0; e < 2; ++e) {
@@ -903,7 +911,13 @@ int32_t run_search(asgart_index *idx, const uint64_t *chunks, int64_t n_chunks,
         rc = run_search_t<uint32_t>(idx, cx, chunks, n_chunks, st, shard, n_shards, want_csr, fam_out,
                                     status_out, rowoff_out, hits_out);
     cx.progress = nullptr;
-    if (rc == 0 && fam_out) idx->tail_ms[(st->reverse ? 2 : 0) | (st->complement ? 1 : 0)] = cx.stats.ms_extend;
+    if (rc == 0 && fam_out && n_shards == 1) {
+        // what asgart_search_duplications_passes orders by: the shortest extension seen for the orientation (a call
+        // that shared the chip with another one measures longer, and the order must not flip because of that)
+        std::lock_guard<std::mutex> lk(idx->mu);
+        double &t = idx->tail_ms[(st->reverse ? 2 : 0) | (st->complement ? 1 : 0)];
+        t = t < 0.0 ? cx.stats.ms_extend : std::min(t, cx.stats.ms_extend);
+    }
     idx->release_one(which);
     return rc;
 }
@@ -1075,9 +1089,10 @@ int32_t asgart_search_duplications_passes_shard(asgart_index *idx, const uint64_
             if (pr[c]) return true;
         return false;
     };
-    std::vector<std::thread> workers;
-    for (int32_t p = 0; p < n_passes; ++p)
-        workers.emplace_back([&, p]() {
+    // the first pass runs on the calling thread, the others on the index's own worker threads
+    std::lock_guard<std::mutex> pass_lock(idx->pass_mu);
+    while ((int32_t)idx->pass_workers.size() + 1 < n_passes) idx->pass_workers.emplace_back(new asgart::PassWorker());
+    auto body = [&](int32_t p) {
             if (p > 0)
                 while (!searched(p - 1)) std::this_thread::sleep_for(std::chrono::microseconds(100));
             const int32_t j = order[p];
@@ -1096,8 +1111,10 @@ int32_t asgart_search_duplications_passes_shard(asgart_index *idx, const uint64_
                 }
             }
             finished[p].store(1, std::memory_order_release);
-        });
-    for (auto &t : workers) t.join();
+    };
+    for (int32_t p = 1; p < n_passes; ++p) idx->pass_workers[(size_t)p - 1]->submit([&body, p]() { body(p); });
+    body(0);
+    for (int32_t p = 1; p < n_passes; ++p) idx->pass_workers[(size_t)p - 1]->wait();
     for (int32_t p = 0; p < n_passes; ++p)
         if (rcs[p] != 0) {
             for (auto *f : fams) delete f;
