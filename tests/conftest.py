@@ -14,13 +14,14 @@ def pytest_configure(config):
 
 
 def pytest_collection_modifyitems(config, items):
-    """A test that hangs (a kernel that never returns, a lost rendezvous) fails with the stacks of every thread
-    instead of stalling the run: pytest-timeout, when it is installed, bounds each test."""
+    """A test that hangs (a kernel that never returns, a lost rendezvous) ends the run with the stacks of every thread
+    instead of stalling it: pytest-timeout, when it is installed, bounds each test ("thread" method: a main thread
+    blocked inside a HIP call never returns to the interpreter, so a signal handler would not run)."""
     if not config.pluginmanager.hasplugin("timeout"):
         return
     for item in items:
         if item.get_closest_marker("timeout") is None:
-            item.add_marker(pytest.mark.timeout(900))
+            item.add_marker(pytest.mark.timeout(900, method="thread"))
 
 
 @pytest.fixture(scope="session")
