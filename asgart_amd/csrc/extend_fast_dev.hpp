@@ -645,8 +645,8 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
 
         // ---- a probe run by wave 0 alone: every live arm is one of its 64 layer-0 slots, the hits are few ----------
         // Same transitions as A + B (src/automaton.rs:96-200), without the table: every hit is tested against the 64
-        // arms at once (ballot), its arm is the accepting one with the smallest creation number (DPP minimum), the
-        // last hit an arm wins extends it, the unmatched hits take the empty lanes in hit order.
+        // arms at once (ballot), its arm is the accepting one with the smallest creation number (DPP minimum when more
+        // than one accepts), the last hit an arm wins extends it, the unmatched hits take the empty lanes in hit order.
         auto solo_probe = [&](const Probe &q) -> uint32_t {
             const uint32_t cnt = q.cnt, off = q.off;
             const uint64_t i = q.i;
@@ -672,27 +672,47 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
             const PosT lo = (PosT)(a_re[0] - k + 1u);
             const WinT w = live ? (WinT)a_thr[0] + (WinT)(k - 1u) : (WinT)0;
             const PosT x_l = (uint32_t)lane < cnt ? s_hits[off + lane] : (PosT)0;  // lane j holds hit j (cnt <= kSoloHits)
-            uint32_t ext = 0;               // 1 + the last hit this arm won
-            unsigned long long newm = 0;    // unmatched hits
+            // the lanes empty before this probe take its new arms (an arm that dies in this probe frees its lane for the
+            // next one: solo_a + cnt <= 64 counted the arms alive before)
+            unsigned long long fm = __ballot(!live);
+            bool won = false, born = false;
+            PosT xw = 0, xb = 0;  // the last hit this arm won; the hit this lane's new arm starts from
+            uint32_t rb = 0, n_new = 0;
             for (uint32_t j = 0; j < cnt; ++j) {
                 PosT x;
                 if constexpr (kWidePos) x = (PosT)lane_of((unsigned long long)x_l, j);
                 else x = (PosT)lane_of((uint32_t)x_l, j);
                 const bool ok = (WinT)(PosT)(x - lo) < w;
-                if (__ballot(ok)) {
-                    const uint32_t first = wave_min_u32(ok ? a_seq[0] : 0xFFFFFFFFu);  // first arm in list order (:67-78)
-                    ext = (ok && a_seq[0] == first) ? j + 1u : ext;
-                } else {
-                    newm |= 1ull << j;
+                const unsigned long long okm = __ballot(ok);
+                if (okm) {
+                    // the first accepting arm in list order (:67-78) = the smallest creation number; one arm as a rule
+                    bool mine = ok;
+                    if (okm & (okm - 1ull)) {  // (every lane takes part in the reduction: no short-circuit around it)
+                        const uint32_t first = wave_min_u32(ok ? a_seq[0] : 0xFFFFFFFFu);
+                        mine = ok && a_seq[0] == first;
+                    }
+                    won = won || mine;
+                    xw = mine ? x : xw;  // (hit order: the last one stays, src/automaton.rs:133-150)
+                } else {  // NewArm (src/automaton.rs:151-164), creation numbers in hit order
+                    const uint32_t tl = (uint32_t)(__ffsll((long long)fm) - 1);
+                    fm &= fm - 1ull;
+                    const bool me = (uint32_t)lane == tl;
+                    born = born || me;
+                    xb = me ? x : xb;
+                    rb = me ? n_new : rb;
+                    ++n_new;
                 }
             }
-            const bool won = ext != 0u;
-            const PosT xw = s_hits[off + (won ? ext - 1u : 0u)];
             uint32_t thr_new;
-            if constexpr (kWidePos) thr_new = arm_threshold((uint64_t)(i + k) - (uint64_t)a_ls[0], G);
-            else thr_new = max(G, ((uint32_t)(i + k) - (uint32_t)a_ls[0]) / 10u);
-            const uint64_t sum_g = (uint64_t)a_gap[0] + step;
-            const uint32_t aged = sum_g > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)sum_g;
+            if constexpr (kWidePos) {
+                const uint64_t len = (uint64_t)(i + k) - (uint64_t)a_ls[0];
+                if (__ballot(won && (len >> 32) != 0ull)) thr_new = arm_threshold(len, G);  // (a left arm of 4 Gbp and more)
+                else thr_new = max(G, (uint32_t)len / 10u);
+            } else {
+                thr_new = max(G, ((uint32_t)(i + k) - (uint32_t)a_ls[0]) / 10u);
+            }
+            const uint32_t sum_g = a_gap[0] + step;
+            const uint32_t aged = sum_g < step ? 0xFFFFFFFFu : sum_g;  // (saturating)
             a_re[0] = won ? (PosT)(xw + k) : a_re[0];
             if (won) s_cle[tid] = (PosT)(i + k);
             a_thr[0] = won ? thr_new : a_thr[0];
@@ -704,24 +724,16 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
                 if (__ballot(report)) emit_records(report, a_ls[0], s_cle[tid], rs, a_re[0], a_seq[0]);
             }
             a_seq[0] = dead ? kNoSeq : a_seq[0];
-            // NewArm (src/automaton.rs:151-164): the r-th empty lane takes the r-th unmatched hit
-            const uint32_t n_new = (uint32_t)__popcll(newm);
             if (n_new) {
-                const bool is_free = a_seq[0] == kNoSeq;
-                const unsigned long long fmask = __ballot(is_free);
-                const uint32_t r = (uint32_t)__popcll(fmask & lt_mask);
-                const bool take = is_free && r < n_new;  // (n_new <= empty lanes: solo_a + cnt <= 64 was checked)
-                const uint32_t hsel = select_bit(newm, take ? r : 0u);
-                const PosT x = s_hits[off + (take ? hsel : 0u)];
-                a_ls[0] = take ? (PosT)i : a_ls[0];
-                if (take) {
+                a_ls[0] = born ? (PosT)i : a_ls[0];
+                if (born) {
                     s_cle[tid] = (PosT)(i + k);
-                    s_crs[tid] = x;
+                    s_crs[tid] = xb;
                 }
-                a_re[0] = take ? (PosT)(x + k) : a_re[0];
-                a_gap[0] = take ? step : a_gap[0];
-                a_thr[0] = take ? thr0 : a_thr[0];
-                a_seq[0] = take ? next_seq + r : a_seq[0];
+                a_re[0] = born ? (PosT)(xb + k) : a_re[0];
+                a_gap[0] = born ? step : a_gap[0];
+                a_thr[0] = born ? thr0 : a_thr[0];
+                a_seq[0] = born ? next_seq + rb : a_seq[0];
             }
             next_seq += n_new;
             fam_open = true;
