@@ -130,7 +130,7 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
     __shared__ __attribute__((aligned(16))) uint32_t s_run[2][4];
     const uint32_t kSoloHits = min(16u, P.solo_hits);  // option solo (0: never)
     // arms that move to wave 0's first layer when few are left (migrate below): their fields in transit
-    constexpr uint32_t kMigMax = 48;
+    constexpr uint32_t kMigMax = 64;
     __shared__ PosT s_x_ls[kMigMax], s_x_re[kMigMax], s_x_le[kMigMax], s_x_rs[kMigMax];
     __shared__ uint32_t s_x_thr[kMigMax], s_x_gap[kMigMax], s_x_seq[kMigMax];
     __shared__ uint32_t s_mig[NW][8];  // per (wave, layer): live arms, for the migration
@@ -566,7 +566,7 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
                 const uint32_t free00 = lane_of(fv, 0u);  // empty slots of (layer 0, wave 0)
                 solo_w0 = total_free - free00 == (uint32_t)CAP - 64u && cnt <= free00;  // (the new arms fit there too)
                 solo_a = 64u - free00 + cnt;
-                want_migrate = kSoloHits != 0u && !use_flag && !solo_w0 && A0 + cnt <= 40u;  // (few arms, some astray)
+                want_migrate = kSoloHits != 0u && !use_flag && !solo_w0 && A0 + cnt <= 60u;  // (few arms, some astray)
             }
             PROF_STOP(7);
         };
