@@ -1,5 +1,6 @@
 // common.hpp -- shared host/device definitions of libasgart_hip (gfx950 only).
 #pragma once
+#include <atomic>
 #include <chrono>
 #include <mutex>
 #include <utility>
@@ -116,10 +117,23 @@ struct BlockCache {
     }
 };
 
+// Test hook (option test_fail_alloc = n): the (n+1)-th device allocation of the process from now on fails as if the
+// device were full, once; -1 = off.  Exercises the out-of-memory paths (what is released, what degrades).
+inline std::atomic<long long> &fail_alloc_countdown() {
+    static std::atomic<long long> c{-1};
+    return c;
+}
+inline bool test_alloc_fails() {
+    std::atomic<long long> &c = fail_alloc_countdown();
+    if (c.load(std::memory_order_relaxed) < 0) return false;
+    return c.fetch_sub(1) == 0;
+}
+
 // hipMalloc / hipFree for the long-lived arrays of an index, through the same cache (sizes remembered per pointer)
 inline std::mutex &raw_mu() { static std::mutex m; return m; }
 inline std::vector<std::pair<void *, size_t>> &raw_sizes() { static std::vector<std::pair<void *, size_t>> v; return v; }
 inline hipError_t dev_malloc(void **out, size_t bytes) {
+    if (test_alloc_fails()) return hipErrorOutOfMemory;
     size_t cap = 0;
     void *p = BlockCache::take(bytes, &cap);
     hipError_t e = hipSuccess;
@@ -167,6 +181,10 @@ struct DevBuf {
     int32_t reserve(size_t bytes) {
         if (bytes <= cap) return 0;
         release();
+        if (test_alloc_fails()) {
+            set_error("hipMalloc(%zu bytes) failed: injected by option test_fail_alloc", bytes);
+            return ASGART_E_OOM;
+        }
         size_t want = bytes + bytes / 8 + 256;
         if ((p = BlockCache::take(want, &cap)) != nullptr) return 0;
         hipError_t e;

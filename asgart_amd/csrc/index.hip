@@ -62,6 +62,7 @@ const OptDesc kOptions[] = {
     {"fast", &Options::fast, 0, 255},
     {"cap3_pct", &Options::cap3_pct, 100, 400},
     {"cap45_pct", &Options::cap45_pct, 100, 800},
+    {"test_fail_alloc", &Options::test_fail_alloc, -1, 1000000000},
     {"fast6w", &Options::fast6w, 0, 1},
     {"cap6w_pct", &Options::cap6w_pct, 100, 400},
     {"solo", &Options::solo, 0, 1},
@@ -786,12 +787,7 @@ void asgart_index_destroy(asgart_index *idx) {
     if (idx->d_text) dev_free(idx->d_text);
     if (idx->d_sa) dev_free(idx->d_sa);
     for (auto &cx : idx->ctx) {
-        Workspace &w = cx.ws;
-        DevBuf *bufs[] = {&w.chunks, &w.p_lo, &w.p_raw, &w.p_filt, &w.row_off, &w.blk, &w.hits,
-                          &w.big_list, &w.rank_list, &w.seg_list, &w.counters, &w.fam_sds, &w.ovf_list, &w.own_list,
-                          &w.scratch, &w.hit_flag, &w.seg_keys, &w.seg_vals, &w.sort_tmp, &w.pat,
-                          &w.out_a, &w.out_b};
-        for (DevBuf *b : bufs) b->release();
+        cx.ws.release_all();  // (the record-ordering buffers used to be missing from a list kept here: a leak per index)
         if (cx.h_pinned) (void)hipHostFree(cx.h_pinned);
         cx.h_pinned = nullptr;
         if (cx.h_ctl) (void)hipHostFree(cx.h_ctl);
@@ -1007,6 +1003,7 @@ int32_t asgart_index_set_option(asgart_index *idx, const char *name, int64_t val
     }
     idx->acquire_all();  // never changes under a running call
     const int32_t rc = option_set(idx->opt, name, value);
+    if (rc == 0 && !strcmp(name, "test_fail_alloc")) asgart::fail_alloc_countdown().store(value);  // (process-wide)
     if (rc == 0 && !strcmp(name, "kfilter_bits")) {  // rebuilt at the new size by the next call
         (void)hipSetDevice(idx->device);
         for (auto &f : idx->d_filter) {

@@ -111,6 +111,15 @@ struct Workspace {
     DevBuf rec_k32, rec_k64, rec_idx, rec_sorted;  // ordering of the output records
     DevBuf pat;        // pattern upload scratch
     DevBuf out_a, out_b;
+    // every buffer goes back to the device (or to the block cache): ONE list, next to the members
+    void release_all() {
+        DevBuf *bufs[] = {&chunks, &p_lo, &p_raw, &p_filt, &row_off, &blk, &hits, &big_list, &rank_list, &seg_list,
+                          &counters, &fam_sds, &ovf_list, &own_list, &scratch, &hit_flag, &seg_keys, &seg_vals,
+                          &sort_tmp, &rec_k32, &rec_k64, &rec_idx, &rec_sorted, &pat, &out_a, &out_b};
+        static_assert(sizeof(Workspace) == sizeof(bufs) / sizeof(bufs[0]) * sizeof(DevBuf),
+                      "a buffer of the workspace is missing from release_all");
+        for (DevBuf *b : bufs) b->release();
+    }
 };
 
 }  // namespace asgart
@@ -208,6 +217,7 @@ struct Options {
     int64_t cap6_pct = 140;         // tier 6 accepts segments whose arm bound is up to this percentage of its capacity
     int64_t fast = 124;             // bit t set (t = 2..6): tier t runs the one-barrier arm kernel (extend_fast_dev.hpp) instead of K4c
     int64_t fast_bsh = 0;           // its bucket width: 2^fast_bsh times the smallest power of two >= max_gap_size + k
+    int64_t test_fail_alloc = -1;   // tests: the (n+1)-th device allocation from now on fails once (common.hpp); -1 = off
     int64_t solo = 1;               // one-barrier kernel: sparse probes run on wave 0 alone, in registers (see solo_probe)
     int64_t fast6w = 1;             // 64-bit positions: tier 6 on the one-barrier kernel (4 x 1024 slots) instead of K4c 8 x 512
     int64_t cap6w_pct = 160;        // ... which then accepts segments whose arm bound is up to this percentage of its capacity

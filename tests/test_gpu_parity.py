@@ -1052,3 +1052,52 @@ def test_compute_score_step_end_to_end(hiplib, tmp_path):
             assert np.float32(sd["identity"]) == want, tup
             n_checked += 1
     assert n_checked > 5
+
+
+def test_out_of_memory_paths_release_what_they_hold(hiplib):
+    """Every device allocation of an index preparation and of a first search call fails in turn (option
+    test_fail_alloc: the (n+1)-th allocation from now on is refused once).  The call then either does without what
+    it could not get -- no position-sorted lists, no presence filter: the same duplications -- or fails with
+    ASGART_E_OOM; in both cases the device has its memory back once the index is closed (a leak on this path would
+    stay for the life of the process: the block kept by build_rank_lists when its second buffer failed)."""
+    import torch
+
+    E_OOM = -2  # ASGART_E_OOM (include/asgart_hip.h)
+    pr, cli = _battery_case("dense_repeats")
+    oidx = oracle.Index.build(pr.data)
+    st = asgart_amd.RunSettings.from_cli(reverse=True, complement=True, **cli)
+    with asgart_amd.Index(pr.data, oidx.sa) as idx:
+        ref = idx.search_duplications_raw(pr.chunks, st)
+
+    def free_bytes():
+        torch.cuda.synchronize()
+        return torch.cuda.mem_get_info()[0]
+
+    # Memory the HIP runtime keeps for itself grows while new code paths warm up (kernels that only run without the
+    # lists or the filter are loaded, their scratch is reserved), in steps of a few MiB and once: the sweep over all
+    # failure points is repeated, and the last repetition must not cost a byte more than the one before.
+    done, refused = 0, 0
+    after = []
+    try:
+        for sweep in range(3):
+            for n in range(0, 70):
+                idx = asgart_amd.Index(pr.data, oidx.sa)
+                try:
+                    idx.set_option("test_fail_alloc", n)
+                    try:
+                        idx.prepare(20)
+                        got = idx.search_duplications_raw(pr.chunks, st)
+                        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]), n
+                        done += 1
+                    except asgart_amd.AsgartError as e:
+                        assert e.code == E_OOM, (n, str(e))
+                        refused += 1
+                    idx.set_option("test_fail_alloc", -1)
+                finally:
+                    idx.close()
+            after.append(free_bytes())
+    finally:
+        with asgart_amd.Index(pr.data, oidx.sa) as idx:
+            idx.set_option("test_fail_alloc", -1)
+    assert after[1] - after[2] <= (1 << 20), [a - after[0] for a in after]
+    assert refused > 0 and done > 0, (done, refused)
