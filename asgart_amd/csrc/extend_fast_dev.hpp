@@ -128,7 +128,7 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
     // after a run of probes that wave 0 went through alone (see solo_probe): position in the batch, probes processed,
     // live arms; alternating
     __shared__ __attribute__((aligned(16))) uint32_t s_run[2][4];
-    const uint32_t kSoloHits = min(16u, P.solo_hits);  // option solo (0: never)
+    const uint32_t kSoloHits = min(48u, P.solo_hits);  // option solo (0: never; 1: 16 hits)
     // arms that move to wave 0's first layer when few are left (migrate below): their fields in transit
     constexpr uint32_t kMigMax = 64;
     __shared__ PosT s_x_ls[kMigMax], s_x_re[kMigMax], s_x_le[kMigMax], s_x_rs[kMigMax];

@@ -65,7 +65,7 @@ const OptDesc kOptions[] = {
     {"test_fail_alloc", &Options::test_fail_alloc, -1, 1000000000},
     {"fast6w", &Options::fast6w, 0, 1},
     {"cap6w_pct", &Options::cap6w_pct, 100, 400},
-    {"solo", &Options::solo, 0, 1},
+    {"solo", &Options::solo, 0, 48},
     {"shard_lpt", &Options::shard_lpt, 0, 1},
     {"posbits", &Options::posbits, 0, 1},
     {"fast_bsh", &Options::fast_bsh, 0, 3},

@@ -218,7 +218,7 @@ struct Options {
     int64_t fast = 124;             // bit t set (t = 2..6): tier t runs the one-barrier arm kernel (extend_fast_dev.hpp) instead of K4c
     int64_t fast_bsh = 0;           // its bucket width: 2^fast_bsh times the smallest power of two >= max_gap_size + k
     int64_t test_fail_alloc = -1;   // tests: the (n+1)-th device allocation from now on fails once (common.hpp); -1 = off
-    int64_t solo = 1;               // one-barrier kernel: sparse probes run on wave 0 alone, in registers (see solo_probe)
+    int64_t solo = 1;               // one-barrier kernel: sparse probes run on wave 0 alone, in registers (see solo_probe): 0 never, 1 = probes of up to 16 hits, n = up to n (<= 48) hits; 8 .. 44 measured alike at cfg4 and cfg5
     int64_t fast6w = 1;             // 64-bit positions: tier 6 on the one-barrier kernel (4 x 1024 slots) instead of K4c 8 x 512
     int64_t cap6w_pct = 160;        // ... which then accepts segments whose arm bound is up to this percentage of its capacity
     int64_t cap45_pct = 100;        // tiers 4 and 5 accept segments whose arm bound is up to this percentage of their capacity (what overflows is re-run)

@@ -509,7 +509,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             ep.max_items = 0;
             ep.fast_bsh = (uint32_t)opt.fast_bsh;
             ep.heavy_cap = (uint32_t)heavy_cap64;
-            ep.solo_hits = opt.solo ? 16u : 0u;
+            ep.solo_hits = opt.solo == 1 ? 16u : (uint32_t)opt.solo;  // (1: the default of 16 hits; other values: that many)
             ep.n_levels = (uint32_t)opt.test_levels;
             ep.gen_bits = (uint32_t)opt.test_genbits;
             ep.ctr = d_ctr;
