@@ -244,8 +244,9 @@ __host__ __device__ inline uint32_t acgt_digit(uint32_t code) {
 }
 
 constexpr int kMaxKey = 21;        // bases in one key word: 21 * 3 bits = 63
-constexpr int kMaxK = 2 * kMaxKey; // probe sizes 22..42: the first 21 bases are the key word, the rest is
-                                   // compared through the text (search_dev.hpp: tail_key)
+constexpr int kMaxK = 128;         // probe sizes above 21: the first 21 bases are the key word, the next 21 a second
+                                   // word packed on demand, the rest is compared base by base through the text
+                                   // (search_dev.hpp: tail_key, tail_cmp)
 constexpr int kCacheLen = 8;       // reference src/searcher.rs:15
 constexpr int kCacheEntries = 390625;  // 5^8
 constexpr uint32_t kSkipN = 0xFFFFFFFFu;     // probe skipped: first base 'N'

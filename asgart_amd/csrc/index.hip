@@ -431,10 +431,13 @@ __global__ __launch_bounds__(256) void pattern_search_kernel(IndexView<SlotT> ix
     uint64_t q = 0, q2 = 0;
     for (int j = 0; j < ix.k; ++j) {
         const uint64_t c = base_code(pats[t * ix.k + j]);
-        if (j < kMaxKey) q = (q << 3) | c; else q2 = (q2 << 3) | c;
+        if (j < kMaxKey) q = (q << 3) | c;
+        else if (j < 2 * kMaxKey) q2 = (q2 << 3) | c;
     }
     uint64_t l, h;
-    kmer_range(ix, q, q2, l, h);
+    ProbeRef pr;
+    pr.p = pats + t * ix.k;
+    kmer_range(ix, q, q2, pr, l, h);
     lo[t] = l;
     hi[t] = h;
 }
@@ -868,7 +871,7 @@ static int32_t index_create_impl(const uint8_t *T, int64_t n, const int64_t *SA,
             set_error("'$' may only appear once, as the last byte of the text");
             return ASGART_E_ARG;
         }
-        const int64_t tl = n < 64 ? n : 64;
+        const int64_t tl = n < (int64_t)kMaxK + 32 ? n : (int64_t)kMaxK + 32;  // (the text-tail corner list reads the last k bytes)
         idx->h_tail.assign(T + n - tl, T + n);
         const size_t slot = idx->wide ? 8 : 4;
         HIP_TRY(dev_malloc(&idx->d_sa, ((size_t)n_sa + 16) * slot));

@@ -310,7 +310,7 @@ struct asgart_index {
     uint32_t tail8[asgart::kMaxK];
     int n_tail8 = 0;
     uint64_t tail_bloom = 0;
-    std::vector<uint8_t> h_tail;  // last 64 bytes of the text (host copy)
+    std::vector<uint8_t> h_tail;  // last kMaxK + 32 bytes of the text (host copy)
     double ms_prepare = 0.0;
     double tail_ms[4] = {-1.0, -1.0, -1.0, -1.0};  // per orientation (reverse * 2 + complement): shortest extension time of an unsharded call so far
     asgart::Options opt;

@@ -268,7 +268,11 @@ __global__ __launch_bounds__(kProbeBlock) void probe_count_kernel(IndexView<Slot
     // one probe's lookup: SA interval, filtered count of a small interval (large ones go to big_list)
     auto lookup = [&](uint32_t g_, uint64_t q_, uint64_t q2_, uint64_t i_, uint64_t s_, uint64_t L_) {
         uint64_t lo, hi;
-        const bool all_occurrences = kmer_range(ix, q_, q2_, lo, hi, cb);
+        ProbeRef pr;  // (read only by probes of more than 42 bases)
+        pr.p = rp.reverse ? ix.text + s_ + L_ - 1u - i_ : ix.text + s_ + i_;
+        pr.dir = rp.reverse ? -1 : 1;
+        pr.comp = rp.complement != 0;
+        const bool all_occurrences = kmer_range(ix, q_, q2_, pr, lo, hi, cb);
         const uint64_t raw = hi - lo;
         if (!COUNT) {
             p_lo[g_] = (SlotT)lo;

@@ -63,37 +63,66 @@ __device__ inline uint64_t upper_bound_keys(const uint64_t *__restrict__ keys, u
     return lo;
 }
 
-// Probe sizes above kMaxKey: a key word holds the first kk = 21 bases of a suffix, the remaining k2 = k - 21
-// are packed on demand from the text (bases past the end of the text count as 0, like the padding of the key
-// words).  Slots with equal key words are in suffix order, so their tails are non-decreasing.
+// Where the bases of a probe can be read again: its first base and the direction it runs in (a reversed needle runs
+// down the text), complemented or not.  Only probes longer than two words (k > 42) are read through it.
+struct ProbeRef {
+    const uint8_t *p = nullptr;
+    int dir = 1;
+    bool comp = false;
+    __device__ inline uint32_t code(int j) const {
+        const uint32_t c = base_code(p[(long long)j * dir]);
+        return comp ? comp_code(c) : c;
+    }
+};
+
+// Probe sizes above kMaxKey: a key word holds the first kk = 21 bases of a suffix, the next (up to) 21 are packed on
+// demand from the text into a second word (bases past the end of the text count as 0, like the padding of the key
+// words), what lies beyond is compared base by base.  Slots with equal key words are in suffix order, so their tails
+// are non-decreasing.
 template <class SlotT, class Cnt = NoBytes>
 __device__ inline uint64_t tail_key(const IndexView<SlotT> &ix, uint64_t x, Cnt &&cb = Cnt()) {
     uint64_t t = 0;
-    for (int j = 0; j < ix.k2; ++j) {
+    const int n2 = ix.k2 < kMaxKey ? ix.k2 : kMaxKey;
+    for (int j = 0; j < n2; ++j) {
         const uint64_t p = x + (uint64_t)ix.kk + (uint64_t)j;
         t = (t << 3) | (p < ix.n ? base_code(ix.text[p]) : 0u);
     }
-    cb.rd((uint32_t)ix.k2);
+    cb.rd((uint32_t)n2);
     return t;
 }
 
-// [lo,hi): slots whose key word equals the probe's -> the slots whose tail equals q2 as well
+// tail of the suffix at x against the probe's tail (second word q2, the rest through pr): -1 / 0 / 1
 template <class SlotT, class Cnt = NoBytes>
-__device__ inline void refine_tail(const IndexView<SlotT> &ix, uint64_t q2, uint64_t &lo, uint64_t &hi,
+__device__ inline int tail_cmp(const IndexView<SlotT> &ix, uint64_t x, uint64_t q2, const ProbeRef &pr, Cnt &&cb = Cnt()) {
+    const uint64_t t = tail_key(ix, x, cb);
+    if (t != q2) return t < q2 ? -1 : 1;
+    for (int j = kMaxKey; j < ix.k2; ++j) {  // (k > 42)
+        const uint64_t p = x + (uint64_t)ix.kk + (uint64_t)j;
+        const uint32_t a = p < ix.n ? base_code(ix.text[p]) : 0u;
+        const uint32_t b = pr.code(ix.kk + j);
+        cb.rd(2);
+        if (a != b) return a < b ? -1 : 1;
+    }
+    return 0;
+}
+
+// [lo,hi): slots whose key word equals the probe's -> the slots whose tail equals the probe's as well
+template <class SlotT, class Cnt = NoBytes>
+__device__ inline void refine_tail(const IndexView<SlotT> &ix, uint64_t q2, const ProbeRef &pr, uint64_t &lo, uint64_t &hi,
                                    Cnt &&cb = Cnt()) {
     if (!ix.k2 || lo >= hi) return;
     uint64_t a = lo, b = hi;
-    while (a < b) {  // first slot with tail >= q2
+    while (a < b) {  // first slot with tail >= the probe's
         const uint64_t mid = a + ((b - a) >> 1);
         cb.rd(sizeof(SlotT));
-        if (tail_key(ix, (uint64_t)ix.sa[mid], cb) < q2) a = mid + 1; else b = mid;
+        if (tail_cmp(ix, (uint64_t)ix.sa[mid], q2, pr, cb) < 0) a = mid + 1; else b = mid;
     }
     const uint64_t l = a;
     b = hi;
-    while (a < b) {  // first slot with tail > q2
+    while (a < b) {  // first slot with tail > the probe's
         const uint64_t mid = a + ((b - a) >> 1);
         cb.rd(sizeof(SlotT));
-        if (tail_key(ix, (uint64_t)ix.sa[mid], cb) <= q2) a = mid + 1; else b = mid;
+        if (tail_cmp(ix, (uint64_t)ix.sa[mid], q2, pr, cb) <= 0) a = mid + 1; else b = mid;
     }
     lo = l;
     hi = a;
@@ -124,8 +153,8 @@ __device__ inline bool in_tail_list(const IndexView<SlotT> &ix, uint32_t pre24) 
 // (reference src/searcher.rs:164-170 + superslice equal_range_by): comparator
 // says Less for suffixes shorter than k although they may sort Greater.
 template <class SlotT, class Cnt = NoBytes>
-__device__ inline void kmer_range_tail(const IndexView<SlotT> &ix, uint64_t q, uint64_t q2, uint64_t &lo,
-                                       uint64_t &hi, Cnt &&cb = Cnt()) {
+__device__ inline void kmer_range_tail(const IndexView<SlotT> &ix, uint64_t q, uint64_t q2, const ProbeRef &pr,
+                                       uint64_t &lo, uint64_t &hi, Cnt &&cb = Cnt()) {
     uint32_t pre24 = (uint32_t)(q >> (3 * (ix.kk - kCacheLen)));
     uint32_t c8;
     if (!cache8_index(pre24, c8)) {  // cannot happen for validated text
@@ -146,8 +175,7 @@ __device__ inline void kmer_range_tail(const IndexView<SlotT> &ix, uint64_t q, u
         uint64_t kv = ix.keys[r];
         if (kv != q) return kv < q ? -1 : 1;
         if (!ix.k2) return 0;
-        const uint64_t t = tail_key(ix, x, cb);
-        return t < q2 ? -1 : (t > q2 ? 1 : 0);
+        return tail_cmp(ix, x, q2, pr, cb);
     };
     uint64_t b0 = 0, b1 = 0;
     while (size > 1) {
@@ -180,8 +208,8 @@ __device__ inline bool is_tail_corner(const IndexView<SlotT> &ix, uint64_t q) {
 // inside that bucket: plain bounds over the keys when the bucket is clean, the step-by-step replay of
 // equal_range_by when it holds one of the out-of-place suffixes.
 template <class SlotT, class Cnt = NoBytes>
-__device__ inline void kmer_range_trim(const IndexView<SlotT> &ix, uint64_t q, uint64_t q2, uint64_t &lo,
-                                       uint64_t &hi, Cnt &&cb = Cnt()) {
+__device__ inline void kmer_range_trim(const IndexView<SlotT> &ix, uint64_t q, uint64_t q2, const ProbeRef &pr,
+                                       uint64_t &lo, uint64_t &hi, Cnt &&cb = Cnt()) {
     uint32_t c8;
     if (!cache8_index((uint32_t)(q >> (3 * (ix.kk - kCacheLen))), c8)) {
         lo = hi = 0;
@@ -192,23 +220,23 @@ __device__ inline void kmer_range_trim(const IndexView<SlotT> &ix, uint64_t q, u
     bool dirty = false;
     for (int j = 0; j < ix.n_bad; ++j) dirty |= ix.bad[j] >= L && ix.bad[j] < R;
     if (dirty) {
-        kmer_range_tail(ix, q, q2, lo, hi, cb);
+        kmer_range_tail(ix, q, q2, pr, lo, hi, cb);
         return;
     }
     lo = lower_bound_keys(ix.keys, L, R, q, cb);
     hi = upper_bound_keys(ix.keys, lo, R, q, cb);
-    refine_tail(ix, q2, lo, hi, cb);
+    refine_tail(ix, q2, pr, lo, hi, cb);
 }
 
 template <class SlotT, class Cnt = NoBytes>
-__device__ inline bool kmer_range(const IndexView<SlotT> &ix, uint64_t q, uint64_t q2, uint64_t &lo,
+__device__ inline bool kmer_range(const IndexView<SlotT> &ix, uint64_t q, uint64_t q2, const ProbeRef &pr, uint64_t &lo,
                                   uint64_t &hi, Cnt &&cb = Cnt()) {
     if (ix.trim) {
-        kmer_range_trim(ix, q, q2, lo, hi, cb);
+        kmer_range_trim(ix, q, q2, pr, lo, hi, cb);
         return false;  // the interval need not hold the probe's own position
     }
     if (is_tail_corner(ix, q)) {
-        kmer_range_tail(ix, q, q2, lo, hi, cb);
+        kmer_range_tail(ix, q, q2, pr, lo, hi, cb);
         return false;
     }
     uint64_t lo0 = 0, hi0 = ix.n_sa;
@@ -235,7 +263,7 @@ __device__ inline bool kmer_range(const IndexView<SlotT> &ix, uint64_t q, uint64
     }
     lo = l;
     hi = h;
-    refine_tail(ix, q2, lo, hi, cb);
+    refine_tail(ix, q2, pr, lo, hi, cb);
     return true;
 }
 
@@ -277,7 +305,7 @@ __device__ inline uint64_t transform_key(uint64_t q, int k, bool reverse, bool c
 // key of the probe at needle-local offset i of chunk (s, L) under the run's
 // orientation: needle = chunk | complemented | reversed (reference
 // src/bin/asgart.rs:206-218), probe = needle[i..i+k].  *first = first base code.
-// Probes longer than kMaxKey: the key word is the first kMaxKey bases, *q2 the packed rest.
+// Probes longer than kMaxKey: the key word is the first kMaxKey bases, *q2 the next (up to) kMaxKey, packed.
 __device__ inline uint64_t probe_key(const uint8_t *__restrict__ text, uint64_t s, uint64_t L,
                                      uint64_t i, int k, bool reverse, bool complement,
                                      uint32_t *first, uint64_t *q2 = nullptr) {
@@ -288,7 +316,8 @@ __device__ inline uint64_t probe_key(const uint8_t *__restrict__ text, uint64_t 
         uint32_t c = base_code(reverse ? *(p - j) : p[j]);
         if (complement) c = comp_code(c);
         if (j == 0) f = c;
-        if (j < kMaxKey) q = (q << 3) | c; else t = (t << 3) | c;
+        if (j < kMaxKey) q = (q << 3) | c;
+        else if (j < 2 * kMaxKey) t = (t << 3) | c;  // (the bases beyond are read again when two words tie: ProbeRef)
     }
     *first = f;
     if (q2) *q2 = t;

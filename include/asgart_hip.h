@@ -35,7 +35,7 @@ extern "C" {
 /* RunSettings as it reaches the path (reference src/structs.rs:36-58; Copy).
  * max_gap_size already includes +probe_size (reference src/bin/asgart.rs:681). */
 typedef struct asgart_settings {
-    uint64_t probe_size;              /* -k ; 8 <= k <= 42 in this build          */
+    uint64_t probe_size;              /* -k ; 8 <= k <= 128 in this build         */
     uint32_t max_gap_size;            /* -g + -k                                 */
     uint64_t min_duplication_length;  /* --min-length                            */
     uint64_t max_cardinality;         /* --max-cardinality.  The reference keeps the arms of a chunk in an unbounded

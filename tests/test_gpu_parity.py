@@ -206,9 +206,10 @@ def test_tail_corner_on_gpu(hiplib):
                 assert np.array_equal(offs, eo) and np.array_equal(sds, es)
 
 
-@pytest.mark.parametrize("k", [22, 29, 42])
+@pytest.mark.parametrize("k", [22, 29, 42, 43, 50, 64, 101, 128])
 def test_long_probes_search_and_tail_corner(hiplib, k, monkeypatch):
-    """Probe sizes 22..42 (the reference takes any k >= 8, src/bin/asgart.rs:564-631): Searcher::search against
+    """Probe sizes 22..128 (the reference takes any k >= 8, src/bin/asgart.rs:564-631; up to 42 the tail of a probe is a
+    second packed word, beyond it is compared base by base through the text): Searcher::search against
     the oracle for patterns from the text, random patterns, patterns that differ from a text k-mer only in their
     last bases (same key word, different tail) and the text-tail corner; then whole runs, also with 64-bit slots."""
     import random
@@ -230,7 +231,12 @@ def test_long_probes_search_and_tail_corner(hiplib, k, monkeypatch):
                 t = bytearray(text[p0:p0 + k])
                 t[rng.randrange(21, k)] = rng.choice(b"ACGT")
                 pats.append(bytes(t))
-            pats += [motif + b"A" * (k - 10), motif + b"T" * (k - 10), (motif + rep)[:k], (motif + b"A" * 40)[:k]]
+            if k > 42:
+                for p0 in range(690, 1050, 5):   # same first 42 bases (both words), another base further on
+                    t = bytearray(text[p0:p0 + k])
+                    t[rng.randrange(42, k)] = rng.choice(b"ACGT")
+                    pats.append(bytes(t))
+            pats += [motif + b"A" * (k - 10), motif + b"T" * (k - 10), (motif + rep)[:k], (motif + b"A" * 40 + b"C" * k)[:k]]
             for p, (lo, hi) in zip(pats, s.search_ranges(pats)):
                 exp, (elo, ehi) = oidx.search(p)
                 assert hi - lo == len(exp), p
@@ -253,7 +259,7 @@ def test_errors_on_gpu(hiplib):
         with pytest.raises(asgart_amd.AsgartError):
             idx.search_duplications_raw([(0, 401)], asgart_amd.RunSettings.from_cli())     # covers '$'
         with pytest.raises(asgart_amd.AsgartError):
-            idx.search_duplications_raw([(0, 400)], asgart_amd.RunSettings.from_cli(k=43))  # k > 42
+            idx.search_duplications_raw([(0, 400)], asgart_amd.RunSettings.from_cli(k=129))  # k > 128
         with pytest.raises(asgart_amd.AsgartError):
             idx.search_duplications_raw([(0, 400)], asgart_amd.RunSettings.from_cli(k=7))   # k < 8 (searcher.rs:95-97)
         offs, sds = idx.search_duplications_raw([], asgart_amd.RunSettings.from_cli())
@@ -608,7 +614,7 @@ def test_trim_matches_oracle(hiplib, window, build_on_gpu):
         asgart_amd.Index(pr.data, None, trim=(100, n + 5))      # end past the '$': not a validated trim
 
 
-@pytest.mark.parametrize("k", [25, 40])
+@pytest.mark.parametrize("k", [25, 40, 47, 90])
 def test_trim_with_long_probes(hiplib, k):
     """--trim and a probe longer than one key word together: the literal bisection replay compares key word + tail."""
     pr, cli = _battery_case("long_sds")
@@ -632,7 +638,7 @@ def test_trim_with_long_probes(hiplib, k):
             offs, sds = idx.search_duplications_raw(pr.chunks, st)
             eoffs, esds = oidx.run_raw(pr.chunks, oracle.make_settings(k=k, reverse=reverse, complement=complement), threads=4)
             assert np.array_equal(offs, eoffs) and np.array_equal(sds, esds), (k, reverse)
-            assert len(esds) > 0 or reverse
+            assert len(esds) > 0 or reverse or k > 42  # (90 exact bases in a row are rare in this input's diverged copies)
 
 
 def test_golden_trim_kats_on_gpu(hiplib):
