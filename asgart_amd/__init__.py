@@ -36,6 +36,7 @@ ABI_SYMBOLS = (
     "asgart_index_check_sa", "asgart_index_create_trim", "asgart_index_clone",
     "asgart_search_duplications_multi", "asgart_search_duplications_ex", "asgart_search_duplications_passes",
     "asgart_search_duplications_passes_shard", "asgart_families_keys",
+    "asgart_index_export", "asgart_index_create_device", "asgart_trim_cache",
 )
 
 
@@ -85,7 +86,7 @@ class Stats(C.Structure):
             "probes_total", "probes_n_skipped", "probes_searched", "probes_card_skipped",
             "probes_with_hits", "raw_hits", "filtered_hits", "segments", "families", "proto_sds",
             "bisect_steps", "search_launches", "overflow_segments")] + [("ms_extend_tier2", C.c_double), ("heavy_segments", C.c_uint64), ("ms_probe_count", C.c_double),
-        ("search_bytes", C.c_uint64), ("probes_filter_rejected", C.c_uint64)]
+        ("search_bytes", C.c_uint64), ("probes_filter_rejected", C.c_uint64), ("ms_longest_tier", C.c_double)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -117,6 +118,12 @@ def load_library() -> C.CDLL:
     L.asgart_index_create_trim.restype = C.c_int32
     L.asgart_index_clone.argtypes = [vp, C.c_int32, C.POINTER(vp)]
     L.asgart_index_clone.restype = C.c_int32
+    L.asgart_index_export.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int32)]
+    L.asgart_index_export.restype = C.c_int32
+    L.asgart_index_create_device.argtypes = [vp, C.c_int64, vp, C.c_int64, C.c_int32, C.c_int32, C.POINTER(vp)]
+    L.asgart_index_create_device.restype = C.c_int32
+    L.asgart_trim_cache.argtypes = [C.c_int32]
+    L.asgart_trim_cache.restype = C.c_int64
     L.asgart_search_duplications_multi.argtypes = [C.POINTER(vp), C.c_int32, vp, C.c_int64, C.POINTER(_Settings), vp,
                                                    C.POINTER(vp)]
     L.asgart_search_duplications_multi.restype = C.c_int32
@@ -257,6 +264,7 @@ class Index:
         against it.  `sa` is then that shifted array (end - start + 1 entries) or None."""
         L = load_library()
         self.text = _as_u8(text)
+        self.n = len(self.text)
         self._h = C.c_void_p()
         self.trim = trim
         sa_arr = None
@@ -294,10 +302,30 @@ class Index:
         """A replica of this index on `device` (text + suffix array copied device to device)."""
         other = Index.__new__(Index)
         other.text = self.text
+        other.n = self.n
         other.trim = self.trim
         other._h = C.c_void_p()
         _check(load_library().asgart_index_clone(self._h, device, C.byref(other._h)))
         return other
+
+    def export(self) -> Tuple[int, int, int]:
+        """(device address of the text, of the suffix array, bytes per suffix-array entry): what a one-process-per-GPU
+        host broadcasts to the other ranks (asgart_index_export; multi.replicate_index)."""
+        t, a, w = C.c_void_p(), C.c_void_p(), C.c_int32()
+        _check(load_library().asgart_index_export(self._h, C.byref(t), C.byref(a), C.byref(w)))
+        return int(t.value), int(a.value), int(w.value)
+
+    @classmethod
+    def from_device(cls, d_text: int, n: int, d_sa: int, sa_entry_bytes: int, device: int = 0, text=None) -> "Index":
+        """A replica from text and suffix array already in this GPU's memory (asgart_index_create_device: copied)."""
+        self = cls.__new__(cls)
+        self.text = text
+        self.n = int(n)
+        self.trim = None
+        self._h = C.c_void_p()
+        _check(load_library().asgart_index_create_device(C.c_void_p(d_text), n, C.c_void_p(d_sa), n, sa_entry_bytes,
+                                                         device, C.byref(self._h)))
+        return self
 
     def set_option(self, name: str, value: int):
         """Tuning / test option (include/asgart_hip.h: asgart_index_set_option)."""
@@ -432,6 +460,13 @@ def search_duplications_multi(indices: Sequence[Index], chunks: Sequence[Tuple[i
     finally:
         L.asgart_families_free(h)
     return offs, sds
+
+
+def trim_cache(device: int = 0) -> int:
+    """Device memory the library holds for reuse goes back to the device (asgart_trim_cache); -> bytes released."""
+    r = int(load_library().asgart_trim_cache(device))
+    _check(r)
+    return r
 
 
 def sa_build64(text) -> np.ndarray:

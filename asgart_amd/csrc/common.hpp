@@ -61,14 +61,18 @@ struct AllocTimer {
 // the first large hipMalloc after a lot of memory went back to the driver takes SECONDS (tools/ubench_malloc.hip:
 // 1.5 - 5.5 s for 26 GB after 26 - 150 GB were freed) unless it can take over a block of the same size.  The index
 // build frees ~150 GB of sorter scratch and allocates ~60 GB right after: released blocks of 256 MiB and more are
-// therefore kept (per device, up to kCacheCap bytes) and handed to the next request they fit with little waste;
-// everything is given back when an allocation fails and when the last index of the device is destroyed.
+// therefore kept (per device, up to kCacheCap bytes: what a build takes back, not all it releases) and handed to the
+// next request they fit with little waste.  The cache never outlives its purpose: it is emptied when an allocation
+// fails, at the end of asgart_index_prepare (the sorter's scratch is of no use to the search calls), when the last
+// index of the device is destroyed (live counts below) and by asgart_trim_cache -- other allocators on the GPU (the
+// host application's tensors, RCCL buffers, other processes) cannot see what sits here.
 struct BlockCache {
-    static constexpr size_t kCacheMin = (size_t)256 << 20, kCacheCap = (size_t)200 << 30;
+    static constexpr size_t kCacheMin = (size_t)256 << 20, kCacheCap = (size_t)96 << 30;
     struct Dev {
         std::mutex mu;
         std::vector<std::pair<void *, size_t>> blocks;
         size_t bytes = 0;
+        int live = 0;  // indexes alive on this device
     };
     static Dev &dev() {
         static Dev d[16];
@@ -102,18 +106,51 @@ struct BlockCache {
         d.bytes += cap;
         return true;
     }
-    static void trim() {
+    // gives cached blocks back to the device, largest first, until at most `keep` bytes are held
+    static void trim(size_t keep = 0) {
         Dev &d = dev();
         std::vector<std::pair<void *, size_t>> out;
         {
             std::lock_guard<std::mutex> lk(d.mu);
-            out.swap(d.blocks);
-            d.bytes = 0;
+            while (d.bytes > keep && !d.blocks.empty()) {
+                size_t big = 0;
+                for (size_t i = 1; i < d.blocks.size(); ++i)
+                    if (d.blocks[i].second > d.blocks[big].second) big = i;
+                out.push_back(d.blocks[big]);
+                d.bytes -= d.blocks[big].second;
+                d.blocks.erase(d.blocks.begin() + (ptrdiff_t)big);
+            }
         }
         for (auto &b : out) {
             AllocTimer tm("hipFree  ", b.second);
             (void)hipFree(b.first);
         }
+    }
+    static size_t held() {
+        Dev &d = dev();
+        std::lock_guard<std::mutex> lk(d.mu);
+        return d.bytes;
+    }
+    // indexes alive on the current device: the last one to go empties the cache
+    static void index_born() {
+        Dev &d = dev();
+        std::lock_guard<std::mutex> lk(d.mu);
+        ++d.live;
+    }
+    static void index_gone() {
+        Dev &d = dev();
+        bool last;
+        {
+            std::lock_guard<std::mutex> lk(d.mu);
+            last = --d.live <= 0;
+            if (last) d.live = 0;
+        }
+        if (last) trim();
+    }
+    static int live_indexes() {
+        Dev &d = dev();
+        std::lock_guard<std::mutex> lk(d.mu);
+        return d.live;
     }
 };
 
@@ -252,6 +289,8 @@ constexpr int kCacheEntries = 390625;  // 5^8
 constexpr uint32_t kSkipN = 0xFFFFFFFFu;     // probe skipped: first base 'N'
 constexpr uint32_t kSkipCard = 0xFFFFFFFEu;  // probe skipped: > max_cardinality
 constexpr uint32_t kPending = 0xFFFFFFFDu;   // large interval, counted by the wave kernel
+constexpr uint32_t kPendingRank = 0xFFFFFFFCu;  // ... by bisection of its position-sorted list (rank_count_kernel); both
+                                                // marks are gone when the probe search is over
 
 inline bool valid_text_byte(uint8_t c) {
     return c == 'A' || c == 'C' || c == 'G' || c == 'T' || c == 'N' || c == '$';

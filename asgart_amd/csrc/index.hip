@@ -52,6 +52,9 @@ const OptDesc kOptions[] = {
     {"force_wide", &Options::force_wide, 0, 1},
     {"test_wide_batch", &Options::test_wide_batch, 0, 1ll << 40},
     {"kfilter_bits", &Options::kfilter_bits, 0, 34},
+    {"k7", &Options::k7, 0, 127},
+    {"prewarm", &Options::prewarm, 0, 1},
+    {"watchdog_s", &Options::watchdog_s, 0, 86400},
     {"tier_streams", &Options::tier_streams, 1111111, 7777777},
     {"cap6_pct", &Options::cap6_pct, 100, 200},
     {"early_cascade", &Options::early_cascade, 0, 1},
@@ -515,13 +518,10 @@ static inline unsigned grid_capped(uint64_t n, unsigned block = 256) {
     return (unsigned)(g < (1ull << 22) ? g : (1ull << 22));
 }
 
-static void free_k_specific(asgart_index *idx) {
-    if (idx->d_keys) dev_free(idx->d_keys);
-    if (idx->d_ptab) dev_free(idx->d_ptab);
-    if (idx->d_c8lo) dev_free(idx->d_c8lo);
-    if (idx->d_c8hi) dev_free(idx->d_c8hi);
-    if (idx->d_sap) dev_free(idx->d_sap);
-    idx->d_sap = nullptr;
+// the presence filters of every orientation, their position bitmaps and the "no memory for it" marks: ONE place
+// (option kfilter_bits used to drop the hashed tables only: the bitmaps leaked on the rebuild and went on filtering
+// after the filter had been switched off)
+static void free_filters(asgart_index *idx) {
     for (auto &f : idx->d_filter) {
         if (f) dev_free(f);
         f = nullptr;
@@ -531,6 +531,17 @@ static void free_k_specific(asgart_index *idx) {
         f = nullptr;
     }
     for (auto &f : idx->filter_off) f = false;
+    idx->filter_bits = 0;
+}
+
+static void free_k_specific(asgart_index *idx) {
+    if (idx->d_keys) dev_free(idx->d_keys);
+    if (idx->d_ptab) dev_free(idx->d_ptab);
+    if (idx->d_c8lo) dev_free(idx->d_c8lo);
+    if (idx->d_c8hi) dev_free(idx->d_c8hi);
+    if (idx->d_sap) dev_free(idx->d_sap);
+    idx->d_sap = nullptr;
+    free_filters(idx);
     idx->d_keys = nullptr;
     idx->d_ptab = idx->d_c8lo = idx->d_c8hi = nullptr;
     idx->filter_bits = 0;
@@ -693,6 +704,34 @@ int32_t index_prepare(asgart_index *idx, uint64_t k) {
     }
     idx->k = k;
     idx->d = d;
+    if (idx->opt.prewarm) {
+        // What the first search calls would otherwise pay inside their timed part: the per-probe workspace of both call
+        // contexts (an unsharded call over the whole text has at most n / step probes) and the worker thread of the
+        // passes call with its per-thread runtime state.  Best effort: without the memory the calls allocate as they go.
+        const uint64_t step = k / 2 ? k / 2 : 1;
+        const uint64_t W = std::min<uint64_t>((uint64_t)idx->n / step + 1, 0xFFFFFF00ull);
+        for (auto &cx : idx->ctx)
+            if (reserve_probe_workspace(idx, cx, W) != 0) {
+                (void)hipGetLastError();
+                break;
+            }
+        // (a passes call that prepares lazily holds pass_mu itself and owns the workers: leave them to it)
+        if (idx->pass_mu.try_lock()) {
+            if (idx->pass_workers.empty()) {
+                idx->pass_workers.emplace_back(new asgart::PassWorker());
+                const int dev = idx->device;
+                idx->pass_workers[0]->submit([dev]() {
+                    (void)hipSetDevice(dev);
+                    (void)hipFree(nullptr);
+                });
+                idx->pass_workers[0]->wait();
+            }
+            idx->pass_mu.unlock();
+        }
+        lap("workspace of both contexts");
+    }
+    // the sorter's released scratch is of no use to the search calls (their buffers are a tenth of its blocks)
+    BlockCache::trim();
     idx->ms_prepare =
         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return 0;
@@ -777,6 +816,7 @@ int32_t index_prepare_filter(asgart_index *idx, uint64_t k, int mode) {
                 dev_free(flt);
                 return rc;
             }
+            if (idx->d_pbits[mode]) dev_free(idx->d_pbits[mode]);
             idx->d_pbits[mode] = pb;
         } else {
             (void)hipGetLastError();  // no memory: the hashed filter serves
@@ -815,6 +855,7 @@ void asgart_index_destroy(asgart_index *idx) {
             if (st) (void)hipStreamDestroy(st);
     }
     delete idx;
+    BlockCache::index_gone();  // the last index of the device takes the cached blocks with it
 }
 
 static int32_t index_create_impl(const uint8_t *T, int64_t n, const int64_t *SA, int64_t sa_len,
@@ -847,6 +888,7 @@ static int32_t index_create_impl(const uint8_t *T, int64_t n, const int64_t *SA,
         set_error("out of host memory");
         return ASGART_E_OOM;
     }
+    BlockCache::index_born();  // (check_device made `device` current)
     idx->device = device;
     idx->n = n;
     idx->n_sa = n_sa;
@@ -974,6 +1016,7 @@ int32_t asgart_index_clone(asgart_index *src, int32_t device, asgart_index **out
         set_error("out of host memory");
         return ASGART_E_OOM;
     }
+    BlockCache::index_born();
     idx->device = device;
     idx->n = src->n;
     idx->n_sa = src->n_sa;
@@ -1008,6 +1051,86 @@ int32_t asgart_index_clone(asgart_index *src, int32_t device, asgart_index **out
     return 0;
 }
 
+int64_t asgart_trim_cache(int32_t device) {
+    RC_TRY(check_device(device));
+    const size_t held = BlockCache::held();
+    BlockCache::trim();
+    return (int64_t)held;
+}
+
+int32_t asgart_index_export(asgart_index *idx, const void **d_text, const void **d_sa, int32_t *sa_entry_bytes) {
+    if (!idx) {
+        set_error("index is NULL");
+        return ASGART_E_ARG;
+    }
+    if (d_text) *d_text = idx->d_text;
+    if (d_sa) *d_sa = idx->d_sa;
+    if (sa_entry_bytes) *sa_entry_bytes = idx->wide ? 8 : 4;
+    return 0;
+}
+
+int32_t asgart_index_create_device(const void *d_text, int64_t n, const void *d_sa, int64_t sa_len,
+                                   int32_t sa_entry_bytes, int32_t device, asgart_index **out) {
+    if (!out) {
+        set_error("asgart_index_create_device: out is NULL");
+        return ASGART_E_ARG;
+    }
+    *out = nullptr;
+    if (!d_text || !d_sa || n <= 0 || sa_len != n) {
+        set_error("asgart_index_create_device: need the text and a suffix array of the same length on the device");
+        return ASGART_E_ARG;
+    }
+    RC_TRY(check_device(device));
+    asgart::Options opt;
+    options_from_env(opt);
+    const bool wide = (uint64_t)n >= 0xFFFFFF00ull || opt.force_wide != 0;
+    if (sa_entry_bytes != (wide ? 8 : 4)) {
+        set_error("asgart_index_create_device: a text of %lld bytes takes %d-byte suffix-array entries here (got %d)",
+                  (long long)n, wide ? 8 : 4, sa_entry_bytes);
+        return ASGART_E_ARG;
+    }
+    asgart_index *idx = new (std::nothrow) asgart_index();
+    if (!idx) {
+        set_error("out of host memory");
+        return ASGART_E_OOM;
+    }
+    BlockCache::index_born();
+    idx->device = device;
+    idx->n = n;
+    idx->n_sa = n;
+    idx->opt = opt;
+    idx->wide = wide;
+    for (auto &cx : idx->ctx) memset(&cx.stats, 0, sizeof(cx.stats));
+    int32_t rc = [&]() -> int32_t {
+        for (auto &cx : idx->ctx) RC_TRY(create_ctx_streams(cx));
+        hipStream_t s = idx->ctx[0].stream;
+        const size_t slot = wide ? 8 : 4;
+        HIP_TRY(dev_malloc((void **)&idx->d_text, (size_t)n + 64));
+        HIP_TRY(dev_malloc(&idx->d_sa, ((size_t)n + 16) * slot));
+        HIP_TRY(hipMemsetAsync(idx->d_text + n, 0, 64, s));
+        HIP_TRY(hipMemcpyAsync(idx->d_text, d_text, (size_t)n, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(idx->d_sa, d_sa, (size_t)n * slot, hipMemcpyDeviceToDevice, s));
+        bool dna = false;
+        RC_TRY(text_is_dna(idx->d_text, n, s, &dna));
+        const int64_t tl = n < (int64_t)kMaxK + 32 ? n : (int64_t)kMaxK + 32;
+        idx->h_tail.resize((size_t)tl);
+        HIP_TRY(hipMemcpyAsync(idx->h_tail.data(), idx->d_text + (n - tl), (size_t)tl, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (!dna) {
+            set_error("text contains bytes other than the normalised bases {A,C,G,T,N} and '$' "
+                      "(reference src/bin/asgart.rs:289-301,430)");
+            return ASGART_E_ARG;
+        }
+        return 0;
+    }();
+    if (rc != 0) {
+        asgart_index_destroy(idx);
+        return rc;
+    }
+    *out = idx;
+    return 0;
+}
+
 int32_t asgart_index_set_option(asgart_index *idx, const char *name, int64_t value) {
     if (!idx) {
         set_error("index is NULL");
@@ -1020,13 +1143,9 @@ int32_t asgart_index_set_option(asgart_index *idx, const char *name, int64_t val
     idx->acquire_all();  // never changes under a running call
     const int32_t rc = option_set(idx->opt, name, value);
     if (rc == 0 && !strcmp(name, "test_fail_alloc")) asgart::fail_alloc_countdown().store(value);  // (process-wide)
-    if (rc == 0 && !strcmp(name, "kfilter_bits")) {  // rebuilt at the new size by the next call
+    if (rc == 0 && !strcmp(name, "kfilter_bits")) {  // rebuilt at the new size by the next call (0: searched without)
         (void)hipSetDevice(idx->device);
-        for (auto &f : idx->d_filter) {
-            if (f) dev_free(f);
-            f = nullptr;
-        }
-        idx->filter_bits = 0;
+        free_filters(idx);
     }
     idx->release_all();
     return rc;

@@ -229,6 +229,12 @@ struct Options {
                                     // cfg4, 8 shards: balanced (91-117 ms direct) but the replicated front makes its slowest shard
                                     // slower than the slice mode's (211 vs 184 ms -RC, 117 vs 90 ms direct): the floor is the longest segment
     int64_t tier_streams = 7234562; // digit t (from the left): the stream (1..7, 1 = the call's high-priority main stream) tier t runs on
+    int64_t k7 = 120;               // bit t set (t = 3..6): tier t runs the arm kernel with a control wave (extend_k7_dev.hpp); takes precedence over `fast`
+    int64_t prewarm = 1;            // 1: asgart_index_prepare also reserves the per-probe workspace of both call contexts (sized for an
+                                    // unsharded call over the whole text) and starts the worker thread of the passes call, so that the first
+                                    // search calls allocate nothing chip-sized; 0: everything on first use (hosts that only issue sharded calls)
+    int64_t watchdog_s = 120;       // a search call whose device work makes no progress for this many seconds returns ASGART_E_HIP with the
+                                    // last heartbeats of its kernels instead of waiting forever; 0: wait forever
 };
 int32_t create_ctx_streams(SearchCtx &cx);
 int32_t build_rank_lists(const uint64_t *d_keys, const uint32_t *d_sa, uint64_t n, uint32_t *d_sap, hipStream_t s);  // the streams and events of one call context (current device)
@@ -398,6 +404,8 @@ struct asgart_families {
 
 namespace asgart {
 int32_t index_prepare(asgart_index *idx, uint64_t k);
+// per-probe workspace of one call context for a window of W probes (pipeline.hip; also what run_search_t reserves)
+int32_t reserve_probe_workspace(asgart_index *idx, SearchCtx &cx, uint64_t W);
 int32_t index_prepare_filter(asgart_index *idx, uint64_t k, int mode);  // mode = reverse * 2 + complement
 int32_t run_search(asgart_index *idx, const uint64_t *chunks, int64_t n_chunks,
                    const asgart_settings *st, int32_t shard, int32_t n_shards, bool want_csr,

@@ -6,6 +6,7 @@
 // left fix-up, fold in chunk order).
 #include "pipeline_dev.hpp"
 #include "extend_fast_dev.hpp"
+#include "extend_k7_dev.hpp"
 
 #include <algorithm>
 #include <atomic>
@@ -74,6 +75,12 @@ template <class SlotT> constexpr int kLongArmsLayers = sizeof(SlotT) == 4 ? 5 : 
 template <class SlotT> constexpr int kFastLongLayers = sizeof(SlotT) == 4 ? 5 : 4;   // (64-bit positions: 4 x 1024, a smaller table)
 template <class SlotT> constexpr int kFastHeavyLayers = sizeof(SlotT) == 4 ? 5 : 4;  // tier 6
 template <class SlotT> constexpr int kFastLongRows = sizeof(SlotT) == 4 ? 2048 : 1024;
+// ... of the kernel with a control wave (option k7, extend_k7_dev.hpp): the last wave holds no arms, so a shape of NT
+// threads has S x (NT - 64) slots: tiers 3 and 6 = 5 x 960 (64-bit positions: 4 x 960), tier 4 = 6 x 192 (3 x 192),
+// tier 5 = 5 x 448 (3 x 448)
+template <class SlotT> constexpr int kK7LongLayers = sizeof(SlotT) == 4 ? 5 : 4;
+template <class SlotT> constexpr int kK7Mid4Layers = sizeof(SlotT) == 4 ? 6 : 3;
+template <class SlotT> constexpr int kK7Mid5Layers = sizeof(SlotT) == 4 ? 5 : 3;
 constexpr int kPoleLdsPad = 0;             // > 0: tier 3 workgroups take a whole CU (measured: no gain)
 constexpr int kArmCapSmall = 256;   // live arms per wave in LDS, common case
 constexpr uint32_t kTier1MaxSum = 20000;  // placement: busier segments never run on a single wave
@@ -91,6 +98,20 @@ static uint32_t probes_in_chunk(uint64_t L, uint64_t k, uint64_t step, uint64_t 
     // loop of src/automaton.rs:92-97: `while i < L - k - step { i += step; ... }`
     if (L < M || L < k + step || L - k - step == 0) return 0;
     return (uint32_t)((L - k - step + step - 1) / step);
+}
+
+int32_t reserve_probe_workspace(asgart_index *idx, SearchCtx &cx, uint64_t W) {
+    Workspace &w = cx.ws;
+    const uint64_t n_blk = (W + kScanTile - 1) / kScanTile;
+    RC_TRY(w.p_lo.reserve((size_t)W * (idx->wide ? 8 : 4)));
+    RC_TRY(w.p_raw.reserve((size_t)W * 4));
+    RC_TRY(w.p_filt.reserve((size_t)W * 4));
+    RC_TRY(w.row_off.reserve(((size_t)W + 1) * 8));
+    RC_TRY(w.blk.reserve((size_t)n_blk * sizeof(ScanEl)));
+    RC_TRY(w.big_list.reserve((size_t)W * 4));
+    if (idx->d_sap) RC_TRY(w.rank_list.reserve((size_t)W * 4));
+    RC_TRY(w.counters.reserve(CT_COUNT * 8));
+    return 0;
 }
 
 template <class SlotT>
@@ -157,11 +178,11 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
     // global probe sequence.  It computes probe-search over that slice plus a look-back halo
     // (to decide whether its first probes continue an earlier segment) and a look-ahead halo
     // (to finish segments that run past the slice); no data is exchanged between shards.
-    // With option shard_lpt (default) the shards do not cut the probe sequence at all: every shard computes the
-    // whole front -- probe search, scans, hit rows, placement: a tenth of a step -- and then owns every
-    // n_shards-th segment of each tier's cost-sorted list (take_owned_kernel): the long serial segments, which
-    // sit next to each other in the genome, land on different GPUs.  Still no exchange; the gatherer merges the
-    // shards' families by their keys (asgart_families_keys).
+    // That is the default (option shard_lpt = 0).  With shard_lpt = 1 the shards do not cut the probe sequence at
+    // all: every shard computes the whole front -- probe search, scans, hit rows, placement: a tenth of a step --
+    // and then owns every n_shards-th segment of each tier's cost-sorted list (take_owned_kernel): the long serial
+    // segments, which sit next to each other in the genome, land on different GPUs.  Still no exchange; the
+    // gatherer then MUST merge the shards' families by their keys (asgart_families_keys): they interleave.
     const Options opt = idx->opt;  // options cannot change while this call holds a context
     const bool lpt = n_shards > 1 && opt.shard_lpt != 0;
     const int32_t f_shard = lpt ? 0 : shard, f_n = lpt ? 1 : n_shards;
@@ -182,7 +203,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
     HIP_TRY(hipMemcpyAsync(d_start, h_start, ch_bytes, hipMemcpyHostToDevice, s));  // same layout on the device
     uint64_t total_hits = 0, n_seg = 0, n_overflow = 0, n_heavy = 0;
     bool progress_given = false;
-    double ms_tier2 = 0.0;
+    double ms_tier2 = 0.0, ms_longest_tier = 0.0;
     RunParams rp;
     const auto t_host0 = std::chrono::steady_clock::now();
     for (int win_try = 0;; ++win_try) {
@@ -219,13 +240,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
     // ---- workspace (indexed by absolute probe number through shifted pointers) ---
     const uint32_t n_blk = (W + kScanTile - 1) / kScanTile;
     const uint64_t seg_cap = (uint64_t)W / (rp.tstar + 1) + (uint64_t)n_chunks + 64;
-    RC_TRY(w.p_lo.reserve((size_t)W * sizeof(SlotT)));
-    RC_TRY(w.p_raw.reserve((size_t)W * 4));
-    RC_TRY(w.p_filt.reserve((size_t)W * 4));
-    RC_TRY(w.row_off.reserve(((size_t)W + 1) * 8));
-    RC_TRY(w.blk.reserve((size_t)n_blk * sizeof(ScanEl)));
-    RC_TRY(w.big_list.reserve((size_t)W * 4));
-    if (idx->d_sap) RC_TRY(w.rank_list.reserve((size_t)W * 4));
+    RC_TRY(reserve_probe_workspace(idx, cx, W));
     RC_TRY(w.seg_list.reserve((size_t)seg_cap * 4));
     RC_TRY(w.counters.reserve(CT_COUNT * 8));
     unsigned long long *d_ctr = w.counters.as<unsigned long long>();
@@ -254,6 +269,8 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
     probe_count_kernel<SlotT, false><<<grid_for(W, kProbeBlock), kProbeBlock, 0, s>>>(
         ix, rp, p_lo, p_raw, p_filt, big_list, rank_list, d_ctr);
     HIP_TRY(hipEventRecord(cx.ev[11], s));
+    collect_pending_kernel<<<std::min<uint32_t>((W + kCollectTile - 1) / kCollectTile, 256u * 8u), kCollectBlock, 0, s>>>(
+        rp, p_filt, big_list, rank_list, d_ctr);
     big_count_kernel<SlotT, false><<<2048, 256, 0, s>>>(ix, rp, p_lo, p_raw, p_filt, big_list, d_ctr);
     // (after big_count_kernel: what it appends to big_list is for the fill only)
     if (ix.sap)
@@ -341,30 +358,38 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             if (t == 6 && sizeof(SlotT) == 8 && !opt.fast6w) return false;
             return arms_kernel && ((opt.fast >> t) & 1) != 0 && (uint64_t)idx->n < (1ull << 42);
         };
+        // the kernel with a control wave takes tiers 3..6 where option k7 says so (it needs a second wave: not tier 2)
+        auto k7_tier = [&](int t) {
+            return t >= 3 && t <= 6 && arms_kernel && ((opt.k7 >> t) & 1) != 0 && (uint64_t)idx->n < (1ull << 42);
+        };
         uint32_t tier_cap[kTiers + 1] = {0, kArmCapSmall, 0, 0, 0, 0, 0, 0xFFFFFFFFu};  // (tier 7 takes whatever is left)
         if (arms_kernel) {
             if (arms_small) {
                 tier_cap[2] = (uint32_t)kWaveArmsLayers<SlotT> * 64u;
-                tier_cap[4] = (uint32_t)((uint64_t)kMidArmsLayers<SlotT> * 256u * (uint64_t)opt.cap45_pct / 100u);
+                tier_cap[4] = (uint32_t)((uint64_t)(k7_tier(4) ? kK7Mid4Layers<SlotT> * 192 : kMidArmsLayers<SlotT> * 256) *
+                                         (uint64_t)opt.cap45_pct / 100u);
             }
-            tier_cap[3] = (uint32_t)(fast_tier(3) ? kFastLongLayers<SlotT> : kLongArmsLayers<SlotT>) * 1024u;
+            tier_cap[3] = k7_tier(3) ? (uint32_t)kK7LongLayers<SlotT> * 960u
+                                     : (uint32_t)(fast_tier(3) ? kFastLongLayers<SlotT> : kLongArmsLayers<SlotT>) * 1024u;
 
-            tier_cap[5] = (uint32_t)((uint64_t)kMidArmsLayers<SlotT> * 512u * (uint64_t)opt.cap45_pct / 100u);
+            tier_cap[5] = (uint32_t)((uint64_t)(k7_tier(5) ? kK7Mid5Layers<SlotT> * 448 : kMidArmsLayers<SlotT> * 512) *
+                                     (uint64_t)opt.cap45_pct / 100u);
             // the window bound is pessimistic for tandem arrays (hits extend arms there) and the HBM
             // tier is several times slower per probe: tier 6 also takes segments whose bound exceeds
             // its capacity by up to 40 % (a real overflow falls through the cascade)
             // (64-bit positions on the one-barrier kernel: the HBM tier is an order of magnitude slower per probe and the
             // bound three to four times what a segment really holds -- at cfg5 every segment that went to tier 7 by its
             // bound peaked below 4 096 arms: tier 6 accepts up to cap6w_pct of its capacity)
-            const uint64_t pct6 = (fast_tier(6) && sizeof(SlotT) == 8) ? (uint64_t)opt.cap6w_pct : (uint64_t)opt.cap6_pct;
-            tier_cap[6] = (uint32_t)((uint64_t)(fast_tier(6) ? kFastHeavyLayers<SlotT> * 1024 : kArmsLayers<SlotT> * kHeavyThreads) *
+            const uint64_t pct6 = ((fast_tier(6) || k7_tier(6)) && sizeof(SlotT) == 8) ? (uint64_t)opt.cap6w_pct : (uint64_t)opt.cap6_pct;
+            tier_cap[6] = (uint32_t)((uint64_t)(k7_tier(6) ? kK7LongLayers<SlotT> * 960
+                                                           : (fast_tier(6) ? kFastHeavyLayers<SlotT> * 1024 : kArmsLayers<SlotT> * kHeavyThreads)) *
                                      pct6 / 100u);
             // tier 3 accepts what tier 6 would accept by the bound (a long segment is no less safe there), but
             // never more than the same allowance over its own capacity (with 64-bit positions it holds fewer
             // arms than tier 6, and what it gives up on is re-run from the start)
             // (the bound of a tandem array is three to four times what it really holds: the one-barrier kernel, a fifth
             // faster per probe on such segments, takes them up to cap3_pct of its capacity)
-            const uint64_t pct3 = fast_tier(3) ? (uint64_t)opt.cap3_pct : (uint64_t)opt.cap6_pct;
+            const uint64_t pct3 = (fast_tier(3) || k7_tier(3)) ? (uint64_t)opt.cap3_pct : (uint64_t)opt.cap6_pct;
             tier_cap[3] = std::min<uint32_t>(std::max(tier_cap[3], tier_cap[6]),
                                              (uint32_t)((uint64_t)tier_cap[3] * pct3 / 100u));
         } else {
@@ -471,7 +496,9 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
         // (every live arm was created or extended within the last t* + 1 processed probes, at most max_cardinality
         // per probe; src/automaton.rs:87 keeps them in an unbounded Vec), and its slices are sized for that.  Large
         // bounds get fewer workgroups (a 16 GB budget for the four regions), never fewer than one.
-        const uint64_t heavy_cap64 = std::max<uint64_t>((uint64_t)rp.C * ((uint64_t)rp.tstar + 1u) + 64u, 4096u);
+        // (rounded up to a multiple of 4: a workgroup's slice holds 64-bit position arrays behind arrays of this many
+        // 32-bit words, and slices, regions and the early-cascade regions follow one another at multiples of it)
+        const uint64_t heavy_cap64 = (std::max<uint64_t>((uint64_t)rp.C * ((uint64_t)rp.tstar + 1u) + 64u, 4096u) + 3u) & ~3ull;
         if (heavy_cap64 >= (1ull << 24)) {
             set_error("max_cardinality * (max_gap_size / step + 1) = %llu live arms per segment: more than 2^24 are not supported",
                       (unsigned long long)heavy_cap64);
@@ -568,7 +595,9 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                         extend_heavy_kernel<SlotT, kArmCapMid, kMidThreads, 0><<<grid(kGrid2), kMidThreads, 0, st>>>(ep);
                     break;
                 case 3:
-                    if (fast_tier(3)) {
+                    if (k7_tier(3)) {
+                        extend_k7_kernel<SlotT, kK7LongLayers<SlotT>, 1024, kHitBatch, kFastLongRows<SlotT>, 2><<<grid(256), 1024, 0, st>>>(ep);
+                    } else if (fast_tier(3)) {
                         // (the same capacity in three shapes: per-probe work every wave repeats -- ranking the
                         // empty slots and the unmatched hits -- is paid once per wave sharing a SIMD)
                         extend_fast_kernel<SlotT, kFastLongLayers<SlotT>, 1024, kHitBatch, kFastLongRows<SlotT>, 2><<<grid(256), 1024, 0, st>>>(ep);
@@ -576,7 +605,9 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                         extend_arms_kernel<SlotT, kLongArmsLayers<SlotT>, 1024, kHitBatch, 1024, 4, false, true, kPoleLdsPad><<<grid(256), 1024, 0, st>>>(ep);
                     break;
                 case 4:
-                    if (fast_tier(4))
+                    if (k7_tier(4))
+                        extend_k7_kernel<SlotT, kK7Mid4Layers<SlotT>, 256, kWaveArmsHits, 512, 2><<<grid(256 * 4), 256, 0, st>>>(ep);
+                    else if (fast_tier(4))
                         extend_fast_kernel<SlotT, kMidArmsLayers<SlotT>, 256, kWaveArmsHits, 512, 2><<<grid(256 * 4), 256, 0, st>>>(ep);
                     else if (arms_kernel)
                         extend_arms_kernel<SlotT, kMidArmsLayers<SlotT>, 256, kWaveArmsHits, 512, 4, false, true><<<grid(256 * 4), 256, 0, st>>>(ep);
@@ -586,14 +617,18 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                         extend_heavy_kernel<SlotT, kArmCapBig64, kHeavyThreads, 0><<<grid(256), kHeavyThreads, 0, st>>>(ep);
                     break;
                 case 5:
-                    if (fast_tier(5))
+                    if (k7_tier(5))
+                        extend_k7_kernel<SlotT, kK7Mid5Layers<SlotT>, 512, kHitBatch, 1024, 2><<<grid(256 * 2), 512, 0, st>>>(ep);
+                    else if (fast_tier(5))
                         extend_fast_kernel<SlotT, kMidArmsLayers<SlotT>, 512, kHitBatch, 1024, 2><<<grid(256 * 2), 512, 0, st>>>(ep);
                     else
                         extend_arms_kernel<SlotT, kMidArmsLayers<SlotT>, 512, kHitBatch, 1024, 4, false, true><<<grid(256 * 2), 512, 0, st>>>(ep);
                     break;
                 case 6:
                     if (scratch_override) ep.scratch = scratch_override;
-                    if (fast_tier(6))  // 5 x 1024 >= 9 x 512 slots; 64-bit positions: 4 x 1024 = 8 x 512 with a smaller table
+                    if (k7_tier(6))
+                        extend_k7_kernel<SlotT, kK7LongLayers<SlotT>, 1024, kHitBatch, kFastLongRows<SlotT>, 2><<<grid(256), 1024, 0, st>>>(ep);
+                    else if (fast_tier(6))  // 5 x 1024 >= 9 x 512 slots; 64-bit positions: 4 x 1024 = 8 x 512 with a smaller table
                         extend_fast_kernel<SlotT, kFastHeavyLayers<SlotT>, 1024, kHitBatch, kFastLongRows<SlotT>, 2><<<grid(256), 1024, 0, st>>>(ep);
                     else if (arms_kernel)
                         extend_arms_kernel<SlotT, kArmsLayers<SlotT>, kHeavyThreads, kHitBatch, 1024, 4, false, kArmsCold<SlotT>><<<grid(256), kHeavyThreads, 0, st>>>(ep);
@@ -738,6 +773,15 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             HIP_TRY(hipStreamSynchronize(s));
             PROF_DUMP("concurrent tiers");
             if (opt.debug) fprintf(stderr, "[asgart] all tiers and early re-runs done %.1f ms after the launches\n", since_launch());
+            {   // the tier that ran longest (its early re-run included): the serial floor of this call's extension
+                float longest = 0.f;
+                for (int e : {5, 6, 8, 9, 10, 12}) {
+                    float t = 0.f;
+                    if (hipEventElapsedTime(&t, cx.ev[7], cx.ev[e]) == hipSuccess) longest = std::max(longest, t);
+                    else (void)hipGetLastError();
+                }
+                ms_longest_tier = longest;
+            }
             n_overflow = 0;
             for (int t = 1; t < kTiers; ++t) n_overflow += h_ctr[CT_OVF1 + t - 1];
             if (opt.debug) {
@@ -864,6 +908,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
     stt.heavy_segments = n_heavy;
 
     stt.ms_extend_tier2 = ms_tier2;
+    stt.ms_longest_tier = ms_longest_tier;
     HIP_TRY(hipEventElapsedTime(&ms, cx.ev[0], cx.ev[11]));
     stt.ms_probe_count = ms;
     cx.has_last = true;
@@ -1068,9 +1113,14 @@ int32_t asgart_search_duplications_passes_shard(asgart_index *idx, const uint64_
     // whole text instead of the part behind the probe)
     std::vector<int32_t> order((size_t)n_passes);
     for (int32_t j = 0; j < n_passes; ++j) order[j] = j;
+    double tail_ms[4];
+    {   // (a plain call on the other context may be updating them: run_search writes under the same lock)
+        std::lock_guard<std::mutex> lk(idx->mu);
+        for (int m = 0; m < 4; ++m) tail_ms[m] = idx->tail_ms[m];
+    }
     auto weight = [&](int32_t j) {
         const int mode = (settings[j].reverse ? 2 : 0) | (settings[j].complement ? 1 : 0);
-        const double t = idx->tail_ms[mode];
+        const double t = tail_ms[mode];
         return t >= 0.0 ? t : 1e30 + (settings[j].reverse ? 1e29 : 0.0);
     };
     std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return weight(a) > weight(b); });

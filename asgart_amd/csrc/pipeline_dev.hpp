@@ -224,15 +224,9 @@ __global__ __launch_bounds__(kProbeBlock) void probe_count_kernel(IndexView<Slot
     // (wave ballot + one LDS atomic per wave) and looked up by the first ceil(n / 64) waves with all lanes busy;
     // the other waves retire at once and their slots go to the next workgroup, so that more full waves of
     // gathers are in flight per CU.
-    __shared__ uint32_t s_nsurv, s_nbig, s_nrank;
+    __shared__ uint32_t s_nsurv;
     __shared__ uint8_t s_surv[kProbeBlock];
-    __shared__ uint32_t s_big[kProbeBlock];   // large intervals: counted by streaming from the front, by bisection from the back
-    __shared__ unsigned long long s_bbase, s_rbase;
-    if (tid == 0) {  // (ordered before their first use by the barrier behind the filter tests)
-        s_nsurv = 0;
-        s_nbig = 0;
-        s_nrank = 0;
-    }
+    if (tid == 0) s_nsurv = 0;  // (ordered before its first use by the barrier behind the filter tests)
     uint32_t n_rej = 0;
     bool survivor = false;
     if (valid) {
@@ -292,15 +286,14 @@ __global__ __launch_bounds__(kProbeBlock) void probe_count_kernel(IndexView<Slot
             if (!COUNT) p_filt[g_] = cnt > rp.C ? kSkipCard : cnt;
             cb.wr(4);
         } else {
-            if (!COUNT) {
-                p_filt[g_] = kPending;
-                // a whole k-mer interval of some size: its kept count is a bisection of the position-sorted list
-                if (ix.sap && all_occurrences && raw > (uint64_t)kRankMin)
-                    s_big[kProbeBlock - 1 - atomicAdd(&s_nrank, 1u)] = g_;
-                else
-                    s_big[atomicAdd(&s_nbig, 1u)] = g_;
-            }
-            cb.wr(4 + 4);  // + its work-list entry
+            // a large interval is only MARKED here; collect_pending_kernel turns the marks into the two work lists.
+            // (A workgroup-aggregated append from this kernel cost every workgroup a returning atomic on one of two
+            // adjacent counters: 1.2 M workgroups per GRCh38-sized pass at the ~90 same-address atomics per
+            // microsecond the chip sustains is the whole duration of this kernel.)
+            // a whole k-mer interval of some size: its kept count is a bisection of the position-sorted list
+            if (!COUNT) p_filt[g_] = (ix.sap && all_occurrences && raw > (uint64_t)kRankMin) ? kPendingRank : kPending;
+            cb.wr(4 + 4);  // + its work-list entry (written by the collecting pass)
+            cb.rd(4);      //   ... which reads the mark back
         }
     };
     if (uniform) {
@@ -347,21 +340,70 @@ __global__ __launch_bounds__(kProbeBlock) void probe_count_kernel(IndexView<Slot
             atomicAdd(&ctr[CT_ALG_BYTES], s_tot[0]);
             if (s_tot[1]) atomicAdd(&ctr[CT_FLT_REJECTED], s_tot[1]);
         }
-    } else {
-        // workgroup-aggregated append to the large-interval work list (one global atomic per group); the waves
-        // still running hold every entry: nbig <= the number of survivors
-        __syncthreads();
-        const uint32_t nbig = s_nbig, nrank = s_nrank;
-        if (nbig | nrank) {
-            if (tid == 0) {
-                if (nbig) s_bbase = atomicAdd(&ctr[CT_BIG], (unsigned long long)nbig);
-                if (nrank) s_rbase = atomicAdd(&ctr[CT_RANK], (unsigned long long)nrank);
-            }
-            __syncthreads();
-            if (tid < nbig) big_list[s_bbase + tid] = s_big[tid];
-            if (tid < nrank) rank_list[s_rbase + tid] = s_big[kProbeBlock - 1 - tid];
-        }
     }
+    // (no barrier behind the lookups: the waves that retired above never meet the others again)
+}
+
+// The probes probe_count_kernel marked as large intervals -> the two work lists (big_list: counted by streaming the
+// interval; rank_list: by bisection of its position-sorted list).  Persistent workgroups over contiguous spans of the
+// probe sequence: the marks of a tile are compacted by wave ballots into two LDS buffers, which are appended to the
+// lists with ONE global atomic per 2 K entries instead of one (or two) per 256 probes.  Streams 4 bytes per probe.
+constexpr int kCollectBlock = 256, kCollectItems = 8, kCollectTile = kCollectBlock * kCollectItems;
+constexpr int kCollectCap = 2 * kCollectTile;
+__global__ __launch_bounds__(kCollectBlock) void collect_pending_kernel(RunParams rp, const uint32_t *__restrict__ p_filt,
+                                                                        uint32_t *__restrict__ big_list,
+                                                                        uint32_t *__restrict__ rank_list,
+                                                                        unsigned long long *__restrict__ ctr) {
+    __shared__ uint32_t s_buf[2][kCollectCap];
+    __shared__ uint32_t s_cnt[2];
+    __shared__ unsigned long long s_base[2];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    if (tid < 2) s_cnt[tid] = 0;
+    __syncthreads();
+    const uint32_t W = rp.g_hi - rp.g_lo;
+    const uint32_t n_tiles = (W + (uint32_t)kCollectTile - 1u) / (uint32_t)kCollectTile;
+    // a contiguous run of tiles per workgroup (the lists then follow the probe order in long stretches)
+    const uint32_t t0 = (uint32_t)((uint64_t)n_tiles * blockIdx.x / gridDim.x);
+    const uint32_t t1 = (uint32_t)((uint64_t)n_tiles * (blockIdx.x + 1u) / gridDim.x);
+    auto flush = [&](int which, uint32_t *__restrict__ list, int counter) {  // (workgroup-uniform)
+        const uint32_t n = s_cnt[which];
+        if (!n) return;
+        if (tid == 0) s_base[which] = atomicAdd(&ctr[counter], (unsigned long long)n);
+        __syncthreads();
+        const unsigned long long b = s_base[which];
+        for (uint32_t j = tid; j < n; j += kCollectBlock) list[b + j] = s_buf[which][j];
+        __syncthreads();
+        if (tid == 0) s_cnt[which] = 0;
+        __syncthreads();
+    };
+    for (uint32_t t = t0; t < t1; ++t) {
+        const uint32_t g0 = rp.g_lo + t * (uint32_t)kCollectTile;
+#pragma unroll
+        for (int a = 0; a < kCollectItems; ++a) {
+            const uint32_t g = g0 + (uint32_t)a * kCollectBlock + tid;  // coalesced
+            const uint32_t f = g < rp.g_hi ? p_filt[g] : 0u;
+            const bool big = f == kPending, rank = f == kPendingRank;
+            const unsigned long long mb = __ballot(big), mr = __ballot(rank);
+            if (mb) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&s_cnt[0], (uint32_t)__popcll(mb));
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if (big) s_buf[0][base + (uint32_t)__popcll(mb & lt_mask)] = g;
+            }
+            if (mr) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&s_cnt[1], (uint32_t)__popcll(mr));
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if (rank) s_buf[1][base + (uint32_t)__popcll(mr & lt_mask)] = g;
+            }
+        }
+        __syncthreads();
+        if (s_cnt[0] > (uint32_t)(kCollectCap - kCollectTile)) flush(0, big_list, CT_BIG);
+        if (s_cnt[1] > (uint32_t)(kCollectCap - kCollectTile)) flush(1, rank_list, CT_RANK);
+    }
+    flush(0, big_list, CT_BIG);
+    flush(1, rank_list, CT_RANK);
 }
 
 // Large whole-k-mer intervals when the index holds the position-sorted occurrence lists: the hit filter keeps the

@@ -716,5 +716,7 @@ extern "C" int32_t asgart_sa_build64(const uint8_t *T, int64_t *SA, int64_t n) {
     sa.release();
     out.release();
     if (s) (void)hipStreamDestroy(s);
+    // (a stand-alone suffix sort leaves nothing behind in the block cache unless an index of this device may reuse it)
+    if (BlockCache::live_indexes() == 0) BlockCache::trim();
     return rc;
 }

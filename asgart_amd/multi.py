@@ -1,10 +1,15 @@
-"""Multi-GPU host side: gather the per-shard duplicon lists (one process per GPU).
+"""Multi-GPU host side (one process per GPU): replicate the index, gather the per-shard duplicon lists.
 
-The search itself needs no collective: every shard computes the whole front and
-owns every n-th segment of each extension tier's cost-sorted list; the shards' families, merged by their
-keys (segment start probe, family ordinal), ARE the unsharded result.  This module only moves those small
-lists to one rank with torch.distributed (backend "nccl" == RCCL over xGMI on MI355X, "gloo" in the CPU
-tests) and merges them there.
+The search itself needs no collective.  By default (option shard_lpt = 0) shard r owns the
+automaton segments that START in the r-th contiguous slice of the global probe sequence and searches that slice plus
+halos; with shard_lpt = 1 every shard computes the whole front and owns every n-th segment of each extension tier's
+cost-sorted list, so the shards interleave.  Either way the shards' families, MERGED BY THEIR KEYS (segment start
+probe, family ordinal: asgart_families_keys), are the unsharded result -- gather_families therefore wants the keys
+(without them it can only concatenate in rank order, which is right for contiguous slices alone).
+The two exchanges of the arrangement, both with torch.distributed (backend "nccl" == RCCL over xGMI on MI355X, "gloo"
+in the CPU tests and on one-GPU boxes):
+  replicate_index   text + suffix array broadcast from the rank that sorted the suffixes;
+  gather_families   the small per-shard lists to one rank, merged there (section 8e (2)).
 """
 from __future__ import annotations
 
@@ -55,3 +60,48 @@ def gather_families(offs: np.ndarray, sds: np.ndarray, dist, device: Optional[st
     out_offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
     out_sds = np.concatenate([p[1] for p in parts]) if parts else np.zeros((0, 4), np.uint64)
     return out_offs, out_sds
+
+
+class _DeviceBytes:
+    """A device address range as an object torch.as_tensor understands (zero-copy view of library memory)."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False),
+                                         "version": 2}
+
+
+def replicate_index(idx, dist, device_index: int, src: int = 0, piece: int = 1 << 30):
+    """Every rank ends up with an index of the same text on ITS GPU, the suffixes sorted once: rank `src` passes the
+    index it built (the others pass None); text and suffix array travel device to device as broadcasts of `piece`-byte
+    slabs straight out of the library's buffers (asgart_index_export) and every other rank copies what it received
+    into a replica (asgart_index_create_device).  Returns the rank's index (rank src: `idx` itself)."""
+    import torch
+
+    from . import Index
+
+    rank = dist.get_rank()
+    dev = torch.device("cuda", device_index)
+    nccl = dist.get_backend() == "nccl"
+    meta = torch.zeros(2, dtype=torch.int64, device=dev if nccl else "cpu")
+    if rank == src:
+        t_ptr, sa_ptr, width = idx.export()
+        n = idx.n
+        meta[0], meta[1] = n, width
+    dist.broadcast(meta, src=src)
+    n, width = int(meta[0].item()), int(meta[1].item())
+    if rank == src:
+        text_t = torch.as_tensor(_DeviceBytes(t_ptr, n), device=dev)
+        sa_t = torch.as_tensor(_DeviceBytes(sa_ptr, n * width), device=dev)
+    else:
+        text_t = torch.empty(n, dtype=torch.uint8, device=dev)
+        sa_t = torch.empty(n * width, dtype=torch.uint8, device=dev)
+    for t in (text_t, sa_t):
+        for o in range(0, t.numel(), piece):
+            dist.broadcast(t[o:o + piece], src=src)
+    torch.cuda.synchronize(dev)
+    if rank == src:
+        return idx
+    out = Index.from_device(text_t.data_ptr(), n, sa_t.data_ptr(), width, device=device_index)
+    del text_t, sa_t
+    torch.cuda.empty_cache()   # (torch's caching allocator would keep the 15 GB staging tensors)
+    return out

@@ -105,6 +105,81 @@ def reference_algorithm_bytes(st: dict, k: int, W: int = 8) -> int:
             + W * st["raw_hits"])
 
 
+def end_to_end(recs, files, skip_masked, modes, k, gap, device):
+    """The host chain around the path, once, per stage in seconds (reference src/bin/asgart.rs:731-822: prepare_data,
+    the Step chain -- SearchDuplications, FilterNs, ReOrder, ReduceOverlap, Sort -- ProtoSD -> SD, JSON export), for
+    every pass of the workload.  Untimed in `value`; SURVEY.md section 8d lists these stages as reported separately."""
+    from asgart_amd import Strand, postprocess
+
+    out = {}
+    t0 = time.perf_counter()
+    if files:
+        recs = read_fasta_files(files)
+        out["read_fasta"] = round(time.perf_counter() - t0, 3)
+        t0 = time.perf_counter()
+    pr = prep.prepare_records(recs, skip_masked=skip_masked)
+    out["prepare_data"] = round(time.perf_counter() - t0, 3)
+    strand = Strand(", ".join(files) if files else "synthetic", pr.data, pr.map)
+    t0 = time.perf_counter()
+    with asgart_amd.Index(pr.data, None, device=device) as idx:
+        idx.prepare(k)
+        out["index"] = round(time.perf_counter() - t0, 3)
+        sts = [asgart_amd.RunSettings.from_cli(k=k, gap=gap, reverse=r, complement=c, skip_masked=skip_masked)
+               for r, c in modes]
+        t0 = time.perf_counter()
+        raw = idx.search_duplications_passes(pr.chunks, sts) if len(sts) > 1 else \
+            [idx.search_duplications_raw(pr.chunks, sts[0])]
+        out["search_all_passes"] = round(time.perf_counter() - t0, 3)
+        post, export, n_sd = 0.0, 0.0, 0
+        for st, (offs, sds) in zip(sts, raw):
+            t0 = time.perf_counter()
+            fo, fs = postprocess.post_process_arrays(idx, offs, sds)
+            post += time.perf_counter() - t0
+            t0 = time.perf_counter()
+            text = postprocess.to_json_arrays(fo, fs, strand, st)
+            export += time.perf_counter() - t0
+            n_sd += len(fs)
+            out.setdefault("json_bytes", 0)
+            out["json_bytes"] += len(text)
+        out["post_processing"] = round(post, 3)
+        out["run_result_json"] = round(export, 3)
+        out["sds_after_post_processing"] = n_sd
+    return out
+
+
+def launch_ranks(n_ranks: int) -> int:
+    """`python bench.py --gpus N` with no launcher around it: start N ranks (fresh interpreters, one per GPU, the same
+    command line) and wait for them.  This parent never touches a GPU -- no HIP call, no torch.cuda -- so the children
+    are ordinary child processes of a process without device state (nothing is re-executed).  Rank 0 prints the JSON
+    line on the stdout the children inherit.  Exit code: the first non-zero one of the ranks."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ASGART_BENCH_LAUNCHED="self")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p_ in list(live):
+            code = p_.poll()
+            if code is None:
+                continue
+            live.remove(p_)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                for q_ in live:   # a rank died: the others would wait in a collective forever (exact PIDs, ours)
+                    q_.terminate()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -114,7 +189,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fasta", nargs="+", default=None, help="real FASTA input(s) instead of the synthetic workload")
     ap.add_argument("--skip-masked", action="store_true", help="with --fasta: lower-case bases count as N (-S)")
+    ap.add_argument("--end-to-end", action="store_true",
+                    help="also time the host chain around the path once (records -> prepare_data -> index -> search -> "
+                         "post-processing -> RunResult JSON; reference src/bin/asgart.rs:731-822), untimed in `value`")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -122,15 +203,17 @@ def main():
     if world != args.gpus and world > 1:
         log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}")
     dist = None
+    comm_device = "cpu"
     if world > 1:
         import torch
         import torch.distributed as dist_mod
 
-        # debugging knobs for 1-GPU boxes: all ranks on device 0 + gloo (RCCL refuses two ranks
-        # on one device); the driver's multi-GPU runs use neither
-        if os.environ.get("ASGART_BENCH_ONE_DEVICE"):
+        # debugging knob for 1-GPU boxes: all ranks on device 0 over gloo (RCCL refuses two ranks on one device);
+        # the driver's multi-GPU runs do not use it
+        one_device = bool(os.environ.get("ASGART_BENCH_ONE_DEVICE"))
+        if one_device:
             local_rank = 0
-        backend = os.environ.get("ASGART_BENCH_BACKEND", "nccl")
+        backend = os.environ.get("ASGART_BENCH_BACKEND", "gloo" if one_device else "nccl")
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
             dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -138,39 +221,41 @@ def main():
             dist_mod.init_process_group(backend)
         dist = dist_mod
         comm_device = f"cuda:{local_rank}" if backend == "nccl" else "cpu"
+        assert dist.get_world_size() == world, "the process group is not the world the launcher announced"
 
     cfg, scale, skip_masked, modes, desc = WORKLOADS[args.workload]
     k, gap = 20, 100
-    t0 = time.time()
     files = fasta_inputs(args)
-    data_kind = "synthetic"
+    data_kind = "real" if files else "synthetic"
     if files:
-        recs = read_fasta_files(files)
         skip_masked, modes = bool(args.skip_masked), DIRECT_RC
-        desc = (f"FASTA {', '.join(os.path.basename(f) for f in files)} ({len(recs)} records), direct+RC"
-                f"{', --skip-masked' if skip_masked else ''}, k=20 g=100")
-        data_kind = "real"
+
+    # ---- input: rank 0 reads / generates it; the other ranks only need the chunk table (their index arrives by
+    # broadcast, device to device) --------------------------------------------------------------------------------
+    t0 = time.time()
+    pr = None
+    recs = None
+    if rank == 0:
+        if files:
+            recs = read_fasta_files(files)
+            desc = (f"FASTA {', '.join(os.path.basename(f) for f in files)} ({len(recs)} records), direct+RC"
+                    f"{', --skip-masked' if skip_masked else ''}, k=20 g=100")
+        else:
+            recs = synth.config_genome(cfg, scale)
+        pr = prep.prepare_records(recs, skip_masked=skip_masked)
+        if not args.end_to_end:
+            recs = None
+        log(f"[bench] {desc}: {len(pr.data)} bytes, {len(pr.chunks)} chunks, gen {time.time() - t0:.1f}s")
+    if world > 1:
+        box = [(desc, [tuple(map(int, c)) for c in pr.chunks], int(len(pr.data)))] if rank == 0 else [None]
+        dist.broadcast_object_list(box, src=0)
+        desc, chunks, n_text = box[0]
     else:
-        recs = synth.config_genome(cfg, scale)
-    pr = prep.prepare_records(recs, skip_masked=skip_masked)
-    del recs
-    total_bp = sum(l for _, l in pr.chunks)
-    t_gen = time.time() - t0
-    if rank == 0:
-        log(f"[bench] {desc}: {len(pr.data)} bytes, {len(pr.chunks)} chunks, gen {t_gen:.1f}s")
-
-    # ---- index build (outside the timed region, reported separately) -------------
-    t0 = time.time()
-    idx = asgart_amd.Index(pr.data, None, device=local_rank)   # suffix array built on the GPU
-    t_sa = time.time() - t0
-    t0 = time.time()
-    idx.prepare(k)
-    t_index = time.time() - t0
-    if rank == 0:
-        log(f"[bench] upload + GPU suffix array {t_sa:.2f}s, search keys/tables {t_index:.2f}s")
-
+        chunks, n_text = pr.chunks, int(len(pr.data))
+    total_bp = sum(l for _, l in chunks)
     settings = [asgart_amd.RunSettings.from_cli(k=k, gap=gap, reverse=r, complement=c, skip_masked=skip_masked)
                 for r, c in modes]
+    shard_args = (rank, world) if world > 1 else (0, 1)
 
     def sync():
         if dist is not None:
@@ -179,20 +264,48 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def gather(r_):
+        return multi.gather_families(r_[0], r_[1], dist, device=comm_device, keys=r_[2]) if world > 1 else r_
+
+    def passes_call():
+        if len(settings) > 1:
+            return idx.search_duplications_passes(chunks, settings, *shard_args, with_keys=world > 1)
+        return [idx.search_duplications_raw(chunks, settings[0], *shard_args, with_keys=world > 1)]
+
+    # ---- the cold run: host text -> families of every pass on the host, in this fresh process ----------------------
+    # (upload, GPU suffix array [+ its broadcast to the other ranks], search keys and tables, presence filters, the
+    # first call with its allocations).  Reported as cold_s, never part of `value`.
+    sync()
+    t_c0 = time.perf_counter()
+    idx = asgart_amd.Index(pr.data, None, device=local_rank) if rank == 0 else None   # suffix array built on the GPU
+    t_sa = time.perf_counter() - t_c0
+    t_bc = 0.0
+    if world > 1:
+        t1 = time.perf_counter()
+        idx = multi.replicate_index(idx, dist, local_rank)
+        t_bc = time.perf_counter() - t1
+    t1 = time.perf_counter()
+    idx.prepare(k)
+    t_index = time.perf_counter() - t1
+    t1 = time.perf_counter()
+    first = [gather(r_) for r_ in passes_call()]
+    sync()
+    t_first = time.perf_counter() - t1
+    cold_s = time.perf_counter() - t_c0
+    if rank == 0:
+        log(f"[bench] cold run {cold_s:.2f}s: upload + GPU suffix array {t_sa:.2f}s, "
+            f"{'broadcast %.2fs, ' % t_bc if world > 1 else ''}search keys/tables {t_index:.2f}s, "
+            f"first passes call (filters, allocations) {t_first:.2f}s")
+    del first
+
     def run_pass(st):
-        if world > 1:
-            return idx.search_duplications_raw(pr.chunks, st, shard=rank, n_shards=world, with_keys=True)
-        return idx.search_duplications_raw(pr.chunks, st)
+        return idx.search_duplications_raw(chunks, st, *shard_args, with_keys=world > 1)
 
     def one_step():
-        out = []
-        for st in settings:
-            r_ = run_pass(st)
-            out.append(multi.gather_families(r_[0], r_[1], dist, device=comm_device, keys=r_[2]) if world > 1 else r_)
-        return out
+        return [gather(r_) for r_ in passes_call()]
 
     t0 = time.time()
-    for _ in range(args.warmup):   # the first call of an orientation also builds its presence filter
+    for _ in range(args.warmup):
         one_step()
     t_warm = time.time() - t0
     # per-pass device timings + work counters + the accounting pass (one extra untimed call per
@@ -201,6 +314,17 @@ def main():
     for st in settings:
         run_pass(st)
         pass_stats.append(idx.stats(1).as_dict())   # rank-local work counters
+    # what the scaling model is made of: ONE GPU's front (probe search, scans, hit rows), extension and longest tier
+    # per pass.  With several ranks, rank 0 runs the passes unsharded once while the others wait.
+    if world > 1:
+        whole = []
+        if rank == 0:
+            for st in settings:
+                idx.search_duplications_raw(chunks, st)
+                whole.append(idx.stats(0).as_dict())
+        sync()
+    else:
+        whole = pass_stats
 
     # Timed region.  The library is re-entrant (one internal context per call), so the direct and
     # the RC pass of a step can be issued from two host threads and overlap on the GPU: while one
@@ -210,31 +334,25 @@ def main():
     pool = ThreadPoolExecutor(max_workers=len(settings))
 
     def run_pipelined(order):
-        """Both passes of a step, pipelined: the second call is issued when the first one reports (through
-        the progress array of the C ABI, polled like the reference's progress bar polls its counters) that
-        its probes are searched; its own search phases then run beside the extension of the first, whose
-        tail is a few serial segments.  Returns the results in `settings` order."""
-        first, second = order
-        prog = np.zeros(len(pr.chunks), dtype=np.uint64)
-        fut = pool.submit(idx.search_duplications_raw, pr.chunks, settings[first], rank if world > 1 else 0,
-                          world if world > 1 else 1, prog, world > 1)
+        """Both passes of a step, pipelined by the HOST (the older way; the library's passes call does the same
+        inside): the second call is issued when the first one reports, through the progress array of the C ABI, that
+        its probes are searched.  Returns the results in `settings` order."""
+        first_, second = order
+        prog = np.zeros(len(chunks), dtype=np.uint64)
+        fut = pool.submit(idx.search_duplications_raw, chunks, settings[first_], shard_args[0], shard_args[1], prog,
+                          world > 1)
         while not fut.done() and not prog.any():
             time.sleep(0.0005)
-        res = {second: run_pass(settings[second]), first: fut.result()}
+        res = {second: run_pass(settings[second]), first_: fut.result()}
         return [res[j] for j in range(len(settings))]
 
-    # Four ways to issue the two passes of a step; which is fastest depends on how much of a pass is its
-    # serial extension tail (pipelining hides it) and how much is chip-wide work the passes would only
-    # steal from each other.  One untimed step of each decides (ASGART_BENCH_MODE forces one).
+    # Ways to issue the two passes of a step; the default is the library's own pipelining (ONE C call per step).
     MODES_OF_ISSUE = ("library", "back_to_back", "overlapped", "pipelined_0_first", "pipelined_1_first")
 
     def issue(mode):
         """-> (results in `settings` order, the library's per-call stats)"""
         if mode == "library" and len(settings) > 1:
-            # ONE call for the passes of a step (asgart_search_duplications_passes): the library issues pass j+1 when
-            # pass j's probes are searched, longest extension first -- no host threads, no polling here
-            results = idx.search_duplications_passes(pr.chunks, settings, rank if world > 1 else 0,
-                                                     world if world > 1 else 1, with_keys=world > 1)
+            results = passes_call()
             return results, [idx.stats((ci + 1) << 8) for ci in range(len(settings))]
         if mode == "back_to_back" or len(settings) == 1:
             results, stats = [], []
@@ -250,13 +368,11 @@ def main():
 
     mode_probe_ms = None
     mode = os.environ.get("ASGART_BENCH_MODE", "")
-    if os.environ.get("ASGART_BENCH_OVERLAP") in ("0", "1"):   # (older switch)
-        mode = "back_to_back" if os.environ["ASGART_BENCH_OVERLAP"] == "0" else "overlapped"
     if len(settings) == 1:
         mode = "back_to_back"
     elif mode not in MODES_OF_ISSUE:
-        # default: the library's own pipelining.  One untimed step of each way of issuing is recorded for
-        # information (ASGART_BENCH_MODE=auto picks the fastest of them instead).
+        # One untimed step of each way of issuing is recorded for information (ASGART_BENCH_MODE=auto picks the
+        # fastest of them instead of the library's).
         mode_probe_ms = {}
         for m in MODES_OF_ISSUE if (mode == "auto" or os.environ.get("ASGART_BENCH_PROBE_MODES")) else ("back_to_back", "library"):
             sync()
@@ -272,32 +388,39 @@ def main():
             mode_probe_ms[m] = round(dt * 1e3, 2)
         mode = min(mode_probe_ms, key=mode_probe_ms.get) if mode == "auto" else "library"
     elif mode != "back_to_back":
-        issue(mode)   # untimed: a forced concurrent mode allocates its second call context here, not in the timed region
+        issue(mode)
     sequential = mode == "back_to_back"
 
     sync()
     t0 = time.perf_counter()
     search_ms = 0.0
     probe_count_ms = 0.0
-    phase_ms = {"search": 0.0, "scan": 0.0, "fill": 0.0, "extend": 0.0, "extend_tier2": 0.0}
+    phase_ms = {"search": 0.0, "scan": 0.0, "fill": 0.0, "extend": 0.0, "extend_tier2": 0.0, "longest_tier": 0.0}
     for _ in range(args.steps):
         results, per_call = issue(mode)
         if world > 1:
             # the only exchange of the path: duplicon lists -> rank 0 over RCCL
-            results = [multi.gather_families(r_[0], r_[1], dist, device=comm_device, keys=r_[2]) for r_ in results]
+            results = [gather(r_) for r_ in results]
         for s in per_call:
             search_ms += s.ms_search
             probe_count_ms += s.ms_probe_count
             for ph in phase_ms:
                 phase_ms[ph] += getattr(s, "ms_" + ph)
+    own_elapsed = time.perf_counter() - t0   # this rank's share, before it waits for the others
     sync()
     elapsed = time.perf_counter() - t0
+    per_rank_ms = [round(own_elapsed / args.steps * 1e3, 3)]
+    per_rank_phase = [{ph: round(v / args.steps, 3) for ph, v in phase_ms.items()}]
     if dist is not None:
         import torch
 
         t = torch.tensor([elapsed], device=comm_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        box = [None] * world
+        dist.all_gather_object(box, (per_rank_ms[0], per_rank_phase[0]))
+        per_rank_ms = [b[0] for b in box]
+        per_rank_phase = [b[1] for b in box]
 
     passes = len(modes)
     value = total_bp * passes * args.steps / elapsed / 1e6
@@ -319,23 +442,26 @@ def main():
     traffic = prof.get("traffic_bytes_per_launch")
     traffic_ms = prof.get("kernel_ms_per_launch")
     roofline = {
-        "bound": "hbm", "kernel": "probe_count_kernel + big_count_kernel + rank_count_kernel (one launch = one pass)",
+        "bound": "hbm",
+        "kernel": "probe_count_kernel + collect_pending_kernel + big_count_kernel + rank_count_kernel (one launch = one pass)",
         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 5),
         "kernel_algorithmic_bytes": int(alg_bytes),
         "avg_launch_ms": round(avg_launch_ms, 5),
         "launch_timing": "HIP events on the library's stream, timed region" +
                          ("" if sequential else " (the other pass's kernels share the chip)"),
-        # first kernel of the pair alone (rocprofv3 lists the two kernels separately)
+        # first kernel of the group alone (rocprofv3 lists the kernels separately)
         "probe_count_kernel_ms": round(probe_count_ms / n_launch, 5) if n_launch else 0.0,
         "alone_launch_ms": round(alone_ms, 5),
         "achieved_alone": round(alg_bytes / (alone_ms / 1e3) / 1e9, 2) if alone_ms > 0 else 0.0,
+        "frac_alone": round(alg_bytes / (alone_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5) if alone_ms > 0 else 0.0,
         "traffic": traffic,
         "traffic_ms": traffic_ms,
         "traffic_frac": (round(traffic / (traffic_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5)
                          if traffic and traffic_ms else None),
-        "traffic_x2_applied": False,
+        "traffic_x2_applied": prof.get("x2_applied", False),
         "traffic_source": prof.get("source"),
+        "traffic_build": prof.get("build"),
         "waste": round(traffic / alg_bytes, 3) if traffic and alg_bytes else None,
         # The kernels are random-gather bound: an 8- or 4-byte gather moves (and FETCH_SIZE counts) one 64-byte
         # sector, so `traffic` exceeds the algorithmic bytes by design (`waste` is sector granularity, not re-reads),
@@ -349,6 +475,21 @@ def main():
                                       max(1, sum(s["probes_searched"] for s in pass_stats)), 4),
     }
 
+    # Scaling model: sharding divides a pass's front (probe search, scans, hit rows) and the
+    # throughput part of its extension by N, never its longest tier -- the longest serial automaton segment.  The
+    # fronts of the passes of a step follow one another, their extensions run side by side.
+    model = None
+    if rank == 0 and whole:
+        fronts = [w_["ms_search"] + w_["ms_scan"] + w_["ms_fill"] for w_ in whole]
+        model = {
+            "inputs_one_gpu_ms": [{"front": round(f_, 2), "extend": round(w_["ms_extend"], 2),
+                                   "longest_tier": round(w_["ms_longest_tier"], 2)} for f_, w_ in zip(fronts, whole)],
+            "formula": "sum_p front_p / N + max_p max(longest_tier_p, extend_p / N)",
+        }
+        for n_ in sorted({1, 2, 4, 8, world}):
+            model[f"n{n_}_ms"] = round(sum(fronts) / n_ + max(max(w_["ms_longest_tier"], w_["ms_extend"] / n_)
+                                                               for w_ in whole), 2)
+
     out = {
         "metric": "Mbp/s probe+extend (direct+RC, k=20 g=100)",
         "value": round(value, 3),
@@ -360,23 +501,36 @@ def main():
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
-        "dtype": "u64 keys / u32 SA" if len(pr.data) < 0xFFFFFF00 else "u64 keys / u64 SA",
+        "dtype": "u64 keys / u32 SA" if n_text < 0xFFFFFF00 else "u64 keys / u64 SA",
         "data": data_kind,
         "config": {"workload": desc, "bp_per_pass": total_bp, "passes": passes,
                    "skip_masked": skip_masked,
-                   "text_bytes": int(len(pr.data)), "chunks": len(pr.chunks),
+                   "text_bytes": n_text, "chunks": len(chunks),
                    "parallelism": f"probe-shard x{world}" if world > 1 else "1 GPU",
+                   "ranks_launched_by": os.environ.get("ASGART_BENCH_LAUNCHED", "torchrun" if world > 1 else "none"),
+                   "collective_backend": (dist.get_backend() if dist is not None else None),
                    "passes_issued": mode, "mode_probe_ms": mode_probe_ms},
         "roofline": roofline,
-        "phases_ms_per_step": {ph: round(v / args.steps, 4) for ph, v in phase_ms.items()},
-        "index_build_s": {"upload_and_suffix_array": round(t_sa, 2), "keys_and_tables": round(t_index, 3),
-                          "first_calls_incl_presence_filters": round(t_warm, 3),
+        "phases_ms_per_step": per_rank_phase[0],
+        "per_rank_ms": per_rank_ms,
+        "per_rank_phases_ms_per_step": per_rank_phase if world > 1 else None,
+        "model_ms": (model or {}).get(f"n{world}_ms"),
+        "scaling_model": model,
+        "cold_s": round(cold_s, 3),
+        "index_build_s": {"upload_and_suffix_array": round(t_sa, 3), "broadcast_to_ranks": round(t_bc, 3),
+                          "keys_and_tables": round(t_index, 3),
+                          "first_passes_call_incl_presence_filters": round(t_first, 3),
+                          "warmup_steps": round(t_warm, 3),
                           "sa_builder": "GPU prefix doubling (asgart_sa_build64 path)"},
         "work_per_step": {key: sum(s[key] for s in pass_stats) for key in
                           ("probes_total", "probes_searched", "probes_card_skipped", "probes_filter_rejected",
                            "raw_hits", "filtered_hits", "segments", "overflow_segments", "heavy_segments",
                            "families", "proto_sds")},
+        "work_per_step_scope": "rank 0's shard" if world > 1 else "whole job",
     }
+
+    if rank == 0 and args.end_to_end:
+        out["end_to_end_s"] = end_to_end(recs, files, skip_masked, modes, k, gap, local_rank)
 
     if rank == 0 and not args.no_cpu_baseline:
         # CPU reference: the oracle with the reference's parallel structure (OpenMP over
@@ -384,7 +538,6 @@ def main():
         import oracle  # the CPU checker, used here ONLY as the timed CPU baseline
 
         cores = min(os.cpu_count() or 1, len(pr.chunks))  # threads that can be busy: one per chunk
-        n_text = len(pr.data)
         sa = np.empty(n_text, dtype=np.int64)   # (read back in slabs: sa_read returns a fresh array per call)
         slab = 1 << 28
         for o in range(0, n_text, slab):
@@ -412,6 +565,7 @@ def main():
         print(json.dumps(out), flush=True)
     idx.close()
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -84,6 +84,9 @@ typedef struct asgart_stats {
                                  staging, filter word, prefix-table entries, keys read by the bisection,
                                  suffix-array entries read, outputs): the algorithmic bytes of this kernel */
     uint64_t probes_filter_rejected; /* probes answered by the k-mer presence filter alone          */
+    double ms_longest_tier;   /* part of ms_extend: the extension tier that ran longest, from the launch of the tiers
+                                 (they run side by side) -- in practice the longest serial automaton segment of the
+                                 call, i.e. what sharding the probes over more GPUs cannot shorten              */
 } asgart_stats;
 
 typedef struct asgart_index asgart_index;
@@ -109,6 +112,23 @@ void asgart_index_destroy(asgart_index *idx);
  * rebuilt there on first use).  Replaces nothing in the reference (it has one address space); it is the
  * "SA + text replicated in each HBM" step of the multi-GPU design. */
 int32_t asgart_index_clone(asgart_index *src, int32_t device, asgart_index **out);
+
+/* The same for a host that is one process per GPU (the multi-GPU arrangement of BASELINE.json's north star): the
+ * process that built the suffix array hands out the device addresses of text and suffix array
+ * (asgart_index_export: valid while the index lives, read-only), broadcasts them with its collective library
+ * (ncclBroadcast over xGMI; asgart_amd/multi.py: replicate_index) and every other process creates its replica from
+ * the received DEVICE buffers, which are copied (asgart_index_create_device; d_text: n bytes; d_sa: n entries of
+ * sa_entry_bytes = 4, or 8 when n >= 2^32 - 256, as asgart_index_export reports).  No suffix sort and no host copy
+ * per GPU.  The text is validated on the device like asgart_index_create validates it. */
+int32_t asgart_index_export(asgart_index *idx, const void **d_text, const void **d_sa, int32_t *sa_entry_bytes);
+int32_t asgart_index_create_device(const void *d_text, int64_t n, const void *d_sa, int64_t sa_len,
+                                   int32_t sa_entry_bytes, int32_t device, asgart_index **out);
+
+/* Device memory the library keeps for reuse (released blocks of 256 MiB and more, so that an index build does not
+ * pay the runtime's slow first allocation after large frees) goes back to the device: at the end of
+ * asgart_index_prepare, when the last index of a device is destroyed, when one of the library's own allocations
+ * fails -- and here, for a host about to allocate a lot by other means.  Returns the bytes released, < 0 on error. */
+int64_t asgart_trim_cache(int32_t device);
 
 /* `--trim START END` (reference src/bin/asgart.rs:142-148, validation :432-463, README "trimming"):
  * the suffix array covers only data[start..end] + '$' -- its entries shifted by +start -- and the WHOLE
@@ -164,13 +184,14 @@ int32_t asgart_search_duplications(asgart_index *idx, const uint64_t *chunks, in
                                    asgart_families **out);
 
 /* Same, restricted to shard `shard` of `n_shards` (multi-GPU: one process per GPU, index replicated, no
- * exchange between shards).  Shard r owns the automaton segments that START in the r-th of n_shards equal
- * slices of the global probe sequence; it searches its slice plus a look-back and a look-ahead halo (retrying
- * with larger halos when a decision is ambiguous).  The union of the shards' families, merged by
- * asgart_families_keys -- or simply concatenated in shard order -- is exactly the unsharded result.
- * Option shard_lpt = 1: every shard computes the whole front (probe search, scans, hit rows, placement: a
- * tenth of a step) and then owns every n_shards-th segment of each extension tier's cost-sorted list, in snake
- * order; the shards then interleave and must be merged by key.  Balanced, but not faster where one serial
+ * exchange between shards).  DEFAULT (option shard_lpt = 0): shard r owns the automaton segments that START in
+ * the r-th of n_shards equal slices of the global probe sequence; it searches its slice plus a look-back and a
+ * look-ahead halo (retrying with larger halos when a decision is ambiguous).  The union of the shards' families,
+ * merged by asgart_families_keys -- or, in this default mode only, concatenated in shard order -- is exactly the
+ * unsharded result.  A gatherer that always merges by key is right in both modes (asgart_amd/multi.py does).
+ * Option shard_lpt = 1 (off by default): every shard computes the whole front (probe search, scans, hit rows,
+ * placement: a tenth of a step) and then owns every n_shards-th segment of each extension tier's cost-sorted list,
+ * in snake order; the shards then INTERLEAVE and MUST be merged by key.  Balanced, but not faster where one serial
  * segment is the floor of a pass. */
 int32_t asgart_search_duplications_shard(asgart_index *idx, const uint64_t *chunks,
                                          int64_t n_chunks, const asgart_settings *settings,
@@ -220,8 +241,9 @@ void asgart_families_counts(const asgart_families *f, uint64_t *n_families, uint
 void asgart_families_copy(const asgart_families *f, uint64_t *fam_offsets, asgart_proto_sd *sds);
 /* keys: n_families entries, (first probe of the family's automaton segment << 32) | family ordinal inside it.
  * Ascending keys == the reference's order (chunk order, discovery order inside a chunk, src/bin/asgart.rs:241-253).
- * The shards of a sharded call own interleaved segments: a gatherer merges their families by key
- * (asgart_search_duplications_multi does; one-process-per-GPU hosts do it after the RCCL gather, asgart_amd/multi.py). */
+ * The shards of a sharded call own contiguous slices by default and interleaved segments with option shard_lpt = 1: a
+ * gatherer that merges their families by key is right either way (asgart_search_duplications_multi does;
+ * one-process-per-GPU hosts do it after the RCCL gather, asgart_amd/multi.py). */
 void asgart_families_keys(const asgart_families *f, uint64_t *keys);
 void asgart_families_free(asgart_families *f);
 
