@@ -40,6 +40,55 @@
 
 namespace asgart {
 
+// Diagnostic build (-DASGART_PROFILE_EXTEND): where the waves of a step spend their time -- per wave class (control,
+// arm wave 0, last arm wave) the cycles from the start of a step to barrier 1, waiting there, from barrier 1 to
+// barrier 2, waiting there; summed into ctr[40..55] (printed by the host's profile dump).
+#ifdef ASGART_PROFILE_EXTEND
+#define K7T_DECL unsigned long long k7t[4] = {0, 0, 0, 0}, k7t0 = 0, k7n = 0
+#define K7T_MARK() k7t0 = __builtin_amdgcn_s_memtime()
+#define K7T_LAP(j)                                                   \
+    do {                                                             \
+        const unsigned long long k7now = __builtin_amdgcn_s_memtime(); \
+        k7t[j] += k7now - k7t0;                                      \
+        k7t0 = k7now;                                                \
+    } while (0)
+#define K7T_STEP() ++k7n
+#define K7C(slot, v) do { if (wave == 0u && lane == 0) atomicAdd(&P.ctr[slot], (unsigned long long)(v)); } while (0)
+#define K7U_DECL unsigned long long k7u[8] = {0, 0, 0, 0, 0, 0, 0, 0}, k7u0 = 0
+#define K7U_MARK() k7u0 = __builtin_amdgcn_s_memtime()
+#define K7U_LAP(j)                                                   \
+    do {                                                             \
+        const unsigned long long k7now = __builtin_amdgcn_s_memtime(); \
+        k7u[j] += k7now - k7u0;                                      \
+        k7u0 = k7now;                                                \
+    } while (0)
+#define K7U_FLUSH()                                                                       \
+    do {                                                                                  \
+        if (lane == 0)                                                                    \
+            for (int k7j = 0; k7j < 8; ++k7j) atomicAdd(&P.ctr[57 + k7j], k7u[k7j]);       \
+        for (int k7j = 0; k7j < 8; ++k7j) k7u[k7j] = 0;                                   \
+    } while (0)
+#define K7T_FLUSH(cls)                                                                      \
+    do {                                                                                    \
+        if (lane == 0)                                                                      \
+            for (int k7j = 0; k7j < 4; ++k7j) atomicAdd(&P.ctr[40 + 4 * (cls) + k7j], k7t[k7j]); \
+        if (lane == 0 && (cls) == 0) atomicAdd(&P.ctr[52], k7n);                            \
+        k7t[0] = k7t[1] = k7t[2] = k7t[3] = 0;                                              \
+        k7n = 0;                                                                            \
+    } while (0)
+#else
+#define K7T_DECL
+#define K7T_MARK()
+#define K7T_LAP(j)
+#define K7T_STEP()
+#define K7C(slot, v)
+#define K7U_DECL
+#define K7U_MARK()
+#define K7U_LAP(j)
+#define K7U_FLUSH()
+#define K7T_FLUSH(cls)
+#endif
+
 // command flags (control wave -> everyone, one block per step)
 constexpr uint32_t K7_PREV = 1u;    // a previous probe is to be resolved (and its new arms created)
 constexpr uint32_t K7_CUR = 2u;     // a current probe receives offers
@@ -103,6 +152,8 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
     const WinT w_loop = (WinT)(kRowsLoop - 1u) << bsh;
     const bool use_flag = P.hit_flag != nullptr;
     RecAlloc rec_alloc;
+    K7T_DECL;
+    K7U_DECL;
 
     PosT a_ls[S], a_re[S];
     uint32_t a_thr[S], a_gap[S], a_seq[S], c_h[S];
@@ -256,13 +307,20 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                     offer(e0.x); offer(e0.y); offer(e2.x); offer(e2.y);
                 }
             }
-            for (uint32_t r = 2; __ballot(r < n_rows); ++r) offer_row(b0 + r);
-            for (uint32_t s = 0; s < min(ns, kStash); ++s) offer(s_stash[bb][s]);
+            for (uint32_t r = 2; __ballot(r < n_rows); ++r) {
+                K7C(53, 1);
+                offer_row(b0 + r);
+            }
+            for (uint32_t s = 0; s < min(ns, kStash); ++s) {
+                K7C(56, 1);
+                offer(s_stash[bb][s]);
+            }
             ch = nc > 3u ? kCoop : (ch & 0x3FFFFFFFu) | (nc << 30);
             // arms too wide for the table walk -- and every arm when the stash overflowed
             unsigned long long sm = __ballot(who && (!narrow || povf));
             if (sm) {
                 if (who && (!narrow || povf)) ch = kCoop;
+                K7C(54, __popcll(sm));
                 while (sm) {
                     const uint32_t l = (uint32_t)(__ffsll((long long)sm) - 1);
                     sm &= sm - 1ull;
@@ -321,6 +379,9 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
             for (uint32_t sp = 0;; sp ^= 1u) {
                 uint32_t flags;
                 Probe cur;
+                K7T_MARK();
+                K7T_STEP();
+                K7U_MARK();
                 read_cmd(sp, flags, cur);
                 if (flags & K7_GIVEUP) {
                     overflow = true;
@@ -332,6 +393,7 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                 const uint32_t fam_a = uni(s_fam[sp ^ 1u]);
                 const uint32_t ns_v = (has_cur && !late && livemask) ? s_nstash[cur.bb] : 0u;
                 uint32_t wasfree = 0;  // per lane, bit L: the slot of layer L was empty before this step
+                K7U_LAP(0);
 #pragma unroll
                 for (int L = 0; L < S; ++L) {
                     if (!(livemask >> L)) {
@@ -360,6 +422,7 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                         hw = (was_free || coop) ? 0u : hw;
                         xw = s_hits[prev.off + (hw ? hw - 1u : 0u)];
                         unsigned long long sm = __ballot(coop);
+                        K7C(55, __popcll(sm));
                         while (sm) {  // more than three candidates / wide window: resolved cooperatively
                             const uint32_t l = (uint32_t)(__ffsll((long long)sm) - 1);
                             sm &= sm - 1ull;
@@ -403,6 +466,7 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                 }
                 uint32_t ns = 0;
                 bool povf = false;
+                K7U_LAP(1);
                 if (has_cur && !late && livemask) {
                     ns = uni(ns_v);
                     povf = ns > kStash;
@@ -412,7 +476,11 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                         if (livemask & (1u << L)) c_h[L] = offers(L, a_seq[L] != kNoSeq, cur, ns, povf);
                     }
                 }
+                K7U_LAP(2);
+                K7T_LAP(0);
                 lds_barrier();  // ---- barrier 1 --------------------------------------------------------------
+                K7T_LAP(1);
+                K7U_MARK();
                 // ---------------------------------------------------------------- interval B ----------------
                 const uint4 m0v = *reinterpret_cast<const uint4 *>(&s_mid[0]);
                 const uint32_t mflags = uni(m0v.x);
@@ -428,6 +496,7 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                 uint32_t base_r[S];
 #pragma unroll
                 for (int L = 0; L < S; ++L) base_r[L] = n_new ? s_base[L * NWA + (int)wave] : 0u;
+                K7U_LAP(3);
 #pragma unroll
                 for (int L = 0; L < S; ++L) {
                     const uint32_t b_r = n_new ? uni(base_r[L]) : 0u;
@@ -470,6 +539,7 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                         }
                     }
                 }
+                K7U_LAP(4);
                 mid_actions(mflags);
                 {   // free counts, as the control wave will rank them in the next step
                     uint32_t nfv[8] = {64u, 64u, 64u, 64u, 64u, 64u, 64u, 64u};
@@ -485,16 +555,23 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                     *reinterpret_cast<uint4 *>(&s_free[wave][0]) = make_uint4(nfv[0], nfv[1], nfv[2], nfv[3]);
                     if constexpr (S > 4) *reinterpret_cast<uint4 *>(&s_free[wave][4]) = make_uint4(nfv[4], nfv[5], nfv[6], nfv[7]);
                 }
+                K7U_LAP(5);
                 if (!(flags & K7_LAST)) {  // the hits of the next step's probe (top threads), unless that step is late
                     uint32_t nflags;
                     Probe nx;
                     read_cmd(sp ^ 1u, nflags, nx);
                     if ((nflags & K7_CUR) && !(nflags & K7_LATE)) insert_hits(nx.cnt, nx.off, nx.tb, nx.bb, nx.g10);
                 }
+                K7U_LAP(6);
+                K7T_LAP(2);
                 lds_barrier();  // ---- barrier 2 --------------------------------------------------------------
+                K7T_LAP(3);
                 prev = cur;
                 if (flags & K7_LAST) break;
             }
+            if (wave == 0u) K7T_FLUSH(1);
+            if (wave == 0u) K7U_FLUSH();
+            if (wave == (uint32_t)(NWA - 1)) K7T_FLUSH(2);
             if (!overflow) lds_barrier();  // (3) the control wave reads the final free counts
         } else {
             // =====================================================================================================
@@ -629,6 +706,8 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
             } else {
                 for (uint32_t sp = 0;; sp ^= 1u) {
                     const bool have_prev = (flags & K7_PREV) != 0u;
+                    K7T_MARK();
+                    K7T_STEP();
                     // ------------------------------------------------------------ interval A ----------------
                     if ((flags & K7_CUR) && (flags & K7_LATE)) insert_hits(cur.cnt, cur.off, cur.tb, cur.bb, cur.g10);
                     uint32_t mflags = 0, n_new = 0, seq_base = 0;
@@ -725,7 +804,9 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                         s_fam[sp] = fam_seq;
                     }
                     if (!(flags & K7_LAST)) write_cmd(sp ^ 1u, nflags, nx);
+                    K7T_LAP(0);
                     lds_barrier();  // ---- barrier 1 ----------------------------------------------------------
+                    K7T_LAP(1);
                     // ------------------------------------------------------------ interval B ----------------
                     if (mflags & K7_OVF) {
                         overflow = true;
@@ -736,7 +817,9 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                     if (lane == 0 && have_prev) s_nstash[prev.bb] = 0u;
                     if (!(flags & K7_LAST) && (nflags & K7_CUR) && !(nflags & K7_LATE))
                         insert_hits(nx.cnt, nx.off, nx.tb, nx.bb, nx.g10);
+                    K7T_LAP(2);
                     lds_barrier();  // ---- barrier 2 ----------------------------------------------------------
+                    K7T_LAP(3);
                     if (flags & K7_LAST) break;
                     prev = cur;
                     prev_tb = cur_tb;
@@ -747,6 +830,7 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                     flags = nflags;
                 }
             }
+            K7T_FLUSH(0);
             if (!overflow) {
                 lds_barrier();  // (3)
                 // nothing alive is left behind unless the chunk (or the window of a sharded call) ended first

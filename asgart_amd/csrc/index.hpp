@@ -229,7 +229,7 @@ struct Options {
                                     // cfg4, 8 shards: balanced (91-117 ms direct) but the replicated front makes its slowest shard
                                     // slower than the slice mode's (211 vs 184 ms -RC, 117 vs 90 ms direct): the floor is the longest segment
     int64_t tier_streams = 7234562; // digit t (from the left): the stream (1..7, 1 = the call's high-priority main stream) tier t runs on
-    int64_t k7 = 120;               // bit t set (t = 3..6): tier t runs the arm kernel with a control wave (extend_k7_dev.hpp); takes precedence over `fast`
+    int64_t k7 = 0;                 // bit t set (t = 3..6): tier t runs the arm kernel with a control wave (extend_k7_dev.hpp); takes precedence over `fast`
     int64_t prewarm = 1;            // 1: asgart_index_prepare also reserves the per-probe workspace of both call contexts (sized for an
                                     // unsharded call over the whole text) and starts the worker thread of the passes call, so that the first
                                     // search calls allocate nothing chip-sized; 0: everything on first use (hosts that only issue sharded calls)

@@ -25,6 +25,11 @@ namespace asgart {
                 tag, h_ctr[16], h_ctr[17], h_ctr[18], h_ctr[19], h_ctr[20], h_ctr[21], h_ctr[22], h_ctr[23],  \
                 h_ctr[24], h_ctr[25], h_ctr[26], h_ctr[27], h_ctr[28], h_ctr[29], h_ctr[30] >> 32,            \
                 h_ctr[30] & 0xffffffffull, h_ctr[31] >> 32, h_ctr[31] & 0xffffffffull, h_ctr[32], h_ctr[33]); \
+        fprintf(stderr, "    K7 steps=%llu; cycles [to barrier 1, wait, to barrier 2, wait]: control %llu %llu %llu %llu | arm wave 0 %llu %llu %llu %llu | last arm wave %llu %llu %llu %llu\n", \
+                h_ctr[52], h_ctr[40], h_ctr[41], h_ctr[42], h_ctr[43], h_ctr[44], h_ctr[45], h_ctr[46], h_ctr[47], h_ctr[48], h_ctr[49], h_ctr[50], h_ctr[51]); \
+        fprintf(stderr, "    K7 wave 0: extra row rounds %llu, stash rounds %llu, arms offered cooperatively %llu, resolved cooperatively %llu\n", h_ctr[53], h_ctr[56], h_ctr[54], h_ctr[55]); \
+        fprintf(stderr, "    K7 wave 0 cycles: A[cmd %llu resolve %llu offers %llu] B[mid %llu create+offers %llu publish %llu next-cmd+index %llu]\n", h_ctr[57], h_ctr[58], h_ctr[59], h_ctr[60], h_ctr[61], h_ctr[62], h_ctr[63]); \
+        (void)hipMemsetAsync(d_ctr + 52, 0, 13 * 8, s);                                        \
         fprintf(stderr, "    P1: arm lookups=%llu linear=%llu chain nodes=%llu accepts=%llu by level:", h_ctr[40], h_ctr[41], h_ctr[42], h_ctr[43]); \
         for (int pf_i = 0; pf_i < 8; ++pf_i) fprintf(stderr, " %llu", h_ctr[44 + pf_i]);       \
         fprintf(stderr, "\n");                                                                 \
