@@ -184,6 +184,7 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
         lds_barrier();
         if (seg >= n_seg) break;
         const uint32_t g0 = P.seg_list[seg];
+        if (tid == 0) heartbeat(P, g0, 0u);
         PROF_SEG_BEGIN();
         const int c = chunk_of_uniform(rp.ch, g0);
         const uint64_t cs = rp.ch.start[c], cl = rp.ch.len[c];
@@ -750,6 +751,7 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
             // ---- stage a batch of up to 64 probes (every wave computes the same masks) ----
             PROF_START();
             const uint32_t nb = min(64u, g_end - g);
+            if (tid == 0) heartbeat(P, g0, g);
             const uint32_t f_l = (uint32_t)lane < nb ? P.p_filt[g + lane] : kSkipN;
             const unsigned long long r_l = (uint32_t)lane < nb ? P.row_off[g + lane] : 0ull;
             const unsigned long long r_hi = uni(P.row_off[g + nb]);

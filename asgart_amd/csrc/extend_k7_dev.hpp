@@ -29,6 +29,11 @@
 //                             control wave asked for it
 //     -- barrier 2 --  (every offer to t is in: its winners are final)
 //
+// The control wave plans TWO steps ahead (the command of step s+2 is written during interval B of step s, which it
+// would otherwise spend waiting), so that its interval A holds nothing but the ranking; an arm wave reads one command
+// block per step -- the probe, its predecessor's leftovers and the run's constants, kept in vector registers: nothing
+// uniform has to survive from step to step in scalar registers -- and issues every read that does not depend on
+// another one (command, winners of its candidates, their positions, its cold fields) in one go.
 // The hit rows of 64 probes are staged at a time into one of two buffers, so that the rows of t-1 survive the staging
 // of the next batch; the first probe of a batch cannot be indexed ahead (its rows arrive with barrier 2): its step is
 // "late" -- indexed in interval A, all offers in interval B.  The same form starts a segment and follows a clearing
@@ -114,6 +119,8 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
     constexpr uint32_t kTagShift = kWidePos ? 42u : 32u;
     constexpr uint32_t kGenMax = kWidePos ? 12u : 22u;
     constexpr unsigned long long kPosMask = (1ull << kTagShift) - 1ull;
+    constexpr uint32_t kTabBytes = (uint32_t)(kRows * kE * 8);  // one hit table
+    constexpr uint32_t kCmdWords = 24;
     using WinT = typename std::conditional<kWidePos, uint64_t, uint32_t>::type;
     static_assert(NW >= 2 && HB <= 1024 && S <= 8 && NE <= 128 && (kRows & (kRows - 1)) == 0 && (kE == 2 || kE == 4), "shape");
     if (NT >= 1024 && P.hi_prio) __builtin_amdgcn_s_setprio(3);
@@ -121,14 +128,21 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
     __shared__ __attribute__((aligned(16))) unsigned long long s_tab[2][kRows * kE];
     __shared__ PosT s_hits[2 * HB];
     __shared__ uint8_t s_hflag[2 * HB];
-    __shared__ uint32_t s_best[3][HB];
+    __shared__ __attribute__((aligned(16))) uint32_t s_best[3][HB];
     __shared__ unsigned long long s_stash[3][kStash];
-    __shared__ uint32_t s_nstash[3];
+    __shared__ __attribute__((aligned(16))) uint32_t s_nstash[4];      // (three in use)
     __shared__ __attribute__((aligned(16))) uint32_t s_free[NWA][8];   // per (arm wave, layer): empty slots
-    __shared__ __attribute__((aligned(16))) uint32_t s_cmd[2][12];     // the command of a step (by step parity)
+    __shared__ __attribute__((aligned(16))) uint32_t s_base[NWA][8];   // per (arm wave, layer): rank of its first empty slot
+    // The command of a step (three in rotation: the one being run, the next one -- whose hits are indexed ahead --
+    // and the one the control wave is writing):
+    //   0 flags          1 cnt            2 off (s_hits)    3 byte offset of its hit table
+    //   4 byte offset of its best[]       5 generation tag  6,7 needle offset i
+    //   8 age of the quiet probes before it                 9 stash index    10 -   11 hits of the previous probe
+    //  12,13 needle offset of the previous probe           14 its rows (s_hits)     15 byte offset of its best[]
+    //  16 k    17 step    18 G    19 log2 bucket width     20,21 min_duplication_length    22 threshold of a new arm  23 -
+    __shared__ __attribute__((aligned(16))) uint32_t s_cmd[3][kCmdWords];
     __shared__ __attribute__((aligned(16))) uint32_t s_mid[8];         // decided in interval A, read in interval B
     __shared__ uint32_t s_fam[2];                                      // family ordinal as of the step (by step parity)
-    __shared__ uint32_t s_base[NE];                                    // rank of the first empty slot of (layer, wave)
     __shared__ PosT s_new[HB];                                         // the unmatched hits of the previous probe, by rank
     __shared__ PosT s_cle[CAP], s_crs[CAP];                            // cold fields of an arm, by slot
     __shared__ unsigned long long s_seg[3];                            // g0, chunk start, chunk length (for the records)
@@ -140,16 +154,6 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6);
     const bool is_ctl = wave == (uint32_t)NWA;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    const RunParams &rp = P.rp;
-    const uint64_t n_seg = *P.n_seg_ptr;
-    const uint32_t k = (uint32_t)rp.k, step = (uint32_t)rp.step, G = rp.G;
-    const uint32_t thr0 = arm_threshold(k, G);
-    uint32_t bsh = 3;
-    while ((1ull << bsh) < (unsigned long long)G + k) ++bsh;
-    bsh += P.fast_bsh;
-    const uint32_t kGenBits = min(kGenMax, max(2u, P.gen_bits));
-    const uint32_t cap_eff = min((uint32_t)CAP, P.cap_limit);
-    const WinT w_loop = (WinT)(kRowsLoop - 1u) << bsh;
     const bool use_flag = P.hit_flag != nullptr;
     RecAlloc rec_alloc;
     K7T_DECL;
@@ -177,17 +181,18 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
 
     auto tag_of = [&](unsigned long long e) { return (uint32_t)(e >> kTagShift); };
     auto pos_of = [&](unsigned long long e) { return (PosT)(e & kPosMask); };
+    char *const tab0 = reinterpret_cast<char *>(&s_tab[0][0]);
+    char *const best0 = reinterpret_cast<char *>(&s_best[0][0]);
 
     for (uint32_t n_fetch = 0; !P.max_items || n_fetch < P.max_items; ++n_fetch) {
         if (tid == 0) s_bcast = atomicAdd(P.cursor, 1ull);
-        if (tid < 3) s_nstash[tid] = 0u;
+        if (tid < 4) s_nstash[tid] = 0u;
         if (tid < 2) s_fam[tid] = 0u;
         for (uint32_t j = tid; j < (uint32_t)(NWA * 8); j += NT) (&s_free[0][0])[j] = 64u;
         lds_barrier();
         const unsigned long long seg = uni(s_bcast);
         lds_barrier();
-        if (seg >= n_seg) break;
-        const uint32_t g0 = P.seg_list[seg];
+        if (seg >= *P.n_seg_ptr) break;
 
         // ---- records (cold: what a record needs beyond the arm is read where it is written) -------------------------
         auto emit_records = [&](bool emit, PosT ls, PosT le, PosT rs, PosT re, uint32_t seq, uint32_t fam_seq) {
@@ -198,25 +203,28 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                 const uint64_t cs = s_seg[1], cl = s_seg[2];
                 const uint64_t ll = (uint64_t)le - (uint64_t)ls;
                 SdRec r;
-                r.g_start = g0;
+                r.g_start = (uint32_t)s_seg[0];
                 r.fam_seq = fam_seq;
                 r.create_seq = seq;
                 r.pad = 0;
-                r.sd.left = rp.reverse ? cs + cl - (uint64_t)ls - ll : (uint64_t)ls + cs;  // src/bin/asgart.rs:229-237
+                r.sd.left = P.rp.reverse ? cs + cl - (uint64_t)ls - ll : (uint64_t)ls + cs;  // src/bin/asgart.rs:229-237
                 r.sd.right = rs;
                 r.sd.left_length = ll;
                 r.sd.right_length = (uint64_t)re - (uint64_t)rs;
                 P.recs[at] = r;
             }
         };
-        // index the hits of one probe (cnt hits at s_hits[off..]) under generation tag g10 in table tb, best[] /
-        // stash buffer bb; the TOP threads do it
-        auto insert_hits = [&](uint32_t cnt, uint32_t off, uint32_t tb, uint32_t bb, uint32_t g10) {
-            for (uint32_t h = (uint32_t)(NT - 1 - tid); h < cnt; h += NT) {
+        // index the hits of one probe (cnt hits at s_hits[off..]) under generation tag g10 in the table at byte offset
+        // tabo, winners at byte offset besto, stash bb; the TOP threads do it
+        auto insert_hits = [&](uint32_t cnt, uint32_t off, uint32_t tabo, uint32_t besto, uint32_t bb, uint32_t g10, uint32_t bsh) {
+            // (thread order: the last arm wave first, downwards; the control wave's lanes come last)
+            const uint32_t me = tid < NWA * 64 ? (uint32_t)(NWA * 64 - 1 - tid) : (uint32_t)tid;
+            for (uint32_t h = me; h < cnt; h += NT) {
                 const PosT x = s_hits[off + h];
-                s_best[bb][h] = kNone;
+                *reinterpret_cast<uint32_t *>(best0 + besto + 4u * h) = kNone;
                 unsigned long long e = ((unsigned long long)(g10 | h) << kTagShift) | ((unsigned long long)x & kPosMask);
-                unsigned long long *row = &s_tab[tb][(((uint32_t)((uint64_t)x >> bsh)) & (uint32_t)(kRows - 1)) * (uint32_t)kE];
+                unsigned long long *row = reinterpret_cast<unsigned long long *>(
+                    tab0 + tabo + (((uint32_t)((uint64_t)x >> bsh)) & (uint32_t)(kRows - 1)) * (uint32_t)(kE * 8));
                 bool placed = false;
 #pragma unroll
                 for (int j = 0; j < kE; ++j) {
@@ -232,124 +240,10 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                 }
             }
         };
-        auto coop_offer = [&](PosT lo, WinT w, uint32_t key, uint32_t cnt, uint32_t off, uint32_t bb) {
-            for (uint32_t h0 = 0; h0 < cnt; h0 += 64u) {
-                const uint32_t h = h0 + (uint32_t)lane;
-                if (h < cnt && (WinT)(PosT)(s_hits[off + h] - lo) < w) atomicMin(&s_best[bb][h], key);
-            }
-        };
-        auto coop_resolve = [&](PosT lo, WinT w, uint32_t key, uint32_t cnt, uint32_t off, uint32_t bb, PosT &x_out) {
-            uint32_t hmax = kNone;
-            for (uint32_t h0 = 0; h0 < cnt; h0 += 64u) {
-                const uint32_t h = h0 + (uint32_t)lane;
-                PosT x = 0;
-                bool ok = false;
-                if (h < cnt) {
-                    x = s_hits[off + h];
-                    ok = (WinT)(PosT)(x - lo) < w && s_best[bb][h] == key;
-                }
-                const unsigned long long bm = __ballot(ok);
-                if (bm) {
-                    const uint32_t top = 63u - (uint32_t)__clzll((long long)bm);
-                    hmax = h0 + top;
-                    if constexpr (kWidePos) x_out = (PosT)lane_of((unsigned long long)x, top);
-                    else x_out = (PosT)lane_of((uint32_t)x, top);
-                }
-            }
-            return hmax;
-        };
-
-        // the probe a command names
-        struct Probe {
-            uint32_t cnt, off, tb, bb, g10, pend;
-            uint64_t i;
-        };
-        // ---- offers of the arms of layer L to the hits of probe q (table q.tb, winners best[q.bb]); only the lanes with
-        // `who` set take part; returns the candidate word of the lane -------------------------------------------------
-        auto offers = [&](int L, bool who, const Probe &q, uint32_t ns, bool povf) -> uint32_t {
-            const uint32_t g10 = q.g10, tb = q.tb, bb = q.bb;
-            const PosT lo = (PosT)(a_re[L] - k + 1u);
-            const WinT w = (WinT)a_thr[L] + (WinT)(k - 1u);
-            const uint32_t key = a_seq[L];
-            const bool narrow = who && w <= w_loop;
-            const WinT w_eff = narrow ? w : (WinT)0;  // (an empty window accepts nothing)
-            uint32_t ch = 0, nc = 0;
-            uint32_t *const sink = &s_sink[lane];
-            auto offer = [&](unsigned long long e) {
-                const uint32_t d = tag_of(e) - g10;
-                const WinT t = d < 1024u ? (WinT)(PosT)(pos_of(e) - lo) : ~(WinT)0;
-                const bool ok = t < w_eff;
-                atomicMin(ok ? &s_best[bb][d & 1023u] : sink, key);
-                ch = ok ? ((ch << 10) | d) : ch;
-                nc += ok ? 1u : 0u;
-            };
-            auto offer_row = [&](uint32_t b) {
-                const ulonglong2 *rr = reinterpret_cast<const ulonglong2 *>(&s_tab[tb][(b & (uint32_t)(kRows - 1)) * (uint32_t)kE]);
-                if constexpr (kE == 4) {
-                    const ulonglong2 f0 = rr[0], f1 = rr[1];
-                    offer(f0.x); offer(f0.y); offer(f1.x); offer(f1.y);
-                } else {
-                    const ulonglong2 f0 = rr[0];
-                    offer(f0.x); offer(f0.y);
-                }
-            };
-            const uint32_t b0 = (uint32_t)((uint64_t)lo >> bsh);
-            const uint32_t n_rows = narrow ? (uint32_t)((((uint64_t)lo & ((1ull << bsh) - 1ull)) + (uint64_t)w - 1ull) >> bsh) + 1u : 0u;
-            {   // the two rows of a narrow window: all reads in flight together
-                const ulonglong2 *r0 = reinterpret_cast<const ulonglong2 *>(&s_tab[tb][(b0 & (uint32_t)(kRows - 1)) * (uint32_t)kE]);
-                const ulonglong2 *r1 = reinterpret_cast<const ulonglong2 *>(&s_tab[tb][((b0 + 1u) & (uint32_t)(kRows - 1)) * (uint32_t)kE]);
-                if constexpr (kE == 4) {
-                    const ulonglong2 e0 = r0[0], e1 = r0[1], e2 = r1[0], e3 = r1[1];
-                    offer(e0.x); offer(e0.y); offer(e1.x); offer(e1.y);
-                    offer(e2.x); offer(e2.y); offer(e3.x); offer(e3.y);
-                } else {
-                    const ulonglong2 e0 = r0[0], e2 = r1[0];
-                    offer(e0.x); offer(e0.y); offer(e2.x); offer(e2.y);
-                }
-            }
-            for (uint32_t r = 2; __ballot(r < n_rows); ++r) {
-                K7C(53, 1);
-                offer_row(b0 + r);
-            }
-            for (uint32_t s = 0; s < min(ns, kStash); ++s) {
-                K7C(56, 1);
-                offer(s_stash[bb][s]);
-            }
-            ch = nc > 3u ? kCoop : (ch & 0x3FFFFFFFu) | (nc << 30);
-            // arms too wide for the table walk -- and every arm when the stash overflowed
-            unsigned long long sm = __ballot(who && (!narrow || povf));
-            if (sm) {
-                if (who && (!narrow || povf)) ch = kCoop;
-                K7C(54, __popcll(sm));
-                while (sm) {
-                    const uint32_t l = (uint32_t)(__ffsll((long long)sm) - 1);
-                    sm &= sm - 1ull;
-                    PosT lo_u;
-                    WinT w_u;
-                    if constexpr (kWidePos) {
-                        lo_u = (PosT)lane_of((unsigned long long)lo, l);
-                        w_u = (WinT)lane_of((unsigned long long)w, l);
-                    } else {
-                        lo_u = (PosT)lane_of((uint32_t)lo, l);
-                        w_u = (WinT)lane_of((uint32_t)w, l);
-                    }
-                    coop_offer(lo_u, w_u, lane_of(key, l), q.cnt, q.off, bb);
-                }
-            }
-            return ch;
-        };
-
-        auto read_cmd = [&](uint32_t par, uint32_t &flags, Probe &q) {
-            const uint4 c0 = *reinterpret_cast<const uint4 *>(&s_cmd[par][0]);
-            const uint4 c1 = *reinterpret_cast<const uint4 *>(&s_cmd[par][4]);
-            flags = uni(c0.x);
-            q.cnt = uni(c0.y);
-            q.off = uni(c0.z);
-            q.tb = uni(c0.w) & 1u;
-            q.bb = uni(c0.w) >> 1;
-            q.g10 = uni(c1.x);
-            q.i = ((uint64_t)uni(c1.z) << 32) | uni(c1.y);
-            q.pend = uni(c1.w);
+        // does this wave hold one of the threads that index cnt hits?
+        auto indexes = [&](uint32_t cnt) {
+            const uint32_t first = is_ctl ? (uint32_t)NWA : (uint32_t)(NWA - 1) - wave;  // in units of 64 hits
+            return first < (cnt + 63u) / 64u;
         };
         // stage `tot` hit rows starting at CSR entry `base` into buffer `buf` (all threads)
         auto stage_rows = [&](unsigned long long base, uint32_t tot, uint32_t buf) {
@@ -372,63 +266,252 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
             // =====================================================================================================
             // ARM WAVES
             // =====================================================================================================
-            Probe prev{0, 0, 0, 0, 0, 0, 0};
             lds_barrier();  // (1) the control wave has published the first batch's staging request
             mid_actions(uni(s_mid[0]));
-            lds_barrier();  // (2) the rows are in; the first command is there
-            for (uint32_t sp = 0;; sp ^= 1u) {
-                uint32_t flags;
-                Probe cur;
+            lds_barrier();  // (2) the rows are in; the first two commands are there
+            uint32_t pv_off = 0, pv_besto = 0;  // the previous probe's rows and winners (as in the last command)
+            for (uint32_t sc = 0, sp = 0;; sc = sc == 2u ? 0u : sc + 1u, sp ^= 1u) {
                 K7T_MARK();
                 K7T_STEP();
                 K7U_MARK();
-                read_cmd(sp, flags, cur);
+                // ---- every read that depends on nothing read in this step, in one go ---------------------------
+                const uint32_t sn = sc == 2u ? 0u : sc + 1u;  // the next step's command
+                const uint4 *cq = reinterpret_cast<const uint4 *>(&s_cmd[sc][0]);
+                const uint4 *nq = reinterpret_cast<const uint4 *>(&s_cmd[sn][0]);
+                const uint4 c0 = cq[0], n0 = nq[0];
+                uint4 c1 = make_uint4(0, 0, 0, 0), c2 = c1, c3 = c1, c4 = c1, c5 = c1;
+                // (of the arms, layer 0 -- where they sit unless a burst of a dense repeat is under way -- reads ahead;
+                // the layers above read when their turn comes: five layers' worth of loads in flight would not fit
+                // the register file)
+                uint32_t cb0[3] = {0, 0, 0};
+                PosT xb0[3] = {0, 0, 0}, rs0 = 0;
+                uint4 nst = make_uint4(0, 0, 0, 0);
+                auto read_candidates = [&](int L, uint32_t (&cb)[3], PosT (&xb)[3], PosT &rs) {
+                    const uint32_t ch = c_h[L];
+                    const uint32_t nc = (a_seq[L] == kNoSeq || ch == kCoop) ? 0u : ch >> 30;
+#pragma unroll
+                    for (uint32_t j = 0; j < 3; ++j) {
+                        const uint32_t hj = (ch >> (10u * j)) & 1023u;
+                        cb[j] = *(j < nc ? reinterpret_cast<const uint32_t *>(best0 + pv_besto + 4u * hj) : &s_never);
+                        xb[j] = s_hits[pv_off + (j < nc ? hj : 0u)];
+                    }
+                    rs = s_crs[L * (NWA * 64) + tid];
+                };
+                bool cmd_loaded = livemask != 0u;  // (a wave without arms reads the rest of the command when it gets one)
+                if (livemask) {
+                    c1 = cq[1]; c2 = cq[2]; c3 = cq[3]; c4 = cq[4]; c5 = cq[5];
+                    if (livemask & 1u) read_candidates(0, cb0, xb0, rs0);
+                }
+                const uint32_t flags = uni(c0.x);
                 if (flags & K7_GIVEUP) {
                     overflow = true;
                     break;
                 }
                 const bool has_prev = (flags & K7_PREV) != 0u, has_cur = (flags & K7_CUR) != 0u, late = (flags & K7_LATE) != 0u;
                 // ---------------------------------------------------------------- interval A ----------------
-                if (has_cur && late) insert_hits(cur.cnt, cur.off, cur.tb, cur.bb, cur.g10);
-                const uint32_t fam_a = uni(s_fam[sp ^ 1u]);
-                const uint32_t ns_v = (has_cur && !late && livemask) ? s_nstash[cur.bb] : 0u;
-                uint32_t wasfree = 0;  // per lane, bit L: the slot of layer L was empty before this step
-                K7U_LAP(0);
-#pragma unroll
-                for (int L = 0; L < S; ++L) {
-                    if (!(livemask >> L)) {
-                        wasfree |= ((1u << S) - 1u) & ~((1u << L) - 1u);  // this layer and the ones above: all empty
-                        break;
+                // the hits of this step's probe when it opened a batch (its rows arrived with the last barrier), and those of
+                // the NEXT step's probe otherwise: indexed by the top arm waves while the others resolve
+                if (has_cur && late) {
+                    const uint32_t cnt = uni(c0.y);
+                    if (indexes(cnt)) {
+                        const uint4 d1 = cq[1], d4 = cq[4];
+                        insert_hits(cnt, uni(c0.z), uni(c0.w), uni(d1.x), uni(cq[2].y), uni(d1.y), uni(d4.w));
                     }
-                    const bool was_free = a_seq[L] == kNoSeq;
-                    wasfree |= was_free ? 1u << L : 0u;
-                    if (!(livemask & (1u << L))) continue;
-                    bool won = false;
-                    PosT xw = 0;
-                    if (has_prev) {
-                        // the last hit (SA order) this arm won, if any: src/automaton.rs:133-150 apply in hit order
-                        const uint32_t ch = c_h[L];
-                        const bool coop = !was_free && ch == kCoop;
-                        const uint32_t nc = (was_free || coop) ? 0u : ch >> 30;
-                        uint32_t cb[3];
+                }
+                if (!(flags & K7_LAST)) {
+                    const uint32_t nflags = uni(n0.x), ncnt = uni(n0.y);
+                    if ((nflags & K7_CUR) && !(nflags & K7_LATE) && indexes(ncnt)) {
+                        const uint4 n1 = nq[1], n2 = nq[2], n4 = nq[4];
+                        insert_hits(ncnt, uni(n0.z), uni(n0.w), uni(n1.x), uni(n2.y), uni(n1.y), uni(n4.w));
+                    }
+                }
+                K7U_LAP(0);
+                uint32_t wasfree = 0;  // per lane, bit L: the slot of layer L was empty before this step
+                if (!livemask) {
+                    wasfree = (1u << S) - 1u;
+                } else {
+                    // (vector registers that hold the same value in every lane: the command's fields)
+                    const uint32_t k = c4.x, step = c4.y, G = c4.z, pend = c2.x;
+                    const uint32_t p_i = c3.x;  // low word of the previous probe's needle offset
+                    const uint64_t M = ((uint64_t)c5.y << 32) | c5.x;
 #pragma unroll
-                        for (uint32_t j = 0; j < 3; ++j) cb[j] = *(j < nc ? &s_best[prev.bb][(ch >> (10u * j)) & 1023u] : &s_never);
-                        uint32_t hw = 0;  // 1 + that hit
-#pragma unroll
-                        for (uint32_t j = 0; j < 3; ++j) {
-                            const uint32_t hj = (ch >> (10u * j)) & 1023u;
-                            hw = cb[j] == a_seq[L] ? max(hw, hj + 1u) : hw;
+                    for (int L = 0; L < S; ++L) {
+                        if (!(livemask >> L)) {
+                            wasfree |= ((1u << S) - 1u) & ~((1u << L) - 1u);  // this layer and the ones above: all empty
+                            break;
                         }
-                        hw = (was_free || coop) ? 0u : hw;
-                        xw = s_hits[prev.off + (hw ? hw - 1u : 0u)];
-                        unsigned long long sm = __ballot(coop);
-                        K7C(55, __popcll(sm));
-                        while (sm) {  // more than three candidates / wide window: resolved cooperatively
+                        const bool was_free = a_seq[L] == kNoSeq;
+                        wasfree |= was_free ? 1u << L : 0u;
+                        if (!(livemask & (1u << L))) continue;
+                        bool won = false;
+                        PosT xw = 0;
+                        uint32_t cb[3];
+                        PosT xb[3], rs_L;
+                        if (L == 0) {
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) {
+                                cb[j] = cb0[j];
+                                xb[j] = xb0[j];
+                            }
+                            rs_L = rs0;
+                        } else {
+                            read_candidates(L, cb, xb, rs_L);
+                        }
+                        if (has_prev) {
+                            // the last hit (SA order) this arm won, if any: src/automaton.rs:133-150 apply in hit order
+                            const uint32_t ch = c_h[L];
+                            const bool coop = !was_free && ch == kCoop;
+                            uint32_t hw = 0;  // 1 + that hit
+#pragma unroll
+                            for (uint32_t j = 0; j < 3; ++j) {
+                                const uint32_t hj = (ch >> (10u * j)) & 1023u;
+                                const bool mine = cb[j] == a_seq[L] && hj + 1u > hw;
+                                hw = mine ? hj + 1u : hw;
+                                xw = mine ? xb[j] : xw;
+                            }
+                            hw = (was_free || coop) ? 0u : hw;
+                            unsigned long long sm = __ballot(coop);
+                            K7C(55, __popcll(sm));
+                            if (sm) {  // more than three candidates / wide window: resolved cooperatively
+                                const uint32_t p_cnt = uni(c2.w), p_off = pv_off;
+                                while (sm) {
+                                    const uint32_t l = (uint32_t)(__ffsll((long long)sm) - 1);
+                                    sm &= sm - 1ull;
+                                    const PosT lo = (PosT)(a_re[L] - k + 1u);
+                                    const WinT w = (WinT)a_thr[L] + (WinT)(k - 1u);
+                                    PosT lo_u;
+                                    WinT w_u;
+                                    if constexpr (kWidePos) {
+                                        lo_u = (PosT)lane_of((unsigned long long)lo, l);
+                                        w_u = (WinT)lane_of((unsigned long long)w, l);
+                                    } else {
+                                        lo_u = (PosT)lane_of((uint32_t)lo, l);
+                                        w_u = (WinT)lane_of((uint32_t)w, l);
+                                    }
+                                    const uint32_t key = lane_of(a_seq[L], l);
+                                    uint32_t hmax = kNone;
+                                    PosT x_u = 0;
+                                    for (uint32_t h0 = 0; h0 < p_cnt; h0 += 64u) {
+                                        const uint32_t h = h0 + (uint32_t)lane;
+                                        PosT x = 0;
+                                        bool ok = false;
+                                        if (h < p_cnt) {
+                                            x = s_hits[p_off + h];
+                                            ok = (WinT)(PosT)(x - lo_u) < w_u &&
+                                                 *reinterpret_cast<const uint32_t *>(best0 + pv_besto + 4u * h) == key;
+                                        }
+                                        const unsigned long long bm = __ballot(ok);
+                                        if (bm) {
+                                            const uint32_t top = 63u - (uint32_t)__clzll((long long)bm);
+                                            hmax = h0 + top;
+                                            if constexpr (kWidePos) x_u = (PosT)lane_of((unsigned long long)x, top);
+                                            else x_u = (PosT)lane_of((uint32_t)x, top);
+                                        }
+                                    }
+                                    if ((uint32_t)lane == l && hmax != kNone) {
+                                        hw = hmax + 1u;
+                                        xw = x_u;
+                                    }
+                                }
+                            }
+                            won = hw != 0u;
+                        }
+                        // ExtendArm (src/automaton.rs:133-150) or one more step of age (:166-171), then the quiet probes
+                        // between the previous probe and this one
+                        uint32_t thr_new;
+                        if constexpr (kWidePos) {
+                            const uint64_t p_i64 = ((uint64_t)c3.y << 32) | c3.x;
+                            thr_new = arm_threshold((uint64_t)(p_i64 + k) - (uint64_t)a_ls[L], G);
+                        } else {
+                            thr_new = max(G, ((p_i + k) - (uint32_t)a_ls[L]) / 10u);
+                        }
+                        const uint64_t sum_g = (uint64_t)(won ? 0u : a_gap[L]) + (has_prev && !won ? step : 0u) + pend;
+                        const uint32_t aged = sum_g > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)sum_g;
+                        a_re[L] = won ? (PosT)(xw + k) : a_re[L];
+                        PosT le_new;
+                        if constexpr (kWidePos) le_new = (PosT)((((uint64_t)c3.y << 32) | c3.x) + k);
+                        else le_new = (PosT)(p_i + k);
+                        if (won) s_cle[L * (NWA * 64) + tid] = le_new;
+                        a_thr[L] = won ? thr_new : a_thr[L];
+                        a_gap[L] = aged;
+                        const bool dead = !was_free && aged >= G;  // never matches again
+                        const bool report = dead && (uint64_t)(a_re[L] - rs_L) >= M;
+                        if (__ballot(report))
+                            emit_records(report, a_ls[L], s_cle[L * (NWA * 64) + tid], rs_L, a_re[L], a_seq[L], uni(s_fam[sp ^ 1u]));
+                        a_seq[L] = dead ? kNoSeq : a_seq[L];
+                    }
+                }
+                K7U_LAP(1);
+                // ---- offers of the arms of layer L to the hits of the step's probe; only the lanes with `who` set take
+                // part; returns the candidate word of the lane ---------------------------------------------------------
+                auto offers = [&](int L, bool who, uint32_t ns) -> uint32_t {
+                    const uint32_t k = c4.x, g10 = c1.y, bsh = uni(c4.w);
+                    char *const tab = tab0 + c0.w;
+                    char *const best = best0 + c1.x;
+                    const bool povf = ns > kStash;
+                    const WinT w_loop = (WinT)(kRowsLoop - 1u) << bsh;
+                    const PosT lo = (PosT)(a_re[L] - k + 1u);
+                    const WinT w = (WinT)a_thr[L] + (WinT)(k - 1u);
+                    const uint32_t key = a_seq[L];
+                    const bool narrow = who && w <= w_loop;
+                    const WinT w_eff = narrow ? w : (WinT)0;  // (an empty window accepts nothing)
+                    uint32_t ch = 0, nc = 0;
+                    uint32_t *const sink = &s_sink[lane];
+                    auto offer = [&](unsigned long long e) {
+                        const uint32_t d = tag_of(e) - g10;
+                        const WinT t = d < 1024u ? (WinT)(PosT)(pos_of(e) - lo) : ~(WinT)0;
+                        const bool ok = t < w_eff;
+#ifdef ASGART_K7_MASKED_MIN
+                        if (ok) atomicMin(reinterpret_cast<uint32_t *>(best + 4u * (d & 1023u)), key);
+#else
+                        atomicMin(ok ? reinterpret_cast<uint32_t *>(best + 4u * (d & 1023u)) : sink, key);
+#endif
+                        ch = ok ? ((ch << 10) | d) : ch;
+                        nc += ok ? 1u : 0u;
+                    };
+                    auto offer_row = [&](uint32_t b) {
+                        const ulonglong2 *rr = reinterpret_cast<const ulonglong2 *>(tab + (b & (uint32_t)(kRows - 1)) * (uint32_t)(kE * 8));
+                        if constexpr (kE == 4) {
+                            const ulonglong2 f0 = rr[0], f1 = rr[1];
+                            offer(f0.x); offer(f0.y); offer(f1.x); offer(f1.y);
+                        } else {
+                            const ulonglong2 f0 = rr[0];
+                            offer(f0.x); offer(f0.y);
+                        }
+                    };
+                    const uint32_t b0 = (uint32_t)((uint64_t)lo >> bsh);
+                    const uint32_t n_rows = narrow ? (uint32_t)((((uint64_t)lo & ((1ull << bsh) - 1ull)) + (uint64_t)w - 1ull) >> bsh) + 1u : 0u;
+                    {   // the two rows of a narrow window: all reads in flight together
+                        const ulonglong2 *r0 = reinterpret_cast<const ulonglong2 *>(tab + (b0 & (uint32_t)(kRows - 1)) * (uint32_t)(kE * 8));
+                        const ulonglong2 *r1 = reinterpret_cast<const ulonglong2 *>(tab + ((b0 + 1u) & (uint32_t)(kRows - 1)) * (uint32_t)(kE * 8));
+                        if constexpr (kE == 4) {
+                            const ulonglong2 e0 = r0[0], e1 = r0[1], e2 = r1[0], e3 = r1[1];
+                            offer(e0.x); offer(e0.y); offer(e1.x); offer(e1.y);
+                            offer(e2.x); offer(e2.y); offer(e3.x); offer(e3.y);
+                        } else {
+                            const ulonglong2 e0 = r0[0], e2 = r1[0];
+                            offer(e0.x); offer(e0.y); offer(e2.x); offer(e2.y);
+                        }
+                    }
+                    for (uint32_t r = 2; __ballot(r < n_rows); ++r) {
+                        K7C(53, 1);
+                        offer_row(b0 + r);
+                    }
+                    if (ns) {
+                        const uint32_t bb = uni(c2.y);
+                        for (uint32_t s = 0; s < min(ns, kStash); ++s) offer(s_stash[bb][s]);
+                    }
+                    ch = nc > 3u ? kCoop : (ch & 0x3FFFFFFFu) | (nc << 30);
+                    // arms too wide for the table walk -- and every arm when the stash overflowed
+                    unsigned long long sm = __ballot(who && (!narrow || povf));
+                    if (sm) {
+                        if (who && (!narrow || povf)) ch = kCoop;
+                        K7C(54, __popcll(sm));
+                        const uint32_t cnt = uni(c0.y), off = uni(c0.z);
+                        while (sm) {
                             const uint32_t l = (uint32_t)(__ffsll((long long)sm) - 1);
                             sm &= sm - 1ull;
-                            const PosT lo = (PosT)(a_re[L] - k + 1u);
-                            const WinT w = (WinT)a_thr[L] + (WinT)(k - 1u);
-                            PosT lo_u, x_u = 0;
+                            PosT lo_u;
                             WinT w_u;
                             if constexpr (kWidePos) {
                                 lo_u = (PosT)lane_of((unsigned long long)lo, l);
@@ -437,111 +520,101 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                                 lo_u = (PosT)lane_of((uint32_t)lo, l);
                                 w_u = (WinT)lane_of((uint32_t)w, l);
                             }
-                            const uint32_t hm_ = coop_resolve(lo_u, w_u, lane_of(a_seq[L], l), prev.cnt, prev.off, prev.bb, x_u);
-                            if ((uint32_t)lane == l && hm_ != kNone) {
-                                hw = hm_ + 1u;
-                                xw = x_u;
+                            const uint32_t key_u = lane_of(key, l);
+                            for (uint32_t h0 = 0; h0 < cnt; h0 += 64u) {
+                                const uint32_t h = h0 + (uint32_t)lane;
+                                if (h < cnt && (WinT)(PosT)(s_hits[off + h] - lo_u) < w_u)
+                                    atomicMin(reinterpret_cast<uint32_t *>(best + 4u * h), key_u);
                             }
                         }
-                        won = hw != 0u;
                     }
-                    // ExtendArm (src/automaton.rs:133-150) or one more step of age (:166-171), then the quiet probes
-                    // between the previous probe and this one
-                    uint32_t thr_new;
-                    if constexpr (kWidePos) thr_new = arm_threshold((uint64_t)(prev.i + k) - (uint64_t)a_ls[L], G);
-                    else thr_new = max(G, ((uint32_t)(prev.i + k) - (uint32_t)a_ls[L]) / 10u);
-                    const uint64_t sum_g = (uint64_t)(won ? 0u : a_gap[L]) + (has_prev && !won ? step : 0u) + cur.pend;
-                    const uint32_t aged = sum_g > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)sum_g;
-                    a_re[L] = won ? (PosT)(xw + k) : a_re[L];
-                    if (won) s_cle[L * (NWA * 64) + tid] = (PosT)(prev.i + k);
-                    a_thr[L] = won ? thr_new : a_thr[L];
-                    a_gap[L] = aged;
-                    const bool dead = !was_free && aged >= G;  // never matches again
-                    if (__ballot(dead)) {
-                        const PosT rs = s_crs[L * (NWA * 64) + tid];
-                        const bool report = dead && (uint64_t)(a_re[L] - rs) >= rp.M;
-                        if (__ballot(report)) emit_records(report, a_ls[L], s_cle[L * (NWA * 64) + tid], rs, a_re[L], a_seq[L], fam_a);
-                    }
-                    a_seq[L] = dead ? kNoSeq : a_seq[L];
-                }
-                uint32_t ns = 0;
-                bool povf = false;
-                K7U_LAP(1);
-                if (has_cur && !late && livemask) {
-                    ns = uni(ns_v);
-                    povf = ns > kStash;
-#pragma unroll
-                    for (int L = 0; L < S; ++L) {
-                        if (!(livemask >> L)) break;
-                        if (livemask & (1u << L)) c_h[L] = offers(L, a_seq[L] != kNoSeq, cur, ns, povf);
-                    }
-                }
+                    return ch;
+                };
+                // the stash count of the step's probe (final when its hits are indexed)
+                auto stash_count = [&](const uint4 &n4) {
+                    const uint32_t bb = c2.y;
+                    return uni(bb == 0u ? n4.x : (bb == 1u ? n4.y : n4.z));
+                };
+                (void)nst;
                 K7U_LAP(2);
                 K7T_LAP(0);
                 lds_barrier();  // ---- barrier 1 --------------------------------------------------------------
                 K7T_LAP(1);
                 K7U_MARK();
                 // ---------------------------------------------------------------- interval B ----------------
+                const bool had_live = livemask != 0u;
                 const uint4 m0v = *reinterpret_cast<const uint4 *>(&s_mid[0]);
+                const uint32_t b_first = s_base[wave][0];
+                uint4 bs0 = make_uint4(0, 0, 0, 0), bs1 = bs0, nst2 = bs0;
+                if (had_live) {  // (a wave without arms looks at the rest when it turns out to receive some)
+                    bs0 = *reinterpret_cast<const uint4 *>(&s_base[wave][0]);
+                    if constexpr (S > 4) bs1 = *reinterpret_cast<const uint4 *>(&s_base[wave][4]);
+                    if (has_cur) nst2 = *reinterpret_cast<const uint4 *>(&s_nstash[0]);
+                }
                 const uint32_t mflags = uni(m0v.x);
                 if (mflags & K7_OVF) {
                     overflow = true;
                     break;
                 }
-                if (has_cur && late) {
-                    ns = uni(s_nstash[cur.bb]);
-                    povf = ns > kStash;
-                }
-                const uint32_t n_new = has_prev ? uni(m0v.y) : 0u, seq_base = uni(m0v.z), fam_b = uni(m0v.w);
-                uint32_t base_r[S];
-#pragma unroll
-                for (int L = 0; L < S; ++L) base_r[L] = n_new ? s_base[L * NWA + (int)wave] : 0u;
+                const uint32_t n_new = has_prev ? uni(m0v.y) : 0u;
+                const uint32_t seq_base = m0v.z, fam_b = m0v.w;
                 K7U_LAP(3);
-#pragma unroll
-                for (int L = 0; L < S; ++L) {
-                    const uint32_t b_r = n_new ? uni(base_r[L]) : 0u;
-                    const bool reach = n_new != 0u && b_r < n_new;  // (the empty slots of the lower layers take the rest)
-                    if (!reach && !(livemask >> L)) break;
-                    bool take = false;
-                    if (reach) {
-                        // NewArm by owner pull: the r-th empty slot takes the r-th unmatched hit (src/automaton.rs:151-164)
-                        const bool was_free = (wasfree >> L) & 1u;
-                        const unsigned long long fmask = __ballot(was_free);
-                        const uint32_t r = b_r + (uint32_t)__popcll(fmask & lt_mask);
-                        take = was_free && r < n_new;
-                        const PosT x = s_new[take ? r : 0u];
-                        const uint64_t g_new = (uint64_t)step + cur.pend;  // aged by its own probe, then by the quiet ones
-                        const uint32_t gap_new = g_new > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)g_new;
-                        const bool stillborn = take && gap_new >= G;
-                        if (__ballot(stillborn)) {  // (only when min_duplication_length <= k: a k-base arm is reported)
-                            const bool report = stillborn && (uint64_t)k >= rp.M;
-                            if (__ballot(report)) emit_records(report, (PosT)prev.i, (PosT)(prev.i + k), x, (PosT)(x + k), seq_base + r, fam_b);
-                        }
-                        take = take && !stillborn;
-                        a_ls[L] = take ? (PosT)prev.i : a_ls[L];
-                        if (take) {
-                            s_cle[L * (NWA * 64) + tid] = (PosT)(prev.i + k);
-                            s_crs[L * (NWA * 64) + tid] = x;
-                        }
-                        a_re[L] = take ? (PosT)(x + k) : a_re[L];
-                        a_gap[L] = take ? gap_new : a_gap[L];
-                        a_thr[L] = take ? thr0 : a_thr[L];
-                        a_seq[L] = take ? seq_base + r : a_seq[L];
-                        if (__ballot(take)) livemask |= 1u << L;
+                const bool receives = n_new != 0u && uni(b_first) < n_new;
+                if (receives || (has_cur && livemask)) {
+                    if (!cmd_loaded) {  // (this wave had no arms and now receives some)
+                        c1 = cq[1]; c2 = cq[2]; c3 = cq[3]; c4 = cq[4]; c5 = cq[5];
+                        bs0 = *reinterpret_cast<const uint4 *>(&s_base[wave][0]);
+                        if constexpr (S > 4) bs1 = *reinterpret_cast<const uint4 *>(&s_base[wave][4]);
+                        if (has_cur) nst2 = *reinterpret_cast<const uint4 *>(&s_nstash[0]);
+                        cmd_loaded = true;
                     }
-                    if (has_cur && (livemask & (1u << L))) {
-                        if (late) {
-                            c_h[L] = offers(L, a_seq[L] != kNoSeq, cur, ns, povf);
-                        } else if (__ballot(take)) {
-                            const uint32_t ns2 = uni(s_nstash[cur.bb]);
-                            const uint32_t chn = offers(L, take, cur, ns2, ns2 > kStash);
-                            c_h[L] = take ? chn : c_h[L];
+                    const uint32_t base_r[8] = {bs0.x, bs0.y, bs0.z, bs0.w, bs1.x, bs1.y, bs1.z, bs1.w};
+                    const uint32_t ns_b = has_cur ? stash_count(nst2) : 0u;
+                    const uint32_t k = c4.x, step = c4.y, G = c4.z, pend = c2.x, thr0 = c5.z;
+                    const uint64_t M = ((uint64_t)c5.y << 32) | c5.x;
+                    PosT p_i;
+                    if constexpr (kWidePos) p_i = (PosT)(((uint64_t)c3.y << 32) | c3.x);
+                    else p_i = (PosT)c3.x;
+#pragma unroll
+                    for (int L = 0; L < S; ++L) {
+                        const uint32_t b_r = n_new ? uni(base_r[L]) : 0u;
+                        const bool reach = n_new != 0u && b_r < n_new;  // (the empty slots of the lower layers take the rest)
+                        if (!reach && !(livemask >> L)) break;
+                        bool take = false;
+                        if (reach) {
+                            // NewArm by owner pull: the r-th empty slot takes the r-th unmatched hit (src/automaton.rs:151-164)
+                            const bool was_free = (wasfree >> L) & 1u;
+                            const unsigned long long fmask = __ballot(was_free);
+                            const uint32_t r = b_r + (uint32_t)__popcll(fmask & lt_mask);
+                            take = was_free && r < n_new;
+                            const PosT x = s_new[take ? r : 0u];
+                            const uint64_t g_new = (uint64_t)step + pend;  // aged by its own probe, then by the quiet ones
+                            const uint32_t gap_new = g_new > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)g_new;
+                            const bool stillborn = take && gap_new >= G;
+                            if (__ballot(stillborn)) {  // (only when min_duplication_length <= k: a k-base arm is reported)
+                                const bool report = stillborn && (uint64_t)k >= M;
+                                if (__ballot(report)) emit_records(report, p_i, (PosT)(p_i + k), x, (PosT)(x + k), seq_base + r, fam_b);
+                            }
+                            take = take && !stillborn;
+                            a_ls[L] = take ? p_i : a_ls[L];
+                            if (take) {
+                                s_cle[L * (NWA * 64) + tid] = (PosT)(p_i + k);
+                                s_crs[L * (NWA * 64) + tid] = x;
+                            }
+                            a_re[L] = take ? (PosT)(x + k) : a_re[L];
+                            a_gap[L] = take ? gap_new : a_gap[L];
+                            a_thr[L] = take ? thr0 : a_thr[L];
+                            a_seq[L] = take ? seq_base + r : a_seq[L];
+                            if (__ballot(take)) livemask |= 1u << L;
                         }
+                        // every arm of the layer, old and new, offers to the step's probe
+                        if (has_cur && (livemask & (1u << L))) c_h[L] = offers(L, a_seq[L] != kNoSeq, ns_b);
                     }
                 }
                 K7U_LAP(4);
                 mid_actions(mflags);
-                {   // free counts, as the control wave will rank them in the next step
+                if (had_live || receives) {  // free counts, as the control wave will rank them in the next step (an idle
+                                             // wave's stay as they are: all empty)
                     uint32_t nfv[8] = {64u, 64u, 64u, 64u, 64u, 64u, 64u, 64u};
 #pragma unroll
                     for (int L = 0; L < S; ++L) {
@@ -556,17 +629,12 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                     if constexpr (S > 4) *reinterpret_cast<uint4 *>(&s_free[wave][4]) = make_uint4(nfv[4], nfv[5], nfv[6], nfv[7]);
                 }
                 K7U_LAP(5);
-                if (!(flags & K7_LAST)) {  // the hits of the next step's probe (top threads), unless that step is late
-                    uint32_t nflags;
-                    Probe nx;
-                    read_cmd(sp ^ 1u, nflags, nx);
-                    if ((nflags & K7_CUR) && !(nflags & K7_LATE)) insert_hits(nx.cnt, nx.off, nx.tb, nx.bb, nx.g10);
-                }
                 K7U_LAP(6);
                 K7T_LAP(2);
                 lds_barrier();  // ---- barrier 2 --------------------------------------------------------------
                 K7T_LAP(3);
-                prev = cur;
+                pv_off = c0.z;
+                pv_besto = c1.x;
                 if (flags & K7_LAST) break;
             }
             if (wave == 0u) K7T_FLUSH(1);
@@ -577,6 +645,16 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
             // =====================================================================================================
             // CONTROL WAVE
             // =====================================================================================================
+            const RunParams &rp = P.rp;
+            const uint32_t k = (uint32_t)rp.k, step = (uint32_t)rp.step, G = rp.G;
+            const uint32_t thr0 = arm_threshold(k, G);
+            uint32_t bsh = 3;
+            while ((1ull << bsh) < (unsigned long long)G + k) ++bsh;
+            bsh += P.fast_bsh;
+            const uint32_t kGenBits = min(kGenMax, max(2u, P.gen_bits));
+            const uint32_t cap_eff = min((uint32_t)CAP, P.cap_limit);
+            const uint32_t g0 = P.seg_list[seg];
+            if (lane == 0) heartbeat(P, g0, 0u);
             const int c = chunk_of_uniform(rp.ch, g0);
             const uint64_t cs = rp.ch.start[c], cl = rp.ch.len[c];
             const uint32_t pb = rp.ch.pbase[c];
@@ -589,13 +667,14 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
             }
             uint32_t quiet = 0, pend = 0, fam_seq = 0, next_seq = 0, t_proc = 0, spur_until = 0;
             bool done = false, fam_open = false, giveup = false;
-            uint32_t hbuf = 0;
+            uint32_t hbuf = 1;  // (the first batch flips it to 0)
             // ---- the batch under the cursor ---------------------------------------------------------------------
             uint32_t g = g0, nbb = 0, pos = 0, f_l = 0, rel_l = 0, tot = 0;
             unsigned long long hm = 0, qm = 0, base = 0;
             bool staged = false;  // the rows of the batch under the cursor are in s_hits[hbuf] (or on their way)
             auto load_batch = [&]() {  // -> false: a probe with more hits than the staging area
                 const uint32_t nb = min(64u, g_end - g);
+                if (lane == 0) heartbeat(P, g0, g);
                 f_l = (uint32_t)lane < nb ? P.p_filt[g + lane] : kSkipN;
                 const unsigned long long r_l = (uint32_t)lane < nb ? P.row_off[g + lane] : 0ull;
                 const unsigned long long r_hi = uni(P.row_off[g + nb]);
@@ -616,10 +695,23 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                 staged = false;
                 return true;
             };
+            // One planned step: its command and what has to happen in the interval B of the step BEFORE it (staging of
+            // the batch its probe opens, clearing of the tables at a generation wrap).
+            struct Probe {
+                uint32_t cnt, off, tb, bb, g10, pend, t_before, t_after;
+                uint64_t i;
+            };
+            struct Plan {
+                uint32_t flags, pre;           // command flags; K7_STAGE / K7_CLEAR of the step before
+                unsigned long long st_base;    // staging request
+                uint32_t st_tot, st_buf;
+                Probe q;
+            };
+            const Probe no_probe{0, 0, 0, 0, 0, 0, 0, 0, 0};
             // the next hit-probe of the segment: -> true with `nx` filled in (its quiet run folded into nx.pend); false:
             // the segment is over (done / end of the chunk or window) or not for this kernel (giveup)
-            bool need_stage = false;
-            auto next_probe = [&](Probe &nx, uint32_t &t_before, uint32_t &t_after) -> bool {
+            bool opened = false;  // the probe just found opened a batch (its rows are to be staged)
+            auto next_probe = [&](Probe &nx) -> bool {
                 for (;;) {
                     const unsigned long long hmr = pos >= 64 ? 0ull : (hm >> pos) << pos;
                     const uint32_t b = hmr ? (uint32_t)(__ffsll((long long)hmr) - 1) : 64u;
@@ -638,9 +730,10 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                     if (hmr) {
                         quiet = 0;
                         pos = b + 1;
+                        opened = false;
                         if (!staged) {
                             hbuf ^= 1u;
-                            need_stage = true;
+                            opened = true;
                             staged = true;
                         }
                         nx.cnt = lane_of(f_l, b);
@@ -648,8 +741,8 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                         nx.i = (uint64_t)(g + b - pb + 1) * step;
                         nx.pend = pend;
                         pend = 0;
-                        t_before = t_proc;
-                        t_after = ++t_proc;
+                        nx.t_before = t_proc;
+                        nx.t_after = ++t_proc;
                         return true;
                     }
                     g += nbb;
@@ -660,20 +753,11 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                     }
                 }
             };
-            auto write_cmd = [&](uint32_t sp, uint32_t flags, const Probe &q) {
-                if (lane == 0) {
-                    *reinterpret_cast<uint4 *>(&s_cmd[sp][0]) = make_uint4(flags, q.cnt, q.off, q.tb | (q.bb << 1));
-                    *reinterpret_cast<uint4 *>(&s_cmd[sp][4]) = make_uint4(q.g10, (uint32_t)q.i, (uint32_t)(q.i >> 32), q.pend);
-                }
-            };
-            auto write_stage = [&]() {  // (lane 0) the staging request of the batch under the cursor
-                *reinterpret_cast<uint4 *>(&s_mid[4]) = make_uint4((uint32_t)base, (uint32_t)(base >> 32), tot, hbuf);
-            };
-            // a probe gets its generation (a wrap asks for a clearing of the tables before it is indexed)
-            bool need_clear = false;
+            // a probe gets its generation -> true: the tables must be cleared before it is indexed (wrap)
             auto number_probe = [&](Probe &q) {
+                bool wrap = false;
                 if ((gen + 1u) >> kGenBits) {
-                    need_clear = true;
+                    wrap = true;
                     gen = 0;
                 }
                 ++gen;
@@ -681,36 +765,105 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                 q.tb = par;
                 q.bb = tri;
                 par ^= 1u;
-                tri = (tri + 1u) % 3u;
+                tri = tri == 2u ? 0u : tri + 1u;
+                return wrap;
             };
-
-            Probe cur{0, 0, 0, 0, 0, 0, 0}, prev{0, 0, 0, 0, 0, 0, 0}, held{0, 0, 0, 0, 0, 0, 0};
-            uint32_t cur_tb = 0, cur_ta = 0, prev_tb = 0, prev_ta = 0, held_tb = 0, held_ta = 0;  // processed probes before / after
-            bool have_cur = false, have_held = false;
-            hbuf = 1;  // (the first batch flips it to 0)
-            if (!load_batch()) giveup = true;
-            if (!giveup) have_cur = next_probe(cur, cur_tb, cur_ta);  // (the segment starts with a hit-probe)
-            if (have_cur) number_probe(cur);
-            if (lane == 0) {
-                s_mid[0] = ((need_stage && have_cur) ? K7_STAGE : 0u) | ((need_clear && have_cur) ? K7_CLEAR : 0u);
-                write_stage();
+            // the plan of the step behind `last` (whose probe, if it has one, becomes the new step's predecessor)
+            bool have_held = false;
+            Plan held{};
+            auto advance = [&](const Plan &last) -> Plan {
+                Plan n{};
+                n.q = no_probe;
+                if (have_held) {  // the probe that waited for the tables to be cleared
+                    n = held;
+                    have_held = false;
+                    return n;
+                }
+                Probe nx = no_probe;
+                const bool found = next_probe(nx);
+                if (giveup) {
+                    n.flags = K7_GIVEUP;
+                    return n;
+                }
+                if (!found) {
+                    n.flags = K7_PREV | K7_LAST;
+                    n.q.pend = pend;  // the trailing quiet probes' age
+                    return n;
+                }
+                const bool wrap = number_probe(nx);
+                Plan p{};
+                p.q = nx;
+                p.pre = (opened ? K7_STAGE : 0u) | (wrap ? K7_CLEAR : 0u);
+                p.st_base = base;
+                p.st_tot = tot;
+                p.st_buf = hbuf;
+                p.flags = K7_CUR | ((opened || wrap) ? K7_LATE : 0u);
+                if (wrap && (last.flags & K7_CUR)) {
+                    // the tables can only be cleared once the previous probe has all its offers: a step without a probe
+                    // of its own resolves that one first, the clearing rides in ITS interval B
+                    held = p;
+                    have_held = true;
+                    n.flags = K7_PREV;
+                    return n;
+                }
+                p.flags |= (last.flags & K7_CUR) ? K7_PREV : 0u;
+                return p;
+            };
+            auto write_cmd = [&](uint32_t slot, const Plan &p, const Plan &before) {
+                if (lane == 0) {
+                    uint4 *o = reinterpret_cast<uint4 *>(&s_cmd[slot][0]);
+                    o[0] = make_uint4(p.flags, p.q.cnt, p.q.off, p.q.tb * kTabBytes);
+                    o[1] = make_uint4(p.q.bb * (uint32_t)(HB * 4), p.q.g10, (uint32_t)p.q.i, (uint32_t)(p.q.i >> 32));
+                    o[2] = make_uint4(p.q.pend, p.q.bb, 0u, before.q.cnt);
+                    o[3] = make_uint4((uint32_t)before.q.i, (uint32_t)(before.q.i >> 32), before.q.off, before.q.bb * (uint32_t)(HB * 4));
+                }
+            };
+            if (lane < 3) {  // the run's constants, once per segment, in every command block
+                uint4 *o = reinterpret_cast<uint4 *>(&s_cmd[lane][0]);
+                o[4] = make_uint4(k, step, G, bsh);
+                o[5] = make_uint4((uint32_t)rp.M, (uint32_t)(rp.M >> 32), thr0, 0u);
             }
-            need_stage = need_clear = false;
-            uint32_t flags = giveup ? K7_GIVEUP : (have_cur ? (K7_CUR | K7_LATE) : K7_LAST);
-            write_cmd(0u, flags, cur);
+
+            // ---- the first two steps are planned before the loop ---------------------------------------------------
+            Plan p_prev{}, p_cur{}, p_next{};
+            p_prev.q = no_probe;
+            if (!load_batch()) giveup = true;
+            if (giveup) {
+                p_cur.flags = K7_GIVEUP;
+                p_cur.q = no_probe;
+            } else {
+                p_cur = advance(p_prev);  // (the segment starts with a hit-probe: a late step, its batch staged below)
+            }
+            if (lane == 0) {
+                s_mid[0] = p_cur.pre;
+                *reinterpret_cast<uint4 *>(&s_mid[4]) = make_uint4((uint32_t)p_cur.st_base, (uint32_t)(p_cur.st_base >> 32), p_cur.st_tot, p_cur.st_buf);
+            }
+            write_cmd(0u, p_cur, p_prev);
+            if (!(p_cur.flags & (K7_GIVEUP | K7_LAST))) {
+                p_next = advance(p_cur);
+                write_cmd(1u, p_next, p_cur);
+            }
             lds_barrier();  // (1)
             mid_actions(uni(s_mid[0]));
             lds_barrier();  // (2)
-            if (giveup) {
+            if (p_cur.flags & K7_GIVEUP) {
                 overflow = true;
             } else {
-                for (uint32_t sp = 0;; sp ^= 1u) {
+                for (uint32_t sc = 0, sp = 0;; sc = sc == 2u ? 0u : sc + 1u, sp ^= 1u) {
+                    const uint32_t flags = p_cur.flags;
                     const bool have_prev = (flags & K7_PREV) != 0u;
+                    const Probe &prev = p_prev.q, &cur = p_cur.q;
                     K7T_MARK();
                     K7T_STEP();
                     // ------------------------------------------------------------ interval A ----------------
-                    if ((flags & K7_CUR) && (flags & K7_LATE)) insert_hits(cur.cnt, cur.off, cur.tb, cur.bb, cur.g10);
-                    uint32_t mflags = 0, n_new = 0, seq_base = 0;
+                    if ((flags & K7_CUR) && (flags & K7_LATE) && indexes(cur.cnt))
+                        insert_hits(cur.cnt, cur.off, cur.tb * kTabBytes, cur.bb * (uint32_t)(HB * 4), cur.bb, cur.g10, bsh);
+                    if (!(flags & K7_LAST) && (p_next.flags & K7_CUR) && !(p_next.flags & K7_LATE) && indexes(p_next.q.cnt))
+                        insert_hits(p_next.q.cnt, p_next.q.off, p_next.q.tb * kTabBytes, p_next.q.bb * (uint32_t)(HB * 4), p_next.q.bb,
+                                    p_next.q.g10, bsh);
+                    // what rides in this step's interval B was decided when the NEXT step was planned
+                    uint32_t mflags = (flags & K7_LAST) ? 0u : p_next.pre;
+                    uint32_t n_new = 0, seq_base = 0;
                     if (have_prev) {
                         // empty slots as published at the end of the previous step, ranked (layer, wave, lane)
                         const uint32_t fv = lane < NE ? s_free[lane % NWA][lane / NWA] : 0u;
@@ -719,18 +872,21 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                         const uint32_t bv0 = s_best[prev.bb][h_l];
                         const uint8_t hf0 = use_flag ? s_hflag[prev.off + h_l] : (uint8_t)1;
                         const PosT x0 = s_hits[prev.off + h_l];
-                        const uint32_t fincl = wave_incl_scan(fv);
-                        uint32_t total_free = lane_of(fincl, 63u);
+                        // (one scan for both halves of the entries: two 16-bit fields, each total < 2^16)
+                        const uint32_t packed = wave_incl_scan(fv | (fv2 << 16));
+                        const uint32_t fincl = packed & 0xFFFFu;
+                        const uint32_t tot_p = lane_of(packed, 63u);
+                        uint32_t total_free = tot_p & 0xFFFFu;
                         uint32_t fincl2 = 0;
                         if constexpr (NE > 64) {
-                            fincl2 = wave_incl_scan(fv2) + total_free;
-                            total_free = lane_of(fincl2, 63u);
+                            fincl2 = (packed >> 16) + total_free;
+                            total_free += tot_p >> 16;
                         }
-                        if (lane < NE) s_base[lane] = fincl - fv;
+                        if (lane < NE) s_base[lane % NWA][lane / NWA] = fincl - fv;
                         if constexpr (NE > 64)
-                            if (lane + 64 < NE) s_base[lane + 64] = fincl2 - fv2;
+                            if (lane + 64 < NE) s_base[(lane + 64) % NWA][(lane + 64) / NWA] = fincl2 - fv2;
                         const uint32_t A0 = (uint32_t)CAP - total_free;  // live arms after the quiet probes' deaths
-                        if (fam_open && A0 == 0 && prev_tb >= spur_until) {  // the flush of src/automaton.rs:182-200
+                        if (fam_open && A0 == 0 && prev.t_before >= spur_until) {  // the flush of src/automaton.rs:182-200
                             ++fam_seq;
                             next_seq = 0;
                             fam_open = false;
@@ -759,51 +915,14 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                         seq_base = next_seq;
                         next_seq += n_new;
                         fam_open = true;
-                        if (spur) spur_until = max(spur_until, prev_ta + rp.tstar - 1u);
-                    }
-                    // ---- the next step --------------------------------------------------------------------------
-                    Probe nx{0, 0, 0, 0, 0, 0, 0};
-                    uint32_t nx_tb = 0, nx_ta = 0, nflags = 0;
-                    if (have_held) {
-                        // the probe that had to wait for the tables to be cleared (this step resolves its predecessor
-                        // and clears them; staging, if the probe opened a batch, rides along)
-                        nx = held;
-                        nx_tb = held_tb;
-                        nx_ta = held_ta;
-                        have_held = false;
-                        nflags = K7_CUR | K7_LATE;
-                        mflags |= K7_CLEAR | (need_stage ? K7_STAGE : 0u);
-                        need_stage = need_clear = false;
-                    } else if (flags & K7_CUR) {
-                        const bool have_nx = next_probe(nx, nx_tb, nx_ta);
-                        if (have_nx) number_probe(nx);
-                        if (giveup) mflags |= K7_OVF;  // (a later probe is not for this kernel: the segment is re-run elsewhere)
-                        if (have_nx && need_clear) {
-                            // generation wrap: the tables can only be cleared once the current probe has all its offers,
-                            // i.e. in the NEXT step, which resolves it and has no probe of its own
-                            held = nx;
-                            held_tb = nx_tb;
-                            held_ta = nx_ta;
-                            have_held = true;
-                            nx = Probe{0, 0, 0, 0, 0, 0, 0};
-                            nflags = K7_PREV;
-                        } else {
-                            // the probe that follows a staging is indexed when its rows are there
-                            nflags = K7_PREV | (have_nx ? K7_CUR : K7_LAST) | ((have_nx && need_stage) ? K7_LATE : 0u);
-                            if (!have_nx) nx.pend = pend;  // the trailing quiet probes' age
-                            if (need_stage && have_nx) mflags |= K7_STAGE;
-                            need_stage = false;
-                        }
-                    } else if (!(flags & K7_LAST)) {
-                        // (cannot happen: a step without a probe of its own is the last one or precedes a held probe)
-                        nflags = K7_LAST;
+                        if (spur) spur_until = max(spur_until, prev.t_after + rp.tstar - 1u);
                     }
                     if (lane == 0) {
                         *reinterpret_cast<uint4 *>(&s_mid[0]) = make_uint4(mflags, n_new, seq_base, fam_seq);
-                        if (mflags & K7_STAGE) write_stage();
+                        if (mflags & K7_STAGE)
+                            *reinterpret_cast<uint4 *>(&s_mid[4]) = make_uint4((uint32_t)p_next.st_base, (uint32_t)(p_next.st_base >> 32), p_next.st_tot, p_next.st_buf);
                         s_fam[sp] = fam_seq;
                     }
-                    if (!(flags & K7_LAST)) write_cmd(sp ^ 1u, nflags, nx);
                     K7T_LAP(0);
                     lds_barrier();  // ---- barrier 1 ----------------------------------------------------------
                     K7T_LAP(1);
@@ -815,19 +934,25 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                     mid_actions(mflags);
                     // the stash of the probe after next is the previous probe's: nobody reads it any more
                     if (lane == 0 && have_prev) s_nstash[prev.bb] = 0u;
-                    if (!(flags & K7_LAST) && (nflags & K7_CUR) && !(nflags & K7_LATE))
-                        insert_hits(nx.cnt, nx.off, nx.tb, nx.bb, nx.g10);
+                    const bool more = !(flags & K7_LAST);
+                    // the step after next: planned now, while the arm waves create and offer
+                    Plan p_after{};
+                    p_after.q = no_probe;
+                    if (more && !(p_next.flags & (K7_LAST | K7_GIVEUP))) {
+                        p_after = advance(p_next);
+                        write_cmd(sc == 0u ? 2u : sc - 1u, p_after, p_next);  // (slot of step + 2 = slot of step - 1)
+                    }
                     K7T_LAP(2);
                     lds_barrier();  // ---- barrier 2 ----------------------------------------------------------
                     K7T_LAP(3);
-                    if (flags & K7_LAST) break;
-                    prev = cur;
-                    prev_tb = cur_tb;
-                    prev_ta = cur_ta;
-                    cur = nx;
-                    cur_tb = nx_tb;
-                    cur_ta = nx_ta;
-                    flags = nflags;
+                    if (!more) break;
+                    p_prev = p_cur;
+                    p_cur = p_next;
+                    p_next = p_after;
+                    if (p_cur.flags & K7_GIVEUP) {  // (the arm waves leave when they read it)
+                        overflow = true;
+                        break;
+                    }
                 }
             }
             K7T_FLUSH(0);

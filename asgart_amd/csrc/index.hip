@@ -53,8 +53,11 @@ const OptDesc kOptions[] = {
     {"test_wide_batch", &Options::test_wide_batch, 0, 1ll << 40},
     {"kfilter_bits", &Options::kfilter_bits, 0, 34},
     {"k7", &Options::k7, 0, 127},
+    {"lazy_aux", &Options::lazy_aux, 0, 1},
+    {"dense3", &Options::dense3, 0, 1 << 20},
     {"prewarm", &Options::prewarm, 0, 1},
     {"watchdog_s", &Options::watchdog_s, 0, 86400},
+    {"test_stall_s", &Options::test_stall_s, 0, 60},
     {"tier_streams", &Options::tier_streams, 1111111, 7777777},
     {"cap6_pct", &Options::cap6_pct, 100, 200},
     {"early_cascade", &Options::early_cascade, 0, 1},
@@ -546,6 +549,9 @@ static void free_k_specific(asgart_index *idx) {
     idx->d_ptab = idx->d_c8lo = idx->d_c8hi = nullptr;
     idx->filter_bits = 0;
     idx->k = 0;
+    idx->sap_tried = false;
+    idx->calls_total = 0;
+    for (auto &c : idx->mode_calls) c = 0;
 }
 
 static int choose_depth(int64_t n, uint64_t k, int64_t forced) {
@@ -588,6 +594,45 @@ int32_t text_is_dna(const uint8_t *d_text, int64_t n, hipStream_t s, bool *dna) 
     for (int c = 0; c < 256; ++c)
         if (hist[c] && !valid_text_byte((uint8_t)c)) *dna = false;
     return 0;
+}
+
+// Position-sorted occurrence lists (one key word per probe, whole suffix array, 32-bit positions); the caller holds
+// every call context.  An optimisation only: without the memory for it -- the list or the sort's scratch -- the index
+// does without.
+static int32_t build_sap_locked(asgart_index *idx, uint64_t k) {
+    idx->sap_tried = true;
+    const uint64_t n_sa = (uint64_t)idx->n_sa;
+    if (!(idx->opt.rank_lists && !idx->wide && !idx->trimmed && k <= (uint64_t)kMaxKey && n_sa > 0) || idx->d_sap) return 0;
+    if (dev_malloc(&idx->d_sap, (n_sa + 16) * 4) != hipSuccess) {
+        (void)hipGetLastError();
+        idx->d_sap = nullptr;
+        return 0;
+    }
+    const int32_t rc_rank = build_rank_lists(idx->d_keys, (const uint32_t *)idx->d_sa, n_sa, (uint32_t *)idx->d_sap, idx->ctx[0].stream);
+    if (rc_rank != 0) {
+        dev_free(idx->d_sap);
+        idx->d_sap = nullptr;
+        if (rc_rank != ASGART_E_OOM) return rc_rank;
+    }
+    BlockCache::trim();  // (the sort's scratch)
+    return 0;
+}
+
+// ... for the search path: builds them when the index has none yet and has not tried (keys prepared first)
+int32_t index_prepare_sap(asgart_index *idx, uint64_t k) {
+    RC_TRY(index_prepare(idx, k));
+    {
+        std::lock_guard<std::mutex> lk(idx->mu);
+        if (idx->k == k && (idx->d_sap || idx->sap_tried)) return 0;
+    }
+    idx->acquire_all();
+    struct Unlock {
+        asgart_index *i;
+        ~Unlock() { i->release_all(); }
+    } unlock{idx};
+    if (idx->k != k || idx->d_sap || idx->sap_tried) return 0;
+    HIP_TRY(hipSetDevice(idx->device));
+    return build_sap_locked(idx, k);
 }
 
 int32_t index_prepare(asgart_index *idx, uint64_t k) {
@@ -663,22 +708,12 @@ int32_t index_prepare(asgart_index *idx, uint64_t k) {
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));
     lap("keys + tables");
-    // position-sorted occurrence lists (one key word per probe, whole suffix array, 32-bit positions)
-    if (idx->opt.rank_lists && !idx->wide && !idx->trimmed && k <= (uint64_t)kMaxKey && n_sa > 0) {
-        // (an optimisation only: without the memory for it -- the list or the sort's scratch -- the index does without)
-        if (dev_malloc(&idx->d_sap, (n_sa + 16) * 4) != hipSuccess) {
-            (void)hipGetLastError();
-            idx->d_sap = nullptr;
-        } else {
-            const int32_t rc_rank = build_rank_lists(idx->d_keys, (const uint32_t *)idx->d_sa, n_sa, (uint32_t *)idx->d_sap, s);
-            if (rc_rank != 0) {
-                dev_free(idx->d_sap);
-                idx->d_sap = nullptr;
-                if (rc_rank != ASGART_E_OOM) return rc_rank;
-            }
-        }
+    // position-sorted occurrence lists: at once (option lazy_aux = 0), or by the first search call that has a predecessor
+    idx->sap_tried = false;
+    if (!idx->opt.lazy_aux) {
+        RC_TRY(build_sap_locked(idx, k));
+        lap("position-sorted lists");
     }
-    lap("position-sorted lists");
     // text-tail corner list (host, from the last bytes of the text)
     idx->n_tail8 = 0;
     idx->tail_bloom = 0;
@@ -849,6 +884,8 @@ void asgart_index_destroy(asgart_index *idx) {
         if (cx.h_ctl) (void)hipHostFree(cx.h_ctl);
         cx.h_ctl = nullptr;
         cx.h_ctl_cap = 0;
+        if (cx.h_hb) (void)hipHostFree(cx.h_hb);
+        cx.h_hb = cx.d_hb = nullptr;
         for (auto &e : cx.ev)
             if (e) (void)hipEventDestroy(e);
         for (hipStream_t st : {cx.stream, cx.stream2, cx.stream3, cx.stream4, cx.stream5, cx.stream6, cx.stream7})

@@ -161,6 +161,28 @@ struct SearchCtx {
         *out = h_pinned;
         return 0;
     }
+    // Heartbeats of the persistent extension workgroups (watchdog): a pinned, device-mapped block of kHbTiers x kHbSlots
+    // entries {segment start probe | tier << 32 , position / step counter}; a workgroup stamps its slot when it takes a
+    // segment (and the workgroup kernels again at every batch of probes).  The host reads it while it waits: as long as
+    // it changes, the device is making progress; when a wait outlasts option watchdog_s without any change, the call
+    // returns ASGART_E_HIP with the slots that were in flight.
+    static constexpr int kHbTiers = 8, kHbSlots = 256;
+    unsigned long long *h_hb = nullptr;  // host address
+    unsigned long long *d_hb = nullptr;  // device address of the same block
+    int32_t heartbeat(bool want) {
+        if (!want || h_hb) return 0;
+        void *hp = nullptr, *dp = nullptr;
+        if (hipHostMalloc(&hp, (size_t)kHbTiers * kHbSlots * 16, hipHostMallocMapped) != hipSuccess ||
+            hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            if (hp) (void)hipHostFree(hp);
+            return 0;  // (diagnostics only: the call goes on without)
+        }
+        memset(hp, 0, (size_t)kHbTiers * kHbSlots * 16);
+        h_hb = static_cast<unsigned long long *>(hp);
+        d_hb = static_cast<unsigned long long *>(dp);
+        return 0;
+    }
     // pinned control block: the counters read back several times per call, then the chunk table.  Transfers
     // to and from pageable memory go through a staging copy KERNEL, which needs a free CU -- with another
     // call's persistent extension workgroups on the chip that wait was 20-30 ms per copy.
@@ -229,10 +251,18 @@ struct Options {
                                     // cfg4, 8 shards: balanced (91-117 ms direct) but the replicated front makes its slowest shard
                                     // slower than the slice mode's (211 vs 184 ms -RC, 117 vs 90 ms direct): the floor is the longest segment
     int64_t tier_streams = 7234562; // digit t (from the left): the stream (1..7, 1 = the call's high-priority main stream) tier t runs on
-    int64_t k7 = 0;                 // bit t set (t = 3..6): tier t runs the arm kernel with a control wave (extend_k7_dev.hpp); takes precedence over `fast`
+    int64_t k7 = 8;                 // bit t set (t = 3..6): tier t runs the arm kernel with a control wave (extend_k7_dev.hpp) instead of K6 / K4c. Default: tier 3 only -- the long DENSE segments (option dense3), where its shorter per-probe chain counts; measured in the other tiers (k7 = 120) it loses: a quarter / an eighth of a 256- / 512-thread workgroup holds no arms and a sparse probe costs two barriers instead of one wave's solo run
+    int64_t lazy_aux = 1;           // 1: the presence filter of an orientation is built when that orientation is searched the SECOND time, the
+                                    // position-sorted lists when a search call has had a predecessor: they cost 0.18 s per orientation / 0.2 s
+                                    // at GRCh38 size and save 0.03 / 0.006 s per pass -- a host that runs every orientation once per index
+                                    // (the reference's own use, src/bin/asgart.rs:677-693) never pays for them; 0: filters on first use,
+                                    // lists with the keys
+    int64_t dense3 = 16;            // with k7 in tier 3: long segments go there only with at least this many hits per processed probe on
+                                    // average (0: all of them); the sparse long ones run on tier 6's kernel
     int64_t prewarm = 1;            // 1: asgart_index_prepare also reserves the per-probe workspace of both call contexts (sized for an
                                     // unsharded call over the whole text) and starts the worker thread of the passes call, so that the first
                                     // search calls allocate nothing chip-sized; 0: everything on first use (hosts that only issue sharded calls)
+    int64_t test_stall_s = 0;       // tests: every search call first stalls its stream for this many seconds (exercises the watchdog)
     int64_t watchdog_s = 120;       // a search call whose device work makes no progress for this many seconds returns ASGART_E_HIP with the
                                     // last heartbeats of its kernels instead of waiting forever; 0: wait forever
 };
@@ -317,7 +347,12 @@ struct asgart_index {
     int n_tail8 = 0;
     uint64_t tail_bloom = 0;
     std::vector<uint8_t> h_tail;  // last kMaxK + 32 bytes of the text (host copy)
+    bool sap_tried = false;        // the position-sorted lists were built or given up on for this probe size
+    uint64_t calls_total = 0;      // finished search calls with the current keys ...
+    uint64_t mode_calls[4] = {0, 0, 0, 0};  // ... and started ones per orientation (option lazy_aux)
     double ms_prepare = 0.0;
+    std::atomic<bool> poisoned{false};  // a call gave up waiting for the device (watchdog): work may still be running on the
+                                        // index's streams and buffers, every later call is refused
     double tail_ms[4] = {-1.0, -1.0, -1.0, -1.0};  // per orientation (reverse * 2 + complement): shortest extension time of an unsharded call so far
     asgart::Options opt;
     asgart::SearchCtx ctx[asgart::kNumCtx];
@@ -407,6 +442,7 @@ int32_t index_prepare(asgart_index *idx, uint64_t k);
 // per-probe workspace of one call context for a window of W probes (pipeline.hip; also what run_search_t reserves)
 int32_t reserve_probe_workspace(asgart_index *idx, SearchCtx &cx, uint64_t W);
 int32_t index_prepare_filter(asgart_index *idx, uint64_t k, int mode);  // mode = reverse * 2 + complement
+int32_t index_prepare_sap(asgart_index *idx, uint64_t k);
 int32_t run_search(asgart_index *idx, const uint64_t *chunks, int64_t n_chunks,
                    const asgart_settings *st, int32_t shard, int32_t n_shards, bool want_csr,
                    asgart_families *fam_out, std::vector<uint8_t> *status_out,

@@ -99,10 +99,79 @@ static inline unsigned grid_for(uint64_t n, unsigned block = 256) {
     return (unsigned)((n + block - 1) / block);
 }
 
+// Test hook (option test_stall_s): a kernel that does nothing for that many seconds on the call's main stream, so
+// that the watchdog's way out of a stuck device can be exercised (wall_clock64 ticks at 100 MHz).
+__global__ void stall_kernel(unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(100);
+}
+
 static uint32_t probes_in_chunk(uint64_t L, uint64_t k, uint64_t step, uint64_t M) {
     // loop of src/automaton.rs:92-97: `while i < L - k - step { i += step; ... }`
     if (L < M || L < k + step || L - k - step == 0) return 0;
     return (uint32_t)((L - k - step + step - 1) / step);
+}
+
+// Waits for everything queued on stream `st`.  With option watchdog_s > 0 the wait polls: while the heartbeat block of
+// the call's extension workgroups keeps changing the device is making progress, however long it takes; a wait that
+// outlasts watchdog_s seconds without any change gives up: the call returns ASGART_E_HIP naming the phase and the
+// workgroups that were in flight, and the index refuses further calls (its streams may still hold the stuck work) --
+// the host should report and exit, or go on in a fresh process.  (One GPU test run of round 3 sat in a call for 40
+// minutes with nothing to tell where.)
+static int32_t wd_sync(asgart_index *idx, SearchCtx &cx, hipStream_t st, const char *phase) {
+    const int64_t limit_s = idx->opt.watchdog_s;
+    if (limit_s <= 0) {
+        HIP_TRY(hipStreamSynchronize(st));
+        return 0;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    auto t_change = t0;
+    unsigned long long sig = 0;
+    auto signature = [&]() {
+        unsigned long long h = 1469598103934665603ull;
+        if (cx.h_hb) {
+            const volatile unsigned long long *p = cx.h_hb;
+            for (int i = 0; i < SearchCtx::kHbTiers * SearchCtx::kHbSlots * 2; ++i) h = (h ^ p[i]) * 1099511628211ull;
+        }
+        return h;
+    };
+    for (unsigned spins = 0;; ++spins) {
+        const hipError_t q = hipStreamQuery(st);
+        if (q == hipSuccess) return 0;
+        if (q != hipErrorNotReady) HIP_TRY(q);
+        (void)hipGetLastError();
+        if (spins < 64) continue;                    // (short waits: no sleep at all)
+        std::this_thread::sleep_for(std::chrono::microseconds(spins < 2000 ? 20 : 500));
+        if ((spins & 1023u) == 0) {
+            const auto now = std::chrono::steady_clock::now();
+            const unsigned long long s2 = signature();
+            if (s2 != sig) {
+                sig = s2;
+                t_change = now;
+            }
+            if (std::chrono::duration<double>(now - t_change).count() > (double)limit_s) {
+                std::string who;
+                if (cx.h_hb) {
+                    int shown = 0;
+                    for (int t = 0; t < SearchCtx::kHbTiers && shown < 12; ++t)
+                        for (int w = 0; w < SearchCtx::kHbSlots && shown < 12; ++w) {
+                            const unsigned long long a = cx.h_hb[2 * (t * SearchCtx::kHbSlots + w)], b = cx.h_hb[2 * (t * SearchCtx::kHbSlots + w) + 1];
+                            if (!(a >> 63)) continue;
+                            char buf[96];
+                            snprintf(buf, sizeof buf, "%s tier %d wg %d: segment at probe %llu, position %llu", shown ? ";" : "", t, w,
+                                     a & 0xFFFFFFFFull, b);
+                            who += buf;
+                            ++shown;
+                        }
+                }
+                idx->poisoned.store(true);
+                set_error("watchdog: no progress for %lld s while waiting for %s (%.1f s into the wait); last heartbeats:%s -- the index is "
+                          "unusable from here on (option watchdog_s = 0 waits forever)", (long long)limit_s, phase,
+                          std::chrono::duration<double>(now - t0).count(), who.empty() ? " none" : who.c_str());
+                return ASGART_E_HIP;
+            }
+        }
+    }
 }
 
 int32_t reserve_probe_workspace(asgart_index *idx, SearchCtx &cx, uint64_t W) {
@@ -269,6 +338,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
     uint32_t *rank_list = w.rank_list.as<uint32_t>();
     uint32_t *seg_list = w.seg_list.as<uint32_t>();
 
+    if (opt.test_stall_s > 0) stall_kernel<<<1, 64, 0, s>>>((unsigned long long)opt.test_stall_s * 100000000ull);
     // ---- K1: probe search + filtered counts -----------------------------------
     HIP_TRY(hipEventRecord(cx.ev[0], s));
     probe_count_kernel<SlotT, false><<<grid_for(W, kProbeBlock), kProbeBlock, 0, s>>>(
@@ -289,7 +359,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
     HIP_TRY(hipEventRecord(cx.ev[2], s));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, kCtrBytes, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    RC_TRY(wd_sync(idx, cx, s, "the probe search and the scans"));
     total_hits = h_ctr[CT_TOTAL_HITS];
     n_seg = h_ctr[CT_SEG];
     if (cx.progress && opt.progress_at < 2 && !progress_given && !h_ctr[CT_AMBIG]) signal_progress();
@@ -404,12 +474,16 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
         }
         auto tier_enabled = [&](int t) { return t >= 1 && t <= kTiers && tier_cap[t] != 0; };
         PlaceParams pp;
-        pp.long3 = pp.long3_big = 0;
+        pp.long3 = pp.long3_big = pp.dense3 = 0;
         for (int t = 1; t < kTiers; ++t) pp.cap[t - 1] = tier_cap[t];
         if (arms_kernel) {
             pp.long3 = (uint32_t)opt.long3;
             pp.long3_big = opt.long3_big >= 0 ? (uint32_t)opt.long3_big : pp.long3 / 4u;
-            if (force_tier == 3) pp.long3 = pp.long3_big = 1;
+            if (k7_tier(3) && tier_cap[6]) pp.dense3 = (uint32_t)opt.dense3;
+            if (force_tier == 3) {
+                pp.long3 = pp.long3_big = 1;
+                pp.dense3 = 0;
+            }
             pp.cap[0] = (uint32_t)std::min<int64_t>(opt.cap1, kArmCapSmall);
         }
         int force_eff = force_tier;  // a forced tier that has no kernel in this mode: the next one that has
@@ -447,7 +521,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
         tier_bounds_kernel<<<1, 64, 0, s>>>(sorted_keys, d_ctr + CT_SEG, d_ctr);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, kCtrBytes, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        RC_TRY(wd_sync(idx, cx, s, "the hit rows and the placement of the segments"));
         uint64_t n_t[kTiers], seg_off[kTiers + 1] = {0};
         for (int t = 0; t < kTiers; ++t) {
             n_t[t] = h_ctr[CT_N1 + t];
@@ -545,6 +619,9 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             ep.n_levels = (uint32_t)opt.test_levels;
             ep.gen_bits = (uint32_t)opt.test_genbits;
             ep.ctr = d_ctr;
+            ep.hb = nullptr;
+            RC_TRY(cx.heartbeat(opt.watchdog_s > 0));
+            if (cx.h_hb) memset(cx.h_hb, 0, (size_t)SearchCtx::kHbTiers * SearchCtx::kHbSlots * 16);
             // The tiers are launched together on separate streams, each with a grid that can fill
             // the chip on its own (persistent workgroups, longest segment first): the hardware
             // back-fills CUs as workgroups retire, so the tails of one tier overlap the next.
@@ -578,6 +655,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                 const bool retiring = !cascade_launch && (tier == 1 || (arms_kernel && tier >= 2 && tier <= 5));
                 const uint64_t items_wg = retiring ? (uint64_t)(tier <= 2 ? opt.wg_items12 : opt.wg_items) : 0;
                 ep.max_items = (uint32_t)items_wg;
+                ep.hb = cx.d_hb ? cx.d_hb + (size_t)2 * SearchCtx::kHbSlots * (size_t)(tier & 7) : nullptr;
                 auto grid = [&](uint64_t dflt) -> unsigned {
                     uint64_t g = dflt;
                     if (opt.grid[tier] > 0) g = tier >= 3 ? std::min<uint64_t>(dflt, (uint64_t)opt.grid[tier]) : (uint64_t)opt.grid[tier];
@@ -708,6 +786,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                     bool pending;
                 } early[2] = {{3, 0, cx.ev[6], st3, false}, {6, 0, cx.ev[10], st6, false}};
                 int n_pending = 0;
+                unsigned early_polls = 0;
                 for (int e = 0; e < 2; ++e) {
                     Early &E = early[e];
                     int dst = E.src + 1;
@@ -765,7 +844,20 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                         HIP_TRY(hipGetLastError());
                         HIP_TRY(hipEventRecord(E.ev, E.st));
                     }
-                    if (n_pending && !progressed) std::this_thread::sleep_for(std::chrono::microseconds(50));
+                    if (n_pending && !progressed) {
+                        std::this_thread::sleep_for(std::chrono::microseconds(50));
+                        // (the same watchdog as every other wait of the call: here the wait is for tier 3 / tier 6)
+                        if ((++early_polls & 0x3FFFu) == 0) {
+                            for (int e = 0; e < 2; ++e)
+                                if (early[e].pending) {
+                                    const hipError_t q2 = hipEventQuery(early[e].ev);
+                                    if (q2 == hipErrorNotReady) {
+                                        (void)hipGetLastError();
+                                        RC_TRY(wd_sync(idx, cx, early[e].st, e == 0 ? "extension tier 3" : "extension tier 6"));
+                                    }
+                                }
+                        }
+                    }
                 }
             }
             HIP_TRY(hipStreamWaitEvent(s, cx.ev[5], 0));
@@ -775,7 +867,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             HIP_TRY(hipStreamWaitEvent(s, cx.ev[10], 0));
             HIP_TRY(hipStreamWaitEvent(s, cx.ev[12], 0));
             HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, kCtrBytes, hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
+            RC_TRY(wd_sync(idx, cx, s, "the extension tiers"));
             PROF_DUMP("concurrent tiers");
             if (opt.debug) fprintf(stderr, "[asgart] all tiers and early re-runs done %.1f ms after the launches\n", since_launch());
             {   // the tier that ran longest (its early re-run included): the serial floor of this call's extension
@@ -821,7 +913,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                 launch_kernel(dst, n_ovf, s);
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, kCtrBytes, hipMemcpyDeviceToHost, s));
-                HIP_TRY(hipStreamSynchronize(s));
+                RC_TRY(wd_sync(idx, cx, s, "a re-run of overflowed segments"));
                 PROF_DUMP("cascade");
             }
             ms_tier2 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() -
@@ -861,7 +953,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             HIP_TRY(hipMemcpyAsync(const_cast<SdRec *>(h_recs), w.rec_sorted.p, (size_t)n_rec * sizeof(SdRec),
                                    hipMemcpyDeviceToHost, s));
         }
-        HIP_TRY(hipStreamSynchronize(s));
+        RC_TRY(wd_sync(idx, cx, s, "the ordering of the records"));
         fam_out->sds.reserve(n_hrec);
         for (size_t f0 = 0; f0 < n_hrec;) {
             if (h_recs[f0].g_start == kVoidStart) break;  // unused slots of the waves' record chunks: sorted last
@@ -938,18 +1030,37 @@ int32_t run_search(asgart_index *idx, const uint64_t *chunks, int64_t n_chunks,
         set_error("bad shard %d of %d", shard, n_shards);
         return ASGART_E_ARG;
     }
+    if (idx->poisoned.load()) {
+        set_error("this index gave up waiting for the device in an earlier call (watchdog): work may still be running on its "
+                  "streams; destroy it and continue in a fresh process");
+        return ASGART_E_HIP;
+    }
     HIP_TRY(hipSetDevice(idx->device));
     // take a free per-call context; the keys can only change while no context is in use
     int which = 0;
+    const int mode = (st->reverse ? 2 : 0) | (st->complement ? 1 : 0);
     for (;;) {
         SearchCtx &probe = idx->acquire_one(&which);
         (void)probe;
-        const int mode = (st->reverse ? 2 : 0) | (st->complement ? 1 : 0);
-        if (idx->k == st->probe_size && (idx->opt.kfilter_bits == 0 || idx->trimmed || idx->d_filter[mode] ||
-                                         idx->filter_off[mode] || st->probe_size > (uint64_t)kMaxKey))
-            break;
+        // The presence filter and the position-sorted lists are optimisations that cost more than they save in ONE pass
+        // (option lazy_aux): an orientation gets its filter at its second search, the index its lists at its second call.
+        bool want_filter, want_sap, ready;
+        {
+            std::lock_guard<std::mutex> lk(idx->mu);
+            ready = idx->k == st->probe_size;
+            const bool lazy = idx->opt.lazy_aux != 0;
+            want_filter = !(idx->opt.kfilter_bits == 0 || idx->trimmed || st->probe_size > (uint64_t)kMaxKey) &&
+                          !(lazy && ready && idx->mode_calls[mode] == 0) && !(lazy && !ready);
+            want_sap = !(lazy && (!ready || idx->calls_total == 0)) && !idx->sap_tried;
+            if (ready && (!want_filter || idx->d_filter[mode] || idx->filter_off[mode]) && !(want_sap && !idx->d_sap)) {
+                ++idx->mode_calls[mode];
+                break;
+            }
+        }
         idx->release_one(which);
-        RC_TRY(index_prepare_filter(idx, st->probe_size, mode));
+        if (!ready) RC_TRY(index_prepare(idx, st->probe_size));
+        else if (want_sap && !idx->d_sap) RC_TRY(index_prepare_sap(idx, st->probe_size));
+        else RC_TRY(index_prepare_filter(idx, st->probe_size, mode));
     }
     SearchCtx &cx = idx->ctx[which];
     cx.progress = progress;
@@ -961,6 +1072,10 @@ int32_t run_search(asgart_index *idx, const uint64_t *chunks, int64_t n_chunks,
         rc = run_search_t<uint32_t>(idx, cx, chunks, n_chunks, st, shard, n_shards, want_csr, fam_out,
                                     status_out, rowoff_out, hits_out);
     cx.progress = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(idx->mu);
+        ++idx->calls_total;
+    }
     if (rc == 0 && fam_out && n_shards == 1) {
         // what asgart_search_duplications_passes orders by: the shortest extension seen for the orientation (a call
         // that shared the chip with another one measures longer, and the order must not flip because of that)

@@ -1024,7 +1024,18 @@ struct ExtParams {
     uint32_t heavy_cap;                   // K4b MODE 2 (tier 7): arm slots per workgroup in its HBM slice
     uint32_t solo_hits;                   // K6: probes with up to this many hits may run on wave 0 alone (0: never)
     unsigned long long *ctr;
+    unsigned long long *hb;               // heartbeat slots of this launch's tier (pinned host memory; null: none)
 };
+
+// a workgroup's sign of life (see SearchCtx::heartbeat): which segment it is on and how far
+template <class PosT>
+__device__ inline void heartbeat(const ExtParams<PosT> &P, uint32_t g0, uint32_t at) {
+    if (P.hb) {
+        unsigned long long *slot = P.hb + 2u * (blockIdx.x % 256u);
+        __builtin_nontemporal_store((unsigned long long)g0 | 1ull << 63, slot);
+        __builtin_nontemporal_store((unsigned long long)at, slot + 1);
+    }
+}
 
 // The whole predicate of try_extend_arms (src/automaton.rs:68-70) for an active arm with right
 // segment [rs, re], threshold thr, and a hit m = [x, x+k]:
@@ -1131,6 +1142,7 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
         if (seg >= n_seg) continue;
         const uint32_t g0 = P.seg_list[seg];
         PROF_SEG_BEGIN();
+        if (lane == 0 && j == 0) heartbeat(P, g0, 0u);  // (once per fetched group of segments)
         const int c = chunk_of_uniform(rp.ch, g0);
         const uint64_t cs = rp.ch.start[c], cl = rp.ch.len[c];
         const uint32_t pb = rp.ch.pbase[c];
@@ -1567,6 +1579,10 @@ struct PlaceParams {
     int use_filter;             // 0: flag every hit (k >= M, huge gaps or cardinalities)
     uint32_t long3;             // > 0: tier 3 is reserved for segments of at least this many probes
     uint32_t long3_big;         // ... or this many, for segments beyond tier 5's capacity
+    uint32_t dense3;            // > 0: ... and only the DENSE ones (at least this many hits per processed probe on average:
+                                // tandem arrays); the sparse long ones (a chromosome against its homologue: a few hits per
+                                // probe, mostly run by one wave alone) go to tier 6's kernel -- set when tier 3 runs the
+                                // kernel with a control wave, whose step costs the same whatever the probe holds
 };
 
 // Sort key of a segment inside its tier (ascending = launch order).  Heavy tiers: longest first,
@@ -1593,8 +1609,10 @@ __device__ inline int place_tier(uint32_t bound, unsigned long long sum, uint32_
     // tier 6 pays ~3x tier 3's time per probe (many arms per thread): its segments count as long
     // from a quarter of the threshold on
     if (pp.long3 && bound <= pp.cap[2] &&
-        (n_probes >= pp.long3 || (bound > pp.cap[4] && n_probes >= pp.long3_big)))
-        return 3;
+        (n_probes >= pp.long3 || (bound > pp.cap[4] && n_probes >= pp.long3_big))) {
+        if (!pp.dense3 || sum >= (unsigned long long)pp.dense3 * n_probes || bound > pp.cap[5]) return 3;
+        return 6;
+    }
     for (int t = 2; t < kTiers; ++t) {
         if (t == 3 && pp.long3) continue;
         if (bound <= pp.cap[t - 1]) return t;
@@ -2067,6 +2085,7 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
         __syncthreads();
         if (seg >= n_seg) break;
         const uint32_t g0 = P.seg_list[seg];
+        if (tid == 0) heartbeat(P, g0, 0u);
         PROF_SEG_BEGIN();
         const int c = chunk_of_uniform(rp.ch, g0);
         const uint64_t cs = rp.ch.start[c], cl = rp.ch.len[c];
@@ -2201,6 +2220,7 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
             // ---- stage a batch of up to 64 probes (every wave computes the same masks) ----
             PROF_START();
             const uint32_t nb = min(64u, g_end - g);
+            if (tid == 0) heartbeat(P, g0, g);
             const uint32_t f_l = (uint32_t)lane < nb ? P.p_filt[g + lane] : kSkipN;
             const uint32_t nfl_l = (uint32_t)lane < nb ? P.p_nflag[g + lane] : 0u;
             const unsigned long long r_l = (uint32_t)lane < nb ? P.row_off[g + lane] : 0ull;
@@ -2578,6 +2598,7 @@ __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
         lds_barrier();
         if (seg >= n_seg) break;
         const uint32_t g0 = P.seg_list[seg];
+        if (tid == 0) heartbeat(P, g0, 0u);
         PROF_SEG_BEGIN();
         const int c = chunk_of_uniform(rp.ch, g0);
         const uint64_t cs = rp.ch.start[c], cl = rp.ch.len[c];
@@ -2748,6 +2769,7 @@ __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
             // ---- stage a batch of up to 64 probes (every wave computes the same masks) ----
             PROF_START();
             const uint32_t nb = min(64u, g_end - g);
+            if (tid == 0) heartbeat(P, g0, g);
             const uint32_t f_l = (uint32_t)lane < nb ? P.p_filt[g + lane] : kSkipN;
             const uint32_t nfl_l = (uint32_t)lane < nb ? P.p_nflag[g + lane] : 0u;
             const unsigned long long r_l = (uint32_t)lane < nb ? P.row_off[g + lane] : 0ull;

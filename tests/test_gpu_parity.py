@@ -1,5 +1,6 @@
 """GPU parity tests: the HIP path (through the C ABI) must be bit-exact against the
 CPU oracle on the same seeded inputs.  Run with `pytest -m gpu` on an MI355X."""
+import time
 import numpy as np
 import pytest
 
@@ -1107,3 +1108,84 @@ def test_out_of_memory_paths_release_what_they_hold(hiplib):
             idx.set_option("test_fail_alloc", -1)
     assert after[1] - after[2] <= (1 << 20), [a - after[0] for a in after]
     assert refused > 0 and done > 0, (done, refused)
+
+
+def test_watchdog_gives_up_on_a_stalled_device_and_names_the_phase(hiplib):
+    """Option test_stall_s parks a kernel that does nothing on the call's stream; with watchdog_s below it the call
+    must come back with ASGART_E_HIP, say what it waited for, and the index must refuse further calls (its stream still
+    holds the stuck work) -- instead of sitting in the call for as long as the device takes."""
+    pr, cli = _battery_case("dense_repeats")
+    st = asgart_amd.RunSettings.from_cli(**cli)
+    with asgart_amd.Index(pr.data, None) as idx:
+        ref = idx.search_duplications_raw(pr.chunks, st)
+        idx.set_option("watchdog_s", 1)
+        idx.set_option("test_stall_s", 4)
+        t0 = time.time()
+        with pytest.raises(asgart_amd.AsgartError) as e:
+            idx.search_duplications_raw(pr.chunks, st)
+        assert e.value.code == -3 and "watchdog" in str(e.value) and "probe search" in str(e.value)
+        assert time.time() - t0 < 3.5
+        idx.set_option("test_stall_s", 0)
+        with pytest.raises(asgart_amd.AsgartError) as e2:
+            idx.search_duplications_raw(pr.chunks, st)
+        assert "fresh process" in str(e2.value)
+        time.sleep(3.0)   # (the parked kernel ends by itself; the index is closed behind it)
+    # a long wait with a patient watchdog is not an error: the same stall, the default limit
+    with asgart_amd.Index(pr.data, None) as idx:
+        idx.set_option("test_stall_s", 2)
+        got = idx.search_duplications_raw(pr.chunks, st)
+        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+
+
+def test_block_cache_is_trimmed_and_filter_can_be_switched_off(hiplib):
+    """(advisor, round 3) The blocks the library keeps for reuse go back to the device when the last index closes and on
+    asgart_trim_cache; option kfilter_bits = 0 really searches without the presence filter (its position bitmaps used
+    to survive and go on filtering) and switching it back on rebuilds both without leaking the old bitmap."""
+    import torch
+
+    pr, cli = _battery_case("dense_repeats")
+    oidx = oracle.Index.build(pr.data)
+    st = asgart_amd.RunSettings.from_cli(reverse=True, complement=True, **cli)
+    exp = oidx.run_raw(pr.chunks, oracle.make_settings(reverse=True, complement=True, **cli))
+
+    def free_bytes():
+        torch.cuda.synchronize()
+        return torch.cuda.mem_get_info()[0]
+
+    with asgart_amd.Index(pr.data, oidx.sa) as idx:
+        a = idx.search_duplications_raw(pr.chunks, st)
+        rej_on = idx.stats(1).probes_filter_rejected
+        idx.set_option("kfilter_bits", 0)
+        b = idx.search_duplications_raw(pr.chunks, st)
+        rej_off = idx.stats(1).probes_filter_rejected
+        idx.set_option("kfilter_bits", 30)
+        f0 = None
+        for _ in range(4):   # (rebuilding the filter again and again must not grow the footprint)
+            idx.set_option("kfilter_bits", 0)
+            idx.set_option("kfilter_bits", 30)
+            c = idx.search_duplications_raw(pr.chunks, st)
+            f1 = free_bytes()
+            assert f0 is None or f1 >= f0 - (1 << 20), (f0, f1)
+            f0 = f1
+        for got in (a, b, c):
+            assert np.array_equal(got[0], exp[0]) and np.array_equal(got[1], exp[1])
+        assert rej_on > 0 and rej_off == 0
+    assert asgart_amd.trim_cache(0) >= 0
+    assert asgart_amd.trim_cache(0) == 0   # nothing left to give back
+
+
+def test_replica_from_device_buffers_matches(hiplib):
+    """asgart_index_export + asgart_index_create_device: a second index built from the first one's device buffers
+    (what a one-process-per-GPU host does with the broadcast text and suffix array) gives the same families."""
+    pr, cli = _battery_case("dense_repeats")
+    st = asgart_amd.RunSettings.from_cli(**cli)
+    with asgart_amd.Index(pr.data, None) as idx:
+        ref = idx.search_duplications_raw(pr.chunks, st)
+        t_ptr, sa_ptr, width = idx.export()
+        assert width == 4 and t_ptr and sa_ptr
+        with asgart_amd.Index.from_device(t_ptr, len(pr.data), sa_ptr, width) as rep:
+            got = rep.search_duplications_raw(pr.chunks, st)
+            assert rep.check_sa() == 0
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+    with pytest.raises(asgart_amd.AsgartError):
+        asgart_amd.Index.from_device(t_ptr, len(pr.data), sa_ptr, 8)   # wrong entry width for this text

@@ -153,3 +153,29 @@ def test_gather_families_rccl_backend():
     p.join(300)
     assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+@pytest.mark.gpu
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it starts two ranks itself (fresh interpreters, before any
+    GPU call in the parent), replicates the index by broadcast, and reports n_gpus = the ranks the process group saw.
+    On a one-GPU box both ranks share device 0 over gloo (ASGART_BENCH_ONE_DEVICE)."""
+    import json
+    import subprocess
+
+    env = dict(os.environ, ASGART_BENCH_ONE_DEVICE="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "tiny", "--steps", "2",
+                          "--warmup", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and len(line["per_rank_ms"]) == 2
+    assert line["config"]["ranks_launched_by"] == "self" and line["config"]["collective_backend"] == "gloo"
+    assert line["index_build_s"]["broadcast_to_ranks"] > 0 and line["cold_s"] > 0 and line["model_ms"] > 0
+    # the same workload on one rank: same work, same results size
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "tiny", "--steps", "2",
+                          "--warmup", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    l1 = json.loads(one.stdout.strip().splitlines()[-1])
+    assert l1["n_gpus"] == 1 and l1["config"]["bp_per_pass"] == line["config"]["bp_per_pass"]
