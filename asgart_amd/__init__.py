@@ -36,7 +36,7 @@ ABI_SYMBOLS = (
     "asgart_index_check_sa", "asgart_index_create_trim", "asgart_index_clone",
     "asgart_search_duplications_multi", "asgart_search_duplications_ex", "asgart_search_duplications_passes",
     "asgart_search_duplications_passes_shard", "asgart_families_keys",
-    "asgart_index_export", "asgart_index_create_device", "asgart_trim_cache",
+    "asgart_index_export", "asgart_index_create_device", "asgart_trim_cache", "asgart_post_process",
 )
 
 
@@ -124,6 +124,8 @@ def load_library() -> C.CDLL:
     L.asgart_index_create_device.restype = C.c_int32
     L.asgart_trim_cache.argtypes = [C.c_int32]
     L.asgart_trim_cache.restype = C.c_int64
+    L.asgart_post_process.argtypes = [vp, vp, C.c_uint64, vp, C.c_int32, C.POINTER(vp)]
+    L.asgart_post_process.restype = C.c_int32
     L.asgart_search_duplications_multi.argtypes = [C.POINTER(vp), C.c_int32, vp, C.c_int64, C.POINTER(_Settings), vp,
                                                    C.POINTER(vp)]
     L.asgart_search_duplications_multi.restype = C.c_int32
@@ -353,6 +355,25 @@ class Index:
         _check(load_library().asgart_compute_scores(self._h, _ptr(sds), len(sds), int(reversed_),
                                                     int(complemented), _ptr(out)))
         return out
+
+    def post_process(self, offs: np.ndarray, sds: np.ndarray, threads: int = 0) -> Tuple[np.ndarray, np.ndarray]:
+        """FilterNs -> ReOrder -> ReduceOverlap -> Sort (reference src/bin/asgart.rs:738-747) on raw family arrays as
+        search_duplications_raw returns them -> the same form (asgart_post_process: N counts on the GPU, the reduction
+        on host threads)."""
+        L = load_library()
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        sds = np.ascontiguousarray(sds, dtype=np.uint64).reshape(-1, 4)
+        h = C.c_void_p()
+        _check(L.asgart_post_process(self._h, _ptr(offs), len(offs) - 1, _ptr(sds), threads, C.byref(h)))
+        try:
+            nf, ns = C.c_uint64(), C.c_uint64()
+            L.asgart_families_counts(h, C.byref(nf), C.byref(ns))
+            o = np.zeros(nf.value + 1, dtype=np.uint64)
+            d = np.zeros((ns.value, 4), dtype=np.uint64)
+            L.asgart_families_copy(h, _ptr(o), _ptr(d))
+        finally:
+            L.asgart_families_free(h)
+        return o, d
 
     def stats(self, flags: int = 0) -> Stats:
         st = Stats()

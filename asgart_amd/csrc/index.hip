@@ -63,6 +63,7 @@ const OptDesc kOptions[] = {
     {"early_cascade", &Options::early_cascade, 0, 1},
     {"progress_at", &Options::progress_at, 0, 2},
     {"rank_lists", &Options::rank_lists, 0, 1},
+    {"rank_runs", &Options::rank_runs, 0, 1},
     {"wg_items", &Options::wg_items, 0, 1 << 30},
     {"wg_items12", &Options::wg_items12, 0, 1 << 30},
     {"fast", &Options::fast, 0, 255},
@@ -602,13 +603,20 @@ int32_t text_is_dna(const uint8_t *d_text, int64_t n, hipStream_t s, bool *dna) 
 static int32_t build_sap_locked(asgart_index *idx, uint64_t k) {
     idx->sap_tried = true;
     const uint64_t n_sa = (uint64_t)idx->n_sa;
-    if (!(idx->opt.rank_lists && !idx->wide && !idx->trimmed && k <= (uint64_t)kMaxKey && n_sa > 0) || idx->d_sap) return 0;
-    if (dev_malloc(&idx->d_sap, (n_sa + 16) * 4) != hipSuccess) {
+    const bool runs = idx->opt.rank_runs != 0;
+    if (!(idx->opt.rank_lists && (runs || !idx->wide) && !idx->trimmed && k <= (uint64_t)kMaxKey && n_sa > 0) || idx->d_sap) return 0;
+    const size_t slot = idx->wide ? 8 : 4;
+    if (dev_malloc(&idx->d_sap, (n_sa + 16) * slot) != hipSuccess) {
         (void)hipGetLastError();
         idx->d_sap = nullptr;
         return 0;
     }
-    const int32_t rc_rank = build_rank_lists(idx->d_keys, (const uint32_t *)idx->d_sa, n_sa, (uint32_t *)idx->d_sap, idx->ctx[0].stream);
+    hipStream_t s = idx->ctx[0].stream;
+    // (kRankMin of pipeline_dev.hpp: rank_count_kernel only consults the list of an interval of more than 256 entries)
+    const int32_t rc_rank =
+        !runs ? build_rank_lists(idx->d_keys, (const uint32_t *)idx->d_sa, n_sa, (uint32_t *)idx->d_sap, s)
+              : (idx->wide ? build_rank_lists_runs<uint64_t>(idx->d_keys, (const uint64_t *)idx->d_sa, n_sa, (uint64_t *)idx->d_sap, 256u, (int)k, s)
+                           : build_rank_lists_runs<uint32_t>(idx->d_keys, (const uint32_t *)idx->d_sa, n_sa, (uint32_t *)idx->d_sap, 256u, (int)k, s));
     if (rc_rank != 0) {
         dev_free(idx->d_sap);
         idx->d_sap = nullptr;

@@ -233,7 +233,10 @@ struct Options {
     int64_t kfilter_bits = 30;      // log2(bits) of the k-mer presence filter (search_dev.hpp); 0: no filter
     int64_t wg_items = 0;           // segments a workgroup of tiers 3..7 runs before it retires (0: persistent)
     int64_t wg_items12 = 0;         // ... work-list fetches (8 segments / 1 segment) of a tier-1 / tier-2 wave
-    int64_t rank_lists = 1;         // 1: position-sorted occurrence lists for the cardinality test (32-bit indexes, k <= 21)
+    int64_t rank_lists = 1;         // 1: position-sorted occurrence lists for the cardinality test (k <= 21, no --trim)
+    int64_t rank_runs = 1;          // how they are built: 1 = only the runs of more than 256 equal keys, by a segmented sort in place
+                                    // (any slot width); 0 = all slots by two device-wide pair sorts (32-bit slots only: without it an
+                                    // index of 64-bit slots has no lists)
     int64_t progress_at = 2;        // when a call reports its probes as searched (pipeline.hip: progress)
     int64_t early_cascade = 1;      // 1: tier 6's overflow is re-run as soon as tier 6 is done, not after the last tier
     int64_t cap6_pct = 140;         // tier 6 accepts segments whose arm bound is up to this percentage of its capacity
@@ -267,7 +270,10 @@ struct Options {
                                     // last heartbeats of its kernels instead of waiting forever; 0: wait forever
 };
 int32_t create_ctx_streams(SearchCtx &cx);
-int32_t build_rank_lists(const uint64_t *d_keys, const uint32_t *d_sa, uint64_t n, uint32_t *d_sap, hipStream_t s);  // the streams and events of one call context (current device)
+int32_t build_rank_lists(const uint64_t *d_keys, const uint32_t *d_sa, uint64_t n, uint32_t *d_sap, hipStream_t s);
+template <class SlotT>
+int32_t build_rank_lists_runs(const uint64_t *d_keys, const SlotT *d_sa, uint64_t n, SlotT *d_sap, uint32_t min_run, int k,
+                              hipStream_t s);  // (sa_build.hip: only the runs of more than min_run equal keys; any slot width)  // the streams and events of one call context (current device)
 int32_t option_set(Options &o, const char *name, int64_t value);  // ASGART_E_ARG: unknown name / bad value
 void options_from_env(Options &o);
 }  // namespace asgart

@@ -671,6 +671,103 @@ int32_t build_rank_lists(const uint64_t *d_keys, const uint32_t *d_sa, uint64_t 
     return 0;
 }
 
+// The same lists for 64-bit slots (n >= 2^32: two genomes), and for any index when only the LARGE intervals matter
+// (rank_count_kernel reads the list of an interval of more than kRankMin entries only): the suffix array is copied and
+// every run of more than `min_run` equal keys is sorted by position in place, as one segment of a segmented radix
+// sort -- a seventh of the slots of a GRCh38-shaped text instead of all of them, and no pair of n-word buffers.
+// rocPRIM's segmented sort counts elements in 32 bits: the array is worked through in windows of 2^30 slots, a run
+// belongs to the window it starts in.  Runs of k-mers that start with N are left alone: probes that start with N are
+// never searched (src/automaton.rs:100-102), and the all-N run of an assembly's gaps is tens of millions long.
+namespace {
+template <class SlotT>
+__global__ __launch_bounds__(256) void big_runs_kernel(const uint64_t *__restrict__ keys, uint64_t n, uint64_t w0, uint64_t w1,
+                                                       uint32_t min_run, int k, uint32_t *__restrict__ begins,
+                                                       uint32_t *__restrict__ ends, unsigned long long *__restrict__ ctr) {
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint64_t r0 = w0 + (((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) & ~63ull); r0 < w1;
+         r0 += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = r0 + lane;
+        bool big = false;
+        uint64_t end = 0;
+        if (r < w1 && r + min_run < n) {
+            const uint64_t u = keys[r];
+            const uint32_t first = (uint32_t)(u >> (3 * (k - 1))) & 7u;
+            big = (r == 0 || keys[r - 1] != u) && keys[r + min_run] == u && first != 4u;
+            if (big) {  // first slot beyond the run: gallop, then bisect
+                uint64_t lo = r + min_run, step = min_run;
+                while (lo + step < n && keys[lo + step] == u) {
+                    lo += step;
+                    step <<= 1;
+                }
+                uint64_t hi = lo + step < n ? lo + step : n;  // keys[lo] == u, keys[hi] != u (or hi == n)
+                while (hi - lo > 1) {
+                    const uint64_t mid = lo + ((hi - lo) >> 1);
+                    if (keys[mid] == u) lo = mid; else hi = mid;
+                }
+                end = hi;
+            }
+        }
+        const unsigned long long m = __ballot(big);
+        if (m) {
+            const int leader = __ffsll((long long)m) - 1;
+            unsigned long long at = 0;
+            if ((int)lane == leader) at = atomicAdd(&ctr[0], (unsigned long long)__popcll(m));
+            at = __shfl(at, leader);
+            if (big) {
+                const unsigned long long j = at + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
+                begins[j] = (uint32_t)(r - w0);
+                ends[j] = (uint32_t)(end - w0);
+                atomicMax(&ctr[1], (unsigned long long)(end - w0));
+            }
+        }
+    }
+}
+}  // namespace
+
+template <class SlotT>
+int32_t build_rank_lists_runs(const uint64_t *d_keys, const SlotT *d_sa, uint64_t n, SlotT *d_sap, uint32_t min_run, int k,
+                              hipStream_t s) {
+    if (n == 0) return 0;
+    constexpr uint64_t kWindow = 1ull << 30;
+    const uint64_t max_runs = kWindow / (min_run + 1u) + 2u;  // per window
+    DevBuf b_beg, b_end, b_ctr, temp;
+    struct Free {
+        DevBuf &a, &b, &c, &t;
+        ~Free() { a.release(); b.release(); c.release(); t.release(); }
+    } guard{b_beg, b_end, b_ctr, temp};
+    RC_TRY(b_beg.reserve((size_t)max_runs * 4));
+    RC_TRY(b_end.reserve((size_t)max_runs * 4));
+    RC_TRY(b_ctr.reserve(16));
+    HIP_TRY(hipMemcpyAsync(d_sap, d_sa, (size_t)n * sizeof(SlotT), hipMemcpyDeviceToDevice, s));
+    int pos_bits = 1;
+    while (pos_bits < 64 && (n >> pos_bits)) ++pos_bits;
+    for (uint64_t w0 = 0; w0 < n; w0 += kWindow) {
+        const uint64_t w1 = std::min(n, w0 + kWindow);
+        HIP_TRY(hipMemsetAsync(b_ctr.p, 0, 16, s));
+        big_runs_kernel<SlotT><<<(unsigned)std::min<uint64_t>((w1 - w0 + 255) / 256, 1u << 16), 256, 0, s>>>(
+            d_keys, n, w0, w1, min_run, k, b_beg.as<uint32_t>(), b_end.as<uint32_t>(), b_ctr.as<unsigned long long>());
+        HIP_TRY(hipGetLastError());
+        unsigned long long h[2] = {0, 0};
+        HIP_TRY(hipMemcpyAsync(h, b_ctr.p, 16, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (!h[0]) continue;
+        if (h[1] >= 0xFFFFFFFFull) {
+            set_error("internal: a run of equal keys longer than 2^32 - 2^30 slots");
+            return ASGART_E_CAP;
+        }
+        size_t bytes = 0;
+        HIP_TRY(rocprim::segmented_radix_sort_keys(nullptr, bytes, d_sa + w0, d_sap + w0, (unsigned)h[1], (unsigned)h[0],
+                                                   b_beg.as<uint32_t>(), b_end.as<uint32_t>(), 0, (unsigned)pos_bits, s));
+        RC_TRY(temp.reserve(bytes));
+        HIP_TRY(rocprim::segmented_radix_sort_keys(temp.p, bytes, d_sa + w0, d_sap + w0, (unsigned)h[1], (unsigned)h[0],
+                                                   b_beg.as<uint32_t>(), b_end.as<uint32_t>(), 0, (unsigned)pos_bits, s));
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+template int32_t build_rank_lists_runs<uint32_t>(const uint64_t *, const uint32_t *, uint64_t, uint32_t *, uint32_t, int, hipStream_t);
+template int32_t build_rank_lists_runs<uint64_t>(const uint64_t *, const uint64_t *, uint64_t, uint64_t *, uint32_t, int, hipStream_t);
+
 }  // namespace asgart
 
 extern "C" int32_t asgart_sa_build64(const uint8_t *T, int64_t *SA, int64_t n) {

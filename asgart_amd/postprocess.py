@@ -279,6 +279,68 @@ def to_json(result: dict) -> str:
     return "".join(out)
 
 
+def post_process_arrays(index, offs: np.ndarray, sds: np.ndarray, threads: int = 0):
+    """The step chain behind the search (FilterNs, ReOrder, ReduceOverlap, Sort) on raw family arrays, at the scale of
+    a whole-genome run: asgart_post_process (N counts on the GPU, the quadratic reduction on host threads) instead of
+    the per-object loops above, which remain the readable statement of the same steps (tests compare the two)."""
+    return index.post_process(offs, sds, threads)
+
+
+def to_json_arrays(offs: np.ndarray, sds: np.ndarray, strand, settings: RunSettings, identity: Optional[np.ndarray] = None) -> str:
+    """`to_json(run_result(...))` for family arrays: the same bytes, one format operation per duplication (the
+    chromosome of a position by bisection of the strand map, whose records follow one another: the reference's
+    first-match scan, src/structs.rs:85-90, finds the same record)."""
+    offs = np.asarray(offs, dtype=np.int64)
+    sds = np.asarray(sds, dtype=np.uint64).reshape(-1, 4)
+    starts = np.array([c.position for c in strand.map], dtype=np.uint64)
+    ends = starts + np.array([c.length for c in strand.map], dtype=np.uint64)
+    names = [json.dumps(c.name, ensure_ascii=False) for c in strand.map] + ['"unknown"']
+
+    def locate(pos):
+        i = np.searchsorted(starts, pos, side="right").astype(np.int64) - 1
+        ok = (i >= 0) & (pos < ends[np.maximum(i, 0)])
+        i = np.where(ok, i, len(strand.map))
+        return i, np.where(ok, pos - starts[np.minimum(np.maximum(i, 0), len(starts) - 1)], pos)
+
+    if len(strand.map):
+        il, pl = locate(sds[:, 0])
+        ir, pr_ = locate(sds[:, 1])
+    else:
+        il = ir = np.zeros(len(sds), dtype=np.int64)
+        pl, pr_ = sds[:, 0], sds[:, 1]
+    ident = [f32_repr(v) for v in identity] if identity is not None else None
+    rev = "true" if settings.reverse else "false"
+    comp = "true" if settings.complement else "false"
+    sd_txt = []
+    L, R, LL, RL = (sds[:, j].tolist() for j in range(4))
+    il, ir, pl, pr_ = il.tolist(), ir.tolist(), pl.tolist(), pr_.tolist()
+    for j in range(len(sds)):
+        sd_txt.append(
+            '      {\n'
+            f'        "chr_left": {names[il[j]]},\n'
+            f'        "chr_right": {names[ir[j]]},\n'
+            f'        "global_left_position": {L[j]},\n'
+            f'        "global_right_position": {R[j]},\n'
+            f'        "chr_left_position": {pl[j]},\n'
+            f'        "chr_right_position": {pr_[j]},\n'
+            f'        "left_length": {LL[j]},\n'
+            f'        "right_length": {RL[j]},\n'
+            '        "left_seq": null,\n'
+            '        "right_seq": null,\n'
+            f'        "identity": {ident[j] if ident else "0.0"},\n'
+            f'        "reversed": {rev},\n'
+            f'        "complemented": {comp}\n'
+            '      }')
+    fams = []
+    for f in range(len(offs) - 1):
+        a, b = int(offs[f]), int(offs[f + 1])
+        fams.append("    [\n" + ",\n".join(sd_txt[a:b]) + "\n    ]" if b > a else "    []")
+    head = to_json({"strand": run_result([], strand, settings)["strand"], "settings": run_result([], strand, settings)["settings"]})
+    # (head ends with "\n}"; the families array is appended as the third field)
+    body = "[\n" + ",\n".join(fams) + "\n  ]" if fams else "[]"
+    return head[:-2] + ',\n  "families": ' + body + "\n}"
+
+
 def out_filename(files: Sequence[str], settings: RunSettings, prefix: str = "") -> str:
     """Default output name, src/bin/asgart.rs:642-714: {prefix}{stems joined '-'}[_][R][C][_a-b].json"""
     import os

@@ -281,6 +281,41 @@ def repeat_rich_genome(record_lengths: Sequence[int], seed: int, *, sine_frac: f
     return [(name, seq[offs[r]:offs[r + 1]]) for r, (name, _) in enumerate(recs)]
 
 
+def plant_hor_arrays(records: List[Tuple[str, np.ndarray]], seed: int, *, per_record: int = 1,
+                     array_bp: Tuple[int, int] = (400_000, 3_000_000), min_record: int = 40_000_000,
+                     monomer_div: Tuple[float, float] = (0.18, 0.32), copy_div: Tuple[float, float] = (0.01, 0.02)
+                     ) -> List[Tuple[str, np.ndarray]]:
+    """Centromere-like satellite arrays with HIGHER-ORDER structure, planted over `records` (in place of what was
+    there): a 171-bp monomer, m = 6..12 variants of it that differ from one another by `monomer_div` (as the monomers
+    of an alpha-satellite higher-order repeat do), and that m-monomer unit repeated over `array_bp` bases with only
+    `copy_div` substitutions between copies of the unit.  A probe inside such an array matches the SAME monomer of every
+    other unit copy (period 171 m, near-identical) and hardly its neighbours -- unlike make_genome's flat arrays, whose
+    copies all derive from one monomer."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for name, seq in records:
+        seq = seq.copy()
+        if len(seq) >= min_record:
+            for _ in range(per_record):
+                base = _background(rng, 171)
+                m = int(rng.integers(6, 13))
+                unit = np.concatenate([_mutate(rng, base, float(rng.uniform(*monomer_div))) for _ in range(m)])
+                total = int(min(rng.integers(array_bp[0], array_bp[1] + 1), len(seq) // 20))
+                copies = max(2, total // len(unit))
+                arr = np.tile(unit, copies)
+                rate = float(rng.uniform(*copy_div))
+                blk = 1 << 22
+                for off in range(0, len(arr), blk):
+                    arr[off:off + blk] = _mutate(rng, arr[off:off + blk], rate)
+                p = int(rng.integers(len(seq) // 3, len(seq) // 3 + len(seq) // 4))
+                keep_n = seq[p:p + len(arr)] == ord("N")
+                new = _BASES[arr] | 0x20
+                new[keep_n[:len(new)]] = ord("N")
+                seq[p:p + len(arr)] = new[:len(seq) - p]
+        out.append((name, seq))
+    return out
+
+
 def config_genome(cfg: int, scale: float = 1.0) -> List[Tuple[str, np.ndarray]]:
     """Synthetic stand-ins for BASELINE.json configs 1-5 (scale<1 shrinks them).  Config 5 is two
     "files": the config-4 genome plus a 1.2 %-diverged, rearranged copy of it (the cross-genome
@@ -291,6 +326,10 @@ def config_genome(cfg: int, scale: float = 1.0) -> List[Tuple[str, np.ndarray]]:
     if cfg == 6:   # chr1-sized, repeat-rich (young interspersed repeats): not a BASELINE.json config, a realism check
         lens6 = GRCH38_PRIMARY[:1] if scale == 1.0 else scaled(GRCH38_PRIMARY[:1], int(GRCH38_PRIMARY[0] * scale))
         return repeat_rich_genome(lens6, SEED_BASE + 6)
+    if cfg == 7:   # GRCh38-sized, repeat-rich, with higher-order satellite arrays: the realism check at full size
+        lens7 = GRCH38_PRIMARY if scale == 1.0 else scaled(GRCH38_PRIMARY, int(sum(GRCH38_PRIMARY) * scale))
+        return plant_hor_arrays(repeat_rich_genome(lens7, SEED_BASE + 7), SEED_BASE + 77,
+                                min_record=int(40_000_000 * min(1.0, scale)) if scale < 1.0 else 40_000_000)
     table = {1: ECOLI_MG1655, 2: SCEREVISIAE_S288C, 3: GRCH38_PRIMARY[:1], 4: GRCH38_PRIMARY}[cfg]
     lens = table if scale == 1.0 else scaled(table, int(sum(table) * scale))
     return make_genome(lens, SEED_BASE + cfg)

@@ -62,6 +62,7 @@ WORKLOADS = {
     "cfg4": (4, 1.0, False, DIRECT_RC, "GRCh38-shaped synthetic (3.1 Gb, 25 records), direct+RC, k=20 g=100"),
     "cfg5": (5, 1.0, False, DIRECT_RC, "GRCh38-shaped + 1.2 %-diverged second genome (two files, 6.1 Gb), direct+RC, k=20 g=100"),
     # not a BASELINE.json config: a realism check (young interspersed repeats: two probes in five pass the filter)
+    "cfg4r": (7, 1.0, False, DIRECT_RC, "GRCh38-sized, repeat-rich synthetic (3.1 Gb, 25 records; 27 % SINE-like + 15 % LINE-like families at 1-5 % divergence; higher-order satellite arrays: 6-12 monomers of 171 bp at 18-32 % from one another, unit copies at 1-2 %), direct+RC, k=20 g=100"),
     "cfg3r": (6, 1.0, False, DIRECT_RC, "human chr1-sized, repeat-rich synthetic (249 Mb; 27 % SINE-like + 15 % LINE-like families at 1-5 % divergence), direct+RC, k=20 g=100"),
 }
 

@@ -258,6 +258,19 @@ void asgart_families_free(asgart_families *f);
 int32_t asgart_compute_scores(asgart_index *idx, const asgart_proto_sd *sds, int64_t n_sd,
                               int32_t reversed, int32_t complemented, float *identity);
 
+/* ---- the steps behind the search step ------------------------------------------
+ * Replaces FilterNs, ReOrder, ReduceOverlap and Sort of the reference's step chain (src/bin/asgart.rs:33-96 with
+ * ProtoSD::n_content src/structs.rs:454-467, reduce_overlap :481-562; order :738-747) for the families of one run,
+ * given as the arrays asgart_families_copy fills (fam_offsets: n_families + 1 entries).  ComputeScore, the optional
+ * step between ReduceOverlap and Sort, is asgart_compute_scores (call it on the result: Sort does not look at it).
+ * The N content of every arm is counted on the GPU over the resident text (inclusive ranges [p ..= p + length], the
+ * f32 quotient and the 0.2 threshold as the reference computes them); the reduction runs on `threads` host threads
+ * (0: all), one family at a time each.  out: the surviving families (asgart_families_counts / _copy / _free;
+ * asgart_families_keys gives the input ordinal of every surviving family).
+ * Errors: a duplication whose inclusive range reaches past the text (the reference panics there). */
+int32_t asgart_post_process(asgart_index *idx, const uint64_t *fam_offsets, uint64_t n_families,
+                            const asgart_proto_sd *sds, int32_t threads, asgart_families **out);
+
 /* ---- finer-grained entry points mirroring the reference's inner API;
  *      used by the parity tests ------------------------------------------ */
 

@@ -9,6 +9,12 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+# An index builds its presence filters and position-sorted lists on SECOND use by default (option lazy_aux: they do not
+# pay back within one pass).  The suite wants every first call on the filtered / list-assisted paths -- that is where
+# the code is -- so it switches the laziness off; test_lazy_filter_and_lists_same_results covers the default.
+os.environ.setdefault("ASGART_LAZY_AUX", "0")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu via gpurun)")
 

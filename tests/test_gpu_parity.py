@@ -1189,3 +1189,29 @@ def test_replica_from_device_buffers_matches(hiplib):
     assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
     with pytest.raises(asgart_amd.AsgartError):
         asgart_amd.Index.from_device(t_ptr, len(pr.data), sa_ptr, 8)   # wrong entry width for this text
+
+
+def test_lazy_filter_and_lists_same_results(hiplib, monkeypatch):
+    """Default behaviour of an index (option lazy_aux = 1; the suite otherwise runs with 0 so that every first call
+    takes the filtered paths): the first search of an orientation runs without the presence filter and without the
+    position-sorted lists, the second one with both -- identical families, and identical to the oracle."""
+    monkeypatch.setenv("ASGART_LAZY_AUX", "1")
+    pr, cli = _battery_case("dense_repeats")
+    oidx = oracle.Index.build(pr.data)
+    with asgart_amd.Index(pr.data, oidx.sa) as idx:
+        for rc in (False, True):
+            st = asgart_amd.RunSettings.from_cli(reverse=rc, complement=rc, **cli)
+            exp = oidx.run_raw(pr.chunks, oracle.make_settings(reverse=rc, complement=rc, **cli))
+            first = idx.search_duplications_raw(pr.chunks, st)
+            rej_first = idx.stats(1).probes_filter_rejected
+            second = idx.search_duplications_raw(pr.chunks, st)
+            rej_second = idx.stats(1).probes_filter_rejected
+            assert rej_first == 0 and rej_second > 0
+            for got in (first, second):
+                assert np.array_equal(got[0], exp[0]) and np.array_equal(got[1], exp[1])
+        # the passes call: both orientations in one call, every structure in place by now
+        sts = [asgart_amd.RunSettings.from_cli(reverse=rc, complement=rc, **cli) for rc in (False, True)]
+        both = idx.search_duplications_passes(pr.chunks, sts)
+        for rc, got in zip((False, True), both):
+            exp = oidx.run_raw(pr.chunks, oracle.make_settings(reverse=rc, complement=rc, **cli))
+            assert np.array_equal(got[0], exp[0]) and np.array_equal(got[1], exp[1])

@@ -241,3 +241,53 @@ def test_oracle_levenshtein_identity_against_plain_python():
             want = np.float32(100.0 * (1.0 - _py_levenshtein(a, b) / max(ll, rl)))
             got = oracle.levenshtein_identity(text, (left, right, ll, rl), rev, comp)
             assert got == want, (left, right, ll, rl, rev, comp)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,mode,min_len", [(31, (False, False), 300), (32, (True, True), 300), (34, (False, False), 200),
+                                               (35, (True, True), 1000)])
+def test_native_chain_matches_oracle_and_python(seed, mode, min_len, hiplib):
+    """asgart_post_process (N counts on the GPU, reduction on host threads) against the oracle's C chain and the Python
+    statement of the same steps, on the families the HIP search itself returns; the array JSON writer against the
+    per-object one."""
+    pr, oidx = _case(seed, short_n_per_mb=60)
+    st = asgart_amd.RunSettings.from_cli(min_length=min_len, reverse=mode[0], complement=mode[1])
+    with asgart_amd.Index(pr.data, oidx.sa) as idx:
+        offs, sds = idx.search_duplications_raw(pr.chunks, st)
+        assert len(sds) > 3
+        for threads in (1, 0):
+            go, gs = postprocess.post_process_arrays(idx, offs, sds, threads)
+            eoffs, esds = oracle.postprocess(pr.data, offs, sds)
+            assert np.array_equal(go, eoffs) and np.array_equal(gs, esds)
+        strand = asgart_amd.Strand("x.fa", pr.data, pr.map)
+        fams = postprocess.post_process(_to_families(offs, sds, *mode), strand)
+        assert [[sd.as_tuple() for sd in fam] for fam in fams] == oracle.families_to_list(go, gs)
+        assert postprocess.to_json_arrays(go, gs, strand, st) == postprocess.to_json(postprocess.run_result(fams, strand, st))
+        # an arm whose inclusive range leaves the text is an error (the reference panics), not a silent clamp
+        bad = np.array([[0, len(pr.data) - 5, 10, 5]], dtype=np.uint64)
+        with pytest.raises(asgart_amd.AsgartError):
+            idx.post_process(np.array([0, 1], dtype=np.uint64), bad)
+        # nothing in, nothing out
+        eo, es = idx.post_process(np.zeros(1, np.uint64), np.zeros((0, 4), np.uint64))
+        assert len(eo) == 1 and len(es) == 0
+
+
+@pytest.mark.gpu
+def test_native_chain_large_family(hiplib):
+    """A tandem array gives one family of thousands of duplications: the quadratic reduction on it, natively, equals
+    the oracle's."""
+    rng = np.random.default_rng(3)
+    mono = rng.integers(0, 4, size=171)
+    arr = np.tile(mono, 700)
+    mut = rng.random(arr.shape) < 0.03
+    arr[mut] = (arr[mut] + rng.integers(1, 4, size=int(mut.sum()))) & 3
+    g = np.concatenate([rng.integers(0, 4, size=20_000), arr, rng.integers(0, 4, size=20_000)])
+    text = np.concatenate([np.frombuffer(b"ACGT", dtype=np.uint8)[g], np.frombuffer(b"$", dtype=np.uint8)])
+    chunks = [(0, len(text) - 1)]
+    st = asgart_amd.RunSettings.from_cli()
+    with asgart_amd.Index(text, None) as idx:
+        offs, sds = idx.search_duplications_raw(chunks, st)
+        assert np.diff(offs.astype(np.int64)).max() > 500
+        go, gs = idx.post_process(offs, sds)
+    eoffs, esds = oracle.postprocess(text, offs, sds)
+    assert np.array_equal(go, eoffs) and np.array_equal(gs, esds)
