@@ -94,6 +94,12 @@ namespace asgart {
 #define K7T_FLUSH(cls)
 #endif
 
+// A taken branch costs a lone wave ~40 cycles (tools/ubench_branch.hip) and a step of an arm wave holds dozens of
+// conditions that almost never hold (a cooperative arm, a record to write, a third table row, a stash, a late probe):
+// the rare side of each is marked, so that the compiler lays the common path out as fall-through.
+#define K7_RARE(x) __builtin_expect(!!(x), 0)
+#define K7_USUAL(x) __builtin_expect(!!(x), 1)
+
 // command flags (control wave -> everyone, one block per step)
 constexpr uint32_t K7_PREV = 1u;    // a previous probe is to be resolved (and its new arms created)
 constexpr uint32_t K7_CUR = 2u;     // a current probe receives offers
@@ -254,11 +260,11 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
         };
         // what interval B does for everyone once the mid-step block is known
         auto mid_actions = [&](uint32_t mflags) {
-            if (mflags & K7_STAGE) {
+            if (K7_RARE(mflags & K7_STAGE)) {
                 const uint4 m1 = *reinterpret_cast<const uint4 *>(&s_mid[4]);
                 stage_rows(((unsigned long long)uni(m1.y) << 32) | uni(m1.x), uni(m1.z), uni(m1.w));
             }
-            if (mflags & K7_CLEAR) clear_table();
+            if (K7_RARE(mflags & K7_CLEAR)) clear_table();
         };
 
         bool overflow = false;
@@ -303,7 +309,7 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                     if (livemask & 1u) read_candidates(0, cb0, xb0, rs0);
                 }
                 const uint32_t flags = uni(c0.x);
-                if (flags & K7_GIVEUP) {
+                if (K7_RARE(flags & K7_GIVEUP)) {
                     overflow = true;
                     break;
                 }
@@ -311,23 +317,23 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                 // ---------------------------------------------------------------- interval A ----------------
                 // the hits of this step's probe when it opened a batch (its rows arrived with the last barrier), and those of
                 // the NEXT step's probe otherwise: indexed by the top arm waves while the others resolve
-                if (has_cur && late) {
+                if (K7_RARE(has_cur && late)) {
                     const uint32_t cnt = uni(c0.y);
                     if (indexes(cnt)) {
                         const uint4 d1 = cq[1], d4 = cq[4];
                         insert_hits(cnt, uni(c0.z), uni(c0.w), uni(d1.x), uni(cq[2].y), uni(d1.y), uni(d4.w));
                     }
                 }
-                if (!(flags & K7_LAST)) {
+                if (K7_USUAL(!(flags & K7_LAST))) {
                     const uint32_t nflags = uni(n0.x), ncnt = uni(n0.y);
-                    if ((nflags & K7_CUR) && !(nflags & K7_LATE) && indexes(ncnt)) {
+                    if (K7_RARE((nflags & K7_CUR) && !(nflags & K7_LATE) && indexes(ncnt))) {
                         const uint4 n1 = nq[1], n2 = nq[2], n4 = nq[4];
                         insert_hits(ncnt, uni(n0.z), uni(n0.w), uni(n1.x), uni(n2.y), uni(n1.y), uni(n4.w));
                     }
                 }
                 K7U_LAP(0);
                 uint32_t wasfree = 0;  // per lane, bit L: the slot of layer L was empty before this step
-                if (!livemask) {
+                if (K7_RARE(!livemask)) {
                     wasfree = (1u << S) - 1u;
                 } else {
                     // (vector registers that hold the same value in every lane: the command's fields)
@@ -357,7 +363,7 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                         } else {
                             read_candidates(L, cb, xb, rs_L);
                         }
-                        if (has_prev) {
+                        if (K7_USUAL(has_prev)) {
                             // the last hit (SA order) this arm won, if any: src/automaton.rs:133-150 apply in hit order
                             const uint32_t ch = c_h[L];
                             const bool coop = !was_free && ch == kCoop;
@@ -372,7 +378,7 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                             hw = (was_free || coop) ? 0u : hw;
                             unsigned long long sm = __ballot(coop);
                             K7C(55, __popcll(sm));
-                            if (sm) {  // more than three candidates / wide window: resolved cooperatively
+                            if (K7_RARE(sm != 0ull)) {  // more than three candidates / wide window: resolved cooperatively
                                 const uint32_t p_cnt = uni(c2.w), p_off = pv_off;
                                 while (sm) {
                                     const uint32_t l = (uint32_t)(__ffsll((long long)sm) - 1);
@@ -436,7 +442,7 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                         a_gap[L] = aged;
                         const bool dead = !was_free && aged >= G;  // never matches again
                         const bool report = dead && (uint64_t)(a_re[L] - rs_L) >= M;
-                        if (__ballot(report))
+                        if (K7_RARE(__ballot(report) != 0ull))
                             emit_records(report, a_ls[L], s_cle[L * (NWA * 64) + tid], rs_L, a_re[L], a_seq[L], uni(s_fam[sp ^ 1u]));
                         a_seq[L] = dead ? kNoSeq : a_seq[L];
                     }
@@ -493,18 +499,18 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                             offer(e0.x); offer(e0.y); offer(e2.x); offer(e2.y);
                         }
                     }
-                    for (uint32_t r = 2; __ballot(r < n_rows); ++r) {
+                    for (uint32_t r = 2; K7_RARE(__ballot(r < n_rows) != 0ull); ++r) {
                         K7C(53, 1);
                         offer_row(b0 + r);
                     }
-                    if (ns) {
+                    if (K7_RARE(ns != 0u)) {
                         const uint32_t bb = uni(c2.y);
                         for (uint32_t s = 0; s < min(ns, kStash); ++s) offer(s_stash[bb][s]);
                     }
                     ch = nc > 3u ? kCoop : (ch & 0x3FFFFFFFu) | (nc << 30);
                     // arms too wide for the table walk -- and every arm when the stash overflowed
                     unsigned long long sm = __ballot(who && (!narrow || povf));
-                    if (sm) {
+                    if (K7_RARE(sm != 0ull)) {
                         if (who && (!narrow || povf)) ch = kCoop;
                         K7C(54, __popcll(sm));
                         const uint32_t cnt = uni(c0.y), off = uni(c0.z);
@@ -552,7 +558,7 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                     if (has_cur) nst2 = *reinterpret_cast<const uint4 *>(&s_nstash[0]);
                 }
                 const uint32_t mflags = uni(m0v.x);
-                if (mflags & K7_OVF) {
+                if (K7_RARE(mflags & K7_OVF)) {
                     overflow = true;
                     break;
                 }
@@ -561,7 +567,7 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                 K7U_LAP(3);
                 const bool receives = n_new != 0u && uni(b_first) < n_new;
                 if (receives || (has_cur && livemask)) {
-                    if (!cmd_loaded) {  // (this wave had no arms and now receives some)
+                    if (K7_RARE(!cmd_loaded)) {  // (this wave had no arms and now receives some)
                         c1 = cq[1]; c2 = cq[2]; c3 = cq[3]; c4 = cq[4]; c5 = cq[5];
                         bs0 = *reinterpret_cast<const uint4 *>(&s_base[wave][0]);
                         if constexpr (S > 4) bs1 = *reinterpret_cast<const uint4 *>(&s_base[wave][4]);
@@ -591,7 +597,7 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                             const uint64_t g_new = (uint64_t)step + pend;  // aged by its own probe, then by the quiet ones
                             const uint32_t gap_new = g_new > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)g_new;
                             const bool stillborn = take && gap_new >= G;
-                            if (__ballot(stillborn)) {  // (only when min_duplication_length <= k: a k-base arm is reported)
+                            if (K7_RARE(__ballot(stillborn) != 0ull)) {  // (only when min_duplication_length <= k: a k-base arm is reported)
                                 const bool report = stillborn && (uint64_t)k >= M;
                                 if (__ballot(report)) emit_records(report, p_i, (PosT)(p_i + k), x, (PosT)(x + k), seq_base + r, fam_b);
                             }
@@ -635,7 +641,7 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                 K7T_LAP(3);
                 pv_off = c0.z;
                 pv_besto = c1.x;
-                if (flags & K7_LAST) break;
+                if (K7_RARE(flags & K7_LAST)) break;
             }
             if (wave == 0u) K7T_FLUSH(1);
             if (wave == 0u) K7U_FLUSH();

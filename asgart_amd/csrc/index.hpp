@@ -260,6 +260,8 @@ struct Options {
                                     // at GRCh38 size and save 0.03 / 0.006 s per pass -- a host that runs every orientation once per index
                                     // (the reference's own use, src/bin/asgart.rs:677-693) never pays for them; 0: filters on first use,
                                     // lists with the keys
+    int64_t sparse_to6 = 1;         // with dense3: where the long segments that are NOT dense go: 1 = tier 6 (1024 threads, the kernel tier 3 used
+                                    // to run), 0 = by their arm bound like any other segment (smaller shapes: several per compute unit)
     int64_t dense3 = 16;            // with k7 in tier 3: long segments go there only with at least this many hits per processed probe on
                                     // average (0: all of them); the sparse long ones run on tier 6's kernel
     int64_t prewarm = 1;            // 1: asgart_index_prepare also reserves the per-probe workspace of both call contexts (sized for an

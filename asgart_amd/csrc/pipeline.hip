@@ -475,6 +475,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
         auto tier_enabled = [&](int t) { return t >= 1 && t <= kTiers && tier_cap[t] != 0; };
         PlaceParams pp;
         pp.long3 = pp.long3_big = pp.dense3 = 0;
+        pp.sparse_to6 = (uint32_t)opt.sparse_to6;
         for (int t = 1; t < kTiers; ++t) pp.cap[t - 1] = tier_cap[t];
         if (arms_kernel) {
             pp.long3 = (uint32_t)opt.long3;
@@ -1357,6 +1358,7 @@ int32_t asgart_get_stats(asgart_index *idx, uint32_t flags, asgart_stats *out) {
             // in bytes instead of executed); the work list of the large intervals is the one the
             // call left in the workspace
             HIP_TRY(hipMemsetAsync(d_ctr + CT_ALG_BYTES, 0, 16, s));
+            HIP_TRY(hipMemsetAsync(d_ctr + CT_ALG_BYTES16, 0, 8, s));
             const int mode = (rp.reverse ? 2 : 0) | (rp.complement ? 1 : 0);
             const unsigned gp = grid_for(rp.g_hi - rp.g_lo, kProbeBlock);
             auto account = [&](auto slot_tag) {
@@ -1377,13 +1379,15 @@ int32_t asgart_get_stats(asgart_index *idx, uint32_t flags, asgart_stats *out) {
             };
             if (idx->wide) account(uint64_t{}); else account(uint32_t{});
             HIP_TRY(hipGetLastError());
-            unsigned long long v = 0, ab[2] = {0, 0};
+            unsigned long long v = 0, ab[2] = {0, 0}, a16 = 0;
             HIP_TRY(hipMemcpyAsync(&v, d_ctr + CT_BISECT, 8, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipMemcpyAsync(ab, d_ctr + CT_ALG_BYTES, 16, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(&a16, d_ctr + CT_ALG_BYTES16, 8, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
             cx.stats.bisect_steps = v;
             cx.stats.search_bytes = ab[0];
             cx.stats.probes_filter_rejected = ab[1];
+            cx.stats.search_bytes_wide_loads = a16;
         }
         *out = cx.stats;
         return 0;

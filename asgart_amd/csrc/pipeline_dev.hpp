@@ -50,6 +50,7 @@ enum Counter {
     CT_ALG_BYTES = 68,  // accounting pass: bytes the probe-search kernels move by design
     CT_FLT_REJECTED,    // accounting pass: probes answered by the presence filter alone
     CT_LONGSEG,         // placement: segments the lane-per-segment walk handed to the wave-per-segment kernel
+    CT_ALG_BYTES16,     // accounting pass: the part of CT_ALG_BYTES that is wide coalesced loads (16 bytes per lane)
     CT_HIST_PEAK = 72,   // diagnostic build: log2 histograms per launch (16 bins each)
     CT_HIST_PROBES = 88,
     CT_N1 = 104,       // list lengths of the extension tiers 1..kTiers (kTiers entries)
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(kProbeBlock) void probe_count_kernel(IndexView<Slot
             uint4 v = make_uint4(0, 0, 0, 0);
             if (a >= 0 && (uint64_t)a + 16u <= ix.n + 64u) {  // the text allocation has 64 spare bytes
                 v = *reinterpret_cast<const uint4 *>(ix.text + a);
-                cb.rd(16);
+                cb.rd16();
             }
             *reinterpret_cast<uint4 *>(s_text + 16u * tid) = v;
         }
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(kProbeBlock) void probe_count_kernel(IndexView<Slot
                 uint4 v = make_uint4(~0u, ~0u, ~0u, ~0u);
                 if (a >= 0 && (uint64_t)a + 16u <= ((ix.n + 63u) / 64u) * 8u + 512u) {  // (the allocation is padded)
                     v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(ix.pbits) + a);
-                    cb.rd(16);
+                    cb.rd16();
                 }
                 *reinterpret_cast<uint4 *>(&s_pb[4u * tid]) = v;
             }
@@ -323,22 +324,25 @@ __global__ __launch_bounds__(kProbeBlock) void probe_count_kernel(IndexView<Slot
     }
     if constexpr (COUNT) {
         // workgroup totals -> two global atomics
-        __shared__ unsigned long long s_tot[2];
-        if (tid < 2) s_tot[tid] = 0;
+        __shared__ unsigned long long s_tot[3];
+        if (tid < 3) s_tot[tid] = 0;
         __syncthreads();
-        unsigned long long b = cb.n, r = n_rej;
+        unsigned long long b = cb.n, r = n_rej, b16 = cb.n16;
         for (int off = 32; off > 0; off >>= 1) {
             b += __shfl_down(b, off);
             r += __shfl_down(r, off);
+            b16 += __shfl_down(b16, off);
         }
         if ((tid & 63u) == 0) {
             atomicAdd(&s_tot[0], b);
             atomicAdd(&s_tot[1], r);
+            atomicAdd(&s_tot[2], b16);
         }
         __syncthreads();
         if (tid == 0) {
             atomicAdd(&ctr[CT_ALG_BYTES], s_tot[0]);
             if (s_tot[1]) atomicAdd(&ctr[CT_FLT_REJECTED], s_tot[1]);
+            if (s_tot[2]) atomicAdd(&ctr[CT_ALG_BYTES16], s_tot[2]);
         }
     }
     // (no barrier behind the lookups: the waves that retired above never meet the others again)
@@ -1579,6 +1583,7 @@ struct PlaceParams {
     int use_filter;             // 0: flag every hit (k >= M, huge gaps or cardinalities)
     uint32_t long3;             // > 0: tier 3 is reserved for segments of at least this many probes
     uint32_t long3_big;         // ... or this many, for segments beyond tier 5's capacity
+    uint32_t sparse_to6;        // 1: the long segments that are not dense go to tier 6 (its kernel is the old tier-3 one); 0: by capacity
     uint32_t dense3;            // > 0: ... and only the DENSE ones (at least this many hits per processed probe on average:
                                 // tandem arrays); the sparse long ones (a chromosome against its homologue: a few hits per
                                 // probe, mostly run by one wave alone) go to tier 6's kernel -- set when tier 3 runs the
@@ -1611,7 +1616,9 @@ __device__ inline int place_tier(uint32_t bound, unsigned long long sum, uint32_
     if (pp.long3 && bound <= pp.cap[2] &&
         (n_probes >= pp.long3 || (bound > pp.cap[4] && n_probes >= pp.long3_big))) {
         if (!pp.dense3 || sum >= (unsigned long long)pp.dense3 * n_probes || bound > pp.cap[5]) return 3;
-        return 6;
+        if (pp.sparse_to6) return 6;
+        // (else: by capacity like any other segment -- a sparse long segment is mostly run by one wave alone, and the
+        // small shapes give it a fraction of a compute unit instead of a whole one)
     }
     for (int t = 2; t < kTiers; ++t) {
         if (t == 3 && pp.long3) continue;

@@ -440,8 +440,14 @@ def main():
                 prof = {}
         except Exception:
             prof = {}
-    traffic = prof.get("traffic_bytes_per_launch")
+    traffic_counted = prof.get("traffic_bytes_per_launch")
     traffic_ms = prof.get("kernel_ms_per_launch")
+    # FETCH_SIZE tallies exactly half the bytes of whole-wave 16-byte-per-lane loads on gfx950 (MI355X_MICROARCH.md, HBM):
+    # the text windows and filter bitmaps of the probe search are such loads -- the accounting pass counts them apart
+    wide_bytes = sum(s.get("search_bytes_wide_loads", 0) for s in pass_stats) / passes
+    traffic = int(traffic_counted + wide_bytes / 2) if traffic_counted else None
+    import hashlib
+    lib_hash = hashlib.sha256(open(asgart_amd.library_path(), "rb").read()).hexdigest()[:12]
     roofline = {
         "bound": "hbm",
         "kernel": "probe_count_kernel + collect_pending_kernel + big_count_kernel + rank_count_kernel (one launch = one pass)",
@@ -457,12 +463,16 @@ def main():
         "achieved_alone": round(alg_bytes / (alone_ms / 1e3) / 1e9, 2) if alone_ms > 0 else 0.0,
         "frac_alone": round(alg_bytes / (alone_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5) if alone_ms > 0 else 0.0,
         "traffic": traffic,
+        "traffic_as_counted": traffic_counted,
+        "wide_load_bytes": int(wide_bytes),
         "traffic_ms": traffic_ms,
         "traffic_frac": (round(traffic / (traffic_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5)
                          if traffic and traffic_ms else None),
-        "traffic_x2_applied": prof.get("x2_applied", False),
+        "traffic_x2_applied": "to the wide coalesced loads only: traffic = FETCH_SIZE + WRITE_SIZE as counted + wide_load_bytes / 2" if traffic else False,
         "traffic_source": prof.get("source"),
         "traffic_build": prof.get("build"),
+        "library_build": lib_hash,
+        "traffic_from_this_build": prof.get("build") == lib_hash if prof.get("build") else None,
         "waste": round(traffic / alg_bytes, 3) if traffic and alg_bytes else None,
         # The kernels are random-gather bound: an 8- or 4-byte gather moves (and FETCH_SIZE counts) one 64-byte
         # sector, so `traffic` exceeds the algorithmic bytes by design (`waste` is sector granularity, not re-reads),
@@ -546,15 +556,23 @@ def main():
         oidx = oracle.Index.build(pr.data, sa)
         # bounded sample: the first `per_chunk` bases of EVERY chunk, so the CPU leg keeps the
         # reference's chunk-level parallelism (one thread per chunk) without its skew
+        # ... sized for about 20 s of CPU work: a first, twenty times smaller sample tells how fast this input goes (a
+        # repeat-rich genome costs the CPU path ten times more per base than the GRCh38-shaped one)
         budget_bp = float(os.environ.get("ASGART_CPU_SAMPLE_BP", 200e6))
+
+        def cpu_sample(per_chunk_):
+            chunks_ = [(s0, min(l0, per_chunk_)) for s0, l0 in pr.chunks]
+            t_ = time.perf_counter()
+            for r, c in modes:
+                oidx.run_raw(chunks_, oracle.make_settings(k=k, gap=gap, reverse=r, complement=c), threads=cores)
+            return sum(l0 for _, l0 in chunks_), time.perf_counter() - t_
+
         per_chunk = max(100_000, int(budget_bp / max(1, len(pr.chunks))))
-        sample_chunks = [(s0, min(l0, per_chunk)) for s0, l0 in pr.chunks]
-        sample_bp = sum(l0 for _, l0 in sample_chunks)
-        t0 = time.perf_counter()
-        for r, c in modes:
-            oidx.run_raw(sample_chunks, oracle.make_settings(k=k, gap=gap, reverse=r, complement=c),
-                         threads=cores)
-        t_cpu = time.perf_counter() - t0
+        if "ASGART_CPU_SAMPLE_BP" not in os.environ and per_chunk > 2_000_000:
+            bp0, t0_ = cpu_sample(per_chunk // 20)
+            target_s = float(os.environ.get("ASGART_CPU_SAMPLE_S", 20.0))
+            per_chunk = int(min(per_chunk, max(per_chunk // 20, (per_chunk // 20) * target_s / max(t0_, 1e-3))))
+        sample_bp, t_cpu = cpu_sample(per_chunk)
         out["cpu_baseline"] = {
             "value": round(sample_bp * passes / t_cpu / 1e6, 3), "unit": "Mbp/s", "cores": cores,
             "kind": "port",

@@ -84,6 +84,8 @@ typedef struct asgart_stats {
                                  staging, filter word, prefix-table entries, keys read by the bisection,
                                  suffix-array entries read, outputs): the algorithmic bytes of this kernel */
     uint64_t probes_filter_rejected; /* probes answered by the k-mer presence filter alone          */
+    uint64_t search_bytes_wide_loads; /* ... of search_bytes, those loaded as whole-wave 16-byte-per-lane reads (text windows,
+                                         filter bitmaps): what FETCH_SIZE counts at half on gfx950 (accounting pass only) */
     double ms_longest_tier;   /* part of ms_extend: the extension tier that ran longest, from the launch of the tiers
                                  (they run side by side) -- in practice the longest serial automaton segment of the
                                  call, i.e. what sharding the probes over more GPUs cannot shorten              */

@@ -53,18 +53,20 @@ def per_launch(ctr, prefix, field="avg_KB_per_launch"):
 probe = "asgart::probe_count_kernel<unsigned int, false>"
 big = "asgart::big_count_kernel<unsigned int, false>"
 rank = "asgart::rank_count_kernel<unsigned int, false>"   # (absent from older profiles: contributes 0 then)
+coll = "asgart::collect_pending_kernel"                   # (round 4: builds the two work lists from the marks)
 if not any(k.startswith(probe) for k in pmc.get("FETCH_SIZE", {})):   # 64-bit index
     probe, big, rank = (x.replace("unsigned int", "unsigned long") for x in (probe, big, rank))
-search = sum(per_launch(c, p) for c in ("FETCH_SIZE", "WRITE_SIZE") for p in (probe, big, rank)) * 1024
+group = (probe, coll, big, rank)
+search = sum(per_launch(c, p) for c in ("FETCH_SIZE", "WRITE_SIZE") for p in group) * 1024
 # the kernels' own durations in the (serialising) PMC passes, averaged over the two passes
-pmc_ms = sum(per_launch(c, p, "avg_ns") for c in ("FETCH_SIZE", "WRITE_SIZE") for p in (probe, big, rank)) / 2 / 1e6
+pmc_ms = sum(per_launch(c, p, "avg_ns") for c in ("FETCH_SIZE", "WRITE_SIZE") for p in group) / 2 / 1e6
 stats_ms = None
 sfile = os.path.join(dst, f"{tag}_{workload}_kernel_stats.csv")
 if os.path.exists(sfile):
     tot = 0.0
     for row in csv.DictReader(open(sfile)):
         nm = short(row["Name"])
-        if nm.startswith(probe) or nm.startswith(big) or nm.startswith(rank):  # (short() keeps the template arguments)
+        if any(nm.startswith(g_) for g_ in group):  # (short() keeps the template arguments)
             tot += float(row["AverageNs"])
     stats_ms = tot / 1e6
 if search > 0:
@@ -77,7 +79,12 @@ if search > 0:
                 allw.update({k: v for k, v in json.load(open(prev)).items() if isinstance(v, dict)})
             except Exception:
                 pass
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.environ.get("ASGART_LIB") or os.path.join(root, "asgart_amd", "libasgart_hip.so")
+    build = hashlib.sha256(open(lib, "rb").read()).hexdigest()[:12] if os.path.exists(lib) else None
     allw[workload] = {
+        "build": build,   # sha256[:12] of the library the passes ran (bench.py compares it with the one it loads)
         "traffic_bytes_per_launch": int(search),
         "kernel_ms_per_launch": round(pmc_ms, 4),
         "stats_kernel_ms_per_launch": None if stats_ms is None else round(stats_ms, 4),
@@ -85,10 +92,11 @@ if search > 0:
                   f"passes, kernels serialised) and profiles/{tag}_{workload}_kernel_stats.csv (--kernel-trace --stats of "
                   "the default bench run)",
     }
-    allw["_note"] = ("per workload: HBM-side bytes per launch (= per pass) of probe_count_kernel + big_count_kernel + rank_count_kernel = "
+    allw["_note"] = ("per workload: HBM-side bytes per launch (= per pass) of probe_count_kernel + collect_pending_kernel + big_count_kernel + rank_count_kernel = "
                      "(FETCH_SIZE + WRITE_SIZE) KB * 1024; kernel_ms_per_launch = the two kernels' durations in those "
                      "PMC passes; stats_kernel_ms_per_launch = their rocprofv3 --stats averages in the un-instrumented "
-                     "bench run (passes overlapped).  Narrow 4-8 byte gathers: FETCH_SIZE is used as reported (no x2); "
+                     "bench run (passes overlapped).  Narrow 4-8 byte gathers: FETCH_SIZE is used as reported (no x2); bench.py adds half the bytes of the "
+                     "wide coalesced loads (text windows, filter bitmaps), which gfx950 counts at one half; "
                      "tools/ubench_gather.hip calibrates bytes per random gather; Infinity-Cache hits are included in "
                      "the counter")
     json.dump(allw, open(tfile, "w"), indent=1)
