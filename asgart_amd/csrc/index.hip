@@ -55,7 +55,7 @@ const OptDesc kOptions[] = {
     {"k7", &Options::k7, 0, 127},
     {"lazy_aux", &Options::lazy_aux, 0, 1},
     {"dense3", &Options::dense3, 0, 1 << 20},
-    {"sparse_to6", &Options::sparse_to6, 0, 1},
+    {"sparse_to6", &Options::sparse_to6, 0, 512},
     {"prewarm", &Options::prewarm, 0, 1},
     {"watchdog_s", &Options::watchdog_s, 0, 86400},
     {"test_stall_s", &Options::test_stall_s, 0, 60},

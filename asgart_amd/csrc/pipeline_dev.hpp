@@ -1616,8 +1616,14 @@ __device__ inline int place_tier(uint32_t bound, unsigned long long sum, uint32_
     if (pp.long3 && bound <= pp.cap[2] &&
         (n_probes >= pp.long3 || (bound > pp.cap[4] && n_probes >= pp.long3_big))) {
         if (!pp.dense3 || sum >= (unsigned long long)pp.dense3 * n_probes || bound > pp.cap[5]) return 3;
-        if (pp.sparse_to6) return 6;
-        // (else: by capacity like any other segment -- a sparse long segment is mostly run by one wave alone, and the
+        if (pp.sparse_to6 == 1) return 6;
+        if (pp.sparse_to6 >= 3) return bound <= pp.sparse_to6 ? 2 : 6;  // (3..: the ones whose arms fit that many slots on the one-wave shape)
+        if (pp.sparse_to6 == 2) {  // by capacity, but not on the one-wave shape (its bursts of dense repeats run layer by layer there)
+            for (int t = 4; t < kTiers; ++t)
+                if (bound <= pp.cap[t - 1]) return t;
+            return kTiers;
+        }
+        // (0: by capacity like any other segment -- a sparse long segment is mostly run by one wave alone, and the
         // small shapes give it a fraction of a compute unit instead of a whole one)
     }
     for (int t = 2; t < kTiers; ++t) {

@@ -1215,3 +1215,29 @@ def test_lazy_filter_and_lists_same_results(hiplib, monkeypatch):
         for rc, got in zip((False, True), both):
             exp = oidx.run_raw(pr.chunks, oracle.make_settings(reverse=rc, complement=rc, **cli))
             assert np.array_equal(got[0], exp[0]) and np.array_equal(got[1], exp[1])
+
+
+@pytest.mark.parametrize("wide", [0, 1])
+@pytest.mark.parametrize("tier", [3, 4, 5, 6])
+def test_control_wave_kernel_in_every_workgroup_tier(hiplib, tier, wide, monkeypatch):
+    """K7 (extend_k7_dev.hpp: a control wave plans the steps, arm waves do nothing but their arms) runs tier 3 by
+    default; option k7 = 120 puts it in tiers 4, 5 and 6 as well (other shapes: 6 x 192, 5 x 448, 5 x 960 slots; with
+    64-bit positions 3 x 192, 3 x 448, 4 x 960).  Every segment with a multi-hit probe forced through each of them,
+    with a generation counter that wraps every few probes in one of the passes: identical to the oracle."""
+    monkeypatch.setenv("ASGART_K7", "120")
+    monkeypatch.setenv("ASGART_FORCE_TIER", str(tier))
+    monkeypatch.setenv("ASGART_FORCE_WIDE", str(wide))
+    for name in ("dense_repeats", "satellites"):
+        pr, cli = _battery_case(name)
+        oidx = oracle.Index.build(pr.data)
+        with asgart_amd.Index(pr.data, oidx.sa) as idx:
+            for rc in (False, True):
+                idx.set_option("test_genbits", 3 if rc else 22)
+                idx.set_option("filter", 1 if (rc and tier % 2) else 0)
+                st = asgart_amd.RunSettings.from_cli(reverse=rc, complement=rc, **cli)
+                offs, sds = idx.search_duplications_raw(pr.chunks, st)
+                key = ("k7_battery", name, rc)
+                if key not in _ORACLE_CACHE:
+                    _ORACLE_CACHE[key] = oidx.run_raw(pr.chunks, oracle.make_settings(reverse=rc, complement=rc, **cli), threads=4)
+                eoffs, esds = _ORACLE_CACHE[key]
+                assert np.array_equal(offs, eoffs) and np.array_equal(sds, esds), (name, tier, wide, rc)
