@@ -341,7 +341,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
     if (opt.test_stall_s > 0) stall_kernel<<<1, 64, 0, s>>>((unsigned long long)opt.test_stall_s * 100000000ull);
     // ---- K1: probe search + filtered counts -----------------------------------
     HIP_TRY(hipEventRecord(cx.ev[0], s));
-    probe_count_kernel<SlotT, false><<<grid_for(W, kProbeBlock), kProbeBlock, 0, s>>>(
+    probe_count_kernel<SlotT, false><<<grid_for(W, kProbeBlock), kProbeThreads, 0, s>>>(
         ix, rp, p_lo, p_raw, p_filt, big_list, rank_list, d_ctr);
     HIP_TRY(hipEventRecord(cx.ev[11], s));
     collect_pending_kernel<<<std::min<uint32_t>((W + kCollectTile - 1) / kCollectTile, 256u * 8u), kCollectBlock, 0, s>>>(
@@ -1367,7 +1367,7 @@ int32_t asgart_get_stats(asgart_index *idx, uint32_t flags, asgart_stats *out) {
                 ix.flt = idx->d_filter[mode];
                 ix.flt_bits = idx->filter_bits;
                 ix.pbits = idx->opt.posbits ? idx->d_pbits[mode] : nullptr;
-                probe_count_kernel<SlotT, true><<<gp, kProbeBlock, 0, s>>>(
+                probe_count_kernel<SlotT, true><<<gp, kProbeThreads, 0, s>>>(
                     ix, rp, nullptr, nullptr, nullptr, nullptr, nullptr, d_ctr);
                 big_count_kernel<SlotT, true><<<2048, 256, 0, s>>>(
                     ix, rp, cx.ws.p_lo.as<SlotT>() - rp.g_lo, cx.ws.p_raw.as<uint32_t>() - rp.g_lo, nullptr,

@@ -124,143 +124,42 @@ __device__ inline unsigned long long lane_of(unsigned long long v, uint32_t l) {
 //
 // COUNT = true is the accounting pass behind bench.py's `kernel_algorithmic_bytes`: the same
 // control flow, no stores, every load / store of the real kernel priced in bytes.
-constexpr int kProbeBlock = 256;
+constexpr int kProbeBlock = 256;  // probes per workgroup (one tile)
+constexpr int kProbeThreads = 64; // ... run by ONE wave: every lane stages and tests four of them, then the survivors (a fifth of
+                                  // the tile on the GRCh38-shaped input: about one per lane) are looked up.  With four waves per tile
+                                  // three of them held their slots through the staging only to retire; a wave slot now spends most
+                                  // of its life in the dependent gathers of the lookup, and no barrier involves a second wave.
+constexpr int kProbeSub = kProbeBlock / kProbeThreads;
 constexpr int kRankMin = 256;  // intervals above this size are counted by bisection when the index has position-sorted lists
 constexpr int kMaxHalf = (kMaxKey + 1) / 2;                                 // bases per half (one-word keys)
 constexpr int kWinBytes = ((kProbeBlock + 2) * kMaxHalf + 15 + 16 + 15) / 16 * 16;  // <= 256 lanes x 16 B
 
 template <class SlotT, bool COUNT>
-__global__ __launch_bounds__(kProbeBlock) void probe_count_kernel(IndexView<SlotT> ix, RunParams rp,
-                                                                  SlotT *__restrict__ p_lo,
-                                                                  uint32_t *__restrict__ p_raw,
-                                                                  uint32_t *__restrict__ p_filt,
-                                                                  uint32_t *__restrict__ big_list,
-                                                                  uint32_t *__restrict__ rank_list,
-                                                                  unsigned long long *__restrict__ ctr) {
+__global__ __launch_bounds__(kProbeThreads) void probe_count_kernel(IndexView<SlotT> ix, RunParams rp,
+                                                                    SlotT *__restrict__ p_lo,
+                                                                    uint32_t *__restrict__ p_raw,
+                                                                    uint32_t *__restrict__ p_filt,
+                                                                    uint32_t *__restrict__ big_list,
+                                                                    uint32_t *__restrict__ rank_list,
+                                                                    unsigned long long *__restrict__ ctr) {
     __shared__ __attribute__((aligned(16))) uint8_t s_text[kWinBytes];
     __shared__ uint32_t s_half[kProbeBlock + 2];
     // the filter's answers for the workgroup's probes: 256 probes at stride k/2 = one contiguous run of bits
     constexpr int kPbLoads = (kProbeBlock * kMaxHalf + 127) / 128 + 2;  // 16-byte loads that cover it
     __shared__ __attribute__((aligned(16))) uint32_t s_pb[kPbLoads * 4];
+    __shared__ uint8_t s_surv[kProbeBlock];
     typename std::conditional<COUNT, CountBytes, NoBytes>::type cb;
-    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = threadIdx.x;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const uint32_t gb = rp.g_lo + blockIdx.x * (uint32_t)kProbeBlock;  // first probe of the workgroup
-    const uint32_t g = gb + tid;
     const uint32_t g_last = min(gb + (uint32_t)kProbeBlock, rp.g_hi) - 1u;
     const int k = rp.k, H = rp.step;
     // one chunk for the whole workgroup (all but a handful of workgroups): staged window
     const int c0 = chunk_of_uniform(rp.ch, gb);
     // (probes longer than one key word -- rare -- take the per-thread path as well)
     const bool uniform = rp.ch.pbase[c0 + 1] > g_last && k <= kMaxKey;
-    uint64_t s = 0, L = 0, i = 0, q = 0, q2 = 0;
-    uint32_t first = 0;
-    const bool valid = g < rp.g_hi;
-    long long pb_lo = 0;  // first bit held by s_pb
-    if (uniform) {
-        s = rp.ch.start[c0];
-        L = rp.ch.len[c0];
-        const uint64_t i0 = (uint64_t)(gb - rp.ch.pbase[c0] + 1) * (uint64_t)H;  // needle offset of probe gb
-        i = i0 + (uint64_t)tid * (uint64_t)H;
-        const int n_half = kProbeBlock + 2;
-        // text positions of half h, base j:  direct  b0 + h*H + j ;  reversed  e0 - h*H - j
-        const long long b0 = (long long)(s + i0), e0 = (long long)(s + L - 1u - i0);
-        const long long w_lo = rp.reverse ? e0 - (long long)n_half * H + 1 : b0;
-        const long long a_lo = w_lo & ~15ll;  // floor to 16 (two's complement: also for negatives)
-        const long long w_hi = rp.reverse ? e0 : b0 + (long long)n_half * H - 1;  // inclusive
-        const uint32_t n_load = (uint32_t)((w_hi - a_lo) / 16 + 1);  // <= kWinBytes / 16
-        if (tid < n_load) {
-            const long long a = a_lo + 16ll * tid;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (a >= 0 && (uint64_t)a + 16u <= ix.n + 64u) {  // the text allocation has 64 spare bytes
-                v = *reinterpret_cast<const uint4 *>(ix.text + a);
-                cb.rd16();
-            }
-            *reinterpret_cast<uint4 *>(s_text + 16u * tid) = v;
-        }
-        if (ix.pbits) {
-            // text positions the probes cover: direct  s + i0 + t H ;  reversed  s + L - i0 - k - t H
-            const long long p_first = rp.reverse ? (long long)(s + L - i0) - k - (long long)(kProbeBlock - 1) * H
-                                                 : (long long)(s + i0);
-            const long long byte_lo = (p_first >> 7) * 16;  // (floor: also for the negatives of the idle lanes)
-            pb_lo = byte_lo * 8;
-            const long long p_last = p_first + (long long)(kProbeBlock - 1) * H;
-            const uint32_t n_pb = (uint32_t)((p_last >> 7) - (p_first >> 7) + 1);  // <= kPbLoads
-            if (tid < n_pb) {
-                const long long a = byte_lo + 16ll * tid;
-                uint4 v = make_uint4(~0u, ~0u, ~0u, ~0u);
-                if (a >= 0 && (uint64_t)a + 16u <= ((ix.n + 63u) / 64u) * 8u + 512u) {  // (the allocation is padded)
-                    v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(ix.pbits) + a);
-                    cb.rd16();
-                }
-                *reinterpret_cast<uint4 *>(&s_pb[4u * tid]) = v;
-            }
-        }
-        __syncthreads();
-        for (uint32_t h = tid; h < (uint32_t)n_half; h += kProbeBlock) {
-            const long long p0 = rp.reverse ? (e0 - a_lo) - (long long)h * H : (b0 - a_lo) + (long long)h * H;
-            uint32_t v = 0;
-            for (int j = 0; j < H; ++j) {
-                uint32_t c = base_code(s_text[rp.reverse ? p0 - j : p0 + j]);
-                if (rp.complement) c = comp_code(c);
-                v = (v << 3) | c;
-            }
-            s_half[h] = v;
-        }
-        __syncthreads();
-        q = ((uint64_t)s_half[tid] << (3 * H)) | (uint64_t)s_half[tid + 1];
-        if (k & 1) q = (q << 3) | (uint64_t)(s_half[tid + 2] >> (3 * (H - 1)));
-        first = (uint32_t)(q >> (3 * (k - 1))) & 7u;
-    } else if (valid) {  // the workgroup straddles a chunk boundary: every thread on its own
-        const int c = chunk_of(rp.ch, g);
-        s = rp.ch.start[c];
-        L = rp.ch.len[c];
-        i = (uint64_t)(g - rp.ch.pbase[c] + 1) * (uint64_t)H;
-        q = probe_key(ix.text, s, L, i, k, rp.reverse, rp.complement, &first, &q2);
-        cb.rd((uint32_t)k);
-    }
-    // ---- presence filter (every probe), then the lookup of the survivors ---------------------------------
-    // About four probes in five are answered by the filter.  The lookup behind it -- prefix table, key bisection,
-    // suffix-array entries -- is a chain of dependent random gathers, and a wave runs it at the speed of its
-    // slowest lane however few lanes are left: the surviving probes of the workgroup are therefore compacted
-    // (wave ballot + one LDS atomic per wave) and looked up by the first ceil(n / 64) waves with all lanes busy;
-    // the other waves retire at once and their slots go to the next workgroup, so that more full waves of
-    // gathers are in flight per CU.
-    __shared__ uint32_t s_nsurv;
-    __shared__ uint8_t s_surv[kProbeBlock];
-    if (tid == 0) s_nsurv = 0;  // (ordered before its first use by the barrier behind the filter tests)
     uint32_t n_rej = 0;
-    bool survivor = false;
-    if (valid) {
-        if (first == 4u) {  // needle[i] == 'N'  (automaton.rs:100-102)
-            if (!COUNT) p_filt[g] = kSkipN;
-            cb.wr(4);
-        } else {
-            survivor = true;
-            if (ix.pbits) {  // the filter's answer, by the text position the probe covers
-                const long long p = rp.reverse ? (long long)(s + L - i) - k : (long long)(s + i);
-                if (uniform) {
-                    const uint32_t b = (uint32_t)(p - pb_lo);
-                    survivor = (s_pb[b >> 5] >> (b & 31u)) & 1u;
-                } else {
-                    cb.rd(8);
-                    survivor = (ix.pbits[(uint64_t)p >> 6] >> ((uint64_t)p & 63u)) & 1ull;
-                }
-            } else if (ix.flt && !is_tail_corner(ix, q)) {
-                cb.rd(8);
-                survivor = filter_test(ix.flt, ix.flt_bits, q);
-            }
-            if (!survivor) {
-                // no hit possible: in the direct pass the interval is the probe itself
-                if (!COUNT) {
-                    p_raw[g] = (!rp.reverse && !rp.complement) ? 1u : 0u;
-                    p_filt[g] = 0u;
-                }
-                cb.wr(8);
-                n_rej = 1;
-            }
-        }
-    }
-    // one probe's lookup: SA interval, filtered count of a small interval (large ones go to big_list)
+    // one probe's lookup: SA interval, filtered count of a small interval (large ones are marked for the wave kernels)
     auto lookup = [&](uint32_t g_, uint64_t q_, uint64_t q2_, uint64_t i_, uint64_t s_, uint64_t L_) {
         uint64_t lo, hi;
         ProbeRef pr;  // (read only by probes of more than 42 bases)
@@ -287,65 +186,165 @@ __global__ __launch_bounds__(kProbeBlock) void probe_count_kernel(IndexView<Slot
             if (!COUNT) p_filt[g_] = cnt > rp.C ? kSkipCard : cnt;
             cb.wr(4);
         } else {
-            // a large interval is only MARKED here; collect_pending_kernel turns the marks into the two work lists.
-            // (A workgroup-aggregated append from this kernel cost every workgroup a returning atomic on one of two
-            // adjacent counters: 1.2 M workgroups per GRCh38-sized pass at the ~90 same-address atomics per
-            // microsecond the chip sustains is the whole duration of this kernel.)
+            // a large interval is only MARKED here; collect_pending_kernel turns the marks into the two work lists (a
+            // workgroup-aggregated append from this kernel cost every workgroup a returning atomic on one of two adjacent
+            // counters and a barrier that its retired waves never reached).
             // a whole k-mer interval of some size: its kept count is a bisection of the position-sorted list
             if (!COUNT) p_filt[g_] = (ix.sap && all_occurrences && raw > (uint64_t)kRankMin) ? kPendingRank : kPending;
             cb.wr(4 + 4);  // + its work-list entry (written by the collecting pass)
             cb.rd(4);      //   ... which reads the mark back
         }
     };
+    // a probe the presence filter (or its first base) answers: what is written for it; -> true: it has to be looked up
+    auto screen = [&](uint32_t g_, uint32_t first_, bool pass_) {
+        if (first_ == 4u) {  // needle[i] == 'N'  (automaton.rs:100-102)
+            if (!COUNT) p_filt[g_] = kSkipN;
+            cb.wr(4);
+            return false;
+        }
+        if (!pass_) {
+            // no hit possible: in the direct pass the interval is the probe itself
+            if (!COUNT) {
+                p_raw[g_] = (!rp.reverse && !rp.complement) ? 1u : 0u;
+                p_filt[g_] = 0u;
+            }
+            cb.wr(8);
+            n_rej += 1;
+            return false;
+        }
+        return true;
+    };
     if (uniform) {
-        const unsigned long long sm = __ballot(survivor);
-        const uint32_t lane = tid & 63u;
-        __syncthreads();  // s_nsurv = 0 is visible
-        if (sm) {
-            uint32_t base = 0;
-            if (lane == (uint32_t)(__ffsll((long long)sm) - 1)) base = atomicAdd(&s_nsurv, (uint32_t)__popcll(sm));
-            base = __shfl(base, __ffsll((long long)sm) - 1);
-            if (survivor) s_surv[base + (uint32_t)__popcll(sm & ((1ull << lane) - 1ull))] = (uint8_t)tid;
+        const uint64_t s = rp.ch.start[c0], L = rp.ch.len[c0];
+        const uint64_t i0 = (uint64_t)(gb - rp.ch.pbase[c0] + 1) * (uint64_t)H;  // needle offset of probe gb
+        const int n_half = kProbeBlock + 2;
+        // text positions of half h, base j:  direct  b0 + h*H + j ;  reversed  e0 - h*H - j
+        const long long b0 = (long long)(s + i0), e0 = (long long)(s + L - 1u - i0);
+        const long long w_lo = rp.reverse ? e0 - (long long)n_half * H + 1 : b0;
+        const long long a_lo = w_lo & ~15ll;  // floor to 16 (two's complement: also for negatives)
+        const long long w_hi = rp.reverse ? e0 : b0 + (long long)n_half * H - 1;  // inclusive
+        const uint32_t n_load = (uint32_t)((w_hi - a_lo) / 16 + 1);  // <= kWinBytes / 16
+        for (uint32_t t = lane; t < n_load; t += kProbeThreads) {   // (three rounds, all in flight together)
+            const long long a = a_lo + 16ll * t;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (a >= 0 && (uint64_t)a + 16u <= ix.n + 64u) {  // the text allocation has 64 spare bytes
+                v = *reinterpret_cast<const uint4 *>(ix.text + a);
+                cb.rd16();
+            }
+            *reinterpret_cast<uint4 *>(s_text + 16u * t) = v;
+        }
+        long long pb_lo = 0;  // first bit held by s_pb
+        if (ix.pbits) {
+            // text positions the probes cover: direct  s + i0 + t H ;  reversed  s + L - i0 - k - t H
+            const long long p_first = rp.reverse ? (long long)(s + L - i0) - k - (long long)(kProbeBlock - 1) * H
+                                                 : (long long)(s + i0);
+            const long long byte_lo = (p_first >> 7) * 16;  // (floor: also for the negatives of the idle lanes)
+            pb_lo = byte_lo * 8;
+            const long long p_last = p_first + (long long)(kProbeBlock - 1) * H;
+            const uint32_t n_pb = (uint32_t)((p_last >> 7) - (p_first >> 7) + 1);  // <= kPbLoads
+            if (lane < n_pb) {
+                const long long a = byte_lo + 16ll * lane;
+                uint4 v = make_uint4(~0u, ~0u, ~0u, ~0u);
+                if (a >= 0 && (uint64_t)a + 16u <= ((ix.n + 63u) / 64u) * 8u + 512u) {  // (the allocation is padded)
+                    v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(ix.pbits) + a);
+                    cb.rd16();
+                }
+                *reinterpret_cast<uint4 *>(&s_pb[4u * lane]) = v;
+            }
+        }
+        __syncthreads();  // (one wave: the barrier orders its own LDS traffic)
+        for (uint32_t h = lane; h < (uint32_t)n_half; h += kProbeThreads) {
+            const long long p0 = rp.reverse ? (e0 - a_lo) - (long long)h * H : (b0 - a_lo) + (long long)h * H;
+            uint32_t v = 0;
+            for (int j = 0; j < H; ++j) {
+                uint32_t c = base_code(s_text[rp.reverse ? p0 - j : p0 + j]);
+                if (rp.complement) c = comp_code(c);
+                v = (v << 3) | c;
+            }
+            s_half[h] = v;
         }
         __syncthreads();
-        const uint32_t n_surv = s_nsurv;
-        // (the accounting pass keeps every wave: its totals are reduced by the whole workgroup below)
-        if (!COUNT && (tid & ~63u) >= n_surv) return;  // this wave has nothing to look up
-        const uint64_t i0 = i - (uint64_t)tid * (uint64_t)H;
-        for (uint32_t j = tid; j < n_surv; j += kProbeBlock) {
-            const uint32_t t = s_surv[j];
+        auto key_of = [&](uint32_t t) {
             uint64_t qt = ((uint64_t)s_half[t] << (3 * H)) | (uint64_t)s_half[t + 1];
             if (k & 1) qt = (qt << 3) | (uint64_t)(s_half[t + 2] >> (3 * (H - 1)));
-            lookup(gb + t, qt, 0ull, i0 + (uint64_t)t * (uint64_t)H, s, L);
+            return qt;
+        };
+        // ---- presence filter (every probe), then the lookup of the survivors ---------------------------------
+        // About four probes in five are answered by the filter.  The lookup behind it -- prefix table, key bisection,
+        // suffix-array entries -- is a chain of dependent random gathers, and a wave runs it at the speed of its
+        // slowest lane however few lanes are left: the survivors of the tile are compacted (ballots) so that the
+        // lookups run with the lanes full.
+        uint32_t n_surv = 0;
+#pragma unroll
+        for (int u = 0; u < kProbeSub; ++u) {
+            const uint32_t t = lane + (uint32_t)u * kProbeThreads, g = gb + t;
+            bool survivor = false;
+            if (g < rp.g_hi) {
+                const uint64_t q = key_of(t);
+                const uint32_t first = (uint32_t)(q >> (3 * (k - 1))) & 7u;
+                bool pass = true;
+                if (first != 4u) {
+                    const uint64_t i = i0 + (uint64_t)t * (uint64_t)H;
+                    if (ix.pbits) {  // the filter's answer, by the text position the probe covers
+                        const long long p = rp.reverse ? (long long)(s + L - i) - k : (long long)(s + i);
+                        const uint32_t b = (uint32_t)(p - pb_lo);
+                        pass = (s_pb[b >> 5] >> (b & 31u)) & 1u;
+                    } else if (ix.flt && !is_tail_corner(ix, q)) {
+                        cb.rd(8);
+                        pass = filter_test(ix.flt, ix.flt_bits, q);
+                    }
+                }
+                survivor = screen(g, first, pass);
+            }
+            const unsigned long long sm = __ballot(survivor);
+            if (survivor) s_surv[n_surv + (uint32_t)__popcll(sm & lt_mask)] = (uint8_t)t;
+            n_surv += (uint32_t)__popcll(sm);
+        }
+        __syncthreads();
+        for (uint32_t j = lane; j < n_surv; j += kProbeThreads) {
+            const uint32_t t = s_surv[j];
+            lookup(gb + t, key_of(t), 0ull, i0 + (uint64_t)t * (uint64_t)H, s, L);
         }
     } else {
-        __syncthreads();
-        if (survivor) lookup(g, q, q2, i, s, L);
+        // the tile straddles a chunk boundary (or the probes are longer than one key word): every probe on its own
+#pragma unroll 1
+        for (int u = 0; u < kProbeSub; ++u) {
+            const uint32_t g = gb + lane + (uint32_t)u * kProbeThreads;
+            if (g >= rp.g_hi) continue;
+            const int c = chunk_of(rp.ch, g);
+            const uint64_t s = rp.ch.start[c], L = rp.ch.len[c];
+            const uint64_t i = (uint64_t)(g - rp.ch.pbase[c] + 1) * (uint64_t)H;
+            uint32_t first = 0;
+            uint64_t q2 = 0;
+            const uint64_t q = probe_key(ix.text, s, L, i, k, rp.reverse, rp.complement, &first, &q2);
+            cb.rd((uint32_t)k);
+            bool pass = true;
+            if (first != 4u) {
+                if (ix.pbits) {
+                    const long long p = rp.reverse ? (long long)(s + L - i) - k : (long long)(s + i);
+                    cb.rd(8);
+                    pass = (ix.pbits[(uint64_t)p >> 6] >> ((uint64_t)p & 63u)) & 1ull;
+                } else if (ix.flt && !is_tail_corner(ix, q)) {
+                    cb.rd(8);
+                    pass = filter_test(ix.flt, ix.flt_bits, q);
+                }
+            }
+            if (screen(g, first, pass)) lookup(g, q, q2, i, s, L);
+        }
     }
     if constexpr (COUNT) {
-        // workgroup totals -> two global atomics
-        __shared__ unsigned long long s_tot[3];
-        if (tid < 3) s_tot[tid] = 0;
-        __syncthreads();
         unsigned long long b = cb.n, r = n_rej, b16 = cb.n16;
         for (int off = 32; off > 0; off >>= 1) {
             b += __shfl_down(b, off);
             r += __shfl_down(r, off);
             b16 += __shfl_down(b16, off);
         }
-        if ((tid & 63u) == 0) {
-            atomicAdd(&s_tot[0], b);
-            atomicAdd(&s_tot[1], r);
-            atomicAdd(&s_tot[2], b16);
-        }
-        __syncthreads();
-        if (tid == 0) {
-            atomicAdd(&ctr[CT_ALG_BYTES], s_tot[0]);
-            if (s_tot[1]) atomicAdd(&ctr[CT_FLT_REJECTED], s_tot[1]);
-            if (s_tot[2]) atomicAdd(&ctr[CT_ALG_BYTES16], s_tot[2]);
+        if (lane == 0) {
+            atomicAdd(&ctr[CT_ALG_BYTES], b);
+            if (r) atomicAdd(&ctr[CT_FLT_REJECTED], r);
+            if (b16) atomicAdd(&ctr[CT_ALG_BYTES16], b16);
         }
     }
-    // (no barrier behind the lookups: the waves that retired above never meet the others again)
 }
 
 // The probes probe_count_kernel marked as large intervals -> the two work lists (big_list: counted by streaming the
