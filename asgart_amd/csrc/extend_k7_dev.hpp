@@ -303,6 +303,11 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                     }
                     rs = s_crs[L * (NWA * 64) + tid];
                 };
+                // (a wave that holds arms goes first wherever it shares a SIMD with waves that only index or wait)
+                if (NT >= 1024 && P.hi_prio) {
+                    if (livemask) __builtin_amdgcn_s_setprio(3);
+                    else __builtin_amdgcn_s_setprio(0);
+                }
                 bool cmd_loaded = livemask != 0u;  // (a wave without arms reads the rest of the command when it gets one)
                 if (livemask) {
                     c1 = cq[1]; c2 = cq[2]; c3 = cq[3]; c4 = cq[4]; c5 = cq[5];

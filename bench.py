@@ -569,10 +569,17 @@ def main():
 
         per_chunk = max(100_000, int(budget_bp / max(1, len(pr.chunks))))
         if "ASGART_CPU_SAMPLE_BP" not in os.environ and per_chunk > 2_000_000:
-            bp0, t0_ = cpu_sample(per_chunk // 20)
+            # (grown at most four-fold at a time: the cost per base is far from uniform along a chunk -- the first
+            # 200 kb of a record say nothing about the satellite array 3 Mb further on)
             target_s = float(os.environ.get("ASGART_CPU_SAMPLE_S", 20.0))
-            per_chunk = int(min(per_chunk, max(per_chunk // 20, (per_chunk // 20) * target_s / max(t0_, 1e-3))))
-        sample_bp, t_cpu = cpu_sample(per_chunk)
+            cap, per_chunk = per_chunk, per_chunk // 20
+            while True:
+                sample_bp, t_cpu = cpu_sample(per_chunk)
+                if per_chunk >= cap or t_cpu >= target_s / 3:
+                    break
+                per_chunk = min(cap, int(per_chunk * min(4.0, max(1.5, target_s / max(t_cpu, 1e-3)))))
+        else:
+            sample_bp, t_cpu = cpu_sample(per_chunk)
         out["cpu_baseline"] = {
             "value": round(sample_bp * passes / t_cpu / 1e6, 3), "unit": "Mbp/s", "cores": cores,
             "kind": "port",
