@@ -120,15 +120,16 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
     constexpr uint32_t kNever = 0xFFFFFFFEu;   // what a candidate read of an idle lane returns: no creation number
     constexpr uint32_t kCoop = 0xFFFFFFFFu;    // candidate register: more than three / wide window / stash overflow
     constexpr uint32_t kStash = 64;
-    constexpr uint32_t kRowsLoop = 6;
+    constexpr uint32_t kRowsWalk = 62;  // rows of a window that an arm walks itself (beyond its first two: by the rows' occupancy bits)
+    constexpr uint32_t kBitWords = (uint32_t)kRows / 32u;
     constexpr bool kWidePos = sizeof(PosT) == 8;
     constexpr uint32_t kTagShift = kWidePos ? 42u : 32u;
     constexpr uint32_t kGenMax = kWidePos ? 12u : 22u;
     constexpr unsigned long long kPosMask = (1ull << kTagShift) - 1ull;
     constexpr uint32_t kTabBytes = (uint32_t)(kRows * kE * 8);  // one hit table
-    constexpr uint32_t kCmdWords = 24;
+    constexpr uint32_t kCmdWords = 32;  // (24 in use: a command is read as one word per lane, two commands per read)
     using WinT = typename std::conditional<kWidePos, uint64_t, uint32_t>::type;
-    static_assert(NW >= 2 && HB <= 1024 && S <= 8 && NE <= 128 && (kRows & (kRows - 1)) == 0 && (kE == 2 || kE == 4), "shape");
+    static_assert(NW >= 2 && HB <= 1024 && S <= 8 && NE <= 128 && (kRows & (kRows - 1)) == 0 && (kE == 2 || kE == 4) && kRows <= 2048, "shape");
     if (NT >= 1024 && P.hi_prio) __builtin_amdgcn_s_setprio(3);
 
     __shared__ __attribute__((aligned(16))) unsigned long long s_tab[2][kRows * kE];
@@ -136,6 +137,7 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
     __shared__ uint8_t s_hflag[2 * HB];
     __shared__ __attribute__((aligned(16))) uint32_t s_best[3][HB];
     __shared__ unsigned long long s_stash[3][kStash];
+    __shared__ uint32_t s_rowbits[3][kRows / 32];                      // per probe in flight (as the stashes): which rows of its hit table hold a hit
     __shared__ __attribute__((aligned(16))) uint32_t s_nstash[4];      // (three in use)
     __shared__ __attribute__((aligned(16))) uint32_t s_free[NWA][8];   // per (arm wave, layer): empty slots
     __shared__ __attribute__((aligned(16))) uint32_t s_base[NWA][8];   // per (arm wave, layer): rank of its first empty slot
@@ -164,6 +166,9 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
     RecAlloc rec_alloc;
     K7T_DECL;
     K7U_DECL;
+#ifdef ASGART_PROFILE_EXTEND
+    unsigned long long k7_sum_a = 0, k7_sum_cnt = 0, k7_sum_n = 0;
+#endif
 
     PosT a_ls[S], a_re[S];
     uint32_t a_thr[S], a_gap[S], a_seq[S], c_h[S];
@@ -193,6 +198,7 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
     for (uint32_t n_fetch = 0; !P.max_items || n_fetch < P.max_items; ++n_fetch) {
         if (tid == 0) s_bcast = atomicAdd(P.cursor, 1ull);
         if (tid < 4) s_nstash[tid] = 0u;
+        for (uint32_t j = tid; j < 3u * kBitWords; j += NT) (&s_rowbits[0][0])[j] = 0u;
         if (tid < 2) s_fam[tid] = 0u;
         for (uint32_t j = tid; j < (uint32_t)(NWA * 8); j += NT) (&s_free[0][0])[j] = 64u;
         lds_barrier();
@@ -229,8 +235,9 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                 const PosT x = s_hits[off + h];
                 *reinterpret_cast<uint32_t *>(best0 + besto + 4u * h) = kNone;
                 unsigned long long e = ((unsigned long long)(g10 | h) << kTagShift) | ((unsigned long long)x & kPosMask);
-                unsigned long long *row = reinterpret_cast<unsigned long long *>(
-                    tab0 + tabo + (((uint32_t)((uint64_t)x >> bsh)) & (uint32_t)(kRows - 1)) * (uint32_t)(kE * 8));
+                const uint32_t ri = ((uint32_t)((uint64_t)x >> bsh)) & (uint32_t)(kRows - 1);
+                unsigned long long *row = reinterpret_cast<unsigned long long *>(tab0 + tabo + ri * (uint32_t)(kE * 8));
+                atomicOr(&s_rowbits[bb][ri >> 5], 1u << (ri & 31u));
                 bool placed = false;
 #pragma unroll
                 for (int j = 0; j < kE; ++j) {
@@ -276,22 +283,24 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
             mid_actions(uni(s_mid[0]));
             lds_barrier();  // (2) the rows are in; the first two commands are there
             uint32_t pv_off = 0, pv_besto = 0;  // the previous probe's rows and winners (as in the last command)
+            const uint32_t *const mid_ptr = lane < 8 ? &s_mid[lane] : (lane < 16 ? &s_base[wave][lane - 8] : (lane < 20 ? &s_nstash[lane - 16] : &s_mid[0]));
             for (uint32_t sc = 0, sp = 0;; sc = sc == 2u ? 0u : sc + 1u, sp ^= 1u) {
                 K7T_MARK();
                 K7T_STEP();
                 K7U_MARK();
                 // ---- every read that depends on nothing read in this step, in one go ---------------------------
                 const uint32_t sn = sc == 2u ? 0u : sc + 1u;  // the next step's command
-                const uint4 *cq = reinterpret_cast<const uint4 *>(&s_cmd[sc][0]);
-                const uint4 *nq = reinterpret_cast<const uint4 *>(&s_cmd[sn][0]);
-                const uint4 c0 = cq[0], n0 = nq[0];
-                uint4 c1 = make_uint4(0, 0, 0, 0), c2 = c1, c3 = c1, c4 = c1, c5 = c1;
+                // (this step's command in lanes 0-31, the next step's in lanes 32-63: ONE 4-byte read per lane, the
+                // fields taken out with v_readlane.  Sixteen waves that each broadcast six 16-byte words of the same
+                // block to all their lanes right behind a barrier kept the LDS return path busy for ~500 cycles.)
+                const uint32_t cw = s_cmd[lane < 32 ? sc : sn][lane & 31];
+                auto C = [&](int j) { return (uint32_t)__builtin_amdgcn_readlane((int)cw, j); };
+                auto N = [&](int j) { return (uint32_t)__builtin_amdgcn_readlane((int)cw, 32 + j); };
                 // (of the arms, layer 0 -- where they sit unless a burst of a dense repeat is under way -- reads ahead;
                 // the layers above read when their turn comes: five layers' worth of loads in flight would not fit
                 // the register file)
                 uint32_t cb0[3] = {0, 0, 0};
                 PosT xb0[3] = {0, 0, 0}, rs0 = 0;
-                uint4 nst = make_uint4(0, 0, 0, 0);
                 auto read_candidates = [&](int L, uint32_t (&cb)[3], PosT (&xb)[3], PosT &rs) {
                     const uint32_t ch = c_h[L];
                     const uint32_t nc = (a_seq[L] == kNoSeq || ch == kCoop) ? 0u : ch >> 30;
@@ -308,12 +317,8 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                     if (livemask) __builtin_amdgcn_s_setprio(3);
                     else __builtin_amdgcn_s_setprio(0);
                 }
-                bool cmd_loaded = livemask != 0u;  // (a wave without arms reads the rest of the command when it gets one)
-                if (livemask) {
-                    c1 = cq[1]; c2 = cq[2]; c3 = cq[3]; c4 = cq[4]; c5 = cq[5];
-                    if (livemask & 1u) read_candidates(0, cb0, xb0, rs0);
-                }
-                const uint32_t flags = uni(c0.x);
+                if (livemask & 1u) read_candidates(0, cb0, xb0, rs0);
+                const uint32_t flags = C(0);
                 if (K7_RARE(flags & K7_GIVEUP)) {
                     overflow = true;
                     break;
@@ -323,28 +328,22 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                 // the hits of this step's probe when it opened a batch (its rows arrived with the last barrier), and those of
                 // the NEXT step's probe otherwise: indexed by the top arm waves while the others resolve
                 if (K7_RARE(has_cur && late)) {
-                    const uint32_t cnt = uni(c0.y);
-                    if (indexes(cnt)) {
-                        const uint4 d1 = cq[1], d4 = cq[4];
-                        insert_hits(cnt, uni(c0.z), uni(c0.w), uni(d1.x), uni(cq[2].y), uni(d1.y), uni(d4.w));
-                    }
+                    const uint32_t cnt = C(1);
+                    if (indexes(cnt)) insert_hits(cnt, C(2), C(3), C(4), C(9), C(5), C(19));
                 }
                 if (K7_USUAL(!(flags & K7_LAST))) {
-                    const uint32_t nflags = uni(n0.x), ncnt = uni(n0.y);
-                    if (K7_RARE((nflags & K7_CUR) && !(nflags & K7_LATE) && indexes(ncnt))) {
-                        const uint4 n1 = nq[1], n2 = nq[2], n4 = nq[4];
-                        insert_hits(ncnt, uni(n0.z), uni(n0.w), uni(n1.x), uni(n2.y), uni(n1.y), uni(n4.w));
-                    }
+                    const uint32_t nflags = N(0), ncnt = N(1);
+                    if (K7_RARE((nflags & K7_CUR) && !(nflags & K7_LATE) && indexes(ncnt)))
+                        insert_hits(ncnt, N(2), N(3), N(4), N(9), N(5), N(19));
                 }
                 K7U_LAP(0);
                 uint32_t wasfree = 0;  // per lane, bit L: the slot of layer L was empty before this step
                 if (K7_RARE(!livemask)) {
                     wasfree = (1u << S) - 1u;
                 } else {
-                    // (vector registers that hold the same value in every lane: the command's fields)
-                    const uint32_t k = c4.x, step = c4.y, G = c4.z, pend = c2.x;
-                    const uint32_t p_i = c3.x;  // low word of the previous probe's needle offset
-                    const uint64_t M = ((uint64_t)c5.y << 32) | c5.x;
+                    const uint32_t k = C(16), step = C(17), G = C(18), pend = C(8);
+                    const uint32_t p_i = C(12);  // low word of the previous probe's needle offset
+                    const uint64_t M = ((uint64_t)C(21) << 32) | C(20);
 #pragma unroll
                     for (int L = 0; L < S; ++L) {
                         if (!(livemask >> L)) {
@@ -384,7 +383,7 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                             unsigned long long sm = __ballot(coop);
                             K7C(55, __popcll(sm));
                             if (K7_RARE(sm != 0ull)) {  // more than three candidates / wide window: resolved cooperatively
-                                const uint32_t p_cnt = uni(c2.w), p_off = pv_off;
+                                const uint32_t p_cnt = C(11), p_off = pv_off;
                                 while (sm) {
                                     const uint32_t l = (uint32_t)(__ffsll((long long)sm) - 1);
                                     sm &= sm - 1ull;
@@ -431,7 +430,7 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                         // between the previous probe and this one
                         uint32_t thr_new;
                         if constexpr (kWidePos) {
-                            const uint64_t p_i64 = ((uint64_t)c3.y << 32) | c3.x;
+                            const uint64_t p_i64 = ((uint64_t)C(13) << 32) | C(12);
                             thr_new = arm_threshold((uint64_t)(p_i64 + k) - (uint64_t)a_ls[L], G);
                         } else {
                             thr_new = max(G, ((p_i + k) - (uint32_t)a_ls[L]) / 10u);
@@ -440,7 +439,7 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                         const uint32_t aged = sum_g > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)sum_g;
                         a_re[L] = won ? (PosT)(xw + k) : a_re[L];
                         PosT le_new;
-                        if constexpr (kWidePos) le_new = (PosT)((((uint64_t)c3.y << 32) | c3.x) + k);
+                        if constexpr (kWidePos) le_new = (PosT)((((uint64_t)C(13) << 32) | C(12)) + k);
                         else le_new = (PosT)(p_i + k);
                         if (won) s_cle[L * (NWA * 64) + tid] = le_new;
                         a_thr[L] = won ? thr_new : a_thr[L];
@@ -456,11 +455,11 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                 // ---- offers of the arms of layer L to the hits of the step's probe; only the lanes with `who` set take
                 // part; returns the candidate word of the lane ---------------------------------------------------------
                 auto offers = [&](int L, bool who, uint32_t ns) -> uint32_t {
-                    const uint32_t k = c4.x, g10 = c1.y, bsh = uni(c4.w);
-                    char *const tab = tab0 + c0.w;
-                    char *const best = best0 + c1.x;
+                    const uint32_t k = C(16), g10 = C(5), bsh = C(19);
+                    char *const tab = tab0 + C(3);
+                    char *const best = best0 + C(4);
                     const bool povf = ns > kStash;
-                    const WinT w_loop = (WinT)(kRowsLoop - 1u) << bsh;
+                    const WinT w_loop = (WinT)(kRowsWalk - 1u) << bsh;
                     const PosT lo = (PosT)(a_re[L] - k + 1u);
                     const WinT w = (WinT)a_thr[L] + (WinT)(k - 1u);
                     const uint32_t key = a_seq[L];
@@ -468,10 +467,10 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                     const WinT w_eff = narrow ? w : (WinT)0;  // (an empty window accepts nothing)
                     uint32_t ch = 0, nc = 0;
                     uint32_t *const sink = &s_sink[lane];
-                    auto offer = [&](unsigned long long e) {
+                    auto offer = [&](unsigned long long e, WinT wl) {
                         const uint32_t d = tag_of(e) - g10;
                         const WinT t = d < 1024u ? (WinT)(PosT)(pos_of(e) - lo) : ~(WinT)0;
-                        const bool ok = t < w_eff;
+                        const bool ok = t < wl;
 #ifdef ASGART_K7_MASKED_MIN
                         if (ok) atomicMin(reinterpret_cast<uint32_t *>(best + 4u * (d & 1023u)), key);
 #else
@@ -480,16 +479,6 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                         ch = ok ? ((ch << 10) | d) : ch;
                         nc += ok ? 1u : 0u;
                     };
-                    auto offer_row = [&](uint32_t b) {
-                        const ulonglong2 *rr = reinterpret_cast<const ulonglong2 *>(tab + (b & (uint32_t)(kRows - 1)) * (uint32_t)(kE * 8));
-                        if constexpr (kE == 4) {
-                            const ulonglong2 f0 = rr[0], f1 = rr[1];
-                            offer(f0.x); offer(f0.y); offer(f1.x); offer(f1.y);
-                        } else {
-                            const ulonglong2 f0 = rr[0];
-                            offer(f0.x); offer(f0.y);
-                        }
-                    };
                     const uint32_t b0 = (uint32_t)((uint64_t)lo >> bsh);
                     const uint32_t n_rows = narrow ? (uint32_t)((((uint64_t)lo & ((1ull << bsh) - 1ull)) + (uint64_t)w - 1ull) >> bsh) + 1u : 0u;
                     {   // the two rows of a narrow window: all reads in flight together
@@ -497,20 +486,43 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                         const ulonglong2 *r1 = reinterpret_cast<const ulonglong2 *>(tab + ((b0 + 1u) & (uint32_t)(kRows - 1)) * (uint32_t)(kE * 8));
                         if constexpr (kE == 4) {
                             const ulonglong2 e0 = r0[0], e1 = r0[1], e2 = r1[0], e3 = r1[1];
-                            offer(e0.x); offer(e0.y); offer(e1.x); offer(e1.y);
-                            offer(e2.x); offer(e2.y); offer(e3.x); offer(e3.y);
+                            offer(e0.x, w_eff); offer(e0.y, w_eff); offer(e1.x, w_eff); offer(e1.y, w_eff);
+                            offer(e2.x, w_eff); offer(e2.y, w_eff); offer(e3.x, w_eff); offer(e3.y, w_eff);
                         } else {
                             const ulonglong2 e0 = r0[0], e2 = r1[0];
-                            offer(e0.x); offer(e0.y); offer(e2.x); offer(e2.y);
+                            offer(e0.x, w_eff); offer(e0.y, w_eff); offer(e2.x, w_eff); offer(e2.y, w_eff);
                         }
                     }
-                    for (uint32_t r = 2; K7_RARE(__ballot(r < n_rows) != 0ull); ++r) {
+                    // The rows behind the first two (an arm of more than ~1 kb has a window of three rows, one of 50 kb
+                    // of fifty): the occupancy bits of the probe's table say which of them hold a hit at all -- a
+                    // probe's hits are kilobases apart, a wide window mostly holds none -- and only those are read.
+                    if (__ballot(n_rows > 2u) != 0ull) {
                         K7C(53, 1);
-                        offer_row(b0 + r);
+                        const uint32_t len = n_rows > 2u ? n_rows - 2u : 0u;                 // <= kRowsWalk - 1 < 64
+                        const uint32_t s0 = (b0 + 2u) & (uint32_t)(kRows - 1);                // first of them (table row)
+                        const uint32_t *const bits = &s_rowbits[C(9)][0];
+                        const uint32_t w0 = s0 >> 5, sh = s0 & 31u;
+                        const uint32_t v0 = bits[w0], v1 = bits[(w0 + 1u) & (kBitWords - 1u)], v2 = bits[(w0 + 2u) & (kBitWords - 1u)];
+                        unsigned long long m = ((((unsigned long long)v1 << 32) | v0) >> sh) | (sh ? (unsigned long long)v2 << (64u - sh) : 0ull);
+                        m &= (1ull << len) - 1ull;
+                        while (__ballot(m != 0ull) != 0ull) {
+                            const bool act = m != 0ull;
+                            const uint32_t r = act ? (uint32_t)(__ffsll((long long)m) - 1) : 0u;
+                            m &= m - 1ull;
+                            const ulonglong2 *rr = reinterpret_cast<const ulonglong2 *>(tab + ((s0 + r) & (uint32_t)(kRows - 1)) * (uint32_t)(kE * 8));
+                            const WinT wl = act ? w_eff : (WinT)0;
+                            if constexpr (kE == 4) {
+                                const ulonglong2 f0 = rr[0], f1 = rr[1];
+                                offer(f0.x, wl); offer(f0.y, wl); offer(f1.x, wl); offer(f1.y, wl);
+                            } else {
+                                const ulonglong2 f0 = rr[0];
+                                offer(f0.x, wl); offer(f0.y, wl);
+                            }
+                        }
                     }
                     if (K7_RARE(ns != 0u)) {
-                        const uint32_t bb = uni(c2.y);
-                        for (uint32_t s = 0; s < min(ns, kStash); ++s) offer(s_stash[bb][s]);
+                        const uint32_t bb = C(9);
+                        for (uint32_t s = 0; s < min(ns, kStash); ++s) offer(s_stash[bb][s], w_eff);
                     }
                     ch = nc > 3u ? kCoop : (ch & 0x3FFFFFFFu) | (nc << 30);
                     // arms too wide for the table walk -- and every arm when the stash overflowed
@@ -518,7 +530,7 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                     if (K7_RARE(sm != 0ull)) {
                         if (who && (!narrow || povf)) ch = kCoop;
                         K7C(54, __popcll(sm));
-                        const uint32_t cnt = uni(c0.y), off = uni(c0.z);
+                        const uint32_t cnt = C(1), off = C(2);
                         while (sm) {
                             const uint32_t l = (uint32_t)(__ffsll((long long)sm) - 1);
                             sm &= sm - 1ull;
@@ -541,12 +553,6 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                     }
                     return ch;
                 };
-                // the stash count of the step's probe (final when its hits are indexed)
-                auto stash_count = [&](const uint4 &n4) {
-                    const uint32_t bb = c2.y;
-                    return uni(bb == 0u ? n4.x : (bb == 1u ? n4.y : n4.z));
-                };
-                (void)nst;
                 K7U_LAP(2);
                 K7T_LAP(0);
                 lds_barrier();  // ---- barrier 1 --------------------------------------------------------------
@@ -554,41 +560,29 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                 K7U_MARK();
                 // ---------------------------------------------------------------- interval B ----------------
                 const bool had_live = livemask != 0u;
-                const uint4 m0v = *reinterpret_cast<const uint4 *>(&s_mid[0]);
-                const uint32_t b_first = s_base[wave][0];
-                uint4 bs0 = make_uint4(0, 0, 0, 0), bs1 = bs0, nst2 = bs0;
-                if (had_live) {  // (a wave without arms looks at the rest when it turns out to receive some)
-                    bs0 = *reinterpret_cast<const uint4 *>(&s_base[wave][0]);
-                    if constexpr (S > 4) bs1 = *reinterpret_cast<const uint4 *>(&s_base[wave][4]);
-                    if (has_cur) nst2 = *reinterpret_cast<const uint4 *>(&s_nstash[0]);
-                }
-                const uint32_t mflags = uni(m0v.x);
+                // (lanes 0-7: the mid-step block; 8-15: this wave's slot ranks; 16-19: the stash counts)
+                const uint32_t mw = *mid_ptr;
+                auto MW = [&](uint32_t j) { return (uint32_t)__builtin_amdgcn_readlane((int)mw, (int)j); };
+                const uint32_t mflags = MW(0);
                 if (K7_RARE(mflags & K7_OVF)) {
                     overflow = true;
                     break;
                 }
-                const uint32_t n_new = has_prev ? uni(m0v.y) : 0u;
-                const uint32_t seq_base = m0v.z, fam_b = m0v.w;
+                const uint32_t n_new = has_prev ? MW(1) : 0u;
+                const uint32_t seq_base = MW(2), fam_b = MW(3);
                 K7U_LAP(3);
-                const bool receives = n_new != 0u && uni(b_first) < n_new;
+                const bool receives = n_new != 0u && MW(8) < n_new;
                 if (receives || (has_cur && livemask)) {
-                    if (K7_RARE(!cmd_loaded)) {  // (this wave had no arms and now receives some)
-                        c1 = cq[1]; c2 = cq[2]; c3 = cq[3]; c4 = cq[4]; c5 = cq[5];
-                        bs0 = *reinterpret_cast<const uint4 *>(&s_base[wave][0]);
-                        if constexpr (S > 4) bs1 = *reinterpret_cast<const uint4 *>(&s_base[wave][4]);
-                        if (has_cur) nst2 = *reinterpret_cast<const uint4 *>(&s_nstash[0]);
-                        cmd_loaded = true;
-                    }
-                    const uint32_t base_r[8] = {bs0.x, bs0.y, bs0.z, bs0.w, bs1.x, bs1.y, bs1.z, bs1.w};
-                    const uint32_t ns_b = has_cur ? stash_count(nst2) : 0u;
-                    const uint32_t k = c4.x, step = c4.y, G = c4.z, pend = c2.x, thr0 = c5.z;
-                    const uint64_t M = ((uint64_t)c5.y << 32) | c5.x;
+                    // the stash count of the step's probe (final when its hits are indexed)
+                    const uint32_t ns_b = has_cur ? MW(16u + C(9)) : 0u;
+                    const uint32_t k = C(16), step = C(17), G = C(18), pend = C(8), thr0 = C(22);
+                    const uint64_t M = ((uint64_t)C(21) << 32) | C(20);
                     PosT p_i;
-                    if constexpr (kWidePos) p_i = (PosT)(((uint64_t)c3.y << 32) | c3.x);
-                    else p_i = (PosT)c3.x;
+                    if constexpr (kWidePos) p_i = (PosT)(((uint64_t)C(13) << 32) | C(12));
+                    else p_i = (PosT)C(12);
 #pragma unroll
                     for (int L = 0; L < S; ++L) {
-                        const uint32_t b_r = n_new ? uni(base_r[L]) : 0u;
+                        const uint32_t b_r = n_new ? MW(8u + (uint32_t)L) : 0u;
                         const bool reach = n_new != 0u && b_r < n_new;  // (the empty slots of the lower layers take the rest)
                         if (!reach && !(livemask >> L)) break;
                         bool take = false;
@@ -644,8 +638,8 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                 K7T_LAP(2);
                 lds_barrier();  // ---- barrier 2 --------------------------------------------------------------
                 K7T_LAP(3);
-                pv_off = c0.z;
-                pv_besto = c1.x;
+                pv_off = C(2);
+                pv_besto = C(4);
                 if (K7_RARE(flags & K7_LAST)) break;
             }
             if (wave == 0u) K7T_FLUSH(1);
@@ -897,6 +891,11 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                         if constexpr (NE > 64)
                             if (lane + 64 < NE) s_base[(lane + 64) % NWA][(lane + 64) / NWA] = fincl2 - fv2;
                         const uint32_t A0 = (uint32_t)CAP - total_free;  // live arms after the quiet probes' deaths
+#ifdef ASGART_PROFILE_EXTEND
+                        k7_sum_a += A0;
+                        k7_sum_cnt += prev.cnt;
+                        ++k7_sum_n;
+#endif
                         if (fam_open && A0 == 0 && prev.t_before >= spur_until) {  // the flush of src/automaton.rs:182-200
                             ++fam_seq;
                             next_seq = 0;
@@ -945,6 +944,7 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                     mid_actions(mflags);
                     // the stash of the probe after next is the previous probe's: nobody reads it any more
                     if (lane == 0 && have_prev) s_nstash[prev.bb] = 0u;
+                    if (have_prev && (uint32_t)lane < kBitWords) s_rowbits[prev.bb][lane] = 0u;  // (kRows <= 2048: one word per lane)
                     const bool more = !(flags & K7_LAST);
                     // the step after next: planned now, while the arm waves create and offer
                     Plan p_after{};
@@ -967,6 +967,15 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                 }
             }
             K7T_FLUSH(0);
+#ifdef ASGART_PROFILE_EXTEND
+            if (lane == 0) {  // (the dump's "sumA", "sumCnt", "lds_probes")
+                atomicAdd(&P.ctr[26], k7_sum_a);
+                atomicAdd(&P.ctr[27], k7_sum_cnt);
+                atomicAdd(&P.ctr[21], k7_sum_n);
+                atomicMax(&P.ctr[29], k7_sum_n);
+            }
+            k7_sum_a = k7_sum_cnt = k7_sum_n = 0;
+#endif
             if (!overflow) {
                 lds_barrier();  // (3)
                 // nothing alive is left behind unless the chunk (or the window of a sharded call) ended first

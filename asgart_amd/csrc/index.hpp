@@ -128,6 +128,16 @@ namespace asgart {
 // Everything one search call mutates.  The index owns two of them so that two passes (say the
 // direct and the -RC run, reference src/bin/asgart.rs runs them as separate invocations) can be
 // in flight at once from two host threads; text, suffix array and keys are shared read-only.
+// Two passes issued by one passes call (pipeline.hip): the first one holds back every extension tier but the one with
+// its longest segments until the second one's search phases are through -- persistent extension workgroups own their
+// compute units until their work list is empty, and a search kernel dispatched behind them crawls (measured at GRCh38
+// size: 117 ms instead of 28 for the second pass's front, which then sets the critical path of the step).
+struct PassGate {
+    std::atomic<int> *front_done = nullptr;       // set when this call's probes are searched and its segments placed
+    std::atomic<int> *next_front_done = nullptr;  // the same of the pass issued behind this one (null: hold nothing back)
+    std::atomic<int> *next_finished = nullptr;    // ... or that pass is over (it may have failed before its front)
+};
+
 struct SearchCtx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr, stream3 = nullptr, stream4 = nullptr;  // concurrent extension tiers
@@ -140,6 +150,7 @@ struct SearchCtx {
     uint32_t last_P = 0;
     bool busy = false;
     volatile uint64_t *progress = nullptr;  // of the call in flight (asgart_search_duplications), or null
+    struct PassGate *gate = nullptr;  // passes call: what this call signals to / waits for from the pass issued behind it
     // pinned host staging for the sorted output records (a pageable target makes the D2H copy several
     // times slower than the kernels that produce it); grow-only, freed with the index
     void *h_pinned = nullptr;
@@ -234,6 +245,12 @@ struct Options {
     int64_t wg_items = 0;           // segments a workgroup of tiers 3..7 runs before it retires (0: persistent)
     int64_t wg_items12 = 0;         // ... work-list fetches (8 segments / 1 segment) of a tier-1 / tier-2 wave
     int64_t rank_lists = 1;         // 1: position-sorted occurrence lists for the cardinality test (k <= 21, no --trim)
+    int64_t pass_gate = 0;          // passes call: 1 = the first pass launches its long-segment tier (3) at once and the other tiers when the
+                                    // second pass's search phases are done (or pass_gate_ms later); 0 = all tiers at once.  Measured at
+                                    // GRCh38 size and left off: the second pass's front drops from 117 to 31 ms, but both passes' tiers then
+                                    // start together and the second pass's longest segments queue behind the first one's workgroups (step
+                                    // 247 -> 270 ms)
+    int64_t pass_gate_ms = 120;
     int64_t rank_runs = 1;          // how they are built: 1 = only the runs of more than 256 equal keys, by a segmented sort in place
                                     // (any slot width); 0 = all slots by two device-wide pair sorts (32-bit slots only: without it an
                                     // index of 64-bit slots has no lists)
@@ -264,6 +281,8 @@ struct Options {
                                     // to run), 0 = by their arm bound like any other segment (smaller shapes: several per compute unit)
     int64_t dense3 = 16;            // with k7 in tier 3: long segments go there only with at least this many hits per processed probe on
                                     // average (0: all of them); the sparse long ones run on tier 6's kernel
+    int64_t dense6 = 0;             // with k7 in tier 3: segments of ANY length whose arm bound sends them to tier 6 go to tier 3 instead with at
+                                    // least this many hits per processed probe on average (0: off)
     int64_t prewarm = 1;            // 1: asgart_index_prepare also reserves the per-probe workspace of both call contexts (sized for an
                                     // unsharded call over the whole text) and starts the worker thread of the passes call, so that the first
                                     // search calls allocate nothing chip-sized; 0: everything on first use (hosts that only issue sharded calls)

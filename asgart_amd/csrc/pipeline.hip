@@ -474,16 +474,17 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
         }
         auto tier_enabled = [&](int t) { return t >= 1 && t <= kTiers && tier_cap[t] != 0; };
         PlaceParams pp;
-        pp.long3 = pp.long3_big = pp.dense3 = 0;
+        pp.long3 = pp.long3_big = pp.dense3 = pp.dense6 = 0;
         pp.sparse_to6 = (uint32_t)opt.sparse_to6;
         for (int t = 1; t < kTiers; ++t) pp.cap[t - 1] = tier_cap[t];
         if (arms_kernel) {
             pp.long3 = (uint32_t)opt.long3;
             pp.long3_big = opt.long3_big >= 0 ? (uint32_t)opt.long3_big : pp.long3 / 4u;
             if (k7_tier(3) && tier_cap[6]) pp.dense3 = (uint32_t)opt.dense3;
+            if (k7_tier(3) && tier_cap[6] && !k7_tier(6)) pp.dense6 = (uint32_t)opt.dense6;
             if (force_tier == 3) {
                 pp.long3 = pp.long3_big = 1;
-                pp.dense3 = 0;
+                pp.dense3 = pp.dense6 = 0;
             }
             pp.cap[0] = (uint32_t)std::min<int64_t>(opt.cap1, kArmCapSmall);
         }
@@ -752,7 +753,31 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             auto since_launch = [&]() {
                 return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_launch).count();
             };
-            for (char c : tier_order) launch_tier(c - '0');
+            PassGate *const gate = attempt == 0 ? cx.gate : nullptr;
+            if (gate && gate->front_done) gate->front_done->store(1, std::memory_order_release);
+            if (gate && gate->next_front_done && opt.pass_gate && !force_tier) {
+                // (struct PassGate, index.hpp) the tier of the longest segments now -- they are this pass's floor --,
+                // the others when the pass behind this one has had the chip for its search phases
+                launch_tier(3);
+                HIP_TRY(hipGetLastError());
+                if (cx.progress && !progress_given) {
+                    HIP_TRY(hipEventSynchronize(cx.ev[3]));
+                    signal_progress();
+                    progress_given = true;
+                }
+                const auto t_gate = std::chrono::steady_clock::now();
+                while (!gate->next_front_done->load(std::memory_order_acquire) &&
+                       !(gate->next_finished && gate->next_finished->load(std::memory_order_acquire)) &&
+                       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_gate).count() < (double)opt.pass_gate_ms)
+                    std::this_thread::sleep_for(std::chrono::microseconds(50));
+                if (opt.debug)
+                    fprintf(stderr, "[asgart] held the tiers behind tier 3 back for %.1f ms (the next pass's search phases)\n",
+                            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_gate).count());
+                for (char c : tier_order)
+                    if (c != '3') launch_tier(c - '0');
+            } else {
+                for (char c : tier_order) launch_tier(c - '0');
+            }
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(cx.ev[12], st7));
             HIP_TRY(hipEventRecord(cx.ev[5], st2));
@@ -1013,6 +1038,8 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
     return 0;
 }
 
+static thread_local PassGate *tl_pass_gate = nullptr;  // set by the passes call around its run_search
+
 int32_t run_search(asgart_index *idx, const uint64_t *chunks, int64_t n_chunks,
                    const asgart_settings *st, int32_t shard, int32_t n_shards, bool want_csr,
                    asgart_families *fam_out, std::vector<uint8_t> *status_out,
@@ -1065,6 +1092,7 @@ int32_t run_search(asgart_index *idx, const uint64_t *chunks, int64_t n_chunks,
     }
     SearchCtx &cx = idx->ctx[which];
     cx.progress = progress;
+    cx.gate = tl_pass_gate;
     int32_t rc;
     if (idx->wide)
         rc = run_search_t<uint64_t>(idx, cx, chunks, n_chunks, st, shard, n_shards, want_csr, fam_out,
@@ -1073,6 +1101,7 @@ int32_t run_search(asgart_index *idx, const uint64_t *chunks, int64_t n_chunks,
         rc = run_search_t<uint32_t>(idx, cx, chunks, n_chunks, st, shard, n_shards, want_csr, fam_out,
                                     status_out, rowoff_out, hits_out);
     cx.progress = nullptr;
+    cx.gate = nullptr;
     {
         std::lock_guard<std::mutex> lk(idx->mu);
         ++idx->calls_total;
@@ -1251,8 +1280,9 @@ int32_t asgart_search_duplications_passes_shard(asgart_index *idx, const uint64_
     std::vector<int32_t> rcs((size_t)n_passes, 0);
     std::vector<std::string> errs((size_t)n_passes);
     std::vector<std::vector<uint64_t>> prog((size_t)n_passes, std::vector<uint64_t>((size_t)std::max<int64_t>(n_chunks, 1), 0));
-    std::vector<std::atomic<int>> finished((size_t)n_passes);
+    std::vector<std::atomic<int>> finished((size_t)n_passes), front_done((size_t)n_passes);
     for (auto &f : finished) f.store(0);
+    for (auto &f : front_done) f.store(0);
     auto searched = [&](int32_t p) {
         if (finished[p].load(std::memory_order_acquire)) return true;
         const volatile uint64_t *pr = prog[p].data();
@@ -1272,8 +1302,18 @@ int32_t asgart_search_duplications_passes_shard(asgart_index *idx, const uint64_
                 rcs[p] = ASGART_E_OOM;
                 errs[p] = "out of host memory";
             } else {
+                // (only the first pass holds tiers back: the second one has a context of its own from the start, a third
+                // one would wait for a context and the second for it)
+                PassGate gate;
+                gate.front_done = &front_done[(size_t)p];
+                if (p == 0 && n_passes > 1) {
+                    gate.next_front_done = &front_done[1];
+                    gate.next_finished = &finished[1];
+                }
+                tl_pass_gate = &gate;
                 rcs[p] = run_search(idx, chunks, n_chunks, &settings[j], shard, n_shards, false, f, nullptr, nullptr,
                                     nullptr, prog[p].data());
+                tl_pass_gate = nullptr;
                 if (rcs[p] != 0) {
                     errs[p] = asgart_last_error();  // the message is thread-local
                     delete f;

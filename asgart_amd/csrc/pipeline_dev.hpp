@@ -1583,6 +1583,8 @@ struct PlaceParams {
     uint32_t long3;             // > 0: tier 3 is reserved for segments of at least this many probes
     uint32_t long3_big;         // ... or this many, for segments beyond tier 5's capacity
     uint32_t sparse_to6;        // 1: the long segments that are not dense go to tier 6 (its kernel is the old tier-3 one); 0: by capacity
+    uint32_t dense6;            // > 0: segments bound for tier 6 by their arms go to tier 3 (when they fit it) with at least this
+                                // many hits per processed probe: the dense ones of ANY length on the kernel with a control wave
     uint32_t dense3;            // > 0: ... and only the DENSE ones (at least this many hits per processed probe on average:
                                 // tandem arrays); the sparse long ones (a chromosome against its homologue: a few hits per
                                 // probe, mostly run by one wave alone) go to tier 6's kernel -- set when tier 3 runs the
@@ -1627,7 +1629,10 @@ __device__ inline int place_tier(uint32_t bound, unsigned long long sum, uint32_
     }
     for (int t = 2; t < kTiers; ++t) {
         if (t == 3 && pp.long3) continue;
-        if (bound <= pp.cap[t - 1]) return t;
+        if (bound <= pp.cap[t - 1]) {
+            if (t == 6 && pp.dense6 && bound <= pp.cap[2] && sum >= (unsigned long long)pp.dense6 * n_probes) return 3;
+            return t;
+        }
     }
     return kTiers;
 }
