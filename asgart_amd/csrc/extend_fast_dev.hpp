@@ -99,14 +99,16 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
     // kCoop: more than three, a window too wide for the table walk, or a probe whose stash overflowed
     constexpr uint32_t kCoop = 0xFFFFFFFFu;
     constexpr uint32_t kStash = 64;
-    constexpr uint32_t kRowsLoop = 6;          // windows of up to this many rows are looked up by the arm itself
+    constexpr uint32_t kRowsLoop = 62;         // windows of up to this many rows are looked up by the arm itself (beyond the first two rows:
+                                               // those whose occupancy bit is set)
+    constexpr uint32_t kBitWords = (uint32_t)kRows / 32u;
     constexpr bool kWidePos = sizeof(PosT) == 8;
     // entry: 32-bit positions  [gen:22 | hit:10 | x:32];  64-bit positions  [gen:12 | hit:10 | x:42]
     constexpr uint32_t kTagShift = kWidePos ? 42u : 32u;
     constexpr uint32_t kGenMax = kWidePos ? 12u : 22u;
     constexpr unsigned long long kPosMask = (1ull << kTagShift) - 1ull;
     using WinT = typename std::conditional<kWidePos, uint64_t, uint32_t>::type;
-    static_assert(HB <= 1024 && S <= 8 && S * NW <= 128 && (kRows & (kRows - 1)) == 0 && (kE == 2 || kE == 4), "shape");
+    static_assert(HB <= 1024 && S <= 8 && S * NW <= 128 && (kRows & (kRows - 1)) == 0 && (kE == 2 || kE == 4) && kRows >= 128 && kRows <= 2048, "shape");
     if (NT >= 1024 && P.hi_prio) __builtin_amdgcn_s_setprio(3);
 
     __shared__ __attribute__((aligned(16))) unsigned long long s_tab[2][kRows * kE];
@@ -115,6 +117,7 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
     __shared__ uint32_t s_best[3][HB];
     __shared__ unsigned long long s_stash[3][kStash];
     __shared__ uint32_t s_nstash[3];
+    __shared__ uint32_t s_rowbits[3][kRows / 32];  // per probe in flight (as the stashes): which rows of its hit table hold a hit
     __shared__ __attribute__((aligned(16))) uint32_t s_free[2][NW][8];  // per (wave, layer): empty slots
     __shared__ unsigned long long s_newmask[NW][HB / 64]; // per wave: unmatched hits of each group of 64
     __shared__ unsigned long long s_bcast;
@@ -179,6 +182,7 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
     for (uint32_t n_fetch = 0; !P.max_items || n_fetch < P.max_items; ++n_fetch) {
         if (tid == 0) s_bcast = atomicAdd(P.cursor, 1ull);
         if (tid < 3) s_nstash[tid] = 0u;  // (a probe indexed ahead but never reached may have left entries)
+        for (uint32_t j = tid; j < 3u * kBitWords; j += NT) (&s_rowbits[0][0])[j] = 0u;
         lds_barrier();
         const unsigned long long seg = uni(s_bcast);
         lds_barrier();
@@ -230,7 +234,9 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
                 const PosT x = s_hits[off + h];
                 s_best[bb][h] = kNone;
                 unsigned long long e = ((unsigned long long)(g10 | h) << kTagShift) | ((unsigned long long)x & kPosMask);
-                unsigned long long *row = &s_tab[tb][(((uint32_t)((uint64_t)x >> bsh)) & (uint32_t)(kRows - 1)) * (uint32_t)kE];
+                const uint32_t ri = ((uint32_t)((uint64_t)x >> bsh)) & (uint32_t)(kRows - 1);
+                unsigned long long *row = &s_tab[tb][ri * (uint32_t)kE];
+                atomicOr(&s_rowbits[bb][ri >> 5], 1u << (ri & 31u));
                 bool placed = false;
 #pragma unroll
                 for (int j = 0; j < kE; ++j) {
@@ -310,24 +316,15 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
                         const WinT w_eff = narrow ? w : (WinT)0;  // (an empty window accepts nothing)
                         uint32_t ch = 0, nc = 0;
                         uint32_t *const sink = &s_sink[lane];
-                        auto offer = [&](unsigned long long e) {
+                        auto offer_w = [&](unsigned long long e, WinT wl) {
                             const uint32_t d = tag_of(e) - g10;
                             const WinT t = d < 1024u ? (WinT)(PosT)(pos_of(e) - lo) : ~(WinT)0;  // (no scalar AND of two masks)
-                            const bool ok = t < w_eff;
+                            const bool ok = t < wl;
                             atomicMin(ok ? &s_best[bb][d & 1023u] : sink, key);
                             ch = ok ? ((ch << 10) | d) : ch;
                             nc += ok ? 1u : 0u;
                         };
-                        auto offer_row = [&](uint32_t b) {
-                            const ulonglong2 *rr = reinterpret_cast<const ulonglong2 *>(&s_tab[tb][(b & (uint32_t)(kRows - 1)) * (uint32_t)kE]);
-                            if constexpr (kE == 4) {
-                                const ulonglong2 f0 = rr[0], f1 = rr[1];
-                                offer(f0.x); offer(f0.y); offer(f1.x); offer(f1.y);
-                            } else {
-                                const ulonglong2 f0 = rr[0];
-                                offer(f0.x); offer(f0.y);
-                            }
-                        };
+                        auto offer = [&](unsigned long long e) { offer_w(e, w_eff); };
                         const uint32_t b0 = (uint32_t)((uint64_t)lo >> bsh);
                         const uint32_t n_rows = narrow ? (uint32_t)((((uint64_t)lo & ((1ull << bsh) - 1ull)) + (uint64_t)w - 1ull) >> bsh) + 1u : 0u;
                         {   // the two rows of a narrow window: all reads in flight together
@@ -347,8 +344,32 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
                             povf = ns > kStash;
                             ns_known = true;
                         }
-                        // (rows beyond a lane's own window hold nothing its range test accepts)
-                        for (uint32_t r = 2; __ballot(r < n_rows); ++r) offer_row(b0 + r);
+                        // The rows behind the first two (an arm of more than ~1 kb has a window of three rows, one of
+                        // 50 kb of fifty): the occupancy bits of the probe's table say which of them hold a hit at all --
+                        // a probe's hits are kilobases apart, a wide window mostly holds none -- and only those are read.
+                        if (__ballot(n_rows > 2u) != 0ull) {
+                            const uint32_t len = n_rows > 2u ? n_rows - 2u : 0u;   // <= kRowsLoop - 2 < 64
+                            const uint32_t s0 = (b0 + 2u) & (uint32_t)(kRows - 1);  // first of them (table row)
+                            const uint32_t *const bits = &s_rowbits[bb][0];
+                            const uint32_t w0 = s0 >> 5, sh = s0 & 31u;
+                            const uint32_t v0 = bits[w0], v1 = bits[(w0 + 1u) & (kBitWords - 1u)], v2 = bits[(w0 + 2u) & (kBitWords - 1u)];
+                            unsigned long long m = ((((unsigned long long)v1 << 32) | v0) >> sh) | (sh ? (unsigned long long)v2 << (64u - sh) : 0ull);
+                            m &= (1ull << len) - 1ull;
+                            while (__ballot(m != 0ull) != 0ull) {
+                                const bool act = m != 0ull;
+                                const uint32_t r = act ? (uint32_t)(__ffsll((long long)m) - 1) : 0u;
+                                m &= m - 1ull;
+                                const ulonglong2 *rr = reinterpret_cast<const ulonglong2 *>(&s_tab[tb][((s0 + r) & (uint32_t)(kRows - 1)) * (uint32_t)kE]);
+                                const WinT wl = act ? w_eff : (WinT)0;
+                                if constexpr (kE == 4) {
+                                    const ulonglong2 f0 = rr[0], f1 = rr[1];
+                                    offer_w(f0.x, wl); offer_w(f0.y, wl); offer_w(f1.x, wl); offer_w(f1.y, wl);
+                                } else {
+                                    const ulonglong2 f0 = rr[0];
+                                    offer_w(f0.x, wl); offer_w(f0.y, wl);
+                                }
+                            }
+                        }
                         for (uint32_t s = 0; s < min(ns, kStash); ++s) offer(s_stash[bb][s]);
                         ch = nc > 3u ? kCoop : (ch & 0x3FFFFFFFu) | (nc << 30);
                         // arms too wide for the table walk -- and every arm when the stash overflowed
@@ -829,6 +850,7 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
                     // wave 0 alone; the others wait for its count at the barrier and will re-read the bookkeeping
                     if (pre_indexed) {  // (this probe was indexed ahead for nothing: forget its stash)
                         if (tid == 0) s_nstash[tri] = 0u;
+                        if ((uint32_t)tid < kBitWords) s_rowbits[tri][tid] = 0u;
                         pre_indexed = false;
                     }
                     if (wave == 0u) {
@@ -899,6 +921,7 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
                 phase_a(cur.cnt, cur.off, true, cur.tb, cur.bb);
                 pend = 0;
                 if (tid == 0) s_nstash[(tri + 2u) % 3u] = 0u;  // the stash of the probe after next (indexed in the next interval)
+                if ((uint32_t)tid < kBitWords) s_rowbits[(tri + 2u) % 3u][tid] = 0u;  // ... and its rows' occupancy bits
                 PROF_STOP(4);
                 PROF_START();
                 {   // next hit probe of this staged batch, if any: the top threads index it in this interval
