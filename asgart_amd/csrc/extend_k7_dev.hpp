@@ -145,9 +145,10 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
     // and the one the control wave is writing):
     //   0 flags          1 cnt            2 off (s_hits)    3 byte offset of its hit table
     //   4 byte offset of its best[]       5 generation tag  6,7 needle offset i
-    //   8 age of the quiet probes before it                 9 stash index    10 -   11 hits of the previous probe
+    //   8 age of the quiet probes before it                 9 stash index    10 K7_STAGE / K7_CLEAR of the step BEFORE it   11 hits of the previous probe
     //  12,13 needle offset of the previous probe           14 its rows (s_hits)     15 byte offset of its best[]
     //  16 k    17 step    18 G    19 log2 bucket width     20,21 min_duplication_length    22 threshold of a new arm  23 -
+    //  24,25 first CSR entry, 26 count, 27 buffer of the batch to stage in the step BEFORE it (when word 10 says so)
     __shared__ __attribute__((aligned(16))) uint32_t s_cmd[3][kCmdWords];
     __shared__ __attribute__((aligned(16))) uint32_t s_mid[8];         // decided in interval A, read in interval B
     __shared__ uint32_t s_fam[2];                                      // family ordinal as of the step (by step parity)
@@ -265,7 +266,36 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                 if (use_flag) s_hflag[buf * (uint32_t)HB + r] = P.hit_flag[base + r];
             }
         };
-        // what interval B does for everyone once the mid-step block is known
+        // ... in two halves: the rows are requested at the top of a step (the request rides in the NEXT step's command, which
+        // every wave reads there) and written to LDS in its interval B -- the HBM / L2 round trip of a batch start (one
+        // step in six to twelve on a tandem array) is over by then instead of sitting in front of barrier 2
+        constexpr int kPf = (HB + NT - 1) / NT;
+        PosT pf_x[kPf];
+        uint8_t pf_f[kPf];
+        auto fetch_rows = [&](unsigned long long base, uint32_t tot) {
+#pragma unroll
+            for (int j = 0; j < kPf; ++j) {
+                const uint32_t r = (uint32_t)tid + (uint32_t)(j * NT);
+                pf_x[j] = r < tot ? P.hits[base + r] : (PosT)0;
+                pf_f[j] = (use_flag && r < tot) ? P.hit_flag[base + r] : (uint8_t)0;
+            }
+        };
+        auto store_rows = [&](uint32_t tot, uint32_t buf) {
+#pragma unroll
+            for (int j = 0; j < kPf; ++j) {
+                const uint32_t r = (uint32_t)tid + (uint32_t)(j * NT);
+                if (r < tot) {
+                    s_hits[buf * (uint32_t)HB + r] = pf_x[j];
+                    if (use_flag) s_hflag[buf * (uint32_t)HB + r] = pf_f[j];
+                }
+            }
+        };
+        // what interval B does for everyone once the mid-step block is known (in the step loop: fetched = the rows of a
+        // staging request are in this thread's registers already)
+        auto mid_actions_f = [&](uint32_t mflags, uint32_t tot, uint32_t buf) {
+            if (K7_RARE(mflags & K7_STAGE)) store_rows(tot, buf);
+            if (K7_RARE(mflags & K7_CLEAR)) clear_table();
+        };
         auto mid_actions = [&](uint32_t mflags) {
             if (K7_RARE(mflags & K7_STAGE)) {
                 const uint4 m1 = *reinterpret_cast<const uint4 *>(&s_mid[4]);
@@ -319,6 +349,9 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                 }
                 if (livemask & 1u) read_candidates(0, cb0, xb0, rs0);
                 const uint32_t flags = C(0);
+                // (the rows that this step's interval B stages: requested now)
+                const uint32_t npre = (flags & (K7_LAST | K7_GIVEUP)) ? 0u : N(10);
+                if (K7_RARE(npre & K7_STAGE)) fetch_rows(((unsigned long long)N(25) << 32) | N(24), N(26));
                 if (K7_RARE(flags & K7_GIVEUP)) {
                     overflow = true;
                     break;
@@ -617,7 +650,7 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                     }
                 }
                 K7U_LAP(4);
-                mid_actions(mflags);
+                mid_actions_f(mflags, N(26), N(27));
                 if (had_live || receives) {  // free counts, as the control wave will rank them in the next step (an idle
                                              // wave's stay as they are: all empty)
                     uint32_t nfv[8] = {64u, 64u, 64u, 64u, 64u, 64u, 64u, 64u};
@@ -819,8 +852,9 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                     uint4 *o = reinterpret_cast<uint4 *>(&s_cmd[slot][0]);
                     o[0] = make_uint4(p.flags, p.q.cnt, p.q.off, p.q.tb * kTabBytes);
                     o[1] = make_uint4(p.q.bb * (uint32_t)(HB * 4), p.q.g10, (uint32_t)p.q.i, (uint32_t)(p.q.i >> 32));
-                    o[2] = make_uint4(p.q.pend, p.q.bb, 0u, before.q.cnt);
+                    o[2] = make_uint4(p.q.pend, p.q.bb, p.pre, before.q.cnt);
                     o[3] = make_uint4((uint32_t)before.q.i, (uint32_t)(before.q.i >> 32), before.q.off, before.q.bb * (uint32_t)(HB * 4));
+                    if (p.pre & K7_STAGE) o[6] = make_uint4((uint32_t)p.st_base, (uint32_t)(p.st_base >> 32), p.st_tot, p.st_buf);
                 }
             };
             if (lane < 3) {  // the run's constants, once per segment, in every command block
@@ -868,6 +902,7 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                                     p_next.q.g10, bsh);
                     // what rides in this step's interval B was decided when the NEXT step was planned
                     uint32_t mflags = (flags & K7_LAST) ? 0u : p_next.pre;
+                    if (mflags & K7_STAGE) fetch_rows(p_next.st_base, p_next.st_tot);
                     uint32_t n_new = 0, seq_base = 0;
                     if (have_prev) {
                         // empty slots as published at the end of the previous step, ranked (layer, wave, lane)
@@ -941,7 +976,7 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                         overflow = true;
                         break;
                     }
-                    mid_actions(mflags);
+                    mid_actions_f(mflags, p_next.st_tot, p_next.st_buf);
                     // the stash of the probe after next is the previous probe's: nobody reads it any more
                     if (lane == 0 && have_prev) s_nstash[prev.bb] = 0u;
                     if (have_prev && (uint32_t)lane < kBitWords) s_rowbits[prev.bb][lane] = 0u;  // (kRows <= 2048: one word per lane)
