@@ -503,6 +503,31 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
                     hw = (was_free || coop) ? 0u : hw;
                     PosT xw = s_hits[off + (hw ? hw - 1u : 0u)];
                     unsigned long long sm = __ballot(coop);
+                    // Many such arms at once (a short-period tandem repeat: every arm's window holds a dozen hits of the
+                    // probe): one pass over the HITS instead of one over the hits per arm -- the arm that won hit h is the
+                    // one whose creation number is best[h], no window test needed; hits in ascending order, so the last
+                    // one an arm won stays.  (The longest segments of tiers 2, 4, 5 and 6 of a GRCh38-shaped pass spent
+                    // 6-54 K cycles per probe in the per-arm loop below.)
+                    if (sm != 0ull && (uint32_t)__popcll(sm) * 8u >= cnt) {
+                        if (lane == 0) DBG_ADD(10, 1);
+                        for (uint32_t h0 = 0; h0 < cnt; h0 += 64u) {
+                            const uint32_t h = h0 + (uint32_t)lane;
+                            const PosT xh = h < cnt ? s_hits[off + h] : (PosT)0;
+                            const uint32_t bh = h < cnt ? s_best[bb][h] : kNone;
+                            const uint32_t nh = min(64u, cnt - h0);
+                            for (uint32_t j = 0; j < nh; ++j) {
+                                const uint32_t b = lane_of(bh, j);
+                                PosT x;
+                                if constexpr (kWidePos) x = (PosT)lane_of((unsigned long long)xh, j);
+                                else x = (PosT)lane_of((uint32_t)xh, j);
+                                const bool mine = coop && a_seq[L] == b;
+                                hw = mine ? h0 + j + 1u : hw;
+                                xw = mine ? x : xw;
+                            }
+                        }
+                        sm = 0ull;
+                    }
+                    if (lane == 0 && sm) DBG_ADD(5, __popcll(sm));
                     while (sm) {  // more than three candidates / wide window: resolved cooperatively
                         const uint32_t l = (uint32_t)(__ffsll((long long)sm) - 1);
                         sm &= sm - 1ull;
@@ -536,9 +561,13 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
                     a_gap[L] = won ? 0u : aged;
                     const bool dead = !was_free && !won && aged >= G;  // never matches again
                     if (__ballot(dead)) {
+                        if (lane == 0) DBG_ADD(6, 1);
                         const PosT rs = s_crs[L * NT + tid];
                         const bool report = dead && (uint64_t)(a_re[L] - rs) >= rp.M;
-                        if (__ballot(report)) emit_records(report, a_ls[L], s_cle[L * NT + tid], rs, a_re[L], a_seq[L]);
+                        if (__ballot(report)) {
+                            if (lane == 0) DBG_ADD(7, 1);
+                            emit_records(report, a_ls[L], s_cle[L * NT + tid], rs, a_re[L], a_seq[L]);
+                        }
                     }
                     a_seq[L] = dead ? kNoSeq : a_seq[L];
                 }
@@ -547,6 +576,7 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
                     const uint32_t base_r = L * NW < 64 ? lane_of(fincl - fv, (uint32_t)(L * NW) + wave)
                                                         : lane_of(fincl2 - fv2, (uint32_t)(L * NW - 64) + wave);
                     if (base_r < n_new) {
+                        if (lane == 0) DBG_ADD(cnt <= 64u ? 8 : 9, 1);
                         const uint32_t r = base_r + (uint32_t)__popcll(fmask & lt_mask);
                         const bool take = was_free && r < n_new;
                         uint32_t hsel = 0;
@@ -979,7 +1009,11 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
 #pragma unroll
         for (int L = 0; L < S; ++L) a_seq[L] = kNoSeq;
         livemask = 0;
+#ifdef ASGART_PROF_WAVE0
+        if (wave == 0u) {  // (diagnostic build with -DASGART_PROF_WAVE0: the wave that holds the first arms reports)
+#else
         if (wave == min(P.n_levels, (uint32_t)(NW - 1))) {  // (diagnostic build: option test_levels picks the reporting wave)
+#endif
             PROF_FLUSH();
         }
         lds_barrier();

@@ -329,25 +329,26 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                 // (of the arms, layer 0 -- where they sit unless a burst of a dense repeat is under way -- reads ahead;
                 // the layers above read when their turn comes: five layers' worth of loads in flight would not fit
                 // the register file)
+                // (the winners of an arm's candidates only: the position of the hit it won is read when the winner is
+                // known -- one dependent read in an interval whose length the control wave sets -- and the right start of
+                // an arm when it is reported.  Seven reads per layer, step and wave right behind the barrier were the
+                // larger part of the burst every wave's first round trip queued in.)
                 uint32_t cb0[3] = {0, 0, 0};
-                PosT xb0[3] = {0, 0, 0}, rs0 = 0;
-                auto read_candidates = [&](int L, uint32_t (&cb)[3], PosT (&xb)[3], PosT &rs) {
+                auto read_candidates = [&](int L, uint32_t (&cb)[3]) {
                     const uint32_t ch = c_h[L];
                     const uint32_t nc = (a_seq[L] == kNoSeq || ch == kCoop) ? 0u : ch >> 30;
 #pragma unroll
                     for (uint32_t j = 0; j < 3; ++j) {
                         const uint32_t hj = (ch >> (10u * j)) & 1023u;
                         cb[j] = *(j < nc ? reinterpret_cast<const uint32_t *>(best0 + pv_besto + 4u * hj) : &s_never);
-                        xb[j] = s_hits[pv_off + (j < nc ? hj : 0u)];
                     }
-                    rs = s_crs[L * (NWA * 64) + tid];
                 };
                 // (a wave that holds arms goes first wherever it shares a SIMD with waves that only index or wait)
                 if (NT >= 1024 && P.hi_prio) {
                     if (livemask) __builtin_amdgcn_s_setprio(3);
                     else __builtin_amdgcn_s_setprio(0);
                 }
-                if (livemask & 1u) read_candidates(0, cb0, xb0, rs0);
+                if (livemask & 1u) read_candidates(0, cb0);
                 const uint32_t flags = C(0);
                 // (the rows that this step's interval B stages: requested now)
                 const uint32_t npre = (flags & (K7_LAST | K7_GIVEUP)) ? 0u : N(10);
@@ -389,16 +390,11 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                         bool won = false;
                         PosT xw = 0;
                         uint32_t cb[3];
-                        PosT xb[3], rs_L;
                         if (L == 0) {
 #pragma unroll
-                            for (int j = 0; j < 3; ++j) {
-                                cb[j] = cb0[j];
-                                xb[j] = xb0[j];
-                            }
-                            rs_L = rs0;
+                            for (int j = 0; j < 3; ++j) cb[j] = cb0[j];
                         } else {
-                            read_candidates(L, cb, xb, rs_L);
+                            read_candidates(L, cb);
                         }
                         if (K7_USUAL(has_prev)) {
                             // the last hit (SA order) this arm won, if any: src/automaton.rs:133-150 apply in hit order
@@ -410,13 +406,33 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                                 const uint32_t hj = (ch >> (10u * j)) & 1023u;
                                 const bool mine = cb[j] == a_seq[L] && hj + 1u > hw;
                                 hw = mine ? hj + 1u : hw;
-                                xw = mine ? xb[j] : xw;
                             }
                             hw = (was_free || coop) ? 0u : hw;
+                            xw = s_hits[pv_off + (hw ? hw - 1u : 0u)];
                             unsigned long long sm = __ballot(coop);
                             K7C(55, __popcll(sm));
                             if (K7_RARE(sm != 0ull)) {  // more than three candidates / wide window: resolved cooperatively
                                 const uint32_t p_cnt = C(11), p_off = pv_off;
+                                // (many of them: one pass over the hits -- the arm that won hit h is the one whose creation
+                                // number is best[h]; extend_fast_dev.hpp, phase_b)
+                                if ((uint32_t)__popcll(sm) * 8u >= p_cnt) {
+                                    for (uint32_t h0 = 0; h0 < p_cnt; h0 += 64u) {
+                                        const uint32_t h = h0 + (uint32_t)lane;
+                                        const PosT xh = h < p_cnt ? s_hits[p_off + h] : (PosT)0;
+                                        const uint32_t bh = h < p_cnt ? *reinterpret_cast<const uint32_t *>(best0 + pv_besto + 4u * h) : kNone;
+                                        const uint32_t nh = min(64u, p_cnt - h0);
+                                        for (uint32_t j = 0; j < nh; ++j) {
+                                            const uint32_t b = lane_of(bh, j);
+                                            PosT x;
+                                            if constexpr (kWidePos) x = (PosT)lane_of((unsigned long long)xh, j);
+                                            else x = (PosT)lane_of((uint32_t)xh, j);
+                                            const bool mine = coop && a_seq[L] == b;
+                                            hw = mine ? h0 + j + 1u : hw;
+                                            xw = mine ? x : xw;
+                                        }
+                                    }
+                                    sm = 0ull;
+                                }
                                 while (sm) {
                                     const uint32_t l = (uint32_t)(__ffsll((long long)sm) - 1);
                                     sm &= sm - 1ull;
@@ -478,9 +494,12 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                         a_thr[L] = won ? thr_new : a_thr[L];
                         a_gap[L] = aged;
                         const bool dead = !was_free && aged >= G;  // never matches again
-                        const bool report = dead && (uint64_t)(a_re[L] - rs_L) >= M;
-                        if (K7_RARE(__ballot(report) != 0ull))
-                            emit_records(report, a_ls[L], s_cle[L * (NWA * 64) + tid], rs_L, a_re[L], a_seq[L], uni(s_fam[sp ^ 1u]));
+                        if (K7_RARE(__ballot(dead) != 0ull)) {
+                            const PosT rs_L = s_crs[L * (NWA * 64) + tid];
+                            const bool report = dead && (uint64_t)(a_re[L] - rs_L) >= M;
+                            if (__ballot(report) != 0ull)
+                                emit_records(report, a_ls[L], s_cle[L * (NWA * 64) + tid], rs_L, a_re[L], a_seq[L], uni(s_fam[sp ^ 1u]));
+                        }
                         a_seq[L] = dead ? kNoSeq : a_seq[L];
                     }
                 }
@@ -522,8 +541,37 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                             offer(e0.x, w_eff); offer(e0.y, w_eff); offer(e1.x, w_eff); offer(e1.y, w_eff);
                             offer(e2.x, w_eff); offer(e2.y, w_eff); offer(e3.x, w_eff); offer(e3.y, w_eff);
                         } else {
+                            // ONE atomic for the four entries: an arm as a rule accepts one hit of a probe (the lanes that
+                            // accept none go to the sink); a wave with a lane that accepts several repeats them all (min is
+                            // idempotent).  Four unconditional LDS atomics per layer and wave were a fifth of the step's LDS
+                            // instructions.
                             const ulonglong2 e0 = r0[0], e2 = r1[0];
-                            offer(e0.x, w_eff); offer(e0.y, w_eff); offer(e2.x, w_eff); offer(e2.y, w_eff);
+                            const unsigned long long ee[4] = {e0.x, e0.y, e2.x, e2.y};
+                            uint32_t first = 0;
+#pragma unroll
+                            for (int j = 3; j >= 0; --j) {
+                                const uint32_t d = tag_of(ee[j]) - g10;
+                                const WinT t = d < 1024u ? (WinT)(PosT)(pos_of(ee[j]) - lo) : ~(WinT)0;
+                                const bool ok = t < w_eff;
+                                first = ok ? d : first;
+                            }
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {  // (the candidate word in entry order, as before)
+                                const uint32_t d = tag_of(ee[j]) - g10;
+                                const WinT t = d < 1024u ? (WinT)(PosT)(pos_of(ee[j]) - lo) : ~(WinT)0;
+                                const bool ok = t < w_eff;
+                                ch = ok ? ((ch << 10) | d) : ch;
+                                nc += ok ? 1u : 0u;
+                            }
+                            atomicMin(nc ? reinterpret_cast<uint32_t *>(best + 4u * (first & 1023u)) : sink, key);
+                            if (K7_RARE(__ballot(nc > 1u) != 0ull)) {
+#pragma unroll
+                                for (int j = 1; j < 4; ++j) {
+                                    const uint32_t d = tag_of(ee[j]) - g10;
+                                    const WinT t = d < 1024u ? (WinT)(PosT)(pos_of(ee[j]) - lo) : ~(WinT)0;
+                                    atomicMin(t < w_eff ? reinterpret_cast<uint32_t *>(best + 4u * (d & 1023u)) : sink, key);
+                                }
+                            }
                         }
                     }
                     // The rows behind the first two (an arm of more than ~1 kb has a window of three rows, one of 50 kb
@@ -535,7 +583,11 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                         const uint32_t s0 = (b0 + 2u) & (uint32_t)(kRows - 1);                // first of them (table row)
                         const uint32_t *const bits = &s_rowbits[C(9)][0];
                         const uint32_t w0 = s0 >> 5, sh = s0 & 31u;
-                        const uint32_t v0 = bits[w0], v1 = bits[(w0 + 1u) & (kBitWords - 1u)], v2 = bits[(w0 + 2u) & (kBitWords - 1u)];
+                        // (two words hold the bits of up to 33 rows behind any start; the third one only for a wave with a
+                        // wider window)
+                        const uint32_t v0 = bits[w0], v1 = bits[(w0 + 1u) & (kBitWords - 1u)];
+                        uint32_t v2 = 0u;
+                        if (K7_RARE(__ballot(len > 33u) != 0ull)) v2 = bits[(w0 + 2u) & (kBitWords - 1u)];
                         unsigned long long m = ((((unsigned long long)v1 << 32) | v0) >> sh) | (sh ? (unsigned long long)v2 << (64u - sh) : 0ull);
                         m &= (1ull << len) - 1ull;
                         while (__ballot(m != 0ull) != 0ull) {
@@ -693,6 +745,9 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
             const uint32_t cap_eff = min((uint32_t)CAP, P.cap_limit);
             const uint32_t g0 = P.seg_list[seg];
             if (lane == 0) heartbeat(P, g0, 0u);
+#ifdef ASGART_PROFILE_EXTEND
+            const unsigned long long k7_seg0 = __builtin_amdgcn_s_memtime();
+#endif
             const int c = chunk_of_uniform(rp.ch, g0);
             const uint64_t cs = rp.ch.start[c], cl = rp.ch.len[c];
             const uint32_t pb = rp.ch.pbase[c];
@@ -1003,11 +1058,16 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
             }
             K7T_FLUSH(0);
 #ifdef ASGART_PROFILE_EXTEND
-            if (lane == 0) {  // (the dump's "sumA", "sumCnt", "lds_probes")
+            if (lane == 0) {  // (the dump's "sumA", "sumCnt", "lds_probes"; "longest": the segment that took longest)
                 atomicAdd(&P.ctr[26], k7_sum_a);
                 atomicAdd(&P.ctr[27], k7_sum_cnt);
                 atomicAdd(&P.ctr[21], k7_sum_n);
-                atomicMax(&P.ctr[29], k7_sum_n);
+                const unsigned long long k7_dt = __builtin_amdgcn_s_memtime() - k7_seg0;
+                if (atomicMax(&P.ctr[28], k7_dt) < k7_dt) {
+                    P.ctr[29] = g0;
+                    P.ctr[30] = k7_sum_n << 32;
+                    P.ctr[31] = (k7_sum_a << 32) | (k7_sum_cnt & 0xffffffffull);
+                }
             }
             k7_sum_a = k7_sum_cnt = k7_sum_n = 0;
 #endif

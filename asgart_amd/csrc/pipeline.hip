@@ -754,8 +754,18 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                 return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_launch).count();
             };
             PassGate *const gate = attempt == 0 ? cx.gate : nullptr;
-            if (gate && gate->front_done) gate->front_done->store(1, std::memory_order_release);
-            if (gate && gate->next_front_done && opt.pass_gate && !force_tier) {
+            if (gate && gate->front_done && opt.pass_gate != 2) gate->front_done->store(1, std::memory_order_release);
+            if (gate && gate->front_done && !gate->next_front_done && opt.pass_gate == 2 && !force_tier) {
+                // (variant 2, the pass behind: its long-segment tiers first, then the signal -- the first pass's held
+                // tiers queue behind them --, its other tiers a moment later)
+                launch_tier(3);
+                launch_tier(6);
+                HIP_TRY(hipGetLastError());
+                gate->front_done->store(1, std::memory_order_release);
+                std::this_thread::sleep_for(std::chrono::microseconds(300));
+                for (char c : tier_order)
+                    if (c != '3' && c != '6') launch_tier(c - '0');
+            } else if (gate && gate->next_front_done && opt.pass_gate && !force_tier) {
                 // (struct PassGate, index.hpp) the tier of the longest segments now -- they are this pass's floor --,
                 // the others when the pass behind this one has had the chip for its search phases
                 launch_tier(3);
@@ -775,8 +785,10 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_gate).count());
                 for (char c : tier_order)
                     if (c != '3') launch_tier(c - '0');
+                if (gate->front_done) gate->front_done->store(1, std::memory_order_release);
             } else {
                 for (char c : tier_order) launch_tier(c - '0');
+                if (gate && gate->front_done) gate->front_done->store(1, std::memory_order_release);
             }
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(cx.ev[12], st7));
