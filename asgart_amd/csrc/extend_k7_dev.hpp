@@ -127,7 +127,7 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
     constexpr uint32_t kGenMax = kWidePos ? 12u : 22u;
     constexpr unsigned long long kPosMask = (1ull << kTagShift) - 1ull;
     constexpr uint32_t kTabBytes = (uint32_t)(kRows * kE * 8);  // one hit table
-    constexpr uint32_t kCmdWords = 32;  // (24 in use: a command is read as one word per lane, two commands per read)
+    constexpr uint32_t kCmdWords = 32;  // (a command is read as one word per lane, two commands per read)
     using WinT = typename std::conditional<kWidePos, uint64_t, uint32_t>::type;
     static_assert(NW >= 2 && HB <= 1024 && S <= 8 && NE <= 128 && (kRows & (kRows - 1)) == 0 && (kE == 2 || kE == 4) && kRows <= 2048, "shape");
     if (NT >= 1024 && P.hi_prio) __builtin_amdgcn_s_setprio(3);
@@ -147,8 +147,11 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
     //   4 byte offset of its best[]       5 generation tag  6,7 needle offset i
     //   8 age of the quiet probes before it                 9 stash index    10 K7_STAGE / K7_CLEAR of the step BEFORE it   11 hits of the previous probe
     //  12,13 needle offset of the previous probe           14 its rows (s_hits)     15 byte offset of its best[]
-    //  16 k    17 step    18 G    19 log2 bucket width     20,21 min_duplication_length    22 threshold of a new arm  23 -
+    //  16 k    17 step    18 G    19 log2 bucket width     20,21 min_duplication_length    22 threshold of a new arm
+    //  23 stash / best[] buffer of the previous probe
     //  24,25 first CSR entry, 26 count, 27 buffer of the batch to stage in the step BEFORE it (when word 10 says so)
+    //  28,29 processed-probe ordinals before / after the previous probe    30,31 the same of this step's probe (the control
+    //  wave keeps no plan in registers: it reads its own commands back)
     __shared__ __attribute__((aligned(16))) uint32_t s_cmd[3][kCmdWords];
     __shared__ __attribute__((aligned(16))) uint32_t s_mid[8];         // decided in interval A, read in interval B
     __shared__ uint32_t s_fam[2];                                      // family ordinal as of the step (by step parity)
@@ -864,7 +867,7 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
             // the plan of the step behind `last` (whose probe, if it has one, becomes the new step's predecessor)
             bool have_held = false;
             Plan held{};
-            auto advance = [&](const Plan &last) -> Plan {
+            auto advance = [&](uint32_t last_flags) -> Plan {
                 Plan n{};
                 n.q = no_probe;
                 if (have_held) {  // the probe that waited for the tables to be cleared
@@ -891,7 +894,7 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                 p.st_tot = tot;
                 p.st_buf = hbuf;
                 p.flags = K7_CUR | ((opened || wrap) ? K7_LATE : 0u);
-                if (wrap && (last.flags & K7_CUR)) {
+                if (wrap && (last_flags & K7_CUR)) {
                     // the tables can only be cleared once the previous probe has all its offers: a step without a probe
                     // of its own resolves that one first, the clearing rides in ITS interval B
                     held = p;
@@ -899,74 +902,117 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                     n.flags = K7_PREV;
                     return n;
                 }
-                p.flags |= (last.flags & K7_CUR) ? K7_PREV : 0u;
+                p.flags |= (last_flags & K7_CUR) ? K7_PREV : 0u;
                 return p;
             };
-            auto write_cmd = [&](uint32_t slot, const Plan &p, const Plan &before) {
+            // (the predecessor's fields as the control wave reads them back from ITS command: the plans of the steps in
+            // flight live in the command ring only -- three of them kept in registers were 48 scalar registers, most of them
+            // spilled, and their rotation 570 cycles at the end of every step)
+            struct Before {
+                uint32_t cnt, i_lo, i_hi, off, bb, t_before, t_after;
+            };
+            auto write_cmd = [&](uint32_t slot, const Plan &p, const Before &b) {
                 if (lane == 0) {
                     uint4 *o = reinterpret_cast<uint4 *>(&s_cmd[slot][0]);
                     o[0] = make_uint4(p.flags, p.q.cnt, p.q.off, p.q.tb * kTabBytes);
                     o[1] = make_uint4(p.q.bb * (uint32_t)(HB * 4), p.q.g10, (uint32_t)p.q.i, (uint32_t)(p.q.i >> 32));
-                    o[2] = make_uint4(p.q.pend, p.q.bb, p.pre, before.q.cnt);
-                    o[3] = make_uint4((uint32_t)before.q.i, (uint32_t)(before.q.i >> 32), before.q.off, before.q.bb * (uint32_t)(HB * 4));
+                    o[2] = make_uint4(p.q.pend, p.q.bb, p.pre, b.cnt);
+                    o[3] = make_uint4(b.i_lo, b.i_hi, b.off, b.bb * (uint32_t)(HB * 4));
+                    s_cmd[slot][23] = b.bb;
                     if (p.pre & K7_STAGE) o[6] = make_uint4((uint32_t)p.st_base, (uint32_t)(p.st_base >> 32), p.st_tot, p.st_buf);
+                    o[7] = make_uint4(b.t_before, b.t_after, p.q.t_before, p.q.t_after);
                 }
+            };
+            auto before_of = [&](const Plan &p) {
+                return Before{p.q.cnt, (uint32_t)p.q.i, (uint32_t)(p.q.i >> 32), p.q.off, p.q.bb, p.q.t_before, p.q.t_after};
             };
             if (lane < 3) {  // the run's constants, once per segment, in every command block
                 uint4 *o = reinterpret_cast<uint4 *>(&s_cmd[lane][0]);
                 o[4] = make_uint4(k, step, G, bsh);
-                o[5] = make_uint4((uint32_t)rp.M, (uint32_t)(rp.M >> 32), thr0, 0u);
+                s_cmd[lane][20] = (uint32_t)rp.M;
+                s_cmd[lane][21] = (uint32_t)(rp.M >> 32);
+                s_cmd[lane][22] = thr0;
             }
 
             // ---- the first two steps are planned before the loop ---------------------------------------------------
-            Plan p_prev{}, p_cur{}, p_next{};
-            p_prev.q = no_probe;
+            Plan p_cur{}, p_next{};
+            p_cur.q = p_next.q = no_probe;
             if (!load_batch()) giveup = true;
             if (giveup) {
                 p_cur.flags = K7_GIVEUP;
-                p_cur.q = no_probe;
             } else {
-                p_cur = advance(p_prev);  // (the segment starts with a hit-probe: a late step, its batch staged below)
+                p_cur = advance(0u);  // (the segment starts with a hit-probe: a late step, its batch staged below)
             }
             if (lane == 0) {
                 s_mid[0] = p_cur.pre;
                 *reinterpret_cast<uint4 *>(&s_mid[4]) = make_uint4((uint32_t)p_cur.st_base, (uint32_t)(p_cur.st_base >> 32), p_cur.st_tot, p_cur.st_buf);
             }
-            write_cmd(0u, p_cur, p_prev);
-            if (!(p_cur.flags & (K7_GIVEUP | K7_LAST))) {
-                p_next = advance(p_cur);
-                write_cmd(1u, p_next, p_cur);
+            {
+                Plan none{};
+                none.q = no_probe;
+                write_cmd(0u, p_cur, before_of(none));
             }
+            if (!(p_cur.flags & (K7_GIVEUP | K7_LAST))) {
+                p_next = advance(p_cur.flags);
+                write_cmd(1u, p_next, before_of(p_cur));
+            }
+            const bool giveup0 = (p_cur.flags & K7_GIVEUP) != 0u;
             lds_barrier();  // (1)
             mid_actions(uni(s_mid[0]));
             lds_barrier();  // (2)
-            if (p_cur.flags & K7_GIVEUP) {
+            if (giveup0) {
                 overflow = true;
             } else {
                 for (uint32_t sc = 0, sp = 0;; sc = sc == 2u ? 0u : sc + 1u, sp ^= 1u) {
-                    const uint32_t flags = p_cur.flags;
+                    // this step's plan (lanes 0-31) and the next one's (32-63), as written two steps / one step ago
+                    const uint32_t sn = sc == 2u ? 0u : sc + 1u;
+                    const uint32_t cw = s_cmd[lane < 32 ? sc : sn][lane & 31];
+                    auto C = [&](int j) { return (uint32_t)__builtin_amdgcn_readlane((int)cw, j); };
+                    auto N = [&](int j) { return (uint32_t)__builtin_amdgcn_readlane((int)cw, 32 + j); };
+                    const uint32_t flags = C(0);
+                    if (flags & K7_GIVEUP) {  // (the arm waves leave when they read it)
+                        overflow = true;
+                        break;
+                    }
                     const bool have_prev = (flags & K7_PREV) != 0u;
-                    const Probe &prev = p_prev.q, &cur = p_cur.q;
+                    const bool more = !(flags & K7_LAST);
+                    const uint32_t nflags = more ? N(0) : 0u;
+                    const uint32_t prev_cnt = C(11), prev_off = C(14), prev_bb = C(23), prev_t_before = C(28), prev_t_after = C(29);
                     K7T_MARK();
                     K7T_STEP();
                     // ------------------------------------------------------------ interval A ----------------
-                    if ((flags & K7_CUR) && (flags & K7_LATE) && indexes(cur.cnt))
-                        insert_hits(cur.cnt, cur.off, cur.tb * kTabBytes, cur.bb * (uint32_t)(HB * 4), cur.bb, cur.g10, bsh);
-                    if (!(flags & K7_LAST) && (p_next.flags & K7_CUR) && !(p_next.flags & K7_LATE) && indexes(p_next.q.cnt))
-                        insert_hits(p_next.q.cnt, p_next.q.off, p_next.q.tb * kTabBytes, p_next.q.bb * (uint32_t)(HB * 4), p_next.q.bb,
-                                    p_next.q.g10, bsh);
+                    if ((flags & K7_CUR) && (flags & K7_LATE) && indexes(C(1))) insert_hits(C(1), C(2), C(3), C(4), C(9), C(5), bsh);
+                    if (more && (nflags & K7_CUR) && !(nflags & K7_LATE) && indexes(N(1))) insert_hits(N(1), N(2), N(3), N(4), N(9), N(5), bsh);
                     // what rides in this step's interval B was decided when the NEXT step was planned
-                    uint32_t mflags = (flags & K7_LAST) ? 0u : p_next.pre;
-                    if (mflags & K7_STAGE) fetch_rows(p_next.st_base, p_next.st_tot);
+                    uint32_t mflags = more ? N(10) : 0u;
+                    const unsigned long long st_base = ((unsigned long long)N(25) << 32) | N(24);
+                    const uint32_t st_tot = N(26), st_buf = N(27);
+                    if (mflags & K7_STAGE) fetch_rows(st_base, st_tot);
                     uint32_t n_new = 0, seq_base = 0;
                     if (have_prev) {
                         // empty slots as published at the end of the previous step, ranked (layer, wave, lane)
                         const uint32_t fv = lane < NE ? s_free[lane % NWA][lane / NWA] : 0u;
                         const uint32_t fv2 = NE > 64 && lane + 64 < NE ? s_free[(lane + 64) % NWA][(lane + 64) / NWA] : 0u;
-                        const uint32_t h_l = min((uint32_t)lane, prev.cnt - 1u);
-                        const uint32_t bv0 = s_best[prev.bb][h_l];
-                        const uint8_t hf0 = use_flag ? s_hflag[prev.off + h_l] : (uint8_t)1;
-                        const PosT x0 = s_hits[prev.off + h_l];
+                        const uint32_t h_l = min((uint32_t)lane, prev_cnt - 1u);
+                        const uint32_t bv0 = s_best[prev_bb][h_l];
+                        const uint8_t hf0 = use_flag ? s_hflag[prev_off + h_l] : (uint8_t)1;
+                        const PosT x0 = s_hits[prev_off + h_l];
+                        // (the second and third group of 64 hits -- a tandem array has 80-200 hits per probe -- requested
+                        // together with the first: the groups behind them go one round trip at a time)
+                        uint32_t bv1 = kNone, bv2 = kNone;
+                        uint8_t hf1 = 1, hf2 = 1;
+                        PosT x1 = 0, x2 = 0;
+                        if (prev_cnt > 64u) {
+                            const uint32_t h1 = min(64u + (uint32_t)lane, prev_cnt - 1u), h2 = min(128u + (uint32_t)lane, prev_cnt - 1u);
+                            bv1 = s_best[prev_bb][h1];
+                            bv2 = s_best[prev_bb][h2];
+                            x1 = s_hits[prev_off + h1];
+                            x2 = s_hits[prev_off + h2];
+                            if (use_flag) {
+                                hf1 = s_hflag[prev_off + h1];
+                                hf2 = s_hflag[prev_off + h2];
+                            }
+                        }
                         // (one scan for both halves of the entries: two 16-bit fields, each total < 2^16)
                         const uint32_t packed = wave_incl_scan(fv | (fv2 << 16));
                         const uint32_t fincl = packed & 0xFFFFu;
@@ -983,44 +1029,43 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                         const uint32_t A0 = (uint32_t)CAP - total_free;  // live arms after the quiet probes' deaths
 #ifdef ASGART_PROFILE_EXTEND
                         k7_sum_a += A0;
-                        k7_sum_cnt += prev.cnt;
+                        k7_sum_cnt += prev_cnt;
                         ++k7_sum_n;
 #endif
-                        if (fam_open && A0 == 0 && prev.t_before >= spur_until) {  // the flush of src/automaton.rs:182-200
+                        if (fam_open && A0 == 0 && prev_t_before >= spur_until) {  // the flush of src/automaton.rs:182-200
                             ++fam_seq;
                             next_seq = 0;
                             fam_open = false;
                         }
                         // unmatched hits, in hit order (= creation order, src/automaton.rs:151-164) -> s_new[rank]
                         bool spur = false;
-                        {
-                            const bool in0 = (uint32_t)lane < prev.cnt;
-                            const bool un0 = in0 && bv0 == kNone && hf0 != 0;
-                            const unsigned long long m0 = __ballot(un0);
-                            if (un0) s_new[(uint32_t)__popcll(m0 & lt_mask)] = x0;
-                            n_new = (uint32_t)__popcll(m0);
-                            spur = use_flag && __ballot(in0 && bv0 == kNone && hf0 == 0) != 0ull;
+                        auto rank_group = [&](uint32_t h0, uint32_t bv, uint8_t hf, PosT x) {
+                            const bool in = h0 + (uint32_t)lane < prev_cnt;
+                            const bool un = in && bv == kNone && hf != 0;
+                            const unsigned long long m = __ballot(un);
+                            if (un) s_new[n_new + (uint32_t)__popcll(m & lt_mask)] = x;
+                            n_new += (uint32_t)__popcll(m);
+                            if (use_flag) spur = spur || __ballot(in && bv == kNone && hf == 0) != 0ull;
+                        };
+                        rank_group(0u, bv0, hf0, x0);
+                        if (prev_cnt > 64u) {
+                            rank_group(64u, bv1, hf1, x1);
+                            if (prev_cnt > 128u) rank_group(128u, bv2, hf2, x2);
                         }
-                        for (uint32_t h0 = 64u; h0 < prev.cnt; h0 += 64u) {  // (most probes have <= 64 hits)
-                            const uint32_t h = min(h0 + (uint32_t)lane, prev.cnt - 1u);
-                            const bool in = h0 + (uint32_t)lane < prev.cnt;
-                            const bool un = in && s_best[prev.bb][h] == kNone;
-                            const bool hf = use_flag ? s_hflag[prev.off + h] != 0 : true;
-                            const unsigned long long nm = __ballot(un && hf);
-                            if (use_flag) spur = spur || __ballot(un && !hf) != 0ull;
-                            if (un && hf) s_new[n_new + (uint32_t)__popcll(nm & lt_mask)] = s_hits[prev.off + h];
-                            n_new += (uint32_t)__popcll(nm);
+                        for (uint32_t h0 = 192u; h0 < prev_cnt; h0 += 64u) {
+                            const uint32_t h = min(h0 + (uint32_t)lane, prev_cnt - 1u);
+                            rank_group(h0, s_best[prev_bb][h], use_flag ? s_hflag[prev_off + h] : (uint8_t)1, s_hits[prev_off + h]);
                         }
                         if (n_new > total_free || A0 + n_new > cap_eff) mflags |= K7_OVF;
                         seq_base = next_seq;
                         next_seq += n_new;
                         fam_open = true;
-                        if (spur) spur_until = max(spur_until, prev.t_after + rp.tstar - 1u);
+                        if (spur) spur_until = max(spur_until, prev_t_after + rp.tstar - 1u);
                     }
                     if (lane == 0) {
                         *reinterpret_cast<uint4 *>(&s_mid[0]) = make_uint4(mflags, n_new, seq_base, fam_seq);
                         if (mflags & K7_STAGE)
-                            *reinterpret_cast<uint4 *>(&s_mid[4]) = make_uint4((uint32_t)p_next.st_base, (uint32_t)(p_next.st_base >> 32), p_next.st_tot, p_next.st_buf);
+                            *reinterpret_cast<uint4 *>(&s_mid[4]) = make_uint4((uint32_t)st_base, (uint32_t)(st_base >> 32), st_tot, st_buf);
                         s_fam[sp] = fam_seq;
                     }
                     K7T_LAP(0);
@@ -1031,29 +1076,19 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
                         overflow = true;
                         break;
                     }
-                    mid_actions_f(mflags, p_next.st_tot, p_next.st_buf);
+                    mid_actions_f(mflags, st_tot, st_buf);
                     // the stash of the probe after next is the previous probe's: nobody reads it any more
-                    if (lane == 0 && have_prev) s_nstash[prev.bb] = 0u;
-                    if (have_prev && (uint32_t)lane < kBitWords) s_rowbits[prev.bb][lane] = 0u;  // (kRows <= 2048: one word per lane)
-                    const bool more = !(flags & K7_LAST);
+                    if (lane == 0 && have_prev) s_nstash[prev_bb] = 0u;
+                    if (have_prev && (uint32_t)lane < kBitWords) s_rowbits[prev_bb][lane] = 0u;  // (kRows <= 2048: one word per lane)
                     // the step after next: planned now, while the arm waves create and offer
-                    Plan p_after{};
-                    p_after.q = no_probe;
-                    if (more && !(p_next.flags & (K7_LAST | K7_GIVEUP))) {
-                        p_after = advance(p_next);
-                        write_cmd(sc == 0u ? 2u : sc - 1u, p_after, p_next);  // (slot of step + 2 = slot of step - 1)
+                    if (more && !(nflags & (K7_LAST | K7_GIVEUP))) {
+                        const Plan p_after = advance(nflags);
+                        write_cmd(sc == 0u ? 2u : sc - 1u, p_after, Before{N(1), N(6), N(7), N(2), N(9), N(30), N(31)});  // (slot of step + 2 = slot of step - 1)
                     }
                     K7T_LAP(2);
                     lds_barrier();  // ---- barrier 2 ----------------------------------------------------------
                     K7T_LAP(3);
                     if (!more) break;
-                    p_prev = p_cur;
-                    p_cur = p_next;
-                    p_next = p_after;
-                    if (p_cur.flags & K7_GIVEUP) {  // (the arm waves leave when they read it)
-                        overflow = true;
-                        break;
-                    }
                 }
             }
             K7T_FLUSH(0);
