@@ -1,0 +1,1081 @@
+// extend_k8_dev.hpp -- "K8": K7 (extend_k7_dev.hpp: a control wave plans and ranks, arm waves do nothing but their
+// arms) with ONE barrier per hit-probe.
+//
+// Why K7 needs two: the arms born of probe t-1's unmatched hits must offer to probe t, so the arm waves wait (barrier
+// 1) for the control wave's ranking of those hits before they create the arms and make any offer.  Here the control
+// wave makes the FIRST offers of the new arms itself -- a newborn arm's window is a function of its hit alone
+// (x + 1, threshold(k) + k - 1) and its creation number is the rank the control wave has just computed -- and leaves
+// the candidates it found beside the hit.  The arm waves pull the new arms one step later, at the top of the step that
+// resolves probe t, candidates included.  A step is then
+//
+//     arm waves   pull the arms born of t-2 (ranked during step s-1) -> resolve t-1 -> offers to t -> free counts
+//     control     flush decision of t-1, unmatched hits of t-1 -> list, their offers to t, slot ranks; plan step s+2
+//     top waves   index the hits of t+1 (from HBM when t+1 opens a batch: its rows reach LDS during this step)
+//     -- barrier --
+//
+// Slots: the control wave assigns the r-th new arm to the r-th empty slot in (layer, wave, lane) order from the counts
+// the arm waves published at the end of the step before; the pull that is still pending when it does so (assigned a step
+// earlier) is subtracted -- the control wave knows how many slots of each (wave, layer) it gave away -- so no slot is
+// given twice, and a wave pulls at most the number it was given, into whatever lanes are empty by then.
+// Hit rows: three buffers (a batch is staged while the two before it may still be read).  Generation wrap: a step that
+// only resolves (and clears the tables), a step that only indexes, then the probe.
+// Creation numbers, record keys and every transition are K7's: results are identical (the tier tests force every
+// segment through this kernel as well).
+#pragma once
+
+#include "extend_k7_dev.hpp"
+
+namespace asgart {
+
+constexpr uint32_t K8_CLEARNOW = 32u;  // command flag: every thread clears the hit tables at the top of this step
+// pull block flags
+constexpr uint32_t K8_OVF = 1u;        // more arms than slots: the segment is given up
+constexpr uint32_t K8_STILL = 2u;      // the new arms of this block die of the quiet probes behind their birth: none is created
+
+template <class PosT, int S, int NT, int HB, int kRows = 1024, int kE = 2>
+__global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
+    constexpr int NW = NT / 64, NWA = NW - 2;  // waves; arm waves (then the RANKING wave and the PLANNING wave)
+    constexpr int CAP = S * NWA * 64;
+    constexpr int NE = S * NWA;                // (layer, wave) entries of the free counts
+    constexpr uint32_t kNone = 0xFFFFFFFFu;    // best[]: no arm accepts this hit
+    constexpr uint32_t kNever = 0xFFFFFFFEu;   // what a candidate read of an idle lane returns: no creation number
+    constexpr uint32_t kCoop = 0xFFFFFFFFu;    // candidate register: more than three / wide window / stash overflow
+    constexpr uint32_t kStash = 64;
+    constexpr uint32_t kRowsWalk = 62;
+    constexpr uint32_t kBitWords = (uint32_t)kRows / 32u;
+    constexpr bool kWidePos = sizeof(PosT) == 8;
+    constexpr uint32_t kTagShift = kWidePos ? 42u : 32u;
+    constexpr uint32_t kGenMax = kWidePos ? 12u : 22u;
+    constexpr unsigned long long kPosMask = (1ull << kTagShift) - 1ull;
+    constexpr uint32_t kTabBytes = (uint32_t)(kRows * kE * 8);  // one hit table
+    constexpr uint32_t kCmdWords = 32;
+    constexpr uint32_t kNewMax = kWidePos ? (uint32_t)HB / 2u : (uint32_t)HB;  // new arms of one probe (more: given up)
+    using WinT = typename std::conditional<kWidePos, uint64_t, uint32_t>::type;
+    static_assert(NW >= 4 && HB <= 1024 && S <= 8 && NE <= 128 && (kRows & (kRows - 1)) == 0 && kE == 2 && kRows <= 2048 && CAP < 65536,
+                  "shape");
+    if (NT >= 1024 && P.hi_prio) __builtin_amdgcn_s_setprio(3);
+
+    __shared__ __attribute__((aligned(16))) unsigned long long s_tab[2][kRows * kE];
+    __shared__ PosT s_hits[3 * HB];
+    __shared__ uint8_t s_hflag[3 * HB];
+    __shared__ __attribute__((aligned(16))) uint32_t s_best[3][HB];
+    __shared__ unsigned long long s_stash[3][kStash];
+    __shared__ uint32_t s_rowbits[3][kRows / 32];
+    // one block per step parity (written by the control wave during step s, read by everyone at the top of step s + 1):
+    //   0 flags  1 new arms  2 first creation number  3 family ordinal  4,5 needle offset of their probe
+    //   6 age of the quiet probes behind it  7 -   8..15 (this wave's words are in s_slot)   24..27 stash counts
+    __shared__ __attribute__((aligned(16))) uint32_t s_pull[2][8];
+    __shared__ uint32_t s_slot[2][NWA][8];                             // per (arm wave, layer): slots given << 16 | rank of the first
+    __shared__ __attribute__((aligned(16))) uint32_t s_nstash[4];      // (three in use)
+    __shared__ __attribute__((aligned(16))) uint32_t s_free[NWA][8];   // per (arm wave, layer): empty slots
+    __shared__ PosT s_newx[2][kNewMax];                                // the unmatched hits of a probe, by rank
+    __shared__ uint32_t s_newch[2][kNewMax];                           // ... and the candidates of the arm born of each
+    __shared__ __attribute__((aligned(16))) uint32_t s_cmd[3][kCmdWords];  // as K7's (word 10: K7_STAGE of the step before)
+    __shared__ __attribute__((aligned(16))) uint32_t s_mid[8];         // before the loop: the first batch's staging request
+    __shared__ PosT s_cle[CAP], s_crs[CAP];                            // cold fields of an arm, by slot
+    __shared__ unsigned long long s_seg[3];                            // g0, chunk start, chunk length (for the records)
+    __shared__ uint32_t s_end[4];                                      // planning wave -> ranking wave, at the end of a segment: processed probes, done, ran out
+    __shared__ unsigned long long s_bcast;
+    __shared__ uint32_t s_sink[64];
+    __shared__ uint32_t s_never;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool is_rank = wave == (uint32_t)NWA, is_plan = wave == (uint32_t)(NWA + 1);
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const bool use_flag = P.hit_flag != nullptr;
+    RecAlloc rec_alloc;
+    K7T_DECL;
+    K7U_DECL;
+#ifdef ASGART_PROFILE_EXTEND
+    unsigned long long k7_sum_a = 0, k7_sum_cnt = 0, k7_sum_n = 0;
+#endif
+
+    PosT a_ls[S], a_re[S];
+    uint32_t a_thr[S], a_gap[S], a_seq[S], c_h[S];
+#pragma unroll
+    for (int L = 0; L < S; ++L) {
+        a_seq[L] = kNoSeq;
+        a_ls[L] = a_re[L] = 0;
+        a_thr[L] = a_gap[L] = 0;
+        c_h[L] = 0;
+    }
+    uint32_t livemask = 0;  // wave-uniform: layers in which this wave may hold an arm
+    uint32_t gen = 0, par = 0, tri = 0;  // (control wave) they run on from segment to segment
+    auto clear_table = [&]() {
+        for (uint32_t e = tid; e < (uint32_t)(2 * kRows * kE); e += NT) (&s_tab[0][0])[e] = 0ull;
+    };
+    clear_table();
+    if (tid == 0) s_never = kNever;
+    lds_barrier();
+
+    auto tag_of = [&](unsigned long long e) { return (uint32_t)(e >> kTagShift); };
+    auto pos_of = [&](unsigned long long e) { return (PosT)(e & kPosMask); };
+    char *const tab0 = reinterpret_cast<char *>(&s_tab[0][0]);
+    char *const best0 = reinterpret_cast<char *>(&s_best[0][0]);
+
+    for (uint32_t n_fetch = 0; !P.max_items || n_fetch < P.max_items; ++n_fetch) {
+        if (tid == 0) s_bcast = atomicAdd(P.cursor, 1ull);
+        if (tid < 4) s_nstash[tid] = 0u;
+        if (tid < 16) (&s_pull[0][0])[tid] = 0u;
+        for (uint32_t j = tid; j < 3u * kBitWords; j += NT) (&s_rowbits[0][0])[j] = 0u;
+        for (uint32_t j = tid; j < (uint32_t)(NWA * 8); j += NT) (&s_free[0][0])[j] = 64u;
+        for (uint32_t j = tid; j < (uint32_t)(2 * NWA * 8); j += NT) (&s_slot[0][0][0])[j] = 0u;
+        lds_barrier();
+        const unsigned long long seg = uni(s_bcast);
+        lds_barrier();
+        if (seg >= *P.n_seg_ptr) break;
+
+        auto emit_records = [&](bool emit, PosT ls, PosT le, PosT rs, PosT re, uint32_t seq, uint32_t fam_seq) {
+            const unsigned long long em = __ballot(emit);
+            if (!em) return;
+            const unsigned long long at = rec_slot(rec_alloc, P, em, lane);
+            if (emit && at < P.rec_cap) {
+                const uint64_t cs = s_seg[1], cl = s_seg[2];
+                const uint64_t ll = (uint64_t)le - (uint64_t)ls;
+                SdRec r;
+                r.g_start = (uint32_t)s_seg[0];
+                r.fam_seq = fam_seq;
+                r.create_seq = seq;
+                r.pad = 0;
+                r.sd.left = P.rp.reverse ? cs + cl - (uint64_t)ls - ll : (uint64_t)ls + cs;  // src/bin/asgart.rs:229-237
+                r.sd.right = rs;
+                r.sd.left_length = ll;
+                r.sd.right_length = (uint64_t)re - (uint64_t)rs;
+                P.recs[at] = r;
+            }
+        };
+        // index the hits of one probe under generation tag g10 in the table at byte offset tabo, winners at byte offset
+        // besto, stash / occupancy bits bb; its rows are at s_hits[off..] or, when gsrc is set (the probe opens a batch
+        // whose rows are on their way to LDS in this very step), at P.hits[gbase..]; the TOP threads do it
+        auto insert_hits = [&](uint32_t cnt, uint32_t off, uint32_t tabo, uint32_t besto, uint32_t bb, uint32_t g10, uint32_t bsh,
+                               bool gsrc, unsigned long long gbase) {
+            const uint32_t me = tid < NWA * 64 ? (uint32_t)(NWA * 64 - 1 - tid) : (uint32_t)tid;
+            for (uint32_t h = me; h < cnt; h += NT) {
+                const PosT x = gsrc ? P.hits[gbase + h] : s_hits[off + h];
+                *reinterpret_cast<uint32_t *>(best0 + besto + 4u * h) = kNone;
+                unsigned long long e = ((unsigned long long)(g10 | h) << kTagShift) | ((unsigned long long)x & kPosMask);
+                const uint32_t ri = ((uint32_t)((uint64_t)x >> bsh)) & (uint32_t)(kRows - 1);
+                unsigned long long *row = reinterpret_cast<unsigned long long *>(tab0 + tabo + ri * (uint32_t)(kE * 8));
+                atomicOr(&s_rowbits[bb][ri >> 5], 1u << (ri & 31u));
+                bool placed = false;
+#pragma unroll
+                for (int j = 0; j < kE; ++j) {
+                    if (!placed) {
+                        const unsigned long long old = atomicExch(&row[j], e);
+                        if (tag_of(old) - g10 >= 1024u) placed = true;  // displaced a stale entry: done
+                        else e = old;                                   // a hit of this probe: it moves on
+                    }
+                }
+                if (!placed) {
+                    const uint32_t at = atomicAdd(&s_nstash[bb], 1u);
+                    if (at < kStash) s_stash[bb][at] = e;
+                }
+            }
+        };
+        auto indexes = [&](uint32_t cnt) {
+            const uint32_t first = wave >= (uint32_t)NWA ? wave : (uint32_t)(NWA - 1) - wave;  // in units of 64 hits
+            return first < (cnt + 63u) / 64u;
+        };
+        constexpr int kPf = (HB + NT - 1) / NT;
+        PosT pf_x[kPf];
+        uint8_t pf_f[kPf];
+        auto fetch_rows = [&](unsigned long long base, uint32_t tot) {
+#pragma unroll
+            for (int j = 0; j < kPf; ++j) {
+                const uint32_t r = (uint32_t)tid + (uint32_t)(j * NT);
+                pf_x[j] = r < tot ? P.hits[base + r] : (PosT)0;
+                pf_f[j] = (use_flag && r < tot) ? P.hit_flag[base + r] : (uint8_t)0;
+            }
+        };
+        auto store_rows = [&](uint32_t tot, uint32_t buf) {
+#pragma unroll
+            for (int j = 0; j < kPf; ++j) {
+                const uint32_t r = (uint32_t)tid + (uint32_t)(j * NT);
+                if (r < tot) {
+                    s_hits[buf * (uint32_t)HB + r] = pf_x[j];
+                    if (use_flag) s_hflag[buf * (uint32_t)HB + r] = pf_f[j];
+                }
+            }
+        };
+        // The offers of ONE window per lane to the hits of a probe (the lanes with `who`): the table walk of K6 / K7 --
+        // two rows, then the rows of the window whose occupancy bit is set, then the stash; wider windows and every
+        // window when the stash overflowed go through the wave-cooperative scan.  Returns the candidate word.
+        struct Cur {
+            uint32_t k, g10, bsh, tabo, besto, bb, cnt, off;
+        };
+        auto offer_window = [&](const Cur &q, PosT lo, WinT w, uint32_t key, bool who, uint32_t ns) -> uint32_t {
+            const uint32_t g10 = q.g10, bsh = q.bsh;
+            char *const tab = tab0 + q.tabo;
+            char *const best = best0 + q.besto;
+            const bool povf = ns > kStash;
+            const WinT w_loop = (WinT)(kRowsWalk - 1u) << bsh;
+            const bool narrow = who && w <= w_loop;
+            const WinT w_eff = narrow ? w : (WinT)0;  // (an empty window accepts nothing)
+            uint32_t ch = 0, nc = 0;
+            uint32_t *const sink = &s_sink[lane];
+            auto offer = [&](unsigned long long e, WinT wl) {
+                const uint32_t d = tag_of(e) - g10;
+                const WinT t = d < 1024u ? (WinT)(PosT)(pos_of(e) - lo) : ~(WinT)0;
+                const bool ok = t < wl;
+                atomicMin(ok ? reinterpret_cast<uint32_t *>(best + 4u * (d & 1023u)) : sink, key);
+                ch = ok ? ((ch << 10) | d) : ch;
+                nc += ok ? 1u : 0u;
+            };
+            const uint32_t b0 = (uint32_t)((uint64_t)lo >> bsh);
+            const uint32_t n_rows = narrow ? (uint32_t)((((uint64_t)lo & ((1ull << bsh) - 1ull)) + (uint64_t)w - 1ull) >> bsh) + 1u : 0u;
+            {   // the two rows of a narrow window: all reads in flight together; ONE atomic for their four entries
+                const ulonglong2 *r0 = reinterpret_cast<const ulonglong2 *>(tab + (b0 & (uint32_t)(kRows - 1)) * (uint32_t)(kE * 8));
+                const ulonglong2 *r1 = reinterpret_cast<const ulonglong2 *>(tab + ((b0 + 1u) & (uint32_t)(kRows - 1)) * (uint32_t)(kE * 8));
+                const ulonglong2 e0 = r0[0], e2 = r1[0];
+                const unsigned long long ee[4] = {e0.x, e0.y, e2.x, e2.y};
+                uint32_t first = 0;
+#pragma unroll
+                for (int j = 3; j >= 0; --j) {
+                    const uint32_t d = tag_of(ee[j]) - g10;
+                    const WinT t = d < 1024u ? (WinT)(PosT)(pos_of(ee[j]) - lo) : ~(WinT)0;
+                    first = t < w_eff ? d : first;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t d = tag_of(ee[j]) - g10;
+                    const WinT t = d < 1024u ? (WinT)(PosT)(pos_of(ee[j]) - lo) : ~(WinT)0;
+                    const bool ok = t < w_eff;
+                    ch = ok ? ((ch << 10) | d) : ch;
+                    nc += ok ? 1u : 0u;
+                }
+                atomicMin(nc ? reinterpret_cast<uint32_t *>(best + 4u * (first & 1023u)) : sink, key);
+                if (K7_RARE(__ballot(nc > 1u) != 0ull)) {
+#pragma unroll
+                    for (int j = 1; j < 4; ++j) {
+                        const uint32_t d = tag_of(ee[j]) - g10;
+                        const WinT t = d < 1024u ? (WinT)(PosT)(pos_of(ee[j]) - lo) : ~(WinT)0;
+                        atomicMin(t < w_eff ? reinterpret_cast<uint32_t *>(best + 4u * (d & 1023u)) : sink, key);
+                    }
+                }
+            }
+            if (__ballot(n_rows > 2u) != 0ull) {
+                const uint32_t len = n_rows > 2u ? n_rows - 2u : 0u;                 // <= kRowsWalk - 1 < 64
+                const uint32_t s0 = (b0 + 2u) & (uint32_t)(kRows - 1);                // first of them (table row)
+                const uint32_t *const bits = &s_rowbits[q.bb][0];
+                const uint32_t w0 = s0 >> 5, sh = s0 & 31u;
+                const uint32_t v0 = bits[w0], v1 = bits[(w0 + 1u) & (kBitWords - 1u)];
+                uint32_t v2 = 0u;
+                if (K7_RARE(__ballot(len > 33u) != 0ull)) v2 = bits[(w0 + 2u) & (kBitWords - 1u)];
+                unsigned long long m = ((((unsigned long long)v1 << 32) | v0) >> sh) | (sh ? (unsigned long long)v2 << (64u - sh) : 0ull);
+                m &= (1ull << len) - 1ull;
+                while (__ballot(m != 0ull) != 0ull) {
+                    const bool act = m != 0ull;
+                    const uint32_t r = act ? (uint32_t)(__ffsll((long long)m) - 1) : 0u;
+                    m &= m - 1ull;
+                    const ulonglong2 *rr = reinterpret_cast<const ulonglong2 *>(tab + ((s0 + r) & (uint32_t)(kRows - 1)) * (uint32_t)(kE * 8));
+                    const WinT wl = act ? w_eff : (WinT)0;
+                    const ulonglong2 f0 = rr[0];
+                    offer(f0.x, wl);
+                    offer(f0.y, wl);
+                }
+            }
+            if (K7_RARE(ns != 0u))
+                for (uint32_t s = 0; s < min(ns, kStash); ++s) offer(s_stash[q.bb][s], w_eff);
+            ch = nc > 3u ? kCoop : (ch & 0x3FFFFFFFu) | (nc << 30);
+            // windows too wide for the table walk -- and every window when the stash overflowed
+            unsigned long long sm = __ballot(who && (!narrow || povf));
+            if (K7_RARE(sm != 0ull)) {
+                if (who && (!narrow || povf)) ch = kCoop;
+                while (sm) {
+                    const uint32_t l = (uint32_t)(__ffsll((long long)sm) - 1);
+                    sm &= sm - 1ull;
+                    PosT lo_u;
+                    WinT w_u;
+                    if constexpr (kWidePos) {
+                        lo_u = (PosT)lane_of((unsigned long long)lo, l);
+                        w_u = (WinT)lane_of((unsigned long long)w, l);
+                    } else {
+                        lo_u = (PosT)lane_of((uint32_t)lo, l);
+                        w_u = (WinT)lane_of((uint32_t)w, l);
+                    }
+                    const uint32_t key_u = lane_of(key, l);
+                    for (uint32_t h0 = 0; h0 < q.cnt; h0 += 64u) {
+                        const uint32_t h = h0 + (uint32_t)lane;
+                        if (h < q.cnt && (WinT)(PosT)(s_hits[q.off + h] - lo_u) < w_u)
+                            atomicMin(reinterpret_cast<uint32_t *>(best + 4u * h), key_u);
+                    }
+                }
+            }
+            return ch;
+        };
+
+        bool overflow = false;
+        if (!is_rank && !is_plan) {
+            // =====================================================================================================
+            // ARM WAVES
+            // =====================================================================================================
+            lds_barrier();  // (1) the control wave has published the first batch's staging request and two commands
+            {
+                const uint4 m1 = *reinterpret_cast<const uint4 *>(&s_mid[4]);
+                if (uni(s_mid[0]) & K7_STAGE) {
+                    fetch_rows(((unsigned long long)uni(m1.y) << 32) | uni(m1.x), uni(m1.z));
+                    store_rows(uni(m1.z), uni(m1.w));
+                }
+            }
+            lds_barrier();  // (2) the rows are in
+            {   // the first probe's hits (every later probe is indexed during the step before its own)
+                const uint32_t w0 = s_cmd[0][lane & 31];
+                auto C0 = [&](int j) { return (uint32_t)__builtin_amdgcn_readlane((int)w0, j); };
+                if ((C0(0) & K7_CUR) && indexes(C0(1))) insert_hits(C0(1), C0(2), C0(3), C0(4), C0(9), C0(5), C0(19), false, 0ull);
+            }
+            lds_barrier();  // (3)
+            uint32_t pv_off = 0, pv_besto = 0;  // the previous probe's rows and winners (as in the last command)
+            // (lanes 0-7: the pull block; 8-15: this wave's slots; 16-19: the stash counts -- per step parity)
+            const uint32_t *const pb_ptr0 = lane < 8 ? &s_pull[0][lane] : (lane < 16 ? &s_slot[0][wave][lane - 8] : (lane < 20 ? &s_nstash[lane - 16] : &s_pull[0][0]));
+            const uint32_t *const pb_ptr1 = lane < 8 ? &s_pull[1][lane] : (lane < 16 ? &s_slot[1][wave][lane - 8] : (lane < 20 ? &s_nstash[lane - 16] : &s_pull[1][0]));
+            for (uint32_t sc = 0, sp = 0;; sc = sc == 2u ? 0u : sc + 1u, sp ^= 1u) {
+                K7T_MARK();
+                K7T_STEP();
+                K7U_MARK();
+                const uint32_t sn = sc == 2u ? 0u : sc + 1u;  // the next step's command
+                const uint32_t cw = s_cmd[lane < 32 ? sc : sn][lane & 31];
+                const uint32_t pw = *(sp ? pb_ptr0 : pb_ptr1);  // (step s reads the block written during step s - 1)
+                auto C = [&](int j) { return (uint32_t)__builtin_amdgcn_readlane((int)cw, j); };
+                auto N = [&](int j) { return (uint32_t)__builtin_amdgcn_readlane((int)cw, 32 + j); };
+                auto PB = [&](uint32_t j) { return (uint32_t)__builtin_amdgcn_readlane((int)pw, (int)j); };
+                // (winners AND positions of an arm's candidates, all requested at once: with one barrier per step every
+                // dependent round trip of an arm wave is on the step's critical path)
+                uint32_t cb0[3] = {0, 0, 0};
+                PosT xb0[3] = {0, 0, 0};
+                auto read_candidates = [&](int L, uint32_t (&cb)[3], PosT (&xb)[3]) {
+                    const uint32_t ch = c_h[L];
+                    const uint32_t nc = (a_seq[L] == kNoSeq || ch == kCoop) ? 0u : ch >> 30;
+#pragma unroll
+                    for (uint32_t j = 0; j < 3; ++j) {
+                        const uint32_t hj = (ch >> (10u * j)) & 1023u;
+                        cb[j] = *(j < nc ? reinterpret_cast<const uint32_t *>(best0 + pv_besto + 4u * hj) : &s_never);
+                        xb[j] = s_hits[pv_off + (j < nc ? hj : 0u)];
+                    }
+                };
+                if (NT >= 1024 && P.hi_prio) {
+                    if (livemask) __builtin_amdgcn_s_setprio(3);
+                    else __builtin_amdgcn_s_setprio(0);
+                }
+                if (livemask & 1u) read_candidates(0, cb0, xb0);
+                const uint32_t flags = C(0);
+                if (K7_RARE((flags & K7_GIVEUP) || (PB(0) & K8_OVF))) {
+                    overflow = true;
+                    break;
+                }
+                const bool has_prev = (flags & K7_PREV) != 0u, has_cur = (flags & K7_CUR) != 0u, more = !(flags & K7_LAST);
+                if (K7_RARE(flags & K8_CLEARNOW)) clear_table();
+                // the rows that are staged during this step: requested now, written to LDS in front of the barrier
+                const uint32_t npre = more ? N(10) : 0u;
+                if (K7_RARE(npre & K7_STAGE)) fetch_rows(((unsigned long long)N(25) << 32) | N(24), N(26));
+                // the hits of the NEXT step's probe: indexed by the top arm waves
+                if (more) {
+                    const uint32_t nflags = N(0), ncnt = N(1);
+                    if (K7_RARE((nflags & K7_CUR) && indexes(ncnt))) {
+                        const bool gsrc = (nflags & K7_LATE) != 0u;
+                        const unsigned long long gbase = (((unsigned long long)N(25) << 32) | N(24)) + (N(2) - N(27) * (uint32_t)HB);
+                        insert_hits(ncnt, N(2), N(3), N(4), N(9), N(5), N(19), gsrc, gbase);
+                    }
+                }
+                K7U_LAP(0);
+                const bool had_live = livemask != 0u;
+                const uint32_t k = C(16), step = C(17), G = C(18), pend = C(8);
+                const uint64_t M = ((uint64_t)C(21) << 32) | C(20);
+                // ---- the arms born of the probe before the previous one: pulled by rank ---------------------------------
+                const uint32_t n_pull = PB(1);
+                bool received = false;
+                if (K7_RARE(n_pull != 0u)) {
+                    const uint32_t pbuf = sp ^ 1u;  // (the lists of the step before)
+                    const uint32_t seq_base = PB(2), fam_b = PB(3), thr0 = C(22);
+                    PosT b_i;
+                    if constexpr (kWidePos) b_i = (PosT)(((uint64_t)PB(5) << 32) | PB(4));
+                    else b_i = (PosT)PB(4);
+                    const uint64_t g_new = (uint64_t)step + PB(6);  // aged by its own probe, then by the quiet ones
+                    const uint32_t gap_new = g_new > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)g_new;
+                    const bool stillborn = (PB(0) & K8_STILL) != 0u;  // (only when min_duplication_length <= k are they reported)
+#pragma unroll
+                    for (int L = 0; L < S; ++L) {
+                        const uint32_t packed = PB(8u + (uint32_t)L);
+                        const uint32_t base_r = packed & 0xFFFFu, given = packed >> 16;
+                        if (base_r >= n_pull) break;  // (ranks ascend with the layer: nothing above either)
+                        if (!given) continue;         // (this layer of this wave is full; the one above may not be)
+                        received = true;
+                        const bool is_free = a_seq[L] == kNoSeq;
+                        const unsigned long long fmask = __ballot(is_free);
+                        const uint32_t idx = (uint32_t)__popcll(fmask & lt_mask);
+                        const uint32_t r = base_r + idx;
+                        bool take = is_free && idx < given && r < n_pull;
+                        const PosT x = s_newx[pbuf][take ? r : 0u];
+                        const uint32_t chn = s_newch[pbuf][take ? r : 0u];
+                        if (K7_RARE(stillborn)) {
+                            const bool report = take && (uint64_t)k >= M;
+                            if (__ballot(report)) emit_records(report, b_i, (PosT)(b_i + k), x, (PosT)(x + k), seq_base + r, fam_b);
+                            take = false;
+                        }
+                        a_ls[L] = take ? b_i : a_ls[L];
+                        if (take) {
+                            s_cle[L * (NWA * 64) + tid] = (PosT)(b_i + k);
+                            s_crs[L * (NWA * 64) + tid] = x;
+                        }
+                        a_re[L] = take ? (PosT)(x + k) : a_re[L];
+                        a_gap[L] = take ? gap_new : a_gap[L];
+                        a_thr[L] = take ? thr0 : a_thr[L];
+                        a_seq[L] = take ? seq_base + r : a_seq[L];
+                        c_h[L] = take ? chn : c_h[L];
+                        if (__ballot(take)) livemask |= 1u << L;
+                    }
+                }
+                // ---- resolve the previous probe, age -------------------------------------------------------------------
+                if (livemask) {
+                    const uint32_t p_i = C(12);  // low word of the previous probe's needle offset
+#pragma unroll
+                    for (int L = 0; L < S; ++L) {
+                        if (!(livemask >> L)) break;
+                        if (!(livemask & (1u << L))) continue;
+                        const bool was_free = a_seq[L] == kNoSeq;
+                        bool won = false;
+                        PosT xw = 0;
+                        uint32_t cb[3];
+                        PosT xb[3];
+                        if (L == 0 && !received) {
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) {
+                                cb[j] = cb0[j];
+                                xb[j] = xb0[j];
+                            }
+                        } else {
+                            read_candidates(L, cb, xb);  // (the arms pulled in this step have their candidates only now)
+                        }
+                        if (K7_USUAL(has_prev)) {
+                            // the last hit (SA order) this arm won, if any: src/automaton.rs:133-150 apply in hit order
+                            const uint32_t ch = c_h[L];
+                            const bool coop = !was_free && ch == kCoop;
+                            uint32_t hw = 0;  // 1 + that hit
+#pragma unroll
+                            for (uint32_t j = 0; j < 3; ++j) {
+                                const uint32_t hj = (ch >> (10u * j)) & 1023u;
+                                const bool mine = cb[j] == a_seq[L] && hj + 1u > hw;
+                                hw = mine ? hj + 1u : hw;
+                                xw = mine ? xb[j] : xw;
+                            }
+                            hw = (was_free || coop) ? 0u : hw;
+                            unsigned long long sm = __ballot(coop);
+                            if (K7_RARE(sm != 0ull)) {  // more than three candidates / wide window: resolved cooperatively
+                                const uint32_t p_cnt = C(11), p_off = pv_off;
+                                if ((uint32_t)__popcll(sm) * 8u >= p_cnt) {  // (many: one pass over the hits, extend_fast_dev.hpp)
+                                    for (uint32_t h0 = 0; h0 < p_cnt; h0 += 64u) {
+                                        const uint32_t h = h0 + (uint32_t)lane;
+                                        const PosT xh = h < p_cnt ? s_hits[p_off + h] : (PosT)0;
+                                        const uint32_t bh = h < p_cnt ? *reinterpret_cast<const uint32_t *>(best0 + pv_besto + 4u * h) : kNone;
+                                        const uint32_t nh = min(64u, p_cnt - h0);
+                                        for (uint32_t j = 0; j < nh; ++j) {
+                                            const uint32_t b = lane_of(bh, j);
+                                            PosT x;
+                                            if constexpr (kWidePos) x = (PosT)lane_of((unsigned long long)xh, j);
+                                            else x = (PosT)lane_of((uint32_t)xh, j);
+                                            const bool mine = coop && a_seq[L] == b;
+                                            hw = mine ? h0 + j + 1u : hw;
+                                            xw = mine ? x : xw;
+                                        }
+                                    }
+                                    sm = 0ull;
+                                }
+                                while (sm) {
+                                    const uint32_t l = (uint32_t)(__ffsll((long long)sm) - 1);
+                                    sm &= sm - 1ull;
+                                    const PosT lo = (PosT)(a_re[L] - k + 1u);
+                                    const WinT w = (WinT)a_thr[L] + (WinT)(k - 1u);
+                                    PosT lo_u;
+                                    WinT w_u;
+                                    if constexpr (kWidePos) {
+                                        lo_u = (PosT)lane_of((unsigned long long)lo, l);
+                                        w_u = (WinT)lane_of((unsigned long long)w, l);
+                                    } else {
+                                        lo_u = (PosT)lane_of((uint32_t)lo, l);
+                                        w_u = (WinT)lane_of((uint32_t)w, l);
+                                    }
+                                    const uint32_t key = lane_of(a_seq[L], l);
+                                    uint32_t hmax = kNone;
+                                    PosT x_u = 0;
+                                    for (uint32_t h0 = 0; h0 < p_cnt; h0 += 64u) {
+                                        const uint32_t h = h0 + (uint32_t)lane;
+                                        PosT x = 0;
+                                        bool ok = false;
+                                        if (h < p_cnt) {
+                                            x = s_hits[p_off + h];
+                                            ok = (WinT)(PosT)(x - lo_u) < w_u &&
+                                                 *reinterpret_cast<const uint32_t *>(best0 + pv_besto + 4u * h) == key;
+                                        }
+                                        const unsigned long long bm = __ballot(ok);
+                                        if (bm) {
+                                            const uint32_t top = 63u - (uint32_t)__clzll((long long)bm);
+                                            hmax = h0 + top;
+                                            if constexpr (kWidePos) x_u = (PosT)lane_of((unsigned long long)x, top);
+                                            else x_u = (PosT)lane_of((uint32_t)x, top);
+                                        }
+                                    }
+                                    if ((uint32_t)lane == l && hmax != kNone) {
+                                        hw = hmax + 1u;
+                                        xw = x_u;
+                                    }
+                                }
+                            }
+                            won = hw != 0u;
+                        }
+                        // ExtendArm (src/automaton.rs:133-150) or one more step of age (:166-171), then the quiet probes
+                        // between the previous probe and this one
+                        uint32_t thr_new;
+                        if constexpr (kWidePos) {
+                            const uint64_t p_i64 = ((uint64_t)C(13) << 32) | C(12);
+                            thr_new = arm_threshold((uint64_t)(p_i64 + k) - (uint64_t)a_ls[L], G);
+                        } else {
+                            thr_new = max(G, ((p_i + k) - (uint32_t)a_ls[L]) / 10u);
+                        }
+                        const uint64_t sum_g = (uint64_t)(won ? 0u : a_gap[L]) + (has_prev && !won ? step : 0u) + pend;
+                        const uint32_t aged = sum_g > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)sum_g;
+                        a_re[L] = won ? (PosT)(xw + k) : a_re[L];
+                        PosT le_new;
+                        if constexpr (kWidePos) le_new = (PosT)((((uint64_t)C(13) << 32) | C(12)) + k);
+                        else le_new = (PosT)(p_i + k);
+                        if (won) s_cle[L * (NWA * 64) + tid] = le_new;
+                        a_thr[L] = won ? thr_new : a_thr[L];
+                        a_gap[L] = aged;
+                        const bool dead = !was_free && aged >= G;  // never matches again
+                        if (K7_RARE(__ballot(dead) != 0ull)) {
+                            const PosT rs_L = s_crs[L * (NWA * 64) + tid];
+                            const bool report = dead && (uint64_t)(a_re[L] - rs_L) >= M;
+                            if (__ballot(report) != 0ull)
+                                emit_records(report, a_ls[L], s_cle[L * (NWA * 64) + tid], rs_L, a_re[L], a_seq[L], PB(3));
+                        }
+                        a_seq[L] = dead ? kNoSeq : a_seq[L];
+                    }
+                }
+                K7U_LAP(1);
+                // ---- every arm offers to this step's probe --------------------------------------------------------------
+                if (has_cur && livemask) {
+                    const Cur q{k, C(5), C(19), C(3), C(4), C(9), C(1), C(2)};
+                    const uint32_t ns_b = PB(16u + C(9));  // the stash count of the step's probe (final: indexed a step ago)
+#pragma unroll
+                    for (int L = 0; L < S; ++L) {
+                        if (!(livemask >> L)) break;
+                        if (livemask & (1u << L))
+                            c_h[L] = offer_window(q, (PosT)(a_re[L] - k + 1u), (WinT)a_thr[L] + (WinT)(k - 1u), a_seq[L], a_seq[L] != kNoSeq, ns_b);
+                    }
+                }
+                K7U_LAP(2);
+                if (had_live || received) {  // free counts, as the control wave will rank them in the next step (an idle
+                                             // wave's stay as they are: all empty)
+                    uint32_t nfv[8] = {64u, 64u, 64u, 64u, 64u, 64u, 64u, 64u};
+#pragma unroll
+                    for (int L = 0; L < S; ++L) {
+                        if (!(livemask >> L)) break;
+                        if (livemask & (1u << L)) {
+                            const uint32_t nf = (uint32_t)__popcll(__ballot(a_seq[L] == kNoSeq));
+                            nfv[L] = nf;
+                            if (nf == 64u) livemask &= ~(1u << L);
+                        }
+                    }
+                    *reinterpret_cast<uint4 *>(&s_free[wave][0]) = make_uint4(nfv[0], nfv[1], nfv[2], nfv[3]);
+                    if constexpr (S > 4) *reinterpret_cast<uint4 *>(&s_free[wave][4]) = make_uint4(nfv[4], nfv[5], nfv[6], nfv[7]);
+                }
+                if (K7_RARE(npre & K7_STAGE)) store_rows(N(26), N(27));
+                K7U_LAP(3);
+                K7T_LAP(0);
+                lds_barrier();  // ---- the barrier of the step ---------------------------------------------------------
+                K7T_LAP(1);
+                pv_off = C(2);
+                pv_besto = C(4);
+                if (K7_RARE(!more)) break;
+            }
+            if (wave == 0u) K7T_FLUSH(1);
+            if (wave == 0u) K7U_FLUSH();
+#ifdef K8_TRACE_WAVE
+            if (wave == (uint32_t)(K8_TRACE_WAVE)) K7T_FLUSH(2);  // (diagnostic build: -DK8_TRACE_WAVE=n traces arm wave n instead)
+#endif
+        } else if (is_rank) {
+            // =====================================================================================================
+            // RANKING WAVE: flushes, unmatched hits -> new arms (ranks, slots, first offers), overflow
+            // =====================================================================================================
+            const RunParams &rp = P.rp;
+            const uint32_t k = (uint32_t)rp.k, step = (uint32_t)rp.step, G = rp.G;
+            const uint32_t thr0 = arm_threshold(k, G);
+            const uint32_t cap_eff = min((uint32_t)CAP, P.cap_limit);
+            const uint32_t g0 = P.seg_list[seg];
+#ifdef ASGART_PROFILE_EXTEND
+            const unsigned long long k7_seg0 = __builtin_amdgcn_s_memtime();
+#endif
+            uint32_t fam_seq = 0, next_seq = 0, spur_until = 0;
+            bool fam_open = false;
+            lds_barrier();  // (1)
+            {
+                const uint4 m1 = *reinterpret_cast<const uint4 *>(&s_mid[4]);
+                if (uni(s_mid[0]) & K7_STAGE) {
+                    fetch_rows(((unsigned long long)uni(m1.y) << 32) | uni(m1.x), uni(m1.z));
+                    store_rows(uni(m1.z), uni(m1.w));
+                }
+            }
+            lds_barrier();  // (2)
+            {
+                const uint32_t w0 = s_cmd[0][lane & 31];
+                auto C0 = [&](int j) { return (uint32_t)__builtin_amdgcn_readlane((int)w0, j); };
+                if ((C0(0) & K7_CUR) && indexes(C0(1))) insert_hits(C0(1), C0(2), C0(3), C0(4), C0(9), C0(5), C0(19), false, 0ull);
+            }
+            lds_barrier();  // (3)
+            // what the pull that is pending took of each (wave, layer) entry (entry j = lane, and lane + 64)
+            uint32_t took1 = 0, took2 = 0, pending_alive = 0;
+            for (uint32_t sc = 0, sp = 0;; sc = sc == 2u ? 0u : sc + 1u, sp ^= 1u) {
+                const uint32_t sn = sc == 2u ? 0u : sc + 1u;
+                const uint32_t cw = s_cmd[lane < 32 ? sc : sn][lane & 31];
+                auto C = [&](int j) { return (uint32_t)__builtin_amdgcn_readlane((int)cw, j); };
+                auto N = [&](int j) { return (uint32_t)__builtin_amdgcn_readlane((int)cw, 32 + j); };
+                const uint32_t flags = C(0);
+                if ((flags & K7_GIVEUP) || overflow) {  // (its own decision of the step before, or the planning wave's)
+                    overflow = true;
+                    break;
+                }
+                const bool have_prev = (flags & K7_PREV) != 0u, has_cur = (flags & K7_CUR) != 0u;
+                const bool more = !(flags & K7_LAST);
+                const uint32_t nflags = more ? N(0) : 0u;
+                const uint32_t prev_cnt = C(11), prev_off = C(14), prev_bb = C(23), prev_t_before = C(28), prev_t_after = C(29);
+                const uint32_t bsh = C(19);
+                K7T_MARK();
+                K7T_STEP();
+                if (flags & K8_CLEARNOW) clear_table();
+                const uint32_t npre = more ? N(10) : 0u;
+                const unsigned long long st_base = ((unsigned long long)N(25) << 32) | N(24);
+                const uint32_t st_tot = N(26), st_buf = N(27);
+                if (npre & K7_STAGE) fetch_rows(st_base, st_tot);
+                if (more && (nflags & K7_CUR) && indexes(N(1)))
+                    insert_hits(N(1), N(2), N(3), N(4), N(9), N(5), bsh, (nflags & K7_LATE) != 0u, st_base + (N(2) - st_buf * (uint32_t)HB));
+                    // ---- slots: what the arm waves published, minus what the pending pull takes --------------------------
+                    const uint32_t fv = lane < NE ? s_free[lane % NWA][lane / NWA] : 0u;
+                    const uint32_t fv2 = NE > 64 && lane + 64 < NE ? s_free[(lane + 64) % NWA][(lane + 64) / NWA] : 0u;
+                    uint32_t n_new = 0, seq_base = 0, pflags = 0;
+                    uint32_t av1 = fv - min(fv, took1), av2 = fv2 - min(fv2, took2);
+                    uint32_t base1 = 0, base2 = 0;
+                    if (have_prev) {
+                        const uint32_t h_l = min((uint32_t)lane, prev_cnt - 1u);
+                        const uint32_t bv0 = s_best[prev_bb][h_l];
+                        const uint8_t hf0 = use_flag ? s_hflag[prev_off + h_l] : (uint8_t)1;
+                        const PosT x0 = s_hits[prev_off + h_l];
+                        uint32_t bv1 = kNone, bv2 = kNone;
+                        uint8_t hf1 = 1, hf2 = 1;
+                        PosT x1 = 0, x2 = 0;
+                        if (prev_cnt > 64u) {
+                            const uint32_t h1 = min(64u + (uint32_t)lane, prev_cnt - 1u), h2 = min(128u + (uint32_t)lane, prev_cnt - 1u);
+                            bv1 = s_best[prev_bb][h1];
+                            bv2 = s_best[prev_bb][h2];
+                            x1 = s_hits[prev_off + h1];
+                            x2 = s_hits[prev_off + h2];
+                            if (use_flag) {
+                                hf1 = s_hflag[prev_off + h1];
+                                hf2 = s_hflag[prev_off + h2];
+                            }
+                        }
+                        // (one scan for both halves of the entries: two 16-bit fields, each total < 2^16)
+                        const uint32_t packed = wave_incl_scan(av1 | (av2 << 16));
+                        const uint32_t fpk = wave_incl_scan(fv | (fv2 << 16));
+                        const uint32_t tot_p = lane_of(packed, 63u), tot_f = lane_of(fpk, 63u);
+                        uint32_t total_av = tot_p & 0xFFFFu;
+                        base1 = (packed & 0xFFFFu) - av1;
+                        if constexpr (NE > 64) {
+                            base2 = (packed >> 16) + total_av - av2;
+                            total_av += tot_p >> 16;
+                        }
+                        const uint32_t total_free = (tot_f & 0xFFFFu) + (NE > 64 ? tot_f >> 16 : 0u);
+                        // live arms when the previous probe is processed: the ones in their slots and the ones still to be pulled
+                        const uint32_t A0 = (uint32_t)CAP - total_free + pending_alive;
+#ifdef ASGART_PROFILE_EXTEND
+                        k7_sum_a += A0;
+                        k7_sum_cnt += prev_cnt;
+                        ++k7_sum_n;
+#endif
+                        if (fam_open && A0 == 0 && prev_t_before >= spur_until) {  // the flush of src/automaton.rs:182-200
+                            ++fam_seq;
+                            next_seq = 0;
+                            fam_open = false;
+                        }
+                        // unmatched hits, in hit order (= creation order, src/automaton.rs:151-164) -> s_newx[rank]
+                        bool spur = false;
+                        auto rank_group = [&](uint32_t h0, uint32_t bv, uint8_t hf, PosT x) {
+                            const bool in = h0 + (uint32_t)lane < prev_cnt;
+                            const bool un = in && bv == kNone && hf != 0;
+                            const unsigned long long m = __ballot(un);
+                            const uint32_t at = n_new + (uint32_t)__popcll(m & lt_mask);
+                            if (un && at < kNewMax) s_newx[sp][at] = x;
+                            n_new += (uint32_t)__popcll(m);
+                            if (use_flag) spur = spur || __ballot(in && bv == kNone && hf == 0) != 0ull;
+                        };
+                        rank_group(0u, bv0, hf0, x0);
+                        if (prev_cnt > 64u) {
+                            rank_group(64u, bv1, hf1, x1);
+                            if (prev_cnt > 128u) rank_group(128u, bv2, hf2, x2);
+                        }
+                        for (uint32_t h0 = 192u; h0 < prev_cnt; h0 += 64u) {
+                            const uint32_t h = min(h0 + (uint32_t)lane, prev_cnt - 1u);
+                            rank_group(h0, s_best[prev_bb][h], use_flag ? s_hflag[prev_off + h] : (uint8_t)1, s_hits[prev_off + h]);
+                        }
+                        if (n_new > total_av || n_new > kNewMax || A0 + n_new > cap_eff) pflags |= K8_OVF;
+                        seq_base = next_seq;
+                        next_seq += n_new;
+                        fam_open = true;
+                        if (spur) spur_until = max(spur_until, prev_t_after + rp.tstar - 1u);
+                    }
+                    // the quiet probes between the previous probe and this step's age its new arms before they can match
+                    const uint64_t g_new = (uint64_t)step + C(8);
+                    const bool stillborn = g_new >= (uint64_t)G;
+                    if (stillborn) pflags |= K8_STILL;
+                    // ---- the new arms' offers to this step's probe, on their behalf --------------------------------------
+                    if (n_new && !(pflags & K8_OVF)) {
+                        const Cur q{k, C(5), C(19), C(3), C(4), C(9), C(1), C(2)};
+                        const uint32_t ns_b = has_cur ? uni(s_nstash[C(9)]) : 0u;
+                        for (uint32_t r0 = 0; r0 < n_new; r0 += 64u) {
+                            const uint32_t r = r0 + (uint32_t)lane;
+                            const bool who = r < n_new && has_cur && !stillborn;
+                            uint32_t ch = 0;
+                            if (has_cur && !stillborn) {
+                                const PosT x = s_newx[sp][min(r, n_new - 1u)];
+                                ch = offer_window(q, (PosT)(x + 1u), (WinT)thr0 + (WinT)(k - 1u), seq_base + r, who, ns_b);
+                            }
+                            if (r < n_new) s_newch[sp][r] = who ? ch : 0u;
+                        }
+                    }
+                    // ---- the pull block of the next step -------------------------------------------------------------------
+                    {
+                        const uint32_t tk1 = n_new > base1 ? min(av1, n_new - base1) : 0u;
+                        const uint32_t tk2 = n_new > base2 ? min(av2, n_new - base2) : 0u;
+                        if (lane < NE) s_slot[sp][lane % NWA][lane / NWA] = (av1 << 16) | base1;
+                        if constexpr (NE > 64)
+                            if (lane + 64 < NE) s_slot[sp][(lane + 64) % NWA][(lane + 64) / NWA] = (av2 << 16) | base2;
+                        took1 = (have_prev && !stillborn) ? tk1 : 0u;
+                        took2 = (have_prev && !stillborn) ? tk2 : 0u;
+                        pending_alive = stillborn ? 0u : n_new;
+                        if (lane == 0) {
+                            *reinterpret_cast<uint4 *>(&s_pull[sp][0]) = make_uint4(pflags, n_new, seq_base, fam_seq);
+                            *reinterpret_cast<uint4 *>(&s_pull[sp][4]) = make_uint4(C(12), C(13), C(8), 0u);
+                        }
+                        if (pflags & K8_OVF) overflow = true;
+                    }
+                    // the stash and the occupancy bits of the previous probe: nobody reads them any more
+                    if (lane == 0 && have_prev) s_nstash[prev_bb] = 0u;
+                    if (have_prev && (uint32_t)lane < kBitWords) s_rowbits[prev_bb][lane] = 0u;
+                if (npre & K7_STAGE) store_rows(st_tot, st_buf);
+                K7T_LAP(0);
+                lds_barrier();  // ---- the barrier of the step -----------------------------------------------------
+                K7T_LAP(1);
+                if (!more) break;
+            }
+            K7T_FLUSH(0);
+#ifdef ASGART_PROFILE_EXTEND
+            if (lane == 0) {
+                atomicAdd(&P.ctr[26], k7_sum_a);
+                atomicAdd(&P.ctr[27], k7_sum_cnt);
+                atomicAdd(&P.ctr[21], k7_sum_n);
+                const unsigned long long k7_dt = __builtin_amdgcn_s_memtime() - k7_seg0;
+                if (atomicMax(&P.ctr[28], k7_dt) < k7_dt) {
+                    P.ctr[29] = g0;
+                    P.ctr[30] = k7_sum_n << 32;
+                    P.ctr[31] = (k7_sum_a << 32) | (k7_sum_cnt & 0xffffffffull);
+                }
+            }
+            k7_sum_a = k7_sum_cnt = k7_sum_n = 0;
+#endif
+            if (!overflow) {
+                // nothing alive is left behind unless the chunk (or the window of a sharded call) ended first
+                const uint32_t fv = lane < NE ? s_free[lane % NWA][lane / NWA] : 0u;
+                uint32_t total_free = lane_of(wave_incl_scan(fv), 63u);
+                if constexpr (NE > 64) {
+                    const uint32_t fv2 = lane + 64 < NE ? s_free[(lane + 64) % NWA][(lane + 64) / NWA] : 0u;
+                    total_free += lane_of(wave_incl_scan(fv2), 63u);
+                }
+                const uint32_t t_proc = uni(s_end[0]);
+                const bool ran_out = uni(s_end[1]) != 0u;
+                if (fam_open && total_free == (uint32_t)CAP && t_proc >= spur_until) fam_open = false;
+                if (ran_out) {
+                    if (lane == 0) atomicAdd(&P.ctr[CT_RANOUT], 1ull);
+                } else if (fam_open) {  // arms alive at the end of the chunk void their family (src/automaton.rs:201-203)
+                    emit_records(lane == 0, (PosT)0, (PosT)0, (PosT)0, (PosT)0, kTombstone, fam_seq);
+                }
+            } else if (lane == 0) {
+                const unsigned long long at = atomicAdd(P.ovf_count, 1ull);
+                if (P.ovf_list) P.ovf_list[at] = g0;
+            }
+        } else {
+            // =====================================================================================================
+            // PLANNING WAVE: walks the probe sequence two steps ahead of the others, writes the commands
+            // =====================================================================================================
+            const RunParams &rp = P.rp;
+            const uint32_t k = (uint32_t)rp.k, step = (uint32_t)rp.step, G = rp.G;
+            const uint32_t thr0 = arm_threshold(k, G);
+            uint32_t bsh = 3;
+            while ((1ull << bsh) < (unsigned long long)G + k) ++bsh;
+            bsh += P.fast_bsh;
+            const uint32_t kGenBits = min(kGenMax, max(2u, P.gen_bits));
+            const uint32_t g0 = P.seg_list[seg];
+            if (lane == 0) heartbeat(P, g0, 0u);
+            const int c = chunk_of_uniform(rp.ch, g0);
+            const uint64_t cs = rp.ch.start[c], cl = rp.ch.len[c];
+            const uint32_t pb = rp.ch.pbase[c];
+            const uint32_t chunk_end = rp.ch.pbase[c + 1];
+            const uint32_t g_end = min(chunk_end, rp.g_hi);
+            if (lane == 0) {
+                s_seg[0] = g0;
+                s_seg[1] = cs;
+                s_seg[2] = cl;
+            }
+            uint32_t quiet = 0, pend = 0, t_proc = 0;
+            bool done = false, giveup = false;
+            uint32_t hbuf = 2;  // (the first batch moves it to 0)
+            // ---- the batch under the cursor ---------------------------------------------------------------------
+            uint32_t g = g0, nbb = 0, pos = 0, f_l = 0, rel_l = 0, tot = 0;
+            unsigned long long hm = 0, qm = 0, base = 0;
+            bool staged = false;  // the rows of the batch under the cursor are in s_hits[hbuf] (or on their way)
+            auto load_batch = [&]() {  // -> false: a probe with more hits than the staging area
+                const uint32_t nb = min(64u, g_end - g);
+                if (lane == 0) heartbeat(P, g0, g);
+                f_l = (uint32_t)lane < nb ? P.p_filt[g + lane] : kSkipN;
+                const unsigned long long r_l = (uint32_t)lane < nb ? P.row_off[g + lane] : 0ull;
+                const unsigned long long r_hi = uni(P.row_off[g + nb]);
+                base = lane_of(r_l, 0u);
+                unsigned long long r_next = __shfl_down(r_l, 1);
+                if ((uint32_t)lane + 1 >= nb) r_next = r_hi;
+                const bool fits = (uint32_t)lane < nb && r_next - base <= (unsigned long long)HB;
+                const unsigned long long fm = __ballot(fits);
+                nbb = (~fm == 0ull) ? 64u : (uint32_t)(__ffsll((long long)~fm) - 1);
+                if (nbb > nb) nbb = nb;
+                if (nbb == 0) return false;
+                rel_l = (uint32_t)(r_l - base);
+                tot = (uint32_t)((nbb == nb ? r_hi : lane_of(r_l, nbb)) - base);
+                const unsigned long long in_batch = nbb >= 64 ? ~0ull : ((1ull << nbb) - 1ull);
+                hm = __ballot(f_l >= 1u && f_l < kPending) & in_batch;
+                qm = __ballot(f_l == 0u) & in_batch;
+                pos = 0;
+                staged = false;
+                return true;
+            };
+            struct Probe {
+                uint32_t cnt, off, tb, bb, g10, pend, t_before, t_after;
+                uint64_t i;
+            };
+            struct Plan {
+                uint32_t flags, pre;           // command flags; K7_STAGE: its batch is staged during the step before
+                unsigned long long st_base;    // staging request
+                uint32_t st_tot, st_buf;
+                Probe q;
+            };
+            const Probe no_probe{0, 0, 0, 0, 0, 0, 0, 0, 0};
+            bool opened = false;  // the probe just found opened a batch (its rows are to be staged)
+            auto next_probe = [&](Probe &nx) -> bool {
+                for (;;) {
+                    const unsigned long long hmr = pos >= 64 ? 0ull : (hm >> pos) << pos;
+                    const uint32_t b = hmr ? (uint32_t)(__ffsll((long long)hmr) - 1) : 64u;
+                    const unsigned long long upto = b >= 64 ? ~0ull : ((1ull << b) - 1ull);
+                    const unsigned long long from = pos >= 64 ? 0ull : ~((1ull << pos) - 1ull);
+                    const uint32_t q = (uint32_t)__popcll(qm & upto & from);
+                    if (q) {
+                        quiet += q;
+                        t_proc += q;
+                        pend += q * step;
+                        if (quiet >= rp.tstar) {  // every arm is dead (gap >= G): the segment is over
+                            done = true;
+                            return false;
+                        }
+                    }
+                    if (hmr) {
+                        quiet = 0;
+                        pos = b + 1;
+                        opened = false;
+                        if (!staged) {
+                            hbuf = hbuf == 2u ? 0u : hbuf + 1u;
+                            opened = true;
+                            staged = true;
+                        }
+                        nx.cnt = lane_of(f_l, b);
+                        nx.off = hbuf * (uint32_t)HB + lane_of(rel_l, b);
+                        nx.i = (uint64_t)(g + b - pb + 1) * step;
+                        nx.pend = pend;
+                        pend = 0;
+                        nx.t_before = t_proc;
+                        nx.t_after = ++t_proc;
+                        return true;
+                    }
+                    g += nbb;
+                    if (g >= g_end) return false;
+                    if (!load_batch()) {
+                        giveup = true;
+                        return false;
+                    }
+                }
+            };
+            auto number_probe = [&](Probe &q) {
+                bool wrap = false;
+                if ((gen + 1u) >> kGenBits) {
+                    wrap = true;
+                    gen = 0;
+                }
+                ++gen;
+                q.g10 = gen << 10;
+                q.tb = par;
+                q.bb = tri;
+                par ^= 1u;
+                tri = tri == 2u ? 0u : tri + 1u;
+                return wrap;
+            };
+            // the plan of the step behind one with flags `last_flags`.  A generation wrap takes two steps of its own: one
+            // that resolves the probe before (if any) and clears the tables, one in which the new probe's hits are indexed.
+            uint32_t held_stage = 0;  // 1: the indexing step is next; 2: then the held probe
+            Plan held{};
+            bool ended = false, tail_done = false;
+            auto advance = [&](uint32_t last_flags) -> Plan {
+                Plan n{};
+                n.q = no_probe;
+                if (held_stage == 1u) {
+                    held_stage = 2u;
+                    return n;  // (no probe: the held probe's hits are indexed during it)
+                }
+                if (held_stage == 2u) {
+                    held_stage = 0u;
+                    return held;
+                }
+                Probe nx = no_probe;
+                bool found = false;
+                if (!ended) found = next_probe(nx);
+                if (giveup) {
+                    n.flags = K7_GIVEUP;
+                    return n;
+                }
+                if (!found) {
+                    ended = true;
+                    if (!tail_done) {  // the last probe is resolved, the trailing quiet probes age the arms ...
+                        tail_done = true;
+                        n.flags = (last_flags & K7_CUR) ? K7_PREV : 0u;
+                        n.q.pend = pend;
+                        pend = 0;
+                        return n;
+                    }
+                    n.flags = K7_LAST;  // ... and the arms born of the last probe are pulled
+                    return n;
+                }
+                const bool wrap = number_probe(nx);
+                Plan p{};
+                p.q = nx;
+                p.pre = opened ? K7_STAGE : 0u;
+                p.st_base = base;
+                p.st_tot = tot;
+                p.st_buf = hbuf;
+                p.flags = K7_CUR | (opened ? K7_LATE : 0u);
+                if (wrap) {
+                    held = p;  // (behind two steps without a probe: no predecessor to resolve)
+                    held_stage = 1u;
+                    n.flags = ((last_flags & K7_CUR) ? K7_PREV : 0u) | K8_CLEARNOW;
+                    return n;
+                }
+                p.flags |= (last_flags & K7_CUR) ? K7_PREV : 0u;
+                return p;
+            };
+            struct Before {
+                uint32_t cnt, i_lo, i_hi, off, bb, t_before, t_after;
+            };
+            auto write_cmd = [&](uint32_t slot, const Plan &p, const Before &b) {
+                if (lane == 0) {
+                    uint4 *o = reinterpret_cast<uint4 *>(&s_cmd[slot][0]);
+                    o[0] = make_uint4(p.flags, p.q.cnt, p.q.off, p.q.tb * kTabBytes);
+                    o[1] = make_uint4(p.q.bb * (uint32_t)(HB * 4), p.q.g10, (uint32_t)p.q.i, (uint32_t)(p.q.i >> 32));
+                    o[2] = make_uint4(p.q.pend, p.q.bb, p.pre, b.cnt);
+                    o[3] = make_uint4(b.i_lo, b.i_hi, b.off, b.bb * (uint32_t)(HB * 4));
+                    s_cmd[slot][23] = b.bb;
+                    if (p.pre & K7_STAGE) o[6] = make_uint4((uint32_t)p.st_base, (uint32_t)(p.st_base >> 32), p.st_tot, p.st_buf);
+                    o[7] = make_uint4(b.t_before, b.t_after, p.q.t_before, p.q.t_after);
+                }
+            };
+            auto before_of = [&](const Plan &p) {
+                return Before{p.q.cnt, (uint32_t)p.q.i, (uint32_t)(p.q.i >> 32), p.q.off, p.q.bb, p.q.t_before, p.q.t_after};
+            };
+            if (lane < 3) {  // the run's constants, once per segment, in every command block
+                uint4 *o = reinterpret_cast<uint4 *>(&s_cmd[lane][0]);
+                o[4] = make_uint4(k, step, G, bsh);
+                s_cmd[lane][20] = (uint32_t)rp.M;
+                s_cmd[lane][21] = (uint32_t)(rp.M >> 32);
+                s_cmd[lane][22] = thr0;
+            }
+
+            // ---- the first two steps are planned before the loop ---------------------------------------------------
+            Plan p_cur{}, p_next{};
+            p_cur.q = p_next.q = no_probe;
+            if (!load_batch()) giveup = true;
+            if (giveup) p_cur.flags = K7_GIVEUP;
+            else p_cur = advance(0u);  // (the segment starts with a hit-probe: its batch is staged and indexed below)
+            if (lane == 0) {
+                s_mid[0] = p_cur.pre;
+                *reinterpret_cast<uint4 *>(&s_mid[4]) = make_uint4((uint32_t)p_cur.st_base, (uint32_t)(p_cur.st_base >> 32), p_cur.st_tot, p_cur.st_buf);
+            }
+            {
+                Plan none{};
+                none.q = no_probe;
+                write_cmd(0u, p_cur, before_of(none));
+            }
+            if (!(p_cur.flags & (K7_GIVEUP | K7_LAST))) {
+                p_next = advance(p_cur.flags);
+                write_cmd(1u, p_next, before_of(p_cur));
+            }
+            lds_barrier();  // (1)
+            if (p_cur.pre & K7_STAGE) {
+                fetch_rows(p_cur.st_base, p_cur.st_tot);
+                store_rows(p_cur.st_tot, p_cur.st_buf);
+            }
+            lds_barrier();  // (2)
+            if ((p_cur.flags & K7_CUR) && indexes(p_cur.q.cnt))
+                insert_hits(p_cur.q.cnt, p_cur.q.off, p_cur.q.tb * kTabBytes, p_cur.q.bb * (uint32_t)(HB * 4), p_cur.q.bb, p_cur.q.g10, bsh, false, 0ull);
+            lds_barrier();  // (3)
+            for (uint32_t sc = 0, sp = 0;; sc = sc == 2u ? 0u : sc + 1u, sp ^= 1u) {
+                const uint32_t sn = sc == 2u ? 0u : sc + 1u;
+                const uint32_t cw = s_cmd[lane < 32 ? sc : sn][lane & 31];
+                const uint32_t pflags_prev = s_pull[sp ^ 1u][0];  // (the ranking wave's decision of the step before)
+                K7T_MARK();
+                auto C = [&](int j) { return (uint32_t)__builtin_amdgcn_readlane((int)cw, j); };
+                auto N = [&](int j) { return (uint32_t)__builtin_amdgcn_readlane((int)cw, 32 + j); };
+                const uint32_t flags = C(0);
+                if ((flags & K7_GIVEUP) || (uni(pflags_prev) & K8_OVF)) {
+                    overflow = true;
+                    break;
+                }
+                const bool more = !(flags & K7_LAST);
+                const uint32_t nflags = more ? N(0) : 0u;
+                if (flags & K8_CLEARNOW) clear_table();
+                const uint32_t npre = more ? N(10) : 0u;
+                const unsigned long long st_base = ((unsigned long long)N(25) << 32) | N(24);
+                const uint32_t st_tot = N(26), st_buf = N(27);
+                if (npre & K7_STAGE) fetch_rows(st_base, st_tot);
+                if (more && (nflags & K7_CUR) && indexes(N(1)))
+                    insert_hits(N(1), N(2), N(3), N(4), N(9), N(5), bsh, (nflags & K7_LATE) != 0u, st_base + (N(2) - st_buf * (uint32_t)HB));
+                // ---- the step after next ---------------------------------------------------------------------------------
+                if (more && !(nflags & (K7_LAST | K7_GIVEUP))) {
+                    const Plan p_after = advance(nflags);
+                    write_cmd(sc == 0u ? 2u : sc - 1u, p_after, Before{N(1), N(6), N(7), N(2), N(9), N(30), N(31)});
+                    if ((p_after.flags & K7_LAST) && lane == 0) {  // (what the ranking wave needs when the segment is over)
+                        s_end[0] = t_proc;
+                        s_end[1] = (!done && g_end < chunk_end) ? 1u : 0u;
+                    }
+                }
+                if (npre & K7_STAGE) store_rows(st_tot, st_buf);
+                K7T_LAP(0);
+                lds_barrier();  // ---- the barrier of the step -----------------------------------------------------
+                K7T_LAP(1);
+                if (!more) break;
+            }
+#ifndef K8_TRACE_WAVE
+            K7T_FLUSH(2);  // (diagnostic build: the planning wave is the third class of the step trace)
+#endif
+            (void)thr0;
+            (void)G;
+        }
+        // leave no arm behind for the next segment
+#pragma unroll
+        for (int L = 0; L < S; ++L) a_seq[L] = kNoSeq;
+        livemask = 0;
+        lds_barrier();
+    }
+    rec_flush(rec_alloc, P, lane);
+}
+
+}  // namespace asgart

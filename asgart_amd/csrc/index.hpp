@@ -272,6 +272,8 @@ struct Options {
                                     // slower than the slice mode's (211 vs 184 ms -RC, 117 vs 90 ms direct): the floor is the longest segment
     int64_t tier_streams = 7234562; // digit t (from the left): the stream (1..7, 1 = the call's high-priority main stream) tier t runs on
     int64_t k7 = 8;                 // bit t set (t = 3..6): tier t runs the arm kernel with a control wave (extend_k7_dev.hpp) instead of K6 / K4c. Default: tier 3 only -- the long DENSE segments (option dense3), where its shorter per-probe chain counts; measured in the other tiers (k7 = 120) it loses: a quarter / an eighth of a 256- / 512-thread workgroup holds no arms and a sparse probe costs two barriers instead of one wave's solo run
+    int64_t k8 = 1;                 // 1: the tiers of option k7 run the one-barrier variant (extend_k8_dev.hpp: the new arms' first offers are
+                                    // made by a ranking wave, a planning wave writes the commands; 14 arm waves instead of 15); 0: K7
     int64_t lazy_aux = 1;           // 1: the presence filter of an orientation is built when that orientation is searched the SECOND time, the
                                     // position-sorted lists when a search call has had a predecessor: they cost 0.18 s per orientation / 0.2 s
                                     // at GRCh38 size and save 0.03 / 0.006 s per pass -- a host that runs every orientation once per index

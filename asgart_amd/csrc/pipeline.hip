@@ -7,6 +7,7 @@
 #include "pipeline_dev.hpp"
 #include "extend_fast_dev.hpp"
 #include "extend_k7_dev.hpp"
+#include "extend_k8_dev.hpp"
 
 #include <algorithm>
 #include <atomic>
@@ -441,13 +442,13 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
         if (arms_kernel) {
             if (arms_small) {
                 tier_cap[2] = (uint32_t)kWaveArmsLayers<SlotT> * 64u;
-                tier_cap[4] = (uint32_t)((uint64_t)(k7_tier(4) ? kK7Mid4Layers<SlotT> * 192 : kMidArmsLayers<SlotT> * 256) *
+                tier_cap[4] = (uint32_t)((uint64_t)(k7_tier(4) ? kK7Mid4Layers<SlotT> * (opt.k8 ? 128 : 192) : kMidArmsLayers<SlotT> * 256) *
                                          (uint64_t)opt.cap45_pct / 100u);
             }
-            tier_cap[3] = k7_tier(3) ? (uint32_t)kK7LongLayers<SlotT> * 960u
+            tier_cap[3] = k7_tier(3) ? (uint32_t)kK7LongLayers<SlotT> * (opt.k8 ? 896u : 960u)
                                      : (uint32_t)(fast_tier(3) ? kFastLongLayers<SlotT> : kLongArmsLayers<SlotT>) * 1024u;
 
-            tier_cap[5] = (uint32_t)((uint64_t)(k7_tier(5) ? kK7Mid5Layers<SlotT> * 448 : kMidArmsLayers<SlotT> * 512) *
+            tier_cap[5] = (uint32_t)((uint64_t)(k7_tier(5) ? kK7Mid5Layers<SlotT> * (opt.k8 ? 384 : 448) : kMidArmsLayers<SlotT> * 512) *
                                      (uint64_t)opt.cap45_pct / 100u);
             // the window bound is pessimistic for tandem arrays (hits extend arms there) and the HBM
             // tier is several times slower per probe: tier 6 also takes segments whose bound exceeds
@@ -456,7 +457,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             // bound three to four times what a segment really holds -- at cfg5 every segment that went to tier 7 by its
             // bound peaked below 4 096 arms: tier 6 accepts up to cap6w_pct of its capacity)
             const uint64_t pct6 = ((fast_tier(6) || k7_tier(6)) && sizeof(SlotT) == 8) ? (uint64_t)opt.cap6w_pct : (uint64_t)opt.cap6_pct;
-            tier_cap[6] = (uint32_t)((uint64_t)(k7_tier(6) ? kK7LongLayers<SlotT> * 960
+            tier_cap[6] = (uint32_t)((uint64_t)(k7_tier(6) ? kK7LongLayers<SlotT> * (opt.k8 ? 896 : 960)
                                                            : (fast_tier(6) ? kFastHeavyLayers<SlotT> * 1024 : kArmsLayers<SlotT> * kHeavyThreads)) *
                                      pct6 / 100u);
             // tier 3 accepts what tier 6 would accept by the bound (a long segment is no less safe there), but
@@ -681,7 +682,8 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                     break;
                 case 3:
                     if (k7_tier(3)) {
-                        extend_k7_kernel<SlotT, kK7LongLayers<SlotT>, 1024, kHitBatch, kFastLongRows<SlotT>, 2><<<grid(256), 1024, 0, st>>>(ep);
+                        if (opt.k8) extend_k8_kernel<SlotT, kK7LongLayers<SlotT>, 1024, kHitBatch, kFastLongRows<SlotT>, 2><<<grid(256), 1024, 0, st>>>(ep);
+                        else extend_k7_kernel<SlotT, kK7LongLayers<SlotT>, 1024, kHitBatch, kFastLongRows<SlotT>, 2><<<grid(256), 1024, 0, st>>>(ep);
                     } else if (fast_tier(3)) {
                         // (the same capacity in three shapes: per-probe work every wave repeats -- ranking the
                         // empty slots and the unmatched hits -- is paid once per wave sharing a SIMD)
@@ -690,7 +692,9 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                         extend_arms_kernel<SlotT, kLongArmsLayers<SlotT>, 1024, kHitBatch, 1024, 4, false, true, kPoleLdsPad><<<grid(256), 1024, 0, st>>>(ep);
                     break;
                 case 4:
-                    if (k7_tier(4))
+                    if (k7_tier(4) && opt.k8)
+                        extend_k8_kernel<SlotT, kK7Mid4Layers<SlotT>, 256, kWaveArmsHits, 512, 2><<<grid(256 * 4), 256, 0, st>>>(ep);
+                    else if (k7_tier(4))
                         extend_k7_kernel<SlotT, kK7Mid4Layers<SlotT>, 256, kWaveArmsHits, 512, 2><<<grid(256 * 4), 256, 0, st>>>(ep);
                     else if (fast_tier(4))
                         extend_fast_kernel<SlotT, kMidArmsLayers<SlotT>, 256, kWaveArmsHits, 512, 2><<<grid(256 * 4), 256, 0, st>>>(ep);
@@ -702,7 +706,9 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                         extend_heavy_kernel<SlotT, kArmCapBig64, kHeavyThreads, 0><<<grid(256), kHeavyThreads, 0, st>>>(ep);
                     break;
                 case 5:
-                    if (k7_tier(5))
+                    if (k7_tier(5) && opt.k8)
+                        extend_k8_kernel<SlotT, kK7Mid5Layers<SlotT>, 512, kHitBatch, 1024, 2><<<grid(256 * 2), 512, 0, st>>>(ep);
+                    else if (k7_tier(5))
                         extend_k7_kernel<SlotT, kK7Mid5Layers<SlotT>, 512, kHitBatch, 1024, 2><<<grid(256 * 2), 512, 0, st>>>(ep);
                     else if (fast_tier(5))
                         extend_fast_kernel<SlotT, kMidArmsLayers<SlotT>, 512, kHitBatch, 1024, 2><<<grid(256 * 2), 512, 0, st>>>(ep);
@@ -711,7 +717,9 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                     break;
                 case 6:
                     if (scratch_override) ep.scratch = scratch_override;
-                    if (k7_tier(6))
+                    if (k7_tier(6) && opt.k8)
+                        extend_k8_kernel<SlotT, kK7LongLayers<SlotT>, 1024, kHitBatch, kFastLongRows<SlotT>, 2><<<grid(256), 1024, 0, st>>>(ep);
+                    else if (k7_tier(6))
                         extend_k7_kernel<SlotT, kK7LongLayers<SlotT>, 1024, kHitBatch, kFastLongRows<SlotT>, 2><<<grid(256), 1024, 0, st>>>(ep);
                     else if (fast_tier(6))  // 5 x 1024 >= 9 x 512 slots; 64-bit positions: 4 x 1024 = 8 x 512 with a smaller table
                         extend_fast_kernel<SlotT, kFastHeavyLayers<SlotT>, 1024, kHitBatch, kFastLongRows<SlotT>, 2><<<grid(256), 1024, 0, st>>>(ep);

@@ -1217,14 +1217,18 @@ def test_lazy_filter_and_lists_same_results(hiplib, monkeypatch):
             assert np.array_equal(got[0], exp[0]) and np.array_equal(got[1], exp[1])
 
 
+@pytest.mark.parametrize("k8", [0, 1])
 @pytest.mark.parametrize("wide", [0, 1])
 @pytest.mark.parametrize("tier", [3, 4, 5, 6])
-def test_control_wave_kernel_in_every_workgroup_tier(hiplib, tier, wide, monkeypatch):
+def test_control_wave_kernel_in_every_workgroup_tier(hiplib, tier, wide, k8, monkeypatch):
     """K7 (extend_k7_dev.hpp: a control wave plans the steps, arm waves do nothing but their arms) runs tier 3 by
     default; option k7 = 120 puts it in tiers 4, 5 and 6 as well (other shapes: 6 x 192, 5 x 448, 5 x 960 slots; with
     64-bit positions 3 x 192, 3 x 448, 4 x 960).  Every segment with a multi-hit probe forced through each of them,
-    with a generation counter that wraps every few probes in one of the passes: identical to the oracle."""
+    with a generation counter that wraps every few probes in one of the passes: identical to the oracle.  k8 = 1: the
+    one-barrier variant of the same kernel (extend_k8_dev.hpp: the control wave makes the new arms' first offers, the arm
+    waves pull them a step later)."""
     monkeypatch.setenv("ASGART_K7", "120")
+    monkeypatch.setenv("ASGART_K8", str(k8))
     monkeypatch.setenv("ASGART_FORCE_TIER", str(tier))
     monkeypatch.setenv("ASGART_FORCE_WIDE", str(wide))
     for name in ("dense_repeats", "satellites"):
@@ -1240,4 +1244,4 @@ def test_control_wave_kernel_in_every_workgroup_tier(hiplib, tier, wide, monkeyp
                 if key not in _ORACLE_CACHE:
                     _ORACLE_CACHE[key] = oidx.run_raw(pr.chunks, oracle.make_settings(reverse=rc, complement=rc, **cli), threads=4)
                 eoffs, esds = _ORACLE_CACHE[key]
-                assert np.array_equal(offs, eoffs) and np.array_equal(sds, esds), (name, tier, wide, rc)
+                assert np.array_equal(offs, eoffs) and np.array_equal(sds, esds), (name, tier, wide, rc, k8)
