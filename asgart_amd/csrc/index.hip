@@ -56,6 +56,7 @@ const OptDesc kOptions[] = {
     {"lazy_aux", &Options::lazy_aux, 0, 1},
     {"dense3", &Options::dense3, 0, 1 << 20},
     {"dense6", &Options::dense6, 0, 1 << 20},
+    {"dense_min", &Options::dense_min, 0, 1 << 30},
     {"k8", &Options::k8, 0, 1},
     {"pass_gate", &Options::pass_gate, 0, 2},
     {"pass_gate_ms", &Options::pass_gate_ms, 0, 100000},

@@ -283,6 +283,8 @@ struct Options {
                                     // to run), 0 = by their arm bound like any other segment (smaller shapes: several per compute unit)
     int64_t dense3 = 16;            // with k7 in tier 3: long segments go there only with at least this many hits per processed probe on
                                     // average (0: all of them); the sparse long ones run on tier 6's kernel
+    int64_t dense_min = 0;          // with k7 in tier 3: dense segments (dense3) of at least this many probes go to tier 3 whatever their arm
+                                    // bound says (0: only the long ones, option long3)
     int64_t dense6 = 0;             // with k7 in tier 3: segments of ANY length whose arm bound sends them to tier 6 go to tier 3 instead with at
                                     // least this many hits per processed probe on average (0: off)
     int64_t prewarm = 1;            // 1: asgart_index_prepare also reserves the per-probe workspace of both call contexts (sized for an

@@ -475,7 +475,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
         }
         auto tier_enabled = [&](int t) { return t >= 1 && t <= kTiers && tier_cap[t] != 0; };
         PlaceParams pp;
-        pp.long3 = pp.long3_big = pp.dense3 = pp.dense6 = 0;
+        pp.long3 = pp.long3_big = pp.dense3 = pp.dense6 = pp.dense_min = 0;
         pp.sparse_to6 = (uint32_t)opt.sparse_to6;
         for (int t = 1; t < kTiers; ++t) pp.cap[t - 1] = tier_cap[t];
         if (arms_kernel) {
@@ -483,9 +483,10 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             pp.long3_big = opt.long3_big >= 0 ? (uint32_t)opt.long3_big : pp.long3 / 4u;
             if (k7_tier(3) && tier_cap[6]) pp.dense3 = (uint32_t)opt.dense3;
             if (k7_tier(3) && tier_cap[6] && !k7_tier(6)) pp.dense6 = (uint32_t)opt.dense6;
+            if (k7_tier(3) && tier_cap[6]) pp.dense_min = (uint32_t)opt.dense_min;
             if (force_tier == 3) {
                 pp.long3 = pp.long3_big = 1;
-                pp.dense3 = pp.dense6 = 0;
+                pp.dense3 = pp.dense6 = pp.dense_min = 0;
             }
             pp.cap[0] = (uint32_t)std::min<int64_t>(opt.cap1, kArmCapSmall);
         }

@@ -1583,6 +1583,7 @@ struct PlaceParams {
     uint32_t long3;             // > 0: tier 3 is reserved for segments of at least this many probes
     uint32_t long3_big;         // ... or this many, for segments beyond tier 5's capacity
     uint32_t sparse_to6;        // 1: the long segments that are not dense go to tier 6 (its kernel is the old tier-3 one); 0: by capacity
+    uint32_t dense_min;         // > 0: segments of at least this many probes that are dense (dense3) go to tier 3 whatever their arm bound
     uint32_t dense6;            // > 0: segments bound for tier 6 by their arms go to tier 3 (when they fit it) with at least this
                                 // many hits per processed probe: the dense ones of ANY length on the kernel with a control wave
     uint32_t dense3;            // > 0: ... and only the DENSE ones (at least this many hits per processed probe on average:
@@ -1627,6 +1628,11 @@ __device__ inline int place_tier(uint32_t bound, unsigned long long sum, uint32_
         // (0: by capacity like any other segment -- a sparse long segment is mostly run by one wave alone, and the
         // small shapes give it a fraction of a compute unit instead of a whole one)
     }
+    // medium segments (dense_min probes and more) that are dense go to the long-segment tier as well: the one-wave and the
+    // small workgroup shapes run a probe with a hundred arms in 20-50 K cycles, the kernel of tier 3 in 4 K
+    if (pp.long3 && pp.dense_min && pp.dense3 && n_probes >= pp.dense_min && bound <= pp.cap[2] && bound > pp.cap[0] &&
+        sum >= (unsigned long long)pp.dense3 * n_probes)
+        return 3;
     for (int t = 2; t < kTiers; ++t) {
         if (t == 3 && pp.long3) continue;
         if (bound <= pp.cap[t - 1]) {
