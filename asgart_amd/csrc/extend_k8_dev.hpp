@@ -31,6 +31,8 @@ constexpr uint32_t K8_CLEARNOW = 32u;  // command flag: every thread clears the 
 // pull block flags
 constexpr uint32_t K8_OVF = 1u;        // more arms than slots: the segment is given up
 constexpr uint32_t K8_STILL = 2u;      // the new arms of this block die of the quiet probes behind their birth: none is created
+constexpr uint32_t K8_BIG = 4u;        // more than 64 new arms: the ranking wave offered for the first 64 only, every wave takes a
+                                       // share of the others at the top of the next step (one extra barrier in such a step)
 
 template <class PosT, int S, int NT, int HB, int kRows = 1024, int kE = 2>
 __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
@@ -305,6 +307,18 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
             return ch;
         };
 
+        // The first offers of the new arms beyond the 64 the ranking wave handled (K8_BIG): round j >= 1 (arms 64 j ...) is
+        // taken by wave (j - 1) mod NW; q describes the probe they offer to (the previous step's), lists in buffer pbuf.
+        auto big_rounds = [&](const Cur &q, uint32_t n_pull, uint32_t seq_base, uint32_t thr0, uint32_t pbuf) {
+            const uint32_t ns_q = uni(s_nstash[q.bb]);
+            for (uint32_t j = 1u + wave; j * 64u < n_pull; j += (uint32_t)NW) {
+                const uint32_t r = j * 64u + (uint32_t)lane;
+                const PosT x = s_newx[pbuf][min(r, n_pull - 1u)];
+                const uint32_t ch = offer_window(q, (PosT)(x + 1u), (WinT)thr0 + (WinT)(q.k - 1u), seq_base + r, r < n_pull, ns_q);
+                if (r < n_pull) s_newch[pbuf][r] = ch;
+            }
+        };
+
         bool overflow = false;
         if (!is_rank && !is_plan) {
             // =====================================================================================================
@@ -326,6 +340,7 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
             }
             lds_barrier();  // (3)
             uint32_t pv_off = 0, pv_besto = 0;  // the previous probe's rows and winners (as in the last command)
+            uint32_t pv_tabo = 0, pv_g10 = 0;   // ... its hit table and generation tag
             // (lanes 0-7: the pull block; 8-15: this wave's slots; 16-19: the stash counts -- per step parity)
             const uint32_t *const pb_ptr0 = lane < 8 ? &s_pull[0][lane] : (lane < 16 ? &s_slot[0][wave][lane - 8] : (lane < 20 ? &s_nstash[lane - 16] : &s_pull[0][0]));
             const uint32_t *const pb_ptr1 = lane < 8 ? &s_pull[1][lane] : (lane < 16 ? &s_slot[1][wave][lane - 8] : (lane < 20 ? &s_nstash[lane - 16] : &s_pull[1][0]));
@@ -364,6 +379,12 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
                     break;
                 }
                 const bool has_prev = (flags & K7_PREV) != 0u, has_cur = (flags & K7_CUR) != 0u, more = !(flags & K7_LAST);
+                bool stale0 = false;  // the winners requested above predate the offers below
+                if (K7_RARE(PB(0) & K8_BIG)) {  // (before anything touches the previous probe's table or its stash count)
+                    big_rounds(Cur{C(16), pv_g10, C(19), pv_tabo, C(15), C(23), C(11), C(14)}, PB(1), PB(2), C(22), sp ^ 1u);
+                    lds_barrier();
+                    stale0 = true;
+                }
                 if (K7_RARE(flags & K8_CLEARNOW)) clear_table();
                 // the rows that are staged during this step: requested now, written to LDS in front of the barrier
                 const uint32_t npre = more ? N(10) : 0u;
@@ -437,7 +458,7 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
                         PosT xw = 0;
                         uint32_t cb[3];
                         PosT xb[3];
-                        if (L == 0 && !received) {
+                        if (L == 0 && !received && !stale0) {
 #pragma unroll
                             for (int j = 0; j < 3; ++j) {
                                 cb[j] = cb0[j];
@@ -585,6 +606,8 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
                 K7T_LAP(1);
                 pv_off = C(2);
                 pv_besto = C(4);
+                pv_tabo = C(3);
+                pv_g10 = C(5);
                 if (K7_RARE(!more)) break;
             }
             if (wave == 0u) K7T_FLUSH(1);
@@ -623,6 +646,7 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
             lds_barrier();  // (3)
             // what the pull that is pending took of each (wave, layer) entry (entry j = lane, and lane + 64)
             uint32_t took1 = 0, took2 = 0, pending_alive = 0;
+            uint32_t pv_tabo = 0, pv_g10 = 0, big_n = 0, big_seq = 0;  // (a K8_BIG block of the step before: its size and first number)
             for (uint32_t sc = 0, sp = 0;; sc = sc == 2u ? 0u : sc + 1u, sp ^= 1u) {
                 const uint32_t sn = sc == 2u ? 0u : sc + 1u;
                 const uint32_t cw = s_cmd[lane < 32 ? sc : sn][lane & 31];
@@ -640,6 +664,11 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
                 const uint32_t bsh = C(19);
                 K7T_MARK();
                 K7T_STEP();
+                if (big_n) {
+                    big_rounds(Cur{k, pv_g10, bsh, pv_tabo, C(15), C(23), C(11), C(14)}, big_n, big_seq, thr0, sp ^ 1u);
+                    lds_barrier();
+                    big_n = 0;
+                }
                 if (flags & K8_CLEARNOW) clear_table();
                 const uint32_t npre = more ? N(10) : 0u;
                 const unsigned long long st_base = ((unsigned long long)N(25) << 32) | N(24);
@@ -729,7 +758,15 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
                     if (n_new && !(pflags & K8_OVF)) {
                         const Cur q{k, C(5), C(19), C(3), C(4), C(9), C(1), C(2)};
                         const uint32_t ns_b = has_cur ? uni(s_nstash[C(9)]) : 0u;
-                        for (uint32_t r0 = 0; r0 < n_new; r0 += 64u) {
+                        // (the first 64 here; the others are shared among all waves at the top of the next step: one wave
+                        // offering for hundreds of new arms, 64 at a time, would be the step)
+                        const bool big = has_cur && !stillborn && n_new > 64u;
+                        if (big) {
+                            pflags |= K8_BIG;
+                            big_n = n_new;
+                            big_seq = seq_base;
+                        }
+                        for (uint32_t r0 = 0; r0 < (big ? 64u : n_new); r0 += 64u) {
                             const uint32_t r = r0 + (uint32_t)lane;
                             const bool who = r < n_new && has_cur && !stillborn;
                             uint32_t ch = 0;
@@ -760,6 +797,8 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
                     if (lane == 0 && have_prev) s_nstash[prev_bb] = 0u;
                     if (have_prev && (uint32_t)lane < kBitWords) s_rowbits[prev_bb][lane] = 0u;
                 if (npre & K7_STAGE) store_rows(st_tot, st_buf);
+                pv_tabo = C(3);
+                pv_g10 = C(5);
                 K7T_LAP(0);
                 lds_barrier();  // ---- the barrier of the step -----------------------------------------------------
                 K7T_LAP(1);
@@ -1027,10 +1066,12 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
             if ((p_cur.flags & K7_CUR) && indexes(p_cur.q.cnt))
                 insert_hits(p_cur.q.cnt, p_cur.q.off, p_cur.q.tb * kTabBytes, p_cur.q.bb * (uint32_t)(HB * 4), p_cur.q.bb, p_cur.q.g10, bsh, false, 0ull);
             lds_barrier();  // (3)
+            uint32_t pv_tabo = 0, pv_g10 = 0;
             for (uint32_t sc = 0, sp = 0;; sc = sc == 2u ? 0u : sc + 1u, sp ^= 1u) {
                 const uint32_t sn = sc == 2u ? 0u : sc + 1u;
                 const uint32_t cw = s_cmd[lane < 32 ? sc : sn][lane & 31];
                 const uint32_t pflags_prev = s_pull[sp ^ 1u][0];  // (the ranking wave's decision of the step before)
+                const uint32_t pn_prev = s_pull[sp ^ 1u][1], pseq_prev = s_pull[sp ^ 1u][2];
                 K7T_MARK();
                 auto C = [&](int j) { return (uint32_t)__builtin_amdgcn_readlane((int)cw, j); };
                 auto N = [&](int j) { return (uint32_t)__builtin_amdgcn_readlane((int)cw, 32 + j); };
@@ -1041,6 +1082,10 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
                 }
                 const bool more = !(flags & K7_LAST);
                 const uint32_t nflags = more ? N(0) : 0u;
+                if (uni(pflags_prev) & K8_BIG) {
+                    big_rounds(Cur{k, pv_g10, bsh, pv_tabo, C(15), C(23), C(11), C(14)}, uni(pn_prev), uni(pseq_prev), thr0, sp ^ 1u);
+                    lds_barrier();
+                }
                 if (flags & K8_CLEARNOW) clear_table();
                 const uint32_t npre = more ? N(10) : 0u;
                 const unsigned long long st_base = ((unsigned long long)N(25) << 32) | N(24);
@@ -1058,6 +1103,8 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
                     }
                 }
                 if (npre & K7_STAGE) store_rows(st_tot, st_buf);
+                pv_tabo = C(3);
+                pv_g10 = C(5);
                 K7T_LAP(0);
                 lds_barrier();  // ---- the barrier of the step -----------------------------------------------------
                 K7T_LAP(1);

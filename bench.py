@@ -577,7 +577,7 @@ def main():
                 sample_bp, t_cpu = cpu_sample(per_chunk)
                 if per_chunk >= cap or t_cpu >= target_s / 3:
                     break
-                per_chunk = min(cap, int(per_chunk * min(4.0, max(1.5, target_s / max(t_cpu, 1e-3)))))
+                per_chunk = min(cap, int(per_chunk * min(4.0 if t_cpu < 2.0 else 2.0, max(1.5, target_s / max(t_cpu, 1e-3)))))
         else:
             sample_bp, t_cpu = cpu_sample(per_chunk)
         out["cpu_baseline"] = {
