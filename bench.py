@@ -575,7 +575,7 @@ def main():
             cap, per_chunk = per_chunk, per_chunk // 20
             while True:
                 sample_bp, t_cpu = cpu_sample(per_chunk)
-                if per_chunk >= cap or t_cpu >= target_s / 3:
+                if per_chunk >= cap or t_cpu >= target_s / 4:
                     break
                 per_chunk = min(cap, int(per_chunk * min(4.0 if t_cpu < 2.0 else 2.0, max(1.5, target_s / max(t_cpu, 1e-3)))))
         else:

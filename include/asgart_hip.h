@@ -152,8 +152,12 @@ int32_t asgart_index_create_trim(const uint8_t *T, int64_t n, const int64_t *SA,
  * name or a value out of range.  Names: shard_lookback, shard_lookahead (halo sizes of a sharded
  * call, in probes), force_tier, arms_kernel, long3, long3_big, cap1, filter, tier_order,
  * grid1..grid7 (placement of segments on the extension kernels -- results never depend on
- * them), debug, test_cap_limit, test_levels, test_genbits (parity tests).  ptab_depth and
- * force_wide are fixed at creation (environment only).  Blocks until no call is in flight. */
+ * them), k7, k8, dense3, dense6, dense_min, sparse_to6 (which extension kernel a tier runs and which
+ * segments the long-segment tier takes: placement again), pass_gate, watchdog_s, lazy_aux, prewarm,
+ * debug, test_cap_limit, test_levels, test_genbits (parity tests); the full table with ranges is
+ * kOptions in asgart_amd/csrc/index.hip, every field is described in struct Options
+ * (asgart_amd/csrc/index.hpp).  ptab_depth and force_wide are fixed at creation (environment
+ * only).  Blocks until no call is in flight. */
 int32_t asgart_index_set_option(asgart_index *idx, const char *name, int64_t value);
 
 /* O(n) verifier of the suffix array held by the index, on the GPU: SA must be a permutation of
