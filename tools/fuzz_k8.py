@@ -8,6 +8,7 @@ the cases.  Results must equal the oracle's bit for bit.
 
     python tools/fuzz_k8.py [cases=40] [first seed=0]        (ASGART_K8=0 for K7)
 """
+import faulthandler
 import os
 import sys
 import time
@@ -58,6 +59,7 @@ def main():
     bad = 0
     t_all = time.time()
     for seed in range(seed0, seed0 + cases):
+        faulthandler.dump_traceback_later(int(os.environ.get("FUZZ_STALL_S", "120")), exit=True)  # (a stuck case: where)
         text, cli, genbits = make_case(seed)
         chunks = [(0, len(text) - 1)]
         oidx = oracle.Index.build(text)
@@ -66,7 +68,12 @@ def main():
             idx.set_option("test_genbits", genbits)
             for rc in (False, True):
                 st = asgart_amd.RunSettings.from_cli(reverse=rc, complement=rc, **cli)
+                trace = os.environ.get("FUZZ_TRACE")
+                if trace:
+                    print(f"  seed {seed} {'RC' if rc else 'direct'}: device call ...", flush=True)
                 offs, sds = idx.search_duplications_raw(chunks, st)
+                if trace:
+                    print("  ... oracle ...", flush=True)
                 eo, es = oidx.run_raw(chunks, oracle.make_settings(reverse=rc, complement=rc, **cli), threads=4)
                 ok = np.array_equal(offs, eo) and np.array_equal(sds, es)
                 s = idx.stats(0)
