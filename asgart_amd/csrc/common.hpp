@@ -3,6 +3,7 @@
 #include <atomic>
 #include <chrono>
 #include <mutex>
+#include <thread>
 #include <utility>
 #include <cstdio>
 #include <cstdlib>
@@ -31,6 +32,27 @@ void set_error(const char *fmt, ...);
             return e_ == hipErrorOutOfMemory ? ASGART_E_OOM : ASGART_E_HIP;                 \
         }                                                                                   \
     } while (0)
+
+// hipStreamSynchronize for the waits outside the search calls' own watchdog (index preparation, suffix sort, list builds,
+// post-processing): polls, and gives up after ASGART_BUILD_WATCHDOG_S seconds (default 900; 0 = wait forever) with
+// hipErrorLaunchTimeOut, which HIP_TRY turns into an error that names the file and line of the wait -- a device that stops
+// answering during a build becomes an error with a place instead of a process that hangs.
+inline hipError_t stream_sync(hipStream_t s) {
+    static const double limit = [] {
+        const char *e = getenv("ASGART_BUILD_WATCHDOG_S");
+        return e ? atof(e) : 900.0;
+    }();
+    if (limit <= 0.0) return hipStreamSynchronize(s);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 1;; ++spins) {
+        const hipError_t q = hipStreamQuery(s);
+        if (q != hipErrorNotReady) return q;
+        (void)hipGetLastError();
+        if (spins > 256) std::this_thread::sleep_for(std::chrono::microseconds(spins > 4096 ? 200 : 20));
+        if ((spins & 255u) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit)
+            return hipErrorLaunchTimeOut;
+    }
+}
 
 #define RC_TRY(expr)            \
     do {                        \

@@ -592,7 +592,7 @@ int32_t text_is_dna(const uint8_t *d_text, int64_t n, hipStream_t s, bool *dna) 
         byte_histogram_kernel<<<blocks, 256, 0, s>>>(d_text, (uint64_t)n, d_hist);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(hist, d_hist, sizeof(hist), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(stream_sync(s));
         return 0;
     }();
     hist_b.release();
@@ -713,14 +713,14 @@ int32_t index_prepare(asgart_index *idx, uint64_t k) {
         HIP_TRY(hipGetLastError());
         unsigned long long h[8 + kMaxK + 2];
         HIP_TRY(hipMemcpyAsync(h, d_cnt, sizeof(h), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(stream_sync(s));
         idx->n_bad = (int)std::min<unsigned long long>(h[0], kMaxK + 2);
         for (int j = 0; j < idx->n_bad; ++j) idx->bad[j] = h[8 + j];
         return 0;
     };
     RC_TRY(idx->wide ? build(uint64_t{}) : build(uint32_t{}));
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(stream_sync(s));
     lap("keys + tables");
     // position-sorted occurrence lists: at once (option lazy_aux = 0), or by the first search call that has a predecessor
     idx->sap_tried = false;
@@ -835,7 +835,7 @@ int32_t index_prepare_filter(asgart_index *idx, uint64_t k, int mode) {
             build_filter_kernel<uint32_t><<<g, 256, 0, s>>>(idx->view<uint32_t>(), rev, comp,
                                                             (unsigned long long *)flt, bits);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(stream_sync(s));
         return 0;
     }();
     if (rc != 0) {
@@ -857,7 +857,7 @@ int32_t index_prepare_filter(asgart_index *idx, uint64_t k, int mode) {
                     build_posbits_kernel<uint32_t><<<g, 256, 0, s>>>(idx->view<uint32_t>(), rev, comp, flt, bits,
                                                                      (unsigned long long *)pb, n_words);
                 HIP_TRY(hipGetLastError());
-                HIP_TRY(hipStreamSynchronize(s));
+                HIP_TRY(stream_sync(s));
                 return 0;
             }();
             if (rc != 0) {
@@ -966,7 +966,7 @@ static int32_t index_create_impl(const uint8_t *T, int64_t n, const int64_t *SA,
         HIP_TRY(hipGetLastError());
         unsigned long long hist[256];
         HIP_TRY(hipMemcpyAsync(hist, d_hist, sizeof(hist), hipMemcpyDeviceToHost, idx->ctx[0].stream));
-        HIP_TRY(hipStreamSynchronize(idx->ctx[0].stream));
+        HIP_TRY(stream_sync(idx->ctx[0].stream));
         for (int c = 0; c < 256; ++c)
             if (hist[c] && !valid_text_byte((uint8_t)c)) {
                 set_error("text contains byte 0x%02x; expected normalised bases {A,C,G,T,N} "
@@ -998,7 +998,7 @@ static int32_t index_create_impl(const uint8_t *T, int64_t n, const int64_t *SA,
                 else
                     add_offset_kernel<uint32_t><<<grid_capped((uint64_t)n_sa), 256, 0, s>>>((uint32_t *)idx->d_sa, (uint64_t)n_sa, (uint64_t)trim_start);
                 HIP_TRY(hipGetLastError());
-                HIP_TRY(hipStreamSynchronize(s));
+                HIP_TRY(stream_sync(s));
                 return 0;
             }();
             sub.release();
@@ -1009,7 +1009,7 @@ static int32_t index_create_impl(const uint8_t *T, int64_t n, const int64_t *SA,
         } else if (idx->wide) {
             HIP_TRY(hipMemcpyAsync(idx->d_sa, SA, (size_t)n_sa * 8, hipMemcpyHostToDevice,
                                    idx->ctx[0].stream));
-            HIP_TRY(hipStreamSynchronize(idx->ctx[0].stream));
+            HIP_TRY(stream_sync(idx->ctx[0].stream));
         } else {
             const uint64_t slice = 1ull << 25;
             DevBuf stage;
@@ -1090,7 +1090,7 @@ int32_t asgart_index_clone(asgart_index *src, int32_t device, asgart_index **out
         hipStream_t s = idx->ctx[0].stream;
         HIP_TRY(hipMemcpyPeerAsync(idx->d_text, device, src->d_text, src->device, text_bytes, s));
         HIP_TRY(hipMemcpyPeerAsync(idx->d_sa, device, src->d_sa, src->device, sa_bytes, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(stream_sync(s));
         return 0;
     }();
     src->release_all();
@@ -1166,7 +1166,7 @@ int32_t asgart_index_create_device(const void *d_text, int64_t n, const void *d_
         const int64_t tl = n < (int64_t)kMaxK + 32 ? n : (int64_t)kMaxK + 32;
         idx->h_tail.resize((size_t)tl);
         HIP_TRY(hipMemcpyAsync(idx->h_tail.data(), idx->d_text + (n - tl), (size_t)tl, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(stream_sync(s));
         if (!dna) {
             set_error("text contains bytes other than the normalised bases {A,C,G,T,N} and '$' "
                       "(reference src/bin/asgart.rs:289-301,430)");
@@ -1239,7 +1239,7 @@ int64_t asgart_index_check_sa(asgart_index *idx) {
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(&h_errs, errs.p, 8, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(stream_sync(s));
         return 0;
     }();
     isa.release();
@@ -1300,7 +1300,7 @@ static int32_t run_pattern_kernel(asgart_index *idx, const uint8_t *pats, int64_
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(lo, w.out_a.p, (size_t)n_pat * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(hi, w.out_b.p, (size_t)n_pat * 8, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(stream_sync(s));
     return 0;
 }
 
@@ -1358,7 +1358,7 @@ int32_t asgart_sa_read(asgart_index *idx, uint64_t lo, uint64_t hi, int64_t *out
         HIP_TRY(hipMemcpyAsync(out, idx->ctx[0].ws.out_a.p, cnt * 8, hipMemcpyDeviceToHost,
                                idx->ctx[0].stream));
     }
-    HIP_TRY(hipStreamSynchronize(idx->ctx[0].stream));
+    HIP_TRY(stream_sync(idx->ctx[0].stream));
     return 0;
 }
 

@@ -148,7 +148,7 @@ extern "C" int32_t asgart_post_process(asgart_index *idx, const uint64_t *fam_of
             n_count_kernel<<<grid, 256, 0, s>>>(idx->d_text, n, d_sds.as<asgart_proto_sd>(), n_arms, d_out.as<unsigned long long>());
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(n_cnt.data(), d_out.p, (size_t)n_arms * 8, hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
+            HIP_TRY(stream_sync(s));
             return 0;
         }();
         d_sds.release();

@@ -222,7 +222,7 @@ int32_t build_t(const uint8_t *d_text, int64_t n_, IdxT *d_sa, bool dna, hipStre
             }
             size_t h_count = 0;
             HIP_TRY(hipMemcpyAsync(&h_count, d_count, sizeof(size_t), hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
+            HIP_TRY(stream_sync(s));
             if (h_count == 0) break;
             if (h >= n) {
                 set_error("internal: suffix sort did not converge");
@@ -365,7 +365,7 @@ int32_t build_wide(const uint8_t *d_text, int64_t n_, uint64_t *d_sa, bool dna, 
         byte_histogram_for_sa<<<blocks, 256, 0, s>>>(d_text, n, hist_b.as<unsigned long long>());
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(hist, hist_b.p, 256 * 8, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(stream_sync(s));
         std::vector<int> syms;
         for (int c = 0; c < 256; ++c)
             if (hist[c]) syms.push_back(c);
@@ -382,7 +382,7 @@ int32_t build_wide(const uint8_t *d_text, int64_t n_, uint64_t *d_sa, bool dna, 
             pair_histogram_kernel<<<blocks, 256, 0, s>>>(d_text, n, code_b.as<uint8_t>(), S, hist_b.as<unsigned long long>());
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(hist, hist_b.p, (size_t)S * (S + 1) * 8, hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
+            HIP_TRY(stream_sync(s));
             for (int a = 0; a < S; ++a)
                 for (int b = 0; b <= S; ++b)   // b == 0: the one-byte suffix, sorts first
                     if (hist[a * (S + 1) + b]) classes.push_back({syms[a], b ? syms[b - 1] : -1, hist[a * (S + 1) + b]});
@@ -440,7 +440,7 @@ int32_t build_wide(const uint8_t *d_text, int64_t n_, uint64_t *d_sa, bool dna, 
             HIP_TRY(rocprim::select(temp.p, bytes, it, tied, out_b.as<uint64_t>(), d_count, (size_t)cnt, s));
             size_t h_count = 0;
             HIP_TRY(hipMemcpyAsync(&h_count, d_count, sizeof(size_t), hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
+            HIP_TRY(stream_sync(s));
             if (h_count) {
                 offset_slots_kernel<<<grid_for(h_count), 256, 0, s>>>(out_b.as<uint64_t>(), h_count, slot_base);
                 HIP_TRY(hipGetLastError());
@@ -449,7 +449,7 @@ int32_t build_wide(const uint8_t *d_text, int64_t n_, uint64_t *d_sa, bool dna, 
             }
             slot_base += cnt;
         }
-        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(stream_sync(s));
         K1.release(); V.release(); grp_b.release(); tied_b.release(); out_b.release();
         // ---- doubling rounds over the tied suffixes, batch by batch --------------------------------
         uint64_t h = dna ? 21 : 7;
@@ -468,7 +468,7 @@ int32_t build_wide(const uint8_t *d_text, int64_t n_, uint64_t *d_sa, bool dna, 
                     group_end_kernel<<<1, 1, 0, s>>>(list, d_sa, rank, m, end, reinterpret_cast<uint64_t *>(d_count));
                     HIP_TRY(hipGetLastError());
                     HIP_TRY(hipMemcpyAsync(&end, d_count, 8, hipMemcpyDeviceToHost, s));
-                    HIP_TRY(hipStreamSynchronize(s));
+                    HIP_TRY(stream_sync(s));
                 }
                 const uint64_t bm = end - done;
                 const uint64_t *slots = list + done;
@@ -511,13 +511,13 @@ int32_t build_wide(const uint8_t *d_text, int64_t n_, uint64_t *d_sa, bool dna, 
                 HIP_TRY(rocprim::select(temp.p, bytes, slots, tied, out_b.as<uint64_t>(), d_count, (size_t)bm, s));
                 size_t h_count = 0;
                 HIP_TRY(hipMemcpyAsync(&h_count, d_count, sizeof(size_t), hipMemcpyDeviceToHost, s));
-                HIP_TRY(hipStreamSynchronize(s));
+                HIP_TRY(stream_sync(s));
                 // in-place compaction of the list: the survivors trail the read position
                 if (h_count) HIP_TRY(hipMemcpyAsync(list + kept, out_b.p, h_count * 8, hipMemcpyDeviceToDevice, s));
                 kept += h_count;
                 done = end;
             }
-            HIP_TRY(hipStreamSynchronize(s));
+            HIP_TRY(stream_sync(s));
             m = kept;
             h *= 2;
         }
@@ -667,7 +667,7 @@ int32_t build_rank_lists(const uint64_t *d_keys, const uint32_t *d_sa, uint64_t 
     if (pos2.current() != d_sap)
         HIP_TRY(hipMemcpyAsync(d_sap, pos2.current(), (size_t)n * 4, hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(stream_sync(s));
     return 0;
 }
 
@@ -749,7 +749,7 @@ int32_t build_rank_lists_runs(const uint64_t *d_keys, const SlotT *d_sa, uint64_
         HIP_TRY(hipGetLastError());
         unsigned long long h[2] = {0, 0};
         HIP_TRY(hipMemcpyAsync(h, b_ctr.p, 16, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(stream_sync(s));
         if (!h[0]) continue;
         if (h[1] >= 0xFFFFFFFFull) {
             set_error("internal: a run of equal keys longer than 2^32 - 2^30 slots");
@@ -762,7 +762,7 @@ int32_t build_rank_lists_runs(const uint64_t *d_keys, const SlotT *d_sa, uint64_
         HIP_TRY(rocprim::segmented_radix_sort_keys(temp.p, bytes, d_sa + w0, d_sap + w0, (unsigned)h[1], (unsigned)h[0],
                                                    b_beg.as<uint32_t>(), b_end.as<uint32_t>(), 0, (unsigned)pos_bits, s));
     }
-    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(stream_sync(s));
     return 0;
 }
 template int32_t build_rank_lists_runs<uint32_t>(const uint64_t *, const uint32_t *, uint64_t, uint32_t *, uint32_t, int, hipStream_t);
@@ -803,10 +803,10 @@ extern "C" int32_t asgart_sa_build64(const uint8_t *T, int64_t *SA, int64_t n) {
                                                            out.as<int64_t>(), cnt);
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipMemcpyAsync(SA + off, out.p, cnt * 8, hipMemcpyDeviceToHost, s));
-                HIP_TRY(hipStreamSynchronize(s));
+                HIP_TRY(stream_sync(s));
             }
         }
-        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(stream_sync(s));
         return 0;
     }();
     text.release();

@@ -377,7 +377,7 @@ extern "C" int32_t asgart_compute_scores(asgart_index *idx, const asgart_proto_s
         HIP_TRY(hipMemcpyAsync(d_list, long_list.data(), long_list.size() * 4, hipMemcpyHostToDevice, s));
     if (!wave_list.empty())
         HIP_TRY(hipMemcpyAsync(d_list + long_list.size(), wave_list.data(), wave_list.size() * 4, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipStreamSynchronize(s));  // the host vectors go out of use below
+    HIP_TRY(stream_sync(s));  // the host vectors go out of use below
     if (grid_l)
         levenshtein_long_kernel<<<grid_l, 64 * kLongWaves, 0, s>>>(
             idx->d_text, w.out_a.as<asgart_proto_sd>(), d_list, (uint64_t)long_list.size(), reversed != 0,
@@ -388,6 +388,6 @@ extern "C" int32_t asgart_compute_scores(asgart_index *idx, const asgart_proto_s
             reversed != 0, complemented != 0, w.scratch.as<uint32_t>(), stride_w, cursor, w.out_b.as<float>());
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(identity, w.out_b.p, (size_t)n_sd * sizeof(float), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(stream_sync(s));
     return 0;
 }
