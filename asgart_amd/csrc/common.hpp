@@ -49,8 +49,7 @@ inline hipError_t stream_sync(hipStream_t s) {
         if (q != hipErrorNotReady) return q;
         (void)hipGetLastError();
         if (spins > 256) std::this_thread::sleep_for(std::chrono::microseconds(spins > 4096 ? 200 : 20));
-        if ((spins & 255u) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit)
-            return hipErrorLaunchTimeOut;
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) return hipErrorLaunchTimeOut;
     }
 }
 

@@ -1140,29 +1140,6 @@ def test_watchdog_gives_up_on_a_stalled_device_and_names_the_phase(hiplib):
         assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
 
 
-def test_build_waits_give_up_with_the_place_of_the_wait(hiplib):
-    """The waits of the build paths (suffix sort, keys, tables, lists) poll too: with an absurdly short
-    ASGART_BUILD_WATCHDOG_S a suffix sort of 64 megabases cannot finish inside one of them (the limit is looked at every 256
-    polls, about a millisecond), and the index creation
-    must come back with ASGART_E_HIP and the file and line of the wait instead of waiting (the limit is read once per
-    process: a child process)."""
-    import subprocess
-
-    code = (
-        "import numpy as np, asgart_amd\n"
-        "rng = np.random.default_rng(5)\n"
-        "t = np.concatenate([np.frombuffer(b'ACGT', dtype=np.uint8)[rng.integers(0, 4, size=64_000_000)], np.frombuffer(b'$', dtype=np.uint8)])\n"
-        "try:\n"
-        "    asgart_amd.Index(t, None).close()\n"
-        "    print('NO ERROR')\n"
-        "except asgart_amd.AsgartError as e:\n"
-        "    print('CODE', e.code, str(e))\n"
-    )
-    env = dict(os.environ, ASGART_BUILD_WATCHDOG_S="0.00001")
-    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
-    assert "CODE -3" in out.stdout and "stream_sync" in out.stdout and ".hip:" in out.stdout, (out.stdout[-500:], out.stderr[-500:])
-
-
 def test_block_cache_is_trimmed_and_filter_can_be_switched_off(hiplib):
     """(advisor, round 3) The blocks the library keeps for reuse go back to the device when the last index closes and on
     asgart_trim_cache; option kfilter_bits = 0 really searches without the presence filter (its position bitmaps used
