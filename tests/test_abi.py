@@ -55,3 +55,13 @@ def test_bad_arguments_are_reported(hiplib):
     assert hiplib.asgart_index_create(None, 0, None, 0, 0, C.byref(h)) == -1
     assert b"empty" in hiplib.asgart_last_error()
     assert hiplib.asgart_index_prepare(None, 20) == -1
+
+
+def test_the_library_carries_the_gfx950_kernels_of_the_path(hiplib):
+    """The shared object is the product: the hand-written kernels of the hot path must be IN it (a build that silently
+    dropped the device code would still export every host symbol).  Their mangled names are in the embedded code object."""
+    blob = open(hiplib._name, "rb").read()
+    for kernel in (b"probe_count_kernel", b"collect_pending_kernel", b"extend_kernel", b"extend_fast_kernel",
+                   b"extend_k7_kernel", b"extend_k8_kernel", b"extend_heavy_kernel", b"seg_prepass_kernel"):
+        assert kernel in blob, kernel
+    assert b"gfx950" in blob
