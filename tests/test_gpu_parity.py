@@ -1224,8 +1224,9 @@ def test_lazy_filter_and_lists_same_results(hiplib, monkeypatch):
 @pytest.mark.parametrize("wide", [0, 1])
 @pytest.mark.parametrize("tier", [3, 4, 5, 6])
 def test_control_wave_kernel_in_every_workgroup_tier(hiplib, tier, wide, k8, monkeypatch):
-    """K7 (extend_k7_dev.hpp: a control wave plans the steps, arm waves do nothing but their arms) runs tier 3 by
-    default; option k7 = 120 puts it in tiers 4, 5 and 6 as well (other shapes: 6 x 192, 5 x 448, 5 x 960 slots; with
+    """The kernels with specialised waves run tier 3 by default (K8, extend_k8_dev.hpp; with k8 = 0 K7,
+    extend_k7_dev.hpp: a control wave plans the steps, arm waves do nothing but their arms); option k7 = 120 puts them
+    in tiers 4, 5 and 6 as well (other shapes: 6 x 192, 5 x 448, 5 x 960 slots; with
     64-bit positions 3 x 192, 3 x 448, 4 x 960).  Every segment with a multi-hit probe forced through each of them,
     with a generation counter that wraps every few probes in one of the passes: identical to the oracle.  k8 = 1: the
     one-barrier variant of the same kernel (extend_k8_dev.hpp: the control wave makes the new arms' first offers, the arm
