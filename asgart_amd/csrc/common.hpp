@@ -2,6 +2,9 @@
 #pragma once
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <utility>
@@ -51,6 +54,92 @@ inline hipError_t stream_sync(hipStream_t s) {
         if (spins > 256) std::this_thread::sleep_for(std::chrono::microseconds(spins > 4096 ? 200 : 20));
         if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) return hipErrorLaunchTimeOut;
     }
+}
+
+// A device-to-host copy into PAGEABLE memory blocks inside the copy call until everything queued on the stream before it
+// has run -- the polled wait behind it then finds an idle stream and its limit never applies.  Builders read their
+// counters back through this: the stream is drained by the polled wait FIRST, the copy then has nothing to wait for.
+inline hipError_t read_back(void *dst, const void *src, size_t bytes, hipStream_t s) {
+    hipError_t e = stream_sync(s);
+    if (e != hipSuccess) return e;
+    e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s);
+    if (e != hipSuccess) return e;
+    return stream_sync(s);
+}
+
+// Runs fn() on the process's teardown thread and waits for it at most limit_s seconds (<= 0: runs it inline, however long
+// it takes).  For runtime calls that cannot be polled (hipFree, hipHostFree, hipStreamDestroy: each synchronises with the
+// device inside the runtime).  false: fn did not return in time -- the thread is left behind in it (a fresh one serves the
+// next call) and whatever fn captured must stay alive; the caller reports and gives up on the rest of its work.
+// ONE long-lived thread, not one per call: every host thread that makes HIP calls costs the runtime some device memory
+// that it does not give back when the thread ends (measured: 70 create/destroy cycles with five helper threads each
+// lowered the free device memory by 16 MB).
+struct TeardownWorker {
+    std::mutex m;
+    std::condition_variable cv;
+    std::vector<std::function<void()>> q;
+    bool stuck = false;
+    void loop() {
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            cv.wait(lk, [&] { return !q.empty(); });
+            std::function<void()> j = std::move(q.front());
+            q.erase(q.begin());
+            lk.unlock();
+            j();
+            lk.lock();
+        }
+    }
+    static std::shared_ptr<TeardownWorker> current() {
+        static std::mutex gm;
+        static std::shared_ptr<TeardownWorker> w;
+        std::lock_guard<std::mutex> lk(gm);
+        bool fresh = !w;
+        if (w) {
+            std::lock_guard<std::mutex> lk2(w->m);
+            fresh = w->stuck;
+        }
+        if (fresh) {
+            w = std::make_shared<TeardownWorker>();
+            std::shared_ptr<TeardownWorker> keep = w;  // (the thread keeps its worker alive)
+            std::thread([keep]() { keep->loop(); }).detach();
+        }
+        return w;
+    }
+};
+template <class F>
+inline bool bounded_call(double limit_s, F fn) {
+    if (limit_s <= 0.0) {
+        fn();
+        return true;
+    }
+    struct State {
+        std::mutex m;
+        std::condition_variable cv;
+        bool done = false;
+    };
+    auto st = std::make_shared<State>();
+    std::shared_ptr<TeardownWorker> w = TeardownWorker::current();
+    {
+        std::lock_guard<std::mutex> lk(w->m);
+        w->q.emplace_back([st, fn]() mutable {
+            fn();
+            {
+                std::lock_guard<std::mutex> lk2(st->m);
+                st->done = true;
+            }
+            st->cv.notify_all();
+        });
+    }
+    w->cv.notify_all();
+    std::unique_lock<std::mutex> lk(st->m);
+    const bool ok = st->cv.wait_for(lk, std::chrono::duration<double>(limit_s), [&] { return st->done; });
+    lk.unlock();
+    if (!ok) {
+        std::lock_guard<std::mutex> lk2(w->m);
+        w->stuck = true;
+    }
+    return ok;
 }
 
 #define RC_TRY(expr)            \

@@ -192,6 +192,7 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
         PROF_SEG_BEGIN();
         const int c = chunk_of_uniform(rp.ch, g0);
         const uint64_t cs = rp.ch.start[c], cl = rp.ch.len[c];
+        const bool seg_rev = (rp.mode_of(c) & 2u) != 0u;  // (the orientation of the chunk's pass)
         const uint32_t pb = rp.ch.pbase[c];
         const uint32_t chunk_end = rp.ch.pbase[c + 1];
         const uint32_t g_end = min(chunk_end, rp.g_hi);
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
                 r.fam_seq = fam_seq;
                 r.create_seq = seq;
                 r.pad = 0;
-                r.sd.left = rp.reverse ? cs + cl - (uint64_t)ls - ll : (uint64_t)ls + cs;  // src/bin/asgart.rs:229-237
+                r.sd.left = seg_rev ? cs + cl - (uint64_t)ls - ll : (uint64_t)ls + cs;  // src/bin/asgart.rs:229-237
                 r.sd.right = rs;
                 r.sd.left_length = ll;
                 r.sd.right_length = (uint64_t)re - (uint64_t)rs;

@@ -216,14 +216,15 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
             if (!em) return;
             const unsigned long long at = rec_slot(rec_alloc, P, em, lane);
             if (emit && at < P.rec_cap) {
-                const uint64_t cs = s_seg[1], cl = s_seg[2];
+                const uint64_t cs = s_seg[1], cl = s_seg[2] & ~(1ull << 63);
+                const bool seg_rev = (s_seg[2] >> 63) != 0ull;  // (the orientation of the chunk's pass rides in the top bit)
                 const uint64_t ll = (uint64_t)le - (uint64_t)ls;
                 SdRec r;
                 r.g_start = (uint32_t)s_seg[0];
                 r.fam_seq = fam_seq;
                 r.create_seq = seq;
                 r.pad = 0;
-                r.sd.left = P.rp.reverse ? cs + cl - (uint64_t)ls - ll : (uint64_t)ls + cs;  // src/bin/asgart.rs:229-237
+                r.sd.left = seg_rev ? cs + cl - (uint64_t)ls - ll : (uint64_t)ls + cs;  // src/bin/asgart.rs:229-237
                 r.sd.right = rs;
                 r.sd.left_length = ll;
                 r.sd.right_length = (uint64_t)re - (uint64_t)rs;
@@ -759,7 +760,7 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
             if (lane == 0) {
                 s_seg[0] = g0;
                 s_seg[1] = cs;
-                s_seg[2] = cl;
+                s_seg[2] = cl | ((unsigned long long)((rp.mode_of(c) >> 1) & 1u) << 63);
             }
             uint32_t quiet = 0, pend = 0, fam_seq = 0, next_seq = 0, t_proc = 0, spur_until = 0;
             bool done = false, fam_open = false, giveup = false;

@@ -69,7 +69,16 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
     __shared__ __attribute__((aligned(16))) uint32_t s_pull[2][8];
     __shared__ uint32_t s_slot[2][NWA][8];                             // per (arm wave, layer): slots given << 16 | rank of the first
     __shared__ __attribute__((aligned(16))) uint32_t s_nstash[4];      // (three in use)
-    __shared__ __attribute__((aligned(16))) uint32_t s_free[NWA][8];   // per (arm wave, layer): empty slots
+    // per step parity, (arm wave, layer): empty slots.  An arm wave writes the block of ITS step's parity in front of the
+    // step's barrier, the ranking wave reads the block of the step BEFORE behind it: writer and reader of one block
+    // are always a barrier apart (with one block the publication of step s + 1 raced the ranking wave's read of
+    // step s's counts -- nothing but time separated them).  K8_SINGLE_FREE (tools/k8_race.sh only) brings that back.
+#ifdef K8_SINGLE_FREE
+    constexpr uint32_t kFreeBufs = 1;
+#else
+    constexpr uint32_t kFreeBufs = 2;
+#endif
+    __shared__ __attribute__((aligned(16))) uint32_t s_free[kFreeBufs][NWA][8];
     __shared__ PosT s_newx[2][kNewMax];                                // the unmatched hits of a probe, by rank
     __shared__ uint32_t s_newch[2][kNewMax];                           // ... and the candidates of the arm born of each
     __shared__ __attribute__((aligned(16))) uint32_t s_cmd[3][kCmdWords];  // as K7's (word 10: K7_STAGE of the step before)
@@ -121,7 +130,7 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
         if (tid < 4) s_nstash[tid] = 0u;
         if (tid < 16) (&s_pull[0][0])[tid] = 0u;
         for (uint32_t j = tid; j < 3u * kBitWords; j += NT) (&s_rowbits[0][0])[j] = 0u;
-        for (uint32_t j = tid; j < (uint32_t)(NWA * 8); j += NT) (&s_free[0][0])[j] = 64u;
+        for (uint32_t j = tid; j < kFreeBufs * (uint32_t)(NWA * 8); j += NT) (&s_free[0][0][0])[j] = 64u;
         for (uint32_t j = tid; j < (uint32_t)(2 * NWA * 8); j += NT) (&s_slot[0][0][0])[j] = 0u;
         lds_barrier();
         const unsigned long long seg = uni(s_bcast);
@@ -133,14 +142,15 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
             if (!em) return;
             const unsigned long long at = rec_slot(rec_alloc, P, em, lane);
             if (emit && at < P.rec_cap) {
-                const uint64_t cs = s_seg[1], cl = s_seg[2];
+                const uint64_t cs = s_seg[1], cl = s_seg[2] & ~(1ull << 63);
+                const bool seg_rev = (s_seg[2] >> 63) != 0ull;  // (the orientation of the chunk's pass rides in the top bit)
                 const uint64_t ll = (uint64_t)le - (uint64_t)ls;
                 SdRec r;
                 r.g_start = (uint32_t)s_seg[0];
                 r.fam_seq = fam_seq;
                 r.create_seq = seq;
                 r.pad = 0;
-                r.sd.left = P.rp.reverse ? cs + cl - (uint64_t)ls - ll : (uint64_t)ls + cs;  // src/bin/asgart.rs:229-237
+                r.sd.left = seg_rev ? cs + cl - (uint64_t)ls - ll : (uint64_t)ls + cs;  // src/bin/asgart.rs:229-237
                 r.sd.right = rs;
                 r.sd.left_length = ll;
                 r.sd.right_length = (uint64_t)re - (uint64_t)rs;
@@ -339,6 +349,7 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
                 if ((C0(0) & K7_CUR) && indexes(C0(1))) insert_hits(C0(1), C0(2), C0(3), C0(4), C0(9), C0(5), C0(19), false, 0ull);
             }
             lds_barrier();  // (3)
+            bool pub_prev = false;              // this wave published its free counts in the step before
             uint32_t pv_off = 0, pv_besto = 0;  // the previous probe's rows and winners (as in the last command)
             uint32_t pv_tabo = 0, pv_g10 = 0;   // ... its hit table and generation tag
             // (lanes 0-7: the pull block; 8-15: this wave's slots; 16-19: the stash counts -- per step parity)
@@ -584,8 +595,10 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
                     }
                 }
                 K7U_LAP(2);
-                if (had_live || received) {  // free counts, as the control wave will rank them in the next step (an idle
-                                             // wave's stay as they are: all empty)
+                // free counts, as the ranking wave will read them in the next step.  A wave that goes idle publishes once
+                // more, into the other block: both blocks of an idle wave then say "all empty" and stay that way.
+                const bool pub = had_live || received;
+                if (pub || pub_prev) {
                     uint32_t nfv[8] = {64u, 64u, 64u, 64u, 64u, 64u, 64u, 64u};
 #pragma unroll
                     for (int L = 0; L < S; ++L) {
@@ -596,9 +609,11 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
                             if (nf == 64u) livemask &= ~(1u << L);
                         }
                     }
-                    *reinterpret_cast<uint4 *>(&s_free[wave][0]) = make_uint4(nfv[0], nfv[1], nfv[2], nfv[3]);
-                    if constexpr (S > 4) *reinterpret_cast<uint4 *>(&s_free[wave][4]) = make_uint4(nfv[4], nfv[5], nfv[6], nfv[7]);
+                    uint32_t *const fr = &s_free[sp & (kFreeBufs - 1u)][wave][0];
+                    *reinterpret_cast<uint4 *>(fr) = make_uint4(nfv[0], nfv[1], nfv[2], nfv[3]);
+                    if constexpr (S > 4) *reinterpret_cast<uint4 *>(fr + 4) = make_uint4(nfv[4], nfv[5], nfv[6], nfv[7]);
                 }
+                pub_prev = pub;
                 if (K7_RARE(npre & K7_STAGE)) store_rows(N(26), N(27));
                 K7U_LAP(3);
                 K7T_LAP(0);
@@ -647,7 +662,8 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
             // what the pull that is pending took of each (wave, layer) entry (entry j = lane, and lane + 64)
             uint32_t took1 = 0, took2 = 0, pending_alive = 0;
             uint32_t pv_tabo = 0, pv_g10 = 0, big_n = 0, big_seq = 0;  // (a K8_BIG block of the step before: its size and first number)
-            for (uint32_t sc = 0, sp = 0;; sc = sc == 2u ? 0u : sc + 1u, sp ^= 1u) {
+            uint32_t sp = 0;  // step parity (after the loop: the last step's)
+            for (uint32_t sc = 0;; sc = sc == 2u ? 0u : sc + 1u, sp ^= 1u) {
                 const uint32_t sn = sc == 2u ? 0u : sc + 1u;
                 const uint32_t cw = s_cmd[lane < 32 ? sc : sn][lane & 31];
                 auto C = [&](int j) { return (uint32_t)__builtin_amdgcn_readlane((int)cw, j); };
@@ -676,9 +692,16 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
                 if (npre & K7_STAGE) fetch_rows(st_base, st_tot);
                 if (more && (nflags & K7_CUR) && indexes(N(1)))
                     insert_hits(N(1), N(2), N(3), N(4), N(9), N(5), bsh, (nflags & K7_LATE) != 0u, st_base + (N(2) - st_buf * (uint32_t)HB));
-                    // ---- slots: what the arm waves published, minus what the pending pull takes --------------------------
-                    const uint32_t fv = lane < NE ? s_free[lane % NWA][lane / NWA] : 0u;
-                    const uint32_t fv2 = NE > 64 && lane + 64 < NE ? s_free[(lane + 64) % NWA][(lane + 64) / NWA] : 0u;
+                {   // ---- slots: what the arm waves published, minus what the pending pull takes ----------------------
+                    // (the block the arm waves wrote in front of the barrier this step began with; test hook k8_delay:
+                    // the read is held back that many cycles -- results must not depend on when it happens)
+                    if (K7_RARE(P.k8_delay != 0u)) {
+                        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+                        while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)P.k8_delay) __builtin_amdgcn_s_sleep(2);
+                    }
+                    const uint32_t (*const fr)[8] = s_free[(sp ^ 1u) & (kFreeBufs - 1u)];
+                    const uint32_t fv = lane < NE ? fr[lane % NWA][lane / NWA] : 0u;
+                    const uint32_t fv2 = NE > 64 && lane + 64 < NE ? fr[(lane + 64) % NWA][(lane + 64) / NWA] : 0u;
                     uint32_t n_new = 0, seq_base = 0, pflags = 0;
                     uint32_t av1 = fv - min(fv, took1), av2 = fv2 - min(fv2, took2);
                     uint32_t base1 = 0, base2 = 0;
@@ -796,6 +819,7 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
                     // the stash and the occupancy bits of the previous probe: nobody reads them any more
                     if (lane == 0 && have_prev) s_nstash[prev_bb] = 0u;
                     if (have_prev && (uint32_t)lane < kBitWords) s_rowbits[prev_bb][lane] = 0u;
+                }
                 if (npre & K7_STAGE) store_rows(st_tot, st_buf);
                 pv_tabo = C(3);
                 pv_g10 = C(5);
@@ -821,10 +845,12 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
 #endif
             if (!overflow) {
                 // nothing alive is left behind unless the chunk (or the window of a sharded call) ended first
-                const uint32_t fv = lane < NE ? s_free[lane % NWA][lane / NWA] : 0u;
+                // (the counts of the last step: behind its barrier)
+                const uint32_t (*const fr)[8] = s_free[sp & (kFreeBufs - 1u)];
+                const uint32_t fv = lane < NE ? fr[lane % NWA][lane / NWA] : 0u;
                 uint32_t total_free = lane_of(wave_incl_scan(fv), 63u);
                 if constexpr (NE > 64) {
-                    const uint32_t fv2 = lane + 64 < NE ? s_free[(lane + 64) % NWA][(lane + 64) / NWA] : 0u;
+                    const uint32_t fv2 = lane + 64 < NE ? fr[(lane + 64) % NWA][(lane + 64) / NWA] : 0u;
                     total_free += lane_of(wave_incl_scan(fv2), 63u);
                 }
                 const uint32_t t_proc = uni(s_end[0]);
@@ -860,7 +886,7 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
             if (lane == 0) {
                 s_seg[0] = g0;
                 s_seg[1] = cs;
-                s_seg[2] = cl;
+                s_seg[2] = cl | ((unsigned long long)((rp.mode_of(c) >> 1) & 1u) << 63);
             }
             uint32_t quiet = 0, pend = 0, t_proc = 0;
             bool done = false, giveup = false;

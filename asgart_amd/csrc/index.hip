@@ -11,9 +11,16 @@
 #include <chrono>
 #include <cstdlib>
 
+#include <dirent.h>
+#include <execinfo.h>
+#include <signal.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+
 namespace asgart {
 
 static thread_local char g_err[512] = "";
+thread_local bool tl_owns_pass_mu = false;
 
 // Runtime note.  The extension tiers of one call run on six HIP streams (twelve with
 // two calls in flight); ROCm maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and kernels of
@@ -47,6 +54,7 @@ const OptDesc kOptions[] = {
     {"test_cap_limit", &Options::test_cap_limit, -1, 1ll << 31},
     {"test_levels", &Options::test_levels, 0, 15},
     {"test_genbits", &Options::test_genbits, 2, 22},
+    {"test_k8_delay", &Options::test_k8_delay, 0, 1 << 22},
     {"tier_order", &Options::tier_order, 1, 7777777},
     {"ptab_depth", &Options::ptab_depth, 0, 15},
     {"force_wide", &Options::force_wide, 0, 1},
@@ -54,6 +62,7 @@ const OptDesc kOptions[] = {
     {"kfilter_bits", &Options::kfilter_bits, 0, 34},
     {"k7", &Options::k7, 0, 127},
     {"lazy_aux", &Options::lazy_aux, 0, 1},
+    {"fuse_passes", &Options::fuse_passes, 0, 1},
     {"dense3", &Options::dense3, 0, 1 << 20},
     {"dense6", &Options::dense6, 0, 1 << 20},
     {"dense_min", &Options::dense_min, 0, 1 << 30},
@@ -591,7 +600,7 @@ int32_t text_is_dna(const uint8_t *d_text, int64_t n, hipStream_t s, bool *dna) 
         if (blocks > 4096) blocks = 4096;
         byte_histogram_kernel<<<blocks, 256, 0, s>>>(d_text, (uint64_t)n, d_hist);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(hist, d_hist, sizeof(hist), hipMemcpyDeviceToHost, s));
+        HIP_TRY(read_back(hist, d_hist, sizeof(hist), s));
         HIP_TRY(stream_sync(s));
         return 0;
     }();
@@ -639,6 +648,7 @@ int32_t index_prepare_sap(asgart_index *idx, uint64_t k) {
         std::lock_guard<std::mutex> lk(idx->mu);
         if (idx->k == k && (idx->d_sap || idx->sap_tried)) return 0;
     }
+    REFUSE_POISONED(idx);
     idx->acquire_all();
     struct Unlock {
         asgart_index *i;
@@ -660,6 +670,7 @@ int32_t index_prepare(asgart_index *idx, uint64_t k) {
         std::lock_guard<std::mutex> lk(idx->mu);
         if (idx->k == k) return 0;
     }
+    REFUSE_POISONED(idx);
     idx->acquire_all();  // no search call may be using the old keys
     struct Unlock {
         asgart_index *i;
@@ -712,7 +723,7 @@ int32_t index_prepare(asgart_index *idx, uint64_t k) {
         bad_slots_kernel<SlotT><<<grid_capped(n_sa), 256, 0, s>>>(sa, n_sa, first_bad, d_out, d_cnt, kMaxK + 2);
         HIP_TRY(hipGetLastError());
         unsigned long long h[8 + kMaxK + 2];
-        HIP_TRY(hipMemcpyAsync(h, d_cnt, sizeof(h), hipMemcpyDeviceToHost, s));
+        HIP_TRY(read_back(h, d_cnt, sizeof(h), s));
         HIP_TRY(stream_sync(s));
         idx->n_bad = (int)std::min<unsigned long long>(h[0], kMaxK + 2);
         for (int j = 0; j < idx->n_bad; ++j) idx->bad[j] = h[8 + j];
@@ -759,13 +770,14 @@ int32_t index_prepare(asgart_index *idx, uint64_t k) {
         // passes call with its per-thread runtime state.  Best effort: without the memory the calls allocate as they go.
         const uint64_t step = k / 2 ? k / 2 : 1;
         const uint64_t W = std::min<uint64_t>((uint64_t)idx->n / step + 1, 0xFFFFFF00ull);
-        for (auto &cx : idx->ctx)
-            if (reserve_probe_workspace(idx, cx, W) != 0) {
+        // (the first context for TWO passes: the direct and the -RC run of a passes call are one job over both passes' probes)
+        for (int c = 0; c < kNumCtx; ++c)
+            if (reserve_probe_workspace(idx, idx->ctx[c], c == 0 ? std::min<uint64_t>(2 * W, 0xFFFFFF00ull) : W) != 0) {
                 (void)hipGetLastError();
                 break;
             }
         // (a passes call that prepares lazily holds pass_mu itself and owns the workers: leave them to it)
-        if (idx->pass_mu.try_lock()) {
+        if (!tl_owns_pass_mu && idx->pass_mu.try_lock()) {
             if (idx->pass_workers.empty()) {
                 idx->pass_workers.emplace_back(new asgart::PassWorker());
                 const int dev = idx->device;
@@ -796,6 +808,7 @@ int32_t index_prepare_filter(asgart_index *idx, uint64_t k, int mode) {
         std::lock_guard<std::mutex> lk(idx->mu);
         if (idx->k == k && (idx->d_filter[mode] || idx->filter_off[mode])) return 0;
     }
+    REFUSE_POISONED(idx);
     idx->acquire_all();
     struct Unlock {
         asgart_index *i;
@@ -885,28 +898,184 @@ const char *asgart_last_error(void) { return asgart::g_err; }
 
 const char *asgart_version(void) { return "asgart-hip 0.2.0 gfx950"; }
 
+// ---- native stacks of every thread (asgart_hip.h: asgart_debug_dump_stacks) ------------------------------------------
+namespace {
+std::atomic<int> g_dump_busy{0};
+void dump_stack_handler(int) {
+    void *frames[64];
+    const int n = backtrace(frames, 64);
+    char head[96];
+    const int len = snprintf(head, sizeof head, "---- native stack of thread %ld ----\n", (long)syscall(SYS_gettid));
+    if (len > 0) (void)!write(2, head, (size_t)len);
+    backtrace_symbols_fd(frames, n, 2);
+    g_dump_busy.store(0, std::memory_order_release);
+}
+}  // namespace
+
+int32_t asgart_debug_dump_stacks(void) {
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    {   // (the first backtrace of a process loads libgcc: not from inside a signal handler)
+        void *warm[4];
+        (void)backtrace(warm, 4);
+    }
+    struct sigaction sa, old;
+    memset(&sa, 0, sizeof sa);
+    sa.sa_handler = dump_stack_handler;
+    sa.sa_flags = SA_RESTART;
+    sigemptyset(&sa.sa_mask);
+    if (sigaction(SIGUSR2, &sa, &old) != 0) return -1;
+    int asked = 0;
+    const pid_t pid = getpid();
+    if (DIR *d = opendir("/proc/self/task")) {
+        std::vector<long> tids;
+        while (struct dirent *e = readdir(d)) {
+            char *end = nullptr;
+            const long tid = strtol(e->d_name, &end, 10);
+            if (end && *end == 0 && tid > 0) tids.push_back(tid);
+        }
+        closedir(d);
+        for (long tid : tids) {
+            g_dump_busy.store(1, std::memory_order_release);
+            if (syscall(SYS_tgkill, pid, (pid_t)tid, SIGUSR2) != 0) continue;
+            ++asked;
+            // one at a time (the dumps would interleave); a thread that cannot take the signal is given 0.5 s
+            for (int spin = 0; spin < 500 && g_dump_busy.load(std::memory_order_acquire); ++spin)
+                std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        }
+    }
+    (void)sigaction(SIGUSR2, &old, nullptr);
+    return asked;
+}
+
+// Teardown in stages, none of which can hold the host for ever (three stalls of round 4 ended in here or in a
+// build's read-back, on boxes that were slow to begin with; no wait of this function was polled then):
+//   1  every stream of both call contexts is drained by a POLLED wait (limit: option watchdog_s, 0 = for ever).  Streams
+//      that do not drain -- or an index the watchdog has given up on whose streams still do not -- mean work is in
+//      flight on the buffers: nothing is freed, the index is leaked, the reason goes to stderr and asgart_last_error;
+//   2  the worker threads of the passes call are joined (idle by now: a passes call in flight would own the contexts);
+//   3  events and streams are destroyed, 4 pinned host blocks freed, 5 device buffers given back, 6 the block cache
+//      trimmed when this was the device's last index -- every one of them a runtime call that synchronises with the
+//      device inside the runtime and cannot be polled: they run on a helper thread that is waited for watchdog_s
+//      seconds PER STAGE; a stage that does not come back is reported (stage name, index, seconds) and the rest of the
+//      teardown is abandoned (leak) instead of hanging the caller.
+// ASGART_DEBUG=1 (option debug) stamps every stage on stderr.
 void asgart_index_destroy(asgart_index *idx) {
     if (!idx) return;
-    (void)hipSetDevice(idx->device);
-    free_k_specific(idx);
-    if (idx->d_text) dev_free(idx->d_text);
-    if (idx->d_sa) dev_free(idx->d_sa);
-    for (auto &cx : idx->ctx) {
-        cx.ws.release_all();  // (the record-ordering buffers used to be missing from a list kept here: a leak per index)
-        if (cx.h_pinned) (void)hipHostFree(cx.h_pinned);
-        cx.h_pinned = nullptr;
-        if (cx.h_ctl) (void)hipHostFree(cx.h_ctl);
-        cx.h_ctl = nullptr;
-        cx.h_ctl_cap = 0;
-        if (cx.h_hb) (void)hipHostFree(cx.h_hb);
-        cx.h_hb = cx.d_hb = nullptr;
-        for (auto &e : cx.ev)
-            if (e) (void)hipEventDestroy(e);
-        for (hipStream_t st : {cx.stream, cx.stream2, cx.stream3, cx.stream4, cx.stream5, cx.stream6, cx.stream7})
-            if (st) (void)hipStreamDestroy(st);
+    const bool dbg = idx->opt.debug != 0;
+    const double limit = (double)idx->opt.watchdog_s;
+    // (an index the watchdog has already given up on: its streams are given a few more seconds, not another full limit)
+    const double drain_limit = idx->poisoned.load() ? (limit > 0.0 && limit < 5.0 ? limit : 5.0) : limit;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+    auto stamp = [&](const char *what) {
+        if (dbg) fprintf(stderr, "[asgart] destroy %p: %s (+%.1f ms)\n", (void *)idx, what, since());
+    };
+    auto give_up = [&](const char *stage) {
+        set_error("asgart_index_destroy: %s did not finish within %.0f s (option watchdog_s); the index and its device memory "
+                  "are left behind (leaked) instead of hanging the caller -- report and exit, or continue in a fresh process",
+                  stage, limit);
+        fprintf(stderr, "[asgart] %s\n", asgart_last_error());
+        idx->poisoned.store(true);
+    };
+    const int dev = idx->device;
+    (void)hipSetDevice(dev);
+    stamp("begin");
+    // ---- 1: polled drain -------------------------------------------------------------------------------------------
+    for (int c = 0; c < kNumCtx; ++c) {
+        SearchCtx &cx = idx->ctx[c];
+        int j = 0;
+        for (hipStream_t st : {cx.stream, cx.stream2, cx.stream3, cx.stream4, cx.stream5, cx.stream6, cx.stream7}) {
+            ++j;
+            if (!st) continue;
+            const auto t1 = std::chrono::steady_clock::now();
+            for (unsigned spins = 1;; ++spins) {
+                const hipError_t q = hipStreamQuery(st);
+                if (q != hipErrorNotReady) {
+                    (void)hipGetLastError();
+                    break;  // (idle, or an error the frees below will meet again: nothing to wait for either way)
+                }
+                (void)hipGetLastError();
+                if (spins > 256) std::this_thread::sleep_for(std::chrono::microseconds(spins > 4096 ? 200 : 20));
+                if (drain_limit > 0.0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count() > drain_limit) {
+                    char what[64];
+                    snprintf(what, sizeof what, "the drain of stream %d of call context %d", j, c);
+                    give_up(what);
+                    return;
+                }
+            }
+        }
     }
+    stamp("streams drained");
+    // ---- 2: workers ------------------------------------------------------------------------------------------------
+    if (!bounded_call(limit, [idx]() { idx->pass_workers.clear(); })) {
+        give_up("joining the worker threads of the passes call");
+        return;
+    }
+    stamp("workers joined");
+    // ---- 3: events and streams -------------------------------------------------------------------------------------
+    if (!bounded_call(limit, [idx, dev]() {
+            (void)hipSetDevice(dev);
+            for (auto &cx : idx->ctx) {
+                for (auto &e : cx.ev)
+                    if (e) {
+                        (void)hipEventDestroy(e);
+                        e = nullptr;
+                    }
+                for (hipStream_t *st : {&cx.stream, &cx.stream2, &cx.stream3, &cx.stream4, &cx.stream5, &cx.stream6, &cx.stream7})
+                    if (*st) {
+                        (void)hipStreamDestroy(*st);
+                        *st = nullptr;
+                    }
+            }
+        })) {
+        give_up("destroying the events and streams");
+        return;
+    }
+    stamp("events and streams destroyed");
+    // ---- 4: pinned host memory (the device-mapped heartbeat block among it) ---------------------------------------------
+    if (!bounded_call(limit, [idx, dev]() {
+            (void)hipSetDevice(dev);
+            for (auto &cx : idx->ctx) {
+                if (cx.h_pinned) (void)hipHostFree(cx.h_pinned);
+                cx.h_pinned = nullptr;
+                cx.h_pinned_cap = 0;
+                if (cx.h_ctl) (void)hipHostFree(cx.h_ctl);
+                cx.h_ctl = nullptr;
+                cx.h_ctl_cap = 0;
+                if (cx.h_hb) (void)hipHostFree(cx.h_hb);
+                cx.h_hb = cx.d_hb = nullptr;
+            }
+        })) {
+        give_up("freeing the pinned host blocks");
+        return;
+    }
+    stamp("pinned host memory freed");
+    // ---- 5: device buffers (to the block cache, or to the device) ----------------------------------------------------------
+    if (!bounded_call(limit, [idx, dev]() {
+            (void)hipSetDevice(dev);
+            free_k_specific(idx);
+            if (idx->d_text) dev_free(idx->d_text);
+            if (idx->d_sa) dev_free(idx->d_sa);
+            idx->d_text = nullptr;
+            idx->d_sa = nullptr;
+            for (auto &cx : idx->ctx) cx.ws.release_all();  // (the record-ordering buffers used to be missing from a list kept here)
+        })) {
+        give_up("releasing the device buffers");
+        return;
+    }
+    stamp("device buffers released");
     delete idx;
-    BlockCache::index_gone();  // the last index of the device takes the cached blocks with it
+    // ---- 6: the last index of the device takes the cached blocks with it -------------------------------------------------------
+    if (!bounded_call(limit, [dev]() {
+            (void)hipSetDevice(dev);
+            BlockCache::index_gone();
+        })) {
+        set_error("asgart_index_destroy: giving the cached device blocks back did not finish within %.0f s (option watchdog_s)", limit);
+        fprintf(stderr, "[asgart] %s\n", asgart_last_error());
+        return;
+    }
+    if (dbg) fprintf(stderr, "[asgart] destroy: done (+%.1f ms)\n", since());
 }
 
 static int32_t index_create_impl(const uint8_t *T, int64_t n, const int64_t *SA, int64_t sa_len,
@@ -965,7 +1134,7 @@ static int32_t index_create_impl(const uint8_t *T, int64_t n, const int64_t *SA,
         byte_histogram_kernel<<<blocks, 256, 0, idx->ctx[0].stream>>>(idx->d_text, (uint64_t)n, d_hist);
         HIP_TRY(hipGetLastError());
         unsigned long long hist[256];
-        HIP_TRY(hipMemcpyAsync(hist, d_hist, sizeof(hist), hipMemcpyDeviceToHost, idx->ctx[0].stream));
+        HIP_TRY(read_back(hist, d_hist, sizeof(hist), idx->ctx[0].stream));
         HIP_TRY(stream_sync(idx->ctx[0].stream));
         for (int c = 0; c < 256; ++c)
             if (hist[c] && !valid_text_byte((uint8_t)c)) {
@@ -1165,7 +1334,7 @@ int32_t asgart_index_create_device(const void *d_text, int64_t n, const void *d_
         RC_TRY(text_is_dna(idx->d_text, n, s, &dna));
         const int64_t tl = n < (int64_t)kMaxK + 32 ? n : (int64_t)kMaxK + 32;
         idx->h_tail.resize((size_t)tl);
-        HIP_TRY(hipMemcpyAsync(idx->h_tail.data(), idx->d_text + (n - tl), (size_t)tl, hipMemcpyDeviceToHost, s));
+        HIP_TRY(read_back(idx->h_tail.data(), idx->d_text + (n - tl), (size_t)tl, s));
         HIP_TRY(stream_sync(s));
         if (!dna) {
             set_error("text contains bytes other than the normalised bases {A,C,G,T,N} and '$' "
@@ -1191,6 +1360,7 @@ int32_t asgart_index_set_option(asgart_index *idx, const char *name, int64_t val
         set_error("option %s is fixed when the index is created (set ASGART_<NAME> in the environment before)", name);
         return ASGART_E_ARG;
     }
+    if (name && !strcmp(name, "kfilter_bits")) REFUSE_POISONED(idx);  // (it frees device buffers)
     idx->acquire_all();  // never changes under a running call
     const int32_t rc = option_set(idx->opt, name, value);
     if (rc == 0 && !strcmp(name, "test_fail_alloc")) asgart::fail_alloc_countdown().store(value);  // (process-wide)
@@ -1211,6 +1381,7 @@ int64_t asgart_index_check_sa(asgart_index *idx) {
         set_error("asgart_index_check_sa: not for a --trim index (its array covers a window of the text)");
         return ASGART_E_ARG;
     }
+    REFUSE_POISONED(idx);
     HIP_TRY(hipSetDevice(idx->device));
     idx->acquire_all();
     struct Unlock {
@@ -1238,7 +1409,7 @@ int64_t asgart_index_check_sa(asgart_index *idx) {
                                                         errs.as<unsigned long long>());
         }
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(&h_errs, errs.p, 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(read_back(&h_errs, errs.p, 8, s));
         HIP_TRY(stream_sync(s));
         return 0;
     }();
@@ -1267,6 +1438,7 @@ static bool pattern_bytes_ok(const uint8_t *p, int64_t cnt) {
 static int32_t run_pattern_kernel(asgart_index *idx, const uint8_t *pats, int64_t n_pat,
                                   int64_t width, bool cache, uint64_t *lo, uint64_t *hi) {
     if (n_pat == 0) return 0;
+    REFUSE_POISONED(idx);
     HIP_TRY(hipSetDevice(idx->device));
     idx->acquire_all();
     struct Unlock {
@@ -1298,8 +1470,8 @@ static int32_t run_pattern_kernel(asgart_index *idx, const uint8_t *pats, int64_
                                                                w.out_b.as<uint64_t>());
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(lo, w.out_a.p, (size_t)n_pat * 8, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(hi, w.out_b.p, (size_t)n_pat * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(read_back(lo, w.out_a.p, (size_t)n_pat * 8, s));
+    HIP_TRY(read_back(hi, w.out_b.p, (size_t)n_pat * 8, s));
     HIP_TRY(stream_sync(s));
     return 0;
 }
@@ -1340,6 +1512,7 @@ int32_t asgart_sa_read(asgart_index *idx, uint64_t lo, uint64_t hi, int64_t *out
         return ASGART_E_ARG;
     }
     if (hi == lo) return 0;
+    REFUSE_POISONED(idx);
     HIP_TRY(hipSetDevice(idx->device));
     idx->acquire_all();
     struct Unlock {
@@ -1348,15 +1521,13 @@ int32_t asgart_sa_read(asgart_index *idx, uint64_t lo, uint64_t hi, int64_t *out
     } unlock{idx};
     const uint64_t cnt = hi - lo;
     if (idx->wide) {
-        HIP_TRY(hipMemcpyAsync(out, (const uint64_t *)idx->d_sa + lo, cnt * 8,
-                               hipMemcpyDeviceToHost, idx->ctx[0].stream));
+        HIP_TRY(read_back(out, (const uint64_t *)idx->d_sa + lo, cnt * 8, idx->ctx[0].stream));
     } else {
         RC_TRY(idx->ctx[0].ws.out_a.reserve(cnt * 8));
         widen_sa_kernel<<<grid_for(cnt), 256, 0, idx->ctx[0].stream>>>(
             (const uint32_t *)idx->d_sa + lo, idx->ctx[0].ws.out_a.as<int64_t>(), cnt);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(out, idx->ctx[0].ws.out_a.p, cnt * 8, hipMemcpyDeviceToHost,
-                               idx->ctx[0].stream));
+        HIP_TRY(read_back(out, idx->ctx[0].ws.out_a.p, cnt * 8, idx->ctx[0].stream));
     }
     HIP_TRY(stream_sync(idx->ctx[0].stream));
     return 0;

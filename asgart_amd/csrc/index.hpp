@@ -40,13 +40,7 @@ struct IndexView {
     uint32_t tail8[kMaxK];
     int n_tail8;
     uint64_t tail_bloom;
-    // presence filter of the orientation of this call (search_dev.hpp); null: no filter
-    const uint64_t *flt;
-    int flt_bits;
-    // ... the same answers laid out by TEXT POSITION (bit p: the probe that covers text[p .. p + k) in this
-    // orientation passes the filter): the 256 probes of a workgroup read 320 contiguous bytes instead of 256
-    // random words.  null: the kernels test the hashed filter.
-    const uint64_t *pbits;
+    // (the presence filters and their position bitmaps are per orientation: RunParams::flt / pbits)
     // occurrences of every k-mer interval sorted by position (sa_build.hip: build_rank_lists); null: none
     const SlotT *sap;
     // number of suffix-array slots: n, or end - start + 1 for a --trim index (reference
@@ -77,7 +71,24 @@ struct RunParams {
     uint32_t tstar;       // ceil(G / step)
     uint64_t M;           // min_duplication_length
     uint32_t C;           // max_cardinality (clamped)
-    uint8_t reverse, complement;
+    // The probe sequence of a call is the chunk list once per PASS (one pass = one orientation = one invocation of the
+    // reference's binary, src/bin/asgart.rs:677-693): pass p owns chunks [p * pass_chunks, (p + 1) * pass_chunks) of the
+    // chunk table and its probes are needles prepared the pass's way (asgart.rs:206-218).  A plain call has one pass;
+    // asgart_search_duplications_passes runs up to four as ONE job -- one front over all their probes, one launch per
+    // extension tier over the merged, cost-sorted segment list.
+    uint32_t n_passes, pass_chunks;
+    uint32_t modes;       // 8 bits per pass: bit 1 = reversed needle, bit 0 = complemented
+    const uint64_t *flt[4];    // per pass: presence filter of its orientation (search_dev.hpp); null: none
+    const uint64_t *pbits[4];  // ... its answers laid out by TEXT POSITION (bit p: the probe that covers text[p .. p + k) in
+                               // this orientation passes the filter); null: the kernels test the hashed filter
+    int flt_bits;
+    __host__ __device__ inline uint32_t pass_of(int c) const {
+        if (n_passes <= 1u) return 0u;
+        const uint32_t uc = (uint32_t)c;
+        return (uc >= pass_chunks ? 1u : 0u) + (uc >= 2u * pass_chunks ? 1u : 0u) + (uc >= 3u * pass_chunks ? 1u : 0u);
+    }
+    __host__ __device__ inline uint32_t mode_of_pass(uint32_t p) const { return (modes >> (8u * p)) & 3u; }
+    __host__ __device__ inline uint32_t mode_of(int c) const { return mode_of_pass(pass_of(c)); }
 };
 
 // One emitted duplication arm, keyed for the reference's output order (chunk order, discovery order
@@ -236,6 +247,8 @@ struct Options {
     int64_t test_cap_limit = -1;    // tests: shrink every tier's capacity (forces the cascade)
     int64_t test_levels = 4;        // tests: usable hit-table levels of the arm-resident kernel
     int64_t test_genbits = 22;      // tests: width of its generation counter
+    int64_t test_k8_delay = 0;      // tests: cycles K8's ranking wave waits in every step before it reads the free counts the arm
+                                    // waves published (results must not depend on it: the counts are double-buffered by step parity)
     int64_t tier_order = 3654217;   // launch order of the extension tiers, as decimal digits
     int64_t grid[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // grid[t] > 0: workgroups of tier t (clamped to its maximum)
     int64_t ptab_depth = 0;         // 0: chosen from the text length
@@ -274,6 +287,9 @@ struct Options {
     int64_t k7 = 8;                 // bit t set (t = 3..6): tier t runs the arm kernel with a control wave (extend_k7_dev.hpp) instead of K6 / K4c. Default: tier 3 only -- the long DENSE segments (option dense3), where its shorter per-probe chain counts; measured in the other tiers (k7 = 120) it loses: a quarter / an eighth of a 256- / 512-thread workgroup holds no arms and a sparse probe costs two barriers instead of one wave's solo run
     int64_t k8 = 1;                 // 1: the tiers of option k7 run the one-barrier variant (extend_k8_dev.hpp: the new arms' first offers are
                                     // made by a ranking wave, a planning wave writes the commands; 14 arm waves instead of 15); 0: K7
+    int64_t fuse_passes = 1;        // 1: asgart_search_duplications_passes runs passes that differ in orientation only as ONE job (one
+                                    // front over all their probes, one launch per extension tier over the merged segment list);
+                                    // 0: as pipelined single-pass calls on the two call contexts (what sharded calls still do)
     int64_t lazy_aux = 1;           // 1: the presence filter of an orientation is built when that orientation is searched the SECOND time, the
                                     // position-sorted lists when a search call has had a predecessor: they cost 0.18 s per orientation / 0.2 s
                                     // at GRCh38 size and save 0.03 / 0.006 s per pass -- a host that runs every orientation once per index
@@ -449,9 +465,6 @@ struct asgart_index {
         for (int j = 0; j < asgart::kMaxK; ++j) v.tail8[j] = tail8[j];
         v.n_tail8 = n_tail8;
         v.tail_bloom = tail_bloom;
-        v.flt = nullptr;
-        v.flt_bits = 0;
-        v.pbits = nullptr;
         v.sap = reinterpret_cast<const SlotT *>(d_sap);
         v.n_sa = (uint64_t)n_sa;
         v.trim = trimmed ? 1 : 0;
@@ -469,11 +482,29 @@ struct asgart_families {
 };
 
 namespace asgart {
+// An index whose watchdog gave up (or whose teardown did) may still have work running on its streams and buffers: every
+// entry point that would touch them refuses it.
+#define REFUSE_POISONED(idx)                                                                                              \
+    do {                                                                                                                  \
+        if ((idx)->poisoned.load()) {                                                                                     \
+            ::asgart::set_error("this index gave up waiting for the device in an earlier call (watchdog): work may still be " \
+                                "running on its streams; destroy it and continue in a fresh process");                    \
+            return ASGART_E_HIP;                                                                                          \
+        }                                                                                                                 \
+    } while (0)
+// set by the passes call on the thread that holds asgart_index::pass_mu (index_prepare's prewarm must not try to lock a
+// mutex its own thread owns: undefined for std::mutex)
+extern thread_local bool tl_owns_pass_mu;
 int32_t index_prepare(asgart_index *idx, uint64_t k);
 // per-probe workspace of one call context for a window of W probes (pipeline.hip; also what run_search_t reserves)
 int32_t reserve_probe_workspace(asgart_index *idx, SearchCtx &cx, uint64_t W);
 int32_t index_prepare_filter(asgart_index *idx, uint64_t k, int mode);  // mode = reverse * 2 + complement
 int32_t index_prepare_sap(asgart_index *idx, uint64_t k);
+int32_t run_search_passes(asgart_index *idx, const uint64_t *chunks, int64_t n_chunks,
+                          const asgart_settings *sts, int32_t n_passes, int32_t shard, int32_t n_shards, bool want_csr,
+                          asgart_families *const *fams, std::vector<uint8_t> *status_out,
+                          std::vector<uint64_t> *rowoff_out, std::vector<uint64_t> *hits_out,
+                          volatile uint64_t *progress);
 int32_t run_search(asgart_index *idx, const uint64_t *chunks, int64_t n_chunks,
                    const asgart_settings *st, int32_t shard, int32_t n_shards, bool want_csr,
                    asgart_families *fam_out, std::vector<uint8_t> *status_out,

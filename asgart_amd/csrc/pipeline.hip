@@ -119,23 +119,60 @@ static uint32_t probes_in_chunk(uint64_t L, uint64_t k, uint64_t step, uint64_t 
 // workgroups that were in flight, and the index refuses further calls (its streams may still hold the stuck work) --
 // the host should report and exit, or go on in a fresh process.  (One GPU test run of round 3 sat in a call for 40
 // minutes with nothing to tell where.)
-static int32_t wd_sync(asgart_index *idx, SearchCtx &cx, hipStream_t st, const char *phase) {
-    const int64_t limit_s = idx->opt.watchdog_s;
-    if (limit_s <= 0) {
-        HIP_TRY(hipStreamSynchronize(st));
-        return 0;
-    }
-    const auto t0 = std::chrono::steady_clock::now();
-    auto t_change = t0;
+struct Watchdog {
+    asgart_index *idx;
+    SearchCtx &cx;
+    std::chrono::steady_clock::time_point t0, t_change;
     unsigned long long sig = 0;
-    auto signature = [&]() {
+    Watchdog(asgart_index *i, SearchCtx &c) : idx(i), cx(c), t0(std::chrono::steady_clock::now()), t_change(t0) {}
+    unsigned long long signature() const {
         unsigned long long h = 1469598103934665603ull;
         if (cx.h_hb) {
             const volatile unsigned long long *p = cx.h_hb;
             for (int i = 0; i < SearchCtx::kHbTiers * SearchCtx::kHbSlots * 2; ++i) h = (h ^ p[i]) * 1099511628211ull;
         }
         return h;
-    };
+    }
+    // One look at the heartbeats (never blocks).  true: nothing has changed for watchdog_s seconds -- the error is set and
+    // the index poisoned; the caller returns ASGART_E_HIP.
+    bool expired(const char *phase) {
+        const int64_t limit_s = idx->opt.watchdog_s;
+        if (limit_s <= 0) return false;
+        const auto now = std::chrono::steady_clock::now();
+        const unsigned long long s2 = signature();
+        if (s2 != sig) {
+            sig = s2;
+            t_change = now;
+        }
+        if (std::chrono::duration<double>(now - t_change).count() <= (double)limit_s) return false;
+        std::string who;
+        if (cx.h_hb) {
+            int shown = 0;
+            for (int t = 0; t < SearchCtx::kHbTiers && shown < 12; ++t)
+                for (int w = 0; w < SearchCtx::kHbSlots && shown < 12; ++w) {
+                    const unsigned long long a = cx.h_hb[2 * (t * SearchCtx::kHbSlots + w)], b = cx.h_hb[2 * (t * SearchCtx::kHbSlots + w) + 1];
+                    if (!(a >> 63)) continue;
+                    char buf[96];
+                    snprintf(buf, sizeof buf, "%s tier %d wg %d: segment at probe %llu, position %llu", shown ? ";" : "", t, w,
+                             a & 0xFFFFFFFFull, b);
+                    who += buf;
+                    ++shown;
+                }
+        }
+        idx->poisoned.store(true);
+        set_error("watchdog: no progress for %lld s while waiting for %s (%.1f s into the wait); last heartbeats:%s -- the index is "
+                  "unusable from here on (option watchdog_s = 0 waits forever)", (long long)limit_s, phase,
+                  std::chrono::duration<double>(now - t0).count(), who.empty() ? " none" : who.c_str());
+        return true;
+    }
+};
+
+static int32_t wd_sync(asgart_index *idx, SearchCtx &cx, hipStream_t st, const char *phase) {
+    if (idx->opt.watchdog_s <= 0) {
+        HIP_TRY(hipStreamSynchronize(st));
+        return 0;
+    }
+    Watchdog wd(idx, cx);
     for (unsigned spins = 0;; ++spins) {
         const hipError_t q = hipStreamQuery(st);
         if (q == hipSuccess) return 0;
@@ -143,35 +180,24 @@ static int32_t wd_sync(asgart_index *idx, SearchCtx &cx, hipStream_t st, const c
         (void)hipGetLastError();
         if (spins < 64) continue;                    // (short waits: no sleep at all)
         std::this_thread::sleep_for(std::chrono::microseconds(spins < 2000 ? 20 : 500));
-        if ((spins & 1023u) == 0) {
-            const auto now = std::chrono::steady_clock::now();
-            const unsigned long long s2 = signature();
-            if (s2 != sig) {
-                sig = s2;
-                t_change = now;
-            }
-            if (std::chrono::duration<double>(now - t_change).count() > (double)limit_s) {
-                std::string who;
-                if (cx.h_hb) {
-                    int shown = 0;
-                    for (int t = 0; t < SearchCtx::kHbTiers && shown < 12; ++t)
-                        for (int w = 0; w < SearchCtx::kHbSlots && shown < 12; ++w) {
-                            const unsigned long long a = cx.h_hb[2 * (t * SearchCtx::kHbSlots + w)], b = cx.h_hb[2 * (t * SearchCtx::kHbSlots + w) + 1];
-                            if (!(a >> 63)) continue;
-                            char buf[96];
-                            snprintf(buf, sizeof buf, "%s tier %d wg %d: segment at probe %llu, position %llu", shown ? ";" : "", t, w,
-                                     a & 0xFFFFFFFFull, b);
-                            who += buf;
-                            ++shown;
-                        }
-                }
-                idx->poisoned.store(true);
-                set_error("watchdog: no progress for %lld s while waiting for %s (%.1f s into the wait); last heartbeats:%s -- the index is "
-                          "unusable from here on (option watchdog_s = 0 waits forever)", (long long)limit_s, phase,
-                          std::chrono::duration<double>(now - t0).count(), who.empty() ? " none" : who.c_str());
-                return ASGART_E_HIP;
-            }
-        }
+        if ((spins & 1023u) == 0 && wd.expired(phase)) return ASGART_E_HIP;
+    }
+}
+// ... for an event (a stream may have more queued behind it)
+static int32_t wd_event_sync(asgart_index *idx, SearchCtx &cx, hipEvent_t ev, const char *phase) {
+    if (idx->opt.watchdog_s <= 0) {
+        HIP_TRY(hipEventSynchronize(ev));
+        return 0;
+    }
+    Watchdog wd(idx, cx);
+    for (unsigned spins = 0;; ++spins) {
+        const hipError_t q = hipEventQuery(ev);
+        if (q == hipSuccess) return 0;
+        if (q != hipErrorNotReady) HIP_TRY(q);
+        (void)hipGetLastError();
+        if (spins < 64) continue;
+        std::this_thread::sleep_for(std::chrono::microseconds(spins < 2000 ? 20 : 500));
+        if ((spins & 1023u) == 0 && wd.expired(phase)) return ASGART_E_HIP;
     }
 }
 
@@ -189,14 +215,19 @@ int32_t reserve_probe_workspace(asgart_index *idx, SearchCtx &cx, uint64_t W) {
     return 0;
 }
 
+// One job over the probes of n_passes passes (orientations) of the same chunk list: sts[p] differ in reverse /
+// complement only (the caller has checked); fams[p] receives pass p's families (null: none wanted -- the CSR surface).
 template <class SlotT>
-static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *chunks, int64_t n_chunks,
-                            const asgart_settings *st, int32_t shard, int32_t n_shards,
-                            bool want_csr, asgart_families *fam_out,
+static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *chunks, int64_t n_chunks_pass,
+                            const asgart_settings *sts, int32_t n_passes, int32_t shard, int32_t n_shards,
+                            bool want_csr, asgart_families *const *fams,
                             std::vector<uint8_t> *status_out, std::vector<uint64_t> *rowoff_out,
                             std::vector<uint64_t> *hits_out) {
     Workspace &w = cx.ws;
     hipStream_t s = cx.stream;
+    const asgart_settings *const st = &sts[0];
+    const bool fam_out = fams != nullptr;
+    const int64_t n_chunks = n_chunks_pass * (int64_t)n_passes;  // entries of the chunk table: the chunk list once per pass
     const uint64_t k = st->probe_size, step = k / 2;
     const uint64_t n = (uint64_t)idx->n;
 
@@ -214,8 +245,8 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
     uint64_t P64 = 0;
     const uint64_t text_end = (idx->h_tail.size() && idx->h_tail.back() == '$') ? n - 1 : n;
     for (int64_t c = 0; c < n_chunks; ++c) {
-        h_start[c] = chunks[2 * c];
-        h_len[c] = chunks[2 * c + 1];
+        h_start[c] = chunks[2 * (c % n_chunks_pass)];
+        h_len[c] = chunks[2 * (c % n_chunks_pass) + 1];
         if (h_start[c] > text_end || h_len[c] > text_end - h_start[c]) {
             set_error("chunk %lld = (%llu, %llu) exceeds the text (%llu bases before '$')",
                       (long long)c, (unsigned long long)h_start[c], (unsigned long long)h_len[c],
@@ -234,11 +265,12 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
     cx.last_P = P;
     memset(&cx.stats, 0, sizeof(cx.stats));
     cx.stats.probes_total = P;
-    if (fam_out) {
-        fam_out->fam_offsets.assign(1, 0);
-        fam_out->fam_keys.clear();
-        fam_out->sds.clear();
-    }
+    if (fam_out)
+        for (int32_t p = 0; p < n_passes; ++p) {
+            fams[p]->fam_offsets.assign(1, 0);
+            fams[p]->fam_keys.clear();
+            fams[p]->sds.clear();
+        }
     if (want_csr) {
         status_out->assign(P, 0);
         rowoff_out->assign((size_t)P + 1, 0);
@@ -307,8 +339,18 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
     if (rp.tstar == 0) rp.tstar = 1;
     rp.M = st->min_duplication_length;
     rp.C = st->max_cardinality > 0xFFFFFF00ull ? 0xFFFFFF00u : (uint32_t)st->max_cardinality;
-    rp.reverse = st->reverse ? 1 : 0;
-    rp.complement = st->complement ? 1 : 0;
+    rp.n_passes = (uint32_t)n_passes;
+    rp.pass_chunks = (uint32_t)n_chunks_pass;
+    rp.modes = 0;
+    rp.flt_bits = idx->filter_bits;
+    for (int p = 0; p < 4; ++p) {
+        rp.flt[p] = rp.pbits[p] = nullptr;
+        if (p >= n_passes) continue;
+        const int mode = (sts[p].reverse ? 2 : 0) | (sts[p].complement ? 1 : 0);
+        rp.modes |= (uint32_t)mode << (8 * p);
+        rp.flt[p] = idx->d_filter[mode];  // null: filter off
+        rp.pbits[p] = opt.posbits ? idx->d_pbits[mode] : nullptr;
+    }
     cx.last_rp = rp;
     cx.has_last = false;
 
@@ -320,16 +362,13 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
     RC_TRY(w.counters.reserve(CT_COUNT * 8));
     unsigned long long *d_ctr = w.counters.as<unsigned long long>();
     HIP_TRY(hipMemsetAsync(d_ctr, 0, CT_COUNT * 8, s));
-    auto signal_progress = [&]() {
-        for (int64_t c = 0; c < n_chunks; ++c)
+    auto signal_progress = [&]() {  // (only single-pass calls have a progress array)
+        for (int64_t c = 0; c < n_chunks_pass; ++c)
             cx.progress[c] = (uint64_t)probes_in_chunk(h_len[c], k, step, st->min_duplication_length) * step;
         progress_given = true;
     };
 
     IndexView<SlotT> ix = idx->view<SlotT>();
-    ix.flt = idx->d_filter[(st->reverse ? 2 : 0) | (st->complement ? 1 : 0)];  // null: filter off
-    ix.flt_bits = idx->filter_bits;
-    ix.pbits = opt.posbits ? idx->d_pbits[(st->reverse ? 2 : 0) | (st->complement ? 1 : 0)] : nullptr;
     SlotT *p_lo = w.p_lo.as<SlotT>() - w_lo;
     uint32_t *p_raw = w.p_raw.as<uint32_t>() - w_lo;
     uint32_t *p_filt = w.p_filt.as<uint32_t>() - w_lo;
@@ -386,6 +425,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
     if (want_csr) {
         std::vector<uint32_t> h_filt(P);
         std::vector<SlotT> h_hits((size_t)total_hits);
+        RC_TRY(wd_sync(idx, cx, s, "the hit rows"));  // (the copies below go to pageable memory: they block inside the copy)
         HIP_TRY(hipMemcpyAsync(h_filt.data(), p_filt, (size_t)P * 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpyAsync(rowoff_out->data(), row_off, ((size_t)P + 1) * 8,
                                hipMemcpyDeviceToHost, s));
@@ -567,7 +607,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                 seg_off[t + 1] = seg_off[t] + n_t[t];
             }
             HIP_TRY(hipMemcpyAsync(d_ctr + CT_N1, h_off + 2 * (kTiers + 1), (size_t)kTiers * 8, hipMemcpyHostToDevice, s));
-            HIP_TRY(hipStreamSynchronize(s));  // (h_off is reused by the next call)
+            RC_TRY(wd_sync(idx, cx, s, "the ownership lists"));  // (h_off is reused by the next call)
             order = own;
             n_seg = own_total;
         }
@@ -622,6 +662,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             ep.solo_hits = opt.solo == 1 ? 16u : (uint32_t)opt.solo;  // (1: the default of 16 hits; other values: that many)
             ep.n_levels = (uint32_t)opt.test_levels;
             ep.gen_bits = (uint32_t)opt.test_genbits;
+            ep.k8_delay = (uint32_t)opt.test_k8_delay;
             ep.ctr = d_ctr;
             ep.hb = nullptr;
             RC_TRY(cx.heartbeat(opt.watchdog_s > 0));
@@ -780,7 +821,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                 launch_tier(3);
                 HIP_TRY(hipGetLastError());
                 if (cx.progress && !progress_given) {
-                    HIP_TRY(hipEventSynchronize(cx.ev[3]));
+                    RC_TRY(wd_event_sync(idx, cx, cx.ev[3], "the hit rows"));
                     signal_progress();
                     progress_given = true;
                 }
@@ -814,7 +855,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                 // phases then run beside this call's extension, whose tail is a few serial segments.
                 // (option progress_at = 2; with 0 or 1 the signal was given right after the scans, above)
                 if (!progress_given) {
-                    HIP_TRY(hipEventSynchronize(cx.ev[3]));  // probe search, scans and CSR fill are done
+                    RC_TRY(wd_event_sync(idx, cx, cx.ev[3], "the hit rows"));  // probe search, scans and CSR fill are done
                     signal_progress();
                 }
             }
@@ -834,6 +875,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                 } early[2] = {{3, 0, cx.ev[6], st3, false}, {6, 0, cx.ev[10], st6, false}};
                 int n_pending = 0;
                 unsigned early_polls = 0;
+                Watchdog early_wd(idx, cx);
                 for (int e = 0; e < 2; ++e) {
                     Early &E = early[e];
                     int dst = E.src + 1;
@@ -867,7 +909,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                         --n_pending;
                         progressed = true;
                         HIP_TRY(hipMemcpyAsync(h_scalar + 1 + e, d_ctr + CT_OVF1 + E.src - 1, 8, hipMemcpyDeviceToHost, s));
-                        HIP_TRY(hipStreamSynchronize(s));
+                        RC_TRY(wd_sync(idx, cx, s, "an overflow count"));
                         const uint64_t n_e = h_scalar[1 + e];
                         if (opt.debug)
                             fprintf(stderr, "[asgart] tier %d done %.1f ms after the launches, %llu segment(s) to re-run in tier %d\n",
@@ -893,17 +935,10 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                     }
                     if (n_pending && !progressed) {
                         std::this_thread::sleep_for(std::chrono::microseconds(50));
-                        // (the same watchdog as every other wait of the call: here the wait is for tier 3 / tier 6)
-                        if ((++early_polls & 0x3FFFu) == 0) {
-                            for (int e = 0; e < 2; ++e)
-                                if (early[e].pending) {
-                                    const hipError_t q2 = hipEventQuery(early[e].ev);
-                                    if (q2 == hipErrorNotReady) {
-                                        (void)hipGetLastError();
-                                        RC_TRY(wd_sync(idx, cx, early[e].st, e == 0 ? "extension tier 3" : "extension tier 6"));
-                                    }
-                                }
-                        }
+                        // (the same watchdog as every other wait of the call -- one look at the heartbeats, never a blocking
+                        // wait: the other tier's early re-run must not wait for this one's stream to drain)
+                        if ((++early_polls & 0x3FFu) == 0 && early_wd.expired(early[0].pending ? "extension tier 3" : "extension tier 6"))
+                            return ASGART_E_HIP;
                     }
                 }
             }
@@ -1001,26 +1036,32 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                                    hipMemcpyDeviceToHost, s));
         }
         RC_TRY(wd_sync(idx, cx, s, "the ordering of the records"));
-        fam_out->sds.reserve(n_hrec);
+        // (sorted by segment start probe: pass 0's families first, then pass 1's ...; a family's key counts probes from
+        // the start of its OWN pass, so that it equals the key a single-pass call gives the same family)
+        if (n_passes == 1) fams[0]->sds.reserve(n_hrec);
+        int32_t pass = 0;
         for (size_t f0 = 0; f0 < n_hrec;) {
             if (h_recs[f0].g_start == kVoidStart) break;  // unused slots of the waves' record chunks: sorted last
             size_t f1 = f0;
             while (f1 < n_hrec && h_recs[f1].g_start == h_recs[f0].g_start &&
                    h_recs[f1].fam_seq == h_recs[f0].fam_seq)
                 ++f1;
+            while (pass + 1 < n_passes && h_recs[f0].g_start >= h_pbase[(int64_t)(pass + 1) * n_chunks_pass]) ++pass;
+            asgart_families *const fo = fams[pass];
             if (h_recs[f1 - 1].create_seq != kTombstone) {
                 for (size_t j = f0; j < f1; ++j) {
                     if (j > f0 && h_recs[j].create_seq == h_recs[j - 1].create_seq) continue;
-                    fam_out->sds.push_back(h_recs[j].sd);
+                    fo->sds.push_back(h_recs[j].sd);
                 }
-                fam_out->fam_offsets.push_back(fam_out->sds.size());
-                fam_out->fam_keys.push_back(((uint64_t)h_recs[f0].g_start << 32) | (uint64_t)h_recs[f0].fam_seq);
+                fo->fam_offsets.push_back(fo->sds.size());
+                fo->fam_keys.push_back(((uint64_t)(h_recs[f0].g_start - h_pbase[(int64_t)pass * n_chunks_pass]) << 32) |
+                                       (uint64_t)h_recs[f0].fam_seq);
             }
             f0 = f1;
         }
     } else {
         HIP_TRY(hipEventRecord(cx.ev[4], s));
-        HIP_TRY(hipStreamSynchronize(s));
+        RC_TRY(wd_sync(idx, cx, s, "the hit rows"));
     }
     break;
     }  // shard-window retry loop
@@ -1045,8 +1086,12 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
     stt.raw_hits = h_ctr[CT_RAW_HITS];
     stt.filtered_hits = total_hits;
     stt.segments = n_seg;
-    stt.families = fam_out ? fam_out->fam_offsets.size() - 1 : 0;
-    stt.proto_sds = fam_out ? fam_out->sds.size() : 0;
+    stt.families = stt.proto_sds = 0;
+    for (int32_t p = 0; fam_out && p < n_passes; ++p) {
+        stt.families += fams[p]->fam_offsets.size() - 1;
+        stt.proto_sds += fams[p]->sds.size();
+    }
+    stt.passes = (uint64_t)n_passes;
     stt.search_launches = 1;
     stt.overflow_segments = n_overflow;
     stt.heavy_segments = n_heavy;
@@ -1061,65 +1106,68 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
 
 static thread_local PassGate *tl_pass_gate = nullptr;  // set by the passes call around its run_search
 
-int32_t run_search(asgart_index *idx, const uint64_t *chunks, int64_t n_chunks,
-                   const asgart_settings *st, int32_t shard, int32_t n_shards, bool want_csr,
-                   asgart_families *fam_out, std::vector<uint8_t> *status_out,
-                   std::vector<uint64_t> *rowoff_out, std::vector<uint64_t> *hits_out,
-                   volatile uint64_t *progress) {
-    if (!idx || !st || n_chunks < 0 || (n_chunks && !chunks)) {
+// n_passes > 1: ONE job over the probes of all passes (sts differ in reverse / complement only, n_shards == 1;
+// checked by the caller); fams: n_passes result objects, or null (the CSR surface of a single pass).
+int32_t run_search_passes(asgart_index *idx, const uint64_t *chunks, int64_t n_chunks,
+                          const asgart_settings *sts, int32_t n_passes, int32_t shard, int32_t n_shards, bool want_csr,
+                          asgart_families *const *fams, std::vector<uint8_t> *status_out,
+                          std::vector<uint64_t> *rowoff_out, std::vector<uint64_t> *hits_out,
+                          volatile uint64_t *progress) {
+    if (!idx || !sts || n_passes < 1 || n_passes > 4 || n_chunks < 0 || (n_chunks && !chunks)) {
         set_error("bad argument");
         return ASGART_E_ARG;
     }
+    const asgart_settings *const st = &sts[0];
     if (st->max_gap_size == 0) {
         // the CLI always passes gap + probe_size (reference src/bin/asgart.rs:681), never 0
         set_error("max_gap_size must be >= 1 (it includes probe_size, src/bin/asgart.rs:681)");
         return ASGART_E_ARG;
     }
-    if (n_shards < 1 || shard < 0 || shard >= n_shards) {
+    if (n_shards < 1 || shard < 0 || shard >= n_shards || (n_passes > 1 && (n_shards != 1 || want_csr || progress))) {
         set_error("bad shard %d of %d", shard, n_shards);
         return ASGART_E_ARG;
     }
-    if (idx->poisoned.load()) {
-        set_error("this index gave up waiting for the device in an earlier call (watchdog): work may still be running on its "
-                  "streams; destroy it and continue in a fresh process");
-        return ASGART_E_HIP;
-    }
+    REFUSE_POISONED(idx);
     HIP_TRY(hipSetDevice(idx->device));
     // take a free per-call context; the keys can only change while no context is in use
     int which = 0;
-    const int mode = (st->reverse ? 2 : 0) | (st->complement ? 1 : 0);
     for (;;) {
         SearchCtx &probe = idx->acquire_one(&which);
         (void)probe;
         // The presence filter and the position-sorted lists are optimisations that cost more than they save in ONE pass
         // (option lazy_aux): an orientation gets its filter at its second search, the index its lists at its second call.
-        bool want_filter, want_sap, ready;
+        bool want_sap, ready;
+        int need_filter = -1;  // an orientation of this call whose filter is due and missing
         {
             std::lock_guard<std::mutex> lk(idx->mu);
             ready = idx->k == st->probe_size;
             const bool lazy = idx->opt.lazy_aux != 0;
-            want_filter = !(idx->opt.kfilter_bits == 0 || idx->trimmed || st->probe_size > (uint64_t)kMaxKey) &&
-                          !(lazy && ready && idx->mode_calls[mode] == 0) && !(lazy && !ready);
+            for (int32_t p = 0; p < n_passes && need_filter < 0; ++p) {
+                const int mode = (sts[p].reverse ? 2 : 0) | (sts[p].complement ? 1 : 0);
+                const bool want_filter = !(idx->opt.kfilter_bits == 0 || idx->trimmed || st->probe_size > (uint64_t)kMaxKey) &&
+                                         !(lazy && ready && idx->mode_calls[mode] == 0) && !(lazy && !ready);
+                if (want_filter && !idx->d_filter[mode] && !idx->filter_off[mode]) need_filter = mode;
+            }
             want_sap = !(lazy && (!ready || idx->calls_total == 0)) && !idx->sap_tried;
-            if (ready && (!want_filter || idx->d_filter[mode] || idx->filter_off[mode]) && !(want_sap && !idx->d_sap)) {
-                ++idx->mode_calls[mode];
+            if (ready && need_filter < 0 && !(want_sap && !idx->d_sap)) {
+                for (int32_t p = 0; p < n_passes; ++p) ++idx->mode_calls[(sts[p].reverse ? 2 : 0) | (sts[p].complement ? 1 : 0)];
                 break;
             }
         }
         idx->release_one(which);
         if (!ready) RC_TRY(index_prepare(idx, st->probe_size));
         else if (want_sap && !idx->d_sap) RC_TRY(index_prepare_sap(idx, st->probe_size));
-        else RC_TRY(index_prepare_filter(idx, st->probe_size, mode));
+        else RC_TRY(index_prepare_filter(idx, st->probe_size, need_filter));
     }
     SearchCtx &cx = idx->ctx[which];
     cx.progress = progress;
-    cx.gate = tl_pass_gate;
+    cx.gate = n_passes == 1 ? tl_pass_gate : nullptr;
     int32_t rc;
     if (idx->wide)
-        rc = run_search_t<uint64_t>(idx, cx, chunks, n_chunks, st, shard, n_shards, want_csr, fam_out,
+        rc = run_search_t<uint64_t>(idx, cx, chunks, n_chunks, sts, n_passes, shard, n_shards, want_csr, fams,
                                     status_out, rowoff_out, hits_out);
     else
-        rc = run_search_t<uint32_t>(idx, cx, chunks, n_chunks, st, shard, n_shards, want_csr, fam_out,
+        rc = run_search_t<uint32_t>(idx, cx, chunks, n_chunks, sts, n_passes, shard, n_shards, want_csr, fams,
                                     status_out, rowoff_out, hits_out);
     cx.progress = nullptr;
     cx.gate = nullptr;
@@ -1127,15 +1175,26 @@ int32_t run_search(asgart_index *idx, const uint64_t *chunks, int64_t n_chunks,
         std::lock_guard<std::mutex> lk(idx->mu);
         ++idx->calls_total;
     }
-    if (rc == 0 && fam_out && n_shards == 1) {
-        // what asgart_search_duplications_passes orders by: the shortest extension seen for the orientation (a call
-        // that shared the chip with another one measures longer, and the order must not flip because of that)
+    if (rc == 0 && fams && n_shards == 1 && n_passes == 1) {
+        // what asgart_search_duplications_passes orders by when it pipelines single-pass calls: the shortest extension seen
+        // for the orientation (a call that shared the chip with another one measures longer, and the order must not flip
+        // because of that)
         std::lock_guard<std::mutex> lk(idx->mu);
         double &t = idx->tail_ms[(st->reverse ? 2 : 0) | (st->complement ? 1 : 0)];
         t = t < 0.0 ? cx.stats.ms_extend : std::min(t, cx.stats.ms_extend);
     }
     idx->release_one(which);
     return rc;
+}
+
+int32_t run_search(asgart_index *idx, const uint64_t *chunks, int64_t n_chunks,
+                   const asgart_settings *st, int32_t shard, int32_t n_shards, bool want_csr,
+                   asgart_families *fam_out, std::vector<uint8_t> *status_out,
+                   std::vector<uint64_t> *rowoff_out, std::vector<uint64_t> *hits_out,
+                   volatile uint64_t *progress) {
+    asgart_families *one[1] = {fam_out};
+    return run_search_passes(idx, chunks, n_chunks, st, 1, shard, n_shards, want_csr, fam_out ? one : nullptr, status_out,
+                             rowoff_out, hits_out, progress);
 }
 
 }  // namespace asgart
@@ -1279,6 +1338,52 @@ int32_t asgart_search_duplications_passes_shard(asgart_index *idx, const uint64_
         return ASGART_E_ARG;
     }
     if (n_passes == 0) return 0;
+    // ---- the passes as ONE job (option fuse_passes, default) ------------------------------------------------------------
+    // Passes that differ in orientation only -- the direct and the -RC run of one genome, what the call exists for --
+    // share one probe sequence (pass 0's chunks, then pass 1's, ...: chunk order inside each pass as in
+    // src/bin/asgart.rs:201-253): ONE probe search, scan, hit-row fill and placement over all their probes at full chip
+    // rate, ONE launch per extension tier over the merged cost-sorted segment list -- every pass's longest segments
+    // start at t = 0 of the extension on compute units of their own.  (Pipelined as two calls on two contexts -- below,
+    // kept for sharded calls and passes with different settings -- the second pass's front crawled behind the first
+    // one's persistent extension workgroups: 117 ms instead of 28 at GRCh38 size.)
+    {
+        bool fusable = idx->opt.fuse_passes != 0 && n_passes >= 2 && n_passes <= 4 && n_shards == 1;
+        for (int32_t j = 1; fusable && j < n_passes; ++j)
+            fusable = settings[j].probe_size == settings[0].probe_size && settings[j].max_gap_size == settings[0].max_gap_size &&
+                      settings[j].min_duplication_length == settings[0].min_duplication_length &&
+                      settings[j].max_cardinality == settings[0].max_cardinality;
+        if (fusable) {  // (2^32 probes per call: the passes together)
+            const uint64_t k = settings[0].probe_size, step = k / 2;
+            uint64_t P1 = 0;
+            for (int64_t c = 0; c < n_chunks && step; ++c)
+                P1 += probes_in_chunk(chunks[2 * c + 1], k, step, settings[0].min_duplication_length);
+            fusable = step && P1 * (uint64_t)n_passes < 0xFFFFFF00ull;
+        }
+        if (fusable) {
+            std::lock_guard<std::mutex> pass_lock(idx->pass_mu);
+            struct Owns {
+                Owns() { asgart::tl_owns_pass_mu = true; }
+                ~Owns() { asgart::tl_owns_pass_mu = false; }
+            } owns;
+            std::vector<asgart_families *> fams((size_t)n_passes, nullptr);
+            for (auto &f : fams) {
+                f = new (std::nothrow) asgart_families();
+                if (!f) {
+                    for (auto *g : fams) delete g;
+                    set_error("out of host memory");
+                    return ASGART_E_OOM;
+                }
+            }
+            const int32_t rc = run_search_passes(idx, chunks, n_chunks, settings, n_passes, 0, 1, false, fams.data(), nullptr,
+                                                 nullptr, nullptr, nullptr);
+            if (rc != 0) {
+                for (auto *f : fams) delete f;
+                return rc;
+            }
+            for (int32_t j = 0; j < n_passes; ++j) out[j] = fams[(size_t)j];
+            return 0;
+        }
+    }
     // issue order: longest extension first (what is known from earlier calls; an orientation never run yet
     // counts as longest, reversed ones ahead of the others: their tandem arrays are walked against the
     // whole text instead of the part behind the probe)
@@ -1313,6 +1418,10 @@ int32_t asgart_search_duplications_passes_shard(asgart_index *idx, const uint64_
     };
     // the first pass runs on the calling thread, the others on the index's own worker threads
     std::lock_guard<std::mutex> pass_lock(idx->pass_mu);
+    struct Owns {  // (index_prepare's prewarm, reached from body(0) below, must not try to lock it again)
+        Owns() { asgart::tl_owns_pass_mu = true; }
+        ~Owns() { asgart::tl_owns_pass_mu = false; }
+    } owns;
     while ((int32_t)idx->pass_workers.size() + 1 < n_passes) idx->pass_workers.emplace_back(new asgart::PassWorker());
     auto body = [&](int32_t p) {
             if (p > 0)
@@ -1402,11 +1511,17 @@ int32_t asgart_get_stats(asgart_index *idx, uint32_t flags, asgart_stats *out) {
     SearchCtx &cx = idx->ctx[sel >= 1 && sel <= kNumCtx ? sel - 1 : idx->last_ctx];
     int32_t rc = [&]() -> int32_t {
         if ((flags & ASGART_STATS_YARDSTICK) && cx.has_last && cx.last_P) {
+            REFUSE_POISONED(idx);
             HIP_TRY(hipSetDevice(idx->device));
             unsigned long long *d_ctr = cx.ws.counters.as<unsigned long long>();
             hipStream_t s = cx.stream;
             HIP_TRY(hipMemsetAsync(d_ctr + CT_BISECT, 0, 8, s));
-            const RunParams &rp = cx.last_rp;
+            RunParams rp = cx.last_rp;
+            for (uint32_t p = 0; p < rp.n_passes && p < 4u; ++p) {  // (the filters as they are now)
+                rp.flt[p] = idx->d_filter[rp.mode_of_pass(p)];
+                rp.pbits[p] = idx->opt.posbits ? idx->d_pbits[rp.mode_of_pass(p)] : nullptr;
+            }
+            rp.flt_bits = idx->filter_bits;
             const unsigned g = grid_for(rp.g_hi - rp.g_lo);
             if (idx->wide)
                 yardstick_kernel<uint64_t><<<g, 256, 0, s>>>(idx->view<uint64_t>(), rp,
@@ -1420,14 +1535,10 @@ int32_t asgart_get_stats(asgart_index *idx, uint32_t flags, asgart_stats *out) {
             // call left in the workspace
             HIP_TRY(hipMemsetAsync(d_ctr + CT_ALG_BYTES, 0, 16, s));
             HIP_TRY(hipMemsetAsync(d_ctr + CT_ALG_BYTES16, 0, 8, s));
-            const int mode = (rp.reverse ? 2 : 0) | (rp.complement ? 1 : 0);
             const unsigned gp = grid_for(rp.g_hi - rp.g_lo, kProbeBlock);
             auto account = [&](auto slot_tag) {
                 using SlotT = decltype(slot_tag);
                 IndexView<SlotT> ix = idx->view<SlotT>();
-                ix.flt = idx->d_filter[mode];
-                ix.flt_bits = idx->filter_bits;
-                ix.pbits = idx->opt.posbits ? idx->d_pbits[mode] : nullptr;
                 probe_count_kernel<SlotT, true><<<gp, kProbeThreads, 0, s>>>(
                     ix, rp, nullptr, nullptr, nullptr, nullptr, nullptr, d_ctr);
                 big_count_kernel<SlotT, true><<<2048, 256, 0, s>>>(
@@ -1441,10 +1552,9 @@ int32_t asgart_get_stats(asgart_index *idx, uint32_t flags, asgart_stats *out) {
             if (idx->wide) account(uint64_t{}); else account(uint32_t{});
             HIP_TRY(hipGetLastError());
             unsigned long long v = 0, ab[2] = {0, 0}, a16 = 0;
-            HIP_TRY(hipMemcpyAsync(&v, d_ctr + CT_BISECT, 8, hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipMemcpyAsync(ab, d_ctr + CT_ALG_BYTES, 16, hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipMemcpyAsync(&a16, d_ctr + CT_ALG_BYTES16, 8, hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
+            HIP_TRY(read_back(&v, d_ctr + CT_BISECT, 8, s));  // (polled drain first: common.hpp)
+            HIP_TRY(read_back(ab, d_ctr + CT_ALG_BYTES, 16, s));
+            HIP_TRY(read_back(&a16, d_ctr + CT_ALG_BYTES16, 8, s));
             cx.stats.bisect_steps = v;
             cx.stats.search_bytes = ab[0];
             cx.stats.probes_filter_rejected = ab[1];

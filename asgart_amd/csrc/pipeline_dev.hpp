@@ -160,12 +160,13 @@ __global__ __launch_bounds__(kProbeThreads) void probe_count_kernel(IndexView<Sl
     const bool uniform = rp.ch.pbase[c0 + 1] > g_last && k <= kMaxKey;
     uint32_t n_rej = 0;
     // one probe's lookup: SA interval, filtered count of a small interval (large ones are marked for the wave kernels)
-    auto lookup = [&](uint32_t g_, uint64_t q_, uint64_t q2_, uint64_t i_, uint64_t s_, uint64_t L_) {
+    auto lookup = [&](uint32_t g_, uint64_t q_, uint64_t q2_, uint64_t i_, uint64_t s_, uint64_t L_, uint32_t md_) {
+        const bool reverse = (md_ & 2u) != 0u, complement = (md_ & 1u) != 0u;
         uint64_t lo, hi;
         ProbeRef pr;  // (read only by probes of more than 42 bases)
-        pr.p = rp.reverse ? ix.text + s_ + L_ - 1u - i_ : ix.text + s_ + i_;
-        pr.dir = rp.reverse ? -1 : 1;
-        pr.comp = rp.complement != 0;
+        pr.p = reverse ? ix.text + s_ + L_ - 1u - i_ : ix.text + s_ + i_;
+        pr.dir = reverse ? -1 : 1;
+        pr.comp = complement;
         const bool all_occurrences = kmer_range(ix, q_, q2_, pr, lo, hi, cb);
         const uint64_t raw = hi - lo;
         if (!COUNT) {
@@ -178,10 +179,10 @@ __global__ __launch_bounds__(kProbeThreads) void probe_count_kernel(IndexView<Sl
             // Direct pass: the needle is the text itself, so the probe's own position is one of
             // the occurrences; a single occurrence is that one, and the filter (x > i + s)
             // drops it -- no need to fetch the suffix-array entry.
-            const bool only_self = all_occurrences && raw == 1 && !rp.reverse && !rp.complement;
+            const bool only_self = all_occurrences && raw == 1 && md_ == 0u;
             for (uint64_t r = lo; r < hi && !only_self; ++r) {
                 cb.rd(sizeof(SlotT));
-                cnt += keep_hit(ix.sa[r], i_, s_, L_, rp.reverse) ? 1u : 0u;
+                cnt += keep_hit(ix.sa[r], i_, s_, L_, reverse) ? 1u : 0u;
             }
             if (!COUNT) p_filt[g_] = cnt > rp.C ? kSkipCard : cnt;
             cb.wr(4);
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(kProbeThreads) void probe_count_kernel(IndexView<Sl
         }
     };
     // a probe the presence filter (or its first base) answers: what is written for it; -> true: it has to be looked up
-    auto screen = [&](uint32_t g_, uint32_t first_, bool pass_) {
+    auto screen = [&](uint32_t g_, uint32_t first_, bool pass_, uint32_t md_) {
         if (first_ == 4u) {  // needle[i] == 'N'  (automaton.rs:100-102)
             if (!COUNT) p_filt[g_] = kSkipN;
             cb.wr(4);
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(kProbeThreads) void probe_count_kernel(IndexView<Sl
         if (!pass_) {
             // no hit possible: in the direct pass the interval is the probe itself
             if (!COUNT) {
-                p_raw[g_] = (!rp.reverse && !rp.complement) ? 1u : 0u;
+                p_raw[g_] = md_ == 0u ? 1u : 0u;
                 p_filt[g_] = 0u;
             }
             cb.wr(8);
@@ -215,14 +216,17 @@ __global__ __launch_bounds__(kProbeThreads) void probe_count_kernel(IndexView<Sl
         return true;
     };
     if (uniform) {
+        const uint32_t pass0 = rp.pass_of(c0), md = rp.mode_of_pass(pass0);  // (the orientation of the chunk's pass)
+        const bool reverse = (md & 2u) != 0u, complement = (md & 1u) != 0u;
+        const uint64_t *const pbits = rp.pbits[pass0], *const flt = rp.flt[pass0];
         const uint64_t s = rp.ch.start[c0], L = rp.ch.len[c0];
         const uint64_t i0 = (uint64_t)(gb - rp.ch.pbase[c0] + 1) * (uint64_t)H;  // needle offset of probe gb
         const int n_half = kProbeBlock + 2;
         // text positions of half h, base j:  direct  b0 + h*H + j ;  reversed  e0 - h*H - j
         const long long b0 = (long long)(s + i0), e0 = (long long)(s + L - 1u - i0);
-        const long long w_lo = rp.reverse ? e0 - (long long)n_half * H + 1 : b0;
+        const long long w_lo = reverse ? e0 - (long long)n_half * H + 1 : b0;
         const long long a_lo = w_lo & ~15ll;  // floor to 16 (two's complement: also for negatives)
-        const long long w_hi = rp.reverse ? e0 : b0 + (long long)n_half * H - 1;  // inclusive
+        const long long w_hi = reverse ? e0 : b0 + (long long)n_half * H - 1;  // inclusive
         const uint32_t n_load = (uint32_t)((w_hi - a_lo) / 16 + 1);  // <= kWinBytes / 16
         for (uint32_t t = lane; t < n_load; t += kProbeThreads) {   // (three rounds, all in flight together)
             const long long a = a_lo + 16ll * t;
@@ -234,9 +238,9 @@ __global__ __launch_bounds__(kProbeThreads) void probe_count_kernel(IndexView<Sl
             *reinterpret_cast<uint4 *>(s_text + 16u * t) = v;
         }
         long long pb_lo = 0;  // first bit held by s_pb
-        if (ix.pbits) {
+        if (pbits) {
             // text positions the probes cover: direct  s + i0 + t H ;  reversed  s + L - i0 - k - t H
-            const long long p_first = rp.reverse ? (long long)(s + L - i0) - k - (long long)(kProbeBlock - 1) * H
+            const long long p_first = reverse ? (long long)(s + L - i0) - k - (long long)(kProbeBlock - 1) * H
                                                  : (long long)(s + i0);
             const long long byte_lo = (p_first >> 7) * 16;  // (floor: also for the negatives of the idle lanes)
             pb_lo = byte_lo * 8;
@@ -246,7 +250,7 @@ __global__ __launch_bounds__(kProbeThreads) void probe_count_kernel(IndexView<Sl
                 const long long a = byte_lo + 16ll * lane;
                 uint4 v = make_uint4(~0u, ~0u, ~0u, ~0u);
                 if (a >= 0 && (uint64_t)a + 16u <= ((ix.n + 63u) / 64u) * 8u + 512u) {  // (the allocation is padded)
-                    v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(ix.pbits) + a);
+                    v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(pbits) + a);
                     cb.rd16();
                 }
                 *reinterpret_cast<uint4 *>(&s_pb[4u * lane]) = v;
@@ -254,11 +258,11 @@ __global__ __launch_bounds__(kProbeThreads) void probe_count_kernel(IndexView<Sl
         }
         __syncthreads();  // (one wave: the barrier orders its own LDS traffic)
         for (uint32_t h = lane; h < (uint32_t)n_half; h += kProbeThreads) {
-            const long long p0 = rp.reverse ? (e0 - a_lo) - (long long)h * H : (b0 - a_lo) + (long long)h * H;
+            const long long p0 = reverse ? (e0 - a_lo) - (long long)h * H : (b0 - a_lo) + (long long)h * H;
             uint32_t v = 0;
             for (int j = 0; j < H; ++j) {
-                uint32_t c = base_code(s_text[rp.reverse ? p0 - j : p0 + j]);
-                if (rp.complement) c = comp_code(c);
+                uint32_t c = base_code(s_text[reverse ? p0 - j : p0 + j]);
+                if (complement) c = comp_code(c);
                 v = (v << 3) | c;
             }
             s_half[h] = v;
@@ -285,16 +289,16 @@ __global__ __launch_bounds__(kProbeThreads) void probe_count_kernel(IndexView<Sl
                 bool pass = true;
                 if (first != 4u) {
                     const uint64_t i = i0 + (uint64_t)t * (uint64_t)H;
-                    if (ix.pbits) {  // the filter's answer, by the text position the probe covers
-                        const long long p = rp.reverse ? (long long)(s + L - i) - k : (long long)(s + i);
+                    if (pbits) {  // the filter's answer, by the text position the probe covers
+                        const long long p = reverse ? (long long)(s + L - i) - k : (long long)(s + i);
                         const uint32_t b = (uint32_t)(p - pb_lo);
                         pass = (s_pb[b >> 5] >> (b & 31u)) & 1u;
-                    } else if (ix.flt && !is_tail_corner(ix, q)) {
+                    } else if (flt && !is_tail_corner(ix, q)) {
                         cb.rd(8);
-                        pass = filter_test(ix.flt, ix.flt_bits, q);
+                        pass = filter_test(flt, rp.flt_bits, q);
                     }
                 }
-                survivor = screen(g, first, pass);
+                survivor = screen(g, first, pass, md);
             }
             const unsigned long long sm = __ballot(survivor);
             if (survivor) s_surv[n_surv + (uint32_t)__popcll(sm & lt_mask)] = (uint8_t)t;
@@ -303,7 +307,7 @@ __global__ __launch_bounds__(kProbeThreads) void probe_count_kernel(IndexView<Sl
         __syncthreads();
         for (uint32_t j = lane; j < n_surv; j += kProbeThreads) {
             const uint32_t t = s_surv[j];
-            lookup(gb + t, key_of(t), 0ull, i0 + (uint64_t)t * (uint64_t)H, s, L);
+            lookup(gb + t, key_of(t), 0ull, i0 + (uint64_t)t * (uint64_t)H, s, L, md);
         }
     } else {
         // the tile straddles a chunk boundary (or the probes are longer than one key word): every probe on its own
@@ -312,24 +316,27 @@ __global__ __launch_bounds__(kProbeThreads) void probe_count_kernel(IndexView<Sl
             const uint32_t g = gb + lane + (uint32_t)u * kProbeThreads;
             if (g >= rp.g_hi) continue;
             const int c = chunk_of(rp.ch, g);
+            const uint32_t pass_c = rp.pass_of(c), md = rp.mode_of_pass(pass_c);
+            const bool reverse = (md & 2u) != 0u, complement = (md & 1u) != 0u;
+            const uint64_t *const pbits = rp.pbits[pass_c], *const flt = rp.flt[pass_c];
             const uint64_t s = rp.ch.start[c], L = rp.ch.len[c];
             const uint64_t i = (uint64_t)(g - rp.ch.pbase[c] + 1) * (uint64_t)H;
             uint32_t first = 0;
             uint64_t q2 = 0;
-            const uint64_t q = probe_key(ix.text, s, L, i, k, rp.reverse, rp.complement, &first, &q2);
+            const uint64_t q = probe_key(ix.text, s, L, i, k, reverse, complement, &first, &q2);
             cb.rd((uint32_t)k);
             bool pass = true;
             if (first != 4u) {
-                if (ix.pbits) {
-                    const long long p = rp.reverse ? (long long)(s + L - i) - k : (long long)(s + i);
+                if (pbits) {
+                    const long long p = reverse ? (long long)(s + L - i) - k : (long long)(s + i);
                     cb.rd(8);
-                    pass = (ix.pbits[(uint64_t)p >> 6] >> ((uint64_t)p & 63u)) & 1ull;
-                } else if (ix.flt && !is_tail_corner(ix, q)) {
+                    pass = (pbits[(uint64_t)p >> 6] >> ((uint64_t)p & 63u)) & 1ull;
+                } else if (flt && !is_tail_corner(ix, q)) {
                     cb.rd(8);
-                    pass = filter_test(ix.flt, ix.flt_bits, q);
+                    pass = filter_test(flt, rp.flt_bits, q);
                 }
             }
-            if (screen(g, first, pass)) lookup(g, q, q2, i, s, L);
+            if (screen(g, first, pass, md)) lookup(g, q, q2, i, s, L, md);
         }
     }
     if constexpr (COUNT) {
@@ -402,8 +409,13 @@ __global__ __launch_bounds__(kCollectBlock) void collect_pending_kernel(RunParam
             }
         }
         __syncthreads();
-        if (s_cnt[0] > (uint32_t)(kCollectCap - kCollectTile)) flush(0, big_list, CT_BIG);
-        if (s_cnt[1] > (uint32_t)(kCollectCap - kCollectTile)) flush(1, rank_list, CT_RANK);
+        // (the decision is taken from a snapshot every thread has read BEFORE anyone may add the next tile's entries:
+        // a wave that ran ahead into the next tile's atomics could otherwise push a slower wave's reading over the
+        // threshold and send only that wave into flush() and its barriers)
+        const uint32_t c0 = s_cnt[0], c1 = s_cnt[1];
+        __syncthreads();
+        if (c0 > (uint32_t)(kCollectCap - kCollectTile)) flush(0, big_list, CT_BIG);
+        if (c1 > (uint32_t)(kCollectCap - kCollectTile)) flush(1, rank_list, CT_RANK);
     }
     flush(0, big_list, CT_BIG);
     flush(1, rank_list, CT_RANK);
@@ -449,7 +461,7 @@ __global__ __launch_bounds__(256) void rank_count_kernel(IndexView<SlotT> ix, Ru
                 return lo;
             };
             uint64_t cnt;
-            if (!rp.reverse) {
+            if (!(rp.mode_of(c) & 2u)) {
                 cnt = R - first_ge(i + s + 1u);  // keep_hit: x > i + s
             } else {
                 const uint64_t t = s + L - i;  // keep_hit: x != i && x >= s + L - i
@@ -503,11 +515,12 @@ __global__ __launch_bounds__(256) void big_count_kernel(IndexView<SlotT> ix, Run
     for (uint64_t e0 = wave * 64u; e0 < n_big; e0 += n_waves * 64u) {
         const uint32_t np = (uint32_t)min((uint64_t)64, n_big - e0);
         // lane l sets up probe e0 + l
-        uint32_t g = 0;
+        uint32_t g = 0, md = 0;
         unsigned long long s = 0, L = 0, i = 0, lo = 0, hi = 0;
         if (lane < np) {
             g = big_list[e0 + lane];
             const int c = chunk_of(rp.ch, g);
+            md = rp.mode_of(c);
             s = rp.ch.start[c];
             L = rp.ch.len[c];
             i = (unsigned long long)(g - rp.ch.pbase[c] + 1) * (unsigned long long)rp.step;
@@ -529,6 +542,7 @@ __global__ __launch_bounds__(256) void big_count_kernel(IndexView<SlotT> ix, Run
         for (uint32_t p = 0; p < np; ++p) {
             const unsigned long long lo_p = lane_of(lo, p), hi_p = lane_of(hi, p), i_p = lane_of(i, p),
                                      s_p = lane_of(s, p), L_p = lane_of(L, p);
+            const bool rev_p = (lane_of(md, p) & 2u) != 0u;
             SlotT x[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) x[u] = xn[u];
@@ -546,7 +560,7 @@ __global__ __launch_bounds__(256) void big_count_kernel(IndexView<SlotT> ix, Run
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const unsigned long long r = base + 64u * u + lane;
-                    const bool keep = r < hi_p && keep_hit(x[u], i_p, s_p, L_p, rp.reverse);
+                    const bool keep = r < hi_p && keep_hit(x[u], i_p, s_p, L_p, rev_p);
                     cnt += __popcll(__ballot(keep));
                 }
                 base += 256;
@@ -867,7 +881,7 @@ __global__ __launch_bounds__(256) void fill_small_kernel(IndexView<SlotT> ix, Ru
     unsigned long long w = row_off[g];
     for (uint32_t r = 0; r < raw; ++r) {
         const SlotT x = ix.sa[lo + r];
-        if (keep_hit(x, i, s, L, rp.reverse)) hits[w++] = x;
+        if (keep_hit(x, i, s, L, (rp.mode_of(c) & 2u) != 0u)) hits[w++] = x;
     }
 }
 
@@ -890,6 +904,7 @@ __global__ __launch_bounds__(256) void fill_big_kernel(IndexView<SlotT> ix, RunP
     for (uint64_t e0 = wave * 64u; e0 < n_big; e0 += n_waves * 64u) {
         const uint32_t np = (uint32_t)min((uint64_t)64, n_big - e0);
         unsigned long long s = 0, L = 0, i = 0, lo = 0, hi = 0, w0 = 0;
+        uint32_t md = 0;
         bool want = false;
         if (lane < np) {
             const uint32_t g = big_list[e0 + lane];
@@ -897,6 +912,7 @@ __global__ __launch_bounds__(256) void fill_big_kernel(IndexView<SlotT> ix, RunP
             want = f != 0 && f < kPending;  // skipped / empty rows have nothing to fill
             if (want) {
                 const int c = chunk_of(rp.ch, g);
+                md = rp.mode_of(c);
                 s = rp.ch.start[c];
                 L = rp.ch.len[c];
                 i = (unsigned long long)(g - rp.ch.pbase[c] + 1) * (unsigned long long)rp.step;
@@ -911,6 +927,7 @@ __global__ __launch_bounds__(256) void fill_big_kernel(IndexView<SlotT> ix, RunP
             todo &= todo - 1;
             const unsigned long long lo_p = lane_of(lo, p), hi_p = lane_of(hi, p), i_p = lane_of(i, p),
                                      s_p = lane_of(s, p), L_p = lane_of(L, p);
+            const bool rev_p = (lane_of(md, p) & 2u) != 0u;
             unsigned long long w = lane_of(w0, p);
             for (unsigned long long base = lo_p; base < hi_p; base += 256) {  // four slices in flight per round trip
                 SlotT x[4];
@@ -922,7 +939,7 @@ __global__ __launch_bounds__(256) void fill_big_kernel(IndexView<SlotT> ix, RunP
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const unsigned long long r = base + 64u * u + lane;
-                    const bool keep = r < hi_p && keep_hit(x[u], i_p, s_p, L_p, rp.reverse);
+                    const bool keep = r < hi_p && keep_hit(x[u], i_p, s_p, L_p, rev_p);
                     const unsigned long long m = __ballot(keep);
                     if (keep) hits[w + __popcll(m & lt_mask)] = x[u];
                     w += __popcll(m);
@@ -1026,6 +1043,7 @@ struct ExtParams {
     uint32_t fast_bsh;                    // K6: log2 of the bucket width beyond the smallest power of two >= G + k
     uint32_t heavy_cap;                   // K4b MODE 2 (tier 7): arm slots per workgroup in its HBM slice
     uint32_t solo_hits;                   // K6: probes with up to this many hits may run on wave 0 alone (0: never)
+    uint32_t k8_delay;                    // K8 (tests): cycles the ranking wave waits before it reads the free counts
     unsigned long long *ctr;
     unsigned long long *hb;               // heartbeat slots of this launch's tier (pinned host memory; null: none)
 };
@@ -1148,6 +1166,7 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
         if (lane == 0 && j == 0) heartbeat(P, g0, 0u);  // (once per fetched group of segments)
         const int c = chunk_of_uniform(rp.ch, g0);
         const uint64_t cs = rp.ch.start[c], cl = rp.ch.len[c];
+        const bool seg_rev = (rp.mode_of(c) & 2u) != 0u;  // (the orientation of the chunk's pass)
         const uint32_t pb = rp.ch.pbase[c];
         const uint32_t chunk_end = rp.ch.pbase[c + 1];
         const uint32_t g_end = min(chunk_end, rp.g_hi);
@@ -1175,7 +1194,7 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
                     r.create_seq = seq;
                     r.pad = 0;
                     // left fix-up, src/bin/asgart.rs:229-237
-                    r.sd.left = rp.reverse ? cs + cl - (uint64_t)ls - ll : (uint64_t)ls + cs;
+                    r.sd.left = seg_rev ? cs + cl - (uint64_t)ls - ll : (uint64_t)ls + cs;
                     r.sd.right = rs;
                     r.sd.left_length = ll;
                     r.sd.right_length = (uint64_t)re - (uint64_t)rs;
@@ -2112,6 +2131,7 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
         PROF_SEG_BEGIN();
         const int c = chunk_of_uniform(rp.ch, g0);
         const uint64_t cs = rp.ch.start[c], cl = rp.ch.len[c];
+        const bool seg_rev = (rp.mode_of(c) & 2u) != 0u;  // (the orientation of the chunk's pass)
         const uint32_t pb = rp.ch.pbase[c];
         const uint32_t chunk_end = rp.ch.pbase[c + 1];
         const uint32_t g_end = min(chunk_end, rp.g_hi);
@@ -2133,7 +2153,7 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
                     r.fam_seq = fam_seq;
                     r.create_seq = seq;
                     r.pad = 0;
-                    r.sd.left = rp.reverse ? cs + cl - (uint64_t)ls - ll : (uint64_t)ls + cs;
+                    r.sd.left = seg_rev ? cs + cl - (uint64_t)ls - ll : (uint64_t)ls + cs;
                     r.sd.right = rs;
                     r.sd.left_length = ll;
                     r.sd.right_length = (uint64_t)re - (uint64_t)rs;
@@ -2625,6 +2645,7 @@ __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
         PROF_SEG_BEGIN();
         const int c = chunk_of_uniform(rp.ch, g0);
         const uint64_t cs = rp.ch.start[c], cl = rp.ch.len[c];
+        const bool seg_rev = (rp.mode_of(c) & 2u) != 0u;  // (the orientation of the chunk's pass)
         const uint32_t pb = rp.ch.pbase[c];
         const uint32_t chunk_end = rp.ch.pbase[c + 1];
         const uint32_t g_end = min(chunk_end, rp.g_hi);
@@ -2645,7 +2666,7 @@ __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
                     r.fam_seq = fam_seq;
                     r.create_seq = seq;
                     r.pad = 0;
-                    r.sd.left = rp.reverse ? cs + cl - (uint64_t)ls - ll : (uint64_t)ls + cs;
+                    r.sd.left = seg_rev ? cs + cl - (uint64_t)ls - ll : (uint64_t)ls + cs;
                     r.sd.right = rs;
                     r.sd.left_length = ll;
                     r.sd.right_length = (uint64_t)re - (uint64_t)rs;
@@ -3069,7 +3090,8 @@ __global__ __launch_bounds__(256) void yardstick_kernel(IndexView<SlotT> ix, Run
         const uint64_t s = rp.ch.start[c], L = rp.ch.len[c];
         const uint64_t i = (uint64_t)(g - rp.ch.pbase[c] + 1) * (uint64_t)rp.step;
         uint32_t first;
-        const uint64_t q = probe_key(ix.text, s, L, i, rp.k, rp.reverse, rp.complement, &first);
+        const uint32_t md = rp.mode_of(c);
+        const uint64_t q = probe_key(ix.text, s, L, i, rp.k, (md & 2u) != 0u, (md & 1u) != 0u, &first);
         uint32_t c8;
         if (cache8_index((uint32_t)(q >> (3 * (ix.kk - kCacheLen))), c8)) {
             const uint64_t b = (uint64_t)ix.c8hi[c8] - (uint64_t)ix.c8lo[c8];

@@ -131,6 +131,10 @@ extern "C" int32_t asgart_post_process(asgart_index *idx, const uint64_t *fam_of
     // ---- FilterNs: N counts of every arm on the GPU ----------------------------------------------------------------
     std::vector<unsigned long long> n_cnt((size_t)n_sd * 2);
     {
+        if (idx->poisoned.load()) {
+            delete res;
+            REFUSE_POISONED(idx);
+        }
         HIP_TRY(hipSetDevice(idx->device));
         idx->acquire_all();  // (the text must stay where it is)
         struct Unlock {
@@ -147,7 +151,7 @@ extern "C" int32_t asgart_post_process(asgart_index *idx, const uint64_t *fam_of
             const unsigned grid = (unsigned)std::min<uint64_t>((n_arms + 3) / 4, 256ull * 32ull);
             n_count_kernel<<<grid, 256, 0, s>>>(idx->d_text, n, d_sds.as<asgart_proto_sd>(), n_arms, d_out.as<unsigned long long>());
             HIP_TRY(hipGetLastError());
-            HIP_TRY(hipMemcpyAsync(n_cnt.data(), d_out.p, (size_t)n_arms * 8, hipMemcpyDeviceToHost, s));
+            HIP_TRY(read_back(n_cnt.data(), d_out.p, (size_t)n_arms * 8, s));
             HIP_TRY(stream_sync(s));
             return 0;
         }();

@@ -221,7 +221,7 @@ int32_t build_t(const uint8_t *d_text, int64_t n_, IdxT *d_sa, bool dna, hipStre
                 HIP_TRY(rocprim::select(temp.p, bytes, slots, tied, outb.as<IdxT>(), d_count, (size_t)m, s));
             }
             size_t h_count = 0;
-            HIP_TRY(hipMemcpyAsync(&h_count, d_count, sizeof(size_t), hipMemcpyDeviceToHost, s));
+            HIP_TRY(read_back(&h_count, d_count, sizeof(size_t), s));
             HIP_TRY(stream_sync(s));
             if (h_count == 0) break;
             if (h >= n) {
@@ -364,7 +364,7 @@ int32_t build_wide(const uint8_t *d_text, int64_t n_, uint64_t *d_sa, bool dna, 
         if (blocks > 4096) blocks = 4096;
         byte_histogram_for_sa<<<blocks, 256, 0, s>>>(d_text, n, hist_b.as<unsigned long long>());
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(hist, hist_b.p, 256 * 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(read_back(hist, hist_b.p, 256 * 8, s));
         HIP_TRY(stream_sync(s));
         std::vector<int> syms;
         for (int c = 0; c < 256; ++c)
@@ -381,7 +381,7 @@ int32_t build_wide(const uint8_t *d_text, int64_t n_, uint64_t *d_sa, bool dna, 
             HIP_TRY(hipMemsetAsync(hist_b.p, 0, sizeof(hist), s));
             pair_histogram_kernel<<<blocks, 256, 0, s>>>(d_text, n, code_b.as<uint8_t>(), S, hist_b.as<unsigned long long>());
             HIP_TRY(hipGetLastError());
-            HIP_TRY(hipMemcpyAsync(hist, hist_b.p, (size_t)S * (S + 1) * 8, hipMemcpyDeviceToHost, s));
+            HIP_TRY(read_back(hist, hist_b.p, (size_t)S * (S + 1) * 8, s));
             HIP_TRY(stream_sync(s));
             for (int a = 0; a < S; ++a)
                 for (int b = 0; b <= S; ++b)   // b == 0: the one-byte suffix, sorts first
@@ -439,7 +439,7 @@ int32_t build_wide(const uint8_t *d_text, int64_t n_, uint64_t *d_sa, bool dna, 
             RC_TRY(temp.reserve(bytes));
             HIP_TRY(rocprim::select(temp.p, bytes, it, tied, out_b.as<uint64_t>(), d_count, (size_t)cnt, s));
             size_t h_count = 0;
-            HIP_TRY(hipMemcpyAsync(&h_count, d_count, sizeof(size_t), hipMemcpyDeviceToHost, s));
+            HIP_TRY(read_back(&h_count, d_count, sizeof(size_t), s));
             HIP_TRY(stream_sync(s));
             if (h_count) {
                 offset_slots_kernel<<<grid_for(h_count), 256, 0, s>>>(out_b.as<uint64_t>(), h_count, slot_base);
@@ -467,7 +467,7 @@ int32_t build_wide(const uint8_t *d_text, int64_t n_, uint64_t *d_sa, bool dna, 
                 if (end < m) {
                     group_end_kernel<<<1, 1, 0, s>>>(list, d_sa, rank, m, end, reinterpret_cast<uint64_t *>(d_count));
                     HIP_TRY(hipGetLastError());
-                    HIP_TRY(hipMemcpyAsync(&end, d_count, 8, hipMemcpyDeviceToHost, s));
+                    HIP_TRY(read_back(&end, d_count, 8, s));
                     HIP_TRY(stream_sync(s));
                 }
                 const uint64_t bm = end - done;
@@ -510,7 +510,7 @@ int32_t build_wide(const uint8_t *d_text, int64_t n_, uint64_t *d_sa, bool dna, 
                 RC_TRY(temp.reserve(bytes));
                 HIP_TRY(rocprim::select(temp.p, bytes, slots, tied, out_b.as<uint64_t>(), d_count, (size_t)bm, s));
                 size_t h_count = 0;
-                HIP_TRY(hipMemcpyAsync(&h_count, d_count, sizeof(size_t), hipMemcpyDeviceToHost, s));
+                HIP_TRY(read_back(&h_count, d_count, sizeof(size_t), s));
                 HIP_TRY(stream_sync(s));
                 // in-place compaction of the list: the survivors trail the read position
                 if (h_count) HIP_TRY(hipMemcpyAsync(list + kept, out_b.p, h_count * 8, hipMemcpyDeviceToDevice, s));
@@ -748,7 +748,7 @@ int32_t build_rank_lists_runs(const uint64_t *d_keys, const SlotT *d_sa, uint64_
             d_keys, n, w0, w1, min_run, k, b_beg.as<uint32_t>(), b_end.as<uint32_t>(), b_ctr.as<unsigned long long>());
         HIP_TRY(hipGetLastError());
         unsigned long long h[2] = {0, 0};
-        HIP_TRY(hipMemcpyAsync(h, b_ctr.p, 16, hipMemcpyDeviceToHost, s));
+        HIP_TRY(read_back(h, b_ctr.p, 16, s));
         HIP_TRY(stream_sync(s));
         if (!h[0]) continue;
         if (h[1] >= 0xFFFFFFFFull) {
@@ -793,7 +793,7 @@ extern "C" int32_t asgart_sa_build64(const uint8_t *T, int64_t *SA, int64_t n) {
         HIP_TRY(hipMemcpyAsync(text.p, T, (size_t)n, hipMemcpyHostToDevice, s));
         RC_TRY(sa_build_device(text.as<uint8_t>(), n, sa.p, wide, s, 0));
         if (wide) {
-            HIP_TRY(hipMemcpyAsync(SA, sa.p, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+            HIP_TRY(read_back(SA, sa.p, (size_t)n * 8, s));
         } else {
             const uint64_t slice = 1ull << 27;
             RC_TRY(out.reserve((size_t)(slice < (uint64_t)n ? slice : (uint64_t)n) * 8));
@@ -802,7 +802,7 @@ extern "C" int32_t asgart_sa_build64(const uint8_t *T, int64_t *SA, int64_t n) {
                 widen_kernel<<<grid_for(cnt), 256, 0, s>>>(sa.as<uint32_t>() + off,
                                                            out.as<int64_t>(), cnt);
                 HIP_TRY(hipGetLastError());
-                HIP_TRY(hipMemcpyAsync(SA + off, out.p, cnt * 8, hipMemcpyDeviceToHost, s));
+                HIP_TRY(read_back(SA + off, out.p, cnt * 8, s));
                 HIP_TRY(stream_sync(s));
             }
         }

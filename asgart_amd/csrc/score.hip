@@ -329,6 +329,7 @@ extern "C" int32_t asgart_compute_scores(asgart_index *idx, const asgart_proto_s
             return ASGART_E_CAP;
         }
     }
+    REFUSE_POISONED(idx);
     HIP_TRY(hipSetDevice(idx->device));
     int which = 0;
     SearchCtx &cx = idx->acquire_one(&which);
@@ -387,7 +388,7 @@ extern "C" int32_t asgart_compute_scores(asgart_index *idx, const asgart_proto_s
             idx->d_text, w.out_a.as<asgart_proto_sd>(), d_list + long_list.size(), (uint64_t)wave_list.size(),
             reversed != 0, complemented != 0, w.scratch.as<uint32_t>(), stride_w, cursor, w.out_b.as<float>());
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(identity, w.out_b.p, (size_t)n_sd * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(read_back(identity, w.out_b.p, (size_t)n_sd * sizeof(float), s));
     HIP_TRY(stream_sync(s));
     return 0;
 }

@@ -311,18 +311,34 @@ def main():
     t_warm = time.time() - t0
     # per-pass device timings + work counters + the accounting pass (one extra untimed call per
     # mode, the passes one after the other: "alone on the chip" kernel durations)
+    # (the passes call runs passes that differ in orientation only as ONE job -- one launch of every kernel over all
+    # their probes, asgart_stats.passes says how many; sharded calls and ASGART_FUSE_PASSES=0 pipeline them as calls)
     pass_stats = []
-    for st in settings:
-        run_pass(st)
-        pass_stats.append(idx.stats(1).as_dict())   # rank-local work counters
+    fused = False
+    if len(settings) > 1 and os.environ.get("ASGART_BENCH_MODE", "") in ("", "library", "auto"):
+        passes_call()
+        st_f = idx.stats(1)
+        if st_f.passes == len(settings):
+            fused = True
+            pass_stats.append(st_f.as_dict())
+    if not fused:
+        for st in settings:
+            run_pass(st)
+            pass_stats.append(idx.stats(1).as_dict())   # rank-local work counters
+    passes_per_launch = len(settings) if fused else 1
     # what the scaling model is made of: ONE GPU's front (probe search, scans, hit rows), extension and longest tier
     # per pass.  With several ranks, rank 0 runs the passes unsharded once while the others wait.
     if world > 1:
         whole = []
         if rank == 0:
-            for st in settings:
-                idx.search_duplications_raw(chunks, st)
-                whole.append(idx.stats(0).as_dict())
+            if len(settings) > 1:
+                idx.search_duplications_passes(chunks, settings)   # unsharded: one fused job
+                if idx.stats(0).passes == len(settings):
+                    whole.append(idx.stats(0).as_dict())
+            if not whole:
+                for st in settings:
+                    idx.search_duplications_raw(chunks, st)
+                    whole.append(idx.stats(0).as_dict())
         sync()
     else:
         whole = pass_stats
@@ -354,6 +370,9 @@ def main():
         """-> (results in `settings` order, the library's per-call stats)"""
         if mode == "library" and len(settings) > 1:
             results = passes_call()
+            last = idx.stats(0)
+            if last.passes == len(settings):   # one fused job: one set of statistics
+                return results, [last]
             return results, [idx.stats((ci + 1) << 8) for ci in range(len(settings))]
         if mode == "back_to_back" or len(settings) == 1:
             results, stats = [], []
@@ -396,12 +415,14 @@ def main():
     t0 = time.perf_counter()
     search_ms = 0.0
     probe_count_ms = 0.0
+    n_launch = 0
     phase_ms = {"search": 0.0, "scan": 0.0, "fill": 0.0, "extend": 0.0, "extend_tier2": 0.0, "longest_tier": 0.0}
     for _ in range(args.steps):
         results, per_call = issue(mode)
         if world > 1:
             # the only exchange of the path: duplicon lists -> rank 0 over RCCL
             results = [gather(r_) for r_ in results]
+        n_launch += len(per_call)
         for s in per_call:
             search_ms += s.ms_search
             probe_count_ms += s.ms_probe_count
@@ -425,12 +446,13 @@ def main():
 
     passes = len(modes)
     value = total_bp * passes * args.steps / elapsed / 1e6
-    n_launch = args.steps * passes
-    alg_bytes = sum(s["search_bytes"] for s in pass_stats) / passes          # per launch, this design
-    ref_bytes = sum(reference_algorithm_bytes(s, k) for s in pass_stats) / passes
+    # one launch of the probe-search kernels covers passes_per_launch passes (all of them when the passes call fuses)
+    n_ls = len(pass_stats)
+    alg_bytes = sum(s["search_bytes"] for s in pass_stats) / n_ls          # per launch, this design
+    ref_bytes = sum(reference_algorithm_bytes(s, k) for s in pass_stats) / n_ls
     avg_launch_ms = search_ms / n_launch if n_launch else 0.0
     achieved = alg_bytes / (avg_launch_ms / 1e3) / 1e9 if avg_launch_ms > 0 else 0.0
-    alone_ms = sum(s["ms_search"] for s in pass_stats) / passes
+    alone_ms = sum(s["ms_search"] for s in pass_stats) / n_ls
     prof = {}
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
@@ -444,19 +466,25 @@ def main():
     traffic_ms = prof.get("kernel_ms_per_launch")
     # FETCH_SIZE tallies exactly half the bytes of whole-wave 16-byte-per-lane loads on gfx950 (MI355X_MICROARCH.md, HBM):
     # the text windows and filter bitmaps of the probe search are such loads -- the accounting pass counts them apart
-    wide_bytes = sum(s.get("search_bytes_wide_loads", 0) for s in pass_stats) / passes
+    wide_bytes = sum(s.get("search_bytes_wide_loads", 0) for s in pass_stats) / n_ls
+    if traffic_counted and prof.get("passes_per_launch", 1) != passes_per_launch:
+        # (the counter passes were collected with a different number of passes per launch: rescale to this run's launch)
+        traffic_counted = traffic_counted * passes_per_launch / prof.get("passes_per_launch", 1)
+        traffic_ms = traffic_ms * passes_per_launch / prof.get("passes_per_launch", 1) if traffic_ms else traffic_ms
     traffic = int(traffic_counted + wide_bytes / 2) if traffic_counted else None
     import hashlib
     lib_hash = hashlib.sha256(open(asgart_amd.library_path(), "rb").read()).hexdigest()[:12]
     roofline = {
         "bound": "hbm",
-        "kernel": "probe_count_kernel + collect_pending_kernel + big_count_kernel + rank_count_kernel (one launch = one pass)",
+        "kernel": "probe_count_kernel + collect_pending_kernel + big_count_kernel + rank_count_kernel (one launch = "
+                  + ("one pass)" if passes_per_launch == 1 else f"the {passes_per_launch} passes of a step as one job)"),
+        "passes_per_launch": passes_per_launch,
         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 5),
         "kernel_algorithmic_bytes": int(alg_bytes),
         "avg_launch_ms": round(avg_launch_ms, 5),
         "launch_timing": "HIP events on the library's stream, timed region" +
-                         ("" if sequential else " (the other pass's kernels share the chip)"),
+                         ("" if sequential or fused else " (the other pass's kernels share the chip)"),
         # first kernel of the group alone (rocprofv3 lists the kernels separately)
         "probe_count_kernel_ms": round(probe_count_ms / n_launch, 5) if n_launch else 0.0,
         "alone_launch_ms": round(alone_ms, 5),
@@ -520,7 +548,8 @@ def main():
                    "parallelism": f"probe-shard x{world}" if world > 1 else "1 GPU",
                    "ranks_launched_by": os.environ.get("ASGART_BENCH_LAUNCHED", "torchrun" if world > 1 else "none"),
                    "collective_backend": (dist.get_backend() if dist is not None else None),
-                   "passes_issued": mode, "mode_probe_ms": mode_probe_ms},
+                   "passes_issued": mode + (" (one fused job)" if fused and mode == "library" else ""),
+                   "mode_probe_ms": mode_probe_ms},
         "roofline": roofline,
         "phases_ms_per_step": per_rank_phase[0],
         "per_rank_ms": per_rank_ms,

@@ -89,6 +89,9 @@ typedef struct asgart_stats {
     double ms_longest_tier;   /* part of ms_extend: the extension tier that ran longest, from the launch of the tiers
                                  (they run side by side) -- in practice the longest serial automaton segment of the
                                  call, i.e. what sharding the probes over more GPUs cannot shorten              */
+    uint64_t passes;          /* passes (orientations) the call ran as ONE job: 1 for a plain call; n for the passes call
+                                 when it fuses them (the counters above are then sums over the passes, the timings those
+                                 of the one job)                                                                 */
 } asgart_stats;
 
 typedef struct asgart_index asgart_index;
@@ -132,6 +135,14 @@ int32_t asgart_index_create_device(const void *d_text, int64_t n, const void *d_
  * fails -- and here, for a host about to allocate a lot by other means.  Returns the bytes released, < 0 on error. */
 int64_t asgart_trim_cache(int32_t device);
 
+/* Diagnostics for a host that suspects a stalled call (no reference counterpart: the reference has no device to wait
+ * for): writes the NATIVE call stack of every thread of the process to stderr (glibc backtrace from a SIGUSR2 handler
+ * the call installs, one thread after the other), so that a wait inside the HIP runtime -- which a Python- or
+ * Rust-level stack dump shows as one opaque frame -- names the runtime call it sits in.  Callable from any thread,
+ * in particular from a watchdog thread while the main thread is blocked (tests/conftest.py does on a test time-out).
+ * Returns the number of threads asked. */
+int32_t asgart_debug_dump_stacks(void);
+
 /* `--trim START END` (reference src/bin/asgart.rs:142-148, validation :432-463, README "trimming"):
  * the suffix array covers only data[start..end] + '$' -- its entries shifted by +start -- and the WHOLE
  * input is then searched against it (Searcher::new(&strand.data, &suffix_array, 0), :151-155).  SA: that
@@ -154,7 +165,7 @@ int32_t asgart_index_create_trim(const uint8_t *T, int64_t n, const int64_t *SA,
  * grid1..grid7 (placement of segments on the extension kernels -- results never depend on
  * them), k7, k8, dense3, dense6, dense_min, sparse_to6 (which extension kernel a tier runs and which
  * segments the long-segment tier takes: placement again), pass_gate, watchdog_s, lazy_aux, prewarm,
- * debug, test_cap_limit, test_levels, test_genbits (parity tests); the full table with ranges is
+ * debug, test_cap_limit, test_levels, test_genbits, test_k8_delay (parity tests); the full table with ranges is
  * kOptions in asgart_amd/csrc/index.hip, every field is described in struct Options
  * (asgart_amd/csrc/index.hpp).  ptab_depth and force_wide are fixed at creation (environment
  * only).  Blocks until no call is in flight. */
@@ -227,7 +238,13 @@ int32_t asgart_search_duplications_ex(asgart_index *idx, const uint64_t *chunks,
  * and without -R / -C over one strand (reference src/bin/asgart.rs:677-693 builds one RunSettings per
  * invocation; the direct and the -RC run of BASELINE.json's "direct+RC" are two of them): settings[j] are
  * the RunSettings of pass j, out[j] receives its families (exactly what asgart_search_duplications returns
- * for settings[j]).  The library pipelines the passes itself: pass j+1 is issued the moment the chip-wide,
+ * for settings[j]).  Passes that differ in orientation only (same probe_size, max_gap_size,
+ * min_duplication_length, max_cardinality; up to four; unsharded) run as ONE job: the probe sequence is pass 0's
+ * chunks followed by pass 1's ... (chunk order inside each pass as in src/bin/asgart.rs:201-253), searched, scanned
+ * and placed in one sweep at full chip rate, and every extension tier is ONE launch over the merged, cost-sorted
+ * segment list, so that every pass's longest serial segments start at once on compute units of their own
+ * (asgart_stats.passes tells; option fuse_passes = 0 switches it off).  Otherwise (sharded calls, different
+ * settings) the library pipelines the passes as single calls: pass j+1 is issued the moment the chip-wide,
  * HBM-bound phases of pass j are over (probe search, scans, hit materialisation -- the moment the `progress`
  * array of a single call jumps), so its search runs beside pass j's extension automaton, whose tail is a few
  * serial segments on one compute unit each; the passes are issued longest extension first (from the

@@ -31,7 +31,7 @@ def test_struct_layouts():
     assert asgart_amd._Settings.max_gap_size.offset == 8
     assert asgart_amd._Settings.min_duplication_length.offset == 16
     assert asgart_amd._Settings.reverse.offset == 32
-    assert C.sizeof(asgart_amd.Stats) == 5 * 8 + 13 * 8 + 8 + 8 + 8 + 2 * 8 + 8 + 8
+    assert C.sizeof(asgart_amd.Stats) == 5 * 8 + 13 * 8 + 8 + 8 + 8 + 2 * 8 + 8 + 8 + 8
 
 
 def test_version_and_settings_from_cli(hiplib):
@@ -65,3 +65,21 @@ def test_the_library_carries_the_gfx950_kernels_of_the_path(hiplib):
                    b"extend_k7_kernel", b"extend_k8_kernel", b"extend_heavy_kernel", b"seg_prepass_kernel"):
         assert kernel in blob, kernel
     assert b"gfx950" in blob
+
+
+def test_native_stack_dump_names_the_threads(hiplib, capfd):
+    """asgart_debug_dump_stacks (what tests/conftest.py calls a minute before a stalled GPU test is ended): every thread of
+    the process writes its native stack to stderr, a thread blocked in a system call included."""
+    import threading
+    import time
+
+    stop = threading.Event()
+    t = threading.Thread(target=lambda: stop.wait(30))
+    t.start()
+    time.sleep(0.05)
+    n = hiplib.asgart_debug_dump_stacks()
+    stop.set()
+    t.join()
+    err = capfd.readouterr().err
+    assert n >= 2 and err.count("---- native stack of thread") == n
+    assert "libasgart_hip" in err       # the dumping thread itself is inside the library

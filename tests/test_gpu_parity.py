@@ -514,6 +514,20 @@ def _check_against_oracle_digest(name):
             assert (len(offs) - 1, len(sds)) == (want["n_families"], want["n_sds"]), (name, label)
             assert _sha_slabs([offs], "<u8") == want["fam_offsets_sha256"], (name, label)
             assert _sha_slabs([sds], "<u8") == want["sds_sha256"], (name, label)
+        # ... and all passes of the configuration as ONE job (what bench.py times: asgart_search_duplications_passes)
+        wants = list(d["passes"].values())
+        if len(wants) > 1:
+            sts = [asgart_amd.RunSettings.from_cli(k=cli["k"], gap=cli["gap"], min_length=cli["min_length"],
+                                                   max_cardinality=cli["max_cardinality"], reverse=w_["reverse"],
+                                                   complement=w_["complement"]) for w_ in wants]
+            got_all = idx.search_duplications_passes(pr.chunks, sts)
+            got = idx.stats().as_dict()
+            assert got["passes"] == len(wants), (name, got["passes"])
+            for key in wants[0]["counters"]:
+                assert got[key] == sum(w_["counters"][key] for w_ in wants), (name, "fused", key)
+            for w_, (offs, sds) in zip(wants, got_all):
+                assert _sha_slabs([offs], "<u8") == w_["fam_offsets_sha256"], (name, "fused")
+                assert _sha_slabs([sds], "<u8") == w_["sds_sha256"], (name, "fused")
 
 
 @pytest.mark.parametrize("kind", ["dna", "bytes", "runs", "dna-batched", "runs-batched"])
@@ -1132,7 +1146,8 @@ def test_watchdog_gives_up_on_a_stalled_device_and_names_the_phase(hiplib):
         with pytest.raises(asgart_amd.AsgartError) as e2:
             idx.search_duplications_raw(pr.chunks, st)
         assert "fresh process" in str(e2.value)
-        time.sleep(3.0)   # (the parked kernel ends by itself; the index is closed behind it)
+        time.sleep(3.5)   # (the parked kernel ends by itself; the index is closed behind it: its teardown drains the streams
+                          # with a polled wait and would leak the index rather than hang if the kernel were still there)
     # a long wait with a patient watchdog is not an error: the same stall, the default limit
     with asgart_amd.Index(pr.data, None) as idx:
         idx.set_option("test_stall_s", 2)
@@ -1249,3 +1264,66 @@ def test_control_wave_kernel_in_every_workgroup_tier(hiplib, tier, wide, k8, mon
                     _ORACLE_CACHE[key] = oidx.run_raw(pr.chunks, oracle.make_settings(reverse=rc, complement=rc, **cli), threads=4)
                 eoffs, esds = _ORACLE_CACHE[key]
                 assert np.array_equal(offs, eoffs) and np.array_equal(sds, esds), (name, tier, wide, rc, k8)
+
+
+@pytest.mark.parametrize("delay", [0, 2_000, 20_000])
+def test_k8_free_counts_do_not_depend_on_timing(hiplib, delay, monkeypatch):
+    """K8 (tier 3's kernel) has ONE barrier per hit-probe: the ranking wave reads the free-slot counts the arm waves
+    published in front of that barrier, and the arm waves publish the next counts in front of the next one.  With one
+    block of counts nothing but time separated the two (round 4: documented, shipped); they are double-buffered by
+    step parity now.  Option test_k8_delay makes the ranking wave wait that many cycles right before the read -- far
+    longer than an arm wave with a few arms needs to reach its next publication -- and the families must not change:
+    tandem-array cases of tools/fuzz_k8.py, every multi-hit segment forced through tier 3, generation wraps included.
+    (tools/k8_race.sh builds the kernel with the single block again, -DK8_SINGLE_FREE, and shows the same cases fail.)"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_k8
+
+    monkeypatch.setenv("ASGART_TEST_K8_DELAY", str(delay))
+    for seed in (0, 3, 5, 8, 13, 21):
+        text, cli, genbits = fuzz_k8.make_case(seed)
+        chunks = [(0, len(text) - 1)]
+        oidx = oracle.Index.build(text)
+        with asgart_amd.Index(text, oidx.sa) as idx:
+            idx.set_option("force_tier", 3)
+            idx.set_option("test_genbits", genbits)
+            for rc in (False, True):
+                st = asgart_amd.RunSettings.from_cli(reverse=rc, complement=rc, **cli)
+                offs, sds = idx.search_duplications_raw(chunks, st)
+                key = ("k8_delay", seed, rc)
+                if key not in _ORACLE_CACHE:
+                    _ORACLE_CACHE[key] = oidx.run_raw(chunks, oracle.make_settings(reverse=rc, complement=rc, **cli), threads=4)
+                eo, es = _ORACLE_CACHE[key]
+                assert np.array_equal(offs, eo) and np.array_equal(sds, es), (seed, rc, delay, cli)
+
+
+@pytest.mark.parametrize("name", ["satellites", "dense_repeats", "masked", "k31_odd", "long_sds"])
+def test_fused_passes_equal_single_calls_keys_included(hiplib, name):
+    """asgart_search_duplications_passes runs passes that differ in orientation only as ONE job (the probe sequence is
+    pass 0's chunks, then pass 1's ...; one front, one launch per extension tier over the merged segment list): every
+    pass must come back exactly as its own single call returns it -- family offsets, ProtoSDs AND keys (segment start
+    probe counted from the start of the pass) -- for any selection and order of orientations; passes with different
+    settings and option fuse_passes = 0 take the pipelined path and give the same."""
+    pr, cli = _battery_case(name)
+    with asgart_amd.Index(pr.data, None) as idx:
+        sts = [asgart_amd.RunSettings.from_cli(reverse=r, complement=c, **cli) for r, c in MODES]
+        single = [idx.search_duplications_raw(pr.chunks, st, with_keys=True) for st in sts]
+        tot = [idx.search_duplications_raw(pr.chunks, st) and idx.stats().as_dict() for st in sts]
+        for sel in ([0, 3], [3, 0], [0, 1, 2, 3], [2, 1, 3], [3, 3]):
+            got = idx.search_duplications_passes(pr.chunks, [sts[j] for j in sel], with_keys=True)
+            stt = idx.stats().as_dict()
+            assert stt["passes"] == len(sel)
+            for key in ("probes_total", "probes_searched", "raw_hits", "filtered_hits", "families", "proto_sds"):
+                assert stt[key] == sum(tot[j][key] for j in sel), (name, sel, key)
+            for j, g in zip(sel, got):
+                for a, b in zip(g, single[j]):
+                    assert np.array_equal(a, b), (name, sel, j)
+        other = asgart_amd.RunSettings.from_cli(reverse=True, complement=True, **dict(cli, min_length=cli.get("min_length", 1000) + 7))
+        got = idx.search_duplications_passes(pr.chunks, [sts[0], other], with_keys=True)
+        assert idx.stats().as_dict()["passes"] == 1      # different settings: two pipelined calls
+        assert all(np.array_equal(a, b) for a, b in zip(got[0], single[0]))
+        assert all(np.array_equal(a, b) for a, b in zip(got[1], idx.search_duplications_raw(pr.chunks, other, with_keys=True)))
+        idx.set_option("fuse_passes", 0)
+        got = idx.search_duplications_passes(pr.chunks, [sts[0], sts[3]], with_keys=True)
+        assert idx.stats().as_dict()["passes"] == 1
+        for j, g in zip((0, 3), got):
+            assert all(np.array_equal(a, b) for a, b in zip(g, single[j]))
