@@ -954,7 +954,7 @@ int32_t asgart_debug_dump_stacks(void) {
 //      that do not drain -- or an index the watchdog has given up on whose streams still do not -- mean work is in
 //      flight on the buffers: nothing is freed, the index is leaked, the reason goes to stderr and asgart_last_error;
 //   2  the worker threads of the passes call are joined (idle by now: a passes call in flight would own the contexts);
-//   3  events and streams are destroyed, 4 pinned host blocks freed, 5 device buffers given back, 6 the block cache
+//   3  pinned host blocks are freed, 4 device buffers given back, 5 events and streams destroyed, 6 the block cache
 //      trimmed when this was the device's last index -- every one of them a runtime call that synchronises with the
 //      device inside the runtime and cannot be polled: they run on a helper thread that is waited for watchdog_s
 //      seconds PER STAGE; a stage that does not come back is reported (stage name, index, seconds) and the rest of the
@@ -1014,7 +1014,12 @@ void asgart_index_destroy(asgart_index *idx) {
     }
     stamp("workers joined");
     // ---- 3: events and streams -------------------------------------------------------------------------------------
-    if (!bounded_call(limit, [idx, dev]() {
+    // They go AFTER the memory (stages 4 and 5 run first): destroyed before it, the runtime kept 16 MB per 70 indexes of the
+    // failure-injection test (test_out_of_memory_paths_release_what_they_hold; the frees-first order of round 4 does
+    // not).  ASGART_TEARDOWN_ORDER=0 (diagnostics) destroys them first.
+    static const bool streams_last = !(getenv("ASGART_TEARDOWN_ORDER") && atoi(getenv("ASGART_TEARDOWN_ORDER")) == 0);
+    auto destroy_streams = [&]() -> bool {
+      return bounded_call(limit, [idx, dev]() {
             (void)hipSetDevice(dev);
             for (auto &cx : idx->ctx) {
                 for (auto &e : cx.ev)
@@ -1028,11 +1033,15 @@ void asgart_index_destroy(asgart_index *idx) {
                         *st = nullptr;
                     }
             }
-        })) {
-        give_up("destroying the events and streams");
-        return;
+        });
+    };
+    if (!streams_last) {
+        if (!destroy_streams()) {
+            give_up("destroying the events and streams");
+            return;
+        }
+        stamp("events and streams destroyed");
     }
-    stamp("events and streams destroyed");
     // ---- 4: pinned host memory (the device-mapped heartbeat block among it) ---------------------------------------------
     if (!bounded_call(limit, [idx, dev]() {
             (void)hipSetDevice(dev);
@@ -1065,6 +1074,13 @@ void asgart_index_destroy(asgart_index *idx) {
         return;
     }
     stamp("device buffers released");
+    if (streams_last) {
+        if (!destroy_streams()) {
+            give_up("destroying the events and streams");
+            return;
+        }
+        stamp("events and streams destroyed");
+    }
     delete idx;
     // ---- 6: the last index of the device takes the cached blocks with it -------------------------------------------------------
     if (!bounded_call(limit, [dev]() {
