@@ -1149,6 +1149,7 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
         lds_barrier();
     }
     rec_flush(rec_alloc, P, lane);
+    wg_busy(rec_alloc, P);
 }
 
 }  // namespace asgart

@@ -239,7 +239,10 @@ struct Options {
     int64_t force_tier = 0;         // tests: minimum extension tier of segments with a multi-hit probe
     int64_t arms_kernel = 1;        // 0: LDS-array kernels in tiers 2, 4, 6 (what max_cardinality > 1024 selects)
     int64_t prio3 = 1;              // 1: tier 3's waves run at raised issue priority (s_setprio)
-    int64_t long3 = 4096;           // probes; longer segments go to the low-latency tier 3
+    int64_t long3 = 16384;          // probes; longer segments go to the long-segment tiers (3: dense, 6: sparse) whatever their arm
+                                    // bound.  Round 5 (the passes of a step as one job: the extension is bound by the compute-unit
+                                    // time the tiers hold, not by a serial chain): 4096 -> 16384, 250 -> 236 ms per step at GRCh38
+                                    // size -- a long SPARSE segment in tier 6 owns a whole compute unit for one wave's work
     int64_t long3_big = -1;         // -1: long3 / 4
     int64_t cap1 = 256;             // live-arm bound up to which a segment may use the one-wave tier
     int64_t filter = 0;             // 1: continuation filter pre-pass
@@ -301,7 +304,7 @@ struct Options {
                                     // average (0: all of them); the sparse long ones run on tier 6's kernel
     int64_t dense_min = 0;          // with k7 in tier 3: dense segments (dense3) of at least this many probes go to tier 3 whatever their arm
                                     // bound says (0: only the long ones, option long3)
-    int64_t dense6 = 0;             // with k7 in tier 3: segments of ANY length whose arm bound sends them to tier 6 go to tier 3 instead with at
+    int64_t dense6 = 32;            // with k7 in tier 3: segments of ANY length whose arm bound sends them to tier 6 go to tier 3 instead with at
                                     // least this many hits per processed probe on average (0: off)
     int64_t prewarm = 1;            // 1: asgart_index_prepare also reserves the per-probe workspace of both call contexts (sized for an
                                     // unsharded call over the whole text) and starts the worker thread of the passes call, so that the first

@@ -517,6 +517,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
         PlaceParams pp;
         pp.long3 = pp.long3_big = pp.dense3 = pp.dense6 = pp.dense_min = 0;
         pp.sparse_to6 = (uint32_t)opt.sparse_to6;
+        pp.stats = opt.debug ? 1u : 0u;
         for (int t = 1; t < kTiers; ++t) pp.cap[t - 1] = tier_cap[t];
         if (arms_kernel) {
             pp.long3 = (uint32_t)opt.long3;
@@ -567,9 +568,12 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
         HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, kCtrBytes, hipMemcpyDeviceToHost, s));
         RC_TRY(wd_sync(idx, cx, s, "the hit rows and the placement of the segments"));
         uint64_t n_t[kTiers], seg_off[kTiers + 1] = {0};
+        uint64_t h_tp[kTiers], h_th[kTiers];  // (option debug: hit-probes and hits per tier, as placed)
         for (int t = 0; t < kTiers; ++t) {
             n_t[t] = h_ctr[CT_N1 + t];
             seg_off[t + 1] = seg_off[t] + n_t[t];
+            h_tp[t] = h_ctr[CT_TPROBES1 + t];
+            h_th[t] = h_ctr[CT_THITS1 + t];
         }
         if (opt.debug) {
             fprintf(stderr, "[asgart] %llu segments, %llu walked wave by wave; per tier:", (unsigned long long)n_seg,
@@ -641,6 +645,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             HIP_TRY(hipMemsetAsync(d_ctr + CT_SD, 0, 8, s));
             HIP_TRY(hipMemsetAsync(d_ctr + CT_NF, 0, (size_t)(CT_COUNT - CT_NF) * 8, s));  // NF, cursors, overflow counts
             HIP_TRY(hipMemsetAsync(d_ctr + CT_EARLY_N, 0, 4 * 8, s));                       // early cascade counts + cursors
+            HIP_TRY(hipMemsetAsync(d_ctr + CT_BUSY1, 0, (size_t)(CT_COUNT - CT_BUSY1) * 8, s));
             HIP_TRY(hipEventRecord(cx.ev[7], s));
             ExtParams<SlotT> ep;
             ep.rp = rp;
@@ -700,6 +705,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                 const bool retiring = !cascade_launch && (tier == 1 || (arms_kernel && tier >= 2 && tier <= 5));
                 const uint64_t items_wg = retiring ? (uint64_t)(tier <= 2 ? opt.wg_items12 : opt.wg_items) : 0;
                 ep.max_items = (uint32_t)items_wg;
+                ep.tier = (uint32_t)tier;
                 ep.hb = cx.d_hb ? cx.d_hb + (size_t)2 * SearchCtx::kHbSlots * (size_t)(tier & 7) : nullptr;
                 auto grid = [&](uint64_t dflt) -> unsigned {
                     uint64_t g = dflt;
@@ -951,7 +957,27 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, kCtrBytes, hipMemcpyDeviceToHost, s));
             RC_TRY(wd_sync(idx, cx, s, "the extension tiers"));
             PROF_DUMP("concurrent tiers");
-            if (opt.debug) fprintf(stderr, "[asgart] all tiers and early re-runs done %.1f ms after the launches\n", since_launch());
+            if (opt.debug) {
+                fprintf(stderr, "[asgart] all tiers and early re-runs done %.1f ms after the launches\n", since_launch());
+                // how much of the chip each tier held: sum of its workgroups' lifetimes x the share of a compute unit one of
+                // them occupies (workgroups per compute unit by LDS / registers: tiers 1..7 = 11, 8, 1, 4, 2, 1, 1)
+                static const double per_cu[kTiers] = {11, 8, 1, 4, 2, 1, 1};
+                double tot = 0.0;
+                fprintf(stderr, "[asgart] compute-unit time held per tier (CU-ms; workgroups):");
+                for (int t = 0; t < kTiers; ++t) {
+                    const double cu_ms = (double)h_ctr[CT_BUSY1 + t] * 1e-5 / per_cu[t];
+                    tot += cu_ms;
+                    fprintf(stderr, " %d: %.0f (%llu)", t + 1, cu_ms, (unsigned long long)h_ctr[CT_WGS1 + t]);
+                }
+                fprintf(stderr, "  total %.0f = %.1f ms of the whole chip\n", tot, tot / 256.0);
+                fprintf(stderr, "[asgart] per tier: hit-probes / hits per hit-probe / CU-microseconds per hit-probe:");
+                for (int t = 0; t < kTiers; ++t) {
+                    const double hp = (double)h_tp[t];
+                    fprintf(stderr, " %d: %.0fK / %.1f / %.2f", t + 1, hp / 1e3, hp > 0 ? (double)h_th[t] / hp : 0.0,
+                            hp > 0 ? (double)h_ctr[CT_BUSY1 + t] * 1e-2 / per_cu[t] / hp : 0.0);
+                }
+                fprintf(stderr, "\n");
+            }
             {   // the tier that ran longest (its early re-run included): the serial floor of this call's extension
                 float longest = 0.f;
                 for (int e : {5, 6, 8, 9, 10, 12}) {

@@ -58,7 +58,12 @@ enum Counter {
     CT_CUR1 = 112,     // work cursors of the tiers (kTiers entries)
     CT_CURF = 119,
     CT_OVF1 = 120,     // segments tier t gave up on (kTiers entries; the last one has nowhere to go)
-    CT_COUNT = 128
+    CT_BUSY1 = 128,    // per tier: sum over its workgroups of their lifetime, in 10-ns ticks (how much of the chip a tier holds:
+                       // persistent workgroups own their share of a compute unit from launch to exit) ...
+    CT_WGS1 = 136,     // ... and the number of workgroups summed
+    CT_TPROBES1 = 144, // placement statistics (option debug only): hit-probes per tier ...
+    CT_THITS1 = 152,   // ... and hits per tier
+    CT_COUNT = 160
 };
 
 __device__ inline int chunk_of(const ChunkTable &ch, uint32_t g) {
@@ -1044,6 +1049,7 @@ struct ExtParams {
     uint32_t heavy_cap;                   // K4b MODE 2 (tier 7): arm slots per workgroup in its HBM slice
     uint32_t solo_hits;                   // K6: probes with up to this many hits may run on wave 0 alone (0: never)
     uint32_t k8_delay;                    // K8 (tests): cycles the ranking wave waits before it reads the free counts
+    uint32_t tier;                        // the tier this launch runs as (statistics)
     unsigned long long *ctr;
     unsigned long long *hb;               // heartbeat slots of this launch's tier (pinned host memory; null: none)
 };
@@ -1095,7 +1101,16 @@ constexpr uint32_t kVoidStart = 0xFFFFFFFFu;
 struct RecAlloc {
     unsigned long long next = 0;  // wave-uniform
     uint32_t left = 0;
+    unsigned long long t0 = wall_clock64();  // when this workgroup started (wg_busy)
 };
+// at the very end of an extension kernel: the workgroup's lifetime goes into its tier's tally (one atomic per workgroup)
+template <class PosT>
+__device__ inline void wg_busy(const RecAlloc &ra, const ExtParams<PosT> &P) {
+    if (threadIdx.x == 0 && P.tier >= 1u && P.tier <= (uint32_t)kTiers) {
+        atomicAdd(&P.ctr[CT_BUSY1 + P.tier - 1u], wall_clock64() - ra.t0);
+        atomicAdd(&P.ctr[CT_WGS1 + P.tier - 1u], 1ull);
+    }
+}
 template <class PosT>
 __device__ inline void rec_flush(RecAlloc &ra, const ExtParams<PosT> &P, int lane) {
     if ((uint32_t)lane < ra.left && ra.next + (unsigned)lane < P.rec_cap) P.recs[ra.next + (unsigned)lane].g_start = kVoidStart;
@@ -1573,6 +1588,7 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
         __syncthreads();
     }
     rec_flush(rec_alloc, P, lane);
+    wg_busy(rec_alloc, P);
 }
 
 // ---------------------------------------------------------------- K3b --------
@@ -1605,6 +1621,7 @@ struct PlaceParams {
     uint32_t dense_min;         // > 0: segments of at least this many probes that are dense (dense3) go to tier 3 whatever their arm bound
     uint32_t dense6;            // > 0: segments bound for tier 6 by their arms go to tier 3 (when they fit it) with at least this
                                 // many hits per processed probe: the dense ones of ANY length on the kernel with a control wave
+    uint32_t stats;             // 1 (option debug): hit-probes and hits per tier are tallied (one atomic pair per segment)
     uint32_t dense3;            // > 0: ... and only the DENSE ones (at least this many hits per processed probe on average:
                                 // tandem arrays); the sparse long ones (a chromosome against its homologue: a few hits per
                                 // probe, mostly run by one wave alone) go to tier 6's kernel -- set when tier 3 runs the
@@ -1827,7 +1844,7 @@ __global__ __launch_bounds__(64) void seg_stats_lanes_kernel(RunParams rp, const
             g_end = min(rp.ch.pbase[chunk_of(rp.ch, g0) + 1], rp.g_hi);
         }
         for (uint32_t r = 0; r < RW; ++r) s_ring[r * 64u + lane] = 0;
-        uint32_t quiet = 0, mx = 0, bound = 0, n_probes = 0, wsum = 0, head = 0, steps = 0, g = g0;
+        uint32_t quiet = 0, mx = 0, bound = 0, n_probes = 0, wsum = 0, head = 0, steps = 0, g = g0, n_hit = 0;
         unsigned long long sum = 0;
         bool done = !have;
         while (!done && g < g_end && steps < kLaneWalk) {
@@ -1846,6 +1863,7 @@ __global__ __launch_bounds__(64) void seg_stats_lanes_kernel(RunParams rp, const
             }
             const uint32_t v = hit ? f : 0u;
             ++n_probes;
+            n_hit += hit ? 1u : 0u;
             const uint32_t at = head * 64u + lane;
             wsum += v - s_ring[at];
             s_ring[at] = v;
@@ -1861,6 +1879,10 @@ __global__ __launch_bounds__(64) void seg_stats_lanes_kernel(RunParams rp, const
             if (mx > 1 && pp.force_tier > tier) tier = min(pp.force_tier, kTiers);
             keys[sidx] = placement_key(tier, sum, g0);
             vals[sidx] = g0;
+            if (pp.stats) {
+                atomicAdd(&ctr[CT_TPROBES1 + tier - 1], (unsigned long long)n_hit);
+                atomicAdd(&ctr[CT_THITS1 + tier - 1], sum);
+            }
         }
         const unsigned long long lm = __ballot(have && !done);
         if (lm) {
@@ -1891,7 +1913,7 @@ __global__ __launch_bounds__(64) void seg_stats_kernel(RunParams rp, const uint3
         const uint32_t g0 = seg_list[sidx];
         const int c = chunk_of_uniform(rp.ch, g0);
         const uint32_t g_end = min(rp.ch.pbase[c + 1], rp.g_hi);
-        uint32_t quiet = 0, mx = 0, bound = 0, n_probes = 0;
+        uint32_t quiet = 0, mx = 0, bound = 0, n_probes = 0, n_hit = 0;
         unsigned long long sum = 0;
         bool done = false;
         s_ext[lane] = 0;
@@ -1934,6 +1956,7 @@ __global__ __launch_bounds__(64) void seg_stats_kernel(RunParams rp, const uint3
             const uint32_t r = (uint32_t)__popcll(procm & lt_mask);
             const uint32_t n_proc = (uint32_t)__popcll(procm);
             n_probes += n_proc;
+            n_hit += (uint32_t)__popcll(hm & live);
             if (proc) s_ext[TW + r] = v;
             lds_barrier();
             uint32_t wsum = 0;
@@ -1960,6 +1983,10 @@ __global__ __launch_bounds__(64) void seg_stats_kernel(RunParams rp, const uint3
             if (mx > 1 && pp.force_tier > tier) tier = min(pp.force_tier, kTiers);
             keys[sidx] = placement_key(tier, sum, g0);
             vals[sidx] = g0;
+            if (pp.stats) {
+                atomicAdd(&ctr[CT_TPROBES1 + tier - 1], (unsigned long long)n_hit);
+                atomicAdd(&ctr[CT_THITS1 + tier - 1], sum);
+            }
         }
         lds_barrier();
     }
@@ -2541,6 +2568,7 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
         __syncthreads();
     }
     rec_flush(rec_alloc, P, lane);
+    wg_busy(rec_alloc, P);
 }
 
 // ---------------------------------------------------------------- K4c --------
@@ -3075,6 +3103,7 @@ __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
         lds_barrier();
     }
     rec_flush(rec_alloc, P, lane);
+    wg_busy(rec_alloc, P);
 }
 
 // yardstick: sum over searched probes of ceil(log2(b_p + 1)), b_p = size of the

@@ -12,8 +12,8 @@ import asgart_amd  # noqa: E402
 from asgart_amd import prep, synth  # noqa: E402
 
 # option defaults (asgart_amd/csrc/index.hpp: struct Options); grid<t> = 0 means "default grid"
-DEFAULTS = {"shard_lookback": 4096, "arms_kernel": 1, "prio3": 1, "kfilter_bits": 30, "long3": 4096, "long3_big": -1, "cap1": 256,
-            "test_cap_limit": -1, "test_levels": 4, "test_genbits": 22, "tier_order": 3654217, "tier_streams": 7234562, "cap6_pct": 140, "wg_items": 0, "wg_items12": 0, "early_cascade": 1, "progress_at": 2, "fast": 124, "cap3_pct": 160, "fast_bsh": 0, "posbits": 1, "shard_lpt": 0, "cap45_pct": 100, "solo": 1, "fast6w": 1, "cap6w_pct": 160, "k7": 8, "k8": 1, "dense3": 16, "dense6": 0, "sparse_to6": 1, "pass_gate": 0}
+DEFAULTS = {"shard_lookback": 4096, "arms_kernel": 1, "prio3": 1, "kfilter_bits": 30, "long3": 16384, "long3_big": -1, "cap1": 256,
+            "test_cap_limit": -1, "test_levels": 4, "test_genbits": 22, "tier_order": 3654217, "tier_streams": 7234562, "cap6_pct": 140, "wg_items": 0, "wg_items12": 0, "early_cascade": 1, "progress_at": 2, "fast": 124, "cap3_pct": 160, "fast_bsh": 0, "posbits": 1, "shard_lpt": 0, "cap45_pct": 100, "solo": 1, "fast6w": 1, "cap6w_pct": 160, "k7": 8, "k8": 1, "dense3": 16, "dense6": 32, "sparse_to6": 1, "pass_gate": 0, "filter": 0, "fuse_passes": 1, "dense_min": 0}
 
 
 def opt_name(key):  # "ASGART_GRID3" or "grid3" -> "grid3"
@@ -22,7 +22,8 @@ def opt_name(key):  # "ASGART_GRID3" or "grid3" -> "grid3"
 
 args = sys.argv[1:]
 PIPELINED = "--pipelined" in args   # time whole steps (RC pass first, direct pass issued at its progress signal)
-args = [a for a in args if a != "--pipelined"]
+FUSED = "--fused" in args           # time whole steps through the passes call (both passes as one job)
+args = [a for a in args if a not in ("--pipelined", "--fused")]
 cfg, scale = 4, 1.0
 if args and args[0].startswith("cfg"):
     cfg = int(args[0][3:]); args = args[1:]
@@ -56,7 +57,19 @@ for conf in configs:
         for r in (r0, r1):
             sig.update(r[0].tobytes()); sig.update(r[1].tobytes())
         line.append("step min %.1f median %.1f ms" % (min(times[1:]), sorted(times[1:])[len(times[1:]) // 2]))
-    for st in ([] if PIPELINED else settings):
+    if FUSED:
+        times = []
+        for rep in range(int(os.environ.get("TUNE_REPS", "5"))):
+            t0 = time.perf_counter()
+            r0, r1 = idx.search_duplications_passes(pr.chunks, settings)
+            times.append((time.perf_counter() - t0) * 1e3)
+        s = idx.stats(0)
+        for r in (r0, r1):
+            sig.update(r[0].tobytes()); sig.update(r[1].tobytes())
+        line.append("step min %.1f median %.1f ms | front %.1f extend %.1f longest tier %.1f ovf %d" % (
+            min(times[1:]), sorted(times[1:])[len(times[1:]) // 2], s.ms_search + s.ms_scan + s.ms_fill, s.ms_extend,
+            s.ms_longest_tier, s.overflow_segments))
+    for st in ([] if PIPELINED or FUSED else settings):
         best = None
         for rep in range(2):
             t0 = time.perf_counter()
