@@ -37,7 +37,7 @@ ABI_SYMBOLS = (
     "asgart_search_duplications_multi", "asgart_search_duplications_ex", "asgart_search_duplications_passes",
     "asgart_search_duplications_passes_shard", "asgart_families_keys",
     "asgart_index_export", "asgart_index_create_device", "asgart_trim_cache", "asgart_post_process",
-    "asgart_debug_dump_stacks",
+    "asgart_debug_dump_stacks", "asgart_prepare_data",
 )
 
 
@@ -88,7 +88,7 @@ class Stats(C.Structure):
             "probes_with_hits", "raw_hits", "filtered_hits", "segments", "families", "proto_sds",
             "bisect_steps", "search_launches", "overflow_segments")] + [("ms_extend_tier2", C.c_double), ("heavy_segments", C.c_uint64), ("ms_probe_count", C.c_double),
         ("search_bytes", C.c_uint64), ("probes_filter_rejected", C.c_uint64), ("search_bytes_wide_loads", C.c_uint64),
-        ("ms_longest_tier", C.c_double), ("passes", C.c_uint64)]
+        ("ms_longest_tier", C.c_double), ("passes", C.c_uint64), ("ms_longest_segment", C.c_double)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -126,6 +126,9 @@ def load_library() -> C.CDLL:
     L.asgart_index_create_device.restype = C.c_int32
     L.asgart_trim_cache.argtypes = [C.c_int32]
     L.asgart_trim_cache.restype = C.c_int64
+    L.asgart_prepare_data.argtypes = [vp, vp, C.c_int64, C.c_int32, C.c_int32, vp, vp, C.c_int64, C.POINTER(C.c_int64),
+                                      C.POINTER(vp)]
+    L.asgart_prepare_data.restype = C.c_int32
     L.asgart_debug_dump_stacks.argtypes = []
     L.asgart_debug_dump_stacks.restype = C.c_int32
     L.asgart_post_process.argtypes = [vp, vp, C.c_uint64, vp, C.c_int32, C.POINTER(vp)]

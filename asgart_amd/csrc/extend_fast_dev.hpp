@@ -158,6 +158,7 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
     const WinT w_loop = (WinT)(kRowsLoop - 1u) << bsh;  // windows up to this width span <= kRowsLoop rows
     const bool use_flag = P.hit_flag != nullptr;
     RecAlloc rec_alloc;
+    wg_begin(P);
     PROF_DECL;
 
     PosT a_ls[S], a_re[S];
@@ -188,7 +189,10 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
         lds_barrier();
         if (seg >= n_seg) break;
         const uint32_t g0 = P.seg_list[seg];
-        if (tid == 0) heartbeat(P, g0, 0u);
+        if (tid == 0) {
+            heartbeat(P, g0, 0u);
+            seg_clock(P);
+        }
         PROF_SEG_BEGIN();
         const int c = chunk_of_uniform(rp.ch, g0);
         const uint64_t cs = rp.ch.start[c], cl = rp.ch.len[c];
@@ -1020,7 +1024,7 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
         lds_barrier();
     }
     rec_flush(rec_alloc, P, lane);
-    wg_busy(rec_alloc, P);
+    wg_busy(P);
 }
 
 }  // namespace asgart

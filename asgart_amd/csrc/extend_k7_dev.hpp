@@ -168,6 +168,7 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const bool use_flag = P.hit_flag != nullptr;
     RecAlloc rec_alloc;
+    wg_begin(P);
     K7T_DECL;
     K7U_DECL;
 #ifdef ASGART_PROFILE_EXTEND
@@ -748,7 +749,10 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
             const uint32_t kGenBits = min(kGenMax, max(2u, P.gen_bits));
             const uint32_t cap_eff = min((uint32_t)CAP, P.cap_limit);
             const uint32_t g0 = P.seg_list[seg];
-            if (lane == 0) heartbeat(P, g0, 0u);
+            if (lane == 0) {
+            heartbeat(P, g0, 0u);
+            seg_clock(P);
+        }
 #ifdef ASGART_PROFILE_EXTEND
             const unsigned long long k7_seg0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -1134,7 +1138,7 @@ __global__ __launch_bounds__(NT) void extend_k7_kernel(ExtParams<PosT> P) {
         lds_barrier();
     }
     rec_flush(rec_alloc, P, lane);
-    wg_busy(rec_alloc, P);
+    wg_busy(P);
 }
 
 }  // namespace asgart

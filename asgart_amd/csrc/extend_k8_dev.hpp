@@ -96,6 +96,7 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const bool use_flag = P.hit_flag != nullptr;
     RecAlloc rec_alloc;
+    wg_begin(P);
     K7T_DECL;
     K7U_DECL;
 #ifdef ASGART_PROFILE_EXTEND
@@ -877,7 +878,10 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
             bsh += P.fast_bsh;
             const uint32_t kGenBits = min(kGenMax, max(2u, P.gen_bits));
             const uint32_t g0 = P.seg_list[seg];
-            if (lane == 0) heartbeat(P, g0, 0u);
+            if (lane == 0) {
+            heartbeat(P, g0, 0u);
+            seg_clock(P);
+        }
             const int c = chunk_of_uniform(rp.ch, g0);
             const uint64_t cs = rp.ch.start[c], cl = rp.ch.len[c];
             const uint32_t pb = rp.ch.pbase[c];
@@ -1149,7 +1153,7 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
         lds_barrier();
     }
     rec_flush(rec_alloc, P, lane);
-    wg_busy(rec_alloc, P);
+    wg_busy(P);
 }
 
 }  // namespace asgart

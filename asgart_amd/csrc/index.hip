@@ -1312,8 +1312,8 @@ int32_t asgart_index_create_device(const void *d_text, int64_t n, const void *d_
         return ASGART_E_ARG;
     }
     *out = nullptr;
-    if (!d_text || !d_sa || n <= 0 || sa_len != n) {
-        set_error("asgart_index_create_device: need the text and a suffix array of the same length on the device");
+    if (!d_text || n <= 0 || sa_len != n) {
+        set_error("asgart_index_create_device: need the text (and a suffix array of the same length, or NULL) on the device");
         return ASGART_E_ARG;
     }
     RC_TRY(check_device(device));
@@ -1345,9 +1345,11 @@ int32_t asgart_index_create_device(const void *d_text, int64_t n, const void *d_
         HIP_TRY(dev_malloc(&idx->d_sa, ((size_t)n + 16) * slot));
         HIP_TRY(hipMemsetAsync(idx->d_text + n, 0, 64, s));
         HIP_TRY(hipMemcpyAsync(idx->d_text, d_text, (size_t)n, hipMemcpyDeviceToDevice, s));
-        HIP_TRY(hipMemcpyAsync(idx->d_sa, d_sa, (size_t)n * slot, hipMemcpyDeviceToDevice, s));
+        if (d_sa) HIP_TRY(hipMemcpyAsync(idx->d_sa, d_sa, (size_t)n * slot, hipMemcpyDeviceToDevice, s));
         bool dna = false;
         RC_TRY(text_is_dna(idx->d_text, n, s, &dna));
+        if (!d_sa && dna)  // no suffix array given: sorted here (asgart_prepare_data hands over the text it normalised)
+            RC_TRY(sa_build_device(idx->d_text, n, idx->d_sa, idx->wide, s, (uint64_t)idx->opt.test_wide_batch));
         const int64_t tl = n < (int64_t)kMaxK + 32 ? n : (int64_t)kMaxK + 32;
         idx->h_tail.resize((size_t)tl);
         HIP_TRY(read_back(idx->h_tail.data(), idx->d_text + (n - tl), (size_t)tl, s));

@@ -122,11 +122,12 @@ struct Workspace {
     DevBuf rec_k32, rec_k64, rec_idx, rec_sorted;  // ordering of the output records
     DevBuf pat;        // pattern upload scratch
     DevBuf out_a, out_b;
+    DevBuf seg_slots;  // u64[8][4096]: per tier and workgroup, when its current segment started (longest-segment statistics)
     // every buffer goes back to the device (or to the block cache): ONE list, next to the members
     void release_all() {
         DevBuf *bufs[] = {&chunks, &p_lo, &p_raw, &p_filt, &row_off, &blk, &hits, &big_list, &rank_list, &seg_list,
                           &counters, &fam_sds, &ovf_list, &own_list, &scratch, &hit_flag, &seg_keys, &seg_vals,
-                          &sort_tmp, &rec_k32, &rec_k64, &rec_idx, &rec_sorted, &pat, &out_a, &out_b};
+                          &sort_tmp, &rec_k32, &rec_k64, &rec_idx, &rec_sorted, &pat, &out_a, &out_b, &seg_slots};
         static_assert(sizeof(Workspace) == sizeof(bufs) / sizeof(bufs[0]) * sizeof(DevBuf),
                       "a buffer of the workspace is missing from release_all");
         for (DevBuf *b : bufs) b->release();

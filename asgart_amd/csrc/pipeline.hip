@@ -310,7 +310,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
     HIP_TRY(hipMemcpyAsync(d_start, h_start, ch_bytes, hipMemcpyHostToDevice, s));  // same layout on the device
     uint64_t total_hits = 0, n_seg = 0, n_overflow = 0, n_heavy = 0;
     bool progress_given = false;
-    double ms_tier2 = 0.0, ms_longest_tier = 0.0;
+    double ms_tier2 = 0.0, ms_longest_tier = 0.0, ms_longest_segment = 0.0;
     RunParams rp;
     const auto t_host0 = std::chrono::steady_clock::now();
     for (int win_try = 0;; ++win_try) {
@@ -647,6 +647,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             HIP_TRY(hipMemsetAsync(d_ctr + CT_EARLY_N, 0, 4 * 8, s));                       // early cascade counts + cursors
             HIP_TRY(hipMemsetAsync(d_ctr + CT_BUSY1, 0, (size_t)(CT_COUNT - CT_BUSY1) * 8, s));
             HIP_TRY(hipEventRecord(cx.ev[7], s));
+            RC_TRY(w.seg_slots.reserve((size_t)8 * 4096 * 8));
             ExtParams<SlotT> ep;
             ep.rp = rp;
             ep.p_filt = p_filt;
@@ -706,6 +707,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                 const uint64_t items_wg = retiring ? (uint64_t)(tier <= 2 ? opt.wg_items12 : opt.wg_items) : 0;
                 ep.max_items = (uint32_t)items_wg;
                 ep.tier = (uint32_t)tier;
+                ep.seg_slots = w.seg_slots.as<unsigned long long>() + (size_t)4096 * (size_t)(tier & 7);
                 ep.hb = cx.d_hb ? cx.d_hb + (size_t)2 * SearchCtx::kHbSlots * (size_t)(tier & 7) : nullptr;
                 auto grid = [&](uint64_t dflt) -> unsigned {
                     uint64_t g = dflt;
@@ -1032,6 +1034,13 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                           (unsigned long long)h_ctr[CT_OVF1 + kTiers - 1], (unsigned long long)heavy_cap64);
                 return ASGART_E_CAP;
             }
+            ms_longest_segment = 0.0;
+            for (int t = 0; t < kTiers; ++t) ms_longest_segment = std::max(ms_longest_segment, (double)h_ctr[CT_SEGMAX1 + t] * 1e-5);
+            if (opt.debug) {
+                fprintf(stderr, "[asgart] longest single segment per tier (ms):");
+                for (int t = 0; t < kTiers; ++t) fprintf(stderr, " %d: %.2f", t + 1, (double)h_ctr[CT_SEGMAX1 + t] * 1e-5);
+                fprintf(stderr, "\n");
+            }
             if (h_ctr[CT_RANOUT]) break;
             if (h_ctr[CT_SD] <= rec_cap) break;
             if (attempt >= 3) {
@@ -1124,6 +1133,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
 
     stt.ms_extend_tier2 = ms_tier2;
     stt.ms_longest_tier = ms_longest_tier;
+    stt.ms_longest_segment = ms_longest_segment;
     HIP_TRY(hipEventElapsedTime(&ms, cx.ev[0], cx.ev[11]));
     stt.ms_probe_count = ms;
     cx.has_last = true;

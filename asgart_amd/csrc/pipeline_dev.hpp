@@ -63,7 +63,9 @@ enum Counter {
     CT_WGS1 = 136,     // ... and the number of workgroups summed
     CT_TPROBES1 = 144, // placement statistics (option debug only): hit-probes per tier ...
     CT_THITS1 = 152,   // ... and hits per tier
-    CT_COUNT = 160
+    CT_SEGMAX1 = 160,  // per tier: the longest time one workgroup spent on ONE segment, in 10-ns ticks -- the serial floor of
+                       // the extension (what neither more compute units nor more GPUs shorten)
+    CT_COUNT = 168
 };
 
 __device__ inline int chunk_of(const ChunkTable &ch, uint32_t g) {
@@ -1050,6 +1052,7 @@ struct ExtParams {
     uint32_t solo_hits;                   // K6: probes with up to this many hits may run on wave 0 alone (0: never)
     uint32_t k8_delay;                    // K8 (tests): cycles the ranking wave waits before it reads the free counts
     uint32_t tier;                        // the tier this launch runs as (statistics)
+    unsigned long long *seg_slots;        // 4096 words of this launch's tier: start time of the segment a workgroup is on (seg_clock)
     unsigned long long *ctr;
     unsigned long long *hb;               // heartbeat slots of this launch's tier (pinned host memory; null: none)
 };
@@ -1101,13 +1104,31 @@ constexpr uint32_t kVoidStart = 0xFFFFFFFFu;
 struct RecAlloc {
     unsigned long long next = 0;  // wave-uniform
     uint32_t left = 0;
-    unsigned long long t0 = wall_clock64();  // when this workgroup started (wg_busy)
 };
-// at the very end of an extension kernel: the workgroup's lifetime goes into its tier's tally (one atomic per workgroup)
+// Statistics of the persistent workgroups, kept in DEVICE memory (not in registers: the 1024-thread shapes sit at their
+// 128-VGPR cap and every value that lives across the segment loop is a spill into it):
+//   wg_begin / wg_busy   the workgroup's lifetime goes into its tier's tally (- start, + end: two atomics per workgroup)
+//   seg_clock            called by ONE thread where the workgroup takes its next segment: the time since the previous
+//                        call is one segment's duration; the longest per tier is the serial floor of the extension
 template <class PosT>
-__device__ inline void wg_busy(const RecAlloc &ra, const ExtParams<PosT> &P) {
+__device__ inline void wg_begin(const ExtParams<PosT> &P) {
     if (threadIdx.x == 0 && P.tier >= 1u && P.tier <= (uint32_t)kTiers) {
-        atomicAdd(&P.ctr[CT_BUSY1 + P.tier - 1u], wall_clock64() - ra.t0);
+        atomicAdd(&P.ctr[CT_BUSY1 + P.tier - 1u], 0ull - wall_clock64());
+        if (P.seg_slots) P.seg_slots[blockIdx.x & 4095u] = 0ull;
+    }
+}
+template <class PosT>
+__device__ inline void seg_clock(const ExtParams<PosT> &P) {
+    if (!P.seg_slots || P.tier < 2u || P.tier > (uint32_t)kTiers) return;  // (tier 1: a million tiny segments)
+    const unsigned long long now = wall_clock64();
+    const unsigned long long prev = atomicExch(&P.seg_slots[blockIdx.x & 4095u], now);
+    if (prev && now > prev) atomicMax(&P.ctr[CT_SEGMAX1 + P.tier - 1u], now - prev);
+}
+template <class PosT>
+__device__ inline void wg_busy(const ExtParams<PosT> &P) {
+    if (threadIdx.x == 0 && P.tier >= 1u && P.tier <= (uint32_t)kTiers) {
+        seg_clock(P);  // (closes the last segment)
+        atomicAdd(&P.ctr[CT_BUSY1 + P.tier - 1u], wall_clock64());
         atomicAdd(&P.ctr[CT_WGS1 + P.tier - 1u], 1ull);
     }
 }
@@ -1153,6 +1174,7 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
     const uint32_t k = (uint32_t)rp.k, step = (uint32_t)rp.step, G = rp.G;
     const uint32_t thr0 = arm_threshold(k, G);
     RecAlloc rec_alloc;
+    wg_begin(P);
     PROF_DECL;
 
     // Segments are fetched kFetch at a time (one contended global atomic per group).  The list is
@@ -1178,7 +1200,10 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
         if (seg >= n_seg) continue;
         const uint32_t g0 = P.seg_list[seg];
         PROF_SEG_BEGIN();
-        if (lane == 0 && j == 0) heartbeat(P, g0, 0u);  // (once per fetched group of segments)
+        if (lane == 0 && j == 0) {
+            heartbeat(P, g0, 0u);
+            seg_clock(P);
+        }  // (once per fetched group of segments)
         const int c = chunk_of_uniform(rp.ch, g0);
         const uint64_t cs = rp.ch.start[c], cl = rp.ch.len[c];
         const bool seg_rev = (rp.mode_of(c) & 2u) != 0u;  // (the orientation of the chunk's pass)
@@ -1588,7 +1613,7 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
         __syncthreads();
     }
     rec_flush(rec_alloc, P, lane);
-    wg_busy(rec_alloc, P);
+    wg_busy(P);
 }
 
 // ---------------------------------------------------------------- K3b --------
@@ -2145,6 +2170,7 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
     while ((1ull << bsh) < (unsigned long long)G + k) ++bsh;
     const uint32_t cap_eff = min(cap_rt, P.cap_limit);
     RecAlloc rec_alloc;
+    wg_begin(P);
     PROF_DECL;
 
     for (uint32_t n_fetch = 0; !P.max_items || n_fetch < P.max_items; ++n_fetch) {
@@ -2154,7 +2180,10 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
         __syncthreads();
         if (seg >= n_seg) break;
         const uint32_t g0 = P.seg_list[seg];
-        if (tid == 0) heartbeat(P, g0, 0u);
+        if (tid == 0) {
+            heartbeat(P, g0, 0u);
+            seg_clock(P);
+        }
         PROF_SEG_BEGIN();
         const int c = chunk_of_uniform(rp.ch, g0);
         const uint64_t cs = rp.ch.start[c], cl = rp.ch.len[c];
@@ -2568,7 +2597,7 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
         __syncthreads();
     }
     rec_flush(rec_alloc, P, lane);
-    wg_busy(rec_alloc, P);
+    wg_busy(P);
 }
 
 // ---------------------------------------------------------------- K4c --------
@@ -2635,6 +2664,7 @@ __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
     const uint32_t cap_eff = min((uint32_t)CAP, P.cap_limit);
     const uint32_t n_lv = min((uint32_t)kLevels, P.n_levels);
     RecAlloc rec_alloc;
+    wg_begin(P);
     PROF_DECL;
 
     // arm state, one arm per (thread, layer)
@@ -2669,7 +2699,10 @@ __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
         lds_barrier();
         if (seg >= n_seg) break;
         const uint32_t g0 = P.seg_list[seg];
-        if (tid == 0) heartbeat(P, g0, 0u);
+        if (tid == 0) {
+            heartbeat(P, g0, 0u);
+            seg_clock(P);
+        }
         PROF_SEG_BEGIN();
         const int c = chunk_of_uniform(rp.ch, g0);
         const uint64_t cs = rp.ch.start[c], cl = rp.ch.len[c];
@@ -3103,7 +3136,7 @@ __global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
         lds_barrier();
     }
     rec_flush(rec_alloc, P, lane);
-    wg_busy(rec_alloc, P);
+    wg_busy(P);
 }
 
 // yardstick: sum over searched probes of ceil(log2(b_p + 1)), b_p = size of the

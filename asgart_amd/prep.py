@@ -3,7 +3,10 @@
 Mirrors reference src/bin/asgart.rs:273-471 for in-memory records (FASTA parsing
 itself is `read_records`): per-record normalisation (:289-301), chunking at
 N-runs longer than 5000 (:317-366), concatenation with per-record chunk offsets
-(:375-395) and the final '$' (:430).  Vectorised numpy; no GPU work here.
+(:375-395) and the final '$' (:430).  prepare_records is the numpy statement of it (host only: what the CPU tests
+and the oracle comparisons use); prepare_records_gpu is the product path: the same step behind the C ABI
+(asgart_prepare_data: normalisation and N-run detection as kernels over the uploaded bytes, the index built from
+the same device buffer).
 """
 from __future__ import annotations
 
@@ -73,6 +76,47 @@ def prepare_records(records: Sequence[Tuple[str, np.ndarray]], skip_masked: bool
         parts.append(seq)
     parts.append(np.frombuffer(b"$", dtype=np.uint8))
     return Prepared(np.concatenate(parts), chunks, starts)
+
+
+def prepare_records_gpu(records: Sequence[Tuple[str, np.ndarray]], skip_masked: bool = False, device: int = 0,
+                        want_text: bool = True, want_index: bool = True):
+    """prepare_data through the library (asgart_prepare_data): -> (Prepared, Index or None).  The raw records are
+    uploaded once; normalisation, chunking and the suffix sort run on the GPU; with want_text = False the prepared strand
+    stays on the device (Prepared.data is None) -- the search, the post-processing and the JSON need only the index, the
+    chunks and the map."""
+    import ctypes as C
+
+    from . import Index, _check, _ptr, load_library
+
+    L = load_library()
+    seqs = [np.ascontiguousarray(np.asarray(seq, dtype=np.uint8)) for _, seq in records]
+    n_rec = len(seqs)
+    ptrs = (C.c_void_p * max(n_rec, 1))(*[s_.ctypes.data for s_ in seqs])
+    lens = np.array([len(s_) for s_ in seqs], dtype=np.uint64)
+    total = int(lens.sum())
+    text = np.empty(total + 1, dtype=np.uint8) if want_text else None
+    cap = 1 << 16
+    h = C.c_void_p()
+    while True:
+        chunks = np.zeros((cap, 2), dtype=np.uint64)
+        nc = C.c_int64()
+        rc = L.asgart_prepare_data(ptrs, _ptr(lens), n_rec, 1 if skip_masked else 0, device, _ptr(text), _ptr(chunks), cap,
+                                   C.byref(nc), C.byref(h) if want_index else None)
+        if rc == -4 and nc.value > cap:   # ASGART_E_CAP: more chunks than room
+            cap = int(nc.value)
+            continue
+        _check(rc)
+        break
+    starts, offset = [], 0
+    for (name, _), ln in zip(records, lens.tolist()):
+        starts.append(Start(name, offset, int(ln)))
+        offset += int(ln)
+    pr = Prepared(text, [(int(a), int(b)) for a, b in chunks[:nc.value]], starts)
+    idx = None
+    if want_index:
+        idx = Index.__new__(Index)
+        idx.text, idx.n, idx.trim, idx._h = text, total + 1, None, h
+    return pr, idx
 
 
 def validate_trim(trim, strand_len: int):

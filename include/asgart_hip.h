@@ -92,6 +92,10 @@ typedef struct asgart_stats {
     uint64_t passes;          /* passes (orientations) the call ran as ONE job: 1 for a plain call; n for the passes call
                                  when it fuses them (the counters above are then sums over the passes, the timings those
                                  of the one job)                                                                 */
+    double ms_longest_segment; /* part of ms_extend: the longest time ONE automaton segment took on its workgroup -- the
+                                  serial floor of the call: src/automaton.rs:96-201 is serial per chunk, and neither more
+                                  compute units nor more GPUs shorten a segment (ms_longest_tier is the tier that FINISHED
+                                  last, which is throughput when the tier holds many segments)                    */
 } asgart_stats;
 
 typedef struct asgart_index asgart_index;
@@ -128,6 +132,25 @@ int32_t asgart_index_clone(asgart_index *src, int32_t device, asgart_index **out
 int32_t asgart_index_export(asgart_index *idx, const void **d_text, const void **d_sa, int32_t *sa_entry_bytes);
 int32_t asgart_index_create_device(const void *d_text, int64_t n, const void *d_sa, int64_t sa_len,
                                    int32_t sa_entry_bytes, int32_t device, asgart_index **out);
+/* (d_sa == NULL: the suffixes are sorted on the GPU, as asgart_index_create does for SA == NULL.) */
+
+/* Replaces prepare_data behind the FASTA reader (reference src/bin/asgart.rs:273-430; the reader itself, bio's, stays
+ * with the host): records[r] / record_lens[r] are the raw sequence bytes of record r as read (all files' records in
+ * order, :375-395).  On the GPU: alphabet normalisation (:289-301: upper-cased unless skip_masked -- then lower-case
+ * bases become N --, everything outside {A,T,G,C,N} becomes N), find_chunks_to_process per record (:317-366: cut at
+ * runs of more than 5000 N; a record without any piece left gives one chunk over all of it), concatenation and the
+ * final '$' (:430).
+ *   text_out   nullable; sum(record_lens) + 1 bytes: the prepared strand (Strand.data) for hosts that want it
+ *   chunks     (start, len) pairs in global coordinates, record order -- what asgart_search_duplications takes;
+ *              *n_chunks receives their number; with chunks_cap too small: ASGART_E_CAP and *n_chunks = the room needed
+ *              (chunks_cap = 0: count only)
+ *   index_out  nullable; an index over the prepared text, its suffixes sorted on the GPU (what asgart_index_create
+ *              would build from text_out, without the text travelling to the host and back)
+ * The strand map (record names / offsets, src/structs.rs:60-65) is the host's: offsets are the prefix sums of
+ * record_lens. */
+int32_t asgart_prepare_data(const uint8_t *const *records, const uint64_t *record_lens, int64_t n_records,
+                            int32_t skip_masked, int32_t device, uint8_t *text_out, uint64_t *chunks,
+                            int64_t chunks_cap, int64_t *n_chunks, asgart_index **index_out);
 
 /* Device memory the library keeps for reuse (released blocks of 256 MiB and more, so that an index build does not
  * pay the runtime's slow first allocation after large frees) goes back to the device: at the end of

@@ -16,7 +16,7 @@ same seeded inputs and compare against these digests ("for
 raw families CPU == HIP").
 
 Usage (CPU only; cfg4 needs ~35 GB of RAM and about an hour on 8 cores):
-    python tests/golden/make_digests.py [cfg3s] [cfg4] [cfg5h] [cfg3r] [--threads N]
+    python tests/golden/make_digests.py [cfg3s] [cfg4] [cfg5h] [cfg3r] [cfg4rq] [--threads N]
 Existing entries of digests.json for configs not named on the command line are kept.
 """
 from __future__ import annotations
@@ -49,6 +49,9 @@ CASES = {
     # chr1-sized, repeat-rich: young interspersed repeat families (synth.repeat_rich_genome) -- two probes in five
     # pass the presence filter instead of one in five; not a BASELINE.json config, a realism check of the bench
     "cfg3r": (6, 1.0, False),
+    # the realism workload of the bench (cfg4r: GRCh38-sized, repeat-rich, higher-order satellite arrays) at a quarter
+    # of its size: 770 Mb, the arrays at their full length (0.4-3 Mb each; the full-size input costs the oracle hours)
+    "cfg4rq": (7, 0.25, False),
 }
 WIDE_N = (1 << 32) - 256  # texts from this size on are indexed with 64-bit slots
 

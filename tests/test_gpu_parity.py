@@ -1327,3 +1327,59 @@ def test_fused_passes_equal_single_calls_keys_included(hiplib, name):
         assert idx.stats().as_dict()["passes"] == 1
         for j, g in zip((0, 3), got):
             assert all(np.array_equal(a, b) for a, b in zip(g, single[j]))
+
+
+@pytest.mark.parametrize("skip_masked", [False, True])
+def test_prepare_data_on_the_gpu_matches_host_and_oracle(hiplib, skip_masked):
+    """asgart_prepare_data (normalisation, chunking at N-runs > 5000 per record, '$', index from the same device buffer)
+    against the numpy statement of prepare_data AND the oracle's literal one (oracle_normalise / oracle_find_chunks):
+    records with lower-case stretches, foreign letters, N-runs of 4999 / 5000 / 5001 / 30 000 bases at the start, in the
+    middle, at the end and across a record boundary, an all-N record, an empty record; then the index it returns gives
+    the same families as one built from the host text."""
+    rng = np.random.default_rng(31)
+
+    def dna(n):
+        return np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=n)].copy()
+
+    def with_runs(n, runs):
+        s_ = dna(n)
+        low = rng.random(n) < 0.2
+        s_[low] |= 0x20                                   # soft-masked
+        odd = rng.random(n) < 0.001
+        s_[odd] = rng.choice(np.frombuffer(b"RYKMxn-*", dtype=np.uint8), size=int(odd.sum()))
+        for a, ln in runs:
+            s_[a:a + ln] = ord("N") if (a // 7) % 2 else ord("n")
+        return s_
+
+    recs = [("r0", with_runs(120_000, [(0, 4999), (20_000, 5000), (40_000, 5001), (70_000, 30_000), (115_000, 5000)])),
+            ("r1", with_runs(90_000, [(0, 6000), (50_000, 5001), (84_000, 6000)])),      # long runs at both ends
+            ("r2", np.full(7000, ord("N"), dtype=np.uint8)),                              # nothing but a long run
+            ("r3", np.zeros(0, dtype=np.uint8)),
+            ("r4", with_runs(60_000, [(59_000, 1000)])), ("r5", with_runs(60_000, [(0, 4500)])),  # 5500 N across a boundary
+            ("r6", _small_genome(seed=3, lens=(150_000,))[0][1])]
+    want = prep.prepare_records(recs, skip_masked=skip_masked)
+    got, idx = prep.prepare_records_gpu(recs, skip_masked=skip_masked)
+    try:
+        assert np.array_equal(got.data, want.data)
+        assert got.chunks == want.chunks
+        assert [(m.name, m.position, m.length) for m in got.map] == [(m.name, m.position, m.length) for m in want.map]
+        # the oracle's literal statement, record by record
+        off = 0
+        lit = []
+        for _, seq in recs:
+            t_ = oracle.normalise(seq, skip_masked)
+            assert np.array_equal(t_, want.data[off:off + len(seq)])
+            lit.extend((off + a, ln) for a, ln in oracle.find_chunks(t_))
+            off += len(seq)
+        assert lit == got.chunks
+        st = asgart_amd.RunSettings.from_cli(reverse=True, complement=True, skip_masked=skip_masked)
+        with asgart_amd.Index(want.data, None) as ref:
+            exp = ref.search_duplications_raw(want.chunks, st)
+            assert np.array_equal(ref.sa_read(0, len(want.data)), idx.sa_read(0, len(want.data)))
+        res = idx.search_duplications_raw(got.chunks, st)
+        assert np.array_equal(res[0], exp[0]) and np.array_equal(res[1], exp[1])
+    finally:
+        idx.close()
+    # the strand may stay on the device; too small a chunk array is reported with the room needed
+    got2, idx2 = prep.prepare_records_gpu(recs, skip_masked=skip_masked, want_text=False, want_index=False)
+    assert got2.data is None and idx2 is None and got2.chunks == want.chunks

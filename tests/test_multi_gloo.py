@@ -155,6 +155,66 @@ def test_gather_families_rccl_backend():
     assert q.get(timeout=5) is True
 
 
+def _nccl_replicate_worker(rank, world, port, q):
+    """replicate_index + a sharded passes call + gather_families with backend "nccl" (= RCCL) and a text of more than
+    1 GiB, so that the zero-copy views of library memory (__cuda_array_interface__) and the slab-wise broadcasts have met
+    RCCL before the first real N > 1 communicator does -- one rank: a 1-GPU box cannot hold two.  The receiving side is
+    walked by hand (what every rank but the source does inside replicate_index)."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+
+    import asgart_amd
+    from asgart_amd import multi
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    rng = np.random.default_rng(77)
+    n = (1 << 30) + (1 << 27)   # 1.125 GiB of text: two slabs of text, five of suffix array
+    g = rng.integers(0, 4, size=n, dtype=np.uint8)
+    g[900_000_000:900_060_000] = g[1_000_000:1_060_000]           # a 60-kb duplication far apart ...
+    g[1_100_000_000:1_100_030_000] = 3 - g[5_030_000:5_000_000:-1]  # ... and an inverted one (found by the -RC pass)
+    text = np.frombuffer(b"ACGT", dtype=np.uint8)[g]
+    del g
+    text = np.concatenate([text, np.frombuffer(b"$", dtype=np.uint8)])
+    chunks = [(0, len(text) - 1)]
+    sts = [asgart_amd.RunSettings.from_cli(reverse=rc, complement=rc) for rc in (False, True)]
+    idx = asgart_amd.Index(text, None, device=0)
+    same = multi.replicate_index(idx, dist, 0)       # the source's side: broadcasts 1-GiB views of the library's buffers
+    ok = same is idx
+    t_ptr, sa_ptr, width = idx.export()
+    text_t = torch.as_tensor(multi._DeviceBytes(t_ptr, idx.n), device="cuda:0").clone()
+    sa_t = torch.as_tensor(multi._DeviceBytes(sa_ptr, idx.n * width), device="cuda:0").clone()
+    for t in (text_t, sa_t):
+        for o in range(0, t.numel(), 1 << 30):
+            dist.broadcast(t[o:o + (1 << 30)], src=0)
+    torch.cuda.synchronize()
+    rep = asgart_amd.Index.from_device(text_t.data_ptr(), idx.n, sa_t.data_ptr(), width, device=0)
+    del text_t, sa_t
+    whole = idx.search_duplications_passes(chunks, sts)
+    parts = rep.search_duplications_passes(chunks, sts, 0, 1, with_keys=True)
+    for w_, p_ in zip(whole, parts):
+        got = multi.gather_families(p_[0], p_[1], dist, device="cuda:0", keys=p_[2])
+        ok = ok and np.array_equal(got[0], w_[0]) and np.array_equal(got[1], w_[1]) and len(w_[1]) > 0
+    rep.close()
+    idx.close()
+    q.put(bool(ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_replicate_index_and_gather_over_rccl_with_gib_slabs():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_replicate_worker, args=(0, 1, _free_port(), q))
+    p.start()
+    p.join(600)
+    assert p.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
 @pytest.mark.gpu
 def test_bench_launches_its_own_ranks():
     """`python bench.py --gpus 2` with no launcher around it starts two ranks itself (fresh interpreters, before any
