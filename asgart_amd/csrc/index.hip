@@ -63,6 +63,7 @@ const OptDesc kOptions[] = {
     {"k7", &Options::k7, 0, 127},
     {"lazy_aux", &Options::lazy_aux, 0, 1},
     {"fuse_passes", &Options::fuse_passes, 0, 1},
+    {"bucket", &Options::bucket, 0, 1},
     {"dense3", &Options::dense3, 0, 1 << 20},
     {"dense6", &Options::dense6, 0, 1 << 20},
     {"dense_min", &Options::dense_min, 0, 1 << 30},

@@ -82,6 +82,8 @@ struct RunParams {
     const uint64_t *pbits[4];  // ... its answers laid out by TEXT POSITION (bit p: the probe that covers text[p .. p + k) in
                                // this orientation passes the filter); null: the kernels test the hashed filter
     int flt_bits;
+    uint32_t bucket_lookup;  // option bucket: 1 = small prefix-table buckets are looked up with keys and suffix-array entries
+                             // requested together (probe_count_kernel)
     __host__ __device__ inline uint32_t pass_of(int c) const {
         if (n_passes <= 1u) return 0u;
         const uint32_t uc = (uint32_t)c;
@@ -291,6 +293,12 @@ struct Options {
     int64_t k7 = 8;                 // bit t set (t = 3..6): tier t runs the arm kernel with a control wave (extend_k7_dev.hpp) instead of K6 / K4c. Default: tier 3 only -- the long DENSE segments (option dense3), where its shorter per-probe chain counts; measured in the other tiers (k7 = 120) it loses: a quarter / an eighth of a 256- / 512-thread workgroup holds no arms and a sparse probe costs two barriers instead of one wave's solo run
     int64_t k8 = 1;                 // 1: the tiers of option k7 run the one-barrier variant (extend_k8_dev.hpp: the new arms' first offers are
                                     // made by a ranking wave, a planning wave writes the commands; 14 arm waves instead of 15); 0: K7
+    int64_t bucket = 0;             // probe search: 1 = the keys AND the suffix-array entries of a small prefix-table bucket (<= 8 slots) are
+                                    // requested together and the equal range / kept count come out of registers (one dependent HBM round
+                                    // trip fewer per lookup); 0 = bisection over the keys, then the entries of the equal range.
+                                    // Measured at GRCh38 size (round 5) and left off: 29.4 instead of 26.7 ms for the two passes of a
+                                    // step -- the kernel is bound by the SECTOR RATE of its gathers (0.7 of the measured ceiling), not by
+                                    // the length of its chain: the entries of the keys that turn out unequal are sectors it did not need
     int64_t fuse_passes = 1;        // 1: asgart_search_duplications_passes runs passes that differ in orientation only as ONE job (one
                                     // front over all their probes, one launch per extension tier over the merged segment list);
                                     // 0: as pipelined single-pass calls on the two call contexts (what sharded calls still do)

@@ -343,6 +343,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
     rp.pass_chunks = (uint32_t)n_chunks_pass;
     rp.modes = 0;
     rp.flt_bits = idx->filter_bits;
+    rp.bucket_lookup = opt.bucket ? 1u : 0u;
     for (int p = 0; p < 4; ++p) {
         rp.flt[p] = rp.pbits[p] = nullptr;
         if (p >= n_passes) continue;

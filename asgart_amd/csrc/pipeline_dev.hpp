@@ -165,6 +165,7 @@ __global__ __launch_bounds__(kProbeThreads) void probe_count_kernel(IndexView<Sl
     const int c0 = chunk_of_uniform(rp.ch, gb);
     // (probes longer than one key word -- rare -- take the per-thread path as well)
     const bool uniform = rp.ch.pbase[c0 + 1] > g_last && k <= kMaxKey;
+    const bool opt_bucket = rp.bucket_lookup != 0u;
     uint32_t n_rej = 0;
     // one probe's lookup: SA interval, filtered count of a small interval (large ones are marked for the wave kernels)
     auto lookup = [&](uint32_t g_, uint64_t q_, uint64_t q2_, uint64_t i_, uint64_t s_, uint64_t L_, uint32_t md_) {
@@ -174,6 +175,44 @@ __global__ __launch_bounds__(kProbeThreads) void probe_count_kernel(IndexView<Sl
         pr.p = reverse ? ix.text + s_ + L_ - 1u - i_ : ix.text + s_ + i_;
         pr.dir = reverse ? -1 : 1;
         pr.comp = complement;
+        // ---- small buckets: keys AND suffix-array entries of the whole bucket requested together ----------------------
+        // The chain of a lookup is prefix table -> keys of the bucket -> suffix-array entries of the equal keys: three
+        // dependent HBM round trips behind the window.  The prefix table (d = 15 at GRCh38 size) leaves a bucket of three
+        // slots on average, and the suffix-array entries of a bucket sit at the SAME slot numbers as its keys: both are
+        // requested at once, the equal range and the kept count come out of registers -- one round trip fewer.
+        // (One-word probes of an untrimmed index outside the text-tail corner; everything else takes kmer_range.)
+        constexpr int kBucketRegs = 8;
+        uint32_t pfx = 0;
+        if (opt_bucket && !ix.trim && !ix.k2 && !is_tail_corner(ix, q_) && prefix_index(q_, ix.kk, ix.d, pfx)) {
+            const uint64_t lo0 = ix.ptab[pfx], hi0 = ix.ptab[pfx + 1];
+            cb.rd(2 * sizeof(SlotT));
+            if (hi0 - lo0 <= (uint64_t)kBucketRegs) {
+                uint64_t kv[kBucketRegs];
+                SlotT sv[kBucketRegs];
+#pragma unroll
+                for (int j = 0; j < kBucketRegs; ++j) {
+                    const bool in = lo0 + (uint64_t)j < hi0;
+                    kv[j] = in ? ix.keys[lo0 + j] : ~0ull;
+                    sv[j] = in ? ix.sa[lo0 + j] : (SlotT)0;
+                    if (in) cb.rd(8 + sizeof(SlotT));
+                }
+                uint32_t below = 0, upto = 0, cnt = 0;
+#pragma unroll
+                for (int j = 0; j < kBucketRegs; ++j) {
+                    below += kv[j] < q_ ? 1u : 0u;
+                    upto += kv[j] <= q_ ? 1u : 0u;   // (the padding ~0 is above every key: 63 bits)
+                    cnt += (kv[j] == q_ && keep_hit((uint64_t)sv[j], i_, s_, L_, reverse)) ? 1u : 0u;
+                }
+                const uint32_t raw = upto - below;
+                if (!COUNT) {
+                    p_lo[g_] = (SlotT)(lo0 + below);
+                    p_raw[g_] = raw;
+                    p_filt[g_] = cnt > rp.C ? kSkipCard : cnt;
+                }
+                cb.wr(sizeof(SlotT) + 4 + 4);
+                return;
+            }
+        }
         const bool all_occurrences = kmer_range(ix, q_, q2_, pr, lo, hi, cb);
         const uint64_t raw = hi - lo;
         if (!COUNT) {

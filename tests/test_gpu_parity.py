@@ -1383,3 +1383,28 @@ def test_prepare_data_on_the_gpu_matches_host_and_oracle(hiplib, skip_masked):
     # the strand may stay on the device; too small a chunk array is reported with the room needed
     got2, idx2 = prep.prepare_records_gpu(recs, skip_masked=skip_masked, want_text=False, want_index=False)
     assert got2.data is None and idx2 is None and got2.chunks == want.chunks
+
+
+@pytest.mark.parametrize("name", ["dense_repeats", "masked", "k12", "k21_odd"])
+def test_bucket_lookup_option_same_results(hiplib, name):
+    """Option bucket = 1 (off by default: measured slower at GRCh38 size): the probe search requests the keys and the
+    suffix-array entries of a small prefix-table bucket together and takes the equal range and the kept count out of
+    registers.  Per-probe hit rows (status, offsets, hits in suffix-array order) and families must equal the default's,
+    in every orientation, with 32- and 64-bit slots."""
+    pr, cli = _battery_case(name)
+    for wide in ("0", "1"):
+        os.environ["ASGART_FORCE_WIDE"] = wide
+        try:
+            with asgart_amd.Index(pr.data, None) as idx:
+                for reverse, complement in MODES:
+                    st = asgart_amd.RunSettings.from_cli(reverse=reverse, complement=complement, **cli)
+                    idx.set_option("bucket", 0)
+                    ref_f = idx.search_duplications_raw(pr.chunks, st)
+                    ref_h = idx.probe_hits(pr.chunks, st)
+                    idx.set_option("bucket", 1)
+                    got_f = idx.search_duplications_raw(pr.chunks, st)
+                    got_h = idx.probe_hits(pr.chunks, st)
+                    assert all(np.array_equal(a, b) for a, b in zip(ref_f, got_f)), (name, wide, reverse, complement)
+                    assert all(np.array_equal(a, b) for a, b in zip(ref_h, got_h)), (name, wide, reverse, complement)
+        finally:
+            os.environ.pop("ASGART_FORCE_WIDE", None)
