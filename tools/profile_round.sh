@@ -19,6 +19,9 @@ fi
 # use): every launch of the search kernels in them is then a steady-state launch, and the per-launch averages of the
 # counters describe the kernels of the timed region, not a mix with the two unfiltered launches of a cold start.
 export ASGART_LAZY_AUX=0
+# ... and every step is issued through the passes call only (no back-to-back probe step with its single-pass launches):
+# a launch of the search kernels is then always the passes of a step as ONE job
+export ASGART_BENCH_MODE=library
 PB="--steps 2 --warmup 1 --no-cpu-baseline"
 rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/${P}_stats" -o run -- python3 bench.py --workload "$WL" $PB > "$OUT/${P}_stats_bench.json" 2> "$OUT/${P}_stats_err.log"
 echo "stats rc=$?"

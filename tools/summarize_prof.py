@@ -83,8 +83,15 @@ if search > 0:
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     lib = os.environ.get("ASGART_LIB") or os.path.join(root, "asgart_amd", "libasgart_hip.so")
     build = hashlib.sha256(open(lib, "rb").read()).hexdigest()[:12] if os.path.exists(lib) else None
+    ppl = 1
+    try:   # passes per launch of the profiled runs (the passes call fuses the passes of a step into one job)
+        sb = open(os.path.join(out, f"{tag}_{workload}_stats_bench.json")).read().strip().splitlines()[-1]
+        ppl = int(json.loads(sb)["roofline"].get("passes_per_launch", 1))
+    except Exception:
+        pass
     allw[workload] = {
-        "build": build,   # sha256[:12] of the library the passes ran (bench.py compares it with the one it loads)
+        "build": build,
+        "passes_per_launch": ppl,   # sha256[:12] of the library the passes ran (bench.py compares it with the one it loads)
         "traffic_bytes_per_launch": int(search),
         "kernel_ms_per_launch": round(pmc_ms, 4),
         "stats_kernel_ms_per_launch": None if stats_ms is None else round(stats_ms, 4),
@@ -92,7 +99,7 @@ if search > 0:
                   f"passes, kernels serialised) and profiles/{tag}_{workload}_kernel_stats.csv (--kernel-trace --stats of "
                   "the default bench run)",
     }
-    allw["_note"] = ("per workload: HBM-side bytes per launch (= per pass) of probe_count_kernel + collect_pending_kernel + big_count_kernel + rank_count_kernel = "
+    allw["_note"] = ("per workload: HBM-side bytes per launch (= passes_per_launch passes: the passes call runs the passes of a step as one job) of probe_count_kernel + collect_pending_kernel + big_count_kernel + rank_count_kernel = "
                      "(FETCH_SIZE + WRITE_SIZE) KB * 1024; kernel_ms_per_launch = the two kernels' durations in those "
                      "PMC passes; stats_kernel_ms_per_launch = their rocprofv3 --stats averages in the un-instrumented "
                      "bench run (passes overlapped).  Narrow 4-8 byte gathers: FETCH_SIZE is used as reported (no x2); bench.py adds half the bytes of the "
