@@ -177,7 +177,10 @@ struct AllocTimer {
 // index of the device is destroyed (live counts below) and by asgart_trim_cache -- other allocators on the GPU (the
 // host application's tensors, RCCL buffers, other processes) cannot see what sits here.
 struct BlockCache {
-    static constexpr size_t kCacheMin = (size_t)256 << 20, kCacheCap = (size_t)96 << 30;
+    // (the cap holds ALL the scratch of a GRCh38-sized suffix sort, 127 GB: what a build releases beyond the cap goes back to
+    // the driver at once, and on most boxes of the pool the NEXT hipMalloc then pays 20-30 ms for every GiB that was freed --
+    // ASGART_TRACE_ALLOC=1: "hipMalloc 6.4 GiB: 2403 ms" behind 82 GiB of frees)
+    static constexpr size_t kCacheMin = (size_t)256 << 20, kCacheCap = (size_t)160 << 30;
     struct Dev {
         std::mutex mu;
         std::vector<std::pair<void *, size_t>> blocks;
@@ -190,14 +193,14 @@ struct BlockCache {
         (void)hipGetDevice(&id);
         return d[(id >= 0 && id < 16) ? id : 0];
     }
-    // a cached block of at least `bytes` that wastes at most a quarter; nullptr: none
-    static void *take(size_t bytes, size_t *cap) {
+    // a cached block of at least `bytes` that wastes at most a quarter (waste_pct = 25); nullptr: none
+    static void *take(size_t bytes, size_t *cap, unsigned waste_pct = 25) {
         if (bytes < kCacheMin) return nullptr;
         Dev &d = dev();
         std::lock_guard<std::mutex> lk(d.mu);
         size_t best = (size_t)-1;
         for (size_t i = 0; i < d.blocks.size(); ++i)
-            if (d.blocks[i].second >= bytes && d.blocks[i].second <= bytes + bytes / 4 &&
+            if (d.blocks[i].second >= bytes && d.blocks[i].second <= bytes + bytes / 100 * waste_pct &&
                 (best == (size_t)-1 || d.blocks[i].second < d.blocks[best].second))
                 best = i;
         if (best == (size_t)-1) return nullptr;
@@ -325,6 +328,7 @@ inline void dev_free(void *p) {
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    bool view = false;  // a piece of another buffer (Workspace::arena): nothing to free; outgrown, it gets memory of its own
     int32_t reserve(size_t bytes) {
         if (bytes <= cap) return 0;
         release();
@@ -355,12 +359,13 @@ struct DevBuf {
         return 0;
     }
     void release() {
-        if (p && !BlockCache::give(p, cap)) {
+        if (p && !view && !BlockCache::give(p, cap)) {
             AllocTimer tm("hipFree  ", cap);
             (void)hipFree(p);
         }
         p = nullptr;
         cap = 0;
+        view = false;
     }
     template <class T>
     T *as() const {

@@ -62,7 +62,8 @@ const OptDesc kOptions[] = {
     {"kfilter_bits", &Options::kfilter_bits, 0, 34},
     {"k7", &Options::k7, 0, 127},
     {"lazy_aux", &Options::lazy_aux, 0, 1},
-    {"fuse_passes", &Options::fuse_passes, 0, 1},
+    {"fuse_passes", &Options::fuse_passes, 0, 2},
+    {"fuse_pole_pct", &Options::fuse_pole_pct, 1, 1000},
     {"bucket", &Options::bucket, 0, 1},
     {"dense3", &Options::dense3, 0, 1 << 20},
     {"dense6", &Options::dense6, 0, 1 << 20},
@@ -72,6 +73,7 @@ const OptDesc kOptions[] = {
     {"pass_gate_ms", &Options::pass_gate_ms, 0, 100000},
     {"sparse_to6", &Options::sparse_to6, 0, 512},
     {"prewarm", &Options::prewarm, 0, 1},
+    {"cache_calls", &Options::cache_calls, 0, 1000000},
     {"watchdog_s", &Options::watchdog_s, 0, 86400},
     {"test_stall_s", &Options::test_stall_s, 0, 60},
     {"tier_streams", &Options::tier_streams, 1111111, 7777777},
@@ -554,16 +556,17 @@ static void free_filters(asgart_index *idx) {
     idx->filter_bits = 0;
 }
 
+// (the prefix table stays: its size depends on the text length alone unless k is tiny, and it was allocated when the
+// index was created -- see prealloc_ptab; asgart_index_destroy frees it)
 static void free_k_specific(asgart_index *idx) {
     if (idx->d_keys) dev_free(idx->d_keys);
-    if (idx->d_ptab) dev_free(idx->d_ptab);
     if (idx->d_c8lo) dev_free(idx->d_c8lo);
     if (idx->d_c8hi) dev_free(idx->d_c8hi);
     if (idx->d_sap) dev_free(idx->d_sap);
     idx->d_sap = nullptr;
     free_filters(idx);
     idx->d_keys = nullptr;
-    idx->d_ptab = idx->d_c8lo = idx->d_c8hi = nullptr;
+    idx->d_c8lo = idx->d_c8hi = nullptr;
     idx->filter_bits = 0;
     idx->k = 0;
     idx->sap_tried = false;
@@ -587,6 +590,22 @@ static int choose_depth(int64_t n, uint64_t k, int64_t forced) {
     if (d > 15) d = 15;  // 4^16 entries would overflow the 32-bit table index
     if ((uint64_t)d > k) d = (int)k;
     return d;
+}
+
+// The prefix table (4^d + 1 slots: 4 GiB at GRCh38 size) is allocated when the index is CREATED, before the suffix sorter
+// takes and gives back its 127 GB of scratch: the first allocation that finds no block of its size in the block cache after
+// that much memory went back to the driver takes more than a second on many boxes of the pool (ASGART_TRACE_ALLOC=1:
+// "hipMalloc 4.0 GiB: 1295.6 ms" -- it was 1.3 of the 1.4 s that "keys + tables" took there, against 0.13 s on the others).
+static void prealloc_ptab(asgart_index *idx) {
+    if (idx->trimmed || idx->d_ptab) return;
+    const int d = choose_depth(idx->n_sa, (uint64_t)kMaxKey, idx->opt.ptab_depth);
+    const uint64_t entries = (1ull << (2 * d)) + 1;
+    if (dev_malloc(&idx->d_ptab, entries * (idx->wide ? 8 : 4)) != hipSuccess) {
+        (void)hipGetLastError();
+        idx->d_ptab = nullptr;  // (asgart_index_prepare tries again)
+        return;
+    }
+    idx->ptab_entries = entries;
 }
 
 // true iff every byte of the device text is one of {$,A,C,G,N,T}
@@ -638,7 +657,7 @@ static int32_t build_sap_locked(asgart_index *idx, uint64_t k) {
         idx->d_sap = nullptr;
         if (rc_rank != ASGART_E_OOM) return rc_rank;
     }
-    BlockCache::trim();  // (the sort's scratch)
+    if (idx->opt.cache_calls == 0 || idx->calls_total >= (uint64_t)idx->opt.cache_calls) BlockCache::trim();  // (the sort's scratch)
     return 0;
 }
 
@@ -696,7 +715,14 @@ int32_t index_prepare(asgart_index *idx, uint64_t k) {
     const int d = idx->trimmed ? 1 : choose_depth(idx->n_sa, kk, idx->opt.ptab_depth);
     const uint64_t entries = (1ull << (2 * d)) + 1;
     HIP_TRY(dev_malloc((void **)&idx->d_keys, (n_sa + 16) * sizeof(uint64_t)));
-    HIP_TRY(dev_malloc(&idx->d_ptab, entries * slot));
+    if (idx->d_ptab && idx->ptab_entries < entries) {  // (allocated at creation for another depth)
+        dev_free(idx->d_ptab);
+        idx->d_ptab = nullptr;
+    }
+    if (!idx->d_ptab) {
+        HIP_TRY(dev_malloc(&idx->d_ptab, entries * slot));
+        idx->ptab_entries = entries;
+    }
     HIP_TRY(dev_malloc(&idx->d_c8lo, (size_t)kCacheEntries * slot));
     HIP_TRY(dev_malloc(&idx->d_c8hi, (size_t)kCacheEntries * slot));
     hipStream_t s = idx->ctx[0].stream;
@@ -772,8 +798,11 @@ int32_t index_prepare(asgart_index *idx, uint64_t k) {
         const uint64_t step = k / 2 ? k / 2 : 1;
         const uint64_t W = std::min<uint64_t>((uint64_t)idx->n / step + 1, 0xFFFFFF00ull);
         // (the first context for TWO passes: the direct and the -RC run of a passes call are one job over both passes' probes)
+        uint64_t Wc[kNumCtx];
+        for (int c = 0; c < kNumCtx; ++c) Wc[c] = c == 0 ? std::min<uint64_t>(2 * W, 0xFFFFFF00ull) : W;
+        (void)carve_probe_workspace(idx, Wc);  // (out of one block the suffix sorter has just released, when there is one)
         for (int c = 0; c < kNumCtx; ++c)
-            if (reserve_probe_workspace(idx, idx->ctx[c], c == 0 ? std::min<uint64_t>(2 * W, 0xFFFFFF00ull) : W) != 0) {
+            if (reserve_probe_workspace(idx, idx->ctx[c], Wc[c]) != 0) {
                 (void)hipGetLastError();
                 break;
             }
@@ -792,8 +821,8 @@ int32_t index_prepare(asgart_index *idx, uint64_t k) {
         }
         lap("workspace of both contexts");
     }
-    // the sorter's released scratch is of no use to the search calls (their buffers are a tenth of its blocks)
-    BlockCache::trim();
+    // the sorter's released scratch goes back to the device when the index has answered `cache_calls` calls (run_search_passes)
+    if (idx->opt.cache_calls == 0) BlockCache::trim();
     idx->ms_prepare =
         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return 0;
@@ -1065,11 +1094,14 @@ void asgart_index_destroy(asgart_index *idx) {
     if (!bounded_call(limit, [idx, dev]() {
             (void)hipSetDevice(dev);
             free_k_specific(idx);
+            if (idx->d_ptab) dev_free(idx->d_ptab);
             if (idx->d_text) dev_free(idx->d_text);
             if (idx->d_sa) dev_free(idx->d_sa);
+            idx->d_ptab = nullptr;
             idx->d_text = nullptr;
             idx->d_sa = nullptr;
             for (auto &cx : idx->ctx) cx.ws.release_all();  // (the record-ordering buffers used to be missing from a list kept here)
+            idx->ws_arena.release();
         })) {
         give_up("releasing the device buffers");
         return;
@@ -1140,6 +1172,7 @@ static int32_t index_create_impl(const uint8_t *T, int64_t n, const int64_t *SA,
     int32_t rc = [&]() -> int32_t {
         for (auto &cx : idx->ctx) RC_TRY(create_ctx_streams(cx));
         HIP_TRY(dev_malloc((void **)&idx->d_text, (size_t)n + 64));
+        prealloc_ptab(idx);
         HIP_TRY(hipMemsetAsync(idx->d_text + n, 0, 64, idx->ctx[0].stream));
         HIP_TRY(hipMemcpyAsync(idx->d_text, T, (size_t)n, hipMemcpyHostToDevice, idx->ctx[0].stream));
         // validate the alphabet on the device
@@ -1344,6 +1377,7 @@ int32_t asgart_index_create_device(const void *d_text, int64_t n, const void *d_
         const size_t slot = wide ? 8 : 4;
         HIP_TRY(dev_malloc((void **)&idx->d_text, (size_t)n + 64));
         HIP_TRY(dev_malloc(&idx->d_sa, ((size_t)n + 16) * slot));
+        prealloc_ptab(idx);
         HIP_TRY(hipMemsetAsync(idx->d_text + n, 0, 64, s));
         HIP_TRY(hipMemcpyAsync(idx->d_text, d_text, (size_t)n, hipMemcpyDeviceToDevice, s));
         if (d_sa) HIP_TRY(hipMemcpyAsync(idx->d_sa, d_sa, (size_t)n * slot, hipMemcpyDeviceToDevice, s));

@@ -299,9 +299,15 @@ struct Options {
                                     // Measured at GRCh38 size (round 5) and left off: 29.4 instead of 26.7 ms for the two passes of a
                                     // step -- the kernel is bound by the SECTOR RATE of its gathers (0.7 of the measured ceiling), not by
                                     // the length of its chain: the entries of the keys that turn out unequal are sectors it did not need
-    int64_t fuse_passes = 1;        // 1: asgart_search_duplications_passes runs passes that differ in orientation only as ONE job (one
-                                    // front over all their probes, one launch per extension tier over the merged segment list);
-                                    // 0: as pipelined single-pass calls on the two call contexts (what sharded calls still do)
+    int64_t fuse_passes = 1;        // asgart_search_duplications_passes, passes that differ in orientation only: 2 = always as ONE job (one
+                                    // front over all their probes, one launch per extension tier over the merged segment list); 0 = always
+                                    // as pipelined single-pass calls on the two call contexts (what sharded calls do); 1 = the first call
+                                    // with given settings runs as one job, and what it measures decides for the calls after it: one job
+                                    // while the extension is bound by compute-unit time (the longest single segment below fuse_pole_pct
+                                    // per cent of the extension: GRCh38-shaped 230 vs 255 ms), pipelined calls when ONE segment is the
+                                    // extension (a megabase higher-order array, a chromosome against its homologue: the other pass's
+                                    // front then hides beside it -- 393 vs 466 ms, 2 071 vs 2 178 ms)
+    int64_t fuse_pole_pct = 88;
     int64_t lazy_aux = 1;           // 1: the presence filter of an orientation is built when that orientation is searched the SECOND time, the
                                     // position-sorted lists when a search call has had a predecessor: they cost 0.18 s per orientation / 0.2 s
                                     // at GRCh38 size and save 0.03 / 0.006 s per pass -- a host that runs every orientation once per index
@@ -315,6 +321,12 @@ struct Options {
                                     // bound says (0: only the long ones, option long3)
     int64_t dense6 = 32;            // with k7 in tier 3: segments of ANY length whose arm bound sends them to tier 6 go to tier 3 instead with at
                                     // least this many hits per processed probe on average (0: off)
+    int64_t cache_calls = 2;        // the blocks an index build released stay in the block cache until the index has answered this many
+                                    // search calls (then, at its destruction, on an allocation failure and by asgart_trim_cache they go
+                                    // back to the device): giving ~100 GB back costs the next allocation of the process 20-30 ms per
+                                    // GiB on most boxes of the pool -- 1.3-2.4 s of a cold GRCh38-sized run when it happened at the end of
+                                    // asgart_index_prepare (0: there, as in round 4); the second call builds the position-sorted lists
+                                    // and the presence filters out of those blocks
     int64_t prewarm = 1;            // 1: asgart_index_prepare also reserves the per-probe workspace of both call contexts (sized for an
                                     // unsharded call over the whole text) and starts the worker thread of the passes call, so that the first
                                     // search calls allocate nothing chip-sized; 0: everything on first use (hosts that only issue sharded calls)
@@ -395,6 +407,7 @@ struct asgart_index {
     int d = 0;
     uint64_t *d_keys = nullptr;
     void *d_ptab = nullptr;
+    uint64_t ptab_entries = 0;  // slots the allocation of d_ptab holds (it is made when the index is created)
     void *d_c8lo = nullptr;
     void *d_c8hi = nullptr;
     void *d_sap = nullptr;   // position-sorted occurrence lists (IndexView::sap), or null
@@ -418,6 +431,14 @@ struct asgart_index {
     int last_ctx = 0;  // context of the most recent search call (asgart_get_stats)
     std::mutex mu;
     std::condition_variable cv;
+    // what the last fused passes call measured, and under which settings (option fuse_passes = 1)
+    struct FuseVerdict {
+        uint64_t k = 0, M = 0, C = 0, modes = 0;
+        uint32_t G = 0;
+        int32_t n_passes = 0;
+        bool pipeline = false;
+    } fuse_verdict;
+    asgart::DevBuf ws_arena;  // the block the call contexts' per-probe buffers were carved from (carve_probe_workspace), or empty
     std::mutex pass_mu;  // one asgart_search_duplications_passes call at a time per index
     std::vector<std::unique_ptr<asgart::PassWorker>> pass_workers;
 
@@ -510,6 +531,9 @@ extern thread_local bool tl_owns_pass_mu;
 int32_t index_prepare(asgart_index *idx, uint64_t k);
 // per-probe workspace of one call context for a window of W probes (pipeline.hip; also what run_search_t reserves)
 int32_t reserve_probe_workspace(asgart_index *idx, SearchCtx &cx, uint64_t W);
+// asgart_index_prepare: the per-probe workspace of ALL call contexts (context c for Wc[c] probes) carved out of ONE block that
+// the suffix sorter has just released, if the block cache holds one of the right size (false: nothing done)
+bool carve_probe_workspace(asgart_index *idx, const uint64_t *Wc);
 int32_t index_prepare_filter(asgart_index *idx, uint64_t k, int mode);  // mode = reverse * 2 + complement
 int32_t index_prepare_sap(asgart_index *idx, uint64_t k);
 int32_t run_search_passes(asgart_index *idx, const uint64_t *chunks, int64_t n_chunks,

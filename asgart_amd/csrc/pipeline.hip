@@ -215,6 +215,44 @@ int32_t reserve_probe_workspace(asgart_index *idx, SearchCtx &cx, uint64_t W) {
     return 0;
 }
 
+// On the slow boxes of the pool every first allocation costs ~30 ms per GiB: the nine buffers of 1-5 GB that the two
+// contexts' workspace used to allocate at asgart_index_prepare were 0.8 s of a cold run there.  The sorter's key
+// buffers (n 64-bit words each) are in the block cache at that moment: one of them holds both contexts' workspace.
+bool carve_probe_workspace(asgart_index *idx, const uint64_t *Wc) {
+    if (idx->ws_arena.p) return false;
+    size_t off = 0;
+    struct Piece {
+        DevBuf *b;
+        size_t off, bytes;
+    };
+    std::vector<Piece> pieces;
+    for (int c = 0; c < kNumCtx; ++c) {
+        Workspace &w = idx->ctx[c].ws;
+        const uint64_t W = Wc[c];
+        const uint64_t n_blk = (W + kScanTile - 1) / kScanTile;
+        DevBuf *bufs[7] = {&w.p_lo, &w.p_raw, &w.p_filt, &w.row_off, &w.blk, &w.big_list, &w.rank_list};
+        const size_t want[7] = {(size_t)W * (idx->wide ? 8 : 4), (size_t)W * 4, (size_t)W * 4, ((size_t)W + 1) * 8,
+                                (size_t)n_blk * sizeof(ScanEl), (size_t)W * 4, (size_t)W * 4};
+        for (int j = 0; j < 7; ++j) {
+            if (bufs[j]->p) return false;  // (something is reserved already: leave everything as it is)
+            const size_t sz = (want[j] + 4095) & ~(size_t)4095;
+            pieces.push_back(Piece{bufs[j], off, sz});
+            off += sz;
+        }
+    }
+    size_t cap = 0;
+    void *p = BlockCache::take(off, &cap, 30);
+    if (!p) return false;
+    idx->ws_arena.p = p;
+    idx->ws_arena.cap = cap;
+    for (const Piece &pc : pieces) {
+        pc.b->p = static_cast<char *>(p) + pc.off;
+        pc.b->cap = pc.bytes;
+        pc.b->view = true;
+    }
+    return true;
+}
+
 // One job over the probes of n_passes passes (orientations) of the same chunk list: sts[p] differ in reverse /
 // complement only (the caller has checked); fams[p] receives pass p's families (null: none wanted -- the CSR surface).
 template <class SlotT>
@@ -647,8 +685,9 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             HIP_TRY(hipMemsetAsync(d_ctr + CT_NF, 0, (size_t)(CT_COUNT - CT_NF) * 8, s));  // NF, cursors, overflow counts
             HIP_TRY(hipMemsetAsync(d_ctr + CT_EARLY_N, 0, 4 * 8, s));                       // early cascade counts + cursors
             HIP_TRY(hipMemsetAsync(d_ctr + CT_BUSY1, 0, (size_t)(CT_COUNT - CT_BUSY1) * 8, s));
-            HIP_TRY(hipEventRecord(cx.ev[7], s));
             RC_TRY(w.seg_slots.reserve((size_t)8 * 4096 * 8));
+            HIP_TRY(hipMemsetAsync(w.seg_slots.p, 0, (size_t)8 * 4096 * 8, s));
+            HIP_TRY(hipEventRecord(cx.ev[7], s));
             ExtParams<SlotT> ep;
             ep.rp = rp;
             ep.p_filt = p_filt;
@@ -1208,10 +1247,13 @@ int32_t run_search_passes(asgart_index *idx, const uint64_t *chunks, int64_t n_c
                                     status_out, rowoff_out, hits_out);
     cx.progress = nullptr;
     cx.gate = nullptr;
+    bool trim_now = false;
     {
         std::lock_guard<std::mutex> lk(idx->mu);
         ++idx->calls_total;
+        trim_now = idx->opt.cache_calls > 0 && idx->calls_total == (uint64_t)idx->opt.cache_calls;
     }
+    if (trim_now) BlockCache::trim();  // (option cache_calls: what the index build released goes back to the device now)
     if (rc == 0 && fams && n_shards == 1 && n_passes == 1) {
         // what asgart_search_duplications_passes orders by when it pipelines single-pass calls: the shortest extension seen
         // for the orientation (a call that shared the chip with another one measures longer, and the order must not flip
@@ -1384,7 +1426,7 @@ int32_t asgart_search_duplications_passes_shard(asgart_index *idx, const uint64_
     // kept for sharded calls and passes with different settings -- the second pass's front crawled behind the first
     // one's persistent extension workgroups: 117 ms instead of 28 at GRCh38 size.)
     {
-        bool fusable = idx->opt.fuse_passes != 0 && n_passes >= 2 && n_passes <= 4 && n_shards == 1;
+        bool fusable = idx->opt.fuse_passes != 0 && n_passes >= 2 && n_passes <= 4 && n_shards == 1;  // (option fuse_passes)
         for (int32_t j = 1; fusable && j < n_passes; ++j)
             fusable = settings[j].probe_size == settings[0].probe_size && settings[j].max_gap_size == settings[0].max_gap_size &&
                       settings[j].min_duplication_length == settings[0].min_duplication_length &&
@@ -1395,6 +1437,18 @@ int32_t asgart_search_duplications_passes_shard(asgart_index *idx, const uint64_
             for (int64_t c = 0; c < n_chunks && step; ++c)
                 P1 += probes_in_chunk(chunks[2 * c + 1], k, step, settings[0].min_duplication_length);
             fusable = step && P1 * (uint64_t)n_passes < 0xFFFFFF00ull;
+        }
+        uint64_t modes_sig = 0;
+        for (int32_t j = 0; fusable && j < n_passes; ++j)
+            modes_sig = modes_sig * 4u + ((settings[j].reverse ? 2u : 0u) | (settings[j].complement ? 1u : 0u));
+        auto same_as_verdict = [&]() {
+            const asgart_index::FuseVerdict &v = idx->fuse_verdict;
+            return v.n_passes == n_passes && v.k == settings[0].probe_size && v.G == settings[0].max_gap_size &&
+                   v.M == settings[0].min_duplication_length && v.C == settings[0].max_cardinality && v.modes == modes_sig;
+        };
+        if (fusable && idx->opt.fuse_passes == 1) {  // what the last fused call with these settings measured decides
+            std::lock_guard<std::mutex> lk(idx->mu);
+            if (same_as_verdict() && idx->fuse_verdict.pipeline) fusable = false;
         }
         if (fusable) {
             std::lock_guard<std::mutex> pass_lock(idx->pass_mu);
@@ -1418,6 +1472,22 @@ int32_t asgart_search_duplications_passes_shard(asgart_index *idx, const uint64_
                 return rc;
             }
             for (int32_t j = 0; j < n_passes; ++j) out[j] = fams[(size_t)j];
+            {   // one segment IS the extension: the passes are better pipelined (the other pass's front beside that segment)
+                std::lock_guard<std::mutex> lk(idx->mu);
+                const asgart_stats &stt = idx->ctx[idx->last_ctx].stats;
+                asgart_index::FuseVerdict &v = idx->fuse_verdict;
+                v.n_passes = n_passes;
+                v.k = settings[0].probe_size;
+                v.G = settings[0].max_gap_size;
+                v.M = settings[0].min_duplication_length;
+                v.C = settings[0].max_cardinality;
+                v.modes = modes_sig;
+                v.pipeline = stt.passes == (uint64_t)n_passes && stt.ms_extend > 0.0 &&
+                             stt.ms_longest_segment * 100.0 > stt.ms_extend * (double)idx->opt.fuse_pole_pct;
+                if (idx->opt.debug)
+                    fprintf(stderr, "[asgart] passes as one job: longest segment %.1f ms of %.1f ms of extension -> the next call %s\n",
+                            stt.ms_longest_segment, stt.ms_extend, v.pipeline ? "pipelines the passes" : "runs as one job too");
+            }
             return 0;
         }
     }

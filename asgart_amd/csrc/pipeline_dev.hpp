@@ -1153,20 +1153,21 @@ template <class PosT>
 __device__ inline void wg_begin(const ExtParams<PosT> &P) {
     if (threadIdx.x == 0 && P.tier >= 1u && P.tier <= (uint32_t)kTiers) {
         atomicAdd(&P.ctr[CT_BUSY1 + P.tier - 1u], 0ull - wall_clock64());
-        if (P.seg_slots) P.seg_slots[blockIdx.x & 4095u] = 0ull;
     }
 }
+// (the slots are zero when a launch starts -- the host clears them, and a workgroup leaves its slot zero -- : the thread
+// that fetches the segments and the thread that closes the last one need not be the same)
 template <class PosT>
-__device__ inline void seg_clock(const ExtParams<PosT> &P) {
+__device__ inline void seg_clock(const ExtParams<PosT> &P, bool last = false) {
     if (!P.seg_slots || P.tier < 2u || P.tier > (uint32_t)kTiers) return;  // (tier 1: a million tiny segments)
     const unsigned long long now = wall_clock64();
-    const unsigned long long prev = atomicExch(&P.seg_slots[blockIdx.x & 4095u], now);
+    const unsigned long long prev = atomicExch(&P.seg_slots[blockIdx.x & 4095u], last ? 0ull : now);
     if (prev && now > prev) atomicMax(&P.ctr[CT_SEGMAX1 + P.tier - 1u], now - prev);
 }
 template <class PosT>
 __device__ inline void wg_busy(const ExtParams<PosT> &P) {
     if (threadIdx.x == 0 && P.tier >= 1u && P.tier <= (uint32_t)kTiers) {
-        seg_clock(P);  // (closes the last segment)
+        seg_clock(P, true);  // (closes the last segment)
         atomicAdd(&P.ctr[CT_BUSY1 + P.tier - 1u], wall_clock64());
         atomicAdd(&P.ctr[CT_WGS1 + P.tier - 1u], 1ull);
     }

@@ -1327,6 +1327,20 @@ def test_fused_passes_equal_single_calls_keys_included(hiplib, name):
         assert idx.stats().as_dict()["passes"] == 1
         for j, g in zip((0, 3), got):
             assert all(np.array_equal(a, b) for a, b in zip(g, single[j]))
+        # the default (fuse_passes = 1) decides from what the first fused call measured: with the threshold at 1 % every
+        # extension counts as "one segment", so the call after the first one pipelines the passes; 1000 %: never
+        idx.set_option("fuse_passes", 1)
+        for pct, want_passes in ((1, 1), (1000, 2)):
+            idx.set_option("fuse_pole_pct", pct)
+            sel = (0, 0) if pct == 1 else (0, 0, 3)   # (selections the index has no verdict for yet, with hits in them)
+            pair = [sts[j] for j in sel]
+            first = idx.search_duplications_passes(pr.chunks, pair, with_keys=True)
+            assert idx.stats().as_dict()["passes"] == len(sel)
+            second = idx.search_duplications_passes(pr.chunks, pair, with_keys=True)
+            assert idx.stats().as_dict()["passes"] == (1 if want_passes == 1 else len(sel)), (name, pct)
+            for got in (first, second):
+                for j, g in zip(sel, got):
+                    assert all(np.array_equal(a, b) for a, b in zip(g, single[j]))
 
 
 @pytest.mark.parametrize("skip_masked", [False, True])
