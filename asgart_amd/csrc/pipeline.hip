@@ -1110,10 +1110,12 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             HIP_TRY(hipMemcpyAsync(const_cast<SdRec *>(h_recs), w.rec_sorted.p, (size_t)n_rec * sizeof(SdRec),
                                    hipMemcpyDeviceToHost, s));
         }
+        const auto t_post0 = std::chrono::steady_clock::now();
         RC_TRY(wd_sync(idx, cx, s, "the ordering of the records"));
+        const auto t_post1 = std::chrono::steady_clock::now();
         // (sorted by segment start probe: pass 0's families first, then pass 1's ...; a family's key counts probes from
         // the start of its OWN pass, so that it equals the key a single-pass call gives the same family)
-        if (n_passes == 1) fams[0]->sds.reserve(n_hrec);
+        for (int32_t p = 0; p < n_passes; ++p) fams[p]->sds.reserve(n_passes == 1 ? n_hrec : n_hrec / (size_t)n_passes + n_hrec / 4);
         int32_t pass = 0;
         for (size_t f0 = 0; f0 < n_hrec;) {
             if (h_recs[f0].g_start == kVoidStart) break;  // unused slots of the waves' record chunks: sorted last
@@ -1134,6 +1136,10 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             }
             f0 = f1;
         }
+        if (opt.debug)
+            fprintf(stderr, "[asgart] records: %llu slots; ordering + copy to the host %.1f ms, families assembled in %.1f ms\n",
+                    (unsigned long long)n_rec, std::chrono::duration<double, std::milli>(t_post1 - t_post0).count(),
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_post1).count());
     } else {
         HIP_TRY(hipEventRecord(cx.ev[4], s));
         RC_TRY(wd_sync(idx, cx, s, "the hit rows"));

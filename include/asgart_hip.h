@@ -187,7 +187,8 @@ int32_t asgart_index_create_trim(const uint8_t *T, int64_t n, const int64_t *SA,
  * call, in probes), force_tier, arms_kernel, long3, long3_big, cap1, filter, tier_order,
  * grid1..grid7 (placement of segments on the extension kernels -- results never depend on
  * them), k7, k8, dense3, dense6, dense_min, sparse_to6 (which extension kernel a tier runs and which
- * segments the long-segment tier takes: placement again), pass_gate, watchdog_s, lazy_aux, prewarm,
+ * segments the long-segment tier takes: placement again), pass_gate, fuse_passes, fuse_pole_pct, cache_calls, bucket,
+ * watchdog_s, lazy_aux, prewarm,
  * debug, test_cap_limit, test_levels, test_genbits, test_k8_delay (parity tests); the full table with ranges is
  * kOptions in asgart_amd/csrc/index.hip, every field is described in struct Options
  * (asgart_amd/csrc/index.hpp).  ptab_depth and force_wide are fixed at creation (environment
@@ -266,7 +267,9 @@ int32_t asgart_search_duplications_ex(asgart_index *idx, const uint64_t *chunks,
  * chunks followed by pass 1's ... (chunk order inside each pass as in src/bin/asgart.rs:201-253), searched, scanned
  * and placed in one sweep at full chip rate, and every extension tier is ONE launch over the merged, cost-sorted
  * segment list, so that every pass's longest serial segments start at once on compute units of their own
- * (asgart_stats.passes tells; option fuse_passes = 0 switches it off).  Otherwise (sharded calls, different
+ * (asgart_stats.passes tells).  The first such call measures: when ONE segment is the whole extension (its longest
+ * single segment above option fuse_pole_pct = 88 % of the extension) the calls after it pipeline the passes instead --
+ * the other pass's front then hides beside that segment; option fuse_passes = 2 / 0 forces either.  Otherwise (sharded calls, different
  * settings) the library pipelines the passes as single calls: pass j+1 is issued the moment the chip-wide,
  * HBM-bound phases of pass j are over (probe search, scans, hit materialisation -- the moment the `progress`
  * array of a single call jumps), so its search runs beside pass j's extension automaton, whose tail is a few
