@@ -293,6 +293,8 @@ struct Options {
     int64_t k7 = 8;                 // bit t set (t = 3..6): tier t runs the arm kernel with a control wave (extend_k7_dev.hpp) instead of K6 / K4c. Default: tier 3 only -- the long DENSE segments (option dense3), where its shorter per-probe chain counts; measured in the other tiers (k7 = 120) it loses: a quarter / an eighth of a 256- / 512-thread workgroup holds no arms and a sparse probe costs two barriers instead of one wave's solo run
     int64_t k8 = 1;                 // 1: the tiers of option k7 run the one-barrier variant (extend_k8_dev.hpp: the new arms' first offers are
                                     // made by a ranking wave, a planning wave writes the commands; 14 arm waves instead of 15); 0: K7
+    int64_t barren = 1;             // 1: segments that provably emit nothing (too few hit-probes for any arm to reach
+                                    // min_duplication_length: pipeline_dev.hpp, segment_is_barren) are not run at all; 0: every segment runs
     int64_t bucket = 0;             // probe search: 1 = the keys AND the suffix-array entries of a small prefix-table bucket (<= 8 slots) are
                                     // requested together and the equal range / kept count come out of registers (one dependent HBM round
                                     // trip fewer per lookup); 0 = bisection over the keys, then the entries of the equal range.

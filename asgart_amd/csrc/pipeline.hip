@@ -557,6 +557,11 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
         pp.long3 = pp.long3_big = pp.dense3 = pp.dense6 = pp.dense_min = 0;
         pp.sparse_to6 = (uint32_t)opt.sparse_to6;
         pp.stats = opt.debug ? 1u : 0u;
+        pp.barren = opt.barren ? 1u : 0u;
+        pp.k = (uint32_t)k;
+        pp.step = (uint32_t)step;
+        pp.G = rp.G;
+        pp.M = rp.M;
         for (int t = 1; t < kTiers; ++t) pp.cap[t - 1] = tier_cap[t];
         if (arms_kernel) {
             pp.long3 = (uint32_t)opt.long3;
@@ -617,8 +622,13 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
         if (opt.debug) {
             fprintf(stderr, "[asgart] %llu segments, %llu walked wave by wave; per tier:", (unsigned long long)n_seg,
                     (unsigned long long)h_ctr[CT_LONGSEG]);
-            for (int t = 0; t < kTiers; ++t) fprintf(stderr, " %llu", (unsigned long long)n_t[t]);
-            fprintf(stderr, "\n");
+            unsigned long long placed = 0;
+            for (int t = 0; t < kTiers; ++t) {
+                fprintf(stderr, " %llu", (unsigned long long)n_t[t]);
+                placed += n_t[t];
+            }
+            fprintf(stderr, "; %llu barren (too few hit-probes for any arm to reach min_duplication_length: not run)\n",
+                    (unsigned long long)n_seg - placed);
         }
         if (lpt) {  // keep this shard's share of every tier's list
             const uint64_t R = (uint64_t)n_shards, r = (uint64_t)shard;

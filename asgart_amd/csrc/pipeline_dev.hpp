@@ -1687,11 +1687,32 @@ struct PlaceParams {
     uint32_t dense6;            // > 0: segments bound for tier 6 by their arms go to tier 3 (when they fit it) with at least this
                                 // many hits per processed probe: the dense ones of ANY length on the kernel with a control wave
     uint32_t stats;             // 1 (option debug): hit-probes and hits per tier are tallied (one atomic pair per segment)
+    uint32_t barren;            // 1: segments that provably emit nothing are not run at all (segment_is_barren)
+    uint32_t k, step, G;        // (of the call: for that bound)
+    unsigned long long M;
     uint32_t dense3;            // > 0: ... and only the DENSE ones (at least this many hits per processed probe on average:
                                 // tandem arrays); the sparse long ones (a chromosome against its homologue: a few hits per
                                 // probe, mostly run by one wave alone) go to tier 6's kernel -- set when tier 3 runs the
                                 // kernel with a control wave, whose step costs the same whatever the probe holds
 };
+
+// A segment that cannot emit anything need not run.  A family holds the arms whose RIGHT segment is at least M long
+// (src/automaton.rs:186-196), and a right segment only grows when its arm is extended (:136-143): to m.end = x + k with
+// x < right.end + threshold (:68-70), i.e. by at most threshold + k - 1 per extension, at most once per hit-probe.  With
+// H hit-probes in the segment an arm born at the first is extended at most H - 1 times, and its threshold
+// max(G, len(left) / 10) is at most max(G, (span * step + k) / 10) while the segment spans `span` probe positions
+// (len(left) = i + k - left.start <= span * step + k).  So
+//     k + (H - 1) * (thr_max + k - 1) < M   =>   no arm of the segment ever reaches M: it emits no family, and -- segments being
+// independent automaton instances -- leaving it out changes nothing.  At the defaults (k = 20, G = 120,
+// M = 1000) that is every segment of up to 8 hit-probes: most of the million-odd tiny segments of a genome-sized pass.
+// (Not when the walk was cut short by the end of a sharded call's window: the segment may go on beyond it.)
+constexpr int kTierBarren = kTiers + 1;
+__device__ inline bool segment_is_barren(const PlaceParams &pp, uint32_t n_hit, uint32_t span_probes) {
+    if (!pp.barren || n_hit == 0u) return false;
+    const unsigned long long len_left_max = (unsigned long long)span_probes * pp.step + pp.k;
+    const unsigned long long thr_max = max((unsigned long long)pp.G, len_left_max / 10ull);
+    return (unsigned long long)pp.k + (unsigned long long)(n_hit - 1u) * (thr_max + pp.k - 1ull) < pp.M;
+}
 
 // Sort key of a segment inside its tier (ascending = launch order).  Heavy tiers: longest first,
 // so that the serial chains start early.  Tier 1 holds over a million mostly tiny segments whose
@@ -1904,14 +1925,17 @@ __global__ __launch_bounds__(64) void seg_stats_lanes_kernel(RunParams rp, const
         const uint64_t sidx = base + lane;
         const bool have = sidx < n_seg;
         uint32_t g0 = 0, g_end = 0;
+        bool window_cut = false;  // the walk may end at the end of a sharded call's window instead of the chunk's
         if (have) {
             g0 = seg_list[sidx];
-            g_end = min(rp.ch.pbase[chunk_of(rp.ch, g0) + 1], rp.g_hi);
+            const uint32_t chunk_end = rp.ch.pbase[chunk_of(rp.ch, g0) + 1];
+            g_end = min(chunk_end, rp.g_hi);
+            window_cut = rp.g_hi < chunk_end;
         }
         for (uint32_t r = 0; r < RW; ++r) s_ring[r * 64u + lane] = 0;
         uint32_t quiet = 0, mx = 0, bound = 0, n_probes = 0, wsum = 0, head = 0, steps = 0, g = g0, n_hit = 0;
         unsigned long long sum = 0;
-        bool done = !have;
+        bool done = !have, by_quiet = false;
         while (!done && g < g_end && steps < kLaneWalk) {
             const uint32_t f = p_filt[g];
             ++g;
@@ -1921,6 +1945,7 @@ __global__ __launch_bounds__(64) void seg_stats_lanes_kernel(RunParams rp, const
             if (!hit) {
                 if (++quiet >= rp.tstar) {  // t* quiet probes: every arm has been retired, the segment is over
                     done = true;
+                    by_quiet = true;
                     break;
                 }
             } else {
@@ -1942,6 +1967,7 @@ __global__ __launch_bounds__(64) void seg_stats_lanes_kernel(RunParams rp, const
             if (rp.tstar > 64u) bound = 0xFFFFFFFFu;  // no estimate for huge gap settings: largest tier
             int tier = place_tier(bound, sum, n_probes, pp);
             if (mx > 1 && pp.force_tier > tier) tier = min(pp.force_tier, kTiers);
+            if ((by_quiet || !window_cut) && segment_is_barren(pp, n_hit, g - g0)) tier = kTierBarren;
             keys[sidx] = placement_key(tier, sum, g0);
             vals[sidx] = g0;
             if (pp.stats) {
@@ -1978,7 +2004,8 @@ __global__ __launch_bounds__(64) void seg_stats_kernel(RunParams rp, const uint3
         const uint32_t g0 = seg_list[sidx];
         const int c = chunk_of_uniform(rp.ch, g0);
         const uint32_t g_end = min(rp.ch.pbase[c + 1], rp.g_hi);
-        uint32_t quiet = 0, mx = 0, bound = 0, n_probes = 0, n_hit = 0;
+        const bool window_cut = rp.g_hi < rp.ch.pbase[c + 1];
+        uint32_t quiet = 0, mx = 0, bound = 0, n_probes = 0, n_hit = 0, g_stop = g_end;
         unsigned long long sum = 0;
         bool done = false;
         s_ext[lane] = 0;
@@ -2008,6 +2035,7 @@ __global__ __launch_bounds__(64) void seg_stats_kernel(RunParams rp, const uint3
                     // probes up to that hit still belong to the segment
                     const uint32_t pos = (uint32_t)(__shfl(lh, __ffsll((long long)term) - 1) + 1);
                     done = true;
+                    g_stop = g + 64u;             // (an upper bound of where the segment ends: all the barren test needs)
                     live = (1ull << pos) - 1ull;  // pos <= 63
                 } else {
                     const int last = hm ? 63 - __clzll((long long)hm) : -1;
@@ -2046,6 +2074,7 @@ __global__ __launch_bounds__(64) void seg_stats_kernel(RunParams rp, const uint3
         if (lane == 0) {
             int tier = place_tier(bound, sum, n_probes, pp);
             if (mx > 1 && pp.force_tier > tier) tier = min(pp.force_tier, kTiers);
+            if ((done || !window_cut) && segment_is_barren(pp, n_hit, min(g_stop, g_end) - g0)) tier = kTierBarren;
             keys[sidx] = placement_key(tier, sum, g0);
             vals[sidx] = g0;
             if (pp.stats) {
