@@ -65,7 +65,7 @@ const OptDesc kOptions[] = {
     {"fuse_passes", &Options::fuse_passes, 0, 2},
     {"fuse_pole_pct", &Options::fuse_pole_pct, 1, 1000},
     {"bucket", &Options::bucket, 0, 1},
-    {"barren", &Options::barren, 0, 1},
+    {"barren", &Options::barren, 0, 2},
     {"dense3", &Options::dense3, 0, 1 << 20},
     {"dense6", &Options::dense6, 0, 1 << 20},
     {"dense_min", &Options::dense_min, 0, 1 << 30},

@@ -124,12 +124,13 @@ struct Workspace {
     DevBuf rec_k32, rec_k64, rec_idx, rec_sorted;  // ordering of the output records
     DevBuf pat;        // pattern upload scratch
     DevBuf out_a, out_b;
+    DevBuf seg_info;   // uint2 per segment: hits and probe positions walked (placement -> cluster_barren_kernel)
     DevBuf seg_slots;  // u64[8][4096]: per tier and workgroup, when its current segment started (longest-segment statistics)
     // every buffer goes back to the device (or to the block cache): ONE list, next to the members
     void release_all() {
         DevBuf *bufs[] = {&chunks, &p_lo, &p_raw, &p_filt, &row_off, &blk, &hits, &big_list, &rank_list, &seg_list,
                           &counters, &fam_sds, &ovf_list, &own_list, &scratch, &hit_flag, &seg_keys, &seg_vals,
-                          &sort_tmp, &rec_k32, &rec_k64, &rec_idx, &rec_sorted, &pat, &out_a, &out_b, &seg_slots};
+                          &sort_tmp, &rec_k32, &rec_k64, &rec_idx, &rec_sorted, &pat, &out_a, &out_b, &seg_info, &seg_slots};
         static_assert(sizeof(Workspace) == sizeof(bufs) / sizeof(bufs[0]) * sizeof(DevBuf),
                       "a buffer of the workspace is missing from release_all");
         for (DevBuf *b : bufs) b->release();
@@ -156,7 +157,7 @@ struct SearchCtx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr, stream3 = nullptr, stream4 = nullptr;  // concurrent extension tiers
     hipStream_t stream5 = nullptr, stream6 = nullptr, stream7 = nullptr;
-    hipEvent_t ev[13] = {};
+    hipEvent_t ev[16] = {};
     Workspace ws;
     asgart_stats stats;
     RunParams last_rp;   // inputs of the last call, kept for the yardstick kernel
@@ -293,8 +294,10 @@ struct Options {
     int64_t k7 = 8;                 // bit t set (t = 3..6): tier t runs the arm kernel with a control wave (extend_k7_dev.hpp) instead of K6 / K4c. Default: tier 3 only -- the long DENSE segments (option dense3), where its shorter per-probe chain counts; measured in the other tiers (k7 = 120) it loses: a quarter / an eighth of a 256- / 512-thread workgroup holds no arms and a sparse probe costs two barriers instead of one wave's solo run
     int64_t k8 = 1;                 // 1: the tiers of option k7 run the one-barrier variant (extend_k8_dev.hpp: the new arms' first offers are
                                     // made by a ranking wave, a planning wave writes the commands; 14 arm waves instead of 15); 0: K7
-    int64_t barren = 1;             // 1: segments that provably emit nothing (too few hit-probes for any arm to reach
-                                    // min_duplication_length: pipeline_dev.hpp, segment_is_barren) are not run at all; 0: every segment runs
+    int64_t barren = 2;             // segments that provably emit nothing are not run at all: 1 = those with too few hit-probes for any arm to
+                                    // reach min_duplication_length (pipeline_dev.hpp: segment_is_barren); 2 = also those whose hits leave
+                                    // no run of consecutive occupied position buckets long enough (cluster_barren_kernel: the bursts of
+                                    // interspersed repeats); 0 = every segment runs
     int64_t bucket = 0;             // probe search: 1 = the keys AND the suffix-array entries of a small prefix-table bucket (<= 8 slots) are
                                     // requested together and the equal range / kept count come out of registers (one dependent HBM round
                                     // trip fewer per lookup); 0 = bisection over the keys, then the entries of the equal range.

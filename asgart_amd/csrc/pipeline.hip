@@ -558,6 +558,13 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
         pp.sparse_to6 = (uint32_t)opt.sparse_to6;
         pp.stats = opt.debug ? 1u : 0u;
         pp.barren = opt.barren ? 1u : 0u;
+        pp.seg_info = nullptr;
+        // (not with the continuation filter -- option filter = 1, whose pre-pass does the placement itself)
+        const bool cluster_barren = opt.barren >= 2 && opt.filter == 0 && rp.M > (uint64_t)k;
+        if (cluster_barren) {
+            RC_TRY(w.seg_info.reserve((size_t)n_seg * sizeof(uint2)));
+            pp.seg_info = w.seg_info.as<uint2>();
+        }
         pp.k = (uint32_t)k;
         pp.step = (uint32_t)step;
         pp.G = rp.G;
@@ -604,6 +611,18 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                 rp, p_filt, seg_list, d_ctr + CT_LONGSEG, long_list, kbuf, vbuf, pp, d_ctr);
         }
         HIP_TRY(hipGetLastError());
+        if (cluster_barren) {
+            HIP_TRY(hipEventRecord(cx.ev[13], s));
+            // barren by position (cluster_barren_kernel): a wave per segment, two bitmap sizes (2 KB: 32 waves per compute
+            // unit; 16 KB: 9)
+            cluster_barren_kernel<SlotT, 16384><<<256 * 32, 64, 0, s>>>(rp, pp, row_off, hits, seg_list, d_ctr + CT_SEG, kbuf, 1u, 1024u,
+                                                                       d_ctr + CT_CLUSTER_CUR, d_ctr);
+            HIP_TRY(hipEventRecord(cx.ev[14], s));
+            cluster_barren_kernel<SlotT, 131072><<<256 * 9, 64, 0, s>>>(rp, pp, row_off, hits, seg_list, d_ctr + CT_SEG, kbuf, 1025u,
+                                                                       16384u, d_ctr + CT_CLUSTER_CUR + 1, d_ctr);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(cx.ev[15], s));
+        }
         const uint32_t *order = nullptr;
         const uint32_t *sorted_keys = nullptr;
         RC_TRY(sort_segments(w, kbuf, vbuf, n_seg, s, &order, &sorted_keys, lpt));
@@ -627,8 +646,16 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                 fprintf(stderr, " %llu", (unsigned long long)n_t[t]);
                 placed += n_t[t];
             }
-            fprintf(stderr, "; %llu barren (too few hit-probes for any arm to reach min_duplication_length: not run)\n",
-                    (unsigned long long)n_seg - placed);
+            fprintf(stderr, "; %llu barren (no arm can reach min_duplication_length: not run), %llu of them by the positions of their hits\n",
+                    (unsigned long long)n_seg - placed, (unsigned long long)h_ctr[CT_CLUSTER_BARREN]);
+            if (cluster_barren) {
+                float ms_a = 0.f, ms_b = 0.f, ms_p = 0.f;
+                (void)hipEventElapsedTime(&ms_a, cx.ev[13], cx.ev[14]);
+                (void)hipEventElapsedTime(&ms_b, cx.ev[14], cx.ev[15]);
+                (void)hipEventElapsedTime(&ms_p, cx.ev[3], cx.ev[13]);
+                fprintf(stderr, "[asgart] placement walk %.2f ms; barren by position: segments of up to 1 024 hits %.2f ms, up to 16 384 hits %.2f ms\n",
+                        ms_p, ms_a, ms_b);
+            }
         }
         if (lpt) {  // keep this shard's share of every tier's list
             const uint64_t R = (uint64_t)n_shards, r = (uint64_t)shard;

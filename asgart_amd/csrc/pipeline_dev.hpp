@@ -65,7 +65,9 @@ enum Counter {
     CT_THITS1 = 152,   // ... and hits per tier
     CT_SEGMAX1 = 160,  // per tier: the longest time one workgroup spent on ONE segment, in 10-ns ticks -- the serial floor of
                        // the extension (what neither more compute units nor more GPUs shorten)
-    CT_COUNT = 168
+    CT_CLUSTER_BARREN = 168,  // segments cluster_barren_kernel proved barren
+    CT_CLUSTER_CUR = 169,     // its work cursors (two launches)
+    CT_COUNT = 176
 };
 
 __device__ inline int chunk_of(const ChunkTable &ch, uint32_t g) {
@@ -1688,6 +1690,8 @@ struct PlaceParams {
                                 // many hits per processed probe: the dense ones of ANY length on the kernel with a control wave
     uint32_t stats;             // 1 (option debug): hit-probes and hits per tier are tallied (one atomic pair per segment)
     uint32_t barren;            // 1: segments that provably emit nothing are not run at all (segment_is_barren)
+    uint2 *seg_info;            // per segment, for cluster_barren_kernel: x = hits, y = probe positions walked | bit 31: the walk saw the
+                                // segment's end (not cut short by a sharded call's window); null: not recorded
     uint32_t k, step, G;        // (of the call: for that bound)
     unsigned long long M;
     uint32_t dense3;            // > 0: ... and only the DENSE ones (at least this many hits per processed probe on average:
@@ -1970,6 +1974,9 @@ __global__ __launch_bounds__(64) void seg_stats_lanes_kernel(RunParams rp, const
             if ((by_quiet || !window_cut) && segment_is_barren(pp, n_hit, g - g0)) tier = kTierBarren;
             keys[sidx] = placement_key(tier, sum, g0);
             vals[sidx] = g0;
+            if (pp.seg_info)
+                pp.seg_info[sidx] = make_uint2(sum > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)sum,
+                                               (g - g0) | ((by_quiet || !window_cut) ? 0x80000000u : 0u));
             if (pp.stats) {
                 atomicAdd(&ctr[CT_TPROBES1 + tier - 1], (unsigned long long)n_hit);
                 atomicAdd(&ctr[CT_THITS1 + tier - 1], sum);
@@ -2077,6 +2084,9 @@ __global__ __launch_bounds__(64) void seg_stats_kernel(RunParams rp, const uint3
             if ((done || !window_cut) && segment_is_barren(pp, n_hit, min(g_stop, g_end) - g0)) tier = kTierBarren;
             keys[sidx] = placement_key(tier, sum, g0);
             vals[sidx] = g0;
+            if (pp.seg_info)
+                pp.seg_info[sidx] = make_uint2(sum > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)sum,
+                                               (min(g_stop, g_end) - g0) | ((done || !window_cut) ? 0x80000000u : 0u));
             if (pp.stats) {
                 atomicAdd(&ctr[CT_TPROBES1 + tier - 1], (unsigned long long)n_hit);
                 atomicAdd(&ctr[CT_THITS1 + tier - 1], sum);
@@ -2084,6 +2094,138 @@ __global__ __launch_bounds__(64) void seg_stats_kernel(RunParams rp, const uint3
         }
         lds_barrier();
     }
+}
+
+// Barren by POSITION.  An arm's right segment is built from a chain of hits x_0 < x_1 < ... (one per hit-probe at most) with
+// x_{j+1} < x_j + k + threshold (src/automaton.rs:68-70 with right.end = x_j + k), and it is reported only when
+// x_m + k - x_0 >= M.  With buckets of w = k + thr_max positions (thr_max: the largest threshold any arm of the segment can
+// have, as in segment_is_barren) every link of a chain stays in its bucket or moves to the next one, so an arm that reaches M
+// leaves a RUN of at least floor((M - k) / w) + 1 consecutive occupied buckets among the segment's hits.  No such run =>
+// the segment emits nothing.  That is the fate of the bursts of interspersed repeats, which are most of the extension's
+// work at genome scale: a probe inside a repeat hits a hundred other copies, every copy collects a few hundred bases of
+// hits over the few dozen probes of the burst, the copies are kilobases apart -- hundreds of arms per probe and not one
+// duplication.  Tandem arrays and real duplications keep their runs and are run as before.
+// One WAVE per segment: the hits' buckets set bits of a hashed LDS bitmap (BITS bits; a collision can only make a bucket look
+// occupied that is not, i.e. a run look longer -- the test stays sound, it only proves a little less), then every hit
+// asks whether the need - 1 buckets behind its own are all occupied.  Order-free, no barrier between waves, a few KB of
+// LDS per wave (the continuation filter of round 2 answered a related question probe by probe, a wave per segment with
+// barriers per probe, and cost more than it saved).  Segments of more than max_hits hits are left alone.
+template <class PosT, int BITS>
+__global__ __launch_bounds__(64) void cluster_barren_kernel(RunParams rp, PlaceParams pp,
+                                                            const unsigned long long *__restrict__ row_off,
+                                                            const PosT *__restrict__ hits,
+                                                            const uint32_t *__restrict__ seg_list,
+                                                            const unsigned long long *__restrict__ n_seg_ptr,
+                                                            uint32_t *__restrict__ keys, uint32_t min_hits, uint32_t max_hits,
+                                                            unsigned long long *__restrict__ cursor,
+                                                            unsigned long long *__restrict__ ctr) {
+    static_assert((BITS & (BITS - 1)) == 0 && BITS >= 2048, "bitmap size");
+    constexpr uint32_t kWords = BITS / 32, kShift = 32 - __builtin_ctz((unsigned)BITS);
+    __shared__ uint32_t s_bits[kWords];
+    const uint32_t lane = threadIdx.x;
+    const uint64_t n_seg = *n_seg_ptr;
+    uint32_t n_barren = 0;
+    auto bit_of = [&](uint32_t b) { return (b * 2654435761u) >> kShift; };
+    for (;;) {
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(cursor, 64ull);
+        base = lane_of(base, 0u);
+        if (base >= n_seg) break;
+        // the 64 segments of the batch side by side: key, hit total, where its rows are (most are not this launch's: already
+        // barren, another size class, cut by a sharded window); the candidates are then walked one after the other, their
+        // set-up already in registers
+        const uint64_t sj = base + lane;
+        bool cand = false;
+        uint32_t key_l = 0, span_l = 0;
+        unsigned long long lo_l = 0, hi_l = 0;
+        if (sj < n_seg) {
+            key_l = keys[sj];
+            const uint2 info = pp.seg_info[sj];
+            span_l = info.y & 0x7FFFFFFFu;
+            cand = (key_l >> 29) < (uint32_t)kTiers && (info.y >> 31) && info.x >= min_hits && info.x <= max_hits;
+            if (cand) {
+                const uint32_t g0 = seg_list[sj];
+                lo_l = row_off[g0];
+                hi_l = row_off[g0 + span_l];
+                cand = hi_l > lo_l && hi_l - lo_l <= (unsigned long long)max_hits;
+            }
+        }
+        unsigned long long todo = __ballot(cand);
+        while (todo) {
+            const uint32_t l = (uint32_t)(__ffsll((long long)todo) - 1);
+            todo &= todo - 1ull;
+            const uint32_t key = lane_of(key_l, l), span = lane_of(span_l, l);
+            const unsigned long long lo = lane_of(lo_l, l);
+            const uint32_t n = (uint32_t)(lane_of(hi_l, l) - lo);
+            const unsigned long long len_left_max = (unsigned long long)span * pp.step + pp.k;
+            const unsigned long long thr_max = max((unsigned long long)pp.G, len_left_max / 10ull);
+            const unsigned long long w = thr_max + pp.k;
+            const unsigned long long need = (pp.M - pp.k) / w + 1ull;  // consecutive occupied buckets an emitting arm leaves
+            if (need < 2ull || need > 64ull) continue;                 // (one bucket proves nothing; M > k: the host has checked)
+            // exact floor(x / w) through a double quotient and one correction (x < 2^53; a 64-bit integer division per hit
+            // would be a hundred instructions)
+            const double inv_w = 1.0 / (double)w;
+            auto bucket_of = [&](unsigned long long x) -> uint32_t {
+                unsigned long long q = (unsigned long long)((double)x * inv_w);
+                const long long r = (long long)(x - q * w);
+                q += r >= (long long)w ? 1ull : 0ull;
+                q -= r < 0 ? 1ull : 0ull;
+                return (uint32_t)q;
+            };
+            for (uint32_t j = lane; j < kWords; j += 64u) s_bits[j] = 0u;
+            __builtin_amdgcn_wave_barrier();
+            __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // (eight independent loads per lane in flight, then the bits: a load-set loop would pay one round trip per pass)
+            for (uint32_t j0 = 0; j0 < n; j0 += 512u) {
+                PosT xv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const uint32_t j = j0 + (uint32_t)u * 64u + lane;
+                    xv[u] = j < n ? hits[lo + j] : (PosT)0;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const uint32_t j = j0 + (uint32_t)u * 64u + lane;
+                    if (j < n) {
+                        const uint32_t bi = bit_of(bucket_of((unsigned long long)xv[u]));
+                        atomicOr(&s_bits[bi >> 5], 1u << (bi & 31u));
+                    }
+                }
+            }
+            __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            bool found = false;
+            for (uint32_t j0 = 0; j0 < n && !found; j0 += 512u) {
+                PosT xv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const uint32_t j = j0 + (uint32_t)u * 64u + lane;
+                    xv[u] = j < n ? hits[lo + j] : (PosT)0;
+                }
+                bool mine = false;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const uint32_t j = j0 + (uint32_t)u * 64u + lane;
+                    if (j < n) {
+                        const uint32_t b = bucket_of((unsigned long long)xv[u]);
+                        bool all = true;
+                        for (uint32_t d = 1; d < (uint32_t)need && all; ++d) {
+                            const uint32_t bi = bit_of(b + d);
+                            all = (s_bits[bi >> 5] >> (bi & 31u)) & 1u;
+                        }
+                        mine = mine || all;
+                    }
+                }
+                found = __ballot(mine) != 0ull;
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (!found) {
+                if (lane == 0) keys[base + l] = (key & 0x1FFFFFFFu) | ((uint32_t)(kTierBarren - 1) << 29);
+                ++n_barren;
+            }
+        }
+    }
+    if (lane == 0 && n_barren) atomicAdd(&ctr[CT_CLUSTER_BARREN], (unsigned long long)n_barren);
 }
 
 // tier list lengths from the sorted placement keys (tier-1 = key >> 29): n_t = first index whose
