@@ -88,7 +88,8 @@ class Stats(C.Structure):
             "probes_with_hits", "raw_hits", "filtered_hits", "segments", "families", "proto_sds",
             "bisect_steps", "search_launches", "overflow_segments")] + [("ms_extend_tier2", C.c_double), ("heavy_segments", C.c_uint64), ("ms_probe_count", C.c_double),
         ("search_bytes", C.c_uint64), ("probes_filter_rejected", C.c_uint64), ("search_bytes_wide_loads", C.c_uint64),
-        ("ms_longest_tier", C.c_double), ("passes", C.c_uint64), ("ms_longest_segment", C.c_double)]
+        ("ms_longest_tier", C.c_double), ("passes", C.c_uint64), ("ms_longest_segment", C.c_double),
+        ("split_segments", C.c_uint64), ("split_refused", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

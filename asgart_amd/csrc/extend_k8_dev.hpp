@@ -34,7 +34,14 @@ constexpr uint32_t K8_STILL = 2u;      // the new arms of this block die of the 
 constexpr uint32_t K8_BIG = 4u;        // more than 64 new arms: the ranking wave offered for the first 64 only, every wave takes a
                                        // share of the others at the top of the next step (one extra barrier in such a step)
 
-template <class PosT, int S, int NT, int HB, int kRows = 1024, int kE = 2>
+// RANGE (32-bit positions): a work item is not a segment but a RUN over part of one (struct RangeRun, pipeline_dev.hpp) --
+// long segments cut into ranges that run side by side, each from an empty arm list some way in front of its cut.  What
+// differs from a whole segment: where the walk starts and stops; creation numbers that do not depend on what the run has
+// seen before (needle offset of the creating probe relative to the segment's first, then the hit's index: the same arm
+// gets the same number in every run that holds it, and the order of the numbers is the creation order); family ordinals
+// that count the flushes from the cut on (the host adds the ranges before); records only from the cut on; and at the end
+// the live arms and the family state are written out, for the comparison that decides whether the cut was sound.
+template <class PosT, int S, int NT, int HB, int kRows = 1024, int kE = 2, bool RANGE = false>
 __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
     constexpr int NW = NT / 64, NWA = NW - 2;  // waves; arm waves (then the RANKING wave and the PLANNING wave)
     constexpr int CAP = S * NWA * 64;
@@ -53,6 +60,7 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
     constexpr uint32_t kCmdWords = 32;
     constexpr uint32_t kNewMax = kWidePos ? (uint32_t)HB / 2u : (uint32_t)HB;  // new arms of one probe (more: given up)
     using WinT = typename std::conditional<kWidePos, uint64_t, uint32_t>::type;
+    static_assert(!RANGE || (sizeof(PosT) == 4 && S * NWA * 64 <= (int)kRunDumpCap), "runs over ranges: 32-bit positions, dump capacity");
     static_assert(NW >= 4 && HB <= 1024 && S <= 8 && NE <= 128 && (kRows & (kRows - 1)) == 0 && kE == 2 && kRows <= 2048 && CAP < 65536,
                   "shape");
     if (NT >= 1024 && P.hi_prio) __builtin_amdgcn_s_setprio(3);
@@ -81,6 +89,7 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
     __shared__ __attribute__((aligned(16))) uint32_t s_free[kFreeBufs][NWA][8];
     __shared__ PosT s_newx[2][kNewMax];                                // the unmatched hits of a probe, by rank
     __shared__ uint32_t s_newch[2][kNewMax];                           // ... and the candidates of the arm born of each
+    __shared__ uint16_t s_newh[2][RANGE ? kNewMax : 1u];               // (RANGE) ... and its index among the probe's hits
     __shared__ __attribute__((aligned(16))) uint32_t s_cmd[3][kCmdWords];  // as K7's (word 10: K7_STAGE of the step before)
     __shared__ __attribute__((aligned(16))) uint32_t s_mid[8];         // before the loop: the first batch's staging request
     __shared__ PosT s_cle[CAP], s_crs[CAP];                            // cold fields of an arm, by slot
@@ -137,6 +146,25 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
         const unsigned long long seg = uni(s_bcast);
         lds_barrier();
         if (seg >= *P.n_seg_ptr) break;
+        // (RANGE) the run; every wave works out the needle offset its records start at for itself
+        RangeRun run{};
+        uint32_t emit_from_i = 0;
+        if constexpr (RANGE) {
+            run = P.runs[seg];
+            run.g_begin = uni(run.g_begin);
+            run.g_stop = uni(run.g_stop);
+            run.g_seg0 = uni(run.g_seg0);
+            run.emit_from = uni(run.emit_from);
+            run.flags = uni(run.flags);
+            const int rc = chunk_of_uniform(P.rp.ch, run.g_seg0);
+            emit_from_i = (run.flags & kRunNoEmit) ? 0xFFFFFFFFu
+                          : (run.emit_from == run.g_seg0 ? 0u : (run.emit_from - P.rp.ch.pbase[rc] + 1u) * (uint32_t)P.rp.step);
+        }
+        // the creation number of the r-th new arm of a probe (lists of buffer pbuf)
+        auto seq_of = [&](uint32_t seq_base, uint32_t r, uint32_t pbuf) -> uint32_t {
+            if constexpr (RANGE) return seq_base | (uint32_t)s_newh[pbuf][r];
+            else return seq_base + r;
+        };
 
         auto emit_records = [&](bool emit, PosT ls, PosT le, PosT rs, PosT re, uint32_t seq, uint32_t fam_seq) {
             const unsigned long long em = __ballot(emit);
@@ -150,7 +178,7 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
                 r.g_start = (uint32_t)s_seg[0];
                 r.fam_seq = fam_seq;
                 r.create_seq = seq;
-                r.pad = 0;
+                r.pad = RANGE ? (uint32_t)seg + 1u : 0u;  // (RANGE: the run, for the host's renumbering of its families)
                 r.sd.left = seg_rev ? cs + cl - (uint64_t)ls - ll : (uint64_t)ls + cs;  // src/bin/asgart.rs:229-237
                 r.sd.right = rs;
                 r.sd.left_length = ll;
@@ -325,7 +353,7 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
             for (uint32_t j = 1u + wave; j * 64u < n_pull; j += (uint32_t)NW) {
                 const uint32_t r = j * 64u + (uint32_t)lane;
                 const PosT x = s_newx[pbuf][min(r, n_pull - 1u)];
-                const uint32_t ch = offer_window(q, (PosT)(x + 1u), (WinT)thr0 + (WinT)(q.k - 1u), seq_base + r, r < n_pull, ns_q);
+                const uint32_t ch = offer_window(q, (PosT)(x + 1u), (WinT)thr0 + (WinT)(q.k - 1u), seq_of(seq_base, min(r, n_pull - 1u), pbuf), r < n_pull, ns_q);
                 if (r < n_pull) s_newch[pbuf][r] = ch;
             }
         };
@@ -351,6 +379,7 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
             }
             lds_barrier();  // (3)
             bool pub_prev = false;              // this wave published its free counts in the step before
+            uint32_t last_i = 0;                // (RANGE) needle offset of the last probe that has been resolved
             uint32_t pv_off = 0, pv_besto = 0;  // the previous probe's rows and winners (as in the last command)
             uint32_t pv_tabo = 0, pv_g10 = 0;   // ... its hit table and generation tag
             // (lanes 0-7: the pull block; 8-15: this wave's slots; 16-19: the stash counts -- per step parity)
@@ -391,6 +420,10 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
                     break;
                 }
                 const bool has_prev = (flags & K7_PREV) != 0u, has_cur = (flags & K7_CUR) != 0u, more = !(flags & K7_LAST);
+                // (RANGE) an arm that dies belongs to the range of the last probe resolved before it is found dead -- in the step
+                // that resolves the probe or, behind a generation wrap, in the step that brings the quiet probes' age: the same
+                // probe in every run, wherever its wraps fall
+                if constexpr (RANGE) last_i = has_prev ? C(12) : last_i;
                 bool stale0 = false;  // the winners requested above predate the offers below
                 if (K7_RARE(PB(0) & K8_BIG)) {  // (before anything touches the previous probe's table or its stash count)
                     big_rounds(Cur{C(16), pv_g10, C(19), pv_tabo, C(15), C(23), C(11), C(14)}, PB(1), PB(2), C(22), sp ^ 1u);
@@ -440,9 +473,10 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
                         bool take = is_free && idx < given && r < n_pull;
                         const PosT x = s_newx[pbuf][take ? r : 0u];
                         const uint32_t chn = s_newch[pbuf][take ? r : 0u];
+                        const uint32_t seq_n = seq_of(seq_base, take ? r : 0u, pbuf);
                         if (K7_RARE(stillborn)) {
-                            const bool report = take && (uint64_t)k >= M;
-                            if (__ballot(report)) emit_records(report, b_i, (PosT)(b_i + k), x, (PosT)(x + k), seq_base + r, fam_b);
+                            const bool report = take && (uint64_t)k >= M && (!RANGE || (uint32_t)b_i >= emit_from_i);
+                            if (__ballot(report)) emit_records(report, b_i, (PosT)(b_i + k), x, (PosT)(x + k), seq_n, fam_b);
                             take = false;
                         }
                         a_ls[L] = take ? b_i : a_ls[L];
@@ -453,7 +487,7 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
                         a_re[L] = take ? (PosT)(x + k) : a_re[L];
                         a_gap[L] = take ? gap_new : a_gap[L];
                         a_thr[L] = take ? thr0 : a_thr[L];
-                        a_seq[L] = take ? seq_base + r : a_seq[L];
+                        a_seq[L] = take ? seq_n : a_seq[L];
                         c_h[L] = take ? chn : c_h[L];
                         if (__ballot(take)) livemask |= 1u << L;
                     }
@@ -576,7 +610,8 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
                         const bool dead = !was_free && aged >= G;  // never matches again
                         if (K7_RARE(__ballot(dead) != 0ull)) {
                             const PosT rs_L = s_crs[L * (NWA * 64) + tid];
-                            const bool report = dead && (uint64_t)(a_re[L] - rs_L) >= M;
+                            // (RANGE: deaths found while a probe in front of the cut is resolved belong to the range before)
+                            const bool report = dead && (uint64_t)(a_re[L] - rs_L) >= M && (!RANGE || last_i >= emit_from_i);
                             if (__ballot(report) != 0ull)
                                 emit_records(report, a_ls[L], s_cle[L * (NWA * 64) + tid], rs_L, a_re[L], a_seq[L], PB(3));
                         }
@@ -626,6 +661,26 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
                 pv_g10 = C(5);
                 if (K7_RARE(!more)) break;
             }
+            if constexpr (RANGE) {
+                // the arms this run leaves alive, in any order (the comparison goes by creation number)
+                if (!overflow) {
+#pragma unroll
+                    for (int L = 0; L < S; ++L) {
+                        const bool live = a_seq[L] != kNoSeq;
+                        const unsigned long long m = __ballot(live);
+                        if (!m) continue;
+                        uint32_t base = 0;
+                        if (lane == 0) base = atomicAdd(&P.run_meta[seg * 8ull + 0ull], (uint32_t)__popcll(m));
+                        base = lane_of(base, 0u);
+                        const uint32_t at = base + (uint32_t)__popcll(m & lt_mask);
+                        if (live && at < kRunDumpCap) {
+                            uint4 *o = reinterpret_cast<uint4 *>(P.run_dump + (seg * (unsigned long long)kRunDumpCap + at) * 8ull);
+                            o[0] = make_uint4(a_seq[L], (uint32_t)a_ls[L], (uint32_t)s_cle[L * (NWA * 64) + tid], (uint32_t)s_crs[L * (NWA * 64) + tid]);
+                            o[1] = make_uint4((uint32_t)a_re[L], a_thr[L], a_gap[L], 0u);
+                        }
+                    }
+                }
+            }
             if (wave == 0u) K7T_FLUSH(1);
             if (wave == 0u) K7U_FLUSH();
 #ifdef K8_TRACE_WAVE
@@ -639,7 +694,9 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
             const uint32_t k = (uint32_t)rp.k, step = (uint32_t)rp.step, G = rp.G;
             const uint32_t thr0 = arm_threshold(k, G);
             const uint32_t cap_eff = min((uint32_t)CAP, P.cap_limit);
-            const uint32_t g0 = P.seg_list[seg];
+            const uint32_t g0 = RANGE ? run.g_seg0 : P.seg_list[seg];
+            uint32_t i_seg0 = 0;  // (RANGE) needle offset of the segment's first probe
+            if constexpr (RANGE) i_seg0 = (g0 - rp.ch.pbase[chunk_of_uniform(rp.ch, g0)] + 1u) * step;
 #ifdef ASGART_PROFILE_EXTEND
             const unsigned long long k7_seg0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -744,7 +801,7 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
                         ++k7_sum_n;
 #endif
                         if (fam_open && A0 == 0 && prev_t_before >= spur_until) {  // the flush of src/automaton.rs:182-200
-                            ++fam_seq;
+                            if (!RANGE || C(12) >= emit_from_i) ++fam_seq;  // (RANGE: the flushes from the cut on)
                             next_seq = 0;
                             fam_open = false;
                         }
@@ -755,7 +812,10 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
                             const bool un = in && bv == kNone && hf != 0;
                             const unsigned long long m = __ballot(un);
                             const uint32_t at = n_new + (uint32_t)__popcll(m & lt_mask);
-                            if (un && at < kNewMax) s_newx[sp][at] = x;
+                            if (un && at < kNewMax) {
+                                s_newx[sp][at] = x;
+                                if constexpr (RANGE) s_newh[sp][at] = (uint16_t)(h0 + (uint32_t)lane);
+                            }
                             n_new += (uint32_t)__popcll(m);
                             if (use_flag) spur = spur || __ballot(in && bv == kNone && hf == 0) != 0ull;
                         };
@@ -769,7 +829,7 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
                             rank_group(h0, s_best[prev_bb][h], use_flag ? s_hflag[prev_off + h] : (uint8_t)1, s_hits[prev_off + h]);
                         }
                         if (n_new > total_av || n_new > kNewMax || A0 + n_new > cap_eff) pflags |= K8_OVF;
-                        seq_base = next_seq;
+                        seq_base = RANGE ? (C(12) - i_seg0) << 10 : next_seq;
                         next_seq += n_new;
                         fam_open = true;
                         if (spur) spur_until = max(spur_until, prev_t_after + rp.tstar - 1u);
@@ -796,7 +856,7 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
                             uint32_t ch = 0;
                             if (has_cur && !stillborn) {
                                 const PosT x = s_newx[sp][min(r, n_new - 1u)];
-                                ch = offer_window(q, (PosT)(x + 1u), (WinT)thr0 + (WinT)(k - 1u), seq_base + r, who, ns_b);
+                                ch = offer_window(q, (PosT)(x + 1u), (WinT)thr0 + (WinT)(k - 1u), seq_of(seq_base, min(r, n_new - 1u), sp), who, ns_b);
                             }
                             if (r < n_new) s_newch[sp][r] = who ? ch : 0u;
                         }
@@ -856,15 +916,30 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
                 }
                 const uint32_t t_proc = uni(s_end[0]);
                 const bool ran_out = uni(s_end[1]) != 0u;
+                if constexpr (RANGE) {
+                    // the family state this run ends in: flushes since the cut, open or not, how long a flush is still held back
+                    if (lane == 0) {
+                        uint32_t *m = P.run_meta + seg * 8ull;
+                        m[1] = fam_seq;
+                        m[2] = fam_open ? 1u : 0u;
+                        m[3] = spur_until > t_proc ? spur_until - t_proc : 0u;
+                    }
+                }
                 if (fam_open && total_free == (uint32_t)CAP && t_proc >= spur_until) fam_open = false;
-                if (ran_out) {
+                if (RANGE && !(run.flags & kRunLast)) {
+                    // (the segment goes on behind this run: its end is the last range's business)
+                } else if (ran_out) {
                     if (lane == 0) atomicAdd(&P.ctr[CT_RANOUT], 1ull);
                 } else if (fam_open) {  // arms alive at the end of the chunk void their family (src/automaton.rs:201-203)
                     emit_records(lane == 0, (PosT)0, (PosT)0, (PosT)0, (PosT)0, kTombstone, fam_seq);
                 }
             } else if (lane == 0) {
-                const unsigned long long at = atomicAdd(P.ovf_count, 1ull);
-                if (P.ovf_list) P.ovf_list[at] = g0;
+                if constexpr (RANGE) {
+                    P.run_meta[seg * 8ull + 4ull] = 1u;  // (the host runs the whole segment instead)
+                } else {
+                    const unsigned long long at = atomicAdd(P.ovf_count, 1ull);
+                    if (P.ovf_list) P.ovf_list[at] = g0;
+                }
             }
         } else {
             // =====================================================================================================
@@ -877,7 +952,7 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
             while ((1ull << bsh) < (unsigned long long)G + k) ++bsh;
             bsh += P.fast_bsh;
             const uint32_t kGenBits = min(kGenMax, max(2u, P.gen_bits));
-            const uint32_t g0 = P.seg_list[seg];
+            const uint32_t g0 = RANGE ? run.g_seg0 : P.seg_list[seg];
             if (lane == 0) {
             heartbeat(P, g0, 0u);
             seg_clock(P);
@@ -886,7 +961,7 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
             const uint64_t cs = rp.ch.start[c], cl = rp.ch.len[c];
             const uint32_t pb = rp.ch.pbase[c];
             const uint32_t chunk_end = rp.ch.pbase[c + 1];
-            const uint32_t g_end = min(chunk_end, rp.g_hi);
+            const uint32_t g_end = RANGE ? min(min(chunk_end, rp.g_hi), run.g_stop) : min(chunk_end, rp.g_hi);
             if (lane == 0) {
                 s_seg[0] = g0;
                 s_seg[1] = cs;
@@ -896,7 +971,7 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
             bool done = false, giveup = false;
             uint32_t hbuf = 2;  // (the first batch moves it to 0)
             // ---- the batch under the cursor ---------------------------------------------------------------------
-            uint32_t g = g0, nbb = 0, pos = 0, f_l = 0, rel_l = 0, tot = 0;
+            uint32_t g = RANGE ? run.g_begin : g0, nbb = 0, pos = 0, f_l = 0, rel_l = 0, tot = 0;
             unsigned long long hm = 0, qm = 0, base = 0;
             bool staged = false;  // the rows of the batch under the cursor are in s_hits[hbuf] (or on their way)
             auto load_batch = [&]() {  // -> false: a probe with more hits than the staging area
@@ -1129,7 +1204,7 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
                     write_cmd(sc == 0u ? 2u : sc - 1u, p_after, Before{N(1), N(6), N(7), N(2), N(9), N(30), N(31)});
                     if ((p_after.flags & K7_LAST) && lane == 0) {  // (what the ranking wave needs when the segment is over)
                         s_end[0] = t_proc;
-                        s_end[1] = (!done && g_end < chunk_end) ? 1u : 0u;
+                        s_end[1] = (!done && g_end < chunk_end && (!RANGE || min(chunk_end, rp.g_hi) == g_end)) ? 1u : 0u;
                     }
                 }
                 if (npre & K7_STAGE) store_rows(st_tot, st_buf);

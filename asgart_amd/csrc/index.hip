@@ -75,6 +75,10 @@ const OptDesc kOptions[] = {
     {"sparse_to6", &Options::sparse_to6, 0, 512},
     {"prewarm", &Options::prewarm, 0, 1},
     {"cache_calls", &Options::cache_calls, 0, 1000000},
+    {"split", &Options::split, 0, 1},
+    {"split_len", &Options::split_len, 64, 1 << 20},
+    {"split_warm", &Options::split_warm, 0, 1 << 20},
+    {"split_min", &Options::split_min, 128, 1ll << 31},
     {"watchdog_s", &Options::watchdog_s, 0, 86400},
     {"test_stall_s", &Options::test_stall_s, 0, 60},
     {"tier_streams", &Options::tier_streams, 1111111, 7777777},

@@ -126,11 +126,13 @@ struct Workspace {
     DevBuf out_a, out_b;
     DevBuf seg_info;   // uint2 per segment: hits and probe positions walked (placement -> cluster_barren_kernel)
     DevBuf seg_slots;  // u64[8][4096]: per tier and workgroup, when its current segment started (longest-segment statistics)
+    DevBuf split_buf;  // long segments run as ranges (option split): counters, runs, cuts, split segments, run states, verdicts
+    DevBuf split_dump; // ... and the arms every run leaves alive (8 words per arm, kRunDumpCap arms per run)
     // every buffer goes back to the device (or to the block cache): ONE list, next to the members
     void release_all() {
         DevBuf *bufs[] = {&chunks, &p_lo, &p_raw, &p_filt, &row_off, &blk, &hits, &big_list, &rank_list, &seg_list,
                           &counters, &fam_sds, &ovf_list, &own_list, &scratch, &hit_flag, &seg_keys, &seg_vals,
-                          &sort_tmp, &rec_k32, &rec_k64, &rec_idx, &rec_sorted, &pat, &out_a, &out_b, &seg_info, &seg_slots};
+                          &sort_tmp, &rec_k32, &rec_k64, &rec_idx, &rec_sorted, &pat, &out_a, &out_b, &seg_info, &seg_slots, &split_buf, &split_dump};
         static_assert(sizeof(Workspace) == sizeof(bufs) / sizeof(bufs[0]) * sizeof(DevBuf),
                       "a buffer of the workspace is missing from release_all");
         for (DevBuf *b : bufs) b->release();
@@ -326,6 +328,14 @@ struct Options {
                                     // bound says (0: only the long ones, option long3)
     int64_t dense6 = 32;            // with k7 in tier 3: segments of ANY length whose arm bound sends them to tier 6 go to tier 3 instead with at
                                     // least this many hits per processed probe on average (0: off)
+    int64_t split = 1;              // 1: the long segments of the long-shape tiers run as RANGES side by side (plan_ranges_kernel,
+                                    // pipeline_dev.hpp): every range starts from an empty arm list split_warm probes in front of its cut,
+                                    // and what it holds AT the cut is compared with what the range before holds there; a segment with a cut
+                                    // that differs is run again as a whole (and not cut again by this index).  32-bit positions, unsharded
+                                    // calls.  0: every segment is one work item
+    int64_t split_len = 8192;       // probes per range
+    int64_t split_warm = 3072;      // probes a range starts in front of its cut
+    int64_t split_min = 24576;      // segments shorter than this (probe positions) are not cut
     int64_t cache_calls = 2;        // the blocks an index build released stay in the block cache until the index has answered this many
                                     // search calls (then, at its destruction, on an allocation failure and by asgart_trim_cache they go
                                     // back to the device): giving ~100 GB back costs the next allocation of the process 20-30 ms per
@@ -443,6 +453,8 @@ struct asgart_index {
         int32_t n_passes = 0;
         bool pipeline = false;
     } fuse_verdict;
+    // segments a cut of which did not hold (option split): orientation << 32 | first probe counted from the start of its pass
+    std::vector<uint64_t> split_blocked;
     asgart::DevBuf ws_arena;  // the block the call contexts' per-probe buffers were carved from (carve_probe_workspace), or empty
     std::mutex pass_mu;  // one asgart_search_duplications_passes call at a time per index
     std::vector<std::unique_ptr<asgart::PassWorker>> pass_workers;

@@ -274,12 +274,14 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
     constexpr size_t kCtrBytes = (size_t)CT_COUNT * 8;
     const size_t ch_bytes = (size_t)n_chunks * 16 + ((size_t)n_chunks + 1) * 4;
     void *ctl_p = nullptr;
-    RC_TRY(cx.ctl(kCtrBytes + ch_bytes + 256, &ctl_p));
+    constexpr size_t kSplitMirror = 64 << 10;  // (option split: host copy of Workspace::split_buf)
+    RC_TRY(cx.ctl(kCtrBytes + ch_bytes + 256 + 64 + kSplitMirror, &ctl_p));
     unsigned long long *const h_ctr = static_cast<unsigned long long *>(ctl_p);
     unsigned long long *const h_scalar = h_ctr + CT_COUNT;  // source of small host-to-device updates
     uint64_t *const h_start = reinterpret_cast<uint64_t *>(static_cast<char *>(ctl_p) + kCtrBytes + 256);
     uint64_t *const h_len = h_start + n_chunks;
     uint32_t *const h_pbase = reinterpret_cast<uint32_t *>(h_len + n_chunks);
+    char *const h_split = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(h_pbase + n_chunks + 1) + 63u) & ~(uintptr_t)63u);
     uint64_t P64 = 0;
     const uint64_t text_end = (idx->h_tail.size() && idx->h_tail.back() == '$') ? n - 1 : n;
     for (int64_t c = 0; c < n_chunks; ++c) {
@@ -349,6 +351,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
     uint64_t total_hits = 0, n_seg = 0, n_overflow = 0, n_heavy = 0;
     bool progress_given = false;
     double ms_tier2 = 0.0, ms_longest_tier = 0.0, ms_longest_segment = 0.0;
+    uint64_t n_split_segments = 0, n_split_refused = 0;
     RunParams rp;
     const auto t_host0 = std::chrono::steady_clock::now();
     for (int win_try = 0;; ++win_try) {
@@ -561,9 +564,26 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
         pp.seg_info = nullptr;
         // (not with the continuation filter -- option filter = 1, whose pre-pass does the placement itself)
         const bool cluster_barren = opt.barren >= 2 && opt.filter == 0 && rp.M > (uint64_t)k;
-        if (cluster_barren) {
+        // long segments as ranges side by side (option split; plan_ranges_kernel in pipeline_dev.hpp): the long shape of the
+        // one-barrier kernel, 32-bit positions, a call over every probe (no shard window, no ownership lists)
+        const bool split_on = opt.split != 0 && sizeof(SlotT) == 4 && n_shards == 1 && !lpt && k7_tier(3) && opt.k8 != 0 &&
+                              opt.filter == 0 && opt.split_len >= 64;
+        if (cluster_barren || split_on) {
             RC_TRY(w.seg_info.reserve((size_t)n_seg * sizeof(uint2)));
             pp.seg_info = w.seg_info.as<uint2>();
+        }
+        // Workspace::split_buf: [4 counters (u64): runs, cuts, split segments, work cursor | runs | cuts | split segments |
+        // run states | verdicts per cut | per run: what is added to its records' family ordinals | segments to run again]
+        constexpr uint32_t kMaxRuns = 512, kMaxCuts = 256, kMaxSplits = 128;
+        constexpr size_t kOffRuns = 64, kOffCuts = kOffRuns + kMaxRuns * sizeof(RangeRun), kOffSplits = kOffCuts + kMaxCuts * 8,
+                         kOffMeta = kOffSplits + kMaxSplits * sizeof(SplitSeg), kOffOk = kOffMeta + kMaxRuns * 32,
+                         kOffFix = kOffOk + kMaxCuts * 4, kOffAgain = kOffFix + kMaxRuns * 4, kSplitBytes = kOffAgain + kMaxSplits * 4;
+        static_assert(kSplitBytes <= kSplitMirror, "split mirror");
+        char *d_split = nullptr;
+        if (split_on) {
+            RC_TRY(w.split_buf.reserve(kSplitBytes));
+            d_split = w.split_buf.as<char>();
+            HIP_TRY(hipMemsetAsync(d_split, 0, 64, s));
         }
         pp.k = (uint32_t)k;
         pp.step = (uint32_t)step;
@@ -623,6 +643,30 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(cx.ev[15], s));
         }
+        if (split_on) {
+            SplitParams sp{};
+            sp.range_len = (uint32_t)opt.split_len;
+            sp.warm = (uint32_t)opt.split_warm;
+            sp.min_span = (uint32_t)std::min<int64_t>(opt.split_min, 0x7FFFFFFF);
+            sp.max_runs = kMaxRuns;
+            sp.max_cuts = kMaxCuts;
+            sp.max_splits = kMaxSplits;
+            {   // segments a cut of which failed in an earlier call of this index: as probe numbers of THIS call
+                std::lock_guard<std::mutex> lk(idx->mu);
+                for (uint64_t b : idx->split_blocked)
+                    for (int32_t p_ = 0; p_ < n_passes && sp.n_blocked < 16u; ++p_)
+                        if (((rp.modes >> (8 * p_)) & 0xFFu) == (uint32_t)(b >> 32))
+                            sp.blocked[sp.n_blocked++] = h_pbase[(int64_t)p_ * n_chunks_pass] + (uint32_t)b;
+                if (idx->split_blocked.size() > 8) sp.min_span = 0x7FFFFFFFu;  // (an input that keeps refusing: no more cuts)
+            }
+            plan_ranges_kernel<<<grid_for(n_seg), 256, 0, s>>>(rp, sp, p_filt, seg_list, d_ctr + CT_SEG, kbuf, pp.seg_info,
+                                                              reinterpret_cast<unsigned long long *>(d_split),
+                                                              reinterpret_cast<RangeRun *>(d_split + kOffRuns),
+                                                              reinterpret_cast<uint2 *>(d_split + kOffCuts),
+                                                              reinterpret_cast<SplitSeg *>(d_split + kOffSplits));
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(h_split, d_split, kOffMeta, hipMemcpyDeviceToHost, s));
+        }
         const uint32_t *order = nullptr;
         const uint32_t *sorted_keys = nullptr;
         RC_TRY(sort_segments(w, kbuf, vbuf, n_seg, s, &order, &sorted_keys, lpt));
@@ -638,6 +682,15 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             h_tp[t] = h_ctr[CT_TPROBES1 + t];
             h_th[t] = h_ctr[CT_THITS1 + t];
         }
+        const unsigned long long *const h_split_hdr = reinterpret_cast<const unsigned long long *>(h_split);
+        const uint32_t n_runs = split_on ? (uint32_t)h_split_hdr[0] : 0u, n_cuts = split_on ? (uint32_t)h_split_hdr[1] : 0u,
+                       n_splits = split_on ? (uint32_t)h_split_hdr[2] : 0u;
+        std::vector<SplitSeg> split_segs(n_splits);
+        if (n_splits) memcpy(split_segs.data(), h_split + kOffSplits, (size_t)n_splits * sizeof(SplitSeg));
+        n_split_segments = n_splits;
+        if (opt.debug && split_on)
+            fprintf(stderr, "[asgart] %u long segment(s) cut into ranges: %u runs (ranges of %lld probes + warm-ups of %lld), %u cuts to check\n",
+                    n_splits, n_runs, (long long)opt.split_len, (long long)opt.split_warm, n_cuts);
         if (opt.debug) {
             fprintf(stderr, "[asgart] %llu segments, %llu walked wave by wave; per tier:", (unsigned long long)n_seg,
                     (unsigned long long)h_ctr[CT_LONGSEG]);
@@ -863,6 +916,29 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                     break;
                 }
             };
+            // the runs over ranges of the cut segments: first, on the main stream (idle while the tiers run) -- they are the
+            // longest work items of the call, one workgroup each
+            if (n_runs) {
+                if constexpr (sizeof(SlotT) == 4) {
+                    RC_TRY(w.split_dump.reserve((size_t)n_runs * kRunDumpCap * 32));
+                    HIP_TRY(hipMemsetAsync(d_split + 24, 0, 8, s));                         // work cursor
+                    HIP_TRY(hipMemsetAsync(d_split + kOffMeta, 0, (size_t)n_runs * 32, s));  // run states
+                    ep.runs = reinterpret_cast<const RangeRun *>(d_split + kOffRuns);
+                    ep.run_meta = reinterpret_cast<uint32_t *>(d_split + kOffMeta);
+                    ep.run_dump = w.split_dump.as<uint32_t>();
+                    ep.seg_list = nullptr;
+                    ep.n_seg_ptr = reinterpret_cast<const unsigned long long *>(d_split);
+                    ep.cursor = reinterpret_cast<unsigned long long *>(d_split + 24);
+                    ep.ovf_list = nullptr;
+                    ep.ovf_count = d_ctr + CT_OVF1 + 2;
+                    ep.max_items = 0;
+                    ep.tier = 3;  // (statistics: with the long-segment tier)
+                    ep.seg_slots = w.seg_slots.as<unsigned long long>();  // (slot block 0: no tier's)
+                    ep.hb = cx.d_hb ? cx.d_hb : nullptr;
+                    extend_k8_kernel<SlotT, kK7LongLayers<SlotT>, 1024, kHitBatch, kFastLongRows<SlotT>, 2, true><<<n_runs, 1024, 0, s>>>(ep);
+                    HIP_TRY(hipGetLastError());
+                }
+            }
             hipStream_t tier_stream[kTiers + 1] = {s, st7, st2, st3, st4, st5, st6, st2};
             {   // option tier_streams: tiers that share a stream run one after the other, in launch order
                 const hipStream_t pool[8] = {s, s, st2, st3, st4, st5, st6, st7};
@@ -1033,8 +1109,79 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             HIP_TRY(hipStreamWaitEvent(s, cx.ev[9], 0));
             HIP_TRY(hipStreamWaitEvent(s, cx.ev[10], 0));
             HIP_TRY(hipStreamWaitEvent(s, cx.ev[12], 0));
+            if (n_cuts) {
+                validate_cuts_kernel<<<n_cuts, 256, 0, s>>>(reinterpret_cast<const uint2 *>(d_split + kOffCuts),
+                                                           reinterpret_cast<const uint32_t *>(d_split + kOffMeta), w.split_dump.as<uint32_t>(),
+                                                           reinterpret_cast<uint32_t *>(d_split + kOffOk));
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipMemcpyAsync(h_split + kOffMeta, d_split + kOffMeta, kOffFix - kOffMeta, hipMemcpyDeviceToHost, s));
+            }
             HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, kCtrBytes, hipMemcpyDeviceToHost, s));
             RC_TRY(wd_sync(idx, cx, s, "the extension tiers"));
+            if (n_runs) {
+                // Every cut of a segment held: the family ordinals of range j count on from the flushes of ranges 0 .. j - 1.
+                // One did not: the segment's range records are dropped and it runs again as a whole, behind the tiers (and
+                // this index does not cut it again).
+                const uint32_t *h_meta = reinterpret_cast<const uint32_t *>(h_split + kOffMeta);
+                const uint32_t *h_ok = reinterpret_cast<const uint32_t *>(h_split + kOffOk);
+                uint32_t *h_fix = reinterpret_cast<uint32_t *>(h_split + kOffFix);
+                uint32_t *h_again = reinterpret_cast<uint32_t *>(h_split + kOffAgain);
+                uint32_t n_again = 0;
+                for (const SplitSeg &sg : split_segs) {
+                    bool ok = true;
+                    for (uint32_t j = 0; j + 1 < sg.n_ranges; ++j) ok = ok && h_ok[sg.cut_base + j] != 0u;
+                    ok = ok && h_meta[(size_t)(sg.run_base + sg.n_ranges - 1) * 8 + 4] == 0u;  // (the last range is no cut's left side)
+                    uint32_t base = 0;
+                    for (uint32_t j = 0; j < sg.n_ranges; ++j) {
+                        h_fix[sg.run_base + j] = ok ? base : 0xFFFFFFFFu;
+                        base += h_meta[(size_t)(sg.run_base + j) * 8 + 1];
+                    }
+                    for (uint32_t j = 0; j + 1 < sg.n_ranges; ++j) h_fix[sg.run_base + sg.n_ranges + j] = 0xFFFFFFFFu;  // (warm-ups write none)
+                    if (!ok && opt.debug) {
+                        fprintf(stderr, "[asgart] ranges: segment at probe %u (%u ranges) did not join up; cuts (arms in front / in the warm-up, family open, held flush):",
+                                sg.g_seg0, sg.n_ranges);
+                        for (uint32_t j = 0; j + 1 < sg.n_ranges; ++j) {
+                            const uint32_t *ma = h_meta + (size_t)(sg.run_base + j) * 8, *mb = h_meta + (size_t)(sg.run_base + sg.n_ranges + j) * 8;
+                            fprintf(stderr, " %s%u/%u,%u/%u,%u/%u%s", h_ok[sg.cut_base + j] ? "" : "[", ma[0], mb[0], ma[2], mb[2], ma[3], mb[3],
+                                    h_ok[sg.cut_base + j] ? "" : "]");
+                        }
+                        fprintf(stderr, "%s\n", h_meta[(size_t)(sg.run_base + sg.n_ranges - 1) * 8 + 4] ? " (the last range gave up)" : "");
+                    }
+                    if (!ok) {
+                        h_again[n_again++] = sg.g_seg0;
+                        const int64_t c_ = chunk_of_host(sg.g_seg0);
+                        const int64_t p_ = c_ / n_chunks_pass;
+                        std::lock_guard<std::mutex> lk(idx->mu);
+                        idx->split_blocked.push_back((uint64_t)((rp.modes >> (8 * p_)) & 0xFFu) << 32 |
+                                                     (uint64_t)(sg.g_seg0 - h_pbase[p_ * n_chunks_pass]));
+                    }
+                }
+                n_split_refused = n_again;
+                if (opt.debug)
+                    fprintf(stderr, "[asgart] ranges: %u of %u cut segment(s) joined up%s\n", n_splits - n_again, n_splits,
+                            n_again ? "; the others run again as a whole" : "");
+                HIP_TRY(hipMemcpyAsync(d_split + kOffFix, h_fix, kSplitBytes - kOffFix, hipMemcpyHostToDevice, s));
+                const uint64_t n_slots = std::min<uint64_t>(h_ctr[CT_SD], rec_cap);
+                if (n_slots) fixup_records_kernel<<<grid_for(n_slots), 256, 0, s>>>(w.fam_sds.as<SdRec>(), n_slots, reinterpret_cast<const uint32_t *>(d_split + kOffFix));
+                HIP_TRY(hipGetLastError());
+                if (n_again) {
+                    *h_scalar = n_again;
+                    HIP_TRY(hipMemcpyAsync(d_ctr + CT_NF, h_scalar, 8, hipMemcpyHostToDevice, s));
+                    HIP_TRY(hipMemsetAsync(d_ctr + CT_CURF, 0, 8, s));
+                    ep.seg_list = reinterpret_cast<const uint32_t *>(d_split + kOffAgain);
+                    ep.n_seg_ptr = d_ctr + CT_NF;
+                    ep.cursor = d_ctr + CT_CURF;
+                    ep.ovf_list = ovf[3 - 1];
+                    ep.ovf_count = d_ctr + CT_OVF1 + 3 - 1;  // (what the whole segment overflows goes the way of tier 3's own)
+                    ep.escalate_cost = 0xFFFFFFFFu;
+                    cascade_launch = true;
+                    launch_kernel(3, n_again, s);
+                    cascade_launch = false;
+                    HIP_TRY(hipGetLastError());
+                }
+                HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, kCtrBytes, hipMemcpyDeviceToHost, s));
+                RC_TRY(wd_sync(idx, cx, s, "the ranges of the cut segments"));
+            }
             PROF_DUMP("concurrent tiers");
             if (opt.debug) {
                 fprintf(stderr, "[asgart] all tiers and early re-runs done %.1f ms after the launches\n", since_launch());
@@ -1217,6 +1364,8 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
     stt.ms_extend_tier2 = ms_tier2;
     stt.ms_longest_tier = ms_longest_tier;
     stt.ms_longest_segment = ms_longest_segment;
+    stt.split_segments = n_split_segments;
+    stt.split_refused = n_split_refused;
     HIP_TRY(hipEventElapsedTime(&ms, cx.ev[0], cx.ev[11]));
     stt.ms_probe_count = ms;
     cx.has_last = true;

@@ -1066,8 +1066,31 @@ constexpr uint32_t kTombstone = 0xFFFFFFFFu;
 constexpr int kHitBatch = 1024;  // LDS staging for the hit rows of one probe batch
 constexpr uint32_t kEscalateCost = 40000;  // sum of (live arms + hits) over LDS-path probes
 
+// A RUN over part of a long segment (extend_k8_kernel<..., RANGE = true>; plan_ranges_kernel makes them): the walk starts at
+// probe g_begin with no arm and stops in front of g_stop; records are written from probe emit_from on (the cut: a hit-probe;
+// what lies in front of it is the run's warm-up and belongs to the range before).
+struct RangeRun {
+    uint32_t g_begin, g_stop;  // [g_begin, g_stop) (g_stop = ~0u: to the segment's end)
+    uint32_t g_seg0;           // first probe of the segment (record key, chunk)
+    uint32_t emit_from;        // the cut this run reports from (g_seg0: from the start)
+    uint32_t flags;            // kRunNoEmit | kRunLast
+    uint32_t split;            // which split segment (struct SplitSeg)
+    uint32_t pad0, pad1;
+};
+constexpr uint32_t kRunNoEmit = 1u;    // a warm-up on its own: only its final state is wanted (what the run behind the cut starts from)
+constexpr uint32_t kRunLast = 2u;      // the run that reaches the segment's end
+constexpr uint32_t kRunDumpCap = 5120; // arms a run can leave alive (the long shape's slots)
+// per run, 8 words (run_meta): 0 arms written to run_dump  1 flushes since the cut  2 family open  3 probes a flush is still held
+// back for  4 gave up (more arms than slots, a probe with more hits than the staging area)
+// per arm, 8 words (run_dump): creation number, left start, left end, right start | right end, threshold, gap, 0
+struct SplitSeg {
+    uint32_t g_seg0, run_base, n_ranges, cut_base;  // runs run_base .. + n_ranges - 1: the ranges; then the n_ranges - 1 warm-ups
+};
+
 template <class PosT>
 struct ExtParams {
+    const RangeRun *runs;                 // (RANGE launches) the work list
+    uint32_t *run_meta, *run_dump;        // ... and what the runs leave behind (see RangeRun)
     RunParams rp;
     const uint32_t *p_filt;
     const unsigned long long *row_off;
@@ -2226,6 +2249,151 @@ __global__ __launch_bounds__(64) void cluster_barren_kernel(RunParams rp, PlaceP
         }
     }
     if (lane == 0 && n_barren) atomicAdd(&ctr[CT_CLUSTER_BARREN], (unsigned long long)n_barren);
+}
+
+// ---- long segments as ranges that run side by side (option split) ---------------------------------------------------------
+// The probes of a segment are strictly serial, and the longest segment of a pass is the floor of its extension.  But the arm
+// list a tandem array leaves behind at some probe c is, some way into the array, a function of the last few thousand probes
+// only: a run that starts with NO arm `warm` probes in front of c holds, at c, exactly the arms (and the family state) of the
+// run that started at the segment's first probe -- when it does.  Whether it does is CHECKED, never assumed: the range in
+// front of the cut and a warm-up that stops at the cut both write out what they hold there (validate_cuts_kernel compares),
+// and a segment with a cut that fails is run again as a whole, its ranges' records dropped.
+//   plan_ranges_kernel     one thread per segment: the long ones of the long-shape tiers (3, 6) are taken off their tier's
+//                          list and cut at the first hit-probe at or behind every range_len-th probe
+//   validate_cuts_kernel   one workgroup per cut: same arms (by creation number, every field), same family state
+//   fixup_records_kernel   one thread per record slot: family ordinals of a range + the flushes of the ranges before it;
+//                          records of a segment that failed -> void
+struct SplitParams {
+    uint32_t range_len, warm, min_span;   // probes per range, warm-up probes in front of a cut, shortest segment that is cut
+    uint32_t max_runs, max_cuts, max_splits;
+    uint32_t n_blocked;
+    uint32_t blocked[16];                 // segments (first probe) that are not cut: a cut of theirs failed in an earlier call
+};
+__global__ __launch_bounds__(256) void plan_ranges_kernel(RunParams rp, SplitParams sp, const uint32_t *__restrict__ p_filt,
+                                                         const uint32_t *__restrict__ seg_list,
+                                                         const unsigned long long *__restrict__ n_seg_ptr,
+                                                         uint32_t *__restrict__ keys, const uint2 *__restrict__ seg_info,
+                                                         unsigned long long *__restrict__ hdr,  // 0 runs, 1 cuts, 2 split segments
+                                                         RangeRun *__restrict__ runs, uint2 *__restrict__ cuts,
+                                                         SplitSeg *__restrict__ splits) {
+    const unsigned long long sj = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (sj >= *n_seg_ptr) return;
+    const uint32_t key = keys[sj];
+    const uint32_t tier = (key >> 29) + 1u;
+    if (tier != 3u && tier != 6u) return;
+    const uint2 info = seg_info[sj];
+    const uint32_t span = info.y & 0x7FFFFFFFu;
+    if (!(info.y >> 31) || span < sp.min_span || span < 2u * sp.range_len) return;
+    // (creation numbers of a run: needle offset relative to the segment's first probe << 10 | hit index)
+    if ((unsigned long long)span * (unsigned long long)rp.step >= (1ull << 22) - 2ull) return;
+    const uint32_t g0 = seg_list[sj];
+    for (uint32_t b = 0; b < sp.n_blocked; ++b)
+        if (sp.blocked[b] == g0) return;
+    const uint32_t n_r = span / sp.range_len;
+    auto cut_of = [&](uint32_t j) -> uint32_t {  // first hit-probe at or behind g0 + j * range_len (0: none in reach)
+        uint32_t c = g0 + j * sp.range_len;
+        const uint32_t lim = min(g0 + span, c + sp.range_len / 2u);
+        while (c < lim) {
+            const uint32_t f = p_filt[c];
+            if (f >= 1u && f < kPending) return c;
+            ++c;
+        }
+        return 0u;
+    };
+    for (uint32_t j = 1; j < n_r; ++j)
+        if (!cut_of(j)) return;
+    const uint32_t n_runs = 2u * n_r - 1u;
+    const uint32_t run_base = (uint32_t)atomicAdd(&hdr[0], (unsigned long long)n_runs);
+    if (run_base + n_runs > sp.max_runs) {
+        atomicAdd(&hdr[0], 0ull - (unsigned long long)n_runs);
+        return;
+    }
+    const uint32_t cut_base = (uint32_t)atomicAdd(&hdr[1], (unsigned long long)(n_r - 1u));
+    const uint32_t split = (uint32_t)atomicAdd(&hdr[2], 1ull);
+    if (cut_base + n_r - 1u > sp.max_cuts || split >= sp.max_splits) {  // (sized together with max_runs: does not happen)
+        atomicAdd(&hdr[0], 0ull - (unsigned long long)n_runs);
+        atomicAdd(&hdr[1], 0ull - (unsigned long long)(n_r - 1u));
+        atomicAdd(&hdr[2], 0ull - 1ull);
+        return;
+    }
+    keys[sj] = (key & 0x1FFFFFFFu) | ((uint32_t)(kTierBarren - 1) << 29);  // off its tier's list
+    splits[split] = SplitSeg{g0, run_base, n_r, cut_base};
+    uint32_t c_prev = g0;
+    for (uint32_t j = 0; j < n_r; ++j) {
+        const uint32_t c_next = j + 1u < n_r ? cut_of(j + 1u) : 0xFFFFFFFFu;
+        RangeRun r{};
+        r.g_begin = (j == 0u || c_prev - g0 <= sp.warm) ? g0 : c_prev - sp.warm;
+        r.g_stop = c_next;
+        r.g_seg0 = g0;
+        r.emit_from = c_prev;
+        r.flags = j + 1u == n_r ? kRunLast : 0u;
+        r.split = split;
+        runs[run_base + j] = r;
+        if (j) {  // the warm-up in front of this range's cut, on its own: compared with what range j - 1 holds there
+            RangeRun w = r;
+            w.g_stop = c_prev;
+            w.flags = kRunNoEmit;
+            runs[run_base + n_r + j - 1u] = w;
+            cuts[cut_base + j - 1u] = make_uint2(run_base + j - 1u, run_base + n_r + j - 1u);
+        }
+        c_prev = c_next;
+    }
+}
+
+__global__ __launch_bounds__(256) void validate_cuts_kernel(const uint2 *__restrict__ cuts, const uint32_t *__restrict__ run_meta,
+                                                           const uint32_t *__restrict__ run_dump, uint32_t *__restrict__ cut_ok) {
+    constexpr uint32_t kSlots = 16384;  // > 3 x kRunDumpCap
+    __shared__ uint32_t s_tab[kSlots];
+    __shared__ uint32_t s_ok;
+    const uint2 cut = cuts[blockIdx.x];
+    const uint32_t *ma = run_meta + (size_t)cut.x * 8, *mb = run_meta + (size_t)cut.y * 8;
+    const uint32_t n = ma[0];
+    const bool meta_ok = n == mb[0] && n <= kRunDumpCap && ma[2] == mb[2] && ma[3] == mb[3] && !ma[4] && !mb[4];
+    for (uint32_t j = threadIdx.x; j < kSlots; j += blockDim.x) s_tab[j] = 0u;
+    if (threadIdx.x == 0) s_ok = meta_ok ? 1u : 0u;
+    __syncthreads();
+    if (meta_ok) {
+        const uint4 *da = reinterpret_cast<const uint4 *>(run_dump + (size_t)cut.x * kRunDumpCap * 8);
+        const uint4 *db = reinterpret_cast<const uint4 *>(run_dump + (size_t)cut.y * kRunDumpCap * 8);
+        for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) {
+            uint32_t h = (da[2 * j].x * 2654435761u) >> 18;
+            while (atomicCAS(&s_tab[h], 0u, j + 1u) != 0u) h = (h + 1u) & (kSlots - 1u);
+        }
+        __syncthreads();
+        bool ok = true;
+        for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) {
+            const uint4 b0 = db[2 * j], b1 = db[2 * j + 1];
+            uint32_t h = (b0.x * 2654435761u) >> 18;
+            bool found = false;
+            for (uint32_t probe = 0; probe < kSlots; ++probe) {
+                const uint32_t e = s_tab[h];
+                if (!e) break;
+                const uint4 a0 = da[2 * (e - 1u)];
+                if (a0.x == b0.x) {
+                    const uint4 a1 = da[2 * (e - 1u) + 1];
+                    found = a0.y == b0.y && a0.z == b0.z && a0.w == b0.w && a1.x == b1.x && a1.y == b1.y && a1.z == b1.z;
+                    break;
+                }
+                h = (h + 1u) & (kSlots - 1u);
+            }
+            ok = ok && found;
+        }
+        if (!ok) s_ok = 0u;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) cut_ok[blockIdx.x] = s_ok;
+}
+
+// run_fix[run]: what is added to the family ordinals of the run's records; ~0u: the run's records are dropped
+__global__ __launch_bounds__(256) void fixup_records_kernel(SdRec *__restrict__ recs, unsigned long long n, const uint32_t *__restrict__ run_fix) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    SdRec &r = recs[i];
+    if (r.g_start == kVoidStart || r.pad == 0u) return;
+    const uint32_t f = run_fix[r.pad - 1u];
+    if (f == 0xFFFFFFFFu) r.g_start = kVoidStart;
+    else r.fam_seq += f;
+    r.pad = 0u;
 }
 
 // tier list lengths from the sorted placement keys (tier-1 = key >> 29): n_t = first index whose

@@ -96,6 +96,8 @@ typedef struct asgart_stats {
                                   serial floor of the call: src/automaton.rs:96-201 is serial per chunk, and neither more
                                   compute units nor more GPUs shorten a segment (ms_longest_tier is the tier that FINISHED
                                   last, which is throughput when the tier holds many segments)                    */
+    uint64_t split_segments;   /* long segments that ran as ranges side by side (option split) ...                */
+    uint64_t split_refused;    /* ... and those of them whose ranges did not join up: run again as a whole        */
 } asgart_stats;
 
 typedef struct asgart_index asgart_index;

@@ -31,7 +31,7 @@ def test_struct_layouts():
     assert asgart_amd._Settings.max_gap_size.offset == 8
     assert asgart_amd._Settings.min_duplication_length.offset == 16
     assert asgart_amd._Settings.reverse.offset == 32
-    assert C.sizeof(asgart_amd.Stats) == 5 * 8 + 13 * 8 + 8 + 8 + 8 + 2 * 8 + 8 + 8 + 8 + 8
+    assert C.sizeof(asgart_amd.Stats) == 5 * 8 + 13 * 8 + 8 + 8 + 8 + 2 * 8 + 8 + 8 + 8 + 8 + 2 * 8
 
 
 def test_version_and_settings_from_cli(hiplib):

@@ -1305,6 +1305,58 @@ def test_k8_free_counts_do_not_depend_on_timing(hiplib, delay, monkeypatch):
                 assert np.array_equal(offs, eo) and np.array_equal(sds, es), (seed, rc, delay, cli)
 
 
+@pytest.mark.parametrize("shape", [(256, 128, 512), (256, 1024, 512), (128, 512, 256)])
+def test_long_segments_as_ranges_equal_whole_segments(hiplib, shape):
+    """Option split: a long segment runs as RANGES side by side -- every range starts from an empty arm list split_warm
+    probes in front of its cut, and what it holds at the cut (every arm, every field; family open or not; a held flush) is
+    compared on the device with what the range in front of the cut holds there.  Where the cuts hold, the ranges' records
+    (family ordinals counted on from the ranges before, creation order by (probe, hit)) must be the whole segment's; where
+    one does not, the segment runs again as a whole and the index does not cut it again.  Tandem-array cases of
+    tools/fuzz_k8.py with ranges of 128-256 probes (the shipped 8192 never cut a test-sized segment), every multi-hit
+    segment forced through the long shape, generation wraps every few probes in some cases: families, ProtoSDs AND keys
+    equal to the uncut run and to the oracle, for single calls and for both orientations as one job; both outcomes
+    (joined up / refused) must occur over the cases."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_k8
+
+    ln, warm, mn = shape
+    joined = refused = 0
+    for seed in (1, 4, 5, 6, 8, 11, 101, 107, 117, 123):
+        text, cli, genbits = fuzz_k8.make_case(seed)
+        chunks = [(0, len(text) - 1)]
+        oidx = oracle.Index.build(text)
+        with asgart_amd.Index(text, oidx.sa) as idx:
+            idx.set_option("force_tier", 3)
+            idx.set_option("test_genbits", genbits)
+            sts = [asgart_amd.RunSettings.from_cli(reverse=rc, complement=rc, **cli) for rc in (False, True)]
+            idx.set_option("split", 0)
+            whole = [idx.search_duplications_raw(chunks, st, with_keys=True) for st in sts]
+            assert idx.stats().split_segments == 0
+            key = ("ranges", seed)
+            if key not in _ORACLE_CACHE:
+                _ORACLE_CACHE[key] = oidx.run_raw(chunks, oracle.make_settings(reverse=False, complement=False, **cli), threads=4)
+            eo, es = _ORACLE_CACHE[key]
+            assert np.array_equal(whole[0][0], eo) and np.array_equal(whole[0][1], es), (seed, cli)
+            idx.set_option("split", 1)
+            idx.set_option("split_len", ln)
+            idx.set_option("split_warm", warm)
+            idx.set_option("split_min", mn)
+            for rep in range(2):   # (the second round: what was refused in the first is not cut again)
+                for j, st in enumerate(sts):
+                    got = idx.search_duplications_raw(chunks, st, with_keys=True)
+                    stt = idx.stats()
+                    assert all(np.array_equal(a, b) for a, b in zip(got, whole[j])), (seed, shape, rep, j, cli)
+                    if rep == 0:
+                        joined += stt.split_segments - stt.split_refused
+                        refused += stt.split_refused
+                    else:
+                        assert stt.split_refused == 0, (seed, shape, j)
+            both = idx.search_duplications_passes(chunks, sts, with_keys=True)
+            for j in range(2):
+                assert all(np.array_equal(a, b) for a, b in zip(both[j], whole[j])), (seed, shape, "one job", j)
+    assert joined > 0 and refused > 0, (shape, joined, refused)
+
+
 @pytest.mark.parametrize("name", ["satellites", "dense_repeats", "masked", "k31_odd", "long_sds"])
 def test_fused_passes_equal_single_calls_keys_included(hiplib, name):
     """asgart_search_duplications_passes runs passes that differ in orientation only as ONE job (the probe sequence is

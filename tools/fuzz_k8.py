@@ -6,7 +6,8 @@ random probe size / gap / minimum length, every segment with a multi-hit probe f
 barrier per probe, option k8 = 1; or K7 with k8 = 0), with a generation counter that wraps every few probes in some of
 the cases.  Results must equal the oracle's bit for bit.
 
-    python tools/fuzz_k8.py [cases=40] [first seed=0]        (ASGART_K8=0 for K7)
+    python tools/fuzz_k8.py [cases=40] [first seed=0]        (ASGART_K8=0 for K7; FUZZ_SPLIT=len,warm,min: with the long
+                                                              segments cut into ranges of len probes -- option split)
 """
 import faulthandler
 import os
@@ -66,6 +67,14 @@ def main():
         with asgart_amd.Index(text, oidx.sa) as idx:
             idx.set_option("force_tier", 3)
             idx.set_option("test_genbits", genbits)
+            if os.environ.get("FUZZ_SPLIT"):  # "len,warm,min": long segments as ranges (option split), sized for these cases
+                ln, warm, mn = (int(v) for v in os.environ["FUZZ_SPLIT"].split(","))
+                idx.set_option("split", 1)
+                idx.set_option("split_len", ln)
+                idx.set_option("split_warm", warm)
+                idx.set_option("split_min", mn)
+            else:
+                idx.set_option("split", 0)
             for rc in (False, True):
                 st = asgart_amd.RunSettings.from_cli(reverse=rc, complement=rc, **cli)
                 trace = os.environ.get("FUZZ_TRACE")
@@ -78,7 +87,8 @@ def main():
                 ok = np.array_equal(offs, eo) and np.array_equal(sds, es)
                 s = idx.stats(0)
                 print(f"seed {seed} n={len(text)} {cli} genbits={genbits} {'RC' if rc else 'direct'}: sds {len(sds)} "
-                      f"heavy {s.heavy_segments} ovf {s.overflow_segments} {'ok' if ok else 'DIFFERS'}", flush=True)
+                      f"heavy {s.heavy_segments} ovf {s.overflow_segments} cut {s.split_segments} refused {s.split_refused} "
+                      f"{'ok' if ok else 'DIFFERS'}", flush=True)
                 bad += 0 if ok else 1
     print(f"{cases} cases, {time.time() - t_all:.0f} s, {bad} mismatch(es)")
     sys.exit(1 if bad else 0)
