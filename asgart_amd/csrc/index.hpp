@@ -333,8 +333,8 @@ struct Options {
                                     // and what it holds AT the cut is compared with what the range before holds there; a segment with a cut
                                     // that differs is run again as a whole (and not cut again by this index).  32-bit positions, unsharded
                                     // calls.  0: every segment is one work item
-    int64_t split_len = 8192;       // probes per range
-    int64_t split_warm = 3072;      // probes a range starts in front of its cut
+    int64_t split_len = 12288;      // probes per range (about: the ranges of a segment are of one length)
+    int64_t split_warm = 6144;      // probes a range starts in front of its cut
     int64_t split_min = 24576;      // segments shorter than this (probe positions) are not cut
     int64_t cache_calls = 2;        // the blocks an index build released stay in the block cache until the index has answered this many
                                     // search calls (then, at its destruction, on an allocation failure and by asgart_trim_cache they go
@@ -454,7 +454,8 @@ struct asgart_index {
         bool pipeline = false;
     } fuse_verdict;
     // segments a cut of which did not hold (option split): orientation << 32 | first probe counted from the start of its pass
-    std::vector<uint64_t> split_blocked;
+    // (... and how many times)
+    std::vector<std::pair<uint64_t, uint32_t>> split_blocked;
     asgart::DevBuf ws_arena;  // the block the call contexts' per-probe buffers were carved from (carve_probe_workspace), or empty
     std::mutex pass_mu;  // one asgart_search_duplications_passes call at a time per index
     std::vector<std::unique_ptr<asgart::PassWorker>> pass_workers;

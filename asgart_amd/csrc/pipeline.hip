@@ -274,7 +274,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
     constexpr size_t kCtrBytes = (size_t)CT_COUNT * 8;
     const size_t ch_bytes = (size_t)n_chunks * 16 + ((size_t)n_chunks + 1) * 4;
     void *ctl_p = nullptr;
-    constexpr size_t kSplitMirror = 64 << 10;  // (option split: host copy of Workspace::split_buf)
+    constexpr size_t kSplitMirror = 512 << 10;  // (option split: host copy of Workspace::split_buf)
     RC_TRY(cx.ctl(kCtrBytes + ch_bytes + 256 + 64 + kSplitMirror, &ctl_p));
     unsigned long long *const h_ctr = static_cast<unsigned long long *>(ctl_p);
     unsigned long long *const h_scalar = h_ctr + CT_COUNT;  // source of small host-to-device updates
@@ -574,7 +574,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
         }
         // Workspace::split_buf: [4 counters (u64): runs, cuts, split segments, work cursor | runs | cuts | split segments |
         // run states | verdicts per cut | per run: what is added to its records' family ordinals | segments to run again]
-        constexpr uint32_t kMaxRuns = 512, kMaxCuts = 256, kMaxSplits = 128;
+        constexpr uint32_t kMaxRuns = 4096, kMaxCuts = 2048, kMaxSplits = 1024;
         constexpr size_t kOffRuns = 64, kOffCuts = kOffRuns + kMaxRuns * sizeof(RangeRun), kOffSplits = kOffCuts + kMaxCuts * 8,
                          kOffMeta = kOffSplits + kMaxSplits * sizeof(SplitSeg), kOffOk = kOffMeta + kMaxRuns * 32,
                          kOffFix = kOffOk + kMaxCuts * 4, kOffAgain = kOffFix + kMaxRuns * 4, kSplitBytes = kOffAgain + kMaxSplits * 4;
@@ -653,11 +653,13 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             sp.max_splits = kMaxSplits;
             {   // segments a cut of which failed in an earlier call of this index: as probe numbers of THIS call
                 std::lock_guard<std::mutex> lk(idx->mu);
-                for (uint64_t b : idx->split_blocked)
-                    for (int32_t p_ = 0; p_ < n_passes && sp.n_blocked < 16u; ++p_)
-                        if (((rp.modes >> (8 * p_)) & 0xFFu) == (uint32_t)(b >> 32))
-                            sp.blocked[sp.n_blocked++] = h_pbase[(int64_t)p_ * n_chunks_pass] + (uint32_t)b;
-                if (idx->split_blocked.size() > 8) sp.min_span = 0x7FFFFFFFu;  // (an input that keeps refusing: no more cuts)
+                for (const auto &b : idx->split_blocked)
+                    for (int32_t p_ = 0; p_ < n_passes && sp.n_blocked < 64u; ++p_)
+                        if (((rp.modes >> (8 * p_)) & 0xFFu) == (uint32_t)(b.first >> 32)) {
+                            sp.blocked[sp.n_blocked] = h_pbase[(int64_t)p_ * n_chunks_pass] + (uint32_t)b.first;
+                            sp.level[sp.n_blocked++] = (uint8_t)std::min<uint32_t>(b.second, 255u);
+                        }
+                if (idx->split_blocked.size() > 48) sp.min_span = 0x7FFFFFFFu;  // (an input that keeps refusing: no more cuts)
             }
             plan_ranges_kernel<<<grid_for(n_seg), 256, 0, s>>>(rp, sp, p_filt, seg_list, d_ctr + CT_SEG, kbuf, pp.seg_info,
                                                               reinterpret_cast<unsigned long long *>(d_split),
@@ -1151,9 +1153,15 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                         h_again[n_again++] = sg.g_seg0;
                         const int64_t c_ = chunk_of_host(sg.g_seg0);
                         const int64_t p_ = c_ / n_chunks_pass;
+                        const uint64_t key_ = (uint64_t)((rp.modes >> (8 * p_)) & 0xFFu) << 32 | (uint64_t)(sg.g_seg0 - h_pbase[p_ * n_chunks_pass]);
                         std::lock_guard<std::mutex> lk(idx->mu);
-                        idx->split_blocked.push_back((uint64_t)((rp.modes >> (8 * p_)) & 0xFFu) << 32 |
-                                                     (uint64_t)(sg.g_seg0 - h_pbase[p_ * n_chunks_pass]));
+                        bool known = false;
+                        for (auto &b : idx->split_blocked)
+                            if (b.first == key_) {
+                                ++b.second;
+                                known = true;
+                            }
+                        if (!known) idx->split_blocked.emplace_back(key_, 1u);
                     }
                 }
                 n_split_refused = n_again;

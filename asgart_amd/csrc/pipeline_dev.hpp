@@ -2267,7 +2267,8 @@ struct SplitParams {
     uint32_t range_len, warm, min_span;   // probes per range, warm-up probes in front of a cut, shortest segment that is cut
     uint32_t max_runs, max_cuts, max_splits;
     uint32_t n_blocked;
-    uint32_t blocked[16];                 // segments (first probe) that are not cut: a cut of theirs failed in an earlier call
+    uint32_t blocked[64];                 // segments (first probe) a cut of which did not hold in an earlier call of the index ...
+    uint8_t level[64];                    // ... how often: once -> four times the warm-up; twice -> not cut again
 };
 __global__ __launch_bounds__(256) void plan_ranges_kernel(RunParams rp, SplitParams sp, const uint32_t *__restrict__ p_filt,
                                                          const uint32_t *__restrict__ seg_list,
@@ -2280,19 +2281,25 @@ __global__ __launch_bounds__(256) void plan_ranges_kernel(RunParams rp, SplitPar
     if (sj >= *n_seg_ptr) return;
     const uint32_t key = keys[sj];
     const uint32_t tier = (key >> 29) + 1u;
-    if (tier != 3u && tier != 6u) return;
+    if (tier < 2u || tier > 6u) return;  // (the one-wave tier's segments are short; tier 7's arms do not fit the long shape)
     const uint2 info = seg_info[sj];
     const uint32_t span = info.y & 0x7FFFFFFFu;
-    if (!(info.y >> 31) || span < sp.min_span || span < 2u * sp.range_len) return;
+    if (!(info.y >> 31) || span < sp.min_span || span < 128u) return;
     // (creation numbers of a run: needle offset relative to the segment's first probe << 10 | hit index)
     if ((unsigned long long)span * (unsigned long long)rp.step >= (1ull << 22) - 2ull) return;
     const uint32_t g0 = seg_list[sj];
+    uint32_t warm = sp.warm;
     for (uint32_t b = 0; b < sp.n_blocked; ++b)
-        if (sp.blocked[b] == g0) return;
-    const uint32_t n_r = span / sp.range_len;
-    auto cut_of = [&](uint32_t j) -> uint32_t {  // first hit-probe at or behind g0 + j * range_len (0: none in reach)
-        uint32_t c = g0 + j * sp.range_len;
-        const uint32_t lim = min(g0 + span, c + sp.range_len / 2u);
+        if (sp.blocked[b] == g0) {
+            if (sp.level[b] > 1u) return;
+            warm = (uint32_t)min((unsigned long long)warm * 4ull, 0x7FFFFFFFull);
+        }
+    // ranges of about range_len probes, all of one length, at least two
+    const uint32_t n_r = max(2u, (span + sp.range_len / 2u) / sp.range_len);
+    const uint32_t len = (span + n_r - 1u) / n_r;
+    auto cut_of = [&](uint32_t j) -> uint32_t {  // first hit-probe at or behind g0 + j * len (0: none in reach)
+        uint32_t c = g0 + j * len;
+        const uint32_t lim = min(g0 + span, c + len / 2u);
         while (c < lim) {
             const uint32_t f = p_filt[c];
             if (f >= 1u && f < kPending) return c;
@@ -2322,7 +2329,7 @@ __global__ __launch_bounds__(256) void plan_ranges_kernel(RunParams rp, SplitPar
     for (uint32_t j = 0; j < n_r; ++j) {
         const uint32_t c_next = j + 1u < n_r ? cut_of(j + 1u) : 0xFFFFFFFFu;
         RangeRun r{};
-        r.g_begin = (j == 0u || c_prev - g0 <= sp.warm) ? g0 : c_prev - sp.warm;
+        r.g_begin = (j == 0u || c_prev - g0 <= warm) ? g0 : c_prev - warm;
         r.g_stop = c_next;
         r.g_seg0 = g0;
         r.emit_from = c_prev;
