@@ -571,7 +571,7 @@ def main():
         "work_per_step": {key: sum(s[key] for s in pass_stats) for key in
                           ("probes_total", "probes_searched", "probes_card_skipped", "probes_filter_rejected",
                            "raw_hits", "filtered_hits", "segments", "overflow_segments", "heavy_segments",
-                           "families", "proto_sds")},
+                           "families", "proto_sds", "split_segments", "split_refused")},
         "work_per_step_scope": "rank 0's shard" if world > 1 else "whole job",
     }
 
