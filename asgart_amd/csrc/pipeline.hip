@@ -565,8 +565,10 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
         // (not with the continuation filter -- option filter = 1, whose pre-pass does the placement itself)
         const bool cluster_barren = opt.barren >= 2 && opt.filter == 0 && rp.M > (uint64_t)k;
         // long segments as ranges side by side (option split; plan_ranges_kernel in pipeline_dev.hpp): the long shape of the
-        // one-barrier kernel, 32-bit positions, a call over every probe (no shard window, no ownership lists)
-        const bool split_on = opt.split != 0 && sizeof(SlotT) == 4 && n_shards == 1 && !lpt && k7_tier(3) && opt.k8 != 0 &&
+        // one-barrier kernel, 32-bit positions; also in a sharded call (the segments its window cuts short are left alone: only
+        // a segment whose end the placement walk has seen is cut), but not with ownership lists (option shard_lpt: every shard
+        // holds every segment there)
+        const bool split_on = opt.split != 0 && sizeof(SlotT) == 4 && !lpt && k7_tier(3) && opt.k8 != 0 &&
                               opt.filter == 0 && opt.split_len >= 64;
         if (cluster_barren || split_on) {
             RC_TRY(w.seg_info.reserve((size_t)n_seg * sizeof(uint2)));

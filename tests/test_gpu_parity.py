@@ -1320,7 +1320,7 @@ def test_long_segments_as_ranges_equal_whole_segments(hiplib, shape):
     import fuzz_k8
 
     ln, warm, mn = shape
-    joined = refused = 0
+    joined = refused = sharded_cut = 0
     for seed in (1, 4, 5, 6, 8, 11, 101, 107, 117, 123):
         text, cli, genbits = fuzz_k8.make_case(seed)
         chunks = [(0, len(text) - 1)]
@@ -1356,6 +1356,22 @@ def test_long_segments_as_ranges_equal_whole_segments(hiplib, shape):
             both = idx.search_duplications_passes(chunks, sts, with_keys=True)
             for j in range(2):
                 assert all(np.array_equal(a, b) for a, b in zip(both[j], whole[j])), (seed, shape, "one job", j)
+            # sharded calls cut the segments their window holds whole (a fresh verdict per segment: new index)
+        with asgart_amd.Index(text, oidx.sa) as idx:
+            idx.set_option("force_tier", 3)
+            idx.set_option("test_genbits", genbits)
+            idx.set_option("split_len", ln)
+            idx.set_option("split_warm", warm)
+            idx.set_option("split_min", mn)
+            n_cut = 0
+            parts = []
+            for r in range(3):
+                parts.append(idx.search_duplications_raw(chunks, sts[0], shard=r, n_shards=3, with_keys=True))
+                n_cut += idx.stats().split_segments
+            mo, ms = asgart_amd.merge_shards(parts)
+            assert np.array_equal(mo, whole[0][0]) and np.array_equal(ms, whole[0][1]), (seed, shape, "3 shards")
+            sharded_cut += n_cut
+    assert sharded_cut > 0, shape
     assert joined > 0 and refused > 0, (shape, joined, refused)
 
 
