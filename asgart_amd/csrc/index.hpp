@@ -331,8 +331,9 @@ struct Options {
     int64_t split = 1;              // 1: the long segments of the long-shape tiers run as RANGES side by side (plan_ranges_kernel,
                                     // pipeline_dev.hpp): every range starts from an empty arm list split_warm probes in front of its cut,
                                     // and what it holds AT the cut is compared with what the range before holds there; a segment with a cut
-                                    // that differs is run again as a whole (and not cut again by this index).  32-bit positions, unsharded
-                                    // calls.  0: every segment is one work item
+                                    // that differs keeps the ranges up to it and runs the rest as ONE more run (the whole segment again when
+                                    // its first cut fails); the index then plans only the cuts that held.  32-bit positions.  0: every
+                                    // segment is one work item
     int64_t split_len = 12288;      // probes per range (about: the ranges of a segment are of one length)
     int64_t split_warm = 6144;      // probes a range starts in front of its cut
     int64_t split_min = 24576;      // segments shorter than this (probe positions) are not cut
@@ -454,7 +455,7 @@ struct asgart_index {
         bool pipeline = false;
     } fuse_verdict;
     // segments a cut of which did not hold (option split): orientation << 32 | first probe counted from the start of its pass
-    // (... and how many times)
+    // (... and how many of their cuts, from the start, held: only those are planned again)
     std::vector<std::pair<uint64_t, uint32_t>> split_blocked;
     asgart::DevBuf ws_arena;  // the block the call contexts' per-probe buffers were carved from (carve_probe_workspace), or empty
     std::mutex pass_mu;  // one asgart_search_duplications_passes call at a time per index

@@ -650,7 +650,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             sp.range_len = (uint32_t)opt.split_len;
             sp.warm = (uint32_t)opt.split_warm;
             sp.min_span = (uint32_t)std::min<int64_t>(opt.split_min, 0x7FFFFFFF);
-            sp.max_runs = kMaxRuns;
+            sp.max_runs = kMaxRuns - kMaxSplits;  // (one more run per cut segment may follow)
             sp.max_cuts = kMaxCuts;
             sp.max_splits = kMaxSplits;
             {   // segments a cut of which failed in an earlier call of this index: as probe numbers of THIS call
@@ -659,7 +659,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                     for (int32_t p_ = 0; p_ < n_passes && sp.n_blocked < 64u; ++p_)
                         if (((rp.modes >> (8 * p_)) & 0xFFu) == (uint32_t)(b.first >> 32)) {
                             sp.blocked[sp.n_blocked] = h_pbase[(int64_t)p_ * n_chunks_pass] + (uint32_t)b.first;
-                            sp.level[sp.n_blocked++] = (uint8_t)std::min<uint32_t>(b.second, 255u);
+                            sp.allowed[sp.n_blocked++] = (uint16_t)std::min<uint32_t>(b.second, 0xFFFFu);
                         }
                 if (idx->split_blocked.size() > 48) sp.min_span = 0x7FFFFFFFu;  // (an input that keeps refusing: no more cuts)
             }
@@ -922,11 +922,8 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             };
             // the runs over ranges of the cut segments: first, on the main stream (idle while the tiers run) -- they are the
             // longest work items of the call, one workgroup each
-            if (n_runs) {
+            auto launch_runs = [&](uint32_t n_items) {  // the runs from the work cursor on, one workgroup each
                 if constexpr (sizeof(SlotT) == 4) {
-                    RC_TRY(w.split_dump.reserve((size_t)n_runs * kRunDumpCap * 32));
-                    HIP_TRY(hipMemsetAsync(d_split + 24, 0, 8, s));                         // work cursor
-                    HIP_TRY(hipMemsetAsync(d_split + kOffMeta, 0, (size_t)n_runs * 32, s));  // run states
                     ep.runs = reinterpret_cast<const RangeRun *>(d_split + kOffRuns);
                     ep.run_meta = reinterpret_cast<uint32_t *>(d_split + kOffMeta);
                     ep.run_dump = w.split_dump.as<uint32_t>();
@@ -939,9 +936,16 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                     ep.tier = 3;  // (statistics: with the long-segment tier)
                     ep.seg_slots = w.seg_slots.as<unsigned long long>();  // (slot block 0: no tier's)
                     ep.hb = cx.d_hb ? cx.d_hb : nullptr;
-                    extend_k8_kernel<SlotT, kK7LongLayers<SlotT>, 1024, kHitBatch, kFastLongRows<SlotT>, 2, true><<<n_runs, 1024, 0, s>>>(ep);
-                    HIP_TRY(hipGetLastError());
+                    extend_k8_kernel<SlotT, kK7LongLayers<SlotT>, 1024, kHitBatch, kFastLongRows<SlotT>, 2, true><<<n_items, 1024, 0, s>>>(ep);
                 }
+            };
+            if (n_runs) {
+                // (room for one more run per cut segment: the rest behind the last cut that held, see below)
+                RC_TRY(w.split_dump.reserve((size_t)(n_runs + n_splits) * kRunDumpCap * 32));
+                HIP_TRY(hipMemsetAsync(d_split + 24, 0, 8, s));                         // work cursor
+                HIP_TRY(hipMemsetAsync(d_split + kOffMeta, 0, (size_t)n_runs * 32, s));  // run states
+                launch_runs(n_runs);
+                HIP_TRY(hipGetLastError());
             }
             hipStream_t tier_stream[kTiers + 1] = {s, st7, st2, st3, st4, st5, st6, st2};
             {   // option tier_streams: tiers that share a stream run one after the other, in launch order
@@ -1124,57 +1128,122 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             RC_TRY(wd_sync(idx, cx, s, "the extension tiers"));
             if (n_runs) {
                 // Every cut of a segment held: the family ordinals of range j count on from the flushes of ranges 0 .. j - 1.
-                // One did not: the segment's range records are dropped and it runs again as a whole, behind the tiers (and
-                // this index does not cut it again).
+                // The first cut that did not hold is cut f: ranges 0 .. f stand (range f started from a state that was checked),
+                // the records of the ranges behind it are dropped, and ONE more run covers the rest -- from where range f started
+                // (it passes cut f in the checked state, so it is exact from there on), reporting from cut f + 1 to the segment's
+                // end.  f = 0, or a run that gave up: the segment runs again as a whole on the ordinary kernel.  The index remembers
+                // how many cuts of the segment held and plans only those from then on.
                 const uint32_t *h_meta = reinterpret_cast<const uint32_t *>(h_split + kOffMeta);
                 const uint32_t *h_ok = reinterpret_cast<const uint32_t *>(h_split + kOffOk);
+                RangeRun *h_runs = reinterpret_cast<RangeRun *>(h_split + kOffRuns);
                 uint32_t *h_fix = reinterpret_cast<uint32_t *>(h_split + kOffFix);
                 uint32_t *h_again = reinterpret_cast<uint32_t *>(h_split + kOffAgain);
-                uint32_t n_again = 0;
+                uint32_t n_again = 0, n_tail = 0;
+                n_split_refused = 0;
+                struct Tail {
+                    uint32_t run, base, g_seg0, run_base, f;
+                };
+                std::vector<uint32_t> held_base;  // family-ordinal bases of the ranges whose records wait for their segment's last run
+                std::vector<Tail> tails;
+                auto remember = [&](uint32_t g_seg0, uint32_t allowed) {
+                    const int64_t p_ = chunk_of_host(g_seg0) / n_chunks_pass;
+                    const uint64_t key_ = (uint64_t)((rp.modes >> (8 * p_)) & 0xFFu) << 32 | (uint64_t)(g_seg0 - h_pbase[p_ * n_chunks_pass]);
+                    std::lock_guard<std::mutex> lk(idx->mu);
+                    for (auto &b : idx->split_blocked)
+                        if (b.first == key_) {
+                            b.second = std::min(b.second, allowed);
+                            return;
+                        }
+                    idx->split_blocked.emplace_back(key_, allowed);
+                };
                 for (const SplitSeg &sg : split_segs) {
-                    bool ok = true;
-                    for (uint32_t j = 0; j + 1 < sg.n_ranges; ++j) ok = ok && h_ok[sg.cut_base + j] != 0u;
-                    ok = ok && h_meta[(size_t)(sg.run_base + sg.n_ranges - 1) * 8 + 4] == 0u;  // (the last range is no cut's left side)
+                    const uint32_t n_cuts_sg = sg.n_ranges - 1;
+                    uint32_t f = n_cuts_sg;  // first cut that did not hold
+                    for (uint32_t j = 0; j < n_cuts_sg; ++j)
+                        if (!h_ok[sg.cut_base + j]) {
+                            f = j;
+                            break;
+                        }
+                    const bool last_gave_up = h_meta[(size_t)(sg.run_base + sg.n_ranges - 1) * 8 + 4] != 0u;
+                    const bool ok = f == n_cuts_sg && !last_gave_up;
+                    if (f == n_cuts_sg && last_gave_up) f = 0;  // (more arms than the long shape holds: the cascade's business)
                     uint32_t base = 0;
                     for (uint32_t j = 0; j < sg.n_ranges; ++j) {
-                        h_fix[sg.run_base + j] = ok ? base : 0xFFFFFFFFu;
+                        // (ranges in front of a cut that did not hold: decided when the run over the rest has come back)
+                        h_fix[sg.run_base + j] = ok ? base : ((f > 0 && j <= f) ? 0xFFFFFFFEu : 0xFFFFFFFFu);
+                        if (!ok && f > 0 && j <= f) held_base.push_back(base);
                         base += h_meta[(size_t)(sg.run_base + j) * 8 + 1];
+                        if (!ok && f > 0 && j == f) {
+                            RangeRun t = h_runs[sg.run_base + f];
+                            t.g_stop = 0xFFFFFFFFu;
+                            t.emit_from = h_runs[sg.run_base + f + 1].emit_from;
+                            t.flags = kRunLast;
+                            h_runs[n_runs + n_tail] = t;
+                            tails.push_back(Tail{n_runs + n_tail, base, sg.g_seg0, sg.run_base, f});
+                            ++n_tail;
+                        }
                     }
-                    for (uint32_t j = 0; j + 1 < sg.n_ranges; ++j) h_fix[sg.run_base + sg.n_ranges + j] = 0xFFFFFFFFu;  // (warm-ups write none)
+                    for (uint32_t j = 0; j < n_cuts_sg; ++j) h_fix[sg.run_base + sg.n_ranges + j] = 0xFFFFFFFFu;  // (warm-ups write none)
                     if (!ok && opt.debug) {
-                        fprintf(stderr, "[asgart] ranges: segment at probe %u (%u ranges) did not join up; cuts (arms in front / in the warm-up, family open, held flush):",
-                                sg.g_seg0, sg.n_ranges);
-                        for (uint32_t j = 0; j + 1 < sg.n_ranges; ++j) {
+                        fprintf(stderr, "[asgart] ranges: segment at probe %u (%u ranges): %u cut(s) held; cuts (arms in front / in the warm-up, family open, held flush):",
+                                sg.g_seg0, sg.n_ranges, f);
+                        for (uint32_t j = 0; j < n_cuts_sg; ++j) {
                             const uint32_t *ma = h_meta + (size_t)(sg.run_base + j) * 8, *mb = h_meta + (size_t)(sg.run_base + sg.n_ranges + j) * 8;
                             fprintf(stderr, " %s%u/%u,%u/%u,%u/%u%s", h_ok[sg.cut_base + j] ? "" : "[", ma[0], mb[0], ma[2], mb[2], ma[3], mb[3],
                                     h_ok[sg.cut_base + j] ? "" : "]");
                         }
-                        fprintf(stderr, "%s\n", h_meta[(size_t)(sg.run_base + sg.n_ranges - 1) * 8 + 4] ? " (the last range gave up)" : "");
+                        fprintf(stderr, "%s\n", last_gave_up ? " (the last range gave up)" : "");
                     }
                     if (!ok) {
-                        h_again[n_again++] = sg.g_seg0;
-                        const int64_t c_ = chunk_of_host(sg.g_seg0);
-                        const int64_t p_ = c_ / n_chunks_pass;
-                        const uint64_t key_ = (uint64_t)((rp.modes >> (8 * p_)) & 0xFFu) << 32 | (uint64_t)(sg.g_seg0 - h_pbase[p_ * n_chunks_pass]);
-                        std::lock_guard<std::mutex> lk(idx->mu);
-                        bool known = false;
-                        for (auto &b : idx->split_blocked)
-                            if (b.first == key_) {
-                                ++b.second;
-                                known = true;
-                            }
-                        if (!known) idx->split_blocked.emplace_back(key_, 1u);
+                        ++n_split_refused;
+                        remember(sg.g_seg0, f);
+                        if (f == 0) h_again[n_again++] = sg.g_seg0;
                     }
                 }
-                n_split_refused = n_again;
                 if (opt.debug)
-                    fprintf(stderr, "[asgart] ranges: %u of %u cut segment(s) joined up%s\n", n_splits - n_again, n_splits,
-                            n_again ? "; the others run again as a whole" : "");
-                HIP_TRY(hipMemcpyAsync(d_split + kOffFix, h_fix, kSplitBytes - kOffFix, hipMemcpyHostToDevice, s));
-                const uint64_t n_slots = std::min<uint64_t>(h_ctr[CT_SD], rec_cap);
+                    fprintf(stderr, "[asgart] ranges: %llu of %u cut segment(s) joined up%s\n", (unsigned long long)(n_splits - n_split_refused), n_splits,
+                            n_split_refused ? "; the others: the rest behind the last cut that held as one more run, or the whole segment again" : "");
+                for (const Tail &t : tails) h_fix[t.run] = 0xFFFFFFFEu;  // (until the run has come back)
+                HIP_TRY(hipMemcpyAsync(d_split + kOffFix, h_fix, kOffAgain - kOffFix, hipMemcpyHostToDevice, s));
+                uint64_t n_slots = std::min<uint64_t>(h_ctr[CT_SD], rec_cap);
                 if (n_slots) fixup_records_kernel<<<grid_for(n_slots), 256, 0, s>>>(w.fam_sds.as<SdRec>(), n_slots, reinterpret_cast<const uint32_t *>(d_split + kOffFix));
                 HIP_TRY(hipGetLastError());
+                if (n_tail) {
+                    if constexpr (sizeof(SlotT) == 4) {
+                        HIP_TRY(hipMemcpyAsync(d_split + kOffRuns + (size_t)n_runs * sizeof(RangeRun), h_runs + n_runs, (size_t)n_tail * sizeof(RangeRun),
+                                               hipMemcpyHostToDevice, s));
+                        h_scalar[8] = (unsigned long long)n_runs + n_tail;  // list length
+                        h_scalar[9] = n_runs;                               // work cursor: behind the runs that are done
+                        HIP_TRY(hipMemcpyAsync(d_split, h_scalar + 8, 8, hipMemcpyHostToDevice, s));
+                        HIP_TRY(hipMemcpyAsync(d_split + 24, h_scalar + 9, 8, hipMemcpyHostToDevice, s));
+                        HIP_TRY(hipMemsetAsync(d_split + kOffMeta + (size_t)n_runs * 32, 0, (size_t)n_tail * 32, s));
+                        launch_runs(n_tail);
+                        HIP_TRY(hipMemcpyAsync(h_split + kOffMeta + (size_t)n_runs * 32, d_split + kOffMeta + (size_t)n_runs * 32, (size_t)n_tail * 32,
+                                               hipMemcpyDeviceToHost, s));
+                        HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, kCtrBytes, hipMemcpyDeviceToHost, s));
+                        RC_TRY(wd_sync(idx, cx, s, "the rest of the cut segments"));
+                        h_scalar[8] = n_runs;  // (a second attempt of the call -- record buffer too small -- starts from the planned list)
+                        HIP_TRY(hipMemcpyAsync(d_split, h_scalar + 8, 8, hipMemcpyHostToDevice, s));
+                        size_t hb = 0;
+                        for (const Tail &t : tails) {
+                            // (a last run that gave up -- more arms than the long shape holds --: everything the segment's runs wrote
+                            // is dropped and the whole segment goes the cascade's way)
+                            const bool gave_up = h_meta[(size_t)t.run * 8 + 4] != 0u;
+                            h_fix[t.run] = gave_up ? 0xFFFFFFFFu : t.base;
+                            for (uint32_t j = 0; j <= t.f; ++j, ++hb) h_fix[t.run_base + j] = gave_up ? 0xFFFFFFFFu : held_base[hb];
+                            if (gave_up) {
+                                h_again[n_again++] = t.g_seg0;
+                                remember(t.g_seg0, 0u);
+                            }
+                        }
+                        HIP_TRY(hipMemcpyAsync(d_split + kOffFix, h_fix, kOffAgain - kOffFix, hipMemcpyHostToDevice, s));
+                        n_slots = std::min<uint64_t>(h_ctr[CT_SD], rec_cap);
+                        if (n_slots) fixup_records_kernel<<<grid_for(n_slots), 256, 0, s>>>(w.fam_sds.as<SdRec>(), n_slots, reinterpret_cast<const uint32_t *>(d_split + kOffFix));
+                        HIP_TRY(hipGetLastError());
+                    }
+                }
                 if (n_again) {
+                    HIP_TRY(hipMemcpyAsync(d_split + kOffAgain, h_again, (size_t)n_again * 4, hipMemcpyHostToDevice, s));
                     *h_scalar = n_again;
                     HIP_TRY(hipMemcpyAsync(d_ctr + CT_NF, h_scalar, 8, hipMemcpyHostToDevice, s));
                     HIP_TRY(hipMemsetAsync(d_ctr + CT_CURF, 0, 8, s));

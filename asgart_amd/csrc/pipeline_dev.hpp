@@ -2268,7 +2268,7 @@ struct SplitParams {
     uint32_t max_runs, max_cuts, max_splits;
     uint32_t n_blocked;
     uint32_t blocked[64];                 // segments (first probe) a cut of which did not hold in an earlier call of the index ...
-    uint8_t level[64];                    // ... how often: once -> four times the warm-up; twice -> not cut again
+    uint16_t allowed[64];                 // ... and how many of their cuts, counted from the segment's start, held (0: not cut again)
 };
 __global__ __launch_bounds__(256) void plan_ranges_kernel(RunParams rp, SplitParams sp, const uint32_t *__restrict__ p_filt,
                                                          const uint32_t *__restrict__ seg_list,
@@ -2288,15 +2288,16 @@ __global__ __launch_bounds__(256) void plan_ranges_kernel(RunParams rp, SplitPar
     // (creation numbers of a run: needle offset relative to the segment's first probe << 10 | hit index)
     if ((unsigned long long)span * (unsigned long long)rp.step >= (1ull << 22) - 2ull) return;
     const uint32_t g0 = seg_list[sj];
-    uint32_t warm = sp.warm;
+    const uint32_t warm = sp.warm;
+    uint32_t n_cut_max = 0xFFFFFFFFu;
     for (uint32_t b = 0; b < sp.n_blocked; ++b)
-        if (sp.blocked[b] == g0) {
-            if (sp.level[b] > 1u) return;
-            warm = (uint32_t)min((unsigned long long)warm * 4ull, 0x7FFFFFFFull);
-        }
-    // ranges of about range_len probes, all of one length, at least two
-    const uint32_t n_r = max(2u, (span + sp.range_len / 2u) / sp.range_len);
-    const uint32_t len = (span + n_r - 1u) / n_r;
+        if (sp.blocked[b] == g0) n_cut_max = min(n_cut_max, (uint32_t)sp.allowed[b]);
+    // ranges of about range_len probes, all of one length, at least two; a segment whose cuts held only up to some point in
+    // an earlier call keeps those cuts (same places) and runs the rest as its last range
+    const uint32_t n_r_all = max(2u, (span + sp.range_len / 2u) / sp.range_len);
+    const uint32_t len = (span + n_r_all - 1u) / n_r_all;
+    const uint32_t n_r = min(n_r_all, n_cut_max == 0xFFFFFFFFu ? n_r_all : n_cut_max + 1u);
+    if (n_r < 2u) return;
     auto cut_of = [&](uint32_t j) -> uint32_t {  // first hit-probe at or behind g0 + j * len (0: none in reach)
         uint32_t c = g0 + j * len;
         const uint32_t lim = min(g0 + span, c + len / 2u);
@@ -2391,13 +2392,15 @@ __global__ __launch_bounds__(256) void validate_cuts_kernel(const uint2 *__restr
     if (threadIdx.x == 0) cut_ok[blockIdx.x] = s_ok;
 }
 
-// run_fix[run]: what is added to the family ordinals of the run's records; ~0u: the run's records are dropped
+// run_fix[run]: what is added to the family ordinals of the run's records; ~0u: the run's records are dropped; ~0u - 1: not
+// decided yet (left as they are for a later pass)
 __global__ __launch_bounds__(256) void fixup_records_kernel(SdRec *__restrict__ recs, unsigned long long n, const uint32_t *__restrict__ run_fix) {
     const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     SdRec &r = recs[i];
     if (r.g_start == kVoidStart || r.pad == 0u) return;
     const uint32_t f = run_fix[r.pad - 1u];
+    if (f == 0xFFFFFFFEu) return;
     if (f == 0xFFFFFFFFu) r.g_start = kVoidStart;
     else r.fam_seq += f;
     r.pad = 0u;
