@@ -21,6 +21,12 @@ constexpr int kSmallInterval = 32;  // intervals up to this size are handled by 
 constexpr int kScanItems = 8;       // probes per thread in the scan kernels
 constexpr int kScanBlock = 256;
 constexpr int kScanTile = kScanItems * kScanBlock;
+// LDS position of tile element i: every thread walks kScanItems CONSECUTIVE elements (i = thread * kScanItems + a), which at
+// stride kScanItems words puts the lanes of a wave on 4 of the 32 banks; one word of padding per kScanItems elements makes the
+// stride odd (9 words; 18 for the 64-bit row offsets) and the walk conflict-free, while the coalesced passes (i = thread,
+// thread + 256, ...) stay within two lanes per bank
+constexpr int kScanTilePad = kScanTile + kScanTile / kScanItems;
+__device__ inline uint32_t scan_pos(uint32_t i) { return i + i / (uint32_t)kScanItems; }
 
 constexpr int kTiers = 7;  // extension tiers (see the placement in pipeline.hip)
 
@@ -705,8 +711,8 @@ __device__ inline void stage_scan_tile(const RunParams &rp, const uint32_t *__re
                                        uint32_t tile_g0, uint32_t *s_f, uint8_t *s_first) {
     for (uint32_t idx = threadIdx.x; idx < (uint32_t)kScanTile; idx += kScanBlock) {
         const uint32_t g = tile_g0 + idx;
-        s_f[idx] = g < rp.g_hi ? p_filt[g] : kSkipN;
-        s_first[idx] = 0;
+        s_f[scan_pos(idx)] = g < rp.g_hi ? p_filt[g] : kSkipN;
+        s_first[scan_pos(idx)] = 0;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -715,7 +721,7 @@ __device__ inline void stage_scan_tile(const RunParams &rp, const uint32_t *__re
             const uint32_t pb = rp.ch.pbase[c];
             if (pb >= tile_end) break;
             // only non-empty chunks have a first probe
-            if (pb >= tile_g0 && rp.ch.pbase[c + 1] > pb) s_first[pb - tile_g0] = 1;
+            if (pb >= tile_g0 && rp.ch.pbase[c + 1] > pb) s_first[scan_pos(pb - tile_g0)] = 1;
         }
     }
     __syncthreads();
@@ -724,7 +730,7 @@ __device__ inline void stage_scan_tile(const RunParams &rp, const uint32_t *__re
 // the kScanItems elements of this thread (from the staged tile); returns their combination
 __device__ inline ScanEl load_thread_items(const uint32_t *s_f, const uint8_t *s_first, ScanEl *items) {
     ScanEl agg = scan_identity();
-    const uint32_t i0 = threadIdx.x * kScanItems;
+    const uint32_t i0 = scan_pos(threadIdx.x * kScanItems);
     for (int a = 0; a < kScanItems; ++a) {
         const uint32_t f = s_f[i0 + a];
         // probes past the end of the window were staged as skipped: identity elements
@@ -738,8 +744,8 @@ __global__ __launch_bounds__(kScanBlock) void scan_reduce_kernel(RunParams rp,
                                                                  const uint32_t *__restrict__ p_filt,
                                                                  ScanEl *__restrict__ blk) {
     __shared__ ScanEl sh[kScanBlock];
-    __shared__ uint32_t s_f[kScanTile];
-    __shared__ uint8_t s_first[kScanTile];
+    __shared__ uint32_t s_f[kScanTilePad];
+    __shared__ uint8_t s_first[kScanTilePad];
     ScanEl items[kScanItems];
     stage_scan_tile(rp, p_filt, rp.g_lo + blockIdx.x * (uint32_t)kScanTile, s_f, s_first);
     ScanEl agg = load_thread_items(s_f, s_first, items);
@@ -791,9 +797,9 @@ __global__ __launch_bounds__(kScanBlock) void scan_down_kernel(RunParams rp,
                                                                unsigned long long *__restrict__ ctr) {
     __shared__ ScanEl sh[kScanBlock];
     __shared__ unsigned long long sh_stat[5];
-    __shared__ uint32_t s_f[kScanTile];
-    __shared__ uint8_t s_first[kScanTile];
-    __shared__ unsigned long long s_row[kScanTile];
+    __shared__ uint32_t s_f[kScanTilePad];
+    __shared__ uint8_t s_first[kScanTilePad];
+    __shared__ unsigned long long s_row[kScanTilePad];
     __shared__ uint32_t s_start[kStartCap];
     __shared__ uint32_t s_nstart;
     __shared__ unsigned long long s_gbase;
@@ -838,8 +844,8 @@ __global__ __launch_bounds__(kScanBlock) void scan_down_kernel(RunParams rp,
             const bool valid = g < rp.g_hi;
             bool start = false;
             if (valid) {
-                const uint32_t f = s_f[i0 + a];
-                s_row[i0 + a] = run.hits;
+                const uint32_t f = s_f[scan_pos(i0) + a];
+                s_row[scan_pos(i0) + a] = run.hits;
                 const bool hit = f < kPending && f > 0;
                 if (f == kSkipN) ++st_n;
                 else {
@@ -875,8 +881,8 @@ __global__ __launch_bounds__(kScanBlock) void scan_down_kernel(RunParams rp,
         for (uint32_t idx = threadIdx.x; idx < (uint32_t)kScanTile; idx += kScanBlock) {
             const uint32_t g = tile_g0 + idx;
             if (g < rp.g_hi) {
-                row_off[g] = s_row[idx];
-                if (s_f[idx] != kSkipN) st_raw += p_raw[g];
+                row_off[g] = s_row[scan_pos(idx)];
+                if (s_f[scan_pos(idx)] != kSkipN) st_raw += p_raw[g];
             }
         }
         __syncthreads();  // the staged tile is overwritten by the next one
@@ -917,12 +923,15 @@ __global__ __launch_bounds__(256) void fill_small_kernel(IndexView<SlotT> ix, Ru
                                                          const unsigned long long *__restrict__ row_off,
                                                          SlotT *__restrict__ hits) {
     const uint32_t g = rp.g_lo + blockIdx.x * blockDim.x + threadIdx.x;
+    // (the chunk of the workgroup's first probe, once, in scalar registers; a thread whose probe lies behind a chunk boundary
+    // steps on from there -- 256 consecutive probes rarely span two chunks -- instead of bisecting the table per thread)
+    int c = chunk_of_uniform(rp.ch, min(rp.g_lo + blockIdx.x * blockDim.x, rp.g_hi - 1u));
     if (g >= rp.g_hi) return;
     const uint32_t f = p_filt[g];
     if (f == 0 || f >= kPending) return;
     const uint32_t raw = p_raw[g];
     if (raw > (uint32_t)kSmallInterval) return;
-    const int c = chunk_of(rp.ch, g);
+    while (c + 1 < rp.ch.n_chunks && g >= rp.ch.pbase[c + 1]) ++c;
     const uint64_t s = rp.ch.start[c], L = rp.ch.len[c];
     const uint64_t i = (uint64_t)(g - rp.ch.pbase[c] + 1) * (uint64_t)rp.step;
     const uint64_t lo = p_lo[g];
