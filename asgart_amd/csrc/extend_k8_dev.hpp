@@ -160,6 +160,23 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
             emit_from_i = (run.flags & kRunNoEmit) ? 0xFFFFFFFFu
                           : (run.emit_from == run.g_seg0 ? 0u : (run.emit_from - P.rp.ch.pbase[rc] + 1u) * (uint32_t)P.rp.step);
         }
+        // (RANGE) one arm into dump `which` of this run (0: what the run holds when it stops, 1: what it holds when it reaches
+        // its cut), slot handed out by the dump's counter
+        auto dump_arm = [&](uint32_t which, bool live, uint32_t seq, uint32_t ls, uint32_t le, uint32_t rs, uint32_t re, uint32_t thr, uint32_t gap) {
+            if constexpr (RANGE) {
+                const unsigned long long m = __ballot(live);
+                if (!m) return;
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&P.run_meta[seg * 16ull + which * 8ull], (uint32_t)__popcll(m));
+                base = lane_of(base, 0u);
+                const uint32_t at = base + (uint32_t)__popcll(m & lt_mask);
+                if (live && at < kRunDumpCap) {
+                    uint4 *o = reinterpret_cast<uint4 *>(P.run_dump + ((seg * 2ull + which) * (unsigned long long)kRunDumpCap + at) * 8ull);
+                    o[0] = make_uint4(seq, ls, le, rs);
+                    o[1] = make_uint4(re, thr, gap, 0u);
+                }
+            }
+        };
         // the creation number of the r-th new arm of a probe (lists of buffer pbuf)
         auto seq_of = [&](uint32_t seq_base, uint32_t r, uint32_t pbuf) -> uint32_t {
             if constexpr (RANGE) return seq_base | (uint32_t)s_newh[pbuf][r];
@@ -619,6 +636,18 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
                     }
                 }
                 K7U_LAP(1);
+                if constexpr (RANGE) {
+                    // The step whose probe is this run's cut: the arms stand as they stand in front of the cut -- everything before
+                    // it resolved and aged (behind a generation wrap: by this very step), the arms born of the probe before it not
+                    // yet pulled (the ranking wave writes those, below) -- which is what a run that STOPS at the cut holds at its
+                    // end.  Written out for the comparison with the range in front of the cut.
+                    if (K7_RARE(has_cur && emit_from_i != 0u && emit_from_i != 0xFFFFFFFFu && C(6) == emit_from_i)) {
+#pragma unroll
+                        for (int L = 0; L < S; ++L)
+                            dump_arm(1u, a_seq[L] != kNoSeq, a_seq[L], (uint32_t)a_ls[L], (uint32_t)s_cle[L * (NWA * 64) + tid],
+                                     (uint32_t)s_crs[L * (NWA * 64) + tid], (uint32_t)a_re[L], a_thr[L], a_gap[L]);
+                    }
+                }
                 // ---- every arm offers to this step's probe --------------------------------------------------------------
                 if (has_cur && livemask) {
                     const Cur q{k, C(5), C(19), C(3), C(4), C(9), C(1), C(2)};
@@ -665,20 +694,9 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
                 // the arms this run leaves alive, in any order (the comparison goes by creation number)
                 if (!overflow) {
 #pragma unroll
-                    for (int L = 0; L < S; ++L) {
-                        const bool live = a_seq[L] != kNoSeq;
-                        const unsigned long long m = __ballot(live);
-                        if (!m) continue;
-                        uint32_t base = 0;
-                        if (lane == 0) base = atomicAdd(&P.run_meta[seg * 8ull + 0ull], (uint32_t)__popcll(m));
-                        base = lane_of(base, 0u);
-                        const uint32_t at = base + (uint32_t)__popcll(m & lt_mask);
-                        if (live && at < kRunDumpCap) {
-                            uint4 *o = reinterpret_cast<uint4 *>(P.run_dump + (seg * (unsigned long long)kRunDumpCap + at) * 8ull);
-                            o[0] = make_uint4(a_seq[L], (uint32_t)a_ls[L], (uint32_t)s_cle[L * (NWA * 64) + tid], (uint32_t)s_crs[L * (NWA * 64) + tid]);
-                            o[1] = make_uint4((uint32_t)a_re[L], a_thr[L], a_gap[L], 0u);
-                        }
-                    }
+                    for (int L = 0; L < S; ++L)
+                        dump_arm(0u, a_seq[L] != kNoSeq, a_seq[L], (uint32_t)a_ls[L], (uint32_t)s_cle[L * (NWA * 64) + tid],
+                                 (uint32_t)s_crs[L * (NWA * 64) + tid], (uint32_t)a_re[L], a_thr[L], a_gap[L]);
                 }
             }
             if (wave == 0u) K7T_FLUSH(1);
@@ -838,6 +856,26 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
                     const uint64_t g_new = (uint64_t)step + C(8);
                     const bool stillborn = g_new >= (uint64_t)G;
                     if (stillborn) pflags |= K8_STILL;
+                    if constexpr (RANGE) {
+                        // (the step whose probe is this run's cut, see the arm waves: the arms born of the probe in front of the cut
+                        // as they will be pulled, and the family state)
+                        if (K7_RARE(has_cur && emit_from_i != 0u && emit_from_i != 0xFFFFFFFFu && C(6) == emit_from_i)) {
+                            if (n_new && !stillborn && !(pflags & K8_OVF)) {
+                                const uint32_t gap_n = g_new > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)g_new;
+                                for (uint32_t r0 = 0; r0 < n_new; r0 += 64u) {
+                                    const uint32_t r = min(r0 + (uint32_t)lane, n_new - 1u);
+                                    const uint32_t x = (uint32_t)s_newx[sp][r];
+                                    dump_arm(1u, r0 + (uint32_t)lane < n_new, seq_of(seq_base, r, sp), C(12), C(12) + k, x, x + k, thr0, gap_n);
+                                }
+                            }
+                            if (lane == 0) {
+                                uint32_t *m = P.run_meta + seg * 16ull + 8ull;
+                                m[1] = 0u;
+                                m[2] = fam_open ? 1u : 0u;
+                                m[3] = spur_until > C(30) ? spur_until - C(30) : 0u;
+                            }
+                        }
+                    }
                     // ---- the new arms' offers to this step's probe, on their behalf --------------------------------------
                     if (n_new && !(pflags & K8_OVF)) {
                         const Cur q{k, C(5), C(19), C(3), C(4), C(9), C(1), C(2)};
@@ -919,7 +957,7 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
                 if constexpr (RANGE) {
                     // the family state this run ends in: flushes since the cut, open or not, how long a flush is still held back
                     if (lane == 0) {
-                        uint32_t *m = P.run_meta + seg * 8ull;
+                        uint32_t *m = P.run_meta + seg * 16ull;
                         m[1] = fam_seq;
                         m[2] = fam_open ? 1u : 0u;
                         m[3] = spur_until > t_proc ? spur_until - t_proc : 0u;
@@ -935,7 +973,7 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
                 }
             } else if (lane == 0) {
                 if constexpr (RANGE) {
-                    P.run_meta[seg * 8ull + 4ull] = 1u;  // (the host runs the whole segment instead)
+                    P.run_meta[seg * 16ull + 4ull] = 1u;  // (the host runs the whole segment instead)
                 } else {
                     const unsigned long long at = atomicAdd(P.ovf_count, 1ull);
                     if (P.ovf_list) P.ovf_list[at] = g0;

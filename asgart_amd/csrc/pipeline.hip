@@ -578,7 +578,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
         // run states | verdicts per cut | per run: what is added to its records' family ordinals | segments to run again]
         constexpr uint32_t kMaxRuns = 4096, kMaxCuts = 2048, kMaxSplits = 1024;
         constexpr size_t kOffRuns = 64, kOffCuts = kOffRuns + kMaxRuns * sizeof(RangeRun), kOffSplits = kOffCuts + kMaxCuts * 8,
-                         kOffMeta = kOffSplits + kMaxSplits * sizeof(SplitSeg), kOffOk = kOffMeta + kMaxRuns * 32,
+                         kOffMeta = kOffSplits + kMaxSplits * sizeof(SplitSeg), kOffOk = kOffMeta + kMaxRuns * 64,
                          kOffFix = kOffOk + kMaxCuts * 4, kOffAgain = kOffFix + kMaxRuns * 4, kSplitBytes = kOffAgain + kMaxSplits * 4;
         static_assert(kSplitBytes <= kSplitMirror, "split mirror");
         char *d_split = nullptr;
@@ -693,7 +693,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
         if (n_splits) memcpy(split_segs.data(), h_split + kOffSplits, (size_t)n_splits * sizeof(SplitSeg));
         n_split_segments = n_splits;
         if (opt.debug && split_on)
-            fprintf(stderr, "[asgart] %u long segment(s) cut into ranges: %u runs (ranges of %lld probes + warm-ups of %lld), %u cuts to check\n",
+            fprintf(stderr, "[asgart] %u long segment(s) cut into ranges: %u runs (ranges of %lld probes, each started %lld probes in front of its cut), %u cuts to check\n",
                     n_splits, n_runs, (long long)opt.split_len, (long long)opt.split_warm, n_cuts);
         if (opt.debug) {
             fprintf(stderr, "[asgart] %llu segments, %llu walked wave by wave; per tier:", (unsigned long long)n_seg,
@@ -941,9 +941,9 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             };
             if (n_runs) {
                 // (room for one more run per cut segment: the rest behind the last cut that held, see below)
-                RC_TRY(w.split_dump.reserve((size_t)(n_runs + n_splits) * kRunDumpCap * 32));
+                RC_TRY(w.split_dump.reserve((size_t)(n_runs + n_splits) * 2 * kRunDumpCap * 32));
                 HIP_TRY(hipMemsetAsync(d_split + 24, 0, 8, s));                         // work cursor
-                HIP_TRY(hipMemsetAsync(d_split + kOffMeta, 0, (size_t)n_runs * 32, s));  // run states
+                HIP_TRY(hipMemsetAsync(d_split + kOffMeta, 0, (size_t)n_runs * 64, s));  // run states
                 launch_runs(n_runs);
                 HIP_TRY(hipGetLastError());
             }
@@ -1164,7 +1164,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                             f = j;
                             break;
                         }
-                    const bool last_gave_up = h_meta[(size_t)(sg.run_base + sg.n_ranges - 1) * 8 + 4] != 0u;
+                    const bool last_gave_up = h_meta[(size_t)(sg.run_base + sg.n_ranges - 1) * 16 + 4] != 0u;
                     const bool ok = f == n_cuts_sg && !last_gave_up;
                     if (f == n_cuts_sg && last_gave_up) f = 0;  // (more arms than the long shape holds: the cascade's business)
                     uint32_t base = 0;
@@ -1172,7 +1172,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                         // (ranges in front of a cut that did not hold: decided when the run over the rest has come back)
                         h_fix[sg.run_base + j] = ok ? base : ((f > 0 && j <= f) ? 0xFFFFFFFEu : 0xFFFFFFFFu);
                         if (!ok && f > 0 && j <= f) held_base.push_back(base);
-                        base += h_meta[(size_t)(sg.run_base + j) * 8 + 1];
+                        base += h_meta[(size_t)(sg.run_base + j) * 16 + 1];
                         if (!ok && f > 0 && j == f) {
                             RangeRun t = h_runs[sg.run_base + f];
                             t.g_stop = 0xFFFFFFFFu;
@@ -1183,12 +1183,11 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                             ++n_tail;
                         }
                     }
-                    for (uint32_t j = 0; j < n_cuts_sg; ++j) h_fix[sg.run_base + sg.n_ranges + j] = 0xFFFFFFFFu;  // (warm-ups write none)
                     if (!ok && opt.debug) {
-                        fprintf(stderr, "[asgart] ranges: segment at probe %u (%u ranges): %u cut(s) held; cuts (arms in front / in the warm-up, family open, held flush):",
+                        fprintf(stderr, "[asgart] ranges: segment at probe %u (%u ranges): %u cut(s) held; cuts (arms in the range in front / in the range behind, family open, held flush):",
                                 sg.g_seg0, sg.n_ranges, f);
                         for (uint32_t j = 0; j < n_cuts_sg; ++j) {
-                            const uint32_t *ma = h_meta + (size_t)(sg.run_base + j) * 8, *mb = h_meta + (size_t)(sg.run_base + sg.n_ranges + j) * 8;
+                            const uint32_t *ma = h_meta + (size_t)(sg.run_base + j) * 16, *mb = h_meta + (size_t)(sg.run_base + j + 1) * 16 + 8;
                             fprintf(stderr, " %s%u/%u,%u/%u,%u/%u%s", h_ok[sg.cut_base + j] ? "" : "[", ma[0], mb[0], ma[2], mb[2], ma[3], mb[3],
                                     h_ok[sg.cut_base + j] ? "" : "]");
                         }
@@ -1216,9 +1215,9 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                         h_scalar[9] = n_runs;                               // work cursor: behind the runs that are done
                         HIP_TRY(hipMemcpyAsync(d_split, h_scalar + 8, 8, hipMemcpyHostToDevice, s));
                         HIP_TRY(hipMemcpyAsync(d_split + 24, h_scalar + 9, 8, hipMemcpyHostToDevice, s));
-                        HIP_TRY(hipMemsetAsync(d_split + kOffMeta + (size_t)n_runs * 32, 0, (size_t)n_tail * 32, s));
+                        HIP_TRY(hipMemsetAsync(d_split + kOffMeta + (size_t)n_runs * 64, 0, (size_t)n_tail * 64, s));
                         launch_runs(n_tail);
-                        HIP_TRY(hipMemcpyAsync(h_split + kOffMeta + (size_t)n_runs * 32, d_split + kOffMeta + (size_t)n_runs * 32, (size_t)n_tail * 32,
+                        HIP_TRY(hipMemcpyAsync(h_split + kOffMeta + (size_t)n_runs * 64, d_split + kOffMeta + (size_t)n_runs * 64, (size_t)n_tail * 64,
                                                hipMemcpyDeviceToHost, s));
                         HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, kCtrBytes, hipMemcpyDeviceToHost, s));
                         RC_TRY(wd_sync(idx, cx, s, "the rest of the cut segments"));
@@ -1228,7 +1227,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                         for (const Tail &t : tails) {
                             // (a last run that gave up -- more arms than the long shape holds --: everything the segment's runs wrote
                             // is dropped and the whole segment goes the cascade's way)
-                            const bool gave_up = h_meta[(size_t)t.run * 8 + 4] != 0u;
+                            const bool gave_up = h_meta[(size_t)t.run * 16 + 4] != 0u;
                             h_fix[t.run] = gave_up ? 0xFFFFFFFFu : t.base;
                             for (uint32_t j = 0; j <= t.f; ++j, ++hb) h_fix[t.run_base + j] = gave_up ? 0xFFFFFFFFu : held_base[hb];
                             if (gave_up) {

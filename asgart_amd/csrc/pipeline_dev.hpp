@@ -1089,11 +1089,13 @@ struct RangeRun {
 constexpr uint32_t kRunNoEmit = 1u;    // a warm-up on its own: only its final state is wanted (what the run behind the cut starts from)
 constexpr uint32_t kRunLast = 2u;      // the run that reaches the segment's end
 constexpr uint32_t kRunDumpCap = 5120; // arms a run can leave alive (the long shape's slots)
-// per run, 8 words (run_meta): 0 arms written to run_dump  1 flushes since the cut  2 family open  3 probes a flush is still held
-// back for  4 gave up (more arms than slots, a probe with more hits than the staging area)
-// per arm, 8 words (run_dump): creation number, left start, left end, right start | right end, threshold, gap, 0
+// per run two states, 8 words each (run_meta): [0] what it holds when it STOPS, [1] what it holds when it reaches its cut:
+// 0 arms written to run_dump  1 flushes since the cut  2 family open  3 probes a flush is still held back for  4 ([0] only) gave up
+// (more arms than slots, a probe with more hits than the staging area)
+// per run two dumps of kRunDumpCap arms, 8 words per arm (run_dump): creation number, left start, left end, right start | right
+// end, threshold, gap, 0
 struct SplitSeg {
-    uint32_t g_seg0, run_base, n_ranges, cut_base;  // runs run_base .. + n_ranges - 1: the ranges; then the n_ranges - 1 warm-ups
+    uint32_t g_seg0, run_base, n_ranges, cut_base;  // runs run_base .. + n_ranges - 1: the ranges; cuts cut_base .. + n_ranges - 2
 };
 
 template <class PosT>
@@ -2319,7 +2321,7 @@ __global__ __launch_bounds__(256) void plan_ranges_kernel(RunParams rp, SplitPar
     };
     for (uint32_t j = 1; j < n_r; ++j)
         if (!cut_of(j)) return;
-    const uint32_t n_runs = 2u * n_r - 1u;
+    const uint32_t n_runs = n_r;
     const uint32_t run_base = (uint32_t)atomicAdd(&hdr[0], (unsigned long long)n_runs);
     if (run_base + n_runs > sp.max_runs) {
         atomicAdd(&hdr[0], 0ull - (unsigned long long)n_runs);
@@ -2346,13 +2348,8 @@ __global__ __launch_bounds__(256) void plan_ranges_kernel(RunParams rp, SplitPar
         r.flags = j + 1u == n_r ? kRunLast : 0u;
         r.split = split;
         runs[run_base + j] = r;
-        if (j) {  // the warm-up in front of this range's cut, on its own: compared with what range j - 1 holds there
-            RangeRun w = r;
-            w.g_stop = c_prev;
-            w.flags = kRunNoEmit;
-            runs[run_base + n_r + j - 1u] = w;
-            cuts[cut_base + j - 1u] = make_uint2(run_base + j - 1u, run_base + n_r + j - 1u);
-        }
+        // (what range j - 1 holds when it stops at this range's cut against what this range holds when it reaches it)
+        if (j) cuts[cut_base + j - 1u] = make_uint2(run_base + j - 1u, run_base + j);
         c_prev = c_next;
     }
 }
@@ -2363,15 +2360,16 @@ __global__ __launch_bounds__(256) void validate_cuts_kernel(const uint2 *__restr
     __shared__ uint32_t s_tab[kSlots];
     __shared__ uint32_t s_ok;
     const uint2 cut = cuts[blockIdx.x];
-    const uint32_t *ma = run_meta + (size_t)cut.x * 8, *mb = run_meta + (size_t)cut.y * 8;
+    // (x: the run in front of the cut, its end state; y: the run behind it, its state at the cut)
+    const uint32_t *ma = run_meta + (size_t)cut.x * 16, *mb = run_meta + (size_t)cut.y * 16 + 8;
     const uint32_t n = ma[0];
-    const bool meta_ok = n == mb[0] && n <= kRunDumpCap && ma[2] == mb[2] && ma[3] == mb[3] && !ma[4] && !mb[4];
+    const bool meta_ok = n == mb[0] && n <= kRunDumpCap && ma[2] == mb[2] && ma[3] == mb[3] && !ma[4] && !run_meta[(size_t)cut.y * 16 + 4];
     for (uint32_t j = threadIdx.x; j < kSlots; j += blockDim.x) s_tab[j] = 0u;
     if (threadIdx.x == 0) s_ok = meta_ok ? 1u : 0u;
     __syncthreads();
     if (meta_ok) {
-        const uint4 *da = reinterpret_cast<const uint4 *>(run_dump + (size_t)cut.x * kRunDumpCap * 8);
-        const uint4 *db = reinterpret_cast<const uint4 *>(run_dump + (size_t)cut.y * kRunDumpCap * 8);
+        const uint4 *da = reinterpret_cast<const uint4 *>(run_dump + (size_t)cut.x * 2 * kRunDumpCap * 8);
+        const uint4 *db = reinterpret_cast<const uint4 *>(run_dump + ((size_t)cut.y * 2 + 1) * kRunDumpCap * 8);
         for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) {
             uint32_t h = (da[2 * j].x * 2654435761u) >> 18;
             while (atomicCAS(&s_tab[h], 0u, j + 1u) != 0u) h = (h + 1u) & (kSlots - 1u);
