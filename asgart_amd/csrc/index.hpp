@@ -127,7 +127,7 @@ struct Workspace {
     DevBuf seg_info;   // uint2 per segment: hits and probe positions walked (placement -> cluster_barren_kernel)
     DevBuf seg_slots;  // u64[8][4096]: per tier and workgroup, when its current segment started (longest-segment statistics)
     DevBuf split_buf;  // long segments run as ranges (option split): counters, runs, cuts, split segments, run states, verdicts
-    DevBuf split_dump; // ... and the arms every run leaves alive (8 words per arm, kRunDumpCap arms per run)
+    DevBuf split_dump; // ... and the arms every run holds at its cut and at its end (8 words per arm, 2 x kRunDumpCap arms per run)
     // every buffer goes back to the device (or to the block cache): ONE list, next to the members
     void release_all() {
         DevBuf *bufs[] = {&chunks, &p_lo, &p_raw, &p_filt, &row_off, &blk, &hits, &big_list, &rank_list, &seg_list,
