@@ -76,9 +76,12 @@ const OptDesc kOptions[] = {
     {"prewarm", &Options::prewarm, 0, 1},
     {"cache_calls", &Options::cache_calls, 0, 1000000},
     {"split", &Options::split, 0, 1},
-    {"split_len", &Options::split_len, 64, 1 << 20},
+    {"split_len", &Options::split_len, 0, 1 << 20},
+    {"split_runs", &Options::split_runs, 1, 3072},
+    {"split_tier", &Options::split_tier, 2, 6},
+    {"split_dense", &Options::split_dense, 0, 1 << 20},
     {"split_warm", &Options::split_warm, 0, 1 << 20},
-    {"split_min", &Options::split_min, 128, 1ll << 31},
+    {"split_min", &Options::split_min, 0, 1ll << 31},
     {"watchdog_s", &Options::watchdog_s, 0, 86400},
     {"test_stall_s", &Options::test_stall_s, 0, 60},
     {"tier_streams", &Options::tier_streams, 1111111, 7777777},

@@ -82,6 +82,8 @@ struct RunParams {
     const uint64_t *pbits[4];  // ... its answers laid out by TEXT POSITION (bit p: the probe that covers text[p .. p + k) in
                                // this orientation passes the filter); null: the kernels test the hashed filter
     int flt_bits;
+    uint32_t split_tier_lo;  // option split_tier: lowest tier whose segments may be cut into ranges
+    uint32_t split_dense;    // option split_dense: ... and only those with at least this many hits per probe position
     uint32_t bucket_lookup;  // option bucket: 1 = small prefix-table buckets are looked up with keys and suffix-array entries
                              // requested together (probe_count_kernel)
     __host__ __device__ inline uint32_t pass_of(int c) const {
@@ -172,6 +174,12 @@ struct SearchCtx {
     // times slower than the kernels that produce it); grow-only, freed with the index
     void *h_pinned = nullptr;
     size_t h_pinned_cap = 0;
+    // host-side parts of the family assembly (run_search_t), kept for their capacity
+    struct FamPart {
+        std::vector<asgart_proto_sd> sds[4];
+        std::vector<uint64_t> ends[4], keys[4];  // per family: records up to and including it (within the part), key
+    };
+    std::vector<FamPart> fam_parts;
     int32_t pinned(size_t bytes, void **out) {
         if (bytes > h_pinned_cap) {
             if (h_pinned) (void)hipHostFree(h_pinned);
@@ -334,9 +342,15 @@ struct Options {
                                     // that differs keeps the ranges up to it and runs the rest as ONE more run (the whole segment again when
                                     // its first cut fails); the index then plans only the cuts that held.  32-bit positions.  0: every
                                     // segment is one work item
-    int64_t split_len = 12288;      // probes per range (about: the ranges of a segment are of one length)
-    int64_t split_warm = 6144;      // probes a range starts in front of its cut
-    int64_t split_min = 24576;      // segments shorter than this (probe positions) are not cut
+    int64_t split_len = 0;          // probes per range (about: the ranges of a segment are of one length); 0: the smallest of 2048 ... 32768
+                                    // for which the call's runs stay within split_runs (split_tally_kernel), warm-up half of it (at least
+                                    // 2048), shortest segment cut twice it -- a small job gets short ranges, a genome-sized one long ones
+    int64_t split_tier = 3;         // lowest tier whose long segments are cut (2: also the one-wave tier's -- a wave on its own passes a
+                                    // sparse probe faster than the long shape's sixteen)
+    int64_t split_dense = 0;        // segments with fewer hits per probe position than this are not cut (0: any)
+    int64_t split_runs = 224;       // ... that budget: every run holds a compute unit while it runs
+    int64_t split_warm = 6144;      // (split_len > 0) probes a range starts in front of its cut
+    int64_t split_min = 0;          // segments shorter than this (probe positions) are not cut (split_len = 0: at least this)
     int64_t cache_calls = 2;        // the blocks an index build released stay in the block cache until the index has answered this many
                                     // search calls (then, at its destruction, on an allocation failure and by asgart_trim_cache they go
                                     // back to the device): giving ~100 GB back costs the next allocation of the process 20-30 ms per
@@ -456,7 +470,11 @@ struct asgart_index {
     } fuse_verdict;
     // segments a cut of which did not hold (option split): orientation << 32 | first probe counted from the start of its pass
     // (... and how many of their cuts, from the start, held: only those are planned again)
-    std::vector<std::pair<uint64_t, uint32_t>> split_blocked;
+    struct SplitVerdict {
+        uint64_t key;
+        uint32_t allowed, range_len;  // (the count belongs to the range length it was found at)
+    };
+    std::vector<SplitVerdict> split_blocked;
     asgart::DevBuf ws_arena;  // the block the call contexts' per-probe buffers were carved from (carve_probe_workspace), or empty
     std::mutex pass_mu;  // one asgart_search_duplications_passes call at a time per index
     std::vector<std::unique_ptr<asgart::PassWorker>> pass_workers;

@@ -382,6 +382,8 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
     rp.C = st->max_cardinality > 0xFFFFFF00ull ? 0xFFFFFF00u : (uint32_t)st->max_cardinality;
     rp.n_passes = (uint32_t)n_passes;
     rp.pass_chunks = (uint32_t)n_chunks_pass;
+    rp.split_tier_lo = (uint32_t)idx->opt.split_tier;
+    rp.split_dense = (uint32_t)idx->opt.split_dense;
     rp.modes = 0;
     rp.flt_bits = idx->filter_bits;
     rp.bucket_lookup = opt.bucket ? 1u : 0u;
@@ -569,7 +571,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
         // a segment whose end the placement walk has seen is cut), but not with ownership lists (option shard_lpt: every shard
         // holds every segment there)
         const bool split_on = opt.split != 0 && sizeof(SlotT) == 4 && !lpt && k7_tier(3) && opt.k8 != 0 &&
-                              opt.filter == 0 && opt.split_len >= 64;
+                              opt.filter == 0 && (opt.split_len == 0 || opt.split_len >= 64);
         if (cluster_barren || split_on) {
             RC_TRY(w.seg_info.reserve((size_t)n_seg * sizeof(uint2)));
             pp.seg_info = w.seg_info.as<uint2>();
@@ -579,7 +581,9 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
         constexpr uint32_t kMaxRuns = 4096, kMaxCuts = 2048, kMaxSplits = 1024;
         constexpr size_t kOffRuns = 64, kOffCuts = kOffRuns + kMaxRuns * sizeof(RangeRun), kOffSplits = kOffCuts + kMaxCuts * 8,
                          kOffMeta = kOffSplits + kMaxSplits * sizeof(SplitSeg), kOffOk = kOffMeta + kMaxRuns * 64,
-                         kOffFix = kOffOk + kMaxCuts * 4, kOffAgain = kOffFix + kMaxRuns * 4, kSplitBytes = kOffAgain + kMaxSplits * 4;
+                         kOffFix = kOffOk + kMaxCuts * 4, kOffAgain = kOffFix + kMaxRuns * 4, kOffChoice = kOffAgain + kMaxSplits * 4,
+                         kSplitBytes = kOffChoice + 128;
+        static_assert(sizeof(SplitChoice) <= 128 && kOffChoice % 8 == 0, "split choice");
         static_assert(kSplitBytes <= kSplitMirror, "split mirror");
         char *d_split = nullptr;
         if (split_on) {
@@ -657,17 +661,24 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                 std::lock_guard<std::mutex> lk(idx->mu);
                 for (const auto &b : idx->split_blocked)
                     for (int32_t p_ = 0; p_ < n_passes && sp.n_blocked < 64u; ++p_)
-                        if (((rp.modes >> (8 * p_)) & 0xFFu) == (uint32_t)(b.first >> 32)) {
-                            sp.blocked[sp.n_blocked] = h_pbase[(int64_t)p_ * n_chunks_pass] + (uint32_t)b.first;
-                            sp.allowed[sp.n_blocked++] = (uint16_t)std::min<uint32_t>(b.second, 0xFFFFu);
+                        if (((rp.modes >> (8 * p_)) & 0xFFu) == (uint32_t)(b.key >> 32)) {
+                            sp.blocked[sp.n_blocked] = h_pbase[(int64_t)p_ * n_chunks_pass] + (uint32_t)b.key;
+                            sp.blocked_len[sp.n_blocked] = b.range_len;
+                            sp.allowed[sp.n_blocked++] = (uint16_t)std::min<uint32_t>(b.allowed, 0xFFFFu);
                         }
                 if (idx->split_blocked.size() > 48) sp.min_span = 0x7FFFFFFFu;  // (an input that keeps refusing: no more cuts)
+            }
+            SplitChoice *const d_choice = reinterpret_cast<SplitChoice *>(d_split + kOffChoice);
+            if (!sp.range_len) {  // the range length by budget
+                HIP_TRY(hipMemsetAsync(d_choice, 0, sizeof(SplitChoice), s));
+                split_tally_kernel<<<grid_for(n_seg), 256, 0, s>>>(rp, d_ctr + CT_SEG, kbuf, pp.seg_info, d_choice);
+                split_pick_kernel<<<1, 1, 0, s>>>(d_choice, (uint32_t)opt.split_runs);
             }
             plan_ranges_kernel<<<grid_for(n_seg), 256, 0, s>>>(rp, sp, p_filt, seg_list, d_ctr + CT_SEG, kbuf, pp.seg_info,
                                                               reinterpret_cast<unsigned long long *>(d_split),
                                                               reinterpret_cast<RangeRun *>(d_split + kOffRuns),
                                                               reinterpret_cast<uint2 *>(d_split + kOffCuts),
-                                                              reinterpret_cast<SplitSeg *>(d_split + kOffSplits));
+                                                              reinterpret_cast<SplitSeg *>(d_split + kOffSplits), d_choice);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(h_split, d_split, kOffMeta, hipMemcpyDeviceToHost, s));
         }
@@ -693,8 +704,12 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
         if (n_splits) memcpy(split_segs.data(), h_split + kOffSplits, (size_t)n_splits * sizeof(SplitSeg));
         n_split_segments = n_splits;
         if (opt.debug && split_on)
-            fprintf(stderr, "[asgart] %u long segment(s) cut into ranges: %u runs (ranges of %lld probes, each started %lld probes in front of its cut), %u cuts to check\n",
-                    n_splits, n_runs, (long long)opt.split_len, (long long)opt.split_warm, n_cuts);
+            for (const SplitSeg &sg : split_segs)
+                fprintf(stderr, "[asgart] ranges: segment at probe %u: tier %u, %u probe positions, %u hits -> %u ranges\n", sg.g_seg0, sg.tier, sg.span,
+                        sg.hits, sg.n_ranges);
+        if (opt.debug && split_on)
+            fprintf(stderr, "[asgart] %u long segment(s) cut into ranges: %u runs (ranges of %llu probes%s), %u cuts to check\n",
+                    n_splits, n_runs, (unsigned long long)h_split_hdr[4], opt.split_len ? "" : ": the shortest that keeps the runs within the budget", n_cuts);
         if (opt.debug) {
             fprintf(stderr, "[asgart] %llu segments, %llu walked wave by wave; per tier:", (unsigned long long)n_seg,
                     (unsigned long long)h_ctr[CT_LONGSEG]);
@@ -1148,13 +1163,15 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                 auto remember = [&](uint32_t g_seg0, uint32_t allowed) {
                     const int64_t p_ = chunk_of_host(g_seg0) / n_chunks_pass;
                     const uint64_t key_ = (uint64_t)((rp.modes >> (8 * p_)) & 0xFFu) << 32 | (uint64_t)(g_seg0 - h_pbase[p_ * n_chunks_pass]);
+                    const uint32_t len_ = (uint32_t)h_split_hdr[4];
                     std::lock_guard<std::mutex> lk(idx->mu);
                     for (auto &b : idx->split_blocked)
-                        if (b.first == key_) {
-                            b.second = std::min(b.second, allowed);
+                        if (b.key == key_) {
+                            b.allowed = b.range_len == len_ ? std::min(b.allowed, allowed) : allowed;
+                            b.range_len = len_;
                             return;
                         }
-                    idx->split_blocked.emplace_back(key_, allowed);
+                    idx->split_blocked.push_back({key_, allowed, len_});
                 };
                 for (const SplitSeg &sg : split_segs) {
                     const uint32_t n_cuts_sg = sg.n_ranges - 1;
@@ -1377,26 +1394,70 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
         const auto t_post1 = std::chrono::steady_clock::now();
         // (sorted by segment start probe: pass 0's families first, then pass 1's ...; a family's key counts probes from
         // the start of its OWN pass, so that it equals the key a single-pass call gives the same family)
-        for (int32_t p = 0; p < n_passes; ++p) fams[p]->sds.reserve(n_passes == 1 ? n_hrec : n_hrec / (size_t)n_passes + n_hrec / 4);
-        int32_t pass = 0;
-        for (size_t f0 = 0; f0 < n_hrec;) {
-            if (h_recs[f0].g_start == kVoidStart) break;  // unused slots of the waves' record chunks: sorted last
-            size_t f1 = f0;
-            while (f1 < n_hrec && h_recs[f1].g_start == h_recs[f0].g_start &&
-                   h_recs[f1].fam_seq == h_recs[f0].fam_seq)
-                ++f1;
-            while (pass + 1 < n_passes && h_recs[f0].g_start >= h_pbase[(int64_t)(pass + 1) * n_chunks_pass]) ++pass;
-            asgart_families *const fo = fams[pass];
-            if (h_recs[f1 - 1].create_seq != kTombstone) {
-                for (size_t j = f0; j < f1; ++j) {
-                    if (j > f0 && h_recs[j].create_seq == h_recs[j - 1].create_seq) continue;
-                    fo->sds.push_back(h_recs[j].sd);
+        // Assembly: the records are read once (48 bytes each: a memory-bound loop) -- large lists by up to four host threads,
+        // each over a slice that starts at a family boundary, their parts joined in order.
+        using Part = SearchCtx::FamPart;  // (kept by the call context: fresh vectors of this size cost their page faults every call)
+        auto assemble = [&](size_t b0, size_t b1, Part &out) {
+            int32_t pass = 0;
+            for (size_t f0 = b0; f0 < b1;) {
+                if (h_recs[f0].g_start == kVoidStart) break;  // unused slots of the waves' record chunks: sorted last
+                size_t f1 = f0;
+                while (f1 < n_hrec && h_recs[f1].g_start == h_recs[f0].g_start && h_recs[f1].fam_seq == h_recs[f0].fam_seq) ++f1;
+                while (pass + 1 < n_passes && h_recs[f0].g_start >= h_pbase[(int64_t)(pass + 1) * n_chunks_pass]) ++pass;
+                if (h_recs[f1 - 1].create_seq != kTombstone) {
+                    std::vector<asgart_proto_sd> &sds = out.sds[pass];
+                    for (size_t j = f0; j < f1; ++j) {
+                        if (j > f0 && h_recs[j].create_seq == h_recs[j - 1].create_seq) continue;
+                        sds.push_back(h_recs[j].sd);
+                    }
+                    out.ends[pass].push_back(sds.size());
+                    out.keys[pass].push_back(((uint64_t)(h_recs[f0].g_start - h_pbase[(int64_t)pass * n_chunks_pass]) << 32) |
+                                             (uint64_t)h_recs[f0].fam_seq);
                 }
-                fo->fam_offsets.push_back(fo->sds.size());
-                fo->fam_keys.push_back(((uint64_t)(h_recs[f0].g_start - h_pbase[(int64_t)pass * n_chunks_pass]) << 32) |
-                                       (uint64_t)h_recs[f0].fam_seq);
+                f0 = f1;
             }
-            f0 = f1;
+        };
+        const size_t n_parts = n_hrec >= (1u << 17) ? 4 : 1;
+        size_t bound[5] = {0, 0, 0, 0, n_hrec};
+        for (size_t t = 1; t < n_parts; ++t) {  // slice boundaries moved forward to the next family start
+            size_t b = std::max(bound[t - 1], n_hrec * t / n_parts);
+            while (b > 0 && b < n_hrec && h_recs[b].g_start == h_recs[b - 1].g_start && h_recs[b].fam_seq == h_recs[b - 1].fam_seq) ++b;
+            bound[t] = b;
+        }
+        for (size_t t = n_parts; t < 4; ++t) bound[t] = n_hrec;
+        std::vector<Part> &parts = cx.fam_parts;
+        parts.resize(4);
+        for (size_t t = 0; t < 4; ++t)
+            for (int32_t p = 0; p < 4; ++p) {
+                parts[t].sds[p].clear();
+                parts[t].ends[p].clear();
+                parts[t].keys[p].clear();
+                if (t < n_parts && p < n_passes)
+                    parts[t].sds[p].reserve((bound[t + 1] - bound[t]) / (size_t)n_passes + (bound[t + 1] - bound[t]) / 4 + 16);
+            }
+        {
+            std::vector<std::thread> workers;
+            for (size_t t = 1; t < n_parts; ++t) workers.emplace_back([&, t]() { assemble(bound[t], bound[t + 1], parts[t]); });
+            assemble(bound[0], bound[1], parts[0]);
+            for (auto &th : workers) th.join();
+        }
+        for (int32_t p = 0; p < n_passes; ++p) {
+            asgart_families *const fo = fams[p];
+            size_t tot = 0, nf = 0;
+            for (const Part &pt : parts) {
+                tot += pt.sds[p].size();
+                nf += pt.ends[p].size();
+            }
+            if (!tot && !nf) continue;
+            fo->sds.reserve(fo->sds.size() + tot);
+            fo->fam_offsets.reserve(fo->fam_offsets.size() + nf);
+            fo->fam_keys.reserve(fo->fam_keys.size() + nf);
+            for (const Part &pt : parts) {
+                const size_t at = fo->sds.size();
+                fo->sds.insert(fo->sds.end(), pt.sds[p].begin(), pt.sds[p].end());
+                for (uint64_t e : pt.ends[p]) fo->fam_offsets.push_back(at + e);
+                fo->fam_keys.insert(fo->fam_keys.end(), pt.keys[p].begin(), pt.keys[p].end());
+            }
         }
         if (opt.debug)
             fprintf(stderr, "[asgart] records: %llu slots; ordering + copy to the host %.1f ms, families assembled in %.1f ms\n",

@@ -1096,6 +1096,7 @@ constexpr uint32_t kRunDumpCap = 5120; // arms a run can leave alive (the long s
 // end, threshold, gap, 0
 struct SplitSeg {
     uint32_t g_seg0, run_base, n_ranges, cut_base;  // runs run_base .. + n_ranges - 1: the ranges; cuts cut_base .. + n_ranges - 2
+    uint32_t span, hits, tier, pad;                 // (what the placement knew of the segment: option debug prints it)
 };
 
 template <class PosT>
@@ -2274,12 +2275,67 @@ __global__ __launch_bounds__(64) void cluster_barren_kernel(RunParams rp, PlaceP
 //   validate_cuts_kernel   one workgroup per cut: same arms (by creation number, every field), same family state
 //   fixup_records_kernel   one thread per record slot: family ordinals of a range + the flushes of the ranges before it;
 //                          records of a segment that failed -> void
+// Range length by budget (option split_len = 0): every run holds a compute unit, so the number of runs is what the cutting
+// may cost.  split_tally_kernel counts, for each candidate length T, the runs that cutting every eligible segment of at least
+// 2 T probe positions would make; split_pick_kernel takes the SMALLEST T whose count fits the budget (a small job gets short
+// ranges -- its few long segments are its whole extension --, a genome-sized one long ranges); warm-up max(T / 2, 2 048),
+// shortest segment cut max(2 T, 3 warm-ups).  The choice depends on the segments only: the same in every call over the same input and settings.
+constexpr int kSplitCand = 9;
+__device__ inline uint32_t split_len_of(int c) {
+    constexpr uint32_t t[kSplitCand] = {2048, 3072, 4096, 6144, 8192, 12288, 16384, 24576, 32768};
+    return t[c];
+}
+struct SplitChoice {
+    uint32_t range_len, warm, min_span, pad;
+    unsigned long long runs[kSplitCand];
+};
+__device__ inline bool split_eligible(const RunParams &rp, uint32_t key, uint2 info) {
+    const uint32_t tier = (key >> 29) + 1u;
+    // (tiers 1 and 2 are one-wave kernels: a wave on its own passes a sparse probe several times faster than the long shape's
+    // sixteen waves and their barrier -- cutting a yeast-sized input's longest tier-2 segment in two doubled its step; tier 7's
+    // arms do not fit the long shape)
+    if (tier < (uint32_t)rp.split_tier_lo || tier > 6u) return false;
+    const uint32_t span = info.y & 0x7FFFFFFFu;
+    if (!(info.y >> 31) || span < 128u) return false;  // (cut short by a shard window: left alone)
+    if (rp.split_dense && (unsigned long long)info.x < (unsigned long long)rp.split_dense * span) return false;
+    // (creation numbers of a run: needle offset relative to the segment's first probe << 10 | hit index)
+    return (unsigned long long)span * (unsigned long long)rp.step < (1ull << 22) - 2ull;
+}
+__global__ __launch_bounds__(256) void split_tally_kernel(RunParams rp, const unsigned long long *__restrict__ n_seg_ptr,
+                                                         const uint32_t *__restrict__ keys, const uint2 *__restrict__ seg_info,
+                                                         SplitChoice *__restrict__ choice) {
+    const unsigned long long sj = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (sj >= *n_seg_ptr) return;
+    const uint2 info = seg_info[sj];
+    const uint32_t span = info.y & 0x7FFFFFFFu;
+    if (span < 2u * split_len_of(0) || !split_eligible(rp, keys[sj], info)) return;
+    for (int c = 0; c < kSplitCand; ++c) {
+        const uint32_t T = split_len_of(c);
+        if (span < max(2u * T, 3u * max(T / 2u, 2048u))) break;
+        atomicAdd(&choice->runs[c], (unsigned long long)max(2u, (span + T / 2u) / T));
+    }
+}
+__global__ void split_pick_kernel(SplitChoice *choice, uint32_t budget) {
+    int pick = kSplitCand - 1;
+    for (int c = 0; c < kSplitCand; ++c)
+        if (choice->runs[c] <= (unsigned long long)budget) {
+            pick = c;
+            break;
+        }
+    choice->range_len = split_len_of(pick);
+    choice->warm = max(split_len_of(pick) / 2u, 2048u);  // (E. coli-sized inputs: cuts with 1 024 probes of warm-up did not hold)
+    // (two ranges of a segment shorter than three warm-ups are each nearly the segment)
+    choice->min_span = max(2u * split_len_of(pick), 3u * choice->warm);
+}
+
 struct SplitParams {
     uint32_t range_len, warm, min_span;   // probes per range, warm-up probes in front of a cut, shortest segment that is cut
+                                          // (range_len = 0: as split_pick_kernel chose)
     uint32_t max_runs, max_cuts, max_splits;
     uint32_t n_blocked;
     uint32_t blocked[64];                 // segments (first probe) a cut of which did not hold in an earlier call of the index ...
     uint16_t allowed[64];                 // ... and how many of their cuts, counted from the segment's start, held (0: not cut again)
+    uint32_t blocked_len[64];             // ... at which range length (the count means nothing at another)
 };
 __global__ __launch_bounds__(256) void plan_ranges_kernel(RunParams rp, SplitParams sp, const uint32_t *__restrict__ p_filt,
                                                          const uint32_t *__restrict__ seg_list,
@@ -2287,22 +2343,26 @@ __global__ __launch_bounds__(256) void plan_ranges_kernel(RunParams rp, SplitPar
                                                          uint32_t *__restrict__ keys, const uint2 *__restrict__ seg_info,
                                                          unsigned long long *__restrict__ hdr,  // 0 runs, 1 cuts, 2 split segments
                                                          RangeRun *__restrict__ runs, uint2 *__restrict__ cuts,
-                                                         SplitSeg *__restrict__ splits) {
+                                                         SplitSeg *__restrict__ splits, const SplitChoice *__restrict__ choice) {
     const unsigned long long sj = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (sj >= *n_seg_ptr) return;
+    if (!sp.range_len) {  // (hdr[3] is the runs' work cursor: hdr[4] tells the host which length was used)
+        sp.range_len = choice->range_len;
+        sp.warm = choice->warm;
+        sp.min_span = max(sp.min_span, choice->min_span);
+        if (sj == 0) hdr[4] = sp.range_len;
+    } else if (sj == 0) {
+        hdr[4] = sp.range_len;
+    }
     const uint32_t key = keys[sj];
-    const uint32_t tier = (key >> 29) + 1u;
-    if (tier < 2u || tier > 6u) return;  // (the one-wave tier's segments are short; tier 7's arms do not fit the long shape)
     const uint2 info = seg_info[sj];
     const uint32_t span = info.y & 0x7FFFFFFFu;
-    if (!(info.y >> 31) || span < sp.min_span || span < 128u) return;
-    // (creation numbers of a run: needle offset relative to the segment's first probe << 10 | hit index)
-    if ((unsigned long long)span * (unsigned long long)rp.step >= (1ull << 22) - 2ull) return;
+    if (span < sp.min_span || !split_eligible(rp, key, info)) return;
     const uint32_t g0 = seg_list[sj];
     const uint32_t warm = sp.warm;
     uint32_t n_cut_max = 0xFFFFFFFFu;
     for (uint32_t b = 0; b < sp.n_blocked; ++b)
-        if (sp.blocked[b] == g0) n_cut_max = min(n_cut_max, (uint32_t)sp.allowed[b]);
+        if (sp.blocked[b] == g0 && sp.blocked_len[b] == sp.range_len) n_cut_max = min(n_cut_max, (uint32_t)sp.allowed[b]);
     // ranges of about range_len probes, all of one length, at least two; a segment whose cuts held only up to some point in
     // an earlier call keeps those cuts (same places) and runs the rest as its last range
     const uint32_t n_r_all = max(2u, (span + sp.range_len / 2u) / sp.range_len);
@@ -2336,7 +2396,7 @@ __global__ __launch_bounds__(256) void plan_ranges_kernel(RunParams rp, SplitPar
         return;
     }
     keys[sj] = (key & 0x1FFFFFFFu) | ((uint32_t)(kTierBarren - 1) << 29);  // off its tier's list
-    splits[split] = SplitSeg{g0, run_base, n_r, cut_base};
+    splits[split] = SplitSeg{g0, run_base, n_r, cut_base, span, info.x, (key >> 29) + 1u, 0u};
     uint32_t c_prev = g0;
     for (uint32_t j = 0; j < n_r; ++j) {
         const uint32_t c_next = j + 1u < n_r ? cut_of(j + 1u) : 0xFFFFFFFFu;
