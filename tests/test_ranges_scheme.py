@@ -1,0 +1,150 @@
+"""The RANGES scheme of DESIGN.md 4.8, restated on the CPU (no GPU, no HIP code): a long segment of the automaton is cut
+at hit-probes; every range runs from an EMPTY arm list `warm` probes in front of its cut, reports from the cut on, and is
+accepted only if what it holds when it reaches its cut equals what the range in front of it holds when it stops there
+(every arm, every field, by creation key; family open or not).  Where the first cut fails, the ranges in front of it stand
+and ONE more run covers the rest from a checked state.  The joined output -- family ordinals counted on from the flushes
+of the ranges before, creation order by (probe, hit) -- must be the whole run's, which is itself pinned against the
+oracle here.
+
+What the test restates (plain Python over the oracle's per-probe hit rows, live arms only):
+    src/automaton.rs:119-171   one processed probe: the first accepting arm in list order takes a hit, the last hit of
+                               an arm wins, unmatched hits start arms in hit order, unextended arms age by `step`
+    src/automaton.rs:173-200   dead arms retire (reported when len(right) >= M), the family is flushed when no arm is left
+The kernels do the same per range (extend_k8_kernel<RANGE>), with lazily applied ages and waves a step apart -- which is
+why their cuts sit at hit-probes; this model ages eagerly, so any probe would do, but the cuts are placed the same way.
+"""
+import numpy as np
+import pytest
+
+import oracle
+
+K, GAP, STEP = 20, 100, 10
+G = GAP + K
+M = 200
+BASES = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+def _text(seed, period, copies, sub):
+    rng = np.random.default_rng(seed)
+    arr = np.tile(rng.integers(0, 4, size=period), copies)
+    mut = rng.random(arr.shape) < sub
+    arr[mut] = (arr[mut] + rng.integers(1, 4, size=int(mut.sum()))) & 3
+    g = np.concatenate([rng.integers(0, 4, size=3000), arr, rng.integers(0, 4, size=3000)])
+    return np.concatenate([BASES[g], np.frombuffer(b"$", dtype=np.uint8)])
+
+
+class Run:
+    """the automaton over probes [t0, t1) from an empty arm list; records from probe `emit_from` on"""
+
+    def __init__(self, status, offs, hits, t0, t1, emit_from, snap_at=None):
+        self.arms = []          # [key, ls, le, rs, re, gap] in creation order; key = (probe, index of the creating hit)
+        self.open = False
+        self.flushes = 0        # flushes at probes >= emit_from
+        self.recs = []          # (family ordinal counted from emit_from, key, ls, le, rs, re)
+        self.at_cut = None
+        for t in range(t0, t1):
+            if t == snap_at:
+                self.at_cut = self.state()
+            if status[t]:
+                continue        # skipped probes neither age nor reset (:100-102, :115-117)
+            self.probe(t, (t + 1) * STEP, hits[offs[t]:offs[t + 1]], t >= emit_from)
+        self.end = self.state()
+
+    def state(self):
+        return (sorted(tuple(a) for a in self.arms), self.open)
+
+    def probe(self, t, i, xs, emit):
+        won = {}
+        new = []
+        for h, x in enumerate(xs):
+            for n, a in enumerate(self.arms):           # first accepting arm in list order (:67-78)
+                thr = max(G, (a[2] - a[1]) // 10)
+                if a[4] - K < x < a[4] + thr:           # the whole predicate
+                    won[n] = x                          # the LAST hit of an arm wins (:136-143)
+                    break
+            else:
+                new.append((h, int(x)))
+        for n, a in enumerate(self.arms):
+            if n in won:
+                a[2], a[4], a[5] = i + K, int(won[n]) + K, 0
+            else:
+                a[5] += STEP                            # (:166-171)
+        for h, x in new:                                # NewArm in hit order (:145-163); they age at once
+            self.arms.append([(t, h), i, i + K, x, x + K, STEP])
+            self.open = True
+        alive = []
+        for a in self.arms:
+            if a[5] < G:
+                alive.append(a)
+            elif a[4] - a[3] >= M and emit:             # retired: reported when long enough (:186-196)
+                self.recs.append((self.flushes, a[0], a[1], a[2], a[3], a[4]))
+        self.arms = alive
+        if self.open and not self.arms:                 # the family is flushed when no arm is left (:182-200)
+            self.open = False
+            if emit:
+                self.flushes += 1
+
+
+def _families(recs):
+    fams = {}
+    for f, key, ls, le, rs, re in sorted(recs):
+        fams.setdefault(f, []).append((ls, le - ls, rs, re - rs))
+    return [fams[f] for f in sorted(fams)]
+
+
+def _ranges(status, offs, hits, s0, s1, last_hit_probe, n_ranges, warm):
+    """-> (joined records, cuts that held, number of runs)"""
+    cnt = np.diff(offs)
+    cuts = []
+    for j in range(1, n_ranges):
+        c = s0 + (last_hit_probe - s0) * j // n_ranges
+        while status[c] or cnt[c] == 0:                 # moved forward to a hit-probe
+            c += 1
+        cuts.append(c)
+    starts = [s0] + cuts
+    stops = cuts + [s1]
+    begin = [s0] + [max(s0, c - warm) for c in cuts]
+    runs = [Run(status, offs, hits, begin[j], stops[j], starts[j], snap_at=starts[j] if j else None) for j in range(n_ranges)]
+    held = 0
+    while held < n_ranges - 1 and runs[held].end == runs[held + 1].at_cut:
+        held += 1
+    n_runs = n_ranges
+    kept = runs[:held + 1]
+    if held < n_ranges - 1:                             # the rest as ONE more run, from where the last good range started
+        kept = runs[:held + 1] + [Run(status, offs, hits, begin[held], s1, stops[held])]
+        n_runs += 1
+    out, base = [], 0
+    for r in kept:
+        out += [(base + f,) + tuple(rest) for (f, *rest) in r.recs]
+        base += r.flushes
+    return out, held, n_runs
+
+
+@pytest.mark.parametrize("period,copies,sub,n_ranges,warm,expect", [
+    (64, 150, 0.06, 5, 400, "all"),     # arms die of the substitutions within the warm-up: every cut holds
+    (64, 150, 0.06, 5, 8, "some"),      # a warm-up of 8 probes: cuts fail, the rest runs from the last good one
+    (171, 60, 0.0, 4, 200, "some"),     # exact copies: one arm per offset lives through the whole array
+])
+def test_ranges_joined_equal_the_whole_run_and_the_oracle(period, copies, sub, n_ranges, warm, expect):
+    text = _text(11, period, copies, sub)
+    oidx = oracle.Index.build(text)
+    st = oracle.make_settings(k=K, gap=GAP, min_length=M)
+    chunk = (0, len(text) - 1)
+    status, offs, hits = oidx.probe_hits(oracle.prepare_needle(text, chunk, st), 0, st)
+    offs, hits = offs.astype(np.int64), hits.astype(np.int64)
+    hp = np.nonzero((status == 0) & (np.diff(offs) > 0))[0]
+    # the segment: from its first hit-probe to the quiet probes behind its last one that let every arm die
+    s0, s1 = int(hp[0]), min(len(status), int(hp[-1]) + 1 + 2 * ((G + STEP - 1) // STEP))
+    whole = Run(status, offs, hits, s0, s1, s0)
+    assert not whole.arms                               # (the flank is unique: nothing alive at the end of the chunk)
+    want = _families(whole.recs)
+    # the restatement itself against the oracle's run over the same chunk
+    eo, es = oidx.run_raw([chunk], st)
+    got = [[(int(a), int(b), int(c), int(d)) for a, c, b, d in es[eo[f]:eo[f + 1]]] for f in range(len(eo) - 1)]
+    assert got == want and len(want) > 0
+    joined, held, n_runs = _ranges(status, offs, hits, s0, s1, int(hp[-1]), n_ranges, warm)
+    assert _families(joined) == want
+    if expect == "all":
+        assert held == n_ranges - 1 and n_runs == n_ranges
+    else:
+        assert held < n_ranges - 1 and n_runs == n_ranges + 1
