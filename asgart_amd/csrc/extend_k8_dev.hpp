@@ -961,6 +961,7 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
                         m[1] = fam_seq;
                         m[2] = fam_open ? 1u : 0u;
                         m[3] = spur_until > t_proc ? spur_until - t_proc : 0u;
+                        m[5] = (uint32_t)wall_clock64() - s_end[3];  // (10-ns ticks)
                     }
                 }
                 if (fam_open && total_free == (uint32_t)CAP && t_proc >= spur_until) fam_open = false;
@@ -1001,6 +1002,7 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
             const uint32_t chunk_end = rp.ch.pbase[c + 1];
             const uint32_t g_end = RANGE ? min(min(chunk_end, rp.g_hi), run.g_stop) : min(chunk_end, rp.g_hi);
             if (lane == 0) {
+                if constexpr (RANGE) s_end[3] = (uint32_t)wall_clock64();  // (the run's duration goes into its state: option debug)
                 s_seg[0] = g0;
                 s_seg[1] = cs;
                 s_seg[2] = cl | ((unsigned long long)((rp.mode_of(c) >> 1) & 1u) << 63);

@@ -78,6 +78,7 @@ const OptDesc kOptions[] = {
     {"split", &Options::split, 0, 1},
     {"split_len", &Options::split_len, 0, 1 << 20},
     {"split_runs", &Options::split_runs, 1, 3072},
+    {"split_hw", &Options::split_hw, 0, 1 << 20},
     {"split_tier", &Options::split_tier, 2, 6},
     {"split_dense", &Options::split_dense, 0, 1 << 20},
     {"split_warm", &Options::split_warm, 0, 1 << 20},

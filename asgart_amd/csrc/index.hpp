@@ -84,6 +84,7 @@ struct RunParams {
     int flt_bits;
     uint32_t split_tier_lo;  // option split_tier: lowest tier whose segments may be cut into ranges
     uint32_t split_dense;    // option split_dense: ... and only those with at least this many hits per probe position
+    uint32_t split_hw;       // option split_hw: a segment's size is positions + hits / split_hw (0: positions)
     uint32_t bucket_lookup;  // option bucket: 1 = small prefix-table buckets are looked up with keys and suffix-array entries
                              // requested together (probe_count_kernel)
     __host__ __device__ inline uint32_t pass_of(int c) const {
@@ -348,6 +349,8 @@ struct Options {
     int64_t split_tier = 3;         // lowest tier whose long segments are cut (2: also the one-wave tier's -- a wave on its own passes a
                                     // sparse probe faster than the long shape's sixteen)
     int64_t split_dense = 0;        // segments with fewer hits per probe position than this are not cut (0: any)
+    int64_t split_hw = 0;           // (split_len = 0) a segment's size for the cutting is positions + hits / split_hw, and its cuts sit at
+                                    // equal shares of that (0: positions only)
     int64_t split_runs = 224;       // ... that budget: every run holds a compute unit while it runs
     int64_t split_warm = 6144;      // (split_len > 0) probes a range starts in front of its cut
     int64_t split_min = 0;          // segments shorter than this (probe positions) are not cut (split_len = 0: at least this)

@@ -384,6 +384,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
     rp.pass_chunks = (uint32_t)n_chunks_pass;
     rp.split_tier_lo = (uint32_t)idx->opt.split_tier;
     rp.split_dense = (uint32_t)idx->opt.split_dense;
+    rp.split_hw = (uint32_t)idx->opt.split_hw;
     rp.modes = 0;
     rp.flt_bits = idx->filter_bits;
     rp.bucket_lookup = opt.bucket ? 1u : 0u;
@@ -678,7 +679,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                                                               reinterpret_cast<unsigned long long *>(d_split),
                                                               reinterpret_cast<RangeRun *>(d_split + kOffRuns),
                                                               reinterpret_cast<uint2 *>(d_split + kOffCuts),
-                                                              reinterpret_cast<SplitSeg *>(d_split + kOffSplits), d_choice);
+                                                              reinterpret_cast<SplitSeg *>(d_split + kOffSplits), d_choice, row_off);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(h_split, d_split, kOffMeta, hipMemcpyDeviceToHost, s));
         }
@@ -1214,6 +1215,13 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                         ++n_split_refused;
                         remember(sg.g_seg0, f);
                         if (f == 0) h_again[n_again++] = sg.g_seg0;
+                    }
+                }
+                if (opt.debug) {  // the runs' durations, per cut segment (ms)
+                    for (const SplitSeg &sg : split_segs) {
+                        fprintf(stderr, "[asgart] ranges: segment at probe %u (tier %u, %u positions, %u hits): runs", sg.g_seg0, sg.tier, sg.span, sg.hits);
+                        for (uint32_t j = 0; j < sg.n_ranges; ++j) fprintf(stderr, " %.1f", (double)h_meta[(size_t)(sg.run_base + j) * 16 + 5] * 1e-5);
+                        fprintf(stderr, " ms\n");
                     }
                 }
                 if (opt.debug)

@@ -2275,16 +2275,23 @@ __global__ __launch_bounds__(64) void cluster_barren_kernel(RunParams rp, PlaceP
 //   validate_cuts_kernel   one workgroup per cut: same arms (by creation number, every field), same family state
 //   fixup_records_kernel   one thread per record slot: family ordinals of a range + the flushes of the ranges before it;
 //                          records of a segment that failed -> void
-// Range length by budget (option split_len = 0): every run holds a compute unit, so the number of runs is what the cutting
-// may cost.  split_tally_kernel counts, for each candidate length T, the runs that cutting every eligible segment of at least
-// 2 T probe positions would make; split_pick_kernel takes the SMALLEST T whose count fits the budget (a small job gets short
-// ranges -- its few long segments are its whole extension --, a genome-sized one long ranges); warm-up max(T / 2, 2 048),
-// shortest segment cut max(2 T, 3 warm-ups).  The choice depends on the segments only: the same in every call over the same input and settings.
-constexpr int kSplitCand = 9;
+// Range size by budget (option split_len = 0): every run holds a compute unit, so the number of runs is what the cutting
+// may cost, and what a run takes is not its probe positions but its WORK: measured on the long shape, ~0.4 us per probe
+// position plus ~17 ns per hit (a 27 K-position segment with 274 hits per position ran 46 + 67 ms in two ranges of equal
+// length, a 60 K-position one whose array sits at its end 5 + 7 + 8 + 8 + 41 ms in five).  So a segment's size is
+// cost = positions + hits / kSplitHitWeight, it gets round(cost / C) ranges, and its cuts sit at equal shares of that cost
+// along the segment (the CSR row offsets are the running hit count).  split_tally_kernel counts, for each candidate C, the
+// runs that cutting every eligible segment would make; split_pick_kernel takes the SMALLEST C whose count fits the budget (a
+// small job gets small ranges -- its few long segments are its whole extension --, a genome-sized one large ranges); warm-up
+// C / 2 positions within [2 048, 6 144]; a segment is cut when it costs at least 2 C and is at least 3 warm-ups long.  The choice
+// depends on the segments only: the same in every call over the same input and settings.
+constexpr int kSplitCand = 12;
+constexpr uint32_t kSplitHitWeight = 24;
 __device__ inline uint32_t split_len_of(int c) {
-    constexpr uint32_t t[kSplitCand] = {2048, 3072, 4096, 6144, 8192, 12288, 16384, 24576, 32768};
+    constexpr uint32_t t[kSplitCand] = {2048, 3072, 4096, 6144, 8192, 12288, 16384, 24576, 32768, 49152, 65536, 98304};
     return t[c];
 }
+__device__ inline uint32_t split_warm_of(uint32_t C) { return min(max(C / 2u, 2048u), 6144u); }
 struct SplitChoice {
     uint32_t range_len, warm, min_span, pad;
     unsigned long long runs[kSplitCand];
@@ -2308,11 +2315,12 @@ __global__ __launch_bounds__(256) void split_tally_kernel(RunParams rp, const un
     if (sj >= *n_seg_ptr) return;
     const uint2 info = seg_info[sj];
     const uint32_t span = info.y & 0x7FFFFFFFu;
-    if (span < 2u * split_len_of(0) || !split_eligible(rp, keys[sj], info)) return;
+    if (span < 3u * 2048u || !split_eligible(rp, keys[sj], info)) return;
+    const unsigned long long cost = (unsigned long long)span + (rp.split_hw ? info.x / rp.split_hw : 0u);
     for (int c = 0; c < kSplitCand; ++c) {
-        const uint32_t T = split_len_of(c);
-        if (span < max(2u * T, 3u * max(T / 2u, 2048u))) break;
-        atomicAdd(&choice->runs[c], (unsigned long long)max(2u, (span + T / 2u) / T));
+        const unsigned long long C = split_len_of(c);
+        if (cost < 2ull * C || span < 3u * split_warm_of((uint32_t)C)) break;
+        atomicAdd(&choice->runs[c], max(2ull, (cost + C / 2ull) / C));
     }
 }
 __global__ void split_pick_kernel(SplitChoice *choice, uint32_t budget) {
@@ -2323,14 +2331,14 @@ __global__ void split_pick_kernel(SplitChoice *choice, uint32_t budget) {
             break;
         }
     choice->range_len = split_len_of(pick);
-    choice->warm = max(split_len_of(pick) / 2u, 2048u);  // (E. coli-sized inputs: cuts with 1 024 probes of warm-up did not hold)
-    // (two ranges of a segment shorter than three warm-ups are each nearly the segment)
-    choice->min_span = max(2u * split_len_of(pick), 3u * choice->warm);
+    choice->warm = split_warm_of(split_len_of(pick));  // (E. coli-sized inputs: cuts with 1 024 probes of warm-up did not hold)
+    choice->min_span = 3u * choice->warm;               // (two ranges of a shorter segment are each nearly the segment)
 }
 
 struct SplitParams {
-    uint32_t range_len, warm, min_span;   // probes per range, warm-up probes in front of a cut, shortest segment that is cut
-                                          // (range_len = 0: as split_pick_kernel chose)
+    uint32_t range_len, warm, min_span;   // size of a range (probe positions; range_len = 0: cost units, as split_pick_kernel chose),
+                                          // warm-up probes in front of a cut, shortest segment that is cut
+    uint32_t hit_weight;                  // cost = positions + hits / hit_weight (0: positions only)
     uint32_t max_runs, max_cuts, max_splits;
     uint32_t n_blocked;
     uint32_t blocked[64];                 // segments (first probe) a cut of which did not hold in an earlier call of the index ...
@@ -2343,13 +2351,15 @@ __global__ __launch_bounds__(256) void plan_ranges_kernel(RunParams rp, SplitPar
                                                          uint32_t *__restrict__ keys, const uint2 *__restrict__ seg_info,
                                                          unsigned long long *__restrict__ hdr,  // 0 runs, 1 cuts, 2 split segments
                                                          RangeRun *__restrict__ runs, uint2 *__restrict__ cuts,
-                                                         SplitSeg *__restrict__ splits, const SplitChoice *__restrict__ choice) {
+                                                         SplitSeg *__restrict__ splits, const SplitChoice *__restrict__ choice,
+                                                         const unsigned long long *__restrict__ row_off) {
     const unsigned long long sj = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (sj >= *n_seg_ptr) return;
     if (!sp.range_len) {  // (hdr[3] is the runs' work cursor: hdr[4] tells the host which length was used)
         sp.range_len = choice->range_len;
         sp.warm = choice->warm;
         sp.min_span = max(sp.min_span, choice->min_span);
+        sp.hit_weight = rp.split_hw;
         if (sj == 0) hdr[4] = sp.range_len;
     } else if (sj == 0) {
         hdr[4] = sp.range_len;
@@ -2363,24 +2373,42 @@ __global__ __launch_bounds__(256) void plan_ranges_kernel(RunParams rp, SplitPar
     uint32_t n_cut_max = 0xFFFFFFFFu;
     for (uint32_t b = 0; b < sp.n_blocked; ++b)
         if (sp.blocked[b] == g0 && sp.blocked_len[b] == sp.range_len) n_cut_max = min(n_cut_max, (uint32_t)sp.allowed[b]);
-    // ranges of about range_len probes, all of one length, at least two; a segment whose cuts held only up to some point in
-    // an earlier call keeps those cuts (same places) and runs the rest as its last range
-    const uint32_t n_r_all = max(2u, (span + sp.range_len / 2u) / sp.range_len);
-    const uint32_t len = (span + n_r_all - 1u) / n_r_all;
+    // ranges of about range_len units of cost each (scaled by the hit weight: positions x weight + hits), at least two, their
+    // cuts at equal shares of the cost along the segment; a segment whose cuts held only up to some point in an earlier call
+    // keeps those cuts (same places) and runs the rest as its last range
+    const unsigned long long hw = sp.hit_weight, r0 = row_off[g0];
+    auto cost_to = [&](uint32_t g) -> unsigned long long {  // of the probes g0 .. g - 1
+        return hw ? (unsigned long long)(g - g0) * hw + (row_off[g] - r0) : (unsigned long long)(g - g0);
+    };
+    const unsigned long long total = cost_to(g0 + span), unit = (unsigned long long)sp.range_len * (hw ? hw : 1ull);
+    if (total < 2ull * unit) return;
+    const uint32_t n_r_all = (uint32_t)min(1024ull, max(2ull, (total + unit / 2ull) / unit));
     const uint32_t n_r = min(n_r_all, n_cut_max == 0xFFFFFFFFu ? n_r_all : n_cut_max + 1u);
     if (n_r < 2u) return;
-    auto cut_of = [&](uint32_t j) -> uint32_t {  // first hit-probe at or behind g0 + j * len (0: none in reach)
-        uint32_t c = g0 + j * len;
-        const uint32_t lim = min(g0 + span, c + len / 2u);
-        while (c < lim) {
+    auto cut_of = [&](uint32_t j) -> uint32_t {  // first hit-probe at or behind the j-th share of the cost (0: none)
+        const unsigned long long want = total / n_r_all * j;
+        uint32_t lo = g0, hi = g0 + span;                // smallest g with cost_to(g) >= want
+        while (lo < hi) {
+            const uint32_t mid = lo + (hi - lo) / 2u;
+            if (cost_to(mid) >= want) hi = mid;
+            else lo = mid + 1u;
+        }
+        uint32_t c = lo;
+        while (c < g0 + span) {
             const uint32_t f = p_filt[c];
             if (f >= 1u && f < kPending) return c;
             ++c;
         }
         return 0u;
     };
-    for (uint32_t j = 1; j < n_r; ++j)
-        if (!cut_of(j)) return;
+    {   // (every cut behind its predecessor, the first behind the segment's start)
+        uint32_t before = g0;
+        for (uint32_t j = 1; j < n_r; ++j) {
+            const uint32_t c = cut_of(j);
+            if (c <= before) return;
+            before = c;
+        }
+    }
     const uint32_t n_runs = n_r;
     const uint32_t run_base = (uint32_t)atomicAdd(&hdr[0], (unsigned long long)n_runs);
     if (run_base + n_runs > sp.max_runs) {
