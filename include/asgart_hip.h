@@ -97,7 +97,8 @@ typedef struct asgart_stats {
                                   compute units nor more GPUs shorten a segment (ms_longest_tier is the tier that FINISHED
                                   last, which is throughput when the tier holds many segments)                    */
     uint64_t split_segments;   /* long segments that ran as ranges side by side (option split) ...                */
-    uint64_t split_refused;    /* ... and those of them whose ranges did not join up: run again as a whole        */
+    uint64_t split_refused;    /* ... and those of them with a cut that did not hold (the rest behind it ran as one more
+                                  run, or the whole segment again)                                                 */
 } asgart_stats;
 
 typedef struct asgart_index asgart_index;
