@@ -344,8 +344,8 @@ struct Options {
                                     // its first cut fails); the index then plans only the cuts that held.  32-bit positions.  0: every
                                     // segment is one work item
     int64_t split_len = 0;          // probes per range (about: the ranges of a segment are of one length); 0: the smallest of 2048 ... 32768
-                                    // for which the call's runs stay within split_runs (split_tally_kernel), warm-up half of it (at least
-                                    // 2048), shortest segment cut twice it -- a small job gets short ranges, a genome-sized one long ones
+                                    // for which the call's runs stay within split_runs (split_tally_kernel), warm-up as long (2048 .. 6144),
+                                    // shortest segment cut twice it -- a small job gets short ranges, a genome-sized one long ones
     int64_t split_tier = 3;         // lowest tier whose long segments are cut (2: also the one-wave tier's -- a wave on its own passes a
                                     // sparse probe faster than the long shape's sixteen)
     int64_t split_dense = 0;        // segments with fewer hits per probe position than this are not cut (0: any)

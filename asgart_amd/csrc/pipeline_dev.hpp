@@ -2283,7 +2283,7 @@ __global__ __launch_bounds__(64) void cluster_barren_kernel(RunParams rp, PlaceP
 // along the segment (the CSR row offsets are the running hit count).  split_tally_kernel counts, for each candidate C, the
 // runs that cutting every eligible segment would make; split_pick_kernel takes the SMALLEST C whose count fits the budget (a
 // small job gets small ranges -- its few long segments are its whole extension --, a genome-sized one large ranges); warm-up
-// C / 2 positions within [2 048, 6 144]; a segment is cut when it costs at least 2 C and is at least 3 warm-ups long.  The choice
+// C positions within [2 048, 6 144]; a segment is cut when it costs at least 2 C and is at least 3 warm-ups long.  The choice
 // depends on the segments only: the same in every call over the same input and settings.
 constexpr int kSplitCand = 12;
 constexpr uint32_t kSplitHitWeight = 24;
@@ -2291,7 +2291,9 @@ __device__ inline uint32_t split_len_of(int c) {
     constexpr uint32_t t[kSplitCand] = {2048, 3072, 4096, 6144, 8192, 12288, 16384, 24576, 32768, 49152, 65536, 98304};
     return t[c];
 }
-__device__ inline uint32_t split_warm_of(uint32_t C) { return min(max(C / 2u, 2048u), 6144u); }
+// (half a range was not enough at the middle sizes: with ranges of 6 144 probes -- what a shard of a genome-sized call gets --
+// and 3 072 of warm-up 20 of 44 cut segments had a cut that did not hold; with 6 144 every cut of the unsharded call holds)
+__device__ inline uint32_t split_warm_of(uint32_t C) { return min(max(C, 2048u), 6144u); }
 struct SplitChoice {
     uint32_t range_len, warm, min_span, pad;
     unsigned long long runs[kSplitCand];
