@@ -2269,7 +2269,8 @@ __global__ __launch_bounds__(64) void cluster_barren_kernel(RunParams rp, PlaceP
 // only: a run that starts with NO arm `warm` probes in front of c holds, at c, exactly the arms (and the family state) of the
 // run that started at the segment's first probe -- when it does.  Whether it does is CHECKED, never assumed: the range in
 // front of the cut and a warm-up that stops at the cut both write out what they hold there (validate_cuts_kernel compares),
-// and a segment with a cut that fails is run again as a whole, its ranges' records dropped.
+// where a cut fails the ranges in front of it stand, the records of those behind it are dropped and the rest of the segment
+// runs as one more run from the last checked state (the whole segment again when its first cut fails).
 //   plan_ranges_kernel     one thread per segment: the long ones of the long-shape tiers (3, 6) are taken off their tier's
 //                          list and cut at the first hit-probe at or behind every range_len-th probe
 //   validate_cuts_kernel   one workgroup per cut: same arms (by creation number, every field), same family state

@@ -192,8 +192,8 @@ int32_t asgart_index_create_trim(const uint8_t *T, int64_t n, const int64_t *SA,
  * them), k7, k8, dense3, dense6, dense_min, sparse_to6 (which extension kernel a tier runs and which
  * segments the long-segment tier takes: placement again), barren (segments that provably emit nothing are not run: 0 none,
  * 1 by their number of hit-probes, 2 also by the positions of their hits), split, split_len, split_runs, split_hw, split_tier, split_dense, split_warm, split_min (long
- * segments run as ranges side by side, each checked against its predecessor at the cut; a segment with a cut that does not
- * hold runs again as a whole -- results never depend on any of these), pass_gate, fuse_passes, fuse_pole_pct, cache_calls,
+ * segments run as ranges side by side, each checked against its predecessor at the cut; where a cut does not hold the
+ * ranges in front of it stand and the rest of the segment runs as one more run -- results never depend on any of these), pass_gate, fuse_passes, fuse_pole_pct, cache_calls,
  * bucket, watchdog_s, lazy_aux, prewarm,
  * debug, test_cap_limit, test_levels, test_genbits, test_k8_delay (parity tests); the full table with ranges is
  * kOptions in asgart_amd/csrc/index.hip, every field is described in struct Options
