@@ -109,7 +109,7 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
     constexpr unsigned long long kPosMask = (1ull << kTagShift) - 1ull;
     using WinT = typename std::conditional<kWidePos, uint64_t, uint32_t>::type;
     static_assert(HB <= 1024 && S <= 8 && S * NW <= 128 && (kRows & (kRows - 1)) == 0 && (kE == 2 || kE == 4) && kRows >= 128 && kRows <= 2048, "shape");
-    if (NT >= 1024 && P.hi_prio) __builtin_amdgcn_s_setprio(3);
+    if (NT >= 1024) __builtin_amdgcn_s_setprio(3);
 
     __shared__ __attribute__((aligned(16))) unsigned long long s_tab[2][kRows * kE];
     __shared__ PosT s_hits[HB];
@@ -147,12 +147,9 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
     const uint64_t n_seg = *P.n_seg_ptr;
     const uint32_t k = (uint32_t)rp.k, step = (uint32_t)rp.step, G = rp.G;
     const uint32_t thr0 = arm_threshold(k, G);
-    // bucket width: 2^fast_bsh times the smallest power of two >= G + k.  With buckets of G + k a
-    // young arm's window spans at most two rows, but the arms of a tandem array grow longer and most
-    // waves then have a lane that needs a third row: twice that width by default.
+    // bucket width: the smallest power of two >= G + k (a young arm's window spans at most two rows)
     uint32_t bsh = 3;
     while ((1ull << bsh) < (unsigned long long)G + k) ++bsh;
-    bsh += P.fast_bsh;
     const uint32_t kGenBits = min(kGenMax, max(2u, P.gen_bits));
     const uint32_t cap_eff = min((uint32_t)CAP, P.cap_limit);
     const WinT w_loop = (WinT)(kRowsLoop - 1u) << bsh;  // windows up to this width span <= kRowsLoop rows
@@ -180,7 +177,7 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
     uint32_t gen = 0, par = 0, tri = 0;  // generation; parity (table, free counts); best[] / stash buffer
     lds_barrier();
 
-    for (uint32_t n_fetch = 0; !P.max_items || n_fetch < P.max_items; ++n_fetch) {
+    for (;;) {
         if (tid == 0) s_bcast = atomicAdd(P.cursor, 1ull);
         if (tid < 3) s_nstash[tid] = 0u;  // (a probe indexed ahead but never reached may have left entries)
         for (uint32_t j = tid; j < 3u * kBitWords; j += NT) (&s_rowbits[0][0])[j] = 0u;
@@ -1017,7 +1014,7 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
 #ifdef ASGART_PROF_WAVE0
         if (wave == 0u) {  // (diagnostic build with -DASGART_PROF_WAVE0: the wave that holds the first arms reports)
 #else
-        if (wave == min(P.n_levels, (uint32_t)(NW - 1))) {  // (diagnostic build: option test_levels picks the reporting wave)
+        if (wave == min(4u, (uint32_t)(NW - 1))) {  // (diagnostic build: the reporting wave)
 #endif
             PROF_FLUSH();
         }

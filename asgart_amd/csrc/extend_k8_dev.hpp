@@ -1,31 +1,114 @@
-// extend_k8_dev.hpp -- "K8": K7 (extend_k7_dev.hpp: a control wave plans and ranks, arm waves do nothing but their
-// arms) with ONE barrier per hit-probe.
+// extend_k8_dev.hpp -- "K8": the arm-resident extension kernel with SPECIALISED waves and ONE barrier per hit-probe
+// (tier 3: the long dense segments, and every run over a range of a cut segment).
 //
-// Why K7 needs two: the arms born of probe t-1's unmatched hits must offer to probe t, so the arm waves wait (barrier
-// 1) for the control wave's ranking of those hits before they create the arms and make any offer.  Here the control
-// wave makes the FIRST offers of the new arms itself -- a newborn arm's window is a function of its hit alone
-// (x + 1, threshold(k) + k - 1) and its creation number is the rank the control wave has just computed -- and leaves
-// the candidates it found beside the hit.  The arm waves pull the new arms one step later, at the top of the step that
-// resolves probe t, candidates included.  A step is then
+// Same automaton as the other extension kernels (reference src/automaton.rs:57-204; representation of
+// pipeline_dev.hpp: only live arms are kept, winners by creation number, families by records), same hit table and
+// per-arm code as K6 (extend_fast_dev.hpp).  What changes is who runs what.
+//
+// A wave issues at most one instruction every four cycles, so the time of a hit-probe is the length of the longest
+// instruction stream any one wave runs for it.  In K6 every wave that holds arms runs everything: the bookkeeping of
+// the probe loop, the ranking of the empty slots and of the unmatched hits, then its arms -- ~1 250 instructions per
+// probe on the busy waves of a tandem-array segment, of which the arms themselves are a tenth.  Here
+//
+//   * the ARM waves (all but the last two) do nothing but their arms: per step they read a command block, pull the
+//     arms they were assigned a step earlier, resolve the previous probe for their arms (winners -> ExtendArm / age /
+//     retire), offer to the current probe's hits, and publish their free-slot counts;
+//   * the RANKING wave holds no arms: it decides flushes and overflow, ranks the unmatched hits of the previous probe
+//     into a compact list, ranks the empty slots from the counts the arm waves published, and makes the FIRST offers
+//     of the new arms itself -- a newborn arm's window is a function of its hit alone (x + 1, threshold(k) + k - 1)
+//     and its creation number is the rank just computed -- leaving the candidates it found beside the hit.  (With the
+//     new arms' offers made by the arm waves -- the predecessor of this kernel, "K7", removed in round 6 -- a step
+//     needed a second barrier: the arm waves had to wait for the ranking before they could create the arms.)
+//   * the PLANNING wave walks the probe sequence (batches, quiet runs, generation numbers, segment end) two steps ahead
+//     and writes the commands;
+//   * the top arm waves (which hold no arms while a segment is small) index the hits of the next probe.
 //
 //     arm waves   pull the arms born of t-2 (ranked during step s-1) -> resolve t-1 -> offers to t -> free counts
-//     control     flush decision of t-1, unmatched hits of t-1 -> list, their offers to t, slot ranks; plan step s+2
+//     ranking     flush decision of t-1, unmatched hits of t-1 -> list, their offers to t, slot ranks
+//     planning    the command of step s+2
 //     top waves   index the hits of t+1 (from HBM when t+1 opens a batch: its rows reach LDS during this step)
 //     -- barrier --
 //
-// Slots: the control wave assigns the r-th new arm to the r-th empty slot in (layer, wave, lane) order from the counts
+// Slots: the ranking wave assigns the r-th new arm to the r-th empty slot in (layer, wave, lane) order from the counts
 // the arm waves published at the end of the step before; the pull that is still pending when it does so (assigned a step
-// earlier) is subtracted -- the control wave knows how many slots of each (wave, layer) it gave away -- so no slot is
+// earlier) is subtracted -- the ranking wave knows how many slots of each (wave, layer) it gave away -- so no slot is
 // given twice, and a wave pulls at most the number it was given, into whatever lanes are empty by then.
 // Hit rows: three buffers (a batch is staged while the two before it may still be read).  Generation wrap: a step that
 // only resolves (and clears the tables), a step that only indexes, then the probe.
-// Creation numbers, record keys and every transition are K7's: results are identical (the tier tests force every
+// Creation numbers, record keys and every transition are K6's: results are identical (the tier tests force every
 // segment through this kernel as well).
 #pragma once
 
-#include "extend_k7_dev.hpp"
+#include "extend_fast_dev.hpp"
 
 namespace asgart {
+
+// Diagnostic build (-DASGART_PROFILE_EXTEND): where the waves of a step spend their time -- per wave class (control,
+// arm wave 0, last arm wave) the cycles from the start of a step to barrier 1, waiting there, from barrier 1 to
+// barrier 2, waiting there; summed into ctr[40..55] (printed by the host's profile dump).
+#ifdef ASGART_PROFILE_EXTEND
+#define K7T_DECL unsigned long long k7t[4] = {0, 0, 0, 0}, k7t0 = 0, k7n = 0
+#define K7T_MARK() k7t0 = __builtin_amdgcn_s_memtime()
+#define K7T_LAP(j)                                                   \
+    do {                                                             \
+        const unsigned long long k7now = __builtin_amdgcn_s_memtime(); \
+        k7t[j] += k7now - k7t0;                                      \
+        k7t0 = k7now;                                                \
+    } while (0)
+#define K7T_STEP() ++k7n
+#define K7C(slot, v) do { if (wave == 0u && lane == 0) atomicAdd(&P.ctr[slot], (unsigned long long)(v)); } while (0)
+#define K7U_DECL unsigned long long k7u[8] = {0, 0, 0, 0, 0, 0, 0, 0}, k7u0 = 0
+#define K7U_MARK() k7u0 = __builtin_amdgcn_s_memtime()
+#define K7U_LAP(j)                                                   \
+    do {                                                             \
+        const unsigned long long k7now = __builtin_amdgcn_s_memtime(); \
+        k7u[j] += k7now - k7u0;                                      \
+        k7u0 = k7now;                                                \
+    } while (0)
+#define K7U_FLUSH()                                                                       \
+    do {                                                                                  \
+        if (lane == 0)                                                                    \
+            for (int k7j = 0; k7j < 8; ++k7j) atomicAdd(&P.ctr[57 + k7j], k7u[k7j]);       \
+        for (int k7j = 0; k7j < 8; ++k7j) k7u[k7j] = 0;                                   \
+    } while (0)
+#define K7T_FLUSH(cls)                                                                      \
+    do {                                                                                    \
+        if (lane == 0)                                                                      \
+            for (int k7j = 0; k7j < 4; ++k7j) atomicAdd(&P.ctr[40 + 4 * (cls) + k7j], k7t[k7j]); \
+        if (lane == 0 && (cls) == 0) atomicAdd(&P.ctr[52], k7n);                            \
+        k7t[0] = k7t[1] = k7t[2] = k7t[3] = 0;                                              \
+        k7n = 0;                                                                            \
+    } while (0)
+#else
+#define K7T_DECL
+#define K7T_MARK()
+#define K7T_LAP(j)
+#define K7T_STEP()
+#define K7C(slot, v)
+#define K7U_DECL
+#define K7U_MARK()
+#define K7U_LAP(j)
+#define K7U_FLUSH()
+#define K7T_FLUSH(cls)
+#endif
+
+// A taken branch costs a lone wave ~40 cycles (tools/ubench_branch.hip) and a step of an arm wave holds dozens of
+// conditions that almost never hold (a cooperative arm, a record to write, a third table row, a stash, a late probe):
+// the rare side of each is marked, so that the compiler lays the common path out as fall-through.
+#define K7_RARE(x) __builtin_expect(!!(x), 0)
+#define K7_USUAL(x) __builtin_expect(!!(x), 1)
+
+// command flags (control wave -> everyone, one block per step)
+constexpr uint32_t K7_PREV = 1u;    // a previous probe is to be resolved (and its new arms created)
+constexpr uint32_t K7_CUR = 2u;     // a current probe receives offers
+constexpr uint32_t K7_LATE = 4u;    // the current probe's hits are indexed in interval A, all offers made in interval B
+constexpr uint32_t K7_LAST = 8u;    // the step loop ends behind this step
+constexpr uint32_t K7_GIVEUP = 16u; // not for this kernel (a probe with more hits than the staging area): leave at once
+// mid-step flags (decided in interval A, acted upon in interval B)
+constexpr uint32_t K7_OVF = 1u;     // more arms than slots: the segment is given up
+constexpr uint32_t K7_STAGE = 2u;   // stage a batch of hit rows
+constexpr uint32_t K7_CLEAR = 4u;   // clear both hit tables (generation wrap)
+
 
 constexpr uint32_t K8_CLEARNOW = 32u;  // command flag: every thread clears the hit tables at the top of this step
 // pull block flags
@@ -63,7 +146,7 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
     static_assert(!RANGE || (sizeof(PosT) == 4 && S * NWA * 64 <= (int)kRunDumpCap), "runs over ranges: 32-bit positions, dump capacity");
     static_assert(NW >= 4 && HB <= 1024 && S <= 8 && NE <= 128 && (kRows & (kRows - 1)) == 0 && kE == 2 && kRows <= 2048 && CAP < 65536,
                   "shape");
-    if (NT >= 1024 && P.hi_prio) __builtin_amdgcn_s_setprio(3);
+    if (NT >= 1024) __builtin_amdgcn_s_setprio(3);
 
     __shared__ __attribute__((aligned(16))) unsigned long long s_tab[2][kRows * kE];
     __shared__ PosT s_hits[3 * HB];
@@ -135,7 +218,7 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
     char *const tab0 = reinterpret_cast<char *>(&s_tab[0][0]);
     char *const best0 = reinterpret_cast<char *>(&s_best[0][0]);
 
-    for (uint32_t n_fetch = 0; !P.max_items || n_fetch < P.max_items; ++n_fetch) {
+    for (;;) {
         if (tid == 0) s_bcast = atomicAdd(P.cursor, 1ull);
         if (tid < 4) s_nstash[tid] = 0u;
         if (tid < 16) (&s_pull[0][0])[tid] = 0u;
@@ -426,7 +509,7 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
                         xb[j] = s_hits[pv_off + (j < nc ? hj : 0u)];
                     }
                 };
-                if (NT >= 1024 && P.hi_prio) {
+                if (NT >= 1024) {
                     if (livemask) __builtin_amdgcn_s_setprio(3);
                     else __builtin_amdgcn_s_setprio(0);
                 }
@@ -989,8 +1072,7 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
             const uint32_t thr0 = arm_threshold(k, G);
             uint32_t bsh = 3;
             while ((1ull << bsh) < (unsigned long long)G + k) ++bsh;
-            bsh += P.fast_bsh;
-            const uint32_t kGenBits = min(kGenMax, max(2u, P.gen_bits));
+                    const uint32_t kGenBits = min(kGenMax, max(2u, P.gen_bits));
             const uint32_t g0 = RANGE ? run.g_seg0 : P.seg_list[seg];
             if (lane == 0) {
             heartbeat(P, g0, 0u);

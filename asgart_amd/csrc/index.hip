@@ -45,14 +45,10 @@ const OptDesc kOptions[] = {
     {"shard_lookahead", &Options::shard_lookahead, 0, 1ll << 31},
     {"force_tier", &Options::force_tier, 0, 7},
     {"arms_kernel", &Options::arms_kernel, 0, 1},
-    {"prio3", &Options::prio3, 0, 1},
     {"long3", &Options::long3, 0, 1ll << 31},
-    {"long3_big", &Options::long3_big, -1, 1ll << 31},
     {"cap1", &Options::cap1, 1, 256},
-    {"filter", &Options::filter, 0, 1},
     {"debug", &Options::debug, 0, 1},
     {"test_cap_limit", &Options::test_cap_limit, -1, 1ll << 31},
-    {"test_levels", &Options::test_levels, 0, 15},
     {"test_genbits", &Options::test_genbits, 2, 22},
     {"test_k8_delay", &Options::test_k8_delay, 0, 1 << 22},
     {"tier_order", &Options::tier_order, 1, 7777777},
@@ -60,49 +56,29 @@ const OptDesc kOptions[] = {
     {"force_wide", &Options::force_wide, 0, 1},
     {"test_wide_batch", &Options::test_wide_batch, 0, 1ll << 40},
     {"kfilter_bits", &Options::kfilter_bits, 0, 34},
-    {"k7", &Options::k7, 0, 127},
     {"lazy_aux", &Options::lazy_aux, 0, 1},
     {"fuse_passes", &Options::fuse_passes, 0, 2},
     {"fuse_pole_pct", &Options::fuse_pole_pct, 1, 1000},
-    {"bucket", &Options::bucket, 0, 1},
     {"barren", &Options::barren, 0, 2},
     {"dense3", &Options::dense3, 0, 1 << 20},
     {"dense6", &Options::dense6, 0, 1 << 20},
-    {"dense_min", &Options::dense_min, 0, 1 << 30},
-    {"k8", &Options::k8, 0, 1},
-    {"pass_gate", &Options::pass_gate, 0, 2},
-    {"pass_gate_ms", &Options::pass_gate_ms, 0, 100000},
-    {"sparse_to6", &Options::sparse_to6, 0, 512},
     {"prewarm", &Options::prewarm, 0, 1},
     {"cache_calls", &Options::cache_calls, 0, 1000000},
     {"split", &Options::split, 0, 1},
     {"split_len", &Options::split_len, 0, 1 << 20},
     {"split_runs", &Options::split_runs, 1, 3072},
-    {"split_hw", &Options::split_hw, 0, 1 << 20},
-    {"split_tier", &Options::split_tier, 2, 6},
-    {"split_dense", &Options::split_dense, 0, 1 << 20},
     {"split_warm", &Options::split_warm, 0, 1 << 20},
     {"split_min", &Options::split_min, 0, 1ll << 31},
     {"watchdog_s", &Options::watchdog_s, 0, 86400},
     {"test_stall_s", &Options::test_stall_s, 0, 60},
-    {"tier_streams", &Options::tier_streams, 1111111, 7777777},
     {"cap6_pct", &Options::cap6_pct, 100, 200},
-    {"early_cascade", &Options::early_cascade, 0, 1},
-    {"progress_at", &Options::progress_at, 0, 2},
     {"rank_lists", &Options::rank_lists, 0, 1},
-    {"rank_runs", &Options::rank_runs, 0, 1},
-    {"wg_items", &Options::wg_items, 0, 1 << 30},
-    {"wg_items12", &Options::wg_items12, 0, 1 << 30},
-    {"fast", &Options::fast, 0, 255},
     {"cap3_pct", &Options::cap3_pct, 100, 400},
     {"cap45_pct", &Options::cap45_pct, 100, 800},
     {"test_fail_alloc", &Options::test_fail_alloc, -1, 1000000000},
-    {"fast6w", &Options::fast6w, 0, 1},
     {"cap6w_pct", &Options::cap6w_pct, 100, 400},
     {"solo", &Options::solo, 0, 48},
-    {"shard_lpt", &Options::shard_lpt, 0, 1},
     {"posbits", &Options::posbits, 0, 1},
-    {"fast_bsh", &Options::fast_bsh, 0, 3},
 };
 }  // namespace
 
@@ -647,8 +623,7 @@ int32_t text_is_dna(const uint8_t *d_text, int64_t n, hipStream_t s, bool *dna) 
 static int32_t build_sap_locked(asgart_index *idx, uint64_t k) {
     idx->sap_tried = true;
     const uint64_t n_sa = (uint64_t)idx->n_sa;
-    const bool runs = idx->opt.rank_runs != 0;
-    if (!(idx->opt.rank_lists && (runs || !idx->wide) && !idx->trimmed && k <= (uint64_t)kMaxKey && n_sa > 0) || idx->d_sap) return 0;
+    if (!(idx->opt.rank_lists && !idx->trimmed && k <= (uint64_t)kMaxKey && n_sa > 0) || idx->d_sap) return 0;
     const size_t slot = idx->wide ? 8 : 4;
     if (dev_malloc(&idx->d_sap, (n_sa + 16) * slot) != hipSuccess) {
         (void)hipGetLastError();
@@ -658,9 +633,8 @@ static int32_t build_sap_locked(asgart_index *idx, uint64_t k) {
     hipStream_t s = idx->ctx[0].stream;
     // (kRankMin of pipeline_dev.hpp: rank_count_kernel only consults the list of an interval of more than 256 entries)
     const int32_t rc_rank =
-        !runs ? build_rank_lists(idx->d_keys, (const uint32_t *)idx->d_sa, n_sa, (uint32_t *)idx->d_sap, s)
-              : (idx->wide ? build_rank_lists_runs<uint64_t>(idx->d_keys, (const uint64_t *)idx->d_sa, n_sa, (uint64_t *)idx->d_sap, 256u, (int)k, s)
-                           : build_rank_lists_runs<uint32_t>(idx->d_keys, (const uint32_t *)idx->d_sa, n_sa, (uint32_t *)idx->d_sap, 256u, (int)k, s));
+        idx->wide ? build_rank_lists_runs<uint64_t>(idx->d_keys, (const uint64_t *)idx->d_sa, n_sa, (uint64_t *)idx->d_sap, 256u, (int)k, s)
+                  : build_rank_lists_runs<uint32_t>(idx->d_keys, (const uint32_t *)idx->d_sa, n_sa, (uint32_t *)idx->d_sap, 256u, (int)k, s);
     if (rc_rank != 0) {
         dev_free(idx->d_sap);
         idx->d_sap = nullptr;

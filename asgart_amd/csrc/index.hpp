@@ -82,11 +82,6 @@ struct RunParams {
     const uint64_t *pbits[4];  // ... its answers laid out by TEXT POSITION (bit p: the probe that covers text[p .. p + k) in
                                // this orientation passes the filter); null: the kernels test the hashed filter
     int flt_bits;
-    uint32_t split_tier_lo;  // option split_tier: lowest tier whose segments may be cut into ranges
-    uint32_t split_dense;    // option split_dense: ... and only those with at least this many hits per probe position
-    uint32_t split_hw;       // option split_hw: a segment's size is positions + hits / split_hw (0: positions)
-    uint32_t bucket_lookup;  // option bucket: 1 = small prefix-table buckets are looked up with keys and suffix-array entries
-                             // requested together (probe_count_kernel)
     __host__ __device__ inline uint32_t pass_of(int c) const {
         if (n_passes <= 1u) return 0u;
         const uint32_t uc = (uint32_t)c;
@@ -120,7 +115,6 @@ struct Workspace {
     DevBuf counters;   // u64[32] device counters
     DevBuf fam_sds;    // SdRec[cap] output records of the extension kernel
     DevBuf ovf_list;   // u32 segments that overflowed the small arm tier
-    DevBuf own_list;   // u32 sharded call with cost-aware ownership: this shard's segments, tier by tier
     DevBuf scratch;    // arm storage of the global heavy tier
     DevBuf hit_flag;   // u8 per CSR entry: continuation flag (pre-pass)
     DevBuf seg_keys, seg_vals, sort_tmp;  // segment placement: (tier, work) keys, double-buffered
@@ -134,7 +128,7 @@ struct Workspace {
     // every buffer goes back to the device (or to the block cache): ONE list, next to the members
     void release_all() {
         DevBuf *bufs[] = {&chunks, &p_lo, &p_raw, &p_filt, &row_off, &blk, &hits, &big_list, &rank_list, &seg_list,
-                          &counters, &fam_sds, &ovf_list, &own_list, &scratch, &hit_flag, &seg_keys, &seg_vals,
+                          &counters, &fam_sds, &ovf_list, &scratch, &hit_flag, &seg_keys, &seg_vals,
                           &sort_tmp, &rec_k32, &rec_k64, &rec_idx, &rec_sorted, &pat, &out_a, &out_b, &seg_info, &seg_slots, &split_buf, &split_dump};
         static_assert(sizeof(Workspace) == sizeof(bufs) / sizeof(bufs[0]) * sizeof(DevBuf),
                       "a buffer of the workspace is missing from release_all");
@@ -148,16 +142,6 @@ namespace asgart {
 // Everything one search call mutates.  The index owns two of them so that two passes (say the
 // direct and the -RC run, reference src/bin/asgart.rs runs them as separate invocations) can be
 // in flight at once from two host threads; text, suffix array and keys are shared read-only.
-// Two passes issued by one passes call (pipeline.hip): the first one holds back every extension tier but the one with
-// its longest segments until the second one's search phases are through -- persistent extension workgroups own their
-// compute units until their work list is empty, and a search kernel dispatched behind them crawls (measured at GRCh38
-// size: 117 ms instead of 28 for the second pass's front, which then sets the critical path of the step).
-struct PassGate {
-    std::atomic<int> *front_done = nullptr;       // set when this call's probes are searched and its segments placed
-    std::atomic<int> *next_front_done = nullptr;  // the same of the pass issued behind this one (null: hold nothing back)
-    std::atomic<int> *next_finished = nullptr;    // ... or that pass is over (it may have failed before its front)
-};
-
 struct SearchCtx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr, stream3 = nullptr, stream4 = nullptr;  // concurrent extension tiers
@@ -170,7 +154,6 @@ struct SearchCtx {
     uint32_t last_P = 0;
     bool busy = false;
     volatile uint64_t *progress = nullptr;  // of the call in flight (asgart_search_duplications), or null
-    struct PassGate *gate = nullptr;  // passes call: what this call signals to / waits for from the pass issued behind it
     // pinned host staging for the sorted output records (a pageable target makes the D2H copy several
     // times slower than the kernels that produce it); grow-only, freed with the index
     void *h_pinned = nullptr;
@@ -253,18 +236,14 @@ struct Options {
     int64_t shard_lookahead = 0;    // 0: max(65536, own range / 16)
     int64_t force_tier = 0;         // tests: minimum extension tier of segments with a multi-hit probe
     int64_t arms_kernel = 1;        // 0: LDS-array kernels in tiers 2, 4, 6 (what max_cardinality > 1024 selects)
-    int64_t prio3 = 1;              // 1: tier 3's waves run at raised issue priority (s_setprio)
     int64_t long3 = 16384;          // probes; longer segments go to the long-segment tiers (3: dense, 6: sparse) whatever their arm
                                     // bound.  Round 5 (the passes of a step as one job: the extension is bound by the compute-unit
                                     // time the tiers hold, not by a serial chain): 4096 -> 16384, 250 -> 236 ms per step at GRCh38
                                     // size -- a long SPARSE segment in tier 6 owns a whole compute unit for one wave's work
-    int64_t long3_big = -1;         // -1: long3 / 4
     int64_t cap1 = 256;             // live-arm bound up to which a segment may use the one-wave tier
-    int64_t filter = 0;             // 1: continuation filter pre-pass
     int64_t debug = 0;              // 1: per-call tier statistics on stderr
     int64_t test_cap_limit = -1;    // tests: shrink every tier's capacity (forces the cascade)
-    int64_t test_levels = 4;        // tests: usable hit-table levels of the arm-resident kernel
-    int64_t test_genbits = 22;      // tests: width of its generation counter
+    int64_t test_genbits = 22;      // tests: width of the arm-resident kernels' table generation counter
     int64_t test_k8_delay = 0;      // tests: cycles K8's ranking wave waits in every step before it reads the free counts the arm
                                     // waves published (results must not depend on it: the counts are double-buffered by step parity)
     int64_t tier_order = 3654217;   // launch order of the extension tiers, as decimal digits
@@ -273,51 +252,21 @@ struct Options {
     int64_t force_wide = 0;         // tests: 64-bit slots and positions for a small text
     int64_t test_wide_batch = 0;    // tests: batch size of the 64-bit suffix sorter's doubling rounds (0: 2^29)
     int64_t kfilter_bits = 30;      // log2(bits) of the k-mer presence filter (search_dev.hpp); 0: no filter
-    int64_t wg_items = 0;           // segments a workgroup of tiers 3..7 runs before it retires (0: persistent)
-    int64_t wg_items12 = 0;         // ... work-list fetches (8 segments / 1 segment) of a tier-1 / tier-2 wave
     int64_t rank_lists = 1;         // 1: position-sorted occurrence lists for the cardinality test (k <= 21, no --trim)
-    int64_t pass_gate = 0;          // passes call: 1 = the first pass launches its long-segment tier (3) at once and the other tiers when the
-                                    // second pass's search phases are done (or pass_gate_ms later); 0 = all tiers at once.  Measured at
-                                    // GRCh38 size and left off: the second pass's front drops from 117 to 31 ms, but both passes' tiers then
-                                    // start together and the second pass's longest segments queue behind the first one's workgroups (step
-                                    // 247 -> 270 ms)
-    int64_t pass_gate_ms = 120;
-    int64_t rank_runs = 1;          // how they are built: 1 = only the runs of more than 256 equal keys, by a segmented sort in place
-                                    // (any slot width); 0 = all slots by two device-wide pair sorts (32-bit slots only: without it an
-                                    // index of 64-bit slots has no lists)
-    int64_t progress_at = 2;        // when a call reports its probes as searched (pipeline.hip: progress)
-    int64_t early_cascade = 1;      // 1: tier 6's overflow is re-run as soon as tier 6 is done, not after the last tier
     int64_t cap6_pct = 140;         // tier 6 accepts segments whose arm bound is up to this percentage of its capacity
-    int64_t fast = 124;             // bit t set (t = 2..6): tier t runs the one-barrier arm kernel (extend_fast_dev.hpp) instead of K4c
-    int64_t fast_bsh = 0;           // its bucket width: 2^fast_bsh times the smallest power of two >= max_gap_size + k
     int64_t test_fail_alloc = -1;   // tests: the (n+1)-th device allocation from now on fails once (common.hpp); -1 = off
     int64_t solo = 1;               // one-barrier kernel: sparse probes run on wave 0 alone, in registers (see solo_probe): 0 never, 1 = probes of up to 16 hits, n = up to n (<= 48) hits; 8 .. 44 measured alike at cfg4 and cfg5
-    int64_t fast6w = 1;             // 64-bit positions: tier 6 on the one-barrier kernel (4 x 1024 slots) instead of K4c 8 x 512
-    int64_t cap6w_pct = 160;        // ... which then accepts segments whose arm bound is up to this percentage of its capacity
+    int64_t cap6w_pct = 160;        // ... with 64-bit positions (the bound is three to four times what a segment really holds there)
     int64_t cap45_pct = 100;        // tiers 4 and 5 accept segments whose arm bound is up to this percentage of their capacity (what overflows is re-run)
-    int64_t cap3_pct = 160;         // tier 3 with the one-barrier kernel accepts segments whose arm bound is up to this percentage of its capacity
+    int64_t cap3_pct = 160;         // tier 3 accepts segments whose arm bound is up to this percentage of its capacity
     int64_t posbits = 1;            // 1: the presence filter's answers are also laid out by text position (index build) and the search reads those
-    int64_t shard_lpt = 0;          // sharded calls: 0 = contiguous probe slices with halos; 1 = every shard computes the whole front and
-                                    // owns every n_shards-th segment of each tier's cost-sorted list (snake order) -- measured at
-                                    // cfg4, 8 shards: balanced (91-117 ms direct) but the replicated front makes its slowest shard
-                                    // slower than the slice mode's (211 vs 184 ms -RC, 117 vs 90 ms direct): the floor is the longest segment
-    int64_t tier_streams = 7234562; // digit t (from the left): the stream (1..7, 1 = the call's high-priority main stream) tier t runs on
-    int64_t k7 = 8;                 // bit t set (t = 3..6): tier t runs the arm kernel with a control wave (extend_k7_dev.hpp) instead of K6 / K4c. Default: tier 3 only -- the long DENSE segments (option dense3), where its shorter per-probe chain counts; measured in the other tiers (k7 = 120) it loses: a quarter / an eighth of a 256- / 512-thread workgroup holds no arms and a sparse probe costs two barriers instead of one wave's solo run
-    int64_t k8 = 1;                 // 1: the tiers of option k7 run the one-barrier variant (extend_k8_dev.hpp: the new arms' first offers are
-                                    // made by a ranking wave, a planning wave writes the commands; 14 arm waves instead of 15); 0: K7
     int64_t barren = 2;             // segments that provably emit nothing are not run at all: 1 = those with too few hit-probes for any arm to
                                     // reach min_duplication_length (pipeline_dev.hpp: segment_is_barren); 2 = also those whose hits leave
                                     // no run of consecutive occupied position buckets long enough (cluster_barren_kernel: the bursts of
                                     // interspersed repeats); 0 = every segment runs
-    int64_t bucket = 0;             // probe search: 1 = the keys AND the suffix-array entries of a small prefix-table bucket (<= 8 slots) are
-                                    // requested together and the equal range / kept count come out of registers (one dependent HBM round
-                                    // trip fewer per lookup); 0 = bisection over the keys, then the entries of the equal range.
-                                    // Measured at GRCh38 size (round 5) and left off: 29.4 instead of 26.7 ms for the two passes of a
-                                    // step -- the kernel is bound by the SECTOR RATE of its gathers (0.7 of the measured ceiling), not by
-                                    // the length of its chain: the entries of the keys that turn out unequal are sectors it did not need
     int64_t fuse_passes = 1;        // asgart_search_duplications_passes, passes that differ in orientation only: 2 = always as ONE job (one
                                     // front over all their probes, one launch per extension tier over the merged segment list); 0 = always
-                                    // as pipelined single-pass calls on the two call contexts (what sharded calls do); 1 = the first call
+                                    // as pipelined single-pass calls on the two call contexts; 1 = the first call
                                     // with given settings runs as one job, and what it measures decides for the calls after it: one job
                                     // while the extension is bound by compute-unit time (the longest single segment below fuse_pole_pct
                                     // per cent of the extension: GRCh38-shaped 230 vs 255 ms), pipelined calls when ONE segment is the
@@ -329,14 +278,10 @@ struct Options {
                                     // at GRCh38 size and save 0.03 / 0.006 s per pass -- a host that runs every orientation once per index
                                     // (the reference's own use, src/bin/asgart.rs:677-693) never pays for them; 0: filters on first use,
                                     // lists with the keys
-    int64_t sparse_to6 = 1;         // with dense3: where the long segments that are NOT dense go: 1 = tier 6 (1024 threads, the kernel tier 3 used
-                                    // to run), 0 = by their arm bound like any other segment (smaller shapes: several per compute unit)
-    int64_t dense3 = 16;            // with k7 in tier 3: long segments go there only with at least this many hits per processed probe on
-                                    // average (0: all of them); the sparse long ones run on tier 6's kernel
-    int64_t dense_min = 0;          // with k7 in tier 3: dense segments (dense3) of at least this many probes go to tier 3 whatever their arm
-                                    // bound says (0: only the long ones, option long3)
-    int64_t dense6 = 32;            // with k7 in tier 3: segments of ANY length whose arm bound sends them to tier 6 go to tier 3 instead with at
-                                    // least this many hits per processed probe on average (0: off)
+    int64_t dense3 = 16;            // long segments go to tier 3 (K8) only with at least this many hits per processed probe on average
+                                    // (0: all of them); the sparse long ones run on tier 6's kernel (K6, solo probes)
+    int64_t dense6 = 32;            // segments of ANY length whose arm bound sends them to tier 6 go to tier 3 instead with at least this
+                                    // many hits per processed probe on average (0: off)
     int64_t split = 1;              // 1: the long segments of the long-shape tiers run as RANGES side by side (plan_ranges_kernel,
                                     // pipeline_dev.hpp): every range starts from an empty arm list split_warm probes in front of its cut,
                                     // and what it holds AT the cut is compared with what the range before holds there; a segment with a cut
@@ -346,11 +291,6 @@ struct Options {
     int64_t split_len = 0;          // probes per range (about: the ranges of a segment are of one length); 0: the smallest of 2048 ... 32768
                                     // for which the call's runs stay within split_runs (split_tally_kernel), warm-up as long (2048 .. 6144),
                                     // shortest segment cut twice it -- a small job gets short ranges, a genome-sized one long ones
-    int64_t split_tier = 3;         // lowest tier whose long segments are cut (2: also the one-wave tier's -- a wave on its own passes a
-                                    // sparse probe faster than the long shape's sixteen)
-    int64_t split_dense = 0;        // segments with fewer hits per probe position than this are not cut (0: any)
-    int64_t split_hw = 0;           // (split_len = 0) a segment's size for the cutting is positions + hits / split_hw, and its cuts sit at
-                                    // equal shares of that (0: positions only)
     int64_t split_runs = 224;       // ... that budget: every run holds a compute unit while it runs
     int64_t split_warm = 6144;      // (split_len > 0) probes a range starts in front of its cut
     int64_t split_min = 0;          // segments shorter than this (probe positions) are not cut (split_len = 0: at least this)
@@ -368,7 +308,6 @@ struct Options {
                                     // last heartbeats of its kernels instead of waiting forever; 0: wait forever
 };
 int32_t create_ctx_streams(SearchCtx &cx);
-int32_t build_rank_lists(const uint64_t *d_keys, const uint32_t *d_sa, uint64_t n, uint32_t *d_sap, hipStream_t s);
 template <class SlotT>
 int32_t build_rank_lists_runs(const uint64_t *d_keys, const SlotT *d_sa, uint64_t n, SlotT *d_sap, uint32_t min_run, int k,
                               hipStream_t s);  // (sa_build.hip: only the runs of more than min_run equal keys; any slot width)  // the streams and events of one call context (current device)

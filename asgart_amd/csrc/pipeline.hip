@@ -6,7 +6,6 @@
 // left fix-up, fold in chunk order).
 #include "pipeline_dev.hpp"
 #include "extend_fast_dev.hpp"
-#include "extend_k7_dev.hpp"
 #include "extend_k8_dev.hpp"
 
 #include <algorithm>
@@ -64,30 +63,20 @@ namespace asgart {
 
 // default launch order / grid sizes of the extension tiers (see the launch site)
 constexpr uint64_t kGrid1 = 256ull * 8ull, kGrid2 = 256ull * 3ull;
-// arms per thread of the largest arm-resident shape
-// tier 6: 9 x 512 = 4608 arm slots, cold fields in LDS; with 64-bit positions 8 x 512 = 4096, the left ends in HBM
-// (COLD = 2; with the cold fields in LDS only 6 x 512 fit).  Measured for 32-bit positions as well: 12 x 512 slots
-// with COLD = 2 need 256 VGPRs + spills and make the GRCh38-shaped step 4 % slower.
-template <class SlotT> constexpr int kArmsLayers = sizeof(SlotT) == 4 ? 9 : 8;
-template <class SlotT> constexpr int kArmsCold = sizeof(SlotT) == 4 ? 1 : 2;
-// its one-wave shape: 8 x 64 = 512 live arms per wave, probes with up to 512 hits
+// Arm slots of the arm-resident shapes (S arms per thread x NT threads; 64-bit positions hold fewer).
+// tier 2, the one-wave shape: 8 x 64 = 512 live arms per wave, probes with up to 512 hits
 template <class SlotT> constexpr int kWaveArmsLayers = sizeof(SlotT) == 4 ? 8 : 5;
 // tiers 4 and 5: 4 arms per thread x 256 / 512 threads, cold fields in LDS
 template <class SlotT> constexpr int kMidArmsLayers = sizeof(SlotT) == 4 ? 4 : 2;
 constexpr int kWaveArmsHits = 512;
 constexpr uint64_t kGrid2Arms = 256ull * 8ull;
-template <class SlotT> constexpr int kLongArmsLayers = sizeof(SlotT) == 4 ? 5 : 2;  // tier 3: 5 x 1024 arms
-// ... of the one-barrier kernel (option fast, extend_fast_dev.hpp): 5 x 1024 / 2 x 1024 arm slots
-template <class SlotT> constexpr int kFastLongLayers = sizeof(SlotT) == 4 ? 5 : 4;   // (64-bit positions: 4 x 1024, a smaller table)
-template <class SlotT> constexpr int kFastHeavyLayers = sizeof(SlotT) == 4 ? 5 : 4;  // tier 6
+// tier 6 on the one-barrier kernel (extend_fast_dev.hpp): 5 x 1024 arm slots (64-bit positions: 4 x 1024, a smaller table)
+template <class SlotT> constexpr int kFastHeavyLayers = sizeof(SlotT) == 4 ? 5 : 4;
 template <class SlotT> constexpr int kFastLongRows = sizeof(SlotT) == 4 ? 2048 : 1024;
-// ... of the kernel with a control wave (option k7, extend_k7_dev.hpp): the last wave holds no arms, so a shape of NT
-// threads has S x (NT - 64) slots: tiers 3 and 6 = 5 x 960 (64-bit positions: 4 x 960), tier 4 = 6 x 192 (3 x 192),
-// tier 5 = 5 x 448 (3 x 448)
-template <class SlotT> constexpr int kK7LongLayers = sizeof(SlotT) == 4 ? 5 : 4;
-template <class SlotT> constexpr int kK7Mid4Layers = sizeof(SlotT) == 4 ? 6 : 3;
-template <class SlotT> constexpr int kK7Mid5Layers = sizeof(SlotT) == 4 ? 5 : 3;
-constexpr int kPoleLdsPad = 0;             // > 0: tier 3 workgroups take a whole CU (measured: no gain)
+// tier 3 and the runs over ranges on the kernel with specialised waves (extend_k8_dev.hpp): two of the sixteen waves hold
+// no arms, so the shape has S x 896 slots: 5 x 896 (64-bit positions: 4 x 896)
+template <class SlotT> constexpr int kK8LongLayers = sizeof(SlotT) == 4 ? 5 : 4;
+constexpr uint32_t kK8LongSlots = 896;
 constexpr int kArmCapSmall = 256;   // live arms per wave in LDS, common case
 constexpr uint32_t kTier1MaxSum = 20000;  // placement: busier segments never run on a single wave
 constexpr int kArmCapMid = 768;     // second tier: block-cooperative kernel, 256 threads per segment
@@ -325,16 +314,9 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
     // global probe sequence.  It computes probe-search over that slice plus a look-back halo
     // (to decide whether its first probes continue an earlier segment) and a look-ahead halo
     // (to finish segments that run past the slice); no data is exchanged between shards.
-    // That is the default (option shard_lpt = 0).  With shard_lpt = 1 the shards do not cut the probe sequence at
-    // all: every shard computes the whole front -- probe search, scans, hit rows, placement: a tenth of a step --
-    // and then owns every n_shards-th segment of each tier's cost-sorted list (take_owned_kernel): the long serial
-    // segments, which sit next to each other in the genome, land on different GPUs.  Still no exchange; the
-    // gatherer then MUST merge the shards' families by their keys (asgart_families_keys): they interleave.
     const Options opt = idx->opt;  // options cannot change while this call holds a context
-    const bool lpt = n_shards > 1 && opt.shard_lpt != 0;
-    const int32_t f_shard = lpt ? 0 : shard, f_n = lpt ? 1 : n_shards;
-    const uint32_t own_lo = (uint32_t)((uint64_t)P * (uint64_t)f_shard / (uint64_t)f_n);
-    const uint32_t own_hi = (uint32_t)((uint64_t)P * (uint64_t)(f_shard + 1) / (uint64_t)f_n);
+    const uint32_t own_lo = (uint32_t)((uint64_t)P * (uint64_t)shard / (uint64_t)n_shards);
+    const uint32_t own_hi = (uint32_t)((uint64_t)P * (uint64_t)(shard + 1) / (uint64_t)n_shards);
     if (own_lo == own_hi) return 0;
     uint64_t look_back = (uint64_t)opt.shard_lookback;
     uint64_t look_ahead = opt.shard_lookahead > 0 ? (uint64_t)opt.shard_lookahead
@@ -382,12 +364,8 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
     rp.C = st->max_cardinality > 0xFFFFFF00ull ? 0xFFFFFF00u : (uint32_t)st->max_cardinality;
     rp.n_passes = (uint32_t)n_passes;
     rp.pass_chunks = (uint32_t)n_chunks_pass;
-    rp.split_tier_lo = (uint32_t)idx->opt.split_tier;
-    rp.split_dense = (uint32_t)idx->opt.split_dense;
-    rp.split_hw = (uint32_t)idx->opt.split_hw;
     rp.modes = 0;
     rp.flt_bits = idx->filter_bits;
-    rp.bucket_lookup = opt.bucket ? 1u : 0u;
     for (int p = 0; p < 4; ++p) {
         rp.flt[p] = rp.pbits[p] = nullptr;
         if (p >= n_passes) continue;
@@ -447,7 +425,6 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
     RC_TRY(wd_sync(idx, cx, s, "the probe search and the scans"));
     total_hits = h_ctr[CT_TOTAL_HITS];
     n_seg = h_ctr[CT_SEG];
-    if (cx.progress && opt.progress_at < 2 && !progress_given && !h_ctr[CT_AMBIG]) signal_progress();
     if (h_ctr[CT_AMBIG]) {  // a start decision needs more history: widen the look-back halo
         look_back *= 8;
         continue;
@@ -498,61 +475,46 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
         uint32_t *kbuf = w.seg_keys.as<uint32_t>(), *vbuf = w.seg_vals.as<uint32_t>();
         HIP_TRY(hipMemsetAsync(d_ctr + CT_N1, 0, (size_t)(CT_COUNT - CT_N1) * 8, s));
         // ---- the tiers ------------------------------------------------------------------------
-        //  1  one wave per segment, arms in registers / LDS arrays (K4)              <= 256 arms
-        //  2  arm-resident, one wave, 8 per CU (K4c 8x64)                            <= 512
-        //  3  arm-resident, 1024 threads: lowest per-probe latency, LONG segments    <= 5120
-        //  4  arm-resident, 256 threads, 4 workgroups per CU (K4c 4x256)             <= 1024
-        //  5  arm-resident, 512 threads, 2 per CU (K4c 4x512)                        <= 2048
-        //  6  arm-resident, 512 threads, 1 per CU (K4c 9x512)                        <= 4608 * 1.4 (by the bound)
-        //  7  arms in HBM scratch (K4b MODE 2)                                       <= 16384
-        // (64-bit positions: 5x64 / 2x1024 / 2x256 / 2x512 / 8x512 with the left ends in HBM / 8192.)
+        //  1  one wave per segment, arms in registers / LDS arrays (extend_kernel)                 <= 256 arms
+        //  2  arm-resident, one wave, 8 per CU (K6 8x64)                                           <= 512
+        //  3  arm-resident, specialised waves, 1024 threads (K8 5x896): the LONG DENSE segments    <= 4480 * 1.6 (by the bound)
+        //  4  arm-resident, 256 threads, 4 workgroups per CU (K6 4x256)                            <= 1024
+        //  5  arm-resident, 512 threads, 2 per CU (K6 4x512)                                       <= 2048
+        //  6  arm-resident, 1024 threads, 1 per CU (K6 5x1024): the long sparse segments           <= 5120 * 1.4 (by the bound)
+        //  7  arms in HBM scratch (extend_heavy_kernel MODE 2)                                     any
+        // (64-bit positions: 5x64 / 4x896 / 2x256 / 2x512 / 4x1024.)
         // Streams: the short chip-wide kernels on the call's high-priority main stream; tiers 1..6 on six
-        // low-priority streams of their own, tier 7 behind tier 2 (option tier_streams).
-        // With max_cardinality > 1024 (or ASGART_ARMS_KERNEL=0, tests) the LDS-array kernels K4b take
+        // low-priority streams of their own, tier 7 behind tier 2.
+        // With max_cardinality > 1024 (or ASGART_ARMS_KERNEL=0, tests) the LDS-array kernels (extend_heavy_kernel) take
         // tiers 2, 4 and 6 (768 / 2432 / 4608 * 1.4 arms) and tiers 3 and 5 stay empty; the small
         // shapes 2 and 4 stage 512 hits per probe and are skipped when max_cardinality > 512.
         constexpr int caph = sizeof(SlotT) == 4 ? kArmCapHybrid32 : kArmCapHybrid64;
-        const bool arms_kernel = rp.C <= (uint64_t)kHitBatch && opt.arms_kernel != 0;
+        // (the arm-resident kernels pack a position into 42 bits of a table entry)
+        const bool arms_kernel = rp.C <= (uint64_t)kHitBatch && opt.arms_kernel != 0 && (uint64_t)idx->n < (1ull << 42);
         const bool arms_small = arms_kernel && rp.C <= (uint64_t)kWaveArmsHits;
-        // the two-barrier kernel packs a 64-bit position into 42 bits of a table entry
-        auto fast_tier = [&](int t) {
-            if (t == 6 && sizeof(SlotT) == 8 && !opt.fast6w) return false;
-            return arms_kernel && ((opt.fast >> t) & 1) != 0 && (uint64_t)idx->n < (1ull << 42);
-        };
-        // the kernel with a control wave takes tiers 3..6 where option k7 says so (it needs a second wave: not tier 2)
-        auto k7_tier = [&](int t) {
-            return t >= 3 && t <= 6 && arms_kernel && ((opt.k7 >> t) & 1) != 0 && (uint64_t)idx->n < (1ull << 42);
-        };
         uint32_t tier_cap[kTiers + 1] = {0, kArmCapSmall, 0, 0, 0, 0, 0, 0xFFFFFFFFu};  // (tier 7 takes whatever is left)
         if (arms_kernel) {
             if (arms_small) {
                 tier_cap[2] = (uint32_t)kWaveArmsLayers<SlotT> * 64u;
-                tier_cap[4] = (uint32_t)((uint64_t)(k7_tier(4) ? kK7Mid4Layers<SlotT> * (opt.k8 ? 128 : 192) : kMidArmsLayers<SlotT> * 256) *
-                                         (uint64_t)opt.cap45_pct / 100u);
+                tier_cap[4] = (uint32_t)((uint64_t)(kMidArmsLayers<SlotT> * 256) * (uint64_t)opt.cap45_pct / 100u);
             }
-            tier_cap[3] = k7_tier(3) ? (uint32_t)kK7LongLayers<SlotT> * (opt.k8 ? 896u : 960u)
-                                     : (uint32_t)(fast_tier(3) ? kFastLongLayers<SlotT> : kLongArmsLayers<SlotT>) * 1024u;
-
-            tier_cap[5] = (uint32_t)((uint64_t)(k7_tier(5) ? kK7Mid5Layers<SlotT> * (opt.k8 ? 384 : 448) : kMidArmsLayers<SlotT> * 512) *
-                                     (uint64_t)opt.cap45_pct / 100u);
+            tier_cap[3] = (uint32_t)kK8LongLayers<SlotT> * kK8LongSlots;
+            tier_cap[5] = (uint32_t)((uint64_t)(kMidArmsLayers<SlotT> * 512) * (uint64_t)opt.cap45_pct / 100u);
             // the window bound is pessimistic for tandem arrays (hits extend arms there) and the HBM
             // tier is several times slower per probe: tier 6 also takes segments whose bound exceeds
             // its capacity by up to 40 % (a real overflow falls through the cascade)
             // (64-bit positions on the one-barrier kernel: the HBM tier is an order of magnitude slower per probe and the
             // bound three to four times what a segment really holds -- at cfg5 every segment that went to tier 7 by its
             // bound peaked below 4 096 arms: tier 6 accepts up to cap6w_pct of its capacity)
-            const uint64_t pct6 = ((fast_tier(6) || k7_tier(6)) && sizeof(SlotT) == 8) ? (uint64_t)opt.cap6w_pct : (uint64_t)opt.cap6_pct;
-            tier_cap[6] = (uint32_t)((uint64_t)(k7_tier(6) ? kK7LongLayers<SlotT> * (opt.k8 ? 896 : 960)
-                                                           : (fast_tier(6) ? kFastHeavyLayers<SlotT> * 1024 : kArmsLayers<SlotT> * kHeavyThreads)) *
-                                     pct6 / 100u);
+            const uint64_t pct6 = sizeof(SlotT) == 8 ? (uint64_t)opt.cap6w_pct : (uint64_t)opt.cap6_pct;
+            tier_cap[6] = (uint32_t)((uint64_t)(kFastHeavyLayers<SlotT> * 1024) * pct6 / 100u);
             // tier 3 accepts what tier 6 would accept by the bound (a long segment is no less safe there), but
             // never more than the same allowance over its own capacity (with 64-bit positions it holds fewer
             // arms than tier 6, and what it gives up on is re-run from the start)
             // (the bound of a tandem array is three to four times what it really holds: the one-barrier kernel, a fifth
             // faster per probe on such segments, takes them up to cap3_pct of its capacity)
-            const uint64_t pct3 = (fast_tier(3) || k7_tier(3)) ? (uint64_t)opt.cap3_pct : (uint64_t)opt.cap6_pct;
             tier_cap[3] = std::min<uint32_t>(std::max(tier_cap[3], tier_cap[6]),
-                                             (uint32_t)((uint64_t)tier_cap[3] * pct3 / 100u));
+                                             (uint32_t)((uint64_t)tier_cap[3] * (uint64_t)opt.cap3_pct / 100u));
         } else {
             tier_cap[2] = kArmCapMid;
             tier_cap[4] = sizeof(SlotT) == 4 ? kArmCapBig32 : kArmCapBig64;
@@ -560,19 +522,15 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
         }
         auto tier_enabled = [&](int t) { return t >= 1 && t <= kTiers && tier_cap[t] != 0; };
         PlaceParams pp;
-        pp.long3 = pp.long3_big = pp.dense3 = pp.dense6 = pp.dense_min = 0;
-        pp.sparse_to6 = (uint32_t)opt.sparse_to6;
+        pp.long3 = pp.long3_big = pp.dense3 = pp.dense6 = 0;
         pp.stats = opt.debug ? 1u : 0u;
         pp.barren = opt.barren ? 1u : 0u;
         pp.seg_info = nullptr;
-        // (not with the continuation filter -- option filter = 1, whose pre-pass does the placement itself)
-        const bool cluster_barren = opt.barren >= 2 && opt.filter == 0 && rp.M > (uint64_t)k;
+        const bool cluster_barren = opt.barren >= 2 && rp.M > (uint64_t)k;
         // long segments as ranges side by side (option split; plan_ranges_kernel in pipeline_dev.hpp): the long shape of the
         // one-barrier kernel, 32-bit positions; also in a sharded call (the segments its window cuts short are left alone: only
-        // a segment whose end the placement walk has seen is cut), but not with ownership lists (option shard_lpt: every shard
-        // holds every segment there)
-        const bool split_on = opt.split != 0 && sizeof(SlotT) == 4 && !lpt && k7_tier(3) && opt.k8 != 0 &&
-                              opt.filter == 0 && (opt.split_len == 0 || opt.split_len >= 64);
+        // a segment whose end the placement walk has seen is cut)
+        const bool split_on = opt.split != 0 && sizeof(SlotT) == 4 && arms_kernel && (opt.split_len == 0 || opt.split_len >= 64);
         if (cluster_barren || split_on) {
             RC_TRY(w.seg_info.reserve((size_t)n_seg * sizeof(uint2)));
             pp.seg_info = w.seg_info.as<uint2>();
@@ -599,13 +557,12 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
         for (int t = 1; t < kTiers; ++t) pp.cap[t - 1] = tier_cap[t];
         if (arms_kernel) {
             pp.long3 = (uint32_t)opt.long3;
-            pp.long3_big = opt.long3_big >= 0 ? (uint32_t)opt.long3_big : pp.long3 / 4u;
-            if (k7_tier(3) && tier_cap[6]) pp.dense3 = (uint32_t)opt.dense3;
-            if (k7_tier(3) && tier_cap[6] && !k7_tier(6)) pp.dense6 = (uint32_t)opt.dense6;
-            if (k7_tier(3) && tier_cap[6]) pp.dense_min = (uint32_t)opt.dense_min;
+            pp.long3_big = pp.long3 / 4u;
+            pp.dense3 = (uint32_t)opt.dense3;
+            pp.dense6 = (uint32_t)opt.dense6;
             if (force_tier == 3) {
                 pp.long3 = pp.long3_big = 1;
-                pp.dense3 = pp.dense6 = pp.dense_min = 0;
+                pp.dense3 = pp.dense6 = 0;
             }
             pp.cap[0] = (uint32_t)std::min<int64_t>(opt.cap1, kArmCapSmall);
         }
@@ -613,22 +570,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
         while (force_eff > 1 && force_eff < kTiers && !tier_enabled(force_eff)) ++force_eff;
         pp.sum1 = kTier1MaxSum;
         pp.force_tier = force_eff;
-        // an unextended arm has len(right) = k: it may only be dropped when that is never reported
-        // Measured on the GRCh38-shaped workload the filter removes ~85 % of the arms of dense
-        // repeat clusters but its LDS-atomic pre-pass costs more than the extension tiers gain
-        // while a few long tandem-array segments set the critical path, so it is opt-in
-        // (option filter = 1) until the pre-pass is cheaper.  Results are identical either way.
-        pp.use_filter = (k < st->min_duplication_length && rp.tstar <= 64u && rp.C <= 5000u &&
-                         opt.filter != 0) ? 1 : 0;
-        uint8_t *hit_flag = nullptr;             // without the filter: no flag array at all
-        const uint32_t *p_nflag = p_filt;        // ... and every hit may create an arm
-        if (pp.use_filter) {
-            RC_TRY(w.hit_flag.reserve((size_t)total_hits + 64));
-            hit_flag = w.hit_flag.as<uint8_t>();
-            seg_prepass_kernel<SlotT><<<(unsigned)std::min<uint64_t>(n_seg, 256ull * 9ull), 64, 0, s>>>(
-                rp, p_filt, row_off, hits, hit_flag, p_raw, seg_list, d_ctr + CT_SEG, kbuf, vbuf, pp, d_ctr);
-            p_nflag = p_raw;  // rewritten by the pre-pass: flagged hits per probe
-        } else {
+        {
             // one segment per lane for the first kLaneWalk probes, the longer ones wave by wave (their list
             // borrows the overflow lists' buffer, which the tiers only use afterwards)
             uint32_t *long_list = w.ovf_list.as<uint32_t>();
@@ -679,13 +621,13 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                                                               reinterpret_cast<unsigned long long *>(d_split),
                                                               reinterpret_cast<RangeRun *>(d_split + kOffRuns),
                                                               reinterpret_cast<uint2 *>(d_split + kOffCuts),
-                                                              reinterpret_cast<SplitSeg *>(d_split + kOffSplits), d_choice, row_off);
+                                                              reinterpret_cast<SplitSeg *>(d_split + kOffSplits), d_choice);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(h_split, d_split, kOffMeta, hipMemcpyDeviceToHost, s));
         }
         const uint32_t *order = nullptr;
         const uint32_t *sorted_keys = nullptr;
-        RC_TRY(sort_segments(w, kbuf, vbuf, n_seg, s, &order, &sorted_keys, lpt));
+        RC_TRY(sort_segments(w, kbuf, vbuf, n_seg, s, &order, &sorted_keys, false));
         tier_bounds_kernel<<<1, 64, 0, s>>>(sorted_keys, d_ctr + CT_SEG, d_ctr);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, kCtrBytes, hipMemcpyDeviceToHost, s));
@@ -730,40 +672,6 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                         ms_p, ms_a, ms_b);
             }
         }
-        if (lpt) {  // keep this shard's share of every tier's list
-            const uint64_t R = (uint64_t)n_shards, r = (uint64_t)shard;
-            unsigned long long *h_off = h_scalar + 4;  // [kTiers + 1] offsets in order, [kTiers + 1] offsets in own
-            uint64_t own_total = 0;
-            for (int t = 0; t <= kTiers; ++t) h_off[t] = seg_off[t];
-            for (int t = 0; t < kTiers; ++t) {
-                // entries i with i * R + (i even ? r : R - 1 - r) < n_t
-                uint64_t cnt = 0;
-                const uint64_t full = n_t[t] / (2 * R);          // complete pairs of rounds: two entries each
-                cnt = 2 * full;
-                const uint64_t rest = n_t[t] - full * 2 * R;     // < 2 R entries of the last pair of rounds
-                if (rest > r) ++cnt;
-                if (rest > R + (R - 1 - r)) ++cnt;
-                h_off[kTiers + 1 + t] = own_total;
-                own_total += cnt;
-                n_t[t] = cnt;
-            }
-            h_off[kTiers + 1 + kTiers] = own_total;
-            RC_TRY(w.own_list.reserve((size_t)(own_total + 1) * 4 + 2 * (kTiers + 1) * 8));
-            uint32_t *own = w.own_list.as<uint32_t>();
-            unsigned long long *d_off = reinterpret_cast<unsigned long long *>(w.own_list.as<char>() + (((size_t)(own_total + 1) * 4 + 7) & ~(size_t)7));
-            HIP_TRY(hipMemcpyAsync(d_off, h_off, 2 * (kTiers + 1) * 8, hipMemcpyHostToDevice, s));
-            if (own_total)
-                take_owned_kernel<<<grid_for(own_total), 256, 0, s>>>(order, own, d_off, d_off + kTiers + 1, (uint32_t)R, (uint32_t)r);
-            HIP_TRY(hipGetLastError());
-            for (int t = 0; t < kTiers; ++t) {
-                h_off[2 * (kTiers + 1) + t] = n_t[t];
-                seg_off[t + 1] = seg_off[t] + n_t[t];
-            }
-            HIP_TRY(hipMemcpyAsync(d_ctr + CT_N1, h_off + 2 * (kTiers + 1), (size_t)kTiers * 8, hipMemcpyHostToDevice, s));
-            RC_TRY(wd_sync(idx, cx, s, "the ownership lists"));  // (h_off is reused by the next call)
-            order = own;
-            n_seg = own_total;
-        }
         uint32_t *ovf[kTiers];  // ovf[t-1]: segments tier t gave up on
         for (int t = 0; t < kTiers; ++t) ovf[t] = w.ovf_list.as<uint32_t>() + (size_t)t * (n_seg + 1);
         // HBM arm storage of the LDS-array kernels: tier 6 (MODE 1) and tier 7 (MODE 2) may run at the
@@ -781,7 +689,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             return ASGART_E_CAP;
         }
         const size_t per_wg7 = (size_t)heavy_cap64 * (4 * sizeof(SlotT) + 28);
-        const size_t per_wg6 = (size_t)std::max(caph, (int)(kArmsLayers<SlotT> * kHeavyThreads)) * (4 * sizeof(SlotT) + 16);
+        const size_t per_wg6 = (size_t)caph * (4 * sizeof(SlotT) + 16);
         const size_t per_wg = std::max(per_wg6, per_wg7);
         const unsigned n_wg7 = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(256, (16ull << 30) / (4 * per_wg)));
         const unsigned n_wg_region = per_wg6 * 256 > per_wg * n_wg7 ? 256u : n_wg7;  // (a region serves either kind of launch)
@@ -803,20 +711,16 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             ep.p_filt = p_filt;
             ep.row_off = row_off;
             ep.hits = hits;
-            ep.hit_flag = hit_flag;
-            ep.p_nflag = p_nflag;
             ep.recs = w.fam_sds.as<SdRec>();
             ep.rec_cap = rec_cap;
             ep.scratch = scratch6;
             // option test_cap_limit (tests): shrink the tiers' capacity to exercise the cascade
             ep.cap_limit = opt.test_cap_limit >= 0 ? (uint32_t)opt.test_cap_limit : 0xFFFFFFFFu;
             ep.escalate_cost = 0xFFFFFFFFu;
-            ep.hi_prio = (uint32_t)opt.prio3;
-            ep.max_items = 0;
-            ep.fast_bsh = (uint32_t)opt.fast_bsh;
+            ep.hit_flag = nullptr;
+            ep.p_nflag = p_filt;
             ep.heavy_cap = (uint32_t)heavy_cap64;
             ep.solo_hits = opt.solo == 1 ? 16u : (uint32_t)opt.solo;  // (1: the default of 16 hits; other values: that many)
-            ep.n_levels = (uint32_t)opt.test_levels;
             ep.gen_bits = (uint32_t)opt.test_genbits;
             ep.k8_delay = (uint32_t)opt.test_k8_delay;
             ep.ctr = d_ctr;
@@ -844,28 +748,16 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             // start at once instead of queueing behind another tier's bulk.
             const std::string tier_order = std::to_string((long long)opt.tier_order);
             // one launch of tier `tier`'s kernel over the list described by ep
-            bool cascade_launch = false;
             char *scratch_override = nullptr;  // HBM slices of an early cascade launch
             auto launch_kernel = [&](int tier, uint64_t n_items, hipStream_t st) {
                 // option grid<t> may shrink a tier's grid; the workgroup kernels (tiers 3..7) never get
                 // more workgroups than their default (HBM scratch is reserved for that many)
-                // options wg_items / wg_items12: workgroups that retire after that many work-list fetches
-                // (the grid then covers the list; slots are given back to the device all along)
-                // (not the LDS-array kernels: their HBM arm slices are indexed by workgroup, 256 of them)
-                // (nor tier 6: its left-end slices in HBM are indexed by workgroup as well)
-                const bool retiring = !cascade_launch && (tier == 1 || (arms_kernel && tier >= 2 && tier <= 5));
-                const uint64_t items_wg = retiring ? (uint64_t)(tier <= 2 ? opt.wg_items12 : opt.wg_items) : 0;
-                ep.max_items = (uint32_t)items_wg;
                 ep.tier = (uint32_t)tier;
                 ep.seg_slots = w.seg_slots.as<unsigned long long>() + (size_t)4096 * (size_t)(tier & 7);
                 ep.hb = cx.d_hb ? cx.d_hb + (size_t)2 * SearchCtx::kHbSlots * (size_t)(tier & 7) : nullptr;
                 auto grid = [&](uint64_t dflt) -> unsigned {
                     uint64_t g = dflt;
                     if (opt.grid[tier] > 0) g = tier >= 3 ? std::min<uint64_t>(dflt, (uint64_t)opt.grid[tier]) : (uint64_t)opt.grid[tier];
-                    if (items_wg) {
-                        const uint64_t fetch = tier == 1 ? 8 : 1;  // extend_kernel fetches 8 segments at a time
-                        return (unsigned)std::min<uint64_t>((n_items + fetch * items_wg - 1) / (fetch * items_wg) + 1, 0x7FFFFFFFull);
-                    }
                     return (unsigned)std::min<uint64_t>(n_items, g);
                 };
                 switch (tier) {
@@ -873,58 +765,29 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                     extend_kernel<SlotT, kArmCapSmall><<<grid(kGrid1), 64, 0, st>>>(ep);
                     break;
                 case 2:
-                    if (fast_tier(2))
+                    if (arms_kernel)
                         extend_fast_kernel<SlotT, kWaveArmsLayers<SlotT>, 64, kWaveArmsHits, 256, 2><<<grid(kGrid2Arms), 64, 0, st>>>(ep);
-                    else if (arms_kernel)
-                        extend_arms_kernel<SlotT, kWaveArmsLayers<SlotT>, 64, kWaveArmsHits, 512, 3, false><<<grid(kGrid2Arms), 64, 0, st>>>(ep);
                     else
                         extend_heavy_kernel<SlotT, kArmCapMid, kMidThreads, 0><<<grid(kGrid2), kMidThreads, 0, st>>>(ep);
                     break;
-                case 3:
-                    if (k7_tier(3)) {
-                        if (opt.k8) extend_k8_kernel<SlotT, kK7LongLayers<SlotT>, 1024, kHitBatch, kFastLongRows<SlotT>, 2><<<grid(256), 1024, 0, st>>>(ep);
-                        else extend_k7_kernel<SlotT, kK7LongLayers<SlotT>, 1024, kHitBatch, kFastLongRows<SlotT>, 2><<<grid(256), 1024, 0, st>>>(ep);
-                    } else if (fast_tier(3)) {
-                        // (the same capacity in three shapes: per-probe work every wave repeats -- ranking the
-                        // empty slots and the unmatched hits -- is paid once per wave sharing a SIMD)
-                        extend_fast_kernel<SlotT, kFastLongLayers<SlotT>, 1024, kHitBatch, kFastLongRows<SlotT>, 2><<<grid(256), 1024, 0, st>>>(ep);
-                    } else
-                        extend_arms_kernel<SlotT, kLongArmsLayers<SlotT>, 1024, kHitBatch, 1024, 4, false, true, kPoleLdsPad><<<grid(256), 1024, 0, st>>>(ep);
+                case 3:  // (arm-resident kernels only: the long dense segments)
+                    extend_k8_kernel<SlotT, kK8LongLayers<SlotT>, 1024, kHitBatch, kFastLongRows<SlotT>, 2><<<grid(256), 1024, 0, st>>>(ep);
                     break;
                 case 4:
-                    if (k7_tier(4) && opt.k8)
-                        extend_k8_kernel<SlotT, kK7Mid4Layers<SlotT>, 256, kWaveArmsHits, 512, 2><<<grid(256 * 4), 256, 0, st>>>(ep);
-                    else if (k7_tier(4))
-                        extend_k7_kernel<SlotT, kK7Mid4Layers<SlotT>, 256, kWaveArmsHits, 512, 2><<<grid(256 * 4), 256, 0, st>>>(ep);
-                    else if (fast_tier(4))
+                    if (arms_kernel)
                         extend_fast_kernel<SlotT, kMidArmsLayers<SlotT>, 256, kWaveArmsHits, 512, 2><<<grid(256 * 4), 256, 0, st>>>(ep);
-                    else if (arms_kernel)
-                        extend_arms_kernel<SlotT, kMidArmsLayers<SlotT>, 256, kWaveArmsHits, 512, 4, false, true><<<grid(256 * 4), 256, 0, st>>>(ep);
                     else if constexpr (sizeof(SlotT) == 4)
                         extend_heavy_kernel<SlotT, kArmCapBig32, kHeavyThreads, 0><<<grid(256), kHeavyThreads, 0, st>>>(ep);
                     else
                         extend_heavy_kernel<SlotT, kArmCapBig64, kHeavyThreads, 0><<<grid(256), kHeavyThreads, 0, st>>>(ep);
                     break;
-                case 5:
-                    if (k7_tier(5) && opt.k8)
-                        extend_k8_kernel<SlotT, kK7Mid5Layers<SlotT>, 512, kHitBatch, 1024, 2><<<grid(256 * 2), 512, 0, st>>>(ep);
-                    else if (k7_tier(5))
-                        extend_k7_kernel<SlotT, kK7Mid5Layers<SlotT>, 512, kHitBatch, 1024, 2><<<grid(256 * 2), 512, 0, st>>>(ep);
-                    else if (fast_tier(5))
-                        extend_fast_kernel<SlotT, kMidArmsLayers<SlotT>, 512, kHitBatch, 1024, 2><<<grid(256 * 2), 512, 0, st>>>(ep);
-                    else
-                        extend_arms_kernel<SlotT, kMidArmsLayers<SlotT>, 512, kHitBatch, 1024, 4, false, true><<<grid(256 * 2), 512, 0, st>>>(ep);
+                case 5:  // (arm-resident kernels only)
+                    extend_fast_kernel<SlotT, kMidArmsLayers<SlotT>, 512, kHitBatch, 1024, 2><<<grid(256 * 2), 512, 0, st>>>(ep);
                     break;
                 case 6:
                     if (scratch_override) ep.scratch = scratch_override;
-                    if (k7_tier(6) && opt.k8)
-                        extend_k8_kernel<SlotT, kK7LongLayers<SlotT>, 1024, kHitBatch, kFastLongRows<SlotT>, 2><<<grid(256), 1024, 0, st>>>(ep);
-                    else if (k7_tier(6))
-                        extend_k7_kernel<SlotT, kK7LongLayers<SlotT>, 1024, kHitBatch, kFastLongRows<SlotT>, 2><<<grid(256), 1024, 0, st>>>(ep);
-                    else if (fast_tier(6))  // 5 x 1024 >= 9 x 512 slots; 64-bit positions: 4 x 1024 = 8 x 512 with a smaller table
+                    if (arms_kernel)  // 5 x 1024 slots; 64-bit positions: 4 x 1024 with a smaller table
                         extend_fast_kernel<SlotT, kFastHeavyLayers<SlotT>, 1024, kHitBatch, kFastLongRows<SlotT>, 2><<<grid(256), 1024, 0, st>>>(ep);
-                    else if (arms_kernel)
-                        extend_arms_kernel<SlotT, kArmsLayers<SlotT>, kHeavyThreads, kHitBatch, 1024, 4, false, kArmsCold<SlotT>><<<grid(256), kHeavyThreads, 0, st>>>(ep);
                     else
                         extend_heavy_kernel<SlotT, caph, kHeavyThreads, 1><<<grid(256), kHeavyThreads, 0, st>>>(ep);
                     ep.scratch = scratch6;
@@ -948,11 +811,10 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                     ep.cursor = reinterpret_cast<unsigned long long *>(d_split + 24);
                     ep.ovf_list = nullptr;
                     ep.ovf_count = d_ctr + CT_OVF1 + 2;
-                    ep.max_items = 0;
                     ep.tier = 3;  // (statistics: with the long-segment tier)
                     ep.seg_slots = w.seg_slots.as<unsigned long long>();  // (slot block 0: no tier's)
                     ep.hb = cx.d_hb ? cx.d_hb : nullptr;
-                    extend_k8_kernel<SlotT, kK7LongLayers<SlotT>, 1024, kHitBatch, kFastLongRows<SlotT>, 2, true><<<n_items, 1024, 0, s>>>(ep);
+                    extend_k8_kernel<SlotT, kK8LongLayers<SlotT>, 1024, kHitBatch, kFastLongRows<SlotT>, 2, true><<<n_items, 1024, 0, s>>>(ep);
                 }
             };
             if (n_runs) {
@@ -964,12 +826,6 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                 HIP_TRY(hipGetLastError());
             }
             hipStream_t tier_stream[kTiers + 1] = {s, st7, st2, st3, st4, st5, st6, st2};
-            {   // option tier_streams: tiers that share a stream run one after the other, in launch order
-                const hipStream_t pool[8] = {s, s, st2, st3, st4, st5, st6, st7};
-                const std::string ts = std::to_string((long long)opt.tier_streams);
-                for (int t = 1; t <= kTiers && t <= (int)ts.size(); ++t)
-                    if (ts[t - 1] >= '1' && ts[t - 1] <= '7') tier_stream[t] = pool[ts[t - 1] - '0'];
-            }
             auto launch_tier = [&](int tier) {
                 if (tier < 1 || tier > kTiers || !n_t[tier - 1]) return;
                 ep.seg_list = order + seg_off[tier - 1];
@@ -988,43 +844,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             auto since_launch = [&]() {
                 return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_launch).count();
             };
-            PassGate *const gate = attempt == 0 ? cx.gate : nullptr;
-            if (gate && gate->front_done && opt.pass_gate != 2) gate->front_done->store(1, std::memory_order_release);
-            if (gate && gate->front_done && !gate->next_front_done && opt.pass_gate == 2 && !force_tier) {
-                // (variant 2, the pass behind: its long-segment tiers first, then the signal -- the first pass's held
-                // tiers queue behind them --, its other tiers a moment later)
-                launch_tier(3);
-                launch_tier(6);
-                HIP_TRY(hipGetLastError());
-                gate->front_done->store(1, std::memory_order_release);
-                std::this_thread::sleep_for(std::chrono::microseconds(300));
-                for (char c : tier_order)
-                    if (c != '3' && c != '6') launch_tier(c - '0');
-            } else if (gate && gate->next_front_done && opt.pass_gate && !force_tier) {
-                // (struct PassGate, index.hpp) the tier of the longest segments now -- they are this pass's floor --,
-                // the others when the pass behind this one has had the chip for its search phases
-                launch_tier(3);
-                HIP_TRY(hipGetLastError());
-                if (cx.progress && !progress_given) {
-                    RC_TRY(wd_event_sync(idx, cx, cx.ev[3], "the hit rows"));
-                    signal_progress();
-                    progress_given = true;
-                }
-                const auto t_gate = std::chrono::steady_clock::now();
-                while (!gate->next_front_done->load(std::memory_order_acquire) &&
-                       !(gate->next_finished && gate->next_finished->load(std::memory_order_acquire)) &&
-                       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_gate).count() < (double)opt.pass_gate_ms)
-                    std::this_thread::sleep_for(std::chrono::microseconds(50));
-                if (opt.debug)
-                    fprintf(stderr, "[asgart] held the tiers behind tier 3 back for %.1f ms (the next pass's search phases)\n",
-                            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_gate).count());
-                for (char c : tier_order)
-                    if (c != '3') launch_tier(c - '0');
-                if (gate->front_done) gate->front_done->store(1, std::memory_order_release);
-            } else {
-                for (char c : tier_order) launch_tier(c - '0');
-                if (gate && gate->front_done) gate->front_done->store(1, std::memory_order_release);
-            }
+            for (char c : tier_order) launch_tier(c - '0');
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(cx.ev[12], st7));
             HIP_TRY(hipEventRecord(cx.ev[5], st2));
@@ -1038,7 +858,6 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                 // HBM-bound, chip-wide part of the call is over, the extension automaton is under way.
                 // A host that pipelines calls (bench.py) issues the next one when it sees this: its search
                 // phases then run beside this call's extension, whose tail is a few serial segments.
-                // (option progress_at = 2; with 0 or 1 the signal was given right after the scans, above)
                 if (!progress_given) {
                     RC_TRY(wd_event_sync(idx, cx, cx.ev[3], "the hit rows"));  // probe search, scans and CSR fill are done
                     signal_progress();
@@ -1067,7 +886,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                     while (dst < kTiers && (!tier_enabled(dst) || tier_cap[dst] <= tier_cap[E.src])) ++dst;
                     E.dst = dst;
                     // (a re-run in the HBM tier would share that tier's slices with its own list, if it has one)
-                    E.pending = opt.early_cascade && n_t[E.src - 1] && tier_stream[E.src] == E.st &&
+                    E.pending = n_t[E.src - 1] && tier_stream[E.src] == E.st &&
                                 (dst < kTiers || !n_t[kTiers - 1]);
                     n_pending += E.pending ? 1 : 0;
                 }
@@ -1110,11 +929,9 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                         ep.ovf_count = d_ctr + CT_OVF1 + E.dst - 1;
                         ep.escalate_cost = 0xFFFFFFFFu;
                         ep.cap_limit = 0xFFFFFFFFu;
-                        cascade_launch = true;
                         scratch_override = scratch6 + region * (size_t)(2 + e);
                         launch_kernel(E.dst, n_e, E.st);
                         scratch_override = nullptr;
-                        cascade_launch = false;
                         HIP_TRY(hipGetLastError());
                         HIP_TRY(hipEventRecord(E.ev, E.st));
                     }
@@ -1277,9 +1094,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                     ep.ovf_list = ovf[3 - 1];
                     ep.ovf_count = d_ctr + CT_OVF1 + 3 - 1;  // (what the whole segment overflows goes the way of tier 3's own)
                     ep.escalate_cost = 0xFFFFFFFFu;
-                    cascade_launch = true;
                     launch_kernel(3, n_again, s);
-                    cascade_launch = false;
                     HIP_TRY(hipGetLastError());
                 }
                 HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, kCtrBytes, hipMemcpyDeviceToHost, s));
@@ -1346,7 +1161,6 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                 ep.ovf_count = d_ctr + CT_OVF1 + dst - 1;  // appended behind what is already there
                 ep.escalate_cost = 0xFFFFFFFFu;
                 ep.cap_limit = 0xFFFFFFFFu;
-                cascade_launch = true;
                 launch_kernel(dst, n_ovf, s);
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, kCtrBytes, hipMemcpyDeviceToHost, s));
@@ -1519,8 +1333,6 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
     return 0;
 }
 
-static thread_local PassGate *tl_pass_gate = nullptr;  // set by the passes call around its run_search
-
 // n_passes > 1: ONE job over the probes of all passes (sts differ in reverse / complement only, n_shards == 1;
 // checked by the caller); fams: n_passes result objects, or null (the CSR surface of a single pass).
 int32_t run_search_passes(asgart_index *idx, const uint64_t *chunks, int64_t n_chunks,
@@ -1576,7 +1388,6 @@ int32_t run_search_passes(asgart_index *idx, const uint64_t *chunks, int64_t n_c
     }
     SearchCtx &cx = idx->ctx[which];
     cx.progress = progress;
-    cx.gate = n_passes == 1 ? tl_pass_gate : nullptr;
     int32_t rc;
     if (idx->wide)
         rc = run_search_t<uint64_t>(idx, cx, chunks, n_chunks, sts, n_passes, shard, n_shards, want_csr, fams,
@@ -1585,7 +1396,6 @@ int32_t run_search_passes(asgart_index *idx, const uint64_t *chunks, int64_t n_c
         rc = run_search_t<uint32_t>(idx, cx, chunks, n_chunks, sts, n_passes, shard, n_shards, want_csr, fams,
                                     status_out, rowoff_out, hits_out);
     cx.progress = nullptr;
-    cx.gate = nullptr;
     bool trim_now = false;
     {
         std::lock_guard<std::mutex> lk(idx->mu);
@@ -1852,9 +1662,8 @@ int32_t asgart_search_duplications_passes_shard(asgart_index *idx, const uint64_
     std::vector<int32_t> rcs((size_t)n_passes, 0);
     std::vector<std::string> errs((size_t)n_passes);
     std::vector<std::vector<uint64_t>> prog((size_t)n_passes, std::vector<uint64_t>((size_t)std::max<int64_t>(n_chunks, 1), 0));
-    std::vector<std::atomic<int>> finished((size_t)n_passes), front_done((size_t)n_passes);
+    std::vector<std::atomic<int>> finished((size_t)n_passes);
     for (auto &f : finished) f.store(0);
-    for (auto &f : front_done) f.store(0);
     auto searched = [&](int32_t p) {
         if (finished[p].load(std::memory_order_acquire)) return true;
         const volatile uint64_t *pr = prog[p].data();
@@ -1878,18 +1687,8 @@ int32_t asgart_search_duplications_passes_shard(asgart_index *idx, const uint64_
                 rcs[p] = ASGART_E_OOM;
                 errs[p] = "out of host memory";
             } else {
-                // (only the first pass holds tiers back: the second one has a context of its own from the start, a third
-                // one would wait for a context and the second for it)
-                PassGate gate;
-                gate.front_done = &front_done[(size_t)p];
-                if (p == 0 && n_passes > 1) {
-                    gate.next_front_done = &front_done[1];
-                    gate.next_finished = &finished[1];
-                }
-                tl_pass_gate = &gate;
                 rcs[p] = run_search(idx, chunks, n_chunks, &settings[j], shard, n_shards, false, f, nullptr, nullptr,
                                     nullptr, prog[p].data());
-                tl_pass_gate = nullptr;
                 if (rcs[p] != 0) {
                     errs[p] = asgart_last_error();  // the message is thread-local
                     delete f;

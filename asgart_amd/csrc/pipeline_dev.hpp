@@ -173,7 +173,6 @@ __global__ __launch_bounds__(kProbeThreads) void probe_count_kernel(IndexView<Sl
     const int c0 = chunk_of_uniform(rp.ch, gb);
     // (probes longer than one key word -- rare -- take the per-thread path as well)
     const bool uniform = rp.ch.pbase[c0 + 1] > g_last && k <= kMaxKey;
-    const bool opt_bucket = rp.bucket_lookup != 0u;
     uint32_t n_rej = 0;
     // one probe's lookup: SA interval, filtered count of a small interval (large ones are marked for the wave kernels)
     auto lookup = [&](uint32_t g_, uint64_t q_, uint64_t q2_, uint64_t i_, uint64_t s_, uint64_t L_, uint32_t md_) {
@@ -183,44 +182,6 @@ __global__ __launch_bounds__(kProbeThreads) void probe_count_kernel(IndexView<Sl
         pr.p = reverse ? ix.text + s_ + L_ - 1u - i_ : ix.text + s_ + i_;
         pr.dir = reverse ? -1 : 1;
         pr.comp = complement;
-        // ---- small buckets: keys AND suffix-array entries of the whole bucket requested together ----------------------
-        // The chain of a lookup is prefix table -> keys of the bucket -> suffix-array entries of the equal keys: three
-        // dependent HBM round trips behind the window.  The prefix table (d = 15 at GRCh38 size) leaves a bucket of three
-        // slots on average, and the suffix-array entries of a bucket sit at the SAME slot numbers as its keys: both are
-        // requested at once, the equal range and the kept count come out of registers -- one round trip fewer.
-        // (One-word probes of an untrimmed index outside the text-tail corner; everything else takes kmer_range.)
-        constexpr int kBucketRegs = 8;
-        uint32_t pfx = 0;
-        if (opt_bucket && !ix.trim && !ix.k2 && !is_tail_corner(ix, q_) && prefix_index(q_, ix.kk, ix.d, pfx)) {
-            const uint64_t lo0 = ix.ptab[pfx], hi0 = ix.ptab[pfx + 1];
-            cb.rd(2 * sizeof(SlotT));
-            if (hi0 - lo0 <= (uint64_t)kBucketRegs) {
-                uint64_t kv[kBucketRegs];
-                SlotT sv[kBucketRegs];
-#pragma unroll
-                for (int j = 0; j < kBucketRegs; ++j) {
-                    const bool in = lo0 + (uint64_t)j < hi0;
-                    kv[j] = in ? ix.keys[lo0 + j] : ~0ull;
-                    sv[j] = in ? ix.sa[lo0 + j] : (SlotT)0;
-                    if (in) cb.rd(8 + sizeof(SlotT));
-                }
-                uint32_t below = 0, upto = 0, cnt = 0;
-#pragma unroll
-                for (int j = 0; j < kBucketRegs; ++j) {
-                    below += kv[j] < q_ ? 1u : 0u;
-                    upto += kv[j] <= q_ ? 1u : 0u;   // (the padding ~0 is above every key: 63 bits)
-                    cnt += (kv[j] == q_ && keep_hit((uint64_t)sv[j], i_, s_, L_, reverse)) ? 1u : 0u;
-                }
-                const uint32_t raw = upto - below;
-                if (!COUNT) {
-                    p_lo[g_] = (SlotT)(lo0 + below);
-                    p_raw[g_] = raw;
-                    p_filt[g_] = cnt > rp.C ? kSkipCard : cnt;
-                }
-                cb.wr(sizeof(SlotT) + 4 + 4);
-                return;
-            }
-        }
         const bool all_occurrences = kmer_range(ix, q_, q2_, pr, lo, hi, cb);
         const uint64_t raw = hi - lo;
         if (!COUNT) {
@@ -1117,13 +1078,9 @@ struct ExtParams {
     uint32_t *ovf_list;                   // segments this launch gives up on go here (may be null)
     unsigned long long *ovf_count;        // ... appended at *ovf_count (device counter)
     char *scratch;                        // heavy global tier: per-workgroup arm storage
-    uint32_t n_levels;                    // K4c: usable hit-table levels (tests shrink it)
-    uint32_t gen_bits;                    // K4c: bits of the table generation counter (tests shrink it)
+    uint32_t gen_bits;                    // arm-resident kernels: bits of the table generation counter (tests shrink it)
     uint32_t escalate_cost;               // one-wave tiers: give up after this much LDS-path work
     uint32_t cap_limit;                   // effective live-arm capacity (<= CAP; tests lower it)
-    uint32_t hi_prio;                     // 1: the long-segment shape raises its waves' issue priority
-    uint32_t max_items;                   // work-list fetches per workgroup before it retires (0: until the list is empty)
-    uint32_t fast_bsh;                    // K6: log2 of the bucket width beyond the smallest power of two >= G + k
     uint32_t heavy_cap;                   // K4b MODE 2 (tier 7): arm slots per workgroup in its HBM slice
     uint32_t solo_hits;                   // K6: probes with up to this many hits may run on wave 0 alone (0: never)
     uint32_t k8_delay;                    // K8 (tests): cycles the ranking wave waits before it reads the free counts
@@ -1261,10 +1218,9 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
     const unsigned long long head_groups = min((unsigned long long)gridDim.x, n_seg / kFetch);
     const unsigned long long head = head_groups * kFetch;
     unsigned long long seg_base = 0;
-    uint32_t seg_j = (uint32_t)kFetch, n_fetch = 0;
+    uint32_t seg_j = (uint32_t)kFetch;
     for (;;) {
         if (seg_j == (uint32_t)kFetch) {
-            if (P.max_items && n_fetch++ >= P.max_items) break;  // retire: the slot goes to whatever is waiting
             unsigned long long sb = 0;
             if (lane == 0) sb = atomicAdd(P.cursor, kFetch);
             seg_base = uni(sb);
@@ -1693,34 +1649,18 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
     wg_busy(P);
 }
 
-// ---------------------------------------------------------------- K3b --------
-// Per-segment pre-pass (one wave per segment): continuation flags + placement.
-//
-// (1) Continuation filter.  A NewArm created by hit x at processed probe t has right = [x, x+k],
-//     thr = max(G, k/10), and stays active for the next W = t*-1 processed probes.  Unless one of
-//     those probes has a hit x' with  x < x' < x + k + thr  it never accepts anything
-//     (arm_accepts), so it never changes another arm's fate and, with k < M, is never reported:
-//     its only effect is to keep its family open until it dies.  Such hits get flag 0; the
-//     extension kernels do not create the arm and only remember when it would have died
-//     (`spur_until`).  At genome scale this removes most arms of dense repeat clusters.
-//     Implementation: a sliding counting filter in LDS over the hit positions (buckets of
-//     2^bsh >= k + thr bases) of the W processed probes ahead of the current one.  Bucket
-//     granularity and hash collisions can only produce flag 1 for a dead-end hit (harmless:
-//     the arm is created and dies), never the reverse.
-// (2) Placement.  Every live arm was created or extended by a distinct hit of the last t*
-//     processed probes, so B = max over probes of (hits of this probe + hits of the previous t*
-//     processed probes) bounds live arms + new arms from above: the tier whose capacity fits B
-//     never overflows (the cascade only serves the test knobs).
-//     key = (tier-1) << 29 | (2^29-1 - min(total hits, 2^29-1)): ascending sort = tier, longest first.
+// ---------------------------------------------------------------- placement ---
+// Every live arm was created or extended by a distinct hit of the last t* processed probes, so
+// B = max over probes of (hits of this probe + hits of the previous t* processed probes) bounds
+// live arms + new arms from above: the tier whose capacity fits B never overflows (the cascade
+// serves the tiers that accept segments above their capacity by an allowance, and the test knobs).
+// key = (tier-1) << 29 | (2^29-1 - min(total hits, 2^29-1)): ascending sort = tier, longest first.
 struct PlaceParams {
     uint32_t cap[kTiers - 1];   // live-arm capacity of tiers 1..kTiers-1 (0: tier unused); the last takes the rest
     uint32_t sum1;              // segments with more hits than this never go to the one-wave tier
     int force_tier;             // tests: minimum tier for segments with a multi-hit probe
-    int use_filter;             // 0: flag every hit (k >= M, huge gaps or cardinalities)
     uint32_t long3;             // > 0: tier 3 is reserved for segments of at least this many probes
     uint32_t long3_big;         // ... or this many, for segments beyond tier 5's capacity
-    uint32_t sparse_to6;        // 1: the long segments that are not dense go to tier 6 (its kernel is the old tier-3 one); 0: by capacity
-    uint32_t dense_min;         // > 0: segments of at least this many probes that are dense (dense3) go to tier 3 whatever their arm bound
     uint32_t dense6;            // > 0: segments bound for tier 6 by their arms go to tier 3 (when they fit it) with at least this
                                 // many hits per processed probe: the dense ones of ANY length on the kernel with a control wave
     uint32_t stats;             // 1 (option debug): hit-probes and hits per tier are tallied (one atomic pair per segment)
@@ -1779,21 +1719,8 @@ __device__ inline int place_tier(uint32_t bound, unsigned long long sum, uint32_
     if (pp.long3 && bound <= pp.cap[2] &&
         (n_probes >= pp.long3 || (bound > pp.cap[4] && n_probes >= pp.long3_big))) {
         if (!pp.dense3 || sum >= (unsigned long long)pp.dense3 * n_probes || bound > pp.cap[5]) return 3;
-        if (pp.sparse_to6 == 1) return 6;
-        if (pp.sparse_to6 >= 3) return bound <= pp.sparse_to6 ? 2 : 6;  // (3..: the ones whose arms fit that many slots on the one-wave shape)
-        if (pp.sparse_to6 == 2) {  // by capacity, but not on the one-wave shape (its bursts of dense repeats run layer by layer there)
-            for (int t = 4; t < kTiers; ++t)
-                if (bound <= pp.cap[t - 1]) return t;
-            return kTiers;
-        }
-        // (0: by capacity like any other segment -- a sparse long segment is mostly run by one wave alone, and the
-        // small shapes give it a fraction of a compute unit instead of a whole one)
+        return 6;  // (the long segments that are not dense: mostly run by one wave alone, on K6's solo probes)
     }
-    // medium segments (dense_min probes and more) that are dense go to the long-segment tier as well: the one-wave and the
-    // small workgroup shapes run a probe with a hundred arms in 20-50 K cycles, the kernel of tier 3 in 4 K
-    if (pp.long3 && pp.dense_min && pp.dense3 && n_probes >= pp.dense_min && bound <= pp.cap[2] && bound > pp.cap[0] &&
-        sum >= (unsigned long long)pp.dense3 * n_probes)
-        return 3;
     for (int t = 2; t < kTiers; ++t) {
         if (t == 3 && pp.long3) continue;
         if (bound <= pp.cap[t - 1]) {
@@ -1804,144 +1731,7 @@ __device__ inline int place_tier(uint32_t bound, unsigned long long sum, uint32_
     return kTiers;
 }
 
-constexpr uint32_t kFilterBits = 13;  // 8192 16-bit counters = 16 KB of LDS per wave
-
-template <class PosT>
-__global__ __launch_bounds__(64) void seg_prepass_kernel(RunParams rp, const uint32_t *__restrict__ p_filt,
-                                                         const unsigned long long *__restrict__ row_off,
-                                                         const PosT *__restrict__ hits,
-                                                         uint8_t *__restrict__ hit_flag,
-                                                         uint32_t *__restrict__ p_nflag,
-                                                         const uint32_t *__restrict__ seg_list,
-                                                         const unsigned long long *__restrict__ n_seg_ptr,
-                                                         uint32_t *__restrict__ keys,
-                                                         uint32_t *__restrict__ vals, PlaceParams pp,
-                                                         unsigned long long *__restrict__ ctr) {
-    __shared__ uint32_t s_cnt[1u << (kFilterBits - 1)];  // two 16-bit counters per word
-    __shared__ unsigned long long s_qrow[64];            // queue of processed probes ahead: CSR row start
-    __shared__ uint32_t s_qcnt[64];                      //   and hit count (0 = quiet probe)
-    __shared__ uint32_t s_qg[64];                        //   and probe number
-    __shared__ uint32_t s_nf[64];                        // ring: flagged hits of the last t* probes
-    const int lane = threadIdx.x;
-    const uint64_t n_seg = *n_seg_ptr;
-    const uint32_t k = (uint32_t)rp.k;
-    const uint32_t thr0 = arm_threshold(k, rp.G);
-    uint32_t bsh = 3;
-    while ((1ull << bsh) < (unsigned long long)thr0 + k) ++bsh;
-    const uint32_t W = rp.tstar - 1u;  // probes during which a fresh arm can still accept a hit
-    const bool filt = pp.use_filter && rp.tstar <= 64u;
-    for (uint32_t h = lane; h < (1u << (kFilterBits - 1)); h += 64) s_cnt[h] = 0;
-    __syncthreads();
-    auto slot_of = [&](uint64_t v) -> uint32_t {
-        return (((uint32_t)(v >> bsh)) * 2654435761u) >> (32 - kFilterBits);
-    };
-    auto filter_add = [&](unsigned long long row, uint32_t cnt, bool add) {
-        for (uint32_t t0 = 0; t0 < cnt; t0 += 64) {
-            if (t0 + lane < cnt) {
-                const uint32_t sl = slot_of((uint64_t)hits[row + t0 + lane]);
-                const uint32_t inc = 1u << (16u * (sl & 1u));
-                if (add) atomicAdd(&s_cnt[sl >> 1], inc); else atomicSub(&s_cnt[sl >> 1], inc);
-            }
-        }
-    };
-    for (uint64_t sidx = blockIdx.x; sidx < n_seg; sidx += gridDim.x) {
-        const uint32_t g0 = seg_list[sidx];
-        const int c = chunk_of_uniform(rp.ch, g0);
-        const uint32_t g_end = min(rp.ch.pbase[c + 1], rp.g_hi);
-        // lead cursor state
-        uint32_t quiet = 0, q_head = 0, q_size = 0;  // queue = ring of 64
-        bool lead_done = false;
-        // trail (current probe) state
-        uint32_t mx = 0, bound = 0, nf_sum = 0, t_idx = 0;
-        unsigned long long sum = 0;
-        s_nf[lane] = 0;
-        __syncthreads();
-        // pops the oldest queued probe = the current probe of the trail cursor
-        auto trail_step = [&]() {
-            const unsigned long long row = s_qrow[q_head];
-            const uint32_t cnt = s_qcnt[q_head];
-            const uint32_t gq = s_qg[q_head];
-            q_head = (q_head + 1u) & 63u;
-            --q_size;
-            uint32_t nf = 0;
-            if (cnt) {
-                if (filt) filter_add(row, cnt, false);  // window = probes strictly ahead
-                __syncthreads();
-                for (uint32_t t0 = 0; t0 < cnt; t0 += 64) {
-                    bool fl = false;
-                    if (t0 + lane < cnt) {
-                        fl = true;
-                        if (filt) {
-                            const uint64_t x = (uint64_t)hits[row + t0 + lane];
-                            const uint32_t s0 = slot_of(x + 1u), s1 = slot_of(x + k + thr0 - 1u);
-                            const uint32_t c0 = (s_cnt[s0 >> 1] >> (16u * (s0 & 1u))) & 0xFFFFu;
-                            const uint32_t c1 = (s_cnt[s1 >> 1] >> (16u * (s1 & 1u))) & 0xFFFFu;
-                            fl = (c0 | c1) != 0u;
-                        }
-                        hit_flag[row + t0 + lane] = fl ? 1 : 0;
-                    }
-                    nf += (uint32_t)__popcll(__ballot(fl));
-                }
-                if (lane == 0) p_nflag[gq] = nf;
-                sum += cnt;
-                mx = max(mx, cnt);
-                bound = max(bound, nf_sum + cnt);  // nf_sum: ALL hits of the previous t* processed probes
-            }
-            // sliding sum of the flagged hits of the last t* processed probes
-            const uint32_t ring = min(rp.tstar, 64u);
-            const uint32_t pos = t_idx % ring;
-            const uint32_t old = s_nf[pos];
-            __syncthreads();
-            if (lane == 0) s_nf[pos] = cnt;  // strict: an unflagged hit can still extend a (wide) arm
-            nf_sum = nf_sum - old + cnt;
-            ++t_idx;
-            __syncthreads();
-        };
-        for (uint32_t g = g0; g < g_end && !lead_done; g += 64) {
-            const uint32_t nb = min(64u, g_end - g);
-            const uint32_t f = (uint32_t)lane < nb ? p_filt[g + lane] : kSkipN;
-            const unsigned long long r = (uint32_t)lane < nb ? row_off[g + lane] : 0ull;
-            const unsigned long long procm = __ballot(f < kPending);
-            unsigned long long rest = procm;
-            while (rest && !lead_done) {
-                const uint32_t b = (uint32_t)(__ffsll((long long)rest) - 1);
-                rest &= rest - 1;
-                const uint32_t cnt = __shfl(f, (int)b);
-                const unsigned long long row = __shfl(r, (int)b);
-                if (cnt == 0) {
-                    if (++quiet >= rp.tstar) lead_done = true;  // the segment ends here
-                } else {
-                    quiet = 0;
-                }
-                if (q_size == W + 1u || q_size == 64u) trail_step();
-                const uint32_t tail = (q_head + q_size) & 63u;
-                if (lane == 0) {
-                    s_qrow[tail] = row;
-                    s_qcnt[tail] = cnt;
-                    s_qg[tail] = g + b;
-                }
-                ++q_size;
-                if (cnt && filt) filter_add(row, cnt, true);
-                __syncthreads();
-            }
-        }
-        while (q_size) trail_step();
-        if (rp.tstar > 64u) bound = 0xFFFFFFFFu;  // no estimate for huge gap settings: largest tier
-        if (lane == 0) {
-            int tier = place_tier(bound, sum, t_idx, pp);
-            if (mx > 1 && pp.force_tier > tier) tier = min(pp.force_tier, kTiers);
-#ifdef ASGART_PROFILE_EXTEND
-            if (g0 == 4841535u || g0 == 22631158u) printf("[prepass] g0=%u sidx=%llu bound=%u sum=%llu mx=%u tier=%d t_idx=%u\n", g0, (unsigned long long)sidx, bound, sum, mx, tier, t_idx);
-#endif
-            keys[sidx] = placement_key(tier, sum, g0);
-            vals[sidx] = g0;
-        }
-        __syncthreads();
-    }
-}
-
-// Placement only (continuation filter off): the same walk and window bound as the pre-pass, with
-// no hit accesses at all.
+// The placement walk reads the per-probe hit counts only -- no hit accesses at all.
 //
 // Most segments are a handful of probes long (3.4 M segments per GRCh38-shaped step, a dozen probes each), and a
 // wave per segment spends its time on the per-segment chain of dependent loads.  So the first kernel walks ONE
@@ -2277,17 +2067,12 @@ __global__ __launch_bounds__(64) void cluster_barren_kernel(RunParams rp, PlaceP
 //   fixup_records_kernel   one thread per record slot: family ordinals of a range + the flushes of the ranges before it;
 //                          records of a segment that failed -> void
 // Range size by budget (option split_len = 0): every run holds a compute unit, so the number of runs is what the cutting
-// may cost, and what a run takes is not its probe positions but its WORK: measured on the long shape, ~0.4 us per probe
-// position plus ~17 ns per hit (a 27 K-position segment with 274 hits per position ran 46 + 67 ms in two ranges of equal
-// length, a 60 K-position one whose array sits at its end 5 + 7 + 8 + 8 + 41 ms in five).  So a segment's size is
-// cost = positions + hits / kSplitHitWeight, it gets round(cost / C) ranges, and its cuts sit at equal shares of that cost
-// along the segment (the CSR row offsets are the running hit count).  split_tally_kernel counts, for each candidate C, the
-// runs that cutting every eligible segment would make; split_pick_kernel takes the SMALLEST C whose count fits the budget (a
-// small job gets small ranges -- its few long segments are its whole extension --, a genome-sized one large ranges); warm-up
-// C positions within [2 048, 6 144]; a segment is cut when it costs at least 2 C and is at least 3 warm-ups long.  The choice
-// depends on the segments only: the same in every call over the same input and settings.
+// may cost.  A segment of `span` probe positions gets round(span / C) ranges of one length.  split_tally_kernel counts, for
+// each candidate C, the runs that cutting every eligible segment would make; split_pick_kernel takes the SMALLEST C whose
+// count fits the budget (a small job gets small ranges -- its few long segments are its whole extension --, a genome-sized
+// one large ranges); warm-up C positions within [2 048, 6 144]; a segment is cut when it is at least 2 C and at least 3
+// warm-ups long.  The choice depends on the segments only: the same in every call over the same input and settings.
 constexpr int kSplitCand = 12;
-constexpr uint32_t kSplitHitWeight = 24;
 __device__ inline uint32_t split_len_of(int c) {
     constexpr uint32_t t[kSplitCand] = {2048, 3072, 4096, 6144, 8192, 12288, 16384, 24576, 32768, 49152, 65536, 98304};
     return t[c];
@@ -2304,10 +2089,9 @@ __device__ inline bool split_eligible(const RunParams &rp, uint32_t key, uint2 i
     // (tiers 1 and 2 are one-wave kernels: a wave on its own passes a sparse probe several times faster than the long shape's
     // sixteen waves and their barrier -- cutting a yeast-sized input's longest tier-2 segment in two doubled its step; tier 7's
     // arms do not fit the long shape)
-    if (tier < (uint32_t)rp.split_tier_lo || tier > 6u) return false;
+    if (tier < 3u || tier > 6u) return false;
     const uint32_t span = info.y & 0x7FFFFFFFu;
     if (!(info.y >> 31) || span < 128u) return false;  // (cut short by a shard window: left alone)
-    if (rp.split_dense && (unsigned long long)info.x < (unsigned long long)rp.split_dense * span) return false;
     // (creation numbers of a run: needle offset relative to the segment's first probe << 10 | hit index)
     return (unsigned long long)span * (unsigned long long)rp.step < (1ull << 22) - 2ull;
 }
@@ -2319,7 +2103,7 @@ __global__ __launch_bounds__(256) void split_tally_kernel(RunParams rp, const un
     const uint2 info = seg_info[sj];
     const uint32_t span = info.y & 0x7FFFFFFFu;
     if (span < 3u * 2048u || !split_eligible(rp, keys[sj], info)) return;
-    const unsigned long long cost = (unsigned long long)span + (rp.split_hw ? info.x / rp.split_hw : 0u);
+    const unsigned long long cost = (unsigned long long)span;
     for (int c = 0; c < kSplitCand; ++c) {
         const unsigned long long C = split_len_of(c);
         if (cost < 2ull * C || span < 3u * split_warm_of((uint32_t)C)) break;
@@ -2341,7 +2125,6 @@ __global__ void split_pick_kernel(SplitChoice *choice, uint32_t budget) {
 struct SplitParams {
     uint32_t range_len, warm, min_span;   // size of a range (probe positions; range_len = 0: cost units, as split_pick_kernel chose),
                                           // warm-up probes in front of a cut, shortest segment that is cut
-    uint32_t hit_weight;                  // cost = positions + hits / hit_weight (0: positions only)
     uint32_t max_runs, max_cuts, max_splits;
     uint32_t n_blocked;
     uint32_t blocked[64];                 // segments (first probe) a cut of which did not hold in an earlier call of the index ...
@@ -2354,15 +2137,13 @@ __global__ __launch_bounds__(256) void plan_ranges_kernel(RunParams rp, SplitPar
                                                          uint32_t *__restrict__ keys, const uint2 *__restrict__ seg_info,
                                                          unsigned long long *__restrict__ hdr,  // 0 runs, 1 cuts, 2 split segments
                                                          RangeRun *__restrict__ runs, uint2 *__restrict__ cuts,
-                                                         SplitSeg *__restrict__ splits, const SplitChoice *__restrict__ choice,
-                                                         const unsigned long long *__restrict__ row_off) {
+                                                         SplitSeg *__restrict__ splits, const SplitChoice *__restrict__ choice) {
     const unsigned long long sj = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (sj >= *n_seg_ptr) return;
     if (!sp.range_len) {  // (hdr[3] is the runs' work cursor: hdr[4] tells the host which length was used)
         sp.range_len = choice->range_len;
         sp.warm = choice->warm;
         sp.min_span = max(sp.min_span, choice->min_span);
-        sp.hit_weight = rp.split_hw;
         if (sj == 0) hdr[4] = sp.range_len;
     } else if (sj == 0) {
         hdr[4] = sp.range_len;
@@ -2376,27 +2157,16 @@ __global__ __launch_bounds__(256) void plan_ranges_kernel(RunParams rp, SplitPar
     uint32_t n_cut_max = 0xFFFFFFFFu;
     for (uint32_t b = 0; b < sp.n_blocked; ++b)
         if (sp.blocked[b] == g0 && sp.blocked_len[b] == sp.range_len) n_cut_max = min(n_cut_max, (uint32_t)sp.allowed[b]);
-    // ranges of about range_len units of cost each (scaled by the hit weight: positions x weight + hits), at least two, their
-    // cuts at equal shares of the cost along the segment; a segment whose cuts held only up to some point in an earlier call
-    // keeps those cuts (same places) and runs the rest as its last range
-    const unsigned long long hw = sp.hit_weight, r0 = row_off[g0];
-    auto cost_to = [&](uint32_t g) -> unsigned long long {  // of the probes g0 .. g - 1
-        return hw ? (unsigned long long)(g - g0) * hw + (row_off[g] - r0) : (unsigned long long)(g - g0);
-    };
-    const unsigned long long total = cost_to(g0 + span), unit = (unsigned long long)sp.range_len * (hw ? hw : 1ull);
+    // ranges of about range_len probe positions each, at least two, their cuts at equal shares of the segment; a segment whose
+    // cuts held only up to some point in an earlier call keeps those cuts (same places) and runs the rest as its last range
+    // (cuts at equal shares of positions + hits / w instead were measured at GRCh38 size and did not move the step: DESIGN_HISTORY.md)
+    const unsigned long long total = span, unit = sp.range_len;
     if (total < 2ull * unit) return;
     const uint32_t n_r_all = (uint32_t)min(1024ull, max(2ull, (total + unit / 2ull) / unit));
     const uint32_t n_r = min(n_r_all, n_cut_max == 0xFFFFFFFFu ? n_r_all : n_cut_max + 1u);
     if (n_r < 2u) return;
     auto cut_of = [&](uint32_t j) -> uint32_t {  // first hit-probe at or behind the j-th share of the cost (0: none)
-        const unsigned long long want = total / n_r_all * j;
-        uint32_t lo = g0, hi = g0 + span;                // smallest g with cost_to(g) >= want
-        while (lo < hi) {
-            const uint32_t mid = lo + (hi - lo) / 2u;
-            if (cost_to(mid) >= want) hi = mid;
-            else lo = mid + 1u;
-        }
-        uint32_t c = lo;
+        uint32_t c = g0 + (uint32_t)(total / n_r_all * j);
         while (c < g0 + span) {
             const uint32_t f = p_filt[c];
             if (f >= 1u && f < kPending) return c;
@@ -2506,22 +2276,6 @@ __global__ __launch_bounds__(256) void fixup_records_kernel(SdRec *__restrict__ 
 
 // tier list lengths from the sorted placement keys (tier-1 = key >> 29): n_t = first index whose
 // tier exceeds t, by bisection -- instead of one contended global atomic per segment
-// Cost-aware ownership of a sharded call (option shard_lpt): the r-th of R shards takes, of every tier's list
-// (sorted by decreasing work), the entries j = i * R + (i even ? r : R - 1 - r) -- the longest segments go to
-// different shards, and the snake order evens out what follows.  One thread per owned entry.
-__global__ __launch_bounds__(256) void take_owned_kernel(const uint32_t *__restrict__ order, uint32_t *__restrict__ own,
-                                                        const unsigned long long *__restrict__ tier_off,   // kTiers + 1 entries: offsets in order
-                                                        const unsigned long long *__restrict__ own_off,    // kTiers + 1 entries: offsets in own
-                                                        uint32_t R, uint32_t r) {
-    const unsigned long long t0 = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t0 >= own_off[kTiers]) return;
-    int t = 0;
-    while (t + 1 < kTiers && t0 >= own_off[t + 1]) ++t;
-    const unsigned long long i = t0 - own_off[t];
-    const unsigned long long j = i * R + ((i & 1ull) ? (unsigned long long)(R - 1u - r) : (unsigned long long)r);
-    own[t0] = order[tier_off[t] + j];
-}
-
 __global__ void tier_bounds_kernel(const uint32_t *__restrict__ sorted_keys,
                                    const unsigned long long *__restrict__ n_seg_ptr,
                                    unsigned long long *__restrict__ ctr) {
@@ -2660,7 +2414,7 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
     wg_begin(P);
     PROF_DECL;
 
-    for (uint32_t n_fetch = 0; !P.max_items || n_fetch < P.max_items; ++n_fetch) {
+    for (;;) {
         if (tid == 0) s_bcast = atomicAdd(P.cursor, 1ull);
         __syncthreads();
         const unsigned long long seg = s_bcast;
@@ -3082,545 +2836,6 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
             PROF_FLUSH();
         }
         __syncthreads();
-    }
-    rec_flush(rec_alloc, P, lane);
-    wg_busy(P);
-}
-
-// ---------------------------------------------------------------- K4c --------
-// Arm-resident extension kernel: one workgroup (or one wave) per segment, every live arm OWNED
-// by a thread and kept in that thread's registers (S arms per thread, slot = layer * NT +
-// thread).  Per probe the HITS are indexed (a few hundred at most) and every arm looks up the
-// hits inside its own accept window, so nothing about an arm lives in LDS:
-//   P0  hit h -> hash tables keyed by x >> (bsh + 2*level); generation-tagged heads, so the
-//       tables are never cleared; head and chain nodes carry the hit's position, one LDS
-//       round trip per chain link (PACK)                                             | barrier
-//   P1  each arm walks the buckets covering its window [re-k+1, re+thr-1] at the level whose
-//       bucket is at least a quarter of the window; accepted hits take
-//       atomicMin(best[h], creation number << 20 | slot): first arm in list order
-//       (src/automaton.rs:67-78)                                                     | barrier
-//   P2  each hit posts h+1 to its winner's mailbox (atomicMax: last hit in SA order wins) or,
-//       unmatched and flagged, to a free slot in hit order (= creation order)        | barrier
-//   P3  owners read their mailboxes: extend / age / retire (emit if len(right) >= M) / create.
-// The per-probe bookkeeping is wave-uniform and kept in scalar registers (uni / lane_of).
-// Two shapes: NT = 64 (one wave per segment, several segments per CU: the bulk of the dense
-// segments) and NT >= 512 (the few segments with thousands of live arms or tens of thousands
-// of probes, whose serial chain sets the critical path of a pass).
-// Results are identical to K4 and K4b; tested by forcing every multi-hit segment through it.
-template <class PosT, int S, int NT, int HB, int kHT, int kLevels, bool PACK, int COLD = 0, int PAD = 0>
-__global__ __launch_bounds__(NT) void extend_arms_kernel(ExtParams<PosT> P) {
-    constexpr int CAP = S * NT;
-    constexpr uint32_t kNoHit = 0xFFFFu;
-    // the 1024-thread shape runs the long serial segments that set a pass's critical path: its waves
-    // win the issue arbitration against whatever else is resident on the CU (P.hi_prio: option prio3)
-    if (NT >= 1024 && P.hi_prio) __builtin_amdgcn_s_setprio(3);
-    const uint32_t kGenBits = min(22u, max(2u, P.gen_bits));  // generation counter width (22; tests: less)
-    static_assert(HB <= 1024 && HB <= kHitBatch && CAP < (1 << 20), "hit index is packed into 10 bits");
-    // PACK: head = ((generation << 10 | hit) << 32) | low word of x, node[h] = (next hit << 32) | its x
-    using HeadT = typename std::conditional<PACK, unsigned long long, uint32_t>::type;
-    using NodeT = typename std::conditional<PACK, unsigned long long, uint16_t>::type;
-    __shared__ PosT s_hits[HB];
-    __shared__ uint8_t s_hflag[HB];
-    __shared__ HeadT s_head[kLevels][kHT];
-    __shared__ NodeT s_node[kLevels][HB];            // chain through the hits of one bucket
-    __shared__ unsigned long long s_best[HB];        // per hit: (creation number << 20) | slot
-    __shared__ uint16_t s_rank[HB];                  // per new hit: rank among the new arms
-    __shared__ uint32_t s_msg[CAP];                  // per slot: 1 + index of the hit for it
-    __shared__ uint16_t s_free[CAP];                 // stack of empty slots below H
-    __shared__ uint32_t s_nfreed[2], s_nnew[2], s_nspur[2];
-    __shared__ unsigned long long s_bcast;
-    // COLD = 1: the fields an arm only needs when it is extended or retired (left start, left end,
-    // right start) live in LDS instead of registers -- more arms per thread without spilling.
-    // COLD = 2 (the largest shape): left and right start stay in registers, the left END -- written at every
-    // extension, read only when a long enough arm is reported -- lives in the workgroup's slice of the HBM
-    // scratch, and the LDS that the three arrays took holds twice the arm slots instead.
-    __shared__ PosT s_cls[COLD == 1 ? CAP : 1], s_cle[COLD == 1 ? CAP : 1], s_crs[COLD == 1 ? CAP : 1];
-    PosT *const g_cle = COLD == 2 ? reinterpret_cast<PosT *>(P.scratch) + (size_t)blockIdx.x * CAP : nullptr;
-    // PAD > 0: claim the rest of the CU's LDS so that no other workgroup shares the CU with a
-    // latency-critical segment (its waves would take issue slots and LDS bandwidth)
-    __shared__ uint32_t s_pad[PAD > 0 ? PAD / 4 : 1];
-    if (P.cap_limit == 0xFEEDF00Du) s_pad[threadIdx.x % (PAD > 0 ? PAD / 4 : 1)] = 1u;  // keeps the allocation
-    const int tid = threadIdx.x, lane = tid & 63;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    const RunParams &rp = P.rp;
-    const uint64_t n_seg = *P.n_seg_ptr;
-    const uint32_t k = (uint32_t)rp.k, step = (uint32_t)rp.step, G = rp.G;
-    const uint32_t thr0 = arm_threshold(k, G);
-    uint32_t bsh = 3;  // level-0 bucket: 2^bsh >= G + k covers a narrow arm's window
-    while ((1ull << bsh) < (unsigned long long)G + k) ++bsh;
-    const uint32_t cap_eff = min((uint32_t)CAP, P.cap_limit);
-    const uint32_t n_lv = min((uint32_t)kLevels, P.n_levels);
-    RecAlloc rec_alloc;
-    wg_begin(P);
-    PROF_DECL;
-
-    // arm state, one arm per (thread, layer)
-    constexpr int SC = COLD == 1 ? 1 : S;  // left / right start in registers
-    constexpr int SE = COLD == 0 ? S : 1;  // left end in registers
-    PosT a_ls[SC], a_le[SE], a_rs[SC], a_re[S];
-    uint32_t a_thr[S], a_gap[S], a_seq[S];
-#pragma unroll
-    for (int L = 0; L < S; ++L) {
-        a_seq[L] = kNoSeq;
-        a_re[L] = 0;
-        if (L < SC) a_ls[L] = a_rs[L] = 0;
-        if (L < SE) a_le[L] = 0;
-        a_thr[L] = a_gap[L] = 0;
-    }
-    auto clear_tables = [&]() {
-        for (uint32_t h = tid; h < (uint32_t)(kLevels * kHT); h += NT) (&s_head[0][0])[h] = 0;
-    };
-    clear_tables();
-    for (uint32_t j = tid; j < (uint32_t)CAP; j += NT) s_msg[j] = 0u;
-    if (tid < 2) s_nfreed[tid] = s_nnew[tid] = s_nspur[tid] = 0u;
-    // Monotonic counters in pairs, used by alternate probes / owner passes and never reset: a
-    // pass reads its counter after its barrier while the next pass already adds to the other.
-    uint32_t gen = 0, par = 0, freed_seen0 = 0, freed_seen1 = 0;
-    uint32_t ppar = 0, new_seen0 = 0, new_seen1 = 0, spur_seen0 = 0, spur_seen1 = 0;
-    lds_barrier();
-
-    for (uint32_t n_fetch = 0; !P.max_items || n_fetch < P.max_items; ++n_fetch) {
-        if (tid == 0) s_bcast = atomicAdd(P.cursor, 1ull);
-        lds_barrier();
-        const unsigned long long seg = uni(s_bcast);
-        lds_barrier();
-        if (seg >= n_seg) break;
-        const uint32_t g0 = P.seg_list[seg];
-        if (tid == 0) {
-            heartbeat(P, g0, 0u);
-            seg_clock(P);
-        }
-        PROF_SEG_BEGIN();
-        const int c = chunk_of_uniform(rp.ch, g0);
-        const uint64_t cs = rp.ch.start[c], cl = rp.ch.len[c];
-        const bool seg_rev = (rp.mode_of(c) & 2u) != 0u;  // (the orientation of the chunk's pass)
-        const uint32_t pb = rp.ch.pbase[c];
-        const uint32_t chunk_end = rp.ch.pbase[c + 1];
-        const uint32_t g_end = min(chunk_end, rp.g_hi);
-        // block-uniform: A live arms in slots [0,H), n_free empty ones on s_free
-        uint32_t A = 0, H = 0, n_free = 0, quiet = 0, fam_seq = 0, next_seq = 0;
-        uint32_t t_proc = 0, spur_until = 0;
-        bool overflow = false, done = false, fam_open = false;
-
-        auto emit_records = [&](bool emit, PosT ls, PosT le, PosT rs, PosT re, uint32_t seq) {
-            const unsigned long long em = __ballot(emit);
-            if (!em) return;
-            const unsigned long long at = rec_slot(rec_alloc, P, em, lane);
-            if (emit) {
-                if (at < P.rec_cap) {
-                    const uint64_t ll = (uint64_t)le - (uint64_t)ls;
-                    SdRec r;
-                    r.g_start = g0;
-                    r.fam_seq = fam_seq;
-                    r.create_seq = seq;
-                    r.pad = 0;
-                    r.sd.left = seg_rev ? cs + cl - (uint64_t)ls - ll : (uint64_t)ls + cs;
-                    r.sd.right = rs;
-                    r.sd.left_length = ll;
-                    r.sd.right_length = (uint64_t)re - (uint64_t)rs;
-                    P.recs[at] = r;
-                }
-            }
-        };
-        // owner pass: mailboxes (with_msg) / ageing by `add` / retirement / creation.
-        // i, off: the probe whose hits are referenced by the mailboxes; seq_base: creation number
-        // of its first new arm.  Block-uniform on exit: A, n_free, H.
-        // `pre`: work that shares the pass's barrier interval (P0 of the next probe)
-        auto owner_pass = [&](uint32_t add, bool with_msg, uint64_t i, uint32_t off, uint32_t seq_base, auto &&pre) {
-            const uint32_t n_layers = (H + NT - 1u) / NT;
-            const uint32_t freed_base = par ? freed_seen1 : freed_seen0;
-#pragma unroll
-            for (int L = 0; L < S; ++L) {
-                if ((uint32_t)L < n_layers) {  // block-uniform
-                    const uint32_t slot = (uint32_t)L * NT + tid;
-                    uint32_t m = 0;
-                    if (with_msg && slot < H) {
-                        m = s_msg[slot];
-                        if (m) s_msg[slot] = 0u;
-                    }
-                    bool dead = false;
-                    const uint32_t sq = a_seq[L];
-                    if (sq != kNoSeq) {
-                        if (m) {  // ExtendArm, src/automaton.rs:133-150
-                            const PosT x = s_hits[off + m - 1u];
-                            a_re[L] = (PosT)(x + k);
-                            PosT ls;
-                            if constexpr (COLD == 1) {
-                                ls = s_cls[slot];
-                                s_cle[slot] = (PosT)(i + k);
-                            } else if constexpr (COLD == 2) {
-                                ls = a_ls[L];
-                                g_cle[slot] = (PosT)(i + k);
-                            } else {
-                                ls = a_ls[L];
-                                a_le[L] = (PosT)(i + k);
-                            }
-                            a_thr[L] = arm_threshold((uint64_t)(i + k) - (uint64_t)ls, G);
-                            a_gap[L] = 0;
-                        } else {
-                            const uint64_t sum_g = (uint64_t)a_gap[L] + add;
-                            const uint32_t ng = sum_g > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)sum_g;
-                            a_gap[L] = ng;
-                            dead = ng >= G;  // src/automaton.rs:166-171: never matches again
-                        }
-                    } else if (m) {  // NewArm, src/automaton.rs:151-164 (aged by this very probe)
-                        const PosT x = s_hits[off + m - 1u];
-                        if constexpr (COLD == 1) {
-                            s_cls[slot] = (PosT)i; s_cle[slot] = (PosT)(i + k); s_crs[slot] = x;
-                        } else if constexpr (COLD == 2) {
-                            a_ls[L] = (PosT)i; a_rs[L] = x; g_cle[slot] = (PosT)(i + k);
-                        } else {
-                            a_ls[L] = (PosT)i; a_le[L] = (PosT)(i + k); a_rs[L] = x;
-                        }
-                        a_re[L] = (PosT)(x + k);
-                        a_gap[L] = step;
-                        a_thr[L] = thr0;
-                        a_seq[L] = seq_base + s_rank[m - 1u];
-                    }
-                    if (__ballot(dead)) {  // wave-uniform
-                        if (dead) {
-                            a_seq[L] = kNoSeq;
-                            s_free[n_free + (atomicAdd(&s_nfreed[par], 1u) - freed_base)] = (uint16_t)slot;
-                        }
-                        PosT ls = 0, le = 0, rs = 0;
-                        if (dead) {
-                            if constexpr (COLD == 1) {
-                                ls = s_cls[slot]; le = s_cle[slot]; rs = s_crs[slot];
-                            } else if constexpr (COLD == 2) {
-                                ls = a_ls[L]; rs = a_rs[L];
-                            } else {
-                                ls = a_ls[L]; le = a_le[L]; rs = a_rs[L];
-                            }
-                        }
-                        const bool report = dead && (uint64_t)(a_re[L] - rs) >= rp.M;
-                        if constexpr (COLD == 2) {
-                            if (report) le = g_cle[slot];  // (this thread's own store, or a newer one of its own)
-                        }
-                        emit_records(report, ls, le, rs, a_re[L], sq);
-                    }
-                }
-                // (the largest shape: one layer at a time -- interleaving 16 unrolled layers costs hundreds of
-                // registers for their temporaries)
-                if constexpr (COLD == 2) __builtin_amdgcn_sched_barrier(0);
-            }
-            pre();
-            lds_barrier();
-            const uint32_t freed_now = uni(s_nfreed[par]);
-            const uint32_t nd = freed_now - freed_base;
-            if (par) freed_seen1 = freed_now; else freed_seen0 = freed_now;
-            par ^= 1u;
-            A -= nd;
-            n_free += nd;
-            if (A == 0) {  // every slot is empty again
-                H = 0;
-                n_free = 0;
-            }
-        };
-        // P0: index the hits of one probe (cnt hits at s_hits[off..]) under generation `gen`
-        auto index_hits = [&](uint32_t cnt, uint32_t off) {
-            for (uint32_t h = tid; h < cnt; h += NT) {
-                const PosT x = s_hits[off + h];
-                s_best[h] = ~0ull;
-                const HeadT mine = PACK ? (HeadT)(((unsigned long long)((gen << 10) | h) << 32) | (uint32_t)x)
-                                        : (HeadT)((gen << 10) | h);
-                HeadT old[kLevels];  // all exchanges in flight before the first result is used
-#pragma unroll
-                for (uint32_t lv = 0; lv < (uint32_t)kLevels; ++lv) {
-                    const uint32_t bkt = (uint32_t)((uint64_t)x >> (bsh + 2u * lv));
-                    old[lv] = atomicExch(&s_head[lv][((bkt * 2654435761u) >> 12) & ((uint32_t)kHT - 1u)], mine);
-                }
-#pragma unroll
-                for (uint32_t lv = 0; lv < (uint32_t)kLevels; ++lv) {
-                    if constexpr (PACK) {
-                        const uint32_t tag = (uint32_t)(old[lv] >> 32);
-                        s_node[lv][h] = (tag >> 10) == gen
-                                            ? ((unsigned long long)(tag & 1023u) << 32) | (uint32_t)old[lv]
-                                            : (unsigned long long)kNoHit << 32;
-                    } else {
-                        s_node[lv][h] = (old[lv] >> 10) == gen ? (uint16_t)(old[lv] & 1023u) : (uint16_t)kNoHit;
-                    }
-                }
-            }
-        };
-        auto maybe_close = [&]() {  // the flush of src/automaton.rs:182-200
-            if (fam_open && A == 0 && t_proc >= spur_until) {
-                ++fam_seq;
-                next_seq = 0;
-                fam_open = false;
-            }
-        };
-        auto advance_quiet = [&](uint32_t q) {
-            quiet += q;
-            t_proc += q;
-            if (A > 0) owner_pass(q * step, false, 0, 0, 0, [] {});
-            maybe_close();
-            if (A == 0 && quiet >= rp.tstar) done = true;
-        };
-
-        for (uint32_t g = g0; g < g_end && !done;) {
-            // ---- stage a batch of up to 64 probes (every wave computes the same masks) ----
-            PROF_START();
-            const uint32_t nb = min(64u, g_end - g);
-            if (tid == 0) heartbeat(P, g0, g);
-            const uint32_t f_l = (uint32_t)lane < nb ? P.p_filt[g + lane] : kSkipN;
-            const uint32_t nfl_l = (uint32_t)lane < nb ? P.p_nflag[g + lane] : 0u;
-            const unsigned long long r_l = (uint32_t)lane < nb ? P.row_off[g + lane] : 0ull;
-            const unsigned long long r_hi = uni(P.row_off[g + nb]);
-            const unsigned long long base = lane_of(r_l, 0u);
-            unsigned long long r_next = __shfl_down(r_l, 1);
-            if ((uint32_t)lane + 1 >= nb) r_next = r_hi;
-            const bool fits = (uint32_t)lane < nb && r_next - base <= (unsigned long long)HB;
-            const unsigned long long fm = __ballot(fits);
-            uint32_t nbb = (~fm == 0ull) ? 64u : (uint32_t)(__ffsll((long long)~fm) - 1);
-            if (nbb > nb) nbb = nb;
-            if (nbb == 0) {  // one probe with more hits than the staging area: not for this kernel
-                overflow = true;
-                break;
-            }
-            const uint32_t rel_l = (uint32_t)(r_l - base);
-            {
-                const unsigned long long end = nbb == nb ? r_hi : lane_of(r_l, nbb);
-                const uint32_t tot = (uint32_t)(end - base);
-                for (uint32_t r = tid; r < tot; r += NT) {
-                    s_hits[r] = P.hits[base + r];
-                    s_hflag[r] = (P.hit_flag ? P.hit_flag[base + r] : (uint8_t)1);
-                }
-            }
-            lds_barrier();
-            const unsigned long long in_batch = nbb >= 64 ? ~0ull : ((1ull << nbb) - 1ull);
-            const unsigned long long hm = __ballot(f_l >= 1u && f_l < kPending) & in_batch;
-            const unsigned long long qm = __ballot(f_l == 0u) & in_batch;
-            PROF_STOP(0);
-            PROF_COUNT(1, 1);
-            uint32_t pos = 0;
-            bool pre_indexed = false;
-            while (!done) {
-                const unsigned long long hmr = pos >= 64 ? 0ull : (hm >> pos) << pos;
-                if (!hmr) break;
-                const uint32_t b = (uint32_t)(__ffsll((long long)hmr) - 1);
-                {
-                    const unsigned long long range = ((1ull << b) - 1ull) & ~((1ull << pos) - 1ull);
-                    const uint32_t q = (uint32_t)__popcll(qm & range);
-                    if (q) {
-                        advance_quiet(q);
-                        if (done) break;
-                    }
-                }
-                quiet = 0;
-                pos = b + 1;
-                const uint32_t cnt = lane_of(f_l, b);
-                const uint32_t nfl = lane_of(nfl_l, b);
-                const uint32_t off = lane_of(rel_l, b);
-                const uint64_t i = (uint64_t)(g + b - pb + 1) * step;
-                ++t_proc;
-                if (A + nfl > cap_eff) {
-                    overflow = true;
-                    done = true;
-                    break;
-                }
-                PROF_COUNT(5, 1);
-                PROF_COUNT(10, A);
-                PROF_COUNT(11, cnt);
-                PROF_MAX(9, A + nfl);
-                PROF_START();
-                // ---- P0: index the hits of this probe (unless the previous probe's owner pass
-                // already did, in its own barrier interval) -------------------------------------
-                if (!pre_indexed) {
-                    if (++gen >> kGenBits) {  // generation wrap: clear the tables once
-                        lds_barrier();
-                        clear_tables();
-                        gen = 1;
-                        lds_barrier();
-                    }
-                    index_hits(cnt, off);
-                    lds_barrier();
-                }
-                pre_indexed = false;
-                PROF_STOP(2);
-                PROF_START();
-                // ---- P1: every arm looks up the hits inside its window ------------------------
-                {
-                    const uint32_t n_layers = (H + NT - 1u) / NT;
-#pragma unroll
-                    for (int L = 0; L < S; ++L) {
-                        if ((uint32_t)L < n_layers && a_seq[L] != kNoSeq) {
-                            const PosT lo = (PosT)(a_re[L] - k + 1u);
-                            const uint64_t w = (uint64_t)a_thr[L] + k - 1u;
-                            const unsigned long long key =
-                                ((unsigned long long)a_seq[L] << 20) | ((uint32_t)L * NT + tid);
-                            // exact test on the full position (the packed low word is a pre-filter
-                            // that is already exact for 32-bit positions)
-                            auto offer = [&](uint32_t h, uint32_t x32) {
-                                if constexpr (sizeof(PosT) == 4) {
-                                    if ((uint64_t)(uint32_t)(x32 - (uint32_t)lo) < w) atomicMin(&s_best[h], key);
-                                } else {
-                                    if ((uint64_t)(uint32_t)(x32 - (uint32_t)lo) < w &&
-                                        (uint64_t)(PosT)(s_hits[off + h] - lo) < w)
-                                        atomicMin(&s_best[h], key);
-                                }
-                            };
-                            // smallest level whose bucket is at least a quarter of the window
-                            uint32_t lv = 0;
-                            if (w > (4ull << bsh)) {
-                                const uint32_t bits = 64u - (uint32_t)__clzll((long long)(w - 1u));  // ceil(log2 w)
-                                lv = (bits - bsh - 1u) >> 1;  // ceil((bits - bsh - 2) / 2)
-                            }
-                            DBG_ADD(0, 1);            // arms looking up
-                            DBG_ADD(4 + min(lv, 7u), 1);  // ... by level
-                            if (lv >= n_lv) {  // wider than any table: every hit is a candidate
-                                DBG_ADD(1, 1);
-                                for (uint32_t h = 0; h < cnt; ++h)
-                                    if ((uint64_t)(PosT)(s_hits[off + h] - lo) < w) {
-                                        atomicMin(&s_best[h], key);
-                                        DBG_ADD(3, 1);
-                                    }
-                            } else {
-                                const uint32_t sh = bsh + 2u * lv;
-                                const uint64_t b0 = (uint64_t)lo >> sh, b1 = ((uint64_t)lo + w - 1u) >> sh;
-                                for (uint64_t bk = b0; bk <= b1; ++bk) {
-                                    const HeadT e = s_head[lv][(((uint32_t)bk * 2654435761u) >> 12) & ((uint32_t)kHT - 1u)];
-                                    if constexpr (PACK) {
-                                        const uint32_t tag = (uint32_t)(e >> 32);
-                                        if ((tag >> 10) != gen) continue;
-                                        uint32_t h = tag & 1023u, x32 = (uint32_t)e;
-                                        for (;;) {
-                                            const unsigned long long nd = s_node[lv][h];
-                                            DBG_ADD(2, 1);  // chain nodes visited
-                                            offer(h, x32);
-                                            h = (uint32_t)(nd >> 32);
-                                            x32 = (uint32_t)nd;
-                                            if (h == kNoHit) break;
-                                        }
-                                    } else {
-                                        if ((e >> 10) != gen) continue;
-                                        uint32_t h = e & 1023u;
-                                        while (h != kNoHit) {
-                                            const PosT x = s_hits[off + h];
-                                            const uint32_t nx = s_node[lv][h];
-                                            DBG_ADD(2, 1);  // chain nodes visited
-                                            if ((uint64_t)(PosT)(x - lo) < w) DBG_ADD(3, 1);
-                                            if ((uint64_t)(PosT)(x - lo) < w) atomicMin(&s_best[h], key);
-                                            h = nx;
-                                        }
-                                    }
-                                }
-                            }
-                        }
-                        if constexpr (COLD == 2) __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-                lds_barrier();
-                PROF_STOP(4);
-                PROF_START();
-                // ---- P2: hits notify arms / claim free slots ----------------------------------
-                // Wave w owns the hit groups w, w + NT/64, ...; the rank of an unmatched flagged hit
-                // among the new arms (hit order = creation order) needs the counts of the earlier
-                // groups, which the owning wave recomputes itself (no barrier).  The totals reach
-                // the other waves through counters read after the barrier.
-                const uint32_t new_base = ppar ? new_seen1 : new_seen0;
-                const uint32_t spur_base = ppar ? spur_seen1 : spur_seen0;
-                for (uint32_t h0 = (uint32_t)tid & ~63u; h0 < cnt; h0 += NT) {
-                    uint32_t before = 0;
-                    bool any_spur = false;
-                    for (uint32_t c0 = 0; c0 <= h0; c0 += 64) {
-                        const uint32_t h = c0 + lane;
-                        unsigned long long best = 0;
-                        bool un = false, hf = false;
-                        if (h < cnt) {
-                            best = s_best[h];
-                            un = best == ~0ull;
-                            hf = s_hflag[off + h] != 0;
-                        }
-                        const unsigned long long nm = __ballot(un && hf);
-                        if (c0 < h0) {
-                            before += (uint32_t)__popcll(nm);
-                            continue;
-                        }
-                        any_spur = __ballot(un && !hf) != 0ull;
-                        if (h < cnt) {
-                            if (!un) {
-                                atomicMax(&s_msg[(uint32_t)(best & 0xFFFFFu)], h + 1u);
-                            } else if (hf) {
-                                const uint32_t bf = before + (uint32_t)__popcll(nm & lt_mask);
-                                const uint32_t slot = bf < n_free ? (uint32_t)s_free[n_free - 1u - bf] : H + (bf - n_free);
-                                s_msg[slot] = h + 1u;
-                                s_rank[h] = (uint16_t)bf;
-                            }
-                        }
-                        if (lane == 0) {
-                            if (nm) atomicAdd(&s_nnew[ppar], (uint32_t)__popcll(nm));
-                            if (any_spur) atomicAdd(&s_nspur[ppar], 1u);
-                        }
-                    }
-                }
-                lds_barrier();
-                const uint32_t new_now = uni(s_nnew[ppar]), spur_now = uni(s_nspur[ppar]);
-                const uint32_t n_new = new_now - new_base;
-                const bool spur = spur_now != spur_base;
-                if (ppar) { new_seen1 = new_now; spur_seen1 = spur_now; } else { new_seen0 = new_now; spur_seen0 = spur_now; }
-                ppar ^= 1u;
-                if (n_new <= n_free) {
-                    n_free -= n_new;
-                } else {
-                    H += n_new - n_free;
-                    n_free = 0;
-                }
-                A += n_new;
-                const uint32_t seq_base = next_seq;
-                next_seq += n_new;
-                PROF_STOP(6);
-                PROF_START();
-                // ---- P3: owners apply -----------------------------------------------------------
-                {
-                    // next hit probe of this staged batch, if any: its P0 rides in this pass's barrier
-                    // interval (nothing in P3 reads the hit tables, s_best or the chain nodes)
-                    const unsigned long long nxt = pos >= 64 ? 0ull : (hm >> pos) << pos;
-                    const bool can_pre = nxt != 0ull && ((gen + 1u) >> kGenBits) == 0u;
-                    uint32_t ncnt = 0, noff = 0;
-                    if (can_pre) {
-                        const uint32_t nb2 = (uint32_t)(__ffsll((long long)nxt) - 1);
-                        ncnt = lane_of(f_l, nb2);
-                        noff = lane_of(rel_l, nb2);
-                        ++gen;
-                    }
-                    owner_pass(step, true, i, off, seq_base, [&] {
-                        if (can_pre) index_hits(ncnt, noff);
-                    });
-                    pre_indexed = can_pre;
-                }
-                fam_open = true;
-                if (spur) spur_until = max(spur_until, t_proc + rp.tstar - 1u);
-                maybe_close();
-                PROF_STOP(7);
-            }
-            if (overflow) break;
-            if (!done) {
-                const unsigned long long range = pos >= 64 ? 0ull : ~((1ull << pos) - 1ull);
-                const uint32_t q = (uint32_t)__popcll(qm & range);
-                if (q) advance_quiet(q);
-            }
-            lds_barrier();
-            g += nbb;
-        }
-        if (overflow) done = true;
-        if (!done && g_end < chunk_end) {
-            if (tid == 0) atomicAdd(&P.ctr[CT_RANOUT], 1ull);
-        } else if (!overflow && fam_open) {
-            emit_records(tid == 0, (PosT)0, (PosT)0, (PosT)0, (PosT)0, kTombstone);
-        }
-        if (overflow && tid == 0) {
-            const unsigned long long at = atomicAdd(P.ovf_count, 1ull);
-            if (P.ovf_list) P.ovf_list[at] = g0;
-        }
-        // leave no arm behind for the next segment (mailboxes are empty: every P2 has its P3)
-        if (A > 0) {
-#pragma unroll
-            for (int L = 0; L < S; ++L) a_seq[L] = kNoSeq;
-        }
-        if (tid < 64) {
-            PROF_FLUSH();
-        }
-        lds_barrier();
     }
     rec_flush(rec_alloc, P, lane);
     wg_busy(P);

@@ -616,64 +616,10 @@ int32_t sa_build_device(const uint8_t *d_text, int64_t n, void *d_sa, bool wide,
 // sap[lo..hi) = the suffix-array entries of the k-mer interval [lo,hi), sorted by POSITION.  The probe filter
 // of the reference (src/automaton.rs:105-114) keeps the occurrences beyond a position threshold, so the kept count
 // of a large interval is a bisection in this list instead of a read of the interval -- what the cardinality test
-// of a repeat-rich genome otherwise streams (16 GB per GRCh38-shaped pass).  Built as ONE device-wide sort of
-// (rank of the interval << 32 | position); 32-bit positions only.
-namespace {
-__global__ __launch_bounds__(256) void run_head_kernel(const uint64_t *__restrict__ keys, uint32_t *__restrict__ head,
-                                                       uint64_t n) {
-    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (uint64_t)gridDim.x * blockDim.x)
-        head[r] = (r > 0 && keys[r] != keys[r - 1]) ? 1u : 0u;
-}
-__global__ __launch_bounds__(256) void rank_pos_kernel(const uint32_t *__restrict__ rank, const uint32_t *__restrict__ sa,
-                                                       unsigned long long *__restrict__ out, uint64_t n) {
-    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (uint64_t)gridDim.x * blockDim.x)
-        out[r] = ((unsigned long long)rank[r] << 32) | sa[r];
-}
-__global__ __launch_bounds__(256) void low_word_kernel(const unsigned long long *__restrict__ in, uint32_t *__restrict__ out,
-                                                       uint64_t n) {
-    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (uint64_t)gridDim.x * blockDim.x)
-        out[r] = (uint32_t)in[r];
-}
-}  // namespace
+// of a repeat-rich genome otherwise streams (16 GB per GRCh38-shaped pass).
 
-int32_t build_rank_lists(const uint64_t *d_keys, const uint32_t *d_sa, uint64_t n, uint32_t *d_sap, hipStream_t s) {
-    if (n == 0) return 0;
-    const unsigned g = (unsigned)std::min<uint64_t>((n + 255) / 256, 1u << 20);
-    // Two stable 32-bit pair sorts -- by position, then by interval rank -- on buffers of n words each: the sizes
-    // the suffix sorter has just released (common.hpp: block cache), instead of one 64-bit sort on two fresh
-    // buffers of 2 n words.
-    DevBuf ka, kb, vb, temp;
-    struct Free {  // (before the first reservation: a failed later one must not leave the earlier ones behind)
-        DevBuf &x, &y, &z, &t;
-        ~Free() { x.release(); y.release(); z.release(); t.release(); }
-    } guard{ka, kb, vb, temp};
-    RC_TRY(ka.reserve(n * 4));
-    RC_TRY(kb.reserve(n * 4));
-    RC_TRY(vb.reserve(n * 4));
-    // interval ranks (in d_sap, which is free until the end): inclusive sum of the run heads
-    run_head_kernel<<<g, 256, 0, s>>>(d_keys, d_sap, n);
-    size_t bytes = 0;
-    HIP_TRY(rocprim::inclusive_scan(nullptr, bytes, d_sap, d_sap, (size_t)n, rocprim::plus<uint32_t>(), s));
-    RC_TRY(temp.reserve(bytes));
-    HIP_TRY(rocprim::inclusive_scan(temp.p, bytes, d_sap, d_sap, (size_t)n, rocprim::plus<uint32_t>(), s));
-    HIP_TRY(hipMemcpyAsync(ka.p, d_sa, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
-    rocprim::double_buffer<uint32_t> pos(ka.as<uint32_t>(), kb.as<uint32_t>()), rank(d_sap, vb.as<uint32_t>());
-    bytes = 0;
-    HIP_TRY(rocprim::radix_sort_pairs(nullptr, bytes, pos, rank, (size_t)n, 0, 32, s));
-    RC_TRY(temp.reserve(bytes));
-    HIP_TRY(rocprim::radix_sort_pairs(temp.p, bytes, pos, rank, (size_t)n, 0, 32, s));   // by position
-    rocprim::double_buffer<uint32_t> rank2(rank.current(), rank.alternate()), pos2(pos.current(), pos.alternate());
-    HIP_TRY(rocprim::radix_sort_pairs(temp.p, bytes, rank2, pos2, (size_t)n, 0, 32, s)); // stable, by rank
-    if (pos2.current() != d_sap)
-        HIP_TRY(hipMemcpyAsync(d_sap, pos2.current(), (size_t)n * 4, hipMemcpyDeviceToDevice, s));
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(stream_sync(s));
-    return 0;
-}
-
-// The same lists for 64-bit slots (n >= 2^32: two genomes), and for any index when only the LARGE intervals matter
-// (rank_count_kernel reads the list of an interval of more than kRankMin entries only): the suffix array is copied and
-// every run of more than `min_run` equal keys is sorted by position in place, as one segment of a segmented radix
+// Only the LARGE intervals matter (rank_count_kernel reads the list of an interval of more than kRankMin entries only): the
+// suffix array is copied and every run of more than `min_run` equal keys is sorted by position in place, as one segment of a segmented radix
 // sort -- a seventh of the slots of a GRCh38-shaped text instead of all of them, and no pair of n-word buffers.
 // rocPRIM's segmented sort counts elements in 32 bits: the array is worked through in windows of 2^30 slots, a run
 // belongs to the window it starts in.  Runs of k-mers that start with N are left alone: probes that start with N are

@@ -1,11 +1,9 @@
 """Multi-GPU host side (one process per GPU): replicate the index, gather the per-shard duplicon lists.
 
-The search itself needs no collective.  By default (option shard_lpt = 0) shard r owns the
-automaton segments that START in the r-th contiguous slice of the global probe sequence and searches that slice plus
-halos; with shard_lpt = 1 every shard computes the whole front and owns every n-th segment of each extension tier's
-cost-sorted list, so the shards interleave.  Either way the shards' families, MERGED BY THEIR KEYS (segment start
-probe, family ordinal: asgart_families_keys), are the unsharded result -- gather_families therefore wants the keys
-(without them it can only concatenate in rank order, which is right for contiguous slices alone).
+The search itself needs no collective: shard r owns the automaton segments that START in the
+r-th contiguous slice of every pass's probe sequence and searches those slices plus halos.  The shards' families,
+MERGED BY THEIR KEYS (segment start probe, family ordinal: asgart_families_keys), are the unsharded result; without
+keys gather_families concatenates in rank order, which is the same thing for contiguous slices.
 The two exchanges of the arrangement, both with torch.distributed (backend "nccl" == RCCL over xGMI on MI355X, "gloo"
 in the CPU tests and on one-GPU boxes):
   replicate_index   text + suffix array broadcast from the rank that sorted the suffixes;
@@ -22,7 +20,7 @@ def gather_families(offs: np.ndarray, sds: np.ndarray, dist, device: Optional[st
                     dst: int = 0, keys: Optional[np.ndarray] = None) -> Optional[Tuple[np.ndarray, np.ndarray]]:
     """offs: uint64[n_fam+1], sds: uint64[n_sd,4], keys: uint64[n_fam] (asgart_families_keys) of this rank.
     Returns, on rank `dst` (None elsewhere), the families of all ranks merged by key -- or, without keys
-    (contiguous shards, option shard_lpt = 0), concatenated in rank order."""
+    (contiguous shards), concatenated in rank order."""
     import torch
 
     world, rank = dist.get_world_size(), dist.get_rank()

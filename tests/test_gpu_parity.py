@@ -135,11 +135,8 @@ def _battery_case(name):
     return pr, spec.get("cli", {})
 
 
-@pytest.mark.parametrize("filt", ["0", "1"])
 @pytest.mark.parametrize("name", sorted(BATTERY))
-def test_battery_families_and_csr(hiplib, name, filt, monkeypatch):
-    # filt=1: with the continuation filter (arms that can never match are not materialised)
-    monkeypatch.setenv("ASGART_FILTER", filt)
+def test_battery_families_and_csr(hiplib, name, monkeypatch):
     pr, cli = _battery_case(name)
     oidx = oracle.Index.build(pr.data)
     with asgart_amd.Index(pr.data, oidx.sa) as idx:
@@ -305,13 +302,11 @@ def test_index_builds_its_own_suffix_array(case):
 
 
 @pytest.mark.parametrize("name", ["long_sds", "dense_repeats", "satellites", "masked"])
-@pytest.mark.parametrize("halo,lpt", [("default", "1"), ("default", "0"), ("tiny", "0")])
-def test_shards_concatenate_to_unsharded(hiplib, name, halo, lpt, monkeypatch):
+@pytest.mark.parametrize("halo", ["default", "tiny"])
+def test_shards_concatenate_to_unsharded(hiplib, name, halo, monkeypatch):
     """Multi-GPU logic on one GPU: shards 0..R-1, run one after the other, merged by their family keys, must
-    give exactly the unsharded result (segments are never split; no exchange).  shard_lpt = 0 (default): contiguous
-    slices of the probe sequence with halos -- `tiny` halos force the look-back / look-ahead retry paths; 1: every
-    shard computes the whole front and owns every R-th segment of each tier's cost-sorted list."""
-    monkeypatch.setenv("ASGART_SHARD_LPT", lpt)
+    give exactly the unsharded result (segments are never split; no exchange): contiguous slices of the probe
+    sequence with halos -- `tiny` halos force the look-back / look-ahead retry paths."""
     if halo == "tiny":
         monkeypatch.setenv("ASGART_SHARD_LOOKBACK", "2")
         monkeypatch.setenv("ASGART_SHARD_LOOKAHEAD", "3")
@@ -324,8 +319,8 @@ def test_shards_concatenate_to_unsharded(hiplib, name, halo, lpt, monkeypatch):
             for R in (2, 3, 8, 61):
                 parts = [idx.search_duplications_raw(pr.chunks, st, shard=r, n_shards=R, with_keys=True) for r in range(R)]
                 got_offs, got_sds = asgart_amd.merge_shards(parts)
-                if lpt == "0":   # contiguous slices: plain concatenation in shard order is the result as well
-                    assert np.array_equal(np.concatenate([p[1] for p in parts]), sds)
+                # contiguous slices: plain concatenation in shard order is the result as well
+                assert np.array_equal(np.concatenate([p[1] for p in parts]), sds)
                 assert np.array_equal(got_offs, offs), (name, R, reverse)
                 assert np.array_equal(got_sds, sds), (name, R, reverse)
 
@@ -346,25 +341,22 @@ def test_overflow_cascade_gives_identical_results(hiplib, cap, monkeypatch):
             assert np.array_equal(offs, eoffs) and np.array_equal(sds, esds), (cap, reverse)
 
 
-@pytest.mark.parametrize("tier", [2, 3, 4, 5, 6, 7, "2-lds", "4-lds", "6-lds", "6-filter"])
+@pytest.mark.parametrize("tier", [2, 3, 4, 5, 6, 7, "2-lds", "4-lds", "6-lds"])
 @pytest.mark.parametrize("name", ["dense_repeats", "satellites", "long_sds"])
 def test_escalation_tiers_give_identical_results(hiplib, name, tier, monkeypatch):
-    """Segments that do not fit the one-wave kernel go to larger tiers: the arm-resident kernel in five
-    shapes (2: one wave, 3: 1024 threads for long segments, 4/5/6: 256/512/512 threads by capacity), the
-    HBM-scratch kernel (7), or -- "N-lds", what max_cardinality > 1024 selects -- the LDS-array workgroup
+    """Segments that do not fit the one-wave kernel go to larger tiers: the arm-resident kernels in five
+    shapes (2: one wave, 3: the kernel with specialised waves for long dense segments, 4/5/6: 256/512/1024 threads by
+    capacity), the HBM-scratch kernel (7), or -- "N-lds", what max_cardinality > 1024 selects -- the LDS-array workgroup
     kernels in tiers 2, 4 and 6.  Forcing every segment with a multi-hit probe into tier `tier` must not
     change a single ProtoSD."""
     pr, cli = _battery_case(name)
     oidx = oracle.Index.build(pr.data)
-    filt = False
     if isinstance(tier, str):
         tier, variant = tier.split("-")
         tier = int(tier)
         if variant == "lds":
             monkeypatch.setenv("ASGART_ARMS_KERNEL", "0")
-        filt = variant == "filter"
     monkeypatch.setenv("ASGART_FORCE_TIER", str(tier))
-    monkeypatch.setenv("ASGART_FILTER", "1" if (filt or tier % 2) else "0")
     with asgart_amd.Index(pr.data, oidx.sa) as idx:
         for reverse, complement in ((False, False), (True, True)):
             st = asgart_amd.RunSettings.from_cli(reverse=reverse, complement=complement, **cli)
@@ -392,23 +384,6 @@ def test_large_max_cardinality_tier_sets(hiplib, card, force, monkeypatch):
             offs, sds = idx.search_duplications_raw(pr.chunks, st)
             eoffs, esds = oidx.run_raw(pr.chunks, oracle.make_settings(reverse=rc, complement=rc, **cli), threads=4)
             assert np.array_equal(offs, eoffs) and np.array_equal(sds, esds), rc
-
-
-@pytest.mark.parametrize("levels", [0, 1, 2])
-def test_arm_kernel_window_levels(hiplib, levels, monkeypatch):
-    """The arm-resident kernel looks hits up in per-probe hash tables at four bucket widths and falls
-    back to a linear scan for windows wider than the coarsest; with fewer usable levels the long arms
-    of `long_sds` take the coarser paths and the scan."""
-    pr, cli = _battery_case("long_sds")
-    oidx = oracle.Index.build(pr.data)
-    monkeypatch.setenv("ASGART_FORCE_TIER", "5")
-    monkeypatch.setenv("ASGART_TEST_LEVELS", str(levels))
-    with asgart_amd.Index(pr.data, oidx.sa) as idx:
-        for rc in (False, True):
-            st = asgart_amd.RunSettings.from_cli(reverse=rc, complement=rc, **cli)
-            offs, sds = idx.search_duplications_raw(pr.chunks, st)
-            eoffs, esds = oidx.run_raw(pr.chunks, oracle.make_settings(reverse=rc, complement=rc, **cli), threads=4)
-            assert np.array_equal(offs, eoffs) and np.array_equal(sds, esds), (levels, rc)
 
 
 def test_cfg1_ecoli_sized_direct_bit_exact(hiplib):
@@ -893,8 +868,6 @@ def test_random_sweep_default_and_forced_tiers(hiplib, seed, monkeypatch):
         assert np.array_equal(offs, eoffs) and np.array_equal(sds, esds), ("default", cli, rc)
         tier = int(rng.integers(2, 8))
         idx.set_option("force_tier", tier)
-        if rng.integers(0, 2):
-            idx.set_option("filter", 1)
         offs, sds = idx.search_duplications_raw(pr.chunks, st)
         assert np.array_equal(offs, eoffs) and np.array_equal(sds, esds), ("forced", tier, cli, rc)
 
@@ -1244,19 +1217,13 @@ def test_lazy_filter_and_lists_same_results(hiplib, monkeypatch):
             assert np.array_equal(got[0], exp[0]) and np.array_equal(got[1], exp[1])
 
 
-@pytest.mark.parametrize("k8", [0, 1])
 @pytest.mark.parametrize("wide", [0, 1])
-@pytest.mark.parametrize("tier", [3, 4, 5, 6])
-def test_control_wave_kernel_in_every_workgroup_tier(hiplib, tier, wide, k8, monkeypatch):
-    """The kernels with specialised waves run tier 3 by default (K8, extend_k8_dev.hpp; with k8 = 0 K7,
-    extend_k7_dev.hpp: a control wave plans the steps, arm waves do nothing but their arms); option k7 = 120 puts them
-    in tiers 4, 5 and 6 as well (other shapes: 6 x 192, 5 x 448, 5 x 960 slots; with
-    64-bit positions 3 x 192, 3 x 448, 4 x 960).  Every segment with a multi-hit probe forced through each of them,
-    with a generation counter that wraps every few probes in one of the passes: identical to the oracle.  k8 = 1: the
-    one-barrier variant of the same kernel (extend_k8_dev.hpp: the control wave makes the new arms' first offers, the arm
-    waves pull them a step later)."""
-    monkeypatch.setenv("ASGART_K7", "120")
-    monkeypatch.setenv("ASGART_K8", str(k8))
+def test_specialised_wave_kernel_with_generation_wraps(hiplib, wide, monkeypatch):
+    """The kernel with specialised waves (K8, extend_k8_dev.hpp: a planning wave writes the steps' commands, a ranking
+    wave makes the new arms' first offers, arm waves do nothing but their arms) runs tier 3 in two shapes: 5 x 896
+    slots and, with 64-bit positions, 4 x 896.  Every segment with a multi-hit probe forced through it, with a
+    generation counter that wraps every few probes in one of the passes: identical to the oracle."""
+    tier = 3
     monkeypatch.setenv("ASGART_FORCE_TIER", str(tier))
     monkeypatch.setenv("ASGART_FORCE_WIDE", str(wide))
     for name in ("dense_repeats", "satellites"):
@@ -1265,14 +1232,13 @@ def test_control_wave_kernel_in_every_workgroup_tier(hiplib, tier, wide, k8, mon
         with asgart_amd.Index(pr.data, oidx.sa) as idx:
             for rc in (False, True):
                 idx.set_option("test_genbits", 3 if rc else 22)
-                idx.set_option("filter", 1 if (rc and tier % 2) else 0)
                 st = asgart_amd.RunSettings.from_cli(reverse=rc, complement=rc, **cli)
                 offs, sds = idx.search_duplications_raw(pr.chunks, st)
-                key = ("k7_battery", name, rc)
+                key = ("k8_battery", name, rc)
                 if key not in _ORACLE_CACHE:
                     _ORACLE_CACHE[key] = oidx.run_raw(pr.chunks, oracle.make_settings(reverse=rc, complement=rc, **cli), threads=4)
                 eoffs, esds = _ORACLE_CACHE[key]
-                assert np.array_equal(offs, eoffs) and np.array_equal(sds, esds), (name, tier, wide, rc, k8)
+                assert np.array_equal(offs, eoffs) and np.array_equal(sds, esds), (name, tier, wide, rc)
 
 
 @pytest.mark.parametrize("delay", [0, 2_000, 20_000])
@@ -1481,28 +1447,3 @@ def test_prepare_data_on_the_gpu_matches_host_and_oracle(hiplib, skip_masked):
     # the strand may stay on the device; too small a chunk array is reported with the room needed
     got2, idx2 = prep.prepare_records_gpu(recs, skip_masked=skip_masked, want_text=False, want_index=False)
     assert got2.data is None and idx2 is None and got2.chunks == want.chunks
-
-
-@pytest.mark.parametrize("name", ["dense_repeats", "masked", "k12", "k21_odd"])
-def test_bucket_lookup_option_same_results(hiplib, name):
-    """Option bucket = 1 (off by default: measured slower at GRCh38 size): the probe search requests the keys and the
-    suffix-array entries of a small prefix-table bucket together and takes the equal range and the kept count out of
-    registers.  Per-probe hit rows (status, offsets, hits in suffix-array order) and families must equal the default's,
-    in every orientation, with 32- and 64-bit slots."""
-    pr, cli = _battery_case(name)
-    for wide in ("0", "1"):
-        os.environ["ASGART_FORCE_WIDE"] = wide
-        try:
-            with asgart_amd.Index(pr.data, None) as idx:
-                for reverse, complement in MODES:
-                    st = asgart_amd.RunSettings.from_cli(reverse=reverse, complement=complement, **cli)
-                    idx.set_option("bucket", 0)
-                    ref_f = idx.search_duplications_raw(pr.chunks, st)
-                    ref_h = idx.probe_hits(pr.chunks, st)
-                    idx.set_option("bucket", 1)
-                    got_f = idx.search_duplications_raw(pr.chunks, st)
-                    got_h = idx.probe_hits(pr.chunks, st)
-                    assert all(np.array_equal(a, b) for a, b in zip(ref_f, got_f)), (name, wide, reverse, complement)
-                    assert all(np.array_equal(a, b) for a, b in zip(ref_h, got_h)), (name, wide, reverse, complement)
-        finally:
-            os.environ.pop("ASGART_FORCE_WIDE", None)

@@ -2,12 +2,12 @@
 
 Every case is a small text made of tandem arrays (monomers of 3-400 bp, 20-400 copies, 0-10 % substitutions, one or
 two arrays, optionally an interleaved second copy of the first) between random flanks, searched direct and -RC with a
-random probe size / gap / minimum length, every segment with a multi-hit probe forced into tier 3 (the kernel with one
-barrier per probe, option k8 = 1; or K7 with k8 = 0), with a generation counter that wraps every few probes in some of
-the cases.  Results must equal the oracle's bit for bit.
+random probe size / gap / minimum length, every segment with a multi-hit probe forced into tier 3 (K8: the kernel with
+specialised waves and one barrier per probe), with a generation counter that wraps every few probes in some of the
+cases.  Results must equal the oracle's bit for bit.
 
-    python tools/fuzz_k8.py [cases=40] [first seed=0]        (ASGART_K8=0 for K7; FUZZ_SPLIT=len,warm,min: with the long
-                                                              segments cut into ranges of len probes -- option split)
+    python tools/fuzz_k8.py [cases=40] [first seed=0]        (FUZZ_SPLIT=len,warm,min: with the long segments cut into
+                                                              ranges of len probes -- option split)
 """
 import faulthandler
 import os

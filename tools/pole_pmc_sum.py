@@ -10,7 +10,7 @@ for f in glob.glob(out_dir + "/g*/**/*counter_collection.csv", recursive=True):
     per_dispatch = {}
     for row in csv.DictReader(open(f)):
         kn = row.get("Kernel_Name", "")
-        if not any(t in kn for t in ("extend_fast_kernel", "extend_arms_kernel", "extend_k7_kernel", "extend_k8_kernel")):
+        if not any(t in kn for t in ("extend_fast_kernel", "extend_k8_kernel")):
             continue
         key = row.get("Dispatch_Id")
         per_dispatch.setdefault(key, {"k": kn})[row["Counter_Name"]] = float(row["Counter_Value"])

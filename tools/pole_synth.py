@@ -19,8 +19,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import asgart_amd  # noqa: E402
 
-DEFAULTS = {"shard_lookback": 4096, "arms_kernel": 1, "prio3": 1, "kfilter_bits": 30, "long3": 16384, "long3_big": -1, "cap1": 256,
-            "test_cap_limit": -1, "test_levels": 4, "test_genbits": 22, "tier_order": 3654217, "tier_streams": 7234562, "cap6_pct": 140, "wg_items": 0, "wg_items12": 0, "early_cascade": 1, "progress_at": 2, "fast": 124, "cap3_pct": 160, "fast_bsh": 0, "posbits": 1, "shard_lpt": 0, "cap45_pct": 100, "solo": 1, "fast6w": 1, "cap6w_pct": 160, "k7": 8, "k8": 1}
+DEFAULTS = {"shard_lookback": 4096, "arms_kernel": 1, "kfilter_bits": 30, "long3": 16384, "cap1": 256,
+            "test_cap_limit": -1, "test_genbits": 22, "tier_order": 3654217, "cap6_pct": 140, "cap3_pct": 160, "posbits": 1,
+            "cap45_pct": 100, "solo": 1, "cap6w_pct": 160, "dense3": 16, "dense6": 32, "fuse_passes": 1, "barren": 2, "split": 1,
+            "split_len": 0, "split_warm": 6144, "split_min": 0, "split_runs": 224}
 
 
 def make_text(copies, sub, seed=5, flank=400_000):

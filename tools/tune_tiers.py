@@ -12,8 +12,10 @@ import asgart_amd  # noqa: E402
 from asgart_amd import prep, synth  # noqa: E402
 
 # option defaults (asgart_amd/csrc/index.hpp: struct Options); grid<t> = 0 means "default grid"
-DEFAULTS = {"shard_lookback": 4096, "arms_kernel": 1, "prio3": 1, "kfilter_bits": 30, "long3": 16384, "long3_big": -1, "cap1": 256,
-            "test_cap_limit": -1, "test_levels": 4, "test_genbits": 22, "tier_order": 3654217, "tier_streams": 7234562, "cap6_pct": 140, "wg_items": 0, "wg_items12": 0, "early_cascade": 1, "progress_at": 2, "fast": 124, "cap3_pct": 160, "fast_bsh": 0, "posbits": 1, "shard_lpt": 0, "cap45_pct": 100, "solo": 1, "fast6w": 1, "cap6w_pct": 160, "k7": 8, "k8": 1, "dense3": 16, "dense6": 32, "sparse_to6": 1, "pass_gate": 0, "filter": 0, "fuse_passes": 1, "dense_min": 0, "barren": 2, "split": 1, "split_len": 0, "split_warm": 6144, "split_min": 0, "split_runs": 224, "split_hw": 0}
+DEFAULTS = {"shard_lookback": 4096, "arms_kernel": 1, "kfilter_bits": 30, "long3": 16384, "cap1": 256,
+            "test_cap_limit": -1, "test_genbits": 22, "tier_order": 3654217, "cap6_pct": 140, "cap3_pct": 160, "posbits": 1,
+            "cap45_pct": 100, "solo": 1, "cap6w_pct": 160, "dense3": 16, "dense6": 32, "fuse_passes": 1, "barren": 2, "split": 1,
+            "split_len": 0, "split_warm": 6144, "split_min": 0, "split_runs": 224}
 
 
 def opt_name(key):  # "ASGART_GRID3" or "grid3" -> "grid3"
