@@ -20,7 +20,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 os.environ.setdefault("ASGART_LAZY_AUX", "0")
 LAZY_BOTH = {
     "test_battery_families_and_csr", "test_random_sweep_default_and_forced_tiers",
-    "test_passes_entry_point_equals_single_calls", "test_control_wave_kernel_in_every_workgroup_tier",
+    "test_passes_entry_point_equals_single_calls", "test_specialised_wave_kernel_with_generation_wraps",
     "test_escalation_tiers_give_identical_results", "test_shards_concatenate_to_unsharded",
     "test_progress_array_and_pipelined_calls", "test_k8_free_counts_do_not_depend_on_timing",
 }
