@@ -196,7 +196,7 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
         const bool seg_rev = (rp.mode_of(c) & 2u) != 0u;  // (the orientation of the chunk's pass)
         const uint32_t pb = rp.ch.pbase[c];
         const uint32_t chunk_end = rp.ch.pbase[c + 1];
-        const uint32_t g_end = min(chunk_end, rp.g_hi);
+        const uint32_t g_end = min(chunk_end, rp.win_end(g0));  // (sharded calls: the window ends first)
         // block-uniform bookkeeping
         uint32_t quiet = 0, pend = 0, fam_seq = 0, next_seq = 0, t_proc = 0, spur_until = 0;
         bool overflow = false, done = false, fam_open = false;

@@ -1082,7 +1082,8 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
             const uint64_t cs = rp.ch.start[c], cl = rp.ch.len[c];
             const uint32_t pb = rp.ch.pbase[c];
             const uint32_t chunk_end = rp.ch.pbase[c + 1];
-            const uint32_t g_end = RANGE ? min(min(chunk_end, rp.g_hi), run.g_stop) : min(chunk_end, rp.g_hi);
+            const uint32_t w_end = min(chunk_end, rp.win_end(g0));  // (sharded calls: the window ends first)
+            const uint32_t g_end = RANGE ? min(w_end, run.g_stop) : w_end;
             if (lane == 0) {
                 if constexpr (RANGE) s_end[3] = (uint32_t)wall_clock64();  // (the run's duration goes into its state: option debug)
                 s_seg[0] = g0;
@@ -1326,7 +1327,7 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
                     write_cmd(sc == 0u ? 2u : sc - 1u, p_after, Before{N(1), N(6), N(7), N(2), N(9), N(30), N(31)});
                     if ((p_after.flags & K7_LAST) && lane == 0) {  // (what the ranking wave needs when the segment is over)
                         s_end[0] = t_proc;
-                        s_end[1] = (!done && g_end < chunk_end && (!RANGE || min(chunk_end, rp.g_hi) == g_end)) ? 1u : 0u;
+                        s_end[1] = (!done && g_end < chunk_end && (!RANGE || w_end == g_end)) ? 1u : 0u;
                     }
                 }
                 if (npre & K7_STAGE) store_rows(st_tot, st_buf);

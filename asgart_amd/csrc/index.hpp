@@ -63,9 +63,17 @@ struct ChunkTable {
 
 struct RunParams {
     ChunkTable ch;
-    uint32_t g_lo, g_hi;  // probe window computed by this call (own range + halo)
-    uint32_t own_lo, own_hi;  // segments starting in [own_lo, own_hi) belong to this call
-    uint32_t init_unknown;    // 1: the automaton state just before g_lo is unknown (mid-chunk window)
+    // The probes this call computes: one WINDOW per pass, all of one length and one stride apart --
+    //     window w = [g_lo + w * win_stride, g_lo + w * win_stride + win_len),   w < n_passes
+    // An unsharded call: the windows are the passes themselves (win_len == win_stride == probes of a pass).  Shard r of
+    // n: every window is the r-th slice of its pass's probe sequence plus halos, and the call numbers its probes
+    // VIRTUALLY -- only the chunks a window touches keep their probes in ChunkTable::pbase (the others are empty there),
+    // so that the per-probe arrays span [g_lo, g_hi) with nothing but the cut chunks' remainders between the windows.
+    // Every kernel that walks probes maps tiles to windows (tile_of) or stops at its window's end (win_end).
+    uint32_t g_lo, g_hi;           // extent of the per-probe arrays: first probe of window 0, end of the last window
+    uint32_t win_len, win_stride;
+    uint32_t own_off_lo, own_off_hi;  // segments that start at window offsets [own_off_lo, own_off_hi) belong to this call
+    uint32_t init_unknown;         // 1: the automaton state in front of a window is unknown (the windows start mid-chunk)
     int k, step;
     uint32_t G;           // max_gap_size
     uint32_t tstar;       // ceil(G / step)
@@ -89,6 +97,29 @@ struct RunParams {
     }
     __host__ __device__ inline uint32_t mode_of_pass(uint32_t p) const { return (modes >> (8u * p)) & 3u; }
     __host__ __device__ inline uint32_t mode_of(int c) const { return mode_of_pass(pass_of(c)); }
+    // window of probe g (g_lo <= g < g_hi; a probe between two windows counts with the window in front of it)
+    __host__ __device__ inline uint32_t win_of(uint32_t g) const {
+        if (n_passes <= 1u) return 0u;
+        const uint32_t d = g - g_lo;
+        return (d >= win_stride ? 1u : 0u) + (d >= 2u * win_stride ? 1u : 0u) + (d >= 3u * win_stride ? 1u : 0u);
+    }
+    __host__ __device__ inline uint32_t win_lo(uint32_t w) const { return g_lo + w * win_stride; }
+    __host__ __device__ inline uint32_t win_end(uint32_t g) const { return win_lo(win_of(g)) + win_len; }
+    __host__ __device__ inline bool owned(uint32_t g) const {
+        const uint32_t off = g - win_lo(win_of(g));
+        return off >= own_off_lo && off < own_off_hi;
+    }
+    // Tiles of `tile` probes laid over the windows, window by window (a window's last tile may be partial):
+    // tile t -> its first probe, and through `end` the end of its window
+    __host__ __device__ inline uint32_t tiles_per_window(uint32_t tile) const { return (win_len + tile - 1u) / tile; }
+    __host__ __device__ inline uint32_t n_tiles(uint32_t tile) const { return n_passes * tiles_per_window(tile); }
+    __host__ __device__ inline uint32_t tile_of(uint32_t t, uint32_t tile, uint32_t &end) const {
+        const uint32_t tw = tiles_per_window(tile);
+        const uint32_t w = n_passes <= 1u ? 0u : (t >= tw ? 1u : 0u) + (t >= 2u * tw ? 1u : 0u) + (t >= 3u * tw ? 1u : 0u);
+        const uint32_t lo = win_lo(w);
+        end = lo + win_len;
+        return lo + (t - w * tw) * tile;
+    }
 };
 
 // One emitted duplication arm, keyed for the reference's output order (chunk order, discovery order
@@ -407,7 +438,7 @@ struct asgart_index {
     struct FuseVerdict {
         uint64_t k = 0, M = 0, C = 0, modes = 0;
         uint32_t G = 0;
-        int32_t n_passes = 0;
+        int32_t n_passes = 0, shard = 0, n_shards = 1;
         bool pipeline = false;
     } fuse_verdict;
     // segments a cut of which did not hold (option split): orientation << 32 | first probe counted from the start of its pass

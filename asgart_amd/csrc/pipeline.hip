@@ -192,7 +192,7 @@ static int32_t wd_event_sync(asgart_index *idx, SearchCtx &cx, hipEvent_t ev, co
 
 int32_t reserve_probe_workspace(asgart_index *idx, SearchCtx &cx, uint64_t W) {
     Workspace &w = cx.ws;
-    const uint64_t n_blk = (W + kScanTile - 1) / kScanTile;
+    const uint64_t n_blk = (W + kScanTile - 1) / kScanTile + 4;  // (every window of a call ends with a partial tile)
     RC_TRY(w.p_lo.reserve((size_t)W * (idx->wide ? 8 : 4)));
     RC_TRY(w.p_raw.reserve((size_t)W * 4));
     RC_TRY(w.p_filt.reserve((size_t)W * 4));
@@ -218,7 +218,7 @@ bool carve_probe_workspace(asgart_index *idx, const uint64_t *Wc) {
     for (int c = 0; c < kNumCtx; ++c) {
         Workspace &w = idx->ctx[c].ws;
         const uint64_t W = Wc[c];
-        const uint64_t n_blk = (W + kScanTile - 1) / kScanTile;
+        const uint64_t n_blk = (W + kScanTile - 1) / kScanTile + 4;
         DevBuf *bufs[7] = {&w.p_lo, &w.p_raw, &w.p_filt, &w.row_off, &w.blk, &w.big_list, &w.rank_list};
         const size_t want[7] = {(size_t)W * (idx->wide ? 8 : 4), (size_t)W * 4, (size_t)W * 4, ((size_t)W + 1) * 8,
                                 (size_t)n_blk * sizeof(ScanEl), (size_t)W * 4, (size_t)W * 4};
@@ -271,26 +271,28 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
     uint64_t *const h_len = h_start + n_chunks;
     uint32_t *const h_pbase = reinterpret_cast<uint32_t *>(h_len + n_chunks);
     char *const h_split = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(h_pbase + n_chunks + 1) + 63u) & ~(uintptr_t)63u);
-    uint64_t P64 = 0;
     const uint64_t text_end = (idx->h_tail.size() && idx->h_tail.back() == '$') ? n - 1 : n;
-    for (int64_t c = 0; c < n_chunks; ++c) {
-        h_start[c] = chunks[2 * (c % n_chunks_pass)];
-        h_len[c] = chunks[2 * (c % n_chunks_pass) + 1];
-        if (h_start[c] > text_end || h_len[c] > text_end - h_start[c]) {
-            set_error("chunk %lld = (%llu, %llu) exceeds the text (%llu bases before '$')",
-                      (long long)c, (unsigned long long)h_start[c], (unsigned long long)h_len[c],
-                      (unsigned long long)text_end);
-            return ASGART_E_ARG;
+    // probes of the chunk list, counted from the start of a pass (every pass walks the same list)
+    std::vector<uint32_t> lp((size_t)n_chunks_pass + 1);
+    {
+        uint64_t P64 = 0;
+        for (int64_t c = 0; c < n_chunks_pass; ++c) {
+            const uint64_t c_start = chunks[2 * c], c_len = chunks[2 * c + 1];
+            if (c_start > text_end || c_len > text_end - c_start) {
+                set_error("chunk %lld = (%llu, %llu) exceeds the text (%llu bases before '$')",
+                          (long long)c, (unsigned long long)c_start, (unsigned long long)c_len, (unsigned long long)text_end);
+                return ASGART_E_ARG;
+            }
+            lp[(size_t)c] = (uint32_t)P64;
+            P64 += probes_in_chunk(c_len, k, step, st->min_duplication_length);
+            if (P64 * (uint64_t)n_passes >= 0xFFFFFF00ull) {
+                set_error("more than 2^32 probes in one call");
+                return ASGART_E_CAP;
+            }
         }
-        h_pbase[c] = (uint32_t)P64;
-        P64 += probes_in_chunk(h_len[c], k, step, st->min_duplication_length);
-        if (P64 >= 0xFFFFFF00ull) {
-            set_error("more than 2^32 probes in one call");
-            return ASGART_E_CAP;
-        }
+        lp[(size_t)n_chunks_pass] = (uint32_t)P64;
     }
-    h_pbase[n_chunks] = (uint32_t)P64;
-    const uint32_t P = (uint32_t)P64;
+    const uint32_t Ppass = lp[(size_t)n_chunks_pass], P = Ppass * (uint32_t)n_passes;
     cx.last_P = P;
     memset(&cx.stats, 0, sizeof(cx.stats));
     cx.stats.probes_total = P;
@@ -306,24 +308,37 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
         hits_out->clear();
     }
     if (P == 0 || n_chunks == 0) return 0;
-    if (want_csr && n_shards != 1) {
-        set_error("asgart_probe_hits is not sharded");
+    if (want_csr && (n_shards != 1 || n_passes != 1)) {
+        set_error("asgart_probe_hits is one unsharded pass");
         return ASGART_E_ARG;
     }
-    // Multi-GPU sharding: shard r owns the automaton segments that START in its slice of the
-    // global probe sequence.  It computes probe-search over that slice plus a look-back halo
-    // (to decide whether its first probes continue an earlier segment) and a look-ahead halo
-    // (to finish segments that run past the slice); no data is exchanged between shards.
+    // Multi-GPU sharding: shard r owns the automaton segments that START in the r-th slice of EVERY pass's probe
+    // sequence (chunk order inside each pass as in src/bin/asgart.rs:201-253).  It computes, per pass, probe-search over
+    // that slice plus a look-back halo (to decide whether its first probes continue an earlier segment) and a look-ahead
+    // halo (to finish segments that run past the slice): one WINDOW per pass, all passes' windows as ONE job -- one front,
+    // one launch per extension tier.  No data is exchanged between shards.
     const Options opt = idx->opt;  // options cannot change while this call holds a context
-    const uint32_t own_lo = (uint32_t)((uint64_t)P * (uint64_t)shard / (uint64_t)n_shards);
-    const uint32_t own_hi = (uint32_t)((uint64_t)P * (uint64_t)(shard + 1) / (uint64_t)n_shards);
+    const uint32_t own_lo = (uint32_t)((uint64_t)Ppass * (uint64_t)shard / (uint64_t)n_shards);  // (from the start of a pass)
+    const uint32_t own_hi = (uint32_t)((uint64_t)Ppass * (uint64_t)(shard + 1) / (uint64_t)n_shards);
     if (own_lo == own_hi) return 0;
     uint64_t look_back = (uint64_t)opt.shard_lookback;
     uint64_t look_ahead = opt.shard_lookahead > 0 ? (uint64_t)opt.shard_lookahead
                                                   : std::max<uint64_t>(65536, (own_hi - own_lo) / 16);
-    auto chunk_of_host = [&](uint32_t g) {
-        return (int64_t)(std::upper_bound(h_pbase, h_pbase + n_chunks + 1, g) - h_pbase) - 1;
-    };
+    // The chunks a window can touch: c0 .. c1 of the list (a segment ends with its chunk).  The call numbers its probes
+    // VIRTUALLY (RunParams): these chunks keep their probes, the others are empty in the table it uploads -- pass p's kept
+    // probes are [p * K, (p + 1) * K), so probe g of the call is the (lo_lim + g - p * K)-th of pass p = g / K.
+    const int64_t c0 = (int64_t)(std::upper_bound(lp.begin(), lp.end(), own_lo) - lp.begin()) - 1;
+    const int64_t c1 = (int64_t)(std::upper_bound(lp.begin(), lp.end(), own_hi - 1u) - lp.begin()) - 1;
+    const uint32_t lo_lim = lp[(size_t)c0], hi_lim = lp[(size_t)c1 + 1], K = hi_lim - lo_lim;
+    for (int64_t c = 0; c < n_chunks; ++c) {
+        const int64_t cl = c % n_chunks_pass, p = c / n_chunks_pass;
+        h_start[c] = chunks[2 * cl];
+        h_len[c] = chunks[2 * cl + 1];
+        h_pbase[c] = (uint32_t)p * K + (std::min(std::max(lp[(size_t)cl], lo_lim), hi_lim) - lo_lim);
+    }
+    h_pbase[n_chunks] = (uint32_t)n_passes * K;
+    auto pass_of_probe = [&](uint32_t g) { return std::min<uint32_t>(g / K, (uint32_t)n_passes - 1u); };
+    auto pass_offset = [&](uint32_t g) { return lo_lim + (g - pass_of_probe(g) * K); };  // from the start of its pass
 
     RC_TRY(w.chunks.reserve(ch_bytes));
     uint64_t *d_start = w.chunks.as<uint64_t>();
@@ -341,20 +356,19 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
         set_error("internal: shard window did not converge");
         return ASGART_E_CAP;
     }
-    uint32_t w_lo = own_lo, w_hi = own_hi;
-    {
-        const int64_t c0 = chunk_of_host(own_lo), c1 = chunk_of_host(own_hi - 1);
-        const uint64_t lo_lim = h_pbase[c0], hi_lim = h_pbase[c1 + 1];
-        w_lo = (uint32_t)std::max<uint64_t>(lo_lim, own_lo > look_back ? own_lo - look_back : 0);
-        w_hi = (uint32_t)std::min<uint64_t>(hi_lim, (uint64_t)own_hi + look_ahead);
-        rp.init_unknown = w_lo != lo_lim ? 1u : 0u;
-    }
-    const uint32_t W = w_hi - w_lo;
+    // the window of a pass, counted from the start of the pass
+    const uint32_t w_lo = (uint32_t)std::max<uint64_t>(lo_lim, own_lo > look_back ? own_lo - look_back : 0);
+    const uint32_t w_hi = (uint32_t)std::min<uint64_t>(hi_lim, (uint64_t)own_hi + look_ahead);
+    rp.init_unknown = w_lo != lo_lim ? 1u : 0u;
     rp.ch = ChunkTable{d_start, d_len, d_pbase, (int)n_chunks};
-    rp.g_lo = w_lo;
-    rp.g_hi = w_hi;
-    rp.own_lo = own_lo;
-    rp.own_hi = own_hi;
+    rp.win_len = w_hi - w_lo;
+    rp.win_stride = K;
+    rp.g_lo = w_lo - lo_lim;
+    rp.g_hi = rp.g_lo + ((uint32_t)n_passes - 1u) * K + rp.win_len;
+    rp.own_off_lo = own_lo - w_lo;
+    rp.own_off_hi = own_hi - w_lo;
+    const uint32_t W = rp.g_hi - rp.g_lo;                     // extent of the per-probe arrays
+    const uint32_t W_probes = (uint32_t)n_passes * rp.win_len;  // probes the call computes
     rp.k = (int)k;
     rp.step = (int)step;
     rp.G = st->max_gap_size;
@@ -378,8 +392,8 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
     cx.has_last = false;
 
     // ---- workspace (indexed by absolute probe number through shifted pointers) ---
-    const uint32_t n_blk = (W + kScanTile - 1) / kScanTile;
-    const uint64_t seg_cap = (uint64_t)W / (rp.tstar + 1) + (uint64_t)n_chunks + 64;
+    const uint32_t n_blk = rp.n_tiles((uint32_t)kScanTile);
+    const uint64_t seg_cap = (uint64_t)W_probes / (rp.tstar + 1) + (uint64_t)n_chunks + 64;
     RC_TRY(reserve_probe_workspace(idx, cx, W));
     RC_TRY(w.seg_list.reserve((size_t)seg_cap * 4));
     RC_TRY(w.counters.reserve(CT_COUNT * 8));
@@ -392,10 +406,10 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
     };
 
     IndexView<SlotT> ix = idx->view<SlotT>();
-    SlotT *p_lo = w.p_lo.as<SlotT>() - w_lo;
-    uint32_t *p_raw = w.p_raw.as<uint32_t>() - w_lo;
-    uint32_t *p_filt = w.p_filt.as<uint32_t>() - w_lo;
-    unsigned long long *row_off = w.row_off.as<unsigned long long>() - w_lo;
+    SlotT *p_lo = w.p_lo.as<SlotT>() - rp.g_lo;
+    uint32_t *p_raw = w.p_raw.as<uint32_t>() - rp.g_lo;
+    uint32_t *p_filt = w.p_filt.as<uint32_t>() - rp.g_lo;
+    unsigned long long *row_off = w.row_off.as<unsigned long long>() - rp.g_lo;
     ScanEl *blk = w.blk.as<ScanEl>();
     uint32_t *big_list = w.big_list.as<uint32_t>();
     uint32_t *rank_list = w.rank_list.as<uint32_t>();
@@ -404,10 +418,10 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
     if (opt.test_stall_s > 0) stall_kernel<<<1, 64, 0, s>>>((unsigned long long)opt.test_stall_s * 100000000ull);
     // ---- K1: probe search + filtered counts -----------------------------------
     HIP_TRY(hipEventRecord(cx.ev[0], s));
-    probe_count_kernel<SlotT, false><<<grid_for(W, kProbeBlock), kProbeThreads, 0, s>>>(
+    probe_count_kernel<SlotT, false><<<rp.n_tiles((uint32_t)kProbeBlock), kProbeThreads, 0, s>>>(
         ix, rp, p_lo, p_raw, p_filt, big_list, rank_list, d_ctr);
     HIP_TRY(hipEventRecord(cx.ev[11], s));
-    collect_pending_kernel<<<std::min<uint32_t>((W + kCollectTile - 1) / kCollectTile, 256u * 8u), kCollectBlock, 0, s>>>(
+    collect_pending_kernel<<<std::min<uint32_t>(rp.n_tiles((uint32_t)kCollectTile), 256u * 8u), kCollectBlock, 0, s>>>(
         rp, p_filt, big_list, rank_list, d_ctr);
     big_count_kernel<SlotT, false><<<2048, 256, 0, s>>>(ix, rp, p_lo, p_raw, p_filt, big_list, d_ctr);
     // (after big_count_kernel: what it appends to big_list is for the fill only)
@@ -437,7 +451,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
     // ---- K3: CSR fill -----------------------------------------------------------
     RC_TRY(w.hits.reserve((size_t)(total_hits + 64) * sizeof(SlotT)));
     SlotT *hits = w.hits.as<SlotT>();
-    fill_small_kernel<SlotT><<<grid_for(W), 256, 0, s>>>(ix, rp, p_lo, p_raw, p_filt, row_off, hits);
+    fill_small_kernel<SlotT><<<rp.n_tiles(256u), 256, 0, s>>>(ix, rp, p_lo, p_raw, p_filt, row_off, hits);
     if (h_ctr[CT_BIG])
         fill_big_kernel<SlotT><<<2048, 256, 0, s>>>(ix, rp, p_lo, p_raw, p_filt, row_off, hits,
                                                     big_list, d_ctr);
@@ -604,8 +618,8 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                 std::lock_guard<std::mutex> lk(idx->mu);
                 for (const auto &b : idx->split_blocked)
                     for (int32_t p_ = 0; p_ < n_passes && sp.n_blocked < 64u; ++p_)
-                        if (((rp.modes >> (8 * p_)) & 0xFFu) == (uint32_t)(b.key >> 32)) {
-                            sp.blocked[sp.n_blocked] = h_pbase[(int64_t)p_ * n_chunks_pass] + (uint32_t)b.key;
+                        if (((rp.modes >> (8 * p_)) & 0xFFu) == (uint32_t)(b.key >> 32) && (uint32_t)b.key >= lo_lim && (uint32_t)b.key < hi_lim) {
+                            sp.blocked[sp.n_blocked] = (uint32_t)p_ * K + ((uint32_t)b.key - lo_lim);
                             sp.blocked_len[sp.n_blocked] = b.range_len;
                             sp.allowed[sp.n_blocked++] = (uint16_t)std::min<uint32_t>(b.allowed, 0xFFFFu);
                         }
@@ -979,8 +993,8 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                 std::vector<uint32_t> held_base;  // family-ordinal bases of the ranges whose records wait for their segment's last run
                 std::vector<Tail> tails;
                 auto remember = [&](uint32_t g_seg0, uint32_t allowed) {
-                    const int64_t p_ = chunk_of_host(g_seg0) / n_chunks_pass;
-                    const uint64_t key_ = (uint64_t)((rp.modes >> (8 * p_)) & 0xFFu) << 32 | (uint64_t)(g_seg0 - h_pbase[p_ * n_chunks_pass]);
+                    const uint32_t p_ = pass_of_probe(g_seg0);
+                    const uint64_t key_ = (uint64_t)((rp.modes >> (8 * p_)) & 0xFFu) << 32 | (uint64_t)pass_offset(g_seg0);
                     const uint32_t len_ = (uint32_t)h_split_hdr[4];
                     std::lock_guard<std::mutex> lk(idx->mu);
                     for (auto &b : idx->split_blocked)
@@ -1225,7 +1239,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                 if (h_recs[f0].g_start == kVoidStart) break;  // unused slots of the waves' record chunks: sorted last
                 size_t f1 = f0;
                 while (f1 < n_hrec && h_recs[f1].g_start == h_recs[f0].g_start && h_recs[f1].fam_seq == h_recs[f0].fam_seq) ++f1;
-                while (pass + 1 < n_passes && h_recs[f0].g_start >= h_pbase[(int64_t)(pass + 1) * n_chunks_pass]) ++pass;
+                while (pass + 1 < n_passes && h_recs[f0].g_start >= (uint32_t)(pass + 1) * K) ++pass;
                 if (h_recs[f1 - 1].create_seq != kTombstone) {
                     std::vector<asgart_proto_sd> &sds = out.sds[pass];
                     for (size_t j = f0; j < f1; ++j) {
@@ -1233,7 +1247,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                         sds.push_back(h_recs[j].sd);
                     }
                     out.ends[pass].push_back(sds.size());
-                    out.keys[pass].push_back(((uint64_t)(h_recs[f0].g_start - h_pbase[(int64_t)pass * n_chunks_pass]) << 32) |
+                    out.keys[pass].push_back(((uint64_t)(lo_lim + (h_recs[f0].g_start - (uint32_t)pass * K)) << 32) |
                                              (uint64_t)h_recs[f0].fam_seq);
                 }
                 f0 = f1;
@@ -1333,8 +1347,8 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
     return 0;
 }
 
-// n_passes > 1: ONE job over the probes of all passes (sts differ in reverse / complement only, n_shards == 1;
-// checked by the caller); fams: n_passes result objects, or null (the CSR surface of a single pass).
+// n_passes > 1: ONE job over the probes of all passes (sts differ in reverse / complement only; checked by the caller);
+// fams: n_passes result objects, or null (the CSR surface of a single pass).
 int32_t run_search_passes(asgart_index *idx, const uint64_t *chunks, int64_t n_chunks,
                           const asgart_settings *sts, int32_t n_passes, int32_t shard, int32_t n_shards, bool want_csr,
                           asgart_families *const *fams, std::vector<uint8_t> *status_out,
@@ -1350,7 +1364,7 @@ int32_t run_search_passes(asgart_index *idx, const uint64_t *chunks, int64_t n_c
         set_error("max_gap_size must be >= 1 (it includes probe_size, src/bin/asgart.rs:681)");
         return ASGART_E_ARG;
     }
-    if (n_shards < 1 || shard < 0 || shard >= n_shards || (n_passes > 1 && (n_shards != 1 || want_csr || progress))) {
+    if (n_shards < 1 || shard < 0 || shard >= n_shards || (n_passes > 1 && (want_csr || progress))) {
         set_error("bad shard %d of %d", shard, n_shards);
         return ASGART_E_ARG;
     }
@@ -1571,11 +1585,12 @@ int32_t asgart_search_duplications_passes_shard(asgart_index *idx, const uint64_
     // share one probe sequence (pass 0's chunks, then pass 1's, ...: chunk order inside each pass as in
     // src/bin/asgart.rs:201-253): ONE probe search, scan, hit-row fill and placement over all their probes at full chip
     // rate, ONE launch per extension tier over the merged cost-sorted segment list -- every pass's longest segments
-    // start at t = 0 of the extension on compute units of their own.  (Pipelined as two calls on two contexts -- below,
-    // kept for sharded calls and passes with different settings -- the second pass's front crawled behind the first
-    // one's persistent extension workgroups: 117 ms instead of 28 at GRCh38 size.)
+    // start at t = 0 of the extension on compute units of their own.  A SHARDED call is the same job over the shard's slice
+    // of every pass (run_search_t: one window per pass).  (Pipelined as two calls on two contexts -- below, kept for
+    // passes with different settings and for inputs whose extension is ONE segment -- the second pass's front crawled
+    // behind the first one's persistent extension workgroups: 117 ms instead of 28 at GRCh38 size.)
     {
-        bool fusable = idx->opt.fuse_passes != 0 && n_passes >= 2 && n_passes <= 4 && n_shards == 1;  // (option fuse_passes)
+        bool fusable = idx->opt.fuse_passes != 0 && n_passes >= 2 && n_passes <= 4;  // (option fuse_passes)
         for (int32_t j = 1; fusable && j < n_passes; ++j)
             fusable = settings[j].probe_size == settings[0].probe_size && settings[j].max_gap_size == settings[0].max_gap_size &&
                       settings[j].min_duplication_length == settings[0].min_duplication_length &&
@@ -1593,7 +1608,8 @@ int32_t asgart_search_duplications_passes_shard(asgart_index *idx, const uint64_
         auto same_as_verdict = [&]() {
             const asgart_index::FuseVerdict &v = idx->fuse_verdict;
             return v.n_passes == n_passes && v.k == settings[0].probe_size && v.G == settings[0].max_gap_size &&
-                   v.M == settings[0].min_duplication_length && v.C == settings[0].max_cardinality && v.modes == modes_sig;
+                   v.M == settings[0].min_duplication_length && v.C == settings[0].max_cardinality && v.modes == modes_sig &&
+                   v.shard == shard && v.n_shards == n_shards;
         };
         if (fusable && idx->opt.fuse_passes == 1) {  // what the last fused call with these settings measured decides
             std::lock_guard<std::mutex> lk(idx->mu);
@@ -1614,8 +1630,8 @@ int32_t asgart_search_duplications_passes_shard(asgart_index *idx, const uint64_
                     return ASGART_E_OOM;
                 }
             }
-            const int32_t rc = run_search_passes(idx, chunks, n_chunks, settings, n_passes, 0, 1, false, fams.data(), nullptr,
-                                                 nullptr, nullptr, nullptr);
+            const int32_t rc = run_search_passes(idx, chunks, n_chunks, settings, n_passes, shard, n_shards, false, fams.data(),
+                                                 nullptr, nullptr, nullptr, nullptr);
             if (rc != 0) {
                 for (auto *f : fams) delete f;
                 return rc;
@@ -1631,6 +1647,8 @@ int32_t asgart_search_duplications_passes_shard(asgart_index *idx, const uint64_
                 v.M = settings[0].min_duplication_length;
                 v.C = settings[0].max_cardinality;
                 v.modes = modes_sig;
+                v.shard = shard;
+                v.n_shards = n_shards;
                 v.pipeline = stt.passes == (uint64_t)n_passes && stt.ms_extend > 0.0 &&
                              stt.ms_longest_segment * 100.0 > stt.ms_extend * (double)idx->opt.fuse_pole_pct;
                 if (idx->opt.debug)
@@ -1767,7 +1785,7 @@ int32_t asgart_get_stats(asgart_index *idx, uint32_t flags, asgart_stats *out) {
                 rp.pbits[p] = idx->opt.posbits ? idx->d_pbits[rp.mode_of_pass(p)] : nullptr;
             }
             rp.flt_bits = idx->filter_bits;
-            const unsigned g = grid_for(rp.g_hi - rp.g_lo);
+            const unsigned g = rp.n_tiles(256u);
             if (idx->wide)
                 yardstick_kernel<uint64_t><<<g, 256, 0, s>>>(idx->view<uint64_t>(), rp,
                                                              cx.ws.p_filt.as<uint32_t>() - rp.g_lo, d_ctr);
@@ -1780,7 +1798,7 @@ int32_t asgart_get_stats(asgart_index *idx, uint32_t flags, asgart_stats *out) {
             // call left in the workspace
             HIP_TRY(hipMemsetAsync(d_ctr + CT_ALG_BYTES, 0, 16, s));
             HIP_TRY(hipMemsetAsync(d_ctr + CT_ALG_BYTES16, 0, 8, s));
-            const unsigned gp = grid_for(rp.g_hi - rp.g_lo, kProbeBlock);
+            const unsigned gp = rp.n_tiles((uint32_t)kProbeBlock);
             auto account = [&](auto slot_tag) {
                 using SlotT = decltype(slot_tag);
                 IndexView<SlotT> ix = idx->view<SlotT>();

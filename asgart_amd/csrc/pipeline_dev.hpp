@@ -166,8 +166,9 @@ __global__ __launch_bounds__(kProbeThreads) void probe_count_kernel(IndexView<Sl
     typename std::conditional<COUNT, CountBytes, NoBytes>::type cb;
     const uint32_t lane = threadIdx.x;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    const uint32_t gb = rp.g_lo + blockIdx.x * (uint32_t)kProbeBlock;  // first probe of the workgroup
-    const uint32_t g_last = min(gb + (uint32_t)kProbeBlock, rp.g_hi) - 1u;
+    uint32_t g_end;  // end of the tile's window
+    const uint32_t gb = rp.tile_of(blockIdx.x, (uint32_t)kProbeBlock, g_end);  // first probe of the workgroup
+    const uint32_t g_last = min(gb + (uint32_t)kProbeBlock, g_end) - 1u;
     const int k = rp.k, H = rp.step;
     // one chunk for the whole workgroup (all but a handful of workgroups): staged window
     const int c0 = chunk_of_uniform(rp.ch, gb);
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(kProbeThreads) void probe_count_kernel(IndexView<Sl
         for (int u = 0; u < kProbeSub; ++u) {
             const uint32_t t = lane + (uint32_t)u * kProbeThreads, g = gb + t;
             bool survivor = false;
-            if (g < rp.g_hi) {
+            if (g < g_end) {
                 const uint64_t q = key_of(t);
                 const uint32_t first = (uint32_t)(q >> (3 * (k - 1))) & 7u;
                 bool pass = true;
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(kProbeThreads) void probe_count_kernel(IndexView<Sl
 #pragma unroll 1
         for (int u = 0; u < kProbeSub; ++u) {
             const uint32_t g = gb + lane + (uint32_t)u * kProbeThreads;
-            if (g >= rp.g_hi) continue;
+            if (g >= g_end) continue;
             const int c = chunk_of(rp.ch, g);
             const uint32_t pass_c = rp.pass_of(c), md = rp.mode_of_pass(pass_c);
             const bool reverse = (md & 2u) != 0u, complement = (md & 1u) != 0u;
@@ -386,8 +387,7 @@ __global__ __launch_bounds__(kCollectBlock) void collect_pending_kernel(RunParam
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     if (tid < 2) s_cnt[tid] = 0;
     __syncthreads();
-    const uint32_t W = rp.g_hi - rp.g_lo;
-    const uint32_t n_tiles = (W + (uint32_t)kCollectTile - 1u) / (uint32_t)kCollectTile;
+    const uint32_t n_tiles = rp.n_tiles((uint32_t)kCollectTile);
     // a contiguous run of tiles per workgroup (the lists then follow the probe order in long stretches)
     const uint32_t t0 = (uint32_t)((uint64_t)n_tiles * blockIdx.x / gridDim.x);
     const uint32_t t1 = (uint32_t)((uint64_t)n_tiles * (blockIdx.x + 1u) / gridDim.x);
@@ -403,11 +403,12 @@ __global__ __launch_bounds__(kCollectBlock) void collect_pending_kernel(RunParam
         __syncthreads();
     };
     for (uint32_t t = t0; t < t1; ++t) {
-        const uint32_t g0 = rp.g_lo + t * (uint32_t)kCollectTile;
+        uint32_t g_end;
+        const uint32_t g0 = rp.tile_of(t, (uint32_t)kCollectTile, g_end);
 #pragma unroll
         for (int a = 0; a < kCollectItems; ++a) {
             const uint32_t g = g0 + (uint32_t)a * kCollectBlock + tid;  // coalesced
-            const uint32_t f = g < rp.g_hi ? p_filt[g] : 0u;
+            const uint32_t f = g < g_end ? p_filt[g] : 0u;
             const bool big = f == kPending, rank = f == kPendingRank;
             const unsigned long long mb = __ballot(big), mr = __ballot(rank);
             if (mb) {
@@ -596,12 +597,17 @@ __global__ __launch_bounds__(256) void big_count_kernel(IndexView<SlotT> ix, Run
 
 // ---------------------------------------------------------------- K2 ---------
 // Scan element.  hits: running CSR offset.  (has, c, reset): "quiet count since
-// the last probe with hits, reset at chunk starts" monoid.
+// the last probe with hits, reset at chunk starts" monoid.  A window that starts mid-chunk (sharded calls) begins with
+// a reset of its own, marked "unknown": what the automaton held in front of it is not known, and stays unknown until
+// the first hit-probe or real chunk start behind it.
 struct ScanEl {
     unsigned long long hits;
     uint32_t c;      // processed probes after the last hit-probe (or all, if none)
-    uint32_t flags;  // bit0 = contains a hit-probe, bit1 = contains a chunk start
+    uint32_t flags;  // bit0 = contains a hit-probe, bit1 = contains a reset (chunk start / window start), bit2 = the LAST
+                     // reset is a window start in mid-chunk (the combine below hands it on with the reset it belongs to)
 };
+// "no hit-probe since a window started in mid-chunk": c is only a lower bound of the quiet run
+__device__ inline bool scan_unknown(const ScanEl &e) { return (e.flags & 5u) == 4u; }
 
 __device__ inline ScanEl scan_identity() { return ScanEl{0ull, 0u, 0u}; }
 
@@ -621,13 +627,14 @@ __device__ inline ScanEl scan_combine(const ScanEl &a, const ScanEl &b) {
     return r;
 }
 
-__device__ inline ScanEl scan_element(uint32_t filt, bool chunk_first) {
+// first: 0 = inside a chunk, 1 = first probe of a chunk, 2 = first probe of a window that starts in mid-chunk
+__device__ inline ScanEl scan_element(uint32_t filt, uint32_t first) {
     ScanEl e;
     const bool skipped = filt >= kPending;
     const bool hit = !skipped && filt > 0;
     e.hits = hit ? filt : 0u;
     e.c = (!skipped && !hit) ? 1u : 0u;
-    e.flags = (hit ? 1u : 0u) | (chunk_first ? 2u : 0u);
+    e.flags = (hit ? 1u : 0u) | (first ? 2u : 0u) | (first == 2u ? 4u : 0u);
     return e;
 }
 
@@ -669,21 +676,23 @@ __device__ inline ScanEl block_exclusive_scan(ScanEl v, ScanEl *sh, ScanEl *bloc
 // LDS so that each thread can then walk its kScanItems consecutive probes without strided global
 // accesses or a per-thread chunk bisection.
 __device__ inline void stage_scan_tile(const RunParams &rp, const uint32_t *__restrict__ p_filt,
-                                       uint32_t tile_g0, uint32_t *s_f, uint8_t *s_first) {
+                                       uint32_t tile_g0, uint32_t g_end, uint32_t *s_f, uint8_t *s_first) {
     for (uint32_t idx = threadIdx.x; idx < (uint32_t)kScanTile; idx += kScanBlock) {
         const uint32_t g = tile_g0 + idx;
-        s_f[scan_pos(idx)] = g < rp.g_hi ? p_filt[g] : kSkipN;
+        s_f[scan_pos(idx)] = g < g_end ? p_filt[g] : kSkipN;
         s_first[scan_pos(idx)] = 0;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const uint32_t tile_end = tile_g0 + (uint32_t)kScanTile;
+        const uint32_t tile_end = min(tile_g0 + (uint32_t)kScanTile, g_end);
         for (int c = chunk_of(rp.ch, tile_g0); c < rp.ch.n_chunks; ++c) {
             const uint32_t pb = rp.ch.pbase[c];
             if (pb >= tile_end) break;
             // only non-empty chunks have a first probe
             if (pb >= tile_g0 && rp.ch.pbase[c + 1] > pb) s_first[scan_pos(pb - tile_g0)] = 1;
         }
+        // (the first tile of a window that starts in mid-chunk: a reset of its own kind)
+        if (rp.init_unknown && tile_g0 + rp.win_len == g_end) s_first[0] = 2;
     }
     __syncthreads();
 }
@@ -695,7 +704,7 @@ __device__ inline ScanEl load_thread_items(const uint32_t *s_f, const uint8_t *s
     for (int a = 0; a < kScanItems; ++a) {
         const uint32_t f = s_f[i0 + a];
         // probes past the end of the window were staged as skipped: identity elements
-        items[a] = scan_element(f, s_first[i0 + a] != 0);
+        items[a] = scan_element(f, (uint32_t)s_first[i0 + a]);
         agg = scan_combine(agg, items[a]);
     }
     return agg;
@@ -708,7 +717,9 @@ __global__ __launch_bounds__(kScanBlock) void scan_reduce_kernel(RunParams rp,
     __shared__ uint32_t s_f[kScanTilePad];
     __shared__ uint8_t s_first[kScanTilePad];
     ScanEl items[kScanItems];
-    stage_scan_tile(rp, p_filt, rp.g_lo + blockIdx.x * (uint32_t)kScanTile, s_f, s_first);
+    uint32_t g_end;
+    const uint32_t tile_g0 = rp.tile_of(blockIdx.x, (uint32_t)kScanTile, g_end);
+    stage_scan_tile(rp, p_filt, tile_g0, g_end, s_f, s_first);
     ScanEl agg = load_thread_items(s_f, s_first, items);
     ScanEl total;
     (void)block_exclusive_scan(agg, sh, &total);
@@ -785,24 +796,17 @@ __global__ __launch_bounds__(kScanBlock) void scan_down_kernel(RunParams rp,
     };
     for (uint32_t tile = blockIdx.x; tile < n_blk; tile += gridDim.x) {
         ScanEl items[kScanItems];
-        const uint32_t tile_g0 = rp.g_lo + tile * (uint32_t)kScanTile;
+        uint32_t g_end;
+        const uint32_t tile_g0 = rp.tile_of(tile, (uint32_t)kScanTile, g_end);
         const uint32_t g0 = tile_g0 + i0;
-        stage_scan_tile(rp, p_filt, tile_g0, s_f, s_first);
+        stage_scan_tile(rp, p_filt, tile_g0, g_end, s_f, s_first);
         ScanEl agg = load_thread_items(s_f, s_first, items);
         ScanEl total;
         ScanEl excl = block_exclusive_scan(agg, sh, &total);
         ScanEl run = scan_combine(blk[tile], excl);
-        if (rp.init_unknown) {
-            // Window starts mid-chunk: prepend "state unknown" (bit2).  It is cleared by a chunk
-            // start or a hit-probe; while set, `c` is only a lower bound of the quiet run.
-            ScanEl init{0ull, 0u, 4u};
-            ScanEl r2 = scan_combine(init, run);
-            r2.flags = (r2.flags & 3u) | ((run.flags & 3u) ? 0u : 4u);
-            run = r2;
-        }
         for (int a = 0; a < kScanItems; ++a) {
             const uint32_t g = g0 + a;
-            const bool valid = g < rp.g_hi;
+            const bool valid = g < g_end;
             bool start = false;
             if (valid) {
                 const uint32_t f = s_f[scan_pos(i0) + a];
@@ -814,18 +818,17 @@ __global__ __launch_bounds__(kScanBlock) void scan_down_kernel(RunParams rp,
                     if (f == kSkipCard) ++st_card;
                     else if (hit) ++st_hit;
                 }
-                if (hit && g >= rp.own_lo && g < rp.own_hi) {
-                    const bool chunk_first = items[a].flags & 2u;
-                    const bool has_before = !chunk_first && (run.flags & 1u);
-                    const bool unknown = !chunk_first && (run.flags & 4u);
-                    if (unknown && run.c < rp.tstar) atomicAdd(&ctr[CT_AMBIG], 1ull);
-                    start = !has_before || run.c >= rp.tstar;
+                if (hit && rp.owned(g)) {
+                    // (a window's first probe is never owned when the window starts in mid-chunk: the look-back halo is
+                    // at least one probe; so `run` -- the probes in front of g -- lies in g's window)
+                    const bool win_first = (items[a].flags & 4u) != 0u, chunk_first = (items[a].flags & 6u) == 2u;
+                    const bool has_before = !chunk_first && !win_first && (run.flags & 1u);
+                    const bool unknown = win_first || (!chunk_first && scan_unknown(run));
+                    const uint32_t quiet = win_first ? 0u : run.c;
+                    if (unknown && quiet < rp.tstar) atomicAdd(&ctr[CT_AMBIG], 1ull);
+                    start = !has_before || quiet >= rp.tstar;
                 }
-                {
-                    const uint32_t keep_unknown = (run.flags & 4u) && !(items[a].flags & 3u) ? 4u : 0u;
-                    run = scan_combine(run, items[a]);
-                    run.flags = (run.flags & 3u) | keep_unknown;
-                }
+                run = scan_combine(run, items[a]);
             }
             const unsigned long long m = __ballot(start);
             if (m) {
@@ -836,12 +839,13 @@ __global__ __launch_bounds__(kScanBlock) void scan_down_kernel(RunParams rp,
                 if (start) s_start[base + __popcll(m & ((1ull << lane) - 1ull))] = g;
             }
         }
-        if (g0 < rp.g_hi && g0 + kScanItems >= rp.g_hi) row_off[rp.g_hi] = run.hits;
+        // (the row offset behind a window's last probe: what the CSR holds up to there)
+        if (g0 < g_end && g0 + kScanItems >= g_end) row_off[g_end] = run.hits;
         __syncthreads();
         // coalesced write-out of the row offsets and coalesced read of the interval sizes (stats)
         for (uint32_t idx = threadIdx.x; idx < (uint32_t)kScanTile; idx += kScanBlock) {
             const uint32_t g = tile_g0 + idx;
-            if (g < rp.g_hi) {
+            if (g < g_end) {
                 row_off[g] = s_row[scan_pos(idx)];
                 if (s_f[scan_pos(idx)] != kSkipN) st_raw += p_raw[g];
             }
@@ -883,11 +887,13 @@ __global__ __launch_bounds__(256) void fill_small_kernel(IndexView<SlotT> ix, Ru
                                                          const uint32_t *__restrict__ p_filt,
                                                          const unsigned long long *__restrict__ row_off,
                                                          SlotT *__restrict__ hits) {
-    const uint32_t g = rp.g_lo + blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t g_end;
+    const uint32_t gb = rp.tile_of(blockIdx.x, 256u, g_end);
+    const uint32_t g = gb + threadIdx.x;
     // (the chunk of the workgroup's first probe, once, in scalar registers; a thread whose probe lies behind a chunk boundary
     // steps on from there -- 256 consecutive probes rarely span two chunks -- instead of bisecting the table per thread)
-    int c = chunk_of_uniform(rp.ch, min(rp.g_lo + blockIdx.x * blockDim.x, rp.g_hi - 1u));
-    if (g >= rp.g_hi) return;
+    int c = chunk_of_uniform(rp.ch, gb);
+    if (g >= g_end) return;
     const uint32_t f = p_filt[g];
     if (f == 0 || f >= kPending) return;
     const uint32_t raw = p_raw[g];
@@ -1242,7 +1248,7 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
         const bool seg_rev = (rp.mode_of(c) & 2u) != 0u;  // (the orientation of the chunk's pass)
         const uint32_t pb = rp.ch.pbase[c];
         const uint32_t chunk_end = rp.ch.pbase[c + 1];
-        const uint32_t g_end = min(chunk_end, rp.g_hi);
+        const uint32_t g_end = min(chunk_end, rp.win_end(g0));  // (sharded calls: the window ends first)
 
         // live arms: lane j holds arm j while in_regs (A <= 64), else s_*[0..A)
         PosT r_ls = 0, r_le = 0, r_rs = 0, r_re = 0;
@@ -1758,8 +1764,8 @@ __global__ __launch_bounds__(64) void seg_stats_lanes_kernel(RunParams rp, const
         if (have) {
             g0 = seg_list[sidx];
             const uint32_t chunk_end = rp.ch.pbase[chunk_of(rp.ch, g0) + 1];
-            g_end = min(chunk_end, rp.g_hi);
-            window_cut = rp.g_hi < chunk_end;
+            g_end = min(chunk_end, rp.win_end(g0));
+            window_cut = g_end < chunk_end;
         }
         for (uint32_t r = 0; r < RW; ++r) s_ring[r * 64u + lane] = 0;
         uint32_t quiet = 0, mx = 0, bound = 0, n_probes = 0, wsum = 0, head = 0, steps = 0, g = g0, n_hit = 0;
@@ -1835,8 +1841,8 @@ __global__ __launch_bounds__(64) void seg_stats_kernel(RunParams rp, const uint3
         const uint64_t sidx = idx_list ? (uint64_t)idx_list[item] : item;
         const uint32_t g0 = seg_list[sidx];
         const int c = chunk_of_uniform(rp.ch, g0);
-        const uint32_t g_end = min(rp.ch.pbase[c + 1], rp.g_hi);
-        const bool window_cut = rp.g_hi < rp.ch.pbase[c + 1];
+        const uint32_t g_end = min(rp.ch.pbase[c + 1], rp.win_end(g0));
+        const bool window_cut = g_end < rp.ch.pbase[c + 1];
         uint32_t quiet = 0, mx = 0, bound = 0, n_probes = 0, n_hit = 0, g_stop = g_end;
         unsigned long long sum = 0;
         bool done = false;
@@ -2431,7 +2437,7 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
         const bool seg_rev = (rp.mode_of(c) & 2u) != 0u;  // (the orientation of the chunk's pass)
         const uint32_t pb = rp.ch.pbase[c];
         const uint32_t chunk_end = rp.ch.pbase[c + 1];
-        const uint32_t g_end = min(chunk_end, rp.g_hi);
+        const uint32_t g_end = min(chunk_end, rp.win_end(g0));  // (sharded calls: the window ends first)
         // block-uniform state: A live arms in slots [0,H), n_free of them empty (on s_free)
         uint32_t A = 0, H = 0, n_free = 0, quiet = 0, fam_seq = 0, next_seq = 0;
         uint32_t t_proc = 0, spur_until = 0;  // see extend_kernel
@@ -2847,9 +2853,10 @@ template <class SlotT>
 __global__ __launch_bounds__(256) void yardstick_kernel(IndexView<SlotT> ix, RunParams rp,
                                                         const uint32_t *__restrict__ p_filt,
                                                         unsigned long long *__restrict__ ctr) {
-    const uint32_t g = rp.g_lo + blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t g_end;
+    const uint32_t g = rp.tile_of(blockIdx.x, 256u, g_end) + threadIdx.x;
     unsigned long long steps = 0;
-    if (g < rp.g_hi && p_filt[g] != kSkipN) {
+    if (g < g_end && p_filt[g] != kSkipN) {
         const int c = chunk_of(rp.ch, g);
         const uint64_t s = rp.ch.start[c], L = rp.ch.len[c];
         const uint64_t i = (uint64_t)(g - rp.ch.pbase[c] + 1) * (uint64_t)rp.step;

@@ -413,25 +413,37 @@ def main():
         issue(mode)
     sequential = mode == "back_to_back"
 
+    # All ranks on ONE device (ASGART_BENCH_ONE_DEVICE, a 1-GPU box): the ranks take turns -- rank r runs its shard of a
+    # step while the others wait at a barrier -- so that per_rank_ms is what each rank's shard costs ALONE on a GPU (what
+    # its own GPU would see); ms_per_step is then the SUM of the turns, not a multi-GPU time, and the line says so.
+    take_turns = world > 1 and bool(os.environ.get("ASGART_BENCH_ONE_DEVICE"))
     sync()
     t0 = time.perf_counter()
     search_ms = 0.0
     probe_count_ms = 0.0
     n_launch = 0
+    own_elapsed = 0.0
     phase_ms = {"search": 0.0, "scan": 0.0, "fill": 0.0, "extend": 0.0, "extend_tier2": 0.0, "longest_tier": 0.0,
                 "longest_segment": 0.0}
     for _ in range(args.steps):
-        results, per_call = issue(mode)
+        for turn in (range(world) if take_turns else (rank,)):
+            if turn == rank:
+                t_own = time.perf_counter()
+                results, per_call = issue(mode)
+                own_elapsed += time.perf_counter() - t_own   # this rank's share, before it waits for the others
+            if take_turns:
+                sync()
         if world > 1:
             # the only exchange of the path: duplicon lists -> rank 0 over RCCL
+            t_own = time.perf_counter()
             results = [gather(r_) for r_ in results]
+            own_elapsed += time.perf_counter() - t_own
         n_launch += len(per_call)
         for s in per_call:
             search_ms += s.ms_search
             probe_count_ms += s.ms_probe_count
             for ph in phase_ms:
                 phase_ms[ph] += getattr(s, "ms_" + ph)
-    own_elapsed = time.perf_counter() - t0   # this rank's share, before it waits for the others
     sync()
     elapsed = time.perf_counter() - t0
     per_rank_ms = [round(own_elapsed / args.steps * 1e3, 3)]
@@ -517,23 +529,31 @@ def main():
                                       max(1, sum(s["probes_searched"] for s in pass_stats)), 4),
     }
 
-    # Scaling model: sharding divides a pass's front (probe search, scans, hit rows) and the
-    # throughput part of its extension by N, never its longest tier -- the longest serial automaton segment.  The
-    # fronts of the passes of a step follow one another, their extensions run side by side.
+    # Scaling model.  Rank r of N runs shard r -- the r-th slice of every pass, all passes as one job --
+    # alone on its own GPU, and a step lasts as long as its slowest rank: model_ms(N) = max_r shard_ms(N, r), the shards
+    # timed ONE AFTER THE OTHER ON ONE GPU by tools/shard_check.py (profiles/r06_<workload>_shards.json, committed with the
+    # library hash it was measured on).  Not in it: the gather of the result lists to rank 0 (tens of MB over xGMI) and the
+    # barrier.  NO 1 -> N curve has been measured on N GPUs by the builder (one GPU per gpurun call).
     model = None
+    spath = os.path.join(ROOT, "profiles", f"r06_{args.workload}_shards.json")
+    if rank == 0 and os.path.exists(spath):
+        try:
+            sh = json.load(open(spath))
+            model = {"source": os.path.relpath(spath, ROOT), "measured_on_build": sh.get("library_build"),
+                     "from_this_build": sh.get("library_build") == lib_hash,
+                     "formula": "model_ms(N) = max_r shard_ms(N, r): every shard of a step timed alone on one GPU "
+                                "(tools/shard_check.py); gather and barrier not included",
+                     "curve_measured_on_n_gpus": False}
+            for n_, e_ in sorted(sh.get("n", {}).items(), key=lambda kv: int(kv[0])):
+                model[f"n{n_}_ms"] = e_["max_ms"]
+                model[f"n{n_}_shard_ms"] = [s_["ms"] for s_ in e_["shards"]]
+        except Exception as exc:   # (a damaged file must not cost the bench line)
+            model = {"error": f"{spath}: {exc}"}
     if rank == 0 and whole:
-        fronts = [w_["ms_search"] + w_["ms_scan"] + w_["ms_fill"] for w_ in whole]
-        # the serial floor of a job's extension is its longest single SEGMENT (asgart_stats.ms_longest_segment: measured per
-        # workgroup on the device); the tier that finishes last (ms_longest_tier) is throughput when it holds many segments
-        floor = [w_.get("ms_longest_segment") or w_["ms_longest_tier"] for w_ in whole]
-        model = {
-            "inputs_one_gpu_ms": [{"front": round(f_, 2), "extend": round(w_["ms_extend"], 2),
-                                   "longest_tier": round(w_["ms_longest_tier"], 2), "longest_segment": round(fl_, 2)}
-                                  for f_, w_, fl_ in zip(fronts, whole, floor)],
-            "formula": "sum_j front_j / N + max_j max(longest_segment_j, extend_j / N)   (j: the jobs of a step -- one when the passes are fused)",
-        }
-        for n_ in sorted({1, 2, 4, 8, world}):
-            model[f"n{n_}_ms"] = round(sum(fronts) / n_ + max(max(fl_, w_["ms_extend"] / n_) for w_, fl_ in zip(whole, floor)), 2)
+        model = model or {}
+        model["one_gpu_phases_ms"] = [{"front": round(w_["ms_search"] + w_["ms_scan"] + w_["ms_fill"], 2),
+                                       "extend": round(w_["ms_extend"], 2),
+                                       "longest_segment": round(w_.get("ms_longest_segment") or 0.0, 2)} for w_ in whole]
 
     out = {
         "metric": "Mbp/s probe+extend (direct+RC, k=20 g=100)",
@@ -562,6 +582,10 @@ def main():
         "per_rank_phases_ms_per_step": per_rank_phase if world > 1 else None,
         "model_ms": (model or {}).get(f"n{world}_ms"),
         "scaling_model": model,
+        "ranks_take_turns_on_one_device": take_turns or None,
+        # a host that runs every orientation ONCE per index (the reference: src/bin/asgart.rs:738-757) sees the first call
+        "first_call_ms": round(t_first * 1e3, 2),
+        "first_call_mbps": round(total_bp * passes / t_first / 1e6, 1),
         "cold_s": round(cold_s, 3),
         "index_build_s": {"upload_and_suffix_array": round(t_sa, 3), "broadcast_to_ranks": round(t_bc, 3),
                           "keys_and_tables": round(t_index, 3),

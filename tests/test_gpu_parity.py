@@ -503,6 +503,13 @@ def _check_against_oracle_digest(name):
             for w_, (offs, sds) in zip(wants, got_all):
                 assert _sha_slabs([offs], "<u8") == w_["fam_offsets_sha256"], (name, "fused")
                 assert _sha_slabs([sds], "<u8") == w_["sds_sha256"], (name, "fused")
+            # ... and as R sharded jobs (what N GPUs run: shard r = the r-th slice of every pass), merged by key
+            R = 8 if name == "cfg4" else 3
+            parts = [idx.search_duplications_passes(pr.chunks, sts, shard=r, n_shards=R, with_keys=True) for r in range(R)]
+            for j, w_ in enumerate(wants):
+                offs, sds = asgart_amd.merge_shards([p_[j] for p_ in parts])
+                assert _sha_slabs([offs], "<u8") == w_["fam_offsets_sha256"], (name, "fused shards", R)
+                assert _sha_slabs([sds], "<u8") == w_["sds_sha256"], (name, "fused shards", R)
 
 
 @pytest.mark.parametrize("kind", ["dna", "bytes", "runs", "dna-batched", "runs-batched"])
@@ -1338,6 +1345,16 @@ def test_long_segments_as_ranges_equal_whole_segments(hiplib, shape):
             mo, ms = asgart_amd.merge_shards(parts)
             assert np.array_equal(mo, whole[0][0]) and np.array_equal(ms, whole[0][1]), (seed, shape, "3 shards")
             sharded_cut += n_cut
+            # ... and so does a sharded call over BOTH orientations as one job: shard r takes slice r of each pass
+            for R in (2, 3, 8):
+                parts2 = []
+                for r in range(R):
+                    parts2.append(idx.search_duplications_passes(chunks, sts, shard=r, n_shards=R, with_keys=True))
+                    assert idx.stats().passes == 2, (seed, shape, R, r)
+                for j in range(2):
+                    mo, ms = asgart_amd.merge_shards([q[j] for q in parts2])
+                    assert np.array_equal(mo, whole[j][0]) and np.array_equal(ms, whole[j][1]), (seed, shape, R, "fused shards", j)
+                    assert np.array_equal(np.sort(np.concatenate([q[j][2] for q in parts2])), whole[j][2]), (seed, shape, R, "keys", j)
     assert sharded_cut > 0, shape
     assert joined > 0 and refused > 0, (shape, joined, refused)
 
@@ -1363,6 +1380,18 @@ def test_fused_passes_equal_single_calls_keys_included(hiplib, name):
             for j, g in zip(sel, got):
                 for a, b in zip(g, single[j]):
                     assert np.array_equal(a, b), (name, sel, j)
+        # SHARDED: shard r of R runs the r-th slice of EVERY pass as one job (one window per pass); the shards' families merged
+        # by key -- or concatenated in shard order -- are each pass's own result, keys included
+        for R, sel in ((2, [0, 3]), (3, [3, 0]), (8, [0, 3]), (3, [0, 1, 2, 3]), (61, [2, 3])):
+            parts = []
+            for r in range(R):
+                parts.append(idx.search_duplications_passes(pr.chunks, [sts[j] for j in sel], shard=r, n_shards=R, with_keys=True))
+                assert idx.stats().as_dict()["passes"] == len(sel), (name, R, r)
+            for q, j in enumerate(sel):
+                mo, ms = asgart_amd.merge_shards([p_[q] for p_ in parts])
+                assert np.array_equal(mo, single[j][0]) and np.array_equal(ms, single[j][1]), (name, R, sel, j)
+                assert np.array_equal(np.concatenate([p_[q][1] for p_ in parts]), single[j][1]), (name, R, sel, j, "rank order")
+                assert np.array_equal(np.concatenate([p_[q][2] for p_ in parts]), single[j][2]), (name, R, sel, j, "keys")
         other = asgart_amd.RunSettings.from_cli(reverse=True, complement=True, **dict(cli, min_length=cli.get("min_length", 1000) + 7))
         got = idx.search_duplications_passes(pr.chunks, [sts[0], other], with_keys=True)
         assert idx.stats().as_dict()["passes"] == 1      # different settings: two pipelined calls
