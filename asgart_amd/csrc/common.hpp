@@ -107,6 +107,11 @@ struct TeardownWorker {
         return w;
     }
 };
+// fn() on the worker, waited for at most limit_s seconds COUNTED FROM WHEN IT STARTS TO RUN: the queue is shared by every
+// index and device of the process, and a slow but healthy job of another caller ahead of this one (a hipFree of tens of
+// GB) must not make this caller give up on -- and leak -- a healthy index.  While the job waits in the queue the caller
+// waits with it, up to ten limits in all (the job ahead has a caller of its own who bounds it).  The worker is marked
+// stuck only when the caller's OWN job overran.
 template <class F>
 inline bool bounded_call(double limit_s, F fn) {
     if (limit_s <= 0.0) {
@@ -116,13 +121,20 @@ inline bool bounded_call(double limit_s, F fn) {
     struct State {
         std::mutex m;
         std::condition_variable cv;
-        bool done = false;
+        bool done = false, started = false;
+        std::chrono::steady_clock::time_point t_start;
     };
     auto st = std::make_shared<State>();
     std::shared_ptr<TeardownWorker> w = TeardownWorker::current();
     {
         std::lock_guard<std::mutex> lk(w->m);
         w->q.emplace_back([st, fn]() mutable {
+            {
+                std::lock_guard<std::mutex> lk2(st->m);
+                st->started = true;
+                st->t_start = std::chrono::steady_clock::now();
+            }
+            st->cv.notify_all();
             fn();
             {
                 std::lock_guard<std::mutex> lk2(st->m);
@@ -132,14 +144,38 @@ inline bool bounded_call(double limit_s, F fn) {
         });
     }
     w->cv.notify_all();
+    const auto limit = std::chrono::duration_cast<std::chrono::steady_clock::duration>(std::chrono::duration<double>(limit_s));
+    const auto t_queued = std::chrono::steady_clock::now();
     std::unique_lock<std::mutex> lk(st->m);
-    const bool ok = st->cv.wait_for(lk, std::chrono::duration<double>(limit_s), [&] { return st->done; });
+    bool overran = false;
+    while (!st->done) {
+        if (st->started) {
+            if (!st->cv.wait_until(lk, st->t_start + limit, [&] { return st->done; })) {
+                overran = true;
+                break;
+            }
+        } else {
+            st->cv.wait_for(lk, std::chrono::milliseconds(50), [&] { return st->done || st->started; });
+            if (!st->started && std::chrono::steady_clock::now() - t_queued > 10 * limit) break;  // (never got its turn)
+        }
+    }
+    const bool ok = st->done;
     lk.unlock();
-    if (!ok) {
+    if (overran) {
         std::lock_guard<std::mutex> lk2(w->m);
         w->stuck = true;
     }
     return ok;
+}
+// fn() on the worker, not waited for at all (housekeeping that must not hold a caller: giving cached blocks back)
+template <class F>
+inline void background_call(F fn) {
+    std::shared_ptr<TeardownWorker> w = TeardownWorker::current();
+    {
+        std::lock_guard<std::mutex> lk(w->m);
+        w->q.emplace_back(fn);
+    }
+    w->cv.notify_all();
 }
 
 #define RC_TRY(expr)            \

@@ -113,7 +113,6 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
 
     __shared__ __attribute__((aligned(16))) unsigned long long s_tab[2][kRows * kE];
     __shared__ PosT s_hits[HB];
-    __shared__ uint8_t s_hflag[HB];
     __shared__ uint32_t s_best[3][HB];
     __shared__ unsigned long long s_stash[3][kStash];
     __shared__ uint32_t s_nstash[3];
@@ -125,7 +124,7 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
     // when the arm is reported; the right start is read when the arm dies.  Out of the registers they buy a fifth layer.
     __shared__ PosT s_cle[CAP], s_crs[CAP];
     // Bookkeeping of the automaton that every wave keeps in scalar registers (creation counter, family ordinal, open
-    // family, spur horizon): wave 0 publishes it after each B; a wave that skipped the hit ranking of a probe (it could
+    // family): wave 0 publishes it after each B; a wave that skipped the hit ranking of a probe (it could
     // not be concerned: see phase B) re-reads it before the next B it takes part in.
     __shared__ __attribute__((aligned(16))) uint32_t s_pub[2][4];
     // after a run of probes that wave 0 went through alone (see solo_probe): position in the batch, probes processed,
@@ -153,7 +152,6 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
     const uint32_t kGenBits = min(kGenMax, max(2u, P.gen_bits));
     const uint32_t cap_eff = min((uint32_t)CAP, P.cap_limit);
     const WinT w_loop = (WinT)(kRowsLoop - 1u) << bsh;  // windows up to this width span <= kRowsLoop rows
-    const bool use_flag = P.hit_flag != nullptr;
     RecAlloc rec_alloc;
     wg_begin(P);
     PROF_DECL;
@@ -198,7 +196,7 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
         const uint32_t chunk_end = rp.ch.pbase[c + 1];
         const uint32_t g_end = min(chunk_end, rp.win_end(g0));  // (sharded calls: the window ends first)
         // block-uniform bookkeeping
-        uint32_t quiet = 0, pend = 0, fam_seq = 0, next_seq = 0, t_proc = 0, spur_until = 0;
+        uint32_t quiet = 0, pend = 0, fam_seq = 0, next_seq = 0;
         bool overflow = false, done = false, fam_open = false;
         bool ran_full = true;  // this wave took part in the previous probe's hit ranking (its bookkeeping is current)
         // "solo" probes: while every live arm sits in wave 0's first layer and a probe's few hits cannot overfill it,
@@ -407,7 +405,7 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
 
         // one hit-probe in flight: the probe whose offers have been made and whose B is still to run
         struct Probe {
-            uint32_t cnt, off, t_before, t_after, tb, bb;
+            uint32_t cnt, off, tb, bb;
             uint64_t i;
         };
         // ---- B of probe q: resolve, age / retire, create --------------------------------------------------
@@ -435,7 +433,6 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
             const uint32_t base0 = lane_of(fincl - fv, wave);  // rank of this wave's first layer-0 slot
             const bool full = wave == 0u || !(base0 >= cnt && cnt <= total_free && A0 + cnt <= cap_eff);
             uint32_t n_new = 0;
-            bool spur = false;
             unsigned long long m0 = 0;
             if (full) {
                 if (!ran_full) {  // bookkeeping as of the end of the previous probe
@@ -443,9 +440,8 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
                     next_seq = uni(pv.x);
                     fam_seq = uni(pv.y);
                     fam_open = (uni(pv.z) & 1u) != 0u;
-                    spur_until = uni(pv.w);
                 }
-                if (fam_open && A0 == 0 && q.t_before >= spur_until) {  // the flush of src/automaton.rs:182-200
+                if (fam_open && A0 == 0) {  // the flush of src/automaton.rs:182-200
                     ++fam_seq;
                     next_seq = 0;
                     fam_open = false;
@@ -453,18 +449,14 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
                 // unmatched hits, in hit order (= creation order, src/automaton.rs:151-164)
                 const uint32_t h_l = min((uint32_t)lane, cnt - 1u);
                 const uint32_t bv0 = s_best[bb][h_l];
-                const uint8_t hf0 = use_flag ? s_hflag[off + h_l] : (uint8_t)1;
                 const bool in0 = (uint32_t)lane < cnt;
-                m0 = __ballot(in0 && bv0 == kNone && hf0 != 0);  // group 0 stays in registers
+                m0 = __ballot(in0 && bv0 == kNone);  // group 0 stays in registers
                 n_new = (uint32_t)__popcll(m0);
-                spur = use_flag && __ballot(in0 && bv0 == kNone && hf0 == 0) != 0ull;
                 for (uint32_t h0 = 64u, gi = 1; h0 < cnt; h0 += 64u, ++gi) {  // (most probes have <= 64 hits)
                     const uint32_t h = min(h0 + (uint32_t)lane, cnt - 1u);
                     const bool in = h0 + (uint32_t)lane < cnt;
                     const bool un = in && s_best[bb][h] == kNone;
-                    const bool hf = use_flag ? s_hflag[off + h] != 0 : true;
-                    const unsigned long long nm = __ballot(un && hf);
-                    if (use_flag) spur = spur || __ballot(un && !hf) != 0ull;
+                    const unsigned long long nm = __ballot(un);
                     s_newmask[wave][gi] = nm;
                     n_new += (uint32_t)__popcll(nm);
                 }
@@ -611,16 +603,15 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
             if (full) {
                 next_seq += n_new;
                 fam_open = true;
-                if (spur) spur_until = max(spur_until, q.t_after + rp.tstar - 1u);
                 if (wave == 0u)  // (every lane, same 16 bytes)
-                    *reinterpret_cast<uint4 *>(&s_pub[q.tb][0]) = make_uint4(next_seq, fam_seq, 1u, spur_until);
+                    *reinterpret_cast<uint4 *>(&s_pub[q.tb][0]) = make_uint4(next_seq, fam_seq, 1u, 0u);
             }
             ran_full = full;
             {   // what the next probe can count on (every wave: from the free counts and cnt alone)
                 const uint32_t free00 = lane_of(fv, 0u);  // empty slots of (layer 0, wave 0)
                 solo_w0 = total_free - free00 == (uint32_t)CAP - 64u && cnt <= free00;  // (the new arms fit there too)
                 solo_a = 64u - free00 + cnt;
-                want_migrate = kSoloHits != 0u && !use_flag && !solo_w0 && A0 + cnt <= 60u;  // (few arms, some astray)
+                want_migrate = kSoloHits != 0u && !solo_w0 && A0 + cnt <= 60u;  // (few arms, some astray)
             }
             PROF_STOP(7);
         };
@@ -718,7 +709,7 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
                 a_seq[0] = dead ? kNoSeq : a_seq[0];
                 live = live && !dead;
             }
-            if (fam_open && !__ballot(live) && q.t_before >= spur_until) {  // the flush of src/automaton.rs:182-200
+            if (fam_open && !__ballot(live)) {  // the flush of src/automaton.rs:182-200
                 ++fam_seq;
                 next_seq = 0;
                 fam_open = false;
@@ -824,10 +815,7 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
             if (tot) {  // (a batch of quiet probes stages nothing and needs no barrier)
                 if (staged_before) lds_barrier();  // (the last B of the previous batch read the staged hits)
                 staged_before = true;
-                for (uint32_t r = tid; r < tot; r += NT) {
-                    s_hits[r] = P.hits[base + r];
-                    if (use_flag) s_hflag[r] = P.hit_flag[base + r];
-                }
+                for (uint32_t r = tid; r < tot; r += NT) s_hits[r] = P.hits[base + r];
                 lds_barrier();
             }
             const unsigned long long in_batch = nbb >= 64 ? ~0ull : ((1ull << nbb) - 1ull);
@@ -837,11 +825,11 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
             PROF_COUNT(1, 1);
             uint32_t pos = 0;
             bool pre_indexed = false, have_prev = false;
-            Probe prev{0, 0, 0, 0, 0, 0, 0};
+            Probe prev{0, 0, 0, 0, 0};
             for (;;) {
                 // ---- the next hit-probe of the batch; the quiet probes before it only age ----------
                 bool have_cur = false;
-                Probe cur{0, 0, 0, 0, 0, 0, 0};
+                Probe cur{0, 0, 0, 0, 0};
                 if (!done) {
                     const unsigned long long hmr = pos >= 64 ? 0ull : (hm >> pos) << pos;
                     const uint32_t b = hmr ? (uint32_t)(__ffsll((long long)hmr) - 1) : 64u;
@@ -850,7 +838,6 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
                     const uint32_t q = (uint32_t)__popcll(qm & upto & from);
                     if (q) {  // folded into the next pass over the arms
                         quiet += q;
-                        t_proc += q;
                         pend += q * step;
                         if (quiet >= rp.tstar) done = true;  // every arm is dead (gap >= G): the segment is over
                     }
@@ -861,8 +848,6 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
                         cur.cnt = lane_of(f_l, b);
                         cur.off = lane_of(rel_l, b);
                         cur.i = (uint64_t)(g + b - pb + 1) * step;
-                        cur.t_before = t_proc;
-                        cur.t_after = ++t_proc;
                         cur.tb = par;
                         cur.bb = tri;
                     } else {
@@ -878,7 +863,7 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
                 if (!have_cur) break;
                 PROF_COUNT(5, 1);
                 PROF_COUNT(11, cur.cnt);
-                if (solo_w0 && !use_flag && cur.cnt <= kSoloHits && solo_a + cur.cnt <= 64u) {
+                if (solo_w0 && cur.cnt <= kSoloHits && solo_a + cur.cnt <= 64u) {
                     // wave 0 alone; the others wait for its count at the barrier and will re-read the bookkeeping
                     if (pre_indexed) {  // (this probe was indexed ahead for nothing: forget its stash)
                         if (tid == 0) s_nstash[tri] = 0u;
@@ -899,22 +884,19 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
                             if (q >= rp.tstar) break;  // (the segment ends there: left to the workgroup)
                             const uint32_t cnt2 = lane_of(f_l, b);
                             if (cnt2 > kSoloHits || a_now + cnt2 > 64u) break;
-                            t_proc += q;
                             pend = q * step;
-                            Probe nx{0, 0, 0, 0, 0, 0, 0};
+                            Probe nx{0, 0, 0, 0, 0};
                             nx.cnt = cnt2;
                             nx.off = lane_of(rel_l, b);
                             nx.i = (uint64_t)(g + b - pb + 1) * step;
-                            nx.t_before = t_proc;
-                            nx.t_after = ++t_proc;
                             pos = b + 1;
                             a_now = solo_probe(nx);
                             if (lane == 0) DBG_ADD(0, 1);
                         }
                         // (every lane, same words) what the other waves need: how far this went, the live count, and
                         // the bookkeeping for their next B
-                        *reinterpret_cast<uint4 *>(&s_run[solo_par][0]) = make_uint4(pos, t_proc, a_now, 0u);
-                        const uint4 pv = make_uint4(next_seq, fam_seq, 1u, spur_until);
+                        *reinterpret_cast<uint4 *>(&s_run[solo_par][0]) = make_uint4(pos, 0u, a_now, 0u);
+                        const uint4 pv = make_uint4(next_seq, fam_seq, 1u, 0u);
                         *reinterpret_cast<uint4 *>(&s_pub[0][0]) = pv;
                         *reinterpret_cast<uint4 *>(&s_pub[1][0]) = pv;
                     } else {
@@ -925,7 +907,6 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
                     {
                         const uint4 rv = *reinterpret_cast<const uint4 *>(&s_run[solo_par][0]);
                         pos = uni(rv.x);
-                        t_proc = uni(rv.y);
                         solo_a = uni(rv.z);
                     }
                     solo_par ^= 1u;
@@ -997,7 +978,7 @@ __global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
                 const uint32_t fv2 = lane + 64 < S * NW ? s_free[par][(lane + 64) % NW][(lane + 64) / NW] : 0u;
                 total_free += lane_of(wave_incl_scan(fv2), 63u);
             }
-            if (fam_open && total_free == (uint32_t)CAP && t_proc >= spur_until) fam_open = false;
+            if (fam_open && total_free == (uint32_t)CAP) fam_open = false;
             if (!done && g_end < chunk_end) {
                 if (tid == 0) atomicAdd(&P.ctr[CT_RANOUT], 1ull);
             } else if (fam_open) {  // arms alive at the end of the chunk void their family (src/automaton.rs:201-203)

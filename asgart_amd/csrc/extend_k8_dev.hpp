@@ -150,7 +150,6 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
 
     __shared__ __attribute__((aligned(16))) unsigned long long s_tab[2][kRows * kE];
     __shared__ PosT s_hits[3 * HB];
-    __shared__ uint8_t s_hflag[3 * HB];
     __shared__ __attribute__((aligned(16))) uint32_t s_best[3][HB];
     __shared__ unsigned long long s_stash[3][kStash];
     __shared__ uint32_t s_rowbits[3][kRows / 32];
@@ -177,7 +176,7 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
     __shared__ __attribute__((aligned(16))) uint32_t s_mid[8];         // before the loop: the first batch's staging request
     __shared__ PosT s_cle[CAP], s_crs[CAP];                            // cold fields of an arm, by slot
     __shared__ unsigned long long s_seg[3];                            // g0, chunk start, chunk length (for the records)
-    __shared__ uint32_t s_end[4];                                      // planning wave -> ranking wave, at the end of a segment: processed probes, done, ran out
+    __shared__ uint32_t s_end[4];                                      // planning wave -> ranking wave, at the end of a segment: [1] ran out of the window; [3] start time of a run
     __shared__ unsigned long long s_bcast;
     __shared__ uint32_t s_sink[64];
     __shared__ uint32_t s_never;
@@ -186,7 +185,6 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6);
     const bool is_rank = wave == (uint32_t)NWA, is_plan = wave == (uint32_t)(NWA + 1);
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    const bool use_flag = P.hit_flag != nullptr;
     RecAlloc rec_alloc;
     wg_begin(P);
     K7T_DECL;
@@ -320,23 +318,18 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
         };
         constexpr int kPf = (HB + NT - 1) / NT;
         PosT pf_x[kPf];
-        uint8_t pf_f[kPf];
         auto fetch_rows = [&](unsigned long long base, uint32_t tot) {
 #pragma unroll
             for (int j = 0; j < kPf; ++j) {
                 const uint32_t r = (uint32_t)tid + (uint32_t)(j * NT);
                 pf_x[j] = r < tot ? P.hits[base + r] : (PosT)0;
-                pf_f[j] = (use_flag && r < tot) ? P.hit_flag[base + r] : (uint8_t)0;
             }
         };
         auto store_rows = [&](uint32_t tot, uint32_t buf) {
 #pragma unroll
             for (int j = 0; j < kPf; ++j) {
                 const uint32_t r = (uint32_t)tid + (uint32_t)(j * NT);
-                if (r < tot) {
-                    s_hits[buf * (uint32_t)HB + r] = pf_x[j];
-                    if (use_flag) s_hflag[buf * (uint32_t)HB + r] = pf_f[j];
-                }
+                if (r < tot) s_hits[buf * (uint32_t)HB + r] = pf_x[j];
             }
         };
         // The offers of ONE window per lane to the hits of a probe (the lanes with `who`): the table walk of K6 / K7 --
@@ -801,7 +794,7 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
 #ifdef ASGART_PROFILE_EXTEND
             const unsigned long long k7_seg0 = __builtin_amdgcn_s_memtime();
 #endif
-            uint32_t fam_seq = 0, next_seq = 0, spur_until = 0;
+            uint32_t fam_seq = 0, next_seq = 0;
             bool fam_open = false;
             lds_barrier();  // (1)
             {
@@ -835,7 +828,7 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
                 const bool have_prev = (flags & K7_PREV) != 0u, has_cur = (flags & K7_CUR) != 0u;
                 const bool more = !(flags & K7_LAST);
                 const uint32_t nflags = more ? N(0) : 0u;
-                const uint32_t prev_cnt = C(11), prev_off = C(14), prev_bb = C(23), prev_t_before = C(28), prev_t_after = C(29);
+                const uint32_t prev_cnt = C(11), prev_off = C(14), prev_bb = C(23);
                 const uint32_t bsh = C(19);
                 K7T_MARK();
                 K7T_STEP();
@@ -867,10 +860,8 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
                     if (have_prev) {
                         const uint32_t h_l = min((uint32_t)lane, prev_cnt - 1u);
                         const uint32_t bv0 = s_best[prev_bb][h_l];
-                        const uint8_t hf0 = use_flag ? s_hflag[prev_off + h_l] : (uint8_t)1;
                         const PosT x0 = s_hits[prev_off + h_l];
                         uint32_t bv1 = kNone, bv2 = kNone;
-                        uint8_t hf1 = 1, hf2 = 1;
                         PosT x1 = 0, x2 = 0;
                         if (prev_cnt > 64u) {
                             const uint32_t h1 = min(64u + (uint32_t)lane, prev_cnt - 1u), h2 = min(128u + (uint32_t)lane, prev_cnt - 1u);
@@ -878,10 +869,6 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
                             bv2 = s_best[prev_bb][h2];
                             x1 = s_hits[prev_off + h1];
                             x2 = s_hits[prev_off + h2];
-                            if (use_flag) {
-                                hf1 = s_hflag[prev_off + h1];
-                                hf2 = s_hflag[prev_off + h2];
-                            }
                         }
                         // (one scan for both halves of the entries: two 16-bit fields, each total < 2^16)
                         const uint32_t packed = wave_incl_scan(av1 | (av2 << 16));
@@ -901,16 +888,15 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
                         k7_sum_cnt += prev_cnt;
                         ++k7_sum_n;
 #endif
-                        if (fam_open && A0 == 0 && prev_t_before >= spur_until) {  // the flush of src/automaton.rs:182-200
+                        if (fam_open && A0 == 0) {  // the flush of src/automaton.rs:182-200
                             if (!RANGE || C(12) >= emit_from_i) ++fam_seq;  // (RANGE: the flushes from the cut on)
                             next_seq = 0;
                             fam_open = false;
                         }
                         // unmatched hits, in hit order (= creation order, src/automaton.rs:151-164) -> s_newx[rank]
-                        bool spur = false;
-                        auto rank_group = [&](uint32_t h0, uint32_t bv, uint8_t hf, PosT x) {
+                        auto rank_group = [&](uint32_t h0, uint32_t bv, PosT x) {
                             const bool in = h0 + (uint32_t)lane < prev_cnt;
-                            const bool un = in && bv == kNone && hf != 0;
+                            const bool un = in && bv == kNone;
                             const unsigned long long m = __ballot(un);
                             const uint32_t at = n_new + (uint32_t)__popcll(m & lt_mask);
                             if (un && at < kNewMax) {
@@ -918,22 +904,20 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
                                 if constexpr (RANGE) s_newh[sp][at] = (uint16_t)(h0 + (uint32_t)lane);
                             }
                             n_new += (uint32_t)__popcll(m);
-                            if (use_flag) spur = spur || __ballot(in && bv == kNone && hf == 0) != 0ull;
                         };
-                        rank_group(0u, bv0, hf0, x0);
+                        rank_group(0u, bv0, x0);
                         if (prev_cnt > 64u) {
-                            rank_group(64u, bv1, hf1, x1);
-                            if (prev_cnt > 128u) rank_group(128u, bv2, hf2, x2);
+                            rank_group(64u, bv1, x1);
+                            if (prev_cnt > 128u) rank_group(128u, bv2, x2);
                         }
                         for (uint32_t h0 = 192u; h0 < prev_cnt; h0 += 64u) {
                             const uint32_t h = min(h0 + (uint32_t)lane, prev_cnt - 1u);
-                            rank_group(h0, s_best[prev_bb][h], use_flag ? s_hflag[prev_off + h] : (uint8_t)1, s_hits[prev_off + h]);
+                            rank_group(h0, s_best[prev_bb][h], s_hits[prev_off + h]);
                         }
                         if (n_new > total_av || n_new > kNewMax || A0 + n_new > cap_eff) pflags |= K8_OVF;
                         seq_base = RANGE ? (C(12) - i_seg0) << 10 : next_seq;
                         next_seq += n_new;
                         fam_open = true;
-                        if (spur) spur_until = max(spur_until, prev_t_after + rp.tstar - 1u);
                     }
                     // the quiet probes between the previous probe and this step's age its new arms before they can match
                     const uint64_t g_new = (uint64_t)step + C(8);
@@ -955,7 +939,7 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
                                 uint32_t *m = P.run_meta + seg * 16ull + 8ull;
                                 m[1] = 0u;
                                 m[2] = fam_open ? 1u : 0u;
-                                m[3] = spur_until > C(30) ? spur_until - C(30) : 0u;
+                                m[3] = 0u;  // (no flush is ever held back: every unmatched hit becomes an arm)
                             }
                         }
                     }
@@ -1035,7 +1019,6 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
                     const uint32_t fv2 = lane + 64 < NE ? fr[(lane + 64) % NWA][(lane + 64) / NWA] : 0u;
                     total_free += lane_of(wave_incl_scan(fv2), 63u);
                 }
-                const uint32_t t_proc = uni(s_end[0]);
                 const bool ran_out = uni(s_end[1]) != 0u;
                 if constexpr (RANGE) {
                     // the family state this run ends in: flushes since the cut, open or not, how long a flush is still held back
@@ -1043,11 +1026,11 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
                         uint32_t *m = P.run_meta + seg * 16ull;
                         m[1] = fam_seq;
                         m[2] = fam_open ? 1u : 0u;
-                        m[3] = spur_until > t_proc ? spur_until - t_proc : 0u;
+                        m[3] = 0u;
                         m[5] = (uint32_t)wall_clock64() - s_end[3];  // (10-ns ticks)
                     }
                 }
-                if (fam_open && total_free == (uint32_t)CAP && t_proc >= spur_until) fam_open = false;
+                if (fam_open && total_free == (uint32_t)CAP) fam_open = false;
                 if (RANGE && !(run.flags & kRunLast)) {
                     // (the segment goes on behind this run: its end is the last range's business)
                 } else if (ran_out) {
@@ -1090,7 +1073,7 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
                 s_seg[1] = cs;
                 s_seg[2] = cl | ((unsigned long long)((rp.mode_of(c) >> 1) & 1u) << 63);
             }
-            uint32_t quiet = 0, pend = 0, t_proc = 0;
+            uint32_t quiet = 0, pend = 0;
             bool done = false, giveup = false;
             uint32_t hbuf = 2;  // (the first batch moves it to 0)
             // ---- the batch under the cursor ---------------------------------------------------------------------
@@ -1121,7 +1104,7 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
                 return true;
             };
             struct Probe {
-                uint32_t cnt, off, tb, bb, g10, pend, t_before, t_after;
+                uint32_t cnt, off, tb, bb, g10, pend;
                 uint64_t i;
             };
             struct Plan {
@@ -1130,7 +1113,7 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
                 uint32_t st_tot, st_buf;
                 Probe q;
             };
-            const Probe no_probe{0, 0, 0, 0, 0, 0, 0, 0, 0};
+            const Probe no_probe{0, 0, 0, 0, 0, 0, 0};
             bool opened = false;  // the probe just found opened a batch (its rows are to be staged)
             auto next_probe = [&](Probe &nx) -> bool {
                 for (;;) {
@@ -1141,7 +1124,6 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
                     const uint32_t q = (uint32_t)__popcll(qm & upto & from);
                     if (q) {
                         quiet += q;
-                        t_proc += q;
                         pend += q * step;
                         if (quiet >= rp.tstar) {  // every arm is dead (gap >= G): the segment is over
                             done = true;
@@ -1162,8 +1144,6 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
                         nx.i = (uint64_t)(g + b - pb + 1) * step;
                         nx.pend = pend;
                         pend = 0;
-                        nx.t_before = t_proc;
-                        nx.t_after = ++t_proc;
                         return true;
                     }
                     g += nbb;
@@ -1241,7 +1221,7 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
                 return p;
             };
             struct Before {
-                uint32_t cnt, i_lo, i_hi, off, bb, t_before, t_after;
+                uint32_t cnt, i_lo, i_hi, off, bb;
             };
             auto write_cmd = [&](uint32_t slot, const Plan &p, const Before &b) {
                 if (lane == 0) {
@@ -1252,11 +1232,10 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
                     o[3] = make_uint4(b.i_lo, b.i_hi, b.off, b.bb * (uint32_t)(HB * 4));
                     s_cmd[slot][23] = b.bb;
                     if (p.pre & K7_STAGE) o[6] = make_uint4((uint32_t)p.st_base, (uint32_t)(p.st_base >> 32), p.st_tot, p.st_buf);
-                    o[7] = make_uint4(b.t_before, b.t_after, p.q.t_before, p.q.t_after);
                 }
             };
             auto before_of = [&](const Plan &p) {
-                return Before{p.q.cnt, (uint32_t)p.q.i, (uint32_t)(p.q.i >> 32), p.q.off, p.q.bb, p.q.t_before, p.q.t_after};
+                return Before{p.q.cnt, (uint32_t)p.q.i, (uint32_t)(p.q.i >> 32), p.q.off, p.q.bb};
             };
             if (lane < 3) {  // the run's constants, once per segment, in every command block
                 uint4 *o = reinterpret_cast<uint4 *>(&s_cmd[lane][0]);
@@ -1324,9 +1303,8 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
                 // ---- the step after next ---------------------------------------------------------------------------------
                 if (more && !(nflags & (K7_LAST | K7_GIVEUP))) {
                     const Plan p_after = advance(nflags);
-                    write_cmd(sc == 0u ? 2u : sc - 1u, p_after, Before{N(1), N(6), N(7), N(2), N(9), N(30), N(31)});
+                    write_cmd(sc == 0u ? 2u : sc - 1u, p_after, Before{N(1), N(6), N(7), N(2), N(9)});
                     if ((p_after.flags & K7_LAST) && lane == 0) {  // (what the ranking wave needs when the segment is over)
-                        s_end[0] = t_proc;
                         s_end[1] = (!done && g_end < chunk_end && (!RANGE || w_end == g_end)) ? 1u : 0u;
                     }
                 }

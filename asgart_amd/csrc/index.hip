@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cctype>
+#include <cerrno>
 #include <chrono>
 #include <cstdlib>
 
@@ -557,6 +558,7 @@ static void free_k_specific(asgart_index *idx) {
     idx->sap_tried = false;
     idx->calls_total = 0;
     for (auto &c : idx->mode_calls) c = 0;
+    idx->split_blocked.clear();
 }
 
 static int choose_depth(int64_t n, uint64_t k, int64_t forced) {
@@ -912,32 +914,66 @@ const char *asgart_last_error(void) { return asgart::g_err; }
 const char *asgart_version(void) { return "asgart-hip 0.2.0 gfx950"; }
 
 // ---- native stacks of every thread (asgart_hip.h: asgart_debug_dump_stacks) ------------------------------------------
+// A last resort beside a debugger from a child process (tests/conftest.py tries gdb / rocgdb first): every thread is
+// sent a signal and writes its own stack from the handler.  The signal is a realtime signal of the library's own, its
+// handler is installed ONCE and stays installed: a thread that has the signal blocked, or sits in an uninterruptible
+// driver wait -- the stall this exists for -- takes it whenever it comes back, finds nobody asking for its stack any more
+// and returns; the process is never left with a default disposition and a pending signal.  The handler formats with
+// nothing but arithmetic and write(2); backtrace() has been called once beforehand so that libgcc is loaded, and
+// backtrace_symbols_fd() does not allocate (glibc) -- what remains is that the unwinder may take the loader lock: a thread
+// stopped INSIDE dl_iterate_phdr's critical section could block there, which is why the requester waits for every
+// thread's own acknowledgement with a time limit and goes on without it.
 namespace {
-std::atomic<int> g_dump_busy{0};
+std::atomic<long> g_dump_want{0};   // the thread whose stack is being asked for (0: nobody's)
+std::atomic<long> g_dump_ack{0};    // ... and the last thread that wrote one
+int g_dump_signal = 0;
+void put_line(const char *pre, long v, const char *post) {  // (async-signal-safe: no stdio)
+    char buf[96];
+    size_t n = 0;
+    for (const char *c = pre; *c && n < 48; ++c) buf[n++] = *c;
+    char dig[24];
+    int nd = 0;
+    unsigned long u = v < 0 ? 0ul - (unsigned long)v : (unsigned long)v;
+    do {
+        dig[nd++] = (char)('0' + u % 10u);
+        u /= 10u;
+    } while (u && nd < 22);
+    if (v < 0) buf[n++] = '-';
+    while (nd) buf[n++] = dig[--nd];
+    for (const char *c = post; *c && n + 1 < sizeof buf; ++c) buf[n++] = *c;
+    (void)!write(2, buf, n);
+}
 void dump_stack_handler(int) {
-    void *frames[64];
-    const int n = backtrace(frames, 64);
-    char head[96];
-    const int len = snprintf(head, sizeof head, "---- native stack of thread %ld ----\n", (long)syscall(SYS_gettid));
-    if (len > 0) (void)!write(2, head, (size_t)len);
-    backtrace_symbols_fd(frames, n, 2);
-    g_dump_busy.store(0, std::memory_order_release);
+    const int saved_errno = errno;
+    const long me = (long)syscall(SYS_gettid);
+    if (g_dump_want.load(std::memory_order_acquire) == me) {  // (a late delivery: nobody is asking any more)
+        void *frames[64];
+        const int n = backtrace(frames, 64);
+        put_line("---- native stack of thread ", me, " ----\n");
+        backtrace_symbols_fd(frames, n, 2);
+        g_dump_ack.store(me, std::memory_order_release);
+    }
+    errno = saved_errno;
 }
 }  // namespace
 
 int32_t asgart_debug_dump_stacks(void) {
     static std::mutex mu;
     std::lock_guard<std::mutex> lk(mu);
-    {   // (the first backtrace of a process loads libgcc: not from inside a signal handler)
+    if (!g_dump_signal) {
+        // (the first backtrace of a process loads libgcc: not from inside a signal handler)
         void *warm[4];
         (void)backtrace(warm, 4);
+        const int sig = SIGRTMIN + 6;  // (a realtime signal nothing else in the process is expected to use)
+        if (sig > SIGRTMAX) return -1;
+        struct sigaction sa;
+        memset(&sa, 0, sizeof sa);
+        sa.sa_handler = dump_stack_handler;
+        sa.sa_flags = SA_RESTART;
+        sigemptyset(&sa.sa_mask);
+        if (sigaction(sig, &sa, nullptr) != 0) return -1;  // installed once, never removed
+        g_dump_signal = sig;
     }
-    struct sigaction sa, old;
-    memset(&sa, 0, sizeof sa);
-    sa.sa_handler = dump_stack_handler;
-    sa.sa_flags = SA_RESTART;
-    sigemptyset(&sa.sa_mask);
-    if (sigaction(SIGUSR2, &sa, &old) != 0) return -1;
     int asked = 0;
     const pid_t pid = getpid();
     if (DIR *d = opendir("/proc/self/task")) {
@@ -949,15 +985,21 @@ int32_t asgart_debug_dump_stacks(void) {
         }
         closedir(d);
         for (long tid : tids) {
-            g_dump_busy.store(1, std::memory_order_release);
-            if (syscall(SYS_tgkill, pid, (pid_t)tid, SIGUSR2) != 0) continue;
+            g_dump_want.store(tid, std::memory_order_release);
+            if (syscall(SYS_tgkill, pid, (pid_t)tid, g_dump_signal) != 0) continue;
             ++asked;
-            // one at a time (the dumps would interleave); a thread that cannot take the signal is given 0.5 s
-            for (int spin = 0; spin < 500 && g_dump_busy.load(std::memory_order_acquire); ++spin)
-                std::this_thread::sleep_for(std::chrono::milliseconds(1));
+            // one at a time (the dumps would interleave); every thread acknowledges for itself, and one that cannot take
+            // the signal now is given 0.5 s -- its delivery, whenever it comes, finds g_dump_want moved on and returns
+            bool answered = false;
+            for (int spin = 0; spin < 500 && !answered; ++spin) {
+                answered = g_dump_ack.load(std::memory_order_acquire) == tid;
+                if (!answered) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+            }
+            if (!answered) put_line("---- thread ", tid, " did not answer within 0.5 s (signal blocked, or in an uninterruptible wait) ----\n");
         }
+        g_dump_want.store(0, std::memory_order_release);
+        g_dump_ack.store(0, std::memory_order_release);
     }
-    (void)sigaction(SIGUSR2, &old, nullptr);
     return asked;
 }
 
@@ -1306,6 +1348,7 @@ int32_t asgart_index_clone(asgart_index *src, int32_t device, asgart_index **out
 
 int64_t asgart_trim_cache(int32_t device) {
     RC_TRY(check_device(device));
+    (void)bounded_call(60.0, []() {});  // (a trim a search call left to the background worker: let it finish first)
     const size_t held = BlockCache::held();
     BlockCache::trim();
     return (int64_t)held;

@@ -147,7 +147,6 @@ struct Workspace {
     DevBuf fam_sds;    // SdRec[cap] output records of the extension kernel
     DevBuf ovf_list;   // u32 segments that overflowed the small arm tier
     DevBuf scratch;    // arm storage of the global heavy tier
-    DevBuf hit_flag;   // u8 per CSR entry: continuation flag (pre-pass)
     DevBuf seg_keys, seg_vals, sort_tmp;  // segment placement: (tier, work) keys, double-buffered
     DevBuf rec_k32, rec_k64, rec_idx, rec_sorted;  // ordering of the output records
     DevBuf pat;        // pattern upload scratch
@@ -159,7 +158,7 @@ struct Workspace {
     // every buffer goes back to the device (or to the block cache): ONE list, next to the members
     void release_all() {
         DevBuf *bufs[] = {&chunks, &p_lo, &p_raw, &p_filt, &row_off, &blk, &hits, &big_list, &rank_list, &seg_list,
-                          &counters, &fam_sds, &ovf_list, &scratch, &hit_flag, &seg_keys, &seg_vals,
+                          &counters, &fam_sds, &ovf_list, &scratch, &seg_keys, &seg_vals,
                           &sort_tmp, &rec_k32, &rec_k64, &rec_idx, &rec_sorted, &pat, &out_a, &out_b, &seg_info, &seg_slots, &split_buf, &split_dump};
         static_assert(sizeof(Workspace) == sizeof(bufs) / sizeof(bufs[0]) * sizeof(DevBuf),
                       "a buffer of the workspace is missing from release_all");
@@ -326,7 +325,7 @@ struct Options {
     int64_t split_warm = 6144;      // (split_len > 0) probes a range starts in front of its cut
     int64_t split_min = 0;          // segments shorter than this (probe positions) are not cut (split_len = 0: at least this)
     int64_t cache_calls = 2;        // the blocks an index build released stay in the block cache until the index has answered this many
-                                    // search calls (then, at its destruction, on an allocation failure and by asgart_trim_cache they go
+                                    // search PASSES (a direct + -RC passes call counts two) (then, at its destruction, on an allocation failure and by asgart_trim_cache they go
                                     // back to the device): giving ~100 GB back costs the next allocation of the process 20-30 ms per
                                     // GiB on most boxes of the pool -- 1.3-2.4 s of a cold GRCh38-sized run when it happened at the end of
                                     // asgart_index_prepare (0: there, as in round 4); the second call builds the position-sorted lists
@@ -441,10 +440,11 @@ struct asgart_index {
         int32_t n_passes = 0, shard = 0, n_shards = 1;
         bool pipeline = false;
     } fuse_verdict;
-    // segments a cut of which did not hold (option split): orientation << 32 | first probe counted from the start of its pass
-    // (... and how many of their cuts, from the start, held: only those are planned again)
+    // segments a cut of which did not hold (option split): orientation << 32 | first probe counted from the start of its pass,
+    // under which settings and chunk list (sig), how many of their cuts, from the start, held (only those are planned again)
+    // and at which range length.  Cleared with the keys; the oldest entries age out.
     struct SplitVerdict {
-        uint64_t key;
+        uint64_t key, sig;
         uint32_t allowed, range_len;  // (the count belongs to the range length it was found at)
     };
     std::vector<SplitVerdict> split_blocked;

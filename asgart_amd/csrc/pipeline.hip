@@ -337,6 +337,17 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
         h_pbase[c] = (uint32_t)p * K + (std::min(std::max(lp[(size_t)cl], lo_lim), hi_lim) - lo_lim);
     }
     h_pbase[n_chunks] = (uint32_t)n_passes * K;
+    // what a remembered verdict about a cut segment belongs to: the settings and the chunk list (probe numbers mean nothing
+    // under another step, minimum length or list)
+    uint64_t call_sig = 1469598103934665603ull;
+    {
+        auto mix = [&](uint64_t v) { call_sig = (call_sig ^ v) * 1099511628211ull; };
+        mix(k);
+        mix(st->max_gap_size);
+        mix(st->min_duplication_length);
+        mix(st->max_cardinality);
+        for (int64_t c = 0; c < 2 * n_chunks_pass; ++c) mix(chunks[c]);
+    }
     auto pass_of_probe = [&](uint32_t g) { return std::min<uint32_t>(g / K, (uint32_t)n_passes - 1u); };
     auto pass_offset = [&](uint32_t g) { return lo_lim + (g - pass_of_probe(g) * K); };  // from the start of its pass
 
@@ -614,16 +625,17 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             sp.max_runs = kMaxRuns - kMaxSplits;  // (one more run per cut segment may follow)
             sp.max_cuts = kMaxCuts;
             sp.max_splits = kMaxSplits;
-            {   // segments a cut of which failed in an earlier call of this index: as probe numbers of THIS call
+            {   // segments a cut of which failed in an earlier call of this index with these settings and chunks, if this
+                // call's windows hold them: as probe numbers of THIS call (the newest verdicts first)
                 std::lock_guard<std::mutex> lk(idx->mu);
-                for (const auto &b : idx->split_blocked)
-                    for (int32_t p_ = 0; p_ < n_passes && sp.n_blocked < 64u; ++p_)
-                        if (((rp.modes >> (8 * p_)) & 0xFFu) == (uint32_t)(b.key >> 32) && (uint32_t)b.key >= lo_lim && (uint32_t)b.key < hi_lim) {
-                            sp.blocked[sp.n_blocked] = (uint32_t)p_ * K + ((uint32_t)b.key - lo_lim);
-                            sp.blocked_len[sp.n_blocked] = b.range_len;
-                            sp.allowed[sp.n_blocked++] = (uint16_t)std::min<uint32_t>(b.allowed, 0xFFFFu);
+                for (auto b = idx->split_blocked.rbegin(); b != idx->split_blocked.rend(); ++b)
+                    for (int32_t p_ = 0; p_ < n_passes && sp.n_blocked < kSplitBlockedMax; ++p_)
+                        if (b->sig == call_sig && ((rp.modes >> (8 * p_)) & 0xFFu) == (uint32_t)(b->key >> 32) &&
+                            (uint32_t)b->key >= lo_lim && (uint32_t)b->key < hi_lim) {
+                            sp.blocked[sp.n_blocked] = (uint32_t)p_ * K + ((uint32_t)b->key - lo_lim);
+                            sp.blocked_len[sp.n_blocked] = b->range_len;
+                            sp.allowed[sp.n_blocked++] = (uint16_t)std::min<uint32_t>(b->allowed, 0xFFFFu);
                         }
-                if (idx->split_blocked.size() > 48) sp.min_span = 0x7FFFFFFFu;  // (an input that keeps refusing: no more cuts)
             }
             SplitChoice *const d_choice = reinterpret_cast<SplitChoice *>(d_split + kOffChoice);
             if (!sp.range_len) {  // the range length by budget
@@ -731,8 +743,6 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             // option test_cap_limit (tests): shrink the tiers' capacity to exercise the cascade
             ep.cap_limit = opt.test_cap_limit >= 0 ? (uint32_t)opt.test_cap_limit : 0xFFFFFFFFu;
             ep.escalate_cost = 0xFFFFFFFFu;
-            ep.hit_flag = nullptr;
-            ep.p_nflag = p_filt;
             ep.heavy_cap = (uint32_t)heavy_cap64;
             ep.solo_hits = opt.solo == 1 ? 16u : (uint32_t)opt.solo;  // (1: the default of 16 hits; other values: that many)
             ep.gen_bits = (uint32_t)opt.test_genbits;
@@ -998,12 +1008,14 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                     const uint32_t len_ = (uint32_t)h_split_hdr[4];
                     std::lock_guard<std::mutex> lk(idx->mu);
                     for (auto &b : idx->split_blocked)
-                        if (b.key == key_) {
+                        if (b.key == key_ && b.sig == call_sig) {
                             b.allowed = b.range_len == len_ ? std::min(b.allowed, allowed) : allowed;
                             b.range_len = len_;
                             return;
                         }
-                    idx->split_blocked.push_back({key_, allowed, len_});
+                    // (verdicts age out, oldest first: a forgotten one costs its segment one more refused cut, no more)
+                    if (idx->split_blocked.size() >= 4096) idx->split_blocked.erase(idx->split_blocked.begin());
+                    idx->split_blocked.push_back({key_, call_sig, allowed, len_});
                 };
                 for (const SplitSeg &sg : split_segs) {
                     const uint32_t n_cuts_sg = sg.n_ranges - 1;
@@ -1411,12 +1423,21 @@ int32_t run_search_passes(asgart_index *idx, const uint64_t *chunks, int64_t n_c
                                     status_out, rowoff_out, hits_out);
     cx.progress = nullptr;
     bool trim_now = false;
-    {
+    {   // (counted in PASSES: a host that runs the direct and the -RC pass as one passes call -- the CLI's shape -- has made its
+        // two searches when that call returns, and must not sit on the sorter's ~100 GB of scratch until it destroys the index)
         std::lock_guard<std::mutex> lk(idx->mu);
-        ++idx->calls_total;
-        trim_now = idx->opt.cache_calls > 0 && idx->calls_total == (uint64_t)idx->opt.cache_calls;
+        const uint64_t before = idx->calls_total;
+        idx->calls_total += (uint64_t)n_passes;
+        trim_now = idx->opt.cache_calls > 0 && before < (uint64_t)idx->opt.cache_calls && idx->calls_total >= (uint64_t)idx->opt.cache_calls;
     }
-    if (trim_now) BlockCache::trim();  // (option cache_calls: what the index build released goes back to the device now)
+    if (trim_now) {  // (option cache_calls: what the index build released goes back to the device now -- behind the caller's back:
+                     // the hipFree of ~100 GB is not this call's business)
+        const int dev = idx->device;
+        background_call([dev]() {
+            if (hipSetDevice(dev) == hipSuccess) BlockCache::trim();
+            (void)hipGetLastError();
+        });
+    }
     if (rc == 0 && fams && n_shards == 1 && n_passes == 1) {
         // what asgart_search_duplications_passes orders by when it pipelines single-pass calls: the shortest extension seen
         // for the orientation (a call that shared the chip with another one measures longer, and the order must not flip

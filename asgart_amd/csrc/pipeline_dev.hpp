@@ -1074,8 +1074,6 @@ struct ExtParams {
     const uint32_t *p_filt;
     const unsigned long long *row_off;
     const PosT *hits;
-    const uint8_t *hit_flag;              // 1: the hit may start an arm that matches later (K3b); null: every hit
-    const uint32_t *p_nflag;              // per probe: number of flagged hits
     const uint32_t *seg_list;
     const unsigned long long *n_seg_ptr;  // device count of seg_list entries
     unsigned long long *cursor;           // work-fetch cursor
@@ -1200,7 +1198,6 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
     __shared__ PosT s_ls[CAP], s_le[CAP], s_rs[CAP], s_re[CAP];
     __shared__ uint32_t s_gap[CAP], s_thr[CAP], s_seq[CAP], s_pend[CAP];
     __shared__ PosT s_hits[kHitBatch];
-    __shared__ uint8_t s_hflag[kHitBatch];  // continuation flags of the staged hits
     // candidate index of the LDS path: arms bucketed by right end (see "LDS path")
     constexpr uint32_t HT = CAP <= 256 ? 256u : (CAP <= 1024 ? 1024u : 4096u);
     __shared__ uint32_t s_head[HT];
@@ -1254,10 +1251,7 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
         PosT r_ls = 0, r_le = 0, r_rs = 0, r_re = 0;
         uint32_t r_gap = 0, r_thr = 0, r_seq = 0;
         uint32_t A = 0, quiet = 0, fam_seq = 0, next_seq = 0, lds_cost = 0;
-        // t_proc: processed probes so far; spur_until: processed-probe index at whose end the last
-        // dropped (never-matching) arm would have turned inactive; fam_open: a family is pending
-        uint32_t t_proc = 0, spur_until = 0;
-        bool in_regs = true, overflow = false, done = false, fam_open = false;
+        bool in_regs = true, overflow = false, done = false, fam_open = false;  // fam_open: a family is pending
 
         // ---- helpers -------------------------------------------------------
         auto emit_records = [&](bool emit, PosT ls, PosT le, PosT rs, PosT re, uint32_t seq) {
@@ -1281,9 +1275,9 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
                 }
             }
         };
-        // the flush of src/automaton.rs:182-200: every arm inactive, including the dropped ones
+        // the flush of src/automaton.rs:182-200: every arm inactive
         auto maybe_close = [&]() {
-            if (fam_open && A == 0 && t_proc >= spur_until) {
+            if (fam_open && A == 0) {
                 ++fam_seq;
                 next_seq = 0;
                 fam_open = false;
@@ -1356,7 +1350,6 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
         // q consecutive processed probes without hits
         auto advance_quiet = [&](uint32_t q) {
             quiet += q;
-            t_proc += q;
             if (A > 0) {
                 const uint32_t add = q * step;
                 if (in_regs) {
@@ -1384,7 +1377,6 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
             PROF_START();
             const uint32_t nb = min(64u, g_end - g);
             const uint32_t f_l = (uint32_t)lane < nb ? P.p_filt[g + lane] : kSkipN;
-            const uint32_t nfl_l = (uint32_t)lane < nb ? P.p_nflag[g + lane] : 0u;  // flagged hits
             const unsigned long long r_l = (uint32_t)lane < nb ? P.row_off[g + lane] : 0ull;
             const unsigned long long r_hi = P.row_off[g + nb];
             const unsigned long long base = __shfl(r_l, 0);
@@ -1406,20 +1398,15 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
                 // four loads per lane in flight per round trip; most batches need a single round
                 for (uint32_t r0 = 0; r0 < tot; r0 += 256u) {
                     PosT tmp[4];
-                    uint8_t ftmp[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const uint32_t r = r0 + lane + 64u * u;
                         tmp[u] = r < tot ? P.hits[base + r] : (PosT)0;
-                        ftmp[u] = r < tot ? (P.hit_flag ? P.hit_flag[base + r] : (uint8_t)1) : (uint8_t)0;
                     }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const uint32_t r = r0 + lane + 64u * u;
-                        if (r < tot) {
-                            s_hits[r] = tmp[u];
-                            s_hflag[r] = ftmp[u];
-                        }
+                        if (r < tot) s_hits[r] = tmp[u];
                     }
                 }
             }
@@ -1445,17 +1432,14 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
                 quiet = 0;
                 pos = b + 1;
                 const uint32_t cnt = __shfl(f_l, (int)b);
-                const uint32_t nfl = __shfl(nfl_l, (int)b);  // only flagged hits can create arms
                 const uint32_t off = __shfl(rel_l, (int)b);
                 const uint64_t i = (uint64_t)(g + b - pb + 1) * step;
                 const unsigned long long row = base + off;
-                ++t_proc;
-                bool spur = false;
-                if (in_regs && A + nfl <= 64u && cnt <= 192u && !first_from_global) {
+                if (in_regs && A + cnt <= 64u && !first_from_global) {
                     // ---------------- register path -------------------------------
                     PROF_START();
                     PROF_COUNT(3, 1);
-                    PROF_MAX(9, A + nfl);
+                    PROF_MAX(9, A + cnt);
                     bool pend = false;
                     PosT pend_x = 0;
                     uint32_t newc = 0;
@@ -1468,7 +1452,7 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
                                 pend = true;
                                 pend_x = x;
                             }
-                        } else if (s_hflag[off + t]) {  // NewArm
+                        } else {  // NewArm
                             if ((uint32_t)lane == A + newc) {
                                 r_ls = (PosT)i; r_le = (PosT)(i + k); r_rs = x; r_re = (PosT)(x + k);
                                 r_gap = step;  // not dirty: aged by this very probe
@@ -1476,8 +1460,6 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
                                 r_seq = next_seq + newc;
                             }
                             ++newc;
-                        } else {  // NewArm that can never match: not materialised (K3b)
-                            spur = true;
                         }
                     }
                     if ((uint32_t)lane < A) {
@@ -1500,9 +1482,9 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
                     // hand the segment to the block-cooperative heavy tier when it does not fit
                     // this wave's LDS share, or keeps producing many-hit x many-arm probes
                     lds_cost += A + cnt;
-                    if (A + nfl > min((uint32_t)CAP, P.cap_limit) || lds_cost > P.escalate_cost) {
+                    if (A + cnt > min((uint32_t)CAP, P.cap_limit) || lds_cost > P.escalate_cost) {
 #ifdef ASGART_PROFILE_EXTEND
-                        if (lane == 0) printf("[light overflow] g0=%u g=%u A=%u nfl=%u cnt=%u t_proc=%u cost=%u first_glob=%d\n", g0, g + b, A, nfl, cnt, t_proc, lds_cost, (int)first_from_global);
+                        if (lane == 0) printf("[light overflow] g0=%u g=%u A=%u cnt=%u cost=%u first_glob=%d\n", g0, g + b, A, cnt, lds_cost, (int)first_from_global);
 #endif
                         overflow = true;
                         done = true;
@@ -1513,7 +1495,7 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
                     PROF_COUNT(5, 1);
                     PROF_COUNT(10, A_old);
                     PROF_COUNT(11, cnt);
-                    PROF_MAX(9, A_old + nfl);
+                    PROF_MAX(9, A_old + cnt);
                     PROF_START();
                     // An arm accepts hit x iff  re - k < x < re + thr  (d_ss of src/automaton.rs:207-216
                     // with m = [x, x+k) and len(right) >= k).  So instead of testing every arm
@@ -1585,9 +1567,7 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
                         }
                         const int found = best == 0xFFFFFFFFu ? -1 : (int)best;
                         if (valid && found >= 0) atomicMax(&s_pend[found], t + 1u);
-                        const bool fl = valid && (from_lds ? s_hflag[off + t] : (P.hit_flag ? P.hit_flag[row + t] : (uint8_t)1)) != 0;
-                        const bool is_new = valid && found < 0 && fl;
-                        spur |= __ballot(valid && found < 0 && !fl) != 0ull;
+                        const bool is_new = valid && found < 0;
                         const unsigned long long m = __ballot(is_new);
                         if (is_new) {
                             const uint32_t d = A + __popcll(m & lt_mask);
@@ -1624,9 +1604,8 @@ __global__ __launch_bounds__(64) void extend_kernel(ExtParams<PosT> P) {
                     if (A <= 32) to_regs();
                     PROF_STOP(8);
                 }
-                // every hit of this probe extended an arm or created one (materialised or not)
+                // every hit of this probe extended an arm or created one
                 fam_open = true;
-                if (spur) spur_until = max(spur_until, t_proc + rp.tstar - 1u);
                 maybe_close();
             }
             if (!done) {
@@ -1843,7 +1822,7 @@ __global__ __launch_bounds__(64) void seg_stats_kernel(RunParams rp, const uint3
         const int c = chunk_of_uniform(rp.ch, g0);
         const uint32_t g_end = min(rp.ch.pbase[c + 1], rp.win_end(g0));
         const bool window_cut = g_end < rp.ch.pbase[c + 1];
-        uint32_t quiet = 0, mx = 0, bound = 0, n_probes = 0, n_hit = 0, g_stop = g_end;
+        uint32_t quiet = 0, mx = 0, bound = 0, n_probes = 0, n_hit = 0, g_stop = g_end, g_after_hit = g0 + 1u;
         unsigned long long sum = 0;
         bool done = false;
         s_ext[lane] = 0;
@@ -1873,10 +1852,13 @@ __global__ __launch_bounds__(64) void seg_stats_kernel(RunParams rp, const uint3
                     // probes up to that hit still belong to the segment
                     const uint32_t pos = (uint32_t)(__shfl(lh, __ffsll((long long)term) - 1) + 1);
                     done = true;
-                    g_stop = g + 64u;             // (an upper bound of where the segment ends: all the barren test needs)
+                    // (exactly behind the segment's last hit-probe: the barren tests want an upper bound of the span, the
+                    // cutting into ranges must never place a cut on a hit-probe of the NEXT segment)
+                    g_stop = pos ? g + pos : g_after_hit;
                     live = (1ull << pos) - 1ull;  // pos <= 63
                 } else {
                     const int last = hm ? 63 - __clzll((long long)hm) : -1;
+                    if (last >= 0) g_after_hit = g + (uint32_t)last + 1u;
                     const unsigned long long above = last < 0 ? ~0ull : (last == 63 ? 0ull : ~((2ull << last) - 1ull));
                     quiet = (uint32_t)__popcll(qm & above) + (last < 0 ? quiet : 0u);
                 }
@@ -2128,14 +2110,15 @@ __global__ void split_pick_kernel(SplitChoice *choice, uint32_t budget) {
     choice->min_span = 3u * choice->warm;               // (two ranges of a shorter segment are each nearly the segment)
 }
 
+constexpr uint32_t kSplitBlockedMax = 128;  // verdicts of earlier calls handed to one call (kernel argument space)
 struct SplitParams {
     uint32_t range_len, warm, min_span;   // size of a range (probe positions; range_len = 0: cost units, as split_pick_kernel chose),
                                           // warm-up probes in front of a cut, shortest segment that is cut
     uint32_t max_runs, max_cuts, max_splits;
     uint32_t n_blocked;
-    uint32_t blocked[64];                 // segments (first probe) a cut of which did not hold in an earlier call of the index ...
-    uint16_t allowed[64];                 // ... and how many of their cuts, counted from the segment's start, held (0: not cut again)
-    uint32_t blocked_len[64];             // ... at which range length (the count means nothing at another)
+    uint32_t blocked[kSplitBlockedMax];      // segments (first probe) a cut of which did not hold in an earlier call of the index ...
+    uint16_t allowed[kSplitBlockedMax];      // ... and how many of their cuts, counted from the segment's start, held (0: not cut again)
+    uint32_t blocked_len[kSplitBlockedMax];  // ... at which range length (the count means nothing at another)
 };
 __global__ __launch_bounds__(256) void plan_ranges_kernel(RunParams rp, SplitParams sp, const uint32_t *__restrict__ p_filt,
                                                          const uint32_t *__restrict__ seg_list,
@@ -2402,7 +2385,6 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
         s_next = l_next; s_free = l_free; s_widx = l_widx;
     }
     __shared__ PosT s_hits[kHitBatch];
-    __shared__ uint8_t s_hflag[kHitBatch];
     __shared__ unsigned long long s_best[NT];  // per hit: (creation number << 20) | slot, or ~0
     __shared__ uint32_t s_nwide, s_nfreed;
     __shared__ uint32_t s_wcnt[NT / 64];
@@ -2440,7 +2422,6 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
         const uint32_t g_end = min(chunk_end, rp.win_end(g0));  // (sharded calls: the window ends first)
         // block-uniform state: A live arms in slots [0,H), n_free of them empty (on s_free)
         uint32_t A = 0, H = 0, n_free = 0, quiet = 0, fam_seq = 0, next_seq = 0;
-        uint32_t t_proc = 0, spur_until = 0;  // see extend_kernel
         if (tid == 0) s_nfreed = 0;
         bool overflow = false, done = false, fam_open = false;
 
@@ -2546,9 +2527,9 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
                 n_free = 0;
             }
         };
-        // the flush of src/automaton.rs:182-200: every arm inactive, including the dropped ones
+        // the flush of src/automaton.rs:182-200: every arm inactive
         auto maybe_close = [&]() {
-            if (fam_open && A == 0 && t_proc >= spur_until) {
+            if (fam_open && A == 0) {
                 ++fam_seq;
                 next_seq = 0;
                 fam_open = false;
@@ -2556,7 +2537,6 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
         };
         auto advance_quiet = [&](uint32_t q) {
             quiet += q;
-            t_proc += q;
             if (A > 0) age_and_retire(q * step, false, 0, 0, 0, true);
             maybe_close();
             if (A == 0 && quiet >= rp.tstar) done = true;
@@ -2568,7 +2548,6 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
             const uint32_t nb = min(64u, g_end - g);
             if (tid == 0) heartbeat(P, g0, g);
             const uint32_t f_l = (uint32_t)lane < nb ? P.p_filt[g + lane] : kSkipN;
-            const uint32_t nfl_l = (uint32_t)lane < nb ? P.p_nflag[g + lane] : 0u;
             const unsigned long long r_l = (uint32_t)lane < nb ? P.row_off[g + lane] : 0ull;
             const unsigned long long r_hi = P.row_off[g + nb];
             const unsigned long long base = __shfl(r_l, 0);
@@ -2587,10 +2566,7 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
             if (!first_from_global) {
                 const unsigned long long end = nbb == nb ? r_hi : __shfl(r_l, (int)nbb);
                 const uint32_t tot = (uint32_t)(end - base);
-                for (uint32_t r = tid; r < tot; r += NT) {
-                    s_hits[r] = P.hits[base + r];
-                    s_hflag[r] = (P.hit_flag ? P.hit_flag[base + r] : (uint8_t)1);
-                }
+                for (uint32_t r = tid; r < tot; r += NT) s_hits[r] = P.hits[base + r];
             }
             __syncthreads();
             const unsigned long long in_batch = nbb >= 64 ? ~0ull : ((1ull << nbb) - 1ull);
@@ -2614,13 +2590,10 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
                 quiet = 0;
                 pos = b + 1;
                 const uint32_t cnt = __shfl(f_l, (int)b);
-                const uint32_t nfl = __shfl(nfl_l, (int)b);
                 const uint32_t off = __shfl(rel_l, (int)b);
                 const uint64_t i = (uint64_t)(g + b - pb + 1) * step;
                 const unsigned long long row = base + off;
-                ++t_proc;
-                bool spur = false;
-                if (A + nfl > cap_eff) {
+                if (A + cnt > cap_eff) {
                     overflow = true;
                     done = true;
                     break;
@@ -2629,7 +2602,7 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
                 PROF_COUNT(5, 1);
                 PROF_COUNT(10, A);
                 PROF_COUNT(11, cnt);
-                PROF_MAX(9, A + nfl);
+                PROF_MAX(9, A + cnt);
                 PROF_START();
                 // ---- (0)+(1) candidate index over the live arms ------------------------------
                 uint32_t hmask = 63u;
@@ -2769,22 +2742,15 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
                         best = s_best[tid];
                         if (best != ~0ull) pend_max(s_pend, (uint32_t)(best & kSlotMask), t0 + tid + 1u);
                     }
-                    // unmatched hits: flagged ones become arms, the others are dropped (K3b)
-                    bool fl = false;
-                    if (mine) fl = (from_lds ? s_hflag[off + t0 + tid] : (P.hit_flag ? P.hit_flag[row + t0 + tid] : (uint8_t)1)) != 0;
-                    const bool is_new = mine && best == ~0ull && fl;
+                    // unmatched hits become arms
+                    const bool is_new = mine && best == ~0ull;
                     // rank of this hit among the new arms, in hit order (= creation order): every
-                    // wave recomputes the per-group counts from s_best + flags (no barrier)
+                    // wave recomputes the per-group counts from s_best (no barrier)
                     uint32_t before = 0, n_new = 0;
                     for (uint32_t c0 = 0; c0 < ct; c0 += 64) {
                         const uint32_t hidx = c0 + lane;
-                        bool un = false, hf = false;
-                        if (hidx < ct) {
-                            un = s_best[hidx] == ~0ull;
-                            hf = (from_lds ? s_hflag[off + t0 + hidx] : (P.hit_flag ? P.hit_flag[row + t0 + hidx] : (uint8_t)1)) != 0;
-                        }
-                        const unsigned long long nm = __ballot(un && hf);
-                        spur |= __ballot(un && !hf) != 0ull;
+                        const bool un = hidx < ct && s_best[hidx] == ~0ull;
+                        const unsigned long long nm = __ballot(un);
                         const uint32_t pc = (uint32_t)__popcll(nm);
                         if (c0 < ((uint32_t)tid & ~63u)) before += pc;
                         else if (c0 == ((uint32_t)tid & ~63u)) before += (uint32_t)__popcll(nm & lt_mask);
@@ -2817,7 +2783,6 @@ __global__ __launch_bounds__(NT) void extend_heavy_kernel(ExtParams<PosT> P) {
                 // ---- (4) apply ExtendArm (last hit in SA order wins), age, retire -----------------
                 age_and_retire(step, true, i, off, row, from_lds);
                 fam_open = true;
-                if (spur) spur_until = max(spur_until, t_proc + rp.tstar - 1u);
                 maybe_close();
                 PROF_STOP(7);
             }

@@ -550,10 +550,17 @@ def main():
         except Exception as exc:   # (a damaged file must not cost the bench line)
             model = {"error": f"{spath}: {exc}"}
     if rank == 0 and whole:
-        model = model or {}
-        model["one_gpu_phases_ms"] = [{"front": round(w_["ms_search"] + w_["ms_scan"] + w_["ms_fill"], 2),
-                                       "extend": round(w_["ms_extend"], 2),
-                                       "longest_segment": round(w_.get("ms_longest_segment") or 0.0, 2)} for w_ in whole]
+        fronts = [w_["ms_search"] + w_["ms_scan"] + w_["ms_fill"] for w_ in whole]
+        floor = [w_.get("ms_longest_segment") or w_["ms_longest_tier"] for w_ in whole]
+        if not model or "error" in model:
+            # no shard timings committed for this workload: the coarse formula of the earlier rounds, from ONE unsharded run --
+            # sharding divides a job's front and the throughput part of its extension, never its longest single segment
+            model = dict(model or {}, source="formula", curve_measured_on_n_gpus=False,
+                         formula="sum_j front_j / N + max_j max(longest_segment_j, extend_j / N)   (j: the jobs of a step)")
+            for n_ in sorted({1, 2, 4, 8, world}):
+                model[f"n{n_}_ms"] = round(sum(fronts) / n_ + max(max(fl_, w_["ms_extend"] / n_) for w_, fl_ in zip(whole, floor)), 2)
+        model["one_gpu_phases_ms"] = [{"front": round(f_, 2), "extend": round(w_["ms_extend"], 2), "longest_segment": round(fl_, 2)}
+                                      for f_, w_, fl_ in zip(fronts, whole, floor)]
 
     out = {
         "metric": "Mbp/s probe+extend (direct+RC, k=20 g=100)",

@@ -162,8 +162,9 @@ int32_t asgart_prepare_data(const uint8_t *const *records, const uint64_t *recor
 int64_t asgart_trim_cache(int32_t device);
 
 /* Diagnostics for a host that suspects a stalled call (no reference counterpart: the reference has no device to wait
- * for): writes the NATIVE call stack of every thread of the process to stderr (glibc backtrace from a SIGUSR2 handler
- * the call installs, one thread after the other), so that a wait inside the HIP runtime -- which a Python- or
+ * for): writes the NATIVE call stack of every thread of the process to stderr -- glibc backtrace from the handler of
+ * a realtime signal of the library's own (SIGRTMIN + 6), installed at the first call and never removed, one thread
+ * after the other, each acknowledging for itself -- so that a wait inside the HIP runtime, which a Python- or
  * Rust-level stack dump shows as one opaque frame -- names the runtime call it sits in.  Callable from any thread,
  * in particular from a watchdog thread while the main thread is blocked (tests/conftest.py does on a test time-out).
  * Returns the number of threads asked. */

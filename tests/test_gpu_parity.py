@@ -1359,6 +1359,49 @@ def test_long_segments_as_ranges_equal_whole_segments(hiplib, shape):
     assert joined > 0 and refused > 0, (shape, joined, refused)
 
 
+@pytest.mark.parametrize("block", range(6))
+def test_randomised_cut_cases_against_the_oracle(hiplib, block):
+    """The randomised evidence of the range scheme, on the driver's box: 60 cases of tools/fuzz_k8.py (tandem arrays of
+    3-400 bp monomers, random probe size / gap / minimum length, 3- and 4-bit table generations among them) with the long
+    segments cut into ranges of 128-256 probes, every multi-hit segment forced through the long shape.  Per case: both
+    orientations as single calls, both as ONE job, and both as one job over 2 shards merged by key -- families and
+    ProtoSDs equal to the ORACLE's, twice (the second round plans only the cuts that held)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_k8
+
+    shapes = ((256, 128, 512), (128, 512, 256), (256, 1024, 512))
+    cut = refused = 0
+    for seed in range(200 + 10 * block, 210 + 10 * block):
+        text, cli, genbits = fuzz_k8.make_case(seed)
+        chunks = [(0, len(text) - 1)]
+        oidx = oracle.Index.build(text)
+        exp = [oidx.run_raw(chunks, oracle.make_settings(reverse=rc, complement=rc, **cli), threads=4) for rc in (False, True)]
+        ln, warm, mn = shapes[seed % 3]
+        with asgart_amd.Index(text, oidx.sa) as idx:
+            idx.set_option("force_tier", 3)
+            idx.set_option("test_genbits", genbits)
+            idx.set_option("split", 1)
+            idx.set_option("split_len", ln)
+            idx.set_option("split_warm", warm)
+            idx.set_option("split_min", mn)
+            sts = [asgart_amd.RunSettings.from_cli(reverse=rc, complement=rc, **cli) for rc in (False, True)]
+            for rep in range(2):
+                for j, st in enumerate(sts):
+                    got = idx.search_duplications_raw(chunks, st)
+                    assert np.array_equal(got[0], exp[j][0]) and np.array_equal(got[1], exp[j][1]), (seed, cli, genbits, rep, j)
+                    stt = idx.stats()
+                    cut += stt.split_segments
+                    refused += stt.split_refused
+                both = idx.search_duplications_passes(chunks, sts)
+                for j in range(2):
+                    assert np.array_equal(both[j][0], exp[j][0]) and np.array_equal(both[j][1], exp[j][1]), (seed, cli, "one job", rep, j)
+                parts = [idx.search_duplications_passes(chunks, sts, shard=r, n_shards=2, with_keys=True) for r in range(2)]
+                for j in range(2):
+                    mo, ms = asgart_amd.merge_shards([q[j] for q in parts])
+                    assert np.array_equal(mo, exp[j][0]) and np.array_equal(ms, exp[j][1]), (seed, cli, "2 shards", rep, j)
+    assert cut > 0, (block, cut, refused)
+
+
 @pytest.mark.parametrize("name", ["satellites", "dense_repeats", "masked", "k31_odd", "long_sds"])
 def test_fused_passes_equal_single_calls_keys_included(hiplib, name):
     """asgart_search_duplications_passes runs passes that differ in orientation only as ONE job (the probe sequence is
