@@ -42,20 +42,6 @@
 
 namespace asgart {
 
-// inclusive prefix sum across the 64 lanes of a wave (gfx9 DPP: row shifts + row broadcasts)
-__device__ inline uint32_t wave_incl_scan(uint32_t x) {
-#define ASGART_DPP_ADD(ctrl, rows) \
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, ctrl, rows, 0xf, false)
-    ASGART_DPP_ADD(0x111, 0xf);  // row_shr:1
-    ASGART_DPP_ADD(0x112, 0xf);  // row_shr:2
-    ASGART_DPP_ADD(0x114, 0xf);  // row_shr:4
-    ASGART_DPP_ADD(0x118, 0xf);  // row_shr:8
-    ASGART_DPP_ADD(0x142, 0xa);  // row_bcast:15 -> rows 1, 3
-    ASGART_DPP_ADD(0x143, 0xc);  // row_bcast:31 -> rows 2, 3
-#undef ASGART_DPP_ADD
-    return x;
-}
-
 // minimum across the 64 lanes of a wave (same DPP steps as the scan; the result is wave-uniform)
 __device__ inline uint32_t wave_min_u32(uint32_t x) {
 #define ASGART_DPP_MIN(ctrl, rows) \

@@ -181,6 +181,7 @@ struct SearchCtx {
     asgart_stats stats;
     RunParams last_rp;   // inputs of the last call, kept for the yardstick kernel
     bool has_last = false;
+    bool raw_done = false;  // asgart_stats.raw_hits of the last call has been summed up (asgart_get_stats does it on demand)
     uint32_t last_P = 0;
     bool busy = false;
     volatile uint64_t *progress = nullptr;  // of the call in flight (asgart_search_duplications), or null

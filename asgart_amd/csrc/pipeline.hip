@@ -421,7 +421,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
     uint32_t *p_raw = w.p_raw.as<uint32_t>() - rp.g_lo;
     uint32_t *p_filt = w.p_filt.as<uint32_t>() - rp.g_lo;
     unsigned long long *row_off = w.row_off.as<unsigned long long>() - rp.g_lo;
-    ScanEl *blk = w.blk.as<ScanEl>();
+    unsigned long long *scan_desc = w.blk.as<unsigned long long>();  // two words per scan tile (scan_segments_kernel)
     uint32_t *big_list = w.big_list.as<uint32_t>();
     uint32_t *rank_list = w.rank_list.as<uint32_t>();
     uint32_t *seg_list = w.seg_list.as<uint32_t>();
@@ -440,10 +440,8 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
         rank_count_kernel<SlotT, false><<<2048, 256, 0, s>>>(ix, rp, p_lo, p_raw, p_filt, rank_list, big_list, d_ctr);
     HIP_TRY(hipEventRecord(cx.ev[1], s));
     // ---- K2: scans + segmentation ----------------------------------------------
-    scan_reduce_kernel<<<n_blk, kScanBlock, 0, s>>>(rp, p_filt, blk);
-    scan_mid_kernel<<<1, 1024, 0, s>>>(blk, n_blk, d_ctr);
-    scan_down_kernel<<<std::min<uint32_t>(n_blk, 256u * 3u * 2u), kScanBlock, 0, s>>>(rp, p_filt, p_raw, blk, n_blk, row_off,
-                                                                                     seg_list, d_ctr);
+    HIP_TRY(hipMemsetAsync(scan_desc, 0, (size_t)n_blk * 16, s));
+    scan_segments_kernel<<<std::min<uint32_t>(n_blk, 256u * 3u), kScanBlock, 0, s>>>(rp, p_filt, scan_desc, n_blk, row_off, seg_list, d_ctr);
     HIP_TRY(hipEventRecord(cx.ev[2], s));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, kCtrBytes, hipMemcpyDeviceToHost, s));
@@ -1335,7 +1333,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
     stt.probes_searched = h_ctr[CT_SEARCHED];
     stt.probes_card_skipped = h_ctr[CT_CARD_SKIPPED];
     stt.probes_with_hits = h_ctr[CT_WITH_HITS];
-    stt.raw_hits = h_ctr[CT_RAW_HITS];
+    stt.raw_hits = 0;  // (asgart_get_stats sums them up when asked: raw_hits_kernel)
     stt.filtered_hits = total_hits;
     stt.segments = n_seg;
     stt.families = stt.proto_sds = 0;
@@ -1356,6 +1354,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
     HIP_TRY(hipEventElapsedTime(&ms, cx.ev[0], cx.ev[11]));
     stt.ms_probe_count = ms;
     cx.has_last = true;
+    cx.raw_done = false;
     return 0;
 }
 
@@ -1794,6 +1793,22 @@ int32_t asgart_get_stats(asgart_index *idx, uint32_t flags, asgart_stats *out) {
     const int sel = (int)((flags >> 8) & 0xFFu);
     SearchCtx &cx = idx->ctx[sel >= 1 && sel <= kNumCtx ? sel - 1 : idx->last_ctx];
     int32_t rc = [&]() -> int32_t {
+        if (cx.has_last && cx.last_P && !cx.raw_done) {
+            // raw_hits of the last call: summed up now, from the per-probe arrays it left in this context's workspace
+            REFUSE_POISONED(idx);
+            HIP_TRY(hipSetDevice(idx->device));
+            unsigned long long *d_ctr = cx.ws.counters.as<unsigned long long>();
+            hipStream_t s = cx.stream;
+            const RunParams &rp = cx.last_rp;
+            HIP_TRY(hipMemsetAsync(d_ctr + CT_RAW_HITS, 0, 8, s));
+            raw_hits_kernel<<<std::min<uint32_t>(rp.n_tiles(1024u), 256u * 16u), 256, 0, s>>>(
+                rp, cx.ws.p_filt.as<uint32_t>() - rp.g_lo, cx.ws.p_raw.as<uint32_t>() - rp.g_lo, d_ctr + CT_RAW_HITS);
+            HIP_TRY(hipGetLastError());
+            unsigned long long v = 0;
+            HIP_TRY(read_back(&v, d_ctr + CT_RAW_HITS, 8, s));  // (polled drain first: common.hpp)
+            cx.stats.raw_hits = v;
+            cx.raw_done = true;
+        }
         if ((flags & ASGART_STATS_YARDSTICK) && cx.has_last && cx.last_P) {
             REFUSE_POISONED(idx);
             HIP_TRY(hipSetDevice(idx->device));

@@ -18,23 +18,13 @@
 namespace asgart {
 
 constexpr int kSmallInterval = 32;  // intervals up to this size are handled by one thread
-constexpr int kScanItems = 8;       // probes per thread in the scan kernels
-constexpr int kScanBlock = 256;
-constexpr int kScanTile = kScanItems * kScanBlock;
-// LDS position of tile element i: every thread walks kScanItems CONSECUTIVE elements (i = thread * kScanItems + a), which at
-// stride kScanItems words puts the lanes of a wave on 4 of the 32 banks; one word of padding per kScanItems elements makes the
-// stride odd (9 words; 18 for the 64-bit row offsets) and the walk conflict-free, while the coalesced passes (i = thread,
-// thread + 256, ...) stay within two lanes per bank
-constexpr int kScanTilePad = kScanTile + kScanTile / kScanItems;
-__device__ inline uint32_t scan_pos(uint32_t i) { return i + i / (uint32_t)kScanItems; }
-
 constexpr int kTiers = 7;  // extension tiers (see the placement in pipeline.hip)
 
 // device counters (u64 each)
 enum Counter {
     CT_BIG = 0,       // entries in big_list
     CT_SEG,           // entries in seg_list
-    CT_SEG_CURSOR,    // work-fetch cursor of the extend kernel
+    CT_SCAN_TICKET,   // scan_segments_kernel: the next tile
     CT_FAM,           // families emitted
     CT_SD,            // ProtoSDs emitted
     CT_OVF,           // segments that overflowed the arm capacity
@@ -596,10 +586,20 @@ __global__ __launch_bounds__(256) void big_count_kernel(IndexView<SlotT> ix, Run
 }
 
 // ---------------------------------------------------------------- K2 ---------
-// Scan element.  hits: running CSR offset.  (has, c, reset): "quiet count since
-// the last probe with hits, reset at chunk starts" monoid.  A window that starts mid-chunk (sharded calls) begins with
-// a reset of its own, marked "unknown": what the automaton held in front of it is not known, and stays unknown until
-// the first hit-probe or real chunk start behind it.
+// Row offsets and segmentation: ONE pass over the per-probe hit counts (scan_segments_kernel).
+//
+// What is scanned, per probe, is a small monoid: the running CSR offset (hits) and "quiet processed probes since the last
+// hit-probe, reset at chunk starts" (c, flags) -- a segment starts at a hit-probe preceded by t* quiet probes or by its
+// chunk's start.  A window that starts mid-chunk (sharded calls) begins with a reset of its own, marked
+// "unknown": what the automaton held in front of it is not known, and stays unknown until the first hit-probe or real
+// chunk start behind it.
+// Single pass with decoupled look-back: persistent workgroups take tiles of kScanTile probes in ticket order; a tile's
+// counts are loaded once into registers (32 per lane), its aggregate is published, the exclusive prefix is assembled
+// from the predecessors' published aggregates / prefixes, and the tile is walked again out of the registers -- row
+// offsets written, segment starts decided.  Inside a tile nothing is staged through LDS: a wave owns 2048 consecutive
+// probes as 32 rounds of 64, and everything a round needs about its neighbours comes out of three ballots (hit, quiet,
+// reset) by bit arithmetic.  The round-5 version (reduce, mid, down: three kernels, every tile staged through LDS and
+// walked item by item per thread) streamed 1.2 TB/s; this one is bound by its 12 bytes per probe.
 struct ScanEl {
     unsigned long long hits;
     uint32_t c;      // processed probes after the last hit-probe (or all, if none)
@@ -627,19 +627,53 @@ __device__ inline ScanEl scan_combine(const ScanEl &a, const ScanEl &b) {
     return r;
 }
 
-// first: 0 = inside a chunk, 1 = first probe of a chunk, 2 = first probe of a window that starts in mid-chunk
-__device__ inline ScanEl scan_element(uint32_t filt, uint32_t first) {
-    ScanEl e;
-    const bool skipped = filt >= kPending;
-    const bool hit = !skipped && filt > 0;
-    e.hits = hit ? filt : 0u;
-    e.c = (!skipped && !hit) ? 1u : 0u;
-    e.flags = (hit ? 1u : 0u) | (first ? 2u : 0u) | (first == 2u ? 4u : 0u);
-    return e;
+// inclusive prefix sum across the 64 lanes of a wave (gfx9 DPP: row shifts + row broadcasts)
+__device__ inline uint32_t wave_incl_scan(uint32_t x) {
+#define ASGART_DPP_ADD(ctrl, rows) \
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, ctrl, rows, 0xf, false)
+    ASGART_DPP_ADD(0x111, 0xf);  // row_shr:1
+    ASGART_DPP_ADD(0x112, 0xf);  // row_shr:2
+    ASGART_DPP_ADD(0x114, 0xf);  // row_shr:4
+    ASGART_DPP_ADD(0x118, 0xf);  // row_shr:8
+    ASGART_DPP_ADD(0x142, 0xa);  // row_bcast:15 -> rows 1, 3
+    ASGART_DPP_ADD(0x143, 0xc);  // row_bcast:31 -> rows 2, 3
+#undef ASGART_DPP_ADD
+    return x;
 }
 
-// exclusive block scan of one ScanEl per thread (kScanBlock threads): wave-level scans through
-// register shuffles, one LDS exchange of the four wave totals
+constexpr int kScanBlock = 256;
+constexpr int kScanRounds = 32;                                  // rounds of 64 probes per wave and tile
+constexpr int kScanWaveSpan = 64 * kScanRounds;                  // probes a wave owns in a tile
+constexpr int kScanTile = kScanWaveSpan * (kScanBlock / 64);     // 8192 probes
+constexpr int kStartCap = kScanTile + kScanTile / 2;             // segment starts buffered per workgroup (a tile adds <= kScanTile)
+
+// Tile descriptors of the look-back: two 64-bit words per tile, each carrying the descriptor's status in its top two bits
+// (0 nothing, 1 the tile's own aggregate, 2 its inclusive prefix), written and read with relaxed device-scope atomics -- a
+// reader that finds the two words in different states (a prefix overwriting an aggregate) reads again.
+//   w0 = status << 62 | flags << 32 | c         w1 = status << 62 | hits (< 2^62)
+constexpr unsigned long long kScanAgg = 1ull, kScanPre = 2ull;
+__device__ inline void scan_publish(unsigned long long *desc, unsigned long long tile, unsigned long long status, const ScanEl &e) {
+    __hip_atomic_store(&desc[2 * tile], status << 62 | (unsigned long long)e.flags << 32 | e.c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&desc[2 * tile + 1], status << 62 | e.hits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// -> status (0: not there yet, or caught between two states)
+__device__ inline uint32_t scan_peek(const unsigned long long *desc, unsigned long long tile, ScanEl &e) {
+    const unsigned long long w0 = __hip_atomic_load(&desc[2 * tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long w1 = __hip_atomic_load(&desc[2 * tile + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((w0 >> 62) != (w1 >> 62)) return 0u;
+    e.hits = w1 & ((1ull << 62) - 1ull);
+    e.c = (uint32_t)w0;
+    e.flags = (uint32_t)(w0 >> 32) & 7u;
+    return (uint32_t)(w0 >> 62);
+}
+
+__device__ inline ScanEl shfl_el(const ScanEl &e, int src) {
+    ScanEl r;
+    r.hits = __shfl(e.hits, src);
+    r.c = __shfl(e.c, src);
+    r.flags = __shfl(e.flags, src);
+    return r;
+}
 __device__ inline ScanEl shfl_up_el(const ScanEl &e, int d) {
     ScanEl r;
     r.hits = __shfl_up(e.hits, d);
@@ -648,235 +682,266 @@ __device__ inline ScanEl shfl_up_el(const ScanEl &e, int d) {
     return r;
 }
 
-__device__ inline ScanEl block_exclusive_scan(ScanEl v, ScanEl *sh, ScanEl *block_total) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    ScanEl inc = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const ScanEl o = shfl_up_el(inc, d);
-        if (lane >= d) inc = scan_combine(o, inc);
-    }
-    if (lane == 63) sh[wave] = inc;
-    __syncthreads();
-    ScanEl before = scan_identity(), total = scan_identity();
-#pragma unroll
-    for (int w = 0; w < kScanBlock / 64; ++w) {
-        const ScanEl a = sh[w];
-        if (w < wave) before = scan_combine(before, a);
-        total = scan_combine(total, a);
-    }
-    ScanEl excl = shfl_up_el(inc, 1);
-    if (lane == 0) excl = scan_identity();
-    *block_total = total;
-    __syncthreads();
-    return scan_combine(before, excl);
-}
+// masks of the lanes above / from a lane on (l in 0..63; l = -1: every lane)
+__device__ inline unsigned long long lanes_above(int l) { return l < 0 ? ~0ull : (l >= 63 ? 0ull : ~((2ull << l) - 1ull)); }
+__device__ inline unsigned long long lanes_from(int l) { return l <= 0 ? ~0ull : ~((1ull << l) - 1ull); }
 
-// Coalesced staging of one scan tile: hit counts and "first probe of a chunk" marks go through
-// LDS so that each thread can then walk its kScanItems consecutive probes without strided global
-// accesses or a per-thread chunk bisection.
-__device__ inline void stage_scan_tile(const RunParams &rp, const uint32_t *__restrict__ p_filt,
-                                       uint32_t tile_g0, uint32_t g_end, uint32_t *s_f, uint8_t *s_first) {
-    for (uint32_t idx = threadIdx.x; idx < (uint32_t)kScanTile; idx += kScanBlock) {
-        const uint32_t g = tile_g0 + idx;
-        s_f[scan_pos(idx)] = g < g_end ? p_filt[g] : kSkipN;
-        s_first[scan_pos(idx)] = 0;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint32_t tile_end = min(tile_g0 + (uint32_t)kScanTile, g_end);
-        for (int c = chunk_of(rp.ch, tile_g0); c < rp.ch.n_chunks; ++c) {
-            const uint32_t pb = rp.ch.pbase[c];
-            if (pb >= tile_end) break;
-            // only non-empty chunks have a first probe
-            if (pb >= tile_g0 && rp.ch.pbase[c + 1] > pb) s_first[scan_pos(pb - tile_g0)] = 1;
-        }
-        // (the first tile of a window that starts in mid-chunk: a reset of its own kind)
-        if (rp.init_unknown && tile_g0 + rp.win_len == g_end) s_first[0] = 2;
-    }
-    __syncthreads();
-}
-
-// the kScanItems elements of this thread (from the staged tile); returns their combination
-__device__ inline ScanEl load_thread_items(const uint32_t *s_f, const uint8_t *s_first, ScanEl *items) {
-    ScanEl agg = scan_identity();
-    const uint32_t i0 = scan_pos(threadIdx.x * kScanItems);
-    for (int a = 0; a < kScanItems; ++a) {
-        const uint32_t f = s_f[i0 + a];
-        // probes past the end of the window were staged as skipped: identity elements
-        items[a] = scan_element(f, (uint32_t)s_first[i0 + a]);
-        agg = scan_combine(agg, items[a]);
-    }
-    return agg;
-}
-
-__global__ __launch_bounds__(kScanBlock) void scan_reduce_kernel(RunParams rp,
-                                                                 const uint32_t *__restrict__ p_filt,
-                                                                 ScanEl *__restrict__ blk) {
-    __shared__ ScanEl sh[kScanBlock];
-    __shared__ uint32_t s_f[kScanTilePad];
-    __shared__ uint8_t s_first[kScanTilePad];
-    ScanEl items[kScanItems];
-    uint32_t g_end;
-    const uint32_t tile_g0 = rp.tile_of(blockIdx.x, (uint32_t)kScanTile, g_end);
-    stage_scan_tile(rp, p_filt, tile_g0, g_end, s_f, s_first);
-    ScanEl agg = load_thread_items(s_f, s_first, items);
-    ScanEl total;
-    (void)block_exclusive_scan(agg, sh, &total);
-    if (threadIdx.x == 0) blk[blockIdx.x] = total;
-}
-
-// single block: exclusive scan of the block aggregates in place
-__global__ __launch_bounds__(1024) void scan_mid_kernel(ScanEl *__restrict__ blk, uint32_t n_blk,
-                                                        unsigned long long *__restrict__ ctr) {
-    __shared__ ScanEl sh[1024];
-    const int t = threadIdx.x;
-    const uint32_t per = (n_blk + 1023u) / 1024u;
-    const uint32_t b0 = t * per, b1 = min(n_blk, b0 + per);
-    ScanEl agg = scan_identity();
-    for (uint32_t b = b0; b < b1; ++b) agg = scan_combine(agg, blk[b]);
-    sh[t] = agg;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        ScanEl cur = sh[t];
-        ScanEl prev = t >= off ? sh[t - off] : scan_identity();
-        __syncthreads();
-        if (t >= off) sh[t] = scan_combine(prev, cur);
-        __syncthreads();
-    }
-    ScanEl run = t > 0 ? sh[t - 1] : scan_identity();
-    if (t == 1023) ctr[CT_TOTAL_HITS] = sh[1023].hits;
-    for (uint32_t b = b0; b < b1; ++b) {
-        ScanEl v = blk[b];
-        blk[b] = run;
-        run = scan_combine(run, v);
-    }
-}
-
-// Down-sweep: row offsets, segment starts and the per-call statistics.  Workgroups are persistent (tile =
-// blockIdx.x, + gridDim.x, ...): the statistics stay in registers across tiles and the segment starts in LDS, so a
-// workgroup issues its handful of global atomics once, not per tile -- same-address global atomics run at only
-// ~88 per microsecond chip-wide, and with one workgroup per tile (150 K tiles x 6 counters in one cache line at
-// 3.1 Gbp) they, not the 5 GB the kernel streams, set its duration.
-constexpr int kStartCap = 2 * kScanTile;  // a tile adds at most kScanTile starts (one-probe chunks)
-
-__global__ __launch_bounds__(kScanBlock) void scan_down_kernel(RunParams rp,
-                                                               const uint32_t *__restrict__ p_filt,
-                                                               const uint32_t *__restrict__ p_raw,
-                                                               const ScanEl *__restrict__ blk, uint32_t n_blk,
-                                                               unsigned long long *__restrict__ row_off,
-                                                               uint32_t *__restrict__ seg_list,
-                                                               unsigned long long *__restrict__ ctr) {
-    __shared__ ScanEl sh[kScanBlock];
-    __shared__ unsigned long long sh_stat[5];
-    __shared__ uint32_t s_f[kScanTilePad];
-    __shared__ uint8_t s_first[kScanTilePad];
-    __shared__ unsigned long long s_row[kScanTilePad];
+__global__ __launch_bounds__(kScanBlock) void scan_segments_kernel(RunParams rp, const uint32_t *__restrict__ p_filt,
+                                                                   unsigned long long *__restrict__ desc, uint32_t n_tiles,
+                                                                   unsigned long long *__restrict__ row_off,
+                                                                   uint32_t *__restrict__ seg_list,
+                                                                   unsigned long long *__restrict__ ctr) {
+    __shared__ ScanEl s_wave[kScanBlock / 64];  // the waves' aggregates of the tile
+    __shared__ ScanEl s_excl;                   // the tile's exclusive prefix
+    __shared__ uint32_t s_tile;
     __shared__ uint32_t s_start[kStartCap];
     __shared__ uint32_t s_nstart;
     __shared__ unsigned long long s_gbase;
-    if (threadIdx.x < 5) sh_stat[threadIdx.x] = 0;
-    if (threadIdx.x == 0) s_nstart = 0;
-    unsigned long long st_n = 0, st_card = 0, st_hit = 0, st_raw = 0, st_searched = 0;
-    const int lane = threadIdx.x & 63;
-    const uint32_t i0 = threadIdx.x * kScanItems;
-    // (block-uniform) append the collected segment starts: order is irrelevant, families are sorted by
-    // (start probe, ordinal) afterwards
+    __shared__ unsigned long long sh_stat[4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull, le_mask = lt_mask | (1ull << lane);
+    if (tid < 4) sh_stat[tid] = 0;
+    if (tid == 0) s_nstart = 0;
+    unsigned long long st_n = 0, st_card = 0, st_hit = 0, st_valid = 0;  // (wave-uniform: popcounts of ballots)
+    // (block-uniform) append the collected segment starts: order is irrelevant, families are sorted by (start probe,
+    // ordinal) afterwards
     auto flush_starts = [&]() {
         const uint32_t ns = s_nstart;
         if (ns) {
-            if (threadIdx.x == 0) s_gbase = atomicAdd(&ctr[CT_SEG], (unsigned long long)ns);
+            if (tid == 0) s_gbase = atomicAdd(&ctr[CT_SEG], (unsigned long long)ns);
             __syncthreads();
             const unsigned long long gb = s_gbase;
-            for (uint32_t idx = threadIdx.x; idx < ns; idx += kScanBlock) seg_list[gb + idx] = s_start[idx];
+            for (uint32_t idx = tid; idx < ns; idx += kScanBlock) seg_list[gb + idx] = s_start[idx];
             __syncthreads();
-            if (threadIdx.x == 0) s_nstart = 0;
+            if (tid == 0) s_nstart = 0;
             __syncthreads();
         }
     };
-    for (uint32_t tile = blockIdx.x; tile < n_blk; tile += gridDim.x) {
-        ScanEl items[kScanItems];
+    __syncthreads();
+    for (;;) {
+        if (tid == 0) s_tile = (uint32_t)atomicAdd(&ctr[CT_SCAN_TICKET], 1ull);  // tiles in ticket order: every predecessor
+        __syncthreads();                                                          // of a tile belongs to a running workgroup
+        const uint32_t tile = s_tile;
+        if (tile >= n_tiles) break;
         uint32_t g_end;
         const uint32_t tile_g0 = rp.tile_of(tile, (uint32_t)kScanTile, g_end);
-        const uint32_t g0 = tile_g0 + i0;
-        stage_scan_tile(rp, p_filt, tile_g0, g_end, s_f, s_first);
-        ScanEl agg = load_thread_items(s_f, s_first, items);
-        ScanEl total;
-        ScanEl excl = block_exclusive_scan(agg, sh, &total);
-        ScanEl run = scan_combine(blk[tile], excl);
-        for (int a = 0; a < kScanItems; ++a) {
-            const uint32_t g = g0 + a;
-            const bool valid = g < g_end;
-            bool start = false;
-            if (valid) {
-                const uint32_t f = s_f[scan_pos(i0) + a];
-                s_row[scan_pos(i0) + a] = run.hits;
-                const bool hit = f < kPending && f > 0;
-                if (f == kSkipN) ++st_n;
-                else {
-                    ++st_searched;
-                    if (f == kSkipCard) ++st_card;
-                    else if (hit) ++st_hit;
+        const uint32_t wg0 = tile_g0 + wave * (uint32_t)kScanWaveSpan;  // this wave's first probe
+        const bool syn_first = rp.init_unknown && tile_g0 + rp.win_len == g_end && wave == 0u;  // (a window that starts mid-chunk)
+        // ---- the tile's counts: 32 coalesced loads per lane, all in flight together ----------------------------------
+        uint32_t f[kScanRounds];
+#pragma unroll
+        for (int r = 0; r < kScanRounds; ++r) {
+            const uint32_t g = wg0 + (uint32_t)r * 64u + lane;
+            f[r] = g < g_end ? p_filt[g] : kSkipN;  // (behind the window's end: nothing)
+        }
+        // the chunk starts of this wave's span, round by round: a scalar cursor over the (few) chunks
+        int c_first = chunk_of_uniform(rp.ch, wg0);
+        if (rp.ch.pbase[c_first] < wg0 || rp.ch.pbase[c_first + 1] == rp.ch.pbase[c_first]) {  // next non-empty chunk that starts at or behind wg0
+            ++c_first;
+            while (c_first < rp.ch.n_chunks && rp.ch.pbase[c_first + 1] == rp.ch.pbase[c_first]) ++c_first;
+        }
+        const uint32_t pb_first = c_first < rp.ch.n_chunks ? rp.ch.pbase[c_first] : 0xFFFFFFFFu;
+        // first probes of chunks in [ga, ga + 64): cn / pb = the next chunk that has not started yet and its first probe
+        auto resets_of = [&](int &cn, uint32_t &pb, uint32_t ga) -> unsigned long long {
+            unsigned long long m = 0;
+            while (pb < ga + 64u && pb < g_end) {  // (pb = ~0u once the table is exhausted)
+                const uint32_t pb_next = rp.ch.pbase[cn + 1];             // (the table has n_chunks + 1 entries)
+                if (pb_next > pb) m |= 1ull << (pb - ga);                 // (only non-empty chunks have a first probe)
+                ++cn;
+                pb = cn < rp.ch.n_chunks ? pb_next : 0xFFFFFFFFu;
+            }
+            return m;
+        };
+        // one round's element: what it adds to a running (c, flags)
+        auto round_el = [&](unsigned long long hm, unsigned long long qm, unsigned long long rm, bool syn) -> ScanEl {
+            ScanEl e{0ull, 0u, 0u};
+            const int lh = hm ? 63 - __clzll((long long)hm) : -1, lr = rm ? 63 - __clzll((long long)rm) : -1;
+            if (lr >= 0) {
+                const bool hit_since = lh >= lr;
+                e.c = (uint32_t)__popcll(qm & (hit_since ? lanes_above(lh) : lanes_from(lr)));
+                e.flags = 2u | (hit_since ? 1u : 0u) | ((syn && lr == 0) ? 4u : 0u);
+            } else if (lh >= 0) {
+                e.c = (uint32_t)__popcll(qm & lanes_above(lh));
+                e.flags = 1u;
+            } else {
+                e.c = (uint32_t)__popcll(qm);
+            }
+            return e;
+        };
+        // ---- pass 1: the wave's aggregate -------------------------------------------------------------------------------
+        ScanEl agg = scan_identity();
+        unsigned long long vsum = 0;
+        {
+            int cn = c_first;
+            uint32_t pb = pb_first;
+#pragma unroll
+            for (int r = 0; r < kScanRounds; ++r) {
+                const uint32_t fr = f[r];
+                const bool hit = fr >= 1u && fr < kPending;
+                const unsigned long long hm = __ballot(hit), qm = __ballot(fr == 0u);
+                unsigned long long rm = resets_of(cn, pb, wg0 + (uint32_t)r * 64u);
+                const bool syn = syn_first && r == 0;
+                if (syn) rm |= 1ull;
+                vsum += hit ? fr : 0u;
+                const ScanEl e = round_el(hm, qm, rm, syn);
+                agg = scan_combine(agg, e);
+            }
+            for (int off = 32; off > 0; off >>= 1) vsum += __shfl_down(vsum, off);
+            agg.hits = __shfl(vsum, 0);
+        }
+        if (lane == 0) s_wave[wave] = agg;
+        __syncthreads();
+        // ---- the tile's aggregate is published, its exclusive prefix assembled from its predecessors' (wave 0) --------
+        if (wave == 0) {
+            ScanEl tile_agg = scan_identity();
+            for (int w = 0; w < kScanBlock / 64; ++w) tile_agg = scan_combine(tile_agg, s_wave[w]);
+            ScanEl excl = scan_identity();
+            if (tile == 0) {
+                if (lane == 0) scan_publish(desc, 0, kScanPre, tile_agg);
+            } else {
+                if (lane == 0) scan_publish(desc, tile, kScanAgg, tile_agg);
+                // windows of 64 predecessors, nearest first: lane l looks at tile `hi - 64 + l` (lane 63 = the nearest)
+                ScanEl acc = scan_identity();  // combination of the tiles [hi, tile)
+                long long hi = tile;
+                for (;;) {
+                    const long long t_l = hi - 64 + (long long)lane;
+                    ScanEl e = scan_identity();
+                    uint32_t stt = 3u;  // (no such tile: identity, never waited for)
+                    if (t_l >= 0) stt = scan_peek(desc, (unsigned long long)t_l, e);
+                    const unsigned long long pm = __ballot(stt == (uint32_t)kScanPre), zm = __ballot(stt == 0u);
+                    const int pl = pm ? 63 - __clzll((long long)pm) : -1;  // the nearest tile whose inclusive prefix is known
+                    if (zm & lanes_above(pl)) {  // a tile between it and us has not published yet
+                        __builtin_amdgcn_s_sleep(2);
+                        continue;
+                    }
+                    if ((int)lane < pl || stt == 3u) e = scan_identity();
+                    // ordered combination of the lanes pl .. 63 (an inclusive scan; lane 63 holds the result)
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) {
+                        const ScanEl o = shfl_up_el(e, d);
+                        if ((int)lane >= d) e = scan_combine(o, e);
+                    }
+                    acc = scan_combine(shfl_el(e, 63), acc);
+                    if (pl >= 0 || hi - 64 <= 0) break;
+                    hi -= 64;
                 }
+                excl = acc;
+                if (lane == 0) scan_publish(desc, tile, kScanPre, scan_combine(excl, tile_agg));
+            }
+            if (lane == 0) {
+                s_excl = excl;
+                if (tile + 1u == n_tiles) ctr[CT_TOTAL_HITS] = excl.hits + tile_agg.hits;
+            }
+        }
+        __syncthreads();
+        // ---- pass 2: row offsets and segment starts, out of the registers -----------------------------------------------
+        ScanEl run = s_excl;
+        for (uint32_t w = 0; w < wave; ++w) run = scan_combine(run, s_wave[w]);
+        {
+            int cn = c_first;
+            uint32_t pb = pb_first;
+#pragma unroll
+            for (int r = 0; r < kScanRounds; ++r) {
+                const uint32_t ga = wg0 + (uint32_t)r * 64u, g = ga + lane;
+                const uint32_t fr = f[r];
+                const bool valid = g < g_end;
+                const bool hit = fr >= 1u && fr < kPending;
+                const unsigned long long hm = __ballot(hit), qm = __ballot(fr == 0u);
+                unsigned long long rm = resets_of(cn, pb, ga);
+                const bool syn = syn_first && r == 0;
+                if (syn) rm |= 1ull;
+                // statistics (of the window's probes)
+                const unsigned long long vm = __ballot(valid);
+                st_valid += (unsigned long long)__popcll(vm);
+                st_n += (unsigned long long)__popcll(__ballot(valid && fr == kSkipN));
+                st_card += (unsigned long long)__popcll(__ballot(fr == kSkipCard));
+                st_hit += (unsigned long long)__popcll(hm);
+                // row offsets: exclusive prefix of the hit counts (two 16-bit halves: a count may be anything below 2^32)
+                const uint32_t v = hit ? fr : 0u;
+                const uint32_t lo16 = wave_incl_scan(v & 0xFFFFu), hi16 = wave_incl_scan(v >> 16);
+                const unsigned long long incl = (unsigned long long)lo16 + ((unsigned long long)hi16 << 16);
+                if (valid) row_off[g] = run.hits + incl - v;
+                // (the row offset behind a window's last probe: what the CSR holds up to there)
+                if (valid && g + 1u == g_end) row_off[g_end] = run.hits + incl;
+                // segment starts: a hit-probe of this call's own range with no hit-probe in front of it since its chunk
+                // started, or with t* quiet probes in between
+                bool start = false;
                 if (hit && rp.owned(g)) {
                     // (a window's first probe is never owned when the window starts in mid-chunk: the look-back halo is
-                    // at least one probe; so `run` -- the probes in front of g -- lies in g's window)
-                    const bool win_first = (items[a].flags & 4u) != 0u, chunk_first = (items[a].flags & 6u) == 2u;
-                    const bool has_before = !chunk_first && !win_first && (run.flags & 1u);
-                    const bool unknown = win_first || (!chunk_first && scan_unknown(run));
-                    const uint32_t quiet = win_first ? 0u : run.c;
+                    // at least one probe)
+                    const unsigned long long rb = rm & le_mask;
+                    const int lr = rb ? 63 - __clzll((long long)rb) : -1;         // the last reset at or in front of this probe
+                    const unsigned long long hb = hm & lt_mask & lanes_from(lr);  // hit-probes in front of it, not before that reset
+                    const int lh = hb ? 63 - __clzll((long long)hb) : -1;
+                    bool has_before, unknown;
+                    uint32_t quiet;
+                    if (lh >= 0) {
+                        has_before = true;
+                        unknown = false;
+                        quiet = (uint32_t)__popcll(qm & lt_mask & lanes_above(lh));
+                    } else if (lr >= 0) {
+                        has_before = false;
+                        unknown = syn && lr == 0 && lane != 0u;  // (behind the window's own reset, no hit-probe since)
+                        quiet = (uint32_t)__popcll(qm & lt_mask & lanes_from(lr));
+                        if (unknown) has_before = true;  // (it may have one: decided by the quiet run, or not at all)
+                    } else {
+                        has_before = (run.flags & 1u) != 0u;
+                        unknown = scan_unknown(run);
+                        quiet = run.c + (uint32_t)__popcll(qm & lt_mask);
+                        if (unknown) has_before = true;
+                    }
                     if (unknown && quiet < rp.tstar) atomicAdd(&ctr[CT_AMBIG], 1ull);
                     start = !has_before || quiet >= rp.tstar;
                 }
-                run = scan_combine(run, items[a]);
-            }
-            const unsigned long long m = __ballot(start);
-            if (m) {
-                const int leader = __ffsll((long long)m) - 1;
-                uint32_t base = 0;
-                if (lane == leader) base = atomicAdd(&s_nstart, (uint32_t)__popcll(m));
-                base = __shfl(base, leader);
-                if (start) s_start[base + __popcll(m & ((1ull << lane) - 1ull))] = g;
-            }
-        }
-        // (the row offset behind a window's last probe: what the CSR holds up to there)
-        if (g0 < g_end && g0 + kScanItems >= g_end) row_off[g_end] = run.hits;
-        __syncthreads();
-        // coalesced write-out of the row offsets and coalesced read of the interval sizes (stats)
-        for (uint32_t idx = threadIdx.x; idx < (uint32_t)kScanTile; idx += kScanBlock) {
-            const uint32_t g = tile_g0 + idx;
-            if (g < g_end) {
-                row_off[g] = s_row[scan_pos(idx)];
-                if (s_f[scan_pos(idx)] != kSkipN) st_raw += p_raw[g];
+                const unsigned long long sm = __ballot(start);
+                if (sm) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(&s_nstart, (uint32_t)__popcll(sm));
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                    if (start) s_start[base + (uint32_t)__popcll(sm & lt_mask)] = g;
+                }
+                ScanEl e = round_el(hm, qm, rm, syn);
+                e.hits = __shfl(incl, 63);
+                run = scan_combine(run, e);
             }
         }
-        __syncthreads();  // the staged tile is overwritten by the next one
+        __syncthreads();  // (s_tile, s_wave, s_excl are rewritten by the next tile)
         if (s_nstart > (uint32_t)(kStartCap - kScanTile)) flush_starts();
     }
     flush_starts();
-    // wave reduction first: 256 same-address LDS atomics per counter would serialise
-    for (int off = 32; off > 0; off >>= 1) {
-        st_n += __shfl_down(st_n, off);
-        st_card += __shfl_down(st_card, off);
-        st_hit += __shfl_down(st_hit, off);
-        st_raw += __shfl_down(st_raw, off);
-        st_searched += __shfl_down(st_searched, off);
-    }
     if (lane == 0) {
         atomicAdd(&sh_stat[0], st_n);
         atomicAdd(&sh_stat[1], st_card);
         atomicAdd(&sh_stat[2], st_hit);
-        atomicAdd(&sh_stat[3], st_raw);
-        atomicAdd(&sh_stat[4], st_searched);
+        atomicAdd(&sh_stat[3], st_valid);
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         if (sh_stat[0]) atomicAdd(&ctr[CT_N_SKIPPED], sh_stat[0]);
         if (sh_stat[1]) atomicAdd(&ctr[CT_CARD_SKIPPED], sh_stat[1]);
         if (sh_stat[2]) atomicAdd(&ctr[CT_WITH_HITS], sh_stat[2]);
-        if (sh_stat[3]) atomicAdd(&ctr[CT_RAW_HITS], sh_stat[3]);
-        if (sh_stat[4]) atomicAdd(&ctr[CT_SEARCHED], sh_stat[4]);
+        if (sh_stat[3] > sh_stat[0]) atomicAdd(&ctr[CT_SEARCHED], sh_stat[3] - sh_stat[0]);
     }
+}
+
+// The sum of the raw interval sizes over the searched probes (asgart_stats.raw_hits: a statistic of the call, wanted by
+// the parity tests and the bench's yardstick, not by the path) -- computed when the statistics are asked for, from the
+// per-probe arrays the call left in its workspace, instead of costing every call a second read of 4 bytes per probe.
+__global__ __launch_bounds__(256) void raw_hits_kernel(RunParams rp, const uint32_t *__restrict__ p_filt,
+                                                       const uint32_t *__restrict__ p_raw, unsigned long long *__restrict__ out) {
+    unsigned long long sum = 0;
+    const uint32_t n_t = rp.n_tiles(1024u);
+    for (uint32_t t = blockIdx.x; t < n_t; t += gridDim.x) {
+        uint32_t g_end;
+        const uint32_t g0 = rp.tile_of(t, 1024u, g_end);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const uint32_t g = g0 + (uint32_t)a * 256u + threadIdx.x;
+            if (g < g_end && p_filt[g] != kSkipN) sum += p_raw[g];
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);
+    if ((threadIdx.x & 63u) == 0 && sum) atomicAdd(out, sum);
 }
 
 // ---------------------------------------------------------------- K3 ---------
