@@ -76,7 +76,7 @@ __device__ inline uint32_t select_bit(unsigned long long m, uint32_t n) {
 }
 
 template <class PosT, int S, int NT, int HB, int kRows = 1024, int kE = 4, bool kPipe = true>
-__global__ __launch_bounds__(NT) void extend_fast_kernel(ExtParams<PosT> P) {
+__global__ __launch_bounds__(NT, (NT == 512 || NT == 256) ? 4 : 1) void extend_fast_kernel(ExtParams<PosT> P) {  // (256 / 512 threads: four waves per SIMD, so that four / two workgroups share a compute unit)
     constexpr int CAP = S * NT;
     constexpr int NW = NT / 64;
     constexpr uint32_t kNone = 0xFFFFFFFFu;    // best[]: no arm accepts this hit

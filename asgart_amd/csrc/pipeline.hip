@@ -77,6 +77,9 @@ template <class SlotT> constexpr int kFastLongRows = sizeof(SlotT) == 4 ? 2048 :
 // no arms, so the shape has S x 896 slots: 5 x 896 (64-bit positions: 4 x 896)
 template <class SlotT> constexpr int kK8LongLayers = sizeof(SlotT) == 4 ? 5 : 4;
 constexpr uint32_t kK8LongSlots = 896;
+// (A half shape -- 512 threads, 5 x 384 slots, 75 KB of LDS, two workgroups per compute unit -- was measured in round 6:
+// 37 % less compute-unit time per hit-probe, 25 % more wall time, and the 208 segments of a GRCh38-sized step whose arms
+// do not fit it fall to tier 6's kernel, one of them for 145 ms: the step doubled.  DESIGN_HISTORY.md.)
 constexpr int kArmCapSmall = 256;   // live arms per wave in LDS, common case
 constexpr uint32_t kTier1MaxSum = 20000;  // placement: busier segments never run on a single wave
 constexpr int kArmCapMid = 768;     // second tier: block-cooperative kernel, 256 threads per segment
@@ -441,7 +444,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
     HIP_TRY(hipEventRecord(cx.ev[1], s));
     // ---- K2: scans + segmentation ----------------------------------------------
     HIP_TRY(hipMemsetAsync(scan_desc, 0, (size_t)n_blk * 16, s));
-    scan_segments_kernel<<<std::min<uint32_t>(n_blk, 256u * 3u), kScanBlock, 0, s>>>(rp, p_filt, scan_desc, n_blk, row_off, seg_list, d_ctr);
+    scan_segments_kernel<<<std::min<uint32_t>(n_blk, 256u * 2u), kScanBlock, 0, s>>>(rp, p_filt, scan_desc, n_blk, row_off, seg_list, d_ctr);
     HIP_TRY(hipEventRecord(cx.ev[2], s));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, kCtrBytes, hipMemcpyDeviceToHost, s));

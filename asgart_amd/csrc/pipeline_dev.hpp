@@ -594,11 +594,10 @@ __global__ __launch_bounds__(256) void big_count_kernel(IndexView<SlotT> ix, Run
 // "unknown": what the automaton held in front of it is not known, and stays unknown until the first hit-probe or real
 // chunk start behind it.
 // Single pass with decoupled look-back: persistent workgroups take tiles of kScanTile probes in ticket order; a tile's
-// counts are loaded once into registers (32 per lane), its aggregate is published, the exclusive prefix is assembled
-// from the predecessors' published aggregates / prefixes, and the tile is walked again out of the registers -- row
-// offsets written, segment starts decided.  Inside a tile nothing is staged through LDS: a wave owns 2048 consecutive
-// probes as 32 rounds of 64, and everything a round needs about its neighbours comes out of three ballots (hit, quiet,
-// reset) by bit arithmetic.  The round-5 version (reduce, mid, down: three kernels, every tile staged through LDS and
+// counts are loaded once (16 loads per lane in flight together), its aggregate is published, the exclusive prefix is
+// assembled from the predecessors' published aggregates / prefixes, and the tile is walked again -- row offsets written,
+// segment starts decided.  A wave owns 1024 consecutive probes as 16 rounds of 64, and everything a round needs about
+// its neighbours comes out of three ballots (hit, quiet, reset) by bit arithmetic.  The round-5 version (reduce, mid, down: three kernels, every tile staged through LDS and
 // walked item by item per thread) streamed 1.2 TB/s; this one is bound by its 12 bytes per probe.
 struct ScanEl {
     unsigned long long hits;
@@ -641,11 +640,25 @@ __device__ inline uint32_t wave_incl_scan(uint32_t x) {
     return x;
 }
 
-constexpr int kScanBlock = 256;
-constexpr int kScanRounds = 32;                                  // rounds of 64 probes per wave and tile
+// inclusive running maximum across the 64 lanes of a wave (values >= 0: lanes without a source contribute 0)
+__device__ inline uint32_t wave_incl_max_scan(uint32_t x) {
+#define ASGART_DPP_MAX(ctrl, rows) \
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, ctrl, rows, 0xf, false))
+    ASGART_DPP_MAX(0x111, 0xf);  // row_shr:1
+    ASGART_DPP_MAX(0x112, 0xf);  // row_shr:2
+    ASGART_DPP_MAX(0x114, 0xf);  // row_shr:4
+    ASGART_DPP_MAX(0x118, 0xf);  // row_shr:8
+    ASGART_DPP_MAX(0x142, 0xa);  // row_bcast:15 -> rows 1, 3
+    ASGART_DPP_MAX(0x143, 0xc);  // row_bcast:31 -> rows 2, 3
+#undef ASGART_DPP_MAX
+    return x;
+}
+
+constexpr int kScanBlock = 512;
+constexpr int kScanRounds = 16;                                  // rounds of 64 probes per wave and tile
 constexpr int kScanWaveSpan = 64 * kScanRounds;                  // probes a wave owns in a tile
 constexpr int kScanTile = kScanWaveSpan * (kScanBlock / 64);     // 8192 probes
-constexpr int kStartCap = kScanTile + kScanTile / 2;             // segment starts buffered per workgroup (a tile adds <= kScanTile)
+constexpr int kStartCap = kScanTile + kScanTile / 4;             // segment starts buffered per workgroup (a tile adds <= kScanTile)
 
 // Tile descriptors of the look-back: two 64-bit words per tile, each carrying the descriptor's status in its top two bits
 // (0 nothing, 1 the tile's own aggregate, 2 its inclusive prefix), written and read with relaxed device-scope atomics -- a
@@ -686,11 +699,46 @@ __device__ inline ScanEl shfl_up_el(const ScanEl &e, int d) {
 __device__ inline unsigned long long lanes_above(int l) { return l < 0 ? ~0ull : (l >= 63 ? 0ull : ~((2ull << l) - 1ull)); }
 __device__ inline unsigned long long lanes_from(int l) { return l <= 0 ? ~0ull : ~((1ull << l) - 1ull); }
 
+// The start decision of one hit-probe in a round that holds a chunk start (or the reset of a window that starts in
+// mid-chunk): rare, and kept out of line -- the rounds of a tile are unrolled (their counts sit in registers).
+__device__ __noinline__ void scan_starts_with_resets(bool hit, unsigned long long hm, unsigned long long qm, unsigned long long rm,
+                                                     bool syn, uint32_t run_c, uint32_t run_flags, uint32_t tstar, bool &start,
+                                                     bool &amb) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull, le_mask = lt_mask | (1ull << lane);
+    start = amb = false;
+    if (!hit) return;
+    const unsigned long long rb = rm & le_mask;
+    const int lr = rb ? 63 - __clzll((long long)rb) : -1;         // the last reset at or in front of this probe
+    const unsigned long long hb = hm & lt_mask & lanes_from(lr);  // hit-probes in front of it, not before that reset
+    const int lh = hb ? 63 - __clzll((long long)hb) : -1;
+    bool has_before, unknown;
+    uint32_t quiet;
+    if (lh >= 0) {
+        has_before = true;
+        unknown = false;
+        quiet = (uint32_t)__popcll(qm & lt_mask & lanes_above(lh));
+    } else if (lr >= 0) {
+        has_before = false;
+        unknown = syn && lr == 0 && lane != 0u;  // (behind the window's own reset, no hit-probe since)
+        quiet = (uint32_t)__popcll(qm & lt_mask & lanes_from(lr));
+        if (unknown) has_before = true;  // (it may have one: decided by the quiet run, or not at all)
+    } else {
+        has_before = (run_flags & 1u) != 0u;
+        unknown = (run_flags & 5u) == 4u;
+        quiet = run_c + (uint32_t)__popcll(qm & lt_mask);
+        if (unknown) has_before = true;
+    }
+    amb = unknown && quiet < tstar;
+    start = !has_before || quiet >= tstar;
+}
+
 __global__ __launch_bounds__(kScanBlock) void scan_segments_kernel(RunParams rp, const uint32_t *__restrict__ p_filt,
                                                                    unsigned long long *__restrict__ desc, uint32_t n_tiles,
                                                                    unsigned long long *__restrict__ row_off,
                                                                    uint32_t *__restrict__ seg_list,
                                                                    unsigned long long *__restrict__ ctr) {
+    __shared__ uint32_t s_f[kScanTile];         // the tile's counts (every wave its own span: both passes read them from here)
     __shared__ ScanEl s_wave[kScanBlock / 64];  // the waves' aggregates of the tile
     __shared__ ScanEl s_excl;                   // the tile's exclusive prefix
     __shared__ uint32_t s_tile;
@@ -699,9 +747,10 @@ __global__ __launch_bounds__(kScanBlock) void scan_segments_kernel(RunParams rp,
     __shared__ unsigned long long s_gbase;
     __shared__ unsigned long long sh_stat[4];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull, le_mask = lt_mask | (1ull << lane);
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
     if (tid < 4) sh_stat[tid] = 0;
     if (tid == 0) s_nstart = 0;
+    const bool small_counts = rp.C < (1u << 25);
     unsigned long long st_n = 0, st_card = 0, st_hit = 0, st_valid = 0;  // (wave-uniform: popcounts of ballots)
     // (block-uniform) append the collected segment starts: order is irrelevant, families are sorted by (start probe,
     // ordinal) afterwards
@@ -727,12 +776,16 @@ __global__ __launch_bounds__(kScanBlock) void scan_segments_kernel(RunParams rp,
         const uint32_t tile_g0 = rp.tile_of(tile, (uint32_t)kScanTile, g_end);
         const uint32_t wg0 = tile_g0 + wave * (uint32_t)kScanWaveSpan;  // this wave's first probe
         const bool syn_first = rp.init_unknown && tile_g0 + rp.win_len == g_end && wave == 0u;  // (a window that starts mid-chunk)
-        // ---- the tile's counts: 32 coalesced loads per lane, all in flight together ----------------------------------
-        uint32_t f[kScanRounds];
+        // ---- the tile's counts: 16 coalesced loads per lane, all in flight together ----------------------------------
+        {
+            uint32_t f[kScanRounds];
 #pragma unroll
-        for (int r = 0; r < kScanRounds; ++r) {
-            const uint32_t g = wg0 + (uint32_t)r * 64u + lane;
-            f[r] = g < g_end ? p_filt[g] : kSkipN;  // (behind the window's end: nothing)
+            for (int r = 0; r < kScanRounds; ++r) {
+                const uint32_t g = wg0 + (uint32_t)r * 64u + lane;
+                f[r] = g < g_end ? p_filt[g] : kSkipN;  // (behind the window's end: nothing)
+            }
+#pragma unroll
+            for (int r = 0; r < kScanRounds; ++r) s_f[wave * (uint32_t)kScanWaveSpan + (uint32_t)r * 64u + lane] = f[r];
         }
         // the chunk starts of this wave's span, round by round: a scalar cursor over the (few) chunks
         int c_first = chunk_of_uniform(rp.ch, wg0);
@@ -774,9 +827,9 @@ __global__ __launch_bounds__(kScanBlock) void scan_segments_kernel(RunParams rp,
         {
             int cn = c_first;
             uint32_t pb = pb_first;
-#pragma unroll
+#pragma unroll 1
             for (int r = 0; r < kScanRounds; ++r) {
-                const uint32_t fr = f[r];
+                const uint32_t fr = s_f[wave * (uint32_t)kScanWaveSpan + (uint32_t)r * 64u + lane];
                 const bool hit = fr >= 1u && fr < kPending;
                 const unsigned long long hm = __ballot(hit), qm = __ballot(fr == 0u);
                 unsigned long long rm = resets_of(cn, pb, wg0 + (uint32_t)r * 64u);
@@ -834,71 +887,75 @@ __global__ __launch_bounds__(kScanBlock) void scan_segments_kernel(RunParams rp,
             }
         }
         __syncthreads();
-        // ---- pass 2: row offsets and segment starts, out of the registers -----------------------------------------------
+        // ---- pass 2: row offsets and segment starts (the counts come back from LDS: this loop is not unrolled) -----------
         ScanEl run = s_excl;
         for (uint32_t w = 0; w < wave; ++w) run = scan_combine(run, s_wave[w]);
         {
             int cn = c_first;
             uint32_t pb = pb_first;
-#pragma unroll
+            // this call's own range of the tile's window, as probe numbers (wave-uniform)
+            const uint32_t own_lo_g = g_end - rp.win_len + rp.own_off_lo, own_hi_g = g_end - rp.win_len + rp.own_off_hi;
+#pragma unroll 1
             for (int r = 0; r < kScanRounds; ++r) {
                 const uint32_t ga = wg0 + (uint32_t)r * 64u, g = ga + lane;
-                const uint32_t fr = f[r];
-                const bool valid = g < g_end;
+                const uint32_t fr = s_f[wave * (uint32_t)kScanWaveSpan + (uint32_t)r * 64u + lane];
+                const uint32_t n_valid = ga < g_end ? min(64u, g_end - ga) : 0u;  // (lanes behind the window's end hold kSkipN)
                 const bool hit = fr >= 1u && fr < kPending;
-                const unsigned long long hm = __ballot(hit), qm = __ballot(fr == 0u);
+                const unsigned long long hm = __ballot(hit), qm = __ballot(fr == 0u), cardm = __ballot(fr == kSkipCard);
                 unsigned long long rm = resets_of(cn, pb, ga);
                 const bool syn = syn_first && r == 0;
                 if (syn) rm |= 1ull;
-                // statistics (of the window's probes)
-                const unsigned long long vm = __ballot(valid);
-                st_valid += (unsigned long long)__popcll(vm);
-                st_n += (unsigned long long)__popcll(__ballot(valid && fr == kSkipN));
-                st_card += (unsigned long long)__popcll(__ballot(fr == kSkipCard));
-                st_hit += (unsigned long long)__popcll(hm);
-                // row offsets: exclusive prefix of the hit counts (two 16-bit halves: a count may be anything below 2^32)
+                // statistics (of the window's probes): a probe is a hit-probe, quiet, skipped for its cardinality or for its N
+                const uint32_t n_hit = (uint32_t)__popcll(hm), n_card = (uint32_t)__popcll(cardm);
+                st_valid += n_valid;
+                st_hit += n_hit;
+                st_card += n_card;
+                st_n += n_valid - n_hit - n_card - (uint32_t)__popcll(qm);
+                // row offsets: exclusive prefix of the hit counts (a count is at most max_cardinality: one 32-bit scan while
+                // 64 of them fit, else two 16-bit halves)
                 const uint32_t v = hit ? fr : 0u;
-                const uint32_t lo16 = wave_incl_scan(v & 0xFFFFu), hi16 = wave_incl_scan(v >> 16);
-                const unsigned long long incl = (unsigned long long)lo16 + ((unsigned long long)hi16 << 16);
-                if (valid) row_off[g] = run.hits + incl - v;
-                // (the row offset behind a window's last probe: what the CSR holds up to there)
-                if (valid && g + 1u == g_end) row_off[g_end] = run.hits + incl;
-                // segment starts: a hit-probe of this call's own range with no hit-probe in front of it since its chunk
-                // started, or with t* quiet probes in between
-                bool start = false;
-                if (hit && rp.owned(g)) {
-                    // (a window's first probe is never owned when the window starts in mid-chunk: the look-back halo is
-                    // at least one probe)
-                    const unsigned long long rb = rm & le_mask;
-                    const int lr = rb ? 63 - __clzll((long long)rb) : -1;         // the last reset at or in front of this probe
-                    const unsigned long long hb = hm & lt_mask & lanes_from(lr);  // hit-probes in front of it, not before that reset
-                    const int lh = hb ? 63 - __clzll((long long)hb) : -1;
-                    bool has_before, unknown;
-                    uint32_t quiet;
-                    if (lh >= 0) {
-                        has_before = true;
-                        unknown = false;
-                        quiet = (uint32_t)__popcll(qm & lt_mask & lanes_above(lh));
-                    } else if (lr >= 0) {
-                        has_before = false;
-                        unknown = syn && lr == 0 && lane != 0u;  // (behind the window's own reset, no hit-probe since)
-                        quiet = (uint32_t)__popcll(qm & lt_mask & lanes_from(lr));
-                        if (unknown) has_before = true;  // (it may have one: decided by the quiet run, or not at all)
-                    } else {
-                        has_before = (run.flags & 1u) != 0u;
-                        unknown = scan_unknown(run);
-                        quiet = run.c + (uint32_t)__popcll(qm & lt_mask);
-                        if (unknown) has_before = true;
-                    }
-                    if (unknown && quiet < rp.tstar) atomicAdd(&ctr[CT_AMBIG], 1ull);
-                    start = !has_before || quiet >= rp.tstar;
+                unsigned long long incl;
+                if (small_counts) {
+                    incl = wave_incl_scan(v);
+                } else {
+                    const uint32_t lo16 = wave_incl_scan(v & 0xFFFFu), hi16 = wave_incl_scan(v >> 16);
+                    incl = (unsigned long long)lo16 + ((unsigned long long)hi16 << 16);
                 }
-                const unsigned long long sm = __ballot(start);
+                if (lane < n_valid) row_off[g] = run.hits + incl - v;
+                // (the row offset behind a window's last probe: what the CSR holds up to there)
+                if (lane + 1u == n_valid && g + 1u == g_end) row_off[g_end] = run.hits + incl;
+                // segment starts: a hit-probe of this call's own range with no hit-probe in front of it since its chunk
+                // started, or with t* quiet probes in between.  (A window's first probe is never owned when the window
+                // starts in mid-chunk: the look-back halo is at least one probe.)
+                const uint32_t l_lo = own_lo_g > ga ? min(own_lo_g - ga, 64u) : 0u, l_hi = own_hi_g > ga ? min(own_hi_g - ga, 64u) : 0u;
+                const unsigned long long ownm = (l_hi >= 64u ? ~0ull : (1ull << l_hi) - 1ull) & ~(l_lo >= 64u ? ~0ull : (1ull << l_lo) - 1ull);
+                unsigned long long sm = 0, ambm = 0;
+                if (hm & ownm) {
+                    if (!rm) {
+                        // no chunk starts in the round (all but a handful): the quiet probes below a lane, and -- by an inclusive
+                        // max-scan over the hit lanes, whose counts ascend -- the count at the last hit-probe in front of it
+                        const uint32_t Q = __builtin_amdgcn_mbcnt_hi((uint32_t)(qm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)qm, 0u));
+                        uint32_t xp = __shfl_up(wave_incl_max_scan(hit ? Q + 1u : 0u), 1);
+                        if (lane == 0u) xp = 0u;
+                        const bool has_in = xp != 0u;                                       // a hit-probe in front of it in this round
+                        const bool unknown = !has_in && scan_unknown(run);
+                        const bool has_before = has_in || (run.flags & 1u) != 0u || unknown;  // (unknown: it may have one)
+                        const uint32_t quiet = has_in ? Q - (xp - 1u) : run.c + Q;
+                        sm = __ballot(hit && (!has_before || quiet >= rp.tstar)) & ownm;
+                        ambm = __ballot(hit && unknown && quiet < rp.tstar) & ownm;
+                    } else {
+                        bool start = false, amb = false;
+                        scan_starts_with_resets(hit, hm, qm, rm, syn, run.c, run.flags, rp.tstar, start, amb);
+                        sm = __ballot(start) & ownm;
+                        ambm = __ballot(amb) & ownm;
+                    }
+                }
+                if (ambm && lane == 0u) atomicAdd(&ctr[CT_AMBIG], (unsigned long long)__popcll(ambm));
                 if (sm) {
                     uint32_t base = 0;
                     if (lane == 0) base = atomicAdd(&s_nstart, (uint32_t)__popcll(sm));
                     base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                    if (start) s_start[base + (uint32_t)__popcll(sm & lt_mask)] = g;
+                    if ((sm >> lane) & 1ull) s_start[base + (uint32_t)__popcll(sm & lt_mask)] = g;
                 }
                 ScanEl e = round_el(hm, qm, rm, syn);
                 e.hits = __shfl(incl, 63);

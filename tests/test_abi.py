@@ -62,7 +62,7 @@ def test_the_library_carries_the_gfx950_kernels_of_the_path(hiplib):
     dropped the device code would still export every host symbol).  Their mangled names are in the embedded code object."""
     blob = open(hiplib._name, "rb").read()
     for kernel in (b"probe_count_kernel", b"collect_pending_kernel", b"extend_kernel", b"extend_fast_kernel",
-                   b"extend_k8_kernel", b"extend_heavy_kernel", b"scan_down_kernel", b"cluster_barren_kernel",
+                   b"extend_k8_kernel", b"extend_heavy_kernel", b"scan_segments_kernel", b"cluster_barren_kernel",
                    b"plan_ranges_kernel", b"validate_cuts_kernel"):
         assert kernel in blob, kernel
     assert b"gfx950" in blob
