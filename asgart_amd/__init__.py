@@ -383,7 +383,9 @@ class Index:
             L.asgart_families_free(h)
         return o, d
 
-    def stats(self, flags: int = 0) -> Stats:
+    def stats(self, flags: int = 2) -> Stats:
+        """Statistics of the last search call.  flags: 1 = with the yardstick / accounting passes, 2 (default) = with raw_hits
+        (an untimed pass over the call's probes), 0 = what the call itself recorded; (i + 1) << 8 selects call context i."""
         st = Stats()
         _check(load_library().asgart_get_stats(self._h, flags, C.byref(st)))
         return st

@@ -437,6 +437,9 @@ constexpr int kMaxK = 128;         // probe sizes above 21: the first 21 bases a
                                    // (search_dev.hpp: tail_key, tail_cmp)
 constexpr int kCacheLen = 8;       // reference src/searcher.rs:15
 constexpr int kCacheEntries = 390625;  // 5^8
+constexpr int kSmallInterval = 32;  // suffix-array intervals up to this size are handled by one thread
+constexpr int kRankMin = 256;       // intervals above this size are counted by bisection when the index has position-sorted lists
+constexpr uint32_t kRawUnknown = 0xFFFFFFFFu;  // p_raw of a probe the position filter answered: its interval was never looked up
 constexpr uint32_t kSkipN = 0xFFFFFFFFu;     // probe skipped: first base 'N'
 constexpr uint32_t kSkipCard = 0xFFFFFFFEu;  // probe skipped: > max_cardinality
 constexpr uint32_t kPending = 0xFFFFFFFDu;   // large interval, counted by the wave kernel

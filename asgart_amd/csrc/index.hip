@@ -79,7 +79,7 @@ const OptDesc kOptions[] = {
     {"test_fail_alloc", &Options::test_fail_alloc, -1, 1000000000},
     {"cap6w_pct", &Options::cap6w_pct, 100, 400},
     {"solo", &Options::solo, 0, 48},
-    {"posbits", &Options::posbits, 0, 1},
+    {"posbits", &Options::posbits, 0, 2},
 };
 }  // namespace
 
@@ -392,9 +392,18 @@ __global__ __launch_bounds__(256) void build_filter_kernel(IndexView<SlotT> ix, 
 // The filter's answers by text position: bit p = "the probe that covers text[p .. p + k) in this orientation
 // passes the filter" (or is one of the text-tail corner probes, which never take the filter).  One thread per
 // 64 positions: both rolling keys (forward, and reversed for -R), one filter word per position.
+// refine (option posbits = 2): a position that passes the k-mer filter is looked up once, here, and keeps its bit only
+// if a hit of its probe can be KEPT.  The hit filter of src/automaton.rs:105-114 in text coordinates: a probe that covers
+// text[p .. p + k) keeps the occurrences x > p of its k-mer (needle not reversed: x > i + needle_offset, and i +
+// needle_offset = p) or x >= p + k (reversed needle: x >= needle_offset + L - i = p + k; the extra `m.start != i`
+// only removes hits) -- a property of the text and the position alone, whatever chunk list a call brings.  In the
+// direct pass the LEFT one of every pair of occurrences keeps a hit and the right one does not: half the lookups
+// the k-mer filter lets through end with nothing kept.  Decided exactly for intervals of up to kSmallInterval
+// occurrences (scanned) and, when the index has the position-sorted lists, for those of more than kRankMin (the
+// list's last entry is the interval's largest position); the others keep the k-mer filter's answer.
 template <class SlotT>
 __global__ __launch_bounds__(256) void build_posbits_kernel(IndexView<SlotT> ix, bool reverse, bool complement,
-                                                            const uint64_t *__restrict__ flt, int bits,
+                                                            const uint64_t *__restrict__ flt, int bits, bool refine,
                                                             unsigned long long *__restrict__ out, uint64_t n_words) {
     const int k = ix.k;
     const uint64_t mask = k >= 21 ? ~0ull >> 1 : (1ull << (3 * k)) - 1ull;
@@ -419,7 +428,23 @@ __global__ __launch_bounds__(256) void build_posbits_kernel(IndexView<SlotT> ix,
             rk = (rk >> 3) | (c << (3 * (k - 1)));
             const uint64_t q = reverse ? rk : fk;
             bool pass = true;
-            if (p + (uint64_t)k <= ix.n && !is_tail_corner(ix, q)) pass = filter_test(flt, bits, q);
+            if (p + (uint64_t)k <= ix.n && !is_tail_corner(ix, q)) {
+                pass = filter_test(flt, bits, q);
+                if (pass && refine) {
+                    uint64_t lo, hi;
+                    ProbeRef pr;  // (read only by probes of more than 42 bases: the filter is for one-word probes)
+                    if (kmer_range(ix, q, 0ull, pr, lo, hi)) {  // (every occurrence of the k-mer)
+                        const uint64_t thr = reverse ? p + (uint64_t)k : p + 1u;  // a hit x is kept iff x >= thr
+                        if (hi - lo <= (uint64_t)kSmallInterval) {
+                            bool any = false;
+                            for (uint64_t r = lo; r < hi; ++r) any |= (uint64_t)ix.sa[r] >= thr;
+                            pass = any;
+                        } else if (ix.sap && hi - lo > (uint64_t)kRankMin) {
+                            pass = (uint64_t)ix.sap[hi - 1u] >= thr;
+                        }
+                    }
+                }
+            }
             word |= (unsigned long long)(pass ? 1u : 0u) << b;
         }
         out[w] = word;
@@ -878,11 +903,12 @@ int32_t index_prepare_filter(asgart_index *idx, uint64_t k, int mode) {
             rc = [&]() -> int32_t {
                 HIP_TRY(hipMemsetAsync(pb, 0xFF, (size_t)n_words * 8 + 512, s));
                 const unsigned g = grid_capped(n_words);
+                const bool refine = idx->opt.posbits >= 2 && !idx->trimmed;
                 if (idx->wide)
-                    build_posbits_kernel<uint64_t><<<g, 256, 0, s>>>(idx->view<uint64_t>(), rev, comp, flt, bits,
+                    build_posbits_kernel<uint64_t><<<g, 256, 0, s>>>(idx->view<uint64_t>(), rev, comp, flt, bits, refine,
                                                                      (unsigned long long *)pb, n_words);
                 else
-                    build_posbits_kernel<uint32_t><<<g, 256, 0, s>>>(idx->view<uint32_t>(), rev, comp, flt, bits,
+                    build_posbits_kernel<uint32_t><<<g, 256, 0, s>>>(idx->view<uint32_t>(), rev, comp, flt, bits, refine,
                                                                      (unsigned long long *)pb, n_words);
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(stream_sync(s));

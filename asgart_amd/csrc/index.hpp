@@ -290,7 +290,10 @@ struct Options {
     int64_t cap6w_pct = 160;        // ... with 64-bit positions (the bound is three to four times what a segment really holds there)
     int64_t cap45_pct = 100;        // tiers 4 and 5 accept segments whose arm bound is up to this percentage of their capacity (what overflows is re-run)
     int64_t cap3_pct = 160;         // tier 3 accepts segments whose arm bound is up to this percentage of its capacity
-    int64_t posbits = 1;            // 1: the presence filter's answers are also laid out by text position (index build) and the search reads those
+    int64_t posbits = 2;            // the presence filter's answers laid out by text position (built with the filter; the search reads those):
+                                    // 1 = the k-mer filter's answer, 2 = refined -- a position keeps its bit only if a hit of its probe can be
+                                    // KEPT (an occurrence behind the probe: half the lookups the k-mer filter lets through keep nothing;
+                                    // build_posbits_kernel, index.hip), 0 = none: the kernels test the hashed filter
     int64_t barren = 2;             // segments that provably emit nothing are not run at all: 1 = those with too few hit-probes for any arm to
                                     // reach min_duplication_length (pipeline_dev.hpp: segment_is_barren); 2 = also those whose hits leave
                                     // no run of consecutive occupied position buckets long enough (cluster_barren_kernel: the bursts of

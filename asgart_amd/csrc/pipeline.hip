@@ -1796,16 +1796,22 @@ int32_t asgart_get_stats(asgart_index *idx, uint32_t flags, asgart_stats *out) {
     const int sel = (int)((flags >> 8) & 0xFFu);
     SearchCtx &cx = idx->ctx[sel >= 1 && sel <= kNumCtx ? sel - 1 : idx->last_ctx];
     int32_t rc = [&]() -> int32_t {
-        if (cx.has_last && cx.last_P && !cx.raw_done) {
-            // raw_hits of the last call: summed up now, from the per-probe arrays it left in this context's workspace
+        if ((flags & (ASGART_STATS_YARDSTICK | ASGART_STATS_RAW_HITS)) && cx.has_last && cx.last_P && !cx.raw_done) {
+            // raw_hits of the last call: summed up now, from the per-probe arrays it left in this context's workspace (a probe
+            // the position filter answered has no interval there: it is looked up now)
             REFUSE_POISONED(idx);
             HIP_TRY(hipSetDevice(idx->device));
             unsigned long long *d_ctr = cx.ws.counters.as<unsigned long long>();
             hipStream_t s = cx.stream;
             const RunParams &rp = cx.last_rp;
             HIP_TRY(hipMemsetAsync(d_ctr + CT_RAW_HITS, 0, 8, s));
-            raw_hits_kernel<<<std::min<uint32_t>(rp.n_tiles(1024u), 256u * 16u), 256, 0, s>>>(
-                rp, cx.ws.p_filt.as<uint32_t>() - rp.g_lo, cx.ws.p_raw.as<uint32_t>() - rp.g_lo, d_ctr + CT_RAW_HITS);
+            const unsigned g_raw = std::min<uint32_t>(rp.n_tiles(1024u), 256u * 16u);
+            if (idx->wide)
+                raw_hits_kernel<uint64_t><<<g_raw, 256, 0, s>>>(idx->view<uint64_t>(), rp, cx.ws.p_filt.as<uint32_t>() - rp.g_lo,
+                                                                cx.ws.p_raw.as<uint32_t>() - rp.g_lo, d_ctr + CT_RAW_HITS);
+            else
+                raw_hits_kernel<uint32_t><<<g_raw, 256, 0, s>>>(idx->view<uint32_t>(), rp, cx.ws.p_filt.as<uint32_t>() - rp.g_lo,
+                                                                cx.ws.p_raw.as<uint32_t>() - rp.g_lo, d_ctr + CT_RAW_HITS);
             HIP_TRY(hipGetLastError());
             unsigned long long v = 0;
             HIP_TRY(read_back(&v, d_ctr + CT_RAW_HITS, 8, s));  // (polled drain first: common.hpp)

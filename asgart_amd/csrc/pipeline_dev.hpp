@@ -17,7 +17,6 @@
 
 namespace asgart {
 
-constexpr int kSmallInterval = 32;  // intervals up to this size are handled by one thread
 constexpr int kTiers = 7;  // extension tiers (see the placement in pipeline.hip)
 
 // device counters (u64 each)
@@ -135,7 +134,6 @@ constexpr int kProbeThreads = 64; // ... run by ONE wave: every lane stages and 
                                   // three of them held their slots through the staging only to retire; a wave slot now spends most
                                   // of its life in the dependent gathers of the lookup, and no barrier involves a second wave.
 constexpr int kProbeSub = kProbeBlock / kProbeThreads;
-constexpr int kRankMin = 256;  // intervals above this size are counted by bisection when the index has position-sorted lists
 constexpr int kMaxHalf = (kMaxKey + 1) / 2;                                 // bases per half (one-word keys)
 constexpr int kWinBytes = ((kProbeBlock + 2) * kMaxHalf + 15 + 16 + 15) / 16 * 16;  // <= 256 lanes x 16 B
 
@@ -210,9 +208,10 @@ __global__ __launch_bounds__(kProbeThreads) void probe_count_kernel(IndexView<Sl
             return false;
         }
         if (!pass_) {
-            // no hit possible: in the direct pass the interval is the probe itself
+            // the position filter says: no hit is kept (the probe's interval is never looked up; asgart_get_stats does that
+            // when the raw interval sizes are asked for)
             if (!COUNT) {
-                p_raw[g_] = md_ == 0u ? 1u : 0u;
+                p_raw[g_] = kRawUnknown;
                 p_filt[g_] = 0u;
             }
             cb.wr(8);
@@ -984,17 +983,36 @@ __global__ __launch_bounds__(kScanBlock) void scan_segments_kernel(RunParams rp,
 // The sum of the raw interval sizes over the searched probes (asgart_stats.raw_hits: a statistic of the call, wanted by
 // the parity tests and the bench's yardstick, not by the path) -- computed when the statistics are asked for, from the
 // per-probe arrays the call left in its workspace, instead of costing every call a second read of 4 bytes per probe.
-__global__ __launch_bounds__(256) void raw_hits_kernel(RunParams rp, const uint32_t *__restrict__ p_filt,
+// A probe the position filter answered has no interval there (p_raw = kRawUnknown): its k-mer is looked up here.
+template <class SlotT>
+__global__ __launch_bounds__(256) void raw_hits_kernel(IndexView<SlotT> ix, RunParams rp, const uint32_t *__restrict__ p_filt,
                                                        const uint32_t *__restrict__ p_raw, unsigned long long *__restrict__ out) {
     unsigned long long sum = 0;
     const uint32_t n_t = rp.n_tiles(1024u);
     for (uint32_t t = blockIdx.x; t < n_t; t += gridDim.x) {
         uint32_t g_end;
         const uint32_t g0 = rp.tile_of(t, 1024u, g_end);
-#pragma unroll
+#pragma unroll 1
         for (int a = 0; a < 4; ++a) {
             const uint32_t g = g0 + (uint32_t)a * 256u + threadIdx.x;
-            if (g < g_end && p_filt[g] != kSkipN) sum += p_raw[g];
+            if (g >= g_end || p_filt[g] == kSkipN) continue;
+            uint32_t raw = p_raw[g];
+            if (raw == kRawUnknown) {
+                const int c = chunk_of(rp.ch, g);
+                const uint32_t md = rp.mode_of(c);
+                const uint64_t cs = rp.ch.start[c], cl = rp.ch.len[c];
+                const uint64_t i = (uint64_t)(g - rp.ch.pbase[c] + 1) * (uint64_t)rp.step;
+                uint32_t first = 0;
+                uint64_t q2 = 0, lo, hi;
+                const uint64_t q = probe_key(ix.text, cs, cl, i, rp.k, (md & 2u) != 0u, (md & 1u) != 0u, &first, &q2);
+                ProbeRef pr;
+                pr.p = (md & 2u) ? ix.text + cs + cl - 1u - i : ix.text + cs + i;
+                pr.dir = (md & 2u) ? -1 : 1;
+                pr.comp = (md & 1u) != 0u;
+                kmer_range(ix, q, q2, pr, lo, hi);
+                raw = (uint32_t)(hi - lo);
+            }
+            sum += raw;
         }
     }
     for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);

@@ -67,7 +67,8 @@ typedef struct asgart_stats {
     uint64_t probes_searched;
     uint64_t probes_card_skipped;
     uint64_t probes_with_hits;
-    uint64_t raw_hits;      /* sum of SA-interval sizes h_p                       */
+    uint64_t raw_hits;      /* sum of SA-interval sizes h_p (filled only when ASGART_STATS_RAW_HITS or
+                               ASGART_STATS_YARDSTICK was requested: an untimed pass over the call's probes) */
     uint64_t filtered_hits; /* CSR size                                            */
     uint64_t segments;      /* independent automaton instances                     */
     uint64_t families;
@@ -353,12 +354,14 @@ int64_t asgart_probe_hits(asgart_index *idx, const uint64_t *chunks, int64_t n_c
                           uint64_t *row_offsets, uint64_t *hits, uint64_t *n_hits);
 
 #define ASGART_STATS_YARDSTICK 1u
+#define ASGART_STATS_RAW_HITS 2u
 /* asgart_search_duplications is re-entrant: up to two calls on one index may be in flight from
  * different host threads (e.g. the direct and the -RC pass), each in its own internal context.
  * ASGART_STATS_CTX(i), i = 0 or 1, selects the stats of context i instead of the last call's. */
 #define ASGART_STATS_CTX(i) (((uint32_t)(i) + 1u) << 8)
 /* Stats of the last search call on this index.  With ASGART_STATS_YARDSTICK in
- * `flags` an extra (untimed) kernel also fills bisect_steps. */
+ * `flags` extra (untimed) kernels also fill bisect_steps, the accounting fields and raw_hits; with
+ * ASGART_STATS_RAW_HITS raw_hits alone (the probes the position filter answered are looked up for it). */
 int32_t asgart_get_stats(asgart_index *idx, uint32_t flags, asgart_stats *out);
 
 /* Thread-local message of the last error returned on this thread. */

@@ -1198,6 +1198,40 @@ def test_replica_from_device_buffers_matches(hiplib):
         asgart_amd.Index.from_device(t_ptr, len(pr.data), sa_ptr, 8)   # wrong entry width for this text
 
 
+@pytest.mark.parametrize("name", ["dense_repeats", "satellites", "masked", "k12"])
+def test_refined_position_bits_reject_more_and_change_nothing(hiplib, name, monkeypatch):
+    """Option posbits = 2 (default): a text position keeps its filter bit only if a hit of its probe can be KEPT (an
+    occurrence of the probe's k-mer behind the probe, src/automaton.rs:105-114 in text coordinates) -- decided once, when
+    the bits are built.  Against posbits = 1 (the k-mer filter's answer): more probes answered without a lookup, and
+    NOTHING else changes -- families, per-probe hit rows, and every counter incl. raw_hits (the intervals of the probes
+    the bits answered are looked up when the statistics are asked for), in every orientation, 32- and 64-bit slots."""
+    pr, cli = _battery_case(name)
+    seen = {}
+    for wide in ("0", "1"):
+        monkeypatch.setenv("ASGART_FORCE_WIDE", wide)
+        for pb in ("1", "2"):
+            monkeypatch.setenv("ASGART_POSBITS", pb)
+            with asgart_amd.Index(pr.data, None) as idx:
+                for reverse, complement in MODES:
+                    st = asgart_amd.RunSettings.from_cli(reverse=reverse, complement=complement, **cli)
+                    fam = idx.search_duplications_raw(pr.chunks, st)
+                    stt = idx.stats(1).as_dict()
+                    rows = idx.probe_hits(pr.chunks, st)
+                    key = (wide, reverse, complement)
+                    if pb == "1":
+                        seen[key] = (fam, stt, rows)
+                        continue
+                    fam1, stt1, rows1 = seen[key]
+                    assert all(np.array_equal(a, b) for a, b in zip(fam, fam1)), (name, key)
+                    assert all(np.array_equal(a, b) for a, b in zip(rows, rows1)), (name, key)
+                    for c in ("probes_total", "probes_n_skipped", "probes_searched", "probes_card_skipped", "probes_with_hits",
+                              "raw_hits", "filtered_hits", "segments", "families", "proto_sds"):
+                        assert stt[c] == stt1[c], (name, key, c, stt[c], stt1[c])
+                    assert stt["probes_filter_rejected"] >= stt1["probes_filter_rejected"], (name, key)
+                    if (reverse, complement) == (False, False) and name != "k12":
+                        assert stt["probes_filter_rejected"] > stt1["probes_filter_rejected"], (name, key)
+
+
 def test_lazy_filter_and_lists_same_results(hiplib, monkeypatch):
     """Default behaviour of an index (option lazy_aux = 1; the suite otherwise runs with 0 so that every first call
     takes the filtered paths): the first search of an orientation runs without the presence filter and without the
