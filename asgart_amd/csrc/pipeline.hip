@@ -247,252 +247,351 @@ bool carve_probe_workspace(asgart_index *idx, const uint64_t *Wc) {
 
 // One job over the probes of n_passes passes (orientations) of the same chunk list: sts[p] differ in reverse /
 // complement only (the caller has checked); fams[p] receives pass p's families (null: none wanted -- the CSR surface).
+// The stages of a call, in the order run() takes them:
+//   setup          chunk table, probe numbering, this shard's own range
+//   set_window     the windows of this attempt (halos grow on retry), RunParams
+//   front          probe search, row offsets + segment starts, hit rows            (the HBM-bound, chip-wide part)
+//   csr_out        asgart_probe_hits only: the per-probe hit rows to the host
+//   place          per segment: arm bound -> tier, barren tests, long segments cut into ranges, lists sorted by cost
+//   run_tiers      every extension tier and the runs over ranges launched together; early re-runs of tiers 3 and 6
+//   join_ranges    cuts checked, family ordinals of the ranges chained, refused segments run again
+//   finish_tiers   statistics, the cascade of what overflowed
+//   records        records -> reference order -> families per pass on the host
+//   fill_stats
 template <class SlotT>
-static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *chunks, int64_t n_chunks_pass,
-                            const asgart_settings *sts, int32_t n_passes, int32_t shard, int32_t n_shards,
-                            bool want_csr, asgart_families *const *fams,
-                            std::vector<uint8_t> *status_out, std::vector<uint64_t> *rowoff_out,
-                            std::vector<uint64_t> *hits_out) {
-    Workspace &w = cx.ws;
-    hipStream_t s = cx.stream;
-    const asgart_settings *const st = &sts[0];
-    const bool fam_out = fams != nullptr;
-    const int64_t n_chunks = n_chunks_pass * (int64_t)n_passes;  // entries of the chunk table: the chunk list once per pass
-    const uint64_t k = st->probe_size, step = k / 2;
-    const uint64_t n = (uint64_t)idx->n;
+struct SearchCall {
 
-    // ---- chunk table -------------------------------------------------------
-    // (in the call context's pinned control block: [counters | 32 scalars | start[nc] | len[nc] | pbase[nc + 1]])
-    constexpr size_t kCtrBytes = (size_t)CT_COUNT * 8;
-    const size_t ch_bytes = (size_t)n_chunks * 16 + ((size_t)n_chunks + 1) * 4;
-    void *ctl_p = nullptr;
-    constexpr size_t kSplitMirror = 512 << 10;  // (option split: host copy of Workspace::split_buf)
-    RC_TRY(cx.ctl(kCtrBytes + ch_bytes + 256 + 64 + kSplitMirror, &ctl_p));
-    unsigned long long *const h_ctr = static_cast<unsigned long long *>(ctl_p);
-    unsigned long long *const h_scalar = h_ctr + CT_COUNT;  // source of small host-to-device updates
-    uint64_t *const h_start = reinterpret_cast<uint64_t *>(static_cast<char *>(ctl_p) + kCtrBytes + 256);
-    uint64_t *const h_len = h_start + n_chunks;
-    uint32_t *const h_pbase = reinterpret_cast<uint32_t *>(h_len + n_chunks);
-    char *const h_split = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(h_pbase + n_chunks + 1) + 63u) & ~(uintptr_t)63u);
-    const uint64_t text_end = (idx->h_tail.size() && idx->h_tail.back() == '$') ? n - 1 : n;
-    // probes of the chunk list, counted from the start of a pass (every pass walks the same list)
-    std::vector<uint32_t> lp((size_t)n_chunks_pass + 1);
-    {
-        uint64_t P64 = 0;
-        for (int64_t c = 0; c < n_chunks_pass; ++c) {
-            const uint64_t c_start = chunks[2 * c], c_len = chunks[2 * c + 1];
-            if (c_start > text_end || c_len > text_end - c_start) {
-                set_error("chunk %lld = (%llu, %llu) exceeds the text (%llu bases before '$')",
-                          (long long)c, (unsigned long long)c_start, (unsigned long long)c_len, (unsigned long long)text_end);
-                return ASGART_E_ARG;
-            }
-            lp[(size_t)c] = (uint32_t)P64;
-            P64 += probes_in_chunk(c_len, k, step, st->min_duplication_length);
-            if (P64 * (uint64_t)n_passes >= 0xFFFFFF00ull) {
-                set_error("more than 2^32 probes in one call");
-                return ASGART_E_CAP;
-            }
-        }
-        lp[(size_t)n_chunks_pass] = (uint32_t)P64;
-    }
-    const uint32_t Ppass = lp[(size_t)n_chunks_pass], P = Ppass * (uint32_t)n_passes;
-    cx.last_P = P;
-    memset(&cx.stats, 0, sizeof(cx.stats));
-    cx.stats.probes_total = P;
-    if (fam_out)
-        for (int32_t p = 0; p < n_passes; ++p) {
-            fams[p]->fam_offsets.assign(1, 0);
-            fams[p]->fam_keys.clear();
-            fams[p]->sds.clear();
-        }
-    if (want_csr) {
-        status_out->assign(P, 0);
-        rowoff_out->assign((size_t)P + 1, 0);
-        hits_out->clear();
-    }
-    if (P == 0 || n_chunks == 0) return 0;
-    if (want_csr && (n_shards != 1 || n_passes != 1)) {
-        set_error("asgart_probe_hits is one unsharded pass");
-        return ASGART_E_ARG;
-    }
-    // Multi-GPU sharding: shard r owns the automaton segments that START in the r-th slice of EVERY pass's probe
-    // sequence (chunk order inside each pass as in src/bin/asgart.rs:201-253).  It computes, per pass, probe-search over
-    // that slice plus a look-back halo (to decide whether its first probes continue an earlier segment) and a look-ahead
-    // halo (to finish segments that run past the slice): one WINDOW per pass, all passes' windows as ONE job -- one front,
-    // one launch per extension tier.  No data is exchanged between shards.
-    const Options opt = idx->opt;  // options cannot change while this call holds a context
-    const uint32_t own_lo = (uint32_t)((uint64_t)Ppass * (uint64_t)shard / (uint64_t)n_shards);  // (from the start of a pass)
-    const uint32_t own_hi = (uint32_t)((uint64_t)Ppass * (uint64_t)(shard + 1) / (uint64_t)n_shards);
-    if (own_lo == own_hi) return 0;
-    uint64_t look_back = (uint64_t)opt.shard_lookback;
-    uint64_t look_ahead = opt.shard_lookahead > 0 ? (uint64_t)opt.shard_lookahead
-                                                  : std::max<uint64_t>(65536, (own_hi - own_lo) / 16);
-    // The chunks a window can touch: c0 .. c1 of the list (a segment ends with its chunk).  The call numbers its probes
-    // VIRTUALLY (RunParams): these chunks keep their probes, the others are empty in the table it uploads -- pass p's kept
-    // probes are [p * K, (p + 1) * K), so probe g of the call is the (lo_lim + g - p * K)-th of pass p = g / K.
-    const int64_t c0 = (int64_t)(std::upper_bound(lp.begin(), lp.end(), own_lo) - lp.begin()) - 1;
-    const int64_t c1 = (int64_t)(std::upper_bound(lp.begin(), lp.end(), own_hi - 1u) - lp.begin()) - 1;
-    const uint32_t lo_lim = lp[(size_t)c0], hi_lim = lp[(size_t)c1 + 1], K = hi_lim - lo_lim;
-    for (int64_t c = 0; c < n_chunks; ++c) {
-        const int64_t cl = c % n_chunks_pass, p = c / n_chunks_pass;
-        h_start[c] = chunks[2 * cl];
-        h_len[c] = chunks[2 * cl + 1];
-        h_pbase[c] = (uint32_t)p * K + (std::min(std::max(lp[(size_t)cl], lo_lim), hi_lim) - lo_lim);
-    }
-    h_pbase[n_chunks] = (uint32_t)n_passes * K;
-    // what a remembered verdict about a cut segment belongs to: the settings and the chunk list (probe numbers mean nothing
-    // under another step, minimum length or list)
-    uint64_t call_sig = 1469598103934665603ull;
-    {
-        auto mix = [&](uint64_t v) { call_sig = (call_sig ^ v) * 1099511628211ull; };
-        mix(k);
-        mix(st->max_gap_size);
-        mix(st->min_duplication_length);
-        mix(st->max_cardinality);
-        for (int64_t c = 0; c < 2 * n_chunks_pass; ++c) mix(chunks[c]);
-    }
-    auto pass_of_probe = [&](uint32_t g) { return std::min<uint32_t>(g / K, (uint32_t)n_passes - 1u); };
-    auto pass_offset = [&](uint32_t g) { return lo_lim + (g - pass_of_probe(g) * K); };  // from the start of its pass
-
-    RC_TRY(w.chunks.reserve(ch_bytes));
-    uint64_t *d_start = w.chunks.as<uint64_t>();
-    uint64_t *d_len = d_start + n_chunks;
-    uint32_t *d_pbase = reinterpret_cast<uint32_t *>(d_len + n_chunks);
-    HIP_TRY(hipMemcpyAsync(d_start, h_start, ch_bytes, hipMemcpyHostToDevice, s));  // same layout on the device
+    // ---- the call ---------------------------------------------------------------------------------------------------------
+    asgart_index *const idx;
+    SearchCtx &cx;
+    const uint64_t *const chunks;
+    const int64_t n_chunks_pass;
+    const asgart_settings *const sts;
+    const int32_t n_passes, shard, n_shards;
+    const bool want_csr;
+    asgart_families *const *const fams;
+    std::vector<uint8_t> *const status_out;
+    std::vector<uint64_t> *const rowoff_out, *const hits_out;
+    Workspace &w;
+    const hipStream_t s;
+    const asgart_settings *const st;
+    const bool fam_out;
+    const int64_t n_chunks;      // entries of the chunk table: the chunk list once per pass
+    const uint64_t k, step, n;
+    const Options opt;           // options cannot change while this call holds a context
+    static constexpr size_t kCtrBytes = (size_t)CT_COUNT * 8;
+    static constexpr size_t kSplitMirror = 512 << 10;  // (option split: host copy of Workspace::split_buf)
+    static constexpr int caph = sizeof(SlotT) == 4 ? kArmCapHybrid32 : kArmCapHybrid64;
+    // ---- set up once (setup) --------------------------------------------------------------------------------------------
+    bool nothing_to_do = true;
+    size_t ch_bytes = 0;
+    unsigned long long *h_ctr = nullptr, *h_scalar = nullptr;  // pinned: the counters read back; source of small host-to-device updates
+    uint64_t *h_start = nullptr, *h_len = nullptr;
+    uint32_t *h_pbase = nullptr;
+    char *h_split = nullptr;
+    std::vector<uint32_t> lp;    // probes of the chunk list, counted from the start of a pass
+    uint32_t Ppass = 0, P = 0, own_lo = 0, own_hi = 0, lo_lim = 0, hi_lim = 0, K = 0;
+    uint64_t look_back = 0, look_ahead = 0, call_sig = 0;
+    uint64_t *d_start = nullptr, *d_len = nullptr;
+    uint32_t *d_pbase = nullptr;
+    std::chrono::steady_clock::time_point t_host0, t_launch;
+    // ---- per window (set_window, front) ---------------------------------------------------------------------------------
+    RunParams rp;
+    uint32_t W = 0, W_probes = 0;
+    unsigned long long *d_ctr = nullptr;
+    IndexView<SlotT> ix;
+    SlotT *p_lo = nullptr, *hits = nullptr;
+    uint32_t *p_raw = nullptr, *p_filt = nullptr, *seg_list = nullptr;
+    unsigned long long *row_off = nullptr;
     uint64_t total_hits = 0, n_seg = 0, n_overflow = 0, n_heavy = 0;
     bool progress_given = false;
+    // ---- placement (place) ----------------------------------------------------------------------------------------------
+    uint64_t rec_cap = 0;
+    const SdRec *h_recs = nullptr;  // sorted records on the host (pinned staging of the context)
+    size_t n_hrec = 0;
+    bool arms_kernel = false, split_on = false;
+    uint32_t tier_cap[kTiers + 1] = {};
+    char *d_split = nullptr;
+    const uint32_t *order = nullptr;
+    uint64_t n_t[kTiers] = {}, seg_off[kTiers + 1] = {};
+    uint64_t h_tp[kTiers] = {}, h_th[kTiers] = {};  // (option debug: hit-probes and hits per tier, as placed)
+    const unsigned long long *h_split_hdr = nullptr;
+    uint32_t n_runs = 0, n_cuts = 0, n_splits = 0;
+    std::vector<SplitSeg> split_segs;
+    uint32_t *ovf[kTiers] = {};  // ovf[t-1]: segments tier t gave up on
+    uint64_t heavy_cap64 = 0;
+    unsigned n_wg7 = 1;
+    size_t region = 0;
+    char *scratch6 = nullptr, *scratch7 = nullptr;
+    // ---- the tiers (run_tiers .. finish_tiers) ---------------------------------------------------------------------------
+    ExtParams<SlotT> ep;
+    char *scratch_override = nullptr;  // HBM slices of an early cascade launch
+    hipStream_t tier_stream[kTiers + 1] = {};
+    uint64_t early_n[kTiers + 1] = {};
     double ms_tier2 = 0.0, ms_longest_tier = 0.0, ms_longest_segment = 0.0;
     uint64_t n_split_segments = 0, n_split_refused = 0;
-    RunParams rp;
-    const auto t_host0 = std::chrono::steady_clock::now();
-    for (int win_try = 0;; ++win_try) {
-    if (win_try > 40) {
-        set_error("internal: shard window did not converge");
-        return ASGART_E_CAP;
-    }
-    // the window of a pass, counted from the start of the pass
-    const uint32_t w_lo = (uint32_t)std::max<uint64_t>(lo_lim, own_lo > look_back ? own_lo - look_back : 0);
-    const uint32_t w_hi = (uint32_t)std::min<uint64_t>(hi_lim, (uint64_t)own_hi + look_ahead);
-    rp.init_unknown = w_lo != lo_lim ? 1u : 0u;
-    rp.ch = ChunkTable{d_start, d_len, d_pbase, (int)n_chunks};
-    rp.win_len = w_hi - w_lo;
-    rp.win_stride = K;
-    rp.g_lo = w_lo - lo_lim;
-    rp.g_hi = rp.g_lo + ((uint32_t)n_passes - 1u) * K + rp.win_len;
-    rp.own_off_lo = own_lo - w_lo;
-    rp.own_off_hi = own_hi - w_lo;
-    const uint32_t W = rp.g_hi - rp.g_lo;                     // extent of the per-probe arrays
-    const uint32_t W_probes = (uint32_t)n_passes * rp.win_len;  // probes the call computes
-    rp.k = (int)k;
-    rp.step = (int)step;
-    rp.G = st->max_gap_size;
-    rp.tstar = (uint32_t)((st->max_gap_size + step - 1) / step);
-    if (rp.tstar == 0) rp.tstar = 1;
-    rp.M = st->min_duplication_length;
-    rp.C = st->max_cardinality > 0xFFFFFF00ull ? 0xFFFFFF00u : (uint32_t)st->max_cardinality;
-    rp.n_passes = (uint32_t)n_passes;
-    rp.pass_chunks = (uint32_t)n_chunks_pass;
-    rp.modes = 0;
-    rp.flt_bits = idx->filter_bits;
-    for (int p = 0; p < 4; ++p) {
-        rp.flt[p] = rp.pbits[p] = nullptr;
-        if (p >= n_passes) continue;
-        const int mode = (sts[p].reverse ? 2 : 0) | (sts[p].complement ? 1 : 0);
-        rp.modes |= (uint32_t)mode << (8 * p);
-        rp.flt[p] = idx->d_filter[mode];  // null: filter off
-        rp.pbits[p] = opt.posbits ? idx->d_pbits[mode] : nullptr;
-    }
-    cx.last_rp = rp;
-    cx.has_last = false;
 
-    // ---- workspace (indexed by absolute probe number through shifted pointers) ---
-    const uint32_t n_blk = rp.n_tiles((uint32_t)kScanTile);
-    const uint64_t seg_cap = (uint64_t)W_probes / (rp.tstar + 1) + (uint64_t)n_chunks + 64;
-    RC_TRY(reserve_probe_workspace(idx, cx, W));
-    RC_TRY(w.seg_list.reserve((size_t)seg_cap * 4));
-    RC_TRY(w.counters.reserve(CT_COUNT * 8));
-    unsigned long long *d_ctr = w.counters.as<unsigned long long>();
-    HIP_TRY(hipMemsetAsync(d_ctr, 0, CT_COUNT * 8, s));
-    auto signal_progress = [&]() {  // (only single-pass calls have a progress array)
+    SearchCall(asgart_index *idx_, SearchCtx &cx_, const uint64_t *chunks_, int64_t n_chunks_pass_, const asgart_settings *sts_,
+               int32_t n_passes_, int32_t shard_, int32_t n_shards_, bool want_csr_, asgart_families *const *fams_,
+               std::vector<uint8_t> *status_out_, std::vector<uint64_t> *rowoff_out_, std::vector<uint64_t> *hits_out_)
+        : idx(idx_), cx(cx_), chunks(chunks_), n_chunks_pass(n_chunks_pass_), sts(sts_), n_passes(n_passes_), shard(shard_),
+          n_shards(n_shards_), want_csr(want_csr_), fams(fams_), status_out(status_out_), rowoff_out(rowoff_out_),
+          hits_out(hits_out_), w(cx_.ws), s(cx_.stream), st(&sts_[0]), fam_out(fams_ != nullptr),
+          n_chunks(n_chunks_pass_ * (int64_t)n_passes_), k(sts_[0].probe_size), step(sts_[0].probe_size / 2),
+          n((uint64_t)idx_->n), opt(idx_->opt) {}
+
+    uint32_t pass_of_probe(uint32_t g) const { return std::min<uint32_t>(g / K, (uint32_t)n_passes - 1u); }
+    uint32_t pass_offset(uint32_t g) const { return lo_lim + (g - pass_of_probe(g) * K); }  // from the start of its pass
+    bool tier_enabled(int t) const { return t >= 1 && t <= kTiers && tier_cap[t] != 0; }
+    double since_launch() const {
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_launch).count();
+    }
+    void signal_progress() {  // (only single-pass calls have a progress array)
         for (int64_t c = 0; c < n_chunks_pass; ++c)
             cx.progress[c] = (uint64_t)probes_in_chunk(h_len[c], k, step, st->min_duplication_length) * step;
         progress_given = true;
-    };
-
-    IndexView<SlotT> ix = idx->view<SlotT>();
-    SlotT *p_lo = w.p_lo.as<SlotT>() - rp.g_lo;
-    uint32_t *p_raw = w.p_raw.as<uint32_t>() - rp.g_lo;
-    uint32_t *p_filt = w.p_filt.as<uint32_t>() - rp.g_lo;
-    unsigned long long *row_off = w.row_off.as<unsigned long long>() - rp.g_lo;
-    unsigned long long *scan_desc = w.blk.as<unsigned long long>();  // two words per scan tile (scan_segments_kernel)
-    uint32_t *big_list = w.big_list.as<uint32_t>();
-    uint32_t *rank_list = w.rank_list.as<uint32_t>();
-    uint32_t *seg_list = w.seg_list.as<uint32_t>();
-
-    if (opt.test_stall_s > 0) stall_kernel<<<1, 64, 0, s>>>((unsigned long long)opt.test_stall_s * 100000000ull);
-    // ---- K1: probe search + filtered counts -----------------------------------
-    HIP_TRY(hipEventRecord(cx.ev[0], s));
-    probe_count_kernel<SlotT, false><<<rp.n_tiles((uint32_t)kProbeBlock), kProbeThreads, 0, s>>>(
-        ix, rp, p_lo, p_raw, p_filt, big_list, rank_list, d_ctr);
-    HIP_TRY(hipEventRecord(cx.ev[11], s));
-    collect_pending_kernel<<<std::min<uint32_t>(rp.n_tiles((uint32_t)kCollectTile), 256u * 8u), kCollectBlock, 0, s>>>(
-        rp, p_filt, big_list, rank_list, d_ctr);
-    big_count_kernel<SlotT, false><<<2048, 256, 0, s>>>(ix, rp, p_lo, p_raw, p_filt, big_list, d_ctr);
-    // (after big_count_kernel: what it appends to big_list is for the fill only)
-    if (ix.sap)
-        rank_count_kernel<SlotT, false><<<2048, 256, 0, s>>>(ix, rp, p_lo, p_raw, p_filt, rank_list, big_list, d_ctr);
-    HIP_TRY(hipEventRecord(cx.ev[1], s));
-    // ---- K2: scans + segmentation ----------------------------------------------
-    HIP_TRY(hipMemsetAsync(scan_desc, 0, (size_t)n_blk * 16, s));
-    scan_segments_kernel<<<std::min<uint32_t>(n_blk, 256u * 2u), kScanBlock, 0, s>>>(rp, p_filt, scan_desc, n_blk, row_off, seg_list, d_ctr);
-    HIP_TRY(hipEventRecord(cx.ev[2], s));
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, kCtrBytes, hipMemcpyDeviceToHost, s));
-    RC_TRY(wd_sync(idx, cx, s, "the probe search and the scans"));
-    total_hits = h_ctr[CT_TOTAL_HITS];
-    n_seg = h_ctr[CT_SEG];
-    if (h_ctr[CT_AMBIG]) {  // a start decision needs more history: widen the look-back halo
-        look_back *= 8;
-        continue;
     }
-    if (n_seg > seg_cap) {
-        set_error("internal: segment list overflow (%llu > %llu)", (unsigned long long)n_seg,
-                  (unsigned long long)seg_cap);
-        return ASGART_E_CAP;
-    }
-    // ---- K3: CSR fill -----------------------------------------------------------
-    RC_TRY(w.hits.reserve((size_t)(total_hits + 64) * sizeof(SlotT)));
-    SlotT *hits = w.hits.as<SlotT>();
-    fill_small_kernel<SlotT><<<rp.n_tiles(256u), 256, 0, s>>>(ix, rp, p_lo, p_raw, p_filt, row_off, hits);
-    if (h_ctr[CT_BIG])
-        fill_big_kernel<SlotT><<<2048, 256, 0, s>>>(ix, rp, p_lo, p_raw, p_filt, row_off, hits,
-                                                    big_list, d_ctr);
-    HIP_TRY(hipEventRecord(cx.ev[3], s));
-    HIP_TRY(hipGetLastError());
 
-    if (want_csr) {
-        std::vector<uint32_t> h_filt(P);
-        std::vector<SlotT> h_hits((size_t)total_hits);
-        RC_TRY(wd_sync(idx, cx, s, "the hit rows"));  // (the copies below go to pageable memory: they block inside the copy)
-        HIP_TRY(hipMemcpyAsync(h_filt.data(), p_filt, (size_t)P * 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(rowoff_out->data(), row_off, ((size_t)P + 1) * 8,
-                               hipMemcpyDeviceToHost, s));
-        if (total_hits)
-            HIP_TRY(hipMemcpyAsync(h_hits.data(), hits, (size_t)total_hits * sizeof(SlotT),
+    // Workspace::split_buf: [4 counters (u64): runs, cuts, split segments, work cursor | runs | cuts | split segments |
+    // run states | verdicts per cut | per run: what is added to its records' family ordinals | segments to run again]
+    static constexpr uint32_t kMaxRuns = 4096, kMaxCuts = 2048, kMaxSplits = 1024;
+    static constexpr size_t kOffRuns = 64, kOffCuts = kOffRuns + kMaxRuns * sizeof(RangeRun), kOffSplits = kOffCuts + kMaxCuts * 8,
+                     kOffMeta = kOffSplits + kMaxSplits * sizeof(SplitSeg), kOffOk = kOffMeta + kMaxRuns * 64,
+                     kOffFix = kOffOk + kMaxCuts * 4, kOffAgain = kOffFix + kMaxRuns * 4, kOffChoice = kOffAgain + kMaxSplits * 4,
+                     kSplitBytes = kOffChoice + 128;
+    static_assert(sizeof(SplitChoice) <= 128 && kOffChoice % 8 == 0, "split choice");
+    static_assert(kSplitBytes <= kSplitMirror, "split mirror");
+
+    // ---- chunk table, probe numbering, own range -------------------------------------------------------------------------
+    int32_t setup() {
+        // ---- chunk table -------------------------------------------------------
+        // (in the call context's pinned control block: [counters | 32 scalars | start[nc] | len[nc] | pbase[nc + 1]])
+        ch_bytes = (size_t)n_chunks * 16 + ((size_t)n_chunks + 1) * 4;
+        void *ctl_p = nullptr;
+        RC_TRY(cx.ctl(kCtrBytes + ch_bytes + 256 + 64 + kSplitMirror, &ctl_p));
+        h_ctr = static_cast<unsigned long long *>(ctl_p);
+        h_scalar = h_ctr + CT_COUNT;  // source of small host-to-device updates
+        h_start = reinterpret_cast<uint64_t *>(static_cast<char *>(ctl_p) + kCtrBytes + 256);
+        h_len = h_start + n_chunks;
+        h_pbase = reinterpret_cast<uint32_t *>(h_len + n_chunks);
+        h_split = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(h_pbase + n_chunks + 1) + 63u) & ~(uintptr_t)63u);
+        const uint64_t text_end = (idx->h_tail.size() && idx->h_tail.back() == '$') ? n - 1 : n;
+        // probes of the chunk list, counted from the start of a pass (every pass walks the same list)
+        lp.assign((size_t)n_chunks_pass + 1, 0u);
+        {
+            uint64_t P64 = 0;
+            for (int64_t c = 0; c < n_chunks_pass; ++c) {
+                const uint64_t c_start = chunks[2 * c], c_len = chunks[2 * c + 1];
+                if (c_start > text_end || c_len > text_end - c_start) {
+                    set_error("chunk %lld = (%llu, %llu) exceeds the text (%llu bases before '$')",
+                              (long long)c, (unsigned long long)c_start, (unsigned long long)c_len, (unsigned long long)text_end);
+                    return ASGART_E_ARG;
+                }
+                lp[(size_t)c] = (uint32_t)P64;
+                P64 += probes_in_chunk(c_len, k, step, st->min_duplication_length);
+                if (P64 * (uint64_t)n_passes >= 0xFFFFFF00ull) {
+                    set_error("more than 2^32 probes in one call");
+                    return ASGART_E_CAP;
+                }
+            }
+            lp[(size_t)n_chunks_pass] = (uint32_t)P64;
+        }
+        Ppass = lp[(size_t)n_chunks_pass];
+        P = Ppass * (uint32_t)n_passes;
+        cx.last_P = P;
+        memset(&cx.stats, 0, sizeof(cx.stats));
+        cx.stats.probes_total = P;
+        if (fam_out)
+            for (int32_t p = 0; p < n_passes; ++p) {
+                fams[p]->fam_offsets.assign(1, 0);
+                fams[p]->fam_keys.clear();
+                fams[p]->sds.clear();
+            }
+        if (want_csr) {
+            status_out->assign(P, 0);
+            rowoff_out->assign((size_t)P + 1, 0);
+            hits_out->clear();
+        }
+        if (P == 0 || n_chunks == 0) return 0;  // (nothing_to_do stays set)
+        if (want_csr && (n_shards != 1 || n_passes != 1)) {
+            set_error("asgart_probe_hits is one unsharded pass");
+            return ASGART_E_ARG;
+        }
+        // Multi-GPU sharding: shard r owns the automaton segments that START in the r-th slice of EVERY pass's probe
+        // sequence (chunk order inside each pass as in src/bin/asgart.rs:201-253).  It computes, per pass, probe-search over
+        // that slice plus a look-back halo (to decide whether its first probes continue an earlier segment) and a look-ahead
+        // halo (to finish segments that run past the slice): one WINDOW per pass, all passes' windows as ONE job -- one front,
+        // one launch per extension tier.  No data is exchanged between shards.
+        own_lo = (uint32_t)((uint64_t)Ppass * (uint64_t)shard / (uint64_t)n_shards);  // (from the start of a pass)
+        own_hi = (uint32_t)((uint64_t)Ppass * (uint64_t)(shard + 1) / (uint64_t)n_shards);
+        if (own_lo == own_hi) return 0;  // (nothing_to_do stays set)
+        look_back = (uint64_t)opt.shard_lookback;
+        look_ahead = opt.shard_lookahead > 0 ? (uint64_t)opt.shard_lookahead
+                                                      : std::max<uint64_t>(65536, (own_hi - own_lo) / 16);
+        // The chunks a window can touch: c0 .. c1 of the list (a segment ends with its chunk).  The call numbers its probes
+        // VIRTUALLY (RunParams): these chunks keep their probes, the others are empty in the table it uploads -- pass p's kept
+        // probes are [p * K, (p + 1) * K), so probe g of the call is the (lo_lim + g - p * K)-th of pass p = g / K.
+        const int64_t c0 = (int64_t)(std::upper_bound(lp.begin(), lp.end(), own_lo) - lp.begin()) - 1;
+        const int64_t c1 = (int64_t)(std::upper_bound(lp.begin(), lp.end(), own_hi - 1u) - lp.begin()) - 1;
+        lo_lim = lp[(size_t)c0];
+        hi_lim = lp[(size_t)c1 + 1];
+        K = hi_lim - lo_lim;
+        for (int64_t c = 0; c < n_chunks; ++c) {
+            const int64_t cl = c % n_chunks_pass, p = c / n_chunks_pass;
+            h_start[c] = chunks[2 * cl];
+            h_len[c] = chunks[2 * cl + 1];
+            h_pbase[c] = (uint32_t)p * K + (std::min(std::max(lp[(size_t)cl], lo_lim), hi_lim) - lo_lim);
+        }
+        h_pbase[n_chunks] = (uint32_t)n_passes * K;
+        // what a remembered verdict about a cut segment belongs to: the settings and the chunk list (probe numbers mean nothing
+        // under another step, minimum length or list)
+        call_sig = 1469598103934665603ull;
+        {
+            auto mix = [&](uint64_t v) { call_sig = (call_sig ^ v) * 1099511628211ull; };
+            mix(k);
+            mix(st->max_gap_size);
+            mix(st->min_duplication_length);
+            mix(st->max_cardinality);
+            for (int64_t c = 0; c < 2 * n_chunks_pass; ++c) mix(chunks[c]);
+        }
+        RC_TRY(w.chunks.reserve(ch_bytes));
+        d_start = w.chunks.as<uint64_t>();
+        d_len = d_start + n_chunks;
+        d_pbase = reinterpret_cast<uint32_t *>(d_len + n_chunks);
+        HIP_TRY(hipMemcpyAsync(d_start, h_start, ch_bytes, hipMemcpyHostToDevice, s));  // same layout on the device
+        t_host0 = std::chrono::steady_clock::now();
+        nothing_to_do = false;
+        return 0;
+    }
+
+    // ---- the windows of this attempt ---------------------------------------------------------------------------------------
+    void set_window() {
+        // the window of a pass, counted from the start of the pass
+        const uint32_t w_lo = (uint32_t)std::max<uint64_t>(lo_lim, own_lo > look_back ? own_lo - look_back : 0);
+        const uint32_t w_hi = (uint32_t)std::min<uint64_t>(hi_lim, (uint64_t)own_hi + look_ahead);
+        rp.init_unknown = w_lo != lo_lim ? 1u : 0u;
+        rp.ch = ChunkTable{d_start, d_len, d_pbase, (int)n_chunks};
+        rp.win_len = w_hi - w_lo;
+        rp.win_stride = K;
+        rp.g_lo = w_lo - lo_lim;
+        rp.g_hi = rp.g_lo + ((uint32_t)n_passes - 1u) * K + rp.win_len;
+        rp.own_off_lo = own_lo - w_lo;
+        rp.own_off_hi = own_hi - w_lo;
+        W = rp.g_hi - rp.g_lo;                     // extent of the per-probe arrays
+        W_probes = (uint32_t)n_passes * rp.win_len;  // probes the call computes
+        rp.k = (int)k;
+        rp.step = (int)step;
+        rp.G = st->max_gap_size;
+        rp.tstar = (uint32_t)((st->max_gap_size + step - 1) / step);
+        if (rp.tstar == 0) rp.tstar = 1;
+        rp.M = st->min_duplication_length;
+        rp.C = st->max_cardinality > 0xFFFFFF00ull ? 0xFFFFFF00u : (uint32_t)st->max_cardinality;
+        rp.n_passes = (uint32_t)n_passes;
+        rp.pass_chunks = (uint32_t)n_chunks_pass;
+        rp.modes = 0;
+        rp.flt_bits = idx->filter_bits;
+        for (int p = 0; p < 4; ++p) {
+            rp.flt[p] = rp.pbits[p] = nullptr;
+            if (p >= n_passes) continue;
+            const int mode = (sts[p].reverse ? 2 : 0) | (sts[p].complement ? 1 : 0);
+            rp.modes |= (uint32_t)mode << (8 * p);
+            rp.flt[p] = idx->d_filter[mode];  // null: filter off
+            rp.pbits[p] = opt.posbits ? idx->d_pbits[mode] : nullptr;
+        }
+        cx.last_rp = rp;
+        cx.has_last = false;
+
+    }
+
+    // ---- probe search, row offsets + segment starts, hit rows (*ambiguous: a start decision needs a longer look-back) ----------
+    int32_t front(bool *ambiguous) {
+        // ---- workspace (indexed by absolute probe number through shifted pointers) ---
+        const uint32_t n_blk = rp.n_tiles((uint32_t)kScanTile);
+        const uint64_t seg_cap = (uint64_t)W_probes / (rp.tstar + 1) + (uint64_t)n_chunks + 64;
+        RC_TRY(reserve_probe_workspace(idx, cx, W));
+        RC_TRY(w.seg_list.reserve((size_t)seg_cap * 4));
+        RC_TRY(w.counters.reserve(CT_COUNT * 8));
+        d_ctr = w.counters.as<unsigned long long>();
+        HIP_TRY(hipMemsetAsync(d_ctr, 0, CT_COUNT * 8, s));
+        ix = idx->template view<SlotT>();
+        p_lo = w.p_lo.as<SlotT>() - rp.g_lo;
+        p_raw = w.p_raw.as<uint32_t>() - rp.g_lo;
+        p_filt = w.p_filt.as<uint32_t>() - rp.g_lo;
+        row_off = w.row_off.as<unsigned long long>() - rp.g_lo;
+        unsigned long long *scan_desc = w.blk.as<unsigned long long>();  // two words per scan tile (scan_segments_kernel)
+        uint32_t *big_list = w.big_list.as<uint32_t>();
+        uint32_t *rank_list = w.rank_list.as<uint32_t>();
+        seg_list = w.seg_list.as<uint32_t>();
+
+        if (opt.test_stall_s > 0) stall_kernel<<<1, 64, 0, s>>>((unsigned long long)opt.test_stall_s * 100000000ull);
+        // ---- K1: probe search + filtered counts -----------------------------------
+        HIP_TRY(hipEventRecord(cx.ev[0], s));
+        probe_count_kernel<SlotT, false><<<rp.n_tiles((uint32_t)kProbeBlock), kProbeThreads, 0, s>>>(
+            ix, rp, p_lo, p_raw, p_filt, big_list, rank_list, d_ctr);
+        HIP_TRY(hipEventRecord(cx.ev[11], s));
+        collect_pending_kernel<<<std::min<uint32_t>(rp.n_tiles((uint32_t)kCollectTile), 256u * 8u), kCollectBlock, 0, s>>>(
+            rp, p_filt, big_list, rank_list, d_ctr);
+        big_count_kernel<SlotT, false><<<2048, 256, 0, s>>>(ix, rp, p_lo, p_raw, p_filt, big_list, d_ctr);
+        // (after big_count_kernel: what it appends to big_list is for the fill only)
+        if (ix.sap)
+            rank_count_kernel<SlotT, false><<<2048, 256, 0, s>>>(ix, rp, p_lo, p_raw, p_filt, rank_list, big_list, d_ctr);
+        HIP_TRY(hipEventRecord(cx.ev[1], s));
+        // ---- K2: scans + segmentation ----------------------------------------------
+        HIP_TRY(hipMemsetAsync(scan_desc, 0, (size_t)n_blk * 16, s));
+        scan_segments_kernel<<<std::min<uint32_t>(n_blk, 256u * 2u), kScanBlock, 0, s>>>(rp, p_filt, scan_desc, n_blk, row_off, seg_list, d_ctr);
+        HIP_TRY(hipEventRecord(cx.ev[2], s));
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, kCtrBytes, hipMemcpyDeviceToHost, s));
+        RC_TRY(wd_sync(idx, cx, s, "the probe search and the scans"));
+        total_hits = h_ctr[CT_TOTAL_HITS];
+        n_seg = h_ctr[CT_SEG];
+        if (h_ctr[CT_AMBIG]) {  // a start decision needs more history: the caller widens the look-back halo
+            *ambiguous = true;
+            return 0;
+        }
+        if (n_seg > seg_cap) {
+            set_error("internal: segment list overflow (%llu > %llu)", (unsigned long long)n_seg,
+                      (unsigned long long)seg_cap);
+            return ASGART_E_CAP;
+        }
+        // ---- K3: CSR fill -----------------------------------------------------------
+        RC_TRY(w.hits.reserve((size_t)(total_hits + 64) * sizeof(SlotT)));
+        hits = w.hits.as<SlotT>();
+        fill_small_kernel<SlotT><<<rp.n_tiles(256u), 256, 0, s>>>(ix, rp, p_lo, p_raw, p_filt, row_off, hits);
+        if (h_ctr[CT_BIG])
+            fill_big_kernel<SlotT><<<2048, 256, 0, s>>>(ix, rp, p_lo, p_raw, p_filt, row_off, hits,
+                                                        big_list, d_ctr);
+        HIP_TRY(hipEventRecord(cx.ev[3], s));
+        HIP_TRY(hipGetLastError());
+
+        return 0;
+    }
+
+    // ---- asgart_probe_hits: the per-probe hit rows to the host ----------------------------------------------------------------
+    int32_t csr_out() {
+            std::vector<uint32_t> h_filt(P);
+            std::vector<SlotT> h_hits((size_t)total_hits);
+            RC_TRY(wd_sync(idx, cx, s, "the hit rows"));  // (the copies below go to pageable memory: they block inside the copy)
+            HIP_TRY(hipMemcpyAsync(h_filt.data(), p_filt, (size_t)P * 4, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(rowoff_out->data(), row_off, ((size_t)P + 1) * 8,
                                    hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        for (uint32_t g = 0; g < P; ++g)
-            (*status_out)[g] = h_filt[g] == kSkipN ? 1 : (h_filt[g] == kSkipCard ? 2 : 0);
-        hits_out->resize((size_t)total_hits);
-        for (uint64_t j = 0; j < total_hits; ++j) (*hits_out)[j] = h_hits[j];
+            if (total_hits)
+                HIP_TRY(hipMemcpyAsync(h_hits.data(), hits, (size_t)total_hits * sizeof(SlotT),
+                                       hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            for (uint32_t g = 0; g < P; ++g)
+                (*status_out)[g] = h_filt[g] == kSkipN ? 1 : (h_filt[g] == kSkipCard ? 2 : 0);
+            hits_out->resize((size_t)total_hits);
+            for (uint64_t j = 0; j < total_hits; ++j) (*hits_out)[j] = h_hits[j];
+        return 0;
     }
 
-    // ---- K4: extension automaton ------------------------------------------------
-    if (fam_out && n_seg) {
-        uint64_t rec_cap = std::max<uint64_t>(1u << 18, w.fam_sds.cap / sizeof(SdRec));
+    // ---- placement: per-segment work estimate -> tier, longest first; barren segments; long segments as ranges ----------------
+    int32_t place() {
+        rec_cap = std::max<uint64_t>(1u << 18, w.fam_sds.cap / sizeof(SdRec));
         RC_TRY(w.ovf_list.reserve((size_t)(n_seg + 1) * 4 * kTiers));
-        const SdRec *h_recs = nullptr;  // sorted records on the host (pinned staging of the context)
-        size_t n_hrec = 0;
+        h_recs = nullptr;
+        n_hrec = 0;
         // ---- placement: per-segment work estimate -> tier, longest first --------------------
         // option force_tier = t (tests): start every segment with a multi-hit probe in tier >= t
         const int force_tier = (int)opt.force_tier;
@@ -514,11 +613,12 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
         // With max_cardinality > 1024 (or ASGART_ARMS_KERNEL=0, tests) the LDS-array kernels (extend_heavy_kernel) take
         // tiers 2, 4 and 6 (768 / 2432 / 4608 * 1.4 arms) and tiers 3 and 5 stay empty; the small
         // shapes 2 and 4 stage 512 hits per probe and are skipped when max_cardinality > 512.
-        constexpr int caph = sizeof(SlotT) == 4 ? kArmCapHybrid32 : kArmCapHybrid64;
         // (the arm-resident kernels pack a position into 42 bits of a table entry)
-        const bool arms_kernel = rp.C <= (uint64_t)kHitBatch && opt.arms_kernel != 0 && (uint64_t)idx->n < (1ull << 42);
+        arms_kernel = rp.C <= (uint64_t)kHitBatch && opt.arms_kernel != 0 && (uint64_t)idx->n < (1ull << 42);
         const bool arms_small = arms_kernel && rp.C <= (uint64_t)kWaveArmsHits;
-        uint32_t tier_cap[kTiers + 1] = {0, kArmCapSmall, 0, 0, 0, 0, 0, 0xFFFFFFFFu};  // (tier 7 takes whatever is left)
+        for (int t = 0; t <= kTiers; ++t) tier_cap[t] = 0;
+        tier_cap[1] = kArmCapSmall;
+        tier_cap[kTiers] = 0xFFFFFFFFu;  // (tier 7 takes whatever is left)
         if (arms_kernel) {
             if (arms_small) {
                 tier_cap[2] = (uint32_t)kWaveArmsLayers<SlotT> * 64u;
@@ -546,7 +646,6 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             tier_cap[4] = sizeof(SlotT) == 4 ? kArmCapBig32 : kArmCapBig64;
             tier_cap[6] = (rp.G >= 0xFFF0u || rp.C >= 0xFFF0u) ? 0u : (uint32_t)caph * 7 / 5;  // 16-bit gap/pend
         }
-        auto tier_enabled = [&](int t) { return t >= 1 && t <= kTiers && tier_cap[t] != 0; };
         PlaceParams pp;
         pp.long3 = pp.long3_big = pp.dense3 = pp.dense6 = 0;
         pp.stats = opt.debug ? 1u : 0u;
@@ -556,21 +655,12 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
         // long segments as ranges side by side (option split; plan_ranges_kernel in pipeline_dev.hpp): the long shape of the
         // one-barrier kernel, 32-bit positions; also in a sharded call (the segments its window cuts short are left alone: only
         // a segment whose end the placement walk has seen is cut)
-        const bool split_on = opt.split != 0 && sizeof(SlotT) == 4 && arms_kernel && (opt.split_len == 0 || opt.split_len >= 64);
+        split_on = opt.split != 0 && sizeof(SlotT) == 4 && arms_kernel && (opt.split_len == 0 || opt.split_len >= 64);
         if (cluster_barren || split_on) {
             RC_TRY(w.seg_info.reserve((size_t)n_seg * sizeof(uint2)));
             pp.seg_info = w.seg_info.as<uint2>();
         }
-        // Workspace::split_buf: [4 counters (u64): runs, cuts, split segments, work cursor | runs | cuts | split segments |
-        // run states | verdicts per cut | per run: what is added to its records' family ordinals | segments to run again]
-        constexpr uint32_t kMaxRuns = 4096, kMaxCuts = 2048, kMaxSplits = 1024;
-        constexpr size_t kOffRuns = 64, kOffCuts = kOffRuns + kMaxRuns * sizeof(RangeRun), kOffSplits = kOffCuts + kMaxCuts * 8,
-                         kOffMeta = kOffSplits + kMaxSplits * sizeof(SplitSeg), kOffOk = kOffMeta + kMaxRuns * 64,
-                         kOffFix = kOffOk + kMaxCuts * 4, kOffAgain = kOffFix + kMaxRuns * 4, kOffChoice = kOffAgain + kMaxSplits * 4,
-                         kSplitBytes = kOffChoice + 128;
-        static_assert(sizeof(SplitChoice) <= 128 && kOffChoice % 8 == 0, "split choice");
-        static_assert(kSplitBytes <= kSplitMirror, "split mirror");
-        char *d_split = nullptr;
+        d_split = nullptr;
         if (split_on) {
             RC_TRY(w.split_buf.reserve(kSplitBytes));
             d_split = w.split_buf.as<char>();
@@ -652,25 +742,25 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(h_split, d_split, kOffMeta, hipMemcpyDeviceToHost, s));
         }
-        const uint32_t *order = nullptr;
+        order = nullptr;
         const uint32_t *sorted_keys = nullptr;
         RC_TRY(sort_segments(w, kbuf, vbuf, n_seg, s, &order, &sorted_keys, false));
         tier_bounds_kernel<<<1, 64, 0, s>>>(sorted_keys, d_ctr + CT_SEG, d_ctr);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, kCtrBytes, hipMemcpyDeviceToHost, s));
         RC_TRY(wd_sync(idx, cx, s, "the hit rows and the placement of the segments"));
-        uint64_t n_t[kTiers], seg_off[kTiers + 1] = {0};
-        uint64_t h_tp[kTiers], h_th[kTiers];  // (option debug: hit-probes and hits per tier, as placed)
+        seg_off[0] = 0;
         for (int t = 0; t < kTiers; ++t) {
             n_t[t] = h_ctr[CT_N1 + t];
             seg_off[t + 1] = seg_off[t] + n_t[t];
             h_tp[t] = h_ctr[CT_TPROBES1 + t];
             h_th[t] = h_ctr[CT_THITS1 + t];
         }
-        const unsigned long long *const h_split_hdr = reinterpret_cast<const unsigned long long *>(h_split);
-        const uint32_t n_runs = split_on ? (uint32_t)h_split_hdr[0] : 0u, n_cuts = split_on ? (uint32_t)h_split_hdr[1] : 0u,
-                       n_splits = split_on ? (uint32_t)h_split_hdr[2] : 0u;
-        std::vector<SplitSeg> split_segs(n_splits);
+        h_split_hdr = reinterpret_cast<const unsigned long long *>(h_split);
+        n_runs = split_on ? (uint32_t)h_split_hdr[0] : 0u;
+        n_cuts = split_on ? (uint32_t)h_split_hdr[1] : 0u;
+        n_splits = split_on ? (uint32_t)h_split_hdr[2] : 0u;
+        split_segs.assign(n_splits, SplitSeg{});
         if (n_splits) memcpy(split_segs.data(), h_split + kOffSplits, (size_t)n_splits * sizeof(SplitSeg));
         n_split_segments = n_splits;
         if (opt.debug && split_on)
@@ -699,7 +789,6 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
                         ms_p, ms_a, ms_b);
             }
         }
-        uint32_t *ovf[kTiers];  // ovf[t-1]: segments tier t gave up on
         for (int t = 0; t < kTiers; ++t) ovf[t] = w.ovf_list.as<uint32_t>() + (size_t)t * (n_seg + 1);
         // HBM arm storage of the LDS-array kernels: tier 6 (MODE 1) and tier 7 (MODE 2) may run at the
         // same time on different streams, so each gets its own region of 256 per-workgroup slices
@@ -709,7 +798,7 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
         // bounds get fewer workgroups (a 16 GB budget for the four regions), never fewer than one.
         // (rounded up to a multiple of 4: a workgroup's slice holds 64-bit position arrays behind arrays of this many
         // 32-bit words, and slices, regions and the early-cascade regions follow one another at multiples of it)
-        const uint64_t heavy_cap64 = (std::max<uint64_t>((uint64_t)rp.C * ((uint64_t)rp.tstar + 1u) + 64u, 4096u) + 3u) & ~3ull;
+        heavy_cap64 = (std::max<uint64_t>((uint64_t)rp.C * ((uint64_t)rp.tstar + 1u) + 64u, 4096u) + 3u) & ~3ull;
         if (heavy_cap64 >= (1ull << 24)) {
             set_error("max_cardinality * (max_gap_size / step + 1) = %llu live arms per segment: more than 2^24 are not supported",
                       (unsigned long long)heavy_cap64);
@@ -718,509 +807,518 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
         const size_t per_wg7 = (size_t)heavy_cap64 * (4 * sizeof(SlotT) + 28);
         const size_t per_wg6 = (size_t)caph * (4 * sizeof(SlotT) + 16);
         const size_t per_wg = std::max(per_wg6, per_wg7);
-        const unsigned n_wg7 = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(256, (16ull << 30) / (4 * per_wg)));
+        n_wg7 = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(256, (16ull << 30) / (4 * per_wg)));
         const unsigned n_wg_region = per_wg6 * 256 > per_wg * n_wg7 ? 256u : n_wg7;  // (a region serves either kind of launch)
-        const size_t region = std::max(per_wg6 * 256, per_wg * (size_t)n_wg7);
+        region = std::max(per_wg6 * 256, per_wg * (size_t)n_wg7);
         (void)n_wg_region;
         RC_TRY(w.scratch.reserve(region * 4));  // tier 6, tier 7, and one region per early cascade launch
-        char *const scratch6 = w.scratch.as<char>(), *const scratch7 = scratch6 + region;
-        for (int attempt = 0;; ++attempt) {
-            RC_TRY(w.fam_sds.reserve((size_t)rec_cap * sizeof(SdRec)));
-            HIP_TRY(hipMemsetAsync(d_ctr + CT_SD, 0, 8, s));
-            HIP_TRY(hipMemsetAsync(d_ctr + CT_NF, 0, (size_t)(CT_COUNT - CT_NF) * 8, s));  // NF, cursors, overflow counts
-            HIP_TRY(hipMemsetAsync(d_ctr + CT_EARLY_N, 0, 4 * 8, s));                       // early cascade counts + cursors
-            HIP_TRY(hipMemsetAsync(d_ctr + CT_BUSY1, 0, (size_t)(CT_COUNT - CT_BUSY1) * 8, s));
-            RC_TRY(w.seg_slots.reserve((size_t)8 * 4096 * 8));
-            HIP_TRY(hipMemsetAsync(w.seg_slots.p, 0, (size_t)8 * 4096 * 8, s));
-            HIP_TRY(hipEventRecord(cx.ev[7], s));
-            ExtParams<SlotT> ep;
-            ep.rp = rp;
-            ep.p_filt = p_filt;
-            ep.row_off = row_off;
-            ep.hits = hits;
-            ep.recs = w.fam_sds.as<SdRec>();
-            ep.rec_cap = rec_cap;
+        scratch6 = w.scratch.as<char>();
+        scratch7 = scratch6 + region;
+        return 0;
+    }
+
+    // one launch of tier `tier`'s kernel over the list described by ep
+    void launch_kernel(int tier, uint64_t n_items, hipStream_t st) {
+        // option grid<t> may shrink a tier's grid; the workgroup kernels (tiers 3..7) never get
+        // more workgroups than their default (HBM scratch is reserved for that many)
+        ep.tier = (uint32_t)tier;
+        ep.seg_slots = w.seg_slots.as<unsigned long long>() + (size_t)4096 * (size_t)(tier & 7);
+        ep.hb = cx.d_hb ? cx.d_hb + (size_t)2 * SearchCtx::kHbSlots * (size_t)(tier & 7) : nullptr;
+        auto grid = [&](uint64_t dflt) -> unsigned {
+            uint64_t g = dflt;
+            if (opt.grid[tier] > 0) g = tier >= 3 ? std::min<uint64_t>(dflt, (uint64_t)opt.grid[tier]) : (uint64_t)opt.grid[tier];
+            return (unsigned)std::min<uint64_t>(n_items, g);
+        };
+        switch (tier) {
+        case 1:
+            extend_kernel<SlotT, kArmCapSmall><<<grid(kGrid1), 64, 0, st>>>(ep);
+            break;
+        case 2:
+            if (arms_kernel)
+                extend_fast_kernel<SlotT, kWaveArmsLayers<SlotT>, 64, kWaveArmsHits, 256, 2><<<grid(kGrid2Arms), 64, 0, st>>>(ep);
+            else
+                extend_heavy_kernel<SlotT, kArmCapMid, kMidThreads, 0><<<grid(kGrid2), kMidThreads, 0, st>>>(ep);
+            break;
+        case 3:  // (arm-resident kernels only: the long dense segments)
+            extend_k8_kernel<SlotT, kK8LongLayers<SlotT>, 1024, kHitBatch, kFastLongRows<SlotT>, 2><<<grid(256), 1024, 0, st>>>(ep);
+            break;
+        case 4:
+            if (arms_kernel)
+                extend_fast_kernel<SlotT, kMidArmsLayers<SlotT>, 256, kWaveArmsHits, 512, 2><<<grid(256 * 4), 256, 0, st>>>(ep);
+            else if constexpr (sizeof(SlotT) == 4)
+                extend_heavy_kernel<SlotT, kArmCapBig32, kHeavyThreads, 0><<<grid(256), kHeavyThreads, 0, st>>>(ep);
+            else
+                extend_heavy_kernel<SlotT, kArmCapBig64, kHeavyThreads, 0><<<grid(256), kHeavyThreads, 0, st>>>(ep);
+            break;
+        case 5:  // (arm-resident kernels only)
+            extend_fast_kernel<SlotT, kMidArmsLayers<SlotT>, 512, kHitBatch, 1024, 2><<<grid(256 * 2), 512, 0, st>>>(ep);
+            break;
+        case 6:
+            if (scratch_override) ep.scratch = scratch_override;
+            if (arms_kernel)  // 5 x 1024 slots; 64-bit positions: 4 x 1024 with a smaller table
+                extend_fast_kernel<SlotT, kFastHeavyLayers<SlotT>, 1024, kHitBatch, kFastLongRows<SlotT>, 2><<<grid(256), 1024, 0, st>>>(ep);
+            else
+                extend_heavy_kernel<SlotT, caph, kHeavyThreads, 1><<<grid(256), kHeavyThreads, 0, st>>>(ep);
             ep.scratch = scratch6;
-            // option test_cap_limit (tests): shrink the tiers' capacity to exercise the cascade
-            ep.cap_limit = opt.test_cap_limit >= 0 ? (uint32_t)opt.test_cap_limit : 0xFFFFFFFFu;
-            ep.escalate_cost = 0xFFFFFFFFu;
-            ep.heavy_cap = (uint32_t)heavy_cap64;
-            ep.solo_hits = opt.solo == 1 ? 16u : (uint32_t)opt.solo;  // (1: the default of 16 hits; other values: that many)
-            ep.gen_bits = (uint32_t)opt.test_genbits;
-            ep.k8_delay = (uint32_t)opt.test_k8_delay;
-            ep.ctr = d_ctr;
-            ep.hb = nullptr;
-            RC_TRY(cx.heartbeat(opt.watchdog_s > 0));
-            if (cx.h_hb) memset(cx.h_hb, 0, (size_t)SearchCtx::kHbTiers * SearchCtx::kHbSlots * 16);
-            // The tiers are launched together on separate streams, each with a grid that can fill
-            // the chip on its own (persistent workgroups, longest segment first): the hardware
-            // back-fills CUs as workgroups retire, so the tails of one tier overlap the next.
-            // The window bound guarantees that a segment fits its
-            // tier, so the overflow lists normally stay empty (they feed the cascade below).
-            hipStream_t st2 = cx.stream2, st3 = cx.stream3, st4 = cx.stream4, st5 = cx.stream5, st6 = cx.stream6,
-                        st7 = cx.stream7;
-            HIP_TRY(hipStreamWaitEvent(st2, cx.ev[7], 0));
-            HIP_TRY(hipStreamWaitEvent(st3, cx.ev[7], 0));
-            HIP_TRY(hipStreamWaitEvent(st4, cx.ev[7], 0));
-            HIP_TRY(hipStreamWaitEvent(st5, cx.ev[7], 0));
-            HIP_TRY(hipStreamWaitEvent(st6, cx.ev[7], 0));
-            HIP_TRY(hipStreamWaitEvent(st7, cx.ev[7], 0));
-            // Launch order and grid sizes: workgroups are persistent and hold their LDS until the
-            // tier's work list is exhausted, so whatever is dispatched first owns the CUs.  The
-            // critical path of a pass is the longest tandem-array segment of the heavy tiers
-            // (tens of thousands of probes, strictly serial): those tiers go first, the one-wave
-            // tier last, and the heavy grids are sized so that every tier's longest segments
-            // start at once instead of queueing behind another tier's bulk.
-            const std::string tier_order = std::to_string((long long)opt.tier_order);
-            // one launch of tier `tier`'s kernel over the list described by ep
-            char *scratch_override = nullptr;  // HBM slices of an early cascade launch
-            auto launch_kernel = [&](int tier, uint64_t n_items, hipStream_t st) {
-                // option grid<t> may shrink a tier's grid; the workgroup kernels (tiers 3..7) never get
-                // more workgroups than their default (HBM scratch is reserved for that many)
-                ep.tier = (uint32_t)tier;
-                ep.seg_slots = w.seg_slots.as<unsigned long long>() + (size_t)4096 * (size_t)(tier & 7);
-                ep.hb = cx.d_hb ? cx.d_hb + (size_t)2 * SearchCtx::kHbSlots * (size_t)(tier & 7) : nullptr;
-                auto grid = [&](uint64_t dflt) -> unsigned {
-                    uint64_t g = dflt;
-                    if (opt.grid[tier] > 0) g = tier >= 3 ? std::min<uint64_t>(dflt, (uint64_t)opt.grid[tier]) : (uint64_t)opt.grid[tier];
-                    return (unsigned)std::min<uint64_t>(n_items, g);
-                };
-                switch (tier) {
-                case 1:
-                    extend_kernel<SlotT, kArmCapSmall><<<grid(kGrid1), 64, 0, st>>>(ep);
-                    break;
-                case 2:
-                    if (arms_kernel)
-                        extend_fast_kernel<SlotT, kWaveArmsLayers<SlotT>, 64, kWaveArmsHits, 256, 2><<<grid(kGrid2Arms), 64, 0, st>>>(ep);
-                    else
-                        extend_heavy_kernel<SlotT, kArmCapMid, kMidThreads, 0><<<grid(kGrid2), kMidThreads, 0, st>>>(ep);
-                    break;
-                case 3:  // (arm-resident kernels only: the long dense segments)
-                    extend_k8_kernel<SlotT, kK8LongLayers<SlotT>, 1024, kHitBatch, kFastLongRows<SlotT>, 2><<<grid(256), 1024, 0, st>>>(ep);
-                    break;
-                case 4:
-                    if (arms_kernel)
-                        extend_fast_kernel<SlotT, kMidArmsLayers<SlotT>, 256, kWaveArmsHits, 512, 2><<<grid(256 * 4), 256, 0, st>>>(ep);
-                    else if constexpr (sizeof(SlotT) == 4)
-                        extend_heavy_kernel<SlotT, kArmCapBig32, kHeavyThreads, 0><<<grid(256), kHeavyThreads, 0, st>>>(ep);
-                    else
-                        extend_heavy_kernel<SlotT, kArmCapBig64, kHeavyThreads, 0><<<grid(256), kHeavyThreads, 0, st>>>(ep);
-                    break;
-                case 5:  // (arm-resident kernels only)
-                    extend_fast_kernel<SlotT, kMidArmsLayers<SlotT>, 512, kHitBatch, 1024, 2><<<grid(256 * 2), 512, 0, st>>>(ep);
-                    break;
-                case 6:
-                    if (scratch_override) ep.scratch = scratch_override;
-                    if (arms_kernel)  // 5 x 1024 slots; 64-bit positions: 4 x 1024 with a smaller table
-                        extend_fast_kernel<SlotT, kFastHeavyLayers<SlotT>, 1024, kHitBatch, kFastLongRows<SlotT>, 2><<<grid(256), 1024, 0, st>>>(ep);
-                    else
-                        extend_heavy_kernel<SlotT, caph, kHeavyThreads, 1><<<grid(256), kHeavyThreads, 0, st>>>(ep);
-                    ep.scratch = scratch6;
-                    break;
-                default:
-                    ep.scratch = scratch_override ? scratch_override : scratch7;
-                    extend_heavy_kernel<SlotT, 1, kHeavyThreads, 2><<<grid(n_wg7), kHeavyThreads, 0, st>>>(ep);
-                    ep.scratch = scratch6;
-                    break;
-                }
-            };
-            // the runs over ranges of the cut segments: first, on the main stream (idle while the tiers run) -- they are the
-            // longest work items of the call, one workgroup each
-            auto launch_runs = [&](uint32_t n_items) {  // the runs from the work cursor on, one workgroup each
-                if constexpr (sizeof(SlotT) == 4) {
-                    ep.runs = reinterpret_cast<const RangeRun *>(d_split + kOffRuns);
-                    ep.run_meta = reinterpret_cast<uint32_t *>(d_split + kOffMeta);
-                    ep.run_dump = w.split_dump.as<uint32_t>();
-                    ep.seg_list = nullptr;
-                    ep.n_seg_ptr = reinterpret_cast<const unsigned long long *>(d_split);
-                    ep.cursor = reinterpret_cast<unsigned long long *>(d_split + 24);
-                    ep.ovf_list = nullptr;
-                    ep.ovf_count = d_ctr + CT_OVF1 + 2;
-                    ep.tier = 3;  // (statistics: with the long-segment tier)
-                    ep.seg_slots = w.seg_slots.as<unsigned long long>();  // (slot block 0: no tier's)
-                    ep.hb = cx.d_hb ? cx.d_hb : nullptr;
-                    extend_k8_kernel<SlotT, kK8LongLayers<SlotT>, 1024, kHitBatch, kFastLongRows<SlotT>, 2, true><<<n_items, 1024, 0, s>>>(ep);
-                }
-            };
-            if (n_runs) {
-                // (room for one more run per cut segment: the rest behind the last cut that held, see below)
-                RC_TRY(w.split_dump.reserve((size_t)(n_runs + n_splits) * 2 * kRunDumpCap * 32));
-                HIP_TRY(hipMemsetAsync(d_split + 24, 0, 8, s));                         // work cursor
-                HIP_TRY(hipMemsetAsync(d_split + kOffMeta, 0, (size_t)n_runs * 64, s));  // run states
-                launch_runs(n_runs);
-                HIP_TRY(hipGetLastError());
-            }
-            hipStream_t tier_stream[kTiers + 1] = {s, st7, st2, st3, st4, st5, st6, st2};
-            auto launch_tier = [&](int tier) {
-                if (tier < 1 || tier > kTiers || !n_t[tier - 1]) return;
-                ep.seg_list = order + seg_off[tier - 1];
-                ep.n_seg_ptr = d_ctr + CT_N1 + (tier - 1);
-                ep.cursor = d_ctr + CT_CUR1 + (tier - 1);
-                ep.ovf_list = tier < kTiers ? ovf[tier - 1] : nullptr;
-                ep.ovf_count = d_ctr + CT_OVF1 + (tier - 1);
-                launch_kernel(tier, n_t[tier - 1], tier_stream[tier]);
-#ifdef ASGART_PROFILE_EXTEND
-                char tag[8];
-                snprintf(tag, sizeof tag, "%d", tier);
-                PROF_TIER(tag, tier_stream[tier], n_t[tier - 1]);
-#endif
-            };
-            const auto t_launch = std::chrono::steady_clock::now();
-            auto since_launch = [&]() {
-                return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_launch).count();
-            };
-            for (char c : tier_order) launch_tier(c - '0');
+            break;
+        default:
+            ep.scratch = scratch_override ? scratch_override : scratch7;
+            extend_heavy_kernel<SlotT, 1, kHeavyThreads, 2><<<grid(n_wg7), kHeavyThreads, 0, st>>>(ep);
+            ep.scratch = scratch6;
+            break;
+        }
+    }
+
+    // the runs over ranges of the cut segments: first, on the main stream (idle while the tiers run) -- they are the
+    // longest work items of the call, one workgroup each
+    void launch_runs(uint32_t n_items) {  // the runs from the work cursor on, one workgroup each
+        if constexpr (sizeof(SlotT) == 4) {
+            ep.runs = reinterpret_cast<const RangeRun *>(d_split + kOffRuns);
+            ep.run_meta = reinterpret_cast<uint32_t *>(d_split + kOffMeta);
+            ep.run_dump = w.split_dump.as<uint32_t>();
+            ep.seg_list = nullptr;
+            ep.n_seg_ptr = reinterpret_cast<const unsigned long long *>(d_split);
+            ep.cursor = reinterpret_cast<unsigned long long *>(d_split + 24);
+            ep.ovf_list = nullptr;
+            ep.ovf_count = d_ctr + CT_OVF1 + 2;
+            ep.tier = 3;  // (statistics: with the long-segment tier)
+            ep.seg_slots = w.seg_slots.as<unsigned long long>();  // (slot block 0: no tier's)
+            ep.hb = cx.d_hb ? cx.d_hb : nullptr;
+            extend_k8_kernel<SlotT, kK8LongLayers<SlotT>, 1024, kHitBatch, kFastLongRows<SlotT>, 2, true><<<n_items, 1024, 0, s>>>(ep);
+        }
+    }
+
+    void launch_tier(int tier) {
+        if (tier < 1 || tier > kTiers || !n_t[tier - 1]) return;
+        ep.seg_list = order + seg_off[tier - 1];
+        ep.n_seg_ptr = d_ctr + CT_N1 + (tier - 1);
+        ep.cursor = d_ctr + CT_CUR1 + (tier - 1);
+        ep.ovf_list = tier < kTiers ? ovf[tier - 1] : nullptr;
+        ep.ovf_count = d_ctr + CT_OVF1 + (tier - 1);
+        launch_kernel(tier, n_t[tier - 1], tier_stream[tier]);
+    #ifdef ASGART_PROFILE_EXTEND
+        char tag[8];
+        snprintf(tag, sizeof tag, "%d", tier);
+        PROF_TIER(tag, tier_stream[tier], n_t[tier - 1]);
+    #endif
+    }
+
+    // ---- every tier and the runs over ranges, launched together; early re-runs of what tiers 3 and 6 give up on ----------------
+    int32_t run_tiers(int attempt) {
+        RC_TRY(w.fam_sds.reserve((size_t)rec_cap * sizeof(SdRec)));
+        HIP_TRY(hipMemsetAsync(d_ctr + CT_SD, 0, 8, s));
+        HIP_TRY(hipMemsetAsync(d_ctr + CT_NF, 0, (size_t)(CT_COUNT - CT_NF) * 8, s));  // NF, cursors, overflow counts
+        HIP_TRY(hipMemsetAsync(d_ctr + CT_EARLY_N, 0, 4 * 8, s));                       // early cascade counts + cursors
+        HIP_TRY(hipMemsetAsync(d_ctr + CT_BUSY1, 0, (size_t)(CT_COUNT - CT_BUSY1) * 8, s));
+        RC_TRY(w.seg_slots.reserve((size_t)8 * 4096 * 8));
+        HIP_TRY(hipMemsetAsync(w.seg_slots.p, 0, (size_t)8 * 4096 * 8, s));
+        HIP_TRY(hipEventRecord(cx.ev[7], s));
+        ep.rp = rp;
+        ep.p_filt = p_filt;
+        ep.row_off = row_off;
+        ep.hits = hits;
+        ep.recs = w.fam_sds.as<SdRec>();
+        ep.rec_cap = rec_cap;
+        ep.scratch = scratch6;
+        // option test_cap_limit (tests): shrink the tiers' capacity to exercise the cascade
+        ep.cap_limit = opt.test_cap_limit >= 0 ? (uint32_t)opt.test_cap_limit : 0xFFFFFFFFu;
+        ep.escalate_cost = 0xFFFFFFFFu;
+        ep.heavy_cap = (uint32_t)heavy_cap64;
+        ep.solo_hits = opt.solo == 1 ? 16u : (uint32_t)opt.solo;  // (1: the default of 16 hits; other values: that many)
+        ep.gen_bits = (uint32_t)opt.test_genbits;
+        ep.k8_delay = (uint32_t)opt.test_k8_delay;
+        ep.ctr = d_ctr;
+        ep.hb = nullptr;
+        RC_TRY(cx.heartbeat(opt.watchdog_s > 0));
+        if (cx.h_hb) memset(cx.h_hb, 0, (size_t)SearchCtx::kHbTiers * SearchCtx::kHbSlots * 16);
+        // The tiers are launched together on separate streams, each with a grid that can fill
+        // the chip on its own (persistent workgroups, longest segment first): the hardware
+        // back-fills CUs as workgroups retire, so the tails of one tier overlap the next.
+        // The window bound guarantees that a segment fits its
+        // tier, so the overflow lists normally stay empty (they feed the cascade below).
+        const hipStream_t st2 = cx.stream2, st3 = cx.stream3, st4 = cx.stream4, st5 = cx.stream5, st6 = cx.stream6, st7 = cx.stream7;
+        {
+            const hipStream_t streams[kTiers + 1] = {s, st7, st2, st3, st4, st5, st6, st2};
+            for (int t = 0; t <= kTiers; ++t) tier_stream[t] = streams[t];
+        }
+        HIP_TRY(hipStreamWaitEvent(st2, cx.ev[7], 0));
+        HIP_TRY(hipStreamWaitEvent(st3, cx.ev[7], 0));
+        HIP_TRY(hipStreamWaitEvent(st4, cx.ev[7], 0));
+        HIP_TRY(hipStreamWaitEvent(st5, cx.ev[7], 0));
+        HIP_TRY(hipStreamWaitEvent(st6, cx.ev[7], 0));
+        HIP_TRY(hipStreamWaitEvent(st7, cx.ev[7], 0));
+        // Launch order and grid sizes: workgroups are persistent and hold their LDS until the
+        // tier's work list is exhausted, so whatever is dispatched first owns the CUs.  The
+        // critical path of a pass is the longest tandem-array segment of the heavy tiers
+        // (tens of thousands of probes, strictly serial): those tiers go first, the one-wave
+        // tier last, and the heavy grids are sized so that every tier's longest segments
+        // start at once instead of queueing behind another tier's bulk.
+        const std::string tier_order = std::to_string((long long)opt.tier_order);
+        scratch_override = nullptr;
+        if (n_runs) {
+            // (room for one more run per cut segment: the rest behind the last cut that held, see below)
+            RC_TRY(w.split_dump.reserve((size_t)(n_runs + n_splits) * 2 * kRunDumpCap * 32));
+            HIP_TRY(hipMemsetAsync(d_split + 24, 0, 8, s));                         // work cursor
+            HIP_TRY(hipMemsetAsync(d_split + kOffMeta, 0, (size_t)n_runs * 64, s));  // run states
+            launch_runs(n_runs);
             HIP_TRY(hipGetLastError());
-            HIP_TRY(hipEventRecord(cx.ev[12], st7));
-            HIP_TRY(hipEventRecord(cx.ev[5], st2));
-            HIP_TRY(hipEventRecord(cx.ev[6], st3));
-            HIP_TRY(hipEventRecord(cx.ev[8], st4));
-            HIP_TRY(hipEventRecord(cx.ev[9], st5));
-            HIP_TRY(hipEventRecord(cx.ev[10], st6));
-            if (cx.progress && attempt == 0) {
-                // Progress (reference src/automaton.rs:98 stores every probe's offset for a polled progress
-                // bar): every probe of the call has been searched and its hits are materialised -- the
-                // HBM-bound, chip-wide part of the call is over, the extension automaton is under way.
-                // A host that pipelines calls (bench.py) issues the next one when it sees this: its search
-                // phases then run beside this call's extension, whose tail is a few serial segments.
-                if (!progress_given) {
-                    RC_TRY(wd_event_sync(idx, cx, cx.ev[3], "the hit rows"));  // probe search, scans and CSR fill are done
-                    signal_progress();
-                }
+        }
+        t_launch = std::chrono::steady_clock::now();
+        for (char c : tier_order) launch_tier(c - '0');
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(cx.ev[12], st7));
+        HIP_TRY(hipEventRecord(cx.ev[5], st2));
+        HIP_TRY(hipEventRecord(cx.ev[6], st3));
+        HIP_TRY(hipEventRecord(cx.ev[8], st4));
+        HIP_TRY(hipEventRecord(cx.ev[9], st5));
+        HIP_TRY(hipEventRecord(cx.ev[10], st6));
+        if (cx.progress && attempt == 0) {
+            // Progress (reference src/automaton.rs:98 stores every probe's offset for a polled progress
+            // bar): every probe of the call has been searched and its hits are materialised -- the
+            // HBM-bound, chip-wide part of the call is over, the extension automaton is under way.
+            // A host that pipelines calls (bench.py) issues the next one when it sees this: its search
+            // phases then run beside this call's extension, whose tail is a few serial segments.
+            if (!progress_given) {
+                RC_TRY(wd_event_sync(idx, cx, cx.ev[3], "the hit rows"));  // probe search, scans and CSR fill are done
+                signal_progress();
             }
-            // Early cascades of tiers 3 and 6, the two tiers that accept segments above their real capacity (by
-            // the allowance): what they give up on need not wait for the other tiers to be re-run -- the longest
-            // tier-3 segment of a GRCh38-shaped pass runs 60+ ms longer than tier 6, and in a two-genome run tier 6
-            // runs seconds longer than tier 3.  The host waits for whichever of the two finishes first, reads its
-            // overflow count and launches the re-run behind it on the same stream (the main stream is idle
-            // meanwhile and has the highest priority); each such launch has its own counters and HBM slices.
-            uint64_t early_n[kTiers + 1] = {0};
-            {
-                struct Early {
-                    int src, dst;
-                    hipEvent_t ev;
-                    hipStream_t st;
-                    bool pending;
-                } early[2] = {{3, 0, cx.ev[6], st3, false}, {6, 0, cx.ev[10], st6, false}};
-                int n_pending = 0;
-                unsigned early_polls = 0;
-                Watchdog early_wd(idx, cx);
+        }
+        // Early cascades of tiers 3 and 6, the two tiers that accept segments above their real capacity (by
+        // the allowance): what they give up on need not wait for the other tiers to be re-run -- the longest
+        // tier-3 segment of a GRCh38-shaped pass runs 60+ ms longer than tier 6, and in a two-genome run tier 6
+        // runs seconds longer than tier 3.  The host waits for whichever of the two finishes first, reads its
+        // overflow count and launches the re-run behind it on the same stream (the main stream is idle
+        // meanwhile and has the highest priority); each such launch has its own counters and HBM slices.
+        for (int t = 0; t <= kTiers; ++t) early_n[t] = 0;
+        {
+            struct Early {
+                int src, dst;
+                hipEvent_t ev;
+                hipStream_t st;
+                bool pending;
+            } early[2] = {{3, 0, cx.ev[6], st3, false}, {6, 0, cx.ev[10], st6, false}};
+            int n_pending = 0;
+            unsigned early_polls = 0;
+            Watchdog early_wd(idx, cx);
+            for (int e = 0; e < 2; ++e) {
+                Early &E = early[e];
+                int dst = E.src + 1;
+                while (dst < kTiers && (!tier_enabled(dst) || tier_cap[dst] <= tier_cap[E.src])) ++dst;
+                E.dst = dst;
+                // (a re-run in the HBM tier would share that tier's slices with its own list, if it has one)
+                E.pending = n_t[E.src - 1] && tier_stream[E.src] == E.st &&
+                            (dst < kTiers || !n_t[kTiers - 1]);
+                n_pending += E.pending ? 1 : 0;
+            }
+            // (If tier 3's re-run went to tier 6, its kernel would append to tier 6's overflow list while the host
+            // snapshots that list's length for tier 6's own early re-run -- a count that may be ahead of the entry:
+            // such a re-run waits for the regular cascade below.  With the shipped shapes tier 6 never accepts
+            // more than tier 3 and the case does not arise.)
+            if (early[0].pending && early[1].pending && early[0].dst == early[1].src) {
+                early[0].pending = false;
+                --n_pending;
+            }
+            while (n_pending) {
+                bool progressed = false;
                 for (int e = 0; e < 2; ++e) {
                     Early &E = early[e];
-                    int dst = E.src + 1;
-                    while (dst < kTiers && (!tier_enabled(dst) || tier_cap[dst] <= tier_cap[E.src])) ++dst;
-                    E.dst = dst;
-                    // (a re-run in the HBM tier would share that tier's slices with its own list, if it has one)
-                    E.pending = n_t[E.src - 1] && tier_stream[E.src] == E.st &&
-                                (dst < kTiers || !n_t[kTiers - 1]);
-                    n_pending += E.pending ? 1 : 0;
-                }
-                // (If tier 3's re-run went to tier 6, its kernel would append to tier 6's overflow list while the host
-                // snapshots that list's length for tier 6's own early re-run -- a count that may be ahead of the entry:
-                // such a re-run waits for the regular cascade below.  With the shipped shapes tier 6 never accepts
-                // more than tier 3 and the case does not arise.)
-                if (early[0].pending && early[1].pending && early[0].dst == early[1].src) {
-                    early[0].pending = false;
+                    if (!E.pending) continue;
+                    const hipError_t q = hipEventQuery(E.ev);
+                    if (q == hipErrorNotReady) {
+                        (void)hipGetLastError();
+                        continue;
+                    }
+                    HIP_TRY(q);
+                    E.pending = false;
                     --n_pending;
-                }
-                while (n_pending) {
-                    bool progressed = false;
-                    for (int e = 0; e < 2; ++e) {
-                        Early &E = early[e];
-                        if (!E.pending) continue;
-                        const hipError_t q = hipEventQuery(E.ev);
-                        if (q == hipErrorNotReady) {
-                            (void)hipGetLastError();
-                            continue;
-                        }
-                        HIP_TRY(q);
-                        E.pending = false;
-                        --n_pending;
-                        progressed = true;
-                        HIP_TRY(hipMemcpyAsync(h_scalar + 1 + e, d_ctr + CT_OVF1 + E.src - 1, 8, hipMemcpyDeviceToHost, s));
-                        RC_TRY(wd_sync(idx, cx, s, "an overflow count"));
-                        const uint64_t n_e = h_scalar[1 + e];
-                        if (opt.debug)
-                            fprintf(stderr, "[asgart] tier %d done %.1f ms after the launches, %llu segment(s) to re-run in tier %d\n",
-                                    E.src, since_launch(), (unsigned long long)n_e, E.dst);
-                        if (!n_e) continue;
-                        early_n[E.src] = n_e;
-                        // the count the launch works on is fixed now (the list itself may still grow)
-                        HIP_TRY(hipMemcpyAsync(d_ctr + CT_EARLY_N + e, h_scalar + 1 + e, 8, hipMemcpyHostToDevice, E.st));
-                        ep.seg_list = ovf[E.src - 1];
-                        ep.n_seg_ptr = d_ctr + CT_EARLY_N + e;
-                        ep.cursor = d_ctr + CT_EARLY_CUR + e;
-                        ep.ovf_list = E.dst < kTiers ? ovf[E.dst - 1] : nullptr;
-                        ep.ovf_count = d_ctr + CT_OVF1 + E.dst - 1;
-                        ep.escalate_cost = 0xFFFFFFFFu;
-                        ep.cap_limit = 0xFFFFFFFFu;
-                        scratch_override = scratch6 + region * (size_t)(2 + e);
-                        launch_kernel(E.dst, n_e, E.st);
-                        scratch_override = nullptr;
-                        HIP_TRY(hipGetLastError());
-                        HIP_TRY(hipEventRecord(E.ev, E.st));
-                    }
-                    if (n_pending && !progressed) {
-                        std::this_thread::sleep_for(std::chrono::microseconds(50));
-                        // (the same watchdog as every other wait of the call -- one look at the heartbeats, never a blocking
-                        // wait: the other tier's early re-run must not wait for this one's stream to drain)
-                        if ((++early_polls & 0x3FFu) == 0 && early_wd.expired(early[0].pending ? "extension tier 3" : "extension tier 6"))
-                            return ASGART_E_HIP;
-                    }
-                }
-            }
-            HIP_TRY(hipStreamWaitEvent(s, cx.ev[5], 0));
-            HIP_TRY(hipStreamWaitEvent(s, cx.ev[6], 0));
-            HIP_TRY(hipStreamWaitEvent(s, cx.ev[8], 0));
-            HIP_TRY(hipStreamWaitEvent(s, cx.ev[9], 0));
-            HIP_TRY(hipStreamWaitEvent(s, cx.ev[10], 0));
-            HIP_TRY(hipStreamWaitEvent(s, cx.ev[12], 0));
-            if (n_cuts) {
-                validate_cuts_kernel<<<n_cuts, 256, 0, s>>>(reinterpret_cast<const uint2 *>(d_split + kOffCuts),
-                                                           reinterpret_cast<const uint32_t *>(d_split + kOffMeta), w.split_dump.as<uint32_t>(),
-                                                           reinterpret_cast<uint32_t *>(d_split + kOffOk));
-                HIP_TRY(hipGetLastError());
-                HIP_TRY(hipMemcpyAsync(h_split + kOffMeta, d_split + kOffMeta, kOffFix - kOffMeta, hipMemcpyDeviceToHost, s));
-            }
-            HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, kCtrBytes, hipMemcpyDeviceToHost, s));
-            RC_TRY(wd_sync(idx, cx, s, "the extension tiers"));
-            if (n_runs) {
-                // Every cut of a segment held: the family ordinals of range j count on from the flushes of ranges 0 .. j - 1.
-                // The first cut that did not hold is cut f: ranges 0 .. f stand (range f started from a state that was checked),
-                // the records of the ranges behind it are dropped, and ONE more run covers the rest -- from where range f started
-                // (it passes cut f in the checked state, so it is exact from there on), reporting from cut f + 1 to the segment's
-                // end.  f = 0, or a run that gave up: the segment runs again as a whole on the ordinary kernel.  The index remembers
-                // how many cuts of the segment held and plans only those from then on.
-                const uint32_t *h_meta = reinterpret_cast<const uint32_t *>(h_split + kOffMeta);
-                const uint32_t *h_ok = reinterpret_cast<const uint32_t *>(h_split + kOffOk);
-                RangeRun *h_runs = reinterpret_cast<RangeRun *>(h_split + kOffRuns);
-                uint32_t *h_fix = reinterpret_cast<uint32_t *>(h_split + kOffFix);
-                uint32_t *h_again = reinterpret_cast<uint32_t *>(h_split + kOffAgain);
-                uint32_t n_again = 0, n_tail = 0;
-                n_split_refused = 0;
-                struct Tail {
-                    uint32_t run, base, g_seg0, run_base, f;
-                };
-                std::vector<uint32_t> held_base;  // family-ordinal bases of the ranges whose records wait for their segment's last run
-                std::vector<Tail> tails;
-                auto remember = [&](uint32_t g_seg0, uint32_t allowed) {
-                    const uint32_t p_ = pass_of_probe(g_seg0);
-                    const uint64_t key_ = (uint64_t)((rp.modes >> (8 * p_)) & 0xFFu) << 32 | (uint64_t)pass_offset(g_seg0);
-                    const uint32_t len_ = (uint32_t)h_split_hdr[4];
-                    std::lock_guard<std::mutex> lk(idx->mu);
-                    for (auto &b : idx->split_blocked)
-                        if (b.key == key_ && b.sig == call_sig) {
-                            b.allowed = b.range_len == len_ ? std::min(b.allowed, allowed) : allowed;
-                            b.range_len = len_;
-                            return;
-                        }
-                    // (verdicts age out, oldest first: a forgotten one costs its segment one more refused cut, no more)
-                    if (idx->split_blocked.size() >= 4096) idx->split_blocked.erase(idx->split_blocked.begin());
-                    idx->split_blocked.push_back({key_, call_sig, allowed, len_});
-                };
-                for (const SplitSeg &sg : split_segs) {
-                    const uint32_t n_cuts_sg = sg.n_ranges - 1;
-                    uint32_t f = n_cuts_sg;  // first cut that did not hold
-                    for (uint32_t j = 0; j < n_cuts_sg; ++j)
-                        if (!h_ok[sg.cut_base + j]) {
-                            f = j;
-                            break;
-                        }
-                    const bool last_gave_up = h_meta[(size_t)(sg.run_base + sg.n_ranges - 1) * 16 + 4] != 0u;
-                    const bool ok = f == n_cuts_sg && !last_gave_up;
-                    if (f == n_cuts_sg && last_gave_up) f = 0;  // (more arms than the long shape holds: the cascade's business)
-                    uint32_t base = 0;
-                    for (uint32_t j = 0; j < sg.n_ranges; ++j) {
-                        // (ranges in front of a cut that did not hold: decided when the run over the rest has come back)
-                        h_fix[sg.run_base + j] = ok ? base : ((f > 0 && j <= f) ? 0xFFFFFFFEu : 0xFFFFFFFFu);
-                        if (!ok && f > 0 && j <= f) held_base.push_back(base);
-                        base += h_meta[(size_t)(sg.run_base + j) * 16 + 1];
-                        if (!ok && f > 0 && j == f) {
-                            RangeRun t = h_runs[sg.run_base + f];
-                            t.g_stop = 0xFFFFFFFFu;
-                            t.emit_from = h_runs[sg.run_base + f + 1].emit_from;
-                            t.flags = kRunLast;
-                            h_runs[n_runs + n_tail] = t;
-                            tails.push_back(Tail{n_runs + n_tail, base, sg.g_seg0, sg.run_base, f});
-                            ++n_tail;
-                        }
-                    }
-                    if (!ok && opt.debug) {
-                        fprintf(stderr, "[asgart] ranges: segment at probe %u (%u ranges): %u cut(s) held; cuts (arms in the range in front / in the range behind, family open, held flush):",
-                                sg.g_seg0, sg.n_ranges, f);
-                        for (uint32_t j = 0; j < n_cuts_sg; ++j) {
-                            const uint32_t *ma = h_meta + (size_t)(sg.run_base + j) * 16, *mb = h_meta + (size_t)(sg.run_base + j + 1) * 16 + 8;
-                            fprintf(stderr, " %s%u/%u,%u/%u,%u/%u%s", h_ok[sg.cut_base + j] ? "" : "[", ma[0], mb[0], ma[2], mb[2], ma[3], mb[3],
-                                    h_ok[sg.cut_base + j] ? "" : "]");
-                        }
-                        fprintf(stderr, "%s\n", last_gave_up ? " (the last range gave up)" : "");
-                    }
-                    if (!ok) {
-                        ++n_split_refused;
-                        remember(sg.g_seg0, f);
-                        if (f == 0) h_again[n_again++] = sg.g_seg0;
-                    }
-                }
-                if (opt.debug) {  // the runs' durations, per cut segment (ms)
-                    for (const SplitSeg &sg : split_segs) {
-                        fprintf(stderr, "[asgart] ranges: segment at probe %u (tier %u, %u positions, %u hits): runs", sg.g_seg0, sg.tier, sg.span, sg.hits);
-                        for (uint32_t j = 0; j < sg.n_ranges; ++j) fprintf(stderr, " %.1f", (double)h_meta[(size_t)(sg.run_base + j) * 16 + 5] * 1e-5);
-                        fprintf(stderr, " ms\n");
-                    }
-                }
-                if (opt.debug)
-                    fprintf(stderr, "[asgart] ranges: %llu of %u cut segment(s) joined up%s\n", (unsigned long long)(n_splits - n_split_refused), n_splits,
-                            n_split_refused ? "; the others: the rest behind the last cut that held as one more run, or the whole segment again" : "");
-                for (const Tail &t : tails) h_fix[t.run] = 0xFFFFFFFEu;  // (until the run has come back)
-                HIP_TRY(hipMemcpyAsync(d_split + kOffFix, h_fix, kOffAgain - kOffFix, hipMemcpyHostToDevice, s));
-                uint64_t n_slots = std::min<uint64_t>(h_ctr[CT_SD], rec_cap);
-                if (n_slots) fixup_records_kernel<<<grid_for(n_slots), 256, 0, s>>>(w.fam_sds.as<SdRec>(), n_slots, reinterpret_cast<const uint32_t *>(d_split + kOffFix));
-                HIP_TRY(hipGetLastError());
-                if (n_tail) {
-                    if constexpr (sizeof(SlotT) == 4) {
-                        HIP_TRY(hipMemcpyAsync(d_split + kOffRuns + (size_t)n_runs * sizeof(RangeRun), h_runs + n_runs, (size_t)n_tail * sizeof(RangeRun),
-                                               hipMemcpyHostToDevice, s));
-                        h_scalar[8] = (unsigned long long)n_runs + n_tail;  // list length
-                        h_scalar[9] = n_runs;                               // work cursor: behind the runs that are done
-                        HIP_TRY(hipMemcpyAsync(d_split, h_scalar + 8, 8, hipMemcpyHostToDevice, s));
-                        HIP_TRY(hipMemcpyAsync(d_split + 24, h_scalar + 9, 8, hipMemcpyHostToDevice, s));
-                        HIP_TRY(hipMemsetAsync(d_split + kOffMeta + (size_t)n_runs * 64, 0, (size_t)n_tail * 64, s));
-                        launch_runs(n_tail);
-                        HIP_TRY(hipMemcpyAsync(h_split + kOffMeta + (size_t)n_runs * 64, d_split + kOffMeta + (size_t)n_runs * 64, (size_t)n_tail * 64,
-                                               hipMemcpyDeviceToHost, s));
-                        HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, kCtrBytes, hipMemcpyDeviceToHost, s));
-                        RC_TRY(wd_sync(idx, cx, s, "the rest of the cut segments"));
-                        h_scalar[8] = n_runs;  // (a second attempt of the call -- record buffer too small -- starts from the planned list)
-                        HIP_TRY(hipMemcpyAsync(d_split, h_scalar + 8, 8, hipMemcpyHostToDevice, s));
-                        size_t hb = 0;
-                        for (const Tail &t : tails) {
-                            // (a last run that gave up -- more arms than the long shape holds --: everything the segment's runs wrote
-                            // is dropped and the whole segment goes the cascade's way)
-                            const bool gave_up = h_meta[(size_t)t.run * 16 + 4] != 0u;
-                            h_fix[t.run] = gave_up ? 0xFFFFFFFFu : t.base;
-                            for (uint32_t j = 0; j <= t.f; ++j, ++hb) h_fix[t.run_base + j] = gave_up ? 0xFFFFFFFFu : held_base[hb];
-                            if (gave_up) {
-                                h_again[n_again++] = t.g_seg0;
-                                remember(t.g_seg0, 0u);
-                            }
-                        }
-                        HIP_TRY(hipMemcpyAsync(d_split + kOffFix, h_fix, kOffAgain - kOffFix, hipMemcpyHostToDevice, s));
-                        n_slots = std::min<uint64_t>(h_ctr[CT_SD], rec_cap);
-                        if (n_slots) fixup_records_kernel<<<grid_for(n_slots), 256, 0, s>>>(w.fam_sds.as<SdRec>(), n_slots, reinterpret_cast<const uint32_t *>(d_split + kOffFix));
-                        HIP_TRY(hipGetLastError());
-                    }
-                }
-                if (n_again) {
-                    HIP_TRY(hipMemcpyAsync(d_split + kOffAgain, h_again, (size_t)n_again * 4, hipMemcpyHostToDevice, s));
-                    *h_scalar = n_again;
-                    HIP_TRY(hipMemcpyAsync(d_ctr + CT_NF, h_scalar, 8, hipMemcpyHostToDevice, s));
-                    HIP_TRY(hipMemsetAsync(d_ctr + CT_CURF, 0, 8, s));
-                    ep.seg_list = reinterpret_cast<const uint32_t *>(d_split + kOffAgain);
-                    ep.n_seg_ptr = d_ctr + CT_NF;
-                    ep.cursor = d_ctr + CT_CURF;
-                    ep.ovf_list = ovf[3 - 1];
-                    ep.ovf_count = d_ctr + CT_OVF1 + 3 - 1;  // (what the whole segment overflows goes the way of tier 3's own)
+                    progressed = true;
+                    HIP_TRY(hipMemcpyAsync(h_scalar + 1 + e, d_ctr + CT_OVF1 + E.src - 1, 8, hipMemcpyDeviceToHost, s));
+                    RC_TRY(wd_sync(idx, cx, s, "an overflow count"));
+                    const uint64_t n_e = h_scalar[1 + e];
+                    if (opt.debug)
+                        fprintf(stderr, "[asgart] tier %d done %.1f ms after the launches, %llu segment(s) to re-run in tier %d\n",
+                                E.src, since_launch(), (unsigned long long)n_e, E.dst);
+                    if (!n_e) continue;
+                    early_n[E.src] = n_e;
+                    // the count the launch works on is fixed now (the list itself may still grow)
+                    HIP_TRY(hipMemcpyAsync(d_ctr + CT_EARLY_N + e, h_scalar + 1 + e, 8, hipMemcpyHostToDevice, E.st));
+                    ep.seg_list = ovf[E.src - 1];
+                    ep.n_seg_ptr = d_ctr + CT_EARLY_N + e;
+                    ep.cursor = d_ctr + CT_EARLY_CUR + e;
+                    ep.ovf_list = E.dst < kTiers ? ovf[E.dst - 1] : nullptr;
+                    ep.ovf_count = d_ctr + CT_OVF1 + E.dst - 1;
                     ep.escalate_cost = 0xFFFFFFFFu;
-                    launch_kernel(3, n_again, s);
+                    ep.cap_limit = 0xFFFFFFFFu;
+                    scratch_override = scratch6 + region * (size_t)(2 + e);
+                    launch_kernel(E.dst, n_e, E.st);
+                    scratch_override = nullptr;
+                    HIP_TRY(hipGetLastError());
+                    HIP_TRY(hipEventRecord(E.ev, E.st));
+                }
+                if (n_pending && !progressed) {
+                    std::this_thread::sleep_for(std::chrono::microseconds(50));
+                    // (the same watchdog as every other wait of the call -- one look at the heartbeats, never a blocking
+                    // wait: the other tier's early re-run must not wait for this one's stream to drain)
+                    if ((++early_polls & 0x3FFu) == 0 && early_wd.expired(early[0].pending ? "extension tier 3" : "extension tier 6"))
+                        return ASGART_E_HIP;
+                }
+            }
+        }
+        return 0;
+    }
+
+    // ---- the tiers are through: cuts checked, ranges joined up, refused segments run again --------------------------------------
+    int32_t join_ranges() {
+        HIP_TRY(hipStreamWaitEvent(s, cx.ev[5], 0));
+        HIP_TRY(hipStreamWaitEvent(s, cx.ev[6], 0));
+        HIP_TRY(hipStreamWaitEvent(s, cx.ev[8], 0));
+        HIP_TRY(hipStreamWaitEvent(s, cx.ev[9], 0));
+        HIP_TRY(hipStreamWaitEvent(s, cx.ev[10], 0));
+        HIP_TRY(hipStreamWaitEvent(s, cx.ev[12], 0));
+        if (n_cuts) {
+            validate_cuts_kernel<<<n_cuts, 256, 0, s>>>(reinterpret_cast<const uint2 *>(d_split + kOffCuts),
+                                                       reinterpret_cast<const uint32_t *>(d_split + kOffMeta), w.split_dump.as<uint32_t>(),
+                                                       reinterpret_cast<uint32_t *>(d_split + kOffOk));
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(h_split + kOffMeta, d_split + kOffMeta, kOffFix - kOffMeta, hipMemcpyDeviceToHost, s));
+        }
+        HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, kCtrBytes, hipMemcpyDeviceToHost, s));
+        RC_TRY(wd_sync(idx, cx, s, "the extension tiers"));
+        if (n_runs) {
+            // Every cut of a segment held: the family ordinals of range j count on from the flushes of ranges 0 .. j - 1.
+            // The first cut that did not hold is cut f: ranges 0 .. f stand (range f started from a state that was checked),
+            // the records of the ranges behind it are dropped, and ONE more run covers the rest -- from where range f started
+            // (it passes cut f in the checked state, so it is exact from there on), reporting from cut f + 1 to the segment's
+            // end.  f = 0, or a run that gave up: the segment runs again as a whole on the ordinary kernel.  The index remembers
+            // how many cuts of the segment held and plans only those from then on.
+            const uint32_t *h_meta = reinterpret_cast<const uint32_t *>(h_split + kOffMeta);
+            const uint32_t *h_ok = reinterpret_cast<const uint32_t *>(h_split + kOffOk);
+            RangeRun *h_runs = reinterpret_cast<RangeRun *>(h_split + kOffRuns);
+            uint32_t *h_fix = reinterpret_cast<uint32_t *>(h_split + kOffFix);
+            uint32_t *h_again = reinterpret_cast<uint32_t *>(h_split + kOffAgain);
+            uint32_t n_again = 0, n_tail = 0;
+            n_split_refused = 0;
+            struct Tail {
+                uint32_t run, base, g_seg0, run_base, f;
+            };
+            std::vector<uint32_t> held_base;  // family-ordinal bases of the ranges whose records wait for their segment's last run
+            std::vector<Tail> tails;
+            auto remember = [&](uint32_t g_seg0, uint32_t allowed) {
+                const uint32_t p_ = pass_of_probe(g_seg0);
+                const uint64_t key_ = (uint64_t)((rp.modes >> (8 * p_)) & 0xFFu) << 32 | (uint64_t)pass_offset(g_seg0);
+                const uint32_t len_ = (uint32_t)h_split_hdr[4];
+                std::lock_guard<std::mutex> lk(idx->mu);
+                for (auto &b : idx->split_blocked)
+                    if (b.key == key_ && b.sig == call_sig) {
+                        b.allowed = b.range_len == len_ ? std::min(b.allowed, allowed) : allowed;
+                        b.range_len = len_;
+                        return;
+                    }
+                // (verdicts age out, oldest first: a forgotten one costs its segment one more refused cut, no more)
+                if (idx->split_blocked.size() >= 4096) idx->split_blocked.erase(idx->split_blocked.begin());
+                idx->split_blocked.push_back({key_, call_sig, allowed, len_});
+            };
+            for (const SplitSeg &sg : split_segs) {
+                const uint32_t n_cuts_sg = sg.n_ranges - 1;
+                uint32_t f = n_cuts_sg;  // first cut that did not hold
+                for (uint32_t j = 0; j < n_cuts_sg; ++j)
+                    if (!h_ok[sg.cut_base + j]) {
+                        f = j;
+                        break;
+                    }
+                const bool last_gave_up = h_meta[(size_t)(sg.run_base + sg.n_ranges - 1) * 16 + 4] != 0u;
+                const bool ok = f == n_cuts_sg && !last_gave_up;
+                if (f == n_cuts_sg && last_gave_up) f = 0;  // (more arms than the long shape holds: the cascade's business)
+                uint32_t base = 0;
+                for (uint32_t j = 0; j < sg.n_ranges; ++j) {
+                    // (ranges in front of a cut that did not hold: decided when the run over the rest has come back)
+                    h_fix[sg.run_base + j] = ok ? base : ((f > 0 && j <= f) ? 0xFFFFFFFEu : 0xFFFFFFFFu);
+                    if (!ok && f > 0 && j <= f) held_base.push_back(base);
+                    base += h_meta[(size_t)(sg.run_base + j) * 16 + 1];
+                    if (!ok && f > 0 && j == f) {
+                        RangeRun t = h_runs[sg.run_base + f];
+                        t.g_stop = 0xFFFFFFFFu;
+                        t.emit_from = h_runs[sg.run_base + f + 1].emit_from;
+                        t.flags = kRunLast;
+                        h_runs[n_runs + n_tail] = t;
+                        tails.push_back(Tail{n_runs + n_tail, base, sg.g_seg0, sg.run_base, f});
+                        ++n_tail;
+                    }
+                }
+                if (!ok && opt.debug) {
+                    fprintf(stderr, "[asgart] ranges: segment at probe %u (%u ranges): %u cut(s) held; cuts (arms in the range in front / in the range behind, family open, held flush):",
+                            sg.g_seg0, sg.n_ranges, f);
+                    for (uint32_t j = 0; j < n_cuts_sg; ++j) {
+                        const uint32_t *ma = h_meta + (size_t)(sg.run_base + j) * 16, *mb = h_meta + (size_t)(sg.run_base + j + 1) * 16 + 8;
+                        fprintf(stderr, " %s%u/%u,%u/%u,%u/%u%s", h_ok[sg.cut_base + j] ? "" : "[", ma[0], mb[0], ma[2], mb[2], ma[3], mb[3],
+                                h_ok[sg.cut_base + j] ? "" : "]");
+                    }
+                    fprintf(stderr, "%s\n", last_gave_up ? " (the last range gave up)" : "");
+                }
+                if (!ok) {
+                    ++n_split_refused;
+                    remember(sg.g_seg0, f);
+                    if (f == 0) h_again[n_again++] = sg.g_seg0;
+                }
+            }
+            if (opt.debug) {  // the runs' durations, per cut segment (ms)
+                for (const SplitSeg &sg : split_segs) {
+                    fprintf(stderr, "[asgart] ranges: segment at probe %u (tier %u, %u positions, %u hits): runs", sg.g_seg0, sg.tier, sg.span, sg.hits);
+                    for (uint32_t j = 0; j < sg.n_ranges; ++j) fprintf(stderr, " %.1f", (double)h_meta[(size_t)(sg.run_base + j) * 16 + 5] * 1e-5);
+                    fprintf(stderr, " ms\n");
+                }
+            }
+            if (opt.debug)
+                fprintf(stderr, "[asgart] ranges: %llu of %u cut segment(s) joined up%s\n", (unsigned long long)(n_splits - n_split_refused), n_splits,
+                        n_split_refused ? "; the others: the rest behind the last cut that held as one more run, or the whole segment again" : "");
+            for (const Tail &t : tails) h_fix[t.run] = 0xFFFFFFFEu;  // (until the run has come back)
+            HIP_TRY(hipMemcpyAsync(d_split + kOffFix, h_fix, kOffAgain - kOffFix, hipMemcpyHostToDevice, s));
+            uint64_t n_slots = std::min<uint64_t>(h_ctr[CT_SD], rec_cap);
+            if (n_slots) fixup_records_kernel<<<grid_for(n_slots), 256, 0, s>>>(w.fam_sds.as<SdRec>(), n_slots, reinterpret_cast<const uint32_t *>(d_split + kOffFix));
+            HIP_TRY(hipGetLastError());
+            if (n_tail) {
+                if constexpr (sizeof(SlotT) == 4) {
+                    HIP_TRY(hipMemcpyAsync(d_split + kOffRuns + (size_t)n_runs * sizeof(RangeRun), h_runs + n_runs, (size_t)n_tail * sizeof(RangeRun),
+                                           hipMemcpyHostToDevice, s));
+                    h_scalar[8] = (unsigned long long)n_runs + n_tail;  // list length
+                    h_scalar[9] = n_runs;                               // work cursor: behind the runs that are done
+                    HIP_TRY(hipMemcpyAsync(d_split, h_scalar + 8, 8, hipMemcpyHostToDevice, s));
+                    HIP_TRY(hipMemcpyAsync(d_split + 24, h_scalar + 9, 8, hipMemcpyHostToDevice, s));
+                    HIP_TRY(hipMemsetAsync(d_split + kOffMeta + (size_t)n_runs * 64, 0, (size_t)n_tail * 64, s));
+                    launch_runs(n_tail);
+                    HIP_TRY(hipMemcpyAsync(h_split + kOffMeta + (size_t)n_runs * 64, d_split + kOffMeta + (size_t)n_runs * 64, (size_t)n_tail * 64,
+                                           hipMemcpyDeviceToHost, s));
+                    HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, kCtrBytes, hipMemcpyDeviceToHost, s));
+                    RC_TRY(wd_sync(idx, cx, s, "the rest of the cut segments"));
+                    h_scalar[8] = n_runs;  // (a second attempt of the call -- record buffer too small -- starts from the planned list)
+                    HIP_TRY(hipMemcpyAsync(d_split, h_scalar + 8, 8, hipMemcpyHostToDevice, s));
+                    size_t hb = 0;
+                    for (const Tail &t : tails) {
+                        // (a last run that gave up -- more arms than the long shape holds --: everything the segment's runs wrote
+                        // is dropped and the whole segment goes the cascade's way)
+                        const bool gave_up = h_meta[(size_t)t.run * 16 + 4] != 0u;
+                        h_fix[t.run] = gave_up ? 0xFFFFFFFFu : t.base;
+                        for (uint32_t j = 0; j <= t.f; ++j, ++hb) h_fix[t.run_base + j] = gave_up ? 0xFFFFFFFFu : held_base[hb];
+                        if (gave_up) {
+                            h_again[n_again++] = t.g_seg0;
+                            remember(t.g_seg0, 0u);
+                        }
+                    }
+                    HIP_TRY(hipMemcpyAsync(d_split + kOffFix, h_fix, kOffAgain - kOffFix, hipMemcpyHostToDevice, s));
+                    n_slots = std::min<uint64_t>(h_ctr[CT_SD], rec_cap);
+                    if (n_slots) fixup_records_kernel<<<grid_for(n_slots), 256, 0, s>>>(w.fam_sds.as<SdRec>(), n_slots, reinterpret_cast<const uint32_t *>(d_split + kOffFix));
                     HIP_TRY(hipGetLastError());
                 }
-                HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, kCtrBytes, hipMemcpyDeviceToHost, s));
-                RC_TRY(wd_sync(idx, cx, s, "the ranges of the cut segments"));
             }
-            PROF_DUMP("concurrent tiers");
-            if (opt.debug) {
-                fprintf(stderr, "[asgart] all tiers and early re-runs done %.1f ms after the launches\n", since_launch());
-                // how much of the chip each tier held: sum of its workgroups' lifetimes x the share of a compute unit one of
-                // them occupies (workgroups per compute unit by LDS / registers: tiers 1..7 = 11, 8, 1, 4, 2, 1, 1)
-                static const double per_cu[kTiers] = {11, 8, 1, 4, 2, 1, 1};
-                double tot = 0.0;
-                fprintf(stderr, "[asgart] compute-unit time held per tier (CU-ms; workgroups):");
-                for (int t = 0; t < kTiers; ++t) {
-                    const double cu_ms = (double)h_ctr[CT_BUSY1 + t] * 1e-5 / per_cu[t];
-                    tot += cu_ms;
-                    fprintf(stderr, " %d: %.0f (%llu)", t + 1, cu_ms, (unsigned long long)h_ctr[CT_WGS1 + t]);
-                }
-                fprintf(stderr, "  total %.0f = %.1f ms of the whole chip\n", tot, tot / 256.0);
-                fprintf(stderr, "[asgart] per tier: hit-probes / hits per hit-probe / CU-microseconds per hit-probe:");
-                for (int t = 0; t < kTiers; ++t) {
-                    const double hp = (double)h_tp[t];
-                    fprintf(stderr, " %d: %.0fK / %.1f / %.2f", t + 1, hp / 1e3, hp > 0 ? (double)h_th[t] / hp : 0.0,
-                            hp > 0 ? (double)h_ctr[CT_BUSY1 + t] * 1e-2 / per_cu[t] / hp : 0.0);
-                }
-                fprintf(stderr, "\n");
-            }
-            {   // the tier that ran longest (its early re-run included): the serial floor of this call's extension
-                float longest = 0.f;
-                for (int e : {5, 6, 8, 9, 10, 12}) {
-                    float t = 0.f;
-                    if (hipEventElapsedTime(&t, cx.ev[7], cx.ev[e]) == hipSuccess) longest = std::max(longest, t);
-                    else (void)hipGetLastError();
-                }
-                ms_longest_tier = longest;
-            }
-            n_overflow = 0;
-            for (int t = 1; t < kTiers; ++t) n_overflow += h_ctr[CT_OVF1 + t - 1];
-            if (opt.debug) {
-                fprintf(stderr, "[asgart] overflow out of tiers 1..%d:", kTiers - 1);
-                for (int t = 1; t < kTiers; ++t) fprintf(stderr, " %llu", (unsigned long long)h_ctr[CT_OVF1 + t - 1]);
-                fprintf(stderr, "\n");
-            }
-            n_heavy = 0;
-            for (int t = 3; t <= kTiers; ++t) n_heavy += n_t[t - 1];
-            // ---- cascade: what tier t gave up on is re-run from its start by the next tier that
-            // is in use and holds more arms (its own overflow is appended to that tier's list) ------
-            const auto t_casc0 = std::chrono::steady_clock::now();
-            for (int src = 1; src < kTiers; ++src) {
-                // (the first early_n entries of the list have been re-run already; a lower tier's cascade into
-                // this tier may have appended more)
-                const uint64_t skip = early_n[src];
-                const uint64_t n_ovf = h_ctr[CT_OVF1 + src - 1] - skip;
-                if (!n_ovf) continue;
-                int dst = src + 1;
-                while (dst < kTiers && (!tier_enabled(dst) || tier_cap[dst] <= tier_cap[src])) ++dst;
-                *h_scalar = n_ovf;  // (the previous cascade launch has been waited for)
+            if (n_again) {
+                HIP_TRY(hipMemcpyAsync(d_split + kOffAgain, h_again, (size_t)n_again * 4, hipMemcpyHostToDevice, s));
+                *h_scalar = n_again;
                 HIP_TRY(hipMemcpyAsync(d_ctr + CT_NF, h_scalar, 8, hipMemcpyHostToDevice, s));
                 HIP_TRY(hipMemsetAsync(d_ctr + CT_CURF, 0, 8, s));
-                ep.seg_list = ovf[src - 1] + skip;
+                ep.seg_list = reinterpret_cast<const uint32_t *>(d_split + kOffAgain);
                 ep.n_seg_ptr = d_ctr + CT_NF;
                 ep.cursor = d_ctr + CT_CURF;
-                ep.ovf_list = dst < kTiers ? ovf[dst - 1] : nullptr;
-                ep.ovf_count = d_ctr + CT_OVF1 + dst - 1;  // appended behind what is already there
+                ep.ovf_list = ovf[3 - 1];
+                ep.ovf_count = d_ctr + CT_OVF1 + 3 - 1;  // (what the whole segment overflows goes the way of tier 3's own)
                 ep.escalate_cost = 0xFFFFFFFFu;
-                ep.cap_limit = 0xFFFFFFFFu;
-                launch_kernel(dst, n_ovf, s);
+                launch_kernel(3, n_again, s);
                 HIP_TRY(hipGetLastError());
-                HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, kCtrBytes, hipMemcpyDeviceToHost, s));
-                RC_TRY(wd_sync(idx, cx, s, "a re-run of overflowed segments"));
-                PROF_DUMP("cascade");
             }
-            ms_tier2 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() -
-                                                                 t_casc0).count();
-            if (h_ctr[CT_OVF1 + kTiers - 1]) {
-                // (cannot happen: tier 7 holds the bound on the live arms of any segment -- unless a test shrank it)
-                set_error("internal: %llu segment(s) overflowed the last extension tier (%llu arm slots)",
-                          (unsigned long long)h_ctr[CT_OVF1 + kTiers - 1], (unsigned long long)heavy_cap64);
-                return ASGART_E_CAP;
-            }
-            ms_longest_segment = 0.0;
-            for (int t = 0; t < kTiers; ++t) ms_longest_segment = std::max(ms_longest_segment, (double)h_ctr[CT_SEGMAX1 + t] * 1e-5);
-            if (opt.debug) {
-                fprintf(stderr, "[asgart] longest single segment per tier (ms):");
-                for (int t = 0; t < kTiers; ++t) fprintf(stderr, " %d: %.2f", t + 1, (double)h_ctr[CT_SEGMAX1 + t] * 1e-5);
-                fprintf(stderr, "\n");
-            }
-            if (h_ctr[CT_RANOUT]) break;
-            if (h_ctr[CT_SD] <= rec_cap) break;
-            if (attempt >= 3) {
-                set_error("internal: record buffer keeps overflowing");
-                return ASGART_E_CAP;
-            }
-            rec_cap = h_ctr[CT_SD] * 2;
+            HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, kCtrBytes, hipMemcpyDeviceToHost, s));
+            RC_TRY(wd_sync(idx, cx, s, "the ranges of the cut segments"));
         }
-        if (h_ctr[CT_RANOUT]) {  // a segment runs past the look-ahead halo: widen it
-            look_ahead *= 8;
-            continue;
+        return 0;
+    }
+
+    // ---- statistics of the tiers; the cascade: what tier t gave up on is re-run by the next tier that holds more ------------------
+    int32_t finish_tiers() {
+        PROF_DUMP("concurrent tiers");
+        if (opt.debug) {
+            fprintf(stderr, "[asgart] all tiers and early re-runs done %.1f ms after the launches\n", since_launch());
+            // how much of the chip each tier held: sum of its workgroups' lifetimes x the share of a compute unit one of
+            // them occupies (workgroups per compute unit by LDS / registers: tiers 1..7 = 11, 8, 1, 4, 2, 1, 1)
+            static const double per_cu[kTiers] = {11, 8, 1, 4, 2, 1, 1};
+            double tot = 0.0;
+            fprintf(stderr, "[asgart] compute-unit time held per tier (CU-ms; workgroups):");
+            for (int t = 0; t < kTiers; ++t) {
+                const double cu_ms = (double)h_ctr[CT_BUSY1 + t] * 1e-5 / per_cu[t];
+                tot += cu_ms;
+                fprintf(stderr, " %d: %.0f (%llu)", t + 1, cu_ms, (unsigned long long)h_ctr[CT_WGS1 + t]);
+            }
+            fprintf(stderr, "  total %.0f = %.1f ms of the whole chip\n", tot, tot / 256.0);
+            fprintf(stderr, "[asgart] per tier: hit-probes / hits per hit-probe / CU-microseconds per hit-probe:");
+            for (int t = 0; t < kTiers; ++t) {
+                const double hp = (double)h_tp[t];
+                fprintf(stderr, " %d: %.0fK / %.1f / %.2f", t + 1, hp / 1e3, hp > 0 ? (double)h_th[t] / hp : 0.0,
+                        hp > 0 ? (double)h_ctr[CT_BUSY1 + t] * 1e-2 / per_cu[t] / hp : 0.0);
+            }
+            fprintf(stderr, "\n");
         }
+        {   // the tier that ran longest (its early re-run included): the serial floor of this call's extension
+            float longest = 0.f;
+            for (int e : {5, 6, 8, 9, 10, 12}) {
+                float t = 0.f;
+                if (hipEventElapsedTime(&t, cx.ev[7], cx.ev[e]) == hipSuccess) longest = std::max(longest, t);
+                else (void)hipGetLastError();
+            }
+            ms_longest_tier = longest;
+        }
+        n_overflow = 0;
+        for (int t = 1; t < kTiers; ++t) n_overflow += h_ctr[CT_OVF1 + t - 1];
+        if (opt.debug) {
+            fprintf(stderr, "[asgart] overflow out of tiers 1..%d:", kTiers - 1);
+            for (int t = 1; t < kTiers; ++t) fprintf(stderr, " %llu", (unsigned long long)h_ctr[CT_OVF1 + t - 1]);
+            fprintf(stderr, "\n");
+        }
+        n_heavy = 0;
+        for (int t = 3; t <= kTiers; ++t) n_heavy += n_t[t - 1];
+        // ---- cascade: what tier t gave up on is re-run from its start by the next tier that
+        // is in use and holds more arms (its own overflow is appended to that tier's list) ------
+        const auto t_casc0 = std::chrono::steady_clock::now();
+        for (int src = 1; src < kTiers; ++src) {
+            // (the first early_n entries of the list have been re-run already; a lower tier's cascade into
+            // this tier may have appended more)
+            const uint64_t skip = early_n[src];
+            const uint64_t n_ovf = h_ctr[CT_OVF1 + src - 1] - skip;
+            if (!n_ovf) continue;
+            int dst = src + 1;
+            while (dst < kTiers && (!tier_enabled(dst) || tier_cap[dst] <= tier_cap[src])) ++dst;
+            *h_scalar = n_ovf;  // (the previous cascade launch has been waited for)
+            HIP_TRY(hipMemcpyAsync(d_ctr + CT_NF, h_scalar, 8, hipMemcpyHostToDevice, s));
+            HIP_TRY(hipMemsetAsync(d_ctr + CT_CURF, 0, 8, s));
+            ep.seg_list = ovf[src - 1] + skip;
+            ep.n_seg_ptr = d_ctr + CT_NF;
+            ep.cursor = d_ctr + CT_CURF;
+            ep.ovf_list = dst < kTiers ? ovf[dst - 1] : nullptr;
+            ep.ovf_count = d_ctr + CT_OVF1 + dst - 1;  // appended behind what is already there
+            ep.escalate_cost = 0xFFFFFFFFu;
+            ep.cap_limit = 0xFFFFFFFFu;
+            launch_kernel(dst, n_ovf, s);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, kCtrBytes, hipMemcpyDeviceToHost, s));
+            RC_TRY(wd_sync(idx, cx, s, "a re-run of overflowed segments"));
+            PROF_DUMP("cascade");
+        }
+        ms_tier2 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() -
+                                                             t_casc0).count();
+        if (h_ctr[CT_OVF1 + kTiers - 1]) {
+            // (cannot happen: tier 7 holds the bound on the live arms of any segment -- unless a test shrank it)
+            set_error("internal: %llu segment(s) overflowed the last extension tier (%llu arm slots)",
+                      (unsigned long long)h_ctr[CT_OVF1 + kTiers - 1], (unsigned long long)heavy_cap64);
+            return ASGART_E_CAP;
+        }
+        ms_longest_segment = 0.0;
+        for (int t = 0; t < kTiers; ++t) ms_longest_segment = std::max(ms_longest_segment, (double)h_ctr[CT_SEGMAX1 + t] * 1e-5);
+        if (opt.debug) {
+            fprintf(stderr, "[asgart] longest single segment per tier (ms):");
+            for (int t = 0; t < kTiers; ++t) fprintf(stderr, " %d: %.2f", t + 1, (double)h_ctr[CT_SEGMAX1 + t] * 1e-5);
+            fprintf(stderr, "\n");
+        }
+        return 0;
+    }
+
+    // ---- records -> reference order -> families per pass ----------------------------------------------------------------------
+    int32_t records() {
         HIP_TRY(hipEventRecord(cx.ev[4], s));
         const uint64_t n_rec = h_ctr[CT_SD];
         if (n_rec) {
@@ -1312,54 +1410,114 @@ static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *ch
             fprintf(stderr, "[asgart] records: %llu slots; ordering + copy to the host %.1f ms, families assembled in %.1f ms\n",
                     (unsigned long long)n_rec, std::chrono::duration<double, std::milli>(t_post1 - t_post0).count(),
                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_post1).count());
-    } else {
-        HIP_TRY(hipEventRecord(cx.ev[4], s));
-        RC_TRY(wd_sync(idx, cx, s, "the hit rows"));
+        return 0;
     }
-    break;
-    }  // shard-window retry loop
 
-    // ---- stats ------------------------------------------------------------------
-    asgart_stats &stt = cx.stats;
-    float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, cx.ev[0], cx.ev[1]));
-    stt.ms_search = ms;
-    HIP_TRY(hipEventElapsedTime(&ms, cx.ev[1], cx.ev[2]));
-    stt.ms_scan = ms;
-    HIP_TRY(hipEventElapsedTime(&ms, cx.ev[2], cx.ev[3]));
-    stt.ms_fill = ms;
-    HIP_TRY(hipEventElapsedTime(&ms, cx.ev[3], cx.ev[4]));
-    stt.ms_extend = ms;
-    stt.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() -
-                                                            t_host0).count();
-    stt.probes_n_skipped = h_ctr[CT_N_SKIPPED];
-    stt.probes_searched = h_ctr[CT_SEARCHED];
-    stt.probes_card_skipped = h_ctr[CT_CARD_SKIPPED];
-    stt.probes_with_hits = h_ctr[CT_WITH_HITS];
-    stt.raw_hits = 0;  // (asgart_get_stats sums them up when asked: raw_hits_kernel)
-    stt.filtered_hits = total_hits;
-    stt.segments = n_seg;
-    stt.families = stt.proto_sds = 0;
-    for (int32_t p = 0; fam_out && p < n_passes; ++p) {
-        stt.families += fams[p]->fam_offsets.size() - 1;
-        stt.proto_sds += fams[p]->sds.size();
+    int32_t fill_stats() {
+        // ---- stats ------------------------------------------------------------------
+        asgart_stats &stt = cx.stats;
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, cx.ev[0], cx.ev[1]));
+        stt.ms_search = ms;
+        HIP_TRY(hipEventElapsedTime(&ms, cx.ev[1], cx.ev[2]));
+        stt.ms_scan = ms;
+        HIP_TRY(hipEventElapsedTime(&ms, cx.ev[2], cx.ev[3]));
+        stt.ms_fill = ms;
+        HIP_TRY(hipEventElapsedTime(&ms, cx.ev[3], cx.ev[4]));
+        stt.ms_extend = ms;
+        stt.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() -
+                                                                t_host0).count();
+        stt.probes_n_skipped = h_ctr[CT_N_SKIPPED];
+        stt.probes_searched = h_ctr[CT_SEARCHED];
+        stt.probes_card_skipped = h_ctr[CT_CARD_SKIPPED];
+        stt.probes_with_hits = h_ctr[CT_WITH_HITS];
+        stt.raw_hits = 0;  // (asgart_get_stats sums them up when asked: raw_hits_kernel)
+        stt.filtered_hits = total_hits;
+        stt.segments = n_seg;
+        stt.families = stt.proto_sds = 0;
+        for (int32_t p = 0; fam_out && p < n_passes; ++p) {
+            stt.families += fams[p]->fam_offsets.size() - 1;
+            stt.proto_sds += fams[p]->sds.size();
+        }
+        stt.passes = (uint64_t)n_passes;
+        stt.search_launches = 1;
+        stt.overflow_segments = n_overflow;
+        stt.heavy_segments = n_heavy;
+
+        stt.ms_extend_tier2 = ms_tier2;
+        stt.ms_longest_tier = ms_longest_tier;
+        stt.ms_longest_segment = ms_longest_segment;
+        stt.split_segments = n_split_segments;
+        stt.split_refused = n_split_refused;
+        HIP_TRY(hipEventElapsedTime(&ms, cx.ev[0], cx.ev[11]));
+        stt.ms_probe_count = ms;
+        cx.has_last = true;
+        cx.raw_done = false;
+        return 0;
+        return 0;
     }
-    stt.passes = (uint64_t)n_passes;
-    stt.search_launches = 1;
-    stt.overflow_segments = n_overflow;
-    stt.heavy_segments = n_heavy;
 
-    stt.ms_extend_tier2 = ms_tier2;
-    stt.ms_longest_tier = ms_longest_tier;
-    stt.ms_longest_segment = ms_longest_segment;
-    stt.split_segments = n_split_segments;
-    stt.split_refused = n_split_refused;
-    HIP_TRY(hipEventElapsedTime(&ms, cx.ev[0], cx.ev[11]));
-    stt.ms_probe_count = ms;
-    cx.has_last = true;
-    cx.raw_done = false;
-    return 0;
+    int32_t run() {
+        RC_TRY(setup());
+        if (nothing_to_do) return 0;
+        for (int win_try = 0;; ++win_try) {  // (a sharded call widens its halos until every decision is safe)
+            if (win_try > 40) {
+                set_error("internal: shard window did not converge");
+                return ASGART_E_CAP;
+            }
+            set_window();
+            bool ambiguous = false;
+            RC_TRY(front(&ambiguous));
+            if (ambiguous) {
+                look_back *= 8;
+                continue;
+            }
+            if (want_csr) RC_TRY(csr_out());
+            if (fam_out && n_seg) {
+                RC_TRY(place());
+                for (int attempt = 0;; ++attempt) {  // (again with a larger record buffer when it overflowed)
+                    RC_TRY(run_tiers(attempt));
+                    RC_TRY(join_ranges());
+                    RC_TRY(finish_tiers());
+                    if (h_ctr[CT_RANOUT]) break;
+                    if (h_ctr[CT_SD] <= rec_cap) break;
+                    if (attempt >= 3) {
+                        set_error("internal: record buffer keeps overflowing");
+                        return ASGART_E_CAP;
+                    }
+                    rec_cap = h_ctr[CT_SD] * 2;
+                }
+                if (h_ctr[CT_RANOUT]) {  // a segment runs past the look-ahead halo: widen it
+                    look_ahead *= 8;
+                    continue;
+                }
+                RC_TRY(records());
+            } else {
+                HIP_TRY(hipEventRecord(cx.ev[4], s));
+                RC_TRY(wd_sync(idx, cx, s, "the hit rows"));
+            }
+            break;
+        }
+        return fill_stats();
+    }
+};
+
+template <class SlotT>
+static int32_t run_search_t(asgart_index *idx, SearchCtx &cx, const uint64_t *chunks, int64_t n_chunks_pass,
+                            const asgart_settings *sts, int32_t n_passes, int32_t shard, int32_t n_shards,
+                            bool want_csr, asgart_families *const *fams,
+                            std::vector<uint8_t> *status_out, std::vector<uint64_t> *rowoff_out,
+                            std::vector<uint64_t> *hits_out) {
+    // (on the heap: the call's state holds its kernels' parameter blocks and a few KB of tables)
+    std::unique_ptr<SearchCall<SlotT>> call(new (std::nothrow) SearchCall<SlotT>(idx, cx, chunks, n_chunks_pass, sts, n_passes, shard,
+                                                                                n_shards, want_csr, fams, status_out, rowoff_out, hits_out));
+    if (!call) {
+        set_error("out of host memory");
+        return ASGART_E_OOM;
+    }
+    return call->run();
 }
+
 
 // n_passes > 1: ONE job over the probes of all passes (sts differ in reverse / complement only; checked by the caller);
 // fams: n_passes result objects, or null (the CSR surface of a single pass).
