@@ -569,20 +569,20 @@ struct SearchCall {
 
     // ---- asgart_probe_hits: the per-probe hit rows to the host ----------------------------------------------------------------
     int32_t csr_out() {
-            std::vector<uint32_t> h_filt(P);
-            std::vector<SlotT> h_hits((size_t)total_hits);
-            RC_TRY(wd_sync(idx, cx, s, "the hit rows"));  // (the copies below go to pageable memory: they block inside the copy)
-            HIP_TRY(hipMemcpyAsync(h_filt.data(), p_filt, (size_t)P * 4, hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipMemcpyAsync(rowoff_out->data(), row_off, ((size_t)P + 1) * 8,
+        std::vector<uint32_t> h_filt(P);
+        std::vector<SlotT> h_hits((size_t)total_hits);
+        RC_TRY(wd_sync(idx, cx, s, "the hit rows"));  // (the copies below go to pageable memory: they block inside the copy)
+        HIP_TRY(hipMemcpyAsync(h_filt.data(), p_filt, (size_t)P * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(rowoff_out->data(), row_off, ((size_t)P + 1) * 8,
+                               hipMemcpyDeviceToHost, s));
+        if (total_hits)
+            HIP_TRY(hipMemcpyAsync(h_hits.data(), hits, (size_t)total_hits * sizeof(SlotT),
                                    hipMemcpyDeviceToHost, s));
-            if (total_hits)
-                HIP_TRY(hipMemcpyAsync(h_hits.data(), hits, (size_t)total_hits * sizeof(SlotT),
-                                       hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
-            for (uint32_t g = 0; g < P; ++g)
-                (*status_out)[g] = h_filt[g] == kSkipN ? 1 : (h_filt[g] == kSkipCard ? 2 : 0);
-            hits_out->resize((size_t)total_hits);
-            for (uint64_t j = 0; j < total_hits; ++j) (*hits_out)[j] = h_hits[j];
+        HIP_TRY(hipStreamSynchronize(s));
+        for (uint32_t g = 0; g < P; ++g)
+            (*status_out)[g] = h_filt[g] == kSkipN ? 1 : (h_filt[g] == kSkipCard ? 2 : 0);
+        hits_out->resize((size_t)total_hits);
+        for (uint64_t j = 0; j < total_hits; ++j) (*hits_out)[j] = h_hits[j];
         return 0;
     }
 
