@@ -564,6 +564,8 @@ static void free_filters(asgart_index *idx) {
         f = nullptr;
     }
     for (auto &f : idx->filter_off) f = false;
+    for (auto &f : idx->pbits_learn) f = false;
+    for (auto &u : idx->pbits_uses) u = 0;
     idx->filter_bits = 0;
 }
 
@@ -835,6 +837,42 @@ int32_t index_prepare(asgart_index *idx, uint64_t k) {
     if (idx->opt.cache_calls == 0) BlockCache::trim();
     idx->ms_prepare =
         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return 0;
+}
+
+// Option lazy_aux: no filter is built for orientation `mode`; a blank position bitmap (all ones) is set up instead, which
+// the orientation's searches fill in (RunParams::learn).  Without memory for it the orientation is searched without.
+int32_t index_prepare_learned_bits(asgart_index *idx, uint64_t k, int mode) {
+    RC_TRY(index_prepare(idx, k));
+    if (idx->opt.kfilter_bits == 0 || idx->opt.posbits == 0 || idx->trimmed || mode < 0 || mode > 3 || k > (uint64_t)kMaxKey) return 0;
+    REFUSE_POISONED(idx);
+    idx->acquire_all();
+    struct Unlock {
+        asgart_index *i;
+        ~Unlock() { i->release_all(); }
+    } unlock{idx};
+    if (idx->k != k || idx->d_pbits[mode] || idx->filter_off[mode]) return 0;
+    HIP_TRY(hipSetDevice(idx->device));
+    const uint64_t n_words = ((uint64_t)idx->n + 63u) / 64u;
+    uint64_t *pb = nullptr;
+    if (dev_malloc((void **)&pb, (size_t)n_words * 8 + 512) != hipSuccess) {
+        (void)hipGetLastError();
+        idx->filter_off[mode] = true;
+        return 0;
+    }
+    hipStream_t s = idx->ctx[0].stream;
+    const int32_t rc = [&]() -> int32_t {
+        HIP_TRY(hipMemsetAsync(pb, 0xFF, (size_t)n_words * 8 + 512, s));
+        HIP_TRY(stream_sync(s));
+        return 0;
+    }();
+    if (rc != 0) {
+        dev_free(pb);
+        return rc;
+    }
+    idx->d_pbits[mode] = pb;
+    idx->pbits_learn[mode] = true;
+    idx->pbits_uses[mode] = 0;
     return 0;
 }
 

@@ -90,6 +90,11 @@ struct RunParams {
     const uint64_t *pbits[4];  // ... its answers laid out by TEXT POSITION (bit p: the probe that covers text[p .. p + k) in
                                // this orientation passes the filter); null: the kernels test the hashed filter
     int flt_bits;
+    uint32_t blank;            // bit p: ... and this call finds them blank (the accounting pass prices its probes unfiltered)
+    uint32_t learn;            // bit p: pass p's position bits are LEARNED by the search (option lazy_aux: no filter is ever built for
+                               // the orientation; its bitmap starts all ones and probe_count_kernel clears the bit of every probe it
+                               // finds without an occurrence that could be kept -- the same index-derived fact the refined build
+                               // computes, one call late and only where calls probe)
     __host__ __device__ inline uint32_t pass_of(int c) const {
         if (n_passes <= 1u) return 0u;
         const uint32_t uc = (uint32_t)c;
@@ -307,11 +312,13 @@ struct Options {
                                     // extension (a megabase higher-order array, a chromosome against its homologue: the other pass's
                                     // front then hides beside it -- 393 vs 466 ms, 2 071 vs 2 178 ms)
     int64_t fuse_pole_pct = 88;
-    int64_t lazy_aux = 1;           // 1: the presence filter of an orientation is built when that orientation is searched the SECOND time, the
-                                    // position-sorted lists when a search call has had a predecessor: they cost 0.18 s per orientation / 0.2 s
-                                    // at GRCh38 size and save 0.03 / 0.006 s per pass -- a host that runs every orientation once per index
-                                    // (the reference's own use, src/bin/asgart.rs:677-693) never pays for them; 0: filters on first use,
-                                    // lists with the keys
+    int64_t lazy_aux = 1;           // 1: no presence filter is BUILT: the position bits of an orientation start all ones and its first search
+                                    // clears, as a by-product of its lookups, the bit of every probe without an occurrence that could be
+                                    // kept (from its second search on the orientation is filtered); the position-sorted lists are built
+                                    // when a search call has had a predecessor (0.2 s at GRCh38 size for 0.006 s per pass) -- a host that
+                                    // runs every orientation once per index (the reference's own use, src/bin/asgart.rs:677-693) pays for
+                                    // neither; 0: filter + refined position bits built on first use (0.3 s per orientation), lists with
+                                    // the keys
     int64_t dense3 = 16;            // long segments go to tier 3 (K8) only with at least this many hits per processed probe on average
                                     // (0: all of them); the sparse long ones run on tier 6's kernel (K6, solo probes)
     int64_t dense6 = 32;            // segments of ANY length whose arm bound sends them to tier 6 go to tier 3 instead with at least this
@@ -420,6 +427,8 @@ struct asgart_index {
     uint64_t *d_filter[4] = {nullptr, nullptr, nullptr, nullptr};  // per orientation: reverse * 2 + complement
     uint64_t *d_pbits[4] = {nullptr, nullptr, nullptr, nullptr};   // ... its answers by text position (n bits + padding)
     bool filter_off[4] = {false, false, false, false};             // no memory for it: this orientation is searched without
+    bool pbits_learn[4] = {false, false, false, false};            // its position bits are learned by the searches (RunParams::learn)
+    uint64_t pbits_uses[4] = {0, 0, 0, 0};                         // ... search calls that have used them so far
     int filter_bits = 0;                                           // log2 of their size in bits
     uint32_t tail8[asgart::kMaxK];
     int n_tail8 = 0;
@@ -549,6 +558,7 @@ int32_t reserve_probe_workspace(asgart_index *idx, SearchCtx &cx, uint64_t W);
 // the suffix sorter has just released, if the block cache holds one of the right size (false: nothing done)
 bool carve_probe_workspace(asgart_index *idx, const uint64_t *Wc);
 int32_t index_prepare_filter(asgart_index *idx, uint64_t k, int mode);  // mode = reverse * 2 + complement
+int32_t index_prepare_learned_bits(asgart_index *idx, uint64_t k, int mode);  // a blank bitmap the searches fill in (lazy_aux)
 int32_t index_prepare_sap(asgart_index *idx, uint64_t k);
 int32_t run_search_passes(asgart_index *idx, const uint64_t *chunks, int64_t n_chunks,
                           const asgart_settings *sts, int32_t n_passes, int32_t shard, int32_t n_shards, bool want_csr,

@@ -489,6 +489,7 @@ struct SearchCall {
         rp.n_passes = (uint32_t)n_passes;
         rp.pass_chunks = (uint32_t)n_chunks_pass;
         rp.modes = 0;
+        rp.learn = rp.blank = 0;
         rp.flt_bits = idx->filter_bits;
         for (int p = 0; p < 4; ++p) {
             rp.flt[p] = rp.pbits[p] = nullptr;
@@ -497,6 +498,10 @@ struct SearchCall {
             rp.modes |= (uint32_t)mode << (8 * p);
             rp.flt[p] = idx->d_filter[mode];  // null: filter off
             rp.pbits[p] = opt.posbits ? idx->d_pbits[mode] : nullptr;
+            if (rp.pbits[p] && idx->pbits_learn[mode]) {
+                rp.learn |= 1u << p;
+                if (idx->pbits_uses[mode] == 0) rp.blank |= 1u << p;  // (this call finds them all ones)
+            }
         }
         cx.last_rp = rp;
         cx.has_last = false;
@@ -1549,20 +1554,26 @@ int32_t run_search_passes(asgart_index *idx, const uint64_t *chunks, int64_t n_c
         (void)probe;
         // The presence filter and the position-sorted lists are optimisations that cost more than they save in ONE pass
         // (option lazy_aux): an orientation gets its filter at its second search, the index its lists at its second call.
+        // With lazy_aux no filter is built at all: an orientation's position bits start blank and its searches fill them in.
         bool want_sap, ready;
         int need_filter = -1;  // an orientation of this call whose filter is due and missing
+        int need_blank = -1;   // ... or whose blank position bits are (lazy_aux)
         {
             std::lock_guard<std::mutex> lk(idx->mu);
             ready = idx->k == st->probe_size;
             const bool lazy = idx->opt.lazy_aux != 0;
-            for (int32_t p = 0; p < n_passes && need_filter < 0; ++p) {
+            const bool filterable = !(idx->opt.kfilter_bits == 0 || idx->trimmed || st->probe_size > (uint64_t)kMaxKey);
+            for (int32_t p = 0; p < n_passes && need_filter < 0 && need_blank < 0; ++p) {
                 const int mode = (sts[p].reverse ? 2 : 0) | (sts[p].complement ? 1 : 0);
-                const bool want_filter = !(idx->opt.kfilter_bits == 0 || idx->trimmed || st->probe_size > (uint64_t)kMaxKey) &&
-                                         !(lazy && ready && idx->mode_calls[mode] == 0) && !(lazy && !ready);
-                if (want_filter && !idx->d_filter[mode] && !idx->filter_off[mode]) need_filter = mode;
+                if (!filterable || !ready || idx->filter_off[mode]) continue;
+                if (lazy && idx->opt.posbits != 0) {
+                    if (!idx->d_pbits[mode]) need_blank = mode;
+                } else if (!(lazy && idx->mode_calls[mode] == 0) && !idx->d_filter[mode]) {
+                    need_filter = mode;  // (lazy without position bits: the hashed filter, on second use)
+                }
             }
             want_sap = !(lazy && (!ready || idx->calls_total == 0)) && !idx->sap_tried;
-            if (ready && need_filter < 0 && !(want_sap && !idx->d_sap)) {
+            if (ready && need_filter < 0 && need_blank < 0 && !(want_sap && !idx->d_sap)) {
                 for (int32_t p = 0; p < n_passes; ++p) ++idx->mode_calls[(sts[p].reverse ? 2 : 0) | (sts[p].complement ? 1 : 0)];
                 break;
             }
@@ -1570,6 +1581,7 @@ int32_t run_search_passes(asgart_index *idx, const uint64_t *chunks, int64_t n_c
         idx->release_one(which);
         if (!ready) RC_TRY(index_prepare(idx, st->probe_size));
         else if (want_sap && !idx->d_sap) RC_TRY(index_prepare_sap(idx, st->probe_size));
+        else if (need_blank >= 0) RC_TRY(index_prepare_learned_bits(idx, st->probe_size, need_blank));
         else RC_TRY(index_prepare_filter(idx, st->probe_size, need_filter));
     }
     SearchCtx &cx = idx->ctx[which];
@@ -1588,6 +1600,7 @@ int32_t run_search_passes(asgart_index *idx, const uint64_t *chunks, int64_t n_c
         std::lock_guard<std::mutex> lk(idx->mu);
         const uint64_t before = idx->calls_total;
         idx->calls_total += (uint64_t)n_passes;
+        for (int32_t p = 0; p < n_passes; ++p) ++idx->pbits_uses[(sts[p].reverse ? 2 : 0) | (sts[p].complement ? 1 : 0)];
         trim_now = idx->opt.cache_calls > 0 && before < (uint64_t)idx->opt.cache_calls && idx->calls_total >= (uint64_t)idx->opt.cache_calls;
     }
     if (trim_now) {  // (option cache_calls: what the index build released goes back to the device now -- behind the caller's back:
@@ -1986,7 +1999,10 @@ int32_t asgart_get_stats(asgart_index *idx, uint32_t flags, asgart_stats *out) {
             for (uint32_t p = 0; p < rp.n_passes && p < 4u; ++p) {  // (the filters as they are now)
                 rp.flt[p] = idx->d_filter[rp.mode_of_pass(p)];
                 rp.pbits[p] = idx->opt.posbits ? idx->d_pbits[rp.mode_of_pass(p)] : nullptr;
+                // (a pass whose position bits were blank when the call ran looked every probe up)
+                if ((rp.blank >> p) & 1u) rp.flt[p] = rp.pbits[p] = nullptr;
             }
+            rp.learn = 0;
             rp.flt_bits = idx->filter_bits;
             const unsigned g = rp.n_tiles(256u);
             if (idx->wide)

@@ -164,7 +164,9 @@ __global__ __launch_bounds__(kProbeThreads) void probe_count_kernel(IndexView<Sl
     const bool uniform = rp.ch.pbase[c0 + 1] > g_last && k <= kMaxKey;
     uint32_t n_rej = 0;
     // one probe's lookup: SA interval, filtered count of a small interval (large ones are marked for the wave kernels)
-    auto lookup = [&](uint32_t g_, uint64_t q_, uint64_t q2_, uint64_t i_, uint64_t s_, uint64_t L_, uint32_t md_) {
+    // lrn_: the pass's position bits when they are being learned (RunParams::learn), else null
+    auto lookup = [&](uint32_t g_, uint64_t q_, uint64_t q2_, uint64_t i_, uint64_t s_, uint64_t L_, uint32_t md_,
+                      const uint64_t *lrn_) {
         const bool reverse = (md_ & 2u) != 0u, complement = (md_ & 1u) != 0u;
         uint64_t lo, hi;
         ProbeRef pr;  // (read only by probes of more than 42 bases)
@@ -184,12 +186,25 @@ __global__ __launch_bounds__(kProbeThreads) void probe_count_kernel(IndexView<Sl
             // the occurrences; a single occurrence is that one, and the filter (x > i + s)
             // drops it -- no need to fetch the suffix-array entry.
             const bool only_self = all_occurrences && raw == 1 && md_ == 0u;
+            bool any = false;  // an occurrence that could be kept, whatever chunk the probe came in (a reversed needle's
+                               // `m.start != i` compares a text position with a chunk offset: left out)
             for (uint64_t r = lo; r < hi && !only_self; ++r) {
                 cb.rd(sizeof(SlotT));
-                cnt += keep_hit(ix.sa[r], i_, s_, L_, reverse) ? 1u : 0u;
+                const uint64_t x = ix.sa[r];
+                cnt += keep_hit(x, i_, s_, L_, reverse) ? 1u : 0u;
+                if (reverse) any |= x >= s_ + L_ - i_;
             }
+            if (!reverse) any = cnt != 0u;
             if (!COUNT) p_filt[g_] = cnt > rp.C ? kSkipCard : cnt;
             cb.wr(4);
+            if constexpr (!COUNT) {
+                // learned position bits: no occurrence of this probe's k-mer can ever be kept at this text position
+                if (lrn_ && all_occurrences && !any) {
+                    const uint64_t p = reverse ? s_ + L_ - i_ - (uint64_t)k : s_ + i_;
+                    atomicAnd(const_cast<unsigned long long *>(reinterpret_cast<const unsigned long long *>(lrn_)) + (p >> 6),
+                              ~(1ull << (p & 63u)));
+                }
+            }
         } else {
             // a large interval is only MARKED here; collect_pending_kernel turns the marks into the two work lists (a
             // workgroup-aggregated append from this kernel cost every workgroup a returning atomic on one of two adjacent
@@ -312,7 +327,7 @@ __global__ __launch_bounds__(kProbeThreads) void probe_count_kernel(IndexView<Sl
         __syncthreads();
         for (uint32_t j = lane; j < n_surv; j += kProbeThreads) {
             const uint32_t t = s_surv[j];
-            lookup(gb + t, key_of(t), 0ull, i0 + (uint64_t)t * (uint64_t)H, s, L, md);
+            lookup(gb + t, key_of(t), 0ull, i0 + (uint64_t)t * (uint64_t)H, s, L, md, ((rp.learn >> pass0) & 1u) ? pbits : nullptr);
         }
     } else {
         // the tile straddles a chunk boundary (or the probes are longer than one key word): every probe on its own
@@ -341,7 +356,7 @@ __global__ __launch_bounds__(kProbeThreads) void probe_count_kernel(IndexView<Sl
                     pass = filter_test(flt, rp.flt_bits, q);
                 }
             }
-            if (screen(g, first, pass, md)) lookup(g, q, q2, i, s, L, md);
+            if (screen(g, first, pass, md)) lookup(g, q, q2, i, s, L, md, ((rp.learn >> pass_c) & 1u) ? pbits : nullptr);
         }
     }
     if constexpr (COUNT) {
