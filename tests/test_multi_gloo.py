@@ -223,7 +223,7 @@ def test_bench_launches_its_own_ranks():
     import json
     import subprocess
 
-    env = dict(os.environ, ASGART_BENCH_ONE_DEVICE="1")
+    env = dict(os.environ, ASGART_BENCH_ONE_DEVICE="1", ASGART_FUSE_PASSES="2")   # (2: always one job, whatever a call measures)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "tiny", "--steps", "2",
@@ -233,6 +233,10 @@ def test_bench_launches_its_own_ranks():
     assert line["n_gpus"] == 2 and len(line["per_rank_ms"]) == 2
     assert line["config"]["ranks_launched_by"] == "self" and line["config"]["collective_backend"] == "gloo"
     assert line["index_build_s"]["broadcast_to_ranks"] > 0 and line["cold_s"] > 0 and line["model_ms"] > 0
+    # one device: the ranks take turns, so that per_rank_ms is each shard's cost alone on a GPU; every rank ran its slice of
+    # BOTH passes as one job (what rank r of an N-GPU run executes)
+    assert line["ranks_take_turns_on_one_device"] is True
+    assert "one fused job" in line["config"]["passes_issued"], line["config"]["passes_issued"]
     # the same workload on one rank: same work, same results size
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "tiny", "--steps", "2",
                           "--warmup", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
