@@ -1,6 +1,6 @@
 // extend_fast_dev.hpp -- "K6": the one-barrier arm-resident extension kernel.
 //
-// Same automaton as K4 / K4b / K4c (reference src/automaton.rs:57-204, representation of
+// Same automaton as the other extension kernels (reference src/automaton.rs:57-204, representation of
 // pipeline_dev.hpp: only live arms are kept, winners by creation number, families by records),
 // organised so that one processed hit-probe costs the workgroup ONE barrier, with loop-free
 // lookups and branch-free per-arm code, and a run of quiet probes costs nothing until the next

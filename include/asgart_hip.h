@@ -189,15 +189,15 @@ int32_t asgart_index_create_trim(const uint8_t *T, int64_t n, const int64_t *SA,
  * ASGART_<NAME> (upper case), which is read ONCE, inside asgart_index_create -- the search path
  * itself never reads the environment.  Values are range-checked; ASGART_E_ARG for an unknown
  * name or a value out of range.  Names: shard_lookback, shard_lookahead (halo sizes of a sharded
- * call, in probes), force_tier, arms_kernel, long3, long3_big, cap1, filter, tier_order,
- * grid1..grid7 (placement of segments on the extension kernels -- results never depend on
- * them), k7, k8, dense3, dense6, dense_min, sparse_to6 (which extension kernel a tier runs and which
- * segments the long-segment tier takes: placement again), barren (segments that provably emit nothing are not run: 0 none,
- * 1 by their number of hit-probes, 2 also by the positions of their hits), split, split_len, split_runs, split_hw, split_tier, split_dense, split_warm, split_min (long
- * segments run as ranges side by side, each checked against its predecessor at the cut; where a cut does not hold the
- * ranges in front of it stand and the rest of the segment runs as one more run -- results never depend on any of these), pass_gate, fuse_passes, fuse_pole_pct, cache_calls,
- * bucket, watchdog_s, lazy_aux, prewarm,
- * debug, test_cap_limit, test_levels, test_genbits, test_k8_delay (parity tests); the full table with ranges is
+ * call, in probes); force_tier, arms_kernel, long3, cap1, cap3_pct, cap45_pct, cap6_pct, cap6w_pct, dense3, dense6,
+ * tier_order, grid1..grid7, solo (placement of segments on the extension kernels); barren (segments that provably emit
+ * nothing are not run: 0 none, 1 by their number of hit-probes, 2 also by the positions of their hits); split, split_len,
+ * split_runs, split_warm, split_min (long segments run as ranges side by side, each checked against its predecessor at
+ * the cut; where a cut does not hold the ranges in front of it stand and the rest of the segment runs as one more
+ * run); fuse_passes, fuse_pole_pct (passes of one call as one job or pipelined); kfilter_bits, posbits, rank_lists,
+ * lazy_aux (the position filter and the position-sorted lists, and when they come into being); cache_calls, prewarm
+ * (memory); watchdog_s; debug; test_cap_limit, test_genbits, test_k8_delay, test_fail_alloc, test_stall_s,
+ * test_wide_batch (parity and failure tests).  RESULTS NEVER DEPEND ON ANY OF THEM.  The full table with ranges is
  * kOptions in asgart_amd/csrc/index.hip, every field is described in struct Options
  * (asgart_amd/csrc/index.hpp).  ptab_depth and force_wide are fixed at creation (environment
  * only).  Blocks until no call is in flight. */
@@ -233,15 +233,10 @@ int32_t asgart_search_duplications(asgart_index *idx, const uint64_t *chunks, in
                                    asgart_families **out);
 
 /* Same, restricted to shard `shard` of `n_shards` (multi-GPU: one process per GPU, index replicated, no
- * exchange between shards).  DEFAULT (option shard_lpt = 0): shard r owns the automaton segments that START in
- * the r-th of n_shards equal slices of the global probe sequence; it searches its slice plus a look-back and a
- * look-ahead halo (retrying with larger halos when a decision is ambiguous).  The union of the shards' families,
- * merged by asgart_families_keys -- or, in this default mode only, concatenated in shard order -- is exactly the
- * unsharded result.  A gatherer that always merges by key is right in both modes (asgart_amd/multi.py does).
- * Option shard_lpt = 1 (off by default): every shard computes the whole front (probe search, scans, hit rows,
- * placement: a tenth of a step) and then owns every n_shards-th segment of each extension tier's cost-sorted list,
- * in snake order; the shards then INTERLEAVE and MUST be merged by key.  Balanced, but not faster where one serial
- * segment is the floor of a pass. */
+ * exchange between shards): shard r owns the automaton segments that START in the r-th of n_shards equal slices of
+ * the probe sequence; it searches its slice plus a look-back and a look-ahead halo (retrying with larger halos when a
+ * decision is ambiguous).  The union of the shards' families, merged by asgart_families_keys -- or concatenated in shard
+ * order -- is exactly the unsharded result (asgart_amd/multi.py merges by key). */
 int32_t asgart_search_duplications_shard(asgart_index *idx, const uint64_t *chunks,
                                          int64_t n_chunks, const asgart_settings *settings,
                                          int32_t shard, int32_t n_shards,
@@ -271,13 +266,13 @@ int32_t asgart_search_duplications_ex(asgart_index *idx, const uint64_t *chunks,
  * invocation; the direct and the -RC run of BASELINE.json's "direct+RC" are two of them): settings[j] are
  * the RunSettings of pass j, out[j] receives its families (exactly what asgart_search_duplications returns
  * for settings[j]).  Passes that differ in orientation only (same probe_size, max_gap_size,
- * min_duplication_length, max_cardinality; up to four; unsharded) run as ONE job: the probe sequence is pass 0's
+ * min_duplication_length, max_cardinality; up to four) run as ONE job: the probe sequence is pass 0's
  * chunks followed by pass 1's ... (chunk order inside each pass as in src/bin/asgart.rs:201-253), searched, scanned
  * and placed in one sweep at full chip rate, and every extension tier is ONE launch over the merged, cost-sorted
  * segment list, so that every pass's longest serial segments start at once on compute units of their own
  * (asgart_stats.passes tells).  The first such call measures: when ONE segment is the whole extension (its longest
  * single segment above option fuse_pole_pct = 88 % of the extension) the calls after it pipeline the passes instead --
- * the other pass's front then hides beside that segment; option fuse_passes = 2 / 0 forces either.  Otherwise (sharded calls, different
+ * the other pass's front then hides beside that segment; option fuse_passes = 2 / 0 forces either.  Otherwise (different
  * settings) the library pipelines the passes as single calls: pass j+1 is issued the moment the chip-wide,
  * HBM-bound phases of pass j are over (probe search, scans, hit materialisation -- the moment the `progress`
  * array of a single call jumps), so its search runs beside pass j's extension automaton, whose tail is a few
@@ -288,7 +283,9 @@ int32_t asgart_search_duplications_ex(asgart_index *idx, const uint64_t *chunks,
 int32_t asgart_search_duplications_passes(asgart_index *idx, const uint64_t *chunks, int64_t n_chunks,
                                           const asgart_settings *settings, int32_t n_passes,
                                           asgart_families **out);
-/* ... restricted to shard `shard` of `n_shards` (every pass; see asgart_search_duplications_shard). */
+/* ... restricted to shard `shard` of `n_shards`: the shard's slice of EVERY pass (see asgart_search_duplications_shard),
+ * all of them as the same ONE job -- rank r of an n-GPU run executes the algorithm a single GPU does, on 1/n of the
+ * probes of each pass.  Every pass's families carry keys counted from the start of their own pass. */
 int32_t asgart_search_duplications_passes_shard(asgart_index *idx, const uint64_t *chunks, int64_t n_chunks,
                                                 const asgart_settings *settings, int32_t n_passes,
                                                 int32_t shard, int32_t n_shards, asgart_families **out);
@@ -298,9 +295,9 @@ void asgart_families_counts(const asgart_families *f, uint64_t *n_families, uint
 void asgart_families_copy(const asgart_families *f, uint64_t *fam_offsets, asgart_proto_sd *sds);
 /* keys: n_families entries, (first probe of the family's automaton segment << 32) | family ordinal inside it.
  * Ascending keys == the reference's order (chunk order, discovery order inside a chunk, src/bin/asgart.rs:241-253).
- * The shards of a sharded call own contiguous slices by default and interleaved segments with option shard_lpt = 1: a
- * gatherer that merges their families by key is right either way (asgart_search_duplications_multi does;
- * one-process-per-GPU hosts do it after the RCCL gather, asgart_amd/multi.py). */
+ * The shards of a sharded call own contiguous slices of every pass: a gatherer merges their families by key
+ * (asgart_search_duplications_multi does; one-process-per-GPU hosts do it after the RCCL gather, asgart_amd/multi.py)
+ * or concatenates them in shard order. */
 void asgart_families_keys(const asgart_families *f, uint64_t *keys);
 void asgart_families_free(asgart_families *f);
 

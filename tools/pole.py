@@ -13,8 +13,8 @@ import asgart_amd  # noqa: E402
 from asgart_amd import prep, synth  # noqa: E402
 
 # option defaults (asgart_amd/csrc/index.hpp: struct Options); grid<t> = 0 means "default grid"
-DEFAULTS = {"shard_lookback": 4096, "arms_kernel": 1, "prio3": 1, "kfilter_bits": 30, "long3": 4096, "long3_big": -1, "cap1": 256,
-            "test_cap_limit": -1, "test_levels": 4, "test_genbits": 22, "tier_order": 3654217}
+DEFAULTS = {"shard_lookback": 4096, "arms_kernel": 1, "kfilter_bits": 30, "long3": 16384, "cap1": 256,
+            "test_cap_limit": -1, "test_genbits": 22, "tier_order": 3654217}
 
 
 def opt_name(key):  # "ASGART_GRID3" or "grid3" -> "grid3"
