@@ -422,7 +422,8 @@ def main():
     search_ms = 0.0
     probe_count_ms = 0.0
     n_launch = 0
-    own_elapsed = 0.0
+    own_elapsed = 0.0   # this rank's search calls ...
+    own_gather = 0.0    # ... and its part of the gather of the result lists to rank 0
     phase_ms = {"search": 0.0, "scan": 0.0, "fill": 0.0, "extend": 0.0, "extend_tier2": 0.0, "longest_tier": 0.0,
                 "longest_segment": 0.0}
     for _ in range(args.steps):
@@ -437,7 +438,7 @@ def main():
             # the only exchange of the path: duplicon lists -> rank 0 over RCCL
             t_own = time.perf_counter()
             results = [gather(r_) for r_ in results]
-            own_elapsed += time.perf_counter() - t_own
+            own_gather += time.perf_counter() - t_own
         n_launch += len(per_call)
         for s in per_call:
             search_ms += s.ms_search
@@ -446,7 +447,8 @@ def main():
                 phase_ms[ph] += getattr(s, "ms_" + ph)
     sync()
     elapsed = time.perf_counter() - t0
-    per_rank_ms = [round(own_elapsed / args.steps * 1e3, 3)]
+    per_rank_ms = [round(own_elapsed / args.steps * 1e3, 3)]        # the search calls of a step: what the scaling model predicts
+    per_rank_gather_ms = [round(own_gather / args.steps * 1e3, 3)]   # (RCCL over xGMI on a multi-GPU node; gloo over loopback on one device)
     per_rank_phase = [{ph: round(v / args.steps, 3) for ph, v in phase_ms.items()}]
     if dist is not None:
         import torch
@@ -455,9 +457,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         box = [None] * world
-        dist.all_gather_object(box, (per_rank_ms[0], per_rank_phase[0]))
+        dist.all_gather_object(box, (per_rank_ms[0], per_rank_phase[0], per_rank_gather_ms[0]))
         per_rank_ms = [b[0] for b in box]
         per_rank_phase = [b[1] for b in box]
+        per_rank_gather_ms = [b[2] for b in box]
 
     passes = len(modes)
     value = total_bp * passes * args.steps / elapsed / 1e6
@@ -586,6 +589,9 @@ def main():
         "roofline": roofline,
         "phases_ms_per_step": per_rank_phase[0],
         "per_rank_ms": per_rank_ms,
+        "per_rank_gather_ms": per_rank_gather_ms if world > 1 else None,
+        "model_vs_slowest_rank": (round((model or {}).get(f"n{world}_ms") / max(per_rank_ms), 3)
+                                  if world > 1 and (model or {}).get(f"n{world}_ms") else None),
         "per_rank_phases_ms_per_step": per_rank_phase if world > 1 else None,
         "model_ms": (model or {}).get(f"n{world}_ms"),
         "scaling_model": model,

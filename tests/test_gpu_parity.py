@@ -1232,6 +1232,34 @@ def test_refined_position_bits_reject_more_and_change_nothing(hiplib, name, monk
                         assert stt["probes_filter_rejected"] > stt1["probes_filter_rejected"], (name, key)
 
 
+@pytest.mark.parametrize("name", ["dense_repeats", "satellites", "masked"])
+def test_learned_position_bits_hold_for_any_chunk_list(hiplib, name, monkeypatch):
+    """lazy_aux (the default): an orientation's position bits are LEARNED by its searches -- a probe found without an
+    occurrence that could be kept clears the bit of the text position it covers.  The fact is one about the text and
+    the position (src/automaton.rs:105-114 in text coordinates), so the bits must serve any later chunk list over the
+    same index: whole records first, then the same records cut differently (shifted starts: other probe phases; halves:
+    other needle offsets, other `L - i` of the reversed needle), each compared with the oracle run over the same list,
+    in every orientation, three rounds over the lists (bits learned under one list are used under the others)."""
+    monkeypatch.setenv("ASGART_LAZY_AUX", "1")
+    pr, cli = _battery_case(name)
+    oidx = oracle.Index.build(pr.data)
+    lists = [list(pr.chunks),
+             [(s0 + 3, l0 - 7) for s0, l0 in pr.chunks if l0 > 2000],
+             [c for s0, l0 in pr.chunks if l0 > 4000 for c in ((s0, l0 // 2 + 11), (s0 + l0 // 2 - 5, l0 - l0 // 2 + 5))]]
+    with asgart_amd.Index(pr.data, oidx.sa) as idx:
+        for rnd in range(3):
+            for li, chunks in enumerate(lists):
+                for reverse, complement in MODES:
+                    st = asgart_amd.RunSettings.from_cli(reverse=reverse, complement=complement, **cli)
+                    got = idx.search_duplications_raw(chunks, st)
+                    key = ("learned", name, li, reverse, complement)
+                    if key not in _ORACLE_CACHE:
+                        _ORACLE_CACHE[key] = oidx.run_raw(chunks, oracle.make_settings(reverse=reverse, complement=complement, **cli), threads=4)
+                    exp = _ORACLE_CACHE[key]
+                    assert np.array_equal(got[0], exp[0]) and np.array_equal(got[1], exp[1]), (name, rnd, li, reverse, complement)
+        assert idx.stats(1).probes_filter_rejected > 0
+
+
 def test_lazy_filter_and_lists_same_results(hiplib, monkeypatch):
     """Default behaviour of an index (option lazy_aux = 1; the suite otherwise runs with 0 so that every first call
     takes the filtered paths): the first search of an orientation runs without the presence filter and without the
