@@ -48,7 +48,7 @@ const OptDesc kOptions[] = {
     {"arms_kernel", &Options::arms_kernel, 0, 1},
     {"long3", &Options::long3, 0, 1ll << 31},
     {"cap1", &Options::cap1, 1, 256},
-    {"debug", &Options::debug, 0, 1},
+    {"debug", &Options::debug, 0, 2},
     {"test_cap_limit", &Options::test_cap_limit, -1, 1ll << 31},
     {"test_genbits", &Options::test_genbits, 2, 22},
     {"test_k8_delay", &Options::test_k8_delay, 0, 1 << 22},
@@ -69,6 +69,7 @@ const OptDesc kOptions[] = {
     {"split_len", &Options::split_len, 0, 1 << 20},
     {"split_runs", &Options::split_runs, 1, 3072},
     {"split_warm", &Options::split_warm, 0, 1 << 20},
+    {"split_warm_max", &Options::split_warm_max, 0, 1 << 22},
     {"split_min", &Options::split_min, 0, 1ll << 31},
     {"watchdog_s", &Options::watchdog_s, 0, 86400},
     {"test_stall_s", &Options::test_stall_s, 0, 60},

@@ -277,7 +277,7 @@ struct Options {
                                     // time the tiers hold, not by a serial chain): 4096 -> 16384, 250 -> 236 ms per step at GRCh38
                                     // size -- a long SPARSE segment in tier 6 owns a whole compute unit for one wave's work
     int64_t cap1 = 256;             // live-arm bound up to which a segment may use the one-wave tier
-    int64_t debug = 0;              // 1: per-call tier statistics on stderr
+    int64_t debug = 0;              // 1: per-call tier statistics on stderr; 2: also, per tier, the longest and the richest segment that runs whole
     int64_t test_cap_limit = -1;    // tests: shrink every tier's capacity (forces the cascade)
     int64_t test_genbits = 22;      // tests: width of the arm-resident kernels' table generation counter
     int64_t test_k8_delay = 0;      // tests: cycles K8's ranking wave waits in every step before it reads the free counts the arm
@@ -334,6 +334,8 @@ struct Options {
                                     // shortest segment cut twice it -- a small job gets short ranges, a genome-sized one long ones
     int64_t split_runs = 224;       // ... that budget: every run holds a compute unit while it runs
     int64_t split_warm = 6144;      // (split_len > 0) probes a range starts in front of its cut
+    int64_t split_warm_max = 24576; // a segment with a cut that did not hold gets twice the warm-up in the next call, up to this many probes
+                                    // (then only the cuts that held are planned again); 0: never grown
     int64_t split_min = 0;          // segments shorter than this (probe positions) are not cut (split_len = 0: at least this)
     int64_t cache_calls = 2;        // the blocks an index build released stay in the block cache until the index has answered this many
                                     // search PASSES (a direct + -RC passes call counts two) (then, at its destruction, on an allocation failure and by asgart_trim_cache they go
@@ -459,6 +461,7 @@ struct asgart_index {
     struct SplitVerdict {
         uint64_t key, sig;
         uint32_t allowed, range_len;  // (the count belongs to the range length it was found at)
+        uint32_t warm;                // the warm-up this segment's ranges get from now on (0: the call's own)
     };
     std::vector<SplitVerdict> split_blocked;
     asgart::DevBuf ws_arena;  // the block the call contexts' per-probe buffers were carved from (carve_probe_workspace), or empty

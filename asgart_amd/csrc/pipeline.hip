@@ -730,6 +730,7 @@ struct SearchCall {
                             (uint32_t)b->key >= lo_lim && (uint32_t)b->key < hi_lim) {
                             sp.blocked[sp.n_blocked] = (uint32_t)p_ * K + ((uint32_t)b->key - lo_lim);
                             sp.blocked_len[sp.n_blocked] = b->range_len;
+                            sp.blocked_warm[sp.n_blocked] = b->warm;
                             sp.allowed[sp.n_blocked++] = (uint16_t)std::min<uint32_t>(b->allowed, 0xFFFFu);
                         }
             }
@@ -746,6 +747,25 @@ struct SearchCall {
                                                               reinterpret_cast<SplitSeg *>(d_split + kOffSplits), d_choice);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(h_split, d_split, kOffMeta, hipMemcpyDeviceToHost, s));
+        }
+        if (opt.debug >= 2 && pp.seg_info) {  // the longest and the richest segment every tier runs WHOLE
+            unsigned long long *d_top = nullptr, h_top[2 * kTiers] = {};
+            HIP_TRY(hipMalloc(&d_top, sizeof(h_top)));
+            (void)hipMemsetAsync(d_top, 0, sizeof(h_top), s);
+            top_uncut_kernel<<<grid_for(n_seg), 256, 0, s>>>(d_ctr + CT_SEG, kbuf, pp.seg_info, d_top);
+            (void)hipMemcpyAsync(h_top, d_top, sizeof(h_top), hipMemcpyDeviceToHost, s);
+            (void)hipStreamSynchronize(s);
+            for (int t = 0; t < 2 * kTiers; ++t) {
+                if (!h_top[t]) continue;
+                uint2 info{};
+                uint32_t g0 = 0;
+                const size_t sj = (size_t)(h_top[t] & 0xFFFFFFFFull);
+                (void)hipMemcpy(&info, pp.seg_info + sj, sizeof(info), hipMemcpyDeviceToHost);
+                (void)hipMemcpy(&g0, seg_list + sj, sizeof(g0), hipMemcpyDeviceToHost);
+                fprintf(stderr, "[asgart] tier %d, run whole, the segment with the most %s: at probe %u, %u probe positions%s, %u hits\n", t / 2 + 1,
+                        t % 2 ? "hits" : "probe positions", g0, info.y & 0x7FFFFFFFu, (info.y >> 31) ? "" : " (cut short by the window)", info.x);
+            }
+            (void)hipFree(d_top);
         }
         order = nullptr;
         const uint32_t *sorted_keys = nullptr;
@@ -1108,20 +1128,30 @@ struct SearchCall {
             };
             std::vector<uint32_t> held_base;  // family-ordinal bases of the ranges whose records wait for their segment's last run
             std::vector<Tail> tails;
-            auto remember = [&](uint32_t g_seg0, uint32_t allowed) {
+            // What the index remembers about a segment a cut of which did not hold (allowed: how many of its cuts, from the start,
+            // held; warm_used: the warm-up its ranges had; 0: do not grow it).  While the warm-up can still grow (option
+            // split_warm_max) the next call gives this segment's ranges twice as much and plans all its cuts again -- a shard of a
+            // genome-sized call gets short ranges with short warm-ups, and its tandem arrays need the 6 144 probes the
+            // unsharded call's ranges have: left at "only the cuts that held", the rest of such a segment became one long last
+            // range, the longest work item of the shard (81 ms of a 90-ms shard).  At the limit: only the cuts that held.
+            auto remember = [&](uint32_t g_seg0, uint32_t allowed, uint32_t warm_used) {
                 const uint32_t p_ = pass_of_probe(g_seg0);
                 const uint64_t key_ = (uint64_t)((rp.modes >> (8 * p_)) & 0xFFu) << 32 | (uint64_t)pass_offset(g_seg0);
                 const uint32_t len_ = (uint32_t)h_split_hdr[4];
+                const uint32_t warm_max = (uint32_t)opt.split_warm_max;
+                const uint32_t warm_next = (warm_used && warm_used < warm_max) ? std::min(2u * warm_used, warm_max) : 0u;
+                if (warm_next) allowed = kAllCuts;
                 std::lock_guard<std::mutex> lk(idx->mu);
                 for (auto &b : idx->split_blocked)
                     if (b.key == key_ && b.sig == call_sig) {
-                        b.allowed = b.range_len == len_ ? std::min(b.allowed, allowed) : allowed;
+                        b.allowed = (b.range_len == len_ && !warm_next) ? std::min(b.allowed, allowed) : allowed;
                         b.range_len = len_;
+                        if (warm_next) b.warm = warm_next;
                         return;
                     }
                 // (verdicts age out, oldest first: a forgotten one costs its segment one more refused cut, no more)
                 if (idx->split_blocked.size() >= 4096) idx->split_blocked.erase(idx->split_blocked.begin());
-                idx->split_blocked.push_back({key_, call_sig, allowed, len_});
+                idx->split_blocked.push_back({key_, call_sig, allowed, len_, warm_next});
             };
             for (const SplitSeg &sg : split_segs) {
                 const uint32_t n_cuts_sg = sg.n_ranges - 1;
@@ -1162,7 +1192,7 @@ struct SearchCall {
                 }
                 if (!ok) {
                     ++n_split_refused;
-                    remember(sg.g_seg0, f);
+                    remember(sg.g_seg0, f, sg.warm);
                     if (f == 0) h_again[n_again++] = sg.g_seg0;
                 }
             }
@@ -1206,7 +1236,7 @@ struct SearchCall {
                         for (uint32_t j = 0; j <= t.f; ++j, ++hb) h_fix[t.run_base + j] = gave_up ? 0xFFFFFFFFu : held_base[hb];
                         if (gave_up) {
                             h_again[n_again++] = t.g_seg0;
-                            remember(t.g_seg0, 0u);
+                            remember(t.g_seg0, 0u, 0u);  // (more arms than the long shape holds: not a matter of the warm-up)
                         }
                     }
                     HIP_TRY(hipMemcpyAsync(d_split + kOffFix, h_fix, kOffAgain - kOffFix, hipMemcpyHostToDevice, s));
@@ -1805,7 +1835,11 @@ int32_t asgart_search_duplications_passes_shard(asgart_index *idx, const uint64_
                    v.M == settings[0].min_duplication_length && v.C == settings[0].max_cardinality && v.modes == modes_sig &&
                    v.shard == shard && v.n_shards == n_shards;
         };
-        if (fusable && idx->opt.fuse_passes == 1) {  // what the last fused call with these settings measured decides
+        // what the last fused call with these settings measured decides -- for an unsharded call: what pipelining can win is
+        // the other passes' front beside the one long segment, and a shard's front is 1/N of it, while the second pass's
+        // front crawling behind the first one's persistent workgroups costs a shard as much as it costs the whole call
+        // (GRCh38-shaped, the shards of N = 8 timed alone: 32-64 ms as one job, 47-78 ms pipelined)
+        if (fusable && idx->opt.fuse_passes == 1 && n_shards == 1) {
             std::lock_guard<std::mutex> lk(idx->mu);
             if (same_as_verdict() && idx->fuse_verdict.pipeline) fusable = false;
         }
@@ -1843,7 +1877,7 @@ int32_t asgart_search_duplications_passes_shard(asgart_index *idx, const uint64_
                 v.modes = modes_sig;
                 v.shard = shard;
                 v.n_shards = n_shards;
-                v.pipeline = stt.passes == (uint64_t)n_passes && stt.ms_extend > 0.0 &&
+                v.pipeline = n_shards == 1 && stt.passes == (uint64_t)n_passes && stt.ms_extend > 0.0 &&
                              stt.ms_longest_segment * 100.0 > stt.ms_extend * (double)idx->opt.fuse_pole_pct;
                 if (idx->opt.debug)
                     fprintf(stderr, "[asgart] passes as one job: longest segment %.1f ms of %.1f ms of extension -> the next call %s\n",

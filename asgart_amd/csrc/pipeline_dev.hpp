@@ -1218,7 +1218,7 @@ constexpr uint32_t kRunDumpCap = 5120; // arms a run can leave alive (the long s
 // end, threshold, gap, 0
 struct SplitSeg {
     uint32_t g_seg0, run_base, n_ranges, cut_base;  // runs run_base .. + n_ranges - 1: the ranges; cuts cut_base .. + n_ranges - 2
-    uint32_t span, hits, tier, pad;                 // (what the placement knew of the segment: option debug prints it)
+    uint32_t span, hits, tier, warm;                // (what the placement knew of the segment; the warm-up its ranges got)
 };
 
 template <class PosT>
@@ -2274,7 +2274,9 @@ struct SplitParams {
     uint32_t blocked[kSplitBlockedMax];      // segments (first probe) a cut of which did not hold in an earlier call of the index ...
     uint16_t allowed[kSplitBlockedMax];      // ... and how many of their cuts, counted from the segment's start, held (0: not cut again)
     uint32_t blocked_len[kSplitBlockedMax];  // ... at which range length (the count means nothing at another)
+    uint32_t blocked_warm[kSplitBlockedMax]; // ... and the warm-up this segment's ranges get from now on (0: the call's)
 };
+constexpr uint16_t kAllCuts = 0xFFFFu;       // SplitParams::allowed: no limit (the verdict only asks for a longer warm-up)
 __global__ __launch_bounds__(256) void plan_ranges_kernel(RunParams rp, SplitParams sp, const uint32_t *__restrict__ p_filt,
                                                          const uint32_t *__restrict__ seg_list,
                                                          const unsigned long long *__restrict__ n_seg_ptr,
@@ -2297,10 +2299,15 @@ __global__ __launch_bounds__(256) void plan_ranges_kernel(RunParams rp, SplitPar
     const uint32_t span = info.y & 0x7FFFFFFFu;
     if (span < sp.min_span || !split_eligible(rp, key, info)) return;
     const uint32_t g0 = seg_list[sj];
-    const uint32_t warm = sp.warm;
+    // a segment a cut of which did not hold in an earlier call: its ranges start further in front of their cuts (the warm-up
+    // doubles from call to call up to option split_warm_max), and at that limit only the cuts that held are planned again
+    uint32_t warm = sp.warm;
     uint32_t n_cut_max = 0xFFFFFFFFu;
     for (uint32_t b = 0; b < sp.n_blocked; ++b)
-        if (sp.blocked[b] == g0 && sp.blocked_len[b] == sp.range_len) n_cut_max = min(n_cut_max, (uint32_t)sp.allowed[b]);
+        if (sp.blocked[b] == g0 && sp.blocked_len[b] == sp.range_len) {
+            if (sp.allowed[b] != kAllCuts) n_cut_max = min(n_cut_max, (uint32_t)sp.allowed[b]);
+            warm = max(warm, sp.blocked_warm[b]);
+        }
     // ranges of about range_len probe positions each, at least two, their cuts at equal shares of the segment; a segment whose
     // cuts held only up to some point in an earlier call keeps those cuts (same places) and runs the rest as its last range
     // (cuts at equal shares of positions + hits / w instead were measured at GRCh38 size and did not move the step: DESIGN_HISTORY.md)
@@ -2341,7 +2348,7 @@ __global__ __launch_bounds__(256) void plan_ranges_kernel(RunParams rp, SplitPar
         return;
     }
     keys[sj] = (key & 0x1FFFFFFFu) | ((uint32_t)(kTierBarren - 1) << 29);  // off its tier's list
-    splits[split] = SplitSeg{g0, run_base, n_r, cut_base, span, info.x, (key >> 29) + 1u, 0u};
+    splits[split] = SplitSeg{g0, run_base, n_r, cut_base, span, info.x, (key >> 29) + 1u, warm};
     uint32_t c_prev = g0;
     for (uint32_t j = 0; j < n_r; ++j) {
         const uint32_t c_next = j + 1u < n_r ? cut_of(j + 1u) : 0xFFFFFFFFu;
@@ -2357,6 +2364,19 @@ __global__ __launch_bounds__(256) void plan_ranges_kernel(RunParams rp, SplitPar
         if (j) cuts[cut_base + j - 1u] = make_uint2(run_base + j - 1u, run_base + j);
         c_prev = c_next;
     }
+}
+
+// (option debug = 2: per tier the placed segment with the most probe positions and the one with the most hits that was NOT cut
+// -- top[2 t] and top[2 t + 1] = figure << 32 | segment)
+__global__ __launch_bounds__(256) void top_uncut_kernel(const unsigned long long *__restrict__ n_seg_ptr, const uint32_t *__restrict__ keys,
+                                                       const uint2 *__restrict__ seg_info, unsigned long long *__restrict__ top) {
+    const unsigned long long sj = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (sj >= *n_seg_ptr) return;
+    const uint32_t tier = keys[sj] >> 29;
+    if (tier >= (uint32_t)kTiers) return;
+    const uint2 info = seg_info[sj];
+    atomicMax(&top[2u * tier], (unsigned long long)(info.y & 0x7FFFFFFFu) << 32 | sj);
+    atomicMax(&top[2u * tier + 1u], (unsigned long long)info.x << 32 | sj);
 }
 
 __global__ __launch_bounds__(256) void validate_cuts_kernel(const uint2 *__restrict__ cuts, const uint32_t *__restrict__ run_meta,

@@ -1340,14 +1340,16 @@ def test_k8_free_counts_do_not_depend_on_timing(hiplib, delay, monkeypatch):
                 assert np.array_equal(offs, eo) and np.array_equal(sds, es), (seed, rc, delay, cli)
 
 
-@pytest.mark.parametrize("shape", [(256, 128, 512), (256, 1024, 512), (128, 512, 256)])
+@pytest.mark.parametrize("shape", [(256, 128, 512, 0), (256, 1024, 512, 0), (128, 512, 256, 0), (256, 128, 512, 1024), (128, 64, 256, 24576)])
 def test_long_segments_as_ranges_equal_whole_segments(hiplib, shape):
     """Option split: a long segment runs as RANGES side by side -- every range starts from an empty arm list split_warm
     probes in front of its cut, and what it holds at the cut (every arm, every field; family open or not; a held flush) is
     compared on the device with what the range in front of the cut holds there.  Where the cuts hold, the ranges' records
     (family ordinals counted on from the ranges before, creation order by (probe, hit)) must be the whole segment's; where
     one does not, the ranges in front of it stand, the rest of the segment runs as ONE more run from a checked state (the whole
-    segment again when its first cut fails), and the index plans only the cuts that held from then on.  Tandem-array cases of
+    segment again when its first cut fails), and the index gives that segment's ranges twice the warm-up in the next call, up
+    to option split_warm_max (the shape's 4th number; 0: never), and from there on plans only the cuts that held: after
+    log2(split_warm_max / split_warm) + 2 calls nothing is refused any more.  Tandem-array cases of
     tools/fuzz_k8.py with ranges of 128-256 probes (the shipped 8192 never cut a test-sized segment), every multi-hit
     segment forced through the long shape, generation wraps every few probes in some cases: families, ProtoSDs AND keys
     equal to the uncut run and to the oracle, for single calls and for both orientations as one job; both outcomes
@@ -1355,7 +1357,10 @@ def test_long_segments_as_ranges_equal_whole_segments(hiplib, shape):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import fuzz_k8
 
-    ln, warm, mn = shape
+    ln, warm, mn, warm_max = shape
+    n_grow = 0
+    while warm_max and (warm << n_grow) < warm_max:
+        n_grow += 1
     joined = refused = sharded_cut = 0
     for seed in (1, 4, 5, 6, 8, 11, 101, 107, 117, 123):
         text, cli, genbits = fuzz_k8.make_case(seed)
@@ -1377,9 +1382,10 @@ def test_long_segments_as_ranges_equal_whole_segments(hiplib, shape):
             idx.set_option("split_len", ln)
             idx.set_option("split_warm", warm)
             idx.set_option("split_min", mn)
-            # (a segment with a cut that did not hold keeps the ranges in front of it and runs the rest as one more run; the
-            # next call plans only the cuts that held: it refuses nothing)
-            for rep in range(3):
+            idx.set_option("split_warm_max", warm_max)
+            # (a segment with a cut that did not hold keeps the ranges in front of it and runs the rest as one more run; with
+            # the warm-up at its limit the next call plans only the cuts that held: it refuses nothing)
+            for rep in range(n_grow + 3):
                 for j, st in enumerate(sts):
                     got = idx.search_duplications_raw(chunks, st, with_keys=True)
                     stt = idx.stats()
@@ -1387,7 +1393,7 @@ def test_long_segments_as_ranges_equal_whole_segments(hiplib, shape):
                     if rep == 0:
                         joined += stt.split_segments - stt.split_refused
                         refused += stt.split_refused
-                    else:
+                    elif rep > n_grow:
                         assert stt.split_refused == 0, (seed, shape, rep, j)
             both = idx.search_duplications_passes(chunks, sts, with_keys=True)
             for j in range(2):
@@ -1399,6 +1405,7 @@ def test_long_segments_as_ranges_equal_whole_segments(hiplib, shape):
             idx.set_option("split_len", ln)
             idx.set_option("split_warm", warm)
             idx.set_option("split_min", mn)
+            idx.set_option("split_warm_max", warm_max)
             n_cut = 0
             parts = []
             for r in range(3):

@@ -2,7 +2,7 @@
 all passes as one job: what rank r of N runs) one after the other, each alone on the chip -- exactly what a rank's own
 GPU sees, minus the gather of its result lists.  The shards' families merged by key must equal the unsharded result.
 
-    python tools/shard_check.py [N[,N...]=1,2,4,8] [cfgK=cfg4] [--out FILE] [--reps 3] [option=value ...]
+    python tools/shard_check.py [N[,N...]=1,2,4,8] [cfgK=cfg4] [--out FILE] [--reps 3] [--settle 5] [option=value ...]
 
 Writes FILE (default gpurun_out/shards_<cfg>.json; commit it as profiles/rNN_<cfg>_shards.json): per N the per-shard
 call times (median of --reps steady-state calls, ms) with the library's phase times, max_r = what an N-GPU step takes
@@ -22,7 +22,7 @@ import asgart_amd  # noqa: E402
 from asgart_amd import prep, synth  # noqa: E402
 
 args = [a for a in sys.argv[1:]]
-out_path, reps = None, 3
+out_path, reps, settle = None, 3, 5
 if "--out" in args:
     i = args.index("--out")
     out_path = args[i + 1]
@@ -30,6 +30,10 @@ if "--out" in args:
 if "--reps" in args:
     i = args.index("--reps")
     reps = int(args[i + 1])
+    del args[i:i + 2]
+if "--settle" in args:
+    i = args.index("--settle")
+    settle = int(args[i + 1])
     del args[i:i + 2]
 opts = [a for a in args if "=" in a]
 args = [a for a in args if "=" not in a and a != "--fused"]
@@ -43,7 +47,7 @@ out_path = out_path or os.path.join(ROOT, "gpurun_out", f"shards_{wl}.json")
 pr = prep.prepare_records(synth.config_genome(cfg, scale), skip_masked=skip_masked)
 total_bp = sum(l for _, l in pr.chunks)
 PHASES = ("ms_search", "ms_scan", "ms_fill", "ms_extend", "ms_longest_segment", "ms_total")
-res = {"workload": wl, "bp_per_pass": total_bp, "passes": len(modes), "reps": reps,
+res = {"workload": wl, "bp_per_pass": total_bp, "passes": len(modes), "reps": reps, "settling_calls": settle,
        "library_build": hashlib.sha256(open(asgart_amd.library_path(), "rb").read()).hexdigest()[:12],
        "method": "one GPU; shard r of N = the r-th slice of every pass as ONE job (asgart_search_duplications_passes_shard), "
                  "the shards one after the other, each alone on the chip; per shard the median wall time of the call over "
@@ -62,7 +66,13 @@ with asgart_amd.Index(pr.data, None) as idx:
     for n in ns:
         shards, parts = [], []
         for r in range(n):
-            call(r, n)   # (the first sharded call of a shape plans its cuts; steady state from the second on)
+            # (the first sharded call of a shape plans its cuts, and a segment with a cut that did not hold gets twice the
+            # warm-up in the next one, up to split_warm_max: steady state after at most five calls with the defaults)
+            first_ms = []
+            for _ in range(settle):
+                t0 = time.perf_counter()
+                call(r, n)
+                first_ms.append(round((time.perf_counter() - t0) * 1e3, 1))
             times, stats = [], None
             for _ in range(reps):
                 t0 = time.perf_counter()
@@ -70,7 +80,7 @@ with asgart_amd.Index(pr.data, None) as idx:
                 times.append((time.perf_counter() - t0) * 1e3)
                 stats = idx.stats().as_dict()
             parts.append(part)
-            shards.append({"ms": round(float(np.median(times)), 3), "ms_all": [round(t, 3) for t in times],
+            shards.append({"ms": round(float(np.median(times)), 3), "ms_all": [round(t, 3) for t in times], "ms_settling_calls": first_ms,
                            "passes_as_one_job": stats["passes"] == len(sts),
                            **{ph[3:]: round(stats[ph], 3) for ph in PHASES},
                            "front": round(stats["ms_search"] + stats["ms_scan"] + stats["ms_fill"], 3),
