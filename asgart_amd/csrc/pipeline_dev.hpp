@@ -2230,8 +2230,9 @@ struct SplitChoice {
 __device__ inline bool split_eligible(const RunParams &rp, uint32_t key, uint2 info) {
     const uint32_t tier = (key >> 29) + 1u;
     // (tiers 1 and 2 are one-wave kernels: a wave on its own passes a sparse probe several times faster than the long shape's
-    // sixteen waves and their barrier -- cutting a yeast-sized input's longest tier-2 segment in two doubled its step; tier 7's
-    // arms do not fit the long shape)
+    // sixteen waves and their barrier -- cutting a yeast-sized input's longest tier-2 segment in two doubled its step; cutting
+    // the one-wave segments of 12 288 probe positions and more left a GRCh38-sized step and its shards where they were:
+    // DESIGN_HISTORY.md; tier 7's arms do not fit the long shape)
     if (tier < 3u || tier > 6u) return false;
     const uint32_t span = info.y & 0x7FFFFFFFu;
     if (!(info.y >> 31) || span < 128u) return false;  // (cut short by a shard window: left alone)

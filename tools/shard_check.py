@@ -2,7 +2,7 @@
 all passes as one job: what rank r of N runs) one after the other, each alone on the chip -- exactly what a rank's own
 GPU sees, minus the gather of its result lists.  The shards' families merged by key must equal the unsharded result.
 
-    python tools/shard_check.py [N[,N...]=1,2,4,8] [cfgK=cfg4] [--out FILE] [--reps 3] [--settle 5] [option=value ...]
+    python tools/shard_check.py [N[,N...]=1,2,4,8] [cfgK=cfg4] [--out FILE] [--reps 3] [--settle 5] [--only R] [option=value ...]
 
 Writes FILE (default gpurun_out/shards_<cfg>.json; commit it as profiles/rNN_<cfg>_shards.json): per N the per-shard
 call times (median of --reps steady-state calls, ms) with the library's phase times, max_r = what an N-GPU step takes
@@ -35,6 +35,11 @@ if "--settle" in args:
     i = args.index("--settle")
     settle = int(args[i + 1])
     del args[i:i + 2]
+only = None   # (--only R: just shard R of every N, no merge check -- for a look at one shard with option debug)
+if "--only" in args:
+    i = args.index("--only")
+    only = int(args[i + 1])
+    del args[i:i + 2]
 opts = [a for a in args if "=" in a]
 args = [a for a in args if "=" not in a and a != "--fused"]
 ns = [int(x) for x in (args[0] if args else "1,2,4,8").split(",")]
@@ -65,7 +70,7 @@ with asgart_amd.Index(pr.data, None) as idx:
         whole = call(0, 1)
     for n in ns:
         shards, parts = [], []
-        for r in range(n):
+        for r in (range(n) if only is None else [only]):
             # (the first sharded call of a shape plans its cuts, and a segment with a cut that did not hold gets twice the
             # warm-up in the next one, up to split_warm_max: steady state after at most five calls with the defaults)
             first_ms = []
@@ -87,11 +92,11 @@ with asgart_amd.Index(pr.data, None) as idx:
                            "segments": stats["segments"], "split_segments": stats["split_segments"],
                            "split_refused": stats["split_refused"], "proto_sds": stats["proto_sds"]})
         same = True
-        for j in range(len(sts)):
+        for j in range(len(sts) if only is None else 0):
             mo, ms = asgart_amd.merge_shards([p_[j] for p_ in parts])
             same = same and np.array_equal(mo, whole[j][0]) and np.array_equal(ms, whole[j][1])
         mx = max(s_["ms"] for s_ in shards)
-        res["n"][str(n)] = {"max_ms": mx, "mean_ms": round(sum(s_["ms"] for s_ in shards) / n, 3),
+        res["n"][str(n)] = {"max_ms": mx, "mean_ms": round(sum(s_["ms"] for s_ in shards) / len(shards), 3),
                             "mbp_per_s_if_ranks_ran_side_by_side": round(total_bp * len(sts) / mx / 1e3, 1),
                             "merged_equals_unsharded": bool(same), "shards": shards}
         print(f"N={n}: per-shard ms {' '.join('%.1f' % s_['ms'] for s_ in shards)}; max {mx:.1f}, identical after the merge: {same}",
