@@ -117,7 +117,7 @@ constexpr uint32_t K8_STILL = 2u;      // the new arms of this block die of the 
 constexpr uint32_t K8_BIG = 4u;        // more than 64 new arms: the ranking wave offered for the first 64 only, every wave takes a
                                        // share of the others at the top of the next step (one extra barrier in such a step)
 
-// RANGE (32-bit positions): a work item is not a segment but a RUN over part of one (struct RangeRun, pipeline_dev.hpp) --
+// RANGE: a work item is not a segment but a RUN over part of one (struct RangeRun, pipeline_dev.hpp) --
 // long segments cut into ranges that run side by side, each from an empty arm list some way in front of its cut.  What
 // differs from a whole segment: where the walk starts and stops; creation numbers that do not depend on what the run has
 // seen before (needle offset of the creating probe relative to the segment's first, then the hit's index: the same arm
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
     constexpr uint32_t kCmdWords = 32;
     constexpr uint32_t kNewMax = kWidePos ? (uint32_t)HB / 2u : (uint32_t)HB;  // new arms of one probe (more: given up)
     using WinT = typename std::conditional<kWidePos, uint64_t, uint32_t>::type;
-    static_assert(!RANGE || (sizeof(PosT) == 4 && S * NWA * 64 <= (int)kRunDumpCap), "runs over ranges: 32-bit positions, dump capacity");
+    static_assert(!RANGE || S * NWA * 64 <= (int)kRunDumpCap, "runs over ranges: dump capacity");
     static_assert(NW >= 4 && HB <= 1024 && S <= 8 && NE <= 128 && (kRows & (kRows - 1)) == 0 && kE == 2 && kRows <= 2048 && CAP < 65536,
                   "shape");
     if (NT >= 1024) __builtin_amdgcn_s_setprio(3);
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
         }
         // (RANGE) one arm into dump `which` of this run (0: what the run holds when it stops, 1: what it holds when it reaches
         // its cut), slot handed out by the dump's counter
-        auto dump_arm = [&](uint32_t which, bool live, uint32_t seq, uint32_t ls, uint32_t le, uint32_t rs, uint32_t re, uint32_t thr, uint32_t gap) {
+        auto dump_arm = [&](uint32_t which, bool live, uint32_t seq, PosT ls, PosT le, PosT rs, PosT re, uint32_t thr, uint32_t gap) {
             if constexpr (RANGE) {
                 const unsigned long long m = __ballot(live);
                 if (!m) return;
@@ -252,9 +252,15 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
                 base = lane_of(base, 0u);
                 const uint32_t at = base + (uint32_t)__popcll(m & lt_mask);
                 if (live && at < kRunDumpCap) {
-                    uint4 *o = reinterpret_cast<uint4 *>(P.run_dump + ((seg * 2ull + which) * (unsigned long long)kRunDumpCap + at) * 8ull);
-                    o[0] = make_uint4(seq, ls, le, rs);
-                    o[1] = make_uint4(re, thr, gap, 0u);
+                    uint4 *o = reinterpret_cast<uint4 *>(P.run_dump + ((seg * 2ull + which) * (unsigned long long)kRunDumpCap + at) * kDumpWords<PosT>);
+                    if constexpr (kWidePos) {
+                        o[0] = make_uint4(seq, thr, gap, 0u);
+                        o[1] = make_uint4((uint32_t)ls, (uint32_t)((uint64_t)ls >> 32), (uint32_t)le, (uint32_t)((uint64_t)le >> 32));
+                        o[2] = make_uint4((uint32_t)rs, (uint32_t)((uint64_t)rs >> 32), (uint32_t)re, (uint32_t)((uint64_t)re >> 32));
+                    } else {
+                        o[0] = make_uint4(seq, (uint32_t)ls, (uint32_t)le, (uint32_t)rs);
+                        o[1] = make_uint4((uint32_t)re, thr, gap, 0u);
+                    }
                 }
             }
         };
@@ -720,8 +726,8 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
                     if (K7_RARE(has_cur && emit_from_i != 0u && emit_from_i != 0xFFFFFFFFu && C(6) == emit_from_i)) {
 #pragma unroll
                         for (int L = 0; L < S; ++L)
-                            dump_arm(1u, a_seq[L] != kNoSeq, a_seq[L], (uint32_t)a_ls[L], (uint32_t)s_cle[L * (NWA * 64) + tid],
-                                     (uint32_t)s_crs[L * (NWA * 64) + tid], (uint32_t)a_re[L], a_thr[L], a_gap[L]);
+                            dump_arm(1u, a_seq[L] != kNoSeq, a_seq[L], a_ls[L], s_cle[L * (NWA * 64) + tid], s_crs[L * (NWA * 64) + tid], a_re[L],
+                                     a_thr[L], a_gap[L]);
                     }
                 }
                 // ---- every arm offers to this step's probe --------------------------------------------------------------
@@ -771,8 +777,8 @@ __global__ __launch_bounds__(NT) void extend_k8_kernel(ExtParams<PosT> P) {
                 if (!overflow) {
 #pragma unroll
                     for (int L = 0; L < S; ++L)
-                        dump_arm(0u, a_seq[L] != kNoSeq, a_seq[L], (uint32_t)a_ls[L], (uint32_t)s_cle[L * (NWA * 64) + tid],
-                                 (uint32_t)s_crs[L * (NWA * 64) + tid], (uint32_t)a_re[L], a_thr[L], a_gap[L]);
+                        dump_arm(0u, a_seq[L] != kNoSeq, a_seq[L], a_ls[L], s_cle[L * (NWA * 64) + tid], s_crs[L * (NWA * 64) + tid], a_re[L], a_thr[L],
+                                 a_gap[L]);
                 }
             }
             if (wave == 0u) K7T_FLUSH(1);

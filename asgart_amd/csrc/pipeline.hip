@@ -658,9 +658,9 @@ struct SearchCall {
         pp.seg_info = nullptr;
         const bool cluster_barren = opt.barren >= 2 && rp.M > (uint64_t)k;
         // long segments as ranges side by side (option split; plan_ranges_kernel in pipeline_dev.hpp): the long shape of the
-        // one-barrier kernel, 32-bit positions; also in a sharded call (the segments its window cuts short are left alone: only
+        // one-barrier kernel; also in a sharded call (the segments its window cuts short are left alone: only
         // a segment whose end the placement walk has seen is cut)
-        split_on = opt.split != 0 && sizeof(SlotT) == 4 && arms_kernel && (opt.split_len == 0 || opt.split_len >= 64);
+        split_on = opt.split != 0 && arms_kernel && (opt.split_len == 0 || opt.split_len >= 64);
         if (cluster_barren || split_on) {
             RC_TRY(w.seg_info.reserve((size_t)n_seg * sizeof(uint2)));
             pp.seg_info = w.seg_info.as<uint2>();
@@ -897,20 +897,18 @@ struct SearchCall {
     // the runs over ranges of the cut segments: first, on the main stream (idle while the tiers run) -- they are the
     // longest work items of the call, one workgroup each
     void launch_runs(uint32_t n_items) {  // the runs from the work cursor on, one workgroup each
-        if constexpr (sizeof(SlotT) == 4) {
-            ep.runs = reinterpret_cast<const RangeRun *>(d_split + kOffRuns);
-            ep.run_meta = reinterpret_cast<uint32_t *>(d_split + kOffMeta);
-            ep.run_dump = w.split_dump.as<uint32_t>();
-            ep.seg_list = nullptr;
-            ep.n_seg_ptr = reinterpret_cast<const unsigned long long *>(d_split);
-            ep.cursor = reinterpret_cast<unsigned long long *>(d_split + 24);
-            ep.ovf_list = nullptr;
-            ep.ovf_count = d_ctr + CT_OVF1 + 2;
-            ep.tier = 3;  // (statistics: with the long-segment tier)
-            ep.seg_slots = w.seg_slots.as<unsigned long long>();  // (slot block 0: no tier's)
-            ep.hb = cx.d_hb ? cx.d_hb : nullptr;
-            extend_k8_kernel<SlotT, kK8LongLayers<SlotT>, 1024, kHitBatch, kFastLongRows<SlotT>, 2, true><<<n_items, 1024, 0, s>>>(ep);
-        }
+        ep.runs = reinterpret_cast<const RangeRun *>(d_split + kOffRuns);
+        ep.run_meta = reinterpret_cast<uint32_t *>(d_split + kOffMeta);
+        ep.run_dump = w.split_dump.as<uint32_t>();
+        ep.seg_list = nullptr;
+        ep.n_seg_ptr = reinterpret_cast<const unsigned long long *>(d_split);
+        ep.cursor = reinterpret_cast<unsigned long long *>(d_split + 24);
+        ep.ovf_list = nullptr;
+        ep.ovf_count = d_ctr + CT_OVF1 + 2;
+        ep.tier = 3;  // (statistics: with the long-segment tier)
+        ep.seg_slots = w.seg_slots.as<unsigned long long>();  // (slot block 0: no tier's)
+        ep.hb = cx.d_hb ? cx.d_hb : nullptr;
+        extend_k8_kernel<SlotT, kK8LongLayers<SlotT>, 1024, kHitBatch, kFastLongRows<SlotT>, 2, true><<<n_items, 1024, 0, s>>>(ep);
     }
 
     void launch_tier(int tier) {
@@ -982,7 +980,7 @@ struct SearchCall {
         scratch_override = nullptr;
         if (n_runs) {
             // (room for one more run per cut segment: the rest behind the last cut that held, see below)
-            RC_TRY(w.split_dump.reserve((size_t)(n_runs + n_splits) * 2 * kRunDumpCap * 32));
+            RC_TRY(w.split_dump.reserve((size_t)(n_runs + n_splits) * 2 * kRunDumpCap * kDumpWords<SlotT> * 4));
             HIP_TRY(hipMemsetAsync(d_split + 24, 0, 8, s));                         // work cursor
             HIP_TRY(hipMemsetAsync(d_split + kOffMeta, 0, (size_t)n_runs * 64, s));  // run states
             launch_runs(n_runs);
@@ -1101,7 +1099,7 @@ struct SearchCall {
         HIP_TRY(hipStreamWaitEvent(s, cx.ev[10], 0));
         HIP_TRY(hipStreamWaitEvent(s, cx.ev[12], 0));
         if (n_cuts) {
-            validate_cuts_kernel<<<n_cuts, 256, 0, s>>>(reinterpret_cast<const uint2 *>(d_split + kOffCuts),
+            validate_cuts_kernel<kDumpWords<SlotT>><<<n_cuts, 256, 0, s>>>(reinterpret_cast<const uint2 *>(d_split + kOffCuts),
                                                        reinterpret_cast<const uint32_t *>(d_split + kOffMeta), w.split_dump.as<uint32_t>(),
                                                        reinterpret_cast<uint32_t *>(d_split + kOffOk));
             HIP_TRY(hipGetLastError());
@@ -1212,38 +1210,36 @@ struct SearchCall {
             if (n_slots) fixup_records_kernel<<<grid_for(n_slots), 256, 0, s>>>(w.fam_sds.as<SdRec>(), n_slots, reinterpret_cast<const uint32_t *>(d_split + kOffFix));
             HIP_TRY(hipGetLastError());
             if (n_tail) {
-                if constexpr (sizeof(SlotT) == 4) {
-                    HIP_TRY(hipMemcpyAsync(d_split + kOffRuns + (size_t)n_runs * sizeof(RangeRun), h_runs + n_runs, (size_t)n_tail * sizeof(RangeRun),
-                                           hipMemcpyHostToDevice, s));
-                    h_scalar[8] = (unsigned long long)n_runs + n_tail;  // list length
-                    h_scalar[9] = n_runs;                               // work cursor: behind the runs that are done
-                    HIP_TRY(hipMemcpyAsync(d_split, h_scalar + 8, 8, hipMemcpyHostToDevice, s));
-                    HIP_TRY(hipMemcpyAsync(d_split + 24, h_scalar + 9, 8, hipMemcpyHostToDevice, s));
-                    HIP_TRY(hipMemsetAsync(d_split + kOffMeta + (size_t)n_runs * 64, 0, (size_t)n_tail * 64, s));
-                    launch_runs(n_tail);
-                    HIP_TRY(hipMemcpyAsync(h_split + kOffMeta + (size_t)n_runs * 64, d_split + kOffMeta + (size_t)n_runs * 64, (size_t)n_tail * 64,
-                                           hipMemcpyDeviceToHost, s));
-                    HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, kCtrBytes, hipMemcpyDeviceToHost, s));
-                    RC_TRY(wd_sync(idx, cx, s, "the rest of the cut segments"));
-                    h_scalar[8] = n_runs;  // (a second attempt of the call -- record buffer too small -- starts from the planned list)
-                    HIP_TRY(hipMemcpyAsync(d_split, h_scalar + 8, 8, hipMemcpyHostToDevice, s));
-                    size_t hb = 0;
-                    for (const Tail &t : tails) {
-                        // (a last run that gave up -- more arms than the long shape holds --: everything the segment's runs wrote
-                        // is dropped and the whole segment goes the cascade's way)
-                        const bool gave_up = h_meta[(size_t)t.run * 16 + 4] != 0u;
-                        h_fix[t.run] = gave_up ? 0xFFFFFFFFu : t.base;
-                        for (uint32_t j = 0; j <= t.f; ++j, ++hb) h_fix[t.run_base + j] = gave_up ? 0xFFFFFFFFu : held_base[hb];
-                        if (gave_up) {
-                            h_again[n_again++] = t.g_seg0;
-                            remember(t.g_seg0, 0u, 0u);  // (more arms than the long shape holds: not a matter of the warm-up)
-                        }
+                HIP_TRY(hipMemcpyAsync(d_split + kOffRuns + (size_t)n_runs * sizeof(RangeRun), h_runs + n_runs, (size_t)n_tail * sizeof(RangeRun),
+                                       hipMemcpyHostToDevice, s));
+                h_scalar[8] = (unsigned long long)n_runs + n_tail;  // list length
+                h_scalar[9] = n_runs;                               // work cursor: behind the runs that are done
+                HIP_TRY(hipMemcpyAsync(d_split, h_scalar + 8, 8, hipMemcpyHostToDevice, s));
+                HIP_TRY(hipMemcpyAsync(d_split + 24, h_scalar + 9, 8, hipMemcpyHostToDevice, s));
+                HIP_TRY(hipMemsetAsync(d_split + kOffMeta + (size_t)n_runs * 64, 0, (size_t)n_tail * 64, s));
+                launch_runs(n_tail);
+                HIP_TRY(hipMemcpyAsync(h_split + kOffMeta + (size_t)n_runs * 64, d_split + kOffMeta + (size_t)n_runs * 64, (size_t)n_tail * 64,
+                                       hipMemcpyDeviceToHost, s));
+                HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, kCtrBytes, hipMemcpyDeviceToHost, s));
+                RC_TRY(wd_sync(idx, cx, s, "the rest of the cut segments"));
+                h_scalar[8] = n_runs;  // (a second attempt of the call -- record buffer too small -- starts from the planned list)
+                HIP_TRY(hipMemcpyAsync(d_split, h_scalar + 8, 8, hipMemcpyHostToDevice, s));
+                size_t hb = 0;
+                for (const Tail &t : tails) {
+                    // (a last run that gave up -- more arms than the long shape holds --: everything the segment's runs wrote
+                    // is dropped and the whole segment goes the cascade's way)
+                    const bool gave_up = h_meta[(size_t)t.run * 16 + 4] != 0u;
+                    h_fix[t.run] = gave_up ? 0xFFFFFFFFu : t.base;
+                    for (uint32_t j = 0; j <= t.f; ++j, ++hb) h_fix[t.run_base + j] = gave_up ? 0xFFFFFFFFu : held_base[hb];
+                    if (gave_up) {
+                        h_again[n_again++] = t.g_seg0;
+                        remember(t.g_seg0, 0u, 0u);  // (more arms than the long shape holds: not a matter of the warm-up)
                     }
-                    HIP_TRY(hipMemcpyAsync(d_split + kOffFix, h_fix, kOffAgain - kOffFix, hipMemcpyHostToDevice, s));
-                    n_slots = std::min<uint64_t>(h_ctr[CT_SD], rec_cap);
-                    if (n_slots) fixup_records_kernel<<<grid_for(n_slots), 256, 0, s>>>(w.fam_sds.as<SdRec>(), n_slots, reinterpret_cast<const uint32_t *>(d_split + kOffFix));
-                    HIP_TRY(hipGetLastError());
                 }
+                HIP_TRY(hipMemcpyAsync(d_split + kOffFix, h_fix, kOffAgain - kOffFix, hipMemcpyHostToDevice, s));
+                n_slots = std::min<uint64_t>(h_ctr[CT_SD], rec_cap);
+                if (n_slots) fixup_records_kernel<<<grid_for(n_slots), 256, 0, s>>>(w.fam_sds.as<SdRec>(), n_slots, reinterpret_cast<const uint32_t *>(d_split + kOffFix));
+                HIP_TRY(hipGetLastError());
             }
             if (n_again) {
                 HIP_TRY(hipMemcpyAsync(d_split + kOffAgain, h_again, (size_t)n_again * 4, hipMemcpyHostToDevice, s));

@@ -1214,8 +1214,10 @@ constexpr uint32_t kRunDumpCap = 5120; // arms a run can leave alive (the long s
 // per run two states, 8 words each (run_meta): [0] what it holds when it STOPS, [1] what it holds when it reaches its cut:
 // 0 arms written to run_dump  1 flushes since the cut  2 family open  3 probes a flush is still held back for  4 ([0] only) gave up
 // (more arms than slots, a probe with more hits than the staging area)
-// per run two dumps of kRunDumpCap arms, 8 words per arm (run_dump): creation number, left start, left end, right start | right
-// end, threshold, gap, 0
+// per run two dumps of kRunDumpCap arms (run_dump), kDumpWords per arm, the creation number first (32-bit positions: creation
+// number, left start, left end, right start | right end, threshold, gap, 0; 64-bit: creation number, threshold, gap, 0 | left
+// start, left end | right start, right end)
+template <class PosT> constexpr uint32_t kDumpWords = sizeof(PosT) == 4 ? 8u : 12u;
 struct SplitSeg {
     uint32_t g_seg0, run_base, n_ranges, cut_base;  // runs run_base .. + n_ranges - 1: the ranges; cuts cut_base .. + n_ranges - 2
     uint32_t span, hits, tier, warm;                // (what the placement knew of the segment; the warm-up its ranges got)
@@ -2380,8 +2382,10 @@ __global__ __launch_bounds__(256) void top_uncut_kernel(const unsigned long long
     atomicMax(&top[2u * tier + 1u], (unsigned long long)info.x << 32 | sj);
 }
 
+template <uint32_t W>  // (words per dumped arm: kDumpWords)
 __global__ __launch_bounds__(256) void validate_cuts_kernel(const uint2 *__restrict__ cuts, const uint32_t *__restrict__ run_meta,
                                                            const uint32_t *__restrict__ run_dump, uint32_t *__restrict__ cut_ok) {
+    constexpr uint32_t Q = W / 4u;  // 16-byte quarters of an arm
     constexpr uint32_t kSlots = 16384;  // > 3 x kRunDumpCap
     __shared__ uint32_t s_tab[kSlots];
     __shared__ uint32_t s_ok;
@@ -2394,25 +2398,28 @@ __global__ __launch_bounds__(256) void validate_cuts_kernel(const uint2 *__restr
     if (threadIdx.x == 0) s_ok = meta_ok ? 1u : 0u;
     __syncthreads();
     if (meta_ok) {
-        const uint4 *da = reinterpret_cast<const uint4 *>(run_dump + (size_t)cut.x * 2 * kRunDumpCap * 8);
-        const uint4 *db = reinterpret_cast<const uint4 *>(run_dump + ((size_t)cut.y * 2 + 1) * kRunDumpCap * 8);
+        const uint4 *da = reinterpret_cast<const uint4 *>(run_dump + (size_t)cut.x * 2 * kRunDumpCap * W);
+        const uint4 *db = reinterpret_cast<const uint4 *>(run_dump + ((size_t)cut.y * 2 + 1) * kRunDumpCap * W);
         for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) {
-            uint32_t h = (da[2 * j].x * 2654435761u) >> 18;
+            uint32_t h = (da[Q * j].x * 2654435761u) >> 18;
             while (atomicCAS(&s_tab[h], 0u, j + 1u) != 0u) h = (h + 1u) & (kSlots - 1u);
         }
         __syncthreads();
         bool ok = true;
         for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) {
-            const uint4 b0 = db[2 * j], b1 = db[2 * j + 1];
+            const uint4 b0 = db[Q * j];
             uint32_t h = (b0.x * 2654435761u) >> 18;
             bool found = false;
             for (uint32_t probe = 0; probe < kSlots; ++probe) {
                 const uint32_t e = s_tab[h];
                 if (!e) break;
-                const uint4 a0 = da[2 * (e - 1u)];
-                if (a0.x == b0.x) {
-                    const uint4 a1 = da[2 * (e - 1u) + 1];
-                    found = a0.y == b0.y && a0.z == b0.z && a0.w == b0.w && a1.x == b1.x && a1.y == b1.y && a1.z == b1.z;
+                const uint4 a0 = da[Q * (e - 1u)];
+                if (a0.x == b0.x) {  // (creation numbers are unique within a dump)
+                    found = a0.y == b0.y && a0.z == b0.z && a0.w == b0.w;
+                    for (uint32_t q = 1; q < Q; ++q) {
+                        const uint4 a = da[Q * (e - 1u) + q], b = db[Q * j + q];
+                        found = found && a.x == b.x && a.y == b.y && a.z == b.z && a.w == b.w;
+                    }
                     break;
                 }
                 h = (h + 1u) & (kSlots - 1u);

@@ -1341,7 +1341,8 @@ def test_k8_free_counts_do_not_depend_on_timing(hiplib, delay, monkeypatch):
 
 
 @pytest.mark.parametrize("shape", [(256, 128, 512, 0), (256, 1024, 512, 0), (128, 512, 256, 0), (256, 128, 512, 1024), (128, 64, 256, 24576)])
-def test_long_segments_as_ranges_equal_whole_segments(hiplib, shape):
+@pytest.mark.parametrize("wide", [0, 1])
+def test_long_segments_as_ranges_equal_whole_segments(hiplib, shape, wide, monkeypatch):
     """Option split: a long segment runs as RANGES side by side -- every range starts from an empty arm list split_warm
     probes in front of its cut, and what it holds at the cut (every arm, every field; family open or not; a held flush) is
     compared on the device with what the range in front of the cut holds there.  Where the cuts hold, the ranges' records
@@ -1353,10 +1354,12 @@ def test_long_segments_as_ranges_equal_whole_segments(hiplib, shape):
     tools/fuzz_k8.py with ranges of 128-256 probes (the shipped 8192 never cut a test-sized segment), every multi-hit
     segment forced through the long shape, generation wraps every few probes in some cases: families, ProtoSDs AND keys
     equal to the uncut run and to the oracle, for single calls and for both orientations as one job; both outcomes
-    (joined up / refused) must occur over the cases."""
+    (joined up / refused) must occur over the cases.  wide = 1: the same with 64-bit positions (ASGART_FORCE_WIDE: the
+    instantiations a text of 2^32 bases and more runs -- four layers of arms, dumps of twelve words per arm)."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import fuzz_k8
 
+    monkeypatch.setenv("ASGART_FORCE_WIDE", str(wide))
     ln, warm, mn, warm_max = shape
     n_grow = 0
     while warm_max and (warm << n_grow) < warm_max:
@@ -1429,14 +1432,17 @@ def test_long_segments_as_ranges_equal_whole_segments(hiplib, shape):
 
 
 @pytest.mark.parametrize("block", range(6))
-def test_randomised_cut_cases_against_the_oracle(hiplib, block):
+def test_randomised_cut_cases_against_the_oracle(hiplib, block, monkeypatch):
     """The randomised evidence of the range scheme, on the driver's box: 60 cases of tools/fuzz_k8.py (tandem arrays of
     3-400 bp monomers, random probe size / gap / minimum length, 3- and 4-bit table generations among them) with the long
     segments cut into ranges of 128-256 probes, every multi-hit segment forced through the long shape.  Per case: both
     orientations as single calls, both as ONE job, and both as one job over 2 shards merged by key -- families and
-    ProtoSDs equal to the ORACLE's, twice (the second round plans only the cuts that held)."""
+    ProtoSDs equal to the ORACLE's, twice (the second round gives the segments with a failed cut a longer warm-up).  Odd
+    blocks run with 64-bit positions (ASGART_FORCE_WIDE)."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import fuzz_k8
+
+    monkeypatch.setenv("ASGART_FORCE_WIDE", str(block % 2))
 
     shapes = ((256, 128, 512), (128, 512, 256), (256, 1024, 512))
     cut = refused = 0
