@@ -353,12 +353,13 @@ struct SearchCall {
     }
 
     // Workspace::split_buf: [4 counters (u64): runs, cuts, split segments, work cursor | runs | cuts | split segments |
-    // run states | verdicts per cut | per run: what is added to its records' family ordinals | segments to run again]
+    // run states | verdicts per cut | per run: what is added to its records' family ordinals | segments to run again | range
+    // size chosen | what earlier calls found out about segments with a cut that did not hold]
     static constexpr uint32_t kMaxRuns = 4096, kMaxCuts = 2048, kMaxSplits = 1024;
     static constexpr size_t kOffRuns = 64, kOffCuts = kOffRuns + kMaxRuns * sizeof(RangeRun), kOffSplits = kOffCuts + kMaxCuts * 8,
                      kOffMeta = kOffSplits + kMaxSplits * sizeof(SplitSeg), kOffOk = kOffMeta + kMaxRuns * 64,
                      kOffFix = kOffOk + kMaxCuts * 4, kOffAgain = kOffFix + kMaxRuns * 4, kOffChoice = kOffAgain + kMaxSplits * 4,
-                     kSplitBytes = kOffChoice + 128;
+                     kOffBlocked = kOffChoice + 128, kSplitBytes = kOffBlocked + kSplitBlockedMax * sizeof(BlockedSeg);
     static_assert(sizeof(SplitChoice) <= 128 && kOffChoice % 8 == 0, "split choice");
     static_assert(kSplitBytes <= kSplitMirror, "split mirror");
 
@@ -723,17 +724,17 @@ struct SearchCall {
             sp.max_splits = kMaxSplits;
             {   // segments a cut of which failed in an earlier call of this index with these settings and chunks, if this
                 // call's windows hold them: as probe numbers of THIS call (the newest verdicts first)
+                BlockedSeg *const h_blocked = reinterpret_cast<BlockedSeg *>(h_split + kOffBlocked);
                 std::lock_guard<std::mutex> lk(idx->mu);
                 for (auto b = idx->split_blocked.rbegin(); b != idx->split_blocked.rend(); ++b)
                     for (int32_t p_ = 0; p_ < n_passes && sp.n_blocked < kSplitBlockedMax; ++p_)
                         if (b->sig == call_sig && ((rp.modes >> (8 * p_)) & 0xFFu) == (uint32_t)(b->key >> 32) &&
-                            (uint32_t)b->key >= lo_lim && (uint32_t)b->key < hi_lim) {
-                            sp.blocked[sp.n_blocked] = (uint32_t)p_ * K + ((uint32_t)b->key - lo_lim);
-                            sp.blocked_len[sp.n_blocked] = b->range_len;
-                            sp.blocked_warm[sp.n_blocked] = b->warm;
-                            sp.allowed[sp.n_blocked++] = (uint16_t)std::min<uint32_t>(b->allowed, 0xFFFFu);
-                        }
+                            (uint32_t)b->key >= lo_lim && (uint32_t)b->key < hi_lim)
+                            h_blocked[sp.n_blocked++] = BlockedSeg{(uint32_t)p_ * K + ((uint32_t)b->key - lo_lim), b->range_len, b->allowed, b->warm};
             }
+            sp.blocked = reinterpret_cast<const BlockedSeg *>(d_split + kOffBlocked);
+            if (sp.n_blocked)
+                HIP_TRY(hipMemcpyAsync(d_split + kOffBlocked, h_split + kOffBlocked, (size_t)sp.n_blocked * sizeof(BlockedSeg), hipMemcpyHostToDevice, s));
             SplitChoice *const d_choice = reinterpret_cast<SplitChoice *>(d_split + kOffChoice);
             if (!sp.range_len) {  // the range length by budget
                 HIP_TRY(hipMemsetAsync(d_choice, 0, sizeof(SplitChoice), s));
@@ -1126,18 +1127,24 @@ struct SearchCall {
             };
             std::vector<uint32_t> held_base;  // family-ordinal bases of the ranges whose records wait for their segment's last run
             std::vector<Tail> tails;
-            // What the index remembers about a segment a cut of which did not hold (allowed: how many of its cuts, from the start,
-            // held; warm_used: the warm-up its ranges had; 0: do not grow it).  While the warm-up can still grow (option
-            // split_warm_max) the next call gives this segment's ranges twice as much and plans all its cuts again -- a shard of a
-            // genome-sized call gets short ranges with short warm-ups, and its tandem arrays need the 6 144 probes the
-            // unsharded call's ranges have: left at "only the cuts that held", the rest of such a segment became one long last
-            // range, the longest work item of the shard (81 ms of a 90-ms shard).  At the limit: only the cuts that held.
-            auto remember = [&](uint32_t g_seg0, uint32_t allowed, uint32_t warm_used) {
+            // What the index remembers about a segment a cut of which did not hold.  allowed: how many of its cuts, from the start,
+            // held; warm_used: the warm-up its ranges had (0: the warm-up is not the matter); need: how far in front of the failed
+            // cut the oldest arm of the range before it was born (probes; 0: it held no arm) -- a run that is to hold that arm at
+            // the cut has to start in front of its birth.  While a warm-up of that size is still worth a range (no longer than
+            // two ranges, nor than option split_warm_max) the next call gives this segment's ranges that much and plans all its
+            // cuts again: a shard of a genome-sized call gets short ranges with short warm-ups, and with "only the cuts that
+            // held" the rest of such a segment became one long last range, the longest work item of the shard (81 ms of a 90-ms
+            // shard).  A cut that failed although every arm was born inside the warm-up (thresholds that had not settled) gets
+            // twice the warm-up, under the same limit.  Beyond the limit -- the arms of a flat tandem array live from its first
+            // probe to its last, those of a chromosome run against its homologue for megabases: every run would walk the
+            // stretch again from its start -- only the cuts that held are planned again.
+            auto remember = [&](uint32_t g_seg0, uint32_t allowed, uint32_t warm_used, uint32_t need) {
                 const uint32_t p_ = pass_of_probe(g_seg0);
                 const uint64_t key_ = (uint64_t)((rp.modes >> (8 * p_)) & 0xFFu) << 32 | (uint64_t)pass_offset(g_seg0);
                 const uint32_t len_ = (uint32_t)h_split_hdr[4];
-                const uint32_t warm_max = (uint32_t)opt.split_warm_max;
-                const uint32_t warm_next = (warm_used && warm_used < warm_max) ? std::min(2u * warm_used, warm_max) : 0u;
+                const uint64_t limit = std::min<uint64_t>((uint64_t)opt.split_warm_max, 2ull * len_);
+                const uint64_t want = need > warm_used ? (((uint64_t)need + 64u + 255u) & ~255ull) : 2ull * warm_used;
+                const uint32_t warm_next = (warm_used && want <= limit) ? (uint32_t)want : 0u;
                 if (warm_next) allowed = kAllCuts;
                 std::lock_guard<std::mutex> lk(idx->mu);
                 for (auto &b : idx->split_blocked)
@@ -1155,7 +1162,7 @@ struct SearchCall {
                 const uint32_t n_cuts_sg = sg.n_ranges - 1;
                 uint32_t f = n_cuts_sg;  // first cut that did not hold
                 for (uint32_t j = 0; j < n_cuts_sg; ++j)
-                    if (!h_ok[sg.cut_base + j]) {
+                    if (!(h_ok[sg.cut_base + j] & 1u)) {
                         f = j;
                         break;
                     }
@@ -1183,14 +1190,22 @@ struct SearchCall {
                             sg.g_seg0, sg.n_ranges, f);
                     for (uint32_t j = 0; j < n_cuts_sg; ++j) {
                         const uint32_t *ma = h_meta + (size_t)(sg.run_base + j) * 16, *mb = h_meta + (size_t)(sg.run_base + j + 1) * 16 + 8;
-                        fprintf(stderr, " %s%u/%u,%u/%u,%u/%u%s", h_ok[sg.cut_base + j] ? "" : "[", ma[0], mb[0], ma[2], mb[2], ma[3], mb[3],
-                                h_ok[sg.cut_base + j] ? "" : "]");
+                        fprintf(stderr, " %s%u/%u,%u/%u,%u/%u%s", (h_ok[sg.cut_base + j] & 1u) ? "" : "[", ma[0], mb[0], ma[2], mb[2], ma[3], mb[3],
+                                (h_ok[sg.cut_base + j] & 1u) ? "" : "]");
                     }
                     fprintf(stderr, "%s\n", last_gave_up ? " (the last range gave up)" : "");
                 }
                 if (!ok) {
                     ++n_split_refused;
-                    remember(sg.g_seg0, f, sg.warm);
+                    uint32_t need = 0;  // probes between the birth of the oldest arm in front of the failed cut and that cut
+                    if (f < n_cuts_sg) {
+                        const uint32_t born = (h_ok[sg.cut_base + f] >> 1) / (uint32_t)rp.step, at = h_runs[sg.run_base + f + 1].emit_from - sg.g_seg0;
+                        if ((h_ok[sg.cut_base + f] >> 1) != (0xFFFFFFFFu >> 10) && born <= at) need = at - born;
+                    }
+                    if (opt.debug)
+                        fprintf(stderr, "[asgart] ranges: segment at probe %u: cut %u did not hold with %u probes of warm-up; its oldest arm was born %u probes in front of it\n",
+                                sg.g_seg0, f, sg.warm, need);
+                    remember(sg.g_seg0, f, last_gave_up ? 0u : sg.warm, need);
                     if (f == 0) h_again[n_again++] = sg.g_seg0;
                 }
             }
@@ -1233,7 +1248,7 @@ struct SearchCall {
                     for (uint32_t j = 0; j <= t.f; ++j, ++hb) h_fix[t.run_base + j] = gave_up ? 0xFFFFFFFFu : held_base[hb];
                     if (gave_up) {
                         h_again[n_again++] = t.g_seg0;
-                        remember(t.g_seg0, 0u, 0u);  // (more arms than the long shape holds: not a matter of the warm-up)
+                        remember(t.g_seg0, 0u, 0u, 0u);  // (more arms than the long shape holds: not a matter of the warm-up)
                     }
                 }
                 HIP_TRY(hipMemcpyAsync(d_split + kOffFix, h_fix, kOffAgain - kOffFix, hipMemcpyHostToDevice, s));

@@ -2268,18 +2268,22 @@ __global__ void split_pick_kernel(SplitChoice *choice, uint32_t budget) {
     choice->min_span = 3u * choice->warm;               // (two ranges of a shorter segment are each nearly the segment)
 }
 
-constexpr uint32_t kSplitBlockedMax = 128;  // verdicts of earlier calls handed to one call (kernel argument space)
+constexpr uint32_t kSplitBlockedMax = 2048;  // verdicts of earlier calls handed to one call
+// what an earlier call of the index found out about a segment a cut of which did not hold
+struct BlockedSeg {
+    uint32_t g0;         // the segment (first probe, in this call's numbering)
+    uint32_t range_len;  // at which range length (the verdict means nothing at another)
+    uint32_t allowed;    // how many of its cuts, counted from the segment's start, are planned again (kAllCuts: all of them)
+    uint32_t warm;       // the warm-up its ranges get from now on (0: the call's)
+};
+constexpr uint32_t kAllCuts = 0xFFFFFFFFu;
 struct SplitParams {
     uint32_t range_len, warm, min_span;   // size of a range (probe positions; range_len = 0: cost units, as split_pick_kernel chose),
                                           // warm-up probes in front of a cut, shortest segment that is cut
     uint32_t max_runs, max_cuts, max_splits;
     uint32_t n_blocked;
-    uint32_t blocked[kSplitBlockedMax];      // segments (first probe) a cut of which did not hold in an earlier call of the index ...
-    uint16_t allowed[kSplitBlockedMax];      // ... and how many of their cuts, counted from the segment's start, held (0: not cut again)
-    uint32_t blocked_len[kSplitBlockedMax];  // ... at which range length (the count means nothing at another)
-    uint32_t blocked_warm[kSplitBlockedMax]; // ... and the warm-up this segment's ranges get from now on (0: the call's)
+    const BlockedSeg *blocked;            // segments a cut of which did not hold in an earlier call of the index
 };
-constexpr uint16_t kAllCuts = 0xFFFFu;       // SplitParams::allowed: no limit (the verdict only asks for a longer warm-up)
 __global__ __launch_bounds__(256) void plan_ranges_kernel(RunParams rp, SplitParams sp, const uint32_t *__restrict__ p_filt,
                                                          const uint32_t *__restrict__ seg_list,
                                                          const unsigned long long *__restrict__ n_seg_ptr,
@@ -2302,22 +2306,24 @@ __global__ __launch_bounds__(256) void plan_ranges_kernel(RunParams rp, SplitPar
     const uint32_t span = info.y & 0x7FFFFFFFu;
     if (span < sp.min_span || !split_eligible(rp, key, info)) return;
     const uint32_t g0 = seg_list[sj];
-    // a segment a cut of which did not hold in an earlier call: its ranges start further in front of their cuts (the warm-up
-    // doubles from call to call up to option split_warm_max), and at that limit only the cuts that held are planned again
+    // a segment a cut of which did not hold in an earlier call: its ranges start as far in front of their cuts as the oldest
+    // arm at the failed cut asked for -- or, where that is further than a range is worth, only the cuts that held are planned again
     uint32_t warm = sp.warm;
     uint32_t n_cut_max = 0xFFFFFFFFu;
-    for (uint32_t b = 0; b < sp.n_blocked; ++b)
-        if (sp.blocked[b] == g0 && sp.blocked_len[b] == sp.range_len) {
-            if (sp.allowed[b] != kAllCuts) n_cut_max = min(n_cut_max, (uint32_t)sp.allowed[b]);
-            warm = max(warm, sp.blocked_warm[b]);
+    for (uint32_t b = 0; b < sp.n_blocked; ++b) {
+        const BlockedSeg v = sp.blocked[b];
+        if (v.g0 == g0 && v.range_len == sp.range_len) {
+            n_cut_max = min(n_cut_max, v.allowed);
+            warm = max(warm, v.warm);
         }
+    }
     // ranges of about range_len probe positions each, at least two, their cuts at equal shares of the segment; a segment whose
     // cuts held only up to some point in an earlier call keeps those cuts (same places) and runs the rest as its last range
     // (cuts at equal shares of positions + hits / w instead were measured at GRCh38 size and did not move the step: DESIGN_HISTORY.md)
     const unsigned long long total = span, unit = sp.range_len;
     if (total < 2ull * unit) return;
     const uint32_t n_r_all = (uint32_t)min(1024ull, max(2ull, (total + unit / 2ull) / unit));
-    const uint32_t n_r = min(n_r_all, n_cut_max == 0xFFFFFFFFu ? n_r_all : n_cut_max + 1u);
+    const uint32_t n_r = min(n_r_all, n_cut_max == kAllCuts ? n_r_all : n_cut_max + 1u);
     if (n_r < 2u) return;
     auto cut_of = [&](uint32_t j) -> uint32_t {  // first hit-probe at or behind the j-th share of the cost (0: none)
         uint32_t c = g0 + (uint32_t)(total / n_r_all * j);
@@ -2388,15 +2394,25 @@ __global__ __launch_bounds__(256) void validate_cuts_kernel(const uint2 *__restr
     constexpr uint32_t Q = W / 4u;  // 16-byte quarters of an arm
     constexpr uint32_t kSlots = 16384;  // > 3 x kRunDumpCap
     __shared__ uint32_t s_tab[kSlots];
-    __shared__ uint32_t s_ok;
+    __shared__ uint32_t s_ok, s_oldest;
     const uint2 cut = cuts[blockIdx.x];
     // (x: the run in front of the cut, its end state; y: the run behind it, its state at the cut)
     const uint32_t *ma = run_meta + (size_t)cut.x * 16, *mb = run_meta + (size_t)cut.y * 16 + 8;
     const uint32_t n = ma[0];
     const bool meta_ok = n == mb[0] && n <= kRunDumpCap && ma[2] == mb[2] && ma[3] == mb[3] && !ma[4] && !run_meta[(size_t)cut.y * 16 + 4];
     for (uint32_t j = threadIdx.x; j < kSlots; j += blockDim.x) s_tab[j] = 0u;
-    if (threadIdx.x == 0) s_ok = meta_ok ? 1u : 0u;
+    if (threadIdx.x == 0) {
+        s_ok = meta_ok ? 1u : 0u;
+        s_oldest = 0xFFFFFFFFu;
+    }
     __syncthreads();
+    {   // the oldest arm the range in front of the cut holds there (its creation number: where in the segment it was born): a
+        // run that is to hold it at the cut must start in front of that probe -- what the host sizes the next warm-up by
+        const uint4 *da = reinterpret_cast<const uint4 *>(run_dump + (size_t)cut.x * 2 * kRunDumpCap * W);
+        uint32_t oldest = 0xFFFFFFFFu;
+        for (uint32_t j = threadIdx.x; j < min(n, kRunDumpCap); j += blockDim.x) oldest = min(oldest, da[Q * j].x);
+        if (oldest != 0xFFFFFFFFu) atomicMin(&s_oldest, oldest);
+    }
     if (meta_ok) {
         const uint4 *da = reinterpret_cast<const uint4 *>(run_dump + (size_t)cut.x * 2 * kRunDumpCap * W);
         const uint4 *db = reinterpret_cast<const uint4 *>(run_dump + ((size_t)cut.y * 2 + 1) * kRunDumpCap * W);
@@ -2429,7 +2445,9 @@ __global__ __launch_bounds__(256) void validate_cuts_kernel(const uint2 *__restr
         if (!ok) s_ok = 0u;
     }
     __syncthreads();
-    if (threadIdx.x == 0) cut_ok[blockIdx.x] = s_ok;
+    // (bit 0: the cut holds; above it: needle offset, counted from the segment's first probe, at which the oldest arm was born --
+    // all ones: no arm)
+    if (threadIdx.x == 0) cut_ok[blockIdx.x] = s_ok | ((s_oldest >> 10) << 1);
 }
 
 // run_fix[run]: what is added to the family ordinals of the run's records; ~0u: the run's records are dropped; ~0u - 1: not

@@ -1348,9 +1348,10 @@ def test_long_segments_as_ranges_equal_whole_segments(hiplib, shape, wide, monke
     compared on the device with what the range in front of the cut holds there.  Where the cuts hold, the ranges' records
     (family ordinals counted on from the ranges before, creation order by (probe, hit)) must be the whole segment's; where
     one does not, the ranges in front of it stand, the rest of the segment runs as ONE more run from a checked state (the whole
-    segment again when its first cut fails), and the index gives that segment's ranges twice the warm-up in the next call, up
-    to option split_warm_max (the shape's 4th number; 0: never), and from there on plans only the cuts that held: after
-    log2(split_warm_max / split_warm) + 2 calls nothing is refused any more.  Tandem-array cases of
+    segment again when its first cut fails), and the index gives that segment's ranges a longer warm-up in the next call -- as
+    far back as the oldest arm at the failed cut was born, or twice the last one -- while that stays within two ranges and
+    option split_warm_max (the shape's 4th number; 0: never); beyond, it plans only the cuts that held: after
+    log2(limit / split_warm) + 2 calls nothing is refused any more.  Tandem-array cases of
     tools/fuzz_k8.py with ranges of 128-256 probes (the shipped 8192 never cut a test-sized segment), every multi-hit
     segment forced through the long shape, generation wraps every few probes in some cases: families, ProtoSDs AND keys
     equal to the uncut run and to the oracle, for single calls and for both orientations as one job; both outcomes
@@ -1362,7 +1363,7 @@ def test_long_segments_as_ranges_equal_whole_segments(hiplib, shape, wide, monke
     monkeypatch.setenv("ASGART_FORCE_WIDE", str(wide))
     ln, warm, mn, warm_max = shape
     n_grow = 0
-    while warm_max and (warm << n_grow) < warm_max:
+    while (warm << n_grow) < min(warm_max, 2 * ln):
         n_grow += 1
     joined = refused = sharded_cut = 0
     for seed in (1, 4, 5, 6, 8, 11, 101, 107, 117, 123):
