@@ -181,7 +181,7 @@ struct SearchCtx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr, stream3 = nullptr, stream4 = nullptr;  // concurrent extension tiers
     hipStream_t stream5 = nullptr, stream6 = nullptr, stream7 = nullptr;
-    hipEvent_t ev[16] = {};
+    hipEvent_t ev[17] = {};
     Workspace ws;
     asgart_stats stats;
     RunParams last_rp;   // inputs of the last call, kept for the yardstick kernel
@@ -306,11 +306,12 @@ struct Options {
     int64_t fuse_passes = 1;        // asgart_search_duplications_passes, passes that differ in orientation only: 2 = always as ONE job (one
                                     // front over all their probes, one launch per extension tier over the merged segment list); 0 = always
                                     // as pipelined single-pass calls on the two call contexts; 1 = the first call
-                                    // with given settings runs as one job, and what it measures decides for the calls after it: one job
-                                    // while the extension is bound by compute-unit time (the longest single segment below fuse_pole_pct
-                                    // per cent of the extension: GRCh38-shaped 230 vs 255 ms), pipelined calls when ONE segment is the
-                                    // extension (a megabase higher-order array, a chromosome against its homologue: the other pass's
-                                    // front then hides beside it -- 393 vs 466 ms, 2 071 vs 2 178 ms)
+                                    // with given settings runs as one job; while the extension is bound by compute-unit time (the longest
+                                    // single segment below fuse_pole_pct per cent of the extension: GRCh38-shaped 125 vs 165 ms) so do
+                                    // the calls after it; when ONE segment is the extension (a megabase higher-order array, a chromosome
+                                    // against its homologue: the other pass's front may hide beside it -- 393 vs 466 ms, 2 071 vs
+                                    // 2 178 ms) the next calls are TIMED both ways, two each, and the faster way is kept (a GRCh38-shaped
+                                    // step sits at 85-87 per cent: a guess at the threshold would cost it 40 ms)
     int64_t fuse_pole_pct = 88;
     int64_t lazy_aux = 1;           // 1: no presence filter is BUILT: the position bits of an orientation start all ones and its first search
                                     // clears, as a by-product of its lookups, the bit of every probe without an occurrence that could be
@@ -334,8 +335,11 @@ struct Options {
                                     // shortest segment cut twice it -- a small job gets short ranges, a genome-sized one long ones
     int64_t split_runs = 224;       // ... that budget: every run holds a compute unit while it runs
     int64_t split_warm = 6144;      // (split_len > 0) probes a range starts in front of its cut
-    int64_t split_warm_max = 24576; // a segment with a cut that did not hold gets twice the warm-up in the next call, up to this many probes
-                                    // (then only the cuts that held are planned again); 0: never grown
+    int64_t split_warm_max = 65536; // a segment with a cut that did not hold gets a longer warm-up in the next call -- as far back as the oldest
+                                    // arm in front of the failed cut was born, or twice the last one -- while that stays within two ranges
+                                    // and this many probes (beyond: only the cuts that held are planned again); 0: never grown.  (A
+                                    // repeat-rich GRCh38-sized input with megabase higher-order arrays, ranges of 24 576 probes: 24 of 24 cut
+                                    // segments fail at 6 144 probes of warm-up, 13 at 12 288, 3 at 24 576, 1 at 49 152: 349 -> 256 ms per step)
     int64_t split_min = 0;          // segments shorter than this (probe positions) are not cut (split_len = 0: at least this)
     int64_t cache_calls = 2;        // the blocks an index build released stay in the block cache until the index has answered this many
                                     // search PASSES (a direct + -RC passes call counts two) (then, at its destruction, on an allocation failure and by asgart_trim_cache they go
@@ -448,12 +452,15 @@ struct asgart_index {
     int last_ctx = 0;  // context of the most recent search call (asgart_get_stats)
     std::mutex mu;
     std::condition_variable cv;
-    // what the last fused passes call measured, and under which settings (option fuse_passes = 1)
+    // what the passes calls with one set of settings have measured so far (option fuse_passes = 1): whether ONE segment is
+    // the extension of the job (the last call that ran as one job says), and -- only then -- the shortest call each way
     struct FuseVerdict {
         uint64_t k = 0, M = 0, C = 0, modes = 0;
         uint32_t G = 0;
         int32_t n_passes = 0, shard = 0, n_shards = 1;
-        bool pipeline = false;
+        bool seen = false, pole = false;
+        int32_t n_fused = 0, n_piped = 0;      // calls timed each way
+        double ms_fused = 1e30, ms_piped = 1e30;
     } fuse_verdict;
     // segments a cut of which did not hold (option split): orientation << 32 | first probe counted from the start of its pass,
     // under which settings and chunk list (sig), how many of their cuts, from the start, held (only those are planned again)

@@ -561,13 +561,18 @@ struct SearchCall {
             return ASGART_E_CAP;
         }
         // ---- K3: CSR fill -----------------------------------------------------------
+        // On a stream of its own (idle until the tiers are launched; the main stream has just been drained): the placement
+        // walk, which reads the per-probe counts only, runs beside it -- the fill is bound by the suffix-array intervals it
+        // gathers, the walk by its round trips.  Whoever needs the hit rows waits for ev[3].
         RC_TRY(w.hits.reserve((size_t)(total_hits + 64) * sizeof(SlotT)));
         hits = w.hits.as<SlotT>();
-        fill_small_kernel<SlotT><<<rp.n_tiles(256u), 256, 0, s>>>(ix, rp, p_lo, p_raw, p_filt, row_off, hits);
+        hipStream_t sf = cx.stream2;
+        HIP_TRY(hipEventRecord(cx.ev[16], sf));
+        fill_small_kernel<SlotT><<<rp.n_tiles(256u), 256, 0, sf>>>(ix, rp, p_lo, p_raw, p_filt, row_off, hits);
         if (h_ctr[CT_BIG])
-            fill_big_kernel<SlotT><<<2048, 256, 0, s>>>(ix, rp, p_lo, p_raw, p_filt, row_off, hits,
-                                                        big_list, d_ctr);
-        HIP_TRY(hipEventRecord(cx.ev[3], s));
+            fill_big_kernel<SlotT><<<2048, 256, 0, sf>>>(ix, rp, p_lo, p_raw, p_filt, row_off, hits,
+                                                         big_list, d_ctr);
+        HIP_TRY(hipEventRecord(cx.ev[3], sf));
         HIP_TRY(hipGetLastError());
 
         return 0;
@@ -702,6 +707,7 @@ struct SearchCall {
                 rp, p_filt, seg_list, d_ctr + CT_LONGSEG, long_list, kbuf, vbuf, pp, d_ctr);
         }
         HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamWaitEvent(s, cx.ev[3], 0));  // the hit rows (front(): filled beside the walk above)
         if (cluster_barren) {
             HIP_TRY(hipEventRecord(cx.ev[13], s));
             // barren by position (cluster_barren_kernel): a wave per segment, two bitmap sizes (2 KB: 32 waves per compute
@@ -810,8 +816,8 @@ struct SearchCall {
                 float ms_a = 0.f, ms_b = 0.f, ms_p = 0.f;
                 (void)hipEventElapsedTime(&ms_a, cx.ev[13], cx.ev[14]);
                 (void)hipEventElapsedTime(&ms_b, cx.ev[14], cx.ev[15]);
-                (void)hipEventElapsedTime(&ms_p, cx.ev[3], cx.ev[13]);
-                fprintf(stderr, "[asgart] placement walk %.2f ms; barren by position: segments of up to 1 024 hits %.2f ms, up to 16 384 hits %.2f ms\n",
+                (void)hipEventElapsedTime(&ms_p, cx.ev[16], cx.ev[13]);
+                fprintf(stderr, "[asgart] hit rows filled, placement walk beside it: %.2f ms; barren by position: segments of up to 1 024 hits %.2f ms, up to 16 384 hits %.2f ms\n",
                         ms_p, ms_a, ms_b);
             }
         }
@@ -1467,7 +1473,7 @@ struct SearchCall {
         stt.ms_search = ms;
         HIP_TRY(hipEventElapsedTime(&ms, cx.ev[1], cx.ev[2]));
         stt.ms_scan = ms;
-        HIP_TRY(hipEventElapsedTime(&ms, cx.ev[2], cx.ev[3]));
+        HIP_TRY(hipEventElapsedTime(&ms, cx.ev[16], cx.ev[3]));
         stt.ms_fill = ms;
         HIP_TRY(hipEventElapsedTime(&ms, cx.ev[3], cx.ev[4]));
         stt.ms_extend = ms;
@@ -1518,6 +1524,8 @@ struct SearchCall {
                 look_back *= 8;
                 continue;
             }
+            // (the hit rows are being filled on a stream of their own; place() waits for them where it needs them)
+            if (want_csr || !(fam_out && n_seg)) HIP_TRY(hipStreamWaitEvent(s, cx.ev[3], 0));
             if (want_csr) RC_TRY(csr_out());
             if (fam_out && n_seg) {
                 RC_TRY(place());
@@ -1824,6 +1832,7 @@ int32_t asgart_search_duplications_passes_shard(asgart_index *idx, const uint64_
     // of every pass (run_search_t: one window per pass).  (Pipelined as two calls on two contexts -- below, kept for
     // passes with different settings and for inputs whose extension is ONE segment -- the second pass's front crawled
     // behind the first one's persistent extension workgroups: 117 ms instead of 28 at GRCh38 size.)
+    bool timed_pipelined = false;
     {
         bool fusable = idx->opt.fuse_passes != 0 && n_passes >= 2 && n_passes <= 4;  // (option fuse_passes)
         for (int32_t j = 1; fusable && j < n_passes; ++j)
@@ -1846,14 +1855,24 @@ int32_t asgart_search_duplications_passes_shard(asgart_index *idx, const uint64_
                    v.M == settings[0].min_duplication_length && v.C == settings[0].max_cardinality && v.modes == modes_sig &&
                    v.shard == shard && v.n_shards == n_shards;
         };
-        // what the last fused call with these settings measured decides -- for an unsharded call: what pipelining can win is
-        // the other passes' front beside the one long segment, and a shard's front is 1/N of it, while the second pass's
-        // front crawling behind the first one's persistent workgroups costs a shard as much as it costs the whole call
-        // (GRCh38-shaped, the shards of N = 8 timed alone: 32-64 ms as one job, 47-78 ms pipelined)
-        if (fusable && idx->opt.fuse_passes == 1 && n_shards == 1) {
+        // What the calls with these settings have measured decides -- for an unsharded call: what pipelining can win is the
+        // other passes' front beside the one long segment, and a shard's front is 1/N of it, while the second pass's front
+        // crawling behind the first one's persistent workgroups costs a shard as much as it costs the whole call (GRCh38-
+        // shaped, the shards of N = 8 timed alone: 32-64 ms as one job, 47-78 ms pipelined).  Once a call that ran as one
+        // job has seen ONE segment be its extension, the calls are timed both ways in turn (one job, pipelined, one job,
+        // pipelined) and the faster way is kept.
+        const bool may_pipeline = fusable && idx->opt.fuse_passes == 1 && n_shards == 1;
+        if (may_pipeline) {
             std::lock_guard<std::mutex> lk(idx->mu);
-            if (same_as_verdict() && idx->fuse_verdict.pipeline) fusable = false;
+            const asgart_index::FuseVerdict &v = idx->fuse_verdict;
+            if (same_as_verdict()) {
+                if (v.n_fused >= 2 && v.n_piped >= 2) fusable = v.ms_fused <= v.ms_piped;  // (measured: stands from here on)
+                else if (v.pole && v.n_piped < 2 && v.n_piped < v.n_fused) fusable = false;
+            }
         }
+        const auto t_call0 = std::chrono::steady_clock::now();
+        auto call_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call0).count(); };
+        timed_pipelined = may_pipeline && !fusable;  // (the pipelined path below is timed where it returns)
         if (fusable) {
             std::lock_guard<std::mutex> pass_lock(idx->pass_mu);
             struct Owns {
@@ -1876,27 +1895,52 @@ int32_t asgart_search_duplications_passes_shard(asgart_index *idx, const uint64_
                 return rc;
             }
             for (int32_t j = 0; j < n_passes; ++j) out[j] = fams[(size_t)j];
-            {   // one segment IS the extension: the passes are better pipelined (the other pass's front beside that segment)
+            {   // is one segment the extension?  (then the passes MAY be better pipelined: the other pass's front beside it)
+                const double ms = call_ms();
                 std::lock_guard<std::mutex> lk(idx->mu);
                 const asgart_stats &stt = idx->ctx[idx->last_ctx].stats;
                 asgart_index::FuseVerdict &v = idx->fuse_verdict;
-                v.n_passes = n_passes;
-                v.k = settings[0].probe_size;
-                v.G = settings[0].max_gap_size;
-                v.M = settings[0].min_duplication_length;
-                v.C = settings[0].max_cardinality;
-                v.modes = modes_sig;
-                v.shard = shard;
-                v.n_shards = n_shards;
-                v.pipeline = n_shards == 1 && stt.passes == (uint64_t)n_passes && stt.ms_extend > 0.0 &&
-                             stt.ms_longest_segment * 100.0 > stt.ms_extend * (double)idx->opt.fuse_pole_pct;
+                if (!same_as_verdict()) {
+                    v = asgart_index::FuseVerdict{};
+                    v.n_passes = n_passes;
+                    v.k = settings[0].probe_size;
+                    v.G = settings[0].max_gap_size;
+                    v.M = settings[0].min_duplication_length;
+                    v.C = settings[0].max_cardinality;
+                    v.modes = modes_sig;
+                    v.shard = shard;
+                    v.n_shards = n_shards;
+                }
+                const bool pole = n_shards == 1 && stt.passes == (uint64_t)n_passes && stt.ms_extend > 0.0 &&
+                                  stt.ms_longest_segment * 100.0 > stt.ms_extend * (double)idx->opt.fuse_pole_pct;
+                if (v.seen) {  // (the first call with these settings is not timed: it may be the index's first)
+                    ++v.n_fused;
+                    v.ms_fused = std::min(v.ms_fused, ms);
+                }
+                v.seen = true;
+                v.pole = pole;
                 if (idx->opt.debug)
-                    fprintf(stderr, "[asgart] passes as one job: longest segment %.1f ms of %.1f ms of extension -> the next call %s\n",
-                            stt.ms_longest_segment, stt.ms_extend, v.pipeline ? "pipelines the passes" : "runs as one job too");
+                    fprintf(stderr, "[asgart] passes as one job, %.1f ms: longest segment %.1f ms of %.1f ms of extension%s\n", ms,
+                            stt.ms_longest_segment, stt.ms_extend, pole ? " -> timed against pipelined calls" : "");
             }
             return 0;
         }
     }
+    // (pipelined: timed for the verdict when it was that verdict's choice)
+    struct TimedPipelined {
+        asgart_index *idx;
+        bool on;
+        std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+        bool ok = false;
+        ~TimedPipelined() {
+            if (!on || !ok) return;
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            std::lock_guard<std::mutex> lk(idx->mu);
+            ++idx->fuse_verdict.n_piped;
+            idx->fuse_verdict.ms_piped = std::min(idx->fuse_verdict.ms_piped, ms);
+            if (idx->opt.debug) fprintf(stderr, "[asgart] passes pipelined, %.1f ms (timed against the passes as one job)\n", ms);
+        }
+    } timed{idx, timed_pipelined};
     // issue order: longest extension first (what is known from earlier calls; an orientation never run yet
     // counts as longest, reversed ones ahead of the others: their tandem arrays are walked against the
     // whole text instead of the part behind the probe)
@@ -1965,6 +2009,7 @@ int32_t asgart_search_duplications_passes_shard(asgart_index *idx, const uint64_
             return rcs[p];
         }
     for (int32_t p = 0; p < n_passes; ++p) out[order[p]] = fams[p];
+    timed.ok = true;
     return 0;
 }
 

@@ -1521,24 +1521,30 @@ def test_fused_passes_equal_single_calls_keys_included(hiplib, name):
         assert idx.stats().as_dict()["passes"] == 1
         for j, g in zip((0, 3), got):
             assert all(np.array_equal(a, b) for a, b in zip(g, single[j]))
-        # the default (fuse_passes = 1) decides from what the first fused call measured: with the threshold at 1 % every
-        # extension counts as "one segment", so the call after the first one pipelines the passes; 1000 %: never
+        # the default (fuse_passes = 1) MEASURES: once a call that ran as one job has seen one segment be its extension (with the
+        # threshold at 1 % every extension counts as that), the calls are timed both ways in turn -- one job, pipelined, one
+        # job, pipelined -- and the faster way is kept; 1000 %: always one job
         idx.set_option("fuse_passes", 1)
-        for pct, want_passes in ((1, 1), (1000, 2)):
+        for pct in (1, 1000):
             idx.set_option("fuse_pole_pct", pct)
             sel = (0, 0) if pct == 1 else (0, 0, 3)   # (selections the index has no verdict for yet, with hits in them)
             pair = [sts[j] for j in sel]
-            first = idx.search_duplications_passes(pr.chunks, pair, with_keys=True)
-            st1 = idx.stats().as_dict()
-            assert st1["passes"] == len(sel)
-            # (the longest segment is measured in the workgroup tiers: an input whose segments all run on the one-wave tier
-            # has none, and stays one job)
-            pole = st1["ms_longest_segment"] * 100.0 > st1["ms_extend"] * pct
-            second = idx.search_duplications_passes(pr.chunks, pair, with_keys=True)
-            assert idx.stats().as_dict()["passes"] == (1 if (want_passes == 1 and pole) else len(sel)), (name, pct, st1)
-            for got in (first, second):
+            passes, poles = [], []
+            for call in range(7):
+                got = idx.search_duplications_passes(pr.chunks, pair, with_keys=True)
+                st1 = idx.stats().as_dict()
+                passes.append(st1["passes"])
+                # (the longest segment is measured in the workgroup tiers: an input whose segments all run on the one-wave tier
+                # has none, and stays one job)
+                if st1["passes"] == len(sel):
+                    poles.append(st1["ms_longest_segment"] * 100.0 > st1["ms_extend"] * pct)
                 for j, g in zip(sel, got):
-                    assert all(np.array_equal(a, b) for a, b in zip(g, single[j]))
+                    assert all(np.array_equal(a, b) for a, b in zip(g, single[j])), (name, pct, call)
+            n = len(sel)
+            if pct == 1 and all(poles):
+                assert passes[:5] == [n, n, 1, n, 1] and passes[5] == passes[6], (name, passes)
+            elif not any(poles):
+                assert passes == [n] * 7, (name, pct, passes)
 
 
 @pytest.mark.parametrize("skip_masked", [False, True])
