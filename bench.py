@@ -192,7 +192,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    # (default 5: a passes call that finds one segment to be its extension is followed by calls timed as one job and
+    # pipelined in turn -- asgart_amd/csrc/pipeline.hip, fuse_passes --: after five calls the library has settled)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default=os.environ.get("ASGART_BENCH_WORKLOAD", "cfg4"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fasta", nargs="+", default=None, help="real FASTA input(s) instead of the synthetic workload")
