@@ -271,9 +271,11 @@ int32_t asgart_search_duplications_ex(asgart_index *idx, const uint64_t *chunks,
  * chunks followed by pass 1's ... (chunk order inside each pass as in src/bin/asgart.rs:201-253), searched, scanned
  * and placed in one sweep at full chip rate, and every extension tier is ONE launch over the merged, cost-sorted
  * segment list, so that every pass's longest serial segments start at once on compute units of their own
- * (asgart_stats.passes tells).  The first such call measures: when ONE segment is the whole extension (its longest
- * single segment above option fuse_pole_pct = 88 % of the extension) the calls after it pipeline the passes instead --
- * the other pass's front then hides beside that segment; option fuse_passes = 2 / 0 forces either.  Otherwise (different
+ * (asgart_stats.passes tells).  An unsharded call that finds ONE segment to be its whole extension (its longest single
+ * segment above option fuse_pole_pct = 88 % of the extension: the other pass's front might hide beside that segment)
+ * makes the index TIME the calls that follow both ways in turn -- one job, pipelined single-pass calls, two each -- and
+ * keep the faster way for these settings; sharded calls always run as one job; option fuse_passes = 2 / 0 forces
+ * either.  Otherwise (different
  * settings) the library pipelines the passes as single calls: pass j+1 is issued the moment the chip-wide,
  * HBM-bound phases of pass j are over (probe search, scans, hit materialisation -- the moment the `progress`
  * array of a single call jumps), so its search runs beside pass j's extension automaton, whose tail is a few
