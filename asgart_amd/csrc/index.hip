@@ -96,6 +96,12 @@ int32_t create_ctx_streams(SearchCtx &cx) {
     for (hipStream_t *st : {&cx.stream2, &cx.stream3, &cx.stream4, &cx.stream5, &cx.stream6, &cx.stream7})
         HIP_TRY(hipStreamCreateWithPriority(st, hipStreamNonBlocking, least));
     for (auto &e : cx.ev) HIP_TRY(hipEventCreate(&e));
+    // The CSR fill runs on stream2 beside the placement walk -- unless the process has been told to make do with few
+    // hardware queues (GPU_MAX_HW_QUEUES below 6: several processes sharing one device, bench.py's one-device mode): streams
+    // that share a queue run one after the other, and a tier stream used in the front put the tiers of two ranks on one
+    // device behind one another (283 instead of 74 ms for a rank's shard).
+    const char *q = getenv("GPU_MAX_HW_QUEUES");
+    cx.fill_stream = (q && *q && atoi(q) < 6) ? cx.stream : cx.stream2;
     return 0;
 }
 

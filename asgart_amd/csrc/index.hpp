@@ -181,6 +181,8 @@ struct SearchCtx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr, stream3 = nullptr, stream4 = nullptr;  // concurrent extension tiers
     hipStream_t stream5 = nullptr, stream6 = nullptr, stream7 = nullptr;
+    hipStream_t fill_stream = nullptr;  // where the CSR fill runs beside the placement walk: stream2, or the main stream when
+                                        // hardware queues are scarce (create_ctx_streams)
     hipEvent_t ev[17] = {};
     Workspace ws;
     asgart_stats stats;
@@ -336,7 +338,7 @@ struct Options {
     int64_t split_runs = 224;       // ... that budget: every run holds a compute unit while it runs
     int64_t split_warm = 6144;      // (split_len > 0) probes a range starts in front of its cut
     int64_t split_warm_max = 65536; // a segment with a cut that did not hold gets a longer warm-up in the next call -- as far back as the oldest
-                                    // arm in front of the failed cut was born, or twice the last one -- while that stays within two ranges
+                                    // arm in front of the failed cut was born, or the longest this limit allows -- while that stays within two ranges
                                     // and this many probes (beyond: only the cuts that held are planned again); 0: never grown.  (A
                                     // repeat-rich GRCh38-sized input with megabase higher-order arrays, ranges of 24 576 probes: 24 of 24 cut
                                     // segments fail at 6 144 probes of warm-up, 13 at 12 288, 3 at 24 576, 1 at 49 152: 349 -> 256 ms per step)

@@ -566,7 +566,7 @@ struct SearchCall {
         // gathers, the walk by its round trips.  Whoever needs the hit rows waits for ev[3].
         RC_TRY(w.hits.reserve((size_t)(total_hits + 64) * sizeof(SlotT)));
         hits = w.hits.as<SlotT>();
-        hipStream_t sf = cx.stream2;
+        hipStream_t sf = cx.fill_stream;
         HIP_TRY(hipEventRecord(cx.ev[16], sf));
         fill_small_kernel<SlotT><<<rp.n_tiles(256u), 256, 0, sf>>>(ix, rp, p_lo, p_raw, p_filt, row_off, hits);
         if (h_ctr[CT_BIG])
@@ -1141,7 +1141,7 @@ struct SearchCall {
             // cuts again: a shard of a genome-sized call gets short ranges with short warm-ups, and with "only the cuts that
             // held" the rest of such a segment became one long last range, the longest work item of the shard (81 ms of a 90-ms
             // shard).  A cut that failed although every arm was born inside the warm-up (thresholds that had not settled) gets
-            // twice the warm-up, under the same limit.  Beyond the limit -- the arms of a flat tandem array live from its first
+            // the longest warm-up that limit allows.  Beyond the limit -- the arms of a flat tandem array live from its first
             // probe to its last, those of a chromosome run against its homologue for megabases: every run would walk the
             // stretch again from its start -- only the cuts that held are planned again.
             auto remember = [&](uint32_t g_seg0, uint32_t allowed, uint32_t warm_used, uint32_t need) {
@@ -1149,7 +1149,9 @@ struct SearchCall {
                 const uint64_t key_ = (uint64_t)((rp.modes >> (8 * p_)) & 0xFFu) << 32 | (uint64_t)pass_offset(g_seg0);
                 const uint32_t len_ = (uint32_t)h_split_hdr[4];
                 const uint64_t limit = std::min<uint64_t>((uint64_t)opt.split_warm_max, 2ull * len_);
-                const uint64_t want = need > warm_used ? (((uint64_t)need + 64u + 255u) & ~255ull) : 2ull * warm_used;
+                // (born inside the warm-up and still not the same arms: the longest warm-up a range is worth, at once -- a
+                // doubling per call took a two-genome call, 2-3 s each, five calls to settle)
+                const uint64_t want = need > warm_used ? (((uint64_t)need + 64u + 255u) & ~255ull) : (warm_used < limit ? limit : ~0ull);
                 const uint32_t warm_next = (warm_used && want <= limit) ? (uint32_t)want : 0u;
                 if (warm_next) allowed = kAllCuts;
                 std::lock_guard<std::mutex> lk(idx->mu);

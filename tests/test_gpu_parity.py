@@ -1349,7 +1349,7 @@ def test_long_segments_as_ranges_equal_whole_segments(hiplib, shape, wide, monke
     (family ordinals counted on from the ranges before, creation order by (probe, hit)) must be the whole segment's; where
     one does not, the ranges in front of it stand, the rest of the segment runs as ONE more run from a checked state (the whole
     segment again when its first cut fails), and the index gives that segment's ranges a longer warm-up in the next call -- as
-    far back as the oldest arm at the failed cut was born, or twice the last one -- while that stays within two ranges and
+    far back as the oldest arm at the failed cut was born, or the longest the limit allows -- while that stays within two ranges and
     option split_warm_max (the shape's 4th number; 0: never); beyond, it plans only the cuts that held: after
     log2(limit / split_warm) + 2 calls nothing is refused any more.  Tandem-array cases of
     tools/fuzz_k8.py with ranges of 128-256 probes (the shipped 8192 never cut a test-sized segment), every multi-hit

@@ -22,6 +22,10 @@ export ASGART_LAZY_AUX=0
 # ... and every step is issued through the passes call only (no back-to-back probe step with its single-pass launches):
 # a launch of the search kernels is then always the passes of a step as ONE job
 export ASGART_BENCH_MODE=library
+# ... always as ONE job (option fuse_passes = 2): the library's default may time a few early calls as pipelined single-pass
+# calls (fuse_passes = 1, once one segment is a call's extension), whose launches are half the size -- the timed region of a
+# default bench run lies behind that and is all one-job calls
+export ASGART_FUSE_PASSES=2
 PB="--steps 2 --warmup 1 --no-cpu-baseline"
 rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/${P}_stats" -o run -- python3 bench.py --workload "$WL" $PB > "$OUT/${P}_stats_bench.json" 2> "$OUT/${P}_stats_err.log"
 echo "stats rc=$?"
