@@ -22,6 +22,7 @@ namespace asgart {
 
 static thread_local char g_err[512] = "";
 thread_local bool tl_owns_pass_mu = false;
+thread_local int tl_pass_share = 1;
 
 // Runtime note.  The extension tiers of one call run on six HIP streams (twelve with
 // two calls in flight); ROCm maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and kernels of
@@ -65,7 +66,7 @@ const OptDesc kOptions[] = {
     {"dense6", &Options::dense6, 0, 1 << 20},
     {"prewarm", &Options::prewarm, 0, 1},
     {"cache_calls", &Options::cache_calls, 0, 1000000},
-    {"split", &Options::split, 0, 1},
+    {"split", &Options::split, 0, 2},
     {"split_len", &Options::split_len, 0, 1 << 20},
     {"split_runs", &Options::split_runs, 1, 3072},
     {"split_warm", &Options::split_warm, 0, 1 << 20},

@@ -330,8 +330,11 @@ struct Options {
                                     // pipeline_dev.hpp): every range starts from an empty arm list split_warm probes in front of its cut,
                                     // and what it holds AT the cut is compared with what the range before holds there; a segment with a cut
                                     // that differs keeps the ranges up to it and runs the rest as ONE more run (the whole segment again when
-                                    // its first cut fails); the index then plans only the cuts that held.  32-bit positions.  0: every
-                                    // segment is one work item
+                                    // its first cut fails); the index remembers what the segment needs (split_warm_max).  With 32-bit
+                                    // positions; 2: with 64-bit positions as well -- not the default: the one workload of that size here
+                                    // (two genomes, 6.18 Gb) gains nothing (its step is a chromosome against its homologue, which no range
+                                    // started from an empty arm list joins: 1 993 ms either way) and pays for the cuts that fail in its
+                                    // first call (8.4 instead of 5.7 s).  0: every segment is one work item
     int64_t split_len = 0;          // probes per range (about: the ranges of a segment are of one length); 0: the smallest of 2048 ... 32768
                                     // for which the call's runs stay within split_runs (split_tally_kernel), warm-up as long (2048 .. 6144),
                                     // shortest segment cut twice it -- a small job gets short ranges, a genome-sized one long ones
@@ -462,6 +465,7 @@ struct asgart_index {
         int32_t n_passes = 0, shard = 0, n_shards = 1;
         bool seen = false, pole = false;
         int32_t n_fused = 0, n_piped = 0;      // calls timed each way
+        int32_t unsettled = 0;                 // calls in a row that refused a cut (not samples, unless three in a row)
         double ms_fused = 1e30, ms_piped = 1e30;
     } fuse_verdict;
     // segments a cut of which did not hold (option split): orientation << 32 | first probe counted from the start of its pass,
@@ -469,7 +473,7 @@ struct asgart_index {
     // and at which range length.  Cleared with the keys; the oldest entries age out.
     struct SplitVerdict {
         uint64_t key, sig;
-        uint32_t allowed, range_len;  // (the count belongs to the range length it was found at)
+        uint32_t allowed, range_len;  // (the count belongs to the range length it was found at: one entry per segment and length)
         uint32_t warm;                // the warm-up this segment's ranges get from now on (0: the call's own)
     };
     std::vector<SplitVerdict> split_blocked;
@@ -563,6 +567,10 @@ namespace asgart {
 // set by the passes call on the thread that holds asgart_index::pass_mu (index_prepare's prewarm must not try to lock a
 // mutex its own thread owns: undefined for std::mutex)
 extern thread_local bool tl_owns_pass_mu;
+// how many single-pass calls share the chip with the one this thread is about to make (the pipelined passes of one passes
+// call): the run budget of the ranges is divided by it, so that a pass's segments get the range length they get when the
+// passes run as one job -- and with it the verdicts the index remembers about their cuts (kept per range length)
+extern thread_local int tl_pass_share;
 int32_t index_prepare(asgart_index *idx, uint64_t k);
 // per-probe workspace of one call context for a window of W probes (pipeline.hip; also what run_search_t reserves)
 int32_t reserve_probe_workspace(asgart_index *idx, SearchCtx &cx, uint64_t W);

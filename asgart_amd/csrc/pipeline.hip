@@ -666,7 +666,7 @@ struct SearchCall {
         // long segments as ranges side by side (option split; plan_ranges_kernel in pipeline_dev.hpp): the long shape of the
         // one-barrier kernel; also in a sharded call (the segments its window cuts short are left alone: only
         // a segment whose end the placement walk has seen is cut)
-        split_on = opt.split != 0 && arms_kernel && (opt.split_len == 0 || opt.split_len >= 64);
+        split_on = opt.split >= (sizeof(SlotT) == 4 ? 1 : 2) && arms_kernel && (opt.split_len == 0 || opt.split_len >= 64);
         if (cluster_barren || split_on) {
             RC_TRY(w.seg_info.reserve((size_t)n_seg * sizeof(uint2)));
             pp.seg_info = w.seg_info.as<uint2>();
@@ -745,7 +745,7 @@ struct SearchCall {
             if (!sp.range_len) {  // the range length by budget
                 HIP_TRY(hipMemsetAsync(d_choice, 0, sizeof(SplitChoice), s));
                 split_tally_kernel<<<grid_for(n_seg), 256, 0, s>>>(rp, d_ctr + CT_SEG, kbuf, pp.seg_info, d_choice);
-                split_pick_kernel<<<1, 1, 0, s>>>(d_choice, (uint32_t)opt.split_runs);
+                split_pick_kernel<<<1, 1, 0, s>>>(d_choice, std::max(1u, (uint32_t)opt.split_runs / (uint32_t)std::max(1, asgart::tl_pass_share)));
             }
             plan_ranges_kernel<<<grid_for(n_seg), 256, 0, s>>>(rp, sp, p_filt, seg_list, d_ctr + CT_SEG, kbuf, pp.seg_info,
                                                               reinterpret_cast<unsigned long long *>(d_split),
@@ -1155,10 +1155,11 @@ struct SearchCall {
                 const uint32_t warm_next = (warm_used && want <= limit) ? (uint32_t)want : 0u;
                 if (warm_next) allowed = kAllCuts;
                 std::lock_guard<std::mutex> lk(idx->mu);
+                // (one verdict per segment AND range length: calls of different shapes -- the passes as one job, a pass alone --
+                // get different range lengths from the budget, and each shape keeps what it has learned)
                 for (auto &b : idx->split_blocked)
-                    if (b.key == key_ && b.sig == call_sig) {
-                        b.allowed = (b.range_len == len_ && !warm_next) ? std::min(b.allowed, allowed) : allowed;
-                        b.range_len = len_;
+                    if (b.key == key_ && b.sig == call_sig && b.range_len == len_) {
+                        b.allowed = warm_next ? allowed : std::min(b.allowed, allowed);
                         if (warm_next) b.warm = warm_next;
                         return;
                     }
@@ -1915,9 +1916,12 @@ int32_t asgart_search_duplications_passes_shard(asgart_index *idx, const uint64_
                 }
                 const bool pole = n_shards == 1 && stt.passes == (uint64_t)n_passes && stt.ms_extend > 0.0 &&
                                   stt.ms_longest_segment * 100.0 > stt.ms_extend * (double)idx->opt.fuse_pole_pct;
-                if (v.seen) {  // (the first call with these settings is not timed: it may be the index's first)
+                // (the first call with these settings is not timed: it may be the index's first; nor is one that refused a cut --
+                // the index is still learning which ranges join up, the next call will be shorter -- unless three in a row did)
+                if (v.seen && (stt.split_refused == 0 || ++v.unsettled >= 3)) {
                     ++v.n_fused;
                     v.ms_fused = std::min(v.ms_fused, ms);
+                    v.unsettled = 0;
                 }
                 v.seen = true;
                 v.pole = pole;
@@ -1938,6 +1942,10 @@ int32_t asgart_search_duplications_passes_shard(asgart_index *idx, const uint64_
             if (!on || !ok) return;
             const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             std::lock_guard<std::mutex> lk(idx->mu);
+            uint64_t refused = 0;
+            for (int c = 0; c < asgart::kNumCtx; ++c) refused += idx->ctx[c].stats.split_refused;
+            if (refused != 0 && ++idx->fuse_verdict.unsettled < 3) return;  // (still learning which ranges join up: not a sample)
+            idx->fuse_verdict.unsettled = 0;
             ++idx->fuse_verdict.n_piped;
             idx->fuse_verdict.ms_piped = std::min(idx->fuse_verdict.ms_piped, ms);
             if (idx->opt.debug) fprintf(stderr, "[asgart] passes pipelined, %.1f ms (timed against the passes as one job)\n", ms);
@@ -1985,6 +1993,10 @@ int32_t asgart_search_duplications_passes_shard(asgart_index *idx, const uint64_
             if (p > 0)
                 while (!searched(p - 1)) std::this_thread::sleep_for(std::chrono::microseconds(100));
             const int32_t j = order[p];
+            struct Share {  // (the passes run side by side: each gets its part of the ranges' run budget)
+                explicit Share(int n) { asgart::tl_pass_share = n; }
+                ~Share() { asgart::tl_pass_share = 1; }
+            } share(n_passes);
             asgart_families *f = new (std::nothrow) asgart_families();
             if (!f) {
                 rcs[p] = ASGART_E_OOM;

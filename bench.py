@@ -166,10 +166,11 @@ def launch_ranks(n_ranks: int) -> int:
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ASGART_BENCH_LAUNCHED="self")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if os.environ.get("ASGART_BENCH_ONE_DEVICE") and "GPU_MAX_HW_QUEUES" not in os.environ:
+        if os.environ.get("ASGART_BENCH_ONE_DEVICE") and not os.environ.get("ASGART_BENCH_KEEP_HW_QUEUES"):
             # all ranks on ONE device share its hardware queues: with 8 per process the tiers' streams of a rank are multiplexed
             # onto what is left and run one after the other (measured: per-rank extension 329 / 155 ms instead of 49 / 65); 4
-            # per rank keeps them side by side, two streams to a queue
+            # per rank keeps them side by side, two streams to a queue (set whatever the environment says: the pool's boxes
+            # come with GPU_MAX_HW_QUEUES=8)
             env["GPU_MAX_HW_QUEUES"] = str(max(2, 8 // n_ranks))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0

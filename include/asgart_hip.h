@@ -194,7 +194,8 @@ int32_t asgart_index_create_trim(const uint8_t *T, int64_t n, const int64_t *SA,
  * nothing are not run: 0 none, 1 by their number of hit-probes, 2 also by the positions of their hits); split, split_len,
  * split_runs, split_warm, split_warm_max, split_min (long segments run as ranges side by side, each checked against its
  * predecessor at the cut; where a cut does not hold the ranges in front of it stand, the rest of the segment runs as one
- * more run, and the next call over the same input starts that segment's ranges twice as far in front of their cuts);
+ * more run, and the next call over the same input starts that segment's ranges as far in front of their cuts as the
+ * failed one asked for; split = 2: with 64-bit positions as well);
  * fuse_passes, fuse_pole_pct (passes of one call as one job or pipelined); kfilter_bits, posbits, rank_lists,
  * lazy_aux (the position filter and the position-sorted lists, and when they come into being); cache_calls, prewarm
  * (memory); watchdog_s; debug; test_cap_limit, test_genbits, test_k8_delay, test_fail_alloc, test_stall_s,

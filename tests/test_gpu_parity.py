@@ -1382,7 +1382,7 @@ def test_long_segments_as_ranges_equal_whole_segments(hiplib, shape, wide, monke
                 _ORACLE_CACHE[key] = oidx.run_raw(chunks, oracle.make_settings(reverse=False, complement=False, **cli), threads=4)
             eo, es = _ORACLE_CACHE[key]
             assert np.array_equal(whole[0][0], eo) and np.array_equal(whole[0][1], es), (seed, cli)
-            idx.set_option("split", 1)
+            idx.set_option("split", 1 + wide)   # (64-bit positions: option split = 2)
             idx.set_option("split_len", ln)
             idx.set_option("split_warm", warm)
             idx.set_option("split_min", mn)
@@ -1406,6 +1406,7 @@ def test_long_segments_as_ranges_equal_whole_segments(hiplib, shape, wide, monke
         with asgart_amd.Index(text, oidx.sa) as idx:
             idx.set_option("force_tier", 3)
             idx.set_option("test_genbits", genbits)
+            idx.set_option("split", 1 + wide)
             idx.set_option("split_len", ln)
             idx.set_option("split_warm", warm)
             idx.set_option("split_min", mn)
@@ -1456,7 +1457,7 @@ def test_randomised_cut_cases_against_the_oracle(hiplib, block, monkeypatch):
         with asgart_amd.Index(text, oidx.sa) as idx:
             idx.set_option("force_tier", 3)
             idx.set_option("test_genbits", genbits)
-            idx.set_option("split", 1)
+            idx.set_option("split", 1 + block % 2)   # (64-bit positions: option split = 2)
             idx.set_option("split_len", ln)
             idx.set_option("split_warm", warm)
             idx.set_option("split_min", mn)

@@ -69,7 +69,7 @@ def main():
             idx.set_option("test_genbits", genbits)
             if os.environ.get("FUZZ_SPLIT"):  # "len,warm,min": long segments as ranges (option split), sized for these cases
                 ln, warm, mn = (int(v) for v in os.environ["FUZZ_SPLIT"].split(","))
-                idx.set_option("split", 1)
+                idx.set_option("split", 2)   # (ranges with 32- and 64-bit positions: ASGART_FORCE_WIDE=1 runs the latter)
                 idx.set_option("split_len", ln)
                 idx.set_option("split_warm", warm)
                 idx.set_option("split_min", mn)
