@@ -22,7 +22,6 @@ namespace asgart {
 
 static thread_local char g_err[512] = "";
 thread_local bool tl_owns_pass_mu = false;
-thread_local int tl_pass_share = 1;
 
 // Runtime note.  The extension tiers of one call run on six HIP streams (twelve with
 // two calls in flight); ROCm maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and kernels of

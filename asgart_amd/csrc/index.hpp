@@ -567,10 +567,6 @@ namespace asgart {
 // set by the passes call on the thread that holds asgart_index::pass_mu (index_prepare's prewarm must not try to lock a
 // mutex its own thread owns: undefined for std::mutex)
 extern thread_local bool tl_owns_pass_mu;
-// how many single-pass calls share the chip with the one this thread is about to make (the pipelined passes of one passes
-// call): the run budget of the ranges is divided by it, so that a pass's segments get the range length they get when the
-// passes run as one job -- and with it the verdicts the index remembers about their cuts (kept per range length)
-extern thread_local int tl_pass_share;
 int32_t index_prepare(asgart_index *idx, uint64_t k);
 // per-probe workspace of one call context for a window of W probes (pipeline.hip; also what run_search_t reserves)
 int32_t reserve_probe_workspace(asgart_index *idx, SearchCtx &cx, uint64_t W);

@@ -745,7 +745,7 @@ struct SearchCall {
             if (!sp.range_len) {  // the range length by budget
                 HIP_TRY(hipMemsetAsync(d_choice, 0, sizeof(SplitChoice), s));
                 split_tally_kernel<<<grid_for(n_seg), 256, 0, s>>>(rp, d_ctr + CT_SEG, kbuf, pp.seg_info, d_choice);
-                split_pick_kernel<<<1, 1, 0, s>>>(d_choice, std::max(1u, (uint32_t)opt.split_runs / (uint32_t)std::max(1, asgart::tl_pass_share)));
+                split_pick_kernel<<<1, 1, 0, s>>>(d_choice, (uint32_t)opt.split_runs);
             }
             plan_ranges_kernel<<<grid_for(n_seg), 256, 0, s>>>(rp, sp, p_filt, seg_list, d_ctr + CT_SEG, kbuf, pp.seg_info,
                                                               reinterpret_cast<unsigned long long *>(d_split),
@@ -1993,10 +1993,6 @@ int32_t asgart_search_duplications_passes_shard(asgart_index *idx, const uint64_
             if (p > 0)
                 while (!searched(p - 1)) std::this_thread::sleep_for(std::chrono::microseconds(100));
             const int32_t j = order[p];
-            struct Share {  // (the passes run side by side: each gets its part of the ranges' run budget)
-                explicit Share(int n) { asgart::tl_pass_share = n; }
-                ~Share() { asgart::tl_pass_share = 1; }
-            } share(n_passes);
             asgart_families *f = new (std::nothrow) asgart_families();
             if (!f) {
                 rcs[p] = ASGART_E_OOM;
