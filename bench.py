@@ -316,8 +316,19 @@ def main():
         return [gather(r_) for r_ in passes_call()]
 
     t0 = time.time()
+    # (An unsharded passes call that finds one segment to be its extension makes the library TIME the calls that follow as
+    # one job and as pipelined single-pass calls in turn and keep the faster way -- asgart_hip.h, fuse_passes; calls that
+    # still refuse cuts do not count as samples.  The timed region must lie behind that: after the warm-up steps asked for,
+    # untimed steps go on -- twelve at most -- until four calls in a row have run the same way.)
+    ways = []
+    settling_steps = 0
     for _ in range(args.warmup):
         one_step()
+        ways.append(int(idx.stats(0).passes))
+    while len(settings) > 1 and world == 1 and settling_steps < 12 and (len(ways) < 4 or len(set(ways[-4:])) > 1):
+        one_step()
+        ways.append(int(idx.stats(0).passes))
+        settling_steps += 1
     t_warm = time.time() - t0
     # per-pass device timings + work counters + the accounting pass (one extra untimed call per
     # mode, the passes one after the other: "alone on the chip" kernel durations)
@@ -613,6 +624,7 @@ def main():
                           "keys_and_tables": round(t_index, 3),
                           "first_passes_call_incl_presence_filters": round(t_first, 3),
                           "warmup_steps": round(t_warm, 3),
+                          "settling_steps_after_warmup": settling_steps,
                           "sa_builder": "GPU prefix doubling (asgart_sa_build64 path)"},
         "work_per_step": {key: sum(s[key] for s in pass_stats) for key in
                           ("probes_total", "probes_searched", "probes_card_skipped", "probes_filter_rejected",
