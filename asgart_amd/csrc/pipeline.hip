@@ -1120,7 +1120,7 @@ struct SearchCall {
             // the records of the ranges behind it are dropped, and ONE more run covers the rest -- from where range f started
             // (it passes cut f in the checked state, so it is exact from there on), reporting from cut f + 1 to the segment's
             // end.  f = 0, or a run that gave up: the segment runs again as a whole on the ordinary kernel.  The index remembers
-            // how many cuts of the segment held and plans only those from then on.
+            // what the segment needs from then on (remember(), below): a longer warm-up, or only the cuts that held.
             const uint32_t *h_meta = reinterpret_cast<const uint32_t *>(h_split + kOffMeta);
             const uint32_t *h_ok = reinterpret_cast<const uint32_t *>(h_split + kOffOk);
             RangeRun *h_runs = reinterpret_cast<RangeRun *>(h_split + kOffRuns);
