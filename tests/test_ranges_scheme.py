@@ -148,3 +148,59 @@ def test_ranges_joined_equal_the_whole_run_and_the_oracle(period, copies, sub, n
         assert held == n_ranges - 1 and n_runs == n_ranges
     else:
         assert held < n_ranges - 1 and n_runs == n_ranges + 1
+
+
+@pytest.mark.parametrize("period,copies,sub,n_ranges,warm", [
+    (64, 150, 0.06, 5, 8),
+    (64, 150, 0.06, 8, 16),
+    (171, 60, 0.0, 4, 200),
+])
+def test_a_failed_cut_tells_the_warm_up_its_segment_needs(period, copies, sub, n_ranges, warm):
+    """What the library does with a cut that did not hold (pipeline.hip: remember(); validate_cuts_kernel reports where the
+    oldest arm in front of the cut was born).  A run that is to hold that arm at the cut must START in front of the probe
+    that created it -- creation keys are (probe, hit) in every run -- so a warm-up shorter than that distance cannot hold:
+    the next call gives the segment's ranges that much.  That is necessary, not sufficient (what an arm looks like also
+    depends on arms that died before the cut): a cut that fails although every arm was born inside the warm-up gets the
+    longest warm-up a range is worth -- two ranges -- and beyond that only the cuts that held are planned again.  Here: the
+    failures of a noisy array are of the first kind at short warm-ups and go away within two ranges of warm-up; in an array
+    of exact copies the cuts do not hold even then, although every arm at a cut was born well inside the warm-up (an arm's
+    left end and threshold carry the history of the arms before it): the library ends at "only the cuts that held"."""
+    text = _text(11, period, copies, sub)
+    oidx = oracle.Index.build(text)
+    st = oracle.make_settings(k=K, gap=GAP, min_length=M)
+    chunk = (0, len(text) - 1)
+    status, offs, hits = oidx.probe_hits(oracle.prepare_needle(text, chunk, st), 0, st)
+    offs, hits = offs.astype(np.int64), hits.astype(np.int64)
+    hp = np.nonzero((status == 0) & (np.diff(offs) > 0))[0]
+    s0, s1 = int(hp[0]), min(len(status), int(hp[-1]) + 1 + 2 * ((G + STEP - 1) // STEP))
+    whole = Run(status, offs, hits, s0, s1, s0)
+    want = _families(whole.recs)
+    cnt = np.diff(offs)
+    born_outside = born_inside = 0
+    needs = []
+    for j in range(1, n_ranges):
+        c = s0 + (int(hp[-1]) - s0) * j // n_ranges
+        while status[c] or cnt[c] == 0:
+            c += 1
+        true = Run(status, offs, hits, s0, c, s0).end          # what the segment really holds in front of cut c
+        cold = Run(status, offs, hits, max(s0, c - warm), c, c).end
+        if cold == true:
+            continue
+        assert true[0], (j, c)                                   # (a cut in front of which nothing lives holds from anywhere)
+        born = min(a[0][0] for a in true[0])
+        needs.append(c - born)
+        if c - born > warm:
+            born_outside += 1                                    # the warm-up started behind that birth: it could not hold
+            assert not any(a[0][0] == born for a in cold[0])
+        else:
+            born_inside += 1
+    assert needs                                                # (the cases are chosen so that cuts fail)
+    span = int(hp[-1]) - s0
+    limit = 2 * (span // n_ranges)                              # the longest warm-up a range is worth
+    joined, held, n_runs = _ranges(status, offs, hits, s0, s1, int(hp[-1]), n_ranges, limit)
+    assert _families(joined) == want
+    if sub > 0:
+        assert born_outside > 0 and max(needs) < limit and held == n_ranges - 1, (needs, held)
+    else:
+        # every arm in front of a cut was born well inside two ranges of warm-up -- and still the cuts do not hold
+        assert max(needs) < limit and held < n_ranges - 1, (needs, held)
