@@ -6,7 +6,10 @@ strictly serial probes with hundreds of live arms and ~100 hits each.  Runs the 
 pass) under each option configuration and prints the extension time; results are checked for equality
 across configurations (and against the CPU oracle with --check).
 
-Usage: python tools/pole_synth.py [--copies 3800] [--sub 0.03] [--check] ['force_tier=3' 'force_tier=6' ...]
+Usage: python tools/pole_synth.py [--copies 3800] [--sub 0.03] [--homolog BP] [--check] ['force_tier=3' 'force_tier=6' ...]
+--homolog BP: instead of the array, a random region of BP bases and its 1.2 %-diverged copy further on (a chromosome against
+its homologue, in small: ONE segment of BP / 10 sparse probes with one or two long-lived arms; a short repeat family is
+sprinkled over both so that some probes have a dozen hits)
 Set ASGART_LIB=asgart_amd/libasgart_hip_diag.so for the per-phase cycle breakdown (stderr).
 """
 import os
@@ -36,9 +39,25 @@ def make_text(copies, sub, seed=5, flank=400_000):
     return np.concatenate([bases[g], np.frombuffer(b"$", dtype=np.uint8)])
 
 
+def make_homolog(bp, seed=5, flank=200_000):
+    rng = np.random.default_rng(seed)
+    bases = np.frombuffer(b"ACGT", dtype=np.uint8)
+    a = rng.integers(0, 4, size=bp)
+    rep = rng.integers(0, 4, size=300)
+    n_rep = 0 if os.environ.get("HOMOLOG_NO_REPEATS") else max(1, bp // 50_000)
+    for at in rng.integers(0, bp - 300, size=n_rep):   # a young repeat family: bursts of hits
+        a[at:at + 300] = rep
+    b = a.copy()
+    mut = rng.random(b.shape) < 0.012
+    b[mut] = (b[mut] + rng.integers(1, 4, size=int(mut.sum()))) & 3
+    g = np.concatenate([rng.integers(0, 4, size=flank), a, rng.integers(0, 4, size=50_000), b, rng.integers(0, 4, size=flank)])
+    return np.concatenate([bases[g], np.frombuffer(b"$", dtype=np.uint8)])
+
+
 def main():
     args = sys.argv[1:]
     copies, sub, check = 3800, 0.03, False
+    homolog = 0
     confs = []
     while args:
         a = args.pop(0)
@@ -46,12 +65,14 @@ def main():
             copies = int(args.pop(0))
         elif a == "--sub":
             sub = float(args.pop(0))
+        elif a == "--homolog":
+            homolog = int(args.pop(0))
         elif a == "--check":
             check = True
         else:
             confs.append(a)
     confs = confs or [""]
-    text = make_text(copies, sub)
+    text = make_homolog(homolog) if homolog else make_text(copies, sub)
     chunks = [(0, len(text) - 1)]
     idx = asgart_amd.Index(text, None)
     idx.prepare(20)
