@@ -22,7 +22,14 @@ Only L3 is safe without further checks: thresholds GROW with len(left) = i + k -
 differs takes different decisions later even when it agrees now (L2), unless no hit ever falls between the two windows.
 Also reported: how old the live arms at a cut are (the necessary condition for L3: nobody older than H).
 
-    python tools/split_feasibility.py [pole|pole_rc|hor|homolog ...]      (CPU only: the oracle's suffix array and hit rows)
+Round 6: what THRESHOLD-INTERVAL CARRY could join at best.  The carry accepts a cut at level L1
+when, through the range behind it, no decision of the speculative run would have come out differently under the true (larger)
+thresholds.  Its ceiling is therefore the share of cuts that are L1 at the cut AND STAY L1 -- same (right.end, gap) sequence
+after every probe -- until the next cut ("L1 stable"): where the true run's old arm, with its window of len / 10, takes a hit
+the young arm of the speculative run cannot reach, the two runs part for good.  `homolog5` is the segment cfg5 is made of: a
+region of the config-4 genome (old high-copy interspersed repeats) against its 1.2 %-diverged copy.
+
+    python tools/split_feasibility.py [pole|pole_rc|hor|homolog|homolog5 ...]   (CPU only: the oracle's suffix array and hit rows)
 """
 import os
 import sys
@@ -61,6 +68,16 @@ def make_segment(kind, rng):
         arr = mutate(rng, np.tile(unit, 730), 0.015)
     elif kind == "homolog":                # a 1-Mb region and its 1.2 %-diverged copy (cfg5's chromosome pairs, in small)
         a = rng.integers(0, 4, size=1_000_000)
+        arr = np.concatenate([a, rng.integers(0, 4, size=50_000), mutate(rng, a, 0.012)])
+    elif kind == "homolog5":               # the same with the repeats of the config-4 genome in it (what cfg5 is made of)
+        from asgart_amd import synth
+        rec = synth.make_genome([1_500_000], 1234)[0][1]
+        code = np.zeros(256, dtype=np.int64)
+        for i_, ch in enumerate(b"ACGT"):
+            code[ch] = i_
+            code[ch | 0x20] = i_
+        a = code[rec]
+        a[(rec == ord("N")) | (rec == ord("n"))] = rng.integers(0, 4, size=int(((rec == ord("N")) | (rec == ord("n"))).sum()))
         arr = np.concatenate([a, rng.integers(0, 4, size=50_000), mutate(rng, a, 0.012)])
     else:
         raise SystemExit(f"unknown segment kind {kind}")
@@ -122,15 +139,17 @@ def step_probe(A, t, i, x):
         A.ls, A.le, A.rs, A.re, A.gap, A.born = (a[keep] for a in (A.ls, A.le, A.rs, A.re, A.gap, A.born))
 
 
-def run(status, offs, hits, t0, t1, A, cuts=None):
-    """probes t0 .. t1-1 of the chunk; -> {cut: snapshot} for the cuts passed on the way"""
+def run(status, offs, hits, t0, t1, A, cuts=None, sig=None, sig_from=0):
+    """probes t0 .. t1-1 of the chunk; -> {cut: snapshot} for the cuts passed on the way.  sig: a dict that receives, per
+    probe t >= sig_from, a signature of the (right.end, gap) sequence the arms have AFTER the probe (level L1)"""
     snaps = {}
     for t in range(t0, t1):
         if cuts is not None and t in cuts:
             snaps[t] = A.snapshot()
-        if status[t]:
-            continue                                    # skipped probes neither age nor reset (:100-102, :115-117)
-        step_probe(A, t, (t + 1) * STEP, hits[offs[t]:offs[t + 1]])
+        if not status[t]:                               # skipped probes neither age nor reset (:100-102, :115-117)
+            step_probe(A, t, (t + 1) * STEP, hits[offs[t]:offs[t + 1]])
+        if sig is not None and t >= sig_from:
+            sig[t] = hash((A.re.tobytes(), A.gap.tobytes()))
     return snaps
 
 
@@ -159,7 +178,8 @@ def main():
         s0, s1 = int(hp[bounds[j]]), int(hp[bounds[j + 1] - 1]) + 1
         cuts = sorted({int(s0 + (s1 - s0) * (q + 1) // (P + 1)) for q in range(P)})
         A = Arms()
-        snaps = run(status, offs, hits, s0, s1, A, set(cuts))
+        true_sig = {}
+        snaps = run(status, offs, hits, s0, s1, A, set(cuts), true_sig)
         n_live = np.array([len(snaps[c][3]) for c in cuts])
         ages = [c - snaps[c][5] for c in cuts]
         oldest = np.array([a.max() if len(a) else 0 for a in ages])
@@ -167,11 +187,12 @@ def main():
               f"{int(((status[s0:s1] == 0) & (cnt[s0:s1] > 0)).sum())} hit-probes, {cnt[s0:s1].mean():.1f} hits per probe); "
               f"live arms at the cuts: mean {n_live.mean():.0f}, max {n_live.max()}; oldest live arm at a cut: median "
               f"{int(np.median(oldest))} probes, max {oldest.max()} (true run {time.time() - t_a:.0f} s)")
-        print(f"   {'H':>8} {'probes':>7} | {'L1 (re,gap)':>12} {'L2 (+thr)':>10} {'L3 (all)':>9} | cuts with no live arm older than H | "
+        print(f"   {'H':>8} {'probes':>7} | {'L1 (re,gap)':>12} {'L1 stable':>10} {'L2 (+thr)':>10} {'L3 (all)':>9} | cuts with no live arm older than H | "
               f"live arms older than H")
         for mult in (1, 4, 16, 64, 256, 1024):
             H = mult * TSTAR
             ok = [0, 0, 0]
+            stable = 0
             young_cuts = 0
             older = 0
             total = 0
@@ -189,8 +210,13 @@ def main():
                 ok[0] += l1
                 ok[1] += l2
                 ok[2] += l3
+                if l1:   # ... and does it STAY L1 until the next cut (the ceiling of threshold-interval carry)?
+                    nxt = min([c2 for c2 in cuts if c2 > c] or [s1])
+                    cold_sig = {}
+                    run(status, offs, hits, c, nxt, B, None, cold_sig)
+                    stable += all(cold_sig[t] == true_sig[t] for t in range(c, nxt))
             n_c = len(cuts)
-            print(f"   {mult:>5} t* {H:>7} | {ok[0] / n_c:>11.0%} {ok[1] / n_c:>10.0%} {ok[2] / n_c:>9.0%} | "
+            print(f"   {mult:>5} t* {H:>7} | {ok[0] / n_c:>11.0%} {stable / n_c:>10.0%} {ok[1] / n_c:>10.0%} {ok[2] / n_c:>9.0%} | "
                   f"{young_cuts / n_c:>33.0%} | {older / max(1, total):>21.1%}", flush=True)
         print()
 
