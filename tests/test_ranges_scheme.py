@@ -204,3 +204,96 @@ def test_a_failed_cut_tells_the_warm_up_its_segment_needs(period, copies, sub, n
     else:
         # every arm in front of a cut was born well inside two ranges of warm-up -- and still the cuts do not hold
         assert max(needs) < limit and held < n_ranges - 1, (needs, held)
+
+
+def _plan(cuts, skipped):
+    return [c for j, c in enumerate(cuts) if j not in skipped]
+
+
+def _run_plan(status, offs, hits, s0, s1, kept, warm):
+    """the ranges of one call over the kept cuts -> (runs, index of the first kept cut that does not hold or None)"""
+    starts = [s0] + kept
+    stops = kept + [s1]
+    begin = [s0] + [max(s0, c - warm) for c in kept]
+    runs = [Run(status, offs, hits, begin[j], stops[j], starts[j], snap_at=starts[j] if j else None) for j in range(len(starts))]
+    for j in range(len(kept)):
+        if runs[j].end != runs[j + 1].at_cut:
+            return runs, j
+    return runs, None
+
+
+def _text_two_arrays(seed):
+    """an array of exact copies (no cut inside it holds) and, right behind it, a noisy one (its cuts hold): ONE segment"""
+    rng = np.random.default_rng(seed)
+    a = np.tile(rng.integers(0, 4, size=171), 25)
+    b = np.tile(rng.integers(0, 4, size=64), 120)
+    mut = rng.random(b.shape) < 0.06
+    b[mut] = (b[mut] + rng.integers(1, 4, size=int(mut.sum()))) & 3
+    g = np.concatenate([rng.integers(0, 4, size=3000), a, b, rng.integers(0, 4, size=3000)])
+    return np.concatenate([BASES[g], np.frombuffer(b"$", dtype=np.uint8)])
+
+
+@pytest.mark.parametrize("period,copies,sub,n_ranges,warm", [
+    (64, 150, 0.06, 12, 8),       # a noisy array, a warm-up far too short: most cuts fail
+    (0, 0, 0.0, 10, 300),         # exact copies, then a noisy array: the cuts inside the first fail at any warm-up
+])
+def test_a_set_of_failed_cuts_instead_of_a_prefix(period, copies, sub, n_ranges, warm):
+    """The next step of the scheme, restated before it is built (DESIGN_HISTORY.md, round 6: a two-genome call's longest
+    segment keeps three of its 28 cuts because the library remembers a PREFIX of the cuts that held).  Remember WHICH cuts
+    failed instead: the range in front of a failed cut runs on to the next cut that is kept.  Call by call -- each call drops
+    the first kept cut that does not hold, as the library's validation finds it -- the plan settles on a set of cuts that all
+    hold, and the joined output is the whole run's at every stage (what is behind the failed cut is covered by ONE more run
+    from the last checked state, as today).  The same set comes out of ONE call when the run over the rest also writes
+    down what it holds at every later cut: it is exact from the last checked state on, so comparing it there with what the
+    later ranges hold at their cuts tells every cut that fails."""
+    text = _text(11, period, copies, sub) if period else _text_two_arrays(11)
+    oidx = oracle.Index.build(text)
+    st = oracle.make_settings(k=K, gap=GAP, min_length=M)
+    chunk = (0, len(text) - 1)
+    status, offs, hits = oidx.probe_hits(oracle.prepare_needle(text, chunk, st), 0, st)
+    offs, hits = offs.astype(np.int64), hits.astype(np.int64)
+    hp = np.nonzero((status == 0) & (np.diff(offs) > 0))[0]
+    s0, s1 = int(hp[0]), min(len(status), int(hp[-1]) + 1 + 2 * ((G + STEP - 1) // STEP))
+    want = _families(Run(status, offs, hits, s0, s1, s0).recs)
+    cnt = np.diff(offs)
+    cuts = []
+    for j in range(1, n_ranges):
+        c = s0 + (int(hp[-1]) - s0) * j // n_ranges
+        while status[c] or cnt[c] == 0:
+            c += 1
+        cuts.append(c)
+    # call by call: the first kept cut that fails is dropped
+    skipped, calls = set(), 0
+    while True:
+        calls += 1
+        kept = _plan(cuts, skipped)
+        runs, bad = _run_plan(status, offs, hits, s0, s1, kept, warm)
+        if bad is None:
+            break
+        # what this call returns: the ranges in front of the failed cut, and one more run over the rest
+        begin = s0 if bad == 0 else max(s0, kept[bad - 1] - warm)
+        tail = Run(status, offs, hits, begin, s1, kept[bad - 1] if bad else s0)
+        out, base = [], 0
+        for r in runs[:bad] + [tail]:
+            out += [(base + f,) + tuple(rest) for (f, *rest) in r.recs]
+            base += r.flushes
+        assert _families(out) == want, (calls, bad)
+        skipped.add(cuts.index(kept[bad]))
+        assert calls <= len(cuts) + 1
+    out, base = [], 0
+    for r in runs:
+        out += [(base + f,) + tuple(rest) for (f, *rest) in r.recs]
+        base += r.flushes
+    assert _families(out) == want
+    assert 0 < len(skipped) < len(cuts), (skipped, len(cuts))     # some cuts fail, some hold: a prefix would lose the latter
+    first_bad = min(skipped)
+    assert any(j > first_bad for j in range(len(cuts)) if j not in skipped), skipped   # cuts BEHIND the first failure hold
+    # in one call: truth at every cut from the exact run, compared with what a range started `warm` probes in front of it holds
+    at_once = set()
+    last_good = s0
+    for j, c in enumerate(cuts):
+        true = Run(status, offs, hits, s0, c, s0).end
+        cold = Run(status, offs, hits, max(s0, c - warm), c, c).end if c - warm > s0 else true
+        if cold != true:
+            at_once.add(j)
+    assert at_once == skipped, (at_once, skipped)
